@@ -1,0 +1,45 @@
+// Host-side helpers for the C ABI: error plumbing, stream cast, device buffers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <stdexcept>
+#include <cstdio>
+#include "../../include/cosyvoice_amd.h"
+
+namespace cv {
+
+void set_last_error(const std::string& s);
+
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define CV_CHECK(cond, msg) do { if (!(cond)) throw cv::Error(std::string(msg) + " [" #cond "] at " __FILE__ ":" + std::to_string(__LINE__)); } while (0)
+#define CV_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) throw cv::Error(std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+// wraps an entry point body: C++ exceptions never cross the C ABI
+template <typename F>
+static inline int guarded(F&& f) {
+    try { f(); return 0; }
+    catch (const std::exception& e) { set_last_error(e.what()); return 1; }
+    catch (...) { set_last_error("unknown error"); return 1; }
+}
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// device buffer owned by a handle (workspaces, KV cache)
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void ensure(size_t n) {
+        if (n <= bytes) return;
+        if (p) CV_HIP(hipFree(p));
+        p = nullptr; bytes = 0;
+        CV_HIP(hipMalloc(&p, n)); bytes = n;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace cv

@@ -1,0 +1,106 @@
+// Operator-level C ABI + shared launchers.
+#include "ops.h"
+
+namespace cv {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& s) { g_last_error = s; }
+
+void gemm_conv(GemmConvArgs a, bool w_bf16, int batch, hipStream_t s) {
+    CV_CHECK(a.Kp % 32 == 0 && a.Kp >= a.K, "gemm_conv: Kp must be K rounded up to 32");
+    CV_CHECK(aligned16(a.W), "gemm_conv: W must be 16B aligned");
+    a.a_vec = aligned16(a.A) && (a.lda % 4 == 0) && (a.a_off0 % 4 == 0) && (a.tap_step % 4 == 0) &&
+              (a.a_batch % 4 == 0) && (a.a_len % 4 == 0);
+    a.c_vec = aligned16(a.C) && (a.ldc % 4 == 0) && (a.c_off % 4 == 0) && (a.c_batch % 4 == 0) && (a.c_len % 4 == 0) &&
+              (!a.bias || aligned16(a.bias)) && (!a.res || (aligned16(a.res) && a.res_batch % 4 == 0));
+    if (a.pro == ACT_SNAKE) CV_CHECK(a.pro_alpha && aligned16(a.pro_alpha), "gemm_conv: snake prologue needs 16B aligned alpha[Kp]");
+    launch_gemm_conv(a, w_bf16, batch, s);
+}
+
+void norm_rows(const NormArgs& a, hipStream_t s) {
+    if (a.rows <= 0) return;
+    CV_CHECK(!((a.C & 3) == 0) || (aligned16(a.x)), "norm_rows: x must be 16B aligned when C%4==0");
+    dim3 grid((unsigned)((a.rows + 3) / 4)), block(256);
+    hipLaunchKernelGGL(norm_rows_kernel, grid, block, 0, s, a);
+}
+
+void attention(const AttnArgs& a, hipStream_t s) {
+    if (a.Tq <= 0 || a.B <= 0) return;
+    CV_CHECK(a.Tk > 0, "attention: Tk must be positive");
+    CV_CHECK(aligned16(a.q) && aligned16(a.k) && aligned16(a.v) && aligned16(a.o), "attention: q/k/v/o must be 16B aligned");
+    CV_CHECK(a.q_row % 4 == 0 && a.k_row % 4 == 0 && a.v_row % 4 == 0 && a.o_row % 4 == 0 &&
+             a.q_head % 4 == 0 && a.k_head % 4 == 0 && a.v_head % 4 == 0 && a.o_head % 4 == 0 &&
+             a.q_batch % 4 == 0 && a.k_batch % 4 == 0 && a.v_batch % 4 == 0 && a.o_batch % 4 == 0, "attention: strides must be multiples of 4 floats");
+    CV_CHECK(a.mask_mode != MASK_CHUNK || a.chunk > 0, "attention: chunk mask needs chunk > 0");
+    dim3 grid((a.Tq + 63) / 64, a.H, a.B), block(256);
+    hipLaunchKernelGGL(attention_kernel, grid, block, 0, s, a);
+}
+
+void linear(const float* A, int M, const LinearW& w, float* C, int act, const float* res, hipStream_t s,
+            int lda, int ldc, bool accumulate, float out_scale) {
+    GemmConvArgs a{};
+    if (lda < 0) lda = w.K;
+    if (ldc < 0) ldc = w.N;
+    a.A = A; a.a_batch = 0; a.a_len = (long long)(M - 1) * lda + w.K; a.lda = lda; a.a_off0 = 0; a.tap_step = 0; a.taps = 1; a.K = w.K;
+    // a_len is only used for range checks; round it up when the row pitch allows a whole float4
+    if (lda % 4 == 0 && w.K % 4 == 0) a.a_len = (a.a_len + 3) / 4 * 4;
+    a.pro = ACT_NONE; a.pro_p = 0.f; a.pro_alpha = nullptr;
+    a.W = w.w; a.Kp = w.Kp; a.bias = w.b;
+    a.C = C; a.c_batch = 0; a.c_len = (long long)M * ldc; a.ldc = ldc; a.c_off = 0;
+    a.M = M; a.N = w.N; a.act = act; a.act_p = 0.f; a.res = res; a.res_batch = 0; a.out_scale = out_scale;
+    a.row_scale = nullptr; a.row_scale_batch = 0; a.accumulate = accumulate ? 1 : 0;
+    gemm_conv(a, w.bf16, 1, s);
+}
+
+}  // namespace cv
+
+extern "C" {
+
+const char* cv_last_error(void) { return cv::g_last_error.c_str(); }
+const char* cv_version(void) { return "cosyvoice_amd 0.1 (gfx950)"; }
+int cv_is_emulated(void) {
+#ifdef CV_EMU
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+int cv_gemm_conv(const cv_gemm_conv_args* g, void* stream) {
+    return cv::guarded([&] {
+        cv::GemmConvArgs a{};
+        a.A = g->A; a.a_batch = g->a_batch; a.a_len = g->a_len; a.lda = g->lda; a.a_off0 = g->a_off0; a.tap_step = g->tap_step; a.taps = g->taps; a.K = g->K;
+        a.pro = g->pro; a.pro_p = g->pro_p; a.pro_alpha = g->pro_alpha;
+        a.W = g->W; a.Kp = g->Kp; a.bias = g->bias;
+        a.C = g->C; a.c_batch = g->c_batch; a.c_len = g->c_len; a.ldc = g->ldc; a.c_off = g->c_off;
+        a.M = g->M; a.N = g->N; a.act = g->act; a.act_p = g->act_p; a.res = g->res; a.res_batch = g->res_batch;
+        a.out_scale = g->out_scale; a.row_scale = g->row_scale; a.row_scale_batch = g->row_scale_batch; a.accumulate = g->accumulate;
+        CV_CHECK(g->w_dtype == CV_F32 || g->w_dtype == CV_BF16, "cv_gemm_conv: w_dtype");
+        cv::gemm_conv(a, g->w_dtype == CV_BF16, g->batch, cv::as_stream(stream));
+    });
+}
+
+int cv_norm_rows(const float* x, float* y, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps,
+                 int32_t rms, int32_t act, float scale, const float* row_scale, const float* col_add,
+                 int64_t rows_per_batch, void* stream) {
+    return cv::guarded([&] {
+        cv::NormArgs a{x, y, rows, C, gamma, beta, eps, rms, act, scale, row_scale, col_add, rows_per_batch > 0 ? rows_per_batch : rows};
+        cv::norm_rows(a, cv::as_stream(stream));
+    });
+}
+
+int cv_attention(const cv_attn_args* g, void* stream) {
+    return cv::guarded([&] {
+        cv::AttnArgs a{};
+        a.q = g->q; a.q_batch = g->q_batch; a.q_row = g->q_row; a.q_head = g->q_head;
+        a.k = g->k; a.k_batch = g->k_batch; a.k_row = g->k_row; a.k_head = g->k_head;
+        a.v = g->v; a.v_batch = g->v_batch; a.v_row = g->v_row; a.v_head = g->v_head;
+        a.o = g->o; a.o_batch = g->o_batch; a.o_row = g->o_row; a.o_head = g->o_head;
+        a.B = g->B; a.H = g->H; a.kv_group = g->kv_group; a.Tq = g->Tq; a.Tk = g->Tk;
+        a.scale = g->scale; a.mask_mode = g->mask_mode; a.chunk = g->chunk;
+        a.rel_bd = g->rel_bd; a.bd_batch = g->bd_batch; a.bd_head = g->bd_head; a.bd_row = g->bd_row;
+        cv::attention(a, cv::as_stream(stream));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,155 @@
+// Flash-style attention for head_dim 64 in exact fp32 (v_mfma_f32_16x16x4_f32), gfx950.
+//
+// One workgroup = 4 waves = 64 query rows of one (batch, head); K/V stream through LDS in 64-key tiles.
+// Per wave (16 queries):  S^T = K·Q^T  -> lane l holds scores of query (l&15) for keys (l>>4)*4+r of each
+// 16-key sub-tile, which is *already* the B-operand layout the P·V MFMA wants (k-slot = l>>4, step r),
+// so P never leaves registers and softmax row-reductions are two xor-shuffles (16, 32).
+// O^T = V^T·P^T accumulates [d][query] -> each lane ends with 4 consecutive d of its query: one 16B store.
+// Masks (full / causal / block-causal "chunk") are computed from indices in-kernel: no [B,T,T] bias tensor
+// (the reference materialises one per block group, flow/decoder.py:439-443).
+#pragma once
+#include "common.h"
+
+namespace cv {
+
+struct AttnArgs {
+    const float* q; long long q_batch; int q_row; int q_head;
+    const float* k; long long k_batch; int k_row; int k_head;
+    const float* v; long long v_batch; int v_row; int v_head;
+    float* o; long long o_batch; int o_row; int o_head;
+    int B, H, kv_group, Tq, Tk;
+    float scale; int mask_mode; int chunk;
+    const float* rel_bd; long long bd_batch; long long bd_head; int bd_row;
+};
+
+enum { MASK_NONE = 0, MASK_CAUSAL = 1, MASK_CHUNK = 2 };
+
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
+    constexpr int BQ = 64, BKV = 64, LD = 68;
+    __shared__ __attribute__((aligned(16))) float Ks[BKV * LD];
+    __shared__ __attribute__((aligned(16))) float Vs[BKV * LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 15, lg = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z, hk = h / p.kv_group;
+    const int qi = blockIdx.x * BQ + wave * 16 + lq;
+    const bool qvalid = qi < p.Tq;
+    const float NEG_INF = -__builtin_huge_valf();
+
+    // Q fragments stay in registers: qf[dg] = Q[qi][dg*16 + lg*4 .. +3]
+    float4 qf[4];
+    {
+        const float* qp = p.q + (long long)b * p.q_batch + (long long)(qvalid ? qi : 0) * p.q_row + (long long)h * p.q_head;
+#pragma unroll
+        for (int dg = 0; dg < 4; ++dg) {
+            float4 t = *reinterpret_cast<const float4*>(qp + dg * 16 + lg * 4);
+            if (!qvalid) t = make_float4(0.f, 0.f, 0.f, 0.f);
+            qf[dg] = t;
+        }
+    }
+    const int qmax_blk = min(p.Tq - 1, (int)blockIdx.x * BQ + BQ - 1);
+    int kend = p.Tk;
+    if (p.mask_mode == MASK_CAUSAL) kend = min(p.Tk, qmax_blk + (p.Tk - p.Tq) + 1);
+    else if (p.mask_mode == MASK_CHUNK) kend = min(p.Tk, (qmax_blk / p.chunk + 1) * p.chunk);
+    int klim = p.Tk;   // per-query key limit (exclusive)
+    if (p.mask_mode == MASK_CAUSAL) klim = min(p.Tk, qi + (p.Tk - p.Tq) + 1);
+    else if (p.mask_mode == MASK_CHUNK) klim = min(p.Tk, (qi / p.chunk + 1) * p.chunk);
+    if (!qvalid) klim = 0;
+
+    const float* kb = p.k + (long long)b * p.k_batch + (long long)hk * p.k_head;
+    const float* vb = p.v + (long long)b * p.v_batch + (long long)hk * p.v_head;
+    const float* bd = p.rel_bd ? p.rel_bd + (long long)b * p.bd_batch + (long long)h * p.bd_head + (long long)(qvalid ? qi : 0) * p.bd_row + (p.Tq - 1 - (qvalid ? qi : 0)) : nullptr;
+
+    float m_run = NEG_INF, l_run = 0.f;
+    v4f acc[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) acc[d] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    for (int kt0 = 0; kt0 < kend; kt0 += BKV) {
+        // stage K and V tiles (64 keys x 64 dims each), zero-filled past Tk
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int vv = tid + i * 256, row = vv >> 4, c4 = (vv & 15) * 4;
+            const int key = kt0 + row;
+            float4 kx = make_float4(0.f, 0.f, 0.f, 0.f), vx = kx;
+            if (key < p.Tk) {
+                kx = *reinterpret_cast<const float4*>(kb + (long long)key * p.k_row + c4);
+                vx = *reinterpret_cast<const float4*>(vb + (long long)key * p.v_row + c4);
+            }
+            *reinterpret_cast<float4*>(&Ks[row * LD + c4]) = kx;
+            *reinterpret_cast<float4*>(&Vs[row * LD + c4]) = vx;
+        }
+        __syncthreads();
+
+        // scores: s[kt][r] <-> key kt0 + kt*16 + lg*4 + r, query lq
+        v4f s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            v4f sa = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dg = 0; dg < 4; ++dg) {
+                const float4 kf = *reinterpret_cast<const float4*>(&Ks[(kt * 16 + lq) * LD + dg * 16 + lg * 4]);
+                sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[dg].x, sa, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[dg].y, sa, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[dg].z, sa, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[dg].w, sa, 0, 0, 0);
+            }
+            s[kt] = sa;
+        }
+        float mt = NEG_INF;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt0 + kt * 16 + lg * 4 + r;
+                float x = s[kt][r];
+                if (bd && key < klim) x += bd[key];
+                x = key < klim ? x * p.scale : NEG_INF;
+                s[kt][r] = x;
+                mt = fmaxf(mt, x);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 16));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = (m_run == NEG_INF) ? 0.f : expf(m_run - m_new);
+        float rsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = s[kt][r];
+                const float e = (x == NEG_INF) ? 0.f : expf(x - m_new);
+                s[kt][r] = e;
+                rsum += e;
+            }
+        rsum += __shfl_xor(rsum, 16);
+        rsum += __shfl_xor(rsum, 32);
+        l_run = l_run * alpha + rsum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[d] = acc[d] * alpha;
+
+        // O^T += V^T P^T : a = V[key][d = dt*16 + lq], b = P[query lq][key slot]
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = s[kt][r];
+                const float* vrow = &Vs[(kt * 16 + lg * 4 + r) * LD + lq];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[dt * 16], pv, acc[dt], 0, 0, 0);
+            }
+        __syncthreads();
+    }
+
+    if (qvalid) {
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        float* op = p.o + (long long)b * p.o_batch + (long long)qi * p.o_row + (long long)h * p.o_head;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<float4*>(op + dt * 16 + lg * 4) = make_float4(acc[dt][0] * inv, acc[dt][1] * inv, acc[dt][2] * inv, acc[dt][3] * inv);
+    }
+}
+
+}  // namespace cv

@@ -1,0 +1,82 @@
+// cosyvoice_amd — device-side helpers shared by every gfx950 kernel.
+// Wave = 64 lanes everywhere (CDNA4).  All reductions are fixed-order (deterministic).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cv {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;   // raw bfloat16 bits (weights are stored as bf16, math is fp32)
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+
+// activation ids (shared with the host side: keep in sync with api.cpp / cosyvoice_amd.h)
+enum Act : int {
+    ACT_NONE = 0, ACT_SILU = 1, ACT_GELU_ERF = 2, ACT_ELU = 3, ACT_LEAKY = 4, ACT_TANH = 5,
+    ACT_MISH = 6, ACT_ABS = 7, ACT_SNAKE = 8,
+};
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+__device__ __forceinline__ float apply_act(int act, float v, float p) {
+    switch (act) {
+        case ACT_SILU: return v / (1.f + expf(-v));
+        case ACT_GELU_ERF: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        case ACT_ELU: return v > 0.f ? v : expm1f(v);
+        case ACT_LEAKY: return v > 0.f ? v : v * p;
+        case ACT_TANH: return tanhf(v);
+        case ACT_MISH: return v * tanhf(softplus_f(v));
+        case ACT_ABS: return fabsf(v);
+        default: return v;
+    }
+}
+
+// Snake(x) = x + sin^2(alpha x) / (alpha + 1e-9)   (reference: cosyvoice/transformer/activation.py:73-84)
+__device__ __forceinline__ float snake_f(float x, float alpha) {
+    float s = sinf(x * alpha);
+    return x + (1.0f / (alpha + 1e-9f)) * s * s;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+// reduce over aligned groups of 16 lanes
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// block-wide sum for blocks of up to 16 waves; `red` is an LDS scratch of >= 16 floats.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = red[0];
+    for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+}  // namespace cv

@@ -1,0 +1,192 @@
+// Implicit-GEMM linear / conv1d / transposed-conv kernel for gfx950 (exact-fp32 MFMA).
+//
+//   C[b][m][n] = epi( sum_{tap<taps} sum_{k<K}  pro(A_b[m*lda + a_off0 + tap*tap_step + k]) * W[n][tap*Kp + k] )
+//
+// * activations A are fp32, channel-last ([time][channel]); the flat-index form lets one kernel
+//   serve Linear (taps=1), causal / "same" / dilated Conv1d (tap_step = dilation*C_in, a_off0 = -pad*C_in),
+//   strided Conv1d (lda = stride*C_in, K = k*C_in: an im2col window is contiguous in channel-last),
+//   and ConvTranspose1d in polyphase form (tap_step = -C_in, N = stride*C_out, c_off = -pad*C_out).
+//   Any flat index outside [0, a_len) reads as zero (that IS the zero padding).
+// * weights W are bf16 (LLM / flow: "W16A32") or fp32 (HiFT), row-major [N][taps*Kp], Kp = round_up(K,32)
+//   zero padded by the host repacker (cosyvoice_amd/weights.py).
+// * math: v_mfma_f32_16x16x4_f32 — bitwise an fp32 fma chain (cdna_hip_programming.md §3), so the
+//   result differs from the CPU oracle only by summation order.
+#pragma once
+#include "common.h"
+
+namespace cv {
+
+struct GemmConvArgs {
+    // A operand
+    const float* A; long long a_batch; long long a_len; int lda; int a_off0; int tap_step; int taps; int K;
+    int a_vec;                      // 1: every float4 group is 16B aligned and fully in or fully out of range
+    int pro; float pro_p; const float* pro_alpha;   // prologue activation on A (ACT_NONE / ACT_LEAKY / ACT_SNAKE)
+    // W operand
+    const void* W; int Kp;          // row stride = taps*Kp
+    const float* bias;              // [N] or null
+    // output
+    float* C; long long c_batch; long long c_len; int ldc; long long c_off; int c_vec;
+    int M, N;
+    int act; float act_p;           // epilogue activation
+    const float* res; long long res_batch;          // residual, indexed like C (null = none)
+    float out_scale;
+    const float* row_scale; long long row_scale_batch;  // per-row multiplier (time mask), null = none
+    int accumulate;                 // C += result
+};
+
+template <int BM, int BN, bool WBF16>
+__global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
+    constexpr int BK = 32, LD = BK + 4;
+    constexpr int TM = BM / 32, TN = BN / 32;       // 16x16 tiles per wave (wave tile = BM/2 x BN/2)
+    constexpr int AV = BM / 32, WV = BN / 32;       // float4 groups per thread per k-step
+    __shared__ __attribute__((aligned(16))) float As[BM * LD];
+    __shared__ __attribute__((aligned(16))) float Ws[BN * LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, b = blockIdx.z;
+    const float* Ab = p.A + (long long)b * p.a_batch;
+    const int kchunks = p.Kp / BK;
+    const int nit = p.taps * kchunks;
+    const long long ldw = (long long)p.taps * p.Kp;
+
+    v4f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[AV];
+    float4 rw[WV];
+
+    auto load_tile = [&](int it) {
+        const int tap = it / kchunks, k0 = (it - tap * kchunks) * BK;
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int v = tid + i * 256, row = v >> 3, kk = k0 + (v & 7) * 4;
+            const int m = m0 + row;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < p.M && kk < p.K) {
+                const long long idx = (long long)m * p.lda + p.a_off0 + (long long)tap * p.tap_step + kk;
+                if (p.a_vec && kk + 3 < p.K) {
+                    if (idx >= 0 && idx + 3 < p.a_len) x = *reinterpret_cast<const float4*>(Ab + idx);
+                } else {
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const long long ie = idx + e;
+                        t[e] = (kk + e < p.K && ie >= 0 && ie < p.a_len) ? Ab[ie] : 0.f;
+                    }
+                    x = make_float4(t[0], t[1], t[2], t[3]);
+                }
+                if (p.pro == ACT_LEAKY) {
+                    x.x = x.x > 0.f ? x.x : x.x * p.pro_p; x.y = x.y > 0.f ? x.y : x.y * p.pro_p;
+                    x.z = x.z > 0.f ? x.z : x.z * p.pro_p; x.w = x.w > 0.f ? x.w : x.w * p.pro_p;
+                } else if (p.pro == ACT_SNAKE) {
+                    // kk..kk+3 < Kp and pro_alpha is padded to Kp by the host
+                    const float4 al = *reinterpret_cast<const float4*>(p.pro_alpha + kk);
+                    x.x = snake_f(x.x, al.x); x.y = snake_f(x.y, al.y); x.z = snake_f(x.z, al.z); x.w = snake_f(x.w, al.w);
+                }
+            }
+            ra[i] = x;
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + i * 256, row = v >> 3, kk = k0 + (v & 7) * 4;
+            int n = n0 + row; n = n < p.N ? n : p.N - 1;
+            const long long idx = (long long)n * ldw + (long long)tap * p.Kp + kk;
+            if (WBF16) {
+                const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.W) + idx);
+                rw[i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                    __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+            } else {
+                rw[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.W) + idx);
+            }
+        }
+    };
+
+    load_tile(0);
+    for (int it = 0; it < nit; ++it) {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int v = tid + i * 256;
+            *reinterpret_cast<float4*>(&As[(v >> 3) * LD + (v & 7) * 4]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + i * 256;
+            *reinterpret_cast<float4*>(&Ws[(v >> 3) * LD + (v & 7) * 4]) = rw[i];
+        }
+        __syncthreads();
+        if (it + 1 < nit) load_tile(it + 1);   // global loads stay in flight under the MFMAs
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            float4 af[TM], wf[TN];
+            const int kc = kg * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const float4*>(&As[(wm * (BM / 2) + i * 16 + (lane & 15)) * LD + kc]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                wf[j] = *reinterpret_cast<const float4*>(&Ws[(wn * (BN / 2) + j * 16 + (lane & 15)) * LD + kc]);
+            // k-slot permutation: lane group g = lane>>4 feeds k = kc+s at MFMA step s for both operands.
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j].x, af[i].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j].y, af[i].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j].z, af[i].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j].w, af[i].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds C[m][n..n+3] with m = ..+(lane&15), n = ..+(lane>>4)*4   (W rows were the MFMA "A")
+    float* Cb = p.C + (long long)b * p.c_batch;
+    const float* Rb = p.res ? p.res + (long long)b * p.res_batch : nullptr;
+    const float* RSb = p.row_scale ? p.row_scale + (long long)b * p.row_scale_batch : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const float rs = RSb ? RSb[m] : 1.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+            if (n >= p.N) continue;
+            const long long idx = (long long)m * p.ldc + n + p.c_off;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            const bool full = p.c_vec && (n + 3 < p.N) && idx >= 0 && idx + 3 < p.c_len;
+            if (full) {
+                if (p.bias) { const float4 bb = *reinterpret_cast<const float4*>(p.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(p.act, v[e], p.act_p);
+                if (Rb) { const float4 r = *reinterpret_cast<const float4*>(Rb + idx); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] * p.out_scale * rs;
+                if (p.accumulate) { const float4 o = *reinterpret_cast<const float4*>(Cb + idx); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                *reinterpret_cast<float4*>(Cb + idx) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const long long ie = idx + e;
+                    if (n + e >= p.N || ie < 0 || ie >= p.c_len) continue;
+                    float x = v[e];
+                    if (p.bias) x += p.bias[n + e];
+                    x = apply_act(p.act, x, p.act_p);
+                    if (Rb) x += Rb[ie];
+                    x = x * p.out_scale * rs;
+                    if (p.accumulate) x += Cb[ie];
+                    Cb[ie] = x;
+                }
+            }
+        }
+    }
+}
+
+// host-side dispatch (gemm_conv.hip)
+void launch_gemm_conv(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t stream);
+
+}  // namespace cv

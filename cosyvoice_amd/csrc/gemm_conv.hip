@@ -1,0 +1,34 @@
+// Host dispatch for the implicit-GEMM kernel: picks the tile shape so that a launch fills the
+// 256 CUs of an MI355X where the problem allows it (most of this path's GEMMs are small).
+#include "gemm_conv.h"
+
+namespace cv {
+
+template <int BM, int BN>
+static void launch_cfg(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t stream) {
+    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, batch), block(256);
+    if (w_bf16) hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, true>), grid, block, 0, stream, a);
+    else        hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, false>), grid, block, 0, stream, a);
+}
+
+void launch_gemm_conv(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t stream) {
+    if (a.M <= 0 || a.N <= 0 || batch <= 0) return;
+    struct Cfg { int bm, bn; };
+    static const Cfg cfgs[] = {{128, 128}, {128, 64}, {64, 64}, {32, 64}, {32, 32}};
+    int pick = 4;
+    for (int c = 0; c < 5; ++c) {
+        const long long blocks = (long long)((a.M + cfgs[c].bm - 1) / cfgs[c].bm) * ((a.N + cfgs[c].bn - 1) / cfgs[c].bn) * batch;
+        if (cfgs[c].bn > 32 && a.N <= cfgs[c].bn / 2) continue;       // don't pad N by 2x or more
+        if (cfgs[c].bm > 32 && a.M <= cfgs[c].bm / 2) continue;
+        if (blocks >= 240) { pick = c; break; }
+    }
+    switch (pick) {
+        case 0: launch_cfg<128, 128>(a, w_bf16, batch, stream); break;
+        case 1: launch_cfg<128, 64>(a, w_bf16, batch, stream); break;
+        case 2: launch_cfg<64, 64>(a, w_bf16, batch, stream); break;
+        case 3: launch_cfg<32, 64>(a, w_bf16, batch, stream); break;
+        default: launch_cfg<32, 32>(a, w_bf16, batch, stream); break;
+    }
+}
+
+}  // namespace cv

@@ -1,0 +1,49 @@
+// Row-wise LayerNorm / RMSNorm (fp32), one wave per row, 4 rows per workgroup. HBM/L2-bound:
+// each row is read with 16B/lane coalesced loads; statistics are two-pass (mean, then centred variance)
+// like torch.nn.LayerNorm, reduced with fixed-order wave shuffles.
+#pragma once
+#include "common.h"
+
+namespace cv {
+
+struct NormArgs {
+    const float* x; float* y; long long rows; int C;
+    const float* gamma; const float* beta; float eps; int rms;
+    int act; float scale; const float* row_scale; const float* col_add; long long rows_per_batch;
+};
+
+__global__ __launch_bounds__(256) void norm_rows_kernel(NormArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long row = (long long)blockIdx.x * 4 + wave;
+    if (row >= p.rows) return;
+    const float* xr = p.x + row * p.C;
+    float* yr = p.y + row * p.C;
+    const bool vec = (p.C & 3) == 0;
+    float s = 0.f;
+    if (vec) { for (int c = lane * 4; c < p.C; c += 256) { const float4 v = *reinterpret_cast<const float4*>(xr + c); s += (p.rms ? v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w : v.x + v.y + v.z + v.w); } }
+    else     { for (int c = lane; c < p.C; c += 64) { const float v = xr[c]; s += p.rms ? v * v : v; } }
+    s = wave_sum(s);
+    float mean = 0.f, rstd;
+    if (p.rms) {
+        rstd = rsqrtf(s / (float)p.C + p.eps);
+    } else {
+        mean = s / (float)p.C;
+        float q = 0.f;
+        if (vec) { for (int c = lane * 4; c < p.C; c += 256) { const float4 v = *reinterpret_cast<const float4*>(xr + c); const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean; q += a * a + b * b + cc * cc + d * d; } }
+        else     { for (int c = lane; c < p.C; c += 64) { const float a = xr[c] - mean; q += a * a; } }
+        q = wave_sum(q);
+        rstd = rsqrtf(q / (float)p.C + p.eps);
+    }
+    const float rs = p.scale * (p.row_scale ? p.row_scale[row] : 1.f);
+    const float* ca = p.col_add ? p.col_add + (row / p.rows_per_batch) * p.C : nullptr;
+    for (int c = lane; c < p.C; c += 64) {
+        float v = (xr[c] - mean) * rstd;
+        if (p.gamma) v *= p.gamma[c];
+        if (p.beta) v += p.beta[c];
+        v = apply_act(p.act, v, 0.f) * rs;
+        if (ca) v += ca[c];
+        yr[c] = v;
+    }
+}
+
+}  // namespace cv

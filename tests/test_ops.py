@@ -1,0 +1,166 @@
+"""Operator-level parity: each HIP kernel vs a plain torch fp32 restatement of the same op."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cosyvoice_amd import ops
+
+
+def _dev(lib):
+    return torch.device(lib.device)
+
+
+def _sync(lib):
+    if not lib.emulated:
+        torch.cuda.synchronize()
+
+
+def _rand(shape, dev, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+@pytest.mark.parametrize("M,N,K,wdt", [(5, 7, 9, torch.float32), (37, 48, 64, torch.bfloat16), (130, 200, 96, torch.bfloat16),
+                                       (64, 64, 544, torch.float32)])
+def test_linear(lib, M, N, K, wdt):
+    dev = _dev(lib)
+    A = _rand((M, K), dev, 1)
+    W = _rand((N, K), dev, 2, 0.2).to(wdt).float()
+    b = _rand((N,), dev, 3)
+    Wp, Kp = ops.pack_weight(W, wdt)
+    res = _rand((M, N), dev, 4)
+    out = ops.gemm_conv(lib, A, Wp, Kp, M=M, N=N, K=K, bias=b, act="silu", res=res.reshape(1, M, N), out_scale=0.5)
+    _sync(lib)
+    ref = (F.silu(A @ W.t() + b) + res) * 0.5
+    torch.testing.assert_close(out[0].cpu(), ref.cpu(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("T,Cin,Cout,k,dil,causal", [(50, 16, 24, 3, 1, True), (70, 32, 32, 7, 3, False), (33, 80, 40, 11, 5, False)])
+def test_conv1d(lib, T, Cin, Cout, k, dil, causal):
+    """Conv1d on channel-last activations == torch conv1d on [B,C,T] (flow/decoder.py:36-62, hifigan/generator.py:46-122)."""
+    dev = _dev(lib)
+    B = 2
+    x = _rand((B, T, Cin), dev, 5)                       # channel-last
+    w = _rand((Cout, Cin, k), dev, 6, 0.2)
+    b = _rand((Cout,), dev, 7)
+    alpha = (_rand((Cin,), dev, 8).abs() + 0.5)
+    pad_l = (k - 1) * dil if causal else (k * dil - dil) // 2
+    Wp, Kp = ops.pack_weight(w.permute(0, 2, 1).contiguous(), torch.float32)     # [N, taps, Cin]
+    alpha_p = torch.zeros(Kp, device=dev); alpha_p[:Cin] = alpha
+    out = ops.gemm_conv(lib, x, Wp, Kp, M=T, N=Cout, K=Cin, taps=k, lda=Cin, a_off0=-pad_l * Cin, tap_step=dil * Cin,
+                        a_len=T * Cin, a_batch=T * Cin, batch=B, c_batch=T * Cout, bias=b, pro="snake", pro_alpha=alpha_p)
+    _sync(lib)
+    xs = x.transpose(1, 2)
+    xs = xs + (1.0 / (alpha[None, :, None] + 1e-9)) * torch.sin(xs * alpha[None, :, None]) ** 2
+    if causal:
+        ref = F.conv1d(F.pad(xs, (pad_l, 0)), w, b, dilation=dil)
+    else:
+        ref = F.conv1d(xs, w, b, dilation=dil, padding=pad_l)
+    torch.testing.assert_close(out.cpu(), ref.transpose(1, 2).cpu(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("T,Cin,Cout,k,s,p", [(40, 18, 16, 30, 15, 7), (31, 18, 8, 6, 3, 1)])
+def test_strided_conv(lib, T, Cin, Cout, k, s, p):
+    """source_downs: Conv1d(18, C, k=2u, stride=u, padding=u//2) (hifigan/generator.py:449-451) as an im2col-free GEMM."""
+    dev = _dev(lib)
+    x = _rand((T, Cin), dev, 9)
+    w = _rand((Cout, Cin, k), dev, 10, 0.2)
+    b = _rand((Cout,), dev, 11)
+    Tout = (T + 2 * p - k) // s + 1
+    Wp, Kp = ops.pack_weight(w.permute(0, 2, 1).reshape(Cout, 1, k * Cin).contiguous(), torch.float32)
+    out = ops.gemm_conv(lib, x, Wp, Kp, M=Tout, N=Cout, K=k * Cin, lda=s * Cin, a_off0=-p * Cin, a_len=T * Cin, bias=b)
+    _sync(lib)
+    ref = F.conv1d(x.t()[None], w, b, stride=s, padding=p)[0].t()
+    torch.testing.assert_close(out[0].cpu(), ref.cpu(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("T,Cin,Cout,k,s", [(12, 32, 16, 16, 8), (9, 16, 8, 11, 5), (10, 8, 4, 7, 3)])
+def test_conv_transpose(lib, T, Cin, Cout, k, s):
+    """ConvTranspose1d(k, stride s, padding (k-s)//2) in polyphase form (hifigan/generator.py:428-441)."""
+    dev = _dev(lib)
+    p = (k - s) // 2
+    x = _rand((T, Cin), dev, 12)
+    w = _rand((Cin, Cout, k), dev, 13, 0.2)
+    b = _rand((Cout,), dev, 14)
+    Tout = (T - 1) * s - 2 * p + k
+    q = (k + s - 1) // s
+    wp = torch.zeros(s, Cout, q, Cin, device=dev)          # [(r, co), tap q, ci] = w[ci, co, r + s*q]
+    for r in range(s):
+        for qq in range(q):
+            if r + s * qq < k:
+                wp[r, :, qq, :] = w[:, :, r + s * qq].t()
+    Wp, Kp = ops.pack_weight(wp.reshape(s * Cout, q, Cin), torch.float32)
+    out = torch.zeros(1, Tout, Cout, device=dev)
+    ops.gemm_conv(lib, x, Wp, Kp, M=T + q - 1, N=s * Cout, K=Cin, taps=q, lda=Cin, tap_step=-Cin, a_len=T * Cin,
+                  bias=b.repeat(s), out=out, ldc=s * Cout, c_off=-p * Cout, c_len=Tout * Cout, pro="leaky", pro_p=0.1)
+    _sync(lib)
+    ref = F.conv_transpose1d(F.leaky_relu(x.t()[None], 0.1), w, b, stride=s, padding=p)[0].t()
+    torch.testing.assert_close(out[0].cpu(), ref.cpu(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("rows,C,rms", [(7, 80, False), (9, 256, False), (5, 896, True), (3, 30, False)])
+def test_norm_rows(lib, rows, C, rms):
+    dev = _dev(lib)
+    x = _rand((rows, C), dev, 15) * 3 + 1
+    g = _rand((C,), dev, 16); b = _rand((C,), dev, 17)
+    if rms:
+        out = ops.norm_rows(lib, x, gamma=g, eps=1e-6, rms=True)
+        ref = x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-6) * g
+    else:
+        rs = _rand((rows,), dev, 18); ca = _rand((1, C), dev, 19)
+        out = ops.norm_rows(lib, x, gamma=g, beta=b, eps=1e-5, act="mish", scale=2.0, row_scale=rs, col_add=ca)
+        ref = F.mish(F.layer_norm(x, (C,), g, b, 1e-5)) * 2.0 * rs[:, None] + ca
+    _sync(lib)
+    torch.testing.assert_close(out.cpu(), ref.cpu(), rtol=2e-5, atol=2e-5)
+
+
+def _ref_attn(q, k, v, scale, mask):
+    s = torch.einsum("bqhd,bkhd->bhqk", q, k) * scale
+    s = s.masked_fill(~mask, float("-inf"))
+    return torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v)
+
+
+@pytest.mark.parametrize("Tq,Tk,mode,chunk", [(70, 70, "none", 0), (50, 50, "chunk", 16), (33, 81, "causal", 0), (130, 130, "chunk", 50)])
+def test_attention(lib, Tq, Tk, mode, chunk):
+    dev = _dev(lib)
+    B, H, G = 2, 4, 2
+    qkv = _rand((B, Tq, 3 * H * 64), dev, 20)                 # fused-QKV row layout as the flow estimator produces it
+    q = qkv[..., :H * 64].view(B, Tq, H, 64)
+    if Tk == Tq:
+        k = qkv[..., H * 64:2 * H * 64].view(B, Tq, H, 64); v = qkv[..., 2 * H * 64:].view(B, Tq, H, 64); group = 1
+    else:   # GQA against a cache laid out [B, Hkv, Tk, 64]
+        kc = _rand((B, H // G, Tk, 64), dev, 21); vc = _rand((B, H // G, Tk, 64), dev, 22)
+        k = kc.permute(0, 2, 1, 3); v = vc.permute(0, 2, 1, 3); group = G
+    scale = 1 / 8.0
+    out = ops.attention(lib, q, k, v, scale=scale, mask=mode, chunk=chunk, kv_group=group)
+    _sync(lib)
+    qi = torch.arange(Tq)[:, None]; kj = torch.arange(Tk)[None, :]
+    if mode == "none":
+        m = torch.ones(Tq, Tk, dtype=torch.bool)
+    elif mode == "causal":
+        m = kj <= qi + (Tk - Tq)
+    else:
+        m = kj < (qi // chunk + 1) * chunk
+    kk = k.repeat_interleave(group, dim=2) if group > 1 else k
+    vv = v.repeat_interleave(group, dim=2) if group > 1 else v
+    ref = _ref_attn(q.cpu(), kk.cpu(), vv.cpu(), scale, m[None, None])
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_attention_relpos(lib):
+    """scores = (ac + rel_shift(bd)) / sqrt(d)  (cosyvoice/transformer/attention.py:222-244,318-326)."""
+    dev = _dev(lib)
+    B, H, T = 1, 2, 37
+    q = _rand((B, T, H, 64), dev, 23); k = _rand((B, T, H, 64), dev, 24); v = _rand((B, T, H, 64), dev, 25)
+    bd = _rand((B, H, T, 2 * T - 1), dev, 26)
+    out = ops.attention(lib, q, k, v, scale=1 / 8.0, rel_bd=bd)
+    _sync(lib)
+    x = bd.cpu()
+    zero_pad = torch.zeros((B, H, T, 1))
+    x_padded = torch.cat([zero_pad, x], dim=-1).view(B, H, 2 * T, T)
+    shifted = x_padded[:, :, 1:].view_as(x)[:, :, :, :T]
+    s = (torch.einsum("bqhd,bkhd->bhqk", q.cpu(), k.cpu()) + shifted) / 8.0
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v.cpu())
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-5, atol=2e-5)
