@@ -1,0 +1,209 @@
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference) on seeded inputs.
+
+Run in the build container only:  python tests/golden/make_golden.py
+The reference modules are instantiated with small dims, loaded (strict=True) with oracle.weights' seeded state dicts —
+which also validates the factory's key names/shapes against the reference — and their outputs are stored.  Weights are
+NOT stored: oracle/weights.py regenerates them from the seed (numpy PCG64).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+
+ref_import.install()
+from oracle import weights as W  # noqa: E402
+
+
+def save(name, **arrs):
+    out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()}
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: v.shape for k, v in out.items()})
+
+
+# ------------------------------------------------------------------------------------------------ LLM
+def golden_llm():
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+    import cosyvoice.llm.llm as L
+    from cosyvoice.utils.common import ras_sampling
+
+    cfg = W.tiny()[0]
+
+    class Enc(L.Qwen2Encoder):                          # same forward code, random-init backbone instead of from_pretrained
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            hc = Qwen2Config(vocab_size=cfg.text_vocab, hidden_size=cfg.hidden, intermediate_size=cfg.inter,
+                             num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads, num_key_value_heads=cfg.kv_heads,
+                             max_position_embeddings=4096, rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
+                             tie_word_embeddings=True, attention_dropout=0.0)
+            self.model = Qwen2ForCausalLM(hc)
+
+        def forward_one_step(self, xs, masks, cache=None):
+            # SURVEY.md §0 oracle trap: the reference's [1,1] decode mask is mis-handled by transformers 5.x; the intended
+            # semantics (transformers 4.51.3 drops an all-ones mask) are plain causal attention over the cache.
+            outs = self.model(inputs_embeds=xs, attention_mask=None if xs.shape[1] == 1 else masks[:, -1, :],
+                              output_hidden_states=True, return_dict=True, use_cache=True, past_key_values=cache)
+            return outs.hidden_states[-1], outs.past_key_values
+
+    sd = W.make_llm(cfg)
+    logps = []
+
+    def greedy(scores, decoded, k):
+        logps.append(scores.clone())
+        return int(scores.argmax().item())
+
+    lm = L.Qwen2LM(cfg.hidden, cfg.hidden, cfg.speech_token_size, Enc(), greedy)
+    missing = lm.load_state_dict(sd, strict=True)
+    lm.eval()
+    u = W.synthetic_utterance(cfg, W.tiny()[1], n_prompt_tok=11, n_prompt_text=5, n_text=6)
+    kw = dict(text=u["text"], text_len=torch.tensor([u["text"].shape[1]], dtype=torch.int32),
+              prompt_text=u["prompt_text"], prompt_text_len=torch.tensor([u["prompt_text"].shape[1]], dtype=torch.int32),
+              prompt_speech_token=u["llm_prompt_speech_token"], prompt_speech_token_len=torch.tensor([11], dtype=torch.int32),
+              embedding=u["llm_embedding"])
+    toks = list(lm.inference(**kw, max_token_text_ratio=4, min_token_text_ratio=4))
+    # prefill hidden state of the reference (full-sequence forward) for a stage-level check
+    with torch.inference_mode():
+        text = torch.cat([u["prompt_text"], u["text"]], 1)
+        lm_input = torch.cat([lm.llm_embedding.weight[0].reshape(1, 1, -1), lm.llm.model.model.embed_tokens(text),
+                              lm.llm_embedding.weight[1].reshape(1, 1, -1), lm.speech_embedding(u["llm_prompt_speech_token"])], 1)
+        hid, _ = lm.llm.forward_one_step(lm_input, masks=torch.tril(torch.ones((1, lm_input.shape[1], lm_input.shape[1]))).to(torch.bool))
+    save("llm_tiny", text=u["text"], prompt_text=u["prompt_text"], prompt_speech_token=u["llm_prompt_speech_token"],
+         tokens=np.array(toks), logp=torch.stack(logps[:8]), prefill_hidden=hid[0], lm_input=lm_input[0])
+
+    # ras_sampling decision logic with the multinomial draw replaced by an inverse-CDF on queued uniforms
+    us = list(np.random.default_rng(7).random(400))
+    orig = torch.Tensor.multinomial
+
+    def fake_multinomial(self, n, replacement=False):
+        uu = us.pop(0)
+        cdf = torch.cumsum(self.double() / self.double().sum(), 0)
+        return torch.searchsorted(cdf, torch.tensor([uu], dtype=torch.float64), right=True).clamp(max=self.numel() - 1)
+
+    torch.Tensor.multinomial = fake_multinomial
+    try:
+        g = torch.Generator().manual_seed(3)
+        rows, outs, decs = [], [], []
+        decoded = []
+        for i in range(60):
+            logp = (torch.randn(cfg.speech_token_size + 3, generator=g) * (2.0 if i % 2 else 0.3)).log_softmax(0)
+            rows.append(logp.clone()); decs.append(list(decoded[-10:]) + [-1] * (10 - len(decoded[-10:])))
+            n_before = len(us)
+            t = ras_sampling(logp, decoded, 25)
+            outs.append([t, n_before - len(us)])
+            decoded.append(t)
+    finally:
+        torch.Tensor.multinomial = orig
+    save("ras_sampling", logp=torch.stack(rows), out=np.array(outs), uniforms=np.random.default_rng(7).random(400), window=np.array(decs))
+
+
+# ------------------------------------------------------------------------------------------------ flow
+def build_ref_flow(cfg):
+    from omegaconf import DictConfig
+    from cosyvoice.flow.decoder import CausalConditionalDecoder
+    from cosyvoice.flow.flow import CausalMaskedDiffWithXvec
+    from cosyvoice.flow.flow_matching import CausalConditionalCFM
+    from cosyvoice.transformer.upsample_encoder import UpsampleConformerEncoder
+    enc = UpsampleConformerEncoder(output_size=cfg.dim, attention_heads=cfg.enc_heads, linear_units=cfg.ffn, num_blocks=cfg.enc_blocks,
+                                   dropout_rate=0.1, positional_dropout_rate=0.1, attention_dropout_rate=0.1, normalize_before=True,
+                                   input_layer="linear", pos_enc_layer_type="rel_pos_espnet", selfattention_layer_type="rel_selfattn",
+                                   input_size=cfg.dim, use_cnn_module=False, macaron_style=False, static_chunk_size=cfg.chunk)
+    enc.up_encoders = enc.up_encoders[: cfg.up_blocks]
+    est = CausalConditionalDecoder(in_channels=4 * cfg.mel, out_channels=cfg.mel, channels=[cfg.est_ch], dropout=0.0, attention_head_dim=64,
+                                   n_blocks=cfg.est_blocks, num_mid_blocks=cfg.est_mid, num_heads=cfg.est_heads, act_fn="gelu",
+                                   static_chunk_size=cfg.chunk * 2, num_decoding_left_chunks=-1)
+    cfm = CausalConditionalCFM(in_channels=240, n_spks=1, spk_emb_dim=80,
+                               cfm_params=DictConfig({"sigma_min": 1e-6, "solver": "euler", "t_scheduler": "cosine",
+                                                      "training_cfg_rate": 0.2, "inference_cfg_rate": cfg.cfg_rate, "reg_loss_type": "l1"}),
+                               estimator=est)
+    flow = CausalMaskedDiffWithXvec(input_size=cfg.dim, output_size=cfg.mel, spk_embed_dim=cfg.spk_dim, vocab_size=cfg.vocab,
+                                    input_frame_rate=25, token_mel_ratio=2, pre_lookahead_len=cfg.pre_lookahead, encoder=enc, decoder=cfm)
+    flow.load_state_dict(W.make_flow(cfg), strict=True)
+    return flow.eval()
+
+
+def golden_flow():
+    cfg = W.ref_small_flow()
+    flow = build_ref_flow(cfg)
+    g = torch.Generator().manual_seed(11)
+    n_p, n_t = 9, 16
+    prompt_token = torch.randint(0, cfg.vocab, (1, n_p), generator=g, dtype=torch.int32)
+    token = torch.randint(0, cfg.vocab, (1, n_t), generator=g, dtype=torch.int32)
+    prompt_feat = torch.randn(1, 2 * n_p, 80, generator=g) * 2 - 5
+    emb = torch.randn(1, cfg.spk_dim, generator=g)
+    common = dict(prompt_token=prompt_token, prompt_token_len=torch.tensor([n_p], dtype=torch.int32), prompt_feat=prompt_feat,
+                  prompt_feat_len=torch.tensor([2 * n_p], dtype=torch.int32), embedding=emb)
+    mel_full, _ = flow.inference(token=token, token_len=torch.tensor([n_t], dtype=torch.int32), streaming=False, finalize=True, **common)
+    mel_stream, _ = flow.inference(token=token, token_len=torch.tensor([n_t], dtype=torch.int32), streaming=True, finalize=False, **common)
+    # estimator boundary B3 (flow_matching.py:126-128) on random inputs, both mask modes
+    T = 37
+    x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g); cond = torch.randn(2, 80, T, generator=g)
+    spk = torch.randn(2, 80, generator=g); t = torch.tensor([0.3, 0.3]); mask = torch.ones(2, 1, T)
+    with torch.inference_mode():
+        e_full = flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=False)
+        e_stream = flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=True)
+        # encoder boundary B4
+        tok_emb = flow.input_embedding(torch.cat([prompt_token, token], 1).long())
+        h_full, _ = flow.encoder(tok_emb, torch.tensor([n_p + n_t]), streaming=False)
+        h_ctx, _ = flow.encoder(tok_emb[:, :-3], torch.tensor([n_p + n_t]), context=tok_emb[:, -3:], streaming=True)
+    save("flow_small", prompt_token=prompt_token, token=token, prompt_feat=prompt_feat, embedding=emb, mel_full=mel_full,
+         mel_stream=mel_stream, est_x=x, est_mu=mu, est_cond=cond, est_spk=spk, est_t=t, est_full=e_full, est_stream=e_stream,
+         enc_full=h_full, enc_ctx=h_ctx)
+
+
+# ------------------------------------------------------------------------------------------------ HiFT
+def build_ref_hift(cfg):
+    from cosyvoice.hifigan.f0_predictor import ConvRNNF0Predictor
+    from cosyvoice.hifigan.generator import HiFTGenerator
+    hift = HiFTGenerator(in_channels=cfg.mel, base_channels=cfg.base, nb_harmonics=cfg.harmonics, sampling_rate=cfg.sr,
+                         nsf_alpha=cfg.nsf_alpha, nsf_sigma=cfg.nsf_sigma, nsf_voiced_threshold=cfg.voiced_thr,
+                         upsample_rates=cfg.ups, upsample_kernel_sizes=cfg.up_k, istft_params={"n_fft": cfg.n_fft, "hop_len": cfg.hop},
+                         resblock_kernel_sizes=cfg.res_k, resblock_dilation_sizes=[cfg.res_d] * 3,
+                         source_resblock_kernel_sizes=cfg.src_k, source_resblock_dilation_sizes=[cfg.res_d] * 3,
+                         lrelu_slope=cfg.lrelu, audio_limit=cfg.audio_limit,
+                         f0_predictor=ConvRNNF0Predictor(num_class=1, in_channels=cfg.mel, cond_channels=cfg.f0_ch))
+    hift.load_state_dict(W.make_hift(cfg), strict=True)
+    return hift.eval()
+
+
+def golden_hift():
+    cfg = W.tiny()[2]
+    hift = build_ref_hift(cfg)
+    g = torch.Generator().manual_seed(12)
+    m = 9
+    mel = torch.randn(1, 80, m, generator=g) * 2 - 5
+    with torch.inference_mode():
+        f0 = hift.f0_predictor(mel)
+        torch.manual_seed(99)
+        speech, source = hift.inference(speech_feat=mel)
+        # the global-RNG draws inference() consumed, in order (generator.py:245, :312; :374 is unused)
+        torch.manual_seed(99)
+        rand_ini = torch.rand(1, 9); rand_ini[:, 0] = 0
+        noise = torch.randn_like(torch.empty(1, 9, 480 * m).transpose(1, 2))     # sine_waves is a transposed view: same strides, same fill order
+        cache = torch.randn(1, 1, 480 * 2, generator=g) * 0.1
+        torch.manual_seed(99)
+        speech_c, source_c = hift.inference(speech_feat=mel, cache_source=cache)
+    save("hift_tiny", mel=mel, f0=f0, speech=speech, source=source, rand_ini=rand_ini, noise=noise, cache=cache,
+         speech_c=speech_c, source_c=source_c)
+
+
+def golden_glue():
+    """fade_in_out + masks (cosyvoice/utils/common.py:170-178, utils/mask.py)."""
+    from cosyvoice.utils.common import fade_in_out
+    from cosyvoice.utils.mask import subsequent_chunk_mask
+    g = torch.Generator().manual_seed(13)
+    a = torch.randn(1, 9000, generator=g); b = torch.randn(1, 3840, generator=g)
+    win = np.hamming(2 * 3840)
+    out = fade_in_out(a, b, win)
+    save("glue", fade_a=a, fade_b=b, fade_out=out, chunk_mask=subsequent_chunk_mask(23, 5).to(torch.uint8))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["llm", "flow", "hift", "glue"]
+    for w in which:
+        globals()["golden_" + w]()
