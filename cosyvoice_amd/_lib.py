@@ -65,8 +65,12 @@ class Lib:
         self.dll.cv_last_error.restype = C.c_char_p
         self.dll.cv_version.restype = C.c_char_p
         self.emulated = bool(self.dll.cv_is_emulated())
+        self.tensor_hook = None      # tests install a guard-page allocator here (tests/guard.py); identity in production
         if self.emulated and not allow_emulated:
             raise CosyVoiceAmdError("%s is the CPU-emulator test build; refusing to use it as the product path" % path)
+
+    def hook(self, t):
+        return t if self.tensor_hook is None or t is None else self.tensor_hook(t)
 
     def check(self, rc):
         if rc != 0:

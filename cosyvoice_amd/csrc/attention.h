@@ -24,7 +24,7 @@ struct AttnArgs {
 
 enum { MASK_NONE = 0, MASK_CAUSAL = 1, MASK_CHUNK = 2 };
 
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
+static __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
     constexpr int BQ = 64, BKV = 64, LD = 68;
     __shared__ __attribute__((aligned(16))) float Ks[BKV * LD];
     __shared__ __attribute__((aligned(16))) float Vs[BKV * LD];

@@ -1,0 +1,267 @@
+// Stage driver: Qwen2LM speech-token language model (replaces Qwen2LM.inference / inference_wrapper and
+// Qwen2Encoder.forward_one_step of cosyvoice/llm/llm.py:242-254,458-549 behind boundary B2 of SURVEY.md §8b).
+//
+// prefill: M = L0 rows through the exact-fp32 MFMA GEMM + flash attention, K/V written to a resident fp32 cache.
+// decode : one captured hipGraph per handle = {head GEMV + on-device sampling, embed, 24 x (5 kernels), advance};
+//          it is replayed once per token; the loop state lives in device memory (DecodeState), so no host sync is
+//          needed per token — tokens are read back in chunks.
+#include <vector>
+#include <cmath>
+#include "ops.h"
+#include "tensor_map.h"
+#include "llm_kernels.h"
+
+using namespace cv;
+
+struct cv_llm {
+    cv_llm_config cfg{};
+    TensorMap tm;
+    bool finalized = false;
+    struct Layer { const float* ln1; const bf16_t* wqkv; const float* bqkv; const bf16_t* wo; const float* ln2; const bf16_t* wgu; const bf16_t* wdown; };
+    std::vector<Layer> layers;
+    const float* norm = nullptr; const bf16_t* head_w = nullptr; const float* head_b = nullptr; const bf16_t* speech_emb = nullptr;
+    int V = 0, qkv_dim = 0;
+    // device state
+    DevBuf kcache, vcache, rope_cos, rope_sin, state, tokens, uniforms;
+    DevBuf h, qkv, attn, act, logits;                  // decode activations
+    DevBuf pf_x, pf_xn, pf_qkv, pf_attn, pf_gu, pf_act; // prefill activations (grown on demand)
+    int pf_rows = 0;
+    // decode graph
+    hipGraphExec_t graph = nullptr; hipStream_t graph_stream = nullptr; hipStream_t own_stream = nullptr;
+    cv_sampling sp{}; bool sp_valid = false; bool use_graph = true;
+    int* host_tokens = nullptr; DecodeState* host_state = nullptr;
+    size_t layer_cache() const { return (size_t)cfg.kv_heads * cfg.max_len * 64; }
+    ~cv_llm() {
+        if (graph) (void)hipGraphExecDestroy(graph);
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+        if (host_tokens) (void)hipHostFree(host_tokens);
+        if (host_state) (void)hipHostFree(host_state);
+    }
+};
+
+static void llm_finalize(cv_llm* m) {
+    const auto& c = m->cfg;
+    CV_CHECK(c.hidden % 128 == 0 && c.inter % 128 == 0, "llm: hidden and inter must be multiples of 128");
+    CV_CHECK(c.heads % c.kv_heads == 0 && c.heads * 64 % 128 == 0, "llm: bad head configuration (head_dim is fixed at 64)");
+    CV_CHECK(c.max_len > 0 && c.max_len <= 4096, "llm: max_len must be in (0, 4096]");
+    CV_CHECK(c.hidden <= 4864 && c.inter <= 4864, "llm: hidden/inter above the GEMV LDS staging limit");
+    m->V = c.speech_vocab;
+    CV_CHECK(m->V > 0 && m->V <= 8192, "llm: speech vocab above the sampler limit");
+    m->qkv_dim = (c.heads + 2 * c.kv_heads) * 64;
+    const long long H = c.hidden;
+    m->layers.resize(c.layers);
+    for (int i = 0; i < c.layers; ++i) {
+        const std::string p = "layers." + std::to_string(i) + ".";
+        auto& L = m->layers[i];
+        L.ln1 = m->tm.f32(p + "ln1", H);
+        L.wqkv = m->tm.bf16(p + "wqkv", (long long)m->qkv_dim * H);
+        L.bqkv = m->tm.f32(p + "bqkv", m->qkv_dim);
+        L.wo = m->tm.bf16(p + "wo", H * c.heads * 64);
+        L.ln2 = m->tm.f32(p + "ln2", H);
+        L.wgu = m->tm.bf16(p + "wgu", 2LL * c.inter * H);
+        L.wdown = m->tm.bf16(p + "wdown", H * c.inter);
+    }
+    m->norm = m->tm.f32("norm", H);
+    m->head_w = m->tm.bf16("head.w", (long long)m->V * H);
+    m->head_b = m->tm.f32("head.b", m->V);
+    m->speech_emb = m->tm.bf16("embed.speech", (long long)m->V * H);
+
+    m->kcache.ensure(m->layer_cache() * c.layers * sizeof(float));
+    m->vcache.ensure(m->layer_cache() * c.layers * sizeof(float));
+    // rotate-half RoPE tables (transformers Qwen2RotaryEmbedding: inv_freq = theta^(-2f/64), fp32)
+    std::vector<float> cs((size_t)c.max_len * 32), sn((size_t)c.max_len * 32);
+    for (int f = 0; f < 32; ++f) {
+        const float inv = 1.0f / powf(c.rope_theta, (float)(2 * f) / 64.0f);
+        for (int p = 0; p < c.max_len; ++p) { const float a = (float)p * inv; cs[(size_t)p * 32 + f] = cosf(a); sn[(size_t)p * 32 + f] = sinf(a); }
+    }
+    m->rope_cos.ensure(cs.size() * 4); m->rope_sin.ensure(sn.size() * 4);
+    CV_HIP(hipMemcpy(m->rope_cos.p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+    CV_HIP(hipMemcpy(m->rope_sin.p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+    m->state.ensure(sizeof(DecodeState));
+    m->tokens.ensure((size_t)c.max_len * sizeof(int));
+    m->uniforms.ensure((size_t)c.max_len * 2 * sizeof(float));
+    m->h.ensure(H * 4); m->qkv.ensure((size_t)m->qkv_dim * 4); m->attn.ensure((size_t)c.heads * 64 * 4);
+    m->act.ensure((size_t)c.inter * 4); m->logits.ensure((size_t)m->V * 4);
+    CV_HIP(hipHostMalloc((void**)&m->host_tokens, (size_t)c.max_len * sizeof(int)));
+    CV_HIP(hipHostMalloc((void**)&m->host_state, sizeof(DecodeState)));
+    CV_HIP(hipMemset(m->state.p, 0, sizeof(DecodeState)));
+    m->finalized = true;
+}
+
+// Graph capture is illegal on the legacy default stream: a NULL stream is mapped to a handle-owned *blocking* stream,
+// which HIP orders against the default stream implicitly (so torch work on stream 0 stays ordered with ours).
+static hipStream_t resolve(cv_llm* m, void* s) {
+    if (s) return as_stream(s);
+    if (!m->own_stream) CV_HIP(hipStreamCreate(&m->own_stream));
+    return m->own_stream;
+}
+
+static LinearW lw(const bf16_t* w, const float* b, int N, int K) { LinearW l; l.w = w; l.b = b; l.N = N; l.K = K; l.Kp = round_up32(K); l.bf16 = true; return l; }
+
+static void llm_prefill(cv_llm* m, const float* x_in, int L0, hipStream_t s) {
+    const auto& c = m->cfg;
+    CV_CHECK(m->finalized, "llm: call cv_llm_finalize first");
+    CV_CHECK(L0 > 0 && L0 < c.max_len, "llm_prefill: prompt length out of range");
+    const int H = c.hidden, Q = m->qkv_dim, A = c.heads * 64;
+    if (L0 > m->pf_rows) {
+        m->pf_x.ensure((size_t)L0 * H * 4); m->pf_xn.ensure((size_t)L0 * H * 4); m->pf_qkv.ensure((size_t)L0 * Q * 4);
+        m->pf_attn.ensure((size_t)L0 * A * 4); m->pf_gu.ensure((size_t)L0 * 2 * c.inter * 4); m->pf_act.ensure((size_t)L0 * c.inter * 4);
+        m->pf_rows = L0;
+    }
+    float* x = m->pf_x.as<float>(); float* xn = m->pf_xn.as<float>(); float* qkv = m->pf_qkv.as<float>();
+    float* at = m->pf_attn.as<float>(); float* gu = m->pf_gu.as<float>(); float* act = m->pf_act.as<float>();
+    CV_HIP(hipMemcpyAsync(x, x_in, (size_t)L0 * H * 4, hipMemcpyDeviceToDevice, s));
+    for (int i = 0; i < c.layers; ++i) {
+        const auto& L = m->layers[i];
+        float* kc = m->kcache.as<float>() + m->layer_cache() * i;
+        float* vc = m->vcache.as<float>() + m->layer_cache() * i;
+        norm_rows(NormArgs{x, xn, L0, H, L.ln1, nullptr, c.rms_eps, 1, ACT_NONE, 1.f, nullptr, nullptr, L0}, s);
+        linear(xn, L0, lw(L.wqkv, L.bqkv, Q, H), qkv, ACT_NONE, nullptr, s);
+        hipLaunchKernelGGL(rope_store_kernel, dim3(L0), dim3(256), 0, s, qkv, L0, c.heads, c.kv_heads, 0,
+                           m->rope_cos.as<float>(), m->rope_sin.as<float>(), kc, vc, c.max_len);
+        AttnArgs a{};
+        a.q = qkv; a.q_batch = 0; a.q_row = Q; a.q_head = 64;
+        a.k = kc; a.k_batch = 0; a.k_row = 64; a.k_head = c.max_len * 64;
+        a.v = vc; a.v_batch = 0; a.v_row = 64; a.v_head = c.max_len * 64;
+        a.o = at; a.o_batch = 0; a.o_row = A; a.o_head = 64;
+        a.B = 1; a.H = c.heads; a.kv_group = c.heads / c.kv_heads; a.Tq = L0; a.Tk = L0;
+        a.scale = 0.125f; a.mask_mode = MASK_CAUSAL; a.chunk = 0; a.rel_bd = nullptr;
+        attention(a, s);
+        linear(at, L0, lw(L.wo, nullptr, H, A), x, ACT_NONE, x, s);
+        norm_rows(NormArgs{x, xn, L0, H, L.ln2, nullptr, c.rms_eps, 1, ACT_NONE, 1.f, nullptr, nullptr, L0}, s);
+        linear(xn, L0, lw(L.wgu, nullptr, 2 * c.inter, H), gu, ACT_NONE, nullptr, s);
+        const long long n_out = (long long)L0 * c.inter;
+        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, gu, act, n_out);
+        linear(act, L0, lw(L.wdown, nullptr, H, c.inter), x, ACT_NONE, x, s);
+    }
+    CV_HIP(hipMemcpyAsync(m->h.p, x + (size_t)(L0 - 1) * H, (size_t)H * 4, hipMemcpyDeviceToDevice, s));
+    DecodeState st{}; st.pos = L0; st.step = 0; st.done = 0; st.n_tokens = 0; st.last_token = 0;
+    *m->host_state = st;
+    CV_HIP(hipMemcpyAsync(m->state.p, m->host_state, sizeof(DecodeState), hipMemcpyHostToDevice, s));
+    CV_HIP(hipStreamSynchronize(s));     // host_state is reused by the next call
+}
+
+template <int WAVES>
+static void gemv(const GemvArgs& a, int rows_per_block, hipStream_t s) {
+    const int units = a.mode == 1 ? a.N / 2 : a.N;
+    hipLaunchKernelGGL((gemv_kernel<WAVES>), dim3((units + rows_per_block - 1) / rows_per_block), dim3(WAVES * 64), 0, s, a);
+}
+
+// one token: head + sample, then (unless done) embed + backbone for the sampled token
+static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
+    const auto& c = m->cfg;
+    const DecodeState* st = m->state.as<DecodeState>();
+    float* h = m->h.as<float>(); float* qkv = m->qkv.as<float>(); float* at = m->attn.as<float>(); float* act = m->act.as<float>();
+    gemv<1>(GemvArgs{m->head_w, m->head_b, h, m->logits.as<float>(), m->V, c.hidden, m->norm, c.rms_eps, nullptr, 0, st}, 4, s);
+    SampleArgs sa{};
+    sa.logits = m->logits.as<float>(); sa.V = m->V; sa.eos = m->sp.eos; sa.n_stop = m->sp.n_stop;
+    sa.min_len = m->sp.min_len; sa.max_len = m->sp.max_len; sa.mode = m->sp.mode; sa.top_p = m->sp.top_p; sa.top_k = m->sp.top_k;
+    sa.win = m->sp.win_size; sa.tau_r = m->sp.tau_r; sa.seed = m->sp.seed; sa.uniforms = m->sp.use_uniforms ? m->uniforms.as<float>() : nullptr;
+    sa.st = m->state.as<DecodeState>(); sa.tokens = m->tokens.as<int>(); sa.max_tokens = c.max_len;
+    hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, s, sa);
+    hipLaunchKernelGGL(embed_last_token_kernel, dim3(1), dim3(256), 0, s, m->speech_emb, c.hidden, h, st);
+    for (int i = 0; i < c.layers; ++i) {
+        const auto& L = m->layers[i];
+        gemv<1>(GemvArgs{L.wqkv, L.bqkv, h, qkv, m->qkv_dim, c.hidden, L.ln1, c.rms_eps, nullptr, 0, st}, 4, s);
+        AttnDecodeArgs ad{qkv, m->kcache.as<float>() + m->layer_cache() * i, m->vcache.as<float>() + m->layer_cache() * i,
+                          m->rope_cos.as<float>(), m->rope_sin.as<float>(), at, c.heads, c.kv_heads, c.max_len, st};
+        hipLaunchKernelGGL(attn_decode_kernel, dim3(c.heads), dim3(256), 0, s, ad);
+        gemv<1>(GemvArgs{L.wo, nullptr, at, h, c.hidden, c.heads * 64, nullptr, 0.f, h, 0, st}, 4, s);
+        gemv<1>(GemvArgs{L.wgu, nullptr, h, act, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 1, st}, 4, s);
+        gemv<4>(GemvArgs{L.wdown, nullptr, act, h, c.hidden, c.inter, nullptr, 0.f, h, 0, st}, 4, s);
+    }
+    hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, s, m->state.as<DecodeState>());
+}
+
+static bool same_sampling(const cv_sampling& a, const cv_sampling& b) {
+    return a.mode == b.mode && a.eos == b.eos && a.n_stop == b.n_stop && a.min_len == b.min_len && a.max_len == b.max_len &&
+           a.top_p == b.top_p && a.top_k == b.top_k && a.win_size == b.win_size && a.tau_r == b.tau_r && a.seed == b.seed &&
+           a.use_uniforms == b.use_uniforms;
+}
+
+static void llm_decode(cv_llm* m, int n_steps, const cv_sampling* sp, int32_t* out_tokens, int32_t* n_out, int32_t* finished, hipStream_t s) {
+    CV_CHECK(m->finalized, "llm: call cv_llm_finalize first");
+    CV_CHECK(sp && sp->max_len > 0 && sp->eos >= 0 && sp->eos + sp->n_stop <= m->V, "llm_decode: bad sampling parameters");
+    CV_CHECK(sp->mode == 0 || (sp->top_k > 0 && sp->top_k <= 64 && sp->win_size >= 0), "llm_decode: bad RAS parameters");
+    if (!m->sp_valid || !same_sampling(m->sp, *sp)) {
+        m->sp = *sp; m->sp_valid = true;
+        if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+    }
+    const int before = m->host_state->n_tokens;
+    // never run past the KV cache: each step appends one position
+    CV_CHECK(m->host_state->pos + n_steps < m->cfg.max_len, "llm_decode: KV cache (max_len) exhausted");
+    if (m->use_graph) {
+        if (!m->graph || m->graph_stream != s) {
+            if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+            hipGraph_t g = nullptr;
+            CV_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            llm_enqueue_step(m, s);
+            CV_HIP(hipStreamEndCapture(s, &g));
+            CV_HIP(hipGraphInstantiate(&m->graph, g, nullptr, nullptr, 0));
+            CV_HIP(hipGraphDestroy(g));
+            m->graph_stream = s;
+        }
+        for (int i = 0; i < n_steps; ++i) CV_HIP(hipGraphLaunch(m->graph, s));
+    } else {
+        for (int i = 0; i < n_steps; ++i) llm_enqueue_step(m, s);
+    }
+    CV_HIP(hipMemcpyAsync(m->host_state, m->state.p, sizeof(DecodeState), hipMemcpyDeviceToHost, s));
+    CV_HIP(hipMemcpyAsync(m->host_tokens, m->tokens.p, (size_t)m->cfg.max_len * sizeof(int), hipMemcpyDeviceToHost, s));
+    CV_HIP(hipStreamSynchronize(s));
+    CV_HIP(hipGetLastError());
+    const int after = m->host_state->n_tokens;
+    for (int i = before; i < after; ++i) out_tokens[i - before] = m->host_tokens[i];
+    *n_out = after - before;
+    *finished = m->host_state->done || m->host_state->step >= sp->max_len;
+}
+
+extern "C" {
+
+int cv_llm_create(cv_llm** out, const cv_llm_config* cfg) {
+    return guarded([&] { CV_CHECK(out && cfg, "cv_llm_create: null argument"); auto* m = new cv_llm(); m->cfg = *cfg; *out = m; });
+}
+int cv_llm_set_tensor(cv_llm* m, const char* name, const void* dev_ptr, int32_t dtype, int64_t numel) {
+    return guarded([&] { CV_CHECK(m, "null handle"); m->tm.set(name, dev_ptr, dtype, numel); });
+}
+int cv_llm_finalize(cv_llm* m) { return guarded([&] { CV_CHECK(m, "null handle"); llm_finalize(m); }); }
+void cv_llm_destroy(cv_llm* m) { delete m; }
+int cv_llm_set_option(cv_llm* m, const char* name, int32_t value) {
+    return guarded([&] {
+        CV_CHECK(m && name, "null argument");
+        if (std::string(name) == "use_graph") { m->use_graph = value != 0; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; } }
+        else throw Error(std::string("unknown option ") + name);
+    });
+}
+int cv_llm_prefill(cv_llm* m, const float* lm_input, int32_t L0, void* stream) {
+    return guarded([&] { CV_CHECK(m && lm_input, "null argument"); llm_prefill(m, lm_input, L0, resolve(m, stream)); });
+}
+int cv_llm_set_uniforms(cv_llm* m, const float* host_uniforms, int32_t n, void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && host_uniforms && n > 0 && n <= m->cfg.max_len * 2, "cv_llm_set_uniforms: bad arguments");
+        CV_HIP(hipMemcpyAsync(m->uniforms.p, host_uniforms, (size_t)n * 4, hipMemcpyHostToDevice, as_stream(stream)));
+        CV_HIP(hipStreamSynchronize(as_stream(stream)));
+    });
+}
+int cv_llm_decode(cv_llm* m, int32_t n_steps, const cv_sampling* sp, int32_t* out_tokens, int32_t* n_out, int32_t* finished, void* stream) {
+    return guarded([&] { CV_CHECK(m && out_tokens && n_out && finished && n_steps > 0, "cv_llm_decode: bad arguments");
+                         llm_decode(m, n_steps, sp, out_tokens, n_out, finished, resolve(m, stream)); });
+}
+int cv_llm_last_logits(cv_llm* m, float* host_out, void* stream) {
+    return guarded([&] { CV_CHECK(m && host_out, "null argument");
+                         CV_HIP(hipMemcpyAsync(host_out, m->logits.p, (size_t)m->V * 4, hipMemcpyDeviceToHost, as_stream(stream)));
+                         CV_HIP(hipStreamSynchronize(as_stream(stream))); });
+}
+int cv_llm_last_hidden(cv_llm* m, float* host_out, void* stream) {
+    return guarded([&] { CV_CHECK(m && host_out, "null argument");
+                         CV_HIP(hipMemcpyAsync(host_out, m->h.p, (size_t)m->cfg.hidden * 4, hipMemcpyDeviceToHost, as_stream(stream)));
+                         CV_HIP(hipStreamSynchronize(as_stream(stream))); });
+}
+
+int cv_gather_rows(const void* table, int32_t dtype, int64_t table_rows, int32_t dim, const int32_t* ids_dev, int32_t n, float* out, float scale, void* stream) {
+    return guarded([&] {
+        CV_CHECK(table && ids_dev && out && n > 0, "cv_gather_rows: bad arguments");
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(256), 0, as_stream(stream), table, dtype == CV_BF16 ? 1 : 0, ids_dev, n, dim, out, (long long)table_rows, scale);
+    });
+}
+
+}  // extern "C"

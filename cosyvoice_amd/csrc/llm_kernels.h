@@ -1,0 +1,371 @@
+// LLM (Qwen2 backbone of cosyvoice/llm/llm.py Qwen2LM) decode-path kernels for gfx950.
+// Batch-1 autoregressive decode is HBM-bandwidth bound (727.6 MB of bf16 weights per token): the GEMV streams every
+// weight row once with 16B/lane coalesced loads, activations are fp32 in LDS, accumulation is fp32 in a fixed order.
+// Every kernel reads the loop state (KV length, "done" flag, last token) from device memory so that one captured
+// hipGraph can be replayed for every token without host involvement.
+#pragma once
+#include "common.h"
+
+namespace cv {
+
+struct DecodeState {       // lives in device memory (one per cv_llm handle)
+    int pos;               // number of positions already in the KV cache
+    int step;              // index i of the reference loop `for i in range(max_len)` (llm/llm.py:538)
+    int done;              // set when a stop token was sampled or max_len reached
+    int n_tokens;          // tokens emitted so far
+    int last_token;        // last emitted token (input of the next backbone step)
+    int pad[3];
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// y[n] = epi( sum_k W[n][k] * xn[k] ),  W bf16 [N][K] row-major, K % 128 == 0.
+//   xn = x                      (gamma == nullptr)
+//   xn = rmsnorm(x) * gamma     (Qwen2RMSNorm fused as a prologue: every workgroup recomputes the 896-wide norm)
+// A 16-lane group owns one output row: per step the group reads 256 contiguous bytes of the row (16B per lane).
+// A workgroup = WAVES waves; wave w covers k-steps [w*S/WAVES, (w+1)*S/WAVES) of the same 4 rows (split-K inside the
+// workgroup, combined through LDS in fixed order -> deterministic).
+//   mode 0: y[n] = acc + bias[n] (+ res[n])
+//   mode 1: rows are interleaved (gate_j, up_j); y[j] = silu(gate_j) * up_j          (Qwen2MLP)
+// ---------------------------------------------------------------------------------------------------------------
+struct GemvArgs {
+    const bf16_t* W; const float* bias; const float* x; float* y; int N, K;
+    const float* gamma; float eps; const float* res; int mode; const DecodeState* st;
+};
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
+    __shared__ __attribute__((aligned(16))) float xs[4864];
+    __shared__ float red[16];
+    __shared__ float part[WAVES][8];
+    if (p.st && p.st->done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
+    constexpr int NT = WAVES * 64;
+    // stage activations (+ fused RMSNorm)
+    float ss = 0.f;
+    for (int k = tid * 4; k < p.K; k += NT * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p.x + k);
+        *reinterpret_cast<float4*>(&xs[k]) = v;
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (p.gamma) {
+        const float tot = block_sum(ss, red);
+        const float rstd = rsqrtf(tot / (float)p.K + p.eps);
+        for (int k = tid * 4; k < p.K; k += NT * 4) {
+            float4 v = *reinterpret_cast<float4*>(&xs[k]);
+            const float4 g = *reinterpret_cast<const float4*>(p.gamma + k);
+            v.x = v.x * rstd * g.x; v.y = v.y * rstd * g.y; v.z = v.z * rstd * g.z; v.w = v.w * rstd * g.w;
+            *reinterpret_cast<float4*>(&xs[k]) = v;
+        }
+    }
+    __syncthreads();
+
+    const int rows_per_grp = p.mode == 1 ? 2 : 1;
+    const int row0 = (blockIdx.x * 4 + grp) * rows_per_grp;
+    const int steps = p.K / 128;
+    const int s0 = wave * steps / WAVES, s1 = (wave + 1) * steps / WAVES;
+    float acc[2] = {0.f, 0.f};
+    for (int r = 0; r < rows_per_grp; ++r) {
+        const int row = min(row0 + r, p.N - 1);          // clamp (never break: the group reduction below is a wave collective)
+        const bf16_t* wr = p.W + (long long)row * p.K + sub * 8;
+        float a = 0.f;
+#pragma unroll 8
+        for (int s = s0; s < s1; ++s) {
+            const uint4 u = *reinterpret_cast<const uint4*>(wr + s * 128);
+            const float4 x0 = *reinterpret_cast<const float4*>(&xs[s * 128 + sub * 8]);
+            const float4 x1 = *reinterpret_cast<const float4*>(&xs[s * 128 + sub * 8 + 4]);
+            a += __uint_as_float(u.x << 16) * x0.x;          a += __uint_as_float(u.x & 0xffff0000u) * x0.y;
+            a += __uint_as_float(u.y << 16) * x0.z;          a += __uint_as_float(u.y & 0xffff0000u) * x0.w;
+            a += __uint_as_float(u.z << 16) * x1.x;          a += __uint_as_float(u.z & 0xffff0000u) * x1.y;
+            a += __uint_as_float(u.w << 16) * x1.z;          a += __uint_as_float(u.w & 0xffff0000u) * x1.w;
+        }
+        acc[r] = group16_sum(a);
+    }
+    if (WAVES > 1) {
+        if (sub == 0) { part[wave][grp * 2] = acc[0]; part[wave][grp * 2 + 1] = acc[1]; }
+        __syncthreads();
+        if (wave != 0) return;
+        acc[0] = 0.f; acc[1] = 0.f;
+        for (int w = 0; w < WAVES; ++w) { acc[0] += part[w][grp * 2]; acc[1] += part[w][grp * 2 + 1]; }
+    }
+    if (sub != 0) return;
+    if (p.mode == 1) {
+        const int j = blockIdx.x * 4 + grp;
+        if (row0 + 1 < p.N) { const float g = acc[0]; p.y[j] = (g / (1.f + expf(-g))) * acc[1]; }
+    } else if (row0 < p.N) {
+        float v = acc[0];
+        if (p.bias) v += p.bias[row0];
+        if (p.res) v += p.res[row0];
+        p.y[row0] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Decode attention for one new position (GQA, head_dim 64), fused with rotate-half RoPE on q/k and the KV-cache append.
+// One workgroup per query head.  qkv = [q(H*64) | k(Hkv*64) | v(Hkv*64)] raw projections (+bias) of the new token.
+// cache layout: K,V [Hkv][max_len][64] fp32.  rope table: cos/sin [max_len][32].
+// ---------------------------------------------------------------------------------------------------------------
+struct AttnDecodeArgs {
+    const float* qkv; float* kcache; float* vcache; const float* rope_cos; const float* rope_sin;
+    float* out; int heads, kv_heads, max_len; const DecodeState* st;
+};
+
+static __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs p) {
+    __shared__ __attribute__((aligned(16))) float qs[64];
+    __shared__ __attribute__((aligned(16))) float knew[64];
+    __shared__ float sc[4096];
+    __shared__ float red[16];
+    __shared__ __attribute__((aligned(16))) float op[4][64];
+    if (p.st->done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, g = h / (p.heads / p.kv_heads);
+    const int pos = p.st->pos;                       // the new token sits at index `pos`
+    const float* kq = p.qkv + p.heads * 64 + g * 64;
+    const float* vq = p.qkv + (p.heads + p.kv_heads) * 64 + g * 64;
+    float* kc = p.kcache + (long long)g * p.max_len * 64;
+    float* vc = p.vcache + (long long)g * p.max_len * 64;
+    if (tid < 64) {
+        const int d = tid, f = d & 31;
+        const float c = p.rope_cos[pos * 32 + f], s = p.rope_sin[pos * 32 + f];
+        const float* qraw = p.qkv + h * 64;
+        const float qr = d < 32 ? -qraw[d + 32] : qraw[d - 32];
+        qs[d] = qraw[d] * c + qr * s;
+        const float kr = d < 32 ? -kq[d + 32] : kq[d - 32];
+        const float kn = kq[d] * c + kr * s;
+        knew[d] = kn;
+        if (h % (p.heads / p.kv_heads) == 0) { kc[(long long)pos * 64 + d] = kn; vc[(long long)pos * 64 + d] = vq[d]; }
+    }
+    __syncthreads();
+    // A 16-lane group covers one key row with float4 loads; a wave covers 4 keys per load slot and issues 4 independent
+    // slots per iteration (16 keys / wave, 64 keys / workgroup in flight) so the loop is bandwidth- not latency-paced.
+    const int sub = lane & 15, kk = lane >> 4;
+    const float4 q4 = *reinterpret_cast<const float4*>(&qs[sub * 4]);
+    const float4 kn4 = *reinterpret_cast<const float4*>(&knew[sub * 4]);
+    const int L = pos + 1;
+    for (int j0 = wave * 16; j0 < L; j0 += 64) {
+        float4 k4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * 4 + kk;
+            k4[u] = (j < pos) ? *reinterpret_cast<const float4*>(kc + (long long)j * 64 + sub * 4) : kn4;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * 4 + kk;
+            float a = q4.x * k4[u].x + q4.y * k4[u].y + q4.z * k4[u].z + q4.w * k4[u].w;
+            a = group16_sum(a);
+            if (sub == 0 && j < L) sc[j] = a * 0.125f;
+        }
+    }
+    __syncthreads();
+    float m = -__builtin_huge_valf();
+    for (int j = tid; j < L; j += 256) m = fmaxf(m, sc[j]);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int j = tid; j < L; j += 256) { const float e = expf(sc[j] - m); sc[j] = e; s += e; }
+    s = block_sum(s, red);
+    __syncthreads();
+    // out[d] = sum_j p_j V[j][d]: same (16 lanes x float4) x 4 keys x 4 slots tiling, reduced over the key lanes by shuffles
+    const float4 vn4 = *reinterpret_cast<const float4*>(vq + sub * 4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j0 = wave * 16; j0 < L; j0 += 64) {
+        float4 v4[4]; float pj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * 4 + kk;
+            v4[u] = (j < pos) ? *reinterpret_cast<const float4*>(vc + (long long)j * 64 + sub * 4) : vn4;
+            pj[u] = j < L ? sc[j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc.x += pj[u] * v4[u].x; acc.y += pj[u] * v4[u].y; acc.z += pj[u] * v4[u].z; acc.w += pj[u] * v4[u].w; }
+    }
+    acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
+    acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+    if (kk == 0) *reinterpret_cast<float4*>(&op[wave][sub * 4]) = acc;
+    __syncthreads();
+    if (wave == 0) p.out[h * 64 + lane] = (op[0][lane] + op[1][lane] + op[2][lane] + op[3][lane]) / s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Prefill helpers
+// ---------------------------------------------------------------------------------------------------------------
+// RoPE on q (in place) and k of L rows, and append k,v to the cache at positions pos0..pos0+L-1.
+static __global__ __launch_bounds__(256) void rope_store_kernel(float* qkv, int L, int heads, int kv_heads, int pos0,
+                                                          const float* rope_cos, const float* rope_sin,
+                                                          float* kcache, float* vcache, int max_len) {
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int width = (heads + 2 * kv_heads) * 64;
+    float* r = qkv + (long long)row * width;
+    const int pos = pos0 + row;
+    const int nrot = (heads + kv_heads) * 32;                 // (head, f) pairs to rotate
+    for (int i = tid; i < nrot; i += 256) {
+        const int hh = i >> 5, f = i & 31;
+        const float c = rope_cos[pos * 32 + f], s = rope_sin[pos * 32 + f];
+        const float a = r[hh * 64 + f], b = r[hh * 64 + f + 32];
+        const float ra = a * c - b * s, rb = b * c + a * s;
+        if (hh < heads) { r[hh * 64 + f] = ra; r[hh * 64 + f + 32] = rb; }
+        else {
+            float* kc = kcache + ((long long)(hh - heads) * max_len + pos) * 64;
+            kc[f] = ra; kc[f + 32] = rb;
+        }
+    }
+    for (int i = tid; i < kv_heads * 64; i += 256) {
+        const int g = i >> 6, d = i & 63;
+        vcache[((long long)g * max_len + pos) * 64 + d] = r[(heads + kv_heads) * 64 + i];
+    }
+}
+
+// act[m][j] = silu(gu[m][2j]) * gu[m][2j+1]
+static __global__ __launch_bounds__(256) void silu_mul_kernel(const float* gu, float* act, long long n_out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out) return;
+    const float2 v = *reinterpret_cast<const float2*>(gu + 2 * i);
+    act[i] = (v.x / (1.f + expf(-v.x))) * v.y;
+}
+
+// rows of a bf16 or fp32 table -> fp32 matrix: out[r][:] = table[ids[r]][:]
+static __global__ __launch_bounds__(256) void gather_rows_kernel(const void* table, int bf16, const int* ids, int n_rows, int dim, float* out,
+                                                          long long table_rows, float scale) {
+    const int r = blockIdx.x;
+    long long id = ids[r];
+    if (id < 0) id = 0;
+    if (id >= table_rows) id = table_rows - 1;
+    for (int c = threadIdx.x; c < dim; c += 256) {
+        const float v = bf16 ? bf16_to_f32(reinterpret_cast<const bf16_t*>(table)[id * dim + c]) : reinterpret_cast<const float*>(table)[id * dim + c];
+        out[(long long)r * dim + c] = v * scale;
+    }
+}
+
+// decode: h = speech_embedding[last_token]
+static __global__ __launch_bounds__(256) void embed_last_token_kernel(const bf16_t* table, int dim, float* h, const DecodeState* st) {
+    if (st->done) return;
+    const long long id = st->last_token;
+    for (int c = threadIdx.x; c < dim; c += 256) h[c] = bf16_to_f32(table[id * dim + c]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sampling on device (one workgroup of 1024 threads), llm/llm.py:150-160 + :542-549 and utils/common.py:138-167.
+//   mode 0: greedy argmax (first index on ties)            mode 1: repetition-aware sampling (RAS)
+// ---------------------------------------------------------------------------------------------------------------
+struct SampleArgs {
+    const float* logits; int V; int eos; int n_stop;          // stop ids = [eos, eos + n_stop)
+    int min_len, max_len; int mode; float top_p; int top_k; int win; float tau_r;
+    unsigned long long seed; const float* uniforms;           // optional explicit uniforms [2 per step] (parity tests)
+    DecodeState* st; int* tokens; int max_tokens;
+};
+
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned step, unsigned draw) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (2ull * step + draw + 1ull);      // splitmix64
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+static __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
+    __shared__ float pr[8192];
+    __shared__ float redv[16];
+    __shared__ int redi[16];
+    __shared__ float chunk[1024];
+    __shared__ float selp[64];
+    __shared__ int seli[64];
+    __shared__ int s_tok;
+    DecodeState* st = p.st;
+    if (st->done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int step = st->step;
+    if (step >= p.max_len) { if (tid == 0) st->done = 1; return; }
+    const float NEG = -__builtin_huge_valf();
+    const bool ignore_eos = step < p.min_len;
+    for (int i = tid; i < p.V; i += 1024) pr[i] = (ignore_eos && i == p.eos) ? NEG : p.logits[i];
+    __syncthreads();
+
+    // block arg-max with lowest-index tie-break
+    auto block_argmax = [&](float& bv, int& bi) {
+        float v = NEG; int ix = 0x7fffffff;
+        for (int i = tid; i < p.V; i += 1024) { const float x = pr[i]; if (x > v || (x == v && i < ix)) { v = x; ix = i; } }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(v, off); const int oi = __shfl_xor(ix, off);
+            if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { redv[wave] = v; redi[wave] = ix; }
+        __syncthreads();
+        v = redv[0]; ix = redi[0];
+        for (int w = 1; w < 16; ++w) if (redv[w] > v || (redv[w] == v && redi[w] < ix)) { v = redv[w]; ix = redi[w]; }
+        bv = v; bi = ix;
+    };
+
+    int tok;
+    if (p.mode == 0) {
+        float bv; block_argmax(bv, tok);
+    } else {
+        // softmax probabilities
+        float mx = NEG;
+        for (int i = tid; i < p.V; i += 1024) mx = fmaxf(mx, pr[i]);
+        mx = block_max(mx, redv);
+        float sm = 0.f;
+        for (int i = tid; i < p.V; i += 1024) { const float e = pr[i] == NEG ? 0.f : expf(pr[i] - mx); pr[i] = e; sm += e; }
+        sm = block_sum(sm, redv);
+        __syncthreads();
+        const float inv = 1.f / sm;
+        for (int i = tid; i < p.V; i += 1024) pr[i] *= inv;
+        __syncthreads();
+        // nucleus: stable descending order, add while cum < top_p and count < top_k   (common.py:151-158)
+        int cnt = 0; float cum = 0.f;
+        while (cum < p.top_p && cnt < p.top_k) {
+            float bv; int bi; block_argmax(bv, bi);
+            if (tid == 0) { selp[cnt] = bv; seli[cnt] = bi; pr[bi] = -1.f; }       // -1 marks "taken" (restored below)
+            cum += bv; ++cnt;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            for (int c = 0; c < cnt; ++c) pr[seli[c]] = selp[c];
+            const float u = p.uniforms ? p.uniforms[2 * step] : uniform01(p.seed, step, 0);
+            float tot = 0.f; for (int c = 0; c < cnt; ++c) tot += selp[c];
+            float acc = 0.f; int pick = cnt - 1;
+            for (int c = 0; c < cnt; ++c) { acc += selp[c] / tot; if (u < acc) { pick = c; break; } }
+            int t = seli[pick];
+            int rep = 0;
+            const int n = st->n_tokens;
+            for (int w = 0; w < p.win && w < n; ++w) rep += p.tokens[n - 1 - w] == t;
+            s_tok = (rep >= p.win * p.tau_r) ? -(t + 1) : t;      // negative: needs the full-distribution fallback
+        }
+        __syncthreads();
+        tok = s_tok;
+        if (tok < 0) {
+            const int banned = -tok - 1;
+            if (tid == 0) pr[banned] = 0.f;
+            __syncthreads();
+            // inverse CDF over the full (renormalised) distribution: per-thread contiguous chunks + serial scan of chunk sums
+            const int per = (p.V + 1023) / 1024, b0 = tid * per, b1 = min(p.V, b0 + per);
+            float cs = 0.f;
+            for (int i = b0; i < b1; ++i) cs += pr[i];
+            chunk[tid] = cs;
+            __syncthreads();
+            if (tid == 0) {
+                float tot = 0.f; for (int c = 0; c < 1024; ++c) tot += chunk[c];
+                const float u = (p.uniforms ? p.uniforms[2 * step + 1] : uniform01(p.seed, step, 1)) * tot;
+                float acc = 0.f; int c = 0;
+                for (; c < 1023; ++c) { if (u < acc + chunk[c]) break; acc += chunk[c]; }
+                int i = c * per, last = i;
+                const int e = min(p.V, i + per);
+                for (; i < e; ++i) { if (pr[i] > 0.f) last = i; acc += pr[i]; if (u < acc) break; }
+                s_tok = i < e ? i : last;
+            }
+            __syncthreads();
+            tok = s_tok;
+        }
+    }
+    if (tid == 0) {
+        if (tok >= p.eos && tok < p.eos + p.n_stop) st->done = 1;
+        else {
+            if (st->n_tokens < p.max_tokens) p.tokens[st->n_tokens] = tok;
+            st->n_tokens += 1; st->last_token = tok; st->step = step + 1;
+            if (step + 1 >= p.max_len) { /* loop ends after this token; the next replay marks done */ }
+        }
+    }
+}
+
+// advance the KV length after a backbone step
+static __global__ void advance_pos_kernel(DecodeState* st) { if (!st->done) st->pos += 1; }
+
+}  // namespace cv

@@ -12,7 +12,7 @@ struct NormArgs {
     int act; float scale; const float* row_scale; const float* col_add; long long rows_per_batch;
 };
 
-__global__ __launch_bounds__(256) void norm_rows_kernel(NormArgs p) {
+static __global__ __launch_bounds__(256) void norm_rows_kernel(NormArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long row = (long long)blockIdx.x * 4 + wave;
     if (row >= p.rows) return;

@@ -1,0 +1,149 @@
+"""Host mirror of cosyvoice.llm.llm.Qwen2LM for the inference path (boundary B2).
+
+Same call surface as the reference (`inference(text, text_len, prompt_text, prompt_text_len, prompt_speech_token,
+prompt_speech_token_len, embedding, sampling=25, max_token_text_ratio=20, min_token_text_ratio=2, uuid='')` yielding
+Python ints), but the whole autoregressive loop — backbone, speech-token head, repetition-aware sampling, stop test —
+runs on the MI355X behind cv_llm_* (cosyvoice_amd/csrc/llm.hip); this class only builds `lm_input` with gather kernels
+and drains tokens in chunks.
+"""
+import ctypes as C
+import threading
+
+import torch
+
+from . import weights as Wt
+from ._lib import CV_BF16, get_lib, stream_ptr
+
+
+class LLMConfigC(C.Structure):
+    _fields_ = [("hidden", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32), ("kv_heads", C.c_int32), ("inter", C.c_int32),
+                ("speech_vocab", C.c_int32), ("max_len", C.c_int32), ("rms_eps", C.c_float), ("rope_theta", C.c_float)]
+
+
+class SamplingC(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("eos", C.c_int32), ("n_stop", C.c_int32), ("min_len", C.c_int32), ("max_len", C.c_int32),
+                ("top_p", C.c_float), ("top_k", C.c_int32), ("win_size", C.c_int32), ("tau_r", C.c_float), ("seed", C.c_uint64),
+                ("use_uniforms", C.c_int32)]
+
+
+def register_tensors(lib, set_fn, handle, tensors):
+    for name, t in tensors.items():
+        dt = {torch.float32: 0, torch.bfloat16: 1, torch.int32: 2}[t.dtype]
+        getattr(lib, set_fn)(handle, name.encode(), C.c_void_p(t.data_ptr()), C.c_int32(dt), C.c_int64(t.numel()))
+
+
+class Qwen2LM:
+    """cosyvoice/llm/llm.py:257-549 (inference side).  `sampling` is 'ras' (the yaml default, cosyvoice2.yaml:32-36) or
+    'greedy' (the sampler north-star parity is defined on)."""
+
+    def __init__(self, state_dict, cfg, lib=None, max_len=2048, sampling="ras", top_p=0.8, top_k=25, win_size=10, tau_r=0.1,
+                 seed=1986, decode_chunk=16, use_graph=True):
+        self.lib = lib or get_lib()
+        self.cfg = cfg
+        self.device = torch.device(self.lib.device)
+        self.speech_token_size = cfg.speech_token_size
+        self.llm_input_size = self.llm_output_size = cfg.hidden
+        self.sos, self.task_id = 0, 1
+        self.eos_token = cfg.speech_token_size
+        self.fill_token = cfg.speech_token_size + 2
+        self.stop_token_ids = [cfg.speech_token_size + i for i in range(3)]
+        self.sampling, self.top_p, self.top_k, self.win_size, self.tau_r, self.seed = sampling, top_p, top_k, win_size, tau_r, seed
+        self.decode_chunk = decode_chunk
+        self.max_len = max_len
+        self.lock = threading.Lock()             # one KV cache per handle: requests on one object are serialised
+        self._tensors, self._host = Wt.pack_llm(state_dict, cfg, self.device)
+        self._tensors = {k: self.lib.hook(v) for k, v in self._tensors.items()}
+        self._host = {k: self.lib.hook(v) for k, v in self._host.items()}
+        c = LLMConfigC(cfg.hidden, cfg.layers, cfg.heads, cfg.kv_heads, cfg.inter, cfg.speech_token_size + 3, max_len, cfg.rms_eps, cfg.rope_theta)
+        self._h = C.c_void_p()
+        self.lib.cv_llm_create(C.byref(self._h), C.byref(c))
+        register_tensors(self.lib, "cv_llm_set_tensor", self._h, self._tensors)
+        self.lib.cv_llm_finalize(self._h)
+        self.lib.cv_llm_set_option(self._h, b"use_graph", C.c_int32(int(use_graph)))
+        self._uniforms = None
+        self._request = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.raw("cv_llm_destroy", None)(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- lm_input = [sos | embed_tokens(prompt_text ++ text) | task_id | speech_embedding(prompt)]  (llm.py:472-494)
+    def build_lm_input(self, text, prompt_text, prompt_speech_token, stream=None):
+        ids_text = self.lib.hook(torch.cat([prompt_text, text], dim=1).reshape(-1).to(self.device, torch.int32))
+        ids_sp = self.lib.hook(prompt_speech_token.reshape(-1).to(self.device, torch.int32))
+        n_t, n_s, H = ids_text.numel(), ids_sp.numel(), self.cfg.hidden
+        L0 = 1 + n_t + 1 + n_s
+        out = self.lib.hook(torch.empty(L0, H, dtype=torch.float32, device=self.device))
+        st = stream if stream is not None else stream_ptr(self.lib)
+        fixed = self.lib.hook(torch.tensor([self.sos, self.task_id], dtype=torch.int32, device=self.device))
+
+        def gather(table, ids, row0):
+            if ids.numel() == 0:
+                return
+            self.lib.cv_gather_rows(C.c_void_p(table.data_ptr()), C.c_int32(CV_BF16), C.c_int64(table.shape[0]), C.c_int32(H),
+                                    C.c_void_p(ids.data_ptr()), C.c_int32(ids.numel()), C.c_void_p(out[row0:].data_ptr()), C.c_float(1.0), st)
+        gather(self._host["embed.llm"], fixed[0:1], 0)
+        gather(self._host["embed.text"], ids_text, 1)
+        gather(self._host["embed.llm"], fixed[1:2], 1 + n_t)
+        gather(self._tensors["embed.speech"], ids_sp, 2 + n_t)
+        self._keep = (ids_text, ids_sp, fixed)
+        return out
+
+    def set_uniforms(self, u):
+        """Parity hook: explicit uniform variates (2 per step) instead of the on-device counter RNG."""
+        self._uniforms = None if u is None else torch.as_tensor(u, dtype=torch.float32).contiguous()
+
+    def prefill(self, lm_input, stream=None):
+        st = stream if stream is not None else stream_ptr(self.lib)
+        self.lib.cv_llm_prefill(self._h, C.c_void_p(lm_input.data_ptr()), C.c_int32(lm_input.shape[0]), st)
+
+    def last_logits(self):
+        out = torch.empty(self.cfg.speech_token_size + 3, dtype=torch.float32)
+        self.lib.cv_llm_last_logits(self._h, C.c_void_p(out.data_ptr()), stream_ptr(self.lib))
+        return out
+
+    def last_hidden(self):
+        out = torch.empty(self.cfg.hidden, dtype=torch.float32)
+        self.lib.cv_llm_last_hidden(self._h, C.c_void_p(out.data_ptr()), stream_ptr(self.lib))
+        return out
+
+    def decode(self, n_steps, sp, stream=None):
+        buf = (C.c_int32 * max(n_steps, 1))()
+        n_out, fin = C.c_int32(0), C.c_int32(0)
+        st = stream if stream is not None else stream_ptr(self.lib)
+        self.lib.cv_llm_decode(self._h, C.c_int32(n_steps), C.byref(sp), buf, C.byref(n_out), C.byref(fin), st)
+        return list(buf[: n_out.value]), bool(fin.value)
+
+    def make_sampling(self, min_len, max_len):
+        self._request += 1
+        sp = SamplingC(1 if self.sampling == "ras" else 0, self.eos_token, 3, min_len, max_len, self.top_p, self.top_k, self.win_size,
+                       self.tau_r, self.seed + self._request, 1 if self._uniforms is not None else 0)
+        if self._uniforms is not None:
+            self.lib.cv_llm_set_uniforms(self._h, C.c_void_p(self._uniforms.data_ptr()), C.c_int32(min(self._uniforms.numel(), 2 * self.max_len)), stream_ptr(self.lib))
+        return sp
+
+    @torch.inference_mode()
+    def inference(self, text, text_len, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len, embedding=None,
+                  sampling=25, max_token_text_ratio=20, min_token_text_ratio=2, uuid=""):
+        """Generator of Python ints, one per speech token (llm/llm.py:458-502, 535-549)."""
+        n_text = int(text.shape[1])
+        min_len = int(n_text * min_token_text_ratio)
+        max_len = int(n_text * max_token_text_ratio)
+        with self.lock:
+            lm_input = self.build_lm_input(text, prompt_text, prompt_speech_token)
+            if lm_input.shape[0] + max_len + 1 >= self.max_len:
+                raise ValueError("prompt (%d) + max_len (%d) exceeds the KV capacity %d" % (lm_input.shape[0], max_len, self.max_len))
+            self.prefill(lm_input)
+            sp = self.make_sampling(min_len, max_len)
+            emitted = 0
+            while emitted < max_len:
+                toks, fin = self.decode(min(self.decode_chunk, max_len - emitted + 1), sp)
+                for t in toks:
+                    yield int(t)
+                emitted += len(toks)
+                if fin:
+                    break

@@ -33,7 +33,7 @@ def gemm_conv(lib, A, Wp, Kp, *, M, N, K, taps=1, lda=None, a_off0=0, tap_step=0
     if a_len is None:
         a_len = A.numel() if batch == 1 else a_batch
     if out is None:
-        out = torch.zeros(batch, M, N, dtype=torch.float32, device=A.device)
+        out = lib.hook(torch.zeros(batch, M, N, dtype=torch.float32, device=A.device))
     if c_len is None:
         c_len = out.numel() if batch == 1 else c_batch
     g = GemmConvArgs()
@@ -57,7 +57,7 @@ def norm_rows(lib, x, gamma=None, beta=None, eps=1e-5, rms=False, act="none", sc
               col_add=None, rows_per_batch=0):
     x = x.contiguous()
     rows, c = x.numel() // x.shape[-1], x.shape[-1]
-    y = torch.empty_like(x)
+    y = lib.hook(torch.empty_like(x))
     lib.cv_norm_rows(ptr(x), ptr(y), C.c_int64(rows), C.c_int32(c), ptr(gamma), ptr(beta), C.c_float(eps),
                      C.c_int32(int(rms)), C.c_int32(ACT[act]), C.c_float(scale), ptr(row_scale), ptr(col_add),
                      C.c_int64(rows_per_batch), stream_ptr(lib))
@@ -69,7 +69,7 @@ def attention(lib, q, k, v, *, scale, mask="none", chunk=0, kv_group=1, rel_bd=N
     B, Tq, H, D = q.shape
     Tk = k.shape[1]
     assert D == 64
-    o = torch.empty(B, Tq, H, 64, dtype=torch.float32, device=q.device)
+    o = lib.hook(torch.empty(B, Tq, H, 64, dtype=torch.float32, device=q.device))
     a = AttnArgs()
     for name, t in (("q", q), ("k", k), ("v", v), ("o", o)):
         setattr(a, name, t.data_ptr())

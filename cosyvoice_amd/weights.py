@@ -1,0 +1,194 @@
+"""Weight repacker: reference state dicts (llm.pt / flow.pt / hift.pt key names, SURVEY.md §5 'Checkpoint / resume')
+-> the device layouts the HIP kernels stream.
+
+  * Linear / Conv weights -> row-major [N][taps * Kp] with Kp = round_up(K, 32), zero padded (gemm_conv.h);
+    LLM and flow matrices are stored as bf16 ("W16A32": weights bf16, activations / accumulation fp32),
+    HiFT stays fp32 (the reference always runs HiFT in fp32, cli/model.py:312).
+  * q/k/v projections are fused into one matrix, gate/up rows are interleaved, ConvTranspose1d is re-expressed in
+    polyphase form, weight-norm (g * v / ||v||) is folded (the reference's remove_weight_norm is broken).
+Everything returned is a dict name -> contiguous torch tensor on `device`; cosyvoice_amd/{llm,flow,hift}.py register
+them with cv_*_set_tensor and keep them alive.
+"""
+import torch
+
+from .ops import pack_weight, round_up
+
+
+def _bf16(t, device):
+    return t.to(device=device, dtype=torch.bfloat16).contiguous()
+
+
+def _f32(t, device):
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def pack_llm(sd, cfg, device):
+    """sd: Qwen2LM state dict (cosyvoice/llm/llm.py:257-297 over transformers Qwen2ForCausalLM)."""
+    out = {}
+    for i in range(cfg.layers):
+        p = "llm.model.model.layers.%d." % i
+        q = "layers.%d." % i
+        out[q + "ln1"] = _f32(sd[p + "input_layernorm.weight"], device)
+        out[q + "wqkv"] = _bf16(torch.cat([sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"]], 0), device)
+        out[q + "bqkv"] = _f32(torch.cat([sd[p + "self_attn.q_proj.bias"], sd[p + "self_attn.k_proj.bias"], sd[p + "self_attn.v_proj.bias"]], 0), device)
+        out[q + "wo"] = _bf16(sd[p + "self_attn.o_proj.weight"], device)
+        out[q + "ln2"] = _f32(sd[p + "post_attention_layernorm.weight"], device)
+        gu = torch.stack([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 1).reshape(2 * cfg.inter, cfg.hidden)
+        out[q + "wgu"] = _bf16(gu, device)
+        out[q + "wdown"] = _bf16(sd[p + "mlp.down_proj.weight"], device)
+    out["norm"] = _f32(sd["llm.model.model.norm.weight"], device)
+    out["head.w"] = _bf16(sd["llm_decoder.weight"], device)
+    out["head.b"] = _f32(sd["llm_decoder.bias"], device)
+    out["embed.speech"] = _bf16(sd["speech_embedding.weight"], device)
+    host_only = {
+        "embed.text": _bf16(sd["llm.model.model.embed_tokens.weight"], device),      # gathered by cv_gather_rows
+        "embed.llm": _bf16(sd["llm_embedding.weight"], device),
+    }
+    return out, host_only
+
+
+def _lin(out, name, w, b, device, dtype):
+    wp, _ = pack_weight(w.to(device).float(), dtype)
+    out[name + ".w"] = wp
+    if b is not None:
+        out[name + ".b"] = _f32(b, device)
+
+
+def _conv(out, name, w, b, device, dtype):
+    """Conv1d weight [Cout, Cin, k] -> [Cout][k][Cin_p]."""
+    wp, _ = pack_weight(w.to(device).float().permute(0, 2, 1).contiguous(), dtype)
+    out[name + ".w"] = wp
+    if b is not None:
+        out[name + ".b"] = _f32(b, device)
+
+
+def pack_flow(sd, cfg, device, dtype=torch.bfloat16):
+    """sd: CausalMaskedDiffWithXvec state dict (cosyvoice/flow/flow.py:150-186)."""
+    out = {}
+    out["input_embedding"] = _bf16(sd["input_embedding.weight"], device) if dtype == torch.bfloat16 else _f32(sd["input_embedding.weight"], device)
+    _lin(out, "spk_affine", sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"], device, dtype)
+    e = "encoder."
+    for name in ("embed", "up_embed"):
+        _lin(out, "enc.%s.lin" % name, sd[e + name + ".out.0.weight"], sd[e + name + ".out.0.bias"], device, dtype)
+        out["enc.%s.ln.g" % name] = _f32(sd[e + name + ".out.1.weight"], device)
+        out["enc.%s.ln.b" % name] = _f32(sd[e + name + ".out.1.bias"], device)
+    out["enc.after_norm.g"] = _f32(sd[e + "after_norm.weight"], device)
+    out["enc.after_norm.b"] = _f32(sd[e + "after_norm.bias"], device)
+    _conv(out, "enc.pre.conv1", sd[e + "pre_lookahead_layer.conv1.weight"], sd[e + "pre_lookahead_layer.conv1.bias"], device, dtype)
+    _conv(out, "enc.pre.conv2", sd[e + "pre_lookahead_layer.conv2.weight"], sd[e + "pre_lookahead_layer.conv2.bias"], device, dtype)
+    _conv(out, "enc.up.conv", sd[e + "up_layer.conv.weight"], sd[e + "up_layer.conv.bias"], device, dtype)
+
+    def conformer(src, dst):
+        a = src + "self_attn."
+        _lin(out, dst + "qkv", torch.cat([sd[a + "linear_q.weight"], sd[a + "linear_k.weight"], sd[a + "linear_v.weight"]], 0),
+             torch.cat([sd[a + "linear_q.bias"], sd[a + "linear_k.bias"], sd[a + "linear_v.bias"]], 0), device, dtype)
+        _lin(out, dst + "pos", sd[a + "linear_pos.weight"], None, device, dtype)
+        _lin(out, dst + "out", sd[a + "linear_out.weight"], sd[a + "linear_out.bias"], device, dtype)
+        out[dst + "bias_u"] = _f32(sd[a + "pos_bias_u"].reshape(-1), device)
+        out[dst + "bias_v"] = _f32(sd[a + "pos_bias_v"].reshape(-1), device)
+        _lin(out, dst + "ff1", sd[src + "feed_forward.w_1.weight"], sd[src + "feed_forward.w_1.bias"], device, dtype)
+        _lin(out, dst + "ff2", sd[src + "feed_forward.w_2.weight"], sd[src + "feed_forward.w_2.bias"], device, dtype)
+        for n in ("norm_mha", "norm_ff"):
+            out[dst + n + ".g"] = _f32(sd[src + n + ".weight"], device)
+            out[dst + n + ".b"] = _f32(sd[src + n + ".bias"], device)
+
+    for i in range(cfg.enc_blocks):
+        conformer(e + "encoders.%d." % i, "enc.layers.%d." % i)
+    for i in range(cfg.up_blocks):
+        conformer(e + "up_encoders.%d." % i, "enc.up_layers.%d." % i)
+    _lin(out, "encoder_proj", sd["encoder_proj.weight"], sd["encoder_proj.bias"], device, dtype)
+
+    s = "decoder.estimator."
+    _lin(out, "est.time1", sd[s + "time_mlp.linear_1.weight"], sd[s + "time_mlp.linear_1.bias"], device, dtype)
+    _lin(out, "est.time2", sd[s + "time_mlp.linear_2.weight"], sd[s + "time_mlp.linear_2.bias"], device, dtype)
+
+    def resnet(src, dst):
+        _lin(out, dst + "mlp", sd[src + "mlp.1.weight"], sd[src + "mlp.1.bias"], device, dtype)
+        for b in ("block1", "block2"):
+            _conv(out, dst + b + ".conv", sd[src + b + ".block.0.weight"], sd[src + b + ".block.0.bias"], device, dtype)
+            out[dst + b + ".ln.g"] = _f32(sd[src + b + ".block.2.weight"], device)
+            out[dst + b + ".ln.b"] = _f32(sd[src + b + ".block.2.bias"], device)
+        _conv(out, dst + "res", sd[src + "res_conv.weight"], sd[src + "res_conv.bias"], device, dtype)
+
+    def tblock(src, dst):
+        out[dst + "norm1.g"] = _f32(sd[src + "norm1.weight"], device); out[dst + "norm1.b"] = _f32(sd[src + "norm1.bias"], device)
+        _lin(out, dst + "qkv", torch.cat([sd[src + "attn1.to_q.weight"], sd[src + "attn1.to_k.weight"], sd[src + "attn1.to_v.weight"]], 0), None, device, dtype)
+        _lin(out, dst + "out", sd[src + "attn1.to_out.0.weight"], sd[src + "attn1.to_out.0.bias"], device, dtype)
+        out[dst + "norm3.g"] = _f32(sd[src + "norm3.weight"], device); out[dst + "norm3.b"] = _f32(sd[src + "norm3.bias"], device)
+        _lin(out, dst + "ff1", sd[src + "ff.net.0.proj.weight"], sd[src + "ff.net.0.proj.bias"], device, dtype)
+        _lin(out, dst + "ff2", sd[src + "ff.net.2.weight"], sd[src + "ff.net.2.bias"], device, dtype)
+
+    stages = [(s + "down_blocks.0.", "est.stage.0.")]
+    stages += [(s + "mid_blocks.%d." % i, "est.stage.%d." % (i + 1)) for i in range(cfg.est_mid)]
+    stages += [(s + "up_blocks.0.", "est.stage.%d." % (cfg.est_mid + 1))]
+    for src, dst in stages:
+        resnet(src + "0.", dst + "res.")
+        for j in range(cfg.est_blocks):
+            tblock(src + "1.%d." % j, dst + "tf.%d." % j)
+    _conv(out, "est.down_conv", sd[s + "down_blocks.0.2.weight"], sd[s + "down_blocks.0.2.bias"], device, dtype)
+    _conv(out, "est.up_conv", sd[s + "up_blocks.0.2.weight"], sd[s + "up_blocks.0.2.bias"], device, dtype)
+    _conv(out, "est.final.conv", sd[s + "final_block.block.0.weight"], sd[s + "final_block.block.0.bias"], device, dtype)
+    out["est.final.ln.g"] = _f32(sd[s + "final_block.block.2.weight"], device)
+    out["est.final.ln.b"] = _f32(sd[s + "final_block.block.2.bias"], device)
+    _conv(out, "est.final_proj", sd[s + "final_proj.weight"], sd[s + "final_proj.bias"], device, dtype)
+    return out
+
+
+def fold_weight_norm(sd, p):
+    g, v = sd[p + "parametrizations.weight.original0"].float(), sd[p + "parametrizations.weight.original1"].float()
+    return g * v / v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
+
+
+def _conv_w(sd, p):
+    return fold_weight_norm(sd, p) if (p + "parametrizations.weight.original0") in sd else sd[p + "weight"].float()
+
+
+def pack_hift(sd, cfg, device):
+    """sd: HiFTGenerator state dict (cosyvoice/hifigan/generator.py:378-476), `generator.` prefix already stripped
+    (cli/model.py:70-71)."""
+    out, f32 = {}, torch.float32
+    for j in range(5):
+        p = "f0_predictor.condnet.%d." % (2 * j)
+        _conv(out, "f0.conv%d" % j, _conv_w(sd, p), sd[p + "bias"], device, f32)
+    out["f0.cls.w"] = _f32(sd["f0_predictor.classifier.weight"].reshape(-1), device)
+    out["f0.cls.b"] = _f32(sd["f0_predictor.classifier.bias"], device)
+    out["source.w"] = _f32(sd["m_source.l_linear.weight"].reshape(-1), device)
+    out["source.b"] = _f32(sd["m_source.l_linear.bias"], device)
+    _conv(out, "conv_pre", _conv_w(sd, "conv_pre."), sd["conv_pre.bias"], device, f32)
+    for i, (u, k) in enumerate(zip(cfg.ups, cfg.up_k)):
+        w = _conv_w(sd, "ups.%d." % i)                       # ConvTranspose1d weight [Cin, Cout, k]
+        cin, cout, _ = w.shape
+        q = (k + u - 1) // u
+        wp = torch.zeros(u, cout, q, cin)
+        for r in range(u):
+            for qq in range(q):
+                if r + u * qq < k:
+                    wp[r, :, qq, :] = w[:, :, r + u * qq].t()
+        packed, _ = pack_weight(wp.reshape(u * cout, q, cin).to(device), f32)
+        out["ups.%d.w" % i] = packed
+        out["ups.%d.b" % i] = _f32(sd["ups.%d.bias" % i].repeat(u), device)
+    import numpy as np
+    rates = np.cumprod([1] + cfg.ups[::-1][:-1])[::-1]
+    for i, r in enumerate(rates):
+        w = sd["source_downs.%d.weight" % i].float()          # [C, 18, k]  -> one im2col row of k*18
+        c, cin, k = w.shape
+        packed, _ = pack_weight(w.permute(0, 2, 1).reshape(c, 1, k * cin).to(device), f32)
+        out["source_downs.%d.w" % i] = packed
+        out["source_downs.%d.b" % i] = _f32(sd["source_downs.%d.bias" % i], device)
+
+    def resblock(src, dst):
+        for j in range(len(cfg.res_d)):
+            for grp, act in (("convs1", "activations1"), ("convs2", "activations2")):
+                _conv(out, "%s%s.%d" % (dst, grp, j), _conv_w(sd, "%s%s.%d." % (src, grp, j)), sd["%s%s.%d.bias" % (src, grp, j)], device, f32)
+                a = sd["%s%s.%d.alpha" % (src, act, j)].float()
+                ap = torch.ones(round_up(a.numel(), 32))
+                ap[: a.numel()] = a
+                out["%s%s.%d.alpha" % (dst, grp, j)] = _f32(ap, device)
+
+    for i in range(len(cfg.ups)):
+        resblock("source_resblocks.%d." % i, "source_resblocks.%d." % i)
+        for j in range(len(cfg.res_k)):
+            n = i * len(cfg.res_k) + j
+            resblock("resblocks.%d." % n, "resblocks.%d." % n)
+    _conv(out, "conv_post", _conv_w(sd, "conv_post."), sd["conv_post.bias"], device, f32)
+    return out

@@ -82,6 +82,44 @@ typedef struct cv_attn_args {
 } cv_attn_args;
 int cv_attention(const cv_attn_args* args, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------------
+ * Stage B2 — speech-token language model.  Replaces Qwen2LM.inference / inference_wrapper and
+ * Qwen2Encoder.forward_one_step (cosyvoice/llm/llm.py:242-254, 458-549).  Weights are registered by name
+ * (packed by cosyvoice_amd/weights.py: "layers.N.{ln1,wqkv,bqkv,wo,ln2,wgu,wdown}", "norm", "head.{w,b}",
+ * "embed.speech"); bf16 matrices are [out][in] row-major, wgu interleaves (gate_j, up_j) rows.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct cv_llm_config {
+    int32_t hidden, layers, heads, kv_heads, inter, speech_vocab /* speech_token_size + 3 */, max_len /* KV capacity */;
+    float rms_eps, rope_theta;
+} cv_llm_config;
+
+/* Sampling + loop bounds of Qwen2LM.inference_wrapper (llm/llm.py:535-549) and ras_sampling (utils/common.py:138-167). */
+typedef struct cv_sampling {
+    int32_t mode;            /* 0 greedy (argmax), 1 repetition-aware sampling */
+    int32_t eos, n_stop;     /* stop ids = [eos, eos + n_stop); eos is suppressed while step < min_len */
+    int32_t min_len, max_len;
+    float top_p; int32_t top_k; int32_t win_size; float tau_r;
+    uint64_t seed;
+    int32_t use_uniforms;    /* 1: draw from the uniforms set by cv_llm_set_uniforms (parity tests) */
+} cv_sampling;
+
+int cv_llm_create(cv_llm** out, const cv_llm_config* cfg);
+int cv_llm_set_tensor(cv_llm* m, const char* name, const void* dev_ptr, int32_t dtype, int64_t numel);
+int cv_llm_finalize(cv_llm* m);
+void cv_llm_destroy(cv_llm* m);
+int cv_llm_set_option(cv_llm* m, const char* name, int32_t value);            /* "use_graph" */
+/* lm_input: dev fp32 [L0, hidden] = [sos | text emb | task_id | prompt speech emb] (llm.py:494). Resets the KV cache. */
+int cv_llm_prefill(cv_llm* m, const float* lm_input, int32_t L0, void* stream);
+int cv_llm_set_uniforms(cv_llm* m, const float* host_uniforms, int32_t n, void* stream);
+/* Runs up to n_steps iterations of the decode loop on the device, then synchronises and returns the tokens emitted by
+ * this call (host ints, like the reference's `yield top_ids`).  *finished != 0 when a stop id was sampled or max_len hit. */
+int cv_llm_decode(cv_llm* m, int32_t n_steps, const cv_sampling* sp, int32_t* out_tokens, int32_t* n_out, int32_t* finished, void* stream);
+int cv_llm_last_logits(cv_llm* m, float* host_out, void* stream);
+int cv_llm_last_hidden(cv_llm* m, float* host_out, void* stream);
+/* out[r][:] = table[ids[r]][:] * scale  (nn.Embedding lookups that build lm_input / flow token embeddings) */
+int cv_gather_rows(const void* table, int32_t dtype, int64_t table_rows, int32_t dim, const int32_t* ids_dev, int32_t n, float* out, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

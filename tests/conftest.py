@@ -18,7 +18,10 @@ def emu_lib():
     """The kernels compiled for the CPU emulator of the HIP execution model (test infrastructure)."""
     from emu.build_emu import build_emu
     from cosyvoice_amd._lib import Lib
-    return Lib(build_emu(), allow_emulated=True)
+    from guard import guard
+    lib = Lib(build_emu(), allow_emulated=True)
+    lib.tensor_hook = lambda t: guard(lib, t)          # every operand ends flush against an inaccessible page
+    return lib
 
 
 @pytest.fixture(scope="session")

@@ -275,10 +275,35 @@ emu_v16f emu_mfma_f32_32x32x16_bf16(emu_v8s a, emu_v8s b, emu_v16f c) {
 }
 
 // ---- host runtime -----------------------------------------------------------------------
-hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : hipErrorUnknown; }
-hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+// Guard-page allocator: the buffer END is flush (to 16 B) against a PROT_NONE page and a PROT_NONE page precedes the
+// mapping, so an out-of-bounds read past the end of any device buffer faults immediately under the emulator.
+#include <map>
+static std::map<void*, std::pair<void*, size_t>> g_allocs;
+static std::mutex g_alloc_mutex;
+extern "C" void* emu_guard_alloc(size_t n) {
+    const size_t page = 4096, n16 = (n + 15) / 16 * 16, body = (n16 + page - 1) / page * page;
+    char* base = (char*)mmap(nullptr, body + 2 * page, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (base == (char*)MAP_FAILED) return nullptr;
+    mprotect(base, page, PROT_NONE);
+    mprotect(base + page + body, page, PROT_NONE);
+    char* p = base + page + body - n16;
+    memset(p, 0xFF, n16);                               // poison: uninitialised reads show up as NaN
+    std::lock_guard<std::mutex> lk(g_alloc_mutex);
+    g_allocs[p] = {base, body + 2 * page};
+    return p;
+}
+extern "C" void emu_guard_free(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_alloc_mutex);
+    auto it = g_allocs.find(p);
+    if (it == g_allocs.end()) { fprintf(stderr, "emu: free of unknown pointer\n"); abort(); }
+    munmap(it->second.first, it->second.second);
+    g_allocs.erase(it);
+}
+hipError_t hipMalloc(void** p, size_t n) { *p = emu_guard_alloc(n); return *p ? hipSuccess : hipErrorUnknown; }
+hipError_t hipFree(void* p) { emu_guard_free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
-hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipHostFree(void* p) { return hipFree(p); }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st) {
     if (S(st)->capturing) { S(st)->cap->push_back(Node{dim3(), dim3(), nullptr, 1, d, s, n, 0}); return hipSuccess; }

@@ -1,0 +1,99 @@
+"""Stage B2 parity: HIP Qwen2LM (prefill GEMM path + graph-replayed decode path + on-device sampling) vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from cosyvoice_amd.llm import Qwen2LM
+from oracle import llm as OL
+from oracle import sampling as OS
+from oracle import weights as W
+
+
+@pytest.fixture(scope="module")
+def tiny_sd():
+    cfg = W.tiny()[0]
+    return cfg, W.make_llm(cfg)
+
+
+def _utt(cfg, n_text=6, n_prompt_text=5, n_prompt_tok=11, seed=1986):
+    return W.synthetic_utterance(cfg, W.tiny()[1], n_prompt_tok=n_prompt_tok, n_prompt_text=n_prompt_text, n_text=n_text, seed=seed)
+
+
+def _kw(u):
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    return dict(text=u["text"], text_len=t(u["text"].shape[1]), prompt_text=u["prompt_text"], prompt_text_len=t(u["prompt_text"].shape[1]),
+                prompt_speech_token=u["llm_prompt_speech_token"], prompt_speech_token_len=t(u["llm_prompt_speech_token"].shape[1]),
+                embedding=u["llm_embedding"])
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_greedy_tokens_bit_exact(lib, tiny_sd, use_graph):
+    """north_star: speech-token ids bit-exact under greedy decode."""
+    cfg, sd = tiny_sd
+    u = _utt(cfg)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=128, sampling="greedy", decode_chunk=5, use_graph=use_graph)
+    got = list(lm.inference(**_kw(u), max_token_text_ratio=4, min_token_text_ratio=2))
+    want = OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=4, min_token_text_ratio=2)
+    assert got == want
+    assert len(got) >= 12
+
+
+def test_teacher_forced_logits(lib, tiny_sd):
+    """First-step logits after prefill, and logits after each decode step, against the oracle's log-probs."""
+    cfg, sd = tiny_sd
+    u = _utt(cfg, seed=7)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=128, sampling="greedy")
+    trace = {}
+    want = OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=2, min_token_text_ratio=2, trace=trace)
+    lm_input = lm.build_lm_input(u["text"], u["prompt_text"], u["llm_prompt_speech_token"])
+    ref_in = OL.build_lm_input(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"])
+    torch.testing.assert_close(lm_input.cpu(), ref_in, rtol=0, atol=0)
+    lm.prefill(lm_input)
+    sp = lm.make_sampling(12, 12)
+    for i in range(len(want)):
+        toks, fin = lm.decode(1, sp)
+        logp = lm.last_logits().log_softmax(-1)
+        torch.testing.assert_close(logp, trace["logp"][i], rtol=1e-4, atol=1e-4)
+        assert toks == [want[i]]
+
+
+def test_ras_sampling_matches_oracle_logic(lib, tiny_sd):
+    """RAS decision logic on device == oracle restatement of utils/common.py:138-167 given the same uniform variates."""
+    cfg, sd = tiny_sd
+    u = _utt(cfg, seed=3)
+    us = np.random.default_rng(5).random(400).astype(np.float32)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=128, sampling="ras", decode_chunk=7)
+    lm.set_uniforms(us)
+    got = list(lm.inference(**_kw(u), max_token_text_ratio=5, min_token_text_ratio=2))
+    step = {"i": 0, "fallbacks": 0}
+
+    def sampler(scores, decoded, k):
+        i = step["i"]; step["i"] += 1
+        before = scores.clone()
+        t = OS.ras_sampling(scores, decoded, k, u=(float(us[2 * i]), float(us[2 * i + 1])))
+        step["fallbacks"] += int(not torch.equal(before, scores))
+        return t
+    want = OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], sampling_fn=sampler, max_token_text_ratio=5, min_token_text_ratio=2)
+    assert got == want
+    assert len(set(got)) > 3
+
+
+def test_eos_stops_and_min_len(lib, tiny_sd):
+    """A stop id ends the stream without being emitted; eos is suppressed below min_len (llm/llm.py:150-160,543-545)."""
+    cfg, sd = tiny_sd
+    sd2 = dict(sd)
+    b = sd["llm_decoder.bias"].clone(); b[cfg.speech_token_size] = 50.0       # eos always wins once allowed
+    sd2["llm_decoder.bias"] = b
+    u = _utt(cfg)
+    lm = Qwen2LM(sd2, cfg, lib=lib, max_len=128, sampling="greedy")
+    got = list(lm.inference(**_kw(u), max_token_text_ratio=10, min_token_text_ratio=1.5))
+    want = OL.inference(sd2, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=10, min_token_text_ratio=1.5)
+    assert got == want and len(got) == 9 and all(t < cfg.speech_token_size for t in got)
+
+
+def test_kv_capacity_is_checked(lib, tiny_sd):
+    cfg, sd = tiny_sd
+    u = _utt(cfg)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=32, sampling="greedy")
+    with pytest.raises(ValueError):
+        list(lm.inference(**_kw(u), max_token_text_ratio=20))

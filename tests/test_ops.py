@@ -8,18 +8,22 @@ import torch.nn.functional as F
 from cosyvoice_amd import ops
 
 
-def _dev(lib):
-    return torch.device(lib.device)
-
-
 def _sync(lib):
     if not lib.emulated:
         torch.cuda.synchronize()
 
 
+_LIB = {}
+
+
+def _dev(lib):
+    _LIB["lib"] = lib
+    return torch.device(lib.device)
+
+
 def _rand(shape, dev, seed, scale=1.0):
     g = torch.Generator().manual_seed(seed)
-    return (torch.randn(shape, generator=g) * scale).to(dev)
+    return _LIB["lib"].hook((torch.randn(shape, generator=g) * scale).to(dev))
 
 
 @pytest.mark.parametrize("M,N,K,wdt", [(5, 7, 9, torch.float32), (37, 48, 64, torch.bfloat16), (130, 200, 96, torch.bfloat16),
