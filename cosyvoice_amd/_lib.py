@@ -19,7 +19,7 @@ class GemmConvArgs(C.Structure):
         ("A", C.c_void_p), ("a_batch", C.c_int64), ("a_len", C.c_int64), ("lda", C.c_int32), ("a_off0", C.c_int32),
         ("tap_step", C.c_int32), ("taps", C.c_int32), ("K", C.c_int32),
         ("pro", C.c_int32), ("pro_p", C.c_float), ("pro_alpha", C.c_void_p),
-        ("W", C.c_void_p), ("w_dtype", C.c_int32), ("Kp", C.c_int32),
+        ("W", C.c_void_p), ("w_dtype", C.c_int32), ("Kp", C.c_int32), ("ldw", C.c_int64), ("w_batch", C.c_int64),
         ("bias", C.c_void_p),
         ("C", C.c_void_p), ("c_batch", C.c_int64), ("c_len", C.c_int64), ("ldc", C.c_int32), ("c_off", C.c_int64),
         ("M", C.c_int32), ("N", C.c_int32), ("batch", C.c_int32),

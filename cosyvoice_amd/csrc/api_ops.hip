@@ -8,7 +8,7 @@ void set_last_error(const std::string& s) { g_last_error = s; }
 
 void gemm_conv(GemmConvArgs a, bool w_bf16, int batch, hipStream_t s) {
     CV_CHECK(a.Kp % 32 == 0 && a.Kp >= a.K, "gemm_conv: Kp must be K rounded up to 32");
-    CV_CHECK(aligned16(a.W), "gemm_conv: W must be 16B aligned");
+    CV_CHECK(aligned16(a.W) && a.ldw % 4 == 0 && a.w_batch % 4 == 0, "gemm_conv: W must be 16B aligned (base, row pitch, batch offset)");
     a.a_vec = aligned16(a.A) && (a.lda % 4 == 0) && (a.a_off0 % 4 == 0) && (a.tap_step % 4 == 0) &&
               (a.a_batch % 4 == 0) && (a.a_len % 4 == 0);
     a.c_vec = aligned16(a.C) && (a.ldc % 4 == 0) && (a.c_off % 4 == 0) && (a.c_batch % 4 == 0) && (a.c_len % 4 == 0) &&
@@ -45,7 +45,7 @@ void linear(const float* A, int M, const LinearW& w, float* C, int act, const fl
     // a_len is only used for range checks; round it up when the row pitch allows a whole float4
     if (lda % 4 == 0 && w.K % 4 == 0) a.a_len = (a.a_len + 3) / 4 * 4;
     a.pro = ACT_NONE; a.pro_p = 0.f; a.pro_alpha = nullptr;
-    a.W = w.w; a.Kp = w.Kp; a.bias = w.b;
+    a.W = w.w; a.Kp = w.Kp; a.ldw = 0; a.w_batch = 0; a.bias = w.b;
     a.C = C; a.c_batch = 0; a.c_len = (long long)M * ldc; a.ldc = ldc; a.c_off = 0;
     a.M = M; a.N = w.N; a.act = act; a.act_p = 0.f; a.res = res; a.res_batch = 0; a.out_scale = out_scale;
     a.row_scale = nullptr; a.row_scale_batch = 0; a.accumulate = accumulate ? 1 : 0;
@@ -71,7 +71,7 @@ int cv_gemm_conv(const cv_gemm_conv_args* g, void* stream) {
         cv::GemmConvArgs a{};
         a.A = g->A; a.a_batch = g->a_batch; a.a_len = g->a_len; a.lda = g->lda; a.a_off0 = g->a_off0; a.tap_step = g->tap_step; a.taps = g->taps; a.K = g->K;
         a.pro = g->pro; a.pro_p = g->pro_p; a.pro_alpha = g->pro_alpha;
-        a.W = g->W; a.Kp = g->Kp; a.bias = g->bias;
+        a.W = g->W; a.Kp = g->Kp; a.ldw = g->ldw; a.w_batch = g->w_batch; a.bias = g->bias;
         a.C = g->C; a.c_batch = g->c_batch; a.c_len = g->c_len; a.ldc = g->ldc; a.c_off = g->c_off;
         a.M = g->M; a.N = g->N; a.act = g->act; a.act_p = g->act_p; a.res = g->res; a.res_batch = g->res_batch;
         a.out_scale = g->out_scale; a.row_scale = g->row_scale; a.row_scale_batch = g->row_scale_batch; a.accumulate = g->accumulate;

@@ -1,0 +1,397 @@
+// Stage driver: token -> mel flow-matching decoder (boundaries B3, B4, B5 of SURVEY.md §8b).
+//   cv_flow_encoder     <- UpsampleConformerEncoder.forward            (transformer/upsample_encoder.py:244-307)
+//   cv_flow_estimator   <- CausalConditionalDecoder.forward            (flow/decoder.py:405-494)
+//   cv_flow_inference   <- CausalMaskedDiffWithXvec.inference + CausalConditionalCFM.forward/solve_euler
+//                          (flow/flow.py:235-281, flow/flow_matching.py:71-124,203-227)
+// Everything is channel-last fp32 with bf16 (or fp32) weights; the Euler loop, CFG batching and time embeddings stay on
+// the device — the host only enqueues.
+#include <vector>
+#include <cmath>
+#include "ops.h"
+#include "tensor_map.h"
+#include "flow_kernels.h"
+
+using namespace cv;
+
+namespace {
+
+struct Lin { const void* w = nullptr; const float* b = nullptr; int N = 0, K = 0, Kp = 0, taps = 1; bool bf16 = true; };
+struct LN { const float* g = nullptr; const float* b = nullptr; };
+
+struct ConformerW { LN norm_mha, norm_ff; Lin qkv, pos, out, ff1, ff2; const float* bias_u; const float* bias_v; };
+struct ResnetW { Lin mlp, conv1, conv2, res; LN ln1, ln2; };
+struct TBlockW { LN norm1, norm3; Lin qkv, out, ff1, ff2; };
+struct StageW { ResnetW res; std::vector<TBlockW> tf; };
+
+inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+struct cv_flow {
+    cv_flow_config cfg{};
+    TensorMap tm;
+    bool finalized = false, wbf16 = true;
+    // encoder
+    Lin embed_lin, up_embed_lin, pre1, pre2, upconv, enc_proj, spk_affine;
+    LN embed_ln, up_embed_ln, after_norm;
+    std::vector<ConformerW> enc, enc_up;
+    const void* input_embedding = nullptr;
+    // estimator
+    Lin time1, time2, down_conv, up_conv, final_conv, final_proj;
+    LN final_ln;
+    std::vector<StageW> stages;
+    // workspaces
+    DevBuf e_x, e_xe, e_n, e_qkv, e_qu, e_qv, e_pe, e_p, e_bd, e_att, e_ff, e_x2, e_ctx;    // encoder
+    DevBuf s_in, s_a, s_b, s_c, s_n, s_qkv, s_att, s_ff, s_skip, s_cat, s_out;                    // estimator
+    DevBuf t_val, t_sin, t_h, t_emb, t_mlp;                                                   // time embeddings
+    DevBuf f_tok, f_h, f_mu, f_spk, f_spkn, f_cond, f_x, f_ones;                              // inference glue
+    int enc_cap = 0, est_cap = 0, t_cap = 0, inf_cap = 0;
+};
+
+static Lin get_lin(const cv_flow* m, const std::string& name, int N, int K, int taps, bool bias) {
+    Lin l; l.N = N; l.K = K; l.Kp = round_up32(K); l.taps = taps; l.bf16 = m->wbf16;
+    const long long numel = (long long)N * taps * l.Kp;
+    l.w = m->tm.get(name + ".w", m->wbf16 ? CV_BF16 : CV_F32, numel).p;
+    l.b = bias ? m->tm.f32(name + ".b", N) : nullptr;
+    return l;
+}
+static LN get_ln(const cv_flow* m, const std::string& name, int C) { LN n; n.g = m->tm.f32(name + ".g", C); n.b = m->tm.f32(name + ".b", C); return n; }
+
+static void flow_finalize(cv_flow* m) {
+    const auto& c = m->cfg;
+    CV_CHECK(c.mel == 80, "flow: mel must be 80 (solve_euler hard-codes it, flow_matching.py:95)");
+    CV_CHECK(c.dim % 64 == 0 && c.dim / c.enc_heads == 64 && c.est_ch % 32 == 0, "flow: head_dim is fixed at 64");
+    CV_CHECK(m->tm.has("encoder_proj.w"), "flow: missing tensor 'encoder_proj.w'");
+    m->wbf16 = m->tm.t.at("encoder_proj.w").dtype == CV_BF16;
+    const int d = c.dim, C = c.est_ch, inner = c.est_heads * 64, tdim = 4 * C, cin = 4 * c.mel;
+    m->input_embedding = m->tm.get("input_embedding", m->wbf16 ? CV_BF16 : CV_F32, (long long)c.vocab * d).p;
+    m->spk_affine = get_lin(m, "spk_affine", c.mel, c.spk_dim, 1, true);
+    m->embed_lin = get_lin(m, "enc.embed.lin", d, d, 1, true); m->embed_ln = get_ln(m, "enc.embed.ln", d);
+    m->up_embed_lin = get_lin(m, "enc.up_embed.lin", d, d, 1, true); m->up_embed_ln = get_ln(m, "enc.up_embed.ln", d);
+    m->after_norm = get_ln(m, "enc.after_norm", d);
+    m->pre1 = get_lin(m, "enc.pre.conv1", d, d, c.pre_lookahead + 1, true);
+    m->pre2 = get_lin(m, "enc.pre.conv2", d, d, 3, true);
+    m->upconv = get_lin(m, "enc.up.conv", d, d, 5, true);
+    m->enc_proj = get_lin(m, "encoder_proj", c.mel, d, 1, true);
+    auto conformer = [&](const std::string& p) {
+        ConformerW w;
+        w.norm_mha = get_ln(m, p + "norm_mha", d); w.norm_ff = get_ln(m, p + "norm_ff", d);
+        w.qkv = get_lin(m, p + "qkv", 3 * d, d, 1, true); w.pos = get_lin(m, p + "pos", d, d, 1, false);
+        w.out = get_lin(m, p + "out", d, d, 1, true);
+        w.ff1 = get_lin(m, p + "ff1", c.ffn, d, 1, true); w.ff2 = get_lin(m, p + "ff2", d, c.ffn, 1, true);
+        w.bias_u = m->tm.f32(p + "bias_u", d); w.bias_v = m->tm.f32(p + "bias_v", d);
+        return w;
+    };
+    for (int i = 0; i < c.enc_blocks; ++i) m->enc.push_back(conformer("enc.layers." + std::to_string(i) + "."));
+    for (int i = 0; i < c.up_blocks; ++i) m->enc_up.push_back(conformer("enc.up_layers." + std::to_string(i) + "."));
+    m->time1 = get_lin(m, "est.time1", tdim, cin, 1, true); m->time2 = get_lin(m, "est.time2", tdim, tdim, 1, true);
+    const int nst = c.est_mid + 2;
+    for (int s = 0; s < nst; ++s) {
+        const std::string p = "est.stage." + std::to_string(s) + ".";
+        const int din = s == 0 ? cin : (s == nst - 1 ? 2 * C : C);
+        StageW st;
+        st.res.mlp = get_lin(m, p + "res.mlp", C, tdim, 1, true);
+        st.res.conv1 = get_lin(m, p + "res.block1.conv", C, din, 3, true); st.res.ln1 = get_ln(m, p + "res.block1.ln", C);
+        st.res.conv2 = get_lin(m, p + "res.block2.conv", C, C, 3, true); st.res.ln2 = get_ln(m, p + "res.block2.ln", C);
+        st.res.res = get_lin(m, p + "res.res", C, din, 1, true);
+        for (int j = 0; j < c.est_blocks; ++j) {
+            const std::string q = p + "tf." + std::to_string(j) + ".";
+            TBlockW t;
+            t.norm1 = get_ln(m, q + "norm1", C); t.norm3 = get_ln(m, q + "norm3", C);
+            t.qkv = get_lin(m, q + "qkv", 3 * inner, C, 1, false); t.out = get_lin(m, q + "out", C, inner, 1, true);
+            t.ff1 = get_lin(m, q + "ff1", 4 * C, C, 1, true); t.ff2 = get_lin(m, q + "ff2", C, 4 * C, 1, true);
+            st.tf.push_back(t);
+        }
+        m->stages.push_back(st);
+    }
+    m->down_conv = get_lin(m, "est.down_conv", C, C, 3, true); m->up_conv = get_lin(m, "est.up_conv", C, C, 3, true);
+    m->final_conv = get_lin(m, "est.final.conv", C, C, 3, true); m->final_ln = get_ln(m, "est.final.ln", C);
+    m->final_proj = get_lin(m, "est.final_proj", c.mel, C, 1, true);
+    m->finalized = true;
+}
+
+// ---- generic conv/linear on channel-last activations -----------------------------------------------------------------
+// rows: M per batch, `a_rows` valid input rows per batch (zero padding outside), tap j reads row (m + j*dil - pad_left)
+static void conv_cl(const Lin& l, const float* A, int a_rows, int M, int batch, int pad_left, int dil, float* C, int act, float act_p,
+                    const float* res, hipStream_t s, int pro = ACT_NONE, float pro_p = 0.f, const float* row_scale = nullptr, int ldc = -1) {
+    GemmConvArgs a{};
+    a.A = A; a.a_batch = (long long)a_rows * l.K; a.a_len = (long long)a_rows * l.K; a.lda = l.K; a.a_off0 = -pad_left * l.K;
+    a.tap_step = dil * l.K; a.taps = l.taps; a.K = l.K; a.pro = pro; a.pro_p = pro_p; a.pro_alpha = nullptr;
+    a.W = l.w; a.Kp = l.Kp; a.ldw = 0; a.w_batch = 0; a.bias = l.b;
+    if (ldc < 0) ldc = l.N;
+    a.C = C; a.c_batch = (long long)M * ldc; a.c_len = (long long)M * ldc; a.ldc = ldc; a.c_off = 0; a.M = M; a.N = l.N;
+    a.act = act; a.act_p = act_p; a.res = res; a.res_batch = (long long)M * ldc; a.out_scale = 1.f;
+    a.row_scale = row_scale; a.row_scale_batch = M; a.accumulate = 0;
+    gemm_conv(a, l.bf16, batch, s);
+}
+static void lin_cl(const Lin& l, const float* A, long long rows, float* C, int act, const float* res, hipStream_t s, int pro = ACT_NONE) {
+    conv_cl(l, A, (int)rows, (int)rows, 1, 0, 1, C, act, 0.f, res, s, pro);
+}
+static void ln_rows(const LN& n, const float* x, float* y, long long rows, int C, float eps, hipStream_t s, int act = ACT_NONE, float scale = 1.f,
+                    const float* col_add = nullptr, long long rows_per_batch = 0) {
+    norm_rows(NormArgs{x, y, rows, C, n.g, n.b, eps, 0, act, scale, nullptr, col_add, rows_per_batch > 0 ? rows_per_batch : rows}, s);
+}
+
+// ---- encoder ---------------------------------------------------------------------------------------------------------
+static void enc_reserve(cv_flow* m, int T) {      // T = token count before upsampling
+    if (T <= m->enc_cap) return;
+    const auto& c = m->cfg; const size_t d = c.dim, T2 = 2 * (size_t)T, f = 4;
+    m->e_x.ensure(T2 * d * f); m->e_xe.ensure((T2 + 8) * d * f); m->e_n.ensure(T2 * d * f); m->e_qkv.ensure(T2 * 3 * d * f);
+    m->e_qu.ensure(T2 * d * f); m->e_qv.ensure(T2 * d * f); m->e_pe.ensure((2 * T2) * d * f); m->e_p.ensure((2 * T2) * d * f);
+    m->e_bd.ensure((size_t)c.enc_heads * T2 * (2 * T2) * f); m->e_att.ensure(T2 * d * f); m->e_ff.ensure(T2 * c.ffn * f);
+    m->e_x2.ensure(T2 * d * f); m->e_ctx.ensure(8 * d * f);
+    m->enc_cap = T;
+}
+
+static void conformer_layer(cv_flow* m, const ConformerW& w, float* x, int T, const float* pe, int chunk, hipStream_t s) {
+    const auto& c = m->cfg; const int d = c.dim, H = c.enc_heads, P = 2 * T - 1;
+    float* n = m->e_n.as<float>(); float* qkv = m->e_qkv.as<float>(); float* qu = m->e_qu.as<float>(); float* qv = m->e_qv.as<float>();
+    float* pp = m->e_p.as<float>(); float* bd = m->e_bd.as<float>(); float* att = m->e_att.as<float>(); float* ff = m->e_ff.as<float>();
+    ln_rows(w.norm_mha, x, n, T, d, 1e-12f, s);
+    lin_cl(w.qkv, n, T, qkv, ACT_NONE, nullptr, s);
+    lin_cl(w.pos, pe, P, pp, ACT_NONE, nullptr, s);
+    hipLaunchKernelGGL(add_pos_bias_kernel, dim3(nblk((long long)T * d)), dim3(256), 0, s, qkv, 3 * d, w.bias_u, w.bias_v, qu, qv, T, d);
+    {   // matrix_bd[h] = (q + v)[h] @ p[h]^T  -> [H][T][2T-1]   (attention.py:318)
+        GemmConvArgs a{};
+        a.A = qv; a.a_batch = 64; a.a_len = (long long)T * d; a.lda = d; a.a_off0 = 0; a.tap_step = 0; a.taps = 1; a.K = 64;
+        a.pro = ACT_NONE; a.W = pp; a.Kp = 64; a.ldw = d; a.w_batch = 64; a.bias = nullptr;
+        a.C = bd; a.c_batch = (long long)T * P; a.c_len = (long long)T * P; a.ldc = P; a.c_off = 0; a.M = T; a.N = P;
+        a.act = ACT_NONE; a.res = nullptr; a.out_scale = 1.f; a.row_scale = nullptr; a.accumulate = 0;
+        // a_len is a range check on the flat index of batch b (base + b*64): the last head reads up to T*d - 1 from ITS base
+        a.a_len = (long long)(T - 1) * d + 64;
+        gemm_conv(a, false, H, s);
+    }
+    AttnArgs at{};
+    at.q = qu; at.q_batch = 0; at.q_row = d; at.q_head = 64;
+    at.k = qkv + d; at.k_batch = 0; at.k_row = 3 * d; at.k_head = 64;
+    at.v = qkv + 2 * d; at.v_batch = 0; at.v_row = 3 * d; at.v_head = 64;
+    at.o = att; at.o_batch = 0; at.o_row = d; at.o_head = 64;
+    at.B = 1; at.H = H; at.kv_group = 1; at.Tq = T; at.Tk = T; at.scale = 0.125f;
+    at.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; at.chunk = chunk;
+    at.rel_bd = bd; at.bd_batch = 0; at.bd_head = (long long)T * P; at.bd_row = P;
+    attention(at, s);
+    lin_cl(w.out, att, T, x, ACT_NONE, x, s);
+    ln_rows(w.norm_ff, x, n, T, d, 1e-12f, s);
+    lin_cl(w.ff1, n, T, ff, ACT_SILU, nullptr, s);
+    lin_cl(w.ff2, ff, T, x, ACT_NONE, x, s);
+}
+
+// tok_emb [T][d] (already masked), ctx [pre_lookahead][d] or null  ->  h_out [2T][d]
+static void flow_encoder(cv_flow* m, const float* tok_emb, int T, const float* ctx, int streaming, float* h_out, hipStream_t s) {
+    const auto& c = m->cfg; const int d = c.dim, la = c.pre_lookahead;
+    CV_CHECK(T > 0, "flow_encoder: empty input");
+    enc_reserve(m, T);
+    float* x = m->e_x.as<float>(); float* xe = m->e_xe.as<float>(); float* n = m->e_n.as<float>(); float* pe = m->e_pe.as<float>();
+    const float xscale = sqrtf((float)d);
+    // embed: Linear -> LayerNorm(1e-5) -> * sqrt(d)     (subsampling.py:83-113, embedding.py:256-270)
+    lin_cl(m->embed_lin, tok_emb, T, n, ACT_NONE, nullptr, s);
+    ln_rows(m->embed_ln, n, x, T, d, 1e-5f, s, ACT_NONE, xscale);
+    hipLaunchKernelGGL(rel_pos_emb_kernel, dim3(2 * T - 1), dim3(256), 0, s, pe, T, d);
+    // PreLookaheadLayer (upsample_encoder.py:82-103): xe = [x ; ctx or zeros], conv1 k=la+1 looks right, leaky_relu(0.01),
+    // causal conv2 k3, + residual
+    CV_HIP(hipMemcpyAsync(xe, x, (size_t)T * d * 4, hipMemcpyDeviceToDevice, s));
+    if (ctx) {
+        lin_cl(m->embed_lin, ctx, la, n, ACT_NONE, nullptr, s);
+        ln_rows(m->embed_ln, n, xe + (size_t)T * d, la, d, 1e-5f, s, ACT_NONE, xscale);
+    } else {
+        CV_HIP(hipMemsetAsync(xe + (size_t)T * d, 0, (size_t)la * d * 4, s));
+    }
+    float* y1 = m->e_x2.as<float>();
+    conv_cl(m->pre1, xe, T + la, T, 1, 0, 1, y1, ACT_LEAKY, 0.01f, nullptr, s);
+    conv_cl(m->pre2, y1, T, T, 1, 2, 1, x, ACT_NONE, 0.f, x, s);          // in-place residual: each element read once, then written
+    const int chunk1 = streaming ? c.chunk : 0;
+    for (auto& w : m->enc) conformer_layer(m, w, x, T, pe, chunk1, s);
+    // Upsample1D: nearest x2 -> left pad 4 -> Conv1d k5  (upsample_encoder.py:59-63)
+    const int T2 = 2 * T;
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(nblk((long long)T2 * d)), dim3(256), 0, s, x, xe, T, d);
+    conv_cl(m->upconv, xe, T2, T2, 1, 4, 1, n, ACT_NONE, 0.f, nullptr, s);
+    lin_cl(m->up_embed_lin, n, T2, xe, ACT_NONE, nullptr, s);
+    ln_rows(m->up_embed_ln, xe, x, T2, d, 1e-5f, s, ACT_NONE, xscale);
+    hipLaunchKernelGGL(rel_pos_emb_kernel, dim3(2 * T2 - 1), dim3(256), 0, s, pe, T2, d);
+    const int chunk2 = streaming ? 2 * c.chunk : 0;
+    for (auto& w : m->enc_up) conformer_layer(m, w, x, T2, pe, chunk2, s);
+    ln_rows(m->after_norm, x, h_out, T2, d, 1e-5f, s);
+}
+
+// ---- estimator ---------------------------------------------------------------------------------------------------------
+static void est_reserve(cv_flow* m, int T) {
+    if (T <= m->est_cap) return;
+    const auto& c = m->cfg; const size_t R = 2 * (size_t)T, C = c.est_ch, f = 4;
+    m->s_in.ensure(R * 4 * c.mel * f); m->s_a.ensure(R * C * f); m->s_b.ensure(R * C * f); m->s_c.ensure(R * C * f); m->s_n.ensure(R * C * f);
+    m->s_qkv.ensure(R * 3 * c.est_heads * 64 * f); m->s_att.ensure(R * c.est_heads * 64 * f); m->s_ff.ensure(R * 4 * C * f);
+    m->s_skip.ensure(R * C * f); m->s_cat.ensure(R * 2 * C * f); m->s_out.ensure(R * c.mel * f);
+    m->est_cap = T;
+}
+static void time_reserve(cv_flow* m, int n) {
+    if (n <= m->t_cap) return;
+    const auto& c = m->cfg; const size_t tdim = 4 * c.est_ch;
+    m->t_val.ensure((size_t)n * 4); m->t_sin.ensure((size_t)n * 4 * c.mel * 4); m->t_h.ensure((size_t)n * tdim * 4); m->t_emb.ensure((size_t)n * tdim * 4);
+    m->t_mlp.ensure((size_t)(c.est_mid + 2) * n * c.est_ch * 4);
+    m->t_cap = n;
+}
+// t_val[n] (device) -> per-resnet time projections t_mlp[stage][n][C]  (SinusoidalPosEmb -> TimestepEmbedding -> Mish -> Linear)
+static void time_embed(cv_flow* m, int n, hipStream_t s) {
+    const auto& c = m->cfg; const int tdim = 4 * c.est_ch, cin = 4 * c.mel;
+    hipLaunchKernelGGL(time_sinusoid_kernel, dim3(n), dim3(256), 0, s, m->t_val.as<float>(), m->t_sin.as<float>(), n, cin);
+    lin_cl(m->time1, m->t_sin.as<float>(), n, m->t_h.as<float>(), ACT_SILU, nullptr, s);
+    lin_cl(m->time2, m->t_h.as<float>(), n, m->t_emb.as<float>(), ACT_NONE, nullptr, s);
+    for (size_t i = 0; i < m->stages.size(); ++i)
+        lin_cl(m->stages[i].res.mlp, m->t_emb.as<float>(), n, m->t_mlp.as<float>() + i * (size_t)n * c.est_ch, ACT_NONE, nullptr, s, ACT_MISH);
+    (void)tdim;
+}
+
+// s_in: packed [2][T][4*mel]; t_row: which row of the time tables; t_shared: both CFG rows use the same row;
+// result in s_out [2][T][mel] (not masked).  Buffer discipline: a stage never writes the buffer it reads its input from
+// (res_conv re-reads the stage input after block1/block2), outputs ping-pong between s_a and s_c, s_b is scratch.
+static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bool t_shared, int streaming, hipStream_t s) {
+    const auto& c = m->cfg; const int C = c.est_ch, H = c.est_heads, inner = H * 64; const long long R = 2LL * T;
+    float* pp[2] = {m->s_a.as<float>(), m->s_c.as<float>()};
+    float* xb = m->s_b.as<float>(); float* n = m->s_n.as<float>(); float* qkv = m->s_qkv.as<float>();
+    float* att = m->s_att.as<float>(); float* ff = m->s_ff.as<float>(); float* skip = m->s_skip.as<float>(); float* cat = m->s_cat.as<float>();
+    const int chunk = streaming ? 2 * c.chunk : 0;
+    const float* cur = m->s_in.as<float>();
+    int flip = 0;
+    const int nst = (int)m->stages.size();
+    for (int si = 0; si < nst; ++si) {
+        const StageW& st = m->stages[si];
+        const float* tm = m->t_mlp.as<float>() + ((size_t)si * t_rows_total + t_row) * C;
+        const long long rpb = t_shared ? R : T;          // rows per time-embedding row
+        float* x = pp[flip];                             // stage output (cur never aliases it)
+        // CausalResnetBlock1D (decoder.py:65-85 + matcha ResnetBlock1D): block1 -> + mlp(t) -> block2 -> + res_conv(x)
+        conv_cl(st.res.conv1, cur, T, T, 2, 2, 1, x, ACT_NONE, 0.f, nullptr, s);
+        ln_rows(st.res.ln1, x, xb, R, C, 1e-5f, s, ACT_MISH, 1.f, tm, rpb);
+        conv_cl(st.res.conv2, xb, T, T, 2, 2, 1, x, ACT_NONE, 0.f, nullptr, s);
+        ln_rows(st.res.ln2, x, xb, R, C, 1e-5f, s, ACT_MISH);
+        conv_cl(st.res.res, cur, T, T, 2, 0, 1, x, ACT_NONE, 0.f, xb, s);           // x = res_conv(input) + h
+        for (const TBlockW& t : st.tf) {      // matcha BasicTransformerBlock (self-attention + exact-erf GELU feed-forward)
+            ln_rows(t.norm1, x, n, R, C, 1e-5f, s);
+            lin_cl(t.qkv, n, R, qkv, ACT_NONE, nullptr, s);
+            AttnArgs at{};
+            at.q = qkv; at.q_batch = (long long)T * 3 * inner; at.q_row = 3 * inner; at.q_head = 64;
+            at.k = qkv + inner; at.k_batch = at.q_batch; at.k_row = 3 * inner; at.k_head = 64;
+            at.v = qkv + 2 * inner; at.v_batch = at.q_batch; at.v_row = 3 * inner; at.v_head = 64;
+            at.o = att; at.o_batch = (long long)T * inner; at.o_row = inner; at.o_head = 64;
+            at.B = 2; at.H = H; at.kv_group = 1; at.Tq = T; at.Tk = T; at.scale = 0.125f;
+            at.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; at.chunk = chunk; at.rel_bd = nullptr;
+            attention(at, s);
+            lin_cl(t.out, att, R, x, ACT_NONE, x, s);
+            ln_rows(t.norm3, x, n, R, C, 1e-5f, s);
+            lin_cl(t.ff1, n, R, ff, ACT_GELU_ERF, nullptr, s);
+            lin_cl(t.ff2, ff, R, x, ACT_NONE, x, s);
+        }
+        flip ^= 1;
+        if (si == 0) {                         // keep the skip, then the stride-1 "downsample" CausalConv1d (decoder.py:452-453)
+            CV_HIP(hipMemcpyAsync(skip, x, (size_t)R * C * 4, hipMemcpyDeviceToDevice, s));
+            conv_cl(m->down_conv, x, T, T, 2, 2, 1, pp[flip], ACT_NONE, 0.f, nullptr, s);
+            cur = pp[flip]; flip ^= 1;
+        } else if (si == nst - 2) {            // last mid block: concat with the skip for the up block (decoder.py:476)
+            hipLaunchKernelGGL(concat_cols_kernel, dim3(nblk(R * 2 * C)), dim3(256), 0, s, x, C, skip, C, cat, R);
+            cur = cat;
+        } else if (si == nst - 1) {            // up block's trailing CausalConv1d (decoder.py:490)
+            conv_cl(m->up_conv, x, T, T, 2, 2, 1, pp[flip], ACT_NONE, 0.f, nullptr, s);
+            cur = pp[flip]; flip ^= 1;
+        } else {
+            cur = x;
+        }
+    }
+    // final_block (CausalBlock1D) + final_proj (decoder.py:492-494)
+    float* y = pp[flip];
+    conv_cl(m->final_conv, cur, T, T, 2, 2, 1, y, ACT_NONE, 0.f, nullptr, s);
+    ln_rows(m->final_ln, y, xb, R, C, 1e-5f, s, ACT_MISH);
+    conv_cl(m->final_proj, xb, T, T, 2, 0, 1, m->s_out.as<float>(), ACT_NONE, 0.f, nullptr, s);
+}
+
+// ---- solve_euler + inference -------------------------------------------------------------------------------------------
+static void solve_euler(cv_flow* m, float* x /*[T][mel] in/out*/, const float* mu, const float* spk, const float* cond, int T,
+                        int n_steps, int streaming, hipStream_t s) {
+    const auto& c = m->cfg;
+    est_reserve(m, T); time_reserve(m, n_steps);
+    // cosine schedule and the t / dt recurrences of solve_euler, in fp32 like torch (flow_matching.py:89-122, 223-226)
+    std::vector<float> span(n_steps + 1), tv(n_steps), dts(n_steps);
+    for (int i = 0; i <= n_steps; ++i) {
+        const float lin = n_steps == 0 ? 0.f : (float)i / (float)n_steps;      // torch.linspace(0, 1, n+1)
+        span[i] = 1.f - cosf(lin * 0.5f * 3.14159265358979323846f);
+    }
+    float t = span[0], dt = span[1] - span[0];
+    for (int st = 1; st <= n_steps; ++st) {
+        tv[st - 1] = t; dts[st - 1] = dt;
+        t = t + dt;
+        if (st < n_steps) dt = span[st + 1] - t;
+    }
+    CV_HIP(hipMemcpyAsync(m->t_val.p, tv.data(), (size_t)n_steps * 4, hipMemcpyHostToDevice, s));
+    CV_HIP(hipStreamSynchronize(s));        // tv is a stack vector
+    time_embed(m, n_steps, s);
+    const long long n = (long long)T * c.mel;
+    for (int st = 0; st < n_steps; ++st) {
+        hipLaunchKernelGGL(pack_est_input_kernel, dim3(nblk(2 * n * 4)), dim3(256), 0, s, x, mu, spk, cond, m->s_in.as<float>(), T, c.mel, 1);
+        estimator_forward(m, T, st, n_steps, true, streaming, s);
+        hipLaunchKernelGGL(cfg_euler_kernel, dim3(nblk(n)), dim3(256), 0, s, x, m->s_out.as<float>(), n, dts[st], c.cfg_rate);
+    }
+}
+
+extern "C" {
+
+int cv_flow_create(cv_flow** out, const cv_flow_config* cfg) {
+    return guarded([&] { CV_CHECK(out && cfg, "cv_flow_create: null argument"); auto* m = new cv_flow(); m->cfg = *cfg; *out = m; });
+}
+int cv_flow_set_tensor(cv_flow* m, const char* name, const void* dev_ptr, int32_t dtype, int64_t numel) {
+    return guarded([&] { CV_CHECK(m, "null handle"); m->tm.set(name, dev_ptr, dtype, numel); });
+}
+int cv_flow_finalize(cv_flow* m) { return guarded([&] { CV_CHECK(m, "null handle"); flow_finalize(m); }); }
+void cv_flow_destroy(cv_flow* m) { delete m; }
+
+int cv_flow_encoder(cv_flow* m, const float* tok_emb, int32_t n_tok, const float* context, int32_t streaming, float* h_out, void* stream) {
+    return guarded([&] { CV_CHECK(m && m->finalized && tok_emb && h_out, "cv_flow_encoder: bad arguments");
+                         flow_encoder(m, tok_emb, n_tok, context, streaming, h_out, as_stream(stream)); });
+}
+
+int cv_flow_estimator(cv_flow* m, const float* x, const float* mask, const float* mu, const float* t, const float* spks, const float* cond,
+                      int32_t T, int32_t streaming, float* out, void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && m->finalized && x && mu && t && spks && cond && out && T > 0, "cv_flow_estimator: bad arguments");
+        hipStream_t s = as_stream(stream);
+        const auto& c = m->cfg;
+        est_reserve(m, T); time_reserve(m, 2);
+        CV_HIP(hipMemcpyAsync(m->t_val.p, t, 8, hipMemcpyDeviceToDevice, s));
+        time_embed(m, 2, s);
+        hipLaunchKernelGGL(pack_est_input_kernel, dim3(nblk(2LL * T * 4 * c.mel)), dim3(256), 0, s, x, mu, spks, cond, m->s_in.as<float>(), T, c.mel, 0);
+        estimator_forward(m, T, 0, 2, false, streaming, s);
+        // `mask` must be all ones for the in-kernel (index-computed) attention masks to be exact; it is applied to the output
+        hipLaunchKernelGGL(to_channel_first_kernel, dim3(nblk(2LL * T * c.mel)), dim3(256), 0, s, m->s_out.as<float>(), out, 2, T, c.mel, 0, mask);
+    });
+}
+
+int cv_flow_inference(cv_flow* m, const int32_t* token_ids, int32_t n_tok, const float* prompt_feat, int32_t mel_len1, const float* embedding,
+                      const float* noise_cl, int32_t streaming, int32_t finalize, int32_t n_timesteps, float* mel_out, int32_t* mel_len2_out, void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && m->finalized && token_ids && embedding && noise_cl && mel_out && mel_len2_out, "cv_flow_inference: bad arguments");
+        const auto& c = m->cfg; const int d = c.dim;
+        hipStream_t s = as_stream(stream);
+        const int n_enc = finalize ? n_tok : n_tok - c.pre_lookahead;
+        CV_CHECK(n_enc > 0 && n_timesteps > 0, "cv_flow_inference: too few tokens");
+        const int T = 2 * n_enc, mel_len2 = T - mel_len1;
+        CV_CHECK(mel_len2 > 0 && mel_len1 >= 0, "cv_flow_inference: prompt longer than the sequence");
+        if (n_tok > m->inf_cap) {
+            m->f_tok.ensure((size_t)n_tok * d * 4); m->f_h.ensure((size_t)2 * n_tok * d * 4); m->f_mu.ensure((size_t)2 * n_tok * c.mel * 4);
+            m->f_cond.ensure((size_t)2 * n_tok * c.mel * 4); m->f_x.ensure((size_t)2 * n_tok * c.mel * 4);
+            m->f_spk.ensure((size_t)c.mel * 4); m->f_spkn.ensure((size_t)c.spk_dim * 4);
+            m->inf_cap = n_tok;
+        }
+        // x-vector: F.normalize -> Linear(192, 80)  (flow.py:248-249)
+        hipLaunchKernelGGL(l2_normalize_kernel, dim3(1), dim3(256), 0, s, embedding, m->f_spkn.as<float>(), c.spk_dim);
+        lin_cl(m->spk_affine, m->f_spkn.as<float>(), 1, m->f_spk.as<float>(), ACT_NONE, nullptr, s);
+        // token embedding (mask is all ones for batch 1, flow.py:252-254); gather_rows_kernel lives in llm_kernels.h -> reuse via C ABI
+        CV_CHECK(cv_gather_rows(m->input_embedding, m->wbf16 ? CV_BF16 : CV_F32, c.vocab, d, token_ids, n_tok, m->f_tok.as<float>(), 1.f, stream) == 0, cv_last_error());
+        const float* ctx = finalize ? nullptr : m->f_tok.as<float>() + (size_t)n_enc * d;
+        flow_encoder(m, m->f_tok.as<float>(), n_enc, ctx, streaming, m->f_h.as<float>(), s);
+        lin_cl(m->enc_proj, m->f_h.as<float>(), T, m->f_mu.as<float>(), ACT_NONE, nullptr, s);
+        hipLaunchKernelGGL(copy_rows_zero_tail_kernel, dim3(nblk((long long)T * c.mel)), dim3(256), 0, s, prompt_feat, m->f_cond.as<float>(),
+                           (long long)mel_len1 * c.mel, (long long)T * c.mel);
+        CV_HIP(hipMemcpyAsync(m->f_x.p, noise_cl, (size_t)T * c.mel * 4, hipMemcpyDeviceToDevice, s));
+        solve_euler(m, m->f_x.as<float>(), m->f_mu.as<float>(), m->f_spk.as<float>(), m->f_cond.as<float>(), T, n_timesteps, streaming, s);
+        hipLaunchKernelGGL(to_channel_first_kernel, dim3(nblk((long long)mel_len2 * c.mel)), dim3(256), 0, s, m->f_x.as<float>(), mel_out, 1, T, c.mel, mel_len1, (const float*)nullptr);
+        *mel_len2_out = mel_len2;
+    });
+}
+
+}  // extern "C"

@@ -22,7 +22,8 @@ struct GemmConvArgs {
     int a_vec;                      // 1: every float4 group is 16B aligned and fully in or fully out of range
     int pro; float pro_p; const float* pro_alpha;   // prologue activation on A (ACT_NONE / ACT_LEAKY / ACT_SNAKE)
     // W operand
-    const void* W; int Kp;          // row stride = taps*Kp
+    const void* W; int Kp;          // row stride = ldw (0 -> taps*Kp)
+    long long ldw; long long w_batch;   // W may itself be an activation (rel-pos scores): explicit row pitch + per-batch offset
     const float* bias;              // [N] or null
     // output
     float* C; long long c_batch; long long c_len; int ldc; long long c_off; int c_vec;
@@ -48,7 +49,8 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
     const float* Ab = p.A + (long long)b * p.a_batch;
     const int kchunks = p.Kp / BK;
     const int nit = p.taps * kchunks;
-    const long long ldw = (long long)p.taps * p.Kp;
+    const long long ldw = p.ldw ? p.ldw : (long long)p.taps * p.Kp;
+    const long long wb = (long long)b * p.w_batch;
 
     v4f acc[TM][TN];
 #pragma unroll
@@ -86,6 +88,9 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
                     // kk..kk+3 < Kp and pro_alpha is padded to Kp by the host
                     const float4 al = *reinterpret_cast<const float4*>(p.pro_alpha + kk);
                     x.x = snake_f(x.x, al.x); x.y = snake_f(x.y, al.y); x.z = snake_f(x.z, al.z); x.w = snake_f(x.w, al.w);
+                } else if (p.pro != ACT_NONE) {                 // any other activation with act(0) == 0 (Mish, SiLU, ...)
+                    x.x = apply_act(p.pro, x.x, p.pro_p); x.y = apply_act(p.pro, x.y, p.pro_p);
+                    x.z = apply_act(p.pro, x.z, p.pro_p); x.w = apply_act(p.pro, x.w, p.pro_p);
                 }
             }
             ra[i] = x;
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
         for (int i = 0; i < WV; ++i) {
             const int v = tid + i * 256, row = v >> 3, kk = k0 + (v & 7) * 4;
             int n = n0 + row; n = n < p.N ? n : p.N - 1;
-            const long long idx = (long long)n * ldw + (long long)tap * p.Kp + kk;
+            const long long idx = wb + (long long)n * ldw + (long long)tap * p.Kp + kk;
             if (WBF16) {
                 const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.W) + idx);
                 rw[i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),

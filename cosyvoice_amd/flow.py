@@ -1,0 +1,129 @@
+"""Host mirror of cosyvoice.flow.flow.CausalMaskedDiffWithXvec for inference (boundaries B3/B4/B5).
+
+`inference(token, token_len, prompt_token, prompt_token_len, prompt_feat, prompt_feat_len, embedding, streaming, finalize)`
+returns `(mel[1,80,2*n_new] fp32 on the device, None)` like the reference (flow/flow.py:235-281).  `self.decoder.estimator`
+and `self.encoder` are callables with the reference signatures (the objects the reference swaps for TensorRT /
+TorchScript, cli/model.py:83-92,277-279) and `self.decoder.solve_euler`-style stepping happens on the device.
+"""
+import ctypes as C
+
+import torch
+
+from . import weights as Wt
+from ._lib import get_lib, stream_ptr
+from .llm import register_tensors
+
+
+class FlowConfigC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("vocab", "dim", "enc_heads", "ffn", "enc_blocks", "up_blocks", "spk_dim", "mel", "est_ch",
+                                         "est_heads", "est_blocks", "est_mid", "pre_lookahead", "chunk")] + [("cfg_rate", C.c_float)]
+
+
+def cfm_rand_noise():
+    """CausalConditionalCFM.__init__: set_all_random_seed(0); torch.randn([1, 80, 50*300])  (flow_matching.py:199-200).
+    A local generator with seed 0 yields the same stream without the reference's global-RNG side effect."""
+    g = torch.Generator().manual_seed(0)
+    return torch.randn([1, 80, 50 * 300], generator=g)
+
+
+class _Estimator:
+    """flow.decoder.estimator: (x[2,80,T], mask[2,1,T], mu[2,80,T], t[2], spks[2,80], cond[2,80,T], streaming) -> [2,80,T]."""
+
+    def __init__(self, flow):
+        self.flow = flow
+
+    def __call__(self, x, mask, mu, t, spks, cond, streaming=False):
+        f = self.flow
+        if not bool((mask == 1).all()):
+            raise NotImplementedError("the MI355X estimator computes attention masks from indices and needs an all-ones mask "
+                                      "(batch-1 inference, flow/flow.py:270)")
+        T = x.shape[2]
+        args = [f.lib.hook(a.to(f.device, torch.float32).contiguous()) for a in (x, mask, mu, t, spks, cond)]
+        out = f.lib.hook(torch.empty(2, f.cfg.mel, T, dtype=torch.float32, device=f.device))
+        f.lib.cv_flow_estimator(f._h, *[C.c_void_p(a.data_ptr()) for a in args], C.c_int32(T), C.c_int32(int(streaming)),
+                                C.c_void_p(out.data_ptr()), stream_ptr(f.lib))
+        return out
+
+
+class _Encoder:
+    """flow.encoder: (token_emb[1,n,dim], token_len, context=[1,3,dim] | empty, streaming) -> (h[1,2n,dim], mask[1,1,2n])."""
+
+    def __init__(self, flow):
+        self.flow = flow
+
+    def output_size(self):
+        return self.flow.cfg.dim
+
+    def __call__(self, xs, xs_lens, context=None, streaming=False):
+        f = self.flow
+        assert xs.shape[0] == 1
+        n = xs.shape[1]
+        xs = f.lib.hook(xs.to(f.device, torch.float32).contiguous())
+        ctx = None
+        if context is not None and context.numel() != 0:
+            assert context.shape[1] == f.cfg.pre_lookahead
+            ctx = f.lib.hook(context.to(f.device, torch.float32).contiguous())
+        h = f.lib.hook(torch.empty(1, 2 * n, f.cfg.dim, dtype=torch.float32, device=f.device))
+        f.lib.cv_flow_encoder(f._h, C.c_void_p(xs.data_ptr()), C.c_int32(n), C.c_void_p(ctx.data_ptr()) if ctx is not None else None,
+                              C.c_int32(int(streaming)), C.c_void_p(h.data_ptr()), stream_ptr(f.lib))
+        return h, torch.ones(1, 1, 2 * n, dtype=torch.bool, device=f.device)
+
+
+class _CFM:
+    def __init__(self, flow):
+        self.estimator = _Estimator(flow)
+        self.rand_noise = cfm_rand_noise()
+        self.inference_cfg_rate = flow.cfg.cfg_rate
+        self.t_scheduler = "cosine"
+
+
+class CausalMaskedDiffWithXvec:
+    def __init__(self, state_dict, cfg, lib=None, weight_dtype=torch.bfloat16, n_timesteps=None):
+        self.lib = lib or get_lib()
+        self.cfg = cfg
+        self.device = torch.device(self.lib.device)
+        self.input_frame_rate = 25
+        self.token_mel_ratio = 2
+        self.pre_lookahead_len = cfg.pre_lookahead
+        self.output_size = cfg.mel
+        self.vocab_size = cfg.vocab
+        self.n_timesteps = n_timesteps or cfg.n_timesteps
+        self._tensors = {k: self.lib.hook(v) for k, v in Wt.pack_flow(state_dict, cfg, self.device, weight_dtype).items()}
+        c = FlowConfigC(cfg.vocab, cfg.dim, cfg.enc_heads, cfg.ffn, cfg.enc_blocks, cfg.up_blocks, cfg.spk_dim, cfg.mel, cfg.est_ch,
+                        cfg.est_heads, cfg.est_blocks, cfg.est_mid, cfg.pre_lookahead, cfg.chunk, cfg.cfg_rate)
+        self._h = C.c_void_p()
+        self.lib.cv_flow_create(C.byref(self._h), C.byref(c))
+        register_tensors(self.lib, "cv_flow_set_tensor", self._h, self._tensors)
+        self.lib.cv_flow_finalize(self._h)
+        self.decoder = _CFM(self)
+        self.encoder = _Encoder(self)
+        # channel-last copy of the fixed CFM noise, made once (not on the hot path)
+        self._noise_cl = self.lib.hook(self.decoder.rand_noise[0].t().contiguous().to(self.device))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.raw("cv_flow_destroy", None)(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @torch.inference_mode()
+    def inference(self, token, token_len, prompt_token, prompt_token_len, prompt_feat, prompt_feat_len, embedding, streaming, finalize):
+        assert token.shape[0] == 1
+        ids = self.lib.hook(torch.cat([prompt_token.reshape(-1), token.reshape(-1)]).to(self.device, torch.int32).clamp(min=0).contiguous())
+        n_tok = ids.numel()
+        pf = self.lib.hook(prompt_feat.to(self.device, torch.float32).contiguous())
+        mel_len1 = prompt_feat.shape[1]
+        emb = self.lib.hook(embedding.to(self.device, torch.float32).reshape(-1).contiguous())
+        n_enc = n_tok if finalize else n_tok - self.pre_lookahead_len
+        mel_len2 = 2 * n_enc - mel_len1
+        if mel_len2 <= 0:
+            raise ValueError("no new frames to generate")
+        out = self.lib.hook(torch.empty(1, self.cfg.mel, mel_len2, dtype=torch.float32, device=self.device))
+        got = C.c_int32(0)
+        self.lib.cv_flow_inference(self._h, C.c_void_p(ids.data_ptr()), C.c_int32(n_tok), C.c_void_p(pf.data_ptr()) if mel_len1 else C.c_void_p(out.data_ptr()),
+                                   C.c_int32(mel_len1), C.c_void_p(emb.data_ptr()), C.c_void_p(self._noise_cl.data_ptr()), C.c_int32(int(streaming)),
+                                   C.c_int32(int(finalize)), C.c_int32(self.n_timesteps), C.c_void_p(out.data_ptr()), C.byref(got), stream_ptr(self.lib))
+        assert got.value == mel_len2
+        return out, None

@@ -27,7 +27,7 @@ def pack_weight(w, dtype=torch.bfloat16):
 def gemm_conv(lib, A, Wp, Kp, *, M, N, K, taps=1, lda=None, a_off0=0, tap_step=0, a_len=None, a_batch=0,
               bias=None, out=None, ldc=None, c_off=0, c_len=None, c_batch=0, batch=1,
               pro="none", pro_p=0.0, pro_alpha=None, act="none", act_p=0.0, res=None, res_batch=0,
-              out_scale=1.0, row_scale=None, row_scale_batch=0, accumulate=False):
+              out_scale=1.0, row_scale=None, row_scale_batch=0, accumulate=False, ldw=0, w_batch=0):
     lda = K if lda is None else lda
     ldc = N if ldc is None else ldc
     if a_len is None:
@@ -40,7 +40,7 @@ def gemm_conv(lib, A, Wp, Kp, *, M, N, K, taps=1, lda=None, a_off0=0, tap_step=0
     g.A = A.data_ptr(); g.a_batch = a_batch; g.a_len = a_len; g.lda = lda; g.a_off0 = a_off0
     g.tap_step = tap_step; g.taps = taps; g.K = K
     g.pro = ACT[pro]; g.pro_p = pro_p; g.pro_alpha = pro_alpha.data_ptr() if pro_alpha is not None else None
-    g.W = Wp.data_ptr(); g.w_dtype = CV_BF16 if Wp.dtype == torch.bfloat16 else CV_F32; g.Kp = Kp
+    g.W = Wp.data_ptr(); g.w_dtype = CV_BF16 if Wp.dtype == torch.bfloat16 else CV_F32; g.Kp = Kp; g.ldw = ldw; g.w_batch = w_batch
     g.bias = bias.data_ptr() if bias is not None else None
     g.C = out.data_ptr(); g.c_batch = c_batch; g.c_len = c_len; g.ldc = ldc; g.c_off = c_off
     g.M = M; g.N = N; g.batch = batch

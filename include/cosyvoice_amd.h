@@ -43,7 +43,7 @@ int cv_is_emulated(void);
 typedef struct cv_gemm_conv_args {
     const float* A; int64_t a_batch; int64_t a_len; int32_t lda; int32_t a_off0; int32_t tap_step; int32_t taps; int32_t K;
     int32_t pro; float pro_p; const float* pro_alpha;
-    const void* W; int32_t w_dtype; int32_t Kp;
+    const void* W; int32_t w_dtype; int32_t Kp; int64_t ldw; int64_t w_batch;
     const float* bias;
     float* C; int64_t c_batch; int64_t c_len; int32_t ldc; int64_t c_off;
     int32_t M; int32_t N; int32_t batch;
@@ -119,6 +119,33 @@ int cv_llm_last_logits(cv_llm* m, float* host_out, void* stream);
 int cv_llm_last_hidden(cv_llm* m, float* host_out, void* stream);
 /* out[r][:] = table[ids[r]][:] * scale  (nn.Embedding lookups that build lm_input / flow token embeddings) */
 int cv_gather_rows(const void* table, int32_t dtype, int64_t table_rows, int32_t dim, const int32_t* ids_dev, int32_t n, float* out, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Stages B3/B4/B5 — token -> mel flow-matching decoder.  Weight names: cosyvoice_amd/weights.py:pack_flow.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct cv_flow_config {
+    int32_t vocab, dim, enc_heads, ffn, enc_blocks, up_blocks, spk_dim, mel, est_ch, est_heads, est_blocks, est_mid,
+            pre_lookahead, chunk /* static_chunk_size in tokens; the estimator uses 2*chunk frames */;
+    float cfg_rate;
+} cv_flow_config;
+int cv_flow_create(cv_flow** out, const cv_flow_config* cfg);
+int cv_flow_set_tensor(cv_flow* m, const char* name, const void* dev_ptr, int32_t dtype, int64_t numel);
+int cv_flow_finalize(cv_flow* m);
+void cv_flow_destroy(cv_flow* m);
+/* B4: flow.encoder(token_emb[1,n,dim], token_len, context=[1,3,dim] or empty, streaming) -> h[1,2n,dim]
+ * (cosyvoice/flow/flow.py:258-261, transformer/upsample_encoder.py:244-307).  tok_emb / context / h_out: dev fp32, row-major. */
+int cv_flow_encoder(cv_flow* m, const float* tok_emb, int32_t n_tok, const float* context, int32_t streaming, float* h_out, void* stream);
+/* B3: flow.decoder.estimator(x[2,80,T], mask[2,1,T], mu[2,80,T], t[2], spks[2,80], cond[2,80,T], streaming) -> [2,80,T]
+ * (flow/flow_matching.py:126-128 nn.Module branch, flow/decoder.py:405-494); all dev fp32 contiguous, reference layouts.
+ * mask must be all ones (batch-1 inference, flow.py:270); it is applied to the output like the reference's `output * mask`. */
+int cv_flow_estimator(cv_flow* m, const float* x, const float* mask, const float* mu, const float* t, const float* spks, const float* cond,
+                      int32_t T, int32_t streaming, float* out, void* stream);
+/* B5: flow.inference(token ++ prompt_token, prompt_feat, embedding, streaming, finalize) -> mel[1,80,mel_len2]
+ * (flow/flow.py:235-281 + flow_matching.py:71-124,203-227).  token_ids: dev int32 [n_tok] = prompt tokens then new tokens;
+ * prompt_feat: dev [mel_len1,80]; embedding: dev [spk_dim]; noise_cl: dev [>=T,80] = CausalConditionalCFM.rand_noise
+ * transposed to channel-last; mel_out: dev [80, T - mel_len1] (channel-first like the reference). */
+int cv_flow_inference(cv_flow* m, const int32_t* token_ids, int32_t n_tok, const float* prompt_feat, int32_t mel_len1, const float* embedding,
+                      const float* noise_cl, int32_t streaming, int32_t finalize, int32_t n_timesteps, float* mel_out, int32_t* mel_len2_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,96 @@
+"""Stages B3/B4/B5 parity: HIP flow encoder / estimator / full CFM inference vs the oracle (and the reference goldens)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+from oracle import flow as OF
+from oracle import weights as W
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = W.tiny()[1]
+    return cfg, W.make_flow(cfg)
+
+
+def _inputs(cfg, n_p=7, n_t=13, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    return dict(prompt_token=torch.randint(0, cfg.vocab, (1, n_p), generator=g, dtype=torch.int32),
+                token=torch.randint(0, cfg.vocab, (1, n_t), generator=g, dtype=torch.int32),
+                prompt_feat=torch.randn(1, 2 * n_p, 80, generator=g) * 2 - 5,
+                embedding=torch.randn(1, cfg.spk_dim, generator=g))
+
+
+@pytest.mark.parametrize("streaming,ctx", [(False, False), (True, True)])
+def test_encoder(lib, tiny, streaming, ctx):
+    cfg, sd = tiny
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 31, cfg.dim, generator=g)
+    if ctx:
+        h, mask = flow.encoder(x[:, :-3], torch.tensor([31]), context=x[:, -3:], streaming=streaming)
+        ref = OF.encoder(sd, cfg, x[:, :-3], x[:, -3:], streaming)
+    else:
+        h, mask = flow.encoder(x, torch.tensor([31]), streaming=streaming)
+        ref = OF.encoder(sd, cfg, x, None, streaming)
+    torch.testing.assert_close(h.cpu(), ref, rtol=2e-4, atol=2e-4)
+    assert mask.shape == (1, 1, h.shape[1])
+
+
+@pytest.mark.parametrize("streaming,T", [(False, 41), (True, 70)])
+def test_estimator_boundary(lib, tiny, streaming, T):
+    """B3: same call signature and layouts as flow.decoder.estimator; tolerance = the reference's own rtol 1e-2 / atol 1e-4
+    (cosyvoice/bin/export_onnx.py:109), tightened to 2e-4."""
+    cfg, sd = tiny
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g); cond = torch.randn(2, 80, T, generator=g)
+    spk = torch.randn(2, 80, generator=g); t = torch.tensor([0.3, 0.7]); mask = torch.ones(2, 1, T)
+    out = flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming)
+    ref = OF.estimator(sd, cfg, x, mask, mu, t, spk, cond, streaming)
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("streaming,finalize", [(False, True), (True, False)])
+def test_inference(lib, tiny, streaming, finalize):
+    cfg, sd = tiny
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, n_timesteps=4)
+    u = _inputs(cfg)
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    mel, _ = flow.inference(token=u["token"], token_len=t(13), prompt_token=u["prompt_token"], prompt_token_len=t(7), prompt_feat=u["prompt_feat"],
+                            prompt_feat_len=t(14), embedding=u["embedding"], streaming=streaming, finalize=finalize)
+    ref = OF.inference(sd, cfg, u["token"], u["prompt_token"], u["prompt_feat"], u["embedding"], streaming=streaming, finalize=finalize, n_timesteps=4)
+    assert mel.shape == ref.shape
+    torch.testing.assert_close(mel.cpu(), ref, rtol=1e-3, atol=1e-3)
+
+
+def test_streaming_prefix_invariance(lib, tiny):
+    """The reference's own invariance check (flow/flow.py:417-443 __main__): with chunk-causal masks the mel of a prefix does not
+    change when more tokens arrive (what makes CosyVoice2's re-run-the-flow streaming correct, cli/model.py:292-303)."""
+    cfg, sd = tiny
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, n_timesteps=2)
+    u = _inputs(cfg, n_p=25, n_t=60, seed=9)
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    kw = dict(prompt_token=u["prompt_token"], prompt_token_len=t(25), prompt_feat=u["prompt_feat"], prompt_feat_len=t(50), embedding=u["embedding"], streaming=True)
+    a, _ = flow.inference(token=u["token"][:, :28], token_len=t(28), finalize=False, **kw)          # 25+28-3 = 50 tokens = 2 chunks
+    b, _ = flow.inference(token=u["token"], token_len=t(60), finalize=True, **kw)
+    torch.testing.assert_close(a.cpu(), b.cpu()[:, :, : a.shape[2]], rtol=1e-4, atol=1e-4)
+
+
+def test_matches_reference_golden(lib):
+    """End to end against golden vectors produced by the REAL reference (dim 512, see tests/golden/make_golden.py)."""
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, "flow_small.npz")).items()}
+    cfg = W.ref_small_flow()
+    flow = CausalMaskedDiffWithXvec(W.make_flow(cfg), cfg, lib=lib)
+    mask = torch.ones(2, 1, g["est_x"].shape[-1])
+    out = flow.decoder.estimator(g["est_x"], mask, g["est_mu"], g["est_t"], g["est_spk"], g["est_cond"], streaming=True)
+    torch.testing.assert_close(out.cpu(), g["est_stream"], rtol=1e-2, atol=1e-4)
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    mel, _ = flow.inference(token=g["token"], token_len=t(16), prompt_token=g["prompt_token"], prompt_token_len=t(9), prompt_feat=g["prompt_feat"],
+                            prompt_feat_len=t(18), embedding=g["embedding"], streaming=False, finalize=True)
+    torch.testing.assert_close(mel.cpu(), g["mel_full"], rtol=2e-3, atol=2e-3)
