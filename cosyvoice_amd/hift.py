@@ -1,0 +1,99 @@
+"""Host mirror of cosyvoice.hifigan.generator.HiFTGenerator for inference (boundary B6).
+
+`inference(speech_feat[1,80,m], cache_source[1,1,c]) -> (speech[1,480m], source[1,1,480m])` like the reference
+(hifigan/generator.py:557-569); f0 prediction, the harmonic source, the conv stack and the iSTFT all run behind cv_hift_*.
+"""
+import ctypes as C
+
+import torch
+
+from . import weights as Wt
+from ._lib import get_lib, stream_ptr
+from .llm import register_tensors
+
+
+class HiftConfigC(C.Structure):
+    _fields_ = [("mel", C.c_int32), ("base", C.c_int32), ("harmonics", C.c_int32), ("sr", C.c_int32),
+                ("n_ups", C.c_int32), ("ups", C.c_int32 * 4), ("up_k", C.c_int32 * 4),
+                ("n_res", C.c_int32), ("res_k", C.c_int32 * 4), ("src_k", C.c_int32 * 4),
+                ("n_dil", C.c_int32), ("dil", C.c_int32 * 4),
+                ("n_fft", C.c_int32), ("hop", C.c_int32), ("f0_ch", C.c_int32),
+                ("nsf_alpha", C.c_float), ("nsf_sigma", C.c_float), ("voiced_thr", C.c_float), ("lrelu", C.c_float), ("audio_limit", C.c_float)]
+
+
+def _arr4(v):
+    return (C.c_int32 * 4)(*(list(v) + [0] * (4 - len(v))))
+
+
+class _F0Predictor:
+    def __init__(self, hift):
+        self.hift = hift
+
+    def __call__(self, speech_feat):
+        h = self.hift
+        m = speech_feat.shape[2]
+        x = h.lib.hook(speech_feat.to(h.device, torch.float32).contiguous())
+        out = h.lib.hook(torch.empty(1, m, dtype=torch.float32, device=h.device))
+        h.lib.cv_hift_f0(h._h, C.c_void_p(x.data_ptr()), C.c_int32(m), C.c_void_p(out.data_ptr()), stream_ptr(h.lib))
+        return out
+
+
+class HiFTGenerator:
+    def __init__(self, state_dict, cfg, lib=None, seed=1986):
+        self.lib = lib or get_lib()
+        self.cfg = cfg
+        self.device = torch.device(self.lib.device)
+        self.sampling_rate = cfg.sr
+        self.seed = seed
+        self._calls = 0
+        self.upsample_scale = cfg.hop
+        for u in cfg.ups:
+            self.upsample_scale *= u
+        self._tensors = {k: self.lib.hook(v) for k, v in Wt.pack_hift(state_dict, cfg, self.device).items()}
+        c = HiftConfigC(cfg.mel, cfg.base, cfg.harmonics, cfg.sr, len(cfg.ups), _arr4(cfg.ups), _arr4(cfg.up_k), len(cfg.res_k), _arr4(cfg.res_k),
+                        _arr4(cfg.src_k), len(cfg.res_d), _arr4(cfg.res_d), cfg.n_fft, cfg.hop, cfg.f0_ch, cfg.nsf_alpha, cfg.nsf_sigma,
+                        cfg.voiced_thr, cfg.lrelu, cfg.audio_limit)
+        self._h = C.c_void_p()
+        self.lib.cv_hift_create(C.byref(self._h), C.byref(c))
+        register_tensors(self.lib, "cv_hift_set_tensor", self._h, self._tensors)
+        self.lib.cv_hift_finalize(self._h)
+        self.f0_predictor = _F0Predictor(self)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.raw("cv_hift_destroy", None)(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @torch.inference_mode()
+    def decode(self, x, s):
+        """HiFTGenerator.decode(x[1,80,m], s[1,1,480m]) -> [1,480m]   (generator.py:507-539)."""
+        m = x.shape[2]
+        xx = self.lib.hook(x.to(self.device, torch.float32).contiguous())
+        ss = self.lib.hook(s.to(self.device, torch.float32).contiguous())
+        assert ss.numel() == m * self.upsample_scale
+        out = self.lib.hook(torch.empty(1, m * self.upsample_scale, dtype=torch.float32, device=self.device))
+        self.lib.cv_hift_decode(self._h, C.c_void_p(xx.data_ptr()), C.c_int32(m), C.c_void_p(ss.data_ptr()), C.c_void_p(out.data_ptr()), stream_ptr(self.lib))
+        return out
+
+    @torch.inference_mode()
+    def inference(self, speech_feat, cache_source=None, noise=None):
+        """-> (generated_speech[1,480m], source[1,1,480m]).  `noise` ([480m,9] N(0,1)) is a parity hook; by default the SineGen2
+        noise comes from an in-kernel counter RNG (the reference consumes the global device RNG, generator.py:312)."""
+        m = speech_feat.shape[2]
+        L = m * self.upsample_scale
+        x = self.lib.hook(speech_feat.to(self.device, torch.float32).contiguous())
+        speech = self.lib.hook(torch.empty(1, L, dtype=torch.float32, device=self.device))
+        source = self.lib.hook(torch.empty(1, 1, L, dtype=torch.float32, device=self.device))
+        cs, cl = None, 0
+        if cache_source is not None and cache_source.shape[2] != 0:
+            cs = self.lib.hook(cache_source.to(self.device, torch.float32).contiguous())
+            cl = cs.shape[2]
+        nz = None if noise is None else self.lib.hook(noise.to(self.device, torch.float32).reshape(L, -1).contiguous())
+        self._calls += 1
+        self.lib.cv_hift_inference(self._h, C.c_void_p(x.data_ptr()), C.c_int32(m), C.c_void_p(cs.data_ptr()) if cs is not None else None, C.c_int32(cl),
+                                   C.c_void_p(nz.data_ptr()) if nz is not None else None, C.c_uint64(self.seed + self._calls),
+                                   C.c_void_p(speech.data_ptr()), C.c_void_p(source.data_ptr()), stream_ptr(self.lib))
+        return speech, source

@@ -147,6 +147,30 @@ int cv_flow_estimator(cv_flow* m, const float* x, const float* mask, const float
 int cv_flow_inference(cv_flow* m, const int32_t* token_ids, int32_t n_tok, const float* prompt_feat, int32_t mel_len1, const float* embedding,
                       const float* noise_cl, int32_t streaming, int32_t finalize, int32_t n_timesteps, float* mel_out, int32_t* mel_len2_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Stage B6 — HiFT vocoder.  Weight names: cosyvoice_amd/weights.py:pack_hift (weight-norm folded, fp32).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct cv_hift_config {
+    int32_t mel, base, harmonics, sr;
+    int32_t n_ups, ups[4], up_k[4];
+    int32_t n_res, res_k[4], src_k[4];
+    int32_t n_dil, dil[4];
+    int32_t n_fft, hop, f0_ch;
+    float nsf_alpha, nsf_sigma, voiced_thr, lrelu, audio_limit;
+} cv_hift_config;
+int cv_hift_create(cv_hift** out, const cv_hift_config* cfg);
+int cv_hift_set_tensor(cv_hift* m, const char* name, const void* dev_ptr, int32_t dtype, int64_t numel);
+int cv_hift_finalize(cv_hift* m);
+void cv_hift_destroy(cv_hift* m);
+/* ConvRNNF0Predictor.forward (hifigan/f0_predictor.py:56-59): speech_feat dev [80, frames] -> f0 dev [frames] */
+int cv_hift_f0(cv_hift* m, const float* speech_feat, int32_t frames, float* f0_out, void* stream);
+/* HiFTGenerator.decode(x, s) (hifigan/generator.py:507-539): speech_feat dev [80, frames], source dev [480*frames] -> speech dev [480*frames] */
+int cv_hift_decode(cv_hift* m, const float* speech_feat, int32_t frames, const float* source, float* speech_out, void* stream);
+/* B6: HiFTGenerator.inference(speech_feat[1,80,m], cache_source[1,1,c]) -> (speech[1,480m], source[1,1,480m]) (generator.py:557-569).
+ * noise: optional dev [480m, 9] N(0,1) variates for SineGen2 (parity tests); NULL -> in-kernel counter RNG keyed by `seed`. */
+int cv_hift_inference(cv_hift* m, const float* speech_feat, int32_t frames, const float* cache_source, int32_t cache_len,
+                      const float* noise, uint64_t seed, float* speech_out, float* source_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

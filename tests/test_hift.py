@@ -1,0 +1,60 @@
+"""Stage B6 parity: HIP HiFT (f0 predictor, harmonic source, conv stack, iSTFT) vs the oracle and the reference goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cosyvoice_amd.hift import HiFTGenerator
+from oracle import hift as OH
+from oracle import weights as W
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = W.tiny()[2]
+    return cfg, W.make_hift(cfg)
+
+
+def test_matches_reference_golden(lib, tiny):
+    """f0, source, decode and the cache_source path against vectors produced by the REAL reference (hift_tiny.npz)."""
+    cfg, sd = tiny
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, "hift_tiny.npz")).items()}
+    hift = HiFTGenerator(sd, cfg, lib=lib)
+    torch.testing.assert_close(hift.f0_predictor(g["mel"]).cpu(), g["f0"], rtol=1e-4, atol=1e-3)
+    # decoder pinned tightly by feeding it the reference's own source
+    torch.testing.assert_close(hift.decode(g["mel"], g["source"]).cpu(), g["speech"], rtol=2e-4, atol=2e-4)
+    # full inference with the reference's noise draws: the source integrates f0 into a phase of thousands of radians, so fp32
+    # round-off is amplified (see tests/test_oracle_golden.py) -> 2e-3 on the source
+    speech, source = hift.inference(g["mel"], noise=g["noise"])
+    torch.testing.assert_close(source.cpu(), g["source"], rtol=0, atol=2e-3)
+    speech_c, source_c = hift.inference(g["mel"], cache_source=g["cache"], noise=g["noise"])
+    torch.testing.assert_close(source_c.cpu()[:, :, :960], g["cache"], rtol=0, atol=0)
+    torch.testing.assert_close(source_c.cpu(), g["source_c"], rtol=0, atol=2e-3)
+    torch.testing.assert_close(hift.decode(g["mel"], g["source_c"]).cpu(), g["speech_c"], rtol=2e-4, atol=2e-4)
+
+
+def test_decode_vs_oracle(lib, tiny):
+    cfg, sd = tiny
+    hift = HiFTGenerator(sd, cfg, lib=lib)
+    gen = torch.Generator().manual_seed(4)
+    m = 7
+    mel = torch.randn(1, 80, m, generator=gen) * 2 - 5
+    s = torch.tanh(torch.randn(1, 1, 480 * m, generator=gen))
+    torch.testing.assert_close(hift.decode(mel, s).cpu(), OH.decode(sd, cfg, mel, s), rtol=2e-4, atol=2e-4)
+
+
+def test_source_statistics_with_device_rng(lib, tiny):
+    """Without the parity hook the SineGen2 noise comes from the in-kernel RNG: same f0, same deterministic part, noise ~ N(0,1)."""
+    cfg, sd = tiny
+    hift = HiFTGenerator(sd, cfg, lib=lib)
+    gen = torch.Generator().manual_seed(6)
+    mel = torch.randn(1, 80, 6, generator=gen) * 2 - 5
+    sp1, s1 = hift.inference(mel)
+    sp2, s2 = hift.inference(mel)
+    _, s0 = hift.inference(mel, noise=torch.zeros(480 * 6, 9))
+    assert not torch.equal(s1, s2)                                     # fresh draws per call
+    assert (s1.cpu() - s0.cpu()).abs().max() < 0.6 and (s1.cpu() - s0.cpu()).abs().mean() > 1e-4
+    assert torch.isfinite(sp1).all() and sp1.abs().max() <= cfg.audio_limit + 1e-6
