@@ -1,0 +1,200 @@
+"""Host mirror of cosyvoice.cli.model.CosyVoice2Model (boundaries B1 / B7): same `load`, `tts`,
+`token2wav`, `llm_job` call surface, same per-uuid state dicts and chunking rules, over the MI355X stages.
+
+Differences that are deliberate:
+  * C.1  `token_hop_len` is per request (the reference mutates the attribute, so a streamed request changes the next one);
+  * C.2  the streaming loop waits on a condition variable signalled by the LLM thread instead of `time.sleep(0.1)`;
+  * C.12 `fade_in_out` stays on the device (cv_fade_in_out) and there is no per-request `empty_cache()`.
+"""
+import ctypes as C
+import threading
+import uuid as uuid_mod
+from contextlib import nullcontext
+
+import numpy as np
+import torch
+
+from ._lib import get_lib, stream_ptr
+from .flow import CausalMaskedDiffWithXvec
+from .hift import HiFTGenerator
+from .llm import Qwen2LM
+
+
+class CosyVoice2Model:
+    def __init__(self, llm, flow, hift, fp16=False):
+        """llm / flow / hift: cosyvoice_amd.{llm.Qwen2LM, flow.CausalMaskedDiffWithXvec, hift.HiFTGenerator} (or None before load())."""
+        self.llm, self.flow, self.hift = llm, flow, hift
+        self.lib = (llm or flow or hift).lib if (llm or flow or hift) is not None else get_lib()
+        self.device = torch.device(self.lib.device)
+        self.fp16 = fp16                       # accepted for API compatibility; the HIP path is W16A32 (bf16 weights, fp32 math)
+        self.token_hop_len = 25                # must match the training static_chunk_size (cli/model.py:257-259)
+        self.token_max_hop_len = 4 * self.token_hop_len
+        self.stream_scale_factor = 2
+        self.mel_cache_len = 8
+        self.source_cache_len = int(self.mel_cache_len * 480)
+        self.speech_window = np.hamming(2 * self.source_cache_len)
+        self._window_dev = self.lib.hook(torch.from_numpy(self.speech_window.astype(np.float32)).to(self.device))
+        use_cuda = self.device.type == "cuda"
+        self.llm_stream = torch.cuda.Stream(self.device) if use_cuda else None
+        self.llm_context = torch.cuda.stream(self.llm_stream) if use_cuda else nullcontext()
+        self.lock = threading.Lock()
+        self.t2w_lock = threading.Lock()       # flow / hift handles own their workspaces: one token2wav at a time per model
+        self.tts_speech_token_dict, self.llm_end_dict, self.hift_cache_dict, self._cond = {}, {}, {}, {}
+        self.silent_tokens = []
+
+    # ------------------------------------------------------------------------------------------------ B7
+    @classmethod
+    def from_state_dicts(cls, llm_sd, flow_sd, hift_sd, cfgs, lib=None, **llm_kw):
+        lc, fc, hc = cfgs
+        lib = lib or get_lib()
+        return cls(Qwen2LM(llm_sd, lc, lib=lib, **llm_kw), CausalMaskedDiffWithXvec(flow_sd, fc, lib=lib), HiFTGenerator(hift_sd, hc, lib=lib))
+
+    def load(self, llm_model, flow_model, hift_model, cfgs=None, **llm_kw):
+        """cli/model.py:65-73: state-dict files (llm.pt, flow.pt, hift.pt; `generator.` prefix stripped from hift keys)."""
+        from .configs import cv2
+        lc, fc, hc = cfgs or cv2()
+        llm_sd = torch.load(llm_model, map_location="cpu", weights_only=True)
+        flow_sd = torch.load(flow_model, map_location="cpu", weights_only=True)
+        hift_sd = {k.replace("generator.", ""): v for k, v in torch.load(hift_model, map_location="cpu", weights_only=True).items()}
+        self.llm = Qwen2LM(llm_sd, lc, lib=self.lib, **llm_kw)
+        self.flow = CausalMaskedDiffWithXvec(flow_sd, fc, lib=self.lib)
+        self.hift = HiFTGenerator(hift_sd, hc, lib=self.lib)
+
+    # the reference's accelerator hooks are meaningless here: the MI355X kernels ARE the accelerated path
+    def load_jit(self, *a, **k):
+        raise NotImplementedError("TorchScript export is replaced by the native flow encoder (cv_flow_encoder)")
+
+    def load_trt(self, *a, **k):
+        raise NotImplementedError("TensorRT is replaced by the native flow estimator (cv_flow_estimator)")
+
+    def load_vllm(self, *a, **k):
+        raise NotImplementedError("vLLM is replaced by the native LLM decode loop (cv_llm_decode)")
+
+    # ------------------------------------------------------------------------------------------------ llm_job / vc_job
+    def llm_job(self, text, prompt_text, llm_prompt_speech_token, llm_embedding, uuid):
+        """cli/model.py:101-129 (non-bistream branch)."""
+        cur_silent_token_num, max_silent_token_num = 0, 5
+        cond = self._cond[uuid]
+        try:
+            with self.llm_context:
+                t = lambda n: torch.tensor([n], dtype=torch.int32)
+                gen = self.llm.inference(text=text, text_len=t(text.shape[1]), prompt_text=prompt_text, prompt_text_len=t(prompt_text.shape[1]),
+                                         prompt_speech_token=llm_prompt_speech_token, prompt_speech_token_len=t(llm_prompt_speech_token.shape[1]),
+                                         embedding=llm_embedding, uuid=uuid)
+                for i in gen:
+                    if i in self.silent_tokens:
+                        cur_silent_token_num += 1
+                        if cur_silent_token_num > max_silent_token_num:
+                            continue
+                    else:
+                        cur_silent_token_num = 0
+                    with cond:
+                        self.tts_speech_token_dict[uuid].append(i)
+                        cond.notify_all()
+        finally:
+            with cond:
+                self.llm_end_dict[uuid] = True
+                cond.notify_all()
+
+    def vc_job(self, source_speech_token, uuid):
+        with self._cond[uuid]:
+            self.tts_speech_token_dict[uuid] = source_speech_token.flatten().tolist()
+            self.llm_end_dict[uuid] = True
+            self._cond[uuid].notify_all()
+
+    # ------------------------------------------------------------------------------------------------ B1
+    def _fade(self, speech, cached_speech):
+        n = self.source_cache_len
+        tail = cached_speech[:, -n:].contiguous()
+        self.lib.cv_fade_in_out(C.c_void_p(speech.data_ptr()), C.c_void_p(tail.data_ptr()), C.c_void_p(self._window_dev.data_ptr()), C.c_int32(n), stream_ptr(self.lib))
+        return speech
+
+    @torch.inference_mode()
+    def token2wav(self, token, prompt_token, prompt_feat, embedding, token_offset, uuid, stream=False, finalize=False, speed=1.0):
+        """cli/model.py:292-326."""
+        with self.t2w_lock:
+            t = lambda n: torch.tensor([n], dtype=torch.int32)
+            tts_mel, _ = self.flow.inference(token=token.to(torch.int32), token_len=t(token.shape[1]), prompt_token=prompt_token, prompt_token_len=t(prompt_token.shape[1]),
+                                             prompt_feat=prompt_feat, prompt_feat_len=t(prompt_feat.shape[1]), embedding=embedding, streaming=stream, finalize=finalize)
+            tts_mel = tts_mel[:, :, token_offset * self.flow.token_mel_ratio:]
+            cache = self.hift_cache_dict.get(uuid)
+            if cache is not None:
+                tts_mel = torch.concat([cache["mel"], tts_mel], dim=2)
+                hift_cache_source = cache["source"]
+            else:
+                hift_cache_source = torch.zeros(1, 1, 0)
+            if finalize is False:
+                tts_speech, tts_source = self.hift.inference(speech_feat=tts_mel, cache_source=hift_cache_source)
+                if cache is not None:
+                    tts_speech = self._fade(tts_speech, cache["speech"])
+                self.hift_cache_dict[uuid] = {"mel": tts_mel[:, :, -self.mel_cache_len:].clone(), "source": tts_source[:, :, -self.source_cache_len:].clone(),
+                                              "speech": tts_speech[:, -self.source_cache_len:].clone()}
+                tts_speech = tts_speech[:, :-self.source_cache_len]
+            else:
+                if speed != 1.0:
+                    assert cache is None, "speed change only support non-stream inference mode"
+                    tn = int(tts_mel.shape[2] / speed)
+                    src = tts_mel.contiguous()
+                    dst = torch.empty(1, src.shape[1], tn, dtype=torch.float32, device=self.device)
+                    self.lib.cv_interp_linear(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_int32(src.shape[1]), C.c_int32(src.shape[2]), C.c_int32(tn), stream_ptr(self.lib))
+                    tts_mel = dst
+                tts_speech, tts_source = self.hift.inference(speech_feat=tts_mel, cache_source=hift_cache_source)
+                if cache is not None:
+                    tts_speech = self._fade(tts_speech, cache["speech"])
+            return tts_speech
+
+    def tts(self, text=torch.zeros(1, 0, dtype=torch.int32), flow_embedding=torch.zeros(0, 192), llm_embedding=torch.zeros(0, 192),
+            prompt_text=torch.zeros(1, 0, dtype=torch.int32), llm_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32),
+            flow_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32), prompt_speech_feat=torch.zeros(1, 0, 80),
+            source_speech_token=torch.zeros(1, 0, dtype=torch.int32), stream=False, speed=1.0, **kwargs):
+        """cli/model.py:328-394: generator of {'tts_speech': [1, S] fp32 cpu}."""
+        this_uuid = str(uuid_mod.uuid1())
+        with self.lock:
+            self.tts_speech_token_dict[this_uuid], self.llm_end_dict[this_uuid] = [], False
+            self.hift_cache_dict[this_uuid] = None
+            self._cond[this_uuid] = threading.Condition()
+        cond = self._cond[this_uuid]
+        if source_speech_token.shape[1] == 0:
+            p = threading.Thread(target=self.llm_job, args=(text, prompt_text, llm_prompt_speech_token, llm_embedding, this_uuid))
+        else:
+            p = threading.Thread(target=self.vc_job, args=(source_speech_token, this_uuid))
+        p.start()
+        try:
+            if stream is True:
+                token_offset = 0
+                token_hop_len = self.token_hop_len
+                la = self.flow.pre_lookahead_len
+                prompt_token_pad = int(np.ceil(flow_prompt_speech_token.shape[1] / token_hop_len) * token_hop_len - flow_prompt_speech_token.shape[1])
+                while True:
+                    this_token_hop_len = token_hop_len + prompt_token_pad if token_offset == 0 else token_hop_len
+                    with cond:
+                        cond.wait_for(lambda: len(self.tts_speech_token_dict[this_uuid]) - token_offset >= this_token_hop_len + la or self.llm_end_dict[this_uuid])
+                        n_have = len(self.tts_speech_token_dict[this_uuid])
+                        ended = self.llm_end_dict[this_uuid]
+                        toks = list(self.tts_speech_token_dict[this_uuid][: token_offset + this_token_hop_len + la])
+                    if n_have - token_offset >= this_token_hop_len + la:
+                        this_tts_speech = self.token2wav(token=torch.tensor(toks).unsqueeze(dim=0), prompt_token=flow_prompt_speech_token, prompt_feat=prompt_speech_feat,
+                                                         embedding=flow_embedding, token_offset=token_offset, uuid=this_uuid, stream=stream, finalize=False)
+                        token_offset += this_token_hop_len
+                        token_hop_len = min(self.token_max_hop_len, token_hop_len * self.stream_scale_factor)
+                        yield {"tts_speech": this_tts_speech.cpu()}
+                    elif ended:
+                        break
+                p.join()
+                this_tts_speech_token = torch.tensor(self.tts_speech_token_dict[this_uuid]).unsqueeze(dim=0)
+                this_tts_speech = self.token2wav(token=this_tts_speech_token, prompt_token=flow_prompt_speech_token, prompt_feat=prompt_speech_feat,
+                                                 embedding=flow_embedding, token_offset=token_offset, uuid=this_uuid, finalize=True)
+                yield {"tts_speech": this_tts_speech.cpu()}
+            else:
+                p.join()
+                this_tts_speech_token = torch.tensor(self.tts_speech_token_dict[this_uuid]).unsqueeze(dim=0)
+                this_tts_speech = self.token2wav(token=this_tts_speech_token, prompt_token=flow_prompt_speech_token, prompt_feat=prompt_speech_feat,
+                                                 embedding=flow_embedding, token_offset=0, uuid=this_uuid, finalize=True, speed=speed)
+                yield {"tts_speech": this_tts_speech.cpu()}
+        finally:
+            p.join()
+            with self.lock:
+                self.tts_speech_token_dict.pop(this_uuid, None)
+                self.llm_end_dict.pop(this_uuid, None)
+                self.hift_cache_dict.pop(this_uuid, None)
+                self._cond.pop(this_uuid, None)

@@ -171,6 +171,15 @@ int cv_hift_decode(cv_hift* m, const float* speech_feat, int32_t frames, const f
 int cv_hift_inference(cv_hift* m, const float* speech_feat, int32_t frames, const float* cache_source, int32_t cache_len,
                       const float* noise, uint64_t seed, float* speech_out, float* source_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Glue of CosyVoice2Model.token2wav (boundary B1, cosyvoice/cli/model.py:292-326)
+ * ---------------------------------------------------------------------------------------------------- */
+/* fade_in_out (cosyvoice/utils/common.py:170-178) in place on the device: fade_in[:n] = fade_in[:n]*window[:n] + fade_out_tail[:n]*window[n:2n];
+ * fade_out_tail points at the LAST n samples of the cached speech; window: dev fp32 [2n] (np.hamming). */
+int cv_fade_in_out(float* fade_in, const float* fade_out_tail, const float* window, int32_t overlap, void* stream);
+/* F.interpolate(x[1,C,T], size=Tn, mode='linear') for the `speed` argument (cli/model.py:322), channel-first. */
+int cv_interp_linear(const float* x, float* y, int32_t C, int32_t T, int32_t Tn, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,78 +5,11 @@ architecture (numpy PCG64 streams: reproducible across machines and torch versio
 loading these dicts into the real reference modules with strict=True (tests/golden/make_golden.py).
 Configs: `cv2()` = CosyVoice2-0.5B, `tiny()` = same topology, small dims (emulator-sized tests).
 """
-from dataclasses import dataclass, field
-from typing import List
-
 import numpy as np
 import torch
 
 
-@dataclass
-class LLMConfig:                      # Appendix A.1 (cosyvoice2.yaml:23-36 + Qwen2.5-0.5B config)
-    hidden: int = 896
-    layers: int = 24
-    heads: int = 14
-    kv_heads: int = 2
-    head_dim: int = 64
-    inter: int = 4864
-    text_vocab: int = 151936
-    speech_token_size: int = 6561
-    rms_eps: float = 1e-6
-    rope_theta: float = 1e6
-
-
-@dataclass
-class FlowConfig:                     # Appendix A.2 / A.3 (cosyvoice2.yaml:38-87)
-    vocab: int = 6561
-    dim: int = 512                    # encoder width
-    enc_heads: int = 8
-    ffn: int = 2048
-    enc_blocks: int = 6
-    up_blocks: int = 4
-    spk_dim: int = 192
-    mel: int = 80
-    est_ch: int = 256                 # estimator channels
-    est_heads: int = 8
-    est_blocks: int = 4               # transformer blocks per resnet
-    est_mid: int = 12
-    pre_lookahead: int = 3
-    chunk: int = 25                   # static_chunk_size in tokens (estimator: chunk * 2 frames)
-    cfg_rate: float = 0.7
-    n_timesteps: int = 10
-
-
-@dataclass
-class HiftConfig:                     # Appendix A.4 (cosyvoice2.yaml:89-111)
-    mel: int = 80
-    base: int = 512
-    harmonics: int = 8
-    sr: int = 24000
-    ups: List[int] = field(default_factory=lambda: [8, 5, 3])
-    up_k: List[int] = field(default_factory=lambda: [16, 11, 7])
-    res_k: List[int] = field(default_factory=lambda: [3, 7, 11])
-    res_d: List[int] = field(default_factory=lambda: [1, 3, 5])
-    src_k: List[int] = field(default_factory=lambda: [7, 7, 11])
-    n_fft: int = 16
-    hop: int = 4
-    f0_ch: int = 512
-    nsf_alpha: float = 0.1
-    nsf_sigma: float = 0.003
-    voiced_thr: float = 10.0
-    lrelu: float = 0.1
-    audio_limit: float = 0.99
-
-
-def cv2():
-    return LLMConfig(), FlowConfig(), HiftConfig()
-
-
-def tiny():
-    llm = LLMConfig(hidden=128, layers=2, heads=2, kv_heads=1, inter=256, text_vocab=300, speech_token_size=60)
-    flow = FlowConfig(vocab=60, dim=128, enc_heads=2, ffn=256, enc_blocks=2, up_blocks=1, spk_dim=32, est_ch=64, est_heads=1,
-                      est_blocks=1, est_mid=2)
-    hift = HiftConfig(base=64, f0_ch=32)
-    return llm, flow, hift
+from cosyvoice_amd.configs import FlowConfig, HiftConfig, LLMConfig, cv2, tiny  # noqa: E402,F401  (architecture constants only)
 
 
 class _Gen:

@@ -1,0 +1,65 @@
+"""Boundary B1: CosyVoice2Model.tts / token2wav end to end (LLM -> flow -> HiFT, offline and streaming) vs the oracle pipeline."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from cosyvoice_amd.model import CosyVoice2Model
+from oracle import llm as OL
+from oracle import model as OM
+from oracle import weights as W
+
+
+@pytest.fixture(scope="module")
+def setup():
+    lc, fc, hc = W.tiny()
+    fc = dataclasses.replace(fc, chunk=5, n_timesteps=2)           # small streaming chunks so the emulator run stays short
+    sds = (W.make_llm(lc), W.make_flow(fc), W.make_hift(hc))
+    u = W.synthetic_utterance(lc, fc, n_prompt_tok=8, n_prompt_text=4, n_text=4, seed=21)
+    return (lc, fc, hc), sds, u
+
+
+def _build(lib, cfgs, sds):
+    m = CosyVoice2Model.from_state_dicts(*sds, cfgs, lib=lib, max_len=160, sampling="greedy")
+    m.token_hop_len, m.token_max_hop_len = 5, 20
+    inf = m.hift.inference
+    m.hift.inference = lambda speech_feat, cache_source=None: inf(speech_feat, cache_source, noise=torch.zeros(speech_feat.shape[2] * 480, 9))
+    return m
+
+
+@pytest.mark.parametrize("stream", [False, True])
+def test_tts_matches_oracle(lib, setup, stream):
+    cfgs, sds, u = setup
+    lc, fc, hc = cfgs
+    m = _build(lib, cfgs, sds)
+    # the LLM's ratio arguments are fixed inside llm_job (20 / 2), so shorten through the text length: 4 text tokens -> 8..80 tokens
+    outs = [o["tts_speech"] for o in m.tts(text=u["text"], flow_embedding=u["flow_embedding"], llm_embedding=u["llm_embedding"], prompt_text=u["prompt_text"],
+                                           llm_prompt_speech_token=u["llm_prompt_speech_token"], flow_prompt_speech_token=u["flow_prompt_speech_token"],
+                                           prompt_speech_feat=u["prompt_speech_feat"], stream=stream)]
+    tokens = OL.inference(sds[0], lc, u["text"], u["prompt_text"], u["llm_prompt_speech_token"])
+    pipe = OM.Pipeline(sds, cfgs, token_hop_len=5, n_timesteps=2)
+    want = pipe.tts(tokens, u, stream=stream)
+    assert len(outs) == len(want) and (len(outs) > 2 if stream else len(outs) == 1)
+    for a, b in zip(outs, want):
+        assert a.shape == b.shape and a.device.type == "cpu"
+        # waveform tolerance: the harmonic source amplifies fp32 round-off of f0 (see tests/test_oracle_golden.py), and exp() in
+        # the iSTFT magnitude amplifies it again -> 5e-3 absolute on a signal clamped to +-0.99
+        torch.testing.assert_close(a, b, rtol=0, atol=5e-3)
+    assert sum(o.shape[1] for o in outs) == len(tokens) * 2 * 480
+    assert not m.tts_speech_token_dict and not m.hift_cache_dict             # per-request state is cleaned up (cli/model.py:388-391)
+
+
+def test_speed_and_vc(lib, setup):
+    """speed != 1 (non-stream only, cli/model.py:320-322) and the voice-conversion path (source_speech_token -> vc_job)."""
+    cfgs, sds, u = setup
+    lc, fc, hc = cfgs
+    m = _build(lib, cfgs, sds)
+    src = torch.randint(0, fc.vocab, (1, 12), generator=torch.Generator().manual_seed(2), dtype=torch.int32)
+    kw = dict(flow_embedding=u["flow_embedding"], flow_prompt_speech_token=u["flow_prompt_speech_token"], prompt_speech_feat=u["prompt_speech_feat"],
+              source_speech_token=src)
+    a = next(iter(m.tts(**kw)))["tts_speech"]
+    b = next(iter(m.tts(speed=1.5, **kw)))["tts_speech"]
+    assert a.shape[1] == 12 * 2 * 480 and b.shape[1] == int(24 / 1.5) * 480
+    pipe = OM.Pipeline(sds, cfgs, token_hop_len=5, n_timesteps=2)
+    torch.testing.assert_close(a, pipe.tts(src[0].tolist(), u, stream=False)[0], rtol=0, atol=5e-3)
