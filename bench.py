@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""Headline benchmark: audio-seconds synthesised per wall-second (1/RTF), CosyVoice2-0.5B zero-shot, batch 1, 10 CFM Euler steps
+(BASELINE.json configs[1]) on the synthetic U10 utterance of SURVEY.md §8d, plus first-chunk p50 latency in streaming mode.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One process per GPU.  Utterances are independent, so ranks are replicas of the whole pipeline (no data-path collective, xGMI
+idle — SURVEY.md §8e); RCCL is used only for the barrier + max-over-ranks of the timed region.  A "step" is one complete
+utterance: lm_input build -> LLM prefill(131) -> 250 greedy decode steps -> flow (encoder + 10 CFG Euler steps, T=674) -> HiFT
+(500 frames) -> 240 000 samples copied to the host.  Inputs are resident on the GPU when the timed region starts.
+Weights are seeded random tensors of the real architecture (no checkpoints on the box): `data: synthetic`.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_GEN, N_TEXT, N_PROMPT_TEXT, N_PROMPT_TOK = 250, 30, 12, 87
+AUDIO_S = N_GEN / 25.0
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def build_model():
+    from cosyvoice_amd.configs import cv2
+    from cosyvoice_amd.model import CosyVoice2Model
+    from cosyvoice_amd import synthetic as W
+    cfgs = cv2()
+    model = CosyVoice2Model.from_state_dicts(W.make_llm(cfgs[0]), W.make_flow(cfgs[1]), W.make_hift(cfgs[2]), cfgs,
+                                             max_len=1024, sampling="greedy", decode_chunk=64)
+    u = W.synthetic_utterance(cfgs[0], cfgs[1], n_prompt_tok=N_PROMPT_TOK, n_prompt_text=N_PROMPT_TEXT, n_text=N_TEXT)
+    dev = model.device
+    u = {k: v.to(dev) for k, v in u.items()}
+    return model, u, cfgs
+
+
+def one_utterance(model, u):
+    """The hot path for one utterance; returns the host waveform [1, 240000]."""
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    ratio = N_GEN / N_TEXT
+    with model.llm_context:
+        tokens = list(model.llm.inference(text=u["text"], text_len=t(N_TEXT), prompt_text=u["prompt_text"], prompt_text_len=t(N_PROMPT_TEXT),
+                                          prompt_speech_token=u["llm_prompt_speech_token"], prompt_speech_token_len=t(N_PROMPT_TOK),
+                                          embedding=u["llm_embedding"], max_token_text_ratio=ratio, min_token_text_ratio=ratio))
+    assert len(tokens) == N_GEN, len(tokens)
+    uid = "bench"
+    model.hift_cache_dict[uid] = None
+    wav = model.token2wav(token=torch.tensor(tokens).unsqueeze(0), prompt_token=u["flow_prompt_speech_token"], prompt_feat=u["prompt_speech_feat"],
+                          embedding=u["flow_embedding"], token_offset=0, uuid=uid, finalize=True)
+    out = wav.cpu()
+    model.hift_cache_dict.pop(uid, None)
+    assert out.shape[1] == N_GEN * 2 * 480
+    return out
+
+
+def first_chunk_latency(model, u, reps):
+    """Streaming tts(): time from the call to the first yielded chunk (client_grpc.py:73-87 definition)."""
+    lat = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gen = model.tts(text=u["text"], flow_embedding=u["flow_embedding"], llm_embedding=u["llm_embedding"], prompt_text=u["prompt_text"],
+                        llm_prompt_speech_token=u["llm_prompt_speech_token"], flow_prompt_speech_token=u["flow_prompt_speech_token"],
+                        prompt_speech_feat=u["prompt_speech_feat"], stream=True)
+        first = next(gen)
+        lat.append((time.perf_counter() - t0) * 1e3)
+        assert first["tts_speech"].shape[1] > 0
+        for _ in gen:
+            pass
+    lat.sort()
+    return lat[len(lat) // 2]
+
+
+def roofline_llm(model, u, cfgs):
+    """Per-kernel HIP-event timing of eager decode steps (cv_llm_profile_step) -> roofline of the dominant kernel class."""
+    from cosyvoice_amd.llm import SamplingC
+    lc = cfgs[0]
+    llm = model.llm
+    with model.llm_context:
+        llm.prefill(llm.build_lm_input(u["text"], u["prompt_text"], u["llm_prompt_speech_token"]))
+        sp = SamplingC(0, llm.eos_token, 3, N_GEN, N_GEN, 0.8, 25, 10, 0.1, 0, 0)
+        counts, ms = (C.c_int32 * 8)(), (C.c_float * 8)()
+        tot_c, tot_ms = [0] * 8, [0.0] * 8
+        from cosyvoice_amd._lib import stream_ptr
+        for i in range(40):
+            llm.lib.cv_llm_profile_step(llm._h, C.byref(sp), counts, ms, stream_ptr(llm.lib))
+            if i >= 8:
+                for k in range(8):
+                    tot_c[k] += counts[k]; tot_ms[k] += ms[k]
+    H, I, V, A, Q = lc.hidden, lc.inter, lc.speech_token_size + 3, lc.heads * 64, (lc.heads + 2 * lc.kv_heads) * 64
+    # algorithmic bytes per launch: bf16 weight rows streamed once (2 B/param) — activations/bias are negligible
+    wbytes = {0: 2 * Q * H, 2: 2 * H * A, 3: 2 * 2 * I * H, 4: 2 * H * I, 5: 2 * V * H}
+    names = {0: "gemv_kernel<1> qkv", 2: "gemv_kernel<1> o_proj", 3: "gemv_kernel<1> gate_up", 4: "gemv_kernel<4> down", 5: "gemv_kernel<1> head",
+             1: "attn_decode_kernel", 6: "sample_kernel"}
+    per = {names[k]: dict(launches=tot_c[k], avg_us=1e3 * tot_ms[k] / max(tot_c[k], 1)) for k in names if tot_c[k]}
+    # dominant kernel = gemv_kernel<1> (qkv + o_proj + gate_up + head instances): bytes and time averaged over its launches
+    ks = [0, 2, 3, 5]
+    n = sum(tot_c[k] for k in ks)
+    t_ms = sum(tot_ms[k] for k in ks)
+    bytes_per_launch = sum(tot_c[k] * wbytes[k] for k in ks) / max(n, 1)
+    avg_s = (t_ms / max(n, 1)) * 1e-3
+    achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+    return dict(bound="hbm", kernel="gemv_kernel<1> (LLM decode weight streaming: qkv, o_proj, gate_up, head)", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+                unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, bytes_per_launch=int(bytes_per_launch),
+                avg_launch_us=round(avg_s * 1e6, 2), per_kernel=per)
+
+
+def cpu_baseline(cfgs):
+    """The oracle (CPU restatement of the reference) timed on the host cores, on a bounded sample of U10, extrapolated per stage."""
+    from oracle import flow as OF, hift as OH, llm as OL      # the ONLY place bench.py touches oracle/: the reported CPU baseline
+    from cosyvoice_amd import synthetic as W
+    lc, fc, hc = cfgs
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    u = W.synthetic_utterance(lc, fc, n_prompt_tok=N_PROMPT_TOK, n_prompt_text=N_PROMPT_TEXT, n_text=N_TEXT)
+    with torch.inference_mode():
+        sd = W.make_llm(lc)
+        m = OL.Qwen2Oracle(sd, lc)
+        x = OL.build_lm_input(sd, lc, u["text"], u["prompt_text"], u["llm_prompt_speech_token"])
+        t0 = time.perf_counter(); m.forward(x); t_prefill = time.perf_counter() - t0
+        tok = sd["speech_embedding.weight"][5].reshape(1, -1)
+        m.forward(tok)
+        t0 = time.perf_counter()
+        for _ in range(6):
+            y = m.forward(tok)
+            torch.nn.functional.linear(y[-1], sd["llm_decoder.weight"], sd["llm_decoder.bias"]).log_softmax(-1)
+        t_tok = (time.perf_counter() - t0) / 6
+        del sd, m
+        fsd = W.make_flow(fc)
+        T = 2 * (N_PROMPT_TOK + N_GEN)
+        g = torch.Generator().manual_seed(0)
+        emb = torch.randn(1, N_PROMPT_TOK + N_GEN, fc.dim, generator=g)
+        t0 = time.perf_counter(); OF.encoder(fsd, fc, emb, None, False); t_enc = time.perf_counter() - t0
+        xx = torch.randn(2, 80, T, generator=g)
+        t0 = time.perf_counter()
+        OF.estimator(fsd, fc, xx, torch.ones(2, 1, T), xx, torch.tensor([0.3, 0.3]), torch.randn(2, 80, generator=g), xx, False)
+        t_est = time.perf_counter() - t0
+        del fsd
+        hsd = W.make_hift(hc)
+        mel = torch.randn(1, 80, 100, generator=g) * 2 - 5
+        OH.inference(hsd, hc, mel[:, :, :20])
+        t0 = time.perf_counter(); OH.inference(hsd, hc, mel); t_hift = (time.perf_counter() - t0) * 5.0
+    total = t_prefill + N_GEN * t_tok + t_enc + fc.n_timesteps * t_est + t_hift
+    return dict(value=round(AUDIO_S / total, 4), unit="audio_s/s", cores=cores, kind="port",
+                sample="oracle/ (torch fp32, %d threads): LLM prefill(131) + 6 decode steps, flow encoder(337 tok) + 1 of 10 estimator steps at T=674, "
+                       "HiFT 100 of 500 frames; per-stage times extrapolated to the full U10 utterance" % cores,
+                stage_seconds=dict(llm_prefill=round(t_prefill, 3), llm_per_token=round(t_tok, 4), flow_encoder=round(t_enc, 3),
+                                   flow_estimator_step=round(t_est, 3), hift_500_frames=round(t_hift, 3)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--first-chunk-reps", type=int, default=5)
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    model, u, cfgs = build_model()
+    for _ in range(args.warmup):
+        one_utterance(model, u)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_utterance(model, u)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        value = world * args.steps * AUDIO_S / elapsed
+        out = {
+            "metric": "audio-sec/s (RTF^-1), CosyVoice2-0.5B zero-shot", "value": round(value, 3), "unit": "audio_s/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (bf16 weights, fp32 activations and accumulate; HiFT fp32)", "data": "synthetic",
+            "config": {"workload": "CosyVoice2-0.5B zero-shot, batch=1, 10 CFM Euler steps, synthetic U10: prompt 87 speech tokens / 174 mel frames, "
+                                   "12+30 text tokens, 250 generated tokens = 10.0 s @ 24 kHz (BASELINE.json configs[1])",
+                       "utterances_per_gpu_per_step": 1, "sampler": "greedy, length forced to 250", "parallelism": "replicas x%d, no collective" % world},
+            "per_gpu_audio_s_per_s": round(value / world, 3),
+        }
+        if world == 1:
+            out["first_chunk_ms_p50"] = round(first_chunk_latency(model, u, args.first_chunk_reps), 2)
+            out["roofline"] = roofline_llm(model, u, cfgs)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(cfgs)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

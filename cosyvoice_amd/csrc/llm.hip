@@ -30,6 +30,8 @@ struct cv_llm {
     hipGraphExec_t graph = nullptr; hipStream_t graph_stream = nullptr; hipStream_t own_stream = nullptr;
     cv_sampling sp{}; bool sp_valid = false; bool use_graph = true;
     int* host_tokens = nullptr; DecodeState* host_state = nullptr;
+    // optional per-kernel HIP-event timing of one eager decode step (bench.py roofline)
+    bool profiling = false; std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
     size_t layer_cache() const { return (size_t)cfg.kv_heads * cfg.max_len * 64; }
     ~cv_llm() {
         if (graph) (void)hipGraphExecDestroy(graph);
@@ -141,6 +143,16 @@ static void llm_prefill(cv_llm* m, const float* x_in, int L0, hipStream_t s) {
     CV_HIP(hipStreamSynchronize(s));     // host_state is reused by the next call
 }
 
+// kernel categories for cv_llm_profile_step: 0 qkv, 1 attention, 2 o_proj, 3 gate_up, 4 down, 5 head, 6 sample, 7 other
+struct ProfScope {
+    cv_llm* m; hipStream_t s; int cat; hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(cv_llm* m_, hipStream_t s_, int c) : m(m_), s(s_), cat(c) {
+        if (!m->profiling) return;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, s);
+    }
+    ~ProfScope() { if (!m->profiling) return; (void)hipEventRecord(e1, s); m->prof_events.push_back({cat, {e0, e1}}); }
+};
+
 template <int WAVES>
 static void gemv(const GemvArgs& a, int rows_per_block, hipStream_t s) {
     const int units = a.mode == 1 ? a.N / 2 : a.N;
@@ -152,23 +164,23 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
     const auto& c = m->cfg;
     const DecodeState* st = m->state.as<DecodeState>();
     float* h = m->h.as<float>(); float* qkv = m->qkv.as<float>(); float* at = m->attn.as<float>(); float* act = m->act.as<float>();
-    gemv<1>(GemvArgs{m->head_w, m->head_b, h, m->logits.as<float>(), m->V, c.hidden, m->norm, c.rms_eps, nullptr, 0, st}, 4, s);
+    { ProfScope ps(m, s, 5); gemv<1>(GemvArgs{m->head_w, m->head_b, h, m->logits.as<float>(), m->V, c.hidden, m->norm, c.rms_eps, nullptr, 0, st}, 4, s); }
     SampleArgs sa{};
     sa.logits = m->logits.as<float>(); sa.V = m->V; sa.eos = m->sp.eos; sa.n_stop = m->sp.n_stop;
     sa.min_len = m->sp.min_len; sa.max_len = m->sp.max_len; sa.mode = m->sp.mode; sa.top_p = m->sp.top_p; sa.top_k = m->sp.top_k;
     sa.win = m->sp.win_size; sa.tau_r = m->sp.tau_r; sa.seed = m->sp.seed; sa.uniforms = m->sp.use_uniforms ? m->uniforms.as<float>() : nullptr;
     sa.st = m->state.as<DecodeState>(); sa.tokens = m->tokens.as<int>(); sa.max_tokens = c.max_len;
-    hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, s, sa);
+    { ProfScope ps(m, s, 6); hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, s, sa); }
     hipLaunchKernelGGL(embed_last_token_kernel, dim3(1), dim3(256), 0, s, m->speech_emb, c.hidden, h, st);
     for (int i = 0; i < c.layers; ++i) {
         const auto& L = m->layers[i];
-        gemv<1>(GemvArgs{L.wqkv, L.bqkv, h, qkv, m->qkv_dim, c.hidden, L.ln1, c.rms_eps, nullptr, 0, st}, 4, s);
+        { ProfScope ps(m, s, 0); gemv<1>(GemvArgs{L.wqkv, L.bqkv, h, qkv, m->qkv_dim, c.hidden, L.ln1, c.rms_eps, nullptr, 0, st}, 4, s); }
         AttnDecodeArgs ad{qkv, m->kcache.as<float>() + m->layer_cache() * i, m->vcache.as<float>() + m->layer_cache() * i,
                           m->rope_cos.as<float>(), m->rope_sin.as<float>(), at, c.heads, c.kv_heads, c.max_len, st};
-        hipLaunchKernelGGL(attn_decode_kernel, dim3(c.heads), dim3(256), 0, s, ad);
-        gemv<1>(GemvArgs{L.wo, nullptr, at, h, c.hidden, c.heads * 64, nullptr, 0.f, h, 0, st}, 4, s);
-        gemv<1>(GemvArgs{L.wgu, nullptr, h, act, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 1, st}, 4, s);
-        gemv<4>(GemvArgs{L.wdown, nullptr, act, h, c.hidden, c.inter, nullptr, 0.f, h, 0, st}, 4, s);
+        { ProfScope ps(m, s, 1); hipLaunchKernelGGL(attn_decode_kernel, dim3(c.heads), dim3(256), 0, s, ad); }
+        { ProfScope ps(m, s, 2); gemv<1>(GemvArgs{L.wo, nullptr, at, h, c.hidden, c.heads * 64, nullptr, 0.f, h, 0, st}, 4, s); }
+        { ProfScope ps(m, s, 3); gemv<1>(GemvArgs{L.wgu, nullptr, h, act, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 1, st}, 4, s); }
+        { ProfScope ps(m, s, 4); gemv<4>(GemvArgs{L.wdown, nullptr, act, h, c.hidden, c.inter, nullptr, 0.f, h, 0, st}, 4, s); }
     }
     hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, s, m->state.as<DecodeState>());
 }
@@ -245,6 +257,29 @@ int cv_llm_set_uniforms(cv_llm* m, const float* host_uniforms, int32_t n, void* 
 int cv_llm_decode(cv_llm* m, int32_t n_steps, const cv_sampling* sp, int32_t* out_tokens, int32_t* n_out, int32_t* finished, void* stream) {
     return guarded([&] { CV_CHECK(m && out_tokens && n_out && finished && n_steps > 0, "cv_llm_decode: bad arguments");
                          llm_decode(m, n_steps, sp, out_tokens, n_out, finished, resolve(m, stream)); });
+}
+/* Runs ONE decode step eagerly with a HIP-event pair around every kernel launch on `stream` and returns, per category
+ * (0 qkv, 1 attention, 2 o_proj, 3 gate_up, 4 down, 5 head, 6 sample), the launch count and the summed duration in ms. */
+int cv_llm_profile_step(cv_llm* m, const cv_sampling* sp, int32_t* counts8, float* ms8, void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && m->finalized && sp && counts8 && ms8, "cv_llm_profile_step: bad arguments");
+        hipStream_t s = resolve(m, stream);
+        m->sp = *sp; m->sp_valid = true;
+        if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+        CV_CHECK(m->host_state->pos + 1 < m->cfg.max_len, "cv_llm_profile_step: KV cache exhausted");
+        m->profiling = true; m->prof_events.clear();
+        llm_enqueue_step(m, s);
+        m->profiling = false;
+        CV_HIP(hipMemcpyAsync(m->host_state, m->state.p, sizeof(DecodeState), hipMemcpyDeviceToHost, s));
+        CV_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < 8; ++i) { counts8[i] = 0; ms8[i] = 0.f; }
+        for (auto& e : m->prof_events) {
+            float ms = 0.f; (void)hipEventElapsedTime(&ms, e.second.first, e.second.second);
+            counts8[e.first] += 1; ms8[e.first] += ms;
+            (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second);
+        }
+        m->prof_events.clear();
+    });
 }
 int cv_llm_last_logits(cv_llm* m, float* host_out, void* stream) {
     return guarded([&] { CV_CHECK(m && host_out, "null argument");

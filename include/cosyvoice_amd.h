@@ -115,6 +115,9 @@ int cv_llm_set_uniforms(cv_llm* m, const float* host_uniforms, int32_t n, void* 
 /* Runs up to n_steps iterations of the decode loop on the device, then synchronises and returns the tokens emitted by
  * this call (host ints, like the reference's `yield top_ids`).  *finished != 0 when a stop id was sampled or max_len hit. */
 int cv_llm_decode(cv_llm* m, int32_t n_steps, const cv_sampling* sp, int32_t* out_tokens, int32_t* n_out, int32_t* finished, void* stream);
+/* one eager decode step with a HIP-event pair around every launch: per category (0 qkv, 1 attention, 2 o_proj, 3 gate_up, 4 down,
+ * 5 head, 6 sample) launch count and summed duration in ms — used by bench.py for the live roofline figure */
+int cv_llm_profile_step(cv_llm* m, const cv_sampling* sp, int32_t* counts8, float* ms8, void* stream);
 int cv_llm_last_logits(cv_llm* m, float* host_out, void* stream);
 int cv_llm_last_hidden(cv_llm* m, float* host_out, void* stream);
 /* out[r][:] = table[ids[r]][:] * scale  (nn.Embedding lookups that build lm_input / flow token embeddings) */
