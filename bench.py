@@ -97,17 +97,17 @@ def roofline_llm(model, u, cfgs):
     H, I, V, A, Q = lc.hidden, lc.inter, lc.speech_token_size + 3, lc.heads * 64, (lc.heads + 2 * lc.kv_heads) * 64
     # algorithmic bytes per launch: bf16 weight rows streamed once (2 B/param) — activations/bias are negligible
     wbytes = {0: 2 * Q * H, 2: 2 * H * A, 3: 2 * 2 * I * H, 4: 2 * H * I, 5: 2 * V * H}
-    names = {0: "gemv_kernel<1> qkv", 2: "gemv_kernel<1> o_proj", 3: "gemv_kernel<1> gate_up", 4: "gemv_kernel<4> down", 5: "gemv_kernel<1> head",
+    names = {0: "gemv_kernel<7,1,1> qkv", 2: "gemv_kernel<7,1,1> o_proj", 3: "gemv_kernel<7,2,1> gate_up", 4: "gemv_kernel<10,1,4> down", 5: "gemv_kernel<7,2,1> head",
              1: "attn_decode_kernel", 6: "sample_kernel"}
     per = {names[k]: dict(launches=tot_c[k], avg_us=1e3 * tot_ms[k] / max(tot_c[k], 1)) for k in names if tot_c[k]}
-    # dominant kernel = gemv_kernel<1> (qkv + o_proj + gate_up + head instances): bytes and time averaged over its launches
+    # dominant kernel = gemv_kernel<7,R,1> (qkv + o_proj + gate_up + head instances): bytes and time averaged over its launches
     ks = [0, 2, 3, 5]
     n = sum(tot_c[k] for k in ks)
     t_ms = sum(tot_ms[k] for k in ks)
     bytes_per_launch = sum(tot_c[k] * wbytes[k] for k in ks) / max(n, 1)
     avg_s = (t_ms / max(n, 1)) * 1e-3
     achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
-    return dict(bound="hbm", kernel="gemv_kernel<1> (LLM decode weight streaming: qkv, o_proj, gate_up, head)", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+    return dict(bound="hbm", kernel="gemv_kernel<7,R,1> (LLM decode weight streaming: qkv, o_proj, gate_up, head)", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                 unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, bytes_per_launch=int(bytes_per_launch),
                 avg_launch_us=round(avg_s * 1e6, 2), per_kernel=per)
 

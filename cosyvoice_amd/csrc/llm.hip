@@ -46,7 +46,7 @@ static void llm_finalize(cv_llm* m) {
     CV_CHECK(c.hidden % 128 == 0 && c.inter % 128 == 0, "llm: hidden and inter must be multiples of 128");
     CV_CHECK(c.heads % c.kv_heads == 0 && c.heads * 64 % 128 == 0, "llm: bad head configuration (head_dim is fixed at 64)");
     CV_CHECK(c.max_len > 0 && c.max_len <= 4096, "llm: max_len must be in (0, 4096]");
-    CV_CHECK(c.hidden <= 4864 && c.inter <= 4864, "llm: hidden/inter above the GEMV LDS staging limit");
+    CV_CHECK(c.hidden <= 896 && c.heads * 64 <= 5120 && c.inter <= 5120, "llm: hidden must fit one wave-row (<= 896, fused RMSNorm) and inter <= 5120");
     m->V = c.speech_vocab;
     CV_CHECK(m->V > 0 && m->V <= 8192, "llm: speech vocab above the sampler limit");
     m->qkv_dim = (c.heads + 2 * c.kv_heads) * 64;
@@ -153,10 +153,21 @@ struct ProfScope {
     ~ProfScope() { if (!m->profiling) return; (void)hipEventRecord(e1, s); m->prof_events.push_back({cat, {e0, e1}}); }
 };
 
-template <int WAVES>
-static void gemv(const GemvArgs& a, int rows_per_block, hipStream_t s) {
-    const int units = a.mode == 1 ? a.N / 2 : a.N;
-    hipLaunchKernelGGL((gemv_kernel<WAVES>), dim3((units + rows_per_block - 1) / rows_per_block), dim3(WAVES * 64), 0, s, a);
+// picks the instantiation from K (= 128 * steps): <=7 steps -> one wave per 4*ROWS rows; <=40 steps -> 4-way split-K
+static void gemv(const GemvArgs& a, int rows, hipStream_t s) {
+    const int steps = a.K / 128;
+    CV_CHECK(a.K % 128 == 0 && steps >= 1 && steps <= 40, "gemv: K must be a multiple of 128 and at most 5120");
+    const int units = a.mode == 1 ? a.N / 2 : (a.N + rows - 1) / rows;       // 16-lane groups needed
+    const dim3 grid((units + 3) / 4);
+    if (a.mode == 1) rows = 2;
+    if (steps <= 7) {
+        if (rows == 2) hipLaunchKernelGGL((gemv_kernel<7, 2, 1>), grid, dim3(64), 0, s, a);
+        else           hipLaunchKernelGGL((gemv_kernel<7, 1, 1>), grid, dim3(64), 0, s, a);
+    } else {
+        CV_CHECK(!a.gamma, "gemv: fused RMSNorm needs the whole row in one wave (K <= 896)");
+        if (rows == 2) hipLaunchKernelGGL((gemv_kernel<10, 2, 4>), grid, dim3(256), 0, s, a);
+        else           hipLaunchKernelGGL((gemv_kernel<10, 1, 4>), grid, dim3(256), 0, s, a);
+    }
 }
 
 // one token: head + sample, then (unless done) embed + backbone for the sampled token
@@ -164,7 +175,7 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
     const auto& c = m->cfg;
     const DecodeState* st = m->state.as<DecodeState>();
     float* h = m->h.as<float>(); float* qkv = m->qkv.as<float>(); float* at = m->attn.as<float>(); float* act = m->act.as<float>();
-    { ProfScope ps(m, s, 5); gemv<1>(GemvArgs{m->head_w, m->head_b, h, m->logits.as<float>(), m->V, c.hidden, m->norm, c.rms_eps, nullptr, 0, st}, 4, s); }
+    { ProfScope ps(m, s, 5); gemv(GemvArgs{m->head_w, m->head_b, h, m->logits.as<float>(), m->V, c.hidden, m->norm, c.rms_eps, nullptr, 0, st}, 2, s); }
     SampleArgs sa{};
     sa.logits = m->logits.as<float>(); sa.V = m->V; sa.eos = m->sp.eos; sa.n_stop = m->sp.n_stop;
     sa.min_len = m->sp.min_len; sa.max_len = m->sp.max_len; sa.mode = m->sp.mode; sa.top_p = m->sp.top_p; sa.top_k = m->sp.top_k;
@@ -174,13 +185,13 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
     hipLaunchKernelGGL(embed_last_token_kernel, dim3(1), dim3(256), 0, s, m->speech_emb, c.hidden, h, st);
     for (int i = 0; i < c.layers; ++i) {
         const auto& L = m->layers[i];
-        { ProfScope ps(m, s, 0); gemv<1>(GemvArgs{L.wqkv, L.bqkv, h, qkv, m->qkv_dim, c.hidden, L.ln1, c.rms_eps, nullptr, 0, st}, 4, s); }
+        { ProfScope ps(m, s, 0); gemv(GemvArgs{L.wqkv, L.bqkv, h, qkv, m->qkv_dim, c.hidden, L.ln1, c.rms_eps, nullptr, 0, st}, 1, s); }
         AttnDecodeArgs ad{qkv, m->kcache.as<float>() + m->layer_cache() * i, m->vcache.as<float>() + m->layer_cache() * i,
                           m->rope_cos.as<float>(), m->rope_sin.as<float>(), at, c.heads, c.kv_heads, c.max_len, st};
         { ProfScope ps(m, s, 1); hipLaunchKernelGGL(attn_decode_kernel, dim3(c.heads), dim3(256), 0, s, ad); }
-        { ProfScope ps(m, s, 2); gemv<1>(GemvArgs{L.wo, nullptr, at, h, c.hidden, c.heads * 64, nullptr, 0.f, h, 0, st}, 4, s); }
-        { ProfScope ps(m, s, 3); gemv<1>(GemvArgs{L.wgu, nullptr, h, act, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 1, st}, 4, s); }
-        { ProfScope ps(m, s, 4); gemv<4>(GemvArgs{L.wdown, nullptr, act, h, c.hidden, c.inter, nullptr, 0.f, h, 0, st}, 4, s); }
+        { ProfScope ps(m, s, 2); gemv(GemvArgs{L.wo, nullptr, at, h, c.hidden, c.heads * 64, nullptr, 0.f, h, 0, st}, 1, s); }
+        { ProfScope ps(m, s, 3); gemv(GemvArgs{L.wgu, nullptr, h, act, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 1, st}, 2, s); }
+        { ProfScope ps(m, s, 4); gemv(GemvArgs{L.wdown, nullptr, act, h, c.hidden, c.inter, nullptr, 0.f, h, 0, st}, 1, s); }
     }
     hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, s, m->state.as<DecodeState>());
 }

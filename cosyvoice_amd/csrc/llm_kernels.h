@@ -21,8 +21,8 @@ struct DecodeState {       // lives in device memory (one per cv_llm handle)
 // y[n] = epi( sum_k W[n][k] * xn[k] ),  W bf16 [N][K] row-major, K % 128 == 0.
 //   xn = x                      (gamma == nullptr)
 //   xn = rmsnorm(x) * gamma     (Qwen2RMSNorm fused as a prologue: every workgroup recomputes the 896-wide norm)
-// A 16-lane group owns one output row: per step the group reads 256 contiguous bytes of the row (16B per lane).
-// A workgroup = WAVES waves; wave w covers k-steps [w*S/WAVES, (w+1)*S/WAVES) of the same 4 rows (split-K inside the
+// A 16-lane group owns ROWS consecutive output rows: per step the group reads 256 contiguous bytes of a row (16B per lane).
+// A workgroup = WAVES waves; wave w covers k-steps [w*S/WAVES, (w+1)*S/WAVES) of the same 4*ROWS rows (split-K inside the
 // workgroup, combined through LDS in fixed order -> deterministic).
 //   mode 0: y[n] = acc + bias[n] (+ res[n])
 //   mode 1: rows are interleaved (gate_j, up_j); y[j] = silu(gate_j) * up_j          (Qwen2MLP)
@@ -32,70 +32,95 @@ struct GemvArgs {
     const float* gamma; float eps; const float* res; int mode; const DecodeState* st;
 };
 
-template <int WAVES>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Latency structure (batch-1 decode is a chain of ~125 short kernels, each bounded by ONE memory round trip if written so):
+// every lane first issues ALL of its weight loads (ROWS x STEPS x 16 B, non-temporal: each byte is read once per token),
+// then its slice of x (and gamma) straight from L2 into registers — no LDS staging, no barrier before the weights are in
+// flight.  RMSNorm statistics come from a 16-lane shuffle reduction (each group covers the whole row when WAVES == 1).
+template <int STEPS, int ROWS, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
-    __shared__ __attribute__((aligned(16))) float xs[4864];
-    __shared__ float red[16];
-    __shared__ float part[WAVES][8];
+    __shared__ float part[WAVES][4][ROWS];
     if (p.st && p.st->done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
-    constexpr int NT = WAVES * 64;
-    // stage activations (+ fused RMSNorm)
-    float ss = 0.f;
-    for (int k = tid * 4; k < p.K; k += NT * 4) {
-        const float4 v = *reinterpret_cast<const float4*>(p.x + k);
-        *reinterpret_cast<float4*>(&xs[k]) = v;
-        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-    }
-    if (p.gamma) {
-        const float tot = block_sum(ss, red);
-        const float rstd = rsqrtf(tot / (float)p.K + p.eps);
-        for (int k = tid * 4; k < p.K; k += NT * 4) {
-            float4 v = *reinterpret_cast<float4*>(&xs[k]);
-            const float4 g = *reinterpret_cast<const float4*>(p.gamma + k);
-            v.x = v.x * rstd * g.x; v.y = v.y * rstd * g.y; v.z = v.z * rstd * g.z; v.w = v.w * rstd * g.w;
-            *reinterpret_cast<float4*>(&xs[k]) = v;
-        }
-    }
-    __syncthreads();
-
-    const int rows_per_grp = p.mode == 1 ? 2 : 1;
-    const int row0 = (blockIdx.x * 4 + grp) * rows_per_grp;
     const int steps = p.K / 128;
     const int s0 = wave * steps / WAVES, s1 = (wave + 1) * steps / WAVES;
-    float acc[2] = {0.f, 0.f};
-    for (int r = 0; r < rows_per_grp; ++r) {
-        const int row = min(row0 + r, p.N - 1);          // clamp (never break: the group reduction below is a wave collective)
+    const int row0 = (blockIdx.x * 4 + grp) * ROWS;
+
+    u32x4 w[ROWS][STEPS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int row = min(row0 + r, p.N - 1);              // clamp: the reductions below are wave collectives
         const bf16_t* wr = p.W + (long long)row * p.K + sub * 8;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s)
+            w[r][s] = (s0 + s < s1) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + (s0 + s) * 128)) : (u32x4){0u, 0u, 0u, 0u};
+    }
+    float4 xa[STEPS], xb[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        if (s0 + s < s1) {
+            xa[s] = *reinterpret_cast<const float4*>(p.x + (s0 + s) * 128 + sub * 8);
+            xb[s] = *reinterpret_cast<const float4*>(p.x + (s0 + s) * 128 + sub * 8 + 4);
+        } else { xa[s] = make_float4(0.f, 0.f, 0.f, 0.f); xb[s] = xa[s]; }
+    }
+    if (p.gamma) {                                           // fused Qwen2RMSNorm (host guarantees WAVES == 1 here)
+        float ss = 0.f;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s)
+            ss += xa[s].x * xa[s].x + xa[s].y * xa[s].y + xa[s].z * xa[s].z + xa[s].w * xa[s].w +
+                  xb[s].x * xb[s].x + xb[s].y * xb[s].y + xb[s].z * xb[s].z + xb[s].w * xb[s].w;
+        ss = group16_sum(ss);
+        const float rstd = rsqrtf(ss / (float)p.K + p.eps);
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            if (s0 + s < s1) {
+                const float4 ga = *reinterpret_cast<const float4*>(p.gamma + (s0 + s) * 128 + sub * 8);
+                const float4 gb = *reinterpret_cast<const float4*>(p.gamma + (s0 + s) * 128 + sub * 8 + 4);
+                xa[s].x = xa[s].x * rstd * ga.x; xa[s].y = xa[s].y * rstd * ga.y; xa[s].z = xa[s].z * rstd * ga.z; xa[s].w = xa[s].w * rstd * ga.w;
+                xb[s].x = xb[s].x * rstd * gb.x; xb[s].y = xb[s].y * rstd * gb.y; xb[s].z = xb[s].z * rstd * gb.z; xb[s].w = xb[s].w * rstd * gb.w;
+            }
+        }
+    }
+    float acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
         float a = 0.f;
-#pragma unroll 8
-        for (int s = s0; s < s1; ++s) {
-            const uint4 u = *reinterpret_cast<const uint4*>(wr + s * 128);
-            const float4 x0 = *reinterpret_cast<const float4*>(&xs[s * 128 + sub * 8]);
-            const float4 x1 = *reinterpret_cast<const float4*>(&xs[s * 128 + sub * 8 + 4]);
-            a += __uint_as_float(u.x << 16) * x0.x;          a += __uint_as_float(u.x & 0xffff0000u) * x0.y;
-            a += __uint_as_float(u.y << 16) * x0.z;          a += __uint_as_float(u.y & 0xffff0000u) * x0.w;
-            a += __uint_as_float(u.z << 16) * x1.x;          a += __uint_as_float(u.z & 0xffff0000u) * x1.y;
-            a += __uint_as_float(u.w << 16) * x1.z;          a += __uint_as_float(u.w & 0xffff0000u) * x1.w;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const u32x4 u = w[r][s];
+            a += __uint_as_float(u[0] << 16) * xa[s].x;          a += __uint_as_float(u[0] & 0xffff0000u) * xa[s].y;
+            a += __uint_as_float(u[1] << 16) * xa[s].z;          a += __uint_as_float(u[1] & 0xffff0000u) * xa[s].w;
+            a += __uint_as_float(u[2] << 16) * xb[s].x;          a += __uint_as_float(u[2] & 0xffff0000u) * xb[s].y;
+            a += __uint_as_float(u[3] << 16) * xb[s].z;          a += __uint_as_float(u[3] & 0xffff0000u) * xb[s].w;
         }
         acc[r] = group16_sum(a);
     }
-    if (WAVES > 1) {
-        if (sub == 0) { part[wave][grp * 2] = acc[0]; part[wave][grp * 2 + 1] = acc[1]; }
+    if (WAVES > 1) {                                         // split-K inside the workgroup, combined in fixed order
+        if (sub == 0) {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) part[wave][grp][r] = acc[r];
+        }
         __syncthreads();
         if (wave != 0) return;
-        acc[0] = 0.f; acc[1] = 0.f;
-        for (int w = 0; w < WAVES; ++w) { acc[0] += part[w][grp * 2]; acc[1] += part[w][grp * 2 + 1]; }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { float t = 0.f; for (int ww = 0; ww < WAVES; ++ww) t += part[ww][grp][r]; acc[r] = t; }
     }
     if (sub != 0) return;
-    if (p.mode == 1) {
+    if (p.mode == 1) {                                       // ROWS == 2: (gate_j, up_j)
         const int j = blockIdx.x * 4 + grp;
-        if (row0 + 1 < p.N) { const float g = acc[0]; p.y[j] = (g / (1.f + expf(-g))) * acc[1]; }
-    } else if (row0 < p.N) {
-        float v = acc[0];
-        if (p.bias) v += p.bias[row0];
-        if (p.res) v += p.res[row0];
-        p.y[row0] = v;
+        if (row0 + 1 < p.N) { const float g = acc[0]; p.y[j] = (g / (1.f + expf(-g))) * acc[ROWS - 1]; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int row = row0 + r;
+            if (row < p.N) {
+                float v = acc[r];
+                if (p.bias) v += p.bias[row];
+                if (p.res) v += p.res[row];
+                p.y[row] = v;
+            }
+        }
     }
 }
 

@@ -111,7 +111,7 @@ class CausalMaskedDiffWithXvec:
     @torch.inference_mode()
     def inference(self, token, token_len, prompt_token, prompt_token_len, prompt_feat, prompt_feat_len, embedding, streaming, finalize):
         assert token.shape[0] == 1
-        ids = self.lib.hook(torch.cat([prompt_token.reshape(-1), token.reshape(-1)]).to(self.device, torch.int32).clamp(min=0).contiguous())
+        ids = self.lib.hook(torch.cat([prompt_token.reshape(-1).to(self.device, torch.int32), token.reshape(-1).to(self.device, torch.int32)]).clamp(min=0).contiguous())
         n_tok = ids.numel()
         pf = self.lib.hook(prompt_feat.to(self.device, torch.float32).contiguous())
         mel_len1 = prompt_feat.shape[1]

@@ -73,7 +73,7 @@ class Qwen2LM:
 
     # ---- lm_input = [sos | embed_tokens(prompt_text ++ text) | task_id | speech_embedding(prompt)]  (llm.py:472-494)
     def build_lm_input(self, text, prompt_text, prompt_speech_token, stream=None):
-        ids_text = self.lib.hook(torch.cat([prompt_text, text], dim=1).reshape(-1).to(self.device, torch.int32))
+        ids_text = self.lib.hook(torch.cat([prompt_text.reshape(-1).to(self.device, torch.int32), text.reshape(-1).to(self.device, torch.int32)]).contiguous())
         ids_sp = self.lib.hook(prompt_speech_token.reshape(-1).to(self.device, torch.int32))
         n_t, n_s, H = ids_text.numel(), ids_sp.numel(), self.cfg.hidden
         L0 = 1 + n_t + 1 + n_s
