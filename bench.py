@@ -23,6 +23,13 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+_T0 = time.time()
+
+
+def log(msg):
+    print("[bench %7.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
+
+
 N_GEN, N_TEXT, N_PROMPT_TEXT, N_PROMPT_TOK = 250, 30, 12, 87
 AUDIO_S = N_GEN / 25.0
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -117,7 +124,7 @@ def cpu_baseline(cfgs):
     from oracle import flow as OF, hift as OH, llm as OL      # the ONLY place bench.py touches oracle/: the reported CPU baseline
     from cosyvoice_amd import synthetic as W
     lc, fc, hc = cfgs
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)       # more OpenMP threads than that only adds barrier cost on these small ops
     torch.set_num_threads(cores)
     u = W.synthetic_utterance(lc, fc, n_prompt_tok=N_PROMPT_TOK, n_prompt_text=N_PROMPT_TEXT, n_text=N_TEXT)
     with torch.inference_mode():
@@ -161,7 +168,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--first-chunk-reps", type=int, default=5)
+    ap.add_argument("--first-chunk-reps", type=int, default=3)
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -175,8 +182,10 @@ def main():
         dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     model, u, cfgs = build_model()
+    log("model built")
     for _ in range(args.warmup):
         one_utterance(model, u)
+    log("warmup done")
 
     def barrier():
         if dist is not None:
@@ -196,6 +205,7 @@ def main():
 
     if rank == 0:
         value = world * args.steps * AUDIO_S / elapsed
+        log("timed region: %.3f s for %d steps -> %.2f audio_s/s" % (elapsed, args.steps, value))
         out = {
             "metric": "audio-sec/s (RTF^-1), CosyVoice2-0.5B zero-shot", "value": round(value, 3), "unit": "audio_s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -208,7 +218,9 @@ def main():
         }
         if world == 1:
             out["first_chunk_ms_p50"] = round(first_chunk_latency(model, u, args.first_chunk_reps), 2)
+            log("first chunk p50 %.1f ms" % out["first_chunk_ms_p50"])
             out["roofline"] = roofline_llm(model, u, cfgs)
+            log("roofline done")
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(cfgs)
         print(json.dumps(out), flush=True)

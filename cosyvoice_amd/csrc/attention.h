@@ -65,8 +65,10 @@ static __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
 #pragma unroll
     for (int d = 0; d < 4; ++d) acc[d] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    for (int kt0 = 0; kt0 < kend; kt0 += BKV) {
-        // stage K and V tiles (64 keys x 64 dims each), zero-filled past Tk
+    // K/V tiles go global -> registers -> LDS; the NEXT tile's loads are issued right after the current tile is parked in LDS,
+    // so they are in flight under the 128 MFMAs + softmax of the current tile (one workgroup per CU: nothing else hides them).
+    float4 rk[4], rv[4];
+    auto load_kv = [&](int kt0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int vv = tid + i * 256, row = vv >> 4, c4 = (vv & 15) * 4;
@@ -76,10 +78,19 @@ static __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
                 kx = *reinterpret_cast<const float4*>(kb + (long long)key * p.k_row + c4);
                 vx = *reinterpret_cast<const float4*>(vb + (long long)key * p.v_row + c4);
             }
-            *reinterpret_cast<float4*>(&Ks[row * LD + c4]) = kx;
-            *reinterpret_cast<float4*>(&Vs[row * LD + c4]) = vx;
+            rk[i] = kx; rv[i] = vx;
+        }
+    };
+    if (kend > 0) load_kv(0);
+    for (int kt0 = 0; kt0 < kend; kt0 += BKV) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int vv = tid + i * 256, row = vv >> 4, c4 = (vv & 15) * 4;
+            *reinterpret_cast<float4*>(&Ks[row * LD + c4]) = rk[i];
+            *reinterpret_cast<float4*>(&Vs[row * LD + c4]) = rv[i];
         }
         __syncthreads();
+        if (kt0 + BKV < kend) load_kv(kt0 + BKV);
 
         // scores: s[kt][r] <-> key kt0 + kt*16 + lg*4 + r, query lq
         v4f s[4];

@@ -35,11 +35,14 @@ struct GemmConvArgs {
     int accumulate;                 // C += result
 };
 
-template <int BM, int BN, bool WBF16>
+// Pipeline: most GEMMs on this path are small (M ~ 10^3, K = 256..1024) and run ~1 workgroup per CU, so nothing hides global
+// latency but the kernel itself: a 2-deep REGISTER prefetch ring keeps the loads of k-tiles it+1 and it+2 in flight while tile
+// it is multiplied out of LDS, and the small tiles use BK = 64 to halve the number of barrier-separated iterations.
+template <int BM, int BN, int BK, bool WBF16>
 __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
-    constexpr int BK = 32, LD = BK + 4;
+    constexpr int LD = BK + 4, KV = BK / 4;         // float4 groups per tile row
     constexpr int TM = BM / 32, TN = BN / 32;       // 16x16 tiles per wave (wave tile = BM/2 x BN/2)
-    constexpr int AV = BM / 32, WV = BN / 32;       // float4 groups per thread per k-step
+    constexpr int AV = BM * KV / 256, WV = BN * KV / 256;   // float4 groups per thread per k-step
     __shared__ __attribute__((aligned(16))) float As[BM * LD];
     __shared__ __attribute__((aligned(16))) float Ws[BN * LD];
 
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
     const int wm = wave & 1, wn = wave >> 1;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, b = blockIdx.z;
     const float* Ab = p.A + (long long)b * p.a_batch;
-    const int kchunks = p.Kp / BK;
+    const int kchunks = (p.Kp + BK - 1) / BK;
     const int nit = p.taps * kchunks;
     const long long ldw = p.ldw ? p.ldw : (long long)p.taps * p.Kp;
     const long long wb = (long long)b * p.w_batch;
@@ -58,14 +61,13 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    float4 ra[AV];
-    float4 rw[WV];
+    float4 ra0[AV], rw0[WV], ra1[AV], rw1[WV];
 
-    auto load_tile = [&](int it) {
+    auto load_tile = [&](int it, float4 (&ra)[AV], float4 (&rw)[WV]) {
         const int tap = it / kchunks, k0 = (it - tap * kchunks) * BK;
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
-            const int v = tid + i * 256, row = v >> 3, kk = k0 + (v & 7) * 4;
+            const int v = tid + i * 256, row = v / KV, kk = k0 + (v % KV) * 4;
             const int m = m0 + row;
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < p.M && kk < p.K) {
@@ -97,35 +99,31 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
-            const int v = tid + i * 256, row = v >> 3, kk = k0 + (v & 7) * 4;
+            const int v = tid + i * 256, row = v / KV, kk = k0 + (v % KV) * 4;
             int n = n0 + row; n = n < p.N ? n : p.N - 1;
-            const long long idx = wb + (long long)n * ldw + (long long)tap * p.Kp + kk;
-            if (WBF16) {
-                const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.W) + idx);
-                rw[i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
-                                    __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
-            } else {
-                rw[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.W) + idx);
+            float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kk < p.Kp) {                                    // Kp is a multiple of 32: the last BK=64 step may be half empty
+                const long long idx = wb + (long long)n * ldw + (long long)tap * p.Kp + kk;
+                if (WBF16) {
+                    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.W) + idx);
+                    wv = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                     __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+                } else {
+                    wv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.W) + idx);
+                }
             }
+            rw[i] = wv;
         }
     };
-
-    load_tile(0);
-    for (int it = 0; it < nit; ++it) {
+    auto store_tile = [&](const float4 (&ra)[AV], const float4 (&rw)[WV]) {
 #pragma unroll
-        for (int i = 0; i < AV; ++i) {
-            const int v = tid + i * 256;
-            *reinterpret_cast<float4*>(&As[(v >> 3) * LD + (v & 7) * 4]) = ra[i];
-        }
+        for (int i = 0; i < AV; ++i) { const int v = tid + i * 256; *reinterpret_cast<float4*>(&As[(v / KV) * LD + (v % KV) * 4]) = ra[i]; }
 #pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int v = tid + i * 256;
-            *reinterpret_cast<float4*>(&Ws[(v >> 3) * LD + (v & 7) * 4]) = rw[i];
-        }
-        __syncthreads();
-        if (it + 1 < nit) load_tile(it + 1);   // global loads stay in flight under the MFMAs
+        for (int i = 0; i < WV; ++i) { const int v = tid + i * 256; *reinterpret_cast<float4*>(&Ws[(v / KV) * LD + (v % KV) * 4]) = rw[i]; }
+    };
+    auto compute_tile = [&]() {
 #pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
+        for (int kg = 0; kg < BK / 16; ++kg) {
             float4 af[TM], wf[TN];
             const int kc = kg * 16 + (lane >> 4) * 4;
 #pragma unroll
@@ -145,7 +143,23 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j].w, af[i].w, acc[i][j], 0, 0, 0);
                 }
         }
+    };
+
+    load_tile(0, ra0, rw0);
+    if (nit > 1) load_tile(1, ra1, rw1);
+    for (int it = 0; it < nit; it += 2) {
+        store_tile(ra0, rw0);
         __syncthreads();
+        if (it + 2 < nit) load_tile(it + 2, ra0, rw0);        // stays in flight through this AND the next iteration
+        compute_tile();
+        __syncthreads();
+        if (it + 1 < nit) {
+            store_tile(ra1, rw1);
+            __syncthreads();
+            if (it + 3 < nit) load_tile(it + 3, ra1, rw1);
+            compute_tile();
+            __syncthreads();
+        }
     }
 
     // epilogue: lane holds C[m][n..n+3] with m = ..+(lane&15), n = ..+(lane>>4)*4   (W rows were the MFMA "A")

@@ -4,11 +4,11 @@
 
 namespace cv {
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 static void launch_cfg(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t stream) {
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, batch), block(256);
-    if (w_bf16) hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, true>), grid, block, 0, stream, a);
-    else        hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, false>), grid, block, 0, stream, a);
+    if (w_bf16) hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, true>), grid, block, 0, stream, a);
+    else        hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, false>), grid, block, 0, stream, a);
 }
 
 void launch_gemm_conv(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t stream) {
@@ -23,11 +23,11 @@ void launch_gemm_conv(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t
         if (blocks >= 240) { pick = c; break; }
     }
     switch (pick) {
-        case 0: launch_cfg<128, 128>(a, w_bf16, batch, stream); break;
-        case 1: launch_cfg<128, 64>(a, w_bf16, batch, stream); break;
-        case 2: launch_cfg<64, 64>(a, w_bf16, batch, stream); break;
-        case 3: launch_cfg<32, 64>(a, w_bf16, batch, stream); break;
-        default: launch_cfg<32, 32>(a, w_bf16, batch, stream); break;
+        case 0: launch_cfg<128, 128, 32>(a, w_bf16, batch, stream); break;
+        case 1: launch_cfg<128, 64, 32>(a, w_bf16, batch, stream); break;
+        case 2: launch_cfg<64, 64, 64>(a, w_bf16, batch, stream); break;
+        case 3: launch_cfg<32, 64, 64>(a, w_bf16, batch, stream); break;
+        default: launch_cfg<32, 32, 64>(a, w_bf16, batch, stream); break;
     }
 }
 

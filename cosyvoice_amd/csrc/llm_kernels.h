@@ -41,7 +41,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int STEPS, int ROWS, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     __shared__ float part[WAVES][4][ROWS];
-    if (p.st && p.st->done) return;
+    // no `done` test here: it would put a dependent load in front of the weight stream; a finished request simply recomputes
+    // into buffers nobody reads (sample / embed / advance are the kernels that honour `done`).
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
     const int steps = p.K / 128;
     const int s0 = wave * steps / WAVES, s1 = (wave + 1) * steps / WAVES;
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
 // ---------------------------------------------------------------------------------------------------------------
 // Decode attention for one new position (GQA, head_dim 64), fused with rotate-half RoPE on q/k and the KV-cache append.
 // One workgroup per query head.  qkv = [q(H*64) | k(Hkv*64) | v(Hkv*64)] raw projections (+bias) of the new token.
+// Context length limit: 2048 keys (LDS score buffer).
 // cache layout: K,V [Hkv][max_len][64] fp32.  rope table: cos/sin [max_len][32].
 // ---------------------------------------------------------------------------------------------------------------
 struct AttnDecodeArgs {
@@ -134,20 +136,36 @@ struct AttnDecodeArgs {
     float* out; int heads, kv_heads, max_len; const DecodeState* st;
 };
 
-static __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs p) {
+// 1024 threads = 16 waves; a 16-lane group covers one key row with float4 loads, a wave 4 x 4 = 16 keys, the workgroup 512 keys
+// per pass (2 slabs of 256).  All K rows of a pass are requested right after `pos` is known (one memory round trip, not one per iteration); the V
+// rows are requested as soon as the scores are done, so that round trip overlaps the two softmax block-reductions.
+// (1024 threads cap a lane at 128 VGPRs, hence K and V share the same 8 float4 registers.)
+static __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnDecodeArgs p) {
     __shared__ __attribute__((aligned(16))) float qs[64];
     __shared__ __attribute__((aligned(16))) float knew[64];
-    __shared__ float sc[4096];
+    __shared__ float sc[2048];
     __shared__ float red[16];
-    __shared__ __attribute__((aligned(16))) float op[4][64];
-    if (p.st->done) return;
+    __shared__ __attribute__((aligned(16))) float op[16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane & 15, kk = lane >> 4;
     const int h = blockIdx.x, g = h / (p.heads / p.kv_heads);
     const int pos = p.st->pos;                       // the new token sits at index `pos`
+    const int L = pos + 1, npass = (L + 511) >> 9;
     const float* kq = p.qkv + p.heads * 64 + g * 64;
     const float* vq = p.qkv + (p.heads + p.kv_heads) * 64 + g * 64;
     float* kc = p.kcache + (long long)g * p.max_len * 64;
     float* vc = p.vcache + (long long)g * p.max_len * 64;
+    float4 r[2][4];
+    auto load_rows = [&](const float* base, int ps) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = ps * 512 + sl * 256 + wave * 16 + u * 4 + kk;
+                r[sl][u] = (j < pos) ? *reinterpret_cast<const float4*>(base + (long long)j * 64 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+    };
+    load_rows(kc, 0);
     if (tid < 64) {
         const int d = tid, f = d & 31;
         const float c = p.rope_cos[pos * 32 + f], s = p.rope_sin[pos * 32 + f];
@@ -157,57 +175,57 @@ static __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs 
         const float kr = d < 32 ? -kq[d + 32] : kq[d - 32];
         const float kn = kq[d] * c + kr * s;
         knew[d] = kn;
-        if (h % (p.heads / p.kv_heads) == 0) { kc[(long long)pos * 64 + d] = kn; vc[(long long)pos * 64 + d] = vq[d]; }
+        if (!p.st->done && h % (p.heads / p.kv_heads) == 0) { kc[(long long)pos * 64 + d] = kn; vc[(long long)pos * 64 + d] = vq[d]; }
     }
     __syncthreads();
-    // A 16-lane group covers one key row with float4 loads; a wave covers 4 keys per load slot and issues 4 independent
-    // slots per iteration (16 keys / wave, 64 keys / workgroup in flight) so the loop is bandwidth- not latency-paced.
-    const int sub = lane & 15, kk = lane >> 4;
     const float4 q4 = *reinterpret_cast<const float4*>(&qs[sub * 4]);
     const float4 kn4 = *reinterpret_cast<const float4*>(&knew[sub * 4]);
-    const int L = pos + 1;
-    for (int j0 = wave * 16; j0 < L; j0 += 64) {
-        float4 k4[4];
+    const float4 vn4 = *reinterpret_cast<const float4*>(vq + sub * 4);
+    for (int ps = 0; ps < npass; ++ps) {
+        if (ps > 0) load_rows(kc, ps);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u * 4 + kk;
-            k4[u] = (j < pos) ? *reinterpret_cast<const float4*>(kc + (long long)j * 64 + sub * 4) : kn4;
-        }
+        for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u * 4 + kk;
-            float a = q4.x * k4[u].x + q4.y * k4[u].y + q4.z * k4[u].z + q4.w * k4[u].w;
-            a = group16_sum(a);
-            if (sub == 0 && j < L) sc[j] = a * 0.125f;
-        }
+            for (int u = 0; u < 4; ++u) {
+                const int j = ps * 512 + sl * 256 + wave * 16 + u * 4 + kk;
+                const float4 k4 = (j == pos) ? kn4 : r[sl][u];
+                float a = q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+                a = group16_sum(a);
+                if (sub == 0 && j < L) sc[j] = a * 0.125f;
+            }
     }
+    load_rows(vc, 0);                                // in flight during the softmax reductions
     __syncthreads();
     float m = -__builtin_huge_valf();
-    for (int j = tid; j < L; j += 256) m = fmaxf(m, sc[j]);
+    for (int j = tid; j < L; j += 1024) m = fmaxf(m, sc[j]);
     m = block_max(m, red);
     float s = 0.f;
-    for (int j = tid; j < L; j += 256) { const float e = expf(sc[j] - m); sc[j] = e; s += e; }
+    for (int j = tid; j < L; j += 1024) { const float e = expf(sc[j] - m); sc[j] = e; s += e; }
     s = block_sum(s, red);
     __syncthreads();
-    // out[d] = sum_j p_j V[j][d]: same (16 lanes x float4) x 4 keys x 4 slots tiling, reduced over the key lanes by shuffles
-    const float4 vn4 = *reinterpret_cast<const float4*>(vq + sub * 4);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j0 = wave * 16; j0 < L; j0 += 64) {
-        float4 v4[4]; float pj[4];
+    for (int ps = 0; ps < npass; ++ps) {
+        if (ps > 0) load_rows(vc, ps);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u * 4 + kk;
-            v4[u] = (j < pos) ? *reinterpret_cast<const float4*>(vc + (long long)j * 64 + sub * 4) : vn4;
-            pj[u] = j < L ? sc[j] : 0.f;
-        }
+        for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { acc.x += pj[u] * v4[u].x; acc.y += pj[u] * v4[u].y; acc.z += pj[u] * v4[u].z; acc.w += pj[u] * v4[u].w; }
+            for (int u = 0; u < 4; ++u) {
+                const int j = ps * 512 + sl * 256 + wave * 16 + u * 4 + kk;
+                const float4 v4 = (j == pos) ? vn4 : r[sl][u];
+                const float pj = j < L ? sc[j] : 0.f;
+                acc.x += pj * v4.x; acc.y += pj * v4.y; acc.z += pj * v4.z; acc.w += pj * v4.w;
+            }
     }
     acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
     acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
     if (kk == 0) *reinterpret_cast<float4*>(&op[wave][sub * 4]) = acc;
     __syncthreads();
-    if (wave == 0) p.out[h * 64 + lane] = (op[0][lane] + op[1][lane] + op[2][lane] + op[3][lane]) / s;
+    if (tid < 64) {
+        float o = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) o += op[w][tid];
+        p.out[h * 64 + tid] = o / s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

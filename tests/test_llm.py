@@ -97,3 +97,19 @@ def test_kv_capacity_is_checked(lib, tiny_sd):
     lm = Qwen2LM(sd, cfg, lib=lib, max_len=32, sampling="greedy")
     with pytest.raises(ValueError):
         list(lm.inference(**_kw(u), max_token_text_ratio=20))
+
+
+def test_long_context_multi_pass_attention(lib, tiny_sd):
+    """Contexts > 512 keys take the multi-pass branch of attn_decode_kernel (and > 64-row tiles of the prefill attention)."""
+    cfg, sd = tiny_sd
+    u = _utt(cfg, n_text=3, n_prompt_text=2, n_prompt_tok=560, seed=11)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=640, sampling="greedy", decode_chunk=4)
+    got = list(lm.inference(**_kw(u), max_token_text_ratio=4, min_token_text_ratio=2))
+    trace = {}
+    want = OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=4, min_token_text_ratio=2, trace=trace)
+    assert got == want and len(got) >= 1
+    lm.prefill(lm.build_lm_input(u["text"], u["prompt_text"], u["llm_prompt_speech_token"]))
+    sp = lm.make_sampling(6, 12)
+    for i in range(min(2, len(trace["logp"]))):               # step 1 attends over 567 keys: second attention pass
+        lm.decode(1, sp)
+        torch.testing.assert_close(lm.last_logits().log_softmax(-1), trace["logp"][i], rtol=1e-4, atol=1e-4)
