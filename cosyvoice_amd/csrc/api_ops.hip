@@ -10,7 +10,8 @@ void gemm_conv(GemmConvArgs a, bool w_bf16, int batch, hipStream_t s) {
     CV_CHECK(a.Kp % 32 == 0 && a.Kp >= a.K, "gemm_conv: Kp must be K rounded up to 32");
     CV_CHECK(aligned16(a.W) && a.ldw % 4 == 0 && a.w_batch % 4 == 0, "gemm_conv: W must be 16B aligned (base, row pitch, batch offset)");
     a.a_vec = aligned16(a.A) && (a.lda % 4 == 0) && (a.a_off0 % 4 == 0) && (a.tap_step % 4 == 0) &&
-              (a.a_batch % 4 == 0) && (a.a_len % 4 == 0);
+              (a.a_batch % 4 == 0) && (a.a_len % 4 == 0) && (a.K % 4 == 0) && a.a_len >= 4;
+    CV_CHECK(a.a_len >= 1, "gemm_conv: empty A operand");
     a.c_vec = aligned16(a.C) && (a.ldc % 4 == 0) && (a.c_off % 4 == 0) && (a.c_batch % 4 == 0) && (a.c_len % 4 == 0) &&
               (!a.bias || aligned16(a.bias)) && (!a.res || (aligned16(a.res) && a.res_batch % 4 == 0));
     if (a.pro == ACT_SNAKE) CV_CHECK(a.pro_alpha && aligned16(a.pro_alpha), "gemm_conv: snake prologue needs 16B aligned alpha[Kp]");

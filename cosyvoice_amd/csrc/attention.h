@@ -73,11 +73,11 @@ static __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
         for (int i = 0; i < 4; ++i) {
             const int vv = tid + i * 256, row = vv >> 4, c4 = (vv & 15) * 4;
             const int key = kt0 + row;
-            float4 kx = make_float4(0.f, 0.f, 0.f, 0.f), vx = kx;
-            if (key < p.Tk) {
-                kx = *reinterpret_cast<const float4*>(kb + (long long)key * p.k_row + c4);
-                vx = *reinterpret_cast<const float4*>(vb + (long long)key * p.v_row + c4);
-            }
+            const bool ok = key < p.Tk;                       // unconditional loads (clamped row) keep the vmcnt bookkeeping exact
+            const long long kr = ok ? key : 0;
+            float4 kx = *reinterpret_cast<const float4*>(kb + kr * p.k_row + c4);
+            float4 vx = *reinterpret_cast<const float4*>(vb + kr * p.v_row + c4);
+            if (!ok) { kx = make_float4(0.f, 0.f, 0.f, 0.f); vx = kx; }
             rk[i] = kx; rv[i] = vx;
         }
     };

@@ -19,23 +19,29 @@ enum Act : int {
     ACT_MISH = 6, ACT_ABS = 7, ACT_SNAKE = 8,
 };
 
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
-
-__device__ __forceinline__ float apply_act(int act, float v, float p) {
+// The transcendental-heavy activations are deliberately NOT inlined: libm's erff / tanhf / log1pf / expm1f / sinf expand to
+// hundreds of instructions each, and inlining them at every unrolled epilogue / prologue site made the GEMM kernels 20-90 K
+// instructions long (instruction-cache thrash: ~2.5 us per k-iteration whatever the tile).  One out-of-line copy per kernel.
+__device__ __noinline__ float act_slow(int act, float v) {
     switch (act) {
-        case ACT_SILU: return v / (1.f + expf(-v));
         case ACT_GELU_ERF: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
         case ACT_ELU: return v > 0.f ? v : expm1f(v);
-        case ACT_LEAKY: return v > 0.f ? v : v * p;
         case ACT_TANH: return tanhf(v);
-        case ACT_MISH: return v * tanhf(softplus_f(v));
-        case ACT_ABS: return fabsf(v);
+        case ACT_MISH: { const float sp = v > 20.f ? v : log1pf(expf(v)); return v * tanhf(sp); }
+        case ACT_SILU: return v / (1.f + expf(-v));
         default: return v;
     }
 }
 
+__device__ __forceinline__ float apply_act(int act, float v, float p) {
+    if (act == ACT_NONE) return v;
+    if (act == ACT_LEAKY) return v > 0.f ? v : v * p;
+    if (act == ACT_ABS) return fabsf(v);
+    return act_slow(act, v);
+}
+
 // Snake(x) = x + sin^2(alpha x) / (alpha + 1e-9)   (reference: cosyvoice/transformer/activation.py:73-84)
-__device__ __forceinline__ float snake_f(float x, float alpha) {
+__device__ __noinline__ float snake_f(float x, float alpha) {
     float s = sinf(x * alpha);
     return x + (1.0f / (alpha + 1e-9f)) * s * s;
 }

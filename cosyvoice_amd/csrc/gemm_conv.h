@@ -38,7 +38,7 @@ struct GemmConvArgs {
 // Pipeline: most GEMMs on this path are small (M ~ 10^3, K = 256..1024) and run ~1 workgroup per CU, so nothing hides global
 // latency but the kernel itself: a 2-deep REGISTER prefetch ring keeps the loads of k-tiles it+1 and it+2 in flight while tile
 // it is multiplied out of LDS, and the small tiles use BK = 64 to halve the number of barrier-separated iterations.
-template <int BM, int BN, int BK, bool WBF16>
+template <int BM, int BN, int BK, bool WBF16, bool AVEC>
 __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
     constexpr int LD = BK + 4, KV = BK / 4;         // float4 groups per tile row
     constexpr int TM = BM / 32, TN = BN / 32;       // 16x16 tiles per wave (wave tile = BM/2 x BN/2)
@@ -63,61 +63,71 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
 
     float4 ra0[AV], rw0[WV], ra1[AV], rw1[WV];
 
+    // Loads are UNCONDITIONAL (clamped address + select): a load inside a divergent branch makes the compiler lose count of the
+    // outstanding vector-memory operations and fall back to s_waitcnt vmcnt(0), which drains the prefetch ring every iteration.
+    // For the same reason the prologue activation is applied when the tile is parked in LDS, not when it is requested.
     auto load_tile = [&](int it, float4 (&ra)[AV], float4 (&rw)[WV]) {
         const int tap = it / kchunks, k0 = (it - tap * kchunks) * BK;
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const int v = tid + i * 256, row = v / KV, kk = k0 + (v % KV) * 4;
             const int m = m0 + row;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < p.M && kk < p.K) {
-                const long long idx = (long long)m * p.lda + p.a_off0 + (long long)tap * p.tap_step + kk;
-                if (p.a_vec && kk + 3 < p.K) {
-                    if (idx >= 0 && idx + 3 < p.a_len) x = *reinterpret_cast<const float4*>(Ab + idx);
-                } else {
-                    float t[4];
+            const long long idx = (long long)m * p.lda + p.a_off0 + (long long)tap * p.tap_step + kk;
+            if (AVEC) {       // K % 4 == 0 and every float4 group is 16B aligned and entirely in or out of [0, a_len)
+                const bool ok = m < p.M && kk < p.K && idx >= 0 && idx + 3 < p.a_len;
+                float4 x = *reinterpret_cast<const float4*>(Ab + (ok ? idx : 0));
+                if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
+                ra[i] = x;
+            } else {
+                float t[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const long long ie = idx + e;
-                        t[e] = (kk + e < p.K && ie >= 0 && ie < p.a_len) ? Ab[ie] : 0.f;
-                    }
-                    x = make_float4(t[0], t[1], t[2], t[3]);
+                for (int e = 0; e < 4; ++e) {
+                    const long long ie = idx + e;
+                    const bool ok = m < p.M && kk + e < p.K && ie >= 0 && ie < p.a_len;
+                    const float x = Ab[ok ? ie : 0];
+                    t[e] = ok ? x : 0.f;
                 }
-                if (p.pro == ACT_LEAKY) {
-                    x.x = x.x > 0.f ? x.x : x.x * p.pro_p; x.y = x.y > 0.f ? x.y : x.y * p.pro_p;
-                    x.z = x.z > 0.f ? x.z : x.z * p.pro_p; x.w = x.w > 0.f ? x.w : x.w * p.pro_p;
-                } else if (p.pro == ACT_SNAKE) {
-                    // kk..kk+3 < Kp and pro_alpha is padded to Kp by the host
-                    const float4 al = *reinterpret_cast<const float4*>(p.pro_alpha + kk);
-                    x.x = snake_f(x.x, al.x); x.y = snake_f(x.y, al.y); x.z = snake_f(x.z, al.z); x.w = snake_f(x.w, al.w);
-                } else if (p.pro != ACT_NONE) {                 // any other activation with act(0) == 0 (Mish, SiLU, ...)
-                    x.x = apply_act(p.pro, x.x, p.pro_p); x.y = apply_act(p.pro, x.y, p.pro_p);
-                    x.z = apply_act(p.pro, x.z, p.pro_p); x.w = apply_act(p.pro, x.w, p.pro_p);
-                }
+                ra[i] = make_float4(t[0], t[1], t[2], t[3]);
             }
-            ra[i] = x;
         }
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const int v = tid + i * 256, row = v / KV, kk = k0 + (v % KV) * 4;
             int n = n0 + row; n = n < p.N ? n : p.N - 1;
-            float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kk < p.Kp) {                                    // Kp is a multiple of 32: the last BK=64 step may be half empty
-                const long long idx = wb + (long long)n * ldw + (long long)tap * p.Kp + kk;
-                if (WBF16) {
-                    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.W) + idx);
-                    wv = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
-                                     __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
-                } else {
-                    wv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.W) + idx);
-                }
+            const bool ok = kk < p.Kp;                          // Kp is a multiple of 32: the last BK=64 step may be half empty
+            const long long idx = wb + (long long)n * ldw + (long long)tap * p.Kp + (ok ? kk : 0);
+            float4 wv;
+            if (WBF16) {
+                const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.W) + idx);
+                wv = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                 __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+            } else {
+                wv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.W) + idx);
             }
+            if (!ok) wv = make_float4(0.f, 0.f, 0.f, 0.f);
             rw[i] = wv;
         }
     };
-    auto store_tile = [&](const float4 (&ra)[AV], const float4 (&rw)[WV]) {
+    auto store_tile = [&](int it, const float4 (&ra)[AV], const float4 (&rw)[WV]) {
+        const int tap = it / kchunks, k0 = (it - tap * kchunks) * BK;
 #pragma unroll
-        for (int i = 0; i < AV; ++i) { const int v = tid + i * 256; *reinterpret_cast<float4*>(&As[(v / KV) * LD + (v % KV) * 4]) = ra[i]; }
+        for (int i = 0; i < AV; ++i) {
+            const int v = tid + i * 256, kk = k0 + (v % KV) * 4;
+            float4 x = ra[i];
+            if (p.pro == ACT_LEAKY) {
+                x.x = x.x > 0.f ? x.x : x.x * p.pro_p; x.y = x.y > 0.f ? x.y : x.y * p.pro_p;
+                x.z = x.z > 0.f ? x.z : x.z * p.pro_p; x.w = x.w > 0.f ? x.w : x.w * p.pro_p;
+            } else if (p.pro == ACT_SNAKE) {
+                if (kk < p.K) {                                 // alpha is padded to Kp by the host; Snake(0) == 0 keeps the zero padding
+                    const float4 al = *reinterpret_cast<const float4*>(p.pro_alpha + kk);
+                    x.x = snake_f(x.x, al.x); x.y = snake_f(x.y, al.y); x.z = snake_f(x.z, al.z); x.w = snake_f(x.w, al.w);
+                }
+            } else if (p.pro != ACT_NONE) {                     // any other activation with act(0) == 0 (Mish, SiLU, ...)
+                x.x = apply_act(p.pro, x.x, p.pro_p); x.y = apply_act(p.pro, x.y, p.pro_p);
+                x.z = apply_act(p.pro, x.z, p.pro_p); x.w = apply_act(p.pro, x.w, p.pro_p);
+            }
+            *reinterpret_cast<float4*>(&As[(v / KV) * LD + (v % KV) * 4]) = x;
+        }
 #pragma unroll
         for (int i = 0; i < WV; ++i) { const int v = tid + i * 256; *reinterpret_cast<float4*>(&Ws[(v / KV) * LD + (v % KV) * 4]) = rw[i]; }
     };
@@ -148,13 +158,13 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
     load_tile(0, ra0, rw0);
     if (nit > 1) load_tile(1, ra1, rw1);
     for (int it = 0; it < nit; it += 2) {
-        store_tile(ra0, rw0);
+        store_tile(it, ra0, rw0);
         __syncthreads();
         if (it + 2 < nit) load_tile(it + 2, ra0, rw0);        // stays in flight through this AND the next iteration
         compute_tile();
         __syncthreads();
         if (it + 1 < nit) {
-            store_tile(ra1, rw1);
+            store_tile(it + 1, ra1, rw1);
             __syncthreads();
             if (it + 3 < nit) load_tile(it + 3, ra1, rw1);
             compute_tile();
@@ -178,28 +188,38 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
             const long long idx = (long long)m * p.ldc + n + p.c_off;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             const bool full = p.c_vec && (n + 3 < p.N) && idx >= 0 && idx + 3 < p.c_len;
+            bool ok[4];
+            float bb[4] = {0.f, 0.f, 0.f, 0.f}, rr[4] = {0.f, 0.f, 0.f, 0.f}, oo[4] = {0.f, 0.f, 0.f, 0.f};
             if (full) {
-                if (p.bias) { const float4 bb = *reinterpret_cast<const float4*>(p.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = apply_act(p.act, v[e], p.act_p);
-                if (Rb) { const float4 r = *reinterpret_cast<const float4*>(Rb + idx); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] * p.out_scale * rs;
-                if (p.accumulate) { const float4 o = *reinterpret_cast<const float4*>(Cb + idx); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
-                *reinterpret_cast<float4*>(Cb + idx) = make_float4(v[0], v[1], v[2], v[3]);
+                ok[0] = ok[1] = ok[2] = ok[3] = true;
+                if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + n); bb[0] = t.x; bb[1] = t.y; bb[2] = t.z; bb[3] = t.w; }
+                if (Rb) { const float4 t = *reinterpret_cast<const float4*>(Rb + idx); rr[0] = t.x; rr[1] = t.y; rr[2] = t.z; rr[3] = t.w; }
+                if (p.accumulate) { const float4 t = *reinterpret_cast<const float4*>(Cb + idx); oo[0] = t.x; oo[1] = t.y; oo[2] = t.z; oo[3] = t.w; }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const long long ie = idx + e;
-                    if (n + e >= p.N || ie < 0 || ie >= p.c_len) continue;
-                    float x = v[e];
-                    if (p.bias) x += p.bias[n + e];
-                    x = apply_act(p.act, x, p.act_p);
-                    if (Rb) x += Rb[ie];
-                    x = x * p.out_scale * rs;
-                    if (p.accumulate) x += Cb[ie];
-                    Cb[ie] = x;
+                    ok[e] = (n + e < p.N) && ie >= 0 && ie < p.c_len;
+                    if (ok[e]) {
+                        if (p.bias) bb[e] = p.bias[n + e];
+                        if (Rb) rr[e] = Rb[ie];
+                        if (p.accumulate) oo[e] = Cb[ie];
+                    }
                 }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bb[e];
+            if (p.act != ACT_NONE) {                         // the only activation site of the epilogue
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(p.act, v[e], p.act_p);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (v[e] + rr[e]) * p.out_scale * rs + oo[e];
+            if (full) {
+                *reinterpret_cast<float4*>(Cb + idx) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (ok[e]) Cb[idx + e] = v[e];
             }
         }
     }

@@ -7,8 +7,13 @@ namespace cv {
 template <int BM, int BN, int BK>
 static void launch_cfg(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t stream) {
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, batch), block(256);
-    if (w_bf16) hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, true>), grid, block, 0, stream, a);
-    else        hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, false>), grid, block, 0, stream, a);
+    if (a.a_vec) {
+        if (w_bf16) hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, true, true>), grid, block, 0, stream, a);
+        else        hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, false, true>), grid, block, 0, stream, a);
+    } else {
+        if (w_bf16) hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, true, false>), grid, block, 0, stream, a);
+        else        hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, false, false>), grid, block, 0, stream, a);
+    }
 }
 
 void launch_gemm_conv(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t stream) {

@@ -26,6 +26,7 @@ using std::min; using std::max;
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ inline __attribute__((noinline))
 #define __shared__ static
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
