@@ -31,8 +31,12 @@ static __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 15, lg = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z, hk = h / p.kv_group;
-    const int qi = blockIdx.x * BQ + wave * 16 + lq;
+    // XCD-aware order: all query tiles of one (batch, head) get consecutive remapped ids, i.e. the same XCD, so that head's K/V
+    // stream through ONE L2 instead of all eight.
+    const int nqb = gridDim.x, nbl = gridDim.x * gridDim.y * gridDim.z;
+    const int bl = xcd_remap((int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x), nbl);
+    const int qb = bl % nqb, h = (bl / nqb) % (int)gridDim.y, b = bl / (nqb * (int)gridDim.y), hk = h / p.kv_group;
+    const int qi = qb * BQ + wave * 16 + lq;
     const bool qvalid = qi < p.Tq;
     const float NEG_INF = -__builtin_huge_valf();
 
@@ -47,7 +51,7 @@ static __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
             qf[dg] = t;
         }
     }
-    const int qmax_blk = min(p.Tq - 1, (int)blockIdx.x * BQ + BQ - 1);
+    const int qmax_blk = min(p.Tq - 1, qb * BQ + BQ - 1);
     int kend = p.Tk;
     if (p.mask_mode == MASK_CAUSAL) kend = min(p.Tk, qmax_blk + (p.Tk - p.Tq) + 1);
     else if (p.mask_mode == MASK_CHUNK) kend = min(p.Tk, (qmax_blk / p.chunk + 1) * p.chunk);

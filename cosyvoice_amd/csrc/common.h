@@ -46,6 +46,14 @@ __device__ __noinline__ float snake_f(float x, float alpha) {
     return x + (1.0f / (alpha + 1e-9f)) * s * s;
 }
 
+// XCD-aware workgroup remap (cdna_hip_programming.md T1): workgroup b runs on XCD b % 8, each XCD has a private 4 MB L2.
+// Returns a bijective index b' such that the workgroups of one XCD get a CONTIGUOUS range of b' — the caller then lays tiles
+// out so that neighbours in b' share their big operand, which therefore crosses the fabric once instead of once per XCD.
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, j = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);

@@ -6,6 +6,8 @@
 // Everything is channel-last fp32 with bf16 (or fp32) weights; the Euler loop, CFG batching and time embeddings stay on
 // the device — the host only enqueues.
 #include <vector>
+#include <map>
+#include <tuple>
 #include <cmath>
 #include "ops.h"
 #include "tensor_map.h"
@@ -46,7 +48,25 @@ struct cv_flow {
     DevBuf t_val, t_sin, t_h, t_emb, t_mlp;                                                   // time embeddings
     DevBuf f_tok, f_h, f_mu, f_spk, f_spkn, f_cond, f_x, f_ones;                              // inference glue
     int enc_cap = 0, est_cap = 0, t_cap = 0, inf_cap = 0;
+    // hipGraph cache of the whole Euler solve, keyed by (T, n_steps, streaming): ~5000 launches per utterance become one replay.
+    // A key is captured the second time it is seen (streaming requests change T every chunk and would only pay the instantiation).
+    bool use_graph = true;
+    std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
+    std::map<std::tuple<int, int, int>, int> seen;
+    hipStream_t own_stream = nullptr;
+    std::vector<float> host_t;
+    ~cv_flow() {
+        for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+    }
 };
+
+// Graph capture is illegal on the legacy default stream: NULL maps to a handle-owned blocking stream (implicitly ordered with it).
+static hipStream_t resolve(cv_flow* m, void* s) {
+    if (s) return as_stream(s);
+    if (!m->own_stream) CV_HIP(hipStreamCreate(&m->own_stream));
+    return m->own_stream;
+}
 
 static Lin get_lin(const cv_flow* m, const std::string& name, int N, int K, int taps, bool bias) {
     Lin l; l.N = N; l.K = K; l.Kp = round_up32(K); l.taps = taps; l.bf16 = m->wbf16;
@@ -214,8 +234,11 @@ static void flow_encoder(cv_flow* m, const float* tok_emb, int T, const float* c
 }
 
 // ---- estimator ---------------------------------------------------------------------------------------------------------
+static void drop_graphs(cv_flow* m) { for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second); m->graphs.clear(); m->seen.clear(); }
+
 static void est_reserve(cv_flow* m, int T) {
     if (T <= m->est_cap) return;
+    drop_graphs(m);                       // captured kernels hold the old workspace addresses
     const auto& c = m->cfg; const size_t R = 2 * (size_t)T, C = c.est_ch, f = 4;
     m->s_in.ensure(R * 4 * c.mel * f); m->s_a.ensure(R * C * f); m->s_b.ensure(R * C * f); m->s_c.ensure(R * C * f); m->s_n.ensure(R * C * f);
     m->s_qkv.ensure(R * 3 * c.est_heads * 64 * f); m->s_att.ensure(R * c.est_heads * 64 * f); m->s_ff.ensure(R * 4 * C * f);
@@ -224,6 +247,7 @@ static void est_reserve(cv_flow* m, int T) {
 }
 static void time_reserve(cv_flow* m, int n) {
     if (n <= m->t_cap) return;
+    drop_graphs(m);
     const auto& c = m->cfg; const size_t tdim = 4 * c.est_ch;
     m->t_val.ensure((size_t)n * 4); m->t_sin.ensure((size_t)n * 4 * c.mel * 4); m->t_h.ensure((size_t)n * tdim * 4); m->t_emb.ensure((size_t)n * tdim * 4);
     m->t_mlp.ensure((size_t)(c.est_mid + 2) * n * c.est_ch * 4);
@@ -318,15 +342,37 @@ static void solve_euler(cv_flow* m, float* x /*[T][mel] in/out*/, const float* m
         t = t + dt;
         if (st < n_steps) dt = span[st + 1] - t;
     }
-    CV_HIP(hipMemcpyAsync(m->t_val.p, tv.data(), (size_t)n_steps * 4, hipMemcpyHostToDevice, s));
-    CV_HIP(hipStreamSynchronize(s));        // tv is a stack vector
-    time_embed(m, n_steps, s);
+    m->host_t = tv;                           // kept alive for the async copy
+    CV_HIP(hipMemcpyAsync(m->t_val.p, m->host_t.data(), (size_t)n_steps * 4, hipMemcpyHostToDevice, s));
     const long long n = (long long)T * c.mel;
-    for (int st = 0; st < n_steps; ++st) {
-        hipLaunchKernelGGL(pack_est_input_kernel, dim3(nblk(2 * n * 4)), dim3(256), 0, s, x, mu, spk, cond, m->s_in.as<float>(), T, c.mel, 1);
-        estimator_forward(m, T, st, n_steps, true, streaming, s);
-        hipLaunchKernelGGL(cfg_euler_kernel, dim3(nblk(n)), dim3(256), 0, s, x, m->s_out.as<float>(), n, dts[st], c.cfg_rate);
+    auto body = [&]() {
+        time_embed(m, n_steps, s);
+        for (int st = 0; st < n_steps; ++st) {
+            hipLaunchKernelGGL(pack_est_input_kernel, dim3(nblk(2 * n * 4)), dim3(256), 0, s, x, mu, spk, cond, m->s_in.as<float>(), T, c.mel, 1);
+            estimator_forward(m, T, st, n_steps, true, streaming, s);
+            hipLaunchKernelGGL(cfg_euler_kernel, dim3(nblk(n)), dim3(256), 0, s, x, m->s_out.as<float>(), n, dts[st], c.cfg_rate);
+        }
+    };
+    const auto key = std::make_tuple(T, n_steps, streaming ? 1 : 0);
+    auto it = m->graphs.find(key);
+    if (m->use_graph && it != m->graphs.end() && x == m->f_x.as<float>()) {
+        CV_HIP(hipGraphLaunch(it->second, s));
+        return;
     }
+    // buffers may have been re-allocated by *_reserve since a capture: graphs are dropped whenever a workspace grows (see est_reserve)
+    if (m->use_graph && x == m->f_x.as<float>() && ++m->seen[key] == 2) {
+        if (m->graphs.size() >= 8) { for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second); m->graphs.clear(); }
+        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+        CV_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        body();
+        CV_HIP(hipStreamEndCapture(s, &g));
+        CV_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        CV_HIP(hipGraphDestroy(g));
+        m->graphs[key] = ge;
+        CV_HIP(hipGraphLaunch(ge, s));
+        return;
+    }
+    body();
 }
 
 extern "C" {
@@ -338,6 +384,13 @@ int cv_flow_set_tensor(cv_flow* m, const char* name, const void* dev_ptr, int32_
     return guarded([&] { CV_CHECK(m, "null handle"); m->tm.set(name, dev_ptr, dtype, numel); });
 }
 int cv_flow_finalize(cv_flow* m) { return guarded([&] { CV_CHECK(m, "null handle"); flow_finalize(m); }); }
+int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
+    return guarded([&] {
+        CV_CHECK(m && name, "null argument");
+        if (std::string(name) == "use_graph") { m->use_graph = value != 0; drop_graphs(m); }
+        else throw Error(std::string("unknown option ") + name);
+    });
+}
 void cv_flow_destroy(cv_flow* m) { delete m; }
 
 int cv_flow_encoder(cv_flow* m, const float* tok_emb, int32_t n_tok, const float* context, int32_t streaming, float* h_out, void* stream) {
@@ -366,12 +419,14 @@ int cv_flow_inference(cv_flow* m, const int32_t* token_ids, int32_t n_tok, const
     return guarded([&] {
         CV_CHECK(m && m->finalized && token_ids && embedding && noise_cl && mel_out && mel_len2_out, "cv_flow_inference: bad arguments");
         const auto& c = m->cfg; const int d = c.dim;
-        hipStream_t s = as_stream(stream);
+        hipStream_t s = resolve(m, stream);
+        void* stream_r = reinterpret_cast<void*>(s);
         const int n_enc = finalize ? n_tok : n_tok - c.pre_lookahead;
         CV_CHECK(n_enc > 0 && n_timesteps > 0, "cv_flow_inference: too few tokens");
         const int T = 2 * n_enc, mel_len2 = T - mel_len1;
         CV_CHECK(mel_len2 > 0 && mel_len1 >= 0, "cv_flow_inference: prompt longer than the sequence");
         if (n_tok > m->inf_cap) {
+            drop_graphs(m);
             m->f_tok.ensure((size_t)n_tok * d * 4); m->f_h.ensure((size_t)2 * n_tok * d * 4); m->f_mu.ensure((size_t)2 * n_tok * c.mel * 4);
             m->f_cond.ensure((size_t)2 * n_tok * c.mel * 4); m->f_x.ensure((size_t)2 * n_tok * c.mel * 4);
             m->f_spk.ensure((size_t)c.mel * 4); m->f_spkn.ensure((size_t)c.spk_dim * 4);
@@ -381,7 +436,7 @@ int cv_flow_inference(cv_flow* m, const int32_t* token_ids, int32_t n_tok, const
         hipLaunchKernelGGL(l2_normalize_kernel, dim3(1), dim3(256), 0, s, embedding, m->f_spkn.as<float>(), c.spk_dim);
         lin_cl(m->spk_affine, m->f_spkn.as<float>(), 1, m->f_spk.as<float>(), ACT_NONE, nullptr, s);
         // token embedding (mask is all ones for batch 1, flow.py:252-254); gather_rows_kernel lives in llm_kernels.h -> reuse via C ABI
-        CV_CHECK(cv_gather_rows(m->input_embedding, m->wbf16 ? CV_BF16 : CV_F32, c.vocab, d, token_ids, n_tok, m->f_tok.as<float>(), 1.f, stream) == 0, cv_last_error());
+        CV_CHECK(cv_gather_rows(m->input_embedding, m->wbf16 ? CV_BF16 : CV_F32, c.vocab, d, token_ids, n_tok, m->f_tok.as<float>(), 1.f, stream_r) == 0, cv_last_error());
         const float* ctx = finalize ? nullptr : m->f_tok.as<float>() + (size_t)n_enc * d;
         flow_encoder(m, m->f_tok.as<float>(), n_enc, ctx, streaming, m->f_h.as<float>(), s);
         lin_cl(m->enc_proj, m->f_h.as<float>(), T, m->f_mu.as<float>(), ACT_NONE, nullptr, s);

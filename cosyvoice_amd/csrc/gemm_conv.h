@@ -33,6 +33,7 @@ struct GemmConvArgs {
     float out_scale;
     const float* row_scale; long long row_scale_batch;  // per-row multiplier (time mask), null = none
     int accumulate;                 // C += result
+    long long* dbg;                 // dev tool (tools/ubench/gemm_probe.hip): per-phase clock64() stamps of wave 0, 64 slots per workgroup; null in production
 };
 
 // Pipeline: most GEMMs on this path are small (M ~ 10^3, K = 256..1024) and run ~1 workgroup per CU, so nothing hides global
@@ -48,10 +49,12 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, b = blockIdx.z;
+    // XCD-aware tile order: consecutive remapped ids walk the N tiles of one M band, so an XCD owns ~1/8 of the rows of A
+    // (A crosses the fabric once) and keeps the whole, much smaller, W panel in its own L2.
+    const int bl = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+    const int m0 = (bl / (int)gridDim.y) * BM, n0 = (bl % (int)gridDim.y) * BN, b = blockIdx.z;
     const float* Ab = p.A + (long long)b * p.a_batch;
-    const int kchunks = (p.Kp + BK - 1) / BK;
-    const int nit = p.taps * kchunks;
+    const int nit = p.taps * ((p.Kp + BK - 1) / BK);
     const long long ldw = p.ldw ? p.ldw : (long long)p.taps * p.Kp;
     const long long wb = (long long)b * p.w_batch;
 
@@ -65,16 +68,34 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
 
     // Loads are UNCONDITIONAL (clamped address + select): a load inside a divergent branch makes the compiler lose count of the
     // outstanding vector-memory operations and fall back to s_waitcnt vmcnt(0), which drains the prefetch ring every iteration.
-    // For the same reason the prologue activation is applied when the tile is parked in LDS, not when it is requested.
-    auto load_tile = [&](int it, float4 (&ra)[AV], float4 (&rw)[WV]) {
-        const int tap = it / kchunks, k0 = (it - tap * kchunks) * BK;
+    // All per-thread address arithmetic (64-bit row bases, validity of the row) is done ONCE here; a tile only adds the uniform
+    // offsets of its (tap, k-chunk).  [Measured with tools/ubench/gemm_probe.hip: recomputing it per tile cost ~2500 cycles per
+    // load_tile against ~1300 cycles of MFMA work — one wave per SIMD has nothing to hide VALU address math behind.]
+    long long a_base[AV]; int a_c4[AV]; bool a_row_ok[AV];
+    long long w_base[WV]; int w_c4[WV];
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+        const int v = tid + i * 256, m = m0 + v / KV;
+        a_c4[i] = (v % KV) * 4;
+        a_row_ok[i] = m < p.M;
+        a_base[i] = (long long)m * p.lda + p.a_off0 + a_c4[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+        const int v = tid + i * 256;
+        int n = n0 + v / KV; n = n < p.N ? n : p.N - 1;
+        w_c4[i] = (v % KV) * 4;
+        w_base[i] = wb + (long long)n * ldw + w_c4[i];
+    }
+    auto load_tile = [&](int tap, int k0, float4 (&ra)[AV], float4 (&rw)[WV]) {
+        const long long a_off = (long long)tap * p.tap_step + k0;       // uniform
+        const long long w_off = (long long)tap * p.Kp + k0;             // uniform
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
-            const int v = tid + i * 256, row = v / KV, kk = k0 + (v % KV) * 4;
-            const int m = m0 + row;
-            const long long idx = (long long)m * p.lda + p.a_off0 + (long long)tap * p.tap_step + kk;
+            const int kk = k0 + a_c4[i];
+            const long long idx = a_base[i] + a_off;
             if (AVEC) {       // K % 4 == 0 and every float4 group is 16B aligned and entirely in or out of [0, a_len)
-                const bool ok = m < p.M && kk < p.K && idx >= 0 && idx + 3 < p.a_len;
+                const bool ok = a_row_ok[i] && kk < p.K && idx >= 0 && idx + 3 < p.a_len;
                 float4 x = *reinterpret_cast<const float4*>(Ab + (ok ? idx : 0));
                 if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
                 ra[i] = x;
@@ -83,7 +104,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const long long ie = idx + e;
-                    const bool ok = m < p.M && kk + e < p.K && ie >= 0 && ie < p.a_len;
+                    const bool ok = a_row_ok[i] && kk + e < p.K && ie >= 0 && ie < p.a_len;
                     const float x = Ab[ok ? ie : 0];
                     t[e] = ok ? x : 0.f;
                 }
@@ -92,10 +113,8 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
-            const int v = tid + i * 256, row = v / KV, kk = k0 + (v % KV) * 4;
-            int n = n0 + row; n = n < p.N ? n : p.N - 1;
-            const bool ok = kk < p.Kp;                          // Kp is a multiple of 32: the last BK=64 step may be half empty
-            const long long idx = wb + (long long)n * ldw + (long long)tap * p.Kp + (ok ? kk : 0);
+            const bool ok = k0 + w_c4[i] < p.Kp;                // Kp is a multiple of 32: the last k-step may be partly empty
+            const long long idx = ok ? w_base[i] + w_off : w_base[i];
             float4 wv;
             if (WBF16) {
                 const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.W) + idx);
@@ -108,28 +127,29 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
             rw[i] = wv;
         }
     };
-    auto store_tile = [&](int it, const float4 (&ra)[AV], const float4 (&rw)[WV]) {
-        const int tap = it / kchunks, k0 = (it - tap * kchunks) * BK;
+    auto store_tile = [&](int k0, const float4 (&ra)[AV], const float4 (&rw)[WV]) {
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
-            const int v = tid + i * 256, kk = k0 + (v % KV) * 4;
+            const int v = tid + i * 256, kk = k0 + a_c4[i];
             float4 x = ra[i];
-            if (p.pro == ACT_LEAKY) {
-                x.x = x.x > 0.f ? x.x : x.x * p.pro_p; x.y = x.y > 0.f ? x.y : x.y * p.pro_p;
-                x.z = x.z > 0.f ? x.z : x.z * p.pro_p; x.w = x.w > 0.f ? x.w : x.w * p.pro_p;
-            } else if (p.pro == ACT_SNAKE) {
-                if (kk < p.K) {                                 // alpha is padded to Kp by the host; Snake(0) == 0 keeps the zero padding
-                    const float4 al = *reinterpret_cast<const float4*>(p.pro_alpha + kk);
-                    x.x = snake_f(x.x, al.x); x.y = snake_f(x.y, al.y); x.z = snake_f(x.z, al.z); x.w = snake_f(x.w, al.w);
+            if (p.pro != ACT_NONE) {
+                if (p.pro == ACT_LEAKY) {
+                    x.x = x.x > 0.f ? x.x : x.x * p.pro_p; x.y = x.y > 0.f ? x.y : x.y * p.pro_p;
+                    x.z = x.z > 0.f ? x.z : x.z * p.pro_p; x.w = x.w > 0.f ? x.w : x.w * p.pro_p;
+                } else if (p.pro == ACT_SNAKE) {
+                    if (kk < p.K) {                             // alpha is padded to Kp by the host; Snake(0) == 0 keeps the zero padding
+                        const float4 al = *reinterpret_cast<const float4*>(p.pro_alpha + kk);
+                        x.x = snake_f(x.x, al.x); x.y = snake_f(x.y, al.y); x.z = snake_f(x.z, al.z); x.w = snake_f(x.w, al.w);
+                    }
+                } else {                                        // any other activation with act(0) == 0 (Mish, SiLU, ...)
+                    x.x = apply_act(p.pro, x.x, p.pro_p); x.y = apply_act(p.pro, x.y, p.pro_p);
+                    x.z = apply_act(p.pro, x.z, p.pro_p); x.w = apply_act(p.pro, x.w, p.pro_p);
                 }
-            } else if (p.pro != ACT_NONE) {                     // any other activation with act(0) == 0 (Mish, SiLU, ...)
-                x.x = apply_act(p.pro, x.x, p.pro_p); x.y = apply_act(p.pro, x.y, p.pro_p);
-                x.z = apply_act(p.pro, x.z, p.pro_p); x.w = apply_act(p.pro, x.w, p.pro_p);
             }
-            *reinterpret_cast<float4*>(&As[(v / KV) * LD + (v % KV) * 4]) = x;
+            *reinterpret_cast<float4*>(&As[(v / KV) * LD + a_c4[i]]) = x;
         }
 #pragma unroll
-        for (int i = 0; i < WV; ++i) { const int v = tid + i * 256; *reinterpret_cast<float4*>(&Ws[(v / KV) * LD + (v % KV) * 4]) = rw[i]; }
+        for (int i = 0; i < WV; ++i) { const int v = tid + i * 256; *reinterpret_cast<float4*>(&Ws[(v / KV) * LD + w_c4[i]]) = rw[i]; }
     };
     auto compute_tile = [&]() {
 #pragma unroll
@@ -155,23 +175,36 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
         }
     };
 
-    load_tile(0, ra0, rw0);
-    if (nit > 1) load_tile(1, ra1, rw1);
+    long long* dbg = p.dbg ? p.dbg + ((long long)(blockIdx.y * gridDim.x + blockIdx.x)) * 64 : nullptr;
+    int dn = 0;
+    auto stamp = [&]() { if (dbg && tid == 0 && dn < 64) dbg[dn++] = clock64(); };
+    // (tap, k0) of the tile being LOADED advance incrementally (no integer division in the loop); ks* shadow the tiles being stored
+    int l_tap = 0, l_k0 = 0;
+    auto advance = [&]() { l_k0 += BK; if (l_k0 >= p.Kp) { l_k0 = 0; ++l_tap; } };
+    int ks0 = 0, ks1 = 0;
+    stamp();
+    load_tile(l_tap, l_k0, ra0, rw0); ks0 = l_k0; advance();
+    if (nit > 1) { load_tile(l_tap, l_k0, ra1, rw1); ks1 = l_k0; advance(); }
+    stamp();
     for (int it = 0; it < nit; it += 2) {
-        store_tile(it, ra0, rw0);
+        store_tile(ks0, ra0, rw0);
+        stamp();
         __syncthreads();
-        if (it + 2 < nit) load_tile(it + 2, ra0, rw0);        // stays in flight through this AND the next iteration
+        if (it + 2 < nit) { load_tile(l_tap, l_k0, ra0, rw0); ks0 = l_k0; advance(); }   // in flight through this AND the next iteration
+        stamp();
         compute_tile();
+        stamp();
         __syncthreads();
         if (it + 1 < nit) {
-            store_tile(it + 1, ra1, rw1);
+            store_tile(ks1, ra1, rw1);
             __syncthreads();
-            if (it + 3 < nit) load_tile(it + 3, ra1, rw1);
+            if (it + 3 < nit) { load_tile(l_tap, l_k0, ra1, rw1); ks1 = l_k0; advance(); }
             compute_tile();
             __syncthreads();
         }
     }
 
+    stamp();
     // epilogue: lane holds C[m][n..n+3] with m = ..+(lane&15), n = ..+(lane>>4)*4   (W rows were the MFMA "A")
     float* Cb = p.C + (long long)b * p.c_batch;
     const float* Rb = p.res ? p.res + (long long)b * p.res_batch : nullptr;
@@ -223,6 +256,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
             }
         }
     }
+    stamp();
 }
 
 // host-side dispatch (gemm_conv.hip)

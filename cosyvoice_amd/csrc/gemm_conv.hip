@@ -27,12 +27,15 @@ void launch_gemm_conv(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t
         if (cfgs[c].bm > 32 && a.M <= cfgs[c].bm / 2) continue;
         if (blocks >= 240) { pick = c; break; }
     }
+    // Small tiles run ~1 workgroup per CU and are bound by memory latency per k-iteration (activations written by another XCD,
+    // weights from the Infinity Cache: ~3 us), so they take the biggest BK that fits 64 KB of LDS: fewer, fatter iterations.
+    const bool bigk = a.Kp >= 128;
     switch (pick) {
         case 0: launch_cfg<128, 128, 32>(a, w_bf16, batch, stream); break;
-        case 1: launch_cfg<128, 64, 32>(a, w_bf16, batch, stream); break;
-        case 2: launch_cfg<64, 64, 64>(a, w_bf16, batch, stream); break;
-        case 3: launch_cfg<32, 64, 64>(a, w_bf16, batch, stream); break;
-        default: launch_cfg<32, 32, 64>(a, w_bf16, batch, stream); break;
+        case 1: if (a.Kp >= 64) launch_cfg<128, 64, 64>(a, w_bf16, batch, stream); else launch_cfg<128, 64, 32>(a, w_bf16, batch, stream); break;
+        case 2: if (bigk) launch_cfg<64, 64, 128>(a, w_bf16, batch, stream); else launch_cfg<64, 64, 64>(a, w_bf16, batch, stream); break;
+        case 3: if (bigk) launch_cfg<32, 64, 128>(a, w_bf16, batch, stream); else launch_cfg<32, 64, 64>(a, w_bf16, batch, stream); break;
+        default: if (bigk) launch_cfg<32, 32, 128>(a, w_bf16, batch, stream); else launch_cfg<32, 32, 64>(a, w_bf16, batch, stream); break;
     }
 }
 

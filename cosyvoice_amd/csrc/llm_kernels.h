@@ -55,17 +55,31 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
         const bf16_t* wr = p.W + (long long)row * p.K + sub * 8;
 #pragma unroll
         for (int s = 0; s < STEPS; ++s)
-            w[r][s] = (s0 + s < s1) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + (s0 + s) * 128)) : (u32x4){0u, 0u, 0u, 0u};
+        {
+            const bool ok = s0 + s < s1;
+            u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + (ok ? (s0 + s) : s0) * 128));
+            if (!ok) t = (u32x4){0u, 0u, 0u, 0u};
+            w[r][s] = t;
+        }
     }
     float4 xa[STEPS], xb[STEPS];
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-        if (s0 + s < s1) {
-            xa[s] = *reinterpret_cast<const float4*>(p.x + (s0 + s) * 128 + sub * 8);
-            xb[s] = *reinterpret_cast<const float4*>(p.x + (s0 + s) * 128 + sub * 8 + 4);
-        } else { xa[s] = make_float4(0.f, 0.f, 0.f, 0.f); xb[s] = xa[s]; }
+        const bool ok = s0 + s < s1;
+        const int so = ok ? (s0 + s) : s0;
+        xa[s] = *reinterpret_cast<const float4*>(p.x + so * 128 + sub * 8);
+        xb[s] = *reinterpret_cast<const float4*>(p.x + so * 128 + sub * 8 + 4);
+        if (!ok) { xa[s] = make_float4(0.f, 0.f, 0.f, 0.f); xb[s] = xa[s]; }
     }
     if (p.gamma) {                                           // fused Qwen2RMSNorm (host guarantees WAVES == 1 here)
+        // gamma is requested BEFORE the reduction so its round trip overlaps the weight stream instead of following the shuffles
+        float4 ga[STEPS], gb[STEPS];
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int so = (s0 + s < s1) ? (s0 + s) : s0;
+            ga[s] = *reinterpret_cast<const float4*>(p.gamma + so * 128 + sub * 8);
+            gb[s] = *reinterpret_cast<const float4*>(p.gamma + so * 128 + sub * 8 + 4);
+        }
         float ss = 0.f;
 #pragma unroll
         for (int s = 0; s < STEPS; ++s)
@@ -75,12 +89,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
         const float rstd = rsqrtf(ss / (float)p.K + p.eps);
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
-            if (s0 + s < s1) {
-                const float4 ga = *reinterpret_cast<const float4*>(p.gamma + (s0 + s) * 128 + sub * 8);
-                const float4 gb = *reinterpret_cast<const float4*>(p.gamma + (s0 + s) * 128 + sub * 8 + 4);
-                xa[s].x = xa[s].x * rstd * ga.x; xa[s].y = xa[s].y * rstd * ga.y; xa[s].z = xa[s].z * rstd * ga.z; xa[s].w = xa[s].w * rstd * ga.w;
-                xb[s].x = xb[s].x * rstd * gb.x; xb[s].y = xb[s].y * rstd * gb.y; xb[s].z = xb[s].z * rstd * gb.z; xb[s].w = xb[s].w * rstd * gb.w;
-            }
+            xa[s].x = xa[s].x * rstd * ga[s].x; xa[s].y = xa[s].y * rstd * ga[s].y; xa[s].z = xa[s].z * rstd * ga[s].z; xa[s].w = xa[s].w * rstd * ga[s].w;
+            xb[s].x = xb[s].x * rstd * gb[s].x; xb[s].y = xb[s].y * rstd * gb[s].y; xb[s].z = xb[s].z * rstd * gb[s].z; xb[s].w = xb[s].w * rstd * gb[s].w;
         }
     }
     float acc[ROWS];

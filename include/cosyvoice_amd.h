@@ -134,6 +134,7 @@ typedef struct cv_flow_config {
 int cv_flow_create(cv_flow** out, const cv_flow_config* cfg);
 int cv_flow_set_tensor(cv_flow* m, const char* name, const void* dev_ptr, int32_t dtype, int64_t numel);
 int cv_flow_finalize(cv_flow* m);
+int cv_flow_set_option(cv_flow* m, const char* name, int32_t value);           /* "use_graph" (Euler-solve hipGraph cache, default on) */
 void cv_flow_destroy(cv_flow* m);
 /* B4: flow.encoder(token_emb[1,n,dim], token_len, context=[1,3,dim] or empty, streaming) -> h[1,2n,dim]
  * (cosyvoice/flow/flow.py:258-261, transformer/upsample_encoder.py:244-307).  tok_emb / context / h_out: dev fp32, row-major. */

@@ -148,6 +148,8 @@ static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
+static inline long long clock64() { return 0; }
+static inline long long wall_clock64() { return 0; }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 

@@ -94,3 +94,22 @@ def test_matches_reference_golden(lib):
     mel, _ = flow.inference(token=g["token"], token_len=t(16), prompt_token=g["prompt_token"], prompt_token_len=t(9), prompt_feat=g["prompt_feat"],
                             prompt_feat_len=t(18), embedding=g["embedding"], streaming=False, finalize=True)
     torch.testing.assert_close(mel.cpu(), g["mel_full"], rtol=2e-3, atol=2e-3)
+
+
+def test_graph_replay_is_identical_to_eager(lib, tiny):
+    """cv_flow_inference captures the whole Euler solve into a hipGraph the 2nd time a (T, steps, streaming) key is seen and
+    replays it afterwards: eager, capture+launch and replay must give the same bits, also after another shape ran in between."""
+    cfg, sd = tiny
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, n_timesteps=3)
+    u = _inputs(cfg)
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    kw = dict(prompt_token=u["prompt_token"], prompt_token_len=t(7), prompt_feat=u["prompt_feat"], prompt_feat_len=t(14), embedding=u["embedding"],
+              streaming=False, finalize=True)
+    outs = [flow.inference(token=u["token"], token_len=t(13), **kw)[0].cpu().clone() for _ in range(2)]
+    other = flow.inference(token=u["token"][:, :9], token_len=t(9), **kw)[0].cpu().clone()            # different T in between
+    outs += [flow.inference(token=u["token"], token_len=t(13), **kw)[0].cpu().clone() for _ in range(2)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    ref = OF.inference(sd, cfg, u["token"], u["prompt_token"], u["prompt_feat"], u["embedding"], streaming=False, finalize=True, n_timesteps=3)
+    torch.testing.assert_close(outs[0], ref, rtol=1e-3, atol=1e-3)
+    assert other.shape[2] == 18
