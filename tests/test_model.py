@@ -16,7 +16,7 @@ def setup():
     lc, fc, hc = W.tiny()
     fc = dataclasses.replace(fc, chunk=5, n_timesteps=2)           # small streaming chunks so the emulator run stays short
     sds = (W.make_llm(lc), W.make_flow(fc), W.make_hift(hc))
-    u = W.synthetic_utterance(lc, fc, n_prompt_tok=8, n_prompt_text=4, n_text=4, seed=21)
+    u = W.synthetic_utterance(lc, fc, n_prompt_tok=8, n_prompt_text=4, n_text=2, seed=21)
     return (lc, fc, hc), sds, u
 
 
@@ -33,7 +33,7 @@ def test_tts_matches_oracle(lib, setup, stream):
     cfgs, sds, u = setup
     lc, fc, hc = cfgs
     m = _build(lib, cfgs, sds)
-    # the LLM's ratio arguments are fixed inside llm_job (20 / 2), so shorten through the text length: 4 text tokens -> 8..80 tokens
+    # the ratio arguments are fixed inside llm_job (20 / 2), so the length is set through the text: 2 text tokens -> 4..40 tokens
     outs = [o["tts_speech"] for o in m.tts(text=u["text"], flow_embedding=u["flow_embedding"], llm_embedding=u["llm_embedding"], prompt_text=u["prompt_text"],
                                            llm_prompt_speech_token=u["llm_prompt_speech_token"], flow_prompt_speech_token=u["flow_prompt_speech_token"],
                                            prompt_speech_feat=u["prompt_speech_feat"], stream=stream)]
