@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <string>
+#include <mutex>
 #include <stdexcept>
 #include <cstdio>
 #include "../../include/cosyvoice_amd.h"
@@ -27,6 +28,11 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Process-wide lock serialising the two runtime operations that must never overlap across host threads: stream capture /
+// graph instantiation, and device (re)allocation (hipFree implies a device-wide synchronisation).  CosyVoice2Model.tts runs the
+// LLM on its own thread + stream while the caller's thread runs token2wav, so both can happen at the same moment.
+std::recursive_mutex& runtime_lock();
+
 // device buffer owned by a handle (workspaces, KV cache)
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
@@ -35,8 +41,10 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
     void ensure(size_t n) {
         if (n <= bytes) return;
+        std::lock_guard<std::recursive_mutex> lk(runtime_lock());
         if (p) CV_HIP(hipFree(p));
         p = nullptr; bytes = 0;
+        n += n / 2;                                   // geometric growth: streaming requests grow T chunk by chunk
         CV_HIP(hipMalloc(&p, n)); bytes = n;
     }
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }

@@ -5,6 +5,7 @@ namespace cv {
 
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& s) { g_last_error = s; }
+std::recursive_mutex& runtime_lock() { static std::recursive_mutex m; return m; }
 
 void gemm_conv(GemmConvArgs a, bool w_bf16, int batch, hipStream_t s) {
     CV_CHECK(a.Kp % 32 == 0 && a.Kp >= a.K, "gemm_conv: Kp must be K rounded up to 32");

@@ -234,7 +234,7 @@ static void flow_encoder(cv_flow* m, const float* tok_emb, int T, const float* c
 }
 
 // ---- estimator ---------------------------------------------------------------------------------------------------------
-static void drop_graphs(cv_flow* m) { for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second); m->graphs.clear(); m->seen.clear(); }
+static void drop_graphs(cv_flow* m) { std::lock_guard<std::recursive_mutex> lk(runtime_lock()); for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second); m->graphs.clear(); m->seen.clear(); }
 
 static void est_reserve(cv_flow* m, int T) {
     if (T <= m->est_cap) return;
@@ -362,6 +362,7 @@ static void solve_euler(cv_flow* m, float* x /*[T][mel] in/out*/, const float* m
     // buffers may have been re-allocated by *_reserve since a capture: graphs are dropped whenever a workspace grows (see est_reserve)
     if (m->use_graph && x == m->f_x.as<float>() && ++m->seen[key] == 2) {
         if (m->graphs.size() >= 8) { for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second); m->graphs.clear(); }
+        std::lock_guard<std::recursive_mutex> lk(runtime_lock());
         hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
         CV_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         body();

@@ -22,7 +22,8 @@ struct cv_llm {
     const float* norm = nullptr; const bf16_t* head_w = nullptr; const float* head_b = nullptr; const bf16_t* speech_emb = nullptr;
     int V = 0, qkv_dim = 0;
     // device state
-    DevBuf kcache, vcache, rope_cos, rope_sin, state, tokens, uniforms;
+    DevBuf kcache, vcache, rope_cos, rope_sin, state, tokens, uniforms, sparams;
+    SampleParams* host_sp = nullptr;
     DevBuf h, qkv, attn, act, logits;                  // decode activations
     DevBuf pf_x, pf_xn, pf_qkv, pf_attn, pf_gu, pf_act; // prefill activations (grown on demand)
     int pf_rows = 0;
@@ -38,6 +39,7 @@ struct cv_llm {
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (host_tokens) (void)hipHostFree(host_tokens);
         if (host_state) (void)hipHostFree(host_state);
+        if (host_sp) (void)hipHostFree(host_sp);
     }
 };
 
@@ -86,6 +88,8 @@ static void llm_finalize(cv_llm* m) {
     m->act.ensure((size_t)c.inter * 4); m->logits.ensure((size_t)m->V * 4);
     CV_HIP(hipHostMalloc((void**)&m->host_tokens, (size_t)c.max_len * sizeof(int)));
     CV_HIP(hipHostMalloc((void**)&m->host_state, sizeof(DecodeState)));
+    CV_HIP(hipHostMalloc((void**)&m->host_sp, sizeof(SampleParams)));
+    m->sparams.ensure(sizeof(SampleParams));
     CV_HIP(hipMemset(m->state.p, 0, sizeof(DecodeState)));
     m->finalized = true;
 }
@@ -177,9 +181,7 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
     float* h = m->h.as<float>(); float* qkv = m->qkv.as<float>(); float* at = m->attn.as<float>(); float* act = m->act.as<float>();
     { ProfScope ps(m, s, 5); gemv(GemvArgs{m->head_w, m->head_b, h, m->logits.as<float>(), m->V, c.hidden, m->norm, c.rms_eps, nullptr, 0, st}, 2, s); }
     SampleArgs sa{};
-    sa.logits = m->logits.as<float>(); sa.V = m->V; sa.eos = m->sp.eos; sa.n_stop = m->sp.n_stop;
-    sa.min_len = m->sp.min_len; sa.max_len = m->sp.max_len; sa.mode = m->sp.mode; sa.top_p = m->sp.top_p; sa.top_k = m->sp.top_k;
-    sa.win = m->sp.win_size; sa.tau_r = m->sp.tau_r; sa.seed = m->sp.seed; sa.uniforms = m->sp.use_uniforms ? m->uniforms.as<float>() : nullptr;
+    sa.logits = m->logits.as<float>(); sa.V = m->V; sa.sp = m->sparams.as<SampleParams>(); sa.uniforms = m->uniforms.as<float>();
     sa.st = m->state.as<DecodeState>(); sa.tokens = m->tokens.as<int>(); sa.max_tokens = c.max_len;
     { ProfScope ps(m, s, 6); hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, s, sa); }
     hipLaunchKernelGGL(embed_last_token_kernel, dim3(1), dim3(256), 0, s, m->speech_emb, c.hidden, h, st);
@@ -206,9 +208,12 @@ static void llm_decode(cv_llm* m, int n_steps, const cv_sampling* sp, int32_t* o
     CV_CHECK(m->finalized, "llm: call cv_llm_finalize first");
     CV_CHECK(sp && sp->max_len > 0 && sp->eos >= 0 && sp->eos + sp->n_stop <= m->V, "llm_decode: bad sampling parameters");
     CV_CHECK(sp->mode == 0 || (sp->top_k > 0 && sp->top_k <= 64 && sp->win_size >= 0), "llm_decode: bad RAS parameters");
-    if (!m->sp_valid || !same_sampling(m->sp, *sp)) {
+    if (!m->sp_valid || !same_sampling(m->sp, *sp)) {          // request parameters go to device memory; the graph stays valid
         m->sp = *sp; m->sp_valid = true;
-        if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+        CV_HIP(hipStreamSynchronize(s));                        // host_sp may still be the source of an earlier async copy
+        *m->host_sp = SampleParams{sp->mode, sp->eos, sp->n_stop, sp->min_len, sp->max_len, sp->top_p, sp->top_k, sp->win_size, sp->tau_r,
+                                   sp->use_uniforms, (unsigned long long)sp->seed};
+        CV_HIP(hipMemcpyAsync(m->sparams.p, m->host_sp, sizeof(SampleParams), hipMemcpyHostToDevice, s));
     }
     const int before = m->host_state->n_tokens;
     // never run past the KV cache: each step appends one position
@@ -216,6 +221,7 @@ static void llm_decode(cv_llm* m, int n_steps, const cv_sampling* sp, int32_t* o
     if (m->use_graph) {
         if (!m->graph || m->graph_stream != s) {
             if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+            std::lock_guard<std::recursive_mutex> lk(runtime_lock());
             hipGraph_t g = nullptr;
             CV_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             llm_enqueue_step(m, s);
@@ -276,7 +282,10 @@ int cv_llm_profile_step(cv_llm* m, const cv_sampling* sp, int32_t* counts8, floa
         CV_CHECK(m && m->finalized && sp && counts8 && ms8, "cv_llm_profile_step: bad arguments");
         hipStream_t s = resolve(m, stream);
         m->sp = *sp; m->sp_valid = true;
-        if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+        CV_HIP(hipStreamSynchronize(s));
+        *m->host_sp = SampleParams{sp->mode, sp->eos, sp->n_stop, sp->min_len, sp->max_len, sp->top_p, sp->top_k, sp->win_size, sp->tau_r,
+                                   sp->use_uniforms, (unsigned long long)sp->seed};
+        CV_HIP(hipMemcpyAsync(m->sparams.p, m->host_sp, sizeof(SampleParams), hipMemcpyHostToDevice, s));
         CV_CHECK(m->host_state->pos + 1 < m->cfg.max_len, "cv_llm_profile_step: KV cache exhausted");
         m->profiling = true; m->prof_events.clear();
         llm_enqueue_step(m, s);

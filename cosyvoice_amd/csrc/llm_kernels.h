@@ -299,10 +299,15 @@ static __global__ __launch_bounds__(256) void embed_last_token_kernel(const bf16
 // Sampling on device (one workgroup of 1024 threads), llm/llm.py:150-160 + :542-549 and utils/common.py:138-167.
 //   mode 0: greedy argmax (first index on ties)            mode 1: repetition-aware sampling (RAS)
 // ---------------------------------------------------------------------------------------------------------------
+// Per-request sampling parameters live in DEVICE memory (written once per request), so that the captured decode graph does
+// not depend on the request and is never re-captured when the text length (min_len / max_len) or the seed changes.
+struct SampleParams {
+    int mode; int eos; int n_stop; int min_len; int max_len; float top_p; int top_k; int win; float tau_r; int use_uniforms;
+    unsigned long long seed;
+};
 struct SampleArgs {
-    const float* logits; int V; int eos; int n_stop;          // stop ids = [eos, eos + n_stop)
-    int min_len, max_len; int mode; float top_p; int top_k; int win; float tau_r;
-    unsigned long long seed; const float* uniforms;           // optional explicit uniforms [2 per step] (parity tests)
+    const float* logits; int V; const SampleParams* sp;
+    const float* uniforms;                                    // explicit uniforms [2 per step] when sp->use_uniforms (parity tests)
     DecodeState* st; int* tokens; int max_tokens;
 };
 
@@ -312,7 +317,13 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned ste
     return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
-static __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
+static __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs a) {
+    // flatten (static args + device-resident request parameters) into the names the body uses
+    struct { const float* logits; int V, eos, n_stop, min_len, max_len, mode; float top_p; int top_k, win; float tau_r;
+             unsigned long long seed; const float* uniforms; DecodeState* st; int* tokens; int max_tokens; } p;
+    p.logits = a.logits; p.V = a.V; p.eos = a.sp->eos; p.n_stop = a.sp->n_stop; p.min_len = a.sp->min_len; p.max_len = a.sp->max_len;
+    p.mode = a.sp->mode; p.top_p = a.sp->top_p; p.top_k = a.sp->top_k; p.win = a.sp->win; p.tau_r = a.sp->tau_r; p.seed = a.sp->seed;
+    p.uniforms = a.sp->use_uniforms ? a.uniforms : nullptr; p.st = a.st; p.tokens = a.tokens; p.max_tokens = a.max_tokens;
     __shared__ float pr[8192];
     __shared__ float redv[16];
     __shared__ int redi[16];

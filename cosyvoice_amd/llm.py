@@ -93,6 +93,15 @@ class Qwen2LM:
         self._keep = (ids_text, ids_sp, fixed)
         return out
 
+    def warmup(self):
+        """Run one prefill + one decode step on the CURRENT stream so that the decode hipGraph for this stream is captured now
+        (single-threaded) rather than inside the first request, when CosyVoice2Model runs the LLM on its own thread next to
+        token2wav.  The graph does not depend on the request (sampling parameters live in device memory)."""
+        with self.lock:
+            x = self.lib.hook(torch.zeros(4, self.cfg.hidden, dtype=torch.float32, device=self.device))
+            self.prefill(x)
+            self.decode(1, SamplingC(0, self.eos_token, 3, 1, 2, self.top_p, self.top_k, self.win_size, self.tau_r, 0, 0))
+
     def set_uniforms(self, u):
         """Parity hook: explicit uniform variates (2 per step) instead of the on-device counter RNG."""
         self._uniforms = None if u is None else torch.as_tensor(u, dtype=torch.float32).contiguous()

@@ -41,6 +41,14 @@ class CosyVoice2Model:
         self.t2w_lock = threading.Lock()       # flow / hift handles own their workspaces: one token2wav at a time per model
         self.tts_speech_token_dict, self.llm_end_dict, self.hift_cache_dict, self._cond = {}, {}, {}, {}
         self.silent_tokens = []
+        self._warmup()
+
+    def _warmup(self):
+        if self.llm is not None:
+            with self.llm_context:
+                self.llm.warmup()
+            if self.device.type == "cuda":
+                torch.cuda.synchronize()
 
     # ------------------------------------------------------------------------------------------------ B7
     @classmethod
@@ -59,6 +67,7 @@ class CosyVoice2Model:
         self.llm = Qwen2LM(llm_sd, lc, lib=self.lib, **llm_kw)
         self.flow = CausalMaskedDiffWithXvec(flow_sd, fc, lib=self.lib)
         self.hift = HiFTGenerator(hift_sd, hc, lib=self.lib)
+        self._warmup()
 
     # the reference's accelerator hooks are meaningless here: the MI355X kernels ARE the accelerated path
     def load_jit(self, *a, **k):
