@@ -356,7 +356,7 @@ static void solve_euler(cv_flow* m, float* x /*[T][mel] in/out*/, const float* m
     const auto key = std::make_tuple(T, n_steps, streaming ? 1 : 0);
     auto it = m->graphs.find(key);
     if (m->use_graph && it != m->graphs.end() && x == m->f_x.as<float>()) {
-        CV_HIP(hipGraphLaunch(it->second, s));
+        { std::lock_guard<std::recursive_mutex> lk(runtime_lock()); CV_HIP(hipGraphLaunch(it->second, s)); }
         return;
     }
     // buffers may have been re-allocated by *_reserve since a capture: graphs are dropped whenever a workspace grows (see est_reserve)
@@ -392,7 +392,14 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else throw Error(std::string("unknown option ") + name);
     });
 }
-void cv_flow_destroy(cv_flow* m) { delete m; }
+void cv_flow_destroy(cv_flow* m) {
+    if (!m) return;
+    // may be called from a garbage-collector finaliser on ANY thread while another thread drives a different handle: quiesce the
+    // device and hold the runtime lock so stream / graph / buffer destruction never overlaps a capture, a launch burst or a realloc
+    std::lock_guard<std::recursive_mutex> lk(runtime_lock());
+    (void)hipDeviceSynchronize();
+    delete m;
+}
 
 int cv_flow_encoder(cv_flow* m, const float* tok_emb, int32_t n_tok, const float* context, int32_t streaming, float* h_out, void* stream) {
     return guarded([&] { CV_CHECK(m && m->finalized && tok_emb && h_out, "cv_flow_encoder: bad arguments");

@@ -196,7 +196,14 @@ int cv_hift_set_tensor(cv_hift* m, const char* name, const void* dev_ptr, int32_
     return guarded([&] { CV_CHECK(m, "null handle"); m->tm.set(name, dev_ptr, dtype, numel); });
 }
 int cv_hift_finalize(cv_hift* m) { return guarded([&] { CV_CHECK(m, "null handle"); hift_finalize(m); }); }
-void cv_hift_destroy(cv_hift* m) { delete m; }
+void cv_hift_destroy(cv_hift* m) {
+    if (!m) return;
+    // may be called from a garbage-collector finaliser on ANY thread while another thread drives a different handle: quiesce the
+    // device and hold the runtime lock so stream / graph / buffer destruction never overlaps a capture, a launch burst or a realloc
+    std::lock_guard<std::recursive_mutex> lk(runtime_lock());
+    (void)hipDeviceSynchronize();
+    delete m;
+}
 
 int cv_hift_f0(cv_hift* m, const float* speech_feat, int32_t frames, float* f0_out, void* stream) {
     return guarded([&] {

@@ -230,8 +230,9 @@ static void llm_decode(cv_llm* m, int n_steps, const cv_sampling* sp, int32_t* o
             CV_HIP(hipGraphDestroy(g));
             m->graph_stream = s;
         }
-        for (int i = 0; i < n_steps; ++i) CV_HIP(hipGraphLaunch(m->graph, s));
+        { std::lock_guard<std::recursive_mutex> lk(runtime_lock()); for (int i = 0; i < n_steps; ++i) CV_HIP(hipGraphLaunch(m->graph, s)); }
     } else {
+        std::lock_guard<std::recursive_mutex> lk(runtime_lock());
         for (int i = 0; i < n_steps; ++i) llm_enqueue_step(m, s);
     }
     CV_HIP(hipMemcpyAsync(m->host_state, m->state.p, sizeof(DecodeState), hipMemcpyDeviceToHost, s));
@@ -253,7 +254,14 @@ int cv_llm_set_tensor(cv_llm* m, const char* name, const void* dev_ptr, int32_t 
     return guarded([&] { CV_CHECK(m, "null handle"); m->tm.set(name, dev_ptr, dtype, numel); });
 }
 int cv_llm_finalize(cv_llm* m) { return guarded([&] { CV_CHECK(m, "null handle"); llm_finalize(m); }); }
-void cv_llm_destroy(cv_llm* m) { delete m; }
+void cv_llm_destroy(cv_llm* m) {
+    if (!m) return;
+    // may be called from a garbage-collector finaliser on ANY thread while another thread drives a different handle: quiesce the
+    // device and hold the runtime lock so stream / graph / buffer destruction never overlaps a capture, a launch burst or a realloc
+    std::lock_guard<std::recursive_mutex> lk(runtime_lock());
+    (void)hipDeviceSynchronize();
+    delete m;
+}
 int cv_llm_set_option(cv_llm* m, const char* name, int32_t value) {
     return guarded([&] {
         CV_CHECK(m && name, "null argument");

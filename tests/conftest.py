@@ -40,3 +40,17 @@ BACKENDS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=p
 def lib(request):
     """Every kernel parity test runs twice: under the emulator (CPU, `-m "not gpu"`) and on the MI355X (`-m gpu`)."""
     return request.getfixturevalue(request.param + "_lib")
+
+
+@pytest.fixture(autouse=True)
+def _collect_dead_handles():
+    """Destroy dead library handles BETWEEN tests (not from a finaliser firing in the middle of the next test's threads)."""
+    yield
+    import gc
+    gc.collect()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
