@@ -39,7 +39,7 @@ struct GemmConvArgs {
 // Pipeline: most GEMMs on this path are small (M ~ 10^3, K = 256..1024) and run ~1 workgroup per CU, so nothing hides global
 // latency but the kernel itself: a 2-deep REGISTER prefetch ring keeps the loads of k-tiles it+1 and it+2 in flight while tile
 // it is multiplied out of LDS, and the small tiles use BK = 64 to halve the number of barrier-separated iterations.
-template <int BM, int BN, int BK, bool WBF16, bool AVEC>
+template <int BM, int BN, int BK, bool WBF16, bool AVEC, int STAGES = 2>
 __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
     constexpr int LD = BK + 4, KV = BK / 4;         // float4 groups per tile row
     constexpr int TM = BM / 32, TN = BN / 32;       // 16x16 tiles per wave (wave tile = BM/2 x BN/2)
@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    float4 ra0[AV], rw0[WV], ra1[AV], rw1[WV];
+    // STAGES register sets form the prefetch ring (2..4): every tile pays a full L2-miss round trip (its slowest line), measured at
+    // several microseconds on these shapes, so the small tiles — which have the registers — keep 4 tiles in flight per wave.
+    float4 ra0[AV], rw0[WV], ra1[AV], rw1[WV], ra2[STAGES > 2 ? AV : 1], rw2[STAGES > 2 ? WV : 1], ra3[STAGES > 3 ? AV : 1], rw3[STAGES > 3 ? WV : 1];
 
     // Loads are UNCONDITIONAL (clamped address + select): a load inside a divergent branch makes the compiler lose count of the
     // outstanding vector-memory operations and fall back to s_waitcnt vmcnt(0), which drains the prefetch ring every iteration.
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
         w_c4[i] = (v % KV) * 4;
         w_base[i] = wb + (long long)n * ldw + w_c4[i];
     }
-    auto load_tile = [&](int tap, int k0, float4 (&ra)[AV], float4 (&rw)[WV]) {
+    auto load_tile = [&](int tap, int k0, auto& ra, auto& rw) {
         const long long a_off = (long long)tap * p.tap_step + k0;       // uniform
         const long long w_off = (long long)tap * p.Kp + k0;             // uniform
 #pragma unroll
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
             rw[i] = wv;
         }
     };
-    auto store_tile = [&](int k0, const float4 (&ra)[AV], const float4 (&rw)[WV]) {
+    auto store_tile = [&](int k0, const auto& ra, const auto& rw) {
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const int v = tid + i * 256, kk = k0 + a_c4[i];
@@ -181,16 +183,18 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
     // (tap, k0) of the tile being LOADED advance incrementally (no integer division in the loop); ks* shadow the tiles being stored
     int l_tap = 0, l_k0 = 0;
     auto advance = [&]() { l_k0 += BK; if (l_k0 >= p.Kp) { l_k0 = 0; ++l_tap; } };
-    int ks0 = 0, ks1 = 0;
+    int ks0 = 0, ks1 = 0, ks2 = 0, ks3 = 0;
     stamp();
     load_tile(l_tap, l_k0, ra0, rw0); ks0 = l_k0; advance();
     if (nit > 1) { load_tile(l_tap, l_k0, ra1, rw1); ks1 = l_k0; advance(); }
+    if constexpr (STAGES > 2) { if (nit > 2) { load_tile(l_tap, l_k0, ra2, rw2); ks2 = l_k0; advance(); } }
+    if constexpr (STAGES > 3) { if (nit > 3) { load_tile(l_tap, l_k0, ra3, rw3); ks3 = l_k0; advance(); } }
     stamp();
-    for (int it = 0; it < nit; it += 2) {
+    for (int it = 0; it < nit; it += STAGES) {
         store_tile(ks0, ra0, rw0);
         stamp();
         __syncthreads();
-        if (it + 2 < nit) { load_tile(l_tap, l_k0, ra0, rw0); ks0 = l_k0; advance(); }   // in flight through this AND the next iteration
+        if (it + STAGES < nit) { load_tile(l_tap, l_k0, ra0, rw0); ks0 = l_k0; advance(); }     // in flight for the next STAGES-1 tiles
         stamp();
         compute_tile();
         stamp();
@@ -198,9 +202,27 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
         if (it + 1 < nit) {
             store_tile(ks1, ra1, rw1);
             __syncthreads();
-            if (it + 3 < nit) { load_tile(l_tap, l_k0, ra1, rw1); ks1 = l_k0; advance(); }
+            if (it + 1 + STAGES < nit) { load_tile(l_tap, l_k0, ra1, rw1); ks1 = l_k0; advance(); }
             compute_tile();
             __syncthreads();
+        }
+        if constexpr (STAGES > 2) {
+            if (it + 2 < nit) {
+                store_tile(ks2, ra2, rw2);
+                __syncthreads();
+                if (it + 2 + STAGES < nit) { load_tile(l_tap, l_k0, ra2, rw2); ks2 = l_k0; advance(); }
+                compute_tile();
+                __syncthreads();
+            }
+        }
+        if constexpr (STAGES > 3) {
+            if (it + 3 < nit) {
+                store_tile(ks3, ra3, rw3);
+                __syncthreads();
+                if (it + 3 + STAGES < nit) { load_tile(l_tap, l_k0, ra3, rw3); ks3 = l_k0; advance(); }
+                compute_tile();
+                __syncthreads();
+            }
         }
     }
 

@@ -4,15 +4,15 @@
 
 namespace cv {
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int ST = 2>
 static void launch_cfg(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t stream) {
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, batch), block(256);
     if (a.a_vec) {
-        if (w_bf16) hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, true, true>), grid, block, 0, stream, a);
-        else        hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, false, true>), grid, block, 0, stream, a);
+        if (w_bf16) hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, true, true, ST>), grid, block, 0, stream, a);
+        else        hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, false, true, ST>), grid, block, 0, stream, a);
     } else {
-        if (w_bf16) hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, true, false>), grid, block, 0, stream, a);
-        else        hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, false, false>), grid, block, 0, stream, a);
+        if (w_bf16) hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, true, false, ST>), grid, block, 0, stream, a);
+        else        hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, false, false, ST>), grid, block, 0, stream, a);
     }
 }
 
@@ -34,8 +34,8 @@ void launch_gemm_conv(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t
         case 0: launch_cfg<128, 128, 32>(a, w_bf16, batch, stream); break;
         case 1: if (a.Kp >= 64) launch_cfg<128, 64, 64>(a, w_bf16, batch, stream); else launch_cfg<128, 64, 32>(a, w_bf16, batch, stream); break;
         case 2: if (bigk) launch_cfg<64, 64, 128>(a, w_bf16, batch, stream); else launch_cfg<64, 64, 64>(a, w_bf16, batch, stream); break;
-        case 3: if (bigk) launch_cfg<32, 64, 128>(a, w_bf16, batch, stream); else launch_cfg<32, 64, 64>(a, w_bf16, batch, stream); break;
-        default: if (bigk) launch_cfg<32, 32, 128>(a, w_bf16, batch, stream); else launch_cfg<32, 32, 64>(a, w_bf16, batch, stream); break;
+        case 3: if (bigk) launch_cfg<32, 64, 128, 2>(a, w_bf16, batch, stream); else launch_cfg<32, 64, 64>(a, w_bf16, batch, stream); break;
+        default: if (bigk) launch_cfg<32, 32, 128, 2>(a, w_bf16, batch, stream); else launch_cfg<32, 32, 64>(a, w_bf16, batch, stream); break;
     }
 }
 

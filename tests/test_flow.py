@@ -113,3 +113,22 @@ def test_graph_replay_is_identical_to_eager(lib, tiny):
     ref = OF.inference(sd, cfg, u["token"], u["prompt_token"], u["prompt_feat"], u["embedding"], streaming=False, finalize=True, n_timesteps=3)
     torch.testing.assert_close(outs[0], ref, rtol=1e-3, atol=1e-3)
     assert other.shape[2] == 18
+
+
+def test_no_prompt_and_single_token(lib, tiny):
+    """Edge cases of flow.inference: empty prompt (mel_len1 = 0, cross-lingual style call) and the shortest legal input."""
+    cfg, sd = tiny
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, n_timesteps=2)
+    g = torch.Generator().manual_seed(3)
+    emb = torch.randn(1, cfg.spk_dim, generator=g)
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    for n in (1, 6):
+        tok = torch.randint(0, cfg.vocab, (1, n), generator=g, dtype=torch.int32)
+        mel, _ = flow.inference(token=tok, token_len=t(n), prompt_token=torch.zeros(1, 0, dtype=torch.int32), prompt_token_len=t(0),
+                                prompt_feat=torch.zeros(1, 0, 80), prompt_feat_len=t(0), embedding=emb, streaming=False, finalize=True)
+        ref = OF.inference(sd, cfg, tok, torch.zeros(1, 0, dtype=torch.int32), torch.zeros(1, 0, 80), emb, streaming=False, finalize=True, n_timesteps=2)
+        assert mel.shape == (1, 80, 2 * n)
+        torch.testing.assert_close(mel.cpu(), ref, rtol=1e-3, atol=1e-3)
+    with pytest.raises(ValueError):           # streaming call with fewer tokens than the look-ahead: nothing to generate
+        flow.inference(token=torch.zeros(1, 2, dtype=torch.int32), token_len=t(2), prompt_token=torch.zeros(1, 0, dtype=torch.int32), prompt_token_len=t(0),
+                       prompt_feat=torch.zeros(1, 0, 80), prompt_feat_len=t(0), embedding=emb, streaming=True, finalize=False)

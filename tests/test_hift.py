@@ -58,3 +58,15 @@ def test_source_statistics_with_device_rng(lib, tiny):
     assert not torch.equal(s1, s2)                                     # fresh draws per call
     assert (s1.cpu() - s0.cpu()).abs().max() < 0.6 and (s1.cpu() - s0.cpu()).abs().mean() > 1e-4
     assert torch.isfinite(sp1).all() and sp1.abs().max() <= cfg.audio_limit + 1e-6
+
+
+def test_single_frame_and_f0_boundary(lib, tiny):
+    """Shortest input (one mel frame = 480 samples: every conv is all padding) and the f0 predictor on its own."""
+    cfg, sd = tiny
+    hift = HiFTGenerator(sd, cfg, lib=lib)
+    gen = torch.Generator().manual_seed(8)
+    for m in (1, 3):
+        mel = torch.randn(1, 80, m, generator=gen) * 2 - 5
+        s = torch.tanh(torch.randn(1, 1, 480 * m, generator=gen))
+        torch.testing.assert_close(hift.decode(mel, s).cpu(), OH.decode(sd, cfg, mel, s), rtol=2e-4, atol=2e-4)
+        torch.testing.assert_close(hift.f0_predictor(mel).cpu(), OH.f0_predictor(sd, mel), rtol=1e-4, atol=1e-3)

@@ -113,3 +113,13 @@ def test_long_context_multi_pass_attention(lib, tiny_sd):
     for i in range(min(2, len(trace["logp"]))):               # step 1 attends over 567 keys: second attention pass
         lm.decode(1, sp)
         torch.testing.assert_close(lm.last_logits().log_softmax(-1), trace["logp"][i], rtol=1e-4, atol=1e-4)
+
+
+def test_no_speech_prompt(lib, tiny_sd):
+    """prompt_speech_token_len == 0 (cross-lingual / instruct calls): lm_input = [sos | text | task_id] (llm/llm.py:489-494)."""
+    cfg, sd = tiny_sd
+    u = _utt(cfg, n_text=5, n_prompt_text=0, n_prompt_tok=0, seed=4)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=128, sampling="greedy")
+    got = list(lm.inference(**_kw(u), max_token_text_ratio=3, min_token_text_ratio=1))
+    want = OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=3, min_token_text_ratio=1)
+    assert got == want and len(got) >= 1

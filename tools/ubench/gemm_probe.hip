@@ -17,7 +17,7 @@ int main() {
         a.dbg = rep == 2 ? dbg : nullptr;
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((gemm_conv_kernel<32, 32, 128, true, true>), dim3(43, 8, 1), dim3(256), 0, 0, a);
+        hipLaunchKernelGGL((gemm_conv_kernel<32, 32, 128, true, true, 2>), dim3(43, 8, 1), dim3(256), 0, 0, a);
         (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1); printf("rep %d: %.1f us\n", rep, ms * 1e3);
     }
