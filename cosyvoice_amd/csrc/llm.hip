@@ -190,7 +190,7 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
         { ProfScope ps(m, s, 0); gemv(GemvArgs{L.wqkv, L.bqkv, h, qkv, m->qkv_dim, c.hidden, L.ln1, c.rms_eps, nullptr, 0, st}, 1, s); }
         AttnDecodeArgs ad{qkv, m->kcache.as<float>() + m->layer_cache() * i, m->vcache.as<float>() + m->layer_cache() * i,
                           m->rope_cos.as<float>(), m->rope_sin.as<float>(), at, c.heads, c.kv_heads, c.max_len, st};
-        { ProfScope ps(m, s, 1); hipLaunchKernelGGL(attn_decode_kernel, dim3(c.heads), dim3(1024), 0, s, ad); }
+        { ProfScope ps(m, s, 1); hipLaunchKernelGGL(attn_decode_kernel, dim3(c.heads), dim3(256), 0, s, ad); }
         { ProfScope ps(m, s, 2); gemv(GemvArgs{L.wo, nullptr, at, h, c.hidden, c.heads * 64, nullptr, 0.f, h, 0, st}, 1, s); }
         { ProfScope ps(m, s, 3); gemv(GemvArgs{L.wgu, nullptr, h, act, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 1, st}, 2, s); }
         { ProfScope ps(m, s, 4); gemv(GemvArgs{L.wdown, nullptr, act, h, c.hidden, c.inter, nullptr, 0.f, h, 0, st}, 1, s); }

@@ -146,36 +146,37 @@ struct AttnDecodeArgs {
     float* out; int heads, kv_heads, max_len; const DecodeState* st;
 };
 
-// 1024 threads = 16 waves; a 16-lane group covers one key row with float4 loads, a wave 4 x 4 = 16 keys, the workgroup 512 keys
-// per pass (2 slabs of 256).  All K rows of a pass are requested right after `pos` is known (one memory round trip, not one per iteration); the V
-// rows are requested as soon as the scores are done, so that round trip overlaps the two softmax block-reductions.
-// (1024 threads cap a lane at 128 VGPRs, hence K and V share the same 8 float4 registers.)
-static __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnDecodeArgs p) {
+// 256 threads = 16 lane-groups of 16; a group covers one key row per slot with float4 loads, NS = 24 slots -> 384 keys per pass
+// (the whole context of the benchmark utterance: 131 + 250 = 381).  ALL K rows and ALL V rows of a pass are requested as soon as
+// `pos` is known: one memory round trip per pass for the entire cache read.  Scores never leave registers (every lane of a group
+// holds its key's score after the 16-lane reduction), softmax is online across passes (running max / sum, per-thread partial
+// numerators rescaled by a block-uniform factor), and the block synchronises 4 times per pass instead of ~9.
+static __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs p) {
+    constexpr int NS = 24, PASS = 16 * NS;
     __shared__ __attribute__((aligned(16))) float qs[64];
     __shared__ __attribute__((aligned(16))) float knew[64];
-    __shared__ float sc[2048];
-    __shared__ float red[16];
-    __shared__ __attribute__((aligned(16))) float op[16][64];
+    __shared__ float redm[4], redl[4];
+    __shared__ __attribute__((aligned(16))) float op[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sub = lane & 15, kk = lane >> 4;
+    const int sub = tid & 15, grp = tid >> 4;
     const int h = blockIdx.x, g = h / (p.heads / p.kv_heads);
     const int pos = p.st->pos;                       // the new token sits at index `pos`
-    const int L = pos + 1, npass = (L + 511) >> 9;
+    const int L = pos + 1, npass = (L + PASS - 1) / PASS;
     const float* kq = p.qkv + p.heads * 64 + g * 64;
     const float* vq = p.qkv + (p.heads + p.kv_heads) * 64 + g * 64;
     float* kc = p.kcache + (long long)g * p.max_len * 64;
     float* vc = p.vcache + (long long)g * p.max_len * 64;
-    float4 r[2][4];
-    auto load_rows = [&](const float* base, int ps) {
+    float4 k4[NS], v4[NS];
+    auto load_pass = [&](int ps) {
 #pragma unroll
-        for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = ps * 512 + sl * 256 + wave * 16 + u * 4 + kk;
-                r[sl][u] = (j < pos) ? *reinterpret_cast<const float4*>(base + (long long)j * 64 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+        for (int sl = 0; sl < NS; ++sl) {
+            const int j = ps * PASS + sl * 16 + grp;
+            const long long o = (long long)(j < pos ? j : 0) * 64 + sub * 4;      // unconditional (clamped) loads
+            k4[sl] = *reinterpret_cast<const float4*>(kc + o);
+            v4[sl] = *reinterpret_cast<const float4*>(vc + o);
+        }
     };
-    load_rows(kc, 0);
+    load_pass(0);
     if (tid < 64) {
         const int d = tid, f = d & 31;
         const float c = p.rope_cos[pos * 32 + f], s = p.rope_sin[pos * 32 + f];
@@ -191,50 +192,51 @@ static __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnDecodeArgs
     const float4 q4 = *reinterpret_cast<const float4*>(&qs[sub * 4]);
     const float4 kn4 = *reinterpret_cast<const float4*>(&knew[sub * 4]);
     const float4 vn4 = *reinterpret_cast<const float4*>(vq + sub * 4);
-    for (int ps = 0; ps < npass; ++ps) {
-        if (ps > 0) load_rows(kc, ps);
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = ps * 512 + sl * 256 + wave * 16 + u * 4 + kk;
-                const float4 k4 = (j == pos) ? kn4 : r[sl][u];
-                float a = q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
-                a = group16_sum(a);
-                if (sub == 0 && j < L) sc[j] = a * 0.125f;
-            }
-    }
-    load_rows(vc, 0);                                // in flight during the softmax reductions
-    __syncthreads();
-    float m = -__builtin_huge_valf();
-    for (int j = tid; j < L; j += 1024) m = fmaxf(m, sc[j]);
-    m = block_max(m, red);
-    float s = 0.f;
-    for (int j = tid; j < L; j += 1024) { const float e = expf(sc[j] - m); sc[j] = e; s += e; }
-    s = block_sum(s, red);
-    __syncthreads();
+    const float NEG = -__builtin_huge_valf();
+    float m_run = NEG, l_run = 0.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int ps = 0; ps < npass; ++ps) {
-        if (ps > 0) load_rows(vc, ps);
+        if (ps > 0) load_pass(ps);
+        float sc[NS];
+        float mt = NEG;
 #pragma unroll
-        for (int sl = 0; sl < 2; ++sl)
+        for (int sl = 0; sl < NS; ++sl) {
+            const int j = ps * PASS + sl * 16 + grp;
+            const float4 kk = (j == pos) ? kn4 : k4[sl];
+            float a = q4.x * kk.x + q4.y * kk.y + q4.z * kk.z + q4.w * kk.w;
+            a = group16_sum(a) * 0.125f;
+            sc[sl] = j < L ? a : NEG;
+            mt = fmaxf(mt, sc[sl]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));
+        if (lane == 0) redm[wave] = mt;
+        __syncthreads();
+        const float m_new = fmaxf(m_run, fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3])));
+        const float scale = (m_run == NEG) ? 0.f : expf(m_run - m_new);
+        acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+        float lt = 0.f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = ps * 512 + sl * 256 + wave * 16 + u * 4 + kk;
-                const float4 v4 = (j == pos) ? vn4 : r[sl][u];
-                const float pj = j < L ? sc[j] : 0.f;
-                acc.x += pj * v4.x; acc.y += pj * v4.y; acc.z += pj * v4.z; acc.w += pj * v4.w;
-            }
+        for (int sl = 0; sl < NS; ++sl) {
+            const int j = ps * PASS + sl * 16 + grp;
+            const float e = (sc[sl] == NEG) ? 0.f : expf(sc[sl] - m_new);
+            const float4 vv = (j == pos) ? vn4 : v4[sl];
+            acc.x += e * vv.x; acc.y += e * vv.y; acc.z += e * vv.z; acc.w += e * vv.w;
+            lt += e;
+        }
+        l_run = l_run * scale + lt;                 // per-group partial (identical on the 16 lanes of a group)
+        m_run = m_new;
+        __syncthreads();                             // redm is rewritten by the next pass
     }
+    // combine the 4 groups of a wave by shuffles, the 4 waves through LDS (fixed order)
     acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
     acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
-    if (kk == 0) *reinterpret_cast<float4*>(&op[wave][sub * 4]) = acc;
+    l_run += __shfl_xor(l_run, 16); l_run += __shfl_xor(l_run, 32);
+    if ((lane >> 4) == 0) *reinterpret_cast<float4*>(&op[wave][sub * 4]) = acc;
+    if (lane == 0) redl[wave] = l_run;
     __syncthreads();
     if (tid < 64) {
-        float o = 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) o += op[w][tid];
-        p.out[h * 64 + tid] = o / s;
+        const float l = redl[0] + redl[1] + redl[2] + redl[3];
+        p.out[h * 64 + tid] = (op[0][tid] + op[1][tid] + op[2][tid] + op[3][tid]) / l;
     }
 }
 

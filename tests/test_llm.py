@@ -100,7 +100,7 @@ def test_kv_capacity_is_checked(lib, tiny_sd):
 
 
 def test_long_context_multi_pass_attention(lib, tiny_sd):
-    """Contexts > 512 keys take the multi-pass branch of attn_decode_kernel (and > 64-row tiles of the prefill attention)."""
+    """Contexts > 384 keys take the multi-pass branch of attn_decode_kernel (and > 64-row tiles of the prefill attention)."""
     cfg, sd = tiny_sd
     u = _utt(cfg, n_text=3, n_prompt_text=2, n_prompt_tok=560, seed=11)
     lm = Qwen2LM(sd, cfg, lib=lib, max_len=640, sampling="greedy", decode_chunk=4)
