@@ -35,13 +35,13 @@ AUDIO_S = N_GEN / 25.0
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def build_model():
+def build_model(flow_precision="bf16"):
     from cosyvoice_amd.configs import cv2
     from cosyvoice_amd.model import CosyVoice2Model
     from cosyvoice_amd import synthetic as W
     cfgs = cv2()
     model = CosyVoice2Model.from_state_dicts(W.make_llm(cfgs[0]), W.make_flow(cfgs[1]), W.make_hift(cfgs[2]), cfgs,
-                                             max_len=1024, sampling="greedy", decode_chunk=64)
+                                             max_len=1024, sampling="greedy", decode_chunk=64, fp16=(flow_precision == "bf16"))
     u = W.synthetic_utterance(cfgs[0], cfgs[1], n_prompt_tok=N_PROMPT_TOK, n_prompt_text=N_PROMPT_TEXT, n_text=N_TEXT)
     dev = model.device
     u = {k: v.to(dev) for k, v in u.items()}
@@ -65,6 +65,41 @@ def one_utterance(model, u):
     model.hift_cache_dict.pop(uid, None)
     assert out.shape[1] == N_GEN * 2 * 480
     return out
+
+
+def concurrent_streams(model0, u, n_streams, steps):
+    """Serving-style extra: the batch-1 decode is a latency chain that leaves most of the 256 CUs idle, so S independent model
+    instances (own weights, KV cache, graphs and HIP streams; one host thread each - ctypes drops the GIL inside the library)
+    overlap on one GPU.  Not the headline `value` (that stays batch=1, one utterance in flight)."""
+    import threading
+    models = [model0] + [build_model("bf16" if model0.fp16 else "fp32")[0] for _ in range(n_streams - 1)]
+    for m in models[1:]:
+        one_utterance(m, u)
+    torch.cuda.synchronize()
+    errs = []
+
+    def work(m):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(steps):
+                    one_utterance(m, u)
+            s.synchronize()
+        except Exception as e:                      # pragma: no cover - reported below
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(m,)) for m in models]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if errs:
+        raise RuntimeError("; ".join(errs))
+    return {"streams": n_streams, "utterances": n_streams * steps, "audio_s_per_s": round(n_streams * steps * AUDIO_S / el, 3),
+            "ms_per_utterance_per_stream": round(1e3 * el / steps, 2)}
 
 
 def first_chunk_latency(model, u, reps):
@@ -179,6 +214,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--first-chunk-reps", type=int, default=3)
+    ap.add_argument("--flow-precision", choices=("bf16", "fp32"), default="bf16",
+                    help="operand precision of the flow's Linear/Conv1d products (BASELINE.json configs[1] is a bf16 configuration); "
+                         "fp32 = exact-fp32 MFMA everywhere")
+    ap.add_argument("--streams", type=int, default=1, help="extra (not `value`): S independent model instances on this GPU, one host thread + HIP "
+                    "stream each, all synthesising concurrently; reported as `concurrent_streams`")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -191,7 +231,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    model, u, cfgs = build_model()
+    model, u, cfgs = build_model(args.flow_precision)
     log("model built")
     for _ in range(args.warmup):
         one_utterance(model, u)
@@ -220,12 +260,17 @@ def main():
             "metric": "audio-sec/s (RTF^-1), CosyVoice2-0.5B zero-shot", "value": round(value, 3), "unit": "audio_s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (bf16 weights, fp32 activations and accumulate; HiFT fp32)", "data": "synthetic",
+            "dtype": ("bf16 weights everywhere; LLM: fp32 activations/accumulate (W16A32, token ids bit-exact); flow Linear/Conv1d: bf16 x bf16 "
+                      "MFMA with fp32 accumulate, attention/norms/Euler fp32; HiFT fp32") if args.flow_precision == "bf16" else
+                     "f32 (bf16 weights, fp32 activations and accumulate; HiFT fp32)", "data": "synthetic",
             "config": {"workload": "CosyVoice2-0.5B zero-shot, batch=1, 10 CFM Euler steps, synthetic U10: prompt 87 speech tokens / 174 mel frames, "
                                    "12+30 text tokens, 250 generated tokens = 10.0 s @ 24 kHz (BASELINE.json configs[1])",
-                       "utterances_per_gpu_per_step": 1, "sampler": "greedy, length forced to 250", "parallelism": "replicas x%d, no collective" % world},
+                       "utterances_per_gpu_per_step": 1, "sampler": "greedy, length forced to 250", "flow_precision": args.flow_precision, "parallelism": "replicas x%d, no collective" % world},
             "per_gpu_audio_s_per_s": round(value / world, 3),
         }
+        if world == 1 and args.streams > 1:
+            out["concurrent_streams"] = concurrent_streams(model, u, args.streams, args.steps)
+            log("concurrent streams done")
         if world == 1:
             out["first_chunk_ms_p50"] = round(first_chunk_latency(model, u, args.first_chunk_reps), 2)
             log("first chunk p50 %.1f ms" % out["first_chunk_ms_p50"])

@@ -76,7 +76,7 @@ int cv_gemm_conv(const cv_gemm_conv_args* g, void* stream) {
         a.W = g->W; a.Kp = g->Kp; a.ldw = g->ldw; a.w_batch = g->w_batch; a.bias = g->bias;
         a.C = g->C; a.c_batch = g->c_batch; a.c_len = g->c_len; a.ldc = g->ldc; a.c_off = g->c_off;
         a.M = g->M; a.N = g->N; a.act = g->act; a.act_p = g->act_p; a.res = g->res; a.res_batch = g->res_batch;
-        a.out_scale = g->out_scale; a.row_scale = g->row_scale; a.row_scale_batch = g->row_scale_batch; a.accumulate = g->accumulate;
+        a.out_scale = g->out_scale; a.row_scale = g->row_scale; a.row_scale_batch = g->row_scale_batch; a.accumulate = g->accumulate; a.a_bf16 = g->a_bf16;
         CV_CHECK(g->w_dtype == CV_F32 || g->w_dtype == CV_BF16, "cv_gemm_conv: w_dtype");
         cv::gemm_conv(a, g->w_dtype == CV_BF16, g->batch, cv::as_stream(stream));
     });

@@ -54,20 +54,35 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
+__device__ __forceinline__ float group16_sum(float v);
+__device__ __forceinline__ float group16_max(float v);
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    v = group16_sum(v);
+    v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    v = group16_max(v);
+    v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 32));
     return v;
+}
+// Exchanges inside a 16-lane DPP row run on the VALU (no ds_bpermute round trip through the LDS crossbar): xor 1 / xor 2 as
+// quad permutes, then "the other quad of my half" (row_half_mirror) and "the other half of my row" (row_mirror).  After the
+// two quad steps every lane of a quad holds the same value, so the mirrors pair equal partners: all 16 lanes end bit-identical.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 // reduce over aligned groups of 16 lanes
 __device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    v += dpp_row<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_row<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_row<0x141>(v);         // row_half_mirror
+    v += dpp_row<0x140>(v);         // row_mirror
+    return v;
+}
+__device__ __forceinline__ float group16_max(float v) {
+    v = fmaxf(v, dpp_row<0xB1>(v)); v = fmaxf(v, dpp_row<0x4E>(v)); v = fmaxf(v, dpp_row<0x141>(v)); v = fmaxf(v, dpp_row<0x140>(v));
     return v;
 }
 

@@ -51,6 +51,7 @@ struct cv_flow {
     // hipGraph cache of the whole Euler solve, keyed by (T, n_steps, streaming): ~5000 launches per utterance become one replay.
     // A key is captured the second time it is seen (streaming requests change T every chunk and would only pay the instantiation).
     bool use_graph = true;
+    int bf16_mfma = 0;                 // 1: Linear / Conv1d products on the bf16 MFMA (activations rounded to bf16 in LDS), 0: exact fp32 MFMA
     std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
     std::map<std::tuple<int, int, int>, int> seen;
     hipStream_t own_stream = nullptr;
@@ -130,6 +131,10 @@ static void flow_finalize(cv_flow* m) {
     m->finalized = true;
 }
 
+// precision of the Linear / Conv1d products issued by the current entry point (set from the handle's option for the duration of a call)
+static thread_local int tl_bf16_mfma = 0;
+struct PrecisionScope { int prev; explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma) { tl_bf16_mfma = m->bf16_mfma; } ~PrecisionScope() { tl_bf16_mfma = prev; } };
+
 // ---- generic conv/linear on channel-last activations -----------------------------------------------------------------
 // rows: M per batch, `a_rows` valid input rows per batch (zero padding outside), tap j reads row (m + j*dil - pad_left)
 static void conv_cl(const Lin& l, const float* A, int a_rows, int M, int batch, int pad_left, int dil, float* C, int act, float act_p,
@@ -142,6 +147,7 @@ static void conv_cl(const Lin& l, const float* A, int a_rows, int M, int batch, 
     a.C = C; a.c_batch = (long long)M * ldc; a.c_len = (long long)M * ldc; a.ldc = ldc; a.c_off = 0; a.M = M; a.N = l.N;
     a.act = act; a.act_p = act_p; a.res = res; a.res_batch = (long long)M * ldc; a.out_scale = 1.f;
     a.row_scale = row_scale; a.row_scale_batch = M; a.accumulate = 0;
+    a.a_bf16 = tl_bf16_mfma && l.bf16;
     gemm_conv(a, l.bf16, batch, s);
 }
 static void lin_cl(const Lin& l, const float* A, long long rows, float* C, int act, const float* res, hipStream_t s, int pro = ACT_NONE) {
@@ -389,6 +395,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
     return guarded([&] {
         CV_CHECK(m && name, "null argument");
         if (std::string(name) == "use_graph") { m->use_graph = value != 0; drop_graphs(m); }
+        else if (std::string(name) == "bf16_mfma") { m->bf16_mfma = value != 0; drop_graphs(m); }      // captured graphs bake the kernel choice
         else throw Error(std::string("unknown option ") + name);
     });
 }
@@ -403,6 +410,7 @@ void cv_flow_destroy(cv_flow* m) {
 
 int cv_flow_encoder(cv_flow* m, const float* tok_emb, int32_t n_tok, const float* context, int32_t streaming, float* h_out, void* stream) {
     return guarded([&] { CV_CHECK(m && m->finalized && tok_emb && h_out, "cv_flow_encoder: bad arguments");
+                         PrecisionScope prec(m);
                          flow_encoder(m, tok_emb, n_tok, context, streaming, h_out, as_stream(stream)); });
 }
 
@@ -410,6 +418,7 @@ int cv_flow_estimator(cv_flow* m, const float* x, const float* mask, const float
                       int32_t T, int32_t streaming, float* out, void* stream) {
     return guarded([&] {
         CV_CHECK(m && m->finalized && x && mu && t && spks && cond && out && T > 0, "cv_flow_estimator: bad arguments");
+        PrecisionScope prec(m);
         hipStream_t s = as_stream(stream);
         const auto& c = m->cfg;
         est_reserve(m, T); time_reserve(m, 2);
@@ -426,6 +435,7 @@ int cv_flow_inference(cv_flow* m, const int32_t* token_ids, int32_t n_tok, const
                       const float* noise_cl, int32_t streaming, int32_t finalize, int32_t n_timesteps, float* mel_out, int32_t* mel_len2_out, void* stream) {
     return guarded([&] {
         CV_CHECK(m && m->finalized && token_ids && embedding && noise_cl && mel_out && mel_len2_out, "cv_flow_inference: bad arguments");
+        PrecisionScope prec(m);
         const auto& c = m->cfg; const int d = c.dim;
         hipStream_t s = resolve(m, stream);
         void* stream_r = reinterpret_cast<void*>(s);

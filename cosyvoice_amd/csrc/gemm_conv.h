@@ -11,6 +11,10 @@
 //   zero padded by the host repacker (cosyvoice_amd/weights.py).
 // * math: v_mfma_f32_16x16x4_f32 — bitwise an fp32 fma chain (cdna_hip_programming.md §3), so the
 //   result differs from the CPU oracle only by summation order.
+// * ABF16 variant ("W16A16 operands, fp32 accumulate", BASELINE.json configs[1] is a bf16 configuration): the prologue'd
+//   activations are rounded to bf16 (round-to-nearest-even) when they are staged into LDS, weights stay bf16, the product
+//   runs on v_mfma_f32_16x16x32_bf16 (8x the fp32 MFMA rate, half / quarter the LDS bytes).  Activations in HBM, bias,
+//   epilogue and accumulation stay fp32.  The oracle mirrors the rounding (oracle/flow.py `bf16_act`).
 #pragma once
 #include "common.h"
 
@@ -33,15 +37,27 @@ struct GemmConvArgs {
     float out_scale;
     const float* row_scale; long long row_scale_batch;  // per-row multiplier (time mask), null = none
     int accumulate;                 // C += result
+    int a_bf16;                     // 1: bf16 x bf16 MFMA (needs bf16 weights); 0: exact-fp32 MFMA
     long long* dbg;                 // dev tool (tools/ubench/gemm_probe.hip): per-phase clock64() stamps of wave 0, 64 slots per workgroup; null in production
 };
 
 // Pipeline: most GEMMs on this path are small (M ~ 10^3, K = 256..1024) and run ~1 workgroup per CU, so nothing hides global
 // latency but the kernel itself: a 2-deep REGISTER prefetch ring keeps the loads of k-tiles it+1 and it+2 in flight while tile
 // it is multiplied out of LDS, and the small tiles use BK = 64 to halve the number of barrier-separated iterations.
-template <int BM, int BN, int BK, bool WBF16, bool AVEC, int STAGES = 2>
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+
+// fp32 pair -> packed bf16 pair, round-to-nearest-even (integer form: identical on the device, in the emulator and in numpy)
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a += 0x7fffu + ((a >> 16) & 1u); b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
+
+template <int BM, int BN, int BK, bool WBF16, bool AVEC, int STAGES = 2, bool ABF16 = false>
 __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
-    constexpr int LD = BK + 4, KV = BK / 4;         // float4 groups per tile row
+    static_assert(!ABF16 || WBF16, "the bf16 MFMA path takes bf16 weights");
+    // LD = LDS row pitch in dwords.  fp32 tiles: BK + 4.  bf16 tiles hold BK/2 packed pairs + 4 dwords of padding.
+    constexpr int LD = ABF16 ? BK / 2 + 4 : BK + 4, KV = BK / 4;         // KV = groups of 4 k-values per tile row
     constexpr int TM = BM / 32, TN = BN / 32;       // 16x16 tiles per wave (wave tile = BM/2 x BN/2)
     constexpr int AV = BM * KV / 256, WV = BN * KV / 256;   // float4 groups per thread per k-step
     __shared__ __attribute__((aligned(16))) float As[BM * LD];
@@ -120,8 +136,9 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
             float4 wv;
             if (WBF16) {
                 const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.W) + idx);
-                wv = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
-                                 __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+                if (ABF16) wv = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);      // raw pairs, staged as they are
+                else wv = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                      __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
             } else {
                 wv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.W) + idx);
             }
@@ -148,12 +165,37 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
                     x.z = apply_act(p.pro, x.z, p.pro_p); x.w = apply_act(p.pro, x.w, p.pro_p);
                 }
             }
-            *reinterpret_cast<float4*>(&As[(v / KV) * LD + a_c4[i]]) = x;
+            if (ABF16) *reinterpret_cast<uint2*>(&As[(v / KV) * LD + a_c4[i] / 2]) = make_uint2(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w));
+            else *reinterpret_cast<float4*>(&As[(v / KV) * LD + a_c4[i]]) = x;
         }
 #pragma unroll
-        for (int i = 0; i < WV; ++i) { const int v = tid + i * 256; *reinterpret_cast<float4*>(&Ws[(v / KV) * LD + w_c4[i]]) = rw[i]; }
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + i * 256;
+            if (ABF16) *reinterpret_cast<uint2*>(&Ws[(v / KV) * LD + w_c4[i] / 2]) = make_uint2(__float_as_uint(rw[i].x), __float_as_uint(rw[i].y));
+            else *reinterpret_cast<float4*>(&Ws[(v / KV) * LD + w_c4[i]]) = rw[i];
+        }
     };
     auto compute_tile = [&]() {
+        if constexpr (ABF16) {
+            // v_mfma_f32_16x16x32_bf16: lane (r = lane & 15, g = lane >> 4) supplies k = 8g .. 8g+7 of row r for both operands
+#pragma unroll
+            for (int kg = 0; kg < BK / 32; ++kg) {
+                uint4 af[TM], wf[TN];
+                const int kd = kg * 16 + (lane >> 4) * 4;               // dword offset of the lane's 8 bf16
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[i] = *reinterpret_cast<const uint4*>(&As[(wm * (BM / 2) + i * 16 + (lane & 15)) * LD + kd]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    wf[j] = *reinterpret_cast<const uint4*>(&Ws[(wn * (BN / 2) + j * 16 + (lane & 15)) * LD + kd]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, wf[j]), __builtin_bit_cast(v8bf, af[i]), acc[i][j], 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int kg = 0; kg < BK / 16; ++kg) {
             float4 af[TM], wf[TN];

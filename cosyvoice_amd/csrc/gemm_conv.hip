@@ -7,6 +7,10 @@ namespace cv {
 template <int BM, int BN, int BK, int ST = 2>
 static void launch_cfg(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t stream) {
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, batch), block(256);
+    if (a.a_bf16 && w_bf16 && a.a_vec) {        // bf16 x bf16 MFMA (fp32 accumulate); other layouts keep the exact-fp32 path
+        hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, true, true, ST, true>), grid, block, 0, stream, a);
+        return;
+    }
     if (a.a_vec) {
         if (w_bf16) hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, true, true, ST>), grid, block, 0, stream, a);
         else        hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, false, true, ST>), grid, block, 0, stream, a);

@@ -24,7 +24,8 @@ struct cv_llm {
     // device state
     DevBuf kcache, vcache, rope_cos, rope_sin, state, tokens, uniforms, sparams;
     SampleParams* host_sp = nullptr;
-    DevBuf h, qkv, attn, act, logits;                  // decode activations
+    DevBuf h, qkv, act, logits, attn_part;            // decode activations (+ split-attention partials)
+    int attn_splits = 8;
     DevBuf pf_x, pf_xn, pf_qkv, pf_attn, pf_gu, pf_act; // prefill activations (grown on demand)
     int pf_rows = 0;
     // decode graph
@@ -84,7 +85,8 @@ static void llm_finalize(cv_llm* m) {
     m->state.ensure(sizeof(DecodeState));
     m->tokens.ensure((size_t)c.max_len * sizeof(int));
     m->uniforms.ensure((size_t)c.max_len * 2 * sizeof(float));
-    m->h.ensure(H * 4); m->qkv.ensure((size_t)m->qkv_dim * 4); m->attn.ensure((size_t)c.heads * 64 * 4);
+    m->h.ensure(H * 4); m->qkv.ensure((size_t)m->qkv_dim * 4);
+    m->attn_part.ensure((size_t)c.heads * 16 * ATTN_PART * 4);
     m->act.ensure((size_t)c.inter * 4); m->logits.ensure((size_t)m->V * 4);
     CV_HIP(hipHostMalloc((void**)&m->host_tokens, (size_t)c.max_len * sizeof(int)));
     CV_HIP(hipHostMalloc((void**)&m->host_state, sizeof(DecodeState)));
@@ -158,8 +160,17 @@ struct ProfScope {
 };
 
 // picks the instantiation from K (= 128 * steps): <=7 steps -> one wave per 4*ROWS rows; <=40 steps -> 4-way split-K
-static void gemv(const GemvArgs& a, int rows, hipStream_t s) {
+static void gemv(const GemvArgs& a, int rows, hipStream_t s, int nsp = 0) {
     const int steps = a.K / 128;
+    if (nsp > 0) {                                   // o_proj over split-attention partials (rows == 1, K = heads * 64 <= 1024)
+        CV_CHECK(steps <= 8 && rows == 1 && a.mode == 0 && !a.gamma && a.part, "gemv: partial-combine prologue is for the o_proj shape only");
+        const dim3 g4((a.N + 3) / 4);
+        if (nsp == 4) hipLaunchKernelGGL((gemv_kernel<2, 1, 4, 4>), g4, dim3(256), 0, s, a);
+        else if (nsp == 8) hipLaunchKernelGGL((gemv_kernel<2, 1, 4, 8>), g4, dim3(256), 0, s, a);
+        else if (nsp == 16) hipLaunchKernelGGL((gemv_kernel<2, 1, 4, 16>), g4, dim3(256), 0, s, a);
+        else throw Error("gemv: attn_splits must be 4, 8 or 16");
+        return;
+    }
     CV_CHECK(a.K % 128 == 0 && steps >= 1 && steps <= 40, "gemv: K must be a multiple of 128 and at most 5120");
     const int units = a.mode == 1 ? a.N / 2 : (a.N + rows - 1) / rows;       // 16-lane groups needed
     const dim3 grid((units + 3) / 4);
@@ -178,7 +189,7 @@ static void gemv(const GemvArgs& a, int rows, hipStream_t s) {
 static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
     const auto& c = m->cfg;
     const DecodeState* st = m->state.as<DecodeState>();
-    float* h = m->h.as<float>(); float* qkv = m->qkv.as<float>(); float* at = m->attn.as<float>(); float* act = m->act.as<float>();
+    float* h = m->h.as<float>(); float* qkv = m->qkv.as<float>(); float* act = m->act.as<float>();
     { ProfScope ps(m, s, 5); gemv(GemvArgs{m->head_w, m->head_b, h, m->logits.as<float>(), m->V, c.hidden, m->norm, c.rms_eps, nullptr, 0, st}, 2, s); }
     SampleArgs sa{};
     sa.logits = m->logits.as<float>(); sa.V = m->V; sa.sp = m->sparams.as<SampleParams>(); sa.uniforms = m->uniforms.as<float>();
@@ -188,10 +199,14 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
     for (int i = 0; i < c.layers; ++i) {
         const auto& L = m->layers[i];
         { ProfScope ps(m, s, 0); gemv(GemvArgs{L.wqkv, L.bqkv, h, qkv, m->qkv_dim, c.hidden, L.ln1, c.rms_eps, nullptr, 0, st}, 1, s); }
+        const int nsp = m->attn_splits;
         AttnDecodeArgs ad{qkv, m->kcache.as<float>() + m->layer_cache() * i, m->vcache.as<float>() + m->layer_cache() * i,
-                          m->rope_cos.as<float>(), m->rope_sin.as<float>(), at, c.heads, c.kv_heads, c.max_len, st};
-        { ProfScope ps(m, s, 1); hipLaunchKernelGGL(attn_decode_kernel, dim3(c.heads), dim3(256), 0, s, ad); }
-        { ProfScope ps(m, s, 2); gemv(GemvArgs{L.wo, nullptr, at, h, c.hidden, c.heads * 64, nullptr, 0.f, h, 0, st}, 1, s); }
+                          m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st,
+                          m->attn_part.as<float>(), nsp};
+        { ProfScope ps(m, s, 1); hipLaunchKernelGGL(attn_decode_kernel, dim3(c.heads * nsp), dim3(64), 0, s, ad); }
+        GemvArgs go{L.wo, nullptr, nullptr, h, c.hidden, c.heads * 64, nullptr, 0.f, h, 0, st};
+        go.part = m->attn_part.as<float>();
+        { ProfScope ps(m, s, 2); gemv(go, 1, s, nsp); }
         { ProfScope ps(m, s, 3); gemv(GemvArgs{L.wgu, nullptr, h, act, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 1, st}, 2, s); }
         { ProfScope ps(m, s, 4); gemv(GemvArgs{L.wdown, nullptr, act, h, c.hidden, c.inter, nullptr, 0.f, h, 0, st}, 1, s); }
     }
@@ -265,7 +280,12 @@ void cv_llm_destroy(cv_llm* m) {
 int cv_llm_set_option(cv_llm* m, const char* name, int32_t value) {
     return guarded([&] {
         CV_CHECK(m && name, "null argument");
+        std::lock_guard<std::recursive_mutex> lk(runtime_lock());
         if (std::string(name) == "use_graph") { m->use_graph = value != 0; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; } }
+        else if (std::string(name) == "attn_splits") {       // key-range slices per head in the decode attention (4, 8 or 16)
+            CV_CHECK(value == 4 || value == 8 || value == 16, "attn_splits must be 4, 8 or 16");
+            m->attn_splits = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+        }
         else throw Error(std::string("unknown option ") + name);
     });
 }

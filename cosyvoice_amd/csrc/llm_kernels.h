@@ -30,7 +30,10 @@ struct DecodeState {       // lives in device memory (one per cv_llm handle)
 struct GemvArgs {
     const bf16_t* W; const float* bias; const float* x; float* y; int N, K;
     const float* gamma; float eps; const float* res; int mode; const DecodeState* st;
+    const float* part = nullptr;   // NSP > 0: x is the combination of NSP split-attention partials, [K/64][NSP][ATTN_PART] (see attn_decode_kernel)
 };
+
+constexpr int ATTN_PART = 68;      // 64 unnormalised numerators + running max + denominator (+2 pad: rows stay 16-byte aligned)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -38,7 +41,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // every lane first issues ALL of its weight loads (ROWS x STEPS x 16 B, non-temporal: each byte is read once per token),
 // then its slice of x (and gamma) straight from L2 into registers — no LDS staging, no barrier before the weights are in
 // flight.  RMSNorm statistics come from a 16-lane shuffle reduction (each group covers the whole row when WAVES == 1).
-template <int STEPS, int ROWS, int WAVES>
+template <int STEPS, int ROWS, int WAVES, int NSP = 0>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     __shared__ float part[WAVES][4][ROWS];
     // no `done` test here: it would put a dependent load in front of the weight stream; a finished request simply recomputes
@@ -63,13 +66,52 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
         }
     }
     float4 xa[STEPS], xb[STEPS];
+    if constexpr (NSP == 0) {
 #pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-        const bool ok = s0 + s < s1;
-        const int so = ok ? (s0 + s) : s0;
-        xa[s] = *reinterpret_cast<const float4*>(p.x + so * 128 + sub * 8);
-        xb[s] = *reinterpret_cast<const float4*>(p.x + so * 128 + sub * 8 + 4);
-        if (!ok) { xa[s] = make_float4(0.f, 0.f, 0.f, 0.f); xb[s] = xa[s]; }
+        for (int s = 0; s < STEPS; ++s) {
+            const bool ok = s0 + s < s1;
+            const int so = ok ? (s0 + s) : s0;
+            xa[s] = *reinterpret_cast<const float4*>(p.x + so * 128 + sub * 8);
+            xb[s] = *reinterpret_cast<const float4*>(p.x + so * 128 + sub * 8 + 4);
+            if (!ok) { xa[s] = make_float4(0.f, 0.f, 0.f, 0.f); xb[s] = xa[s]; }
+        }
+    } else {
+        // x = softmax-combination of the NSP partial attention results of each head (flash-decoding merge, fixed order).  The
+        // workgroup merges ONCE: thread t owns dims 4t..4t+3 (head t / 16), i.e. NSP float4 + NSP (max, denominator) pairs per
+        // thread, and publishes x through LDS - the 4 row-groups of every wave would otherwise each fetch the same partials
+        // (64 load instructions per lane measured +2 us on the o_proj launch: address-unit bound, not bandwidth bound).
+        static_assert(WAVES == 4, "partial-combine prologue: 256 threads cover K <= 1024");
+        __shared__ __attribute__((aligned(16))) float xs[1024];
+        if (tid * 4 < p.K) {
+            const float* ph = p.part + (long long)(tid >> 4) * NSP * ATTN_PART;
+            float4 pa[NSP]; float2 ml[NSP];
+#pragma unroll
+            for (int q = 0; q < NSP; ++q) {
+                pa[q] = *reinterpret_cast<const float4*>(ph + q * ATTN_PART + (tid & 15) * 4);
+                ml[q] = *reinterpret_cast<const float2*>(ph + q * ATTN_PART + 64);
+            }
+            float M = ml[0].x;
+#pragma unroll
+            for (int q = 1; q < NSP; ++q) M = fmaxf(M, ml[q].x);
+            float den = 0.f; float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < NSP; ++q) {
+                const float w = (ml[q].y > 0.f) ? expf(ml[q].x - M) : 0.f;       // an empty slice carries l = 0
+                den += w * ml[q].y;
+                a.x += w * pa[q].x; a.y += w * pa[q].y; a.z += w * pa[q].z; a.w += w * pa[q].w;
+            }
+            const float inv = 1.f / den;
+            *reinterpret_cast<float4*>(&xs[tid * 4]) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const bool ok = s0 + s < s1;
+            const int so = ok ? (s0 + s) : s0;
+            xa[s] = *reinterpret_cast<const float4*>(&xs[so * 128 + sub * 8]);
+            xb[s] = *reinterpret_cast<const float4*>(&xs[so * 128 + sub * 8 + 4]);
+            if (!ok) { xa[s] = make_float4(0.f, 0.f, 0.f, 0.f); xb[s] = xa[s]; }
+        }
     }
     if (p.gamma) {                                           // fused Qwen2RMSNorm (host guarantees WAVES == 1 here)
         // gamma is requested BEFORE the reduction so its round trip overlaps the weight stream instead of following the shuffles
@@ -137,87 +179,86 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Decode attention for one new position (GQA, head_dim 64), fused with rotate-half RoPE on q/k and the KV-cache append.
-// One workgroup per query head.  qkv = [q(H*64) | k(Hkv*64) | v(Hkv*64)] raw projections (+bias) of the new token.
-// Context length limit: 2048 keys (LDS score buffer).
+// qkv = [q(H*64) | k(Hkv*64) | v(Hkv*64)] raw projections (+bias) of the new token.
 // cache layout: K,V [Hkv][max_len][64] fp32.  rope table: cos/sin [max_len][32].
 // ---------------------------------------------------------------------------------------------------------------
 struct AttnDecodeArgs {
     const float* qkv; float* kcache; float* vcache; const float* rope_cos; const float* rope_sin;
-    float* out; int heads, kv_heads, max_len; const DecodeState* st;
+    int heads, kv_heads, max_len; const DecodeState* st;
+    float* part; int nsplit;      // wave (h, s) covers the s-th contiguous slice of the keys and writes part[h][s][ATTN_PART]
 };
 
-// 256 threads = 16 lane-groups of 16; a group covers one key row per slot with float4 loads, NS = 24 slots -> 384 keys per pass
-// (the whole context of the benchmark utterance: 131 + 250 = 381).  ALL K rows and ALL V rows of a pass are requested as soon as
-// `pos` is known: one memory round trip per pass for the entire cache read.  Scores never leave registers (every lane of a group
-// holds its key's score after the 16-lane reduction), softmax is online across passes (running max / sum, per-thread partial
-// numerators rescaled by a block-uniform factor), and the block synchronises 4 times per pass instead of ~9.
-static __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs p) {
-    constexpr int NS = 24, PASS = 16 * NS;
-    __shared__ __attribute__((aligned(16))) float qs[64];
-    __shared__ __attribute__((aligned(16))) float knew[64];
-    __shared__ float redm[4], redl[4];
-    __shared__ __attribute__((aligned(16))) float op[4][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sub = tid & 15, grp = tid >> 4;
-    const int h = blockIdx.x, g = h / (p.heads / p.kv_heads);
+// ONE WAVE per (query head, key slice) - the structure the decode GEMVs proved on this chip: single-wave workgroups, no LDS, no
+// barrier, every load of a pass requested before anything is consumed.  A 16-lane group covers one key row with float4 loads,
+// the 4 groups of the wave take 4 consecutive keys, NS = 12 slots -> 48 keys per pass (the 381-key context of the benchmark
+// utterance over 8 slices is exactly one pass).  q and the new k get their rotate-half RoPE in registers straight from the
+// qkv vector; scores stay in registers; softmax is online across passes with shuffle-only reductions.  Each wave leaves an
+// un-normalised partial (64 numerators, running max, denominator); the o_proj GEMV merges the nsplit partials of every head
+// in its prologue (gemv_kernel<..., NSP>): no atomics, no extra launch, fixed summation order.
+// (A workgroup-per-head version with the K/V slice in 2 x 24 float4 registers per lane and LDS reductions measured 14-17 us per
+// launch on MI355X - register-array spills and ~60 full vmcnt waits - against 2.8-7 us for the GEMVs around it.)
+static __global__ __launch_bounds__(64) void attn_decode_kernel(AttnDecodeArgs p) {
+    constexpr int NS = 12, PASS = 4 * NS;
+    const int lane = threadIdx.x, sub = lane & 15, grp = lane >> 4;
+    const int h = blockIdx.x / p.nsplit, sp = blockIdx.x % p.nsplit, gsz = p.heads / p.kv_heads, g = h / gsz;
     const int pos = p.st->pos;                       // the new token sits at index `pos`
-    const int L = pos + 1, npass = (L + PASS - 1) / PASS;
-    const float* kq = p.qkv + p.heads * 64 + g * 64;
-    const float* vq = p.qkv + (p.heads + p.kv_heads) * 64 + g * 64;
-    float* kc = p.kcache + (long long)g * p.max_len * 64;
-    float* vc = p.vcache + (long long)g * p.max_len * 64;
+    const int L = pos + 1;
+    const int per = ((L + p.nsplit * 4 - 1) / (p.nsplit * 4)) * 4;           // keys per slice (multiple of 4)
+    const int kb = sp * per, ke = min(L, kb + per);
+    const float* kc = p.kcache + (long long)g * p.max_len * 64;
+    const float* vc = p.vcache + (long long)g * p.max_len * 64;
     float4 k4[NS], v4[NS];
-    auto load_pass = [&](int ps) {
+    auto load_pass = [&](int base) {
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
-            const int j = ps * PASS + sl * 16 + grp;
-            const long long o = (long long)(j < pos ? j : 0) * 64 + sub * 4;      // unconditional (clamped) loads
+            const int j = base + sl * 4 + grp;
+            const long long o = (long long)((j < pos && j < ke) ? j : 0) * 64 + sub * 4;      // unconditional, clamped
             k4[sl] = *reinterpret_cast<const float4*>(kc + o);
             v4[sl] = *reinterpret_cast<const float4*>(vc + o);
         }
     };
-    load_pass(0);
-    if (tid < 64) {
-        const int d = tid, f = d & 31;
-        const float c = p.rope_cos[pos * 32 + f], s = p.rope_sin[pos * 32 + f];
-        const float* qraw = p.qkv + h * 64;
-        const float qr = d < 32 ? -qraw[d + 32] : qraw[d - 32];
-        qs[d] = qraw[d] * c + qr * s;
-        const float kr = d < 32 ? -kq[d + 32] : kq[d - 32];
-        const float kn = kq[d] * c + kr * s;
-        knew[d] = kn;
-        if (!p.st->done && h % (p.heads / p.kv_heads) == 0) { kc[(long long)pos * 64 + d] = kn; vc[(long long)pos * 64 + d] = vq[d]; }
+    load_pass(kb);
+    // rotate-half RoPE in registers: lane dims d = sub*4 .. +3, partner dims (d + 32) % 64, sign - for d < 32
+    const float* qraw = p.qkv + h * 64;
+    const float* kq = p.qkv + p.heads * 64 + g * 64;
+    const float* vq = p.qkv + (p.heads + p.kv_heads) * 64 + g * 64;
+    const int d0 = sub * 4, dp = (d0 + 32) & 63;
+    const float4 c4 = *reinterpret_cast<const float4*>(p.rope_cos + pos * 32 + (d0 & 31));
+    const float4 s4 = *reinterpret_cast<const float4*>(p.rope_sin + pos * 32 + (d0 & 31));
+    const float4 qa = *reinterpret_cast<const float4*>(qraw + d0), qb = *reinterpret_cast<const float4*>(qraw + dp);
+    const float4 ka = *reinterpret_cast<const float4*>(kq + d0), kp = *reinterpret_cast<const float4*>(kq + dp);
+    const float4 vn4 = *reinterpret_cast<const float4*>(vq + d0);
+    const float sg = d0 < 32 ? -1.f : 1.f;
+    const float4 q4 = make_float4(qa.x * c4.x + sg * qb.x * s4.x, qa.y * c4.y + sg * qb.y * s4.y, qa.z * c4.z + sg * qb.z * s4.z, qa.w * c4.w + sg * qb.w * s4.w);
+    const float4 kn4 = make_float4(ka.x * c4.x + sg * kp.x * s4.x, ka.y * c4.y + sg * kp.y * s4.y, ka.z * c4.z + sg * kp.z * s4.z, ka.w * c4.w + sg * kp.w * s4.w);
+    if (!p.st->done && sp == 0 && h % gsz == 0 && grp == 0) {               // KV-cache append: one wave per kv head
+        *reinterpret_cast<float4*>(p.kcache + ((long long)g * p.max_len + pos) * 64 + d0) = kn4;
+        *reinterpret_cast<float4*>(p.vcache + ((long long)g * p.max_len + pos) * 64 + d0) = vn4;
     }
-    __syncthreads();
-    const float4 q4 = *reinterpret_cast<const float4*>(&qs[sub * 4]);
-    const float4 kn4 = *reinterpret_cast<const float4*>(&knew[sub * 4]);
-    const float4 vn4 = *reinterpret_cast<const float4*>(vq + sub * 4);
     const float NEG = -__builtin_huge_valf();
     float m_run = NEG, l_run = 0.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int ps = 0; ps < npass; ++ps) {
-        if (ps > 0) load_pass(ps);
+    for (int base = kb; base < ke; base += PASS) {   // wave-uniform
+        if (base != kb) load_pass(base);
         float sc[NS];
         float mt = NEG;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
-            const int j = ps * PASS + sl * 16 + grp;
+            const int j = base + sl * 4 + grp;
             const float4 kk = (j == pos) ? kn4 : k4[sl];
             float a = q4.x * kk.x + q4.y * kk.y + q4.z * kk.z + q4.w * kk.w;
             a = group16_sum(a) * 0.125f;
-            sc[sl] = j < L ? a : NEG;
+            sc[sl] = j < ke ? a : NEG;
             mt = fmaxf(mt, sc[sl]);
         }
         mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));
-        if (lane == 0) redm[wave] = mt;
-        __syncthreads();
-        const float m_new = fmaxf(m_run, fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3])));
+        const float m_new = fmaxf(m_run, mt);        // finite: the pass holds at least one key
         const float scale = (m_run == NEG) ? 0.f : expf(m_run - m_new);
         acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
         float lt = 0.f;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
-            const int j = ps * PASS + sl * 16 + grp;
+            const int j = base + sl * 4 + grp;
             const float e = (sc[sl] == NEG) ? 0.f : expf(sc[sl] - m_new);
             const float4 vv = (j == pos) ? vn4 : v4[sl];
             acc.x += e * vv.x; acc.y += e * vv.y; acc.z += e * vv.z; acc.w += e * vv.w;
@@ -225,19 +266,13 @@ static __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs 
         }
         l_run = l_run * scale + lt;                 // per-group partial (identical on the 16 lanes of a group)
         m_run = m_new;
-        __syncthreads();                             // redm is rewritten by the next pass
     }
-    // combine the 4 groups of a wave by shuffles, the 4 waves through LDS (fixed order)
     acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
     acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
     l_run += __shfl_xor(l_run, 16); l_run += __shfl_xor(l_run, 32);
-    if ((lane >> 4) == 0) *reinterpret_cast<float4*>(&op[wave][sub * 4]) = acc;
-    if (lane == 0) redl[wave] = l_run;
-    __syncthreads();
-    if (tid < 64) {
-        const float l = redl[0] + redl[1] + redl[2] + redl[3];
-        p.out[h * 64 + tid] = (op[0][tid] + op[1][tid] + op[2][tid] + op[3][tid]) / l;
-    }
+    float* pr = p.part + (long long)blockIdx.x * ATTN_PART;
+    if (grp == 0) *reinterpret_cast<float4*>(pr + d0) = acc;
+    if (lane == 0) { pr[64] = (l_run > 0.f) ? m_run : 0.f; pr[65] = l_run; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -78,7 +78,13 @@ class _CFM:
 
 
 class CausalMaskedDiffWithXvec:
-    def __init__(self, state_dict, cfg, lib=None, weight_dtype=torch.bfloat16, n_timesteps=None):
+    def __init__(self, state_dict, cfg, lib=None, weight_dtype=torch.bfloat16, n_timesteps=None, precision="fp32"):
+        """precision: "fp32" = W16A32, every product on the exact-fp32 MFMA; "bf16" = the Linear / Conv1d operands are rounded to
+        bf16 when staged into LDS and multiplied on the bf16 MFMA with fp32 accumulation (the reference's fp16 / TensorRT flow,
+        cli/model.py:83-92, is the analogous mode; BASELINE.json configs[1] is quoted in bf16).  Attention, norms, the Euler update
+        and every tensor in HBM stay fp32 in both modes."""
+        assert precision in ("fp32", "bf16")
+        self.precision = precision
         self.lib = lib or get_lib()
         self.cfg = cfg
         self.device = torch.device(self.lib.device)
@@ -95,6 +101,7 @@ class CausalMaskedDiffWithXvec:
         self.lib.cv_flow_create(C.byref(self._h), C.byref(c))
         register_tensors(self.lib, "cv_flow_set_tensor", self._h, self._tensors)
         self.lib.cv_flow_finalize(self._h)
+        self.lib.cv_flow_set_option(self._h, b"bf16_mfma", C.c_int32(int(precision == "bf16")))
         self.decoder = _CFM(self)
         self.encoder = _Encoder(self)
         # channel-last copy of the fixed CFM noise, made once (not on the hot path)

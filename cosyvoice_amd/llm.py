@@ -37,7 +37,7 @@ class Qwen2LM:
     'greedy' (the sampler north-star parity is defined on)."""
 
     def __init__(self, state_dict, cfg, lib=None, max_len=2048, sampling="ras", top_p=0.8, top_k=25, win_size=10, tau_r=0.1,
-                 seed=1986, decode_chunk=16, use_graph=True):
+                 seed=1986, decode_chunk=16, use_graph=True, attn_splits=8):
         self.lib = lib or get_lib()
         self.cfg = cfg
         self.device = torch.device(self.lib.device)
@@ -60,6 +60,7 @@ class Qwen2LM:
         register_tensors(self.lib, "cv_llm_set_tensor", self._h, self._tensors)
         self.lib.cv_llm_finalize(self._h)
         self.lib.cv_llm_set_option(self._h, b"use_graph", C.c_int32(int(use_graph)))
+        self.lib.cv_llm_set_option(self._h, b"attn_splits", C.c_int32(int(attn_splits)))   # key-range slices per head in decode attention
         self._uniforms = None
         self._request = 0
 

@@ -26,7 +26,9 @@ class CosyVoice2Model:
         self.llm, self.flow, self.hift = llm, flow, hift
         self.lib = (llm or flow or hift).lib if (llm or flow or hift) is not None else get_lib()
         self.device = torch.device(self.lib.device)
-        self.fp16 = fp16                       # accepted for API compatibility; the HIP path is W16A32 (bf16 weights, fp32 math)
+        # reference: fp16=True halves llm + flow (cli/model.py:50-52).  Here: the flow's Linear/Conv1d products run on the bf16 MFMA
+        # (precision="bf16", fp32 accumulate and fp32 tensors in HBM); the LLM is W16A32 either way (token ids stay bit-exact).
+        self.fp16 = fp16
         self.token_hop_len = 25                # must match the training static_chunk_size (cli/model.py:257-259)
         self.token_max_hop_len = 4 * self.token_hop_len
         self.stream_scale_factor = 2
@@ -52,10 +54,11 @@ class CosyVoice2Model:
 
     # ------------------------------------------------------------------------------------------------ B7
     @classmethod
-    def from_state_dicts(cls, llm_sd, flow_sd, hift_sd, cfgs, lib=None, **llm_kw):
+    def from_state_dicts(cls, llm_sd, flow_sd, hift_sd, cfgs, lib=None, fp16=False, **llm_kw):
         lc, fc, hc = cfgs
         lib = lib or get_lib()
-        return cls(Qwen2LM(llm_sd, lc, lib=lib, **llm_kw), CausalMaskedDiffWithXvec(flow_sd, fc, lib=lib), HiFTGenerator(hift_sd, hc, lib=lib))
+        flow = CausalMaskedDiffWithXvec(flow_sd, fc, lib=lib, precision="bf16" if fp16 else "fp32")
+        return cls(Qwen2LM(llm_sd, lc, lib=lib, **llm_kw), flow, HiFTGenerator(hift_sd, hc, lib=lib), fp16=fp16)
 
     def load(self, llm_model, flow_model, hift_model, cfgs=None, **llm_kw):
         """cli/model.py:65-73: state-dict files (llm.pt, flow.pt, hift.pt; `generator.` prefix stripped from hift keys)."""
@@ -65,7 +68,7 @@ class CosyVoice2Model:
         flow_sd = torch.load(flow_model, map_location="cpu", weights_only=True)
         hift_sd = {k.replace("generator.", ""): v for k, v in torch.load(hift_model, map_location="cpu", weights_only=True).items()}
         self.llm = Qwen2LM(llm_sd, lc, lib=self.lib, **llm_kw)
-        self.flow = CausalMaskedDiffWithXvec(flow_sd, fc, lib=self.lib)
+        self.flow = CausalMaskedDiffWithXvec(flow_sd, fc, lib=self.lib, precision="bf16" if self.fp16 else "fp32")
         self.hift = HiFTGenerator(hift_sd, hc, lib=self.lib)
         self._warmup()
 

@@ -52,6 +52,8 @@ typedef struct cv_gemm_conv_args {
     float out_scale;
     const float* row_scale; int64_t row_scale_batch;
     int32_t accumulate;
+    int32_t a_bf16;      /* 1: round the (prologue'd) activations to bf16 and multiply on the bf16 MFMA with fp32 accumulate (needs bf16 W,
+                            16-byte aligned A layout; otherwise the exact-fp32 MFMA path runs); 0: exact fp32 */
 } cv_gemm_conv_args;
 int cv_gemm_conv(const cv_gemm_conv_args* args, void* stream);
 

@@ -20,6 +20,34 @@ import torch.nn.functional as F
 
 
 # ------------------------------------------------------------------------------------------ encoder
+# Operand precision of the Linear / Conv1d products.  False (default) is the fp32 restatement pinned against the reference
+# goldens.  True mirrors the product's "bf16" mode: the activation operand (after any fused input activation) is rounded to
+# bfloat16 (round-to-nearest-even) before the product, weights are the same bf16-valued tensors, accumulation is fp32.
+_BF16_ACT = False
+
+
+class bf16_act:
+    """with oracle.flow.bf16_act(): ...   -> products take bf16-rounded activations (cosyvoice_amd/csrc/gemm_conv.h ABF16)."""
+    def __enter__(self):
+        global _BF16_ACT
+        self.prev, _BF16_ACT = _BF16_ACT, True
+    def __exit__(self, *a):
+        global _BF16_ACT
+        _BF16_ACT = self.prev
+
+
+def _r(x):
+    return x.bfloat16().float() if _BF16_ACT else x
+
+
+def _linear(x, w, b=None):
+    return F.linear(_r(x), w, b)
+
+
+def _conv1d(x, w, b=None, **kw):
+    return F.conv1d(_r(x), w, b, **kw)
+
+
 def rel_pos_emb(size, d_model):
     """pos_emb[:, m] encodes relative position (size-1-m), m in [0, 2*size-1)   (embedding.py:225-302, offset=0)."""
     pos = torch.arange(size - 1, -size, -1, dtype=torch.float32).unsqueeze(1)
@@ -46,7 +74,7 @@ def subsequent_chunk_mask(size, chunk):
 
 def embed(sd, p, x, d):
     """LinearNoSubsampling: Linear -> LayerNorm(1e-5) -> * sqrt(d)   (subsampling.py:83-113, embedding.py:256-270)."""
-    x = F.linear(x, sd[p + "out.0.weight"], sd[p + "out.0.bias"])
+    x = _linear(x, sd[p + "out.0.weight"], sd[p + "out.0.bias"])
     x = F.layer_norm(x, (d,), sd[p + "out.1.weight"], sd[p + "out.1.bias"], 1e-5)
     return x * math.sqrt(d)
 
@@ -57,10 +85,10 @@ def conformer_layer(sd, p, x, mask, pos_emb, heads):
     dk = d // heads
     r = x
     n = F.layer_norm(x, (d,), sd[p + "norm_mha.weight"], sd[p + "norm_mha.bias"], 1e-12)
-    q = F.linear(n, sd[p + "self_attn.linear_q.weight"], sd[p + "self_attn.linear_q.bias"]).view(b, t, heads, dk)
-    k = F.linear(n, sd[p + "self_attn.linear_k.weight"], sd[p + "self_attn.linear_k.bias"]).view(b, t, heads, dk).transpose(1, 2)
-    v = F.linear(n, sd[p + "self_attn.linear_v.weight"], sd[p + "self_attn.linear_v.bias"]).view(b, t, heads, dk).transpose(1, 2)
-    pp = F.linear(pos_emb, sd[p + "self_attn.linear_pos.weight"]).view(1, -1, heads, dk).transpose(1, 2)
+    q = _linear(n, sd[p + "self_attn.linear_q.weight"], sd[p + "self_attn.linear_q.bias"]).view(b, t, heads, dk)
+    k = _linear(n, sd[p + "self_attn.linear_k.weight"], sd[p + "self_attn.linear_k.bias"]).view(b, t, heads, dk).transpose(1, 2)
+    v = _linear(n, sd[p + "self_attn.linear_v.weight"], sd[p + "self_attn.linear_v.bias"]).view(b, t, heads, dk).transpose(1, 2)
+    pp = _linear(pos_emb, sd[p + "self_attn.linear_pos.weight"]).view(1, -1, heads, dk).transpose(1, 2)
     qu = (q + sd[p + "self_attn.pos_bias_u"]).transpose(1, 2)
     qv = (q + sd[p + "self_attn.pos_bias_v"]).transpose(1, 2)
     ac = torch.matmul(qu, k.transpose(-2, -1))
@@ -70,10 +98,10 @@ def conformer_layer(sd, p, x, mask, pos_emb, heads):
     scores = scores.masked_fill(m, -float("inf"))
     attn = torch.softmax(scores, dim=-1).masked_fill(m, 0.0)
     a = torch.matmul(attn, v).transpose(1, 2).contiguous().view(b, t, d)
-    x = r + F.linear(a, sd[p + "self_attn.linear_out.weight"], sd[p + "self_attn.linear_out.bias"])
+    x = r + _linear(a, sd[p + "self_attn.linear_out.weight"], sd[p + "self_attn.linear_out.bias"])
     r = x
     n = F.layer_norm(x, (d,), sd[p + "norm_ff.weight"], sd[p + "norm_ff.bias"], 1e-12)
-    f = F.linear(F.silu(F.linear(n, sd[p + "feed_forward.w_1.weight"], sd[p + "feed_forward.w_1.bias"])),
+    f = _linear(F.silu(_linear(n, sd[p + "feed_forward.w_1.weight"], sd[p + "feed_forward.w_1.bias"])),
                  sd[p + "feed_forward.w_2.weight"], sd[p + "feed_forward.w_2.bias"])
     return r + f
 
@@ -98,16 +126,16 @@ def encoder(sd, cfg, xs, context=None, streaming=False):
         o = F.pad(o, (0, cfg.pre_lookahead))
     else:
         o = torch.cat([o, ctx.transpose(1, 2)], dim=2)
-    o = F.leaky_relu(F.conv1d(o, sd[p + "pre_lookahead_layer.conv1.weight"], sd[p + "pre_lookahead_layer.conv1.bias"]))
+    o = F.leaky_relu(_conv1d(o, sd[p + "pre_lookahead_layer.conv1.weight"], sd[p + "pre_lookahead_layer.conv1.bias"]))
     o = F.pad(o, (2, 0))
-    o = F.conv1d(o, sd[p + "pre_lookahead_layer.conv2.weight"], sd[p + "pre_lookahead_layer.conv2.bias"])
+    o = _conv1d(o, sd[p + "pre_lookahead_layer.conv2.weight"], sd[p + "pre_lookahead_layer.conv2.bias"])
     x = o.transpose(1, 2) + x
     for i in range(cfg.enc_blocks):
         x = conformer_layer(sd, p + "encoders.%d." % i, x, mask, pos, heads)
     # Upsample1D: nearest x2, left pad 4, Conv1d k5 (upsample_encoder.py:59-63)
     o = F.interpolate(x.transpose(1, 2), scale_factor=2.0, mode="nearest")
     o = F.pad(o, (4, 0))
-    o = F.conv1d(o, sd[p + "up_layer.conv.weight"], sd[p + "up_layer.conv.bias"])
+    o = _conv1d(o, sd[p + "up_layer.conv.weight"], sd[p + "up_layer.conv.bias"])
     x = o.transpose(1, 2)
     T2 = x.shape[1]
     x = embed(sd, p + "up_embed.", x, d)
@@ -132,7 +160,7 @@ def sinusoidal_pos_emb(t, dim, scale=1000):
 
 def causal_block(sd, p, x, mask):
     """CausalBlock1D: (x*mask) -> causal conv k3 -> LayerNorm over channels -> Mish, * mask   (flow/decoder.py:65-78)."""
-    y = F.conv1d(F.pad(x * mask, (2, 0)), sd[p + "block.0.weight"], sd[p + "block.0.bias"])
+    y = _conv1d(F.pad(x * mask, (2, 0)), sd[p + "block.0.weight"], sd[p + "block.0.bias"])
     y = F.layer_norm(y.transpose(1, 2), (y.shape[1],), sd[p + "block.2.weight"], sd[p + "block.2.bias"], 1e-5).transpose(1, 2)
     return F.mish(y) * mask
 
@@ -140,23 +168,23 @@ def causal_block(sd, p, x, mask):
 def resnet_block(sd, p, x, mask, temb):
     """matcha ResnetBlock1D.forward with CausalBlock1D blocks (Appendix B; flow/decoder.py:81-85)."""
     h = causal_block(sd, p + "block1.", x, mask)
-    h = h + F.linear(F.mish(temb), sd[p + "mlp.1.weight"], sd[p + "mlp.1.bias"]).unsqueeze(-1)
+    h = h + _linear(F.mish(temb), sd[p + "mlp.1.weight"], sd[p + "mlp.1.bias"]).unsqueeze(-1)
     h = causal_block(sd, p + "block2.", h, mask)
-    return h + F.conv1d(x * mask, sd[p + "res_conv.weight"], sd[p + "res_conv.bias"])
+    return h + _conv1d(x * mask, sd[p + "res_conv.weight"], sd[p + "res_conv.bias"])
 
 
 def transformer_block(sd, p, x, bias, heads):
     """matcha BasicTransformerBlock (self-attention only) + diffusers Attention/GELU (Appendix B)."""
     b, t, c = x.shape
     n = F.layer_norm(x, (c,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5)
-    q = F.linear(n, sd[p + "attn1.to_q.weight"]).view(b, t, heads, 64).transpose(1, 2)
-    k = F.linear(n, sd[p + "attn1.to_k.weight"]).view(b, t, heads, 64).transpose(1, 2)
-    v = F.linear(n, sd[p + "attn1.to_v.weight"]).view(b, t, heads, 64).transpose(1, 2)
+    q = _linear(n, sd[p + "attn1.to_q.weight"]).view(b, t, heads, 64).transpose(1, 2)
+    k = _linear(n, sd[p + "attn1.to_k.weight"]).view(b, t, heads, 64).transpose(1, 2)
+    v = _linear(n, sd[p + "attn1.to_v.weight"]).view(b, t, heads, 64).transpose(1, 2)
     s = torch.matmul(q, k.transpose(-2, -1)) / 8.0 + bias.unsqueeze(1)
     a = torch.matmul(torch.softmax(s, dim=-1), v).transpose(1, 2).reshape(b, t, heads * 64)
-    x = F.linear(a, sd[p + "attn1.to_out.0.weight"], sd[p + "attn1.to_out.0.bias"]) + x
+    x = _linear(a, sd[p + "attn1.to_out.0.weight"], sd[p + "attn1.to_out.0.bias"]) + x
     n = F.layer_norm(x, (c,), sd[p + "norm3.weight"], sd[p + "norm3.bias"], 1e-5)
-    f = F.linear(F.gelu(F.linear(n, sd[p + "ff.net.0.proj.weight"], sd[p + "ff.net.0.proj.bias"])),
+    f = _linear(F.gelu(_linear(n, sd[p + "ff.net.0.proj.weight"], sd[p + "ff.net.0.proj.bias"])),
                  sd[p + "ff.net.2.weight"], sd[p + "ff.net.2.bias"])
     return f + x
 
@@ -166,7 +194,7 @@ def estimator(sd, cfg, x, mask, mu, t, spks, cond, streaming=False):
     x, mu, cond [B,80,T]; mask [B,1,T]; t [B]; spks [B,80]  ->  [B,80,T]."""
     e, heads = "decoder.estimator.", cfg.est_heads
     temb = sinusoidal_pos_emb(t, 4 * cfg.mel)
-    temb = F.linear(F.silu(F.linear(temb, sd[e + "time_mlp.linear_1.weight"], sd[e + "time_mlp.linear_1.bias"])),
+    temb = _linear(F.silu(_linear(temb, sd[e + "time_mlp.linear_1.weight"], sd[e + "time_mlp.linear_1.bias"])),
                     sd[e + "time_mlp.linear_2.weight"], sd[e + "time_mlp.linear_2.bias"])
     T = x.shape[-1]
     h = torch.cat([x, mu, spks.unsqueeze(-1).expand(-1, -1, T), cond], dim=1)
@@ -189,14 +217,14 @@ def estimator(sd, cfg, x, mask, mu, t, spks, cond, streaming=False):
 
     h = stage(e + "down_blocks.0.", h, cfg.est_blocks)
     skip = h
-    h = F.conv1d(F.pad(h * mask, (2, 0)), sd[e + "down_blocks.0.2.weight"], sd[e + "down_blocks.0.2.bias"])
+    h = _conv1d(F.pad(h * mask, (2, 0)), sd[e + "down_blocks.0.2.weight"], sd[e + "down_blocks.0.2.bias"])
     for i in range(cfg.est_mid):
         h = stage(e + "mid_blocks.%d." % i, h, cfg.est_blocks)
     h = torch.cat([h[:, :, : skip.shape[-1]], skip], dim=1)
     h = stage(e + "up_blocks.0.", h, cfg.est_blocks)
-    h = F.conv1d(F.pad(h * mask, (2, 0)), sd[e + "up_blocks.0.2.weight"], sd[e + "up_blocks.0.2.bias"])
+    h = _conv1d(F.pad(h * mask, (2, 0)), sd[e + "up_blocks.0.2.weight"], sd[e + "up_blocks.0.2.bias"])
     h = causal_block(sd, e + "final_block.", h, mask)
-    out = F.conv1d(h * mask, sd[e + "final_proj.weight"], sd[e + "final_proj.bias"])
+    out = _conv1d(h * mask, sd[e + "final_proj.weight"], sd[e + "final_proj.bias"])
     return out * mask
 
 
@@ -236,7 +264,7 @@ def inference(sd, cfg, token, prompt_token, prompt_feat, embedding, streaming=Fa
               n_timesteps=None, return_all=False):
     """CausalMaskedDiffWithXvec.inference (flow/flow.py:235-281). token/prompt_token [1,n] ints, prompt_feat [1,2p,80],
     embedding [1,192]  ->  mel [1,80,2*n_new]."""
-    emb = F.linear(F.normalize(embedding, dim=1), sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"])
+    emb = _linear(F.normalize(embedding, dim=1), sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"])
     tok = torch.cat([prompt_token, token], dim=1).long().clamp(min=0)
     x = sd["input_embedding.weight"][tok[0]].unsqueeze(0)
     if finalize:
@@ -245,7 +273,7 @@ def inference(sd, cfg, token, prompt_token, prompt_feat, embedding, streaming=Fa
         h = encoder(sd, cfg, x[:, : -cfg.pre_lookahead], x[:, -cfg.pre_lookahead:], streaming)
     mel_len1 = prompt_feat.shape[1]
     mel_len2 = h.shape[1] - mel_len1
-    mu = F.linear(h, sd["encoder_proj.weight"], sd["encoder_proj.bias"]).transpose(1, 2).contiguous()
+    mu = _linear(h, sd["encoder_proj.weight"], sd["encoder_proj.bias"]).transpose(1, 2).contiguous()
     conds = torch.zeros(1, mel_len1 + mel_len2, cfg.mel)
     conds[:, :mel_len1] = prompt_feat
     conds = conds.transpose(1, 2)

@@ -168,8 +168,18 @@ emu_v4f emu_mfma_f32_16x16x32_bf16(emu_v8s a, emu_v8s b, emu_v4f c);
 emu_v16f emu_mfma_f32_32x32x16_bf16(emu_v8s a, emu_v8s b, emu_v16f c);
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_f32_16x16x4f32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_f32_32x32x2f32((a), (b), (c))
-#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_f32_16x16x32_bf16((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_f32_16x16x32_bf16(__builtin_bit_cast(emu_v8s, (a)), __builtin_bit_cast(emu_v8s, (b)), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_f32_32x32x16_bf16((a), (b), (c))
+// DPP row controls used by the kernels (gfx9 encodings): quad_perm 0x00-0xFF, row_half_mirror 0x141, row_mirror 0x140
+static inline int emu_update_dpp(int src, int ctrl) {
+    int lane = emu::lane_id(), from;
+    if (ctrl < 0x100) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+    else if (ctrl == 0x141) from = (lane & ~7) | (7 - (lane & 7));
+    else if (ctrl == 0x140) from = (lane & ~15) | (15 - (lane & 15));
+    else { fprintf(stderr, "emu: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
+    return __shfl(src, from);
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((src), (ctrl))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))

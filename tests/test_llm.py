@@ -38,11 +38,13 @@ def test_greedy_tokens_bit_exact(lib, tiny_sd, use_graph):
     assert len(got) >= 12
 
 
-def test_teacher_forced_logits(lib, tiny_sd):
-    """First-step logits after prefill, and logits after each decode step, against the oracle's log-probs."""
+@pytest.mark.parametrize("splits", [4, 8, 16])
+def test_teacher_forced_logits(lib, tiny_sd, splits):
+    """First-step logits after prefill, and logits after each decode step, against the oracle's log-probs (short contexts:
+    with 4 slices the last ones are empty for the first steps)."""
     cfg, sd = tiny_sd
     u = _utt(cfg, seed=7)
-    lm = Qwen2LM(sd, cfg, lib=lib, max_len=128, sampling="greedy")
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=128, sampling="greedy", attn_splits=splits)
     trace = {}
     want = OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=2, min_token_text_ratio=2, trace=trace)
     lm_input = lm.build_lm_input(u["text"], u["prompt_text"], u["llm_prompt_speech_token"])
@@ -99,18 +101,20 @@ def test_kv_capacity_is_checked(lib, tiny_sd):
         list(lm.inference(**_kw(u), max_token_text_ratio=20))
 
 
-def test_long_context_multi_pass_attention(lib, tiny_sd):
-    """Contexts > 384 keys take the multi-pass branch of attn_decode_kernel (and > 64-row tiles of the prefill attention)."""
+@pytest.mark.parametrize("splits", [4, 8, 16])
+def test_long_context_multi_pass_attention(lib, tiny_sd, splits):
+    """Contexts > 48 keys per slice take the multi-pass branch of attn_decode_kernel (and > 64-row tiles of the prefill
+    attention); splits = key-range slices per head whose partials the o_proj GEMV merges (default 8)."""
     cfg, sd = tiny_sd
-    u = _utt(cfg, n_text=3, n_prompt_text=2, n_prompt_tok=560, seed=11)
-    lm = Qwen2LM(sd, cfg, lib=lib, max_len=640, sampling="greedy", decode_chunk=4)
+    u = _utt(cfg, n_text=3, n_prompt_text=2, n_prompt_tok=900, seed=11)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=1024, sampling="greedy", decode_chunk=4, attn_splits=splits)
     got = list(lm.inference(**_kw(u), max_token_text_ratio=4, min_token_text_ratio=2))
     trace = {}
     want = OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=4, min_token_text_ratio=2, trace=trace)
     assert got == want and len(got) >= 1
     lm.prefill(lm.build_lm_input(u["text"], u["prompt_text"], u["llm_prompt_speech_token"]))
     sp = lm.make_sampling(6, 12)
-    for i in range(min(2, len(trace["logp"]))):               # step 1 attends over 567 keys: second attention pass
+    for i in range(min(2, len(trace["logp"]))):               # the new position attends over all previous keys: multi-pass slices
         lm.decode(1, sp)
         torch.testing.assert_close(lm.last_logits().log_softmax(-1), trace["logp"][i], rtol=1e-4, atol=1e-4)
 

@@ -41,6 +41,28 @@ def test_linear(lib, M, N, K, wdt):
     torch.testing.assert_close(out[0].cpu(), ref.cpu(), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("M,N,K,taps", [(37, 48, 64, 1), (130, 200, 96, 1), (300, 256, 1024, 1), (70, 96, 320, 3), (33, 40, 36, 1)])
+def test_linear_bf16_mfma(lib, M, N, K, taps):
+    """a_bf16 = 1: activations (after the fused input activation) are rounded to bf16 round-to-nearest-even and multiplied with
+    the bf16 weights on v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Reference = the same rounding done in torch; the products
+    of two bf16 values are exact in fp32, so only the summation order differs."""
+    dev = _dev(lib)
+    x = _rand((M + taps - 1, K), dev, 11)                                     # causal conv over rows when taps > 1
+    W = _rand((N, taps, K), dev, 12, 0.2).bfloat16().float()
+    b = _rand((N,), dev, 13)
+    Wp, Kp = ops.pack_weight(W if taps > 1 else W[:, 0], torch.bfloat16)
+    out = ops.gemm_conv(lib, x, Wp, Kp, M=M, N=N, K=K, taps=taps, lda=K, tap_step=K, a_len=x.numel(), bias=b, pro="leaky", pro_p=0.1, act="gelu_erf", a_bf16=True)
+    _sync(lib)
+    xa = F.leaky_relu(x, 0.1).bfloat16().float()      # (a transcendental prologue could flip a bf16 rounding by its last-ulp difference)
+    ref = sum(xa[j:j + M] @ W[:, j].t() for j in range(taps)) + b
+    ref = F.gelu(ref)
+    torch.testing.assert_close(out[0].cpu(), ref.cpu(), rtol=3e-5, atol=3e-5)
+    exact = ops.gemm_conv(lib, x, Wp, Kp, M=M, N=N, K=K, taps=taps, lda=K, tap_step=K, a_len=x.numel(), bias=b, pro="leaky", pro_p=0.1, act="gelu_erf")
+    _sync(lib)
+    assert not torch.equal(exact, out)                                       # the flag really selects the other kernel
+    torch.testing.assert_close(out[0].cpu(), exact[0].cpu(), rtol=3e-2, atol=3e-2)
+
+
 @pytest.mark.parametrize("T,Cin,Cout,k,dil,causal", [(50, 16, 24, 3, 1, True), (70, 32, 32, 7, 3, False), (33, 80, 40, 11, 5, False)])
 def test_conv1d(lib, T, Cin, Cout, k, dil, causal):
     """Conv1d on channel-last activations == torch conv1d on [B,C,T] (flow/decoder.py:36-62, hifigan/generator.py:46-122)."""
