@@ -35,7 +35,8 @@ void attention(const AttnArgs& a, hipStream_t s) {
              a.q_batch % 4 == 0 && a.k_batch % 4 == 0 && a.v_batch % 4 == 0 && a.o_batch % 4 == 0, "attention: strides must be multiples of 4 floats");
     CV_CHECK(a.mask_mode != MASK_CHUNK || a.chunk > 0, "attention: chunk mask needs chunk > 0");
     dim3 grid((a.Tq + 63) / 64, a.H, a.B), block(256);
-    hipLaunchKernelGGL(attention_kernel, grid, block, 0, s, a);
+    if (a.bf16) hipLaunchKernelGGL(attention_bf16_kernel, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(attention_kernel, grid, block, 0, s, a);
 }
 
 void linear(const float* A, int M, const LinearW& w, float* C, int act, const float* res, hipStream_t s,
@@ -100,7 +101,7 @@ int cv_attention(const cv_attn_args* g, void* stream) {
         a.o = g->o; a.o_batch = g->o_batch; a.o_row = g->o_row; a.o_head = g->o_head;
         a.B = g->B; a.H = g->H; a.kv_group = g->kv_group; a.Tq = g->Tq; a.Tk = g->Tk;
         a.scale = g->scale; a.mask_mode = g->mask_mode; a.chunk = g->chunk;
-        a.rel_bd = g->rel_bd; a.bd_batch = g->bd_batch; a.bd_head = g->bd_head; a.bd_row = g->bd_row;
+        a.rel_bd = g->rel_bd; a.bd_batch = g->bd_batch; a.bd_head = g->bd_head; a.bd_row = g->bd_row; a.bf16 = g->bf16;
         cv::attention(a, cv::as_stream(stream));
     });
 }

@@ -66,6 +66,15 @@ __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 32));
     return v;
 }
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+
+// fp32 pair -> packed bf16 pair, round-to-nearest-even (integer form: identical on the device, in the emulator and in numpy)
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a += 0x7fffu + ((a >> 16) & 1u); b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
+
 // Exchanges inside a 16-lane DPP row run on the VALU (no ds_bpermute round trip through the LDS crossbar): xor 1 / xor 2 as
 // quad permutes, then "the other quad of my half" (row_half_mirror) and "the other half of my row" (row_mirror).  After the
 // two quad steps every lane of a quad holds the same value, so the mirrors pair equal partners: all 16 lanes end bit-identical.

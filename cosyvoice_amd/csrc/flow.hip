@@ -195,6 +195,7 @@ static void conformer_layer(cv_flow* m, const ConformerW& w, float* x, int T, co
     at.B = 1; at.H = H; at.kv_group = 1; at.Tq = T; at.Tk = T; at.scale = 0.125f;
     at.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; at.chunk = chunk;
     at.rel_bd = bd; at.bd_batch = 0; at.bd_head = (long long)T * P; at.bd_row = P;
+    at.bf16 = tl_bf16_mfma;
     attention(at, s);
     lin_cl(w.out, att, T, x, ACT_NONE, x, s);
     ln_rows(w.norm_ff, x, n, T, d, 1e-12f, s);
@@ -303,6 +304,7 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
             at.o = att; at.o_batch = (long long)T * inner; at.o_row = inner; at.o_head = 64;
             at.B = 2; at.H = H; at.kv_group = 1; at.Tq = T; at.Tk = T; at.scale = 0.125f;
             at.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; at.chunk = chunk; at.rel_bd = nullptr;
+            at.bf16 = tl_bf16_mfma;
             attention(at, s);
             lin_cl(t.out, att, R, x, ACT_NONE, x, s);
             ln_rows(t.norm3, x, n, R, C, 1e-5f, s);

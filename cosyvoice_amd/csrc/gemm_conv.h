@@ -44,15 +44,6 @@ struct GemmConvArgs {
 // Pipeline: most GEMMs on this path are small (M ~ 10^3, K = 256..1024) and run ~1 workgroup per CU, so nothing hides global
 // latency but the kernel itself: a 2-deep REGISTER prefetch ring keeps the loads of k-tiles it+1 and it+2 in flight while tile
 // it is multiplied out of LDS, and the small tiles use BK = 64 to halve the number of barrier-separated iterations.
-typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
-
-// fp32 pair -> packed bf16 pair, round-to-nearest-even (integer form: identical on the device, in the emulator and in numpy)
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
-    a += 0x7fffu + ((a >> 16) & 1u); b += 0x7fffu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xffff0000u);
-}
-
 template <int BM, int BN, int BK, bool WBF16, bool AVEC, int STAGES = 2, bool ABF16 = false>
 __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
     static_assert(!ABF16 || WBF16, "the bf16 MFMA path takes bf16 weights");

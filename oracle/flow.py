@@ -40,6 +40,16 @@ def _r(x):
     return x.bfloat16().float() if _BF16_ACT else x
 
 
+def _attn_pv(attn, v):
+    """softmax(S) @ V.  bf16 mode mirrors the flash kernel: the numerator uses bf16-rounded un-normalised probabilities and bf16 V,
+    the denominator the unrounded ones (cosyvoice_amd/csrc/attention.h attention_bf16_kernel)."""
+    if not _BF16_ACT:
+        return torch.matmul(attn, v)
+    # attn = e / sum(e) with e = exp(s - max): recover e up to the row scale (any positive row scale cancels in num / den)
+    e = attn / attn.amax(dim=-1, keepdim=True).clamp_min(1e-30)
+    return torch.matmul(_r(e), _r(v)) / e.sum(dim=-1, keepdim=True)
+
+
 def _linear(x, w, b=None):
     return F.linear(_r(x), w, b)
 
@@ -91,13 +101,13 @@ def conformer_layer(sd, p, x, mask, pos_emb, heads):
     pp = _linear(pos_emb, sd[p + "self_attn.linear_pos.weight"]).view(1, -1, heads, dk).transpose(1, 2)
     qu = (q + sd[p + "self_attn.pos_bias_u"]).transpose(1, 2)
     qv = (q + sd[p + "self_attn.pos_bias_v"]).transpose(1, 2)
-    ac = torch.matmul(qu, k.transpose(-2, -1))
+    ac = torch.matmul(_r(qu), _r(k).transpose(-2, -1))          # bf16 mode: q, k, v and the probabilities are MFMA operands too
     bd = rel_shift(torch.matmul(qv, pp.transpose(-2, -1)))
     scores = (ac + bd) / math.sqrt(dk)
     m = mask.unsqueeze(1).eq(0)                                   # attention.py:108-114
     scores = scores.masked_fill(m, -float("inf"))
     attn = torch.softmax(scores, dim=-1).masked_fill(m, 0.0)
-    a = torch.matmul(attn, v).transpose(1, 2).contiguous().view(b, t, d)
+    a = _attn_pv(attn, v).transpose(1, 2).contiguous().view(b, t, d)
     x = r + _linear(a, sd[p + "self_attn.linear_out.weight"], sd[p + "self_attn.linear_out.bias"])
     r = x
     n = F.layer_norm(x, (d,), sd[p + "norm_ff.weight"], sd[p + "norm_ff.bias"], 1e-12)
@@ -180,8 +190,8 @@ def transformer_block(sd, p, x, bias, heads):
     q = _linear(n, sd[p + "attn1.to_q.weight"]).view(b, t, heads, 64).transpose(1, 2)
     k = _linear(n, sd[p + "attn1.to_k.weight"]).view(b, t, heads, 64).transpose(1, 2)
     v = _linear(n, sd[p + "attn1.to_v.weight"]).view(b, t, heads, 64).transpose(1, 2)
-    s = torch.matmul(q, k.transpose(-2, -1)) / 8.0 + bias.unsqueeze(1)
-    a = torch.matmul(torch.softmax(s, dim=-1), v).transpose(1, 2).reshape(b, t, heads * 64)
+    s = torch.matmul(_r(q), _r(k).transpose(-2, -1)) / 8.0 + bias.unsqueeze(1)
+    a = _attn_pv(torch.softmax(s, dim=-1), v).transpose(1, 2).reshape(b, t, heads * 64)
     x = _linear(a, sd[p + "attn1.to_out.0.weight"], sd[p + "attn1.to_out.0.bias"]) + x
     n = F.layer_norm(x, (c,), sd[p + "norm3.weight"], sd[p + "norm3.bias"], 1e-5)
     f = _linear(F.gelu(_linear(n, sd[p + "ff.net.0.proj.weight"], sd[p + "ff.net.0.proj.bias"])),

@@ -190,3 +190,47 @@ def test_attention_relpos(lib):
     s = (torch.einsum("bqhd,bkhd->bhqk", q.cpu(), k.cpu()) + shifted) / 8.0
     ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v.cpu())
     torch.testing.assert_close(out.cpu(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("Tq,Tk,mode,chunk", [(70, 70, "none", 0), (50, 50, "chunk", 16), (33, 81, "causal", 0), (200, 200, "chunk", 50), (300, 300, "none", 0)])
+def test_attention_bf16_mfma(lib, Tq, Tk, mode, chunk):
+    """bf16 = 1: q, k, v rounded to bf16 (products exact in fp32), probabilities rounded to bf16 for the P.V product only
+    (the denominator sums the unrounded ones).  Reference: the same operand rounding in torch with fp32 probabilities; what is
+    left is the bf16 rounding of P, relative 2^-9 per term and averaging out over the keys: tolerance 4e-3 on O(1) outputs."""
+    dev = _dev(lib)
+    B, H, G = 2, 4, 2
+    qkv = _rand((B, Tq, 3 * H * 64), dev, 20)
+    q = qkv[..., :H * 64].view(B, Tq, H, 64)
+    if Tk == Tq:
+        k = qkv[..., H * 64:2 * H * 64].view(B, Tq, H, 64); v = qkv[..., 2 * H * 64:].view(B, Tq, H, 64); group = 1
+    else:
+        kc = _rand((B, H // G, Tk, 64), dev, 21); vc = _rand((B, H // G, Tk, 64), dev, 22)
+        k = kc.permute(0, 2, 1, 3); v = vc.permute(0, 2, 1, 3); group = G
+    out = ops.attention(lib, q, k, v, scale=1 / 8.0, mask=mode, chunk=chunk, kv_group=group, bf16=True)
+    exact = ops.attention(lib, q, k, v, scale=1 / 8.0, mask=mode, chunk=chunk, kv_group=group)
+    _sync(lib)
+    qi = torch.arange(Tq)[:, None]; kj = torch.arange(Tk)[None, :]
+    m = torch.ones(Tq, Tk, dtype=torch.bool) if mode == "none" else (kj <= qi + (Tk - Tq) if mode == "causal" else kj < (qi // chunk + 1) * chunk)
+    kk = k.repeat_interleave(group, dim=2) if group > 1 else k
+    vv = v.repeat_interleave(group, dim=2) if group > 1 else v
+    r = lambda t: t.cpu().bfloat16().float()
+    ref = _ref_attn(r(q), r(kk), r(vv), 1 / 8.0, m[None, None])
+    torch.testing.assert_close(out.cpu(), ref, rtol=4e-3, atol=4e-3)
+    assert not torch.equal(out, exact)
+    torch.testing.assert_close(out.cpu(), exact.cpu(), rtol=3e-2, atol=3e-2)
+
+
+def test_attention_relpos_bf16_mfma(lib):
+    dev = _dev(lib)
+    B, H, T = 1, 2, 90
+    q = _rand((B, T, H, 64), dev, 23); k = _rand((B, T, H, 64), dev, 24); v = _rand((B, T, H, 64), dev, 25)
+    bd = _rand((B, H, T, 2 * T - 1), dev, 26)
+    out = ops.attention(lib, q, k, v, scale=1 / 8.0, rel_bd=bd, bf16=True)
+    _sync(lib)
+    x = bd.cpu()
+    x_padded = torch.cat([torch.zeros((B, H, T, 1)), x], dim=-1).view(B, H, 2 * T, T)
+    shifted = x_padded[:, :, 1:].view_as(x)[:, :, :, :T]
+    r = lambda t: t.cpu().bfloat16().float()
+    s = (torch.einsum("bqhd,bkhd->bhqk", r(q), r(k)) + shifted) / 8.0
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), r(v))
+    torch.testing.assert_close(out.cpu(), ref, rtol=4e-3, atol=4e-3)

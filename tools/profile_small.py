@@ -18,7 +18,7 @@ if "llm" in which:
     toks, fin = lm.decode(24, sp)
     torch.cuda.synchronize(); del lm
 if "flow" in which:
-    flow = CausalMaskedDiffWithXvec(W.make_flow(fc), fc)
+    flow = CausalMaskedDiffWithXvec(W.make_flow(fc), fc, precision=os.environ.get("FLOW_PRECISION", "bf16"))
     tok = torch.randint(0, fc.vocab, (1, 250), generator=torch.Generator().manual_seed(0), dtype=torch.int32)
     mel, _ = flow.inference(token=tok, token_len=t(250), prompt_token=u["flow_prompt_speech_token"], prompt_token_len=t(87), prompt_feat=u["prompt_speech_feat"],
                             prompt_feat_len=t(174), embedding=u["flow_embedding"], streaming=False, finalize=True)
