@@ -13,6 +13,12 @@ void gemm_conv(GemmConvArgs a, bool w_bf16, int batch, hipStream_t s) {
     a.a_vec = aligned16(a.A) && (a.lda % 4 == 0) && (a.a_off0 % 4 == 0) && (a.tap_step % 4 == 0) &&
               (a.a_batch % 4 == 0) && (a.a_len % 4 == 0) && (a.K % 4 == 0) && a.a_len >= 4;
     CV_CHECK(a.a_len >= 1, "gemm_conv: empty A operand");
+    {   // the vectorised kernels address both operands with 32-bit byte offsets (buffer loads): keep them under 1.75 GiB, else scalar path
+        const long long ldw = a.ldw ? a.ldw : (long long)a.taps * a.Kp;
+        const long long w_bytes = ((long long)(a.N - 1) * ldw + (long long)a.taps * a.Kp) * (w_bf16 ? 2 : 4);
+        const long long a_reach = ((long long)a.M * a.lda + (long long)a.taps * (a.tap_step < 0 ? -a.tap_step : a.tap_step) + a.Kp + (a.a_off0 < 0 ? -a.a_off0 : a.a_off0)) * 4;
+        if (a.a_len * 4 > 0x70000000LL || w_bytes > 0x70000000LL || a_reach > 0x70000000LL) a.a_vec = 0;
+    }
     a.c_vec = aligned16(a.C) && (a.ldc % 4 == 0) && (a.c_off % 4 == 0) && (a.c_batch % 4 == 0) && (a.c_len % 4 == 0) &&
               (!a.bias || aligned16(a.bias)) && (!a.res || (aligned16(a.res) && a.res_batch % 4 == 0));
     if (a.pro == ACT_SNAKE) CV_CHECK(a.pro_alpha && aligned16(a.pro_alpha), "gemm_conv: snake prologue needs 16B aligned alpha[Kp]");

@@ -68,11 +68,31 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
-// fp32 pair -> packed bf16 pair, round-to-nearest-even (integer form: identical on the device, in the emulator and in numpy)
+// fp32 pair -> packed bf16 pair, round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950 (the same conversion the host compiler
+// emits for the emulator build and torch's .bfloat16() performs)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
-    a += 0x7fffu + ((a >> 16) & 1u); b += 0x7fffu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xffff0000u);
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+// Buffer addressing: a 128-bit resource (base, byte size) + a 32-bit byte offset per lane.  The hardware range-checks every dword
+// against the size and returns 0 outside, so zero padding, ragged tiles and masked rows cost no compare / select / 64-bit add in the
+// inner loops (a negative offset is a huge unsigned one).  BUF_OOB is the offset used to force a zero: operands must be < 1.75 GiB.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+constexpr int BUF_OOB = 0x7F000000;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load_f4(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+__device__ __forceinline__ uint2 buf_load_u2(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 0);
+    return make_uint2(v[0], v[1]);
 }
 
 // Exchanges inside a 16-lane DPP row run on the VALU (no ds_bpermute round trip through the LDS crossbar): xor 1 / xor 2 as

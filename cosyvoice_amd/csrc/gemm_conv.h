@@ -82,12 +82,18 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
     // load_tile against ~1300 cycles of MFMA work — one wave per SIMD has nothing to hide VALU address math behind.]
     long long a_base[AV]; int a_c4[AV]; bool a_row_ok[AV];
     long long w_base[WV]; int w_c4[WV];
+    // vectorised operands go through buffer resources: 32-bit byte offsets, hardware range check (see common.h)
+    constexpr int WE = WBF16 ? 2 : 4;                 // bytes per weight element
+    int a_boff[AV], w_boff[WV];
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(Ab, (unsigned)(p.a_len * 4));
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(reinterpret_cast<const char*>(p.W) + wb * WE, (unsigned)(((long long)(p.N - 1) * ldw + (long long)p.taps * p.Kp) * WE));
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
         const int v = tid + i * 256, m = m0 + v / KV;
         a_c4[i] = (v % KV) * 4;
         a_row_ok[i] = m < p.M;
         a_base[i] = (long long)m * p.lda + p.a_off0 + a_c4[i];
+        a_boff[i] = a_row_ok[i] ? (int)(a_base[i] * 4) : BUF_OOB;
     }
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
@@ -95,6 +101,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
         int n = n0 + v / KV; n = n < p.N ? n : p.N - 1;
         w_c4[i] = (v % KV) * 4;
         w_base[i] = wb + (long long)n * ldw + w_c4[i];
+        w_boff[i] = (int)(((long long)n * ldw + w_c4[i]) * WE);
     }
     auto load_tile = [&](int tap, int k0, auto& ra, auto& rw) {
         const long long a_off = (long long)tap * p.tap_step + k0;       // uniform
@@ -104,10 +111,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
             const int kk = k0 + a_c4[i];
             const long long idx = a_base[i] + a_off;
             if (AVEC) {       // K % 4 == 0 and every float4 group is 16B aligned and entirely in or out of [0, a_len)
-                const bool ok = a_row_ok[i] && kk < p.K && idx >= 0 && idx + 3 < p.a_len;
-                float4 x = *reinterpret_cast<const float4*>(Ab + (ok ? idx : 0));
-                if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
-                ra[i] = x;
+                ra[i] = buf_load_f4(rsA, kk < p.K ? a_boff[i] + (int)a_off * 4 : BUF_OOB);      // rows >= M, idx outside [0, a_len): hardware zero
             } else {
                 float t[4];
 #pragma unroll
@@ -123,8 +127,21 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const bool ok = k0 + w_c4[i] < p.Kp;                // Kp is a multiple of 32: the last k-step may be partly empty
-            const long long idx = ok ? w_base[i] + w_off : w_base[i];
             float4 wv;
+            if (AVEC) {                                         // (the host only selects AVEC kernels when W also fits 32-bit offsets)
+                const int off = ok ? w_boff[i] + (int)w_off * WE : BUF_OOB;
+                if (WBF16) {
+                    const uint2 u = buf_load_u2(rsW, off);
+                    if (ABF16) wv = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+                    else wv = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                          __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+                } else {
+                    wv = buf_load_f4(rsW, off);
+                }
+                rw[i] = wv;
+                continue;
+            }
+            const long long idx = ok ? w_base[i] + w_off : w_base[i];
             if (WBF16) {
                 const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.W) + idx);
                 if (ABF16) wv = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);      // raw pairs, staged as they are

@@ -180,6 +180,24 @@ static inline int emu_update_dpp(int src, int ctrl) {
     return __shfl(src, from);
 }
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((src), (ctrl))
+// buffer resources: (base, byte size); loads return 0 for every dword that is not entirely inside [0, size)
+struct emu_rsrc { const char* base; unsigned bytes; };
+typedef emu_rsrc __amdgpu_buffer_rsrc_t;
+typedef unsigned emu_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned emu_u32x2 __attribute__((ext_vector_type(2)));
+static inline emu_rsrc emu_make_rsrc(void* p, unsigned bytes) { return emu_rsrc{(const char*)p, bytes}; }
+static inline unsigned emu_buf_dword(emu_rsrc rs, unsigned off) { unsigned v = 0; if (off <= rs.bytes && rs.bytes - off >= 4) memcpy(&v, rs.base + off, 4); return v; }
+static inline emu_u32x4 emu_buf_load_b128(emu_rsrc rs, int voff, int soff) {
+    const unsigned o = (unsigned)voff + (unsigned)soff;
+    return emu_u32x4{emu_buf_dword(rs, o), emu_buf_dword(rs, o + 4), emu_buf_dword(rs, o + 8), emu_buf_dword(rs, o + 12)};
+}
+static inline emu_u32x2 emu_buf_load_b64(emu_rsrc rs, int voff, int soff) {
+    const unsigned o = (unsigned)voff + (unsigned)soff;
+    return emu_u32x2{emu_buf_dword(rs, o), emu_buf_dword(rs, o + 4)};
+}
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, bytes, flags) emu_make_rsrc((p), (bytes))
+#define __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, aux) emu_buf_load_b128((rs), (voff), (soff))
+#define __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, aux) emu_buf_load_b64((rs), (voff), (soff))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))

@@ -1,4 +1,4 @@
-// Dev tool: per-phase timeline of gemm_conv_kernel on one flow-estimator shape (M=1348, N=256, K=1024, bf16 W).
+// Dev tool: per-phase timeline of gemm_conv_kernel (bf16 MFMA variant) on one flow-estimator shape (M=1348, N=256, K=1024, bf16 W).
 #include "../../cosyvoice_amd/csrc/gemm_conv.h"
 #include <vector>
 #include <cstdio>
@@ -12,12 +12,12 @@ int main() {
     (void)hipMemset(A, 0, (size_t)M * K * 4); (void)hipMemset(W, 0, (size_t)N * K * 2);
     GemmConvArgs a{};
     a.A = A; a.a_len = (long long)M * K; a.lda = K; a.taps = 1; a.K = K; a.a_vec = 1; a.W = W; a.Kp = K; a.C = C; a.c_len = (long long)M * N; a.ldc = N; a.c_vec = 1;
-    a.M = M; a.N = N; a.out_scale = 1.f;
+    a.M = M; a.N = N; a.out_scale = 1.f; a.a_bf16 = 1;
     for (int rep = 0; rep < 3; ++rep) {
         a.dbg = rep == 2 ? dbg : nullptr;
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((gemm_conv_kernel<32, 32, 128, true, true, 2>), dim3(43, 8, 1), dim3(256), 0, 0, a);
+        hipLaunchKernelGGL((gemm_conv_kernel<32, 32, 256, true, true, 2, true>), dim3(43, 8, 1), dim3(256), 0, 0, a);
         (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1); printf("rep %d: %.1f us\n", rep, ms * 1e3);
     }
