@@ -27,7 +27,9 @@ void gemm_conv(GemmConvArgs a, bool w_bf16, int batch, hipStream_t s) {
 
 void norm_rows(const NormArgs& a, hipStream_t s) {
     if (a.rows <= 0) return;
-    CV_CHECK(!((a.C & 3) == 0) || (aligned16(a.x)), "norm_rows: x must be 16B aligned when C%4==0");
+    CV_CHECK(!((a.C & 3) == 0) || (aligned16(a.x) && aligned16(a.y) && (!a.gamma || aligned16(a.gamma)) && (!a.beta || aligned16(a.beta)) &&
+                                   (!a.col_add || aligned16(a.col_add))),
+             "norm_rows: x, y, gamma, beta and col_add must be 16B aligned when C%4==0");
     dim3 grid((unsigned)((a.rows + 3) / 4)), block(256);
     hipLaunchKernelGGL(norm_rows_kernel, grid, block, 0, s, a);
 }

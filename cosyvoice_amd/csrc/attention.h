@@ -192,6 +192,7 @@ static __global__ __launch_bounds__(256) void attention_bf16_kernel(AttnArgs p) 
     const int qi = qb * BQ + wave * 16 + lq;
     const bool qvalid = qi < p.Tq;
     const float NEG_INF = -__builtin_huge_valf();
+    const float scale2 = p.scale * 1.4426950408889634f;
 
     // Q as the B operand of S^T = K.Q^T: lane (q = lq, g = lg) supplies d = 32 dg + 8 g .. + 7
     uint4 qf[2];
@@ -275,21 +276,21 @@ static __global__ __launch_bounds__(256) void attention_bf16_kernel(AttnArgs p) 
                 const int key = kt0 + kt * 16 + lg * 4 + r;
                 float x = s[kt][r];
                 if (bd && key < klim) x += bd[key];
-                x = key < klim ? x * p.scale : NEG_INF;
+                x = key < klim ? x * scale2 : NEG_INF;            // scores in log2 units: softmax via v_exp_f32
                 s[kt][r] = x;
                 mt = fmaxf(mt, x);
             }
         mt = fmaxf(mt, __shfl_xor(mt, 16));
         mt = fmaxf(mt, __shfl_xor(mt, 32));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = (m_run == NEG_INF) ? 0.f : expf(m_run - m_new);
+        const float alpha = (m_run == NEG_INF) ? 0.f : exp2f(m_run - m_new);
         float rsum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x = s[kt][r];
-                const float e = (x == NEG_INF) ? 0.f : expf(x - m_new);
+                const float e = (x == NEG_INF) ? 0.f : exp2f(x - m_new);
                 s[kt][r] = e;
                 rsum += e;                                   // the denominator sums the UNROUNDED probabilities
             }

@@ -19,16 +19,24 @@ enum Act : int {
     ACT_MISH = 6, ACT_ABS = 7, ACT_SNAKE = 8,
 };
 
-// The transcendental-heavy activations are deliberately NOT inlined: libm's erff / tanhf / log1pf / expm1f / sinf expand to
-// hundreds of instructions each, and inlining them at every unrolled epilogue / prologue site made the GEMM kernels 20-90 K
-// instructions long (instruction-cache thrash: ~2.5 us per k-iteration whatever the tile).  One out-of-line copy per kernel.
+// Activations.  At ~1 workgroup per CU nothing hides VALU work, and libm's erff / tanhf / log1pf expand to 40-150 instructions per
+// element (inlined at every unrolled epilogue site they also made the GEMM kernels 20-90 K instructions long), so the hot
+// activations are written on the hardware transcendentals: v_exp_f32 (exp2), v_rcp_f32.
+//   SiLU  x / (1 + e^-x)                       GELU  0.5 x (1 + erf(x / sqrt 2)), erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7)
+//   Mish  x tanh(ln(1 + e^x)) = x w / (w + 2), w = e^x (e^x + 2)             tanh  1 - 2 / (e^2x + 1)
+// Absolute error <= 3e-7 * max(1, |x|) against the libm forms (tests/test_ops.py::test_activations); ELU keeps expm1f (cancellation
+// at 0, and it is only used by the f0 predictor).
+__device__ __forceinline__ float fast_exp(float x) { return exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x), t = fast_rcp(1.f + 0.3275911f * ax);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float y = 1.f - poly * fast_exp(-ax * ax);
+    return x < 0.f ? -y : y;
+}
 __device__ __noinline__ float act_slow(int act, float v) {
     switch (act) {
-        case ACT_GELU_ERF: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
         case ACT_ELU: return v > 0.f ? v : expm1f(v);
-        case ACT_TANH: return tanhf(v);
-        case ACT_MISH: { const float sp = v > 20.f ? v : log1pf(expf(v)); return v * tanhf(sp); }
-        case ACT_SILU: return v / (1.f + expf(-v));
         default: return v;
     }
 }
@@ -37,6 +45,10 @@ __device__ __forceinline__ float apply_act(int act, float v, float p) {
     if (act == ACT_NONE) return v;
     if (act == ACT_LEAKY) return v > 0.f ? v : v * p;
     if (act == ACT_ABS) return fabsf(v);
+    if (act == ACT_SILU) return v * fast_rcp(1.f + fast_exp(-v));
+    if (act == ACT_GELU_ERF) return 0.5f * v * (1.f + fast_erf(v * 0.70710678118654752440f));
+    if (act == ACT_MISH) { const float n = fast_exp(fminf(v, 20.f)), w = n * (n + 2.f); return v > 20.f ? v : v * w * fast_rcp(w + 2.f); }
+    if (act == ACT_TANH) { const float e = fast_exp(2.f * fminf(fmaxf(v, -15.f), 15.f)); return 1.f - 2.f * fast_rcp(e + 1.f); }
     return act_slow(act, v);
 }
 

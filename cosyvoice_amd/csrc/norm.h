@@ -1,6 +1,8 @@
 // Row-wise LayerNorm / RMSNorm (fp32), one wave per row, 4 rows per workgroup. HBM/L2-bound:
 // each row is read with 16B/lane coalesced loads; statistics are two-pass (mean, then centred variance)
 // like torch.nn.LayerNorm, reduced with fixed-order wave shuffles.
+// Rows of up to 1024 channels (every norm on the synthesis path: 256 / 512 / 896) stay in registers: ONE load pass, the
+// second statistic and the affine + activation epilogue run on the registers, gamma / beta / col_add / y move as float4.
 #pragma once
 #include "common.h"
 
@@ -19,6 +21,46 @@ static __global__ __launch_bounds__(256) void norm_rows_kernel(NormArgs p) {
     const float* xr = p.x + row * p.C;
     float* yr = p.y + row * p.C;
     const bool vec = (p.C & 3) == 0;
+    if (vec && p.C <= 1024) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = lane * 4 + k * 256;
+            v[k] = c < p.C ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (lane * 4 + k * 256 < p.C) s += (p.rms ? v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w : v[k].x + v[k].y + v[k].z + v[k].w);
+        s = wave_sum(s);
+        float mean = 0.f, rstd;
+        if (p.rms) {
+            rstd = rsqrtf(s / (float)p.C + p.eps);
+        } else {
+            mean = s / (float)p.C;
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (lane * 4 + k * 256 < p.C) { const float a = v[k].x - mean, b = v[k].y - mean, cc = v[k].z - mean, d = v[k].w - mean; q += a * a + b * b + cc * cc + d * d; }
+            q = wave_sum(q);
+            rstd = rsqrtf(q / (float)p.C + p.eps);
+        }
+        const float rs = p.scale * (p.row_scale ? p.row_scale[row] : 1.f);
+        const float* ca = p.col_add ? p.col_add + (row / p.rows_per_batch) * p.C : nullptr;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = lane * 4 + k * 256;
+            if (c >= p.C) continue;
+            float o[4] = {(v[k].x - mean) * rstd, (v[k].y - mean) * rstd, (v[k].z - mean) * rstd, (v[k].w - mean) * rstd};
+            if (p.gamma) { const float4 g = *reinterpret_cast<const float4*>(p.gamma + c); o[0] *= g.x; o[1] *= g.y; o[2] *= g.z; o[3] *= g.w; }
+            if (p.beta) { const float4 b = *reinterpret_cast<const float4*>(p.beta + c); o[0] += b.x; o[1] += b.y; o[2] += b.z; o[3] += b.w; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = apply_act(p.act, o[e], 0.f) * rs;
+            if (ca) { const float4 a = *reinterpret_cast<const float4*>(ca + c); o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
+            *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        return;
+    }
     float s = 0.f;
     if (vec) { for (int c = lane * 4; c < p.C; c += 256) { const float4 v = *reinterpret_cast<const float4*>(xr + c); s += (p.rms ? v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w : v.x + v.y + v.z + v.w); } }
     else     { for (int c = lane; c < p.C; c += 64) { const float v = xr[c]; s += p.rms ? v * v : v; } }

@@ -198,6 +198,7 @@ static inline emu_u32x2 emu_buf_load_b64(emu_rsrc rs, int voff, int soff) {
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, bytes, flags) emu_make_rsrc((p), (bytes))
 #define __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, aux) emu_buf_load_b128((rs), (voff), (soff))
 #define __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, aux) emu_buf_load_b64((rs), (voff), (soff))
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))

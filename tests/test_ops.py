@@ -234,3 +234,20 @@ def test_attention_relpos_bf16_mfma(lib):
     s = (torch.einsum("bqhd,bkhd->bhqk", r(q), r(k)) + shifted) / 8.0
     ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), r(v))
     torch.testing.assert_close(out.cpu(), ref, rtol=4e-3, atol=4e-3)
+
+
+@pytest.mark.parametrize("act,ref", [("silu", F.silu), ("gelu_erf", F.gelu), ("mish", F.mish), ("tanh", torch.tanh), ("elu", F.elu)])
+def test_activations(lib, act, ref):
+    """Epilogue activations on the hardware transcendentals (common.h): |err| <= 3e-7 * max(1, |x|) against torch's libm forms,
+    over [-30, 30] including the saturated tails.  Driven through the GEMM epilogue with an exact identity weight (fp32)."""
+    dev = _dev(lib)
+    n = 64
+    x = torch.cat([torch.linspace(-30, 30, 40 * n - 4 * n), torch.linspace(-1e-3, 1e-3, 4 * n)]).reshape(-1, n)
+    xd = lib.hook(x.to(dev).contiguous())
+    Wp, Kp = ops.pack_weight(torch.eye(n, device=dev), torch.float32)
+    out = ops.gemm_conv(lib, xd, Wp, Kp, M=x.shape[0], N=n, K=n, act=act)
+    _sync(lib)
+    want = ref(x)
+    err = (out[0].cpu() - want).abs()
+    bound = 3e-7 * torch.clamp(x.abs(), min=1.0)
+    assert bool((err <= bound).all()), (act, err.max().item(), x.flatten()[err.argmax()].item())
