@@ -179,7 +179,8 @@ static __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
 //   * two tiles are in flight behind the one being multiplied (2 register sets): with the MFMA time gone the kernel is bound
 //     by the L2 -> CU latency of the K/V stream (one workgroup per CU, 32 KB per tile).
 // Scores, running max / sum, the output accumulator and everything in HBM stay fp32.
-static __global__ __launch_bounds__(256) void attention_bf16_kernel(AttnArgs p) {
+// (register budget pinned to 2 waves per SIMD: left to itself the compiler aims for 3 and spills 144 B per lane into scratch)
+static __global__ __launch_bounds__(256) CV_WAVES_PER_EU(1, 2) void attention_bf16_kernel(AttnArgs p) {
     constexpr int BQ = 64, BKV = 64, LDH = 36;          // LDS row pitch in dwords: 64 bf16 + 8 pad
     __shared__ __attribute__((aligned(16))) unsigned Ks[BKV * LDH];
     __shared__ __attribute__((aligned(16))) unsigned Vt[64 * LDH];

@@ -6,6 +6,11 @@
 
 namespace cv {
 
+// register budget of a kernel as an occupancy window (the CPU emulator's hip_runtime.h blanks it)
+#ifndef CV_WAVES_PER_EU
+#define CV_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
+#endif
+
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;   // raw bfloat16 bits (weights are stored as bf16, math is fp32)
 
@@ -34,22 +39,35 @@ __device__ __forceinline__ float fast_erf(float x) {
     const float y = 1.f - poly * fast_exp(-ax * ax);
     return x < 0.f ? -y : y;
 }
-__device__ __noinline__ float act_slow(int act, float v) {
-    switch (act) {
-        case ACT_ELU: return v > 0.f ? v : expm1f(v);
-        default: return v;
+// ONE out-of-line copy per kernel, four elements per call: inlined at every unrolled prologue / epilogue site the activation code
+// bloats the GEMM k-loop past the instruction cache again (measured: +8..15 us per launch on the 64x64 / 128x64 tiles).
+__device__ __noinline__ float4 act4_call(int act, float4 x) {
+    float v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t = v[e];
+        float r;
+        if (act == ACT_SILU) r = t * fast_rcp(1.f + fast_exp(-t));
+        else if (act == ACT_GELU_ERF) r = 0.5f * t * (1.f + fast_erf(t * 0.70710678118654752440f));
+        else if (act == ACT_MISH) { const float n = fast_exp(fminf(t, 20.f)), w = n * (n + 2.f); r = t > 20.f ? t : t * w * fast_rcp(w + 2.f); }
+        else if (act == ACT_TANH) { const float e2 = fast_exp(2.f * fminf(fmaxf(t, -15.f), 15.f)); r = 1.f - 2.f * fast_rcp(e2 + 1.f); }
+        else if (act == ACT_ELU) r = t > 0.f ? t : expm1f(t);
+        else r = t;
+        v[e] = r;
     }
+    return make_float4(v[0], v[1], v[2], v[3]);
 }
-
-__device__ __forceinline__ float apply_act(int act, float v, float p) {
+__device__ __forceinline__ float4 apply_act4(int act, float4 v, float p) {
+    if (act == ACT_NONE) return v;
+    if (act == ACT_LEAKY) return make_float4(v.x > 0.f ? v.x : v.x * p, v.y > 0.f ? v.y : v.y * p, v.z > 0.f ? v.z : v.z * p, v.w > 0.f ? v.w : v.w * p);
+    if (act == ACT_ABS) return make_float4(fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w));
+    return act4_call(act, v);
+}
+__device__ __forceinline__ float apply_act(int act, float v, float p) {      // scalar sites (tails, small kernels)
     if (act == ACT_NONE) return v;
     if (act == ACT_LEAKY) return v > 0.f ? v : v * p;
     if (act == ACT_ABS) return fabsf(v);
-    if (act == ACT_SILU) return v * fast_rcp(1.f + fast_exp(-v));
-    if (act == ACT_GELU_ERF) return 0.5f * v * (1.f + fast_erf(v * 0.70710678118654752440f));
-    if (act == ACT_MISH) { const float n = fast_exp(fminf(v, 20.f)), w = n * (n + 2.f); return v > 20.f ? v : v * w * fast_rcp(w + 2.f); }
-    if (act == ACT_TANH) { const float e = fast_exp(2.f * fminf(fmaxf(v, -15.f), 15.f)); return 1.f - 2.f * fast_rcp(e + 1.f); }
-    return act_slow(act, v);
+    return act4_call(act, make_float4(v, 0.f, 0.f, 0.f)).x;
 }
 
 // Snake(x) = x + sin^2(alpha x) / (alpha + 1e-9)   (reference: cosyvoice/transformer/activation.py:73-84)

@@ -169,8 +169,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
                         x.x = snake_f(x.x, al.x); x.y = snake_f(x.y, al.y); x.z = snake_f(x.z, al.z); x.w = snake_f(x.w, al.w);
                     }
                 } else {                                        // any other activation with act(0) == 0 (Mish, SiLU, ...)
-                    x.x = apply_act(p.pro, x.x, p.pro_p); x.y = apply_act(p.pro, x.y, p.pro_p);
-                    x.z = apply_act(p.pro, x.z, p.pro_p); x.w = apply_act(p.pro, x.w, p.pro_p);
+                    x = apply_act4(p.pro, x, p.pro_p);
                 }
             }
             if (ABF16) *reinterpret_cast<uint2*>(&As[(v / KV) * LD + a_c4[i] / 2]) = make_uint2(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w));
@@ -315,8 +314,8 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += bb[e];
             if (p.act != ACT_NONE) {                         // the only activation site of the epilogue
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = apply_act(p.act, v[e], p.act_p);
+                const float4 t = apply_act4(p.act, make_float4(v[0], v[1], v[2], v[3]), p.act_p);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (v[e] + rr[e]) * p.out_scale * rs + oo[e];

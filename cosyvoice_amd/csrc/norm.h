@@ -54,8 +54,7 @@ static __global__ __launch_bounds__(256) void norm_rows_kernel(NormArgs p) {
             float o[4] = {(v[k].x - mean) * rstd, (v[k].y - mean) * rstd, (v[k].z - mean) * rstd, (v[k].w - mean) * rstd};
             if (p.gamma) { const float4 g = *reinterpret_cast<const float4*>(p.gamma + c); o[0] *= g.x; o[1] *= g.y; o[2] *= g.z; o[3] *= g.w; }
             if (p.beta) { const float4 b = *reinterpret_cast<const float4*>(p.beta + c); o[0] += b.x; o[1] += b.y; o[2] += b.z; o[3] += b.w; }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = apply_act(p.act, o[e], 0.f) * rs;
+            { const float4 t = apply_act4(p.act, make_float4(o[0], o[1], o[2], o[3]), 0.f); o[0] = t.x * rs; o[1] = t.y * rs; o[2] = t.z * rs; o[3] = t.w * rs; }
             if (ca) { const float4 a = *reinterpret_cast<const float4*>(ca + c); o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
             *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
         }

@@ -29,6 +29,7 @@ using std::min; using std::max;
 #define __noinline__ inline __attribute__((noinline))
 #define __shared__ static
 #define __launch_bounds__(...)
+#define CV_WAVES_PER_EU(lo, hi)
 #define __restrict__ __restrict
 
 // ---- basic types ----------------------------------------------------------
