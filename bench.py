@@ -139,15 +139,26 @@ def roofline_llm(model, u, cfgs):
     H, I, V, A, Q = lc.hidden, lc.inter, lc.speech_token_size + 3, lc.heads * 64, (lc.heads + 2 * lc.kv_heads) * 64
     # algorithmic bytes per launch: bf16 weight rows streamed once (2 B/param) — activations/bias are negligible
     wbytes = {0: 2 * Q * H, 2: 2 * H * A, 3: 2 * 2 * I * H, 4: 2 * H * I, 5: 2 * V * H}
-    names = {0: "gemv_kernel<7,1,1> qkv", 2: "gemv_kernel<7,1,1> o_proj", 3: "gemv_kernel<7,2,1> gate_up", 4: "gemv_kernel<10,1,4> down", 5: "gemv_kernel<7,2,1> head",
-             1: "attn_decode_kernel", 6: "sample_kernel"}
-    per = {names[k]: dict(launches=tot_c[k], avg_us=1e3 * tot_ms[k] / max(tot_c[k], 1)) for k in names if tot_c[k]}
-    # dominant kernel = gemv_kernel<7,R,1> (qkv + o_proj + gate_up + head instances): bytes and time averaged over its launches
-    ks = [0, 2, 3, 5]
-    n = sum(tot_c[k] for k in ks)
-    t_ms = sum(tot_ms[k] for k in ks)
-    bytes_per_launch = sum(tot_c[k] * wbytes[k] for k in ks) / max(n, 1)
-    avg_s = (t_ms / max(n, 1)) * 1e-3
+    names = {0: "gemv_kernel<7,1,1> qkv", 2: "gemv_kernel<2,1,4,8> o_proj (+ attention-partial merge)", 3: "gemv_kernel<7,2,1> gate_up", 4: "gemv_kernel<10,1,4> down",
+             5: "gemv_kernel<7,2,1> head", 1: "attn_decode_kernel", 6: "sample_kernel"}
+    per = {names[k]: dict(launches=tot_c[k], event_pair_avg_us=round(1e3 * tot_ms[k] / max(tot_c[k], 1), 2)) for k in names if tot_c[k]}
+    # Per-launch duration inside the graph: each kernel class replayed as a dependent chain of its real launches (one per layer, own
+    # weights) between ONE event pair on the decode stream (cv_llm_profile_chain).  An event pair around a single 3-7 us launch adds
+    # ~3 us of its own (kept above as event_pair_avg_us); rocprofv3 averages sit between the two (profiles/).
+    chain = {}
+    with model.llm_context:
+        for k in (0, 1, 2, 3, 4, 5):
+            ms1, n1 = C.c_float(), C.c_int32()
+            llm.lib.cv_llm_profile_chain(llm._h, k, 20, C.byref(ms1), C.byref(n1), stream_ptr(llm.lib))
+            chain[k] = 1e3 * ms1.value / max(n1.value, 1)
+            per[names[k]]["chain_avg_us"] = round(chain[k], 2)
+            if k in wbytes:
+                per[names[k]]["weight_bytes"] = wbytes[k]
+                per[names[k]]["GBps"] = round(wbytes[k] / (chain[k] * 1e-6) / 1e9, 1)
+    # dominant kernel of the whole path: gemv_kernel<7,2,1> on the gate_up matrices (24 launches per token, ~30 % of the decode step,
+    # the largest single share of an utterance)
+    bytes_per_launch = wbytes[3]
+    avg_s = chain[3] * 1e-6
     achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
     # HBM traffic per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run, x1024 B, x2 for
     # the gfx950 wide-read under-count — MI355X_MICROARCH.md §HBM); PMC cannot be collected from inside this process, hence the file.
@@ -155,13 +166,15 @@ def roofline_llm(model, u, cfgs):
     pmc = os.path.join(ROOT, "profiles", "r1_pmc_gemv_fetch.json")
     if os.path.exists(pmc):
         d = json.load(open(pmc))
-        sel = [v for k, v in d.items() if "<7, " in k]
+        sel = [v for k, v in d.items() if "<7, 2, 1>" in k]
         if sel:
             traffic = int(sum(v["n"] * v["hbm_read_bytes_corrected"] for v in sel) / sum(v["n"] for v in sel))
-            traffic_src = "profiles/r1_pmc_gemv_fetch.json (FETCH_SIZE*1024*2, mean over gemv_kernel<7,R,1> launches of tools/profile_small.py llm)"
-    return dict(bound="hbm", kernel="gemv_kernel<7,R,1> (LLM decode weight streaming: qkv, o_proj, gate_up, head)", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+            traffic_src = "profiles/r1_pmc_gemv_fetch.json (FETCH_SIZE*1024*2, mean over the gemv_kernel<7,2,1> launches of tools/profile_small.py llm)"
+    step_us = sum(chain[k] * lc.layers for k in (0, 1, 2, 3, 4)) + chain[5]
+    return dict(bound="hbm", kernel="gemv_kernel<7,2,1> (LLM decode, gate_up weight stream: 2 x 4864 x 896 bf16 per launch)", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                 unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src, bytes_per_launch=int(bytes_per_launch),
-                avg_launch_us=round(avg_s * 1e6, 2), per_kernel=per)
+                avg_launch_us=round(avg_s * 1e6, 2), timing="hipGraph chain of the kernel's 24 per-layer launches x 20 replays between one HIP-event pair on the decode stream",
+                decode_step_us_from_chains=round(step_us, 1), per_kernel=per)
 
 
 def cpu_baseline(cfgs):

@@ -26,6 +26,7 @@ struct cv_llm {
     SampleParams* host_sp = nullptr;
     DevBuf h, qkv, act, logits, attn_part;            // decode activations (+ split-attention partials)
     int attn_splits = 8;
+    int only_cat = -1;                  // cv_llm_profile_chain: enqueue only the launches of this category (-1 = all)
     DevBuf pf_x, pf_xn, pf_qkv, pf_attn, pf_gu, pf_act; // prefill activations (grown on demand)
     int pf_rows = 0;
     // decode graph
@@ -190,27 +191,28 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
     const auto& c = m->cfg;
     const DecodeState* st = m->state.as<DecodeState>();
     float* h = m->h.as<float>(); float* qkv = m->qkv.as<float>(); float* act = m->act.as<float>();
-    { ProfScope ps(m, s, 5); gemv(GemvArgs{m->head_w, m->head_b, h, m->logits.as<float>(), m->V, c.hidden, m->norm, c.rms_eps, nullptr, 0, st}, 2, s); }
+    auto want = [&](int cat) { return m->only_cat < 0 || m->only_cat == cat; };
+    if (want(5)) { ProfScope ps(m, s, 5); gemv(GemvArgs{m->head_w, m->head_b, h, m->logits.as<float>(), m->V, c.hidden, m->norm, c.rms_eps, nullptr, 0, st}, 2, s); }
     SampleArgs sa{};
     sa.logits = m->logits.as<float>(); sa.V = m->V; sa.sp = m->sparams.as<SampleParams>(); sa.uniforms = m->uniforms.as<float>();
     sa.st = m->state.as<DecodeState>(); sa.tokens = m->tokens.as<int>(); sa.max_tokens = c.max_len;
-    { ProfScope ps(m, s, 6); hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, s, sa); }
-    hipLaunchKernelGGL(embed_last_token_kernel, dim3(1), dim3(256), 0, s, m->speech_emb, c.hidden, h, st);
+    if (want(6)) { ProfScope ps(m, s, 6); hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, s, sa); }
+    if (want(7)) hipLaunchKernelGGL(embed_last_token_kernel, dim3(1), dim3(256), 0, s, m->speech_emb, c.hidden, h, st);
     for (int i = 0; i < c.layers; ++i) {
         const auto& L = m->layers[i];
-        { ProfScope ps(m, s, 0); gemv(GemvArgs{L.wqkv, L.bqkv, h, qkv, m->qkv_dim, c.hidden, L.ln1, c.rms_eps, nullptr, 0, st}, 1, s); }
+        if (want(0)) { ProfScope ps(m, s, 0); gemv(GemvArgs{L.wqkv, L.bqkv, h, qkv, m->qkv_dim, c.hidden, L.ln1, c.rms_eps, nullptr, 0, st}, 1, s); }
         const int nsp = m->attn_splits;
         AttnDecodeArgs ad{qkv, m->kcache.as<float>() + m->layer_cache() * i, m->vcache.as<float>() + m->layer_cache() * i,
                           m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st,
                           m->attn_part.as<float>(), nsp};
-        { ProfScope ps(m, s, 1); hipLaunchKernelGGL(attn_decode_kernel, dim3(c.heads * nsp), dim3(64), 0, s, ad); }
+        if (want(1)) { ProfScope ps(m, s, 1); hipLaunchKernelGGL(attn_decode_kernel, dim3(c.heads * nsp), dim3(64), 0, s, ad); }
         GemvArgs go{L.wo, nullptr, nullptr, h, c.hidden, c.heads * 64, nullptr, 0.f, h, 0, st};
         go.part = m->attn_part.as<float>();
-        { ProfScope ps(m, s, 2); gemv(go, 1, s, nsp); }
-        { ProfScope ps(m, s, 3); gemv(GemvArgs{L.wgu, nullptr, h, act, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 1, st}, 2, s); }
-        { ProfScope ps(m, s, 4); gemv(GemvArgs{L.wdown, nullptr, act, h, c.hidden, c.inter, nullptr, 0.f, h, 0, st}, 1, s); }
+        if (want(2)) { ProfScope ps(m, s, 2); gemv(go, 1, s, nsp); }
+        if (want(3)) { ProfScope ps(m, s, 3); gemv(GemvArgs{L.wgu, nullptr, h, act, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 1, st}, 2, s); }
+        if (want(4)) { ProfScope ps(m, s, 4); gemv(GemvArgs{L.wdown, nullptr, act, h, c.hidden, c.inter, nullptr, 0.f, h, 0, st}, 1, s); }
     }
-    hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, s, m->state.as<DecodeState>());
+    if (want(7)) hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, s, m->state.as<DecodeState>());
 }
 
 static bool same_sampling(const cv_sampling& a, const cv_sampling& b) {
@@ -327,6 +329,35 @@ int cv_llm_profile_step(cv_llm* m, const cv_sampling* sp, int32_t* counts8, floa
             (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second);
         }
         m->prof_events.clear();
+    });
+}
+/* Duration of ONE kernel class as it runs inside the decode graph: captures a graph holding only the launches of `category` of
+ * one decode step (one per layer, each on its own layer's weights and KV slice, so nothing is cache-warm that is not in the real
+ * step), replays it `reps` times between a single HIP-event pair on `stream`.  A per-launch event pair costs ~3 us of its own on
+ * a 3-7 us kernel; a dependent chain of the same launches does not.  Clobbers the decode activations (not pos / the KV prefix). */
+int cv_llm_profile_chain(cv_llm* m, int32_t category, int32_t reps, float* total_ms, int32_t* launches, void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && m->finalized && total_ms && launches && reps > 0 && category >= 0 && category <= 5, "cv_llm_profile_chain: bad arguments");
+        hipStream_t s = resolve(m, stream);
+        CV_CHECK(m->sp_valid, "cv_llm_profile_chain: run a decode / profile step first (sampling parameters)");
+        std::lock_guard<std::recursive_mutex> lk(runtime_lock());
+        CV_HIP(hipStreamSynchronize(s));
+        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+        m->only_cat = category;
+        hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) { llm_enqueue_step(m, s); e = hipStreamEndCapture(s, &g); }
+        m->only_cat = -1;
+        CV_HIP(e);
+        CV_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        hipEvent_t e0, e1; CV_HIP(hipEventCreate(&e0)); CV_HIP(hipEventCreate(&e1));
+        for (int i = 0; i < 2; ++i) CV_HIP(hipGraphLaunch(ge, s));
+        CV_HIP(hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) CV_HIP(hipGraphLaunch(ge, s));
+        CV_HIP(hipEventRecord(e1, s));
+        CV_HIP(hipEventSynchronize(e1));
+        CV_HIP(hipEventElapsedTime(total_ms, e0, e1));
+        *launches = (category == 5 ? 1 : m->cfg.layers) * reps;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
     });
 }
 int cv_llm_last_logits(cv_llm* m, float* host_out, void* stream) {

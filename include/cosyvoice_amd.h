@@ -121,6 +121,9 @@ int cv_llm_decode(cv_llm* m, int32_t n_steps, const cv_sampling* sp, int32_t* ou
 /* one eager decode step with a HIP-event pair around every launch: per category (0 qkv, 1 attention, 2 o_proj, 3 gate_up, 4 down,
  * 5 head, 6 sample) launch count and summed duration in ms — used by bench.py for the live roofline figure */
 int cv_llm_profile_step(cv_llm* m, const cv_sampling* sp, int32_t* counts8, float* ms8, void* stream);
+/* one kernel class (category as above, 0..5) as a dependent chain of its real launches (one per layer) in a hipGraph, `reps` replays
+ * between ONE event pair: total duration and number of launches — the per-launch duration bench.py prices against the HBM roofline */
+int cv_llm_profile_chain(cv_llm* m, int32_t category, int32_t reps, float* total_ms, int32_t* launches, void* stream);
 int cv_llm_last_logits(cv_llm* m, float* host_out, void* stream);
 int cv_llm_last_hidden(cv_llm* m, float* host_out, void* stream);
 /* out[r][:] = table[ids[r]][:] * scale  (nn.Embedding lookups that build lm_input / flow token embeddings) */

@@ -127,3 +127,22 @@ def test_no_speech_prompt(lib, tiny_sd):
     got = list(lm.inference(**_kw(u), max_token_text_ratio=3, min_token_text_ratio=1))
     want = OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=3, min_token_text_ratio=1)
     assert got == want and len(got) >= 1
+
+
+def test_profile_chain_leaves_handle_usable(lib, tiny_sd):
+    """cv_llm_profile_chain (bench.py's live per-kernel timing) replays one kernel class of the decode step; it clobbers the running
+    request's activations, so the next request must start with a prefill - after which tokens are bit-exact again."""
+    import ctypes as C
+    from cosyvoice_amd._lib import stream_ptr
+    cfg, sd = tiny_sd
+    u = _utt(cfg)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=128, sampling="greedy", decode_chunk=5)
+    want = OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=4, min_token_text_ratio=2)
+    assert list(lm.inference(**_kw(u), max_token_text_ratio=4, min_token_text_ratio=2)) == want
+    lm.prefill(lm.build_lm_input(u["text"], u["prompt_text"], u["llm_prompt_speech_token"]))
+    lm.decode(2, lm.make_sampling(6, 12))
+    for cat in range(6):
+        ms, n = C.c_float(), C.c_int32()
+        lib.cv_llm_profile_chain(lm._h, cat, 2, C.byref(ms), C.byref(n), stream_ptr(lib))
+        assert n.value == (1 if cat == 5 else cfg.layers) * 2 and ms.value >= 0.0
+    assert list(lm.inference(**_kw(u), max_token_text_ratio=4, min_token_text_ratio=2)) == want
