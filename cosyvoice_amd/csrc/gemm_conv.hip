@@ -26,12 +26,16 @@ void launch_gemm_conv(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t
     if (a.M <= 0 || a.N <= 0 || batch <= 0) return;
     struct Cfg { int bm, bn; };
     static const Cfg cfgs[] = {{128, 128}, {128, 64}, {64, 64}, {32, 64}, {32, 32}};
+    // bf16 tiles are small (LDS and registers) and their launches are latency-bound: ask for ~3 co-resident workgroups per CU (A/B on MI355X: 240 -> 480 -> 720 -> 1024 minimum workgroups gave 238 -> 224 -> 221 -> 226 ms per utterance), so one
+    // workgroup's load wait overlaps another's LDS / MFMA phases; the fp32 tiles keep ~1 per CU.
+    const bool bf16_path = a.a_bf16 && w_bf16 && a.a_vec;
+    const long long min_blocks = bf16_path ? 720 : 240;
     int pick = 4;
     for (int c = 0; c < 5; ++c) {
         const long long blocks = (long long)((a.M + cfgs[c].bm - 1) / cfgs[c].bm) * ((a.N + cfgs[c].bn - 1) / cfgs[c].bn) * batch;
         if (cfgs[c].bn > 32 && a.N <= cfgs[c].bn / 2) continue;       // don't pad N by 2x or more
         if (cfgs[c].bm > 32 && a.M <= cfgs[c].bm / 2) continue;
-        if (blocks >= 240) { pick = c; break; }
+        if (blocks >= min_blocks) { pick = c; break; }
     }
     // Small tiles run ~1 workgroup per CU and are bound by memory latency per k-iteration (activations written by another XCD,
     // weights from the Infinity Cache: ~3 us), so they take the biggest BK that fits 64 KB of LDS: fewer, fatter iterations.
