@@ -20,7 +20,7 @@ struct AttnArgs {
     int B, H, kv_group, Tq, Tk;
     float scale; int mask_mode; int chunk;
     const float* rel_bd; long long bd_batch; long long bd_head; int bd_row;
-    int bf16;      // 1: q, k, v and the probabilities are rounded to bf16 and both products run on v_mfma_f32_16x16x32_bf16 (fp32 softmax / accumulate)
+    int bf16;      // 1 (2, 3: forced workgroup shape): q, k, v and the probabilities are rounded to bf16 and both products run on v_mfma_f32_16x16x32_bf16 (fp32 softmax / accumulate)
 };
 
 enum { MASK_NONE = 0, MASK_CAUSAL = 1, MASK_CHUNK = 2 };
@@ -180,8 +180,12 @@ static __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
 //     by the L2 -> CU latency of the K/V stream (one workgroup per CU, 32 KB per tile).
 // Scores, running max / sum, the output accumulator and everything in HBM stay fp32.
 // (register budget pinned to 2 waves per SIMD: left to itself the compiler aims for 3 and spills 144 B per lane into scratch)
-static __global__ __launch_bounds__(256) CV_WAVES_PER_EU(1, 2) void attention_bf16_kernel(AttnArgs p) {
-    constexpr int BQ = 64, BKV = 64, LDH = 36;          // LDS row pitch in dwords: 64 bf16 + 8 pad
+// NW = waves per workgroup (16 queries each).  NW = 4 streams K/V once per 64 queries (default); NW = 2 doubles the workgroup count
+// (352 for the estimator's T = 674, B = 2, H = 8) so that two or three of them share a CU - measured neutral, kept selectable.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) CV_WAVES_PER_EU(1, 2) void attention_bf16_kernel(AttnArgs p) {
+    constexpr int NT = NW * 64, BQ = NW * 16, BKV = 64, LDH = 36;          // LDS row pitch in dwords: 64 bf16 + 8 pad
+    constexpr int NI = 512 / NT;                        // key pairs staged per thread and tile (32 pairs x 16 column groups / NT)
     __shared__ __attribute__((aligned(16))) unsigned Ks[BKV * LDH];
     __shared__ __attribute__((aligned(16))) unsigned Vt[64 * LDH];
 
@@ -224,15 +228,15 @@ static __global__ __launch_bounds__(256) CV_WAVES_PER_EU(1, 2) void attention_bf
 #pragma unroll
     for (int d = 0; d < 4; ++d) acc[d] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    // thread t stages the key PAIRS (2j, 2j+1), j = (t >> 4) + 16 i, columns c4 .. c4+3: adjacent keys land in one dword of V^T
+    // thread t stages the key PAIRS (2j, 2j+1), j = (t >> 4) + (NT/16) i, columns c4 .. c4+3: adjacent keys land in one dword of V^T
     const int c4 = (tid & 15) * 4, j0 = tid >> 4;
-    float4 rkA[2][2], rvA[2][2], rkB[2][2], rvB[2][2];
+    float4 rkA[NI][2], rvA[NI][2], rkB[NW == 4 ? NI : 1][2], rvB[NW == 4 ? NI : 1][2];
     auto load_kv = [&](int kt0, auto& rk, auto& rv) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
-                const int key = kt0 + 2 * (j0 + 16 * i) + par;
+                const int key = kt0 + 2 * (j0 + (NT / 16) * i) + par;
                 const bool ok = key < p.Tk;                   // unconditional loads (clamped row) keep the vmcnt bookkeeping exact
                 const long long kr = ok ? key : 0;
                 float4 kx = *reinterpret_cast<const float4*>(kb + kr * p.k_row + c4);
@@ -243,8 +247,8 @@ static __global__ __launch_bounds__(256) CV_WAVES_PER_EU(1, 2) void attention_bf
     };
     auto store_kv = [&](const auto& rk, const auto& rv) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int k0 = 2 * (j0 + 16 * i);                 // even key of the pair, 0..62
+        for (int i = 0; i < NI; ++i) {
+            const int k0 = 2 * (j0 + (NT / 16) * i);          // even key of the pair, 0..62
 #pragma unroll
             for (int par = 0; par < 2; ++par)
                 *reinterpret_cast<uint2*>(&Ks[(k0 + par) * LDH + c4 / 2]) = make_uint2(pack_bf16x2(rk[i][par].x, rk[i][par].y), pack_bf16x2(rk[i][par].z, rk[i][par].w));
@@ -314,19 +318,30 @@ static __global__ __launch_bounds__(256) CV_WAVES_PER_EU(1, 2) void attention_bf
         }
     };
 
-    if (kend > 0) load_kv(0, rkA, rvA);
-    if (kend > BKV) load_kv(BKV, rkB, rvB);
-    for (int kt0 = 0; kt0 < kend; kt0 += 2 * BKV) {
-        store_kv(rkA, rvA);
-        __syncthreads();
-        if (kt0 + 2 * BKV < kend) load_kv(kt0 + 2 * BKV, rkA, rvA);
-        compute(kt0);
-        __syncthreads();
-        if (kt0 + BKV < kend) {
-            store_kv(rkB, rvB);
+    if constexpr (NW == 4) {                         // two tiles in flight behind the one being multiplied
+        if (kend > 0) load_kv(0, rkA, rvA);
+        if (kend > BKV) load_kv(BKV, rkB, rvB);
+        for (int kt0 = 0; kt0 < kend; kt0 += 2 * BKV) {
+            store_kv(rkA, rvA);
             __syncthreads();
-            if (kt0 + 3 * BKV < kend) load_kv(kt0 + 3 * BKV, rkB, rvB);
-            compute(kt0 + BKV);
+            if (kt0 + 2 * BKV < kend) load_kv(kt0 + 2 * BKV, rkA, rvA);
+            compute(kt0);
+            __syncthreads();
+            if (kt0 + BKV < kend) {
+                store_kv(rkB, rvB);
+                __syncthreads();
+                if (kt0 + 3 * BKV < kend) load_kv(kt0 + 3 * BKV, rkB, rvB);
+                compute(kt0 + BKV);
+                __syncthreads();
+            }
+        }
+    } else {                                         // small workgroups overlap through co-residency: one tile in flight, half the registers
+        if (kend > 0) load_kv(0, rkA, rvA);
+        for (int kt0 = 0; kt0 < kend; kt0 += BKV) {
+            store_kv(rkA, rvA);
+            __syncthreads();
+            if (kt0 + BKV < kend) load_kv(kt0 + BKV, rkA, rvA);
+            compute(kt0);
             __syncthreads();
         }
     }

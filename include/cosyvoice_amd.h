@@ -81,7 +81,8 @@ typedef struct cv_attn_args {
     int32_t B; int32_t H; int32_t kv_group; int32_t Tq; int32_t Tk;
     float scale; int32_t mask_mode; int32_t chunk;
     const float* rel_bd; int64_t bd_batch; int64_t bd_head; int32_t bd_row;
-    int32_t bf16;        /* 1: q, k, v and the probabilities rounded to bf16, both products on the bf16 MFMA (fp32 softmax and accumulate) */
+    int32_t bf16;        /* 1: q, k, v and the probabilities rounded to bf16, both products on the bf16 MFMA (fp32 softmax and accumulate);
+                            workgroup shape chosen from the problem size (2 / 3 force the 64- / 32-query variant) */
 } cv_attn_args;
 int cv_attention(const cv_attn_args* args, void* stream);
 

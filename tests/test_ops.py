@@ -192,8 +192,9 @@ def test_attention_relpos(lib):
     torch.testing.assert_close(out.cpu(), ref, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("variant", [2, 3])      # 2: 64-query workgroups (two tiles in flight), 3: 32-query workgroups (co-resident)
 @pytest.mark.parametrize("Tq,Tk,mode,chunk", [(70, 70, "none", 0), (50, 50, "chunk", 16), (33, 81, "causal", 0), (200, 200, "chunk", 50), (300, 300, "none", 0)])
-def test_attention_bf16_mfma(lib, Tq, Tk, mode, chunk):
+def test_attention_bf16_mfma(lib, Tq, Tk, mode, chunk, variant):
     """bf16 = 1: q, k, v rounded to bf16 (products exact in fp32), probabilities rounded to bf16 for the P.V product only
     (the denominator sums the unrounded ones).  Reference: the same operand rounding in torch with fp32 probabilities; what is
     left is the bf16 rounding of P, relative 2^-9 per term and averaging out over the keys: tolerance 4e-3 on O(1) outputs."""
@@ -206,7 +207,8 @@ def test_attention_bf16_mfma(lib, Tq, Tk, mode, chunk):
     else:
         kc = _rand((B, H // G, Tk, 64), dev, 21); vc = _rand((B, H // G, Tk, 64), dev, 22)
         k = kc.permute(0, 2, 1, 3); v = vc.permute(0, 2, 1, 3); group = G
-    out = ops.attention(lib, q, k, v, scale=1 / 8.0, mask=mode, chunk=chunk, kv_group=group, bf16=True)
+    out = ops.attention(lib, q, k, v, scale=1 / 8.0, mask=mode, chunk=chunk, kv_group=group, bf16=variant)
+    auto = ops.attention(lib, q, k, v, scale=1 / 8.0, mask=mode, chunk=chunk, kv_group=group, bf16=True)
     exact = ops.attention(lib, q, k, v, scale=1 / 8.0, mask=mode, chunk=chunk, kv_group=group)
     _sync(lib)
     qi = torch.arange(Tq)[:, None]; kj = torch.arange(Tk)[None, :]
@@ -218,6 +220,7 @@ def test_attention_bf16_mfma(lib, Tq, Tk, mode, chunk):
     torch.testing.assert_close(out.cpu(), ref, rtol=4e-3, atol=4e-3)
     assert not torch.equal(out, exact)
     torch.testing.assert_close(out.cpu(), exact.cpu(), rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(auto.cpu(), ref, rtol=4e-3, atol=4e-3)          # bf16=1 picks one of the two variants
 
 
 def test_attention_relpos_bf16_mfma(lib):
