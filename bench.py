@@ -287,10 +287,10 @@ def main():
         if world == 1:
             out["first_chunk_ms_p50"] = round(first_chunk_latency(model, u, args.first_chunk_reps), 2)
             log("first chunk p50 %.1f ms" % out["first_chunk_ms_p50"])
-            out["roofline"] = roofline_llm(model, u, cfgs)
-            log("roofline done")
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(cfgs)
+        out["roofline"] = roofline_llm(model, u, cfgs)          # rank 0's GPU (every replica runs the same kernels)
+        log("roofline done")
+        if world == 1 and not args.no_cpu_baseline:             # the CPU baseline is reported at N = 1 only
+            out["cpu_baseline"] = cpu_baseline(cfgs)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -44,18 +44,23 @@ struct GemmConvArgs {
 // Pipeline: most GEMMs on this path are small (M ~ 10^3, K = 256..1024) and run ~1 workgroup per CU, so nothing hides global
 // latency but the kernel itself: a 2-deep REGISTER prefetch ring keeps the loads of k-tiles it+1 and it+2 in flight while tile
 // it is multiplied out of LDS, and the small tiles use BK = 64 to halve the number of barrier-separated iterations.
-template <int BM, int BN, int BK, bool WBF16, bool AVEC, int STAGES = 2, bool ABF16 = false>
-__global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
+// WM x WN = wave grid of a workgroup (64 * WM * WN threads); a wave owns a (BM / WM) x (BN / WN) sub-tile.  The default 2 x 2 serves
+// every tile from 32 x 32 up; 1 x 2 makes the 16 x 32 tile (two-wave workgroups) that lets the N = 256 GEMMs of the flow run ~3
+// workgroups per CU (680 instead of 344 launches' worth at M = 1348).
+template <int BM, int BN, int BK, bool WBF16, bool AVEC, int STAGES = 2, bool ABF16 = false, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p) {
     static_assert(!ABF16 || WBF16, "the bf16 MFMA path takes bf16 weights");
+    constexpr int NT = 64 * WM * WN;
     // LD = LDS row pitch in dwords.  fp32 tiles: BK + 4.  bf16 tiles hold BK/2 packed pairs + 4 dwords of padding.
     constexpr int LD = ABF16 ? BK / 2 + 4 : BK + 4, KV = BK / 4;         // KV = groups of 4 k-values per tile row
-    constexpr int TM = BM / 32, TN = BN / 32;       // 16x16 tiles per wave (wave tile = BM/2 x BN/2)
-    constexpr int AV = BM * KV / 256, WV = BN * KV / 256;   // float4 groups per thread per k-step
+    constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN);   // 16x16 tiles per wave (wave tile = BM/WM x BN/WN)
+    constexpr int AV = BM * KV / NT, WV = BN * KV / NT;       // float4 groups per thread per k-step
+    static_assert(TM >= 1 && TN >= 1 && AV >= 1 && WV >= 1 && BM * KV % NT == 0 && BN * KV % NT == 0, "tile does not divide over the workgroup");
     __shared__ __attribute__((aligned(16))) float As[BM * LD];
     __shared__ __attribute__((aligned(16))) float Ws[BN * LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave % WM, wn = wave / WM;
     // XCD-aware tile order: consecutive remapped ids walk the N tiles of one M band, so an XCD owns ~1/8 of the rows of A
     // (A crosses the fabric once) and keeps the whole, much smaller, W panel in its own L2.
     const int bl = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
     const __amdgpu_buffer_rsrc_t rsW = make_rsrc(reinterpret_cast<const char*>(p.W) + wb * WE, (unsigned)(((long long)(p.N - 1) * ldw + (long long)p.taps * p.Kp) * WE));
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
-        const int v = tid + i * 256, m = m0 + v / KV;
+        const int v = tid + i * NT, m = m0 + v / KV;
         a_c4[i] = (v % KV) * 4;
         a_row_ok[i] = m < p.M;
         a_base[i] = (long long)m * p.lda + p.a_off0 + a_c4[i];
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
-        const int v = tid + i * 256;
+        const int v = tid + i * NT;
         int n = n0 + v / KV; n = n < p.N ? n : p.N - 1;
         w_c4[i] = (v % KV) * 4;
         w_base[i] = wb + (long long)n * ldw + w_c4[i];
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
     auto store_tile = [&](int k0, const auto& ra, const auto& rw) {
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
-            const int v = tid + i * 256, kk = k0 + a_c4[i];
+            const int v = tid + i * NT, kk = k0 + a_c4[i];
             float4 x = ra[i];
             if (p.pro != ACT_NONE) {
                 if (p.pro == ACT_LEAKY) {
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
-            const int v = tid + i * 256;
+            const int v = tid + i * NT;
             if (ABF16) *reinterpret_cast<uint2*>(&Ws[(v / KV) * LD + w_c4[i] / 2]) = make_uint2(__float_as_uint(rw[i].x), __float_as_uint(rw[i].y));
             else *reinterpret_cast<float4*>(&Ws[(v / KV) * LD + w_c4[i]]) = rw[i];
         }
@@ -191,10 +196,10 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
                 const int kd = kg * 16 + (lane >> 4) * 4;               // dword offset of the lane's 8 bf16
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    af[i] = *reinterpret_cast<const uint4*>(&As[(wm * (BM / 2) + i * 16 + (lane & 15)) * LD + kd]);
+                    af[i] = *reinterpret_cast<const uint4*>(&As[(wm * (BM / WM) + i * 16 + (lane & 15)) * LD + kd]);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    wf[j] = *reinterpret_cast<const uint4*>(&Ws[(wn * (BN / 2) + j * 16 + (lane & 15)) * LD + kd]);
+                    wf[j] = *reinterpret_cast<const uint4*>(&Ws[(wn * (BN / WN) + j * 16 + (lane & 15)) * LD + kd]);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -209,10 +214,10 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
             const int kc = kg * 16 + (lane >> 4) * 4;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const float4*>(&As[(wm * (BM / 2) + i * 16 + (lane & 15)) * LD + kc]);
+                af[i] = *reinterpret_cast<const float4*>(&As[(wm * (BM / WM) + i * 16 + (lane & 15)) * LD + kc]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                wf[j] = *reinterpret_cast<const float4*>(&Ws[(wn * (BN / 2) + j * 16 + (lane & 15)) * LD + kc]);
+                wf[j] = *reinterpret_cast<const float4*>(&Ws[(wn * (BN / WN) + j * 16 + (lane & 15)) * LD + kc]);
             // k-slot permutation: lane group g = lane>>4 feeds k = kc+s at MFMA step s for both operands.
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -282,12 +287,12 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmConvArgs p) {
     const float* RSb = p.row_scale ? p.row_scale + (long long)b * p.row_scale_batch : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+        const int m = m0 + wm * (BM / WM) + i * 16 + (lane & 15);
         if (m >= p.M) continue;
         const float rs = RSb ? RSb[m] : 1.f;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+            const int n = n0 + wn * (BN / WN) + j * 16 + (lane >> 4) * 4;
             if (n >= p.N) continue;
             const long long idx = (long long)m * p.ldc + n + p.c_off;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};

@@ -1,6 +1,8 @@
 // Host dispatch for the implicit-GEMM kernel: picks the tile shape so that a launch fills the
 // 256 CUs of an MI355X where the problem allows it (most of this path's GEMMs are small).
 #include "gemm_conv.h"
+#include <cstdlib>
+#include "api_common.h"
 
 namespace cv {
 
@@ -22,21 +24,36 @@ static void launch_cfg(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_
     }
 }
 
+// dev switch for same-box A/B runs (tools/ab_bench.sh): CV_GEMM_TWO_WAVE_TILE=0 removes the 16 x 32 two-wave tile from the choice
+static bool use_two_wave_tile() {
+    static const bool on = [] { const char* e = getenv("CV_GEMM_TWO_WAVE_TILE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// test hook: CV_GEMM_FORCE_TILE=0..5 pins the tile shape (read at every launch), so that tests/test_ops.py can hold EVERY instantiation
+// to the oracle on small problems - the size-based choice below would only ever give them the smallest tile.
+static int forced_tile() {
+    const char* e = getenv("CV_GEMM_FORCE_TILE");
+    return (e && e[0] >= '0' && e[0] <= '5' && e[1] == 0) ? e[0] - '0' : -1;
+}
+
 void launch_gemm_conv(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0 || batch <= 0) return;
     struct Cfg { int bm, bn; };
-    static const Cfg cfgs[] = {{128, 128}, {128, 64}, {64, 64}, {32, 64}, {32, 32}};
+    static const Cfg cfgs[] = {{128, 128}, {128, 64}, {64, 64}, {32, 64}, {32, 32}, {16, 32}};
     // bf16 tiles are small (LDS and registers) and their launches are latency-bound: ask for ~3 co-resident workgroups per CU (A/B on MI355X: 240 -> 480 -> 720 -> 1024 minimum workgroups gave 238 -> 224 -> 221 -> 226 ms per utterance), so one
     // workgroup's load wait overlaps another's LDS / MFMA phases; the fp32 tiles keep ~1 per CU.
     const bool bf16_path = a.a_bf16 && w_bf16 && a.a_vec;
     const long long min_blocks = bf16_path ? 720 : 240;
-    int pick = 4;
-    for (int c = 0; c < 5; ++c) {
+    const int ncfg = (bf16_path && a.Kp >= 128 && use_two_wave_tile()) ? 6 : 5;   // the 16 x 32 two-wave tile exists for the bf16 path only
+    int pick = ncfg - 1;                             // nothing reaches the target: the smallest tile = the most workgroups
+    for (int c = 0; c < ncfg; ++c) {
         const long long blocks = (long long)((a.M + cfgs[c].bm - 1) / cfgs[c].bm) * ((a.N + cfgs[c].bn - 1) / cfgs[c].bn) * batch;
         if (cfgs[c].bn > 32 && a.N <= cfgs[c].bn / 2) continue;       // don't pad N by 2x or more
         if (cfgs[c].bm > 32 && a.M <= cfgs[c].bm / 2) continue;
         if (blocks >= min_blocks) { pick = c; break; }
     }
+    if (const int f = forced_tile(); f >= 0) { if (f == 5 && !(bf16_path && a.Kp >= 128)) throw Error("CV_GEMM_FORCE_TILE=5 needs the bf16 path and Kp >= 128"); pick = f; }
     // Small tiles run ~1 workgroup per CU and are bound by memory latency per k-iteration (activations written by another XCD,
     // weights from the Infinity Cache: ~3 us), so they take the biggest BK that fits 64 KB of LDS: fewer, fatter iterations.
     const bool bigk = a.Kp >= 128;
@@ -45,7 +62,12 @@ void launch_gemm_conv(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t
         case 1: if (a.Kp >= 64) launch_cfg<128, 64, 64>(a, w_bf16, batch, stream); else launch_cfg<128, 64, 32>(a, w_bf16, batch, stream); break;
         case 2: if (bigk) launch_cfg<64, 64, 128>(a, w_bf16, batch, stream); else launch_cfg<64, 64, 64>(a, w_bf16, batch, stream); break;
         case 3: if (bigk) launch_cfg<32, 64, 128>(a, w_bf16, batch, stream); else launch_cfg<32, 64, 64>(a, w_bf16, batch, stream); break;
-        default: if (bigk) launch_cfg<32, 32, 128>(a, w_bf16, batch, stream); else launch_cfg<32, 32, 64>(a, w_bf16, batch, stream); break;
+        case 4: if (bigk) launch_cfg<32, 32, 128>(a, w_bf16, batch, stream); else launch_cfg<32, 32, 64>(a, w_bf16, batch, stream); break;
+        default: {                                   // 16 x 32, wave grid 1 x 2 (128 threads), bf16 MFMA only
+            dim3 grid((a.M + 15) / 16, (a.N + 31) / 32, batch);
+            hipLaunchKernelGGL((gemm_conv_kernel<16, 32, 128, true, true, 2, true, 1, 2>), grid, dim3(128), 0, stream, a);
+            break;
+        }
     }
 }
 

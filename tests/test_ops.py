@@ -254,3 +254,27 @@ def test_activations(lib, act, ref):
     err = (out[0].cpu() - want).abs()
     bound = 3e-7 * torch.clamp(x.abs(), min=1.0)
     assert bool((err <= bound).all()), (act, err.max().item(), x.flatten()[err.argmax()].item())
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+def test_every_gemm_tile_shape(lib, tile, bf16, monkeypatch):
+    """The tile shape is chosen from the launch size (gemm_conv.hip), so small problems only ever meet the smallest one.
+    CV_GEMM_FORCE_TILE pins it: every instantiation (128x128 .. 32x32, and the two-wave 16x32 of the bf16 path), both K depths, with
+    ragged M / N / K edges, a causal 3-tap conv window, bias + residual epilogue, against torch."""
+    if tile == 5 and not bf16:
+        pytest.skip("the 16x32 two-wave tile exists for the bf16 path only")
+    dev = _dev(lib)
+    monkeypatch.setenv("CV_GEMM_FORCE_TILE", str(tile))
+    for (M, N, K, taps) in [(150, 140, 160, 1), (70, 200, 36, 3), (40, 33, 320, 1)]:
+        if tile == 5 and K < 97:
+            continue                                                  # (Kp >= 128 is required for that tile)
+        x = _rand((M + taps - 1, K), dev, 31)
+        W = _rand((N, taps, K), dev, 32, 0.2).bfloat16().float()
+        b = _rand((N,), dev, 33); res = _rand((M, N), dev, 34)
+        Wp, Kp = ops.pack_weight(W if taps > 1 else W[:, 0], torch.bfloat16)
+        out = ops.gemm_conv(lib, x, Wp, Kp, M=M, N=N, K=K, taps=taps, lda=K, tap_step=K, a_len=x.numel(), bias=b, res=res.reshape(1, M, N), a_bf16=bf16)
+        _sync(lib)
+        xa = x.bfloat16().float() if bf16 else x
+        ref = sum(xa[j:j + M] @ W[:, j].t() for j in range(taps)) + b + res
+        torch.testing.assert_close(out[0].cpu(), ref.cpu(), rtol=3e-5, atol=3e-5)
