@@ -24,9 +24,11 @@ static void launch_cfg(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_
     }
 }
 
-// dev switch for same-box A/B runs (tools/ab_bench.sh): CV_GEMM_TWO_WAVE_TILE=0 removes the 16 x 32 two-wave tile from the choice
+// The 16 x 32 two-wave tile (680 workgroups for the flow's N = 256 GEMMs instead of 344) measured neutral-to-worse on MI355X
+// (222.6 ms per utterance without, 225.4 with, interleaved runs on one box): it stays out of the size-based choice unless
+// CV_GEMM_TWO_WAVE_TILE=1, and stays covered through CV_GEMM_FORCE_TILE=5 (tests/test_ops.py::test_every_gemm_tile_shape).
 static bool use_two_wave_tile() {
-    static const bool on = [] { const char* e = getenv("CV_GEMM_TWO_WAVE_TILE"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char* e = getenv("CV_GEMM_TWO_WAVE_TILE"); return e && e[0] == '1'; }();
     return on;
 }
 
