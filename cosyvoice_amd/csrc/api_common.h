@@ -33,6 +33,18 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // LLM on its own thread + stream while the caller's thread runs token2wav, so both can happen at the same moment.
 std::recursive_mutex& runtime_lock();
 
+// Captures `body()` on `s` into a graph.  If the body throws (argument checks inside the launchers), the capture is ended and the
+// partial graph dropped before the exception travels on: a stream left in capture mode would poison every later call on it.
+template <typename F>
+static inline hipGraph_t capture_graph(hipStream_t s, F&& body) {
+    hipGraph_t g = nullptr;
+    CV_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    try { body(); }
+    catch (...) { (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); throw; }
+    CV_HIP(hipStreamEndCapture(s, &g));
+    return g;
+}
+
 // device buffer owned by a handle (workspaces, KV cache)
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;

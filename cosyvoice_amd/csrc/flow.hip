@@ -371,10 +371,8 @@ static void solve_euler(cv_flow* m, float* x /*[T][mel] in/out*/, const float* m
     if (m->use_graph && x == m->f_x.as<float>() && ++m->seen[key] == 2) {
         if (m->graphs.size() >= 8) { for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second); m->graphs.clear(); }
         std::lock_guard<std::recursive_mutex> lk(runtime_lock());
-        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
-        CV_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        body();
-        CV_HIP(hipStreamEndCapture(s, &g));
+        hipGraphExec_t ge = nullptr;
+        hipGraph_t g = capture_graph(s, body);
         CV_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         CV_HIP(hipGraphDestroy(g));
         m->graphs[key] = ge;

@@ -239,10 +239,7 @@ static void llm_decode(cv_llm* m, int n_steps, const cv_sampling* sp, int32_t* o
         if (!m->graph || m->graph_stream != s) {
             if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
             std::lock_guard<std::recursive_mutex> lk(runtime_lock());
-            hipGraph_t g = nullptr;
-            CV_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            llm_enqueue_step(m, s);
-            CV_HIP(hipStreamEndCapture(s, &g));
+            hipGraph_t g = capture_graph(s, [&] { llm_enqueue_step(m, s); });
             CV_HIP(hipGraphInstantiate(&m->graph, g, nullptr, nullptr, 0));
             CV_HIP(hipGraphDestroy(g));
             m->graph_stream = s;
@@ -343,11 +340,10 @@ int cv_llm_profile_chain(cv_llm* m, int32_t category, int32_t reps, float* total
         std::lock_guard<std::recursive_mutex> lk(runtime_lock());
         CV_HIP(hipStreamSynchronize(s));
         hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+        struct CatScope { cv_llm* m; ~CatScope() { m->only_cat = -1; } } cat_scope{m};      // also on the exception paths below
         m->only_cat = category;
-        hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-        if (e == hipSuccess) { llm_enqueue_step(m, s); e = hipStreamEndCapture(s, &g); }
+        g = capture_graph(s, [&] { llm_enqueue_step(m, s); });
         m->only_cat = -1;
-        CV_HIP(e);
         CV_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         hipEvent_t e0, e1; CV_HIP(hipEventCreate(&e0)); CV_HIP(hipEventCreate(&e1));
         for (int i = 0; i < 2; ++i) CV_HIP(hipGraphLaunch(ge, s));

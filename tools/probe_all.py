@@ -2,7 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import weights as W
+from cosyvoice_amd import synthetic as W
 from cosyvoice_amd.llm import Qwen2LM
 from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
 from cosyvoice_amd.hift import HiFTGenerator
