@@ -19,4 +19,9 @@ Pinning status: the reference ships NO golden vectors, known-an
 
 Precision policy shared with the HIP path ("W16A32"): LLM and flow weights are rounded to bf16 once (weights.py),
 all arithmetic is fp32; HiFT is fp32 throughout (the reference always runs it in fp32, cli/model.py:312).
+`oracle.flow.bf16_act()` additionally mirrors the product's "bf16" mode (operands of the flow's Linear / Conv1d / attention
+products rounded to bfloat16, fp32 accumulation) for the statistical checks of that mode.
+
+The reference is Python: there is no compiled reference to build (`oracle/_ref` does not apply); it is imported in the build
+container only by tests/golden/make_golden.py, which wrote the committed fixtures.
 """
