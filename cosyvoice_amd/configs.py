@@ -17,6 +17,11 @@ class LLMConfig:                      # Appendix A.1 (cosyvoice2.yaml:23-36 + Qw
     speech_token_size: int = 6561
     rms_eps: float = 1e-6
     rope_theta: float = 1e6
+    # CosyVoice3LM (llm/llm.py:664-706): sos / eos / task_id / fill are rows speech_token_size + {0,1,2,3} of speech_embedding
+    # (no llm_embedding table), the head is Linear(hidden, speech_token_size + 200, bias=False) and all 200 extra ids stop decoding.
+    cv3: bool = False
+    n_special: int = 3                # ids >= speech_token_size: 3 for Qwen2LM (eos, +1, fill), 200 for CosyVoice3LM
+    endofprompt_id: int = 151646      # <|endofprompt|>, required in the text of CosyVoice3 requests (llm/llm.py:478-480)
 
 
 @dataclass
@@ -62,6 +67,16 @@ class HiftConfig:                     # Appendix A.4 (cosyvoice2.yaml:89-111)
 
 def cv2():
     return LLMConfig(), FlowConfig(), HiftConfig()
+
+
+def tiny_cv3_llm():
+    """Emulator-sized CosyVoice3LM; the text vocabulary still has to reach the hard-coded <|endofprompt|> id 151646."""
+    return LLMConfig(hidden=128, layers=2, heads=2, kv_heads=1, inter=256, text_vocab=151650, speech_token_size=60, cv3=True, n_special=200)
+
+
+def cv3_llm():
+    """The LM of Fun-CosyVoice3-0.5B (cosyvoice3.yaml:23-36): same Qwen2.5-0.5B backbone, CosyVoice3LM head / embedding layout."""
+    return LLMConfig(cv3=True, n_special=200)
 
 
 def tiny():

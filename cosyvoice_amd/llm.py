@@ -46,7 +46,7 @@ class Qwen2LM:
         self.sos, self.task_id = 0, 1
         self.eos_token = cfg.speech_token_size
         self.fill_token = cfg.speech_token_size + 2
-        self.stop_token_ids = [cfg.speech_token_size + i for i in range(3)]
+        self.stop_token_ids = [cfg.speech_token_size + i for i in range(cfg.n_special)]
         self.sampling, self.top_p, self.top_k, self.win_size, self.tau_r, self.seed = sampling, top_p, top_k, win_size, tau_r, seed
         self.decode_chunk = decode_chunk
         self.max_len = max_len
@@ -54,7 +54,7 @@ class Qwen2LM:
         self._tensors, self._host = Wt.pack_llm(state_dict, cfg, self.device)
         self._tensors = {k: self.lib.hook(v) for k, v in self._tensors.items()}
         self._host = {k: self.lib.hook(v) for k, v in self._host.items()}
-        c = LLMConfigC(cfg.hidden, cfg.layers, cfg.heads, cfg.kv_heads, cfg.inter, cfg.speech_token_size + 3, max_len, cfg.rms_eps, cfg.rope_theta)
+        c = LLMConfigC(cfg.hidden, cfg.layers, cfg.heads, cfg.kv_heads, cfg.inter, cfg.speech_token_size + cfg.n_special, max_len, cfg.rms_eps, cfg.rope_theta)
         self._h = C.c_void_p()
         self.lib.cv_llm_create(C.byref(self._h), C.byref(c))
         register_tensors(self.lib, "cv_llm_set_tensor", self._h, self._tensors)
@@ -87,12 +87,16 @@ class Qwen2LM:
                 return
             self.lib.cv_gather_rows(C.c_void_p(table.data_ptr()), C.c_int32(CV_BF16), C.c_int64(table.shape[0]), C.c_int32(H),
                                     C.c_void_p(ids.data_ptr()), C.c_int32(ids.numel()), C.c_void_p(out[row0:].data_ptr()), C.c_float(1.0), st)
-        gather(self._host["embed.llm"], fixed[0:1], 0)
+        special = self._special_table()                  # llm_embedding (Qwen2LM) or speech_embedding (CosyVoice3LM)
+        gather(special, fixed[0:1], 0)
         gather(self._host["embed.text"], ids_text, 1)
-        gather(self._host["embed.llm"], fixed[1:2], 1 + n_t)
+        gather(special, fixed[1:2], 1 + n_t)
         gather(self._tensors["embed.speech"], ids_sp, 2 + n_t)
         self._keep = (ids_text, ids_sp, fixed)
         return out
+
+    def _special_table(self):
+        return self._host["embed.llm"]
 
     def warmup(self):
         """Run one prefill + one decode step on the CURRENT stream so that the decode hipGraph for this stream is captured now
@@ -101,7 +105,7 @@ class Qwen2LM:
         with self.lock:
             x = self.lib.hook(torch.zeros(4, self.cfg.hidden, dtype=torch.float32, device=self.device))
             self.prefill(x)
-            self.decode(1, SamplingC(0, self.eos_token, 3, 1, 2, self.top_p, self.top_k, self.win_size, self.tau_r, 0, 0))
+            self.decode(1, SamplingC(0, self.cfg.speech_token_size, self.cfg.n_special, 1, 2, self.top_p, self.top_k, self.win_size, self.tau_r, 0, 0))
 
     def set_uniforms(self, u):
         """Parity hook: explicit uniform variates (2 per step) instead of the on-device counter RNG."""
@@ -112,7 +116,7 @@ class Qwen2LM:
         self.lib.cv_llm_prefill(self._h, C.c_void_p(lm_input.data_ptr()), C.c_int32(lm_input.shape[0]), st)
 
     def last_logits(self):
-        out = torch.empty(self.cfg.speech_token_size + 3, dtype=torch.float32)
+        out = torch.empty(self.cfg.speech_token_size + self.cfg.n_special, dtype=torch.float32)
         self.lib.cv_llm_last_logits(self._h, C.c_void_p(out.data_ptr()), stream_ptr(self.lib))
         return out
 
@@ -130,7 +134,9 @@ class Qwen2LM:
 
     def make_sampling(self, min_len, max_len):
         self._request += 1
-        sp = SamplingC(1 if self.sampling == "ras" else 0, self.eos_token, 3, min_len, max_len, self.top_p, self.top_k, self.win_size,
+        # `eos` of the C sampler = first special id = the index sampling_ids masks while ignore_eos (llm/llm.py:150-160: literally
+        # `speech_token_size`, which is eos for Qwen2LM and - a quirk kept as is - sos for CosyVoice3LM); n_stop ids from there stop decoding
+        sp = SamplingC(1 if self.sampling == "ras" else 0, self.cfg.speech_token_size, self.cfg.n_special, min_len, max_len, self.top_p, self.top_k, self.win_size,
                        self.tau_r, self.seed + self._request, 1 if self._uniforms is not None else 0)
         if self._uniforms is not None:
             self.lib.cv_llm_set_uniforms(self._h, C.c_void_p(self._uniforms.data_ptr()), C.c_int32(min(self._uniforms.numel(), 2 * self.max_len)), stream_ptr(self.lib))
@@ -157,3 +163,25 @@ class Qwen2LM:
                 emitted += len(toks)
                 if fin:
                     break
+
+
+class CosyVoice3LM(Qwen2LM):
+    """cosyvoice/llm/llm.py:664-706 (inference side; SURVEY.md §8 row a17, LM part).  Same backbone and the same device kernels as
+    Qwen2LM; what differs is bookkeeping: sos / eos / task_id / fill are ids speech_token_size + {0,1,2,3} whose embeddings are rows
+    of `speech_embedding` (there is no llm_embedding), the head is bias-free over speech_token_size + 200 ids, every id >=
+    speech_token_size stops decoding, and requests must carry <|endofprompt|> (cfg.endofprompt_id) in prompt_text ++ text."""
+
+    def __init__(self, state_dict, cfg, **kw):
+        assert cfg.cv3 and cfg.n_special == 200, "CosyVoice3LM needs a cv3 LLMConfig (configs.cv3_llm())"
+        super().__init__(state_dict, cfg, **kw)
+        sts = cfg.speech_token_size
+        self.sos, self.eos_token, self.task_id, self.fill_token = sts + 0, sts + 1, sts + 2, sts + 3
+
+    def _special_table(self):
+        return self._tensors["embed.speech"]
+
+    @torch.inference_mode()
+    def inference(self, text, text_len, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len, embedding=None, **kw):
+        both = torch.cat([prompt_text.reshape(-1), text.reshape(-1)])
+        assert bool((both == self.cfg.endofprompt_id).any()), "<|endofprompt|> not detected in CosyVoice3 text or prompt_text, check your input!"
+        yield from super().inference(text, text_len, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len, embedding, **kw)

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 
-from .configs import FlowConfig, HiftConfig, LLMConfig, cv2, tiny  # noqa: F401
+from .configs import FlowConfig, HiftConfig, LLMConfig, cv2, cv3_llm, tiny, tiny_cv3_llm  # noqa: F401
 
 
 class _Gen:
@@ -39,9 +39,10 @@ def to_bf16_grid(sd):
 
 
 def make_llm(cfg: LLMConfig, seed=1986):
-    """Keys of cosyvoice.llm.llm.Qwen2LM (llm/llm.py:257-297) over transformers.Qwen2ForCausalLM."""
+    """Keys of cosyvoice.llm.llm.Qwen2LM (llm/llm.py:257-297), or CosyVoice3LM (:664-706) when cfg.cv3, over transformers.Qwen2ForCausalLM."""
     g, sd, H = _Gen(seed), {}, cfg.hidden
-    sd["llm_embedding.weight"] = g.normal((2, H), 0.5)
+    if not cfg.cv3:
+        sd["llm_embedding.weight"] = g.normal((2, H), 0.5)
     sd["llm.model.model.embed_tokens.weight"] = g.normal((cfg.text_vocab, H), 0.5)
     for i in range(cfg.layers):
         p = "llm.model.model.layers.%d." % i
@@ -59,9 +60,15 @@ def make_llm(cfg: LLMConfig, seed=1986):
         sd[p + "post_attention_layernorm.weight"] = g.gamma(H)
     sd["llm.model.model.norm.weight"] = g.gamma(H)
     sd["llm.model.lm_head.weight"] = sd["llm.model.model.embed_tokens.weight"]       # tied (unused by the hot path)
-    sd["llm_decoder.weight"] = g.linear(cfg.speech_token_size + 3, H, gain=3.0)
-    sd["llm_decoder.bias"] = g.normal((cfg.speech_token_size + 3,), 0.1)
-    sd["speech_embedding.weight"] = g.normal((cfg.speech_token_size + 3, H), 0.5)
+    V = cfg.speech_token_size + cfg.n_special
+    sd["llm_decoder.weight"] = g.linear(V, H, gain=3.0)
+    if not cfg.cv3:                                    # CosyVoice3LM: bias=False (llm/llm.py:688)
+        sd["llm_decoder.bias"] = g.normal((V,), 0.1)
+    else:
+        # 200 of the ids are special: with uniformly random rows almost every argmax would be a stop id and every fixture would end
+        # at step 0.  A trained model emits them rarely; the seeded rows of ids > eos are damped so that sequences have a body.
+        sd["llm_decoder.weight"][cfg.speech_token_size + 2:] *= 0.3
+    sd["speech_embedding.weight"] = g.normal((V, H), 0.5)
     return to_bf16_grid(sd)
 
 

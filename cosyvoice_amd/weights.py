@@ -38,12 +38,13 @@ def pack_llm(sd, cfg, device):
         out[q + "wdown"] = _bf16(sd[p + "mlp.down_proj.weight"], device)
     out["norm"] = _f32(sd["llm.model.model.norm.weight"], device)
     out["head.w"] = _bf16(sd["llm_decoder.weight"], device)
-    out["head.b"] = _f32(sd["llm_decoder.bias"], device)
+    # CosyVoice3LM has no head bias (llm/llm.py:688): the fused head GEMV takes a zero vector
+    bias = sd["llm_decoder.bias"] if "llm_decoder.bias" in sd else torch.zeros(sd["llm_decoder.weight"].shape[0])
+    out["head.b"] = _f32(bias, device)
     out["embed.speech"] = _bf16(sd["speech_embedding.weight"], device)
-    host_only = {
-        "embed.text": _bf16(sd["llm.model.model.embed_tokens.weight"], device),      # gathered by cv_gather_rows
-        "embed.llm": _bf16(sd["llm_embedding.weight"], device),
-    }
+    host_only = {"embed.text": _bf16(sd["llm.model.model.embed_tokens.weight"], device)}      # gathered by cv_gather_rows
+    if "llm_embedding.weight" in sd:                    # Qwen2LM: sos / task_id rows; CosyVoice3LM keeps them in speech_embedding
+        host_only["embed.llm"] = _bf16(sd["llm_embedding.weight"], device)
     return out, host_only
 
 

@@ -87,8 +87,12 @@ def build_lm_input(sd, cfg, text, prompt_text, prompt_speech_token):
     """[sos | embed_tokens(prompt_text ++ text) | task_id | speech_embedding(prompt)]   (llm/llm.py:472-494)."""
     text = torch.cat([prompt_text, text], dim=1).long()
     text_emb = sd["llm.model.model.embed_tokens.weight"][text[0]]
-    sos = sd["llm_embedding.weight"][0:1]
-    task = sd["llm_embedding.weight"][1:2]
+    if cfg.cv3:                                              # CosyVoice3LM: rows sts+0 / sts+2 of speech_embedding (llm/llm.py:483-485, 677-681)
+        sos = sd["speech_embedding.weight"][cfg.speech_token_size:cfg.speech_token_size + 1]
+        task = sd["speech_embedding.weight"][cfg.speech_token_size + 2:cfg.speech_token_size + 3]
+    else:
+        sos = sd["llm_embedding.weight"][0:1]
+        task = sd["llm_embedding.weight"][1:2]
     sp = sd["speech_embedding.weight"][prompt_speech_token[0].long()] if prompt_speech_token.shape[1] else torch.zeros(0, cfg.hidden)
     return torch.cat([sos, text_emb, task, sp], dim=0)
 
@@ -106,13 +110,15 @@ def inference(sd, cfg, text, prompt_text, prompt_speech_token, sampling_fn=greed
     text_len = text.shape[1]
     min_len = int(text_len * min_token_text_ratio)           # (text_len + prompt_len - prompt_len) * ratio  (:497-498)
     max_len = int(text_len * max_token_text_ratio)
-    stop = [cfg.speech_token_size + i for i in range(3)]
+    stop = [cfg.speech_token_size + i for i in range(cfg.n_special)]      # 3 for Qwen2LM (:297), 200 for CosyVoice3LM (:703)
+    if cfg.cv3:
+        assert bool((torch.cat([prompt_text, text], dim=1) == cfg.endofprompt_id).any()), "<|endofprompt|> not detected"       # :478-480
     model = Qwen2Oracle(sd, cfg)
     out = []
     x = lm_input
     for i in range(max_len):
         y = model.forward(x)
-        logp = F.linear(y[-1], sd["llm_decoder.weight"], sd["llm_decoder.bias"]).log_softmax(dim=-1)
+        logp = F.linear(y[-1], sd["llm_decoder.weight"], sd.get("llm_decoder.bias")).log_softmax(dim=-1)
         if trace is not None:
             trace.setdefault("logp", []).append(logp.clone())
         if i < min_len:                                      # sampling_ids ignore_eos (:150-160)

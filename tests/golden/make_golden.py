@@ -192,6 +192,50 @@ def golden_hift():
          speech_c=speech_c, source_c=source_c)
 
 
+def golden_llm_cv3():
+    """CosyVoice3LM (llm/llm.py:664-706): sos / task_id rows of speech_embedding, bias-free head over speech_token_size + 200 ids,
+    200 stop ids, <|endofprompt|> required.  Same random-init Qwen2 backbone wrapper as golden_llm()."""
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+    import cosyvoice.llm.llm as L
+
+    cfg = W.tiny_cv3_llm()
+
+    class Enc(L.Qwen2Encoder):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            hc = Qwen2Config(vocab_size=cfg.text_vocab, hidden_size=cfg.hidden, intermediate_size=cfg.inter,
+                             num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads, num_key_value_heads=cfg.kv_heads,
+                             max_position_embeddings=4096, rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
+                             tie_word_embeddings=True, attention_dropout=0.0)
+            self.model = Qwen2ForCausalLM(hc)
+
+        def forward_one_step(self, xs, masks, cache=None):       # see golden_llm(): intended mask semantics
+            outs = self.model(inputs_embeds=xs, attention_mask=None if xs.shape[1] == 1 else masks[:, -1, :],
+                              output_hidden_states=True, return_dict=True, use_cache=True, past_key_values=cache)
+            return outs.hidden_states[-1], outs.past_key_values
+
+    sd = W.make_llm(cfg)
+    logps = []
+
+    def greedy(scores, decoded, k):
+        logps.append(scores.clone())
+        return int(scores.argmax().item())
+
+    lm = L.CosyVoice3LM(cfg.hidden, cfg.hidden, cfg.speech_token_size, Enc(), greedy)
+    lm.load_state_dict(sd, strict=True)
+    lm.eval()
+    # the reference hard-codes id 151646 (:479): the tiny text vocabulary is extended to hold it, the text carries it once
+    u = W.synthetic_utterance(cfg, W.tiny()[1], n_prompt_tok=9, n_prompt_text=4, n_text=5, seed=77)
+    u["prompt_text"][0, -1] = 151646
+    kw = dict(text=u["text"], text_len=torch.tensor([u["text"].shape[1]], dtype=torch.int32),
+              prompt_text=u["prompt_text"], prompt_text_len=torch.tensor([u["prompt_text"].shape[1]], dtype=torch.int32),
+              prompt_speech_token=u["llm_prompt_speech_token"], prompt_speech_token_len=torch.tensor([9], dtype=torch.int32),
+              embedding=u["llm_embedding"])
+    toks = list(lm.inference(**kw, max_token_text_ratio=5, min_token_text_ratio=3))
+    save("llm_cv3_tiny", text=u["text"], prompt_text=u["prompt_text"], prompt_speech_token=u["llm_prompt_speech_token"],
+         tokens=np.array(toks), logp=torch.stack(logps[:8]))
+
+
 def golden_glue():
     """fade_in_out + masks (cosyvoice/utils/common.py:170-178, utils/mask.py)."""
     from cosyvoice.utils.common import fade_in_out

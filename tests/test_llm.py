@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from cosyvoice_amd.llm import Qwen2LM
+from cosyvoice_amd.llm import CosyVoice3LM, Qwen2LM
 from oracle import llm as OL
 from oracle import sampling as OS
 from oracle import weights as W
@@ -146,3 +146,33 @@ def test_profile_chain_leaves_handle_usable(lib, tiny_sd):
         lib.cv_llm_profile_chain(lm._h, cat, 2, C.byref(ms), C.byref(n), stream_ptr(lib))
         assert n.value == (1 if cat == 5 else cfg.layers) * 2 and ms.value >= 0.0
     assert list(lm.inference(**_kw(u), max_token_text_ratio=4, min_token_text_ratio=2)) == want
+
+
+def test_cosyvoice3_lm(lib):
+    """SURVEY.md §8 row a17 (LM part): CosyVoice3LM on the same device kernels - special embeddings from speech_embedding rows, bias-free
+    260-way head, 200 stop ids, index speech_token_size masked while below min_len.  Greedy ids bit-exact vs the oracle (which is pinned
+    to the real reference class by tests/test_oracle_golden.py), on the golden utterance and on seeds that stop on a special id."""
+    import os
+    cfg = W.tiny_cv3_llm()
+    sd = W.make_llm(cfg)
+    lm = CosyVoice3LM(sd, cfg, lib=lib, max_len=160, sampling="greedy", decode_chunk=6)
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "llm_cv3_tiny.npz")).items()}
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    kw = dict(text=g["text"], text_len=t(5), prompt_text=g["prompt_text"], prompt_text_len=t(4), prompt_speech_token=g["prompt_speech_token"],
+              prompt_speech_token_len=t(9))
+    got = list(lm.inference(**kw, max_token_text_ratio=5, min_token_text_ratio=3))
+    assert got == g["tokens"].tolist()                                  # == the real reference's tokens
+    lm_input = lm.build_lm_input(g["text"], g["prompt_text"], g["prompt_speech_token"])
+    torch.testing.assert_close(lm_input.cpu(), OL.build_lm_input(sd, cfg, g["text"], g["prompt_text"], g["prompt_speech_token"]), rtol=0, atol=0)
+    stopped = 0
+    for seed in range(3):                                               # other utterances: some end on one of the 200 stop ids before max_len
+        u = W.synthetic_utterance(cfg, W.tiny()[1], n_prompt_tok=7, n_prompt_text=3, n_text=4, seed=100 + seed)
+        u["text"][0, 0] = cfg.endofprompt_id
+        want = OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=8, min_token_text_ratio=1)
+        got = list(lm.inference(**_kw(u), max_token_text_ratio=8, min_token_text_ratio=1))
+        assert got == want and all(tok < cfg.speech_token_size for tok in got)
+        stopped += len(want) < 32
+    assert stopped >= 1
+    with pytest.raises(AssertionError):
+        list(lm.inference(text=torch.zeros(1, 4, dtype=torch.int32), text_len=t(4), prompt_text=torch.zeros(1, 2, dtype=torch.int32), prompt_text_len=t(2),
+                          prompt_speech_token=g["prompt_speech_token"], prompt_speech_token_len=t(9)))

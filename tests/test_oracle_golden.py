@@ -36,6 +36,24 @@ def test_llm_matches_reference_tokens_and_logp():
     torch.testing.assert_close(lp, ref, rtol=1e-4, atol=1e-4)
 
 
+def test_llm_cv3_matches_reference_tokens_and_logp():
+    """CosyVoice3LM (LM part): the REAL reference class loaded the seeded state dict with strict=True
+    (key names / shapes of the cv3 factory) and produced these tokens / log-probs (tests/golden/make_golden.py::golden_llm_cv3)."""
+    g = load("llm_cv3_tiny")
+    cfg = W.tiny_cv3_llm()
+    sd = W.make_llm(cfg)
+    assert "llm_embedding.weight" not in sd and "llm_decoder.bias" not in sd and sd["llm_decoder.weight"].shape[0] == cfg.speech_token_size + 200
+    trace = {}
+    toks = OL.inference(sd, cfg, g["text"], g["prompt_text"], g["prompt_speech_token"], max_token_text_ratio=5, min_token_text_ratio=3, trace=trace)
+    assert toks == g["tokens"].tolist() and len(toks) > 10
+    lp = torch.stack(trace["logp"][:8])
+    ref = g["logp"].clone()
+    ref[:, cfg.speech_token_size] = lp[:, cfg.speech_token_size]      # reference logged after the in-place mask of index speech_token_size
+    torch.testing.assert_close(lp, ref, rtol=1e-4, atol=1e-4)
+    with pytest.raises(AssertionError):                               # <|endofprompt|> is mandatory (llm/llm.py:478-480)
+        OL.inference(sd, cfg, g["text"], torch.zeros(1, 3, dtype=torch.int32), g["prompt_speech_token"])
+
+
 def test_stepwise_equals_full_sequence():
     """the oracle must assert stepwise == full-sequence forward itself."""
     cfg = W.tiny()[0]
