@@ -119,3 +119,29 @@ def test_two_concurrent_streaming_requests(lib, setup):
     for a, b in zip(got, alone):
         assert torch.equal(a, b)
     assert not m.tts_speech_token_dict and not m.hift_cache_dict
+
+
+def test_llm_job_silent_token_filter(lib, setup):
+    """cli/model.py:101-129: tokens listed in `silent_tokens` (CosyVoice3: FSQ silence / breath ids, :423) are kept for the first
+    5 consecutive occurrences and dropped beyond that; any other token resets the run.  Host logic, driven with a stub generator."""
+    import threading
+    cfgs, sds, u = setup
+    m = _build(lib, cfgs, sds)
+    m.silent_tokens = [1, 2, 28]
+    seq = [5, 1, 2, 1, 2, 1, 2, 28, 1, 7, 1, 1, 1, 1, 1, 1, 1, 9]
+    m.llm.inference = lambda **kw: iter(seq)
+    uuid = "filter-test"
+    m._cond[uuid] = threading.Condition()
+    m.tts_speech_token_dict[uuid], m.llm_end_dict[uuid] = [], False
+    m.llm_job(u["text"], u["prompt_text"], u["llm_prompt_speech_token"], u["llm_embedding"], uuid)
+    want, run = [], 0
+    for tok in seq:                                  # restatement of the reference loop
+        if tok in m.silent_tokens:
+            run += 1
+            if run > 5:
+                continue
+        else:
+            run = 0
+        want.append(tok)
+    assert m.tts_speech_token_dict[uuid] == want == [5, 1, 2, 1, 2, 1, 7, 1, 1, 1, 1, 1, 9]
+    assert m.llm_end_dict[uuid] is True
