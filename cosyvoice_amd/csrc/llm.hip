@@ -107,10 +107,14 @@ static hipStream_t resolve(cv_llm* m, void* s) {
 
 static LinearW lw(const bf16_t* w, const float* b, int N, int K) { LinearW l; l.w = w; l.b = b; l.N = N; l.K = K; l.Kp = round_up32(K); l.bf16 = true; return l; }
 
-static void llm_prefill(cv_llm* m, const float* x_in, int L0, hipStream_t s) {
+// append = false: a new request, the rows become positions 0 .. L0-1.  append = true (inference_bistream, llm/llm.py:551-661): the rows
+// are forwarded on top of the positions already cached, exactly like `forward_one_step(lm_input, cache=cache)` with a multi-row lm_input;
+// the running request (tokens emitted so far, step counter) continues and a `done` left by a fill token is cleared.
+static void llm_prefill(cv_llm* m, const float* x_in, int L0, hipStream_t s, bool append = false) {
     const auto& c = m->cfg;
     CV_CHECK(m->finalized, "llm: call cv_llm_finalize first");
-    CV_CHECK(L0 > 0 && L0 < c.max_len, "llm_prefill: prompt length out of range");
+    const int pos0 = append ? m->host_state->pos : 0;
+    CV_CHECK(L0 > 0 && pos0 + L0 < c.max_len, "llm_prefill: prompt length out of range (KV capacity max_len)");
     const int H = c.hidden, Q = m->qkv_dim, A = c.heads * 64;
     if (L0 > m->pf_rows) {
         m->pf_x.ensure((size_t)L0 * H * 4); m->pf_xn.ensure((size_t)L0 * H * 4); m->pf_qkv.ensure((size_t)L0 * Q * 4);
@@ -126,14 +130,14 @@ static void llm_prefill(cv_llm* m, const float* x_in, int L0, hipStream_t s) {
         float* vc = m->vcache.as<float>() + m->layer_cache() * i;
         norm_rows(NormArgs{x, xn, L0, H, L.ln1, nullptr, c.rms_eps, 1, ACT_NONE, 1.f, nullptr, nullptr, L0}, s);
         linear(xn, L0, lw(L.wqkv, L.bqkv, Q, H), qkv, ACT_NONE, nullptr, s);
-        hipLaunchKernelGGL(rope_store_kernel, dim3(L0), dim3(256), 0, s, qkv, L0, c.heads, c.kv_heads, 0,
+        hipLaunchKernelGGL(rope_store_kernel, dim3(L0), dim3(256), 0, s, qkv, L0, c.heads, c.kv_heads, pos0,
                            m->rope_cos.as<float>(), m->rope_sin.as<float>(), kc, vc, c.max_len);
         AttnArgs a{};
         a.q = qkv; a.q_batch = 0; a.q_row = Q; a.q_head = 64;
         a.k = kc; a.k_batch = 0; a.k_row = 64; a.k_head = c.max_len * 64;
         a.v = vc; a.v_batch = 0; a.v_row = 64; a.v_head = c.max_len * 64;
         a.o = at; a.o_batch = 0; a.o_row = A; a.o_head = 64;
-        a.B = 1; a.H = c.heads; a.kv_group = c.heads / c.kv_heads; a.Tq = L0; a.Tk = L0;
+        a.B = 1; a.H = c.heads; a.kv_group = c.heads / c.kv_heads; a.Tq = L0; a.Tk = pos0 + L0;      // causal with offset Tk - Tq
         a.scale = 0.125f; a.mask_mode = MASK_CAUSAL; a.chunk = 0; a.rel_bd = nullptr;
         attention(a, s);
         linear(at, L0, lw(L.wo, nullptr, H, A), x, ACT_NONE, x, s);
@@ -144,7 +148,8 @@ static void llm_prefill(cv_llm* m, const float* x_in, int L0, hipStream_t s) {
         linear(act, L0, lw(L.wdown, nullptr, H, c.inter), x, ACT_NONE, x, s);
     }
     CV_HIP(hipMemcpyAsync(m->h.p, x + (size_t)(L0 - 1) * H, (size_t)H * 4, hipMemcpyDeviceToDevice, s));
-    DecodeState st{}; st.pos = L0; st.step = 0; st.done = 0; st.n_tokens = 0; st.last_token = 0;
+    DecodeState st{}; st.pos = pos0 + L0; st.step = 0; st.done = 0; st.n_tokens = 0; st.last_token = 0; st.stop_token = -1;
+    if (append) { st.step = m->host_state->step; st.n_tokens = m->host_state->n_tokens; st.last_token = m->host_state->last_token; }
     *m->host_state = st;
     CV_HIP(hipMemcpyAsync(m->state.p, m->host_state, sizeof(DecodeState), hipMemcpyHostToDevice, s));
     CV_HIP(hipStreamSynchronize(s));     // host_state is reused by the next call
@@ -291,6 +296,23 @@ int cv_llm_set_option(cv_llm* m, const char* name, int32_t value) {
 int cv_llm_prefill(cv_llm* m, const float* lm_input, int32_t L0, void* stream) {
     return guarded([&] { CV_CHECK(m && lm_input, "null argument"); llm_prefill(m, lm_input, L0, resolve(m, stream)); });
 }
+int cv_llm_prefill_append(cv_llm* m, const float* rows, int32_t n_rows, void* stream) {
+    return guarded([&] { CV_CHECK(m && rows, "null argument"); llm_prefill(m, rows, n_rows, resolve(m, stream), true); });
+}
+int cv_llm_push_token(cv_llm* m, int32_t token, void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && m->finalized, "null argument");
+        hipStream_t s = resolve(m, stream);
+        const int n = m->host_state->n_tokens;
+        CV_CHECK(n < m->cfg.max_len, "cv_llm_push_token: token history full");
+        m->host_tokens[n] = token;
+        CV_HIP(hipMemcpyAsync(m->tokens.as<int>() + n, m->host_tokens + n, sizeof(int), hipMemcpyHostToDevice, s));
+        m->host_state->n_tokens = n + 1;
+        CV_HIP(hipMemcpyAsync(m->state.p, m->host_state, sizeof(DecodeState), hipMemcpyHostToDevice, s));
+        CV_HIP(hipStreamSynchronize(s));
+    });
+}
+int cv_llm_last_stop_token(cv_llm* m) { return m ? m->host_state->stop_token : -1; }
 int cv_llm_set_uniforms(cv_llm* m, const float* host_uniforms, int32_t n, void* stream) {
     return guarded([&] {
         CV_CHECK(m && host_uniforms && n > 0 && n <= m->cfg.max_len * 2, "cv_llm_set_uniforms: bad arguments");

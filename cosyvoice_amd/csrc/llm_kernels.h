@@ -14,7 +14,9 @@ struct DecodeState {       // lives in device memory (one per cv_llm handle)
     int done;              // set when a stop token was sampled or max_len reached
     int n_tokens;          // tokens emitted so far
     int last_token;        // last emitted token (input of the next backbone step)
-    int pad[3];
+    int stop_token;        // the id that set `done` (eos / fill / any other special id), -1 while running; inference_bistream needs to
+                           // tell a fill token (more text is due) from eos
+    int pad[2];
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -457,7 +459,7 @@ static __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs a) {
         }
     }
     if (tid == 0) {
-        if (tok >= p.eos && tok < p.eos + p.n_stop) st->done = 1;
+        if (tok >= p.eos && tok < p.eos + p.n_stop) { st->done = 1; st->stop_token = tok; }
         else {
             if (st->n_tokens < p.max_tokens) p.tokens[st->n_tokens] = tok;
             st->n_tokens += 1; st->last_token = tok; st->step = step + 1;

@@ -165,6 +165,137 @@ class Qwen2LM:
                     break
 
 
+    # ------------------------------------------------------------------------------------------------ bi-directional streaming
+    def _rows(self, table, ids):
+        """Embedding rows [n, hidden] fp32 on the device (cv_gather_rows), n may be 0."""
+        ids = self.lib.hook(torch.as_tensor(ids, dtype=torch.int32).reshape(-1).to(self.device).contiguous())
+        out = self.lib.hook(torch.empty(ids.numel(), self.cfg.hidden, dtype=torch.float32, device=self.device))
+        if ids.numel():
+            self.lib.cv_gather_rows(C.c_void_p(table.data_ptr()), C.c_int32(CV_BF16), C.c_int64(table.shape[0]), C.c_int32(self.cfg.hidden),
+                                    C.c_void_p(ids.data_ptr()), C.c_int32(ids.numel()), C.c_void_p(out.data_ptr()), C.c_float(1.0), stream_ptr(self.lib))
+        return out
+
+    def _forward_rows(self, rows, first):
+        """forward_one_step(lm_input, cache) of the reference for a multi-row lm_input: a fresh prefill or an append."""
+        rows = self.lib.hook(rows.contiguous())
+        if self._bistream_pos + rows.shape[0] + 2 >= self.max_len:
+            raise ValueError("inference_bistream: KV capacity %d exhausted" % self.max_len)
+        if first:
+            self.lib.cv_llm_prefill(self._h, C.c_void_p(rows.data_ptr()), C.c_int32(rows.shape[0]), stream_ptr(self.lib))
+        else:
+            self.lib.cv_llm_prefill_append(self._h, C.c_void_p(rows.data_ptr()), C.c_int32(rows.shape[0]), stream_ptr(self.lib))
+        self._bistream_pos += rows.shape[0]
+
+    @torch.inference_mode()
+    def inference_bistream(self, text, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len, embedding=None,
+                           sampling=25, max_token_text_ratio=20, min_token_text_ratio=2, mix_ratio=(5, 15)):
+        """cosyvoice/llm/llm.py:551-661: `text` is a generator of [1, n] id tensors arriving while speech is already being produced.
+        Text and speech interleave 5 : 15 (mix_ratio); a fill token (forced every 15 speech tokens, or sampled) means "feed the next 5
+        text ids"; when the text ends, the rest of the text + task_id is appended and decoding runs to eos.
+
+        Mapping onto the device loop: the reference iteration is [forward(lm_input) -> head -> sample]; a device step is
+        [head -> sample -> forward(embedding of the sample)], i.e. the same pipeline shifted by half an iteration - a sampled
+        special id never runs the backbone (`done`), exactly as the reference never forwards it.  Multi-row inputs (text / prompt
+        mixes) go through cv_llm_prefill_append.  `lm_input` of the reference stays visible after it was forwarded and is
+        forwarded AGAIN in front of the final text (:642) - that is reproduced through `stale`."""
+        sts, H = self.cfg.speech_token_size, self.cfg.hidden
+        fill, eos = self.fill_token, self.eos_token
+        BIG = 1 << 30
+        with self.lock:
+            special = self._special_table()
+            sos_row, task_row = self._rows(special, [self.sos]), self._rows(special, [self.task_id])
+            prompt_sp = self._rows(self._tensors["embed.speech"], prompt_speech_token.reshape(-1))
+            prompt_ids = prompt_text.reshape(-1)
+            lm_input = sos_row                                  # the reference's `lm_input`
+            forwarded = False                                   # ... and whether it has been forwarded already (then it is "stale")
+            if self.cfg.cv3:                                    # :583-588
+                pl = prompt_ids.tolist()
+                assert self.cfg.endofprompt_id in pl, "<|endofprompt|> not detected in CosyVoice3 prompt_text, check your input!"
+                k = pl.index(self.cfg.endofprompt_id)
+                lm_input = torch.cat([lm_input, self._rows(self._host["embed.text"], prompt_ids[: k + 1])], 0)
+                prompt_ids = prompt_ids[k + 1:]
+            text_cache = self._rows(self._host["embed.text"], prompt_ids)
+            n_prompt = int(prompt_speech_token.shape[1])
+            next_fill_index = (int(n_prompt / mix_ratio[1]) + 1) * mix_ratio[1] - n_prompt
+            out_tokens = []
+            self._bistream_pos, started = 0, False
+
+            def forward_pending():
+                nonlocal forwarded, started
+                if not forwarded:
+                    self._forward_rows(lm_input, first=not started)
+                    started, forwarded = True, True
+
+            def run_steps(n, ignore_eos):
+                """up to n device steps; returns (real tokens, stop id or None)"""
+                sp = SamplingC(1 if self.sampling == "ras" else 0, sts, self.cfg.n_special, BIG if ignore_eos else 0, BIG, self.top_p, self.top_k,
+                               self.win_size, self.tau_r, self.seed + self._request, 0)
+                toks, fin = self.decode(n, sp)
+                self._bistream_pos += len(toks)
+                stop = self.lib.raw("cv_llm_last_stop_token", C.c_int)(self._h) if fin else None
+                return toks, (stop if fin and stop is not None and stop >= 0 else None)
+
+            self._request += 1
+            for this_text in text:
+                text_cache = torch.cat([text_cache, self._rows(self._host["embed.text"], this_text.reshape(-1))], 0)
+                while prompt_sp.shape[0] != 0:                                                  # :591-600
+                    if text_cache.shape[0] >= mix_ratio[0]:
+                        lm_input = torch.cat([lm_input, text_cache[: mix_ratio[0]], prompt_sp[: mix_ratio[1]]], 0)
+                        assert not forwarded
+                        text_cache, prompt_sp = text_cache[mix_ratio[0]:], prompt_sp[mix_ratio[1]:]
+                    else:
+                        break
+                if prompt_sp.shape[0] != 0:
+                    continue
+                if (out_tokens and out_tokens[-1] == fill) or (not out_tokens and lm_input.shape[0] == 1):   # :602-614
+                    if text_cache.shape[0] >= mix_ratio[0]:
+                        chunk = text_cache[: mix_ratio[0]]
+                        if out_tokens and out_tokens[-1] == fill:
+                            lm_input, forwarded = chunk, False
+                        else:
+                            lm_input = torch.cat([lm_input, chunk], 0)
+                            assert not forwarded
+                        text_cache = text_cache[mix_ratio[0]:]
+                    else:
+                        continue
+                forward_pending()
+                while True:                                                                      # :615-636
+                    if next_fill_index != -1 and len(out_tokens) == next_fill_index:
+                        top = fill
+                        next_fill_index += mix_ratio[1] + 1
+                    else:
+                        budget = (next_fill_index - len(out_tokens)) if next_fill_index > len(out_tokens) else self.decode_chunk
+                        toks, stop = run_steps(max(1, min(budget, self.decode_chunk)), ignore_eos=True)
+                        for t in toks:
+                            out_tokens.append(int(t))
+                            yield int(t)
+                        if toks:                                 # the device forwarded the last real token: that is the reference's lm_input now
+                            lm_input, forwarded = self._rows(self._tensors["embed.speech"], [toks[-1]]), True
+                        if stop is None:
+                            continue
+                        top = stop
+                    if top == fill:
+                        next_fill_index = len(out_tokens) + mix_ratio[1] + 1
+                    out_tokens.append(top)
+                    self.lib.cv_llm_push_token(self._h, C.c_int32(top), stream_ptr(self.lib))   # out_tokens feeds the sampler's window
+                    if top == fill:
+                        break
+                    raise ValueError("should not get token {}".format(top))
+            # 3. final decode (:638-661): the (possibly already forwarded) lm_input is fed in front of the remaining text + task_id
+            lm_input, forwarded = torch.cat([lm_input, text_cache, task_row], 0), False
+            forward_pending()
+            while True:
+                toks, stop = run_steps(self.decode_chunk, ignore_eos=False)
+                for t in toks:
+                    out_tokens.append(int(t))
+                    yield int(t)
+                if stop is None:
+                    continue
+                if stop == eos:
+                    break
+                raise ValueError("should not get token {}".format(stop))
+
+
 class CosyVoice3LM(Qwen2LM):
     """cosyvoice/llm/llm.py:664-706 (inference side; SURVEY.md §8 row a17, LM part).  Same backbone and the same device kernels as
     Qwen2LM; what differs is bookkeeping: sos / eos / task_id / fill are ids speech_token_size + {0,1,2,3} whose embeddings are rows

@@ -8,6 +8,7 @@ Differences that are deliberate:
 """
 import ctypes as C
 import threading
+from types import GeneratorType
 import uuid as uuid_mod
 from contextlib import nullcontext
 
@@ -84,15 +85,21 @@ class CosyVoice2Model:
 
     # ------------------------------------------------------------------------------------------------ llm_job / vc_job
     def llm_job(self, text, prompt_text, llm_prompt_speech_token, llm_embedding, uuid):
-        """cli/model.py:101-129 (non-bistream branch)."""
+        """cli/model.py:101-129: `text` is a tensor (offline text) or a generator of [1, n] id tensors (streaming text ->
+        Qwen2LM.inference_bistream)."""
         cur_silent_token_num, max_silent_token_num = 0, 5
         cond = self._cond[uuid]
         try:
             with self.llm_context:
                 t = lambda n: torch.tensor([n], dtype=torch.int32)
-                gen = self.llm.inference(text=text, text_len=t(text.shape[1]), prompt_text=prompt_text, prompt_text_len=t(prompt_text.shape[1]),
-                                         prompt_speech_token=llm_prompt_speech_token, prompt_speech_token_len=t(llm_prompt_speech_token.shape[1]),
-                                         embedding=llm_embedding, uuid=uuid)
+                if isinstance(text, GeneratorType):
+                    gen = self.llm.inference_bistream(text=text, prompt_text=prompt_text, prompt_text_len=t(prompt_text.shape[1]),
+                                                      prompt_speech_token=llm_prompt_speech_token,
+                                                      prompt_speech_token_len=t(llm_prompt_speech_token.shape[1]), embedding=llm_embedding)
+                else:
+                    gen = self.llm.inference(text=text, text_len=t(text.shape[1]), prompt_text=prompt_text, prompt_text_len=t(prompt_text.shape[1]),
+                                             prompt_speech_token=llm_prompt_speech_token, prompt_speech_token_len=t(llm_prompt_speech_token.shape[1]),
+                                             embedding=llm_embedding, uuid=uuid)
                 for i in gen:
                     if i in self.silent_tokens:
                         cur_silent_token_num += 1

@@ -72,6 +72,20 @@ def make_llm(cfg: LLMConfig, seed=1986):
     return to_bf16_grid(sd)
 
 
+def bistream_fixture(sd, cfg: LLMConfig, eos_bias=0.0):
+    """Head of a seeded Qwen2LM state dict adjusted so that PLAIN greedy decoding can walk inference_bistream (llm/llm.py:551-661) on
+    random weights: the special id speech_token_size + 1 and the fill token never win an argmax (fills are then only the forced ones; a
+    sampled special id raises in the reference), and eos gets `eos_bias` so that the final phase ends.  Returns a new dict."""
+    assert not cfg.cv3
+    out = dict(sd)
+    b = sd["llm_decoder.bias"].clone()
+    b[cfg.speech_token_size + 1] = -60.0
+    b[cfg.speech_token_size + 2] = -60.0
+    b[cfg.speech_token_size] += eos_bias
+    out["llm_decoder.bias"] = b.bfloat16().float()
+    return out
+
+
 def _conformer_layer(g, sd, p, d, heads, ffn):
     sd[p + "self_attn.pos_bias_u"] = g.normal((heads, d // heads), 0.1)
     sd[p + "self_attn.pos_bias_v"] = g.normal((heads, d // heads), 0.1)

@@ -115,6 +115,15 @@ void cv_llm_destroy(cv_llm* m);
 int cv_llm_set_option(cv_llm* m, const char* name, int32_t value);            /* "use_graph" */
 /* lm_input: dev fp32 [L0, hidden] = [sos | text emb | task_id | prompt speech emb] (llm.py:494). Resets the KV cache. */
 int cv_llm_prefill(cv_llm* m, const float* lm_input, int32_t L0, void* stream);
+/* Qwen2LM.inference_bistream (llm/llm.py:551-661): forward `n_rows` more input rows on top of the cached positions - the reference's
+ * `forward_one_step(lm_input, cache=cache)` with a multi-row lm_input - keeping the running request (emitted tokens, step counter) and
+ * clearing a `done` left by a fill token; the next decode samples from the hidden state of the last appended row. */
+int cv_llm_prefill_append(cv_llm* m, const float* rows, int32_t n_rows, void* stream);
+/* appends a token the HOST decided on (a forced or sampled fill token) to the decoded-token history the repetition-aware sampler looks
+ * at (`out_tokens` of the reference loop), without running the backbone */
+int cv_llm_push_token(cv_llm* m, int32_t token, void* stream);
+/* the special id that ended the last cv_llm_decode (eos, fill, ...), -1 if it did not end on one */
+int cv_llm_last_stop_token(cv_llm* m);
 int cv_llm_set_uniforms(cv_llm* m, const float* host_uniforms, int32_t n, void* stream);
 /* Runs up to n_steps iterations of the decode loop on the device, then synchronises and returns the tokens emitted by
  * this call (host ints, like the reference's `yield top_ids`).  *finished != 0 when a stop id was sampled or max_len hit. */

@@ -129,3 +129,84 @@ def inference(sd, cfg, text, prompt_text, prompt_speech_token, sampling_fn=greed
         out.append(top)
         x = sd["speech_embedding.weight"][top].reshape(1, -1)
     return out
+
+
+def inference_bistream(sd, cfg, text_chunks, prompt_text, prompt_speech_token, sampling_fn=greedy_sampling, sampling=25, mix_ratio=(5, 15)):
+    """Qwen2LM / CosyVoice3LM .inference_bistream (llm/llm.py:551-661) statement by statement: `text_chunks` is an iterable of [1, n]
+    id tensors (the generator of the reference).  Returns the yielded tokens.  Kept quirks: `lm_input` stays visible after it was
+    forwarded and is forwarded again in front of the final text (:642); ignore_eos masks index `speech_token_size` (:150-160)."""
+    sts = cfg.speech_token_size
+    if cfg.cv3:
+        sos_id, eos, task_id, fill = sts + 0, sts + 1, sts + 2, sts + 3
+        sos, task = sd["speech_embedding.weight"][sos_id:sos_id + 1], sd["speech_embedding.weight"][task_id:task_id + 1]
+    else:
+        eos, fill = sts, sts + 2
+        sos, task = sd["llm_embedding.weight"][0:1], sd["llm_embedding.weight"][1:2]
+    emb_t = sd["llm.model.model.embed_tokens.weight"]
+    emb_s = sd["speech_embedding.weight"]
+    prompt_sp = emb_s[prompt_speech_token[0].long()] if prompt_speech_token.shape[1] else torch.zeros(0, cfg.hidden)
+    lm_input = sos
+    out_tokens, yielded = [], []
+    model = Qwen2Oracle(sd, cfg)
+    prompt_ids = prompt_text[0].long()
+    if cfg.cv3:                                                                              # :583-588
+        pl = prompt_ids.tolist()
+        assert cfg.endofprompt_id in pl, "<|endofprompt|> not detected in CosyVoice3 prompt_text"
+        k = pl.index(cfg.endofprompt_id)
+        lm_input = torch.cat([lm_input, emb_t[prompt_ids[: k + 1]]], 0)
+        prompt_ids = prompt_ids[k + 1:]
+    text_cache = emb_t[prompt_ids]
+    n_prompt = prompt_speech_token.shape[1]
+    next_fill_index = (int(n_prompt / mix_ratio[1]) + 1) * mix_ratio[1] - n_prompt
+
+    def head(y):
+        return F.linear(y[-1], sd["llm_decoder.weight"], sd.get("llm_decoder.bias")).log_softmax(dim=-1)
+
+    for this_text in text_chunks:
+        text_cache = torch.cat([text_cache, emb_t[this_text[0].long()]], 0)
+        while prompt_sp.shape[0] != 0:
+            if text_cache.shape[0] >= mix_ratio[0]:
+                lm_input = torch.cat([lm_input, text_cache[: mix_ratio[0]], prompt_sp[: mix_ratio[1]]], 0)
+                text_cache, prompt_sp = text_cache[mix_ratio[0]:], prompt_sp[mix_ratio[1]:]
+            else:
+                break
+        if prompt_sp.shape[0] == 0:
+            if (len(out_tokens) != 0 and out_tokens[-1] == fill) or (len(out_tokens) == 0 and lm_input.shape[0] == 1):
+                if text_cache.shape[0] >= mix_ratio[0]:
+                    lm_input_text = text_cache[: mix_ratio[0]]
+                    if len(out_tokens) != 0 and out_tokens[-1] == fill:
+                        lm_input = lm_input_text
+                    else:
+                        lm_input = torch.cat([lm_input, lm_input_text], 0)
+                    text_cache = text_cache[mix_ratio[0]:]
+                else:
+                    continue
+            while True:
+                logp = head(model.forward(lm_input))
+                if next_fill_index != -1 and len(out_tokens) == next_fill_index:
+                    top = fill
+                    next_fill_index += mix_ratio[1] + 1
+                else:
+                    logp[sts] = -float("inf")                                                # sampling_ids(ignore_eos=True)
+                    top = sampling_fn(logp, out_tokens, sampling)
+                if top == fill:
+                    next_fill_index = len(out_tokens) + mix_ratio[1] + 1
+                out_tokens.append(top)
+                if top >= sts:
+                    if top == fill:
+                        break
+                    raise ValueError("should not get token {}".format(top))
+                yielded.append(top)
+                lm_input = emb_s[top].reshape(1, -1)
+    lm_input = torch.cat([lm_input, text_cache, task], 0)                                    # :642 (lm_input may already have been forwarded)
+    while True:
+        logp = head(model.forward(lm_input))
+        top = sampling_fn(logp, out_tokens, sampling)                                        # ignore_eos=False
+        out_tokens.append(top)
+        if top >= sts:
+            if top == eos:
+                break
+            raise ValueError("should not get token {}".format(top))
+        yielded.append(top)
+        lm_input = emb_s[top].reshape(1, -1)
+    return yielded

@@ -236,6 +236,69 @@ def golden_llm_cv3():
          tokens=np.array(toks), logp=torch.stack(logps[:8]))
 
 
+def golden_llm_bistream():
+    """Qwen2LM.inference_bistream (llm/llm.py:551-661) on the real reference class: text arrives in uneven chunks, prompt of 20 speech
+    tokens (one 5:15 mix + a remainder), forced fill tokens, final decode to eos.  Greedy sampler restricted so that the random
+    fixture model terminates: special ids other than eos / fill are never the argmax (a trained model does not emit them)."""
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+    import cosyvoice.llm.llm as L
+
+    cfg = W.tiny()[0]
+
+    class Enc(L.Qwen2Encoder):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            hc = Qwen2Config(vocab_size=cfg.text_vocab, hidden_size=cfg.hidden, intermediate_size=cfg.inter,
+                             num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads, num_key_value_heads=cfg.kv_heads,
+                             max_position_embeddings=4096, rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta,
+                             tie_word_embeddings=True, attention_dropout=0.0)
+            self.model = Qwen2ForCausalLM(hc)
+
+        def forward_one_step(self, xs, masks, cache=None):       # see golden_llm(): intended mask semantics (plain causal over the cache)
+            real = cache.real if cache is not None else None
+            outs = self.model(inputs_embeds=xs, attention_mask=None, output_hidden_states=True, return_dict=True, use_cache=True, past_key_values=real)
+            return outs.hidden_states[-1], LegacyView(outs.past_key_values)
+
+    class LegacyView:
+        """inference_bistream reads `cache[0][0].size(2)` (the tuple cache of transformers 4.51) only to size a mask this wrapper's
+        forward ignores; transformers 5.x returns a DynamicCache, so expose just that one shape."""
+        def __init__(self, real):
+            self.real = real
+
+        def __getitem__(self, i):
+            return (torch.empty(1, 1, self.real.get_seq_length(), 1),)
+
+    sts = cfg.speech_token_size
+
+    def greedy(scores, decoded, k):                              # the plain greedy sampler (what the device implements)
+        return int(scores.argmax().item())
+
+    g = torch.Generator().manual_seed(5)
+    chunks = [torch.randint(0, cfg.text_vocab, (1, n), generator=g, dtype=torch.int32) for n in (3, 4, 6, 2, 7)]
+    prompt_text = torch.randint(0, cfg.text_vocab, (1, 4), generator=g, dtype=torch.int32)
+    prompt_sp = torch.randint(0, sts, (1, 20), generator=g, dtype=torch.int32)
+    base = W.make_llm(cfg)
+    for eos_bias in (1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 8.0):       # smallest eos bias with which the random model ends its final phase
+        sd = W.bistream_fixture(base, cfg, eos_bias)
+        lm = L.Qwen2LM(cfg.hidden, cfg.hidden, sts, Enc(), greedy)
+        lm.load_state_dict(sd, strict=True)
+        lm.eval()
+        toks, ok = [], True
+        for t in lm.inference_bistream(text=iter(chunks), prompt_text=prompt_text, prompt_text_len=torch.tensor([4], dtype=torch.int32),
+                                       prompt_speech_token=prompt_sp, prompt_speech_token_len=torch.tensor([20], dtype=torch.int32),
+                                       embedding=torch.zeros(1, 192)):
+            toks.append(int(t))
+            if len(toks) > 150:
+                ok = False
+                break
+        print("eos_bias", eos_bias, "->", len(toks), "tokens", "(terminated)" if ok else "(no eos)")
+        if ok:
+            break
+    assert ok
+    save("llm_bistream_tiny", prompt_text=prompt_text, prompt_speech_token=prompt_sp, tokens=np.array(toks), eos_bias=np.array(eos_bias),
+         **{"chunk%d" % i: c for i, c in enumerate(chunks)})
+
+
 def golden_glue():
     """fade_in_out + masks (cosyvoice/utils/common.py:170-178, utils/mask.py)."""
     from cosyvoice.utils.common import fade_in_out

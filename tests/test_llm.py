@@ -176,3 +176,31 @@ def test_cosyvoice3_lm(lib):
     with pytest.raises(AssertionError):
         list(lm.inference(text=torch.zeros(1, 4, dtype=torch.int32), text_len=t(4), prompt_text=torch.zeros(1, 2, dtype=torch.int32), prompt_text_len=t(2),
                           prompt_speech_token=g["prompt_speech_token"], prompt_speech_token_len=t(9)))
+
+
+def test_inference_bistream(lib, tiny_sd):
+    """Text arriving as a generator (llm/llm.py:551-661): prompt/text 5:15 mixing, forced and sampled-free fill handling, append-mode
+    prefill on top of the cache, stop-token id read back from the device, final decode to eos.  Greedy ids bit-exact vs the oracle
+    (pinned to the real reference by tests/test_oracle_golden.py) for the golden chunking and for other chunkings / prompt sizes."""
+    import os
+    cfg, base = tiny_sd
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "llm_bistream_tiny.npz")).items()}
+    sd = W.bistream_fixture(base, cfg, float(g["eos_bias"]))
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=256, sampling="greedy", decode_chunk=7)
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    chunks = [g["chunk%d" % i] for i in range(5)]
+    got = list(lm.inference_bistream(text=iter(chunks), prompt_text=g["prompt_text"], prompt_text_len=t(4), prompt_speech_token=g["prompt_speech_token"],
+                                     prompt_speech_token_len=t(20)))
+    assert got == g["tokens"].tolist()                                   # == the real reference
+    gen = torch.Generator().manual_seed(9)
+    for sizes, n_prompt in (((5, 5, 5), 15), ((1, 1, 9, 2), 7), ((12,), 0), ((2, 2), 31)):
+        ch = [torch.randint(0, cfg.text_vocab, (1, n), generator=gen, dtype=torch.int32) for n in sizes]
+        pt = torch.randint(0, cfg.text_vocab, (1, 3), generator=gen, dtype=torch.int32)
+        ps = torch.randint(0, cfg.speech_token_size, (1, n_prompt), generator=gen, dtype=torch.int32)
+        want = OL.inference_bistream(sd, cfg, ch, pt, ps)
+        got = list(lm.inference_bistream(text=iter(ch), prompt_text=pt, prompt_text_len=t(3), prompt_speech_token=ps, prompt_speech_token_len=t(n_prompt)))
+        assert got == want, (sizes, n_prompt)
+    # the offline path still works on the same handle afterwards
+    u = _utt(cfg)
+    assert list(lm.inference(**_kw(u), max_token_text_ratio=3, min_token_text_ratio=1)) == \
+        OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=3, min_token_text_ratio=1)

@@ -145,3 +145,19 @@ def test_llm_job_silent_token_filter(lib, setup):
         want.append(tok)
     assert m.tts_speech_token_dict[uuid] == want == [5, 1, 2, 1, 2, 1, 7, 1, 1, 1, 1, 1, 9]
     assert m.llm_end_dict[uuid] is True
+
+
+def test_tts_with_streaming_text(lib, setup):
+    """tts(text=<generator>) -> llm_job -> Qwen2LM.inference_bistream (cli/model.py:101-117): the audio has exactly the length the
+    oracle's bistream token sequence implies."""
+    cfgs, sds, u = setup
+    lc, fc, hc = cfgs
+    llm_sd = W.bistream_fixture(sds[0], lc, 8.0)              # strong eos bias: a short utterance keeps the emulator run short
+    m = _build(lib, cfgs, (llm_sd, sds[1], sds[2]))
+    g = torch.Generator().manual_seed(3)
+    chunks = [torch.randint(0, lc.text_vocab, (1, n), generator=g, dtype=torch.int32) for n in (5,)]
+    want = OL.inference_bistream(llm_sd, lc, chunks, u["prompt_text"], u["llm_prompt_speech_token"])
+    out = [o["tts_speech"] for o in m.tts(text=(c for c in chunks), flow_embedding=u["flow_embedding"], llm_embedding=u["llm_embedding"],
+                                          prompt_text=u["prompt_text"], llm_prompt_speech_token=u["llm_prompt_speech_token"],
+                                          flow_prompt_speech_token=u["flow_prompt_speech_token"], prompt_speech_feat=u["prompt_speech_feat"], stream=False)]
+    assert len(want) >= 5 and len(out) == 1 and out[0].shape[1] == len(want) * 2 * 480

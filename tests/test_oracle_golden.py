@@ -54,6 +54,18 @@ def test_llm_cv3_matches_reference_tokens_and_logp():
         OL.inference(sd, cfg, g["text"], torch.zeros(1, 3, dtype=torch.int32), g["prompt_speech_token"])
 
 
+def test_llm_bistream_matches_reference_tokens():
+    """Qwen2LM.inference_bistream (llm/llm.py:551-661) run by the REAL reference on text arriving in chunks of
+    3 / 4 / 6 / 2 / 7 ids with a 20-token speech prompt (one 5:15 mix, forced fill tokens, the re-forwarded stale lm_input in front of
+    the final text): the oracle restatement yields the same 44 tokens."""
+    g = load("llm_bistream_tiny")
+    cfg = W.tiny()[0]
+    sd = W.bistream_fixture(W.make_llm(cfg), cfg, float(g["eos_bias"]))
+    chunks = [g["chunk%d" % i] for i in range(5)]
+    toks = OL.inference_bistream(sd, cfg, chunks, g["prompt_text"], g["prompt_speech_token"])
+    assert toks == g["tokens"].tolist() and len(toks) == 44
+
+
 def test_stepwise_equals_full_sequence():
     """the oracle must assert stepwise == full-sequence forward itself."""
     cfg = W.tiny()[0]
