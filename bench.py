@@ -238,6 +238,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     torch.cuda.set_device(local_rank)
+    # the product path's host work is a few tiny CPU tensor ops per utterance: keep torch's intra-op pool small so that N ranks on
+    # one node do not oversubscribe the host (cpu_baseline() sets its own thread count for the oracle run)
+    torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // max(world, 1))))
     dist = None
     if world > 1:
         import torch.distributed as dist
