@@ -67,6 +67,35 @@ def one_utterance(model, u):
     return out
 
 
+def batched_decode(model, u, nb, reps):
+    """Serving-style extra (BASELINE.json configs[2]/[3]): NB copies of the U10 request through tts_batch.  The LM step streams every
+    weight matrix once for all NB sequences; flow and HiFT still run per utterance.  Also reports the LM part alone."""
+    keys = ("text", "flow_embedding", "llm_embedding", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat")
+    reqs = [{k: u[k] for k in keys} for _ in range(nb)]
+    ratio = N_GEN / N_TEXT
+    inf_b = model.llm.inference_batch
+    model.llm.inference_batch = lambda r: inf_b(r, max_token_text_ratio=ratio, min_token_text_ratio=ratio)       # force 250 tokens each
+    try:
+        model.tts_batch(reqs)                                     # warm-up (graph capture for this batch size)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            outs = model.tts_batch(reqs)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        assert all(o["tts_speech"].shape[1] == N_GEN * 2 * 480 for o in outs)
+        lm_reqs = [dict(text=u["text"], prompt_text=u["prompt_text"], prompt_speech_token=u["llm_prompt_speech_token"]) for _ in range(nb)]
+        with model.llm_context:
+            t1 = time.perf_counter()
+            toks = model.llm.inference_batch(lm_reqs)
+            torch.cuda.synchronize()
+            lm_s = time.perf_counter() - t1
+    finally:
+        model.llm.inference_batch = inf_b
+    return {"batch": nb, "audio_s_per_s": round(nb * reps * AUDIO_S / el, 3), "ms_per_batch": round(1e3 * el / reps, 2),
+            "lm_tokens_per_s": round(sum(len(t) for t in toks) / lm_s, 1), "lm_us_per_step": round(1e6 * lm_s / max(len(toks[0]), 1), 1)}
+
+
 def concurrent_streams(model0, u, n_streams, steps):
     """Serving-style extra: the batch-1 decode is a latency chain that leaves most of the 256 CUs idle, so S independent model
     instances (own weights, KV cache, graphs and HIP streams; one host thread each - ctypes drops the GIL inside the library)
@@ -230,6 +259,8 @@ def main():
     ap.add_argument("--flow-precision", choices=("bf16", "fp32"), default="bf16",
                     help="operand precision of the flow's Linear/Conv1d products (BASELINE.json configs[1] is a bf16 configuration); "
                          "fp32 = exact-fp32 MFMA everywhere")
+    ap.add_argument("--batch", type=int, default=0, help="extra (not `value`): NB requests through CosyVoice2Model.tts_batch - lock-step batched "
+                    "LM decode (weights streamed once per step for all of them), flow + HiFT per utterance; reported as `batched_decode`")
     ap.add_argument("--streams", type=int, default=1, help="extra (not `value`): S independent model instances on this GPU, one host thread + HIP "
                     "stream each, all synthesising concurrently; reported as `concurrent_streams`")
     args = ap.parse_args()
@@ -284,6 +315,9 @@ def main():
                        "utterances_per_gpu_per_step": 1, "sampler": "greedy, length forced to 250", "flow_precision": args.flow_precision, "parallelism": "replicas x%d, no collective" % world},
             "per_gpu_audio_s_per_s": round(value / world, 3),
         }
+        if world == 1 and args.batch > 0:
+            out["batched_decode"] = batched_decode(model, u, args.batch, max(1, args.steps // 2))
+            log("batched decode done")
         if world == 1 and args.streams > 1:
             out["concurrent_streams"] = concurrent_streams(model, u, args.streams, args.steps)
             log("concurrent streams done")

@@ -10,6 +10,7 @@
 #include "ops.h"
 #include "tensor_map.h"
 #include "llm_kernels.h"
+#include "llm_batch_kernels.h"
 
 using namespace cv;
 
@@ -33,11 +34,20 @@ struct cv_llm {
     hipGraphExec_t graph = nullptr; hipStream_t graph_stream = nullptr; hipStream_t own_stream = nullptr;
     cv_sampling sp{}; bool sp_valid = false; bool use_graph = true;
     int* host_tokens = nullptr; DecodeState* host_state = nullptr;
+    // lock-step batched decode (llm_batch_kernels.h): nb slots, each with its own KV cache / state / token history
+    struct Batch {
+        int nb = 0;
+        DevBuf kcache, vcache, state, tokens, sparams, uniforms, h, qkv, act, logits, part;
+        std::vector<DecodeState> host_state; std::vector<int> host_tokens; std::vector<SampleParams> host_sp;
+        hipGraphExec_t graph = nullptr; hipStream_t graph_stream = nullptr; int graph_nb = 0;
+    } bt;
+    size_t slot_cache() const { return layer_cache() * cfg.layers; }
     // optional per-kernel HIP-event timing of one eager decode step (bench.py roofline)
     bool profiling = false; std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
     size_t layer_cache() const { return (size_t)cfg.kv_heads * cfg.max_len * 64; }
     ~cv_llm() {
         if (graph) (void)hipGraphExecDestroy(graph);
+        if (bt.graph) (void)hipGraphExecDestroy(bt.graph);
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (host_tokens) (void)hipHostFree(host_tokens);
         if (host_state) (void)hipHostFree(host_state);
@@ -264,6 +274,144 @@ static void llm_decode(cv_llm* m, int n_steps, const cv_sampling* sp, int32_t* o
     *finished = m->host_state->done || m->host_state->step >= sp->max_len;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Lock-step batched decode: nb sequences, one token each per step, every weight matrix streamed once per step.
+// A slot is filled by a normal (single-sequence) prefill whose KV prefix, last hidden state and loop state are then copied into it.
+// ---------------------------------------------------------------------------------------------------------------------------------
+static void batch_begin(cv_llm* m, int nb, hipStream_t s) {
+    CV_CHECK(m->finalized, "llm: call cv_llm_finalize first");
+    CV_CHECK(nb >= 1 && nb <= MAX_NB, "cv_llm_batch_begin: batch size must be 1..8");
+    const auto& c = m->cfg; auto& b = m->bt;
+    std::lock_guard<std::recursive_mutex> lk(runtime_lock());
+    CV_HIP(hipStreamSynchronize(s));
+    b.nb = nb;
+    b.kcache.ensure((size_t)nb * m->slot_cache() * 4); b.vcache.ensure((size_t)nb * m->slot_cache() * 4);
+    b.state.ensure((size_t)nb * sizeof(DecodeState)); b.tokens.ensure((size_t)nb * c.max_len * sizeof(int));
+    b.sparams.ensure((size_t)nb * sizeof(SampleParams)); b.uniforms.ensure((size_t)nb * 2 * c.max_len * 4);
+    b.h.ensure((size_t)nb * c.hidden * 4); b.qkv.ensure((size_t)nb * m->qkv_dim * 4); b.act.ensure((size_t)nb * c.inter * 4);
+    b.logits.ensure((size_t)nb * m->V * 4); b.part.ensure((size_t)nb * c.heads * 16 * ATTN_PART * 4);
+    b.host_state.assign(nb, DecodeState{}); b.host_tokens.assign((size_t)nb * c.max_len, 0); b.host_sp.assign(nb, SampleParams{});
+    for (auto& st : b.host_state) { st.done = 1; st.stop_token = -1; }           // empty slots are "finished"
+    CV_HIP(hipMemcpyAsync(b.state.p, b.host_state.data(), (size_t)nb * sizeof(DecodeState), hipMemcpyHostToDevice, s));
+    CV_HIP(hipStreamSynchronize(s));
+    if (b.graph && b.graph_nb != nb) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
+}
+
+static void batch_prefill(cv_llm* m, int slot, const float* lm_input, int L0, const cv_sampling* sp, hipStream_t s) {
+    auto& b = m->bt; const auto& c = m->cfg;
+    CV_CHECK(slot >= 0 && slot < b.nb, "cv_llm_batch_prefill: slot out of range (call cv_llm_batch_begin first)");
+    CV_CHECK(sp && sp->max_len > 0 && sp->eos >= 0 && sp->eos + sp->n_stop <= m->V, "cv_llm_batch_prefill: bad sampling parameters");
+    CV_CHECK(sp->mode == 0 || (sp->top_k > 0 && sp->top_k <= 64 && sp->win_size >= 0), "cv_llm_batch_prefill: bad RAS parameters");
+    CV_CHECK(!sp->use_uniforms, "cv_llm_batch_prefill: injected uniforms are a single-sequence parity hook");
+    llm_prefill(m, lm_input, L0, s);                              // the validated single-sequence path; leaves K/V in the handle's own cache
+    const size_t row = 64 * sizeof(float);
+    for (int i = 0; i < c.layers; ++i)
+        for (int g = 0; g < c.kv_heads; ++g) {
+            const size_t src = m->layer_cache() * i + (size_t)g * c.max_len * 64;
+            const size_t dst = (size_t)slot * m->slot_cache() + src;
+            CV_HIP(hipMemcpyAsync(b.kcache.as<float>() + dst, m->kcache.as<float>() + src, (size_t)L0 * row, hipMemcpyDeviceToDevice, s));
+            CV_HIP(hipMemcpyAsync(b.vcache.as<float>() + dst, m->vcache.as<float>() + src, (size_t)L0 * row, hipMemcpyDeviceToDevice, s));
+        }
+    CV_HIP(hipMemcpyAsync(b.h.as<float>() + (size_t)slot * c.hidden, m->h.p, (size_t)c.hidden * 4, hipMemcpyDeviceToDevice, s));
+    b.host_state[slot] = *m->host_state;                          // pos = L0, step = 0, done = 0
+    b.host_sp[slot] = SampleParams{sp->mode, sp->eos, sp->n_stop, sp->min_len, sp->max_len, sp->top_p, sp->top_k, sp->win_size, sp->tau_r, 0,
+                                   (unsigned long long)sp->seed};
+    CV_HIP(hipMemcpyAsync(b.state.as<DecodeState>() + slot, &b.host_state[slot], sizeof(DecodeState), hipMemcpyHostToDevice, s));
+    CV_HIP(hipMemcpyAsync(b.sparams.as<SampleParams>() + slot, &b.host_sp[slot], sizeof(SampleParams), hipMemcpyHostToDevice, s));
+    CV_HIP(hipStreamSynchronize(s));
+}
+
+static void gemv_batch(const GemvBatchArgs& a, int rows, hipStream_t s, int nsp = 0) {
+    const int steps = a.K / 128;
+    if (nsp > 0) {
+        CV_CHECK(steps <= 8 && rows == 1 && a.mode == 0 && !a.gamma && a.part && nsp == 8, "gemv_batch: partial-combine prologue is for o_proj with 8 slices");
+        hipLaunchKernelGGL((gemv_batch_kernel<2, 1, 4, 8>), dim3((a.N + 3) / 4), dim3(256), 0, s, a);
+        return;
+    }
+    CV_CHECK(a.K % 128 == 0 && steps >= 1 && steps <= 40, "gemv_batch: K must be a multiple of 128 and at most 5120");
+    const int units = a.mode == 1 ? a.N / 2 : (a.N + rows - 1) / rows;
+    const dim3 grid((units + 3) / 4);
+    if (a.mode == 1) rows = 2;
+    if (steps <= 7) {
+        if (rows == 2) hipLaunchKernelGGL((gemv_batch_kernel<7, 2, 1>), grid, dim3(64), 0, s, a);
+        else           hipLaunchKernelGGL((gemv_batch_kernel<7, 1, 1>), grid, dim3(64), 0, s, a);
+    } else {
+        CV_CHECK(!a.gamma, "gemv_batch: fused RMSNorm needs the whole row in one wave (K <= 896)");
+        if (rows == 2) hipLaunchKernelGGL((gemv_batch_kernel<10, 2, 4>), grid, dim3(256), 0, s, a);
+        else           hipLaunchKernelGGL((gemv_batch_kernel<10, 1, 4>), grid, dim3(256), 0, s, a);
+    }
+}
+
+// one token for every slot: the launch sequence of llm_enqueue_step with the weight-streaming kernels batched
+static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
+    const auto& c = m->cfg; auto& b = m->bt; const int nb = b.nb;
+    const long long H = c.hidden, Q = m->qkv_dim, I = c.inter, V = m->V;
+    DecodeState* st = b.state.as<DecodeState>();
+    float* h = b.h.as<float>(); float* qkv = b.qkv.as<float>(); float* act = b.act.as<float>(); float* logits = b.logits.as<float>();
+    const long long ldpart = (long long)c.heads * 16 * ATTN_PART;
+    GemvBatchArgs hd{m->head_w, m->head_b, h, H, logits, V, (int)V, c.hidden, m->norm, c.rms_eps, nullptr, 0, 0, nb, nullptr, 0};
+    gemv_batch(hd, 2, s);
+    for (int i = 0; i < nb; ++i) {                                // per-slot sampler + embedding of the sampled token (no weights streamed)
+        SampleArgs sa{};
+        sa.logits = logits + i * V; sa.V = (int)V; sa.sp = b.sparams.as<SampleParams>() + i; sa.uniforms = b.uniforms.as<float>() + (size_t)i * 2 * c.max_len;
+        sa.st = st + i; sa.tokens = b.tokens.as<int>() + (size_t)i * c.max_len; sa.max_tokens = c.max_len;
+        hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, s, sa);
+        hipLaunchKernelGGL(embed_last_token_kernel, dim3(1), dim3(256), 0, s, m->speech_emb, c.hidden, h + i * H, st + i);
+    }
+    for (int l = 0; l < c.layers; ++l) {
+        const auto& L = m->layers[l];
+        GemvBatchArgs q{L.wqkv, L.bqkv, h, H, qkv, Q, (int)Q, c.hidden, L.ln1, c.rms_eps, nullptr, 0, 0, nb, nullptr, 0};
+        gemv_batch(q, 1, s);
+        AttnDecodeBatchArgs ad{qkv, Q, b.kcache.as<float>() + m->layer_cache() * l, b.vcache.as<float>() + m->layer_cache() * l, (long long)m->slot_cache(),
+                               m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st, b.part.as<float>(), ldpart, 8};
+        hipLaunchKernelGGL(attn_decode_batch_kernel, dim3(c.heads * 8, nb), dim3(64), 0, s, ad);
+        GemvBatchArgs o{L.wo, nullptr, nullptr, 0, h, H, c.hidden, c.heads * 64, nullptr, 0.f, h, H, 0, nb, b.part.as<float>(), ldpart};
+        gemv_batch(o, 1, s, 8);
+        GemvBatchArgs gu{L.wgu, nullptr, h, H, act, I, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 0, 1, nb, nullptr, 0};
+        gemv_batch(gu, 2, s);
+        GemvBatchArgs dn{L.wdown, nullptr, act, I, h, H, c.hidden, c.inter, nullptr, 0.f, h, H, 0, nb, nullptr, 0};
+        gemv_batch(dn, 1, s);
+    }
+    for (int i = 0; i < nb; ++i) hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, s, st + i);
+}
+
+static void batch_decode(cv_llm* m, int n_steps, int32_t* out_tokens, int32_t* n_out, int32_t* finished, hipStream_t s) {
+    auto& b = m->bt; const auto& c = m->cfg; const int nb = b.nb;
+    CV_CHECK(nb > 0, "cv_llm_batch_decode: call cv_llm_batch_begin first");
+    CV_CHECK(n_steps > 0 && out_tokens && n_out && finished, "cv_llm_batch_decode: bad arguments");
+    std::vector<int> before(nb);
+    for (int i = 0; i < nb; ++i) {
+        before[i] = b.host_state[i].n_tokens;
+        CV_CHECK(b.host_state[i].done || b.host_state[i].pos + n_steps < c.max_len, "cv_llm_batch_decode: KV cache (max_len) exhausted in a slot");
+    }
+    {
+        std::lock_guard<std::recursive_mutex> lk(runtime_lock());
+        if (m->use_graph) {
+            if (!b.graph || b.graph_stream != s || b.graph_nb != nb) {
+                if (b.graph) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
+                hipGraph_t g = capture_graph(s, [&] { batch_enqueue_step(m, s); });
+                CV_HIP(hipGraphInstantiate(&b.graph, g, nullptr, nullptr, 0));
+                CV_HIP(hipGraphDestroy(g));
+                b.graph_stream = s; b.graph_nb = nb;
+            }
+            for (int i = 0; i < n_steps; ++i) CV_HIP(hipGraphLaunch(b.graph, s));
+        } else {
+            for (int i = 0; i < n_steps; ++i) batch_enqueue_step(m, s);
+        }
+    }
+    CV_HIP(hipMemcpyAsync(b.host_state.data(), b.state.p, (size_t)nb * sizeof(DecodeState), hipMemcpyDeviceToHost, s));
+    CV_HIP(hipMemcpyAsync(b.host_tokens.data(), b.tokens.p, (size_t)nb * c.max_len * sizeof(int), hipMemcpyDeviceToHost, s));
+    CV_HIP(hipStreamSynchronize(s));
+    CV_HIP(hipGetLastError());
+    for (int i = 0; i < nb; ++i) {
+        const int after = b.host_state[i].n_tokens;
+        for (int t = before[i]; t < after; ++t) out_tokens[(size_t)i * n_steps + (t - before[i])] = b.host_tokens[(size_t)i * c.max_len + t];
+        n_out[i] = after - before[i];
+        finished[i] = b.host_state[i].done || b.host_state[i].step >= b.host_sp[i].max_len;
+    }
+}
+
+
 extern "C" {
 
 int cv_llm_create(cv_llm** out, const cv_llm_config* cfg) {
@@ -377,6 +525,15 @@ int cv_llm_profile_chain(cv_llm* m, int32_t category, int32_t reps, float* total
         *launches = (category == 5 ? 1 : m->cfg.layers) * reps;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
     });
+}
+int cv_llm_batch_begin(cv_llm* m, int32_t nb, void* stream) {
+    return guarded([&] { CV_CHECK(m, "null handle"); batch_begin(m, nb, resolve(m, stream)); });
+}
+int cv_llm_batch_prefill(cv_llm* m, int32_t slot, const float* lm_input, int32_t L0, const cv_sampling* sp, void* stream) {
+    return guarded([&] { CV_CHECK(m && lm_input, "null argument"); batch_prefill(m, slot, lm_input, L0, sp, resolve(m, stream)); });
+}
+int cv_llm_batch_decode(cv_llm* m, int32_t n_steps, int32_t* out_tokens, int32_t* n_out, int32_t* finished, void* stream) {
+    return guarded([&] { CV_CHECK(m, "null handle"); batch_decode(m, n_steps, out_tokens, n_out, finished, resolve(m, stream)); });
 }
 int cv_llm_last_logits(cv_llm* m, float* host_out, void* stream) {
     return guarded([&] { CV_CHECK(m && host_out, "null argument");

@@ -165,6 +165,40 @@ class Qwen2LM:
                     break
 
 
+    # ------------------------------------------------------------------------------------------------ lock-step batched decode
+    @torch.inference_mode()
+    def inference_batch(self, requests, max_token_text_ratio=20, min_token_text_ratio=2):
+        """Up to 8 requests decoded in lock step on this handle (BASELINE.json configs[2]/[3]; the reference batches through vLLM,
+        cli/model.py:281-290): every weight matrix is streamed once per step for all sequences (llm_batch_kernels.h).  `requests` is a
+        list of dicts with `text`, `prompt_text`, `prompt_speech_token` ([1, n] id tensors).  Returns one token list per request - the
+        same tokens `inference()` yields for that request alone (the per-sequence arithmetic is identical)."""
+        nb = len(requests)
+        assert 1 <= nb <= 8, "1..8 requests per batch"
+        with self.lock:
+            st = stream_ptr(self.lib)
+            self.lib.cv_llm_batch_begin(self._h, C.c_int32(nb), st)
+            max_lens = []
+            for i, r in enumerate(requests):
+                lm_input = self.build_lm_input(r["text"], r["prompt_text"], r["prompt_speech_token"])
+                n_text = int(r["text"].shape[1])
+                min_len, max_len = int(n_text * min_token_text_ratio), int(n_text * max_token_text_ratio)
+                if lm_input.shape[0] + max_len + 1 >= self.max_len:
+                    raise ValueError("request %d: prompt (%d) + max_len (%d) exceeds the KV capacity %d" % (i, lm_input.shape[0], max_len, self.max_len))
+                sp = self.make_sampling(min_len, max_len)
+                self.lib.cv_llm_batch_prefill(self._h, C.c_int32(i), C.c_void_p(lm_input.data_ptr()), C.c_int32(lm_input.shape[0]), C.byref(sp), st)
+                max_lens.append(max_len)
+            outs, fin = [[] for _ in range(nb)], [m == 0 for m in max_lens]
+            chunk = self.decode_chunk
+            while not all(fin):
+                buf = (C.c_int32 * (nb * chunk))()
+                n_out, f = (C.c_int32 * nb)(), (C.c_int32 * nb)()
+                self.lib.cv_llm_batch_decode(self._h, C.c_int32(chunk), buf, n_out, f, st)
+                for i in range(nb):
+                    outs[i].extend(int(buf[i * chunk + k]) for k in range(n_out[i]))
+                    fin[i] = fin[i] or bool(f[i]) or len(outs[i]) >= max_lens[i]
+            return [o[:m] for o, m in zip(outs, max_lens)]
+
+
     # ------------------------------------------------------------------------------------------------ bi-directional streaming
     def _rows(self, table, ids):
         """Embedding rows [n, hidden] fp32 on the device (cv_gather_rows), n may be 0."""

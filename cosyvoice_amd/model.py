@@ -162,6 +162,27 @@ class CosyVoice2Model:
                     tts_speech = self._fade(tts_speech, cache["speech"])
             return tts_speech
 
+    def tts_batch(self, requests, speed=1.0):
+        """Offline synthesis of up to 8 requests (dicts with the keyword arguments of tts()): the speech-token LM runs lock-step
+        batched (Qwen2LM.inference_batch: weights streamed once per step for all requests), flow + HiFT then run per utterance.
+        Returns one {'tts_speech': [1, S]} per request, equal to what tts(**request, stream=False) yields for it."""
+        reqs = [dict(text=r["text"], prompt_text=r["prompt_text"], prompt_speech_token=r["llm_prompt_speech_token"]) for r in requests]
+        with self.llm_context:
+            tokens = self.llm.inference_batch(reqs)
+        if self.device.type == "cuda":
+            self.llm_stream.synchronize()
+        outs = []
+        for r, toks in zip(requests, tokens):
+            uid = str(uuid_mod.uuid1())
+            self.hift_cache_dict[uid] = None
+            try:
+                wav = self.token2wav(token=torch.tensor(toks).unsqueeze(0), prompt_token=r["flow_prompt_speech_token"], prompt_feat=r["prompt_speech_feat"],
+                                     embedding=r["flow_embedding"], token_offset=0, uuid=uid, finalize=True, speed=speed)
+                outs.append({"tts_speech": wav.cpu()})
+            finally:
+                self.hift_cache_dict.pop(uid, None)
+        return outs
+
     def tts(self, text=torch.zeros(1, 0, dtype=torch.int32), flow_embedding=torch.zeros(0, 192), llm_embedding=torch.zeros(0, 192),
             prompt_text=torch.zeros(1, 0, dtype=torch.int32), llm_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32),
             flow_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32), prompt_speech_feat=torch.zeros(1, 0, 80),

@@ -1,0 +1,83 @@
+"""Lock-step batched decode (llm_batch_kernels.h): a sequence decoded in a batch must yield exactly the tokens it yields alone - and
+exactly the oracle's.  New this round and not yet run on hardware: on the MI355X these tests are opt-in (CV_TEST_BATCH_DECODE=1) until
+the kernels have been validated there; under the CPU emulator (guard-page memory) they always run."""
+import os
+
+import pytest
+import torch
+
+from cosyvoice_amd.llm import Qwen2LM
+from oracle import llm as OL
+from oracle import weights as W
+
+
+def _skip_unvalidated(lib):
+    if not lib.emulated and os.environ.get("CV_TEST_BATCH_DECODE") != "1":
+        pytest.skip("batched decode has not been validated on hardware yet (set CV_TEST_BATCH_DECODE=1)")
+
+
+def _req(cfg, seed, n_text, n_prompt_text, n_prompt_tok):
+    u = W.synthetic_utterance(cfg, W.tiny()[1], n_prompt_tok=n_prompt_tok, n_prompt_text=n_prompt_text, n_text=n_text, seed=seed)
+    return dict(text=u["text"], prompt_text=u["prompt_text"], prompt_speech_token=u["llm_prompt_speech_token"])
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_batch_matches_single_and_oracle(lib, use_graph):
+    _skip_unvalidated(lib)
+    cfg = W.tiny()[0]
+    sd = W.make_llm(cfg)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=160, sampling="greedy", decode_chunk=5, use_graph=use_graph)
+    # different prompt lengths, different generated lengths (some stop on eos early, some run to max_len), one slot without a speech prompt
+    reqs = [_req(cfg, 1986, 6, 5, 11), _req(cfg, 7, 4, 3, 20), _req(cfg, 11, 5, 0, 0), _req(cfg, 23, 3, 2, 33), _req(cfg, 5, 6, 4, 9)]
+    got = lm.inference_batch(reqs, max_token_text_ratio=4, min_token_text_ratio=1)
+    assert len(got) == len(reqs)
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    lens = set()
+    for r, g in zip(reqs, got):
+        want = OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=4, min_token_text_ratio=1)
+        alone = list(lm.inference(text=r["text"], text_len=t(r["text"].shape[1]), prompt_text=r["prompt_text"], prompt_text_len=t(r["prompt_text"].shape[1]),
+                                  prompt_speech_token=r["prompt_speech_token"], prompt_speech_token_len=t(r["prompt_speech_token"].shape[1]),
+                                  max_token_text_ratio=4, min_token_text_ratio=1))
+        assert g == alone == want
+        lens.add(len(g))
+    assert len(lens) > 1                                             # the slots really finished at different steps
+    # a second batch of another size on the same handle, then the single-sequence path again
+    got2 = lm.inference_batch(reqs[:2], max_token_text_ratio=3, min_token_text_ratio=1)
+    for r, g in zip(reqs[:2], got2):
+        assert g == OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=3, min_token_text_ratio=1)
+
+
+def test_batch_of_eight_and_long_context(lib):
+    _skip_unvalidated(lib)
+    cfg = W.tiny()[0]
+    sd = W.make_llm(cfg)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=256, sampling="greedy", decode_chunk=8)
+    reqs = [_req(cfg, 100 + i, 3 + (i % 3), 2, 10 + 25 * i) for i in range(8)]      # contexts from 15 to ~200 keys: several attention passes per slice
+    got = lm.inference_batch(reqs, max_token_text_ratio=3, min_token_text_ratio=2)
+    for r, g in zip(reqs, got):
+        assert g == OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=3, min_token_text_ratio=2)
+    with pytest.raises(AssertionError):
+        lm.inference_batch(reqs + reqs[:1])
+
+
+def test_model_tts_batch(lib):
+    """CosyVoice2Model.tts_batch == tts() per request (same tokens from the batched LM, same flow / HiFT)."""
+    _skip_unvalidated(lib)
+    import dataclasses
+    from cosyvoice_amd.model import CosyVoice2Model
+    lc, fc, hc = W.tiny()
+    fc = dataclasses.replace(fc, n_timesteps=1)                       # one Euler step: the emulator run stays short
+    m = CosyVoice2Model.from_state_dicts(W.make_llm(lc), W.make_flow(fc), W.make_hift(hc), (lc, fc, hc), lib=lib, max_len=160, sampling="greedy")
+    inf = m.hift.inference
+    m.hift.inference = lambda speech_feat, cache_source=None: inf(speech_feat, cache_source, noise=torch.zeros(speech_feat.shape[2] * 480, 9))
+    # both LM entry points with a small max ratio (llm_job / tts_batch use the reference defaults 20 / 2): 5 tokens per utterance
+    inf_b, inf_1 = m.llm.inference_batch, m.llm.inference
+    m.llm.inference_batch = lambda reqs: inf_b(reqs, max_token_text_ratio=5, min_token_text_ratio=2)
+    m.llm.inference = lambda **kw: inf_1(**{**kw, "max_token_text_ratio": 5, "min_token_text_ratio": 2})
+    us = [W.synthetic_utterance(lc, fc, n_prompt_tok=5 + 2 * i, n_prompt_text=2, n_text=1, seed=40 + i) for i in range(2)]
+    keys = ("text", "flow_embedding", "llm_embedding", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat")
+    reqs = [{k: u[k] for k in keys} for u in us]
+    got = m.tts_batch(reqs)
+    for r, g in zip(reqs, got):
+        alone = next(iter(m.tts(**r, stream=False)))["tts_speech"]
+        assert torch.equal(g["tts_speech"], alone)
