@@ -197,19 +197,18 @@ def test_bf16_mode_vs_reference_golden(lib):
     assert d.max().item() < 5e-2 and d.mean().item() < 1e-2, (d.max().item(), d.mean().item())
 
 
-def test_bf16_mode_waveform_snr(lib):
-    """waveform SNR >= 30 dB vs the fp32 path given an identical harmonic source.  Mel from the reference-golden flow
-    fixture in both precisions -> the same HiFT (fp32) decode with the source computed once from the fp32 mel."""
+def test_bf16_mode_waveform_snr(lib, tiny):
+    """waveform SNR >= 30 dB vs the fp32 path given an identical harmonic source.  Mel of one request in both precisions
+    -> the same HiFT (fp32) decode with the source computed once from the fp32 mel."""
     from cosyvoice_amd.hift import HiFTGenerator
-    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, "flow_small.npz")).items()}
-    cfg = W.ref_small_flow()
-    sd = W.make_flow(cfg)
+    cfg, sd = tiny
+    u = _inputs(cfg, n_p=3, n_t=5)                  # 10 mel frames: the three HiFT passes dominate the emulator time
     t = lambda n: torch.tensor([n], dtype=torch.int32)
     mels = {}
     for prec in ("fp32", "bf16"):
-        flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision=prec)
-        mels[prec], _ = flow.inference(token=g["token"], token_len=t(16), prompt_token=g["prompt_token"], prompt_token_len=t(9), prompt_feat=g["prompt_feat"],
-                                       prompt_feat_len=t(18), embedding=g["embedding"], streaming=False, finalize=True)
+        flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision=prec, n_timesteps=4)
+        mels[prec], _ = flow.inference(token=u["token"], token_len=t(5), prompt_token=u["prompt_token"], prompt_token_len=t(3), prompt_feat=u["prompt_feat"],
+                                       prompt_feat_len=t(6), embedding=u["embedding"], streaming=False, finalize=True)
     hc = W.tiny()[2]
     hift = HiFTGenerator(W.make_hift(hc), hc, lib=lib)
     _, s = hift.inference(mels["fp32"])            # (speech, source): the harmonic source of the fp32 mel, reused for both decodes

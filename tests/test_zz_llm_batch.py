@@ -24,6 +24,8 @@ def _req(cfg, seed, n_text, n_prompt_text, n_prompt_tok):
 @pytest.mark.parametrize("use_graph", [True, False])
 def test_batch_matches_single_and_oracle(lib, use_graph):
     _skip_unvalidated(lib)
+    if lib.emulated and not use_graph:
+        pytest.skip("eager launches replay the same closures as the captured graph under the emulator")
     cfg = W.tiny()[0]
     sd = W.make_llm(cfg)
     lm = Qwen2LM(sd, cfg, lib=lib, max_len=160, sampling="greedy", decode_chunk=5, use_graph=use_graph)
