@@ -4,11 +4,11 @@ MI355X these tests build the full-size LLM / flow / HiFT (seeded random weights)
 oracle (a few seconds of CPU work each); under the CPU emulator the same code runs on the tiny configuration.
 
 Criteria are relative L2 errors.  They could not be calibrated on hardware when this file was written (GPU budget of the round spent),
-so they carry generous slack over the emulator-size figures scaled by depth: summation-order noise grows ~1.3x per estimator stage
-(measured sensitivity), 14 stages -> fp32 mode expected 1e-5..1e-4; the bf16 rounding noise of a RANDOM-weight 56-block
-estimator may amplify to 1e-1 (5e-3 at tiny size), so that bound only separates "noisy" from "uncorrelated" (~1.4).  A wrong tile index or a
-mis-sized launch gives O(1) errors, far above every bound.  Greedy ids must match wherever the oracle's own top-2 margin is clear.
-The measured errors are printed (run with -s) to tighten the bounds next round."""
+so they are calibrated with the oracle at full size instead: the fp32 estimator moves by 1.3e-6 (rel. L2) under a 1e-6 input perturbation
+(no amplification through the 14 stages), and the oracle's own bf16 mirror sits 6.2e-3 from its fp32 result (max |diff| 1.8e-2 on
+outputs of std 0.69).  Bounds: fp32 mode 2e-4 (~100x the expected summation-order noise), bf16 mode 5e-2 (8x the mirror's distance);
+a wrong tile index or a mis-sized launch gives O(1).  Greedy ids must match wherever the oracle's own top-2 margin is clear.  The
+measured errors are printed (run with -s) to tighten the bounds next round."""
 import pytest
 import torch
 
@@ -70,7 +70,7 @@ def test_flow_estimator_fullsize(lib, precision):
         ref = OF.estimator(sd, fc, x, mask, mu, t, spk, cond, streaming)
         err = _rel(out, ref)
         print("estimator %s streaming=%s: rel L2 %.2e" % (precision, streaming, err))
-        assert err < (2e-3 if precision == "fp32" else 0.5), (precision, streaming, err)     # uncorrelated output (a wrong tile) would be ~1.4
+        assert err < (2e-4 if precision == "fp32" else 5e-2), (precision, streaming, err)
     h, _ = flow.encoder(torch.randn(1, 24 if lib.emulated else 60, fc.dim, generator=g), torch.tensor([60]), streaming=False)
     # (encoder output only has to be finite here; its parity is covered at tiny size and through inference() below at full size)
     assert torch.isfinite(h).all()
