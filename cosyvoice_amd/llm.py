@@ -199,6 +199,64 @@ class Qwen2LM:
             return [o[:m] for o, m in zip(outs, max_lens)]
 
 
+    @torch.inference_mode()
+    def inference_queue(self, requests, slots=8, max_token_text_ratio=20, min_token_text_ratio=2):
+        """Continuous batching over the lock-step decoder: any number of requests, at most `slots` (<= 8) in flight; when a
+        sequence finishes its slot is re-filled from the queue (a normal prefill parked into the free slot) while the other sequences keep
+        decoding.  Yields (request_index, token_list) in completion order; every token list equals `inference()` of that request alone."""
+        assert 1 <= slots <= 8
+        n = len(requests)
+        if n == 0:
+            return
+        with self.lock:
+            st = stream_ptr(self.lib)
+            nb = min(slots, n)
+            self.lib.cv_llm_batch_begin(self._h, C.c_int32(nb), st)
+            owner, outs, limit = [None] * nb, {}, {}
+            nxt = 0
+
+            def fill(slot):
+                nonlocal nxt
+                while nxt < n:
+                    i, r = nxt, requests[nxt]
+                    nxt += 1
+                    lm_input = self.build_lm_input(r["text"], r["prompt_text"], r["prompt_speech_token"])
+                    n_text = int(r["text"].shape[1])
+                    min_len, max_len = int(n_text * min_token_text_ratio), int(n_text * max_token_text_ratio)
+                    if lm_input.shape[0] + max_len + 1 >= self.max_len:
+                        raise ValueError("request %d: prompt (%d) + max_len (%d) exceeds the KV capacity %d" % (i, lm_input.shape[0], max_len, self.max_len))
+                    if max_len == 0:
+                        done.append((i, []))
+                        continue
+                    sp = self.make_sampling(min_len, max_len)
+                    self.lib.cv_llm_batch_prefill(self._h, C.c_int32(slot), C.c_void_p(lm_input.data_ptr()), C.c_int32(lm_input.shape[0]), C.byref(sp), st)
+                    owner[slot], outs[i], limit[i] = i, [], max_len
+                    return
+                owner[slot] = None
+
+            done = []
+            for s_ in range(nb):
+                fill(s_)
+            chunk = self.decode_chunk
+            while True:
+                for item in done:
+                    yield item
+                done = []
+                if all(o is None for o in owner):
+                    return
+                buf = (C.c_int32 * (nb * chunk))()
+                n_out, f = (C.c_int32 * nb)(), (C.c_int32 * nb)()
+                self.lib.cv_llm_batch_decode(self._h, C.c_int32(chunk), buf, n_out, f, st)
+                for s_ in range(nb):
+                    i = owner[s_]
+                    if i is None:
+                        continue
+                    outs[i].extend(int(buf[s_ * chunk + k]) for k in range(n_out[s_]))
+                    if bool(f[s_]) or len(outs[i]) >= limit[i]:
+                        done.append((i, outs.pop(i)[: limit[i]]))
+                        fill(s_)
+
+
     # ------------------------------------------------------------------------------------------------ bi-directional streaming
     def _rows(self, table, ids):
         """Embedding rows [n, hidden] fp32 on the device (cv_gather_rows), n may be 0."""

@@ -62,6 +62,21 @@ def test_batch_of_eight_and_long_context(lib):
         lm.inference_batch(reqs + reqs[:1])
 
 
+def test_continuous_batching(lib):
+    """inference_queue: 7 requests through 3 slots - finished slots are re-filled while the others keep decoding; every request gets
+    exactly the tokens it gets alone."""
+    _skip_unvalidated(lib)
+    cfg = W.tiny()[0]
+    sd = W.make_llm(cfg)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=160, sampling="greedy", decode_chunk=4)
+    reqs = [_req(cfg, 200 + i, 2 + (i % 4), 2 + (i % 2), 5 + 7 * (i % 3)) for i in range(7)]
+    got = dict(lm.inference_queue(reqs, slots=3, max_token_text_ratio=4, min_token_text_ratio=1))
+    assert sorted(got) == list(range(7))
+    for i, r in enumerate(reqs):
+        assert got[i] == OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=4, min_token_text_ratio=1)
+    assert list(lm.inference_queue([], slots=3)) == []
+
+
 def test_model_tts_batch(lib):
     """CosyVoice2Model.tts_batch == tts() per request (same tokens from the batched LM, same flow / HiFT)."""
     _skip_unvalidated(lib)
