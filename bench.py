@@ -73,8 +73,9 @@ def batched_decode(model, u, nb, reps):
     keys = ("text", "flow_embedding", "llm_embedding", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat")
     reqs = [{k: u[k] for k in keys} for _ in range(nb)]
     ratio = N_GEN / N_TEXT
-    inf_b = model.llm.inference_batch
+    inf_b, inf_q = model.llm.inference_batch, model.llm.inference_queue
     model.llm.inference_batch = lambda r: inf_b(r, max_token_text_ratio=ratio, min_token_text_ratio=ratio)       # force 250 tokens each
+    model.llm.inference_queue = lambda r, slots=8: inf_q(r, slots=slots, max_token_text_ratio=ratio, min_token_text_ratio=ratio)
     try:
         model.tts_batch(reqs)                                     # warm-up (graph capture for this batch size)
         torch.cuda.synchronize()
@@ -84,6 +85,12 @@ def batched_decode(model, u, nb, reps):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         assert all(o["tts_speech"].shape[1] == N_GEN * 2 * 480 for o in outs)
+        # pipeline: 2 x NB requests through NB slots, LM (continuous batching, LLM stream / thread) overlapped with flow + HiFT of finished ones
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        n_done = sum(1 for _ in model.tts_queue(reqs + reqs, slots=nb))
+        torch.cuda.synchronize()
+        pipe_s = time.perf_counter() - t2
         lm_reqs = [dict(text=u["text"], prompt_text=u["prompt_text"], prompt_speech_token=u["llm_prompt_speech_token"]) for _ in range(nb)]
         with model.llm_context:
             t1 = time.perf_counter()
@@ -91,8 +98,9 @@ def batched_decode(model, u, nb, reps):
             torch.cuda.synchronize()
             lm_s = time.perf_counter() - t1
     finally:
-        model.llm.inference_batch = inf_b
+        model.llm.inference_batch, model.llm.inference_queue = inf_b, inf_q
     return {"batch": nb, "audio_s_per_s": round(nb * reps * AUDIO_S / el, 3), "ms_per_batch": round(1e3 * el / reps, 2),
+            "pipeline_audio_s_per_s": round(n_done * AUDIO_S / pipe_s, 3),
             "lm_tokens_per_s": round(sum(len(t) for t in toks) / lm_s, 1), "lm_us_per_step": round(1e6 * lm_s / max(len(toks[0]), 1), 1)}
 
 

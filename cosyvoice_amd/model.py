@@ -183,6 +183,45 @@ class CosyVoice2Model:
                 self.hift_cache_dict.pop(uid, None)
         return outs
 
+    def tts_queue(self, requests, slots=8, speed=1.0):
+        """Throughput pipeline for many offline requests (BASELINE.json configs[2]/[3]): a producer thread runs the LM with continuous
+        batching (Qwen2LM.inference_queue, <= `slots` sequences in flight, on the LLM stream) while the calling thread turns every finished
+        token sequence into audio (flow + HiFT on the caller's stream) - LM decode of the next sequences overlaps the vocoding of the
+        finished ones.  Yields (request_index, {'tts_speech': [1, S]}) in completion order; each waveform equals tts(**request)."""
+        import queue
+        q = queue.Queue()
+        lm_reqs = [dict(text=r["text"], prompt_text=r["prompt_text"], prompt_speech_token=r["llm_prompt_speech_token"]) for r in requests]
+
+        def produce():
+            try:
+                with self.llm_context:
+                    for item in self.llm.inference_queue(lm_reqs, slots=slots):
+                        q.put(item)
+                q.put(None)
+            except BaseException as e:          # surfaces in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=produce, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                i, toks = item
+                r, uid = requests[i], str(uuid_mod.uuid1())
+                self.hift_cache_dict[uid] = None
+                try:
+                    wav = self.token2wav(token=torch.tensor(toks).unsqueeze(0), prompt_token=r["flow_prompt_speech_token"], prompt_feat=r["prompt_speech_feat"],
+                                         embedding=r["flow_embedding"], token_offset=0, uuid=uid, finalize=True, speed=speed)
+                    yield i, {"tts_speech": wav.cpu()}
+                finally:
+                    self.hift_cache_dict.pop(uid, None)
+        finally:
+            th.join()
+
     def tts(self, text=torch.zeros(1, 0, dtype=torch.int32), flow_embedding=torch.zeros(0, 192), llm_embedding=torch.zeros(0, 192),
             prompt_text=torch.zeros(1, 0, dtype=torch.int32), llm_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32),
             flow_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32), prompt_speech_feat=torch.zeros(1, 0, 80),

@@ -94,7 +94,13 @@ def test_model_tts_batch(lib):
     us = [W.synthetic_utterance(lc, fc, n_prompt_tok=5 + 2 * i, n_prompt_text=2, n_text=1, seed=40 + i) for i in range(2)]
     keys = ("text", "flow_embedding", "llm_embedding", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat")
     reqs = [{k: u[k] for k in keys} for u in us]
+    alone = [next(iter(m.tts(**r, stream=False)))["tts_speech"] for r in reqs]
     got = m.tts_batch(reqs)
-    for r, g in zip(reqs, got):
-        alone = next(iter(m.tts(**r, stream=False)))["tts_speech"]
-        assert torch.equal(g["tts_speech"], alone)
+    for a, g in zip(alone, got):
+        assert torch.equal(g["tts_speech"], a)
+    # tts_queue: LM with continuous batching on the LLM thread / stream, vocoding of finished sequences on the caller's
+    m.llm.inference_queue = (lambda f: lambda reqs_, slots=8: f(reqs_, slots=slots, max_token_text_ratio=5, min_token_text_ratio=2))(m.llm.inference_queue)
+    seen = dict(m.tts_queue(reqs + reqs[:1], slots=2))
+    assert sorted(seen) == [0, 1, 2]
+    for i, a in enumerate(alone + alone[:1]):
+        assert torch.equal(seen[i]["tts_speech"], a)
