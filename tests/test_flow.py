@@ -56,6 +56,23 @@ def test_estimator_boundary(lib, tiny, streaming, T):
     torch.testing.assert_close(out.cpu(), ref, rtol=2e-4, atol=2e-4)
 
 
+def test_estimator_like_export_onnx_check(lib, tiny):
+    """The reference's only numeric self-check (cosyvoice/bin/export_onnx.py:89-109): 10 random inputs, B = 2, T drawn from [16, 512],
+    estimator output of the accelerated backend vs PyTorch at rtol 1e-2 / atol 1e-4 - here the HIP estimator vs the oracle, same
+    tolerance, same input recipe (x, mu, cond ~ randn, mask = ones, t ~ rand, spks ~ randn).  The emulator runs 3 draws capped at T = 96."""
+    cfg, sd = tiny
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib)
+    g = torch.Generator().manual_seed(1986)
+    n, t_hi = (3, 96) if lib.emulated else (10, 512)
+    for i in range(n):
+        T = int(torch.randint(16, t_hi + 1, (1,), generator=g))
+        x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g); cond = torch.randn(2, 80, T, generator=g)
+        spk = torch.randn(2, 80, generator=g); t = torch.rand(2, generator=g); mask = torch.ones(2, 1, T)
+        out = flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=bool(i % 2))
+        ref = OF.estimator(sd, cfg, x, mask, mu, t, spk, cond, bool(i % 2))
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-2, atol=1e-4)
+
+
 @pytest.mark.parametrize("streaming,finalize", [(False, True), (True, False)])
 def test_inference(lib, tiny, streaming, finalize):
     cfg, sd = tiny
