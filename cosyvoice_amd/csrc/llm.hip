@@ -6,6 +6,7 @@
 //          it is replayed once per token; the loop state lives in device memory (DecodeState), so no host sync is
 //          needed per token — tokens are read back in chunks.
 #include <vector>
+#include <algorithm>
 #include <cmath>
 #include "ops.h"
 #include "tensor_map.h"
@@ -59,7 +60,7 @@ static void llm_finalize(cv_llm* m) {
     const auto& c = m->cfg;
     CV_CHECK(c.hidden % 128 == 0 && c.inter % 128 == 0, "llm: hidden and inter must be multiples of 128");
     CV_CHECK(c.heads % c.kv_heads == 0 && c.heads * 64 % 128 == 0, "llm: bad head configuration (head_dim is fixed at 64)");
-    CV_CHECK(c.max_len > 0 && c.max_len <= 2048, "llm: max_len (KV capacity) must be in (0, 2048]");
+    CV_CHECK(c.max_len > 0 && c.max_len <= 32768, "llm: max_len (KV capacity) must be in (0, 32768] (Qwen2.5 max_position_embeddings)");
     CV_CHECK(c.hidden <= 896 && c.heads * 64 <= 5120 && c.inter <= 5120, "llm: hidden must fit one wave-row (<= 896, fused RMSNorm) and inter <= 5120");
     m->V = c.speech_vocab;
     CV_CHECK(m->V > 0 && m->V <= 8192, "llm: speech vocab above the sampler limit");
@@ -382,7 +383,9 @@ static void batch_decode(cv_llm* m, int n_steps, int32_t* out_tokens, int32_t* n
     std::vector<int> before(nb);
     for (int i = 0; i < nb; ++i) {
         before[i] = b.host_state[i].n_tokens;
-        CV_CHECK(b.host_state[i].done || b.host_state[i].pos + n_steps < c.max_len, "cv_llm_batch_decode: KV cache (max_len) exhausted in a slot");
+        // a slot appends at most (its request's max_len - step) more positions: past that the sampler only marks it done
+        const int left = std::max(0, std::min(n_steps, b.host_sp[i].max_len - b.host_state[i].step));
+        CV_CHECK(b.host_state[i].done || b.host_state[i].pos + left < c.max_len, "cv_llm_batch_decode: KV cache (max_len) exhausted in a slot");
     }
     {
         std::lock_guard<std::recursive_mutex> lk(runtime_lock());

@@ -45,6 +45,23 @@ class _Estimator:
         return out
 
 
+class EstimatorModule(torch.nn.Module):
+    """The product estimator as a `torch.nn.Module`, for dropping into the REFERENCE's own `ConditionalCFM`: `forward_estimator`
+    (flow/flow_matching.py:126-153) dispatches on `isinstance(self.estimator, torch.nn.Module)`; anything else is taken for a TensorRT
+    wrapper (`acquire_estimator()` ...).  `flow.decoder.estimator = EstimatorModule(cosyvoice_amd_flow)` is the whole integration
+    (INTEGRATION.md section 2).  Inputs keep the reference's layouts ([2,80,T] etc.) and may be reused by the caller across Euler steps
+    (solve_euler :103-108 writes into the same buffers): nothing is retained past the call.  The result comes back in x's dtype on x's
+    device.  There are no parameters: the weights live in the library handle owned by the wrapped flow object."""
+
+    def __init__(self, flow):
+        super().__init__()
+        self._flow = [flow]                    # kept out of nn.Module's attribute registration
+
+    def forward(self, x, mask, mu, t, spks, cond, streaming=False):
+        out = self._flow[0].decoder.estimator(x, mask, mu, t, spks, cond, streaming=streaming)
+        return out.to(device=x.device, dtype=x.dtype)
+
+
 class _Encoder:
     """flow.encoder: (token_emb[1,n,dim], token_len, context=[1,3,dim] | empty, streaming) -> (h[1,2n,dim], mask[1,1,2n])."""
 
@@ -127,6 +144,9 @@ class CausalMaskedDiffWithXvec:
         mel_len2 = 2 * n_enc - mel_len1
         if mel_len2 <= 0:
             raise ValueError("no new frames to generate")
+        if 2 * n_enc > self._noise_cl.shape[0]:
+            # the reference slices a fixed [1, 80, 50 * 300] noise buffer (flow_matching.py:199-200, :215) and fails with a shape error beyond it
+            raise ValueError("%d mel frames exceed the fixed CFM noise buffer (%d frames = %d s)" % (2 * n_enc, self._noise_cl.shape[0], self._noise_cl.shape[0] // 50))
         out = self.lib.hook(torch.empty(1, self.cfg.mel, mel_len2, dtype=torch.float32, device=self.device))
         got = C.c_int32(0)
         self.lib.cv_flow_inference(self._h, C.c_void_p(ids.data_ptr()), C.c_int32(n_tok), C.c_void_p(pf.data_ptr()) if mel_len1 else C.c_void_p(out.data_ptr()),

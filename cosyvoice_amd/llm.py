@@ -132,6 +132,15 @@ class Qwen2LM:
         self.lib.cv_llm_decode(self._h, C.c_int32(n_steps), C.byref(sp), buf, C.byref(n_out), C.byref(fin), st)
         return list(buf[: n_out.value]), bool(fin.value)
 
+    def clamp_max_len(self, L0, min_len, max_len, what="request"):
+        """The reference's `max_len` is only a loop bound that is almost never reached (llm/llm.py:499-500, 538); the KV cache here is a
+        fixed-capacity buffer, so the bound is clamped to what still fits instead of refusing the request.  Raises only when not even
+        `min_len` tokens fit (eos is suppressed below min_len, so such a request could not terminate inside the cache)."""
+        room = self.max_len - L0 - 2
+        if room < max(min_len, 1):
+            raise ValueError("%s: prompt (%d) + min_len (%d) exceeds the KV capacity %d" % (what, L0, min_len, self.max_len))
+        return min(max_len, room)
+
     def make_sampling(self, min_len, max_len):
         self._request += 1
         # `eos` of the C sampler = first special id = the index sampling_ids masks while ignore_eos (llm/llm.py:150-160: literally
@@ -151,8 +160,7 @@ class Qwen2LM:
         max_len = int(n_text * max_token_text_ratio)
         with self.lock:
             lm_input = self.build_lm_input(text, prompt_text, prompt_speech_token)
-            if lm_input.shape[0] + max_len + 1 >= self.max_len:
-                raise ValueError("prompt (%d) + max_len (%d) exceeds the KV capacity %d" % (lm_input.shape[0], max_len, self.max_len))
+            max_len = self.clamp_max_len(lm_input.shape[0], min_len, max_len)
             self.prefill(lm_input)
             sp = self.make_sampling(min_len, max_len)
             emitted = 0
@@ -182,9 +190,9 @@ class Qwen2LM:
                 lm_input = self.build_lm_input(r["text"], r["prompt_text"], r["prompt_speech_token"])
                 n_text = int(r["text"].shape[1])
                 min_len, max_len = int(n_text * min_token_text_ratio), int(n_text * max_token_text_ratio)
-                if lm_input.shape[0] + max_len + 1 >= self.max_len:
-                    raise ValueError("request %d: prompt (%d) + max_len (%d) exceeds the KV capacity %d" % (i, lm_input.shape[0], max_len, self.max_len))
-                sp = self.make_sampling(min_len, max_len)
+                if max_len > 0:
+                    max_len = self.clamp_max_len(lm_input.shape[0], min_len, max_len, "request %d" % i)
+                sp = self.make_sampling(min_len, max(max_len, 1))
                 self.lib.cv_llm_batch_prefill(self._h, C.c_int32(i), C.c_void_p(lm_input.data_ptr()), C.c_int32(lm_input.shape[0]), C.byref(sp), st)
                 max_lens.append(max_len)
             outs, fin = [[] for _ in range(nb)], [m == 0 for m in max_lens]
@@ -223,11 +231,10 @@ class Qwen2LM:
                     lm_input = self.build_lm_input(r["text"], r["prompt_text"], r["prompt_speech_token"])
                     n_text = int(r["text"].shape[1])
                     min_len, max_len = int(n_text * min_token_text_ratio), int(n_text * max_token_text_ratio)
-                    if lm_input.shape[0] + max_len + 1 >= self.max_len:
-                        raise ValueError("request %d: prompt (%d) + max_len (%d) exceeds the KV capacity %d" % (i, lm_input.shape[0], max_len, self.max_len))
                     if max_len == 0:
                         done.append((i, []))
                         continue
+                    max_len = self.clamp_max_len(lm_input.shape[0], min_len, max_len, "request %d" % i)
                     sp = self.make_sampling(min_len, max_len)
                     self.lib.cv_llm_batch_prefill(self._h, C.c_int32(slot), C.c_void_p(lm_input.data_ptr()), C.c_int32(lm_input.shape[0]), C.byref(sp), st)
                     owner[slot], outs[i], limit[i] = i, [], max_len

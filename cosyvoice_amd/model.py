@@ -22,10 +22,10 @@ from .llm import Qwen2LM
 
 
 class CosyVoice2Model:
-    def __init__(self, llm, flow, hift, fp16=False):
+    def __init__(self, llm, flow, hift, fp16=False, lib=None):
         """llm / flow / hift: cosyvoice_amd.{llm.Qwen2LM, flow.CausalMaskedDiffWithXvec, hift.HiFTGenerator} (or None before load())."""
         self.llm, self.flow, self.hift = llm, flow, hift
-        self.lib = (llm or flow or hift).lib if (llm or flow or hift) is not None else get_lib()
+        self.lib = lib or ((llm or flow or hift).lib if (llm or flow or hift) is not None else get_lib())
         self.device = torch.device(self.lib.device)
         # reference: fp16=True halves llm + flow (cli/model.py:50-52).  Here: the flow's Linear/Conv1d products run on the bf16 MFMA
         # (precision="bf16", fp32 accumulate and fp32 tensors in HBM); the LLM is W16A32 either way (token ids stay bit-exact).
@@ -43,6 +43,7 @@ class CosyVoice2Model:
         self.lock = threading.Lock()
         self.t2w_lock = threading.Lock()       # flow / hift handles own their workspaces: one token2wav at a time per model
         self.tts_speech_token_dict, self.llm_end_dict, self.hift_cache_dict, self._cond = {}, {}, {}, {}
+        self._llm_error = {}                   # uuid -> exception raised on the LLM thread, re-raised by tts() on the caller's thread
         self.silent_tokens = []
         self._warmup()
 
@@ -110,6 +111,8 @@ class CosyVoice2Model:
                     with cond:
                         self.tts_speech_token_dict[uuid].append(i)
                         cond.notify_all()
+        except BaseException as e:             # a thread's exception would only reach threading.excepthook: hand it to tts()
+            self._llm_error[uuid] = e
         finally:
             with cond:
                 self.llm_end_dict[uuid] = True
@@ -238,6 +241,12 @@ class CosyVoice2Model:
         else:
             p = threading.Thread(target=self.vc_job, args=(source_speech_token, this_uuid))
         p.start()
+
+        def check_llm():
+            err = self._llm_error.pop(this_uuid, None)
+            if err is not None:
+                raise err
+
         try:
             if stream is True:
                 token_offset = 0
@@ -260,12 +269,14 @@ class CosyVoice2Model:
                     elif ended:
                         break
                 p.join()
+                check_llm()
                 this_tts_speech_token = torch.tensor(self.tts_speech_token_dict[this_uuid]).unsqueeze(dim=0)
                 this_tts_speech = self.token2wav(token=this_tts_speech_token, prompt_token=flow_prompt_speech_token, prompt_feat=prompt_speech_feat,
                                                  embedding=flow_embedding, token_offset=token_offset, uuid=this_uuid, finalize=True)
                 yield {"tts_speech": this_tts_speech.cpu()}
             else:
                 p.join()
+                check_llm()
                 this_tts_speech_token = torch.tensor(self.tts_speech_token_dict[this_uuid]).unsqueeze(dim=0)
                 this_tts_speech = self.token2wav(token=this_tts_speech_token, prompt_token=flow_prompt_speech_token, prompt_feat=prompt_speech_feat,
                                                  embedding=flow_embedding, token_offset=0, uuid=this_uuid, finalize=True, speed=speed)
@@ -277,3 +288,4 @@ class CosyVoice2Model:
                 self.llm_end_dict.pop(this_uuid, None)
                 self.hift_cache_dict.pop(this_uuid, None)
                 self._cond.pop(this_uuid, None)
+                self._llm_error.pop(this_uuid, None)

@@ -141,7 +141,15 @@ def fold_weight_norm(sd, p):
 
 
 def _conv_w(sd, p):
-    return fold_weight_norm(sd, p) if (p + "parametrizations.weight.original0") in sd else sd[p + "weight"].float()
+    """Conv / ConvTranspose weight under any of the three spellings a hift.pt can carry: the parametrization API
+    (`parametrizations.weight.original0/1`, hifigan/generator.py:26-29), legacy torch.nn.utils.weight_norm (`weight_g` / `weight_v`, which the
+    reference accepts through its ImportError fallback and torch's compat load hook) or a plain folded `weight`."""
+    if (p + "parametrizations.weight.original0") in sd:
+        return fold_weight_norm(sd, p)
+    if (p + "weight_g") in sd:
+        g, v = sd[p + "weight_g"].float(), sd[p + "weight_v"].float()
+        return g * v / v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
+    return sd[p + "weight"].float()
 
 
 def pack_hift(sd, cfg, device):

@@ -37,7 +37,7 @@ class Pipeline:
         L = mel.shape[2] * 480
         return OH.inference(self.hift_sd, self.hc, mel, cache_source, None, torch.zeros(1, L, self.hc.harmonics + 1))
 
-    def token2wav(self, token, prompt_token, prompt_feat, embedding, token_offset, cache, stream=False, finalize=False):
+    def token2wav(self, token, prompt_token, prompt_feat, embedding, token_offset, cache, stream=False, finalize=False, speed=1.0):
         mel = OF.inference(self.flow_sd, self.fc, token, prompt_token, prompt_feat, embedding, streaming=stream, finalize=finalize,
                            n_timesteps=self.n_timesteps)
         mel = mel[:, :, token_offset * 2:]
@@ -46,6 +46,9 @@ class Pipeline:
             cs = cache["source"]
         else:
             cs = None
+        if finalize and speed != 1.0:                                  # cli/model.py:320-322
+            assert cache is None
+            mel = torch.nn.functional.interpolate(mel, size=int(mel.shape[2] / speed), mode="linear")
         speech, source = self.hift(mel, cs)
         if cache is not None:
             speech = fade_in_out(speech, cache["speech"], self.speech_window)
@@ -54,11 +57,12 @@ class Pipeline:
             return speech[:, : -self.source_cache_len], new_cache
         return speech, cache
 
-    def tts(self, tokens, u, stream=False):
+    def tts(self, tokens, u, stream=False, speed=1.0):
         """tokens: python list produced by the LLM; returns the list of yielded waveforms."""
         outs = []
         if not stream:
-            sp, _ = self.token2wav(torch.tensor(tokens).unsqueeze(0), u["flow_prompt_speech_token"], u["prompt_speech_feat"], u["flow_embedding"], 0, None, False, True)
+            sp, _ = self.token2wav(torch.tensor(tokens).unsqueeze(0), u["flow_prompt_speech_token"], u["prompt_speech_feat"], u["flow_embedding"], 0, None, False, True,
+                                   speed=speed)
             return [sp]
         token_offset, hop, cache, la = 0, self.token_hop_len, None, self.fc.pre_lookahead
         n_p = u["flow_prompt_speech_token"].shape[1]

@@ -310,6 +310,87 @@ def golden_glue():
     save("glue", fade_a=a, fade_b=b, fade_out=out, chunk_mask=subsequent_chunk_mask(23, 5).to(torch.uint8))
 
 
+def golden_model():
+    """B1 / a1 / a16: the REAL cosyvoice.cli.model.CosyVoice2Model (token2wav + the streaming tts loop with its hop doubling, mel / source /
+    speech caches and fade_in_out) around the real tiny flow + HiFT modules and a scripted LLM.  Pins oracle/model.py.  SineGen2's additive
+    noise (generator.py:312, `torch.randn_like`) is patched to zeros for the run - the same convention oracle.model.Pipeline and the HIP
+    tests use (noise is an explicit argument there); `rand_ini` cannot reach the output of this path."""
+    import dataclasses
+    import cosyvoice.cli.model as M
+    lc, _, hc = W.tiny()
+    fc = dataclasses.replace(W.ref_small_flow(), chunk=5, n_timesteps=2)   # the reference encoder hard-codes 512 channels (upsample_encoder.py:238-241)
+    flow, hift = build_ref_flow(fc), build_ref_hift(hc)
+    u = W.synthetic_utterance(lc, fc, n_prompt_tok=8, n_prompt_text=4, n_text=2, seed=21)
+    g = torch.Generator().manual_seed(31)
+    tokens = torch.randint(0, fc.vocab, (37,), generator=g).tolist()
+
+    class ScriptedLLM:
+        def inference(self, **kw):
+            for t in tokens:
+                yield t
+
+    # the reference hard-codes 10 Euler steps (flow/flow.py:278); the tiny fixtures use 2, like every other model-level test here
+    orig_fwd = type(flow.decoder).forward
+
+    def fwd(self, mu, mask, spks, cond, n_timesteps=10, **kw):
+        return orig_fwd(self, mu=mu, mask=mask, spks=spks, cond=cond, n_timesteps=2, **kw)
+    type(flow.decoder).forward = fwd
+    orig_randn_like = torch.randn_like
+    torch.randn_like = lambda t, **kw: torch.zeros_like(t)
+    M.time.sleep = lambda s: None
+    try:
+        out = {}
+        for stream in (False, True):
+            m = M.CosyVoice2Model(ScriptedLLM(), flow, hift)
+            m.token_hop_len, m.token_max_hop_len = 5, 20
+            with torch.inference_mode():
+                chunks = [o["tts_speech"] for o in m.tts(text=u["text"], flow_embedding=u["flow_embedding"], llm_embedding=u["llm_embedding"],
+                                                        prompt_text=u["prompt_text"], llm_prompt_speech_token=u["llm_prompt_speech_token"],
+                                                        flow_prompt_speech_token=u["flow_prompt_speech_token"], prompt_speech_feat=u["prompt_speech_feat"],
+                                                        stream=stream)]
+            key = "stream" if stream else "offline"
+            out[key + "_n"] = np.array([c.shape[1] for c in chunks])
+            out[key] = torch.cat(chunks, 1)
+        # speed != 1 (cli/model.py:320-322)
+        m = M.CosyVoice2Model(ScriptedLLM(), flow, hift)
+        with torch.inference_mode():
+            out["speed"] = next(iter(m.tts(text=u["text"], flow_embedding=u["flow_embedding"], llm_embedding=u["llm_embedding"], prompt_text=u["prompt_text"],
+                                           llm_prompt_speech_token=u["llm_prompt_speech_token"], flow_prompt_speech_token=u["flow_prompt_speech_token"],
+                                           prompt_speech_feat=u["prompt_speech_feat"], stream=False, speed=1.3)))["tts_speech"]
+    finally:
+        torch.randn_like = orig_randn_like
+        type(flow.decoder).forward = orig_fwd
+    save("model_tiny", tokens=np.array(tokens), **out)
+
+
+def golden_estimator_module():
+    """B3: cosyvoice_amd.flow.EstimatorModule (an nn.Module over the product estimator) dropped into the REAL ConditionalCFM.forward_estimator /
+    solve_euler (flow_matching.py:71-153).  There is no GPU in the build container, so the product estimator is driven through the CPU-emulator
+    build of the kernels; what is checked here is the nn.Module branch of forward_estimator, the in-place buffer reuse of solve_euler (:103-108)
+    and the dtype / layout contract.  The test re-runs the same comparison against the stored result."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from emu.build_emu import build_emu
+    from cosyvoice_amd._lib import Lib
+    from cosyvoice_amd.flow import CausalMaskedDiffWithXvec, EstimatorModule
+    cfg = W.ref_small_flow()
+    flow = build_ref_flow(cfg)
+    lib = Lib(build_emu(), allow_emulated=True)
+    mine = CausalMaskedDiffWithXvec(W.make_flow(cfg), cfg, lib=lib)
+    g = torch.Generator().manual_seed(17)
+    T = 23
+    mu = torch.randn(1, 80, T, generator=g); spks = torch.randn(1, 80, generator=g); cond = torch.randn(1, 80, T, generator=g)
+    mask = torch.ones(1, 1, T)
+    with torch.inference_mode():
+        want, _ = flow.decoder(mu=mu, mask=mask, spks=spks, cond=cond, n_timesteps=3, streaming=False)
+        flow.decoder.estimator = EstimatorModule(mine)               # the swap a maintainer would do (INTEGRATION.md section 2)
+        assert isinstance(flow.decoder.estimator, torch.nn.Module)
+        got, _ = flow.decoder(mu=mu, mask=mask, spks=spks, cond=cond, n_timesteps=3, streaming=False)
+    err = (got - want).abs().max().item()
+    print("EstimatorModule inside the real solve_euler: max |diff| = %.2e" % err)
+    assert err < 1e-3, err
+    save("estimator_module", mu=mu, spks=spks, cond=cond, out=want)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["llm", "flow", "hift", "glue"]
     for w in which:

@@ -234,3 +234,35 @@ def test_bf16_mode_waveform_snr(lib, tiny):
     snr = 10 * torch.log10(w32.pow(2).sum() / (w32 - w16).pow(2).sum().clamp_min(1e-20))
     print("bf16 flow -> waveform SNR %.1f dB" % snr.item())
     assert snr.item() >= 30.0, snr.item()
+
+
+def test_estimator_module_contract(lib):
+    """B3: EstimatorModule is an nn.Module (the branch of the reference's forward_estimator, flow_matching.py:126-128), takes the reference's
+    layouts, retains nothing, and reproduces what the REAL ConditionalCFM.solve_euler produced with the REAL estimator
+    (tests/golden/estimator_module.npz, generated by running this module inside the reference's own solve_euler / forward_estimator)."""
+    import numpy as np, os
+    from cosyvoice_amd.flow import EstimatorModule
+    from oracle import flow as OF2
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(os.path.dirname(__file__), "golden", "estimator_module.npz")).items()}
+    cfg = W.ref_small_flow()
+    sd = W.make_flow(cfg)
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib)
+    est = EstimatorModule(flow)
+    assert isinstance(est, torch.nn.Module) and len(list(est.parameters())) == 0
+    T = g["mu"].shape[2]
+    # the reference's solve_euler restated around the module (flow_matching.py:71-124): 3 steps, cosine schedule, CFG 0.7, buffer reuse
+    x = flow.decoder.rand_noise[:, :, :T].clone()
+    t_span = 1 - torch.cos(torch.linspace(0, 1, 4) * 0.5 * torch.pi)
+    t, dt = t_span[0], t_span[1] - t_span[0]
+    x_in, mask_in, mu_in = torch.zeros(2, 80, T), torch.ones(2, 1, T), torch.zeros(2, 80, T)
+    t_in, spks_in, cond_in = torch.zeros(2), torch.zeros(2, 80), torch.zeros(2, 80, T)
+    for step in range(1, 4):
+        x_in[:] = x; mu_in[0] = g["mu"][0]; t_in[:] = t; spks_in[0] = g["spks"][0]; cond_in[0] = g["cond"][0]
+        d = est(x_in, mask_in, mu_in, t_in, spks_in, cond_in, streaming=False)
+        assert d.dtype == x_in.dtype and d.device == x_in.device and d.shape == (2, 80, T)
+        d0, d1 = d[0:1].cpu(), d[1:2].cpu()
+        x = x + dt * ((1.0 + 0.7) * d0 - 0.7 * d1)
+        t = t + dt
+        if step < 3:
+            dt = t_span[step + 1] - t
+    torch.testing.assert_close(x, g["out"], rtol=1e-3, atol=1e-3)

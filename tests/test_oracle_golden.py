@@ -127,3 +127,25 @@ def test_hift_matches_reference():
     torch.testing.assert_close(source[:, :, :960], g["cache"], rtol=0, atol=0)
     torch.testing.assert_close(OH.decode(sd, cfg, g["mel"], g["source_c"]), g["speech_c"], rtol=1e-4, atol=1e-4)
     assert (g["f0"] > cfg.voiced_thr).any() and (g["f0"] < cfg.voiced_thr).any()      # fixture has voiced and unvoiced frames
+
+
+def test_pipeline_matches_reference_model():
+    """oracle/model.py (token2wav, streaming chunk schedule, caches, fade, speed) against the REAL cosyvoice.cli.model.CosyVoice2Model
+    driving the real tiny flow + HiFT (tests/golden/make_golden.py::golden_model)."""
+    import dataclasses
+    from oracle import model as OM
+    g = load("model_tiny")
+    lc, _, hc = W.tiny()
+    fc = dataclasses.replace(W.ref_small_flow(), chunk=5, n_timesteps=2)
+    sds = (None, W.make_flow(fc), W.make_hift(hc))
+    u = W.synthetic_utterance(lc, fc, n_prompt_tok=8, n_prompt_text=4, n_text=2, seed=21)
+    tokens = g["tokens"].tolist()
+    pipe = OM.Pipeline(sds, (lc, fc, hc), token_hop_len=5, n_timesteps=2)
+    for key, stream in (("offline", False), ("stream", True)):
+        outs = pipe.tts(tokens, u, stream=stream)
+        assert [o.shape[1] for o in outs] == g[key + "_n"].tolist()                # the chunk schedule of the reference loop
+        # waveform tolerance as in test_hift_matches_reference: phase integration amplifies fp32 round-off of f0
+        torch.testing.assert_close(torch.cat(outs, 1), g[key], rtol=0, atol=5e-3)
+    assert len(g["stream_n"]) == 3
+    sp = pipe.tts(tokens, u, stream=False, speed=1.3)[0]
+    torch.testing.assert_close(sp, g["speed"], rtol=0, atol=5e-3)
