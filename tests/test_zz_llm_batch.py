@@ -1,19 +1,11 @@
 """Lock-step batched decode (llm_batch_kernels.h): a sequence decoded in a batch must yield exactly the tokens it yields alone - and
-exactly the oracle's.  New this round and not yet run on hardware: on the MI355X these tests are opt-in (CV_TEST_BATCH_DECODE=1) until
-the kernels have been validated there; under the CPU emulator (guard-page memory) they always run."""
-import os
-
+exactly the oracle's.  Runs under the CPU emulator (guard-page memory) and on the MI355X."""
 import pytest
 import torch
 
 from cosyvoice_amd.llm import Qwen2LM
 from oracle import llm as OL
 from oracle import weights as W
-
-
-def _skip_unvalidated(lib):
-    if not lib.emulated and os.environ.get("CV_TEST_BATCH_DECODE") != "1":
-        pytest.skip("batched decode has not been validated on hardware yet (set CV_TEST_BATCH_DECODE=1)")
 
 
 def _req(cfg, seed, n_text, n_prompt_text, n_prompt_tok):
@@ -23,7 +15,6 @@ def _req(cfg, seed, n_text, n_prompt_text, n_prompt_tok):
 
 @pytest.mark.parametrize("use_graph", [True, False])
 def test_batch_matches_single_and_oracle(lib, use_graph):
-    _skip_unvalidated(lib)
     if lib.emulated and not use_graph:
         pytest.skip("eager launches replay the same closures as the captured graph under the emulator")
     cfg = W.tiny()[0]
@@ -50,7 +41,6 @@ def test_batch_matches_single_and_oracle(lib, use_graph):
 
 
 def test_batch_of_eight_and_long_context(lib):
-    _skip_unvalidated(lib)
     cfg = W.tiny()[0]
     sd = W.make_llm(cfg)
     lm = Qwen2LM(sd, cfg, lib=lib, max_len=256, sampling="greedy", decode_chunk=8)
@@ -65,7 +55,6 @@ def test_batch_of_eight_and_long_context(lib):
 def test_continuous_batching(lib):
     """inference_queue: 7 requests through 3 slots - finished slots are re-filled while the others keep decoding; every request gets
     exactly the tokens it gets alone."""
-    _skip_unvalidated(lib)
     cfg = W.tiny()[0]
     sd = W.make_llm(cfg)
     lm = Qwen2LM(sd, cfg, lib=lib, max_len=160, sampling="greedy", decode_chunk=4)
@@ -79,7 +68,6 @@ def test_continuous_batching(lib):
 
 def test_model_tts_batch(lib):
     """CosyVoice2Model.tts_batch == tts() per request (same tokens from the batched LM, same flow / HiFT)."""
-    _skip_unvalidated(lib)
     import dataclasses
     from cosyvoice_amd.model import CosyVoice2Model
     lc, fc, hc = W.tiny()
