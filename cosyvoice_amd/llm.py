@@ -178,7 +178,8 @@ class Qwen2LM:
     def inference_batch(self, requests, max_token_text_ratio=20, min_token_text_ratio=2):
         """Up to 8 requests decoded in lock step on this handle (BASELINE.json configs[2]/[3]; the reference batches through vLLM,
         cli/model.py:281-290): every weight matrix is streamed once per step for all sequences (llm_batch_kernels.h).  `requests` is a
-        list of dicts with `text`, `prompt_text`, `prompt_speech_token` ([1, n] id tensors).  Returns one token list per request - the
+        list of dicts with `text`, `prompt_text`, `prompt_speech_token` ([1, n] id tensors) and, optionally, per-request `min_token_text_ratio` /
+        `max_token_text_ratio`.  Returns one token list per request - the
         same tokens `inference()` yields for that request alone (the per-sequence arithmetic is identical)."""
         nb = len(requests)
         assert 1 <= nb <= 8, "1..8 requests per batch"
@@ -189,7 +190,8 @@ class Qwen2LM:
             for i, r in enumerate(requests):
                 lm_input = self.build_lm_input(r["text"], r["prompt_text"], r["prompt_speech_token"])
                 n_text = int(r["text"].shape[1])
-                min_len, max_len = int(n_text * min_token_text_ratio), int(n_text * max_token_text_ratio)
+                min_len = int(n_text * r.get("min_token_text_ratio", min_token_text_ratio))
+                max_len = int(n_text * r.get("max_token_text_ratio", max_token_text_ratio))
                 if max_len > 0:
                     max_len = self.clamp_max_len(lm_input.shape[0], min_len, max_len, "request %d" % i)
                 sp = self.make_sampling(min_len, max(max_len, 1))
@@ -230,7 +232,8 @@ class Qwen2LM:
                     nxt += 1
                     lm_input = self.build_lm_input(r["text"], r["prompt_text"], r["prompt_speech_token"])
                     n_text = int(r["text"].shape[1])
-                    min_len, max_len = int(n_text * min_token_text_ratio), int(n_text * max_token_text_ratio)
+                    min_len = int(n_text * r.get("min_token_text_ratio", min_token_text_ratio))
+                    max_len = int(n_text * r.get("max_token_text_ratio", max_token_text_ratio))
                     if max_len == 0:
                         done.append((i, []))
                         continue

@@ -193,7 +193,8 @@ class CosyVoice2Model:
         finished ones.  Yields (request_index, {'tts_speech': [1, S]}) in completion order; each waveform equals tts(**request)."""
         import queue
         q = queue.Queue()
-        lm_reqs = [dict(text=r["text"], prompt_text=r["prompt_text"], prompt_speech_token=r["llm_prompt_speech_token"]) for r in requests]
+        lm_reqs = [dict(text=r["text"], prompt_text=r["prompt_text"], prompt_speech_token=r["llm_prompt_speech_token"],
+                        **{k: r[k] for k in ("min_token_text_ratio", "max_token_text_ratio") if k in r}) for r in requests]
 
         def produce():
             try:

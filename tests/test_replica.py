@@ -64,3 +64,39 @@ def test_two_replicas_match_single_process(tmp_path, emu_lib):
                                  prompt_speech_token_len=t(6), embedding=None, max_token_text_ratio=3, min_token_text_ratio=3))
         assert toks == want and len(toks) >= 1              # same tokens whichever replica ran the utterance
     assert got["elapsed"] >= 0
+
+
+def test_bench_refuses_to_mislabel_gpu_count():
+    """`python bench.py --gpus N` outside a launcher spawns N ranks itself and fails loudly when the node has fewer GPUs (this container has
+    none); under a launcher a WORLD_SIZE that disagrees with --gpus is an error - never an N=1 run reported under an N-GPU label."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 requested but only" in r.stderr and not r.stdout.strip()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()
+
+
+def test_mixed64_workload_is_seeded_and_fully_assigned():
+    """BASELINE.json configs[3] workload of bench.py: 64 seeded utterances, equal mix of 125/250/375/500 tokens; every rank count deals each
+    utterance to exactly one rank with balanced audio."""
+    import importlib.util, os
+    import torch
+    from cosyvoice_amd.configs import tiny
+    from cosyvoice_amd.replica import shard_requests
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    cfgs = tiny()
+    a, costs = bench.mixed_requests(cfgs, torch.device("cpu"))
+    b, _ = bench.mixed_requests(cfgs, torch.device("cpu"))
+    assert len(a) == 64 and sorted(set(costs)) == [125, 250, 375, 500] and all(costs.count(c) == 16 for c in set(costs))
+    assert all(torch.equal(x["text"], y["text"]) and torch.equal(x["prompt_speech_feat"], y["prompt_speech_feat"]) for x, y in zip(a, b))
+    assert not torch.equal(a[0]["text"], a[4]["text"])
+    for world in (1, 2, 4, 8):
+        shards = shard_requests(costs, world)
+        assert sorted(i for s in shards for i in s) == list(range(64))
+        loads = [sum(costs[i] for i in s) for s in shards]
+        assert max(loads) - min(loads) <= 125
