@@ -9,9 +9,11 @@
 #include <map>
 #include <tuple>
 #include <cmath>
+#include <cstdlib>
 #include "ops.h"
 #include "tensor_map.h"
 #include "flow_kernels.h"
+#include "flow_fused.h"
 
 using namespace cv;
 
@@ -45,6 +47,10 @@ struct cv_flow {
     // workspaces
     DevBuf e_x, e_xe, e_n, e_qkv, e_qu, e_qv, e_pe, e_p, e_bd, e_att, e_ff, e_x2, e_ctx;    // encoder
     DevBuf s_in, s_a, s_b, s_c, s_n, s_qkv, s_att, s_ff, s_skip, s_cat, s_out;                    // estimator
+    DevBuf h_qk, h_vt, h_att, h_ff;                                                           // estimator, fused bf16 pipeline (flow_fused.h)
+    int vt_pitch = 0;                  // row pitch of V^T = round_up(T capacity, 64)
+    int fused = 1;                     // bf16 mode: LN-prologue GEMMs + bf16 activations + bf16 flash attention for the transformer blocks
+    int flow_tile = 0, attn_waves = 4; // tuning knobs of the fused pipeline (options "flow_tile": 0 = 64x64, 1 = 64x128, 2 = 32x64; "attn_waves": 2 | 4)
     DevBuf t_val, t_sin, t_h, t_emb, t_mlp;                                                   // time embeddings
     DevBuf f_tok, f_h, f_mu, f_spk, f_spkn, f_cond, f_x, f_ones;                              // inference glue
     int enc_cap = 0, est_cap = 0, t_cap = 0, inf_cap = 0;
@@ -133,7 +139,12 @@ static void flow_finalize(cv_flow* m) {
 
 // precision of the Linear / Conv1d products issued by the current entry point (set from the handle's option for the duration of a call)
 static thread_local int tl_bf16_mfma = 0;
-struct PrecisionScope { int prev; explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma) { tl_bf16_mfma = m->bf16_mfma; } ~PrecisionScope() { tl_bf16_mfma = prev; } };
+static thread_local int tl_flow_tile = 0, tl_attn_waves = 4;     // tuning knobs of the fused pipeline, per call like the precision
+struct PrecisionScope {
+    int prev, pt, pw;
+    explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves) { tl_bf16_mfma = m->bf16_mfma; tl_flow_tile = m->flow_tile; tl_attn_waves = m->attn_waves; }
+    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; }
+};
 
 // ---- generic conv/linear on channel-last activations -----------------------------------------------------------------
 // rows: M per batch, `a_rows` valid input rows per batch (zero padding outside), tap j reads row (m + j*dil - pad_left)
@@ -250,6 +261,13 @@ static void est_reserve(cv_flow* m, int T) {
     m->s_in.ensure(R * 4 * c.mel * f); m->s_a.ensure(R * C * f); m->s_b.ensure(R * C * f); m->s_c.ensure(R * C * f); m->s_n.ensure(R * C * f);
     m->s_qkv.ensure(R * 3 * c.est_heads * 64 * f); m->s_att.ensure(R * c.est_heads * 64 * f); m->s_ff.ensure(R * 4 * C * f);
     m->s_skip.ensure(R * C * f); m->s_cat.ensure(R * 2 * C * f); m->s_out.ensure(R * c.mel * f);
+    {   // bf16 activations of the fused pipeline; V^T is [2][heads * 64][pitch] and its never-written pad columns must stay finite (0 x P)
+        const size_t inner = (size_t)c.est_heads * 64, pitch = (size_t)(T + T / 2 + 63) / 64 * 64;
+        m->h_qk.ensure(R * 2 * inner * 2); m->h_att.ensure(R * inner * 2); m->h_ff.ensure(R * 4 * C * 2);
+        const size_t before = m->h_vt.bytes;
+        m->h_vt.ensure(2 * inner * pitch * 2);
+        if (m->h_vt.bytes != before) { CV_HIP(hipMemset(m->h_vt.p, 0, m->h_vt.bytes)); m->vt_pitch = (int)(m->h_vt.bytes / (2 * inner * 2) / 64 * 64); }
+    }
     m->est_cap = T;
 }
 static void time_reserve(cv_flow* m, int n) {
@@ -269,6 +287,39 @@ static void time_embed(cv_flow* m, int n, hipStream_t s) {
     for (size_t i = 0; i < m->stages.size(); ++i)
         lin_cl(m->stages[i].res.mlp, m->t_emb.as<float>(), n, m->t_mlp.as<float>() + i * (size_t)n * c.est_ch, ACT_NONE, nullptr, s, ACT_MISH);
     (void)tdim;
+}
+
+
+// ---- fused bf16 pipeline (flow_fused.h) --------------------------------------------------------------------------------
+// out = act(LN(x) W^T + b) as bf16; columns >= n_row go to the transposed, key-permuted V^T
+static void ln_gemm_bf16(const Lin& l, const LN* ln, float eps, const float* x, int M, int act, bf16_t* out, int ldo, int n_row,
+                         bf16_t* outT, long long t_batch, int ldt, int rows_per_batch, hipStream_t s) {
+    CV_CHECK(l.bf16 && l.K % 32 == 0 && l.K <= 256 && l.taps == 1 && l.N % 4 == 0, "ln_gemm_bf16: needs bf16 weights, K % 32 == 0, K <= 256");
+    FlowGemmArgs a{};
+    a.A = x; a.lda = l.K; a.gamma = ln ? ln->g : nullptr; a.beta = ln ? ln->b : nullptr; a.eps = eps;
+    a.W = reinterpret_cast<const bf16_t*>(l.w); a.Kp = l.Kp; a.bias = l.b; a.M = M; a.N = l.N; a.K = l.K; a.act = act;
+    a.out = out; a.ldo = ldo; a.n_row = n_row; a.outT = outT; a.t_batch = t_batch; a.ldt = ldt; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
+    const int tile = tl_flow_tile;
+    if (n_row < l.N) CV_CHECK(n_row % 128 == 0 || (tile != 1 && n_row % 64 == 0), "ln_gemm_bf16: the transposed section must start on a tile boundary");
+    if (tile == 1) { const unsigned g = ((M + 63) / 64) * ((l.N + 127) / 128); hipLaunchKernelGGL((flow_gemm_kernel<64, 128, 1, 0>), dim3(g), dim3(256), 0, s, a); }
+    else if (tile == 2) { const unsigned g = ((M + 31) / 32) * ((l.N + 63) / 64); hipLaunchKernelGGL((flow_gemm_kernel<32, 64, 1, 0>), dim3(g), dim3(256), 0, s, a); }
+    else { const unsigned g = ((M + 63) / 64) * ((l.N + 63) / 64); hipLaunchKernelGGL((flow_gemm_kernel<64, 64, 1, 0>), dim3(g), dim3(256), 0, s, a); }
+}
+// C = A_bf16 W^T + b (+ res), fp32
+static void gemm_bf16_res(const Lin& l, const bf16_t* A, int lda, int M, float* C, const float* res, hipStream_t s) {
+    CV_CHECK(l.bf16 && l.K % 32 == 0 && l.taps == 1 && l.N % 4 == 0 && lda % 8 == 0, "gemm_bf16_res: needs bf16 weights, K % 32 == 0");
+    FlowGemmArgs a{};
+    a.A = A; a.lda = lda; a.W = reinterpret_cast<const bf16_t*>(l.w); a.Kp = l.Kp; a.bias = l.b; a.M = M; a.N = l.N; a.K = l.K;
+    a.C = C; a.ldc = l.N; a.res = res; a.n_row = l.N;
+    const unsigned g = ((M + 31) / 32) * ((l.N + 63) / 64);
+    hipLaunchKernelGGL((flow_gemm_kernel<32, 64, 0, 1>), dim3(g), dim3(256), 0, s, a);
+}
+static void attn_flow(const bf16_t* qk, int ld, int inner, const bf16_t* vt, long long vt_batch, int ldt, bf16_t* o, int B, int H, int T, int chunk, hipStream_t s) {
+    AttnFlowArgs a{};
+    a.q = qk; a.k = qk + inner; a.ld = ld; a.vt = vt; a.vt_batch = vt_batch; a.ldt = ldt; a.o = o; a.ldo = inner;
+    a.B = B; a.H = H; a.T = T; a.scale = 0.125f; a.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; a.chunk = chunk;
+    if (tl_attn_waves == 2) hipLaunchKernelGGL((attn_flow_kernel<2>), dim3((unsigned)(((T + 31) / 32) * H * B)), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL((attn_flow_kernel<4>), dim3((unsigned)(((T + 63) / 64) * H * B)), dim3(256), 0, s, a);
 }
 
 // s_in: packed [2][T][4*mel]; t_row: which row of the time tables; t_shared: both CFG rows use the same row;
@@ -294,7 +345,18 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
         conv_cl(st.res.conv2, xb, T, T, 2, 2, 1, x, ACT_NONE, 0.f, nullptr, s);
         ln_rows(st.res.ln2, x, xb, R, C, 1e-5f, s, ACT_MISH);
         conv_cl(st.res.res, cur, T, T, 2, 0, 1, x, ACT_NONE, 0.f, xb, s);           // x = res_conv(input) + h
+        const bool fused = tl_bf16_mfma && m->fused && C <= 256 && m->wbf16;
         for (const TBlockW& t : st.tf) {      // matcha BasicTransformerBlock (self-attention + exact-erf GELU feed-forward)
+            if (fused) {                      // flow_fused.h: 5 launches, bf16 activations, same rounding points as the path below
+                bf16_t* qk = m->h_qk.as<bf16_t>(); bf16_t* vt = m->h_vt.as<bf16_t>(); bf16_t* ab = m->h_att.as<bf16_t>(); bf16_t* fb = m->h_ff.as<bf16_t>();
+                const long long vt_batch = (long long)inner * m->vt_pitch;
+                ln_gemm_bf16(t.qkv, &t.norm1, 1e-5f, x, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
+                attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, 2, H, T, chunk, s);
+                gemm_bf16_res(t.out, ab, inner, (int)R, x, x, s);
+                ln_gemm_bf16(t.ff1, &t.norm3, 1e-5f, x, (int)R, ACT_GELU_ERF, fb, 4 * C, 4 * C, nullptr, 0, 0, 0, s);
+                gemm_bf16_res(t.ff2, fb, 4 * C, (int)R, x, x, s);
+                continue;
+            }
             ln_rows(t.norm1, x, n, R, C, 1e-5f, s);
             lin_cl(t.qkv, n, R, qkv, ACT_NONE, nullptr, s);
             AttnArgs at{};
@@ -396,6 +458,9 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         CV_CHECK(m && name, "null argument");
         if (std::string(name) == "use_graph") { m->use_graph = value != 0; drop_graphs(m); }
         else if (std::string(name) == "bf16_mfma") { m->bf16_mfma = value != 0; drop_graphs(m); }      // captured graphs bake the kernel choice
+        else if (std::string(name) == "flow_tile") { CV_CHECK(value >= 0 && value <= 2, "flow_tile must be 0, 1 or 2"); m->flow_tile = value; drop_graphs(m); }
+        else if (std::string(name) == "attn_waves") { CV_CHECK(value == 2 || value == 4, "attn_waves must be 2 or 4"); m->attn_waves = value; drop_graphs(m); }
+        else if (std::string(name) == "fused") { m->fused = value != 0; drop_graphs(m); }              // bf16 mode: fused transformer blocks (flow_fused.h) on / off
         else throw Error(std::string("unknown option ") + name);
     });
 }

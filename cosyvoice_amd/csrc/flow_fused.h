@@ -1,0 +1,381 @@
+// Fused bf16 pipeline of the flow estimator's transformer blocks (matcha BasicTransformerBlock inside CausalConditionalDecoder,
+// cosyvoice/flow/decoder.py:405-494) for gfx950, "bf16" precision mode only (the fp32 mode keeps the exact-fp32 kernels).
+//
+// Per block the round-1 path launched LN, QKV, attention, out, LN, FF1, FF2 with fp32 activations between them (7 launches, every
+// operand rounded to bf16 while it was staged).  Here the rounding points are the same, but the rounded value is what travels:
+//   flow_gemm<LN prologue, bf16 out>   x (fp32 residual stream) -> LayerNorm in the prologue -> Q | K (bf16, row-major) and V^T (bf16,
+//                                      transposed + key-permuted the way the P.V MFMA wants it), or -> GELU(FF1) (bf16)
+//   attn_flow                          bf16 Q / K / V^T in, flash attention with fp32 softmax, bf16 out
+//   flow_gemm<bf16 A, fp32 out + res>  out-projection and FF2, accumulated onto the fp32 residual stream
+// 5 launches per block, half the activation bytes, no conversion or transposition work inside the attention's K/V loop.
+// All products: v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Statistics, softmax, residuals: fp32.
+#pragma once
+#include "common.h"
+#include "attention.h"
+
+namespace cv {
+
+struct FlowGemmArgs {
+    const void* A; int lda;                       // AMODE 0: bf16 [M][lda]     AMODE 1: fp32 [M][lda]
+    const float* gamma; const float* beta; float eps;   // AMODE 1: LayerNorm over the K channels in the prologue (gamma == null: none)
+    const bf16_t* W; int Kp;                      // [N][Kp] bf16 (cosyvoice_amd/weights.py layout), K % 32 == 0 so Kp == K
+    const float* bias;                            // [N] or null
+    int M, N, K;
+    int act;                                      // OMODE 0: epilogue activation
+    bf16_t* out; int ldo; int n_row;              // OMODE 0: columns [0, n_row) -> out[m][n] (row-major bf16)
+    bf16_t* outT; long long t_batch; int ldt; int rows_per_batch;   // columns [n_row, N) -> outT[m / rpb][n - n_row][perm(m % rpb)]
+    float* C; int ldc; const float* res;          // OMODE 1: C[m][n] = acc + bias (+ res[m][n]), fp32
+};
+
+// key (time) index -> column of the transposed V tile: inside every 32-key block, key 16 s + 4 g + r sits at column 8 g + 4 s + r, which
+// makes the 8 bf16 a lane reads for the P.V MFMA (k-slot g) exactly the keys whose probabilities that lane holds after S^T = K.Q^T.
+__device__ __forceinline__ int vt_col(int t) { return (t & ~31) + ((t >> 2) & 3) * 8 + ((t >> 4) & 1) * 4 + (t & 3); }
+
+// BM x BN output tile per workgroup (256 threads, 2 x 2 waves), K staged in chunks of 256 (the whole K for the LN-prologue GEMMs).
+template <int BM, int BN, int AMODE, int OMODE>
+__global__ __launch_bounds__(256) void flow_gemm_kernel(FlowGemmArgs p) {
+    constexpr int KC = 256, LDK = KC / 2 + 4;                 // LDS row pitch in dwords (bf16 pairs + 4 dwords of padding)
+    constexpr int TM = BM / 32, TN = BN / 32;                 // 16 x 16 MFMA tiles per wave (wave tile = BM/2 x BN/2)
+    constexpr int AR = BM / 16;                               // AMODE 1: rows per 16-lane group
+    constexpr int AV = BM / 8, WV = BN / 8;                   // 16-byte chunks per thread and K chunk (AMODE 0 A tile / W tile)
+    static_assert(BM % 32 == 0 && BN % 32 == 0, "tile must split over 2 x 2 waves of 16 x 16 MFMA tiles");
+    __shared__ __attribute__((aligned(16))) unsigned As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) unsigned Ws[BN * LDK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
+    const int ntn = (p.N + BN - 1) / BN;
+    const int bl = xcd_remap((int)blockIdx.x, (int)gridDim.x);        // an XCD walks the N tiles of a band of rows: A crosses the fabric once
+    const int m0 = (bl / ntn) * BM, n0 = (bl % ntn) * BN;
+    const int nchunks = (p.K + KC - 1) / KC;
+    const bool transposed = OMODE == 0 && n0 >= p.n_row;              // uniform: this tile belongs to the V^T section
+
+    v4f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    // ---- W chunk: thread t stages 16-byte pieces v = t + 256 i: row v / 32, k = 8 (v % 32)
+    u32x4_t rw[WV];
+    auto load_w = [&](int kc0) {
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + 256 * i, n = min(n0 + v / 32, p.N - 1), k = kc0 + 8 * (v % 32);
+            rw[i] = *reinterpret_cast<const u32x4_t*>(p.W + (long long)n * p.Kp + min(k, p.Kp - 8));      // clamped: steps beyond Kp are never multiplied
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < WV; ++i) { const int v = tid + 256 * i; *reinterpret_cast<u32x4_t*>(&Ws[(v / 32) * LDK + 4 * (v % 32)]) = rw[i]; }
+    };
+    // ---- A chunk, AMODE 0 (bf16 in memory): same piece mapping as W
+    u32x4_t ra[AMODE == 0 ? AV : 1];
+    auto load_a = [&](int kc0) {
+        if constexpr (AMODE == 0) {
+#pragma unroll
+            for (int i = 0; i < AV; ++i) {
+                const int v = tid + 256 * i, m = min(m0 + v / 32, p.M - 1), k = kc0 + 8 * (v % 32);
+                ra[i] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const bf16_t*>(p.A) + (long long)m * p.lda + min(k, p.K - 8));
+            }
+        }
+    };
+    auto store_a = [&]() {
+        if constexpr (AMODE == 0) {
+#pragma unroll
+            for (int i = 0; i < AV; ++i) { const int v = tid + 256 * i; *reinterpret_cast<u32x4_t*>(&As[(v / 32) * LDK + 4 * (v % 32)]) = ra[i]; }
+        }
+    };
+    auto compute = [&](int ksteps) {
+        for (int kg = 0; kg < ksteps; ++kg) {                 // k-step = 32 values = 16 dwords; lane (r = lane & 15, g = lane >> 4) supplies k = 8 g .. 8 g + 7
+            uint4 af[TM], wf[TN];
+            const int kd = kg * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(&As[(wm * (BM / 2) + i * 16 + (lane & 15)) * LDK + kd]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const uint4*>(&Ws[(wn * (BN / 2) + j * 16 + (lane & 15)) * LDK + kd]);
+            if (transposed) {                                 // activations are the MFMA "A": a lane ends with 4 consecutive ROWS m of one column n
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, af[i]), __builtin_bit_cast(v8bf, wf[j]), acc[i][j], 0, 0, 0);
+            } else {                                          // weights are the MFMA "A": a lane ends with 4 consecutive COLUMNS n of one row m
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, wf[j]), __builtin_bit_cast(v8bf, af[i]), acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    if constexpr (AMODE == 1) {
+        // Whole K (<= 256) at once.  A 16-lane group owns AR rows; lane `sub` holds channels 4 sub + 64 j.  Every load of the tile (W included)
+        // is requested before the first reduction; the LayerNorm statistics are two-pass on registers (mean, then centred variance,
+        // like torch.nn.LayerNorm and norm_rows_kernel), reduced over the 16 lanes with DPP row operations.
+        const int grp = tid >> 4, sub = tid & 15;
+        float4 x[AR][4];
+        load_w(0);
+#pragma unroll
+        for (int r = 0; r < AR; ++r) {
+            const int m = min(m0 + grp + 16 * r, p.M - 1);
+            const float* xr = reinterpret_cast<const float*>(p.A) + (long long)m * p.lda;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * sub + 64 * j;
+                float4 t = *reinterpret_cast<const float4*>(xr + min(k, p.K - 4));
+                if (k >= p.K) t = make_float4(0.f, 0.f, 0.f, 0.f);
+                x[r][j] = t;
+            }
+        }
+        float4 ga[4], be[4];
+        if (p.gamma) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = min(4 * sub + 64 * j, p.K - 4);
+                ga[j] = *reinterpret_cast<const float4*>(p.gamma + k); be[j] = *reinterpret_cast<const float4*>(p.beta + k);
+            }
+        }
+        const float invK = 1.f / (float)p.K;
+#pragma unroll
+        for (int r = 0; r < AR; ++r) {
+            if (p.gamma) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s += x[r][j].x + x[r][j].y + x[r][j].z + x[r][j].w;          // channels >= K hold zeros
+                const float mean = group16_sum(s) * invK;
+                float q = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * sub + 64 * j < p.K) { const float a = x[r][j].x - mean, b = x[r][j].y - mean, c = x[r][j].z - mean, d = x[r][j].w - mean; q += a * a + b * b + c * c + d * d; }
+                const float rstd = rsqrtf(group16_sum(q) * invK + p.eps);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    x[r][j].x = (x[r][j].x - mean) * rstd * ga[j].x + be[j].x; x[r][j].y = (x[r][j].y - mean) * rstd * ga[j].y + be[j].y;
+                    x[r][j].z = (x[r][j].z - mean) * rstd * ga[j].z + be[j].z; x[r][j].w = (x[r][j].w - mean) * rstd * ga[j].w + be[j].w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<uint2*>(&As[(grp + 16 * r) * LDK + 2 * sub + 32 * j]) = make_uint2(pack_bf16x2(x[r][j].x, x[r][j].y), pack_bf16x2(x[r][j].z, x[r][j].w));
+        }
+        store_w();
+        __syncthreads();
+        compute(p.K / 32);
+    } else {
+        // K streamed in chunks of 256: the next chunk's loads are in flight under the MFMAs of the current one (register prefetch)
+        load_a(0); load_w(0);
+        for (int c = 0; c < nchunks; ++c) {
+            store_a(); store_w();
+            __syncthreads();
+            if (c + 1 < nchunks) { load_a((c + 1) * KC); load_w((c + 1) * KC); }
+            compute(min(KC, p.K - c * KC) / 32);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue
+    if constexpr (OMODE == 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+                if (n >= p.N) continue;                       // N % 4 == 0 (host check): a group of 4 columns is entirely in or out
+                float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                const long long idx = (long long)m * p.ldc + n;
+                if (p.res) { const float4 r = *reinterpret_cast<const float4*>(p.res + idx); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+                *reinterpret_cast<float4*>(p.C + idx) = v;
+            }
+        }
+    } else if (!transposed) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+                if (n >= p.N || n >= p.n_row) continue;
+                float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                v = apply_act4(p.act, v, 0.f);
+                *reinterpret_cast<uint2*>(p.out + (long long)m * p.ldo + n) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+            }
+        }
+    } else {
+        // V^T section: lane holds rows m .. m + 3 of column n.  Rows of one request are consecutive (m = b rows_per_batch + t) but a group of
+        // four may straddle a 4-aligned key group or two requests when rows_per_batch % 4 != 0, so every element finds its own slot.
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+                if (n >= p.N) continue;
+                const float bn = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+                    if (m >= p.M) continue;
+                    const int b = m / p.rows_per_batch, t = m - b * p.rows_per_batch;
+                    const unsigned u = pack_bf16x2(acc[i][j][r] + bn, 0.f);
+                    p.outT[(long long)b * p.t_batch + (long long)(n - p.n_row) * p.ldt + vt_col(t)] = (bf16_t)(u & 0xffffu);
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Flash attention over bf16 Q / K (row-major [B * T][ld]) and V^T ([B][H * 64][Tp], key-permuted, see vt_col), head_dim 64, bf16 out.
+// One workgroup = NW waves = NW * 16 queries of one (request, head); K and V^T stream through a DOUBLE-buffered LDS ring in 64-key tiles
+// with a register prefetch stage: per tile one barrier, four 16-byte loads and four 16-byte LDS stores per thread - no conversion, no
+// transposition (the QKV GEMM epilogue delivered both).  Scores / softmax / accumulator fp32; masks are index arithmetic (none / chunk).
+// The S^T = K.Q^T -> P -> O^T += V^T.P^T register dataflow is the one of attention_bf16_kernel (attention.h).
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct AttnFlowArgs {
+    const bf16_t* q; const bf16_t* k; int ld;            // q / k: [B * T][ld], head h at column h * 64
+    const bf16_t* vt; long long vt_batch; int ldt;        // vt: [B][H * 64][ldt]
+    bf16_t* o; int ldo;                                   // [B * T][ldo]
+    int B, H, T; float scale; int mask_mode; int chunk;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_flow_kernel(AttnFlowArgs p) {
+    constexpr int NT = NW * 64, BQ = NW * 16, BKV = 64, LDH = 36;          // LDS row pitch in dwords: 64 bf16 + 8 pad
+    constexpr int NI = 512 / NT;                          // 16-byte pieces per thread and operand tile (64 rows x 8 pieces)
+    __shared__ __attribute__((aligned(16))) unsigned Ks[2][BKV * LDH];
+    __shared__ __attribute__((aligned(16))) unsigned Vt[2][64 * LDH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 15, lg = lane >> 4;
+    const int nqb = (p.T + BQ - 1) / BQ, nbl = gridDim.x;
+    const int bl = xcd_remap((int)blockIdx.x, nbl);       // the query tiles of one (request, head) share an XCD: its K / V^T stream through ONE L2
+    const int qb = bl % nqb, h = (bl / nqb) % p.H, b = bl / (nqb * p.H);
+    const int qi = qb * BQ + wave * 16 + lq;
+    const bool qvalid = qi < p.T;
+    const float NEG_INF = -__builtin_huge_valf();
+    const float scale2 = p.scale * 1.4426950408889634f;
+
+    const bf16_t* kb = p.k + (long long)b * p.T * p.ld + h * 64;
+    const bf16_t* vb = p.vt + (long long)b * p.vt_batch + (long long)h * 64 * p.ldt;
+    int kend = p.T;
+    const int qmax_blk = min(p.T - 1, qb * BQ + BQ - 1);
+    if (p.mask_mode == MASK_CHUNK) kend = min(p.T, (qmax_blk / p.chunk + 1) * p.chunk);
+    int klim = p.T;
+    if (p.mask_mode == MASK_CHUNK) klim = min(p.T, (qi / p.chunk + 1) * p.chunk);
+    if (!qvalid) klim = 0;
+
+    // stage pieces: v = tid + NT i -> row v / 8 (key for K, d for V^T), 8 bf16 at column 8 (v % 8)
+    u32x4_t rk[NI], rv[NI];
+    auto load_kv = [&](int kt0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int v = tid + NT * i, row = v >> 3, c8 = (v & 7) * 8;
+            rk[i] = *reinterpret_cast<const u32x4_t*>(kb + (long long)min(kt0 + row, p.T - 1) * p.ld + c8);     // keys >= T are masked below
+            rv[i] = *reinterpret_cast<const u32x4_t*>(vb + (long long)row * p.ldt + kt0 + c8);                    // ldt >= round_up(T, 64): in range, finite
+        }
+    };
+    auto store_kv = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int v = tid + NT * i, row = v >> 3, c4 = (v & 7) * 4;
+            *reinterpret_cast<u32x4_t*>(&Ks[buf][row * LDH + c4]) = rk[i];
+            *reinterpret_cast<u32x4_t*>(&Vt[buf][row * LDH + c4]) = rv[i];
+        }
+    };
+    if (kend > 0) load_kv(0);
+    // Q as the B operand of S^T = K.Q^T: lane (q = lq, g = lg) supplies d = 32 dg + 8 g .. + 7
+    uint4 qf[2];
+    {
+        const bf16_t* qp = p.q + ((long long)b * p.T + (qvalid ? qi : 0)) * p.ld + h * 64;
+#pragma unroll
+        for (int dg = 0; dg < 2; ++dg) {
+            uint4 t = *reinterpret_cast<const uint4*>(qp + dg * 32 + lg * 8);
+            if (!qvalid) t = make_uint4(0u, 0u, 0u, 0u);
+            qf[dg] = t;
+        }
+    }
+    float m_run = NEG_INF, l_run = 0.f;
+    v4f acc[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) acc[d] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int kt0, int buf) {
+        v4f s[4];                                          // s[kt][r] <-> key kt0 + kt*16 + lg*4 + r, query lq
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            v4f sa = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dg = 0; dg < 2; ++dg) {
+                const uint4 kf = *reinterpret_cast<const uint4*>(&Ks[buf][(kt * 16 + lq) * LDH + dg * 16 + lg * 4]);
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, kf), __builtin_bit_cast(v8bf, qf[dg]), sa, 0, 0, 0);
+            }
+            s[kt] = sa;
+        }
+        float mt = NEG_INF;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt0 + kt * 16 + lg * 4 + r;
+                const float x = key < klim ? s[kt][r] * scale2 : NEG_INF;     // log2 units: softmax on v_exp_f32
+                s[kt][r] = x;
+                mt = fmaxf(mt, x);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 16));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = (m_run == NEG_INF) ? 0.f : exp2f(m_run - m_new);
+        float rsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = s[kt][r];
+                const float e = (x == NEG_INF) ? 0.f : exp2f(x - m_new);
+                s[kt][r] = e;
+                rsum += e;                                 // the denominator sums the UNROUNDED probabilities
+            }
+        rsum += __shfl_xor(rsum, 16);
+        rsum += __shfl_xor(rsum, 32);
+        l_run = l_run * alpha + rsum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[d] = acc[d] * alpha;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {                // k-slot (g, 4 s + r) of 32-key block blk is key 32 blk + 16 s + 4 g + r on both operands
+            const uint4 pb = make_uint4(pack_bf16x2(s[2 * blk][0], s[2 * blk][1]), pack_bf16x2(s[2 * blk][2], s[2 * blk][3]),
+                                        pack_bf16x2(s[2 * blk + 1][0], s[2 * blk + 1][1]), pack_bf16x2(s[2 * blk + 1][2], s[2 * blk + 1][3]));
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint4 vf = *reinterpret_cast<const uint4*>(&Vt[buf][(dt * 16 + lq) * LDH + blk * 16 + lg * 4]);
+                acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, vf), __builtin_bit_cast(v8bf, pb), acc[dt], 0, 0, 0);
+            }
+        }
+    };
+
+    // ring: tile t is multiplied out of buffer t & 1 while tile t + 1 is parked in the other buffer and tile t + 2 is in flight in registers
+    if (kend > 0) { store_kv(0); if (BKV < kend) load_kv(BKV); }
+    __syncthreads();
+    for (int kt0 = 0, t = 0; kt0 < kend; kt0 += BKV, ++t) {
+        compute(kt0, t & 1);
+        if (kt0 + BKV < kend) {
+            store_kv((t + 1) & 1);                          // every wave left buffer (t + 1) & 1 before the barrier that ended iteration t - 1
+            if (kt0 + 2 * BKV < kend) load_kv(kt0 + 2 * BKV);
+        }
+        __syncthreads();
+    }
+
+    if (qvalid) {
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        bf16_t* op = p.o + ((long long)b * p.T + qi) * p.ldo + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<uint2*>(op + dt * 16 + lg * 4) = make_uint2(pack_bf16x2(acc[dt][0] * inv, acc[dt][1] * inv), pack_bf16x2(acc[dt][2] * inv, acc[dt][3] * inv));
+    }
+}
+
+}  // namespace cv

@@ -1,0 +1,50 @@
+"""Dev tool (GPU box): wall time of one flow.inference at the U10 size (337 tokens -> T = 674 frames, 10 Euler steps, bf16 mode) for the
+knobs of the fused estimator pipeline (flow_fused.h): fused on / off, LN-GEMM tile, attention workgroup size."""
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cosyvoice_amd import synthetic as W
+from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+
+lc, fc, hc = W.cv2()
+u = W.synthetic_utterance(lc, fc)
+t = lambda n: torch.tensor([n], dtype=torch.int32)
+flow = CausalMaskedDiffWithXvec(W.make_flow(fc), fc, precision="bf16")
+tok = torch.randint(0, fc.vocab, (1, 250), generator=torch.Generator().manual_seed(0), dtype=torch.int32)
+
+
+def run():
+    mel, _ = flow.inference(token=tok, token_len=t(250), prompt_token=u["flow_prompt_speech_token"], prompt_token_len=t(87), prompt_feat=u["prompt_speech_feat"],
+                            prompt_feat_len=t(174), embedding=u["flow_embedding"], streaming=False, finalize=True)
+    return mel
+
+
+def bench(label, reps=8):
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        mel = run()
+    torch.cuda.synchronize()
+    print("%-40s %7.2f ms per flow.inference" % (label, (time.perf_counter() - t0) / reps * 1e3), flush=True)
+    return mel
+
+
+which = sys.argv[1:] or ["all"]
+opt = lambda k, v: flow.lib.cv_flow_set_option(flow._h, k, C.c_int32(v))
+if "all" in which:
+    opt(b"fused", 0); ref = bench("unfused (round-1 path)")
+    for tile in (0, 1, 2):
+        for waves in (4, 2):
+            opt(b"fused", 1); opt(b"flow_tile", tile); opt(b"attn_waves", waves)
+            mel = bench("fused tile=%d attn_waves=%d" % (tile, waves))
+            print("    max |fused - unfused| = %.3e (mel std %.2f)" % ((mel - ref).abs().max().item(), ref.std().item()), flush=True)
+else:
+    opt(b"fused", int(os.environ.get("FUSED", "1"))); opt(b"flow_tile", int(os.environ.get("TILE", "0"))); opt(b"attn_waves", int(os.environ.get("WAVES", "4")))
+    opt(b"use_graph", 0)
+    bench("profile run", reps=1)
