@@ -50,7 +50,9 @@ struct cv_flow {
     DevBuf h_qk, h_vt, h_att, h_ff;                                                           // estimator, fused bf16 pipeline (flow_fused.h)
     int vt_pitch = 0;                  // row pitch of V^T = round_up(T capacity, 64)
     int fused = 1;                     // bf16 mode: LN-prologue GEMMs + bf16 activations + bf16 flash attention for the transformer blocks
-    int flow_tile = 0, attn_waves = 4; // tuning knobs of the fused pipeline (options "flow_tile": 0 = 64x64, 1 = 64x128, 2 = 32x64; "attn_waves": 2 | 4)
+    // tuning knobs of the fused pipeline.  "flow_tile": 0 = by size (one round of workgroups, see ln_gemm_bf16), 1 = 64x64, 2 = 64x128, 3 = 32x64,
+    // 4 = 64x192; "attn_waves": 2 | 4 waves (32 | 64 queries) per workgroup; "attn_kt": 64-key tiles per iteration (1 | 2)
+    int flow_tile = 0, attn_waves = 4, attn_kt = 1;
     DevBuf t_val, t_sin, t_h, t_emb, t_mlp;                                                   // time embeddings
     DevBuf f_tok, f_h, f_mu, f_spk, f_spkn, f_cond, f_x, f_ones;                              // inference glue
     int enc_cap = 0, est_cap = 0, t_cap = 0, inf_cap = 0;
@@ -139,11 +141,13 @@ static void flow_finalize(cv_flow* m) {
 
 // precision of the Linear / Conv1d products issued by the current entry point (set from the handle's option for the duration of a call)
 static thread_local int tl_bf16_mfma = 0;
-static thread_local int tl_flow_tile = 0, tl_attn_waves = 4;     // tuning knobs of the fused pipeline, per call like the precision
+static thread_local int tl_flow_tile = 0, tl_attn_waves = 4, tl_attn_kt = 2;     // tuning knobs of the fused pipeline, per call like the precision
 struct PrecisionScope {
-    int prev, pt, pw;
-    explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves) { tl_bf16_mfma = m->bf16_mfma; tl_flow_tile = m->flow_tile; tl_attn_waves = m->attn_waves; }
-    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; }
+    int prev, pt, pw, pk;
+    explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves), pk(tl_attn_kt) {
+        tl_bf16_mfma = m->bf16_mfma; tl_flow_tile = m->flow_tile; tl_attn_waves = m->attn_waves; tl_attn_kt = m->attn_kt;
+    }
+    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; }
 };
 
 // ---- generic conv/linear on channel-last activations -----------------------------------------------------------------
@@ -299,11 +303,18 @@ static void ln_gemm_bf16(const Lin& l, const LN* ln, float eps, const float* x, 
     a.A = x; a.lda = l.K; a.gamma = ln ? ln->g : nullptr; a.beta = ln ? ln->b : nullptr; a.eps = eps;
     a.W = reinterpret_cast<const bf16_t*>(l.w); a.Kp = l.Kp; a.bias = l.b; a.M = M; a.N = l.N; a.K = l.K; a.act = act;
     a.out = out; a.ldo = ldo; a.n_row = n_row; a.outT = outT; a.t_batch = t_batch; a.ldt = ldt; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
-    const int tile = tl_flow_tile;
-    if (n_row < l.N) CV_CHECK(n_row % 128 == 0 || (tile != 1 && n_row % 64 == 0), "ln_gemm_bf16: the transposed section must start on a tile boundary");
-    if (tile == 1) { const unsigned g = ((M + 63) / 64) * ((l.N + 127) / 128); hipLaunchKernelGGL((flow_gemm_kernel<64, 128, 1, 0>), dim3(g), dim3(256), 0, s, a); }
-    else if (tile == 2) { const unsigned g = ((M + 31) / 32) * ((l.N + 63) / 64); hipLaunchKernelGGL((flow_gemm_kernel<32, 64, 1, 0>), dim3(g), dim3(256), 0, s, a); }
-    else { const unsigned g = ((M + 63) / 64) * ((l.N + 63) / 64); hipLaunchKernelGGL((flow_gemm_kernel<64, 64, 1, 0>), dim3(g), dim3(256), 0, s, a); }
+    CV_CHECK(n_row % 16 == 0, "ln_gemm_bf16: the transposed section must start on a 16-column boundary");
+    // Tile choice, measured on MI355X at the U10 size (M = 1348, N = 1536 / 1024, K = 256; profiles/r2_probe_flow_2_tiles.txt): per launch
+    // 32x64 9.9 us, 64x64 13.9 us, 64x128 ~16 us, 64x192 22.6 us.  A workgroup of this kernel is one dependent chain (load burst -> LayerNorm ->
+    // MFMAs -> epilogue) and a CU ingests only a few tens of bytes per cycle, so what helps is MANY small co-resident workgroups whose
+    // chains overlap, not fewer re-reads; the big tiles stay selectable for other shapes / later pipelined variants.
+    int tile = tl_flow_tile;
+    if (tile == 0) tile = 3;
+    auto grid = [&](int bm, int bn) { return dim3((unsigned)(((M + bm - 1) / bm) * ((l.N + bn - 1) / bn))); };
+    if (tile == 1) hipLaunchKernelGGL((flow_gemm_kernel<64, 64, 1, 0>), grid(64, 64), dim3(256), 0, s, a);
+    else if (tile == 2) hipLaunchKernelGGL((flow_gemm_kernel<64, 128, 1, 0>), grid(64, 128), dim3(256), 0, s, a);
+    else if (tile == 3) hipLaunchKernelGGL((flow_gemm_kernel<32, 64, 1, 0>), grid(32, 64), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((flow_gemm_kernel<64, 192, 1, 0>), grid(64, 192), dim3(256), 0, s, a);
 }
 // C = A_bf16 W^T + b (+ res), fp32
 static void gemm_bf16_res(const Lin& l, const bf16_t* A, int lda, int M, float* C, const float* res, hipStream_t s) {
@@ -318,8 +329,14 @@ static void attn_flow(const bf16_t* qk, int ld, int inner, const bf16_t* vt, lon
     AttnFlowArgs a{};
     a.q = qk; a.k = qk + inner; a.ld = ld; a.vt = vt; a.vt_batch = vt_batch; a.ldt = ldt; a.o = o; a.ldo = inner;
     a.B = B; a.H = H; a.T = T; a.scale = 0.125f; a.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; a.chunk = chunk;
-    if (tl_attn_waves == 2) hipLaunchKernelGGL((attn_flow_kernel<2>), dim3((unsigned)(((T + 31) / 32) * H * B)), dim3(128), 0, s, a);
-    else hipLaunchKernelGGL((attn_flow_kernel<4>), dim3((unsigned)(((T + 63) / 64) * H * B)), dim3(256), 0, s, a);
+    const dim3 g2((unsigned)(((T + 31) / 32) * H * B)), g4((unsigned)(((T + 63) / 64) * H * B));
+    if (tl_attn_waves == 2) {
+        if (tl_attn_kt == 2) hipLaunchKernelGGL((attn_flow_kernel<2, 2>), g2, dim3(128), 0, s, a);
+        else hipLaunchKernelGGL((attn_flow_kernel<2, 1>), g2, dim3(128), 0, s, a);
+    } else {
+        if (tl_attn_kt == 2) hipLaunchKernelGGL((attn_flow_kernel<4, 2>), g4, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_flow_kernel<4, 1>), g4, dim3(256), 0, s, a);
+    }
 }
 
 // s_in: packed [2][T][4*mel]; t_row: which row of the time tables; t_shared: both CFG rows use the same row;
@@ -458,7 +475,8 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         CV_CHECK(m && name, "null argument");
         if (std::string(name) == "use_graph") { m->use_graph = value != 0; drop_graphs(m); }
         else if (std::string(name) == "bf16_mfma") { m->bf16_mfma = value != 0; drop_graphs(m); }      // captured graphs bake the kernel choice
-        else if (std::string(name) == "flow_tile") { CV_CHECK(value >= 0 && value <= 2, "flow_tile must be 0, 1 or 2"); m->flow_tile = value; drop_graphs(m); }
+        else if (std::string(name) == "flow_tile") { CV_CHECK(value >= 0 && value <= 4, "flow_tile must be 0..4"); m->flow_tile = value; drop_graphs(m); }
+        else if (std::string(name) == "attn_kt") { CV_CHECK(value == 1 || value == 2, "attn_kt must be 1 or 2"); m->attn_kt = value; drop_graphs(m); }
         else if (std::string(name) == "attn_waves") { CV_CHECK(value == 2 || value == 4, "attn_waves must be 2 or 4"); m->attn_waves = value; drop_graphs(m); }
         else if (std::string(name) == "fused") { m->fused = value != 0; drop_graphs(m); }              // bf16 mode: fused transformer blocks (flow_fused.h) on / off
         else throw Error(std::string("unknown option ") + name);

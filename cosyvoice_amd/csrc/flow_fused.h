@@ -47,7 +47,10 @@ __global__ __launch_bounds__(256) void flow_gemm_kernel(FlowGemmArgs p) {
     const int bl = xcd_remap((int)blockIdx.x, (int)gridDim.x);        // an XCD walks the N tiles of a band of rows: A crosses the fabric once
     const int m0 = (bl / ntn) * BM, n0 = (bl % ntn) * BN;
     const int nchunks = (p.K + KC - 1) / KC;
-    const bool transposed = OMODE == 0 && n0 >= p.n_row;              // uniform: this tile belongs to the V^T section
+    // V^T section (OMODE 0): decided per 16-column MFMA tile (wave-uniform), so that n_row only has to be a multiple of 16
+    bool tr[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) tr[j] = OMODE == 0 && n0 + wn * (BN / 2) + j * 16 >= p.n_row;
 
     v4f acc[TM][TN];
 #pragma unroll
@@ -93,18 +96,17 @@ __global__ __launch_bounds__(256) void flow_gemm_kernel(FlowGemmArgs p) {
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(&As[(wm * (BM / 2) + i * 16 + (lane & 15)) * LDK + kd]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const uint4*>(&Ws[(wn * (BN / 2) + j * 16 + (lane & 15)) * LDK + kd]);
-            if (transposed) {                                 // activations are the MFMA "A": a lane ends with 4 consecutive ROWS m of one column n
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+            for (int j = 0; j < TN; ++j) {
+                if (tr[j]) {                                  // activations are the MFMA "A": a lane ends with 4 consecutive ROWS m of one column n
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int i = 0; i < TM; ++i)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, af[i]), __builtin_bit_cast(v8bf, wf[j]), acc[i][j], 0, 0, 0);
-            } else {                                          // weights are the MFMA "A": a lane ends with 4 consecutive COLUMNS n of one row m
+                } else {                                      // weights are the MFMA "A": a lane ends with 4 consecutive COLUMNS n of one row m
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int i = 0; i < TM; ++i)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, wf[j]), __builtin_bit_cast(v8bf, af[i]), acc[i][j], 0, 0, 0);
+                }
             }
         }
     };
@@ -191,40 +193,38 @@ __global__ __launch_bounds__(256) void flow_gemm_kernel(FlowGemmArgs p) {
                 *reinterpret_cast<float4*>(p.C + idx) = v;
             }
         }
-    } else if (!transposed) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
-                if (n >= p.N || n >= p.n_row) continue;
-                float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-                v = apply_act4(p.act, v, 0.f);
-                *reinterpret_cast<uint2*>(p.out + (long long)m * p.ldo + n) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
-            }
-        }
     } else {
-        // V^T section: lane holds rows m .. m + 3 of column n.  Rows of one request are consecutive (m = b rows_per_batch + t) but a group of
-        // four may straddle a 4-aligned key group or two requests when rows_per_batch % 4 != 0, so every element finds its own slot.
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) {
+            if (!tr[j]) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
+                for (int i = 0; i < TM; ++i) {
+                    const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+                    const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+                    if (m >= p.M || n >= p.N) continue;
+                    float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                    v = apply_act4(p.act, v, 0.f);
+                    *reinterpret_cast<uint2*>(p.out + (long long)m * p.ldo + n) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                }
+            } else {
+                // V^T section: lane holds rows m .. m + 3 of column n.  Rows of one request are consecutive (m = b rows_per_batch + t) but a group
+                // of four may straddle a 4-aligned key group or two requests when rows_per_batch % 4 != 0, so every element finds its own slot.
                 const int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
                 if (n >= p.N) continue;
                 const float bn = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
-                    if (m >= p.M) continue;
-                    const int b = m / p.rows_per_batch, t = m - b * p.rows_per_batch;
-                    const unsigned u = pack_bf16x2(acc[i][j][r] + bn, 0.f);
-                    p.outT[(long long)b * p.t_batch + (long long)(n - p.n_row) * p.ldt + vt_col(t)] = (bf16_t)(u & 0xffffu);
-                }
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+                        if (m >= p.M) continue;
+                        const int b = m / p.rows_per_batch, t = m - b * p.rows_per_batch;
+                        const unsigned u = pack_bf16x2(acc[i][j][r] + bn, 0.f);
+                        p.outT[(long long)b * p.t_batch + (long long)(n - p.n_row) * p.ldt + vt_col(t)] = (bf16_t)(u & 0xffffu);
+                    }
             }
+        }
     }
 }
 
@@ -242,12 +242,15 @@ struct AttnFlowArgs {
     int B, H, T; float scale; int mask_mode; int chunk;
 };
 
-template <int NW>
+template <int NW, int KT>
 __global__ __launch_bounds__(NW * 64) void attn_flow_kernel(AttnFlowArgs p) {
-    constexpr int NT = NW * 64, BQ = NW * 16, BKV = 64, LDH = 36;          // LDS row pitch in dwords: 64 bf16 + 8 pad
-    constexpr int NI = 512 / NT;                          // 16-byte pieces per thread and operand tile (64 rows x 8 pieces)
+    // KT = 64-key tiles per iteration: with one workgroup per CU (176 of them at T = 674) each SIMD runs ONE wave, so nothing overlaps the
+    // dependent chain MFMA -> scale -> row max (2 cross-lane exchanges) -> exp2 -> pack -> MFMA of a tile but the tile's own independent
+    // work: KT = 2 halves the number of serial softmax steps and doubles the independent MFMA chains in flight.
+    constexpr int NT = NW * 64, BQ = NW * 16, BKV = 64 * KT, LDH = 36, LDV = BKV / 2 + 4;     // LDS row pitches in dwords
+    constexpr int NI = BKV * 8 / NT;                      // 16-byte pieces per thread and operand tile (BKV x 64 bf16 each)
     __shared__ __attribute__((aligned(16))) unsigned Ks[2][BKV * LDH];
-    __shared__ __attribute__((aligned(16))) unsigned Vt[2][64 * LDH];
+    __shared__ __attribute__((aligned(16))) unsigned Vt[2][64 * LDV];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 15, lg = lane >> 4;
@@ -268,22 +271,23 @@ __global__ __launch_bounds__(NW * 64) void attn_flow_kernel(AttnFlowArgs p) {
     if (p.mask_mode == MASK_CHUNK) klim = min(p.T, (qi / p.chunk + 1) * p.chunk);
     if (!qvalid) klim = 0;
 
-    // stage pieces: v = tid + NT i -> row v / 8 (key for K, d for V^T), 8 bf16 at column 8 (v % 8)
+    // stage pieces: K piece v -> key row v / 8, 8 bf16 at column 8 (v % 8);  V^T piece v -> d row v / (BKV / 8), 8 keys at column 8 (v % (BKV / 8))
     u32x4_t rk[NI], rv[NI];
     auto load_kv = [&](int kt0) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int v = tid + NT * i, row = v >> 3, c8 = (v & 7) * 8;
-            rk[i] = *reinterpret_cast<const u32x4_t*>(kb + (long long)min(kt0 + row, p.T - 1) * p.ld + c8);     // keys >= T are masked below
-            rv[i] = *reinterpret_cast<const u32x4_t*>(vb + (long long)row * p.ldt + kt0 + c8);                    // ldt >= round_up(T, 64): in range, finite
+            const int v = tid + NT * i;
+            rk[i] = *reinterpret_cast<const u32x4_t*>(kb + (long long)min(kt0 + (v >> 3), p.T - 1) * p.ld + (v & 7) * 8);     // keys >= T are masked below
+            const int vr = v / (BKV / 8), vc = (v % (BKV / 8)) * 8;
+            rv[i] = *reinterpret_cast<const u32x4_t*>(vb + (long long)vr * p.ldt + min(kt0 + vc, p.ldt - 8));   // ldt is a multiple of 64; pad columns are finite
         }
     };
     auto store_kv = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int v = tid + NT * i, row = v >> 3, c4 = (v & 7) * 4;
-            *reinterpret_cast<u32x4_t*>(&Ks[buf][row * LDH + c4]) = rk[i];
-            *reinterpret_cast<u32x4_t*>(&Vt[buf][row * LDH + c4]) = rv[i];
+            const int v = tid + NT * i;
+            *reinterpret_cast<u32x4_t*>(&Ks[buf][(v >> 3) * LDH + (v & 7) * 4]) = rk[i];
+            *reinterpret_cast<u32x4_t*>(&Vt[buf][(v / (BKV / 8)) * LDV + (v % (BKV / 8)) * 4]) = rv[i];
         }
     };
     if (kend > 0) load_kv(0);
@@ -304,9 +308,9 @@ __global__ __launch_bounds__(NW * 64) void attn_flow_kernel(AttnFlowArgs p) {
     for (int d = 0; d < 4; ++d) acc[d] = (v4f){0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int kt0, int buf) {
-        v4f s[4];                                          // s[kt][r] <-> key kt0 + kt*16 + lg*4 + r, query lq
+        v4f s[4 * KT];                                     // s[kt][r] <-> key kt0 + kt*16 + lg*4 + r, query lq
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int kt = 0; kt < 4 * KT; ++kt) {
             v4f sa = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int dg = 0; dg < 2; ++dg) {
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(NW * 64) void attn_flow_kernel(AttnFlowArgs p) {
         }
         float mt = NEG_INF;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4 * KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt0 + kt * 16 + lg * 4 + r;
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(NW * 64) void attn_flow_kernel(AttnFlowArgs p) {
         const float alpha = (m_run == NEG_INF) ? 0.f : exp2f(m_run - m_new);
         float rsum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4 * KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x = s[kt][r];
@@ -346,12 +350,12 @@ __global__ __launch_bounds__(NW * 64) void attn_flow_kernel(AttnFlowArgs p) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) acc[d] = acc[d] * alpha;
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {                // k-slot (g, 4 s + r) of 32-key block blk is key 32 blk + 16 s + 4 g + r on both operands
+        for (int blk = 0; blk < 2 * KT; ++blk) {           // k-slot (g, 4 s + r) of 32-key block blk is key 32 blk + 16 s + 4 g + r on both operands
             const uint4 pb = make_uint4(pack_bf16x2(s[2 * blk][0], s[2 * blk][1]), pack_bf16x2(s[2 * blk][2], s[2 * blk][3]),
                                         pack_bf16x2(s[2 * blk + 1][0], s[2 * blk + 1][1]), pack_bf16x2(s[2 * blk + 1][2], s[2 * blk + 1][3]));
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const uint4 vf = *reinterpret_cast<const uint4*>(&Vt[buf][(dt * 16 + lq) * LDH + blk * 16 + lg * 4]);
+                const uint4 vf = *reinterpret_cast<const uint4*>(&Vt[buf][(dt * 16 + lq) * LDV + blk * 16 + lg * 4]);
                 acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, vf), __builtin_bit_cast(v8bf, pb), acc[dt], 0, 0, 0);
             }
         }
