@@ -25,9 +25,43 @@ static __global__ __launch_bounds__(256) void interp_linear_kernel(const float* 
     y[i] = l0 * x[(long long)c * T + i0] + l1 * x[(long long)c * T + i1];
 }
 
+// ---- prompt-mel front end (cli/frontend.py:120-125 -> matcha.utils.audio.mel_spectrogram, center=False) -----------------------------
+// y[0 .. L + 2 pad) = reflect padding of x[0 .. L) by `pad` samples on both sides (torch.nn.functional.pad(mode="reflect"))
+static __global__ __launch_bounds__(256) void reflect_pad_kernel(const float* x, float* y, int L, int pad) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= L + 2 * pad) return;
+    int j = i - pad;
+    if (j < 0) j = -j;
+    if (j >= L) j = 2 * (L - 1) - j;
+    y[i] = x[j];
+}
+// spec [T][2 * bins] = (re | im) of the windowed DFT  ->  mag [T][ldm] = sqrt(re^2 + im^2 + eps), columns >= bins zeroed
+static __global__ __launch_bounds__(256) void stft_magnitude_kernel(const float* spec, float* mag, int T, int bins, int ldm, float eps) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)T * ldm) return;
+    const int t = (int)(i / ldm), f = (int)(i % ldm);
+    float v = 0.f;
+    if (f < bins) { const float re = spec[(long long)t * 2 * bins + f], im = spec[(long long)t * 2 * bins + bins + f]; v = sqrtf(re * re + im * im + eps); }
+    mag[i] = v;
+}
+
 }  // namespace cv
 
 extern "C" {
+
+int cv_reflect_pad(const float* x, float* y, int32_t L, int32_t pad, void* stream) {
+    return cv::guarded([&] {
+        CV_CHECK(x && y && L > pad && pad >= 0, "cv_reflect_pad: needs L > pad (reflection without the edge sample)");
+        hipLaunchKernelGGL(cv::reflect_pad_kernel, dim3((unsigned)((L + 2 * pad + 255) / 256)), dim3(256), 0, cv::as_stream(stream), x, y, L, pad);
+    });
+}
+
+int cv_stft_magnitude(const float* spec, float* mag, int32_t T, int32_t bins, int32_t ldm, float eps, void* stream) {
+    return cv::guarded([&] {
+        CV_CHECK(spec && mag && T > 0 && bins > 0 && ldm >= bins, "cv_stft_magnitude: bad arguments");
+        hipLaunchKernelGGL(cv::stft_magnitude_kernel, dim3((unsigned)(((long long)T * ldm + 255) / 256)), dim3(256), 0, cv::as_stream(stream), spec, mag, T, bins, ldm, eps);
+    });
+}
 
 int cv_fade_in_out(float* fade_in, const float* fade_out_tail, const float* window, int32_t overlap, void* stream) {
     return cv::guarded([&] {

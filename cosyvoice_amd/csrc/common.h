@@ -22,6 +22,8 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(
 enum Act : int {
     ACT_NONE = 0, ACT_SILU = 1, ACT_GELU_ERF = 2, ACT_ELU = 3, ACT_LEAKY = 4, ACT_TANH = 5,
     ACT_MISH = 6, ACT_ABS = 7, ACT_SNAKE = 8,
+    ACT_LOGCLAMP = 9,      // log(max(x, p)): log-mel of matcha.utils.audio.mel_spectrogram
+    ACT_GELU_TANH = 10,    // nn.GELU(approximate='tanh'): the DiT feed-forward (flow/DiT/modules.py:514)
 };
 
 // Activations.  At ~1 workgroup per CU nothing hides VALU work, and libm's erff / tanhf / log1pf expand to 40-150 instructions per
@@ -52,6 +54,7 @@ __device__ __noinline__ float4 act4_call(int act, float4 x) {
         else if (act == ACT_MISH) { const float n = fast_exp(fminf(t, 20.f)), w = n * (n + 2.f); r = t > 20.f ? t : t * w * fast_rcp(w + 2.f); }
         else if (act == ACT_TANH) { const float e2 = fast_exp(2.f * fminf(fmaxf(t, -15.f), 15.f)); r = 1.f - 2.f * fast_rcp(e2 + 1.f); }
         else if (act == ACT_ELU) r = t > 0.f ? t : expm1f(t);
+        else if (act == ACT_GELU_TANH) { const float u = 0.7978845608028654f * (t + 0.044715f * t * t * t), e2 = fast_exp(2.f * fminf(fmaxf(u, -15.f), 15.f)); r = 0.5f * t * (2.f - 2.f * fast_rcp(e2 + 1.f)); }
         else r = t;
         v[e] = r;
     }
@@ -61,12 +64,14 @@ __device__ __forceinline__ float4 apply_act4(int act, float4 v, float p) {
     if (act == ACT_NONE) return v;
     if (act == ACT_LEAKY) return make_float4(v.x > 0.f ? v.x : v.x * p, v.y > 0.f ? v.y : v.y * p, v.z > 0.f ? v.z : v.z * p, v.w > 0.f ? v.w : v.w * p);
     if (act == ACT_ABS) return make_float4(fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w));
+    if (act == ACT_LOGCLAMP) return make_float4(logf(fmaxf(v.x, p)), logf(fmaxf(v.y, p)), logf(fmaxf(v.z, p)), logf(fmaxf(v.w, p)));
     return act4_call(act, v);
 }
 __device__ __forceinline__ float apply_act(int act, float v, float p) {      // scalar sites (tails, small kernels)
     if (act == ACT_NONE) return v;
     if (act == ACT_LEAKY) return v > 0.f ? v : v * p;
     if (act == ACT_ABS) return fabsf(v);
+    if (act == ACT_LOGCLAMP) return logf(fmaxf(v, p));
     return act4_call(act, make_float4(v, 0.f, 0.f, 0.f)).x;
 }
 

@@ -24,7 +24,7 @@ typedef struct cv_hift cv_hift;
 
 enum { CV_F32 = 0, CV_BF16 = 1, CV_I32 = 2 };
 enum { CV_ACT_NONE = 0, CV_ACT_SILU = 1, CV_ACT_GELU_ERF = 2, CV_ACT_ELU = 3, CV_ACT_LEAKY = 4, CV_ACT_TANH = 5,
-       CV_ACT_MISH = 6, CV_ACT_ABS = 7, CV_ACT_SNAKE = 8 };
+       CV_ACT_MISH = 6, CV_ACT_ABS = 7, CV_ACT_SNAKE = 8, CV_ACT_LOGCLAMP = 9 /* log(max(x, act_p)) */, CV_ACT_GELU_TANH = 10 };
 enum { CV_MASK_NONE = 0, CV_MASK_CAUSAL = 1, CV_MASK_CHUNK = 2 };
 
 const char* cv_last_error(void);
@@ -207,6 +207,14 @@ int cv_hift_inference(cv_hift* m, const float* speech_feat, int32_t frames, cons
 int cv_fade_in_out(float* fade_in, const float* fade_out_tail, const float* window, int32_t overlap, void* stream);
 /* F.interpolate(x[1,C,T], size=Tn, mode='linear') for the `speed` argument (cli/model.py:322), channel-first. */
 int cv_interp_linear(const float* x, float* y, int32_t C, int32_t T, int32_t Tn, void* stream);
+
+/* Prompt-mel front end: replaces `matcha.utils.audio.mel_spectrogram(y, n_fft, num_mels, sampling_rate, hop_size, win_size,
+ * fmin, fmax, center=False)` as `CosyVoiceFrontEnd._extract_speech_feat` calls it (cosyvoice/cli/frontend.py:120-125, cosyvoice2.yaml:150-158).
+ * cv_reflect_pad: y[L + 2 pad] = F.pad(x[L], (pad, pad), mode="reflect").  cv_stft_magnitude: spec [T][2 bins] (re | im, produced by cv_gemm_conv
+ * over the padded signal with lda = hop and the windowed DFT basis as W) -> mag [T][ldm] = sqrt(re^2 + im^2 + eps), pad columns zeroed.  The mel
+ * projection + log(clamp(., 1e-5)) is one more cv_gemm_conv with act = CV_ACT_LOGCLAMP.  Host side: cosyvoice_amd/frontend.py. */
+int cv_reflect_pad(const float* x, float* y, int32_t L, int32_t pad, void* stream);
+int cv_stft_magnitude(const float* spec, float* mag, int32_t T, int32_t bins, int32_t ldm, float eps, void* stream);
 
 #ifdef __cplusplus
 }
