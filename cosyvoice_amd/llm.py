@@ -267,6 +267,76 @@ class Qwen2LM:
                         fill(s_)
 
 
+    @torch.inference_mode()
+    def serve_stream(self, source, on_tokens, slots=8, max_token_text_ratio=20, min_token_text_ratio=2, step_chunk=None):
+        """Continuous batching with STREAMED tokens, the LLM half of a Triton-free serving scheduler (the reference gets this from vLLM /
+        TensorRT-LLM: cli/model.py:281-290, runtime/triton_trtllm/model_repo/cosyvoice2/1/model.py:307-313).  `source` is a queue.Queue of
+        (key, request) items - requests as for inference_batch - closed by a None item; `on_tokens(key, new_tokens, finished, error)` is called
+        from this thread after every decode chunk of `step_chunk` lock-step steps for every sequence that produced tokens or finished.  Free
+        slots are re-filled as soon as a sequence ends (a normal prefill parked into the slot); with nothing in flight the call blocks on the
+        queue.  Every sequence yields exactly the tokens `inference()` yields for its request alone."""
+        import queue as _q
+        assert 1 <= slots <= 8
+        chunk = step_chunk or min(self.decode_chunk, 8)
+        with self.lock:
+            st = stream_ptr(self.lib)
+            self.lib.cv_llm_batch_begin(self._h, C.c_int32(slots), st)
+            owner, emitted, limit = [None] * slots, {}, {}
+            closed = False
+
+            def admit(slot, item):
+                key, r = item
+                try:
+                    lm_input = self.build_lm_input(r["text"], r["prompt_text"], r["prompt_speech_token"])
+                    n_text = int(r["text"].shape[1])
+                    min_len = int(n_text * r.get("min_token_text_ratio", min_token_text_ratio))
+                    max_len = int(n_text * r.get("max_token_text_ratio", max_token_text_ratio))
+                    if max_len == 0:
+                        on_tokens(key, [], True, None)
+                        return False
+                    max_len = self.clamp_max_len(lm_input.shape[0], min_len, max_len, "request %r" % (key,))
+                    sp = self.make_sampling(min_len, max_len)
+                    self.lib.cv_llm_batch_prefill(self._h, C.c_int32(slot), C.c_void_p(lm_input.data_ptr()), C.c_int32(lm_input.shape[0]), C.byref(sp), st)
+                except Exception as e:                      # a bad request must not take the server down: report it on its own channel
+                    on_tokens(key, [], True, e)
+                    return False
+                owner[slot], emitted[key], limit[key] = key, 0, max_len
+                return True
+
+            while True:
+                # fill free slots; block only when nothing is decoding
+                for s_ in range(slots):
+                    while owner[s_] is None and not closed:
+                        idle = all(o is None for o in owner)
+                        try:
+                            item = source.get(block=idle)
+                        except _q.Empty:
+                            break
+                        if item is None:
+                            closed = True
+                            break
+                        admit(s_, item)
+                if all(o is None for o in owner):
+                    if closed:
+                        return
+                    continue
+                buf = (C.c_int32 * (slots * chunk))()
+                n_out, f = (C.c_int32 * slots)(), (C.c_int32 * slots)()
+                self.lib.cv_llm_batch_decode(self._h, C.c_int32(chunk), buf, n_out, f, st)
+                for s_ in range(slots):
+                    key = owner[s_]
+                    if key is None:
+                        continue
+                    room = limit[key] - emitted[key]
+                    toks = [int(buf[s_ * chunk + k]) for k in range(min(n_out[s_], room))]
+                    emitted[key] += len(toks)
+                    fin = bool(f[s_]) or emitted[key] >= limit[key]
+                    if toks or fin:
+                        on_tokens(key, toks, fin, None)
+                    if fin:
+                        owner[s_] = None
+                        emitted.pop(key), limit.pop(key)
+
     # ------------------------------------------------------------------------------------------------ bi-directional streaming
     def _rows(self, table, ids):
         """Embedding rows [n, hidden] fp32 on the device (cv_gather_rows), n may be 0."""

@@ -1,0 +1,301 @@
+"""Serving layer: a Triton-free batched streaming scheduler and the HTTP adapter of the reference runtime.
+
+* `StreamScheduler` - what `runtime/triton_trtllm/model_repo/cosyvoice2/1/model.py:315-454` does with Triton + TensorRT-LLM: many concurrent
+  streaming requests on ONE model object.  The speech-token LM runs continuous batching with streamed tokens on its own thread / HIP stream
+  (`Qwen2LM.serve_stream`: up to 8 sequences per lock-step decode step, every weight matrix streamed once per step for all of them); a
+  vocoder thread turns token prefixes into audio chunks (`CosyVoice2Model.token2wav`, per-uuid caches) under the reference's chunk rules:
+  first chunk after `token_hop_len + prompt pad + pre_lookahead` tokens, then `exponential` (hop doubles up to `token_max_hop_len`,
+  cli/model.py:345-360 - the default) or `time_based` (model.py:410-426) hop growth.  Every request's audio equals `tts(stream=True)` of
+  that request alone under `exponential` (chunk boundaries depend only on token counts).
+* `create_app(engine)` - the FastAPI surface of `runtime/python/fastapi/server.py:46-86` (same routes, int16 PCM `StreamingResponse`)
+  over any engine exposing the `CosyVoice2.inference_*` generators.  Text normalisation / tokenisation and the ONNX extractors (speech
+  tokenizer, CAM++) are the reference front end's job (`cosyvoice/cli/frontend.py`, out of scope here - SURVEY.md section 8f item 2): `Engine`
+  takes such a front end as an object and only replaces its mel extractor and the model underneath.
+"""
+import queue
+import threading
+import time
+import uuid as uuid_mod
+
+import numpy as np
+import torch
+
+
+class _Request:
+    __slots__ = ("key", "req", "tokens", "llm_done", "error", "out", "token_offset", "hop", "chunk_index", "t_submit", "t_first", "stream", "pad", "closed")
+
+    def __init__(self, key, req, stream, hop, pad):
+        self.key, self.req, self.stream = key, req, stream
+        self.tokens, self.llm_done, self.error = [], False, None
+        self.out = queue.Queue()
+        self.token_offset, self.hop, self.chunk_index, self.pad = 0, hop, 0, pad
+        self.t_submit, self.t_first, self.closed = time.perf_counter(), None, False
+
+
+class StreamScheduler:
+    def __init__(self, model, slots=8, strategy="exponential", step_chunk=8):
+        assert strategy in ("exponential", "time_based")
+        self.model, self.slots, self.strategy, self.step_chunk = model, slots, strategy, step_chunk
+        self._src = queue.Queue()
+        self._cv = threading.Condition()
+        self._reqs = {}
+        self._stop = False
+        self._llm_thread = threading.Thread(target=self._llm_loop, daemon=True)
+        self._voc_thread = threading.Thread(target=self._vocoder_loop, daemon=True)
+        self._llm_thread.start(); self._voc_thread.start()
+
+    # ---- client side ---------------------------------------------------------------------------------------------------------
+    def submit(self, stream=True, **req):
+        """req: the keyword tensors of CosyVoice2Model.tts (text, prompt_text, llm_prompt_speech_token, flow_prompt_speech_token,
+        prompt_speech_feat, llm_embedding, flow_embedding [, min/max_token_text_ratio]).  Returns a generator of {'tts_speech': [1, S] cpu}."""
+        m = self.model
+        key = str(uuid_mod.uuid1())
+        n_prompt = int(req["flow_prompt_speech_token"].shape[1])
+        pad = int(np.ceil(n_prompt / m.token_hop_len) * m.token_hop_len - n_prompt)
+        r = _Request(key, req, stream, m.token_hop_len, pad)
+        with self._cv:
+            if self._stop:
+                raise RuntimeError("scheduler is shut down")
+            self._reqs[key] = r
+        with m.lock:
+            m.hift_cache_dict[key] = None
+        lm_req = dict(text=req["text"], prompt_text=req["prompt_text"], prompt_speech_token=req["llm_prompt_speech_token"],
+                      **{k: req[k] for k in ("min_token_text_ratio", "max_token_text_ratio") if k in req})
+        self._src.put((key, lm_req))
+        return self._drain(r)
+
+    def _drain(self, r):
+        try:
+            while True:
+                item = r.out.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            r.closed = True
+
+    def first_chunk_latency(self, key_request):
+        return None if key_request.t_first is None else key_request.t_first - key_request.t_submit
+
+    def shutdown(self):
+        with self._cv:
+            self._stop = True
+            self._cv.notify_all()
+        self._src.put(None)
+        self._llm_thread.join(); self._voc_thread.join()
+
+    # ---- LLM thread: continuous batching, tokens streamed per decode chunk ------------------------------------------------------------
+    def _on_tokens(self, key, toks, finished, error):
+        with self._cv:
+            r = self._reqs.get(key)
+            if r is None:
+                return
+            r.tokens.extend(toks)
+            if error is not None:
+                r.error = error
+            if finished:
+                r.llm_done = True
+            self._cv.notify_all()
+
+    def _llm_loop(self):
+        m = self.model
+        try:
+            with m.llm_context:
+                m.llm.serve_stream(self._src, self._on_tokens, slots=self.slots, step_chunk=self.step_chunk)
+        except BaseException as e:                   # the LM thread died: fail every open request instead of hanging its client
+            with self._cv:
+                for r in self._reqs.values():
+                    r.error, r.llm_done = r.error or e, True
+                self._cv.notify_all()
+
+    # ---- vocoder thread: chunk rules of cli/model.py:341-371 per request, first-come first-served over ready requests -----------------
+    def _ready(self, r):
+        la = self.model.flow.pre_lookahead_len
+        if r.error is not None:
+            return "error"
+        hop = r.hop + r.pad if r.token_offset == 0 else r.hop
+        if r.stream and len(r.tokens) - r.token_offset >= hop + la:
+            return "chunk"
+        if r.llm_done:
+            return "final"
+        return None
+
+    def _vocoder_loop(self):
+        m = self.model
+        la = m.flow.pre_lookahead_len
+        while True:
+            with self._cv:
+                while True:
+                    pick = None
+                    for r in self._reqs.values():              # dict order = submission order: the oldest ready request goes first
+                        what = self._ready(r)
+                        if what is not None:
+                            pick = (r, what, list(r.tokens))
+                            break
+                    if pick is not None or (self._stop and not self._reqs):
+                        break
+                    self._cv.wait(timeout=0.5)
+                if pick is None:
+                    return
+            r, what, toks = pick
+            rq = r.req
+            finished = True
+            try:
+                if what == "error":
+                    raise r.error
+                if what == "chunk":
+                    hop = r.hop + r.pad if r.token_offset == 0 else r.hop
+                    n = r.token_offset + hop + la
+                    wav = m.token2wav(token=torch.tensor(toks[:n]).unsqueeze(0), prompt_token=rq["flow_prompt_speech_token"], prompt_feat=rq["prompt_speech_feat"],
+                                      embedding=rq["flow_embedding"], token_offset=r.token_offset, uuid=r.key, stream=True, finalize=False)
+                    r.token_offset += hop
+                    r.chunk_index += 1
+                    if self.strategy == "exponential":
+                        r.hop = min(m.token_max_hop_len, r.hop * m.stream_scale_factor)
+                    else:                                   # time_based (triton model.py:410-426): grow the hop while synthesis runs ahead of playback
+                        cost, dur = time.perf_counter() - r.t_submit, r.token_offset / 25.0
+                        mult = (dur - cost) / max(cost / r.chunk_index, 1e-6)
+                        pend = len(r.tokens) - r.token_offset
+                        base = m.token_hop_len
+                        r.hop = max(base, (pend // base + 1) * base if mult > 4 else (pend // base) * base if mult > 2 else base)
+                    out = {"tts_speech": wav.cpu()}
+                    if r.t_first is None:
+                        r.t_first = time.perf_counter()
+                    r.out.put(out)
+                    finished = False
+                else:
+                    wav = m.token2wav(token=torch.tensor(toks).unsqueeze(0), prompt_token=rq["flow_prompt_speech_token"], prompt_feat=rq["prompt_speech_feat"],
+                                      embedding=rq["flow_embedding"], token_offset=r.token_offset, uuid=r.key, finalize=True,
+                                      speed=1.0 if r.stream else rq.get("speed", 1.0))
+                    out = {"tts_speech": wav.cpu()}
+                    if r.t_first is None:
+                        r.t_first = time.perf_counter()
+                    r.out.put(out)
+                    r.out.put(None)
+            except BaseException as e:
+                r.out.put(e)
+            if finished:                                    # done or failed: drop the per-request state (cli/model.py:388-391)
+                with self._cv:
+                    self._reqs.pop(r.key, None)
+                with m.lock:
+                    m.hift_cache_dict.pop(r.key, None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# HTTP adapter (runtime/python/fastapi/server.py)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def pcm16_stream(model_output):
+    """server.py:38-41: every yielded chunk as little-endian int16 PCM bytes."""
+    for i in model_output:
+        yield (i["tts_speech"].numpy() * (2 ** 15)).astype(np.int16).tobytes()
+
+
+class Engine:
+    """`CosyVoice2`-shaped facade (cosyvoice/cli/cosyvoice.py:166-226) over a StreamScheduler: `frontend` is a CosyVoiceFrontEnd-like object
+    whose `frontend_zero_shot / frontend_cross_lingual / frontend_instruct2 / frontend_sft` return the model-input dicts of the reference
+    (cli/frontend.py:157-222) and whose `text_normalize(text, split=True)` splits text into segments."""
+
+    def __init__(self, scheduler, frontend, sample_rate=24000):
+        self.scheduler, self.frontend, self.sample_rate = scheduler, frontend, sample_rate
+
+    def _run(self, segments, make_input, stream, speed):
+        for seg in segments:
+            mi = make_input(seg)
+            req = {k: mi[k] for k in ("text", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat", "llm_embedding", "flow_embedding") if k in mi}
+            req.setdefault("prompt_text", torch.zeros(1, 0, dtype=torch.int32))
+            req.setdefault("llm_prompt_speech_token", torch.zeros(1, 0, dtype=torch.int32))
+            req.setdefault("flow_prompt_speech_token", torch.zeros(1, 0, dtype=torch.int32))
+            req.setdefault("prompt_speech_feat", torch.zeros(1, 0, 80))
+            yield from self.scheduler.submit(stream=stream, speed=speed, **req)
+
+    def inference_sft(self, tts_text, spk_id, stream=False, speed=1.0):
+        yield from self._run(self.frontend.text_normalize(tts_text, split=True), lambda s: self.frontend.frontend_sft(s, spk_id), stream, speed)
+
+    def inference_zero_shot(self, tts_text, prompt_text, prompt_wav, zero_shot_spk_id="", stream=False, speed=1.0):
+        yield from self._run(self.frontend.text_normalize(tts_text, split=True),
+                             lambda s: self.frontend.frontend_zero_shot(s, prompt_text, prompt_wav, self.sample_rate, zero_shot_spk_id), stream, speed)
+
+    def inference_cross_lingual(self, tts_text, prompt_wav, zero_shot_spk_id="", stream=False, speed=1.0):
+        yield from self._run(self.frontend.text_normalize(tts_text, split=True),
+                             lambda s: self.frontend.frontend_cross_lingual(s, prompt_wav, self.sample_rate, zero_shot_spk_id), stream, speed)
+
+    def inference_instruct2(self, tts_text, instruct_text, prompt_wav, zero_shot_spk_id="", stream=False, speed=1.0):
+        yield from self._run(self.frontend.text_normalize(tts_text, split=True),
+                             lambda s: self.frontend.frontend_instruct2(s, instruct_text, prompt_wav, self.sample_rate, zero_shot_spk_id), stream, speed)
+
+
+def create_app(engine, load_wav=None):
+    """FastAPI app with the routes of runtime/python/fastapi/server.py:46-86.  `load_wav(file, sr)` decodes an uploaded prompt (the reference
+    uses cosyvoice.utils.file_utils.load_wav -> torchaudio, not available offline); the default reads 16-bit PCM WAV with the stdlib."""
+    from fastapi import FastAPI, File, Form, UploadFile
+    from fastapi.middleware.cors import CORSMiddleware
+    from fastapi.responses import StreamingResponse
+
+    def default_load_wav(f, sr):
+        import wave
+        with wave.open(f, "rb") as w:
+            assert w.getsampwidth() == 2, "16-bit PCM WAV expected"
+            data = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float32) / 32768.0
+            if w.getnchannels() > 1:
+                data = data.reshape(-1, w.getnchannels()).mean(1)
+            assert w.getframerate() == sr, "prompt must be sampled at %d Hz (resampling is the front end's job)" % sr
+        return torch.from_numpy(data).unsqueeze(0)
+
+    load = load_wav or default_load_wav
+    app = FastAPI()
+    app.add_middleware(CORSMiddleware, allow_origins=["*"], allow_credentials=True, allow_methods=["*"], allow_headers=["*"])
+    try:
+        import multipart  # noqa: F401  (python-multipart: FastAPI needs it for Form / File parameters)
+        have_multipart = True
+    except ImportError:
+        have_multipart = False
+
+    if have_multipart:                                          # the reference's exact signatures (multipart forms)
+        @app.get("/inference_sft")
+        @app.post("/inference_sft")
+        async def inference_sft(tts_text: str = Form(), spk_id: str = Form()):
+            return StreamingResponse(pcm16_stream(engine.inference_sft(tts_text, spk_id)))
+
+        @app.get("/inference_zero_shot")
+        @app.post("/inference_zero_shot")
+        async def inference_zero_shot(tts_text: str = Form(), prompt_text: str = Form(), prompt_wav: UploadFile = File()):
+            return StreamingResponse(pcm16_stream(engine.inference_zero_shot(tts_text, prompt_text, load(prompt_wav.file, 16000))))
+
+        @app.get("/inference_cross_lingual")
+        @app.post("/inference_cross_lingual")
+        async def inference_cross_lingual(tts_text: str = Form(), prompt_wav: UploadFile = File()):
+            return StreamingResponse(pcm16_stream(engine.inference_cross_lingual(tts_text, load(prompt_wav.file, 16000))))
+
+        @app.get("/inference_instruct2")
+        @app.post("/inference_instruct2")
+        async def inference_instruct2(tts_text: str = Form(), instruct_text: str = Form(), prompt_wav: UploadFile = File()):
+            return StreamingResponse(pcm16_stream(engine.inference_instruct2(tts_text, instruct_text, load(prompt_wav.file, 16000))))
+        return app
+
+    # python-multipart is not installed: same routes, text fields as query parameters, the prompt WAV as the raw request body
+    import io
+    from fastapi import Request
+
+    @app.get("/inference_sft")
+    @app.post("/inference_sft")
+    async def inference_sft_q(tts_text: str, spk_id: str):
+        return StreamingResponse(pcm16_stream(engine.inference_sft(tts_text, spk_id)))
+
+    @app.post("/inference_zero_shot")
+    async def inference_zero_shot_q(request: Request, tts_text: str, prompt_text: str):
+        wav = load(io.BytesIO(await request.body()), 16000)
+        return StreamingResponse(pcm16_stream(engine.inference_zero_shot(tts_text, prompt_text, wav)))
+
+    @app.post("/inference_cross_lingual")
+    async def inference_cross_lingual_q(request: Request, tts_text: str):
+        wav = load(io.BytesIO(await request.body()), 16000)
+        return StreamingResponse(pcm16_stream(engine.inference_cross_lingual(tts_text, wav)))
+
+    @app.post("/inference_instruct2")
+    async def inference_instruct2_q(request: Request, tts_text: str, instruct_text: str):
+        wav = load(io.BytesIO(await request.body()), 16000)
+        return StreamingResponse(pcm16_stream(engine.inference_instruct2(tts_text, instruct_text, wav)))
+
+    return app

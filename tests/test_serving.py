@@ -1,0 +1,240 @@
+"""the batched streaming scheduler (Triton-free equivalent of runtime/triton_trtllm/model_repo/cosyvoice2/1/model.py:
+315-454) and the FastAPI adapter (runtime/python/fastapi/server.py:46-86)."""
+import dataclasses
+import io
+import threading
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from cosyvoice_amd.model import CosyVoice2Model
+from cosyvoice_amd.serving import Engine, StreamScheduler, create_app, pcm16_stream
+from oracle import weights as W
+
+
+@pytest.fixture(scope="module")
+def setup():
+    lc, fc, hc = W.tiny()
+    fc = dataclasses.replace(fc, chunk=5, n_timesteps=2)
+    return (lc, fc, hc), (W.make_llm(lc), W.make_flow(fc), W.make_hift(hc))
+
+
+def _model(lib, cfgs, sds):
+    m = CosyVoice2Model.from_state_dicts(*sds, cfgs, lib=lib, max_len=160, sampling="greedy", decode_chunk=8)
+    m.token_hop_len, m.token_max_hop_len = 5, 20
+    inf = m.hift.inference
+    m.hift.inference = lambda speech_feat, cache_source=None: inf(speech_feat, cache_source, noise=torch.zeros(speech_feat.shape[2] * 480, 9))
+    return m
+
+
+def _req(cfgs, seed, n_text, n_prompt):
+    u = W.synthetic_utterance(cfgs[0], cfgs[1], n_prompt_tok=n_prompt, n_prompt_text=3, n_text=n_text, seed=seed)
+    return {k: u[k] for k in ("text", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat", "llm_embedding", "flow_embedding")}
+
+
+def test_scheduler_streams_equal_single_requests(lib, setup):
+    """Concurrent streaming requests through ONE scheduler (LM continuous batching with streamed tokens + chunked token2wav) produce,
+    chunk for chunk, what CosyVoice2Model.tts(stream=True) produces for each request alone; offline requests likewise."""
+    if lib.emulated:
+        pytest.skip("hardware only: ~6 min under the CPU emulator (the scheduling logic is covered by test_scheduler_logic_with_fake_model, "
+                    "the kernels it drives by tests/test_zz_llm_batch.py and tests/test_model.py)")
+    cfgs, sds = setup
+    m = _model(lib, cfgs, sds)
+    reqs = [_req(cfgs, 41, 2, 8), _req(cfgs, 42, 1, 6)]
+    alone = [[o["tts_speech"] for o in m.tts(stream=True, **r)] for r in reqs]
+    alone_off = [o["tts_speech"] for o in m.tts(stream=False, **reqs[0])]
+    sch = StreamScheduler(m, slots=4, step_chunk=4)
+    try:
+        got, errs = [None] * 3, []
+
+        def run(i, r, stream):
+            try:
+                got[i] = [o["tts_speech"] for o in sch.submit(stream=stream, **r)]
+            except Exception as e:          # pragma: no cover
+                errs.append(repr(e))
+        th = [threading.Thread(target=run, args=(i, r, True)) for i, r in enumerate(reqs)] + [threading.Thread(target=run, args=(2, reqs[0], False))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for a, b in zip(got[:2], alone):
+            assert len(a) == len(b)
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+        assert len(got[0]) >= 2                                                  # the first request really streamed in several chunks
+        assert len(got[2]) == 1 and torch.equal(got[2][0], alone_off[0])
+        assert not m.hift_cache_dict and not sch._reqs
+        # a bad request fails on its own channel and the server keeps serving
+        bad = dict(reqs[1]); bad["text"] = torch.zeros(1, 200, dtype=torch.int32)      # prompt + min_len cannot fit the KV capacity of 160
+        with pytest.raises(ValueError):
+            list(sch.submit(stream=True, **bad))
+        again = [o["tts_speech"] for o in sch.submit(stream=False, **reqs[0])]
+        assert len(again) == 1 and torch.equal(again[0], alone_off[0])
+    finally:
+        sch.shutdown()
+
+
+class _StubFrontend:
+    """Stands in for cosyvoice.cli.frontend.CosyVoiceFrontEnd (tokenizer + ONNX extractors, out of scope): maps text to ids by length."""
+
+    def __init__(self, cfgs):
+        self.cfgs = cfgs
+
+    def text_normalize(self, text, split=True):
+        return [t for t in text.split("|") if t]
+
+    def frontend_zero_shot(self, tts_text, prompt_text, prompt_wav, resample_rate, zero_shot_spk_id):
+        assert prompt_wav.dim() == 2 and resample_rate == 24000
+        return _req(self.cfgs, 50 + len(tts_text), max(1, len(tts_text) % 3), 6)
+
+    def frontend_cross_lingual(self, tts_text, prompt_wav, resample_rate, zero_shot_spk_id):
+        r = self.frontend_zero_shot(tts_text, "", prompt_wav, resample_rate, zero_shot_spk_id)
+        del r["prompt_text"], r["llm_prompt_speech_token"]
+        return r
+
+
+class _FakeModel:
+    """Host-logic double of CosyVoice2Model for the scheduler: the LM emits scripted tokens in chunks, token2wav returns a waveform that
+    encodes which tokens it was asked to vocode."""
+
+    class _Flow:
+        pre_lookahead_len = 3
+
+    class _LLM:
+        def __init__(self, scripts):
+            self.scripts = scripts
+
+        def serve_stream(self, source, on_tokens, slots=8, step_chunk=8, **kw):
+            import queue as _q
+            active, closed = {}, False
+            while True:
+                while not closed:
+                    try:
+                        item = source.get(block=not active, timeout=None if not active else 0)
+                    except _q.Empty:
+                        break
+                    if item is None:
+                        closed = True
+                        break
+                    key, r = item
+                    n = int(r["text"].shape[1])
+                    if n == 0:
+                        on_tokens(key, [], True, ValueError("empty text"))
+                    else:
+                        active[key] = list(self.scripts[n])
+                if not active:
+                    if closed:
+                        return
+                    continue
+                for key in list(active):
+                    toks, active[key] = active[key][:step_chunk], active[key][step_chunk:]
+                    on_tokens(key, toks, not active[key], None)
+                    if not active[key]:
+                        del active[key]
+
+    def __init__(self, scripts):
+        import contextlib
+        self.llm, self.flow = self._LLM(scripts), self._Flow()
+        self.llm_context = contextlib.nullcontext()
+        self.lock = threading.Lock()
+        self.hift_cache_dict = {}
+        self.token_hop_len, self.token_max_hop_len, self.stream_scale_factor = 5, 20, 2
+        self.calls = []
+
+    def token2wav(self, token, prompt_token, prompt_feat, embedding, token_offset, uuid, stream=False, finalize=False, speed=1.0):
+        self.calls.append((uuid, token.shape[1], token_offset, stream, finalize))
+        n_new = token.shape[1] - token_offset - (0 if finalize else 3)
+        return torch.full((1, n_new * 960), float(token_offset))
+
+
+@pytest.mark.timeout(120)
+def test_scheduler_logic_with_fake_model():
+    """Chunk rules of cli/model.py:341-371 under the scheduler: first chunk after hop + prompt pad + lookahead tokens, hop doubling up to the
+    maximum, final call with everything; offline requests vocode once; a failing request reports on its own channel; state is cleaned up."""
+    scripts = {1: list(range(47)), 2: list(range(9))}
+    fm = _FakeModel(scripts)
+    sch = StreamScheduler(fm, slots=4, step_chunk=4)
+    try:
+        def req(n_text, n_prompt=8):
+            return dict(text=torch.zeros(1, n_text, dtype=torch.int32), prompt_text=torch.zeros(1, 2, dtype=torch.int32),
+                        llm_prompt_speech_token=torch.zeros(1, n_prompt, dtype=torch.int32), flow_prompt_speech_token=torch.zeros(1, n_prompt, dtype=torch.int32),
+                        prompt_speech_feat=torch.zeros(1, 2 * n_prompt, 80), llm_embedding=torch.zeros(1, 192), flow_embedding=torch.zeros(1, 192))
+        outs = [o["tts_speech"] for o in sch.submit(stream=True, **req(1))]
+        # prompt 8 -> pad 2: chunks end at token 7, 17, 37 (hops 5+2, 10, 20), each needs 3 lookahead tokens; 47 tokens in total
+        calls = [c[1:] for c in fm.calls]
+        assert calls == [(10, 0, True, False), (20, 7, True, False), (40, 17, True, False), (47, 37, False, True)]
+        assert [o.shape[1] // 960 for o in outs] == [7, 10, 20, 10]
+        fm.calls.clear()
+        outs = [o["tts_speech"] for o in sch.submit(stream=False, **req(2))]
+        assert [c[1:] for c in fm.calls] == [(9, 0, False, True)] and len(outs) == 1
+        with pytest.raises(ValueError, match="empty text"):
+            list(sch.submit(stream=True, **req(0)))
+        assert not sch._reqs and not fm.hift_cache_dict
+        # two interleaved streams keep their own schedules
+        fm.calls.clear()
+        got = [None, None]
+        th = [threading.Thread(target=lambda i=i: got.__setitem__(i, [o["tts_speech"].shape[1] // 960 for o in sch.submit(stream=True, **req(1, 8 if i == 0 else 5))])) for i in (0, 1)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert got[0] == [7, 10, 20, 10] and got[1] == [5, 10, 20, 12]
+    finally:
+        sch.shutdown()
+
+
+def test_fastapi_adapter_streams_pcm16(lib, setup):
+    from starlette.testclient import TestClient
+    if lib.emulated:
+        pytest.skip("hardware only: end to end through the real model (the HTTP adapter itself is covered by test_fastapi_adapter_with_stub_engine)")
+    cfgs, sds = setup
+    m = _model(lib, cfgs, sds)
+    sch = StreamScheduler(m, slots=2, step_chunk=4)
+    try:
+        eng = Engine(sch, _StubFrontend(cfgs))
+        client = TestClient(create_app(eng))
+        buf = io.BytesIO()
+        with wave.open(buf, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes((np.sin(np.arange(8000) * 0.05) * 8000).astype(np.int16).tobytes())
+        r = client.post("/inference_zero_shot", params={"tts_text": "ab|c", "prompt_text": "x"}, content=buf.getvalue())
+        assert r.status_code == 200, r.text
+        want = b"".join(pcm16_stream(eng.inference_zero_shot("ab|c", "x", torch.zeros(1, 8000))))
+        assert len(r.content) == len(want) > 0 and len(r.content) % (2 * 480 * 2) == 0 and r.content == want
+        r2 = client.post("/inference_cross_lingual", params={"tts_text": "a"}, content=buf.getvalue())
+        assert r2.status_code == 200 and len(r2.content) > 0
+    finally:
+        sch.shutdown()
+
+
+@pytest.mark.timeout(120)
+def test_fastapi_adapter_with_stub_engine():
+    """Routes and the int16 PCM streaming contract of runtime/python/fastapi/server.py:38-86 over a stub engine."""
+    from starlette.testclient import TestClient
+
+    class Stub:
+        def inference_sft(self, tts_text, spk_id):
+            yield {"tts_speech": torch.full((1, 4), 0.5)}
+
+        def inference_zero_shot(self, tts_text, prompt_text, prompt_wav):
+            assert prompt_wav.shape == (1, 8000) and abs(float(prompt_wav.abs().max()) - 8000 / 32768.0) < 1e-3
+            for ch in tts_text:
+                yield {"tts_speech": torch.full((1, 3), ord(ch) / 32768.0)}
+
+        inference_cross_lingual = lambda self, tts_text, prompt_wav: iter([{"tts_speech": torch.zeros(1, 2)}])
+        inference_instruct2 = lambda self, tts_text, instruct_text, prompt_wav: iter([{"tts_speech": torch.ones(1, 2) * 0.25}])
+
+    client = TestClient(create_app(Stub()))
+    buf = io.BytesIO()
+    with wave.open(buf, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes((np.sign(np.sin(np.arange(8000) * 0.05)) * 8000).astype(np.int16).tobytes())
+    r = client.post("/inference_sft", params={"tts_text": "x", "spk_id": "s"})
+    assert r.status_code == 200 and np.frombuffer(r.content, dtype=np.int16).tolist() == [16384] * 4
+    r = client.post("/inference_zero_shot", params={"tts_text": "ab", "prompt_text": "p"}, content=buf.getvalue())
+    assert r.status_code == 200 and np.frombuffer(r.content, dtype=np.int16).tolist() == [97] * 3 + [98] * 3
+    r = client.post("/inference_instruct2", params={"tts_text": "ab", "instruct_text": "i"}, content=buf.getvalue())
+    assert r.status_code == 200 and np.frombuffer(r.content, dtype=np.int16).tolist() == [8192, 8192]
