@@ -128,12 +128,15 @@ class StreamScheduler:
         while True:
             with self._cv:
                 while True:
-                    pick = None
-                    for r in self._reqs.values():              # dict order = submission order: the oldest ready request goes first
+                    # Ready work, lowest chunk index first (ties: submission order): a request's FIRST chunk is what its listener is waiting
+                    # for (first-chunk latency), while its later chunks only have to arrive before the audio already delivered runs out.
+                    pick, best = None, None
+                    for r in self._reqs.values():
                         what = self._ready(r)
-                        if what is not None:
-                            pick = (r, what, list(r.tokens))
-                            break
+                        if what is not None and (best is None or r.chunk_index < best):
+                            pick, best = (r, what, list(r.tokens)), r.chunk_index
+                            if best == 0:
+                                break
                     if pick is not None or (self._stop and not self._reqs):
                         break
                     self._cv.wait(timeout=0.5)
