@@ -8,6 +8,7 @@
 #include <vector>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include "ops.h"
 #include "tensor_map.h"
 #include "llm_kernels.h"
@@ -27,6 +28,12 @@ struct cv_llm {
     DevBuf kcache, vcache, rope_cos, rope_sin, state, tokens, uniforms, sparams;
     SampleParams* host_sp = nullptr;
     DevBuf h, qkv, act, logits, attn_part;            // decode activations (+ split-attention partials)
+    DevBuf newtok;                                    // fused qkv + attention: roped q [heads][64], roped k / v [kv_heads][64] of the new token
+    // option "fused_qkv_attn": 1 = qkv_attn_kernel (4 launches per layer), 0 = separate qkv / attention kernels.  Measured on MI355X
+    // (profiles/r2_decode_ab.txt): fused 9.6 us vs 3.4 + 3.9 us - the q rows are recomputed by the 8 key-slice workgroups of a head, which run on
+    // 8 different XCDs, so the PMC shows 13.7 MB of HBM reads per launch instead of 2.1 MB.  Kept, tested, off by default.
+    int fused_qkv_attn = 0;
+    int head_rows = 1;                                // rows per 16-lane group of the head GEMV (1: 411 workgroups, 2: 206)
     int attn_splits = 8;
     int only_cat = -1;                  // cv_llm_profile_chain: enqueue only the launches of this category (-1 = all)
     DevBuf pf_x, pf_xn, pf_qkv, pf_attn, pf_gu, pf_act; // prefill activations (grown on demand)
@@ -99,6 +106,8 @@ static void llm_finalize(cv_llm* m) {
     m->uniforms.ensure((size_t)c.max_len * 2 * sizeof(float));
     m->h.ensure(H * 4); m->qkv.ensure((size_t)m->qkv_dim * 4);
     m->attn_part.ensure((size_t)c.heads * 16 * ATTN_PART * 4);
+    m->newtok.ensure((size_t)(c.heads + 2 * c.kv_heads) * 64 * 4);
+    if (const char* e = getenv("CV_DECODE_FUSED_QKV")) m->fused_qkv_attn = e[0] != '0';     // dev knob for A/B runs (also: option "fused_qkv_attn")
     m->act.ensure((size_t)c.inter * 4); m->logits.ensure((size_t)m->V * 4);
     CV_HIP(hipHostMalloc((void**)&m->host_tokens, (size_t)c.max_len * sizeof(int)));
     CV_HIP(hipHostMalloc((void**)&m->host_state, sizeof(DecodeState)));
@@ -176,6 +185,9 @@ struct ProfScope {
     ~ProfScope() { if (!m->profiling) return; (void)hipEventRecord(e1, s); m->prof_events.push_back({cat, {e0, e1}}); }
 };
 
+// dev knob (CV_GEMV_SHARED_NORM=0 restores the per-wave RMSNorm prologue for A/B runs)
+static const bool g_gemv_shared_norm = [] { const char* e = getenv("CV_GEMV_SHARED_NORM"); return !(e && e[0] == '0'); }();
+
 // picks the instantiation from K (= 128 * steps): <=7 steps -> one wave per 4*ROWS rows; <=40 steps -> 4-way split-K
 static void gemv(const GemvArgs& a, int rows, hipStream_t s, int nsp = 0) {
     const int steps = a.K / 128;
@@ -193,6 +205,12 @@ static void gemv(const GemvArgs& a, int rows, hipStream_t s, int nsp = 0) {
     const dim3 grid((units + 3) / 4);
     if (a.mode == 1) rows = 2;
     if (steps <= 7) {
+        if (a.gamma && g_gemv_shared_norm) {                 // 4 waves share the normalised input through LDS (gemv_norm_kernel)
+            const dim3 g16((units + 15) / 16);
+            if (rows == 2) hipLaunchKernelGGL((gemv_norm_kernel<7, 2>), g16, dim3(256), 0, s, a);
+            else           hipLaunchKernelGGL((gemv_norm_kernel<7, 1>), g16, dim3(256), 0, s, a);
+            return;
+        }
         if (rows == 2) hipLaunchKernelGGL((gemv_kernel<7, 2, 1>), grid, dim3(64), 0, s, a);
         else           hipLaunchKernelGGL((gemv_kernel<7, 1, 1>), grid, dim3(64), 0, s, a);
     } else {
@@ -208,27 +226,37 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
     const DecodeState* st = m->state.as<DecodeState>();
     float* h = m->h.as<float>(); float* qkv = m->qkv.as<float>(); float* act = m->act.as<float>();
     auto want = [&](int cat) { return m->only_cat < 0 || m->only_cat == cat; };
-    if (want(5)) { ProfScope ps(m, s, 5); gemv(GemvArgs{m->head_w, m->head_b, h, m->logits.as<float>(), m->V, c.hidden, m->norm, c.rms_eps, nullptr, 0, st}, 2, s); }
+    if (want(5)) { ProfScope ps(m, s, 5); gemv(GemvArgs{m->head_w, m->head_b, h, m->logits.as<float>(), m->V, c.hidden, m->norm, c.rms_eps, nullptr, 0, st}, m->head_rows, s); }
     SampleArgs sa{};
     sa.logits = m->logits.as<float>(); sa.V = m->V; sa.sp = m->sparams.as<SampleParams>(); sa.uniforms = m->uniforms.as<float>();
     sa.st = m->state.as<DecodeState>(); sa.tokens = m->tokens.as<int>(); sa.max_tokens = c.max_len;
+    sa.emb_table = m->speech_emb; sa.emb_dim = c.hidden; sa.h_out = h;             // sampling + embedding of the sampled token: one launch
     if (want(6)) { ProfScope ps(m, s, 6); hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, s, sa); }
-    if (want(7)) hipLaunchKernelGGL(embed_last_token_kernel, dim3(1), dim3(256), 0, s, m->speech_emb, c.hidden, h, st);
     for (int i = 0; i < c.layers; ++i) {
         const auto& L = m->layers[i];
-        if (want(0)) { ProfScope ps(m, s, 0); gemv(GemvArgs{L.wqkv, L.bqkv, h, qkv, m->qkv_dim, c.hidden, L.ln1, c.rms_eps, nullptr, 0, st}, 1, s); }
         const int nsp = m->attn_splits;
-        AttnDecodeArgs ad{qkv, m->kcache.as<float>() + m->layer_cache() * i, m->vcache.as<float>() + m->layer_cache() * i,
-                          m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st,
-                          m->attn_part.as<float>(), nsp};
-        if (want(1)) { ProfScope ps(m, s, 1); hipLaunchKernelGGL(attn_decode_kernel, dim3(c.heads * nsp), dim3(64), 0, s, ad); }
         GemvArgs go{L.wo, nullptr, nullptr, h, c.hidden, c.heads * 64, nullptr, 0.f, h, 0, st};
         go.part = m->attn_part.as<float>();
+        if (m->fused_qkv_attn) {
+            float* qn = m->newtok.as<float>(); float* kn = qn + c.heads * 64; float* vn = kn + c.kv_heads * 64;
+            QkvAttnArgs qa{L.wqkv, L.bqkv, h, L.ln1, c.rms_eps, c.hidden, m->kcache.as<float>() + m->layer_cache() * i, m->vcache.as<float>() + m->layer_cache() * i,
+                           m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st, m->attn_part.as<float>(), nsp, qn, kn, vn};
+            // profiling category 0 (qkv) carries the fused launch; category 1 (attention) stays empty in this mode
+            if (want(0)) { ProfScope ps(m, s, 0); hipLaunchKernelGGL((qkv_attn_kernel<7>), dim3(c.heads * nsp + 2 * c.kv_heads), dim3(256), 0, s, qa); }
+            go.qnew = qn; go.knew = kn; go.vnew = vn; go.kv_group = c.heads / c.kv_heads;
+        } else {
+            if (want(0)) { ProfScope ps(m, s, 0); gemv(GemvArgs{L.wqkv, L.bqkv, h, qkv, m->qkv_dim, c.hidden, L.ln1, c.rms_eps, nullptr, 0, st}, 1, s); }
+            AttnDecodeArgs ad{qkv, m->kcache.as<float>() + m->layer_cache() * i, m->vcache.as<float>() + m->layer_cache() * i,
+                              m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st,
+                              m->attn_part.as<float>(), nsp};
+            if (want(1)) { ProfScope ps(m, s, 1); hipLaunchKernelGGL(attn_decode_kernel, dim3(c.heads * nsp), dim3(64), 0, s, ad); }
+        }
         if (want(2)) { ProfScope ps(m, s, 2); gemv(go, 1, s, nsp); }
         if (want(3)) { ProfScope ps(m, s, 3); gemv(GemvArgs{L.wgu, nullptr, h, act, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 1, st}, 2, s); }
-        if (want(4)) { ProfScope ps(m, s, 4); gemv(GemvArgs{L.wdown, nullptr, act, h, c.hidden, c.inter, nullptr, 0.f, h, 0, st}, 1, s); }
+        GemvArgs gd{L.wdown, nullptr, act, h, c.hidden, c.inter, nullptr, 0.f, h, 0, st};
+        if (i == c.layers - 1 && m->only_cat < 0) gd.advance = m->state.as<DecodeState>();     // the step's last kernel also advances the KV length
+        if (want(4)) { ProfScope ps(m, s, 4); gemv(gd, 1, s); }
     }
-    if (want(7)) hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, s, m->state.as<DecodeState>());
 }
 
 static bool same_sampling(const cv_sampling& a, const cv_sampling& b) {
@@ -356,8 +384,8 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
         SampleArgs sa{};
         sa.logits = logits + i * V; sa.V = (int)V; sa.sp = b.sparams.as<SampleParams>() + i; sa.uniforms = b.uniforms.as<float>() + (size_t)i * 2 * c.max_len;
         sa.st = st + i; sa.tokens = b.tokens.as<int>() + (size_t)i * c.max_len; sa.max_tokens = c.max_len;
+        sa.emb_table = m->speech_emb; sa.emb_dim = c.hidden; sa.h_out = h + i * H;
         hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, s, sa);
-        hipLaunchKernelGGL(embed_last_token_kernel, dim3(1), dim3(256), 0, s, m->speech_emb, c.hidden, h + i * H, st + i);
     }
     for (int l = 0; l < c.layers; ++l) {
         const auto& L = m->layers[l];
@@ -437,6 +465,8 @@ int cv_llm_set_option(cv_llm* m, const char* name, int32_t value) {
         CV_CHECK(m && name, "null argument");
         std::lock_guard<std::recursive_mutex> lk(runtime_lock());
         if (std::string(name) == "use_graph") { m->use_graph = value != 0; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; } }
+        else if (std::string(name) == "head_rows") { CV_CHECK(value == 1 || value == 2, "head_rows must be 1 or 2"); m->head_rows = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; } }
+        else if (std::string(name) == "fused_qkv_attn") { m->fused_qkv_attn = value != 0; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; } }
         else if (std::string(name) == "attn_splits") {       // key-range slices per head in the decode attention (4, 8 or 16)
             CV_CHECK(value == 4 || value == 8 || value == 16, "attn_splits must be 4, 8 or 16");
             m->attn_splits = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }

@@ -33,6 +33,10 @@ struct GemvArgs {
     const bf16_t* W; const float* bias; const float* x; float* y; int N, K;
     const float* gamma; float eps; const float* res; int mode; const DecodeState* st;
     const float* part = nullptr;   // NSP > 0: x is the combination of NSP split-attention partials, [K/64][NSP][ATTN_PART] (see attn_decode_kernel)
+    // qkv_attn_kernel leaves the NEW token out of its partials (its k / v are computed by other workgroups of the same launch); the merge adds
+    // it as one more partial: score = q_new . k_new / 8, value = v_new.  qnew [K/64][64], knew / vnew [kv heads][64]; null = not used.
+    const float* qnew = nullptr; const float* knew = nullptr; const float* vnew = nullptr; int kv_group = 1;
+    DecodeState* advance = nullptr;   // last GEMV of a backbone step: also advances the KV length (no kernel of the step reads `pos` after it)
 };
 
 constexpr int ATTN_PART = 68;      // 64 unnormalised numerators + running max + denominator (+2 pad: rows stay 16-byte aligned)
@@ -49,6 +53,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     // no `done` test here: it would put a dependent load in front of the weight stream; a finished request simply recomputes
     // into buffers nobody reads (sample / embed / advance are the kernels that honour `done`).
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
+    if (p.advance && blockIdx.x == 0 && tid == 0 && !p.advance->done) p.advance->pos += 1;
     const int steps = p.K / 128;
     const int s0 = wave * steps / WAVES, s1 = (wave + 1) * steps / WAVES;
     const int row0 = (blockIdx.x * 4 + grp) * ROWS;
@@ -84,6 +89,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
         // (64 load instructions per lane measured +2 us on the o_proj launch: address-unit bound, not bandwidth bound).
         static_assert(WAVES == 4, "partial-combine prologue: 256 threads cover K <= 1024");
         __shared__ __attribute__((aligned(16))) float xs[1024];
+        // the new token's own (score, value) when the attention left it out (qkv_attn_kernel): 16 threads of a head share the dot product
+        // (computed by every thread, clamped, so that the cross-lane reduction runs in uniform control flow)
+        float s_new = 0.f; float4 vn = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.qnew) {
+            const int hh = min(tid >> 4, p.K / 64 - 1), g = hh / p.kv_group, d0 = (tid & 15) * 4;
+            const float4 qn = *reinterpret_cast<const float4*>(p.qnew + hh * 64 + d0), kn = *reinterpret_cast<const float4*>(p.knew + g * 64 + d0);
+            vn = *reinterpret_cast<const float4*>(p.vnew + g * 64 + d0);
+            s_new = group16_sum(qn.x * kn.x + qn.y * kn.y + qn.z * kn.z + qn.w * kn.w) * 0.125f;
+        }
         if (tid * 4 < p.K) {
             const float* ph = p.part + (long long)(tid >> 4) * NSP * ATTN_PART;
             float4 pa[NSP]; float2 ml[NSP];
@@ -92,9 +106,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
                 pa[q] = *reinterpret_cast<const float4*>(ph + q * ATTN_PART + (tid & 15) * 4);
                 ml[q] = *reinterpret_cast<const float2*>(ph + q * ATTN_PART + 64);
             }
-            float M = ml[0].x;
+            float M = p.qnew ? s_new : ml[0].x;
 #pragma unroll
-            for (int q = 1; q < NSP; ++q) M = fmaxf(M, ml[q].x);
+            for (int q = 0; q < NSP; ++q) if (ml[q].y > 0.f || !p.qnew) M = fmaxf(M, ml[q].x);
             float den = 0.f; float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int q = 0; q < NSP; ++q) {
@@ -102,6 +116,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
                 den += w * ml[q].y;
                 a.x += w * pa[q].x; a.y += w * pa[q].y; a.z += w * pa[q].z; a.w += w * pa[q].w;
             }
+            if (p.qnew) { const float w = expf(s_new - M); den += w; a.x += w * vn.x; a.y += w * vn.y; a.z += w * vn.z; a.w += w * vn.w; }
             const float inv = 1.f / den;
             *reinterpret_cast<float4*>(&xs[tid * 4]) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
         }
@@ -165,6 +180,87 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     if (p.mode == 1) {                                       // ROWS == 2: (gate_j, up_j)
         const int j = blockIdx.x * 4 + grp;
         if (row0 + 1 < p.N) { const float g = acc[0]; p.y[j] = (g / (1.f + expf(-g))) * acc[ROWS - 1]; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int row = row0 + r;
+            if (row < p.N) {
+                float v = acc[r];
+                if (p.bias) v += p.bias[row];
+                if (p.res) v += p.res[row];
+                p.y[row] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The RMSNorm-prologue GEMVs (qkv, gate / up, head: K = hidden <= 896) with the normalised input SHARED by the 4 waves of a workgroup.
+// In gemv_kernel every wave fetches x AND gamma for itself: 2 x 3.5 KB of L2 reads against 7 - 14 KB of weights - a third to a half of a
+// CU's load instructions went to re-reading the same two vectors (a CU ingests a few tens of bytes per cycle, the binding resource of
+// these kernels).  Here each wave still requests all of its weight rows first; then 224 threads fetch x / gamma once (float4 each), the
+// sum of squares is reduced over the workgroup in a fixed order, x * rstd * gamma is parked in LDS (3.5 KB) and every lane reads its 14
+// float4 from there.  The weight loads stay in flight across both barriers.  Same row -> lane mapping, same FMA order as gemv_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+template <int STEPS, int ROWS>
+__global__ __launch_bounds__(256) void gemv_norm_kernel(GemvArgs p) {
+    __shared__ __attribute__((aligned(16))) float xs[STEPS * 128];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
+    const int steps = p.K / 128;
+    const int unit = (blockIdx.x * 4 + wave) * 4 + grp;      // 16-lane group index: ROWS consecutive rows
+    const int row0 = unit * ROWS;
+
+    u32x4 w[ROWS][STEPS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int row = min(row0 + r, p.N - 1);
+        const bf16_t* wr = p.W + (long long)row * p.K + sub * 8;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const bool ok = s < steps;
+            u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + (ok ? s : 0) * 128));
+            if (!ok) t = (u32x4){0u, 0u, 0u, 0u};
+            w[r][s] = t;
+        }
+    }
+    {
+        const bool have = tid * 4 < p.K;
+        const int k = have ? tid * 4 : 0;
+        float4 xv = *reinterpret_cast<const float4*>(p.x + k), gv = *reinterpret_cast<const float4*>(p.gamma + k);
+        if (!have) xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        float ss = wave_sum(xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        ss = (red[0] + red[1]) + (red[2] + red[3]);
+        const float rstd = rsqrtf(ss / (float)p.K + p.eps);
+        if (have) *reinterpret_cast<float4*>(&xs[k]) = make_float4(xv.x * rstd * gv.x, xv.y * rstd * gv.y, xv.z * rstd * gv.z, xv.w * rstd * gv.w);
+        __syncthreads();
+    }
+    float acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        if (s < steps) {
+            const float4 xa = *reinterpret_cast<const float4*>(&xs[s * 128 + sub * 8]), xb = *reinterpret_cast<const float4*>(&xs[s * 128 + sub * 8 + 4]);
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const u32x4 u = w[r][s];
+                float a = acc[r];
+                a += __uint_as_float(u[0] << 16) * xa.x;          a += __uint_as_float(u[0] & 0xffff0000u) * xa.y;
+                a += __uint_as_float(u[1] << 16) * xa.z;          a += __uint_as_float(u[1] & 0xffff0000u) * xa.w;
+                a += __uint_as_float(u[2] << 16) * xb.x;          a += __uint_as_float(u[2] & 0xffff0000u) * xb.y;
+                a += __uint_as_float(u[3] << 16) * xb.z;          a += __uint_as_float(u[3] & 0xffff0000u) * xb.w;
+                acc[r] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = group16_sum(acc[r]);
+    if (sub != 0) return;
+    if (p.mode == 1) {                                       // ROWS == 2: (gate_j, up_j)
+        if (row0 + 1 < p.N) { const float g = acc[0]; p.y[unit] = (g / (1.f + expf(-g))) * acc[ROWS - 1]; }
     } else {
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
@@ -278,6 +374,188 @@ static __global__ __launch_bounds__(64) void attn_decode_kernel(AttnDecodeArgs p
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// QKV projection + decode attention in ONE launch (one kernel boundary less per layer).
+//   workgroups [0, heads * nsplit):   (head h, key slice sp): RMSNorm (shared through LDS) -> the 64 q rows of head h as a 4-wave GEMV ->
+//       RoPE -> attention over the CACHED keys of the slice (4 waves x 12 keys per pass, online softmax, merged through LDS) -> one
+//       un-normalised partial (64 numerators, max, denominator).  The q GEMV is recomputed by the nsplit workgroups of a head (its 115 KB of
+//       weights come from L2 after the first) - cheaper than a kernel boundary on this chip.
+//   workgroups [heads * nsplit, + 2 * kv_heads):   the new token's k (RoPE'd) and v rows of one kv head: appended to the cache and left in
+//       knew / vnew.  The new token's own score / value cannot be used by the attention workgroups of the same launch, so the o_proj merge
+//       (gemv_kernel<..., NSP>, GemvArgs::qnew) adds it as one more partial.
+// ---------------------------------------------------------------------------------------------------------------
+struct QkvAttnArgs {
+    const bf16_t* W; const float* bias; const float* x; const float* gamma; float eps; int K;
+    float* kcache; float* vcache; const float* rope_cos; const float* rope_sin;
+    int heads, kv_heads, max_len; const DecodeState* st;
+    float* part; int nsplit; float* qnew; float* knew; float* vnew;
+};
+
+template <int STEPS>
+__global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs p) {
+    constexpr int NS = 3, WPASS = 4 * NS, PASS = 4 * WPASS;           // keys per wave / workgroup and pass
+    __shared__ __attribute__((aligned(16))) float xs[STEPS * 128];
+    __shared__ __attribute__((aligned(16))) float vec[64];            // raw projection rows of this workgroup's head
+    __shared__ __attribute__((aligned(16))) float rot[64];            // after RoPE
+    __shared__ __attribute__((aligned(16))) float pw[4][ATTN_PART];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
+    const int steps = p.K / 128;
+    const int n_attn = p.heads * p.nsplit;
+    const bool is_attn = (int)blockIdx.x < n_attn;
+    const int h = is_attn ? blockIdx.x / p.nsplit : 0, sp = is_attn ? blockIdx.x % p.nsplit : 0;
+    const int kvj = is_attn ? 0 : blockIdx.x - n_attn;                 // 0 .. kv_heads-1: k heads, then v heads
+    const int head_row = is_attn ? h * 64 : (p.heads + kvj) * 64;      // first of this workgroup's 64 projection rows
+    const int gsz = p.heads / p.kv_heads, g = is_attn ? h / gsz : kvj % p.kv_heads;
+    const int pos = p.st->pos;
+
+    // 1. every weight row of this wave (16 rows: 4 per 16-lane group)
+    u32x4 w[4][STEPS];
+    const int row_in_head = (wave * 4 + grp) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bf16_t* wr = p.W + (long long)(head_row + row_in_head + r) * p.K + sub * 8;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const bool ok = s < steps;
+            u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + (ok ? s : 0) * 128));
+            if (!ok) t = (u32x4){0u, 0u, 0u, 0u};
+            w[r][s] = t;
+        }
+    }
+    // 2. attention workgroups: the first pass of cached keys of this wave, requested before anything is consumed
+    const int per = ((pos + p.nsplit * 4 - 1) / (p.nsplit * 4)) * 4;   // cached keys per slice (multiple of 4); the new token is not among them
+    const int kb = sp * per, ke = min(pos, kb + per);
+    const float* kc = p.kcache + (long long)g * p.max_len * 64;
+    const float* vc = p.vcache + (long long)g * p.max_len * 64;
+    float4 k4[NS], v4[NS];
+    auto load_pass = [&](int base) {
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            const int j = base + wave * WPASS + sl * 4 + grp;
+            const long long o = (long long)(j < ke ? j : 0) * 64 + sub * 4;   // unconditional, clamped
+            k4[sl] = *reinterpret_cast<const float4*>(kc + o);
+            v4[sl] = *reinterpret_cast<const float4*>(vc + o);
+        }
+    };
+    if (is_attn) load_pass(kb);
+    // 3. RMSNorm of x, shared through LDS (see gemv_norm_kernel)
+    {
+        const bool have = tid * 4 < p.K;
+        const int k = have ? tid * 4 : 0;
+        float4 xv = *reinterpret_cast<const float4*>(p.x + k), gv = *reinterpret_cast<const float4*>(p.gamma + k);
+        if (!have) xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        float ss = wave_sum(xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        ss = (red[0] + red[1]) + (red[2] + red[3]);
+        const float rstd = rsqrtf(ss / (float)p.K + p.eps);
+        if (have) *reinterpret_cast<float4*>(&xs[k]) = make_float4(xv.x * rstd * gv.x, xv.y * rstd * gv.y, xv.z * rstd * gv.z, xv.w * rstd * gv.w);
+        __syncthreads();
+    }
+    // 4. the 64 projection rows
+    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        if (s < steps) {
+            const float4 xa = *reinterpret_cast<const float4*>(&xs[s * 128 + sub * 8]), xb = *reinterpret_cast<const float4*>(&xs[s * 128 + sub * 8 + 4]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const u32x4 u = w[r][s];
+                float a = acc4[r];
+                a += __uint_as_float(u[0] << 16) * xa.x;          a += __uint_as_float(u[0] & 0xffff0000u) * xa.y;
+                a += __uint_as_float(u[1] << 16) * xa.z;          a += __uint_as_float(u[1] & 0xffff0000u) * xa.w;
+                a += __uint_as_float(u[2] << 16) * xb.x;          a += __uint_as_float(u[2] & 0xffff0000u) * xb.y;
+                a += __uint_as_float(u[3] << 16) * xb.z;          a += __uint_as_float(u[3] & 0xffff0000u) * xb.w;
+                acc4[r] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc4[r] = group16_sum(acc4[r]);
+    if (sub == 0) {
+        const float4 b = p.bias ? *reinterpret_cast<const float4*>(p.bias + head_row + row_in_head) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&vec[row_in_head]) = make_float4(acc4[0] + b.x, acc4[1] + b.y, acc4[2] + b.z, acc4[3] + b.w);
+    }
+    __syncthreads();
+    // 5. rotate-half RoPE (q and k heads; v passes through)
+    const bool is_v = !is_attn && kvj >= p.kv_heads;
+    if (tid < 64) {
+        float v = vec[tid];
+        if (!is_v) {
+            const int f = tid & 31;
+            const float c = p.rope_cos[pos * 32 + f], sn = p.rope_sin[pos * 32 + f];
+            v = tid < 32 ? v * c - vec[tid + 32] * sn : v * c + vec[tid - 32] * sn;
+        }
+        rot[tid] = v;
+        if (is_attn) { if (sp == 0) p.qnew[h * 64 + tid] = v; }
+        else {
+            float* dst = is_v ? p.vnew : p.knew;
+            dst[g * 64 + tid] = v;
+            if (!p.st->done) (is_v ? p.vcache : p.kcache)[((long long)g * p.max_len + pos) * 64 + tid] = v;      // KV-cache append
+        }
+    }
+    if (!is_attn) return;
+    __syncthreads();
+    // 6. attention of this wave over its share of the slice
+    const float4 q4 = *reinterpret_cast<const float4*>(&rot[sub * 4]);
+    const float NEG = -__builtin_huge_valf();
+    float m_run = NEG, l_run = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = kb; base < ke; base += PASS) {      // workgroup-uniform
+        if (base != kb) load_pass(base);
+        float sc[NS];
+        float mt = NEG;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            const int j = base + wave * WPASS + sl * 4 + grp;
+            const float4 kk = k4[sl];
+            float a = q4.x * kk.x + q4.y * kk.y + q4.z * kk.z + q4.w * kk.w;
+            a = group16_sum(a) * 0.125f;
+            sc[sl] = j < ke ? a : NEG;
+            mt = fmaxf(mt, sc[sl]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));
+        if (mt == NEG) continue;                         // wave-uniform: this wave holds no key of the pass
+        const float m_new = fmaxf(m_run, mt);
+        const float scale = (m_run == NEG) ? 0.f : expf(m_run - m_new);
+        acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+        float lt = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            const float e = (sc[sl] == NEG) ? 0.f : expf(sc[sl] - m_new);
+            const float4 vv = v4[sl];
+            acc.x += e * vv.x; acc.y += e * vv.y; acc.z += e * vv.z; acc.w += e * vv.w;
+            lt += e;
+        }
+        l_run = l_run * scale + lt;                     // per-group partial (identical on the 16 lanes of a group)
+        m_run = m_new;
+    }
+    acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
+    acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+    l_run += __shfl_xor(l_run, 16); l_run += __shfl_xor(l_run, 32);
+    // 7. merge the 4 waves (fixed order) and leave one partial per (head, slice)
+    if (grp == 0) *reinterpret_cast<float4*>(&pw[wave][sub * 4]) = acc;
+    if (lane == 0) { pw[wave][64] = (l_run > 0.f) ? m_run : 0.f; pw[wave][65] = l_run; }
+    __syncthreads();
+    if (tid < 16) {
+        float M = NEG;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) if (pw[ww][65] > 0.f) M = fmaxf(M, pw[ww][64]);
+        float den = 0.f; float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const float wgt = (pw[ww][65] > 0.f) ? expf(pw[ww][64] - M) : 0.f;
+            const float4 t = *reinterpret_cast<const float4*>(&pw[ww][tid * 4]);
+            den += wgt * pw[ww][65];
+            a.x += wgt * t.x; a.y += wgt * t.y; a.z += wgt * t.z; a.w += wgt * t.w;
+        }
+        float* pr = p.part + (long long)blockIdx.x * ATTN_PART;
+        *reinterpret_cast<float4*>(pr + tid * 4) = a;
+        if (tid == 0) { pr[64] = den > 0.f ? M : 0.f; pr[65] = den; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Prefill helpers
 // ---------------------------------------------------------------------------------------------------------------
 // RoPE on q (in place) and k of L rows, and append k,v to the cache at positions pos0..pos0+L-1.
@@ -348,6 +626,7 @@ struct SampleArgs {
     const float* logits; int V; const SampleParams* sp;
     const float* uniforms;                                    // explicit uniforms [2 per step] when sp->use_uniforms (parity tests)
     DecodeState* st; int* tokens; int max_tokens;
+    const bf16_t* emb_table = nullptr; int emb_dim = 0; float* h_out = nullptr;   // when set: h_out = speech_embedding[token] for an emitted token (was embed_last_token_kernel)
 };
 
 __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned step, unsigned draw) {
@@ -458,14 +737,17 @@ static __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs a) {
             tok = s_tok;
         }
     }
+    const bool stop = tok >= p.eos && tok < p.eos + p.n_stop;
     if (tid == 0) {
-        if (tok >= p.eos && tok < p.eos + p.n_stop) { st->done = 1; st->stop_token = tok; }
+        if (stop) { st->done = 1; st->stop_token = tok; }
         else {
             if (st->n_tokens < p.max_tokens) p.tokens[st->n_tokens] = tok;
             st->n_tokens += 1; st->last_token = tok; st->step = step + 1;
             if (step + 1 >= p.max_len) { /* loop ends after this token; the next replay marks done */ }
         }
     }
+    if (a.h_out && !stop)                                     // input of the backbone step that follows in the same graph replay
+        for (int c = tid; c < a.emb_dim; c += 1024) a.h_out[c] = bf16_to_f32(a.emb_table[(long long)tok * a.emb_dim + c]);
 }
 
 // advance the KV length after a backbone step

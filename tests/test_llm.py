@@ -204,3 +204,25 @@ def test_inference_bistream(lib, tiny_sd):
     u = _utt(cfg)
     assert list(lm.inference(**_kw(u), max_token_text_ratio=3, min_token_text_ratio=1)) == \
         OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=3, min_token_text_ratio=1)
+
+
+@pytest.mark.parametrize("splits,n_prompt", [(8, 11), (4, 300)])
+def test_fused_qkv_attention_variant(lib, tiny_sd, splits, n_prompt):
+    """Option fused_qkv_attn = 1 (qkv_attn_kernel: RMSNorm + q / k / v rows + RoPE + split attention over the cached keys in one launch, the new
+    token joined in the o_proj merge) and head_rows = 2 are alternative decode configurations (measured slower on MI355X, kept selectable):
+    same tokens as the oracle, short and multi-pass contexts."""
+    import ctypes as C
+    cfg, sd = tiny_sd
+    u = _utt(cfg, n_prompt_tok=n_prompt)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=512, sampling="greedy", decode_chunk=6, attn_splits=splits)
+    lib.cv_llm_set_option(lm._h, b"fused_qkv_attn", C.c_int32(1))
+    lib.cv_llm_set_option(lm._h, b"head_rows", C.c_int32(2))
+    got = list(lm.inference(**_kw(u), max_token_text_ratio=2, min_token_text_ratio=2))
+    trace = {}
+    want = OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=2, min_token_text_ratio=2, trace=trace)
+    assert got == want
+    lm.prefill(lm.build_lm_input(u["text"], u["prompt_text"], u["llm_prompt_speech_token"]))
+    sp = lm.make_sampling(6, 12)
+    for i in range(min(3, len(want) + 1)):                    # step i attends over the prompt (several passes per slice at 300 keys) + i new keys
+        lm.decode(1, sp)
+        torch.testing.assert_close(lm.last_logits().log_softmax(-1), trace["logp"][i], rtol=1e-4, atol=1e-4)
