@@ -52,7 +52,7 @@ struct cv_flow {
     int fused = 1;                     // bf16 mode: LN-prologue GEMMs + bf16 activations + bf16 flash attention for the transformer blocks
     // tuning knobs of the fused pipeline.  "flow_tile": 0 = by size (one round of workgroups, see ln_gemm_bf16), 1 = 64x64, 2 = 64x128, 3 = 32x64,
     // 4 = 64x192; "attn_waves": 2 | 4 waves (32 | 64 queries) per workgroup; "attn_kt": 64-key tiles per iteration (1 | 2)
-    int flow_tile = 0, attn_waves = 4, attn_kt = 1;
+    int flow_tile = 0, attn_waves = 4, attn_kt = 1, attn_ks = 2;   // "attn_ks": key splits inside a 64-query workgroup (2 = 8 waves, 128 keys per iteration)
     DevBuf t_val, t_sin, t_h, t_emb, t_mlp;                                                   // time embeddings
     DevBuf f_tok, f_h, f_mu, f_spk, f_spkn, f_cond, f_x, f_ones;                              // inference glue
     int enc_cap = 0, est_cap = 0, t_cap = 0, inf_cap = 0;
@@ -141,13 +141,13 @@ static void flow_finalize(cv_flow* m) {
 
 // precision of the Linear / Conv1d products issued by the current entry point (set from the handle's option for the duration of a call)
 static thread_local int tl_bf16_mfma = 0;
-static thread_local int tl_flow_tile = 0, tl_attn_waves = 4, tl_attn_kt = 2;     // tuning knobs of the fused pipeline, per call like the precision
+static thread_local int tl_flow_tile = 0, tl_attn_waves = 4, tl_attn_kt = 2, tl_attn_ks = 1;     // tuning knobs of the fused pipeline, per call like the precision
 struct PrecisionScope {
-    int prev, pt, pw, pk;
-    explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves), pk(tl_attn_kt) {
-        tl_bf16_mfma = m->bf16_mfma; tl_flow_tile = m->flow_tile; tl_attn_waves = m->attn_waves; tl_attn_kt = m->attn_kt;
+    int prev, pt, pw, pk, ps;
+    explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves), pk(tl_attn_kt), ps(tl_attn_ks) {
+        tl_bf16_mfma = m->bf16_mfma; tl_flow_tile = m->flow_tile; tl_attn_waves = m->attn_waves; tl_attn_kt = m->attn_kt; tl_attn_ks = m->attn_ks;
     }
-    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; }
+    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; tl_attn_ks = ps; }
 };
 
 // ---- generic conv/linear on channel-last activations -----------------------------------------------------------------
@@ -330,6 +330,7 @@ static void attn_flow(const bf16_t* qk, int ld, int inner, const bf16_t* vt, lon
     a.q = qk; a.k = qk + inner; a.ld = ld; a.vt = vt; a.vt_batch = vt_batch; a.ldt = ldt; a.o = o; a.ldo = inner;
     a.B = B; a.H = H; a.T = T; a.scale = 0.125f; a.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; a.chunk = chunk;
     const dim3 g2((unsigned)(((T + 31) / 32) * H * B)), g4((unsigned)(((T + 63) / 64) * H * B));
+    if (tl_attn_ks == 2) { hipLaunchKernelGGL((attn_flow_kernel<4, 2, 2>), g4, dim3(512), 0, s, a); return; }
     if (tl_attn_waves == 2) {
         if (tl_attn_kt == 2) hipLaunchKernelGGL((attn_flow_kernel<2, 2>), g2, dim3(128), 0, s, a);
         else hipLaunchKernelGGL((attn_flow_kernel<2, 1>), g2, dim3(128), 0, s, a);
@@ -476,6 +477,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         if (std::string(name) == "use_graph") { m->use_graph = value != 0; drop_graphs(m); }
         else if (std::string(name) == "bf16_mfma") { m->bf16_mfma = value != 0; drop_graphs(m); }      // captured graphs bake the kernel choice
         else if (std::string(name) == "flow_tile") { CV_CHECK(value >= 0 && value <= 4, "flow_tile must be 0..4"); m->flow_tile = value; drop_graphs(m); }
+        else if (std::string(name) == "attn_ks") { CV_CHECK(value == 1 || value == 2, "attn_ks must be 1 or 2"); m->attn_ks = value; drop_graphs(m); }
         else if (std::string(name) == "attn_kt") { CV_CHECK(value == 1 || value == 2, "attn_kt must be 1 or 2"); m->attn_kt = value; drop_graphs(m); }
         else if (std::string(name) == "attn_waves") { CV_CHECK(value == 2 || value == 4, "attn_waves must be 2 or 4"); m->attn_waves = value; drop_graphs(m); }
         else if (std::string(name) == "fused") { m->fused = value != 0; drop_graphs(m); }              // bf16 mode: fused transformer blocks (flow_fused.h) on / off

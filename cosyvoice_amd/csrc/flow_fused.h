@@ -242,17 +242,22 @@ struct AttnFlowArgs {
     int B, H, T; float scale; int mask_mode; int chunk;
 };
 
-template <int NW, int KT>
-__global__ __launch_bounds__(NW * 64) void attn_flow_kernel(AttnFlowArgs p) {
+template <int NW, int KT, int KS = 1>
+__global__ __launch_bounds__(NW * KS * 64) void attn_flow_kernel(AttnFlowArgs p) {
     // KT = 64-key tiles per iteration: with one workgroup per CU (176 of them at T = 674) each SIMD runs ONE wave, so nothing overlaps the
     // dependent chain MFMA -> scale -> row max (2 cross-lane exchanges) -> exp2 -> pack -> MFMA of a tile but the tile's own independent
     // work: KT = 2 halves the number of serial softmax steps and doubles the independent MFMA chains in flight.
-    constexpr int NT = NW * 64, BQ = NW * 16, BKV = 64 * KT, LDH = 36, LDV = BKV / 2 + 4;     // LDS row pitches in dwords
+    // KS = key splits inside the workgroup: the KT tiles of an iteration are shared out over KS wave sets (wave = query group + NW * split), each
+    // running its own online softmax over its tiles; the sets are merged through LDS at the end.  The problem is too small for the chip
+    // (674 query waves for 1024 SIMDs at T = 674), so the way to shorten a workgroup's serial chain is to put MORE waves on the same queries.
+    constexpr int NT = NW * KS * 64, BQ = NW * 16, BKV = 64 * KT, LDH = 36, LDV = BKV / 2 + 4;     // LDS row pitches in dwords
+    constexpr int KTW = KT / KS;                          // 64-key tiles per wave and iteration
     constexpr int NI = BKV * 8 / NT;                      // 16-byte pieces per thread and operand tile (BKV x 64 bf16 each)
+    static_assert(KT % KS == 0 && KTW >= 1 && BKV * 8 % NT == 0, "attn_flow_kernel: tile / split configuration");
     __shared__ __attribute__((aligned(16))) unsigned Ks[2][BKV * LDH];
     __shared__ __attribute__((aligned(16))) unsigned Vt[2][64 * LDV];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6, wave = wave_all % NW, ks = wave_all / NW;
     const int lq = lane & 15, lg = lane >> 4;
     const int nqb = (p.T + BQ - 1) / BQ, nbl = gridDim.x;
     const int bl = xcd_remap((int)blockIdx.x, nbl);       // the query tiles of one (request, head) share an XCD: its K / V^T stream through ONE L2
@@ -308,23 +313,24 @@ __global__ __launch_bounds__(NW * 64) void attn_flow_kernel(AttnFlowArgs p) {
     for (int d = 0; d < 4; ++d) acc[d] = (v4f){0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int kt0, int buf) {
-        v4f s[4 * KT];                                     // s[kt][r] <-> key kt0 + kt*16 + lg*4 + r, query lq
+        const int koff = ks * KTW * 64;                    // this wave set's keys inside the staged block
+        v4f s[4 * KTW];                                    // s[kt][r] <-> key kt0 + koff + kt*16 + lg*4 + r, query lq
 #pragma unroll
-        for (int kt = 0; kt < 4 * KT; ++kt) {
+        for (int kt = 0; kt < 4 * KTW; ++kt) {
             v4f sa = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int dg = 0; dg < 2; ++dg) {
-                const uint4 kf = *reinterpret_cast<const uint4*>(&Ks[buf][(kt * 16 + lq) * LDH + dg * 16 + lg * 4]);
+                const uint4 kf = *reinterpret_cast<const uint4*>(&Ks[buf][(koff + kt * 16 + lq) * LDH + dg * 16 + lg * 4]);
                 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, kf), __builtin_bit_cast(v8bf, qf[dg]), sa, 0, 0, 0);
             }
             s[kt] = sa;
         }
         float mt = NEG_INF;
 #pragma unroll
-        for (int kt = 0; kt < 4 * KT; ++kt)
+        for (int kt = 0; kt < 4 * KTW; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = kt0 + kt * 16 + lg * 4 + r;
+                const int key = kt0 + koff + kt * 16 + lg * 4 + r;
                 const float x = key < klim ? s[kt][r] * scale2 : NEG_INF;     // log2 units: softmax on v_exp_f32
                 s[kt][r] = x;
                 mt = fmaxf(mt, x);
@@ -335,11 +341,11 @@ __global__ __launch_bounds__(NW * 64) void attn_flow_kernel(AttnFlowArgs p) {
         const float alpha = (m_run == NEG_INF) ? 0.f : exp2f(m_run - m_new);
         float rsum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 4 * KT; ++kt)
+        for (int kt = 0; kt < 4 * KTW; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x = s[kt][r];
-                const float e = (x == NEG_INF) ? 0.f : exp2f(x - m_new);
+                const float e = (x == NEG_INF || m_new == NEG_INF) ? 0.f : exp2f(x - m_new);
                 s[kt][r] = e;
                 rsum += e;                                 // the denominator sums the UNROUNDED probabilities
             }
@@ -350,12 +356,12 @@ __global__ __launch_bounds__(NW * 64) void attn_flow_kernel(AttnFlowArgs p) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) acc[d] = acc[d] * alpha;
 #pragma unroll
-        for (int blk = 0; blk < 2 * KT; ++blk) {           // k-slot (g, 4 s + r) of 32-key block blk is key 32 blk + 16 s + 4 g + r on both operands
+        for (int blk = 0; blk < 2 * KTW; ++blk) {          // k-slot (g, 4 s + r) of 32-key block blk is key 32 blk + 16 s + 4 g + r on both operands
             const uint4 pb = make_uint4(pack_bf16x2(s[2 * blk][0], s[2 * blk][1]), pack_bf16x2(s[2 * blk][2], s[2 * blk][3]),
                                         pack_bf16x2(s[2 * blk + 1][0], s[2 * blk + 1][1]), pack_bf16x2(s[2 * blk + 1][2], s[2 * blk + 1][3]));
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const uint4 vf = *reinterpret_cast<const uint4*>(&Vt[buf][(dt * 16 + lq) * LDV + blk * 16 + lg * 4]);
+                const uint4 vf = *reinterpret_cast<const uint4*>(&Vt[buf][(dt * 16 + lq) * LDV + (ks * 2 * KTW + blk) * 16 + lg * 4]);
                 acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, vf), __builtin_bit_cast(v8bf, pb), acc[dt], 0, 0, 0);
             }
         }
@@ -373,6 +379,34 @@ __global__ __launch_bounds__(NW * 64) void attn_flow_kernel(AttnFlowArgs p) {
         __syncthreads();
     }
 
+    if constexpr (KS > 1) {
+        // merge the key splits of every query group (fixed order): sets 1 .. KS-1 park (max, denominator, numerators) in LDS - the K ring is free
+        // after the loop's last barrier - and set 0 combines.  Row pitch 19 floats per lane.
+        float* mg = reinterpret_cast<float*>(&Ks[0][0]);
+        static_assert(2 * BKV * LDH >= (KS - 1) * NW * 64 * 19, "merge scratch does not fit the K ring");
+        if (ks > 0) {
+            float* d = mg + ((ks - 1) * NW * 64 + wave * 64 + lane) * 19;
+            d[0] = m_run; d[1] = l_run;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { d[2 + dt * 4 + 0] = acc[dt][0]; d[2 + dt * 4 + 1] = acc[dt][1]; d[2 + dt * 4 + 2] = acc[dt][2]; d[2 + dt * 4 + 3] = acc[dt][3]; }
+        }
+        __syncthreads();
+        if (ks > 0) return;
+#pragma unroll
+        for (int o2 = 1; o2 < KS; ++o2) {
+            const float* d = mg + ((o2 - 1) * NW * 64 + wave * 64 + lane) * 19;
+            const float m2 = d[0], l2 = d[1];
+            const float m_new = fmaxf(m_run, m2);
+            const float a1 = (m_run == NEG_INF) ? 0.f : exp2f(m_run - m_new), a2 = (m2 == NEG_INF) ? 0.f : exp2f(m2 - m_new);
+            l_run = l_run * a1 + l2 * a2;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                acc[dt][0] = acc[dt][0] * a1 + d[2 + dt * 4 + 0] * a2; acc[dt][1] = acc[dt][1] * a1 + d[2 + dt * 4 + 1] * a2;
+                acc[dt][2] = acc[dt][2] * a1 + d[2 + dt * 4 + 2] * a2; acc[dt][3] = acc[dt][3] * a1 + d[2 + dt * 4 + 3] * a2;
+            }
+            m_run = m_new;
+        }
+    }
     if (qvalid) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
         bf16_t* op = p.o + ((long long)b * p.T + qi) * p.ldo + h * 64;

@@ -268,8 +268,8 @@ def test_estimator_module_contract(lib):
     torch.testing.assert_close(x, g["out"], rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("tile,waves,kt", [(0, 4, 2), (1, 2, 1), (2, 4, 1), (3, 2, 2), (4, 4, 2)])
-def test_fused_transformer_blocks_match_unfused(lib, tile, waves, kt):
+@pytest.mark.parametrize("tile,waves,kt,ks", [(0, 4, 2, 2), (1, 2, 1, 1), (2, 4, 1, 1), (3, 2, 2, 1), (4, 4, 2, 1)])
+def test_fused_transformer_blocks_match_unfused(lib, tile, waves, kt, ks):
     """bf16 mode: the fused pipeline of the estimator's transformer blocks (flow_fused.h: LayerNorm in the GEMM prologue, bf16 Q / K / V^T /
     attention output / FF hidden between kernels, bf16-in flash attention) rounds the same operands at the same points as the unfused
     launches.  Two heads, a time axis that is not a
@@ -290,6 +290,7 @@ def test_fused_transformer_blocks_match_unfused(lib, tile, waves, kt):
                 lib.cv_flow_set_option(flow._h, b"flow_tile", C.c_int32(tile))
                 lib.cv_flow_set_option(flow._h, b"attn_waves", C.c_int32(waves))
                 lib.cv_flow_set_option(flow._h, b"attn_kt", C.c_int32(kt))
+                lib.cv_flow_set_option(flow._h, b"attn_ks", C.c_int32(ks))
                 outs.append(flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu())
             ref = OF.estimator(sd, cfg, x, mask, mu, t, spk, cond, streaming)
             # A bf16 computation is not a smooth function of its inputs (DESIGN.md section 5 "bf16 mode" iii): where the LayerNorm statistics of the

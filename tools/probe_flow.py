@@ -40,11 +40,11 @@ opt = lambda k, v: flow.lib.cv_flow_set_option(flow._h, k, C.c_int32(v))
 if "all" in which:
     opt(b"fused", 0); ref = bench("unfused (round-1 path)")
     opt(b"fused", 1)
-    for tile, waves, kt in ((0, 4, 2), (0, 4, 1), (0, 2, 2), (1, 4, 2), (2, 4, 2), (3, 4, 2), (4, 4, 2)):
-        opt(b"flow_tile", tile); opt(b"attn_waves", waves); opt(b"attn_kt", kt)
-        mel = bench("fused tile=%d attn_waves=%d attn_kt=%d" % (tile, waves, kt))
+    for tile, waves, kt, ks in ((0, 4, 1, 1), (0, 4, 2, 2), (0, 4, 2, 1)):
+        opt(b"flow_tile", tile); opt(b"attn_waves", waves); opt(b"attn_kt", kt); opt(b"attn_ks", ks)
+        mel = bench("fused tile=%d attn_waves=%d attn_kt=%d attn_ks=%d" % (tile, waves, kt, ks))
         print("    max |fused - unfused| = %.3e (mel std %.2f)" % ((mel - ref).abs().max().item(), ref.std().item()), flush=True)
 else:
-    opt(b"fused", int(os.environ.get("FUSED", "1"))); opt(b"flow_tile", int(os.environ.get("TILE", "0"))); opt(b"attn_waves", int(os.environ.get("WAVES", "4"))); opt(b"attn_kt", int(os.environ.get("KT", "2")))
+    opt(b"fused", int(os.environ.get("FUSED", "1"))); opt(b"flow_tile", int(os.environ.get("TILE", "0"))); opt(b"attn_waves", int(os.environ.get("WAVES", "4"))); opt(b"attn_kt", int(os.environ.get("KT", "1"))); opt(b"attn_ks", int(os.environ.get("KS", "2")))
     opt(b"use_graph", 0)
     bench("profile run", reps=1)
