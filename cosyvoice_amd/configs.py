@@ -42,6 +42,10 @@ class FlowConfig:                     # Appendix A.2 / A.3 (cosyvoice2.yaml:38-8
     chunk: int = 25                   # static_chunk_size in tokens (estimator: chunk * 2 frames)
     cfg_rate: float = 0.7
     n_timesteps: int = 10
+    # estimator family: "unet" = CausalConditionalDecoder (CosyVoice2), "dit" = DiT (Fun-CosyVoice3, flow/DiT/dit.py:104-176).  For "dit" the fields
+    # are read as: dim = flow input_size = mu_dim (80), ffn = PreLookaheadLayer channels (1024), est_ch = DiT width (1024), est_heads (16),
+    # est_blocks = depth (22), est_mid = ff_mult (2); there is no conformer encoder (enc_blocks = up_blocks = 0), chunk = static_chunk_size / 2.
+    estimator: str = "unet"
 
 
 @dataclass
@@ -77,6 +81,17 @@ def tiny_cv3_llm():
 def cv3_llm():
     """The LM of Fun-CosyVoice3-0.5B (cosyvoice3.yaml:23-36): same Qwen2.5-0.5B backbone, CosyVoice3LM head / embedding layout."""
     return LLMConfig(cv3=True, n_special=200)
+
+
+def cv3_flow():
+    """CausalMaskedDiffWithDiT of Fun-CosyVoice3-0.5B (cosyvoice3.yaml:38-75)."""
+    return FlowConfig(vocab=6561, dim=80, enc_heads=0, ffn=1024, enc_blocks=0, up_blocks=0, est_ch=1024, est_heads=16, est_blocks=22, est_mid=2,
+                      chunk=25, estimator="dit")
+
+
+def tiny_cv3_flow():
+    return FlowConfig(vocab=60, dim=80, enc_heads=0, ffn=64, enc_blocks=0, up_blocks=0, spk_dim=32, est_ch=128, est_heads=2, est_blocks=2, est_mid=2,
+                      chunk=5, n_timesteps=2, estimator="dit")
 
 
 def tiny():

@@ -20,7 +20,9 @@ void gemm_conv(GemmConvArgs a, bool w_bf16, int batch, hipStream_t s) {
         if (a.a_len * 4 > 0x70000000LL || w_bytes > 0x70000000LL || a_reach > 0x70000000LL) a.a_vec = 0;
     }
     a.c_vec = aligned16(a.C) && (a.ldc % 4 == 0) && (a.c_off % 4 == 0) && (a.c_batch % 4 == 0) && (a.c_len % 4 == 0) &&
-              (!a.bias || aligned16(a.bias)) && (!a.res || (aligned16(a.res) && a.res_batch % 4 == 0));
+              (!a.bias || (aligned16(a.bias) && a.bias_batch % 4 == 0)) && (!a.res || (aligned16(a.res) && a.res_batch % 4 == 0)) &&
+              (!a.col_scale || (aligned16(a.col_scale) && a.col_scale_stride % 4 == 0));
+    CV_CHECK(!a.col_scale || a.col_scale_rows > 0, "gemm_conv: col_scale needs col_scale_rows > 0");
     if (a.pro == ACT_SNAKE) CV_CHECK(a.pro_alpha && aligned16(a.pro_alpha), "gemm_conv: snake prologue needs 16B aligned alpha[Kp]");
     launch_gemm_conv(a, w_bf16, batch, s);
 }

@@ -26,6 +26,7 @@ struct ConformerW { LN norm_mha, norm_ff; Lin qkv, pos, out, ff1, ff2; const flo
 struct ResnetW { Lin mlp, conv1, conv2, res; LN ln1, ln2; };
 struct TBlockW { LN norm1, norm3; Lin qkv, out, ff1, ff2; };
 struct StageW { ResnetW res; std::vector<TBlockW> tf; };
+struct DitBlockW { Lin mod, qkv, out, ff1, ff2; };       // DiTBlock (flow/DiT/modules.py:500-530)
 
 inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
@@ -40,6 +41,10 @@ struct cv_flow {
     LN embed_ln, up_embed_ln, after_norm;
     std::vector<ConformerW> enc, enc_up;
     const void* input_embedding = nullptr;
+    // DiT estimator + front of CausalMaskedDiffWithDiT (cfg.estimator == 1; Fun-CosyVoice3, flow/flow.py:284-414, flow/DiT/dit.py:104-176)
+    Lin d_pre1, d_pre2, d_time1, d_time2, d_inproj, d_pos1, d_pos2, d_fmod, d_proj;
+    std::vector<DitBlockW> dit;
+    DevBuf d_x, d_y, d_n, d_qkv, d_att, d_ff, d_mod, d_fm, d_temb, d_tsin, d_th;
     // estimator
     Lin time1, time2, down_conv, up_conv, final_conv, final_proj;
     LN final_ln;
@@ -89,12 +94,31 @@ static LN get_ln(const cv_flow* m, const std::string& name, int C) { LN n; n.g =
 static void flow_finalize(cv_flow* m) {
     const auto& c = m->cfg;
     CV_CHECK(c.mel == 80, "flow: mel must be 80 (solve_euler hard-codes it, flow_matching.py:95)");
-    CV_CHECK(c.dim % 64 == 0 && c.dim / c.enc_heads == 64 && c.est_ch % 32 == 0, "flow: head_dim is fixed at 64");
-    CV_CHECK(m->tm.has("encoder_proj.w"), "flow: missing tensor 'encoder_proj.w'");
-    m->wbf16 = m->tm.t.at("encoder_proj.w").dtype == CV_BF16;
+    CV_CHECK(c.estimator == 1 || (c.dim % 64 == 0 && c.dim / c.enc_heads == 64 && c.est_ch % 32 == 0), "flow: head_dim is fixed at 64");
+    CV_CHECK(m->tm.has("spk_affine.w"), "flow: missing tensor 'spk_affine.w'");
+    m->wbf16 = m->tm.t.at("spk_affine.w").dtype == CV_BF16;
     const int d = c.dim, C = c.est_ch, inner = c.est_heads * 64, tdim = 4 * C, cin = 4 * c.mel;
     m->input_embedding = m->tm.get("input_embedding", m->wbf16 ? CV_BF16 : CV_F32, (long long)c.vocab * d).p;
     m->spk_affine = get_lin(m, "spk_affine", c.mel, c.spk_dim, 1, true);
+    if (c.estimator == 1) {            // CausalMaskedDiffWithDiT: no conformer encoder, DiT estimator
+        const int D = c.est_ch, Cp = c.ffn, ffi = c.est_mid * D;
+        CV_CHECK(d == c.mel && D % 64 == 0 && D / c.est_heads == 64 && D % 16 == 0 && (D / 16) % 4 == 0 && c.enc_blocks == 0 && c.up_blocks == 0,
+                 "flow(dit): input_size must equal mel, head_dim 64, 16 position-conv groups of a multiple of 4 channels");
+        m->d_pre1 = get_lin(m, "dit.pre.conv1", Cp, d, c.pre_lookahead + 1, true); m->d_pre2 = get_lin(m, "dit.pre.conv2", d, Cp, 3, true);
+        m->d_time1 = get_lin(m, "dit.time1", D, 256, 1, true); m->d_time2 = get_lin(m, "dit.time2", D, D, 1, true);
+        m->d_inproj = get_lin(m, "dit.in_proj", D, 4 * c.mel, 1, true);
+        m->d_pos1 = get_lin(m, "dit.pos.conv1", D, D / 16, 31, true); m->d_pos2 = get_lin(m, "dit.pos.conv2", D, D / 16, 31, true);
+        for (int i = 0; i < c.est_blocks; ++i) {
+            const std::string p = "dit.blk." + std::to_string(i) + ".";
+            DitBlockW b;
+            b.mod = get_lin(m, p + "mod", 6 * D, D, 1, true); b.qkv = get_lin(m, p + "qkv", 3 * D, D, 1, true); b.out = get_lin(m, p + "out", D, D, 1, true);
+            b.ff1 = get_lin(m, p + "ff1", ffi, D, 1, true); b.ff2 = get_lin(m, p + "ff2", D, ffi, 1, true);
+            m->dit.push_back(b);
+        }
+        m->d_fmod = get_lin(m, "dit.final_mod", 2 * D, D, 1, true); m->d_proj = get_lin(m, "dit.proj_out", c.mel, D, 1, true);
+        m->finalized = true;
+        return;
+    }
     m->embed_lin = get_lin(m, "enc.embed.lin", d, d, 1, true); m->embed_ln = get_ln(m, "enc.embed.ln", d);
     m->up_embed_lin = get_lin(m, "enc.up_embed.lin", d, d, 1, true); m->up_embed_ln = get_ln(m, "enc.up_embed.ln", d);
     m->after_norm = get_ln(m, "enc.after_norm", d);
@@ -413,11 +437,139 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
     conv_cl(m->final_proj, xb, T, T, 2, 0, 1, m->s_out.as<float>(), ACT_NONE, 0.f, nullptr, s);
 }
 
+
+// ---- DiT estimator (Fun-CosyVoice3) ---------------------------------------------------------------------------------------
+// head-0 rotary of x_transformers as the reference applies it (flow/DiT/modules.py:363-373: on the un-split projection with 64-dim freqs):
+// channels 0..63 of q and of k turn as interleaved pairs by angle pos * 10000^(-2i/64); every other head carries no rotary signal
+static __global__ __launch_bounds__(256) void dit_rope_kernel(float* qkv, long long R, int T, int ld, int k_off) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * 64) return;
+    const long long row = i >> 6; const int j = (int)(i & 63), which = j >> 5, pr = j & 31;
+    const float inv = 1.0f / powf(10000.f, (float)(2 * pr) / 64.f);
+    const float ang = (float)(row % T) * inv, c = cosf(ang), s = sinf(ang);
+    float* p = qkv + row * ld + (which ? k_off : 0) + 2 * pr;
+    const float a = p[0], b = p[1];
+    p[0] = a * c - b * s; p[1] = b * c + a * s;
+}
+// h [n][T'][mel] -> out [2 T'][mel] (repeat_interleave(2) along time, flow/flow.py:391)
+static __global__ __launch_bounds__(256) void repeat2_rows_kernel(const float* x, float* y, long long rows, int C) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * rows * C) return;
+    y[i] = x[(i / C / 2) * C + i % C];
+}
+
+static void dit_reserve(cv_flow* m, int T) {
+    const auto& c = m->cfg; const size_t R = 2 * (size_t)T, D = c.est_ch, f = 4;
+    if ((size_t)T <= (size_t)m->est_cap && m->d_x.p) return;
+    drop_graphs(m);
+    m->s_in.ensure(R * 4 * c.mel * f); m->s_out.ensure(R * c.mel * f);
+    m->d_x.ensure(R * D * f); m->d_y.ensure(R * D * f); m->d_n.ensure(R * D * f); m->d_qkv.ensure(R * 3 * D * f); m->d_att.ensure(R * D * f);
+    m->d_ff.ensure(R * c.est_mid * D * f);
+    m->est_cap = T;
+}
+static void dit_time_reserve(cv_flow* m, int n) {
+    if (n <= m->t_cap && m->d_mod.p) return;
+    drop_graphs(m);
+    const auto& c = m->cfg; const size_t D = c.est_ch;
+    m->t_val.ensure((size_t)n * 4); m->d_tsin.ensure((size_t)n * 256 * 4); m->d_th.ensure((size_t)n * D * 4); m->d_temb.ensure((size_t)n * D * 4);
+    m->d_mod.ensure((size_t)c.est_blocks * n * 6 * D * 4); m->d_fm.ensure((size_t)n * 2 * D * 4);
+    m->t_cap = n;
+}
+// t_val[n] -> time embedding (modules.py:606-616) -> adaLN modulations of every block and of the final norm (SiLU -> Linear, :238-241,:266-268);
+// the "+1" of (1 + scale) is folded into the bias of the scale chunks by the weight repacker
+static void dit_time_embed(cv_flow* m, int n, hipStream_t s) {
+    const auto& c = m->cfg; const int D = c.est_ch;
+    hipLaunchKernelGGL(time_sinusoid_kernel, dim3(n), dim3(256), 0, s, m->t_val.as<float>(), m->d_tsin.as<float>(), n, 256);
+    lin_cl(m->d_time1, m->d_tsin.as<float>(), n, m->d_th.as<float>(), ACT_SILU, nullptr, s);
+    lin_cl(m->d_time2, m->d_th.as<float>(), n, m->d_temb.as<float>(), ACT_NONE, nullptr, s);
+    for (int i = 0; i < c.est_blocks; ++i)
+        lin_cl(m->dit[i].mod, m->d_temb.as<float>(), n, m->d_mod.as<float>() + (size_t)i * n * 6 * D, ACT_NONE, nullptr, s, ACT_SILU);
+    lin_cl(m->d_fmod, m->d_temb.as<float>(), n, m->d_fm.as<float>(), ACT_NONE, nullptr, s, ACT_SILU);
+}
+// grouped causal Conv1d(D, D, k = 31, groups = 16) + Mish of one request (T rows): one batched implicit GEMM, batch = group
+static void dit_group_conv(const Lin& l, const float* A, float* C, const float* res, int T, int D, hipStream_t s) {
+    const int G = 16, gc = D / G;
+    GemmConvArgs a{};
+    a.A = A; a.a_batch = gc; a.a_len = (long long)(T - 1) * D + gc; a.lda = D; a.a_off0 = -(l.taps - 1) * D; a.tap_step = D; a.taps = l.taps; a.K = gc;
+    a.pro = ACT_NONE; a.W = l.w; a.Kp = l.Kp; a.ldw = 0; a.w_batch = (long long)gc * l.taps * l.Kp; a.bias = l.b; a.bias_batch = gc;
+    a.C = C; a.c_batch = gc; a.c_len = (long long)(T - 1) * D + gc; a.ldc = D; a.c_off = 0; a.M = T; a.N = gc;
+    a.act = ACT_MISH; a.res = res; a.res_batch = gc; a.out_scale = 1.f; a.row_scale = nullptr; a.accumulate = 0;
+    a.a_bf16 = tl_bf16_mfma && l.bf16;
+    gemm_conv(a, l.bf16, G, s);
+}
+// Linear with the adaLN-zero gate:  C = res + gate[m / rows_per_gate] * (A W^T + b)
+static void lin_gated(const Lin& l, const float* A, long long rows, float* C, const float* res, const float* gate, long long rows_per_gate, long long gate_stride,
+                      hipStream_t s) {
+    GemmConvArgs a{};
+    a.A = A; a.a_batch = 0; a.a_len = rows * l.K; a.lda = l.K; a.a_off0 = 0; a.tap_step = 0; a.taps = 1; a.K = l.K; a.pro = ACT_NONE;
+    a.W = l.w; a.Kp = l.Kp; a.ldw = 0; a.w_batch = 0; a.bias = l.b;
+    a.C = C; a.c_batch = 0; a.c_len = rows * l.N; a.ldc = l.N; a.c_off = 0; a.M = (int)rows; a.N = l.N;
+    a.act = ACT_NONE; a.res = res; a.res_batch = 0; a.out_scale = 1.f; a.row_scale = nullptr; a.accumulate = 0;
+    a.col_scale = gate; a.col_scale_rows = (int)rows_per_gate; a.col_scale_stride = gate_stride;
+    a.a_bf16 = tl_bf16_mfma && l.bf16;
+    gemm_conv(a, l.bf16, 1, s);
+}
+// s_in packed [2][T][4 mel] as [x | mu | spks | cond] (the in_proj columns are permuted to this order by the repacker) -> s_out [2][T][mel]
+static void dit_forward(cv_flow* m, int T, int t_row, int t_rows_total, bool t_shared, int streaming, hipStream_t s) {
+    const auto& c = m->cfg; const int D = c.est_ch, H = c.est_heads; const long long R = 2LL * T;
+    float* x = m->d_x.as<float>(); float* y = m->d_y.as<float>(); float* n = m->d_n.as<float>(); float* qkv = m->d_qkv.as<float>();
+    float* att = m->d_att.as<float>(); float* ff = m->d_ff.as<float>();
+    const int chunk = streaming ? 2 * c.chunk : 0;
+    const long long rpb = t_shared ? R : T, gbs = t_shared ? 0 : 6LL * D;          // rows per modulation row; stride between the two rows' modulations
+    // InputEmbedding (dit.py:76-98): proj, then x + CausalConvPositionEmbedding(x)
+    lin_cl(m->d_inproj, m->s_in.as<float>(), R, x, ACT_NONE, nullptr, s);
+    for (int b = 0; b < 2; ++b) {
+        dit_group_conv(m->d_pos1, x + (size_t)b * T * D, y + (size_t)b * T * D, nullptr, T, D, s);
+        dit_group_conv(m->d_pos2, y + (size_t)b * T * D, n + (size_t)b * T * D, x + (size_t)b * T * D, T, D, s);     // n = Mish(conv2) + x
+    }
+    float* cur = n; float* other = x;                                               // residual stream ping-pongs so no GEMM reads what it writes
+    for (int i = 0; i < c.est_blocks; ++i) {
+        const DitBlockW& w = m->dit[i];
+        const float* mod = m->d_mod.as<float>() + ((size_t)i * t_rows_total + t_row) * 6 * D;     // [shift_msa | 1+scale_msa | gate_msa | shift_mlp | 1+scale_mlp | gate_mlp]
+        NormArgs na{cur, y, R, D, mod + D, mod, 1e-6f, 0, ACT_NONE, 1.f, nullptr, nullptr, rpb}; na.gb_batch = gbs;
+        norm_rows(na, s);
+        lin_cl(w.qkv, y, R, qkv, ACT_NONE, nullptr, s);
+        hipLaunchKernelGGL(dit_rope_kernel, dim3(nblk(R * 64)), dim3(256), 0, s, qkv, R, T, 3 * D, D);
+        AttnArgs at{};
+        at.q = qkv; at.q_batch = (long long)T * 3 * D; at.q_row = 3 * D; at.q_head = 64;
+        at.k = qkv + D; at.k_batch = at.q_batch; at.k_row = 3 * D; at.k_head = 64;
+        at.v = qkv + 2 * D; at.v_batch = at.q_batch; at.v_row = 3 * D; at.v_head = 64;
+        at.o = att; at.o_batch = (long long)T * D; at.o_row = D; at.o_head = 64;
+        at.B = 2; at.H = H; at.kv_group = 1; at.Tq = T; at.Tk = T; at.scale = 0.125f;
+        at.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; at.chunk = chunk; at.rel_bd = nullptr; at.bf16 = tl_bf16_mfma;
+        attention(at, s);
+        lin_gated(w.out, att, R, other, cur, mod + 2 * D, rpb, gbs, s);              // x + gate_msa * to_out(attn)
+        std::swap(cur, other);
+        NormArgs nb{cur, y, R, D, mod + 4 * D, mod + 3 * D, 1e-6f, 0, ACT_NONE, 1.f, nullptr, nullptr, rpb}; nb.gb_batch = gbs;
+        norm_rows(nb, s);
+        lin_cl(w.ff1, y, R, ff, ACT_GELU_TANH, nullptr, s);
+        lin_gated(w.ff2, ff, R, other, cur, mod + 5 * D, rpb, gbs, s);               // x + gate_mlp * ff(...)
+        std::swap(cur, other);
+    }
+    const float* fm = m->d_fm.as<float>() + (size_t)t_row * 2 * D;                  // [1 + scale | shift]
+    NormArgs nf{cur, y, R, D, fm, fm + D, 1e-6f, 0, ACT_NONE, 1.f, nullptr, nullptr, rpb}; nf.gb_batch = t_shared ? 0 : 2LL * D;
+    norm_rows(nf, s);
+    lin_cl(m->d_proj, y, R, m->s_out.as<float>(), ACT_NONE, nullptr, s);
+}
+// front of CausalMaskedDiffWithDiT.inference (flow/flow.py:381-392): PreLookaheadLayer on the token embeddings, then repeat_interleave(2) = mu
+static void dit_front(cv_flow* m, const float* tok_emb, int n_enc, const float* ctx, float* mu_out, hipStream_t s) {
+    const auto& c = m->cfg; const int d = c.dim, la = c.pre_lookahead, Cp = c.ffn;
+    m->e_xe.ensure((size_t)(n_enc + la) * d * 4); m->e_x2.ensure((size_t)n_enc * Cp * 4); m->e_x.ensure((size_t)n_enc * d * 4);
+    float* xe = m->e_xe.as<float>(); float* y1 = m->e_x2.as<float>(); float* h = m->e_x.as<float>();
+    CV_HIP(hipMemcpyAsync(xe, tok_emb, (size_t)n_enc * d * 4, hipMemcpyDeviceToDevice, s));
+    if (ctx) CV_HIP(hipMemcpyAsync(xe + (size_t)n_enc * d, ctx, (size_t)la * d * 4, hipMemcpyDeviceToDevice, s));
+    else CV_HIP(hipMemsetAsync(xe + (size_t)n_enc * d, 0, (size_t)la * d * 4, s));
+    conv_cl(m->d_pre1, xe, n_enc + la, n_enc, 1, 0, 1, y1, ACT_LEAKY, 0.01f, nullptr, s);
+    conv_cl(m->d_pre2, y1, n_enc, n_enc, 1, 2, 1, h, ACT_NONE, 0.f, tok_emb, s);     // + inputs (residual)
+    hipLaunchKernelGGL(repeat2_rows_kernel, dim3(nblk(2LL * n_enc * d)), dim3(256), 0, s, h, mu_out, (long long)n_enc, d);
+}
+
 // ---- solve_euler + inference -------------------------------------------------------------------------------------------
 static void solve_euler(cv_flow* m, float* x /*[T][mel] in/out*/, const float* mu, const float* spk, const float* cond, int T,
                         int n_steps, int streaming, hipStream_t s) {
     const auto& c = m->cfg;
-    est_reserve(m, T); time_reserve(m, n_steps);
+    const bool dit = c.estimator == 1;
+    if (dit) { dit_reserve(m, T); dit_time_reserve(m, n_steps); } else { est_reserve(m, T); time_reserve(m, n_steps); }
     // cosine schedule and the t / dt recurrences of solve_euler, in fp32 like torch (flow_matching.py:89-122, 223-226)
     std::vector<float> span(n_steps + 1), tv(n_steps), dts(n_steps);
     for (int i = 0; i <= n_steps; ++i) {
@@ -434,10 +586,10 @@ static void solve_euler(cv_flow* m, float* x /*[T][mel] in/out*/, const float* m
     CV_HIP(hipMemcpyAsync(m->t_val.p, m->host_t.data(), (size_t)n_steps * 4, hipMemcpyHostToDevice, s));
     const long long n = (long long)T * c.mel;
     auto body = [&]() {
-        time_embed(m, n_steps, s);
+        if (dit) dit_time_embed(m, n_steps, s); else time_embed(m, n_steps, s);
         for (int st = 0; st < n_steps; ++st) {
             hipLaunchKernelGGL(pack_est_input_kernel, dim3(nblk(2 * n * 4)), dim3(256), 0, s, x, mu, spk, cond, m->s_in.as<float>(), T, c.mel, 1);
-            estimator_forward(m, T, st, n_steps, true, streaming, s);
+            if (dit) dit_forward(m, T, st, n_steps, true, streaming, s); else estimator_forward(m, T, st, n_steps, true, streaming, s);
             hipLaunchKernelGGL(cfg_euler_kernel, dim3(nblk(n)), dim3(256), 0, s, x, m->s_out.as<float>(), n, dts[st], c.cfg_rate);
         }
     };
@@ -495,6 +647,7 @@ void cv_flow_destroy(cv_flow* m) {
 
 int cv_flow_encoder(cv_flow* m, const float* tok_emb, int32_t n_tok, const float* context, int32_t streaming, float* h_out, void* stream) {
     return guarded([&] { CV_CHECK(m && m->finalized && tok_emb && h_out, "cv_flow_encoder: bad arguments");
+                         CV_CHECK(m->cfg.estimator == 0, "cv_flow_encoder: CausalMaskedDiffWithDiT has no conformer encoder (its front is PreLookaheadLayer, inside cv_flow_inference)");
                          PrecisionScope prec(m);
                          flow_encoder(m, tok_emb, n_tok, context, streaming, h_out, as_stream(stream)); });
 }
@@ -506,11 +659,12 @@ int cv_flow_estimator(cv_flow* m, const float* x, const float* mask, const float
         PrecisionScope prec(m);
         hipStream_t s = as_stream(stream);
         const auto& c = m->cfg;
-        est_reserve(m, T); time_reserve(m, 2);
+        const bool dit = c.estimator == 1;
+        if (dit) { dit_reserve(m, T); dit_time_reserve(m, 2); } else { est_reserve(m, T); time_reserve(m, 2); }
         CV_HIP(hipMemcpyAsync(m->t_val.p, t, 8, hipMemcpyDeviceToDevice, s));
-        time_embed(m, 2, s);
+        if (dit) dit_time_embed(m, 2, s); else time_embed(m, 2, s);
         hipLaunchKernelGGL(pack_est_input_kernel, dim3(nblk(2LL * T * 4 * c.mel)), dim3(256), 0, s, x, mu, spks, cond, m->s_in.as<float>(), T, c.mel, 0);
-        estimator_forward(m, T, 0, 2, false, streaming, s);
+        if (dit) dit_forward(m, T, 0, 2, false, streaming, s); else estimator_forward(m, T, 0, 2, false, streaming, s);
         // `mask` must be all ones for the in-kernel (index-computed) attention masks to be exact; it is applied to the output
         hipLaunchKernelGGL(to_channel_first_kernel, dim3(nblk(2LL * T * c.mel)), dim3(256), 0, s, m->s_out.as<float>(), out, 2, T, c.mel, 0, mask);
     });
@@ -541,8 +695,11 @@ int cv_flow_inference(cv_flow* m, const int32_t* token_ids, int32_t n_tok, const
         // token embedding (mask is all ones for batch 1, flow.py:252-254); gather_rows_kernel lives in llm_kernels.h -> reuse via C ABI
         CV_CHECK(cv_gather_rows(m->input_embedding, m->wbf16 ? CV_BF16 : CV_F32, c.vocab, d, token_ids, n_tok, m->f_tok.as<float>(), 1.f, stream_r) == 0, cv_last_error());
         const float* ctx = finalize ? nullptr : m->f_tok.as<float>() + (size_t)n_enc * d;
-        flow_encoder(m, m->f_tok.as<float>(), n_enc, ctx, streaming, m->f_h.as<float>(), s);
-        lin_cl(m->enc_proj, m->f_h.as<float>(), T, m->f_mu.as<float>(), ACT_NONE, nullptr, s);
+        if (c.estimator == 1) dit_front(m, m->f_tok.as<float>(), n_enc, ctx, m->f_mu.as<float>(), s);
+        else {
+            flow_encoder(m, m->f_tok.as<float>(), n_enc, ctx, streaming, m->f_h.as<float>(), s);
+            lin_cl(m->enc_proj, m->f_h.as<float>(), T, m->f_mu.as<float>(), ACT_NONE, nullptr, s);
+        }
         hipLaunchKernelGGL(copy_rows_zero_tail_kernel, dim3(nblk((long long)T * c.mel)), dim3(256), 0, s, prompt_feat, m->f_cond.as<float>(),
                            (long long)mel_len1 * c.mel, (long long)T * c.mel);
         CV_HIP(hipMemcpyAsync(m->f_x.p, noise_cl, (size_t)T * c.mel * 4, hipMemcpyDeviceToDevice, s));

@@ -38,6 +38,9 @@ struct GemmConvArgs {
     const float* row_scale; long long row_scale_batch;  // per-row multiplier (time mask), null = none
     int accumulate;                 // C += result
     int a_bf16;                     // 1: bf16 x bf16 MFMA (needs bf16 weights); 0: exact-fp32 MFMA
+    long long bias_batch;           // float offset of the bias per batch (grouped convolutions: one bias slice per group); 0 = shared
+    const float* col_scale; int col_scale_rows; long long col_scale_stride;   // per-(row block, column) multiplier applied to act(acc + bias) BEFORE the residual:
+                                    // the adaLN-zero gates of the DiT (x + gate[b] * f(x), flow/DiT/modules.py:523-528); row m uses block m / col_scale_rows
     long long* dbg;                 // dev tool (tools/ubench/gemm_probe.hip): per-phase clock64() stamps of wave 0, 64 slots per workgroup; null in production
 };
 
@@ -285,11 +288,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
     float* Cb = p.C + (long long)b * p.c_batch;
     const float* Rb = p.res ? p.res + (long long)b * p.res_batch : nullptr;
     const float* RSb = p.row_scale ? p.row_scale + (long long)b * p.row_scale_batch : nullptr;
+    const float* Bb = p.bias ? p.bias + (long long)b * p.bias_batch : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * (BM / WM) + i * 16 + (lane & 15);
         if (m >= p.M) continue;
         const float rs = RSb ? RSb[m] : 1.f;
+        const float* CSr = p.col_scale ? p.col_scale + (long long)(m / p.col_scale_rows) * p.col_scale_stride : nullptr;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * (BN / WN) + j * 16 + (lane >> 4) * 4;
@@ -298,10 +303,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             const bool full = p.c_vec && (n + 3 < p.N) && idx >= 0 && idx + 3 < p.c_len;
             bool ok[4];
-            float bb[4] = {0.f, 0.f, 0.f, 0.f}, rr[4] = {0.f, 0.f, 0.f, 0.f}, oo[4] = {0.f, 0.f, 0.f, 0.f};
+            float bb[4] = {0.f, 0.f, 0.f, 0.f}, rr[4] = {0.f, 0.f, 0.f, 0.f}, oo[4] = {0.f, 0.f, 0.f, 0.f}, cs[4] = {1.f, 1.f, 1.f, 1.f};
             if (full) {
                 ok[0] = ok[1] = ok[2] = ok[3] = true;
-                if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + n); bb[0] = t.x; bb[1] = t.y; bb[2] = t.z; bb[3] = t.w; }
+                if (Bb) { const float4 t = *reinterpret_cast<const float4*>(Bb + n); bb[0] = t.x; bb[1] = t.y; bb[2] = t.z; bb[3] = t.w; }
+                if (CSr) { const float4 t = *reinterpret_cast<const float4*>(CSr + n); cs[0] = t.x; cs[1] = t.y; cs[2] = t.z; cs[3] = t.w; }
                 if (Rb) { const float4 t = *reinterpret_cast<const float4*>(Rb + idx); rr[0] = t.x; rr[1] = t.y; rr[2] = t.z; rr[3] = t.w; }
                 if (p.accumulate) { const float4 t = *reinterpret_cast<const float4*>(Cb + idx); oo[0] = t.x; oo[1] = t.y; oo[2] = t.z; oo[3] = t.w; }
             } else {
@@ -310,7 +316,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
                     const long long ie = idx + e;
                     ok[e] = (n + e < p.N) && ie >= 0 && ie < p.c_len;
                     if (ok[e]) {
-                        if (p.bias) bb[e] = p.bias[n + e];
+                        if (Bb) bb[e] = Bb[n + e];
+                        if (CSr) cs[e] = CSr[n + e];
                         if (Rb) rr[e] = Rb[ie];
                         if (p.accumulate) oo[e] = Cb[ie];
                     }
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
                 v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (v[e] + rr[e]) * p.out_scale * rs + oo[e];
+            for (int e = 0; e < 4; ++e) v[e] = (v[e] * cs[e] + rr[e]) * p.out_scale * rs + oo[e];
             if (full) {
                 *reinterpret_cast<float4*>(Cb + idx) = make_float4(v[0], v[1], v[2], v[3]);
             } else {

@@ -12,6 +12,7 @@ struct NormArgs {
     const float* x; float* y; long long rows; int C;
     const float* gamma; const float* beta; float eps; int rms;
     int act; float scale; const float* row_scale; const float* col_add; long long rows_per_batch;
+    long long gb_batch = 0;     // float offset of gamma / beta per batch of rows_per_batch rows (adaLN modulation: LN(x) * (1 + scale[b]) + shift[b]); 0 = shared
 };
 
 static __global__ __launch_bounds__(256) void norm_rows_kernel(NormArgs p) {
@@ -20,6 +21,9 @@ static __global__ __launch_bounds__(256) void norm_rows_kernel(NormArgs p) {
     if (row >= p.rows) return;
     const float* xr = p.x + row * p.C;
     float* yr = p.y + row * p.C;
+    const long long gbo = p.gb_batch ? (row / p.rows_per_batch) * p.gb_batch : 0;
+    const float* gamma_p = p.gamma ? p.gamma + gbo : nullptr;
+    const float* beta_p = p.beta ? p.beta + gbo : nullptr;
     const bool vec = (p.C & 3) == 0;
     if (vec && p.C <= 1024) {
         float4 v[4];
@@ -52,8 +56,8 @@ static __global__ __launch_bounds__(256) void norm_rows_kernel(NormArgs p) {
             const int c = lane * 4 + k * 256;
             if (c >= p.C) continue;
             float o[4] = {(v[k].x - mean) * rstd, (v[k].y - mean) * rstd, (v[k].z - mean) * rstd, (v[k].w - mean) * rstd};
-            if (p.gamma) { const float4 g = *reinterpret_cast<const float4*>(p.gamma + c); o[0] *= g.x; o[1] *= g.y; o[2] *= g.z; o[3] *= g.w; }
-            if (p.beta) { const float4 b = *reinterpret_cast<const float4*>(p.beta + c); o[0] += b.x; o[1] += b.y; o[2] += b.z; o[3] += b.w; }
+            if (gamma_p) { const float4 g = *reinterpret_cast<const float4*>(gamma_p + c); o[0] *= g.x; o[1] *= g.y; o[2] *= g.z; o[3] *= g.w; }
+            if (beta_p) { const float4 b = *reinterpret_cast<const float4*>(beta_p + c); o[0] += b.x; o[1] += b.y; o[2] += b.z; o[3] += b.w; }
             { const float4 t = apply_act4(p.act, make_float4(o[0], o[1], o[2], o[3]), 0.f); o[0] = t.x * rs; o[1] = t.y * rs; o[2] = t.z * rs; o[3] = t.w * rs; }
             if (ca) { const float4 a = *reinterpret_cast<const float4*>(ca + c); o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
             *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
@@ -79,8 +83,8 @@ static __global__ __launch_bounds__(256) void norm_rows_kernel(NormArgs p) {
     const float* ca = p.col_add ? p.col_add + (row / p.rows_per_batch) * p.C : nullptr;
     for (int c = lane; c < p.C; c += 64) {
         float v = (xr[c] - mean) * rstd;
-        if (p.gamma) v *= p.gamma[c];
-        if (p.beta) v += p.beta[c];
+        if (gamma_p) v *= gamma_p[c];
+        if (beta_p) v += beta_p[c];
         v = apply_act(p.act, v, 0.f) * rs;
         if (ca) v += ca[c];
         yr[c] = v;

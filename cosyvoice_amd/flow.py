@@ -16,7 +16,7 @@ from .llm import register_tensors
 
 class FlowConfigC(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("vocab", "dim", "enc_heads", "ffn", "enc_blocks", "up_blocks", "spk_dim", "mel", "est_ch",
-                                         "est_heads", "est_blocks", "est_mid", "pre_lookahead", "chunk")] + [("cfg_rate", C.c_float)]
+                                         "est_heads", "est_blocks", "est_mid", "pre_lookahead", "chunk")] + [("cfg_rate", C.c_float), ("estimator", C.c_int32)]
 
 
 def cfm_rand_noise():
@@ -111,9 +111,10 @@ class CausalMaskedDiffWithXvec:
         self.output_size = cfg.mel
         self.vocab_size = cfg.vocab
         self.n_timesteps = n_timesteps or cfg.n_timesteps
-        self._tensors = {k: self.lib.hook(v) for k, v in Wt.pack_flow(state_dict, cfg, self.device, weight_dtype).items()}
+        pack = Wt.pack_flow_dit if cfg.estimator == "dit" else Wt.pack_flow
+        self._tensors = {k: self.lib.hook(v) for k, v in pack(state_dict, cfg, self.device, weight_dtype).items()}
         c = FlowConfigC(cfg.vocab, cfg.dim, cfg.enc_heads, cfg.ffn, cfg.enc_blocks, cfg.up_blocks, cfg.spk_dim, cfg.mel, cfg.est_ch,
-                        cfg.est_heads, cfg.est_blocks, cfg.est_mid, cfg.pre_lookahead, cfg.chunk, cfg.cfg_rate)
+                        cfg.est_heads, cfg.est_blocks, cfg.est_mid, cfg.pre_lookahead, cfg.chunk, cfg.cfg_rate, 1 if cfg.estimator == "dit" else 0)
         self._h = C.c_void_p()
         self.lib.cv_flow_create(C.byref(self._h), C.byref(c))
         register_tensors(self.lib, "cv_flow_set_tensor", self._h, self._tensors)
@@ -154,3 +155,15 @@ class CausalMaskedDiffWithXvec:
                                    C.c_int32(int(finalize)), C.c_int32(self.n_timesteps), C.c_void_p(out.data_ptr()), C.byref(got), stream_ptr(self.lib))
         assert got.value == mel_len2
         return out, None
+
+
+class CausalMaskedDiffWithDiT(CausalMaskedDiffWithXvec):
+    """cosyvoice.flow.flow.CausalMaskedDiffWithDiT for inference (flow/flow.py:284-414; Fun-CosyVoice3): the same
+    `inference(...)` surface and the same CFM solver (CausalConditionalCFM.solve_euler with classifier-free guidance), with PreLookaheadLayer +
+    repeat_interleave(2) in front instead of the conformer encoder and the DiT (22 blocks, adaLN-zero, head-0 rotary, causal grouped-conv position
+    embedding) as `decoder.estimator`.  `cfg` = configs.cv3_flow()."""
+
+    def __init__(self, state_dict, cfg, **kw):
+        assert cfg.estimator == "dit", "CausalMaskedDiffWithDiT needs a DiT FlowConfig (configs.cv3_flow())"
+        super().__init__(state_dict, cfg, **kw)
+        self.encoder = None                      # no conformer encoder on this model (flow/flow.py:309-313)

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 
-from .configs import FlowConfig, HiftConfig, LLMConfig, cv2, cv3_llm, tiny, tiny_cv3_llm  # noqa: F401
+from .configs import FlowConfig, HiftConfig, LLMConfig, cv2, cv3_flow, cv3_llm, tiny, tiny_cv3_flow, tiny_cv3_llm  # noqa: F401
 
 
 class _Gen:
@@ -173,6 +173,39 @@ def make_flow(cfg: FlowConfig, seed=1987):
     sd[e + "final_block.block.0.weight"] = g.conv(C, C, 3); sd[e + "final_block.block.0.bias"] = g.normal((C,), 0.05)
     sd[e + "final_block.block.2.weight"] = g.gamma(C); sd[e + "final_block.block.2.bias"] = g.beta(C)
     sd[e + "final_proj.weight"] = g.conv(cfg.mel, C, 1); sd[e + "final_proj.bias"] = g.normal((cfg.mel,), 0.05)
+    return to_bf16_grid(sd)
+
+
+def make_flow_dit(cfg: FlowConfig, seed=1990):
+    """Keys of cosyvoice.flow.flow.CausalMaskedDiffWithDiT (flow/flow.py:284-318) with PreLookaheadLayer and the DiT estimator
+    (flow/DiT/dit.py:104-144, flow/DiT/modules.py).  The adaLN-zero projections are NOT zero here (a trained model's are not either)."""
+    assert cfg.estimator == "dit"
+    g, sd, d, D, Cp = _Gen(seed), {}, cfg.dim, cfg.est_ch, cfg.ffn
+    sd["input_embedding.weight"] = g.normal((cfg.vocab, d), 1.0)
+    sd["spk_embed_affine_layer.weight"] = g.linear(cfg.mel, cfg.spk_dim, gain=4.0)
+    sd["spk_embed_affine_layer.bias"] = g.normal((cfg.mel,), 0.1)
+    sd["pre_lookahead_layer.conv1.weight"] = g.conv(Cp, d, cfg.pre_lookahead + 1)
+    sd["pre_lookahead_layer.conv1.bias"] = g.normal((Cp,), 0.05)
+    sd["pre_lookahead_layer.conv2.weight"] = g.conv(d, Cp, 3)
+    sd["pre_lookahead_layer.conv2.bias"] = g.normal((d,), 0.05)
+    e = "decoder.estimator."
+    sd[e + "time_embed.time_mlp.0.weight"] = g.linear(D, 256); sd[e + "time_embed.time_mlp.0.bias"] = g.normal((D,), 0.05)
+    sd[e + "time_embed.time_mlp.2.weight"] = g.linear(D, D); sd[e + "time_embed.time_mlp.2.bias"] = g.normal((D,), 0.05)
+    sd[e + "input_embed.proj.weight"] = g.linear(D, 4 * cfg.mel); sd[e + "input_embed.proj.bias"] = g.normal((D,), 0.05)
+    for c in ("conv1", "conv2"):
+        sd[e + "input_embed.conv_pos_embed.%s.0.weight" % c] = g.conv(D, D // 16, 31)
+        sd[e + "input_embed.conv_pos_embed.%s.0.bias" % c] = g.normal((D,), 0.05)
+    inner, ffi = cfg.est_heads * 64, cfg.est_mid * D
+    for i in range(cfg.est_blocks):
+        p = e + "transformer_blocks.%d." % i
+        sd[p + "attn_norm.linear.weight"] = g.linear(6 * D, D, gain=0.5); sd[p + "attn_norm.linear.bias"] = g.normal((6 * D,), 0.1)
+        for n in ("to_q", "to_k", "to_v"):
+            sd[p + "attn.%s.weight" % n] = g.linear(inner, D); sd[p + "attn.%s.bias" % n] = g.normal((inner,), 0.05)
+        sd[p + "attn.to_out.0.weight"] = g.linear(D, inner, gain=0.5); sd[p + "attn.to_out.0.bias"] = g.normal((D,), 0.05)
+        sd[p + "ff.ff.0.0.weight"] = g.linear(ffi, D); sd[p + "ff.ff.0.0.bias"] = g.normal((ffi,), 0.05)
+        sd[p + "ff.ff.2.weight"] = g.linear(D, ffi, gain=0.5); sd[p + "ff.ff.2.bias"] = g.normal((D,), 0.05)
+    sd[e + "norm_out.linear.weight"] = g.linear(2 * D, D, gain=0.5); sd[e + "norm_out.linear.bias"] = g.normal((2 * D,), 0.1)
+    sd[e + "proj_out.weight"] = g.linear(cfg.mel, D); sd[e + "proj_out.bias"] = g.normal((cfg.mel,), 0.05)
     return to_bf16_grid(sd)
 
 

@@ -135,6 +135,43 @@ def pack_flow(sd, cfg, device, dtype=torch.bfloat16):
     return out
 
 
+def pack_flow_dit(sd, cfg, device, dtype=torch.bfloat16):
+    """sd: CausalMaskedDiffWithDiT state dict (cosyvoice/flow/flow.py:284-318 + flow/DiT/dit.py:104-144).  Device layout: q / k / v fused; the
+    in_proj columns permuted from the reference's cat order [x | cond | mu | spks] (dit.py:90-96) to the packed estimator input [x | mu | spks |
+    cond]; the grouped position convs as [D rows][31 taps][D/16] (one 64-row panel per group); `1 +` of the adaLN scales folded into the bias
+    of the modulation projections (modules.py:245,270)."""
+    out = {}
+    D, mel = cfg.est_ch, cfg.mel
+    out["input_embedding"] = _bf16(sd["input_embedding.weight"], device) if dtype == torch.bfloat16 else _f32(sd["input_embedding.weight"], device)
+    _lin(out, "spk_affine", sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"], device, dtype)
+    _conv(out, "dit.pre.conv1", sd["pre_lookahead_layer.conv1.weight"], sd["pre_lookahead_layer.conv1.bias"], device, dtype)
+    _conv(out, "dit.pre.conv2", sd["pre_lookahead_layer.conv2.weight"], sd["pre_lookahead_layer.conv2.bias"], device, dtype)
+    e = "decoder.estimator."
+    _lin(out, "dit.time1", sd[e + "time_embed.time_mlp.0.weight"], sd[e + "time_embed.time_mlp.0.bias"], device, dtype)
+    _lin(out, "dit.time2", sd[e + "time_embed.time_mlp.2.weight"], sd[e + "time_embed.time_mlp.2.bias"], device, dtype)
+    w = sd[e + "input_embed.proj.weight"]
+    assert w.shape[1] == 4 * mel
+    w = torch.cat([w[:, 0:mel], w[:, 2 * mel:3 * mel], w[:, 3 * mel:4 * mel], w[:, mel:2 * mel]], 1)
+    _lin(out, "dit.in_proj", w, sd[e + "input_embed.proj.bias"], device, dtype)
+    for c in ("conv1", "conv2"):
+        _conv(out, "dit.pos.%s" % c, sd[e + "input_embed.conv_pos_embed.%s.0.weight" % c], sd[e + "input_embed.conv_pos_embed.%s.0.bias" % c], device, dtype)
+    for i in range(cfg.est_blocks):
+        p, q = e + "transformer_blocks.%d." % i, "dit.blk.%d." % i
+        b = sd[p + "attn_norm.linear.bias"].clone().float()
+        b[D:2 * D] += 1.0; b[4 * D:5 * D] += 1.0                     # (1 + scale_msa), (1 + scale_mlp)
+        _lin(out, q + "mod", sd[p + "attn_norm.linear.weight"], b, device, dtype)
+        _lin(out, q + "qkv", torch.cat([sd[p + "attn.to_q.weight"], sd[p + "attn.to_k.weight"], sd[p + "attn.to_v.weight"]], 0),
+             torch.cat([sd[p + "attn.to_q.bias"], sd[p + "attn.to_k.bias"], sd[p + "attn.to_v.bias"]], 0), device, dtype)
+        _lin(out, q + "out", sd[p + "attn.to_out.0.weight"], sd[p + "attn.to_out.0.bias"], device, dtype)
+        _lin(out, q + "ff1", sd[p + "ff.ff.0.0.weight"], sd[p + "ff.ff.0.0.bias"], device, dtype)
+        _lin(out, q + "ff2", sd[p + "ff.ff.2.weight"], sd[p + "ff.ff.2.bias"], device, dtype)
+    b = sd[e + "norm_out.linear.bias"].clone().float()
+    b[0:D] += 1.0                                                    # AdaLayerNormZero_Final: scale is the FIRST chunk (modules.py:268)
+    _lin(out, "dit.final_mod", sd[e + "norm_out.linear.weight"], b, device, dtype)
+    _lin(out, "dit.proj_out", sd[e + "proj_out.weight"], sd[e + "proj_out.bias"], device, dtype)
+    return out
+
+
 def fold_weight_norm(sd, p):
     g, v = sd[p + "parametrizations.weight.original0"].float(), sd[p + "parametrizations.weight.original1"].float()
     return g * v / v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1)

@@ -154,6 +154,9 @@ typedef struct cv_flow_config {
     int32_t vocab, dim, enc_heads, ffn, enc_blocks, up_blocks, spk_dim, mel, est_ch, est_heads, est_blocks, est_mid,
             pre_lookahead, chunk /* static_chunk_size in tokens; the estimator uses 2*chunk frames */;
     float cfg_rate;
+    int32_t estimator;   /* 0: CausalConditionalDecoder U-Net (CosyVoice2, flow/decoder.py:294-494); 1: DiT (Fun-CosyVoice3: CausalMaskedDiffWithDiT.inference
+                          * flow/flow.py:369-414, DiT.forward flow/DiT/dit.py:145-176).  For 1: dim = input_size = 80, ffn = PreLookaheadLayer channels,
+                          * est_ch = DiT width, est_blocks = depth, est_mid = ff_mult, enc_blocks = up_blocks = 0. */
 } cv_flow_config;
 int cv_flow_create(cv_flow** out, const cv_flow_config* cfg);
 int cv_flow_set_tensor(cv_flow* m, const char* name, const void* dev_ptr, int32_t dtype, int64_t numel);

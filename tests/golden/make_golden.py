@@ -310,6 +310,59 @@ def golden_glue():
     save("glue", fade_a=a, fade_b=b, fade_out=out, chunk_mask=subsequent_chunk_mask(23, 5).to(torch.uint8))
 
 
+def build_ref_dit_flow(cfg):
+    from omegaconf import DictConfig
+    from cosyvoice.flow.DiT.dit import DiT
+    from cosyvoice.flow.flow import CausalMaskedDiffWithDiT
+    from cosyvoice.flow.flow_matching import CausalConditionalCFM
+    from cosyvoice.transformer.upsample_encoder import PreLookaheadLayer
+    est = DiT(dim=cfg.est_ch, depth=cfg.est_blocks, heads=cfg.est_heads, dim_head=64, ff_mult=cfg.est_mid, mel_dim=cfg.mel, mu_dim=cfg.mel, spk_dim=cfg.mel,
+              out_channels=cfg.mel, static_chunk_size=2 * cfg.chunk, num_decoding_left_chunks=-1, dropout=0.0)
+    cfm = CausalConditionalCFM(in_channels=240, n_spks=1, spk_emb_dim=80,
+                               cfm_params=DictConfig({"sigma_min": 1e-6, "solver": "euler", "t_scheduler": "cosine",
+                                                      "training_cfg_rate": 0.2, "inference_cfg_rate": cfg.cfg_rate, "reg_loss_type": "l1"}),
+                               estimator=est)
+    flow = CausalMaskedDiffWithDiT(input_size=cfg.dim, output_size=cfg.mel, spk_embed_dim=cfg.spk_dim, vocab_size=cfg.vocab, input_frame_rate=25,
+                                   token_mel_ratio=2, pre_lookahead_len=cfg.pre_lookahead,
+                                   pre_lookahead_layer=PreLookaheadLayer(in_channels=cfg.dim, channels=cfg.ffn, pre_lookahead_len=cfg.pre_lookahead), decoder=cfm)
+    flow.load_state_dict(W.make_flow_dit(cfg), strict=True)
+    return flow.eval()
+
+
+def golden_dit():
+    """a17: the REAL CausalMaskedDiffWithDiT / DiT / DiTBlock / PreLookaheadLayer (x_transformers' rotary restated in xtransformers_stub.py).  The
+    reference hard-codes 10 Euler steps (flow/flow.py:409); the fixture uses cfg.n_timesteps through the CFM's own n_timesteps argument."""
+    import cosyvoice.flow.flow as FF
+    cfg = W.tiny_cv3_flow()
+    flow = build_ref_dit_flow(cfg)
+    g = torch.Generator().manual_seed(21)
+    n_p, n_t = 6, 11
+    prompt_token = torch.randint(0, cfg.vocab, (1, n_p), generator=g, dtype=torch.int32)
+    token = torch.randint(0, cfg.vocab, (1, n_t), generator=g, dtype=torch.int32)
+    prompt_feat = torch.randn(1, 2 * n_p, 80, generator=g) * 2 - 5
+    emb = torch.randn(1, cfg.spk_dim, generator=g)
+    orig_fwd = type(flow.decoder).forward
+
+    def fwd(self, mu, mask, spks, cond, n_timesteps=10, **kw):
+        return orig_fwd(self, mu=mu, mask=mask, spks=spks, cond=cond, n_timesteps=cfg.n_timesteps, **kw)
+    type(flow.decoder).forward = fwd
+    try:
+        common = dict(prompt_token=prompt_token, prompt_token_len=torch.tensor([n_p], dtype=torch.int32), prompt_feat=prompt_feat,
+                      prompt_feat_len=torch.tensor([2 * n_p], dtype=torch.int32), embedding=emb)
+        mel_full, _ = flow.inference(token=token, token_len=torch.tensor([n_t], dtype=torch.int32), streaming=False, finalize=True, **common)
+        mel_stream, _ = flow.inference(token=token, token_len=torch.tensor([n_t], dtype=torch.int32), streaming=True, finalize=False, **common)
+    finally:
+        type(flow.decoder).forward = orig_fwd
+    T = 27
+    x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g); cond = torch.randn(2, 80, T, generator=g)
+    spk = torch.randn(2, 80, generator=g); t = torch.tensor([0.3, 0.3]); mask = torch.ones(2, 1, T)
+    with torch.inference_mode():
+        e_full = flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=False)
+        e_stream = flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=True)
+    save("dit_tiny", prompt_token=prompt_token, token=token, prompt_feat=prompt_feat, embedding=emb, mel_full=mel_full, mel_stream=mel_stream,
+         est_x=x, est_mu=mu, est_cond=cond, est_spk=spk, est_t=t, est_full=e_full, est_stream=e_stream)
+
+
 def golden_model():
     """B1 / a1 / a16: the REAL cosyvoice.cli.model.CosyVoice2Model (token2wav + the streaming tts loop with its hop doubling, mel / source /
     speech caches and fade_in_out) around the real tiny flow + HiFT modules and a scripted LLM.  Pins oracle/model.py.  SineGen2's additive

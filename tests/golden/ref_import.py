@@ -3,6 +3,7 @@
 Only tests/golden/make_golden.py uses this module, and only here (the GPU box has no /root/reference).
 The reference needs a few third-party packages that are not installed; they are replaced by minimal stubs:
   torchaudio, onnxruntime, omegaconf  - imported at module import time, never called on the hot path
+  x_transformers                      - not installed; RotaryEmbedding / apply_rotary_pos_emb restated in xtransformers_stub.py (published 2.x code)
   matcha.*                            - un-vendored submodule (third_party/Matcha-TTS is empty).  The classes the
                                         reference imports are RESTATED in matcha_stub.py from SURVEY.md Appendix B
                                         (upstream Matcha-TTS + diffusers 0.29 Attention); that restatement is the one
@@ -45,6 +46,13 @@ def install():
                 super().__init__(content or {}, **kw)
             __getattr__ = dict.__getitem__
         _stub("omegaconf", DictConfig=DictConfig)
+    if "x_transformers" not in sys.modules:
+        here = os.path.dirname(os.path.abspath(__file__))
+        if here not in sys.path:
+            sys.path.insert(0, here)
+        import xtransformers_stub
+        _stub("x_transformers")
+        _stub("x_transformers.x_transformers", RotaryEmbedding=xtransformers_stub.RotaryEmbedding, apply_rotary_pos_emb=xtransformers_stub.apply_rotary_pos_emb)
     if "matcha" not in sys.modules:
         here = os.path.dirname(os.path.abspath(__file__))
         if here not in sys.path:

@@ -149,3 +149,22 @@ def test_pipeline_matches_reference_model():
     assert len(g["stream_n"]) == 3
     sp = pipe.tts(tokens, u, stream=False, speed=1.3)[0]
     torch.testing.assert_close(sp, g["speed"], rtol=0, atol=5e-3)
+
+
+def test_dit_flow_matches_reference():
+    """a17: oracle/dit.py against the REAL CausalMaskedDiffWithDiT / DiT / PreLookaheadLayer (tests/golden/make_golden.py::golden_dit): estimator
+    boundary at the reference's own export tolerance (rtol 1e-2 / atol 1e-4) and tighter, full inference offline and streaming."""
+    from oracle import dit as OD
+    g = load("dit_tiny")
+    cfg = W.tiny_cv3_flow()
+    sd = W.make_flow_dit(cfg)
+    mask = torch.ones(2, 1, g["est_x"].shape[-1])
+    for streaming, key in ((False, "est_full"), (True, "est_stream")):
+        out = OD.estimator(sd, cfg, g["est_x"], mask, g["est_mu"], g["est_t"], g["est_spk"], g["est_cond"], streaming)
+        torch.testing.assert_close(out, g[key], rtol=1e-2, atol=1e-4)
+        torch.testing.assert_close(out, g[key], rtol=2e-4, atol=2e-4)
+    assert not torch.allclose(g["est_full"], g["est_stream"], atol=1e-3)          # the chunk mask really bites at T = 27, chunk 10
+    mel = OD.inference(sd, cfg, g["token"], g["prompt_token"], g["prompt_feat"], g["embedding"], streaming=False, finalize=True, n_timesteps=cfg.n_timesteps)
+    torch.testing.assert_close(mel, g["mel_full"], rtol=1e-3, atol=1e-3)
+    mel = OD.inference(sd, cfg, g["token"], g["prompt_token"], g["prompt_feat"], g["embedding"], streaming=True, finalize=False, n_timesteps=cfg.n_timesteps)
+    torch.testing.assert_close(mel, g["mel_stream"], rtol=1e-3, atol=1e-3)
