@@ -67,6 +67,10 @@ class HiftConfig:                     # Appendix A.4 (cosyvoice2.yaml:89-111)
     voiced_thr: float = 10.0
     lrelu: float = 0.1
     audio_limit: float = 0.99
+    # CausalHiFTGenerator (Fun-CosyVoice3, hifigan/generator.py:572-726): every conv causal, conv_pre / the first f0 conv look `look_right` / 3
+    # frames ahead, nearest-neighbour upsampling convs instead of transposed convs, nearest phase interpolation in the harmonic source
+    causal: bool = False
+    look_right: int = 4
 
 
 def cv2():
@@ -81,6 +85,11 @@ def tiny_cv3_llm():
 def cv3_llm():
     """The LM of Fun-CosyVoice3-0.5B (cosyvoice3.yaml:23-36): same Qwen2.5-0.5B backbone, CosyVoice3LM head / embedding layout."""
     return LLMConfig(cv3=True, n_special=200)
+
+
+def cv3_hift():
+    """CausalHiFTGenerator of Fun-CosyVoice3-0.5B (cosyvoice3.yaml:77-100)."""
+    return HiftConfig(causal=True)
 
 
 def cv3_flow():

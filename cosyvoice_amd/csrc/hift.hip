@@ -24,7 +24,7 @@ struct cv_hift {
     const float* f0_cls_w = nullptr; const float* f0_cls_b = nullptr; const float* src_w = nullptr; const float* src_b = nullptr;
     ResBlockW src_rb[4]; std::vector<ResBlockW> rb;
     int scale = 480, sd_rate[4] = {1, 1, 1, 1};
-    DevBuf mel_cl, fa, fb, f0, P, s, sst, x, xs, t1, r0, r1, si, y_spec;
+    DevBuf mel_cl, fa, fb, f0, P, s, sst, x, xs, t1, r0, r1, si, y_spec, xu;
     int cap_m = 0;
 };
 
@@ -43,16 +43,20 @@ static void hift_finalize(cv_hift* m) {
     m->scale = c.hop;
     for (int i = 0; i < c.n_ups; ++i) m->scale *= c.ups[i];
     int cin = c.mel;
-    for (int j = 0; j < 5; ++j) { m->f0c[j] = get_conv(m, "f0.conv" + std::to_string(j), c.f0_ch, cin, 3); cin = c.f0_ch; }
+    CV_CHECK(!c.causal || (c.look_right >= 1 && c.look_right <= 16), "hift: conv_pre_look_right out of range");
+    for (int j = 0; j < 5; ++j) { m->f0c[j] = get_conv(m, "f0.conv" + std::to_string(j), c.f0_ch, cin, (c.causal && j == 0) ? 4 : 3); cin = c.f0_ch; }
     CV_CHECK(c.f0_ch % 32 == 0, "hift: f0_ch must be a multiple of 32");
     m->f0_cls_w = m->tm.f32("f0.cls.w", c.f0_ch); m->f0_cls_b = m->tm.f32("f0.cls.b", 1);
     m->src_w = m->tm.f32("source.w", c.harmonics + 1); m->src_b = m->tm.f32("source.b", 1);
-    m->conv_pre = get_conv(m, "conv_pre", c.base, c.mel, 7);
+    m->conv_pre = get_conv(m, "conv_pre", c.base, c.mel, c.causal ? c.look_right + 1 : 7);
     int ch = c.base;
     for (int i = 0; i < c.n_ups; ++i) {
         const int u = c.ups[i], k = c.up_k[i], q = (k + u - 1) / u;
-        CV_CHECK((k - u) % 2 == 0, "hift: upsample kernel - rate must be even");
-        m->ups[i] = get_conv(m, "ups." + std::to_string(i), u * (ch / 2), ch, q);
+        if (c.causal) m->ups[i] = get_conv(m, "ups." + std::to_string(i), ch / 2, ch, k);       // CausalConv1dUpsample: stride-1 conv behind a nearest upsampling
+        else {
+            CV_CHECK((k - u) % 2 == 0, "hift: upsample kernel - rate must be even");
+            m->ups[i] = get_conv(m, "ups." + std::to_string(i), u * (ch / 2), ch, q);
+        }
         ch /= 2;
     }
     // source_downs strides: cumprod([1] + ups[::-1][:-1])[::-1]   (generator.py:443-455)
@@ -86,6 +90,7 @@ static void reserve(cv_hift* m, int frames) {
     m->mel_cl.ensure(mm * c.mel * 4); m->fa.ensure(mm * c.f0_ch * 4); m->fb.ensure(mm * c.f0_ch * 4); m->f0.ensure((mm + 4) * 4);
     m->P.ensure(mm * (c.harmonics + 1) * 4); m->s.ensure(L * 4); m->sst.ensure(F * 18 * 4); m->y_spec.ensure(F * 18 * 4);
     for (DevBuf* b : {&m->x, &m->xs, &m->t1, &m->r0, &m->r1, &m->si}) b->ensure(big * 4);
+    if (c.causal) m->xu.ensure(2 * big * 4);               // nearest-upsampled input of a CausalConv1dUpsample (twice the channels of its output)
     m->cap_m = frames;
 }
 
@@ -109,24 +114,35 @@ static void resblock(cv_hift* m, const ResBlockW& w, const float* in, long long 
     const float* cur = in;
     for (int j = 0; j < c.n_dil; ++j) {
         const int d = c.dil[j], k = w.k;
-        conv(w.c1[j], cur, T, T, (k * d - d) / 2, d, t1, s, ACT_SNAKE, 0.f, w.a1[j], ACT_NONE, nullptr, 1.f, false);
+        // padding: "same" for HiFTGenerator, all on the left for the causal generator (CausalConv1d 'left': (k - 1) * dilation, convolution.py:172)
+        conv(w.c1[j], cur, T, T, c.causal ? (k - 1) * d : (k * d - d) / 2, d, t1, s, ACT_SNAKE, 0.f, w.a1[j], ACT_NONE, nullptr, 1.f, false);
         const bool last = j == c.n_dil - 1;
         float* out = last ? dest : r[j & 1];
-        conv(w.c2[j], t1, T, T, (k - 1) / 2, 1, out, s, ACT_SNAKE, 0.f, w.a2[j], ACT_NONE, cur, last ? out_scale : 1.f, last && accumulate);
+        conv(w.c2[j], t1, T, T, c.causal ? k - 1 : (k - 1) / 2, 1, out, s, ACT_SNAKE, 0.f, w.a2[j], ACT_NONE, cur, last ? out_scale : 1.f, last && accumulate);
         cur = out;
     }
 }
 
-static void hift_f0(cv_hift* m, const float* mel_cl, int frames, hipStream_t s) {
+// Non-causal: ConvRNNF0Predictor.  Causal (CausalConvRNNF0Predictor, f0_predictor.py:62-103): the first conv (k = 4) looks 3 frames to the RIGHT
+// - zeros after the last frame when `finalize`, otherwise the last 3 frames are only context and frames - 3 values come out - the other four
+// are causal to the left.  Returns the number of f0 values.  (The reference runs this predictor in float64, generator.py:716-717; here it is fp32
+// on the exact-fp32 MFMA: every output row sums its taps in the same order whatever the chunk, so chunked and one-shot calls agree bit for bit.)
+static int hift_f0(cv_hift* m, const float* mel_cl, int frames, hipStream_t s, bool finalize = true) {
     float* a = m->fa.as<float>(); float* b = m->fb.as<float>();
     const float* cur = mel_cl;
+    const bool causal = m->cfg.causal != 0;
+    const int out_frames = (causal && !finalize) ? frames - 3 : frames;
+    CV_CHECK(out_frames > 0, "hift: too few frames for a non-final causal chunk");
     for (int j = 0; j < 5; ++j) {
         float* out = (j & 1) ? b : a;
-        conv(m->f0c[j], cur, frames, frames, 1, 1, out, s, ACT_NONE, 0.f, nullptr, ACT_ELU, nullptr, 1.f, false);
+        if (causal && j == 0) conv(m->f0c[j], cur, frames, out_frames, 0, 1, out, s, ACT_NONE, 0.f, nullptr, ACT_ELU, nullptr, 1.f, false);
+        else conv(m->f0c[j], cur, out_frames, out_frames, causal ? 2 : 1, 1, out, s, ACT_NONE, 0.f, nullptr, ACT_ELU, nullptr, 1.f, false);
         cur = out;
     }
+    frames = out_frames;
     Conv cls; cls.w = m->f0_cls_w; cls.b = m->f0_cls_b; cls.N = 1; cls.K = m->cfg.f0_ch; cls.Kp = m->cfg.f0_ch; cls.taps = 1;
     conv(cls, cur, frames, frames, 0, 1, m->f0.as<float>(), s, ACT_NONE, 0.f, nullptr, ACT_ABS, nullptr, 1.f, false);
+    return frames;
 }
 
 static void hift_source(cv_hift* m, int frames, const float* noise, unsigned long long seed, hipStream_t s) {
@@ -134,7 +150,7 @@ static void hift_source(cv_hift* m, int frames, const float* noise, unsigned lon
     hipLaunchKernelGGL(hift_phase_kernel, dim3(1), dim3(64), 0, s, m->f0.as<float>(), m->P.as<float>(), frames, H, (float)c.sr, (float)m->scale);
     const long long L = (long long)frames * m->scale;
     hipLaunchKernelGGL(hift_source_kernel, dim3(nblk(L)), dim3(256), 0, s, m->f0.as<float>(), m->P.as<float>(), noise, seed, m->src_w, m->src_b,
-                       m->s.as<float>(), frames, H, m->scale, c.nsf_alpha, c.nsf_sigma, c.voiced_thr);
+                       m->s.as<float>(), frames, H, m->scale, c.nsf_alpha, c.nsf_sigma, c.voiced_thr, c.causal ? 1 : 0);
 }
 
 // decode(x = mel, s = source) -> waveform   (generator.py:507-539)
@@ -185,6 +201,65 @@ static void hift_decode(cv_hift* m, const float* mel_cl, int frames, const float
     conv(m->conv_post, x, T, T, 3, 1, spec, s, ACT_LEAKY, 0.01f, nullptr, ACT_NONE, nullptr, 1.f, false);    // F.leaky_relu default slope
     hipLaunchKernelGGL(hift_spec_kernel, dim3(nblk(F * 9)), dim3(256), 0, s, spec, F);
     hipLaunchKernelGGL(hift_istft_kernel, dim3(nblk(L)), dim3(256), 0, s, spec, speech, F, L, c.audio_limit);
+}
+
+
+// CausalHiFTGenerator.decode (generator.py:684-726).  x = mel_cl [mx][mel], src [480 mx].  finalize: every frame is final.  Otherwise the last
+// `look_right` frames are only the right context of conv_pre, the source STFT loses its last prod(ups) * look_right frames and the last
+// prod(ups) * hop samples of the iSTFT are withheld.  Returns the number of samples written to `speech`.
+static long long hift_decode_causal(cv_hift* m, const float* mel_cl, int mx, const float* src, bool finalize, float* speech, hipStream_t s) {
+    const auto& c = m->cfg;
+    int up = 1; for (int i = 0; i < c.n_ups; ++i) up *= c.ups[i];
+    const long long Ls = (long long)mx * m->scale, Fall = Ls / 4 + 1, F = finalize ? Fall : Fall - (long long)up * c.look_right;
+    const int M0 = finalize ? mx : mx - c.look_right;
+    CV_CHECK(M0 > 0 && F > 0 && (finalize || F > up), "hift: too few frames for a non-final causal chunk");
+    float* sst = m->sst.as<float>();
+    hipLaunchKernelGGL(hift_stft_kernel, dim3(nblk(Fall)), dim3(256), 0, s, src, sst, Ls, Fall);
+    float* x = m->x.as<float>(); float* xs = m->xs.as<float>(); float* si = m->si.as<float>(); float* xu = m->xu.as<float>();
+    conv(m->conv_pre, mel_cl, mx, M0, 0, 1, x, s, ACT_NONE, 0.f, nullptr, ACT_NONE, nullptr, 1.f, false);      // taps look right: rows >= mx read as zero
+    long long T = M0; int ch = c.base;
+    for (int i = 0; i < c.n_ups; ++i) {
+        const int u = c.ups[i], k = c.up_k[i], cout = ch / 2;
+        const bool last = i == c.n_ups - 1;
+        const long long Tu = T * u, rows = Tu + (last ? 1 : 0);
+        {   // leaky_relu(0.1) -> nearest x u -> left pad k - 1 -> Conv1d(k)   (CausalConv1dUpsample; leaky commutes with the upsampling)
+            hipLaunchKernelGGL(repeat_rows_kernel, dim3(nblk(Tu * ch)), dim3(256), 0, s, x, xu, T, ch, u);
+            const Conv& w = m->ups[i];
+            GemmConvArgs a{};
+            a.A = xu; a.a_batch = 0; a.a_len = Tu * ch; a.lda = ch; a.a_off0 = -(k - 1) * ch; a.tap_step = ch; a.taps = w.taps; a.K = ch;
+            a.pro = ACT_LEAKY; a.pro_p = c.lrelu; a.pro_alpha = nullptr;
+            a.W = w.w; a.Kp = w.Kp; a.ldw = 0; a.w_batch = 0; a.bias = w.b;
+            a.C = xs; a.c_batch = 0; a.c_len = rows * cout; a.ldc = cout; a.c_off = last ? cout : 0;
+            a.M = (int)Tu; a.N = cout; a.act = ACT_NONE; a.res = nullptr; a.out_scale = 1.f; a.row_scale = nullptr; a.accumulate = 0;
+            gemm_conv(a, false, 1, s);
+            if (last) hipLaunchKernelGGL(reflect_row0_kernel, dim3(1), dim3(256), 0, s, xs, cout);       // ReflectionPad1d((1, 0))
+        }
+        std::swap(x, xs);
+        T = rows; ch = cout;
+        {   // source branch: CausalConv1d(k = 1) or CausalConv1dDownSample(kernel 2 r, stride r, left pad r - 1), then the causal ResBlock
+            const int r = m->sd_rate[i], kk = r == 1 ? 1 : 2 * r, pad = r == 1 ? 0 : r - 1;
+            const long long Tsi = (F + pad - kk) / r + 1;
+            CV_CHECK(Tsi == T, "hift: source branch length does not match the upsampled mel length");
+            const Conv& w = m->sdown[i];
+            GemmConvArgs a{};
+            a.A = sst; a.a_batch = 0; a.a_len = F * 18; a.lda = r * 18; a.a_off0 = -pad * 18; a.tap_step = 0; a.taps = 1; a.K = kk * 18;
+            a.pro = ACT_NONE; a.W = w.w; a.Kp = w.Kp; a.ldw = 0; a.w_batch = 0; a.bias = w.b;
+            a.C = si; a.c_batch = 0; a.c_len = T * ch; a.ldc = ch; a.c_off = 0; a.M = (int)T; a.N = ch;
+            a.act = ACT_NONE; a.res = nullptr; a.out_scale = 1.f; a.row_scale = nullptr; a.accumulate = 0;
+            gemm_conv(a, false, 1, s);
+            resblock(m, m->src_rb[i], si, T, x, 1.f, true, s);
+        }
+        for (int j = 0; j < c.n_res; ++j)
+            resblock(m, m->rb[i * c.n_res + j], x, T, xs, 1.f / (float)c.n_res, j > 0, s);
+        std::swap(x, xs);
+    }
+    CV_CHECK(T == F, "hift: frame bookkeeping mismatch");
+    float* spec = m->y_spec.as<float>();
+    conv(m->conv_post, x, T, T, 6, 1, spec, s, ACT_LEAKY, 0.01f, nullptr, ACT_NONE, nullptr, 1.f, false);    // CausalConv1d(k = 7, 'left')
+    hipLaunchKernelGGL(hift_spec_kernel, dim3(nblk(F * 9)), dim3(256), 0, s, spec, F);
+    const long long L = 4 * (F - 1) - (finalize ? 0 : (long long)up * c.hop);
+    hipLaunchKernelGGL(hift_istft_kernel, dim3(nblk(L)), dim3(256), 0, s, spec, speech, F, L, c.audio_limit);
+    return L;
 }
 
 extern "C" {
@@ -240,6 +315,42 @@ int cv_hift_inference(cv_hift* m, const float* speech_feat, int32_t frames, cons
         if (cache_len > 0) CV_HIP(hipMemcpyAsync(m->s.p, cache_source, (size_t)cache_len * 4, hipMemcpyDeviceToDevice, s));   // generator.py:566-567
         CV_HIP(hipMemcpyAsync(source_out, m->s.p, (size_t)L * 4, hipMemcpyDeviceToDevice, s));
         hift_decode(m, m->mel_cl.as<float>(), frames, m->s.as<float>(), speech_out, s);
+    });
+}
+
+/* CausalHiFTGenerator (Fun-CosyVoice3) entry points; the handle must have been created with cfg.causal = 1. */
+int cv_hift_causal_f0(cv_hift* m, const float* speech_feat, int32_t frames, int32_t finalize, float* f0_out, int32_t* n_out, void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && m->finalized && m->cfg.causal && speech_feat && f0_out && n_out && frames > 0, "cv_hift_causal_f0: bad arguments");
+        hipStream_t s = as_stream(stream);
+        reserve(m, frames);
+        hipLaunchKernelGGL(to_channel_last_kernel, dim3(nblk((long long)frames * m->cfg.mel)), dim3(256), 0, s, speech_feat, m->mel_cl.as<float>(), m->cfg.mel, frames);
+        *n_out = hift_f0(m, m->mel_cl.as<float>(), frames, s, finalize != 0);
+        CV_HIP(hipMemcpyAsync(f0_out, m->f0.p, (size_t)*n_out * 4, hipMemcpyDeviceToDevice, s));
+    });
+}
+int cv_hift_causal_decode(cv_hift* m, const float* speech_feat, int32_t frames, const float* source, int32_t finalize, float* speech_out, int64_t* n_out,
+                          void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && m->finalized && m->cfg.causal && speech_feat && source && speech_out && n_out && frames > 0, "cv_hift_causal_decode: bad arguments");
+        hipStream_t s = as_stream(stream);
+        reserve(m, frames);
+        hipLaunchKernelGGL(to_channel_last_kernel, dim3(nblk((long long)frames * m->cfg.mel)), dim3(256), 0, s, speech_feat, m->mel_cl.as<float>(), m->cfg.mel, frames);
+        *n_out = hift_decode_causal(m, m->mel_cl.as<float>(), frames, source, finalize != 0, speech_out, s);
+    });
+}
+int cv_hift_causal_inference(cv_hift* m, const float* speech_feat, int32_t frames, int32_t finalize, const float* noise, uint64_t seed,
+                             float* speech_out, int64_t* n_speech, float* source_out, int64_t* n_source, void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && m->finalized && m->cfg.causal && speech_feat && speech_out && source_out && n_speech && n_source && frames > 0, "cv_hift_causal_inference: bad arguments");
+        hipStream_t s = as_stream(stream);
+        reserve(m, frames);
+        hipLaunchKernelGGL(to_channel_last_kernel, dim3(nblk((long long)frames * m->cfg.mel)), dim3(256), 0, s, speech_feat, m->mel_cl.as<float>(), m->cfg.mel, frames);
+        const int nf0 = hift_f0(m, m->mel_cl.as<float>(), frames, s, finalize != 0);
+        hift_source(m, nf0, noise, seed, s);
+        *n_source = (long long)nf0 * m->scale;
+        CV_HIP(hipMemcpyAsync(source_out, m->s.p, (size_t)*n_source * 4, hipMemcpyDeviceToDevice, s));
+        *n_speech = hift_decode_causal(m, m->mel_cl.as<float>(), nf0, m->s.as<float>(), finalize != 0, speech_out, s);     // x = speech_feat[:, :, :nf0]
     });
 }
 

@@ -40,6 +40,19 @@ __device__ __forceinline__ float gauss01(unsigned long long seed, unsigned long 
     return sqrtf(-2.f * logf(u1)) * cosf(2.f * CV_PI_F * u2);
 }
 
+__device__ __forceinline__ float unif01(unsigned long long seed, unsigned long long idx) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// nearest-neighbour upsampling of channel-last rows: y[t][c] = x[t / u][c]   (torch.nn.Upsample(scale_factor=u, mode='nearest'))
+static __global__ __launch_bounds__(256) void repeat_rows_kernel(const float* x, float* y, long long T, int C, int u) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * u * C) return;
+    y[i] = x[(i / C / u) * C + i % C];
+}
+
 // SineGen2.forward + SourceModuleHnNSF (generator.py:289-317, 358-375): per output sample
 //   phase = linear x`scale` up-interpolation (align_corners=False) of P;  sine = sin(phase)*amp
 //   uv = f0 > thr;  noise_amp = uv*sigma + (1-uv)*amp/3;  wave_h = sine*uv + noise_amp*noise[t][h]
@@ -47,22 +60,24 @@ __device__ __forceinline__ float gauss01(unsigned long long seed, unsigned long 
 // noise == nullptr -> in-kernel counter RNG (the reference draws torch.randn_like on the device RNG, generator.py:312)
 static __global__ __launch_bounds__(256) void hift_source_kernel(const float* f0, const float* P, const float* noise, unsigned long long seed,
                                                                   const float* lw, const float* lb, float* s, int m, int H, int scale,
-                                                                  float amp, float sigma, float thr) {
+                                                                  float amp, float sigma, float thr, int causal) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long L = (long long)m * scale;
     if (t >= L) return;
     const float rscale = (float)(1.0 / (double)scale);
     float src = rscale * ((float)t + 0.5f) - 0.5f;
     if (src < 0.f) src = 0.f;
-    const int i0 = (int)src, i1 = i0 + (i0 < m - 1 ? 1 : 0);
-    const float l1 = src - (float)i0, l0 = 1.f - l1;
+    int i0 = (int)src, i1 = i0 + (i0 < m - 1 ? 1 : 0);
+    float l1 = src - (float)i0, l0 = 1.f - l1;
+    if (causal) { i0 = i1 = (int)(t / scale); l0 = 1.f; l1 = 0.f; }     // SineGen2(causal=True): nearest phase upsampling (generator.py:255-256)
     const float f = f0[t / scale];
     const float uv = f > thr ? 1.f : 0.f;
     const float namp = uv * sigma + (1.f - uv) * amp / 3.f;
     float acc = 0.f;
     for (int h = 0; h < H; ++h) {
         const float ph = l0 * P[(long long)i0 * H + h] + l1 * P[(long long)i1 * H + h];
-        const float nz = noise ? noise[t * H + h] : gauss01(seed, (unsigned long long)(t * H + h));
+        // causal: the reference adds noise_amp x a fixed UNIFORM buffer (torch.rand at construction, generator.py:223-226, 310-311)
+        const float nz = noise ? noise[t * H + h] : (causal ? unif01(seed, (unsigned long long)(t * H + h)) : gauss01(seed, (unsigned long long)(t * H + h)));
         const float w = sinf(ph) * amp * uv + namp * nz;
         acc += w * lw[h];
     }

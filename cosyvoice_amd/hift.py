@@ -18,7 +18,8 @@ class HiftConfigC(C.Structure):
                 ("n_res", C.c_int32), ("res_k", C.c_int32 * 4), ("src_k", C.c_int32 * 4),
                 ("n_dil", C.c_int32), ("dil", C.c_int32 * 4),
                 ("n_fft", C.c_int32), ("hop", C.c_int32), ("f0_ch", C.c_int32),
-                ("nsf_alpha", C.c_float), ("nsf_sigma", C.c_float), ("voiced_thr", C.c_float), ("lrelu", C.c_float), ("audio_limit", C.c_float)]
+                ("nsf_alpha", C.c_float), ("nsf_sigma", C.c_float), ("voiced_thr", C.c_float), ("lrelu", C.c_float), ("audio_limit", C.c_float),
+                ("causal", C.c_int32), ("look_right", C.c_int32)]
 
 
 def _arr4(v):
@@ -52,7 +53,7 @@ class HiFTGenerator:
         self._tensors = {k: self.lib.hook(v) for k, v in Wt.pack_hift(state_dict, cfg, self.device).items()}
         c = HiftConfigC(cfg.mel, cfg.base, cfg.harmonics, cfg.sr, len(cfg.ups), _arr4(cfg.ups), _arr4(cfg.up_k), len(cfg.res_k), _arr4(cfg.res_k),
                         _arr4(cfg.src_k), len(cfg.res_d), _arr4(cfg.res_d), cfg.n_fft, cfg.hop, cfg.f0_ch, cfg.nsf_alpha, cfg.nsf_sigma,
-                        cfg.voiced_thr, cfg.lrelu, cfg.audio_limit)
+                        cfg.voiced_thr, cfg.lrelu, cfg.audio_limit, int(cfg.causal), cfg.look_right)
         self._h = C.c_void_p()
         self.lib.cv_hift_create(C.byref(self._h), C.byref(c))
         register_tensors(self.lib, "cv_hift_set_tensor", self._h, self._tensors)
@@ -97,3 +98,59 @@ class HiFTGenerator:
                                    C.c_void_p(nz.data_ptr()) if nz is not None else None, C.c_uint64(self.seed + self._calls),
                                    C.c_void_p(speech.data_ptr()), C.c_void_p(source.data_ptr()), stream_ptr(self.lib))
         return speech, source
+
+
+class CausalHiFTGenerator(HiFTGenerator):
+    """cosyvoice.hifigan.generator.CausalHiFTGenerator for inference (generator.py:572-726; Fun-CosyVoice3):
+    `inference(speech_feat[1,80,m], finalize=True) -> (speech, source)`.  A non-final chunk (finalize=False) treats its last frames as look-ahead
+    only: 3 for the f0 predictor, 4 more for conv_pre, and withholds one more frame of samples, so m frames give 480 (m - 8) samples - every
+    sample a chunk emits equals the one-shot result (the reference's own invariance check, generator.py:729-746).
+
+    Differences from the reference, stated: the f0 predictor runs in fp32 (the reference converts it to float64 on every call, :716-717, because
+    its fp32 cuDNN results depend on the chunk; here each f0 value is the same fp32 sum whatever the chunk, so chunked = one-shot bit for bit,
+    and against the float64 reference the harmonic phase agrees to the same 2e-3 as for HiFT v2); the SineGen2 noise comes from a counter RNG
+    (uniform, like the reference's fixed `torch.rand` buffer - 260 MB there) unless `noise` is given."""
+
+    def __init__(self, state_dict, cfg, **kw):
+        assert cfg.causal, "CausalHiFTGenerator needs a causal HiftConfig (configs.cv3_hift())"
+        super().__init__(state_dict, cfg, **kw)
+        self.conv_pre_look_right = cfg.look_right
+
+    @torch.inference_mode()
+    def f0(self, speech_feat, finalize=True):
+        m = speech_feat.shape[2]
+        x = self.lib.hook(speech_feat.to(self.device, torch.float32).contiguous())
+        out = self.lib.hook(torch.empty(1, m, dtype=torch.float32, device=self.device))
+        n = C.c_int32(0)
+        self.lib.cv_hift_causal_f0(self._h, C.c_void_p(x.data_ptr()), C.c_int32(m), C.c_int32(int(finalize)), C.c_void_p(out.data_ptr()), C.byref(n), stream_ptr(self.lib))
+        return out[:, : n.value]
+
+    @torch.inference_mode()
+    def decode(self, x, s, finalize=True):
+        m = x.shape[2]
+        xx = self.lib.hook(x.to(self.device, torch.float32).contiguous())
+        ss = self.lib.hook(s.to(self.device, torch.float32).contiguous())
+        assert ss.numel() == m * self.upsample_scale
+        out = self.lib.hook(torch.empty(1, m * self.upsample_scale, dtype=torch.float32, device=self.device))
+        n = C.c_int64(0)
+        self.lib.cv_hift_causal_decode(self._h, C.c_void_p(xx.data_ptr()), C.c_int32(m), C.c_void_p(ss.data_ptr()), C.c_int32(int(finalize)),
+                                       C.c_void_p(out.data_ptr()), C.byref(n), stream_ptr(self.lib))
+        return out[:, : n.value]
+
+    @torch.inference_mode()
+    def inference(self, speech_feat, finalize=True, noise=None):
+        m = speech_feat.shape[2]
+        L = m * self.upsample_scale
+        x = self.lib.hook(speech_feat.to(self.device, torch.float32).contiguous())
+        speech = self.lib.hook(torch.empty(1, L, dtype=torch.float32, device=self.device))
+        source = self.lib.hook(torch.empty(1, 1, L, dtype=torch.float32, device=self.device))
+        nz = None
+        if noise is not None:
+            nz = self.lib.hook(noise.to(self.device, torch.float32).reshape(-1, self.cfg.harmonics + 1).contiguous())
+            assert nz.shape[0] >= L - (0 if finalize else 3 * self.upsample_scale)
+        self._calls += 1
+        n_sp, n_src = C.c_int64(0), C.c_int64(0)
+        self.lib.cv_hift_causal_inference(self._h, C.c_void_p(x.data_ptr()), C.c_int32(m), C.c_int32(int(finalize)),
+                                          C.c_void_p(nz.data_ptr()) if nz is not None else None, C.c_uint64(self.seed),      # one fixed "buffer" per model, like the reference
+                                          C.c_void_p(speech.data_ptr()), C.byref(n_sp), C.c_void_p(source.data_ptr()), C.byref(n_src), stream_ptr(self.lib))
+        return speech[:, : n_sp.value], source[:, :, : n_src.value]

@@ -16,9 +16,9 @@ import numpy as np
 import torch
 
 from ._lib import get_lib, stream_ptr
-from .flow import CausalMaskedDiffWithXvec
-from .hift import HiFTGenerator
-from .llm import Qwen2LM
+from .flow import CausalMaskedDiffWithDiT, CausalMaskedDiffWithXvec
+from .hift import CausalHiFTGenerator, HiFTGenerator
+from .llm import CosyVoice3LM, Qwen2LM
 
 
 class CosyVoice2Model:
@@ -290,3 +290,59 @@ class CosyVoice2Model:
                 self.hift_cache_dict.pop(this_uuid, None)
                 self._cond.pop(this_uuid, None)
                 self._llm_error.pop(this_uuid, None)
+
+
+class CosyVoice3Model(CosyVoice2Model):
+    """Host mirror of cosyvoice.cli.model.CosyVoice3Model (cli/model.py:397-450; Fun-CosyVoice3): the tts() /
+    llm_job / streaming loop of CosyVoice2Model over CosyVoice3LM + CausalMaskedDiffWithDiT + CausalHiFTGenerator, with the silent / breath
+    token filter switched on (:423) and its own token2wav: the mel of a request accumulates in `hift_cache_dict[uuid]['mel']`, every call
+    vocodes the whole mel so far with the causal generator (finalize flag = look-ahead handling) and returns the samples beyond
+    `speech_offset` - no overlap cross-fade, no source cache."""
+
+    def __init__(self, llm, flow, hift, fp16=False, lib=None):
+        super().__init__(llm, flow, hift, fp16=fp16, lib=lib)
+        self.silent_tokens = [1, 2, 28, 29, 55, 248, 494, 2241, 2242, 2322, 2323]
+
+    @classmethod
+    def from_state_dicts(cls, llm_sd, flow_sd, hift_sd, cfgs, lib=None, fp16=False, **llm_kw):
+        lc, fc, hc = cfgs
+        lib = lib or get_lib()
+        flow = CausalMaskedDiffWithDiT(flow_sd, fc, lib=lib, precision="bf16" if fp16 else "fp32")
+        return cls(CosyVoice3LM(llm_sd, lc, lib=lib, **llm_kw), flow, CausalHiFTGenerator(hift_sd, hc, lib=lib), fp16=fp16)
+
+    def load(self, llm_model, flow_model, hift_model, cfgs=None, **llm_kw):
+        from .configs import cv3_flow, cv3_hift, cv3_llm
+        lc, fc, hc = cfgs or (cv3_llm(), cv3_flow(), cv3_hift())
+        llm_sd = torch.load(llm_model, map_location="cpu", weights_only=True)
+        flow_sd = torch.load(flow_model, map_location="cpu", weights_only=True)
+        hift_sd = {k.replace("generator.", ""): v for k, v in torch.load(hift_model, map_location="cpu", weights_only=True).items()}
+        self.llm = CosyVoice3LM(llm_sd, lc, lib=self.lib, **llm_kw)
+        self.flow = CausalMaskedDiffWithDiT(flow_sd, fc, lib=self.lib, precision="bf16" if self.fp16 else "fp32")
+        self.hift = CausalHiFTGenerator(hift_sd, hc, lib=self.lib)
+        self._warmup()
+
+    @torch.inference_mode()
+    def token2wav(self, token, prompt_token, prompt_feat, embedding, token_offset, uuid, stream=False, finalize=False, speed=1.0):
+        """cli/model.py:425-450."""
+        with self.t2w_lock:
+            t = lambda n: torch.tensor([n], dtype=torch.int32)
+            tts_mel, _ = self.flow.inference(token=token.to(torch.int32), token_len=t(token.shape[1]), prompt_token=prompt_token, prompt_token_len=t(prompt_token.shape[1]),
+                                             prompt_feat=prompt_feat, prompt_feat_len=t(prompt_feat.shape[1]), embedding=embedding, streaming=stream, finalize=finalize)
+            tts_mel = tts_mel[:, :, token_offset * self.flow.token_mel_ratio:]
+            cache = self.hift_cache_dict.get(uuid)
+            if cache is not None:
+                tts_mel = torch.concat([cache["mel"], tts_mel], dim=2)
+                cache["mel"] = tts_mel
+            else:
+                cache = self.hift_cache_dict[uuid] = {"mel": tts_mel, "speech_offset": 0}
+            if speed != 1.0:
+                assert token_offset == 0 and finalize is True, "speed change only support non-stream inference mode"
+                tn = int(tts_mel.shape[2] / speed)
+                src = tts_mel.contiguous()
+                dst = torch.empty(1, src.shape[1], tn, dtype=torch.float32, device=self.device)
+                self.lib.cv_interp_linear(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_int32(src.shape[1]), C.c_int32(src.shape[2]), C.c_int32(tn), stream_ptr(self.lib))
+                tts_mel = dst
+            tts_speech, _ = self.hift.inference(speech_feat=tts_mel, finalize=finalize)
+            tts_speech = tts_speech[:, cache["speech_offset"]:]
+            cache["speech_offset"] += tts_speech.shape[1]
+            return tts_speech

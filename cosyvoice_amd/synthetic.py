@@ -210,8 +210,8 @@ def make_flow_dit(cfg: FlowConfig, seed=1990):
 
 
 def make_hift(cfg: HiftConfig, seed=1988):
-    """Keys of cosyvoice.hifigan.generator.HiFTGenerator (generator.py:378-476) incl. f0_predictor; weight-norm
-    parametrisation keys `parametrizations.weight.original0/1` (g, v) as torch >= 2.1 stores them."""
+    """Keys of cosyvoice.hifigan.generator.HiFTGenerator (generator.py:378-476) or, for cfg.causal, CausalHiFTGenerator (:572-682) incl.
+    f0_predictor; weight-norm parametrisation keys `parametrizations.weight.original0/1` (g, v) as torch >= 2.1 stores them."""
     g, sd = _Gen(seed), {}
 
     def wn(p, v, gain_dim0=True):
@@ -223,11 +223,14 @@ def make_hift(cfg: HiftConfig, seed=1988):
     sd["m_source.l_linear.weight"] = g.normal((1, cfg.harmonics + 1), 1.0)
     sd["m_source.l_linear.bias"] = g.normal((1,), 0.1)
     sd["conv_pre.bias"] = g.normal((cfg.base,), 0.05)
-    wn("conv_pre.", g.conv(cfg.base, cfg.mel, 7))
+    wn("conv_pre.", g.conv(cfg.base, cfg.mel, cfg.look_right + 1 if cfg.causal else 7))       # causal: CausalConv1d(k = look_right + 1, 'right')
     ch = cfg.base
     for i, (u, k) in enumerate(zip(cfg.ups, cfg.up_k)):
         sd["ups.%d.bias" % i] = g.normal((ch // 2,), 0.05)
-        wn("ups.%d." % i, g.normal((ch, ch // 2, k), 1.0 / np.sqrt(ch * k / u)))
+        if cfg.causal:                                        # CausalConv1dUpsample: a Conv1d [C_out, C_in, k] behind a nearest upsampling
+            wn("ups.%d." % i, g.conv(ch // 2, ch, k))
+        else:
+            wn("ups.%d." % i, g.normal((ch, ch // 2, k), 1.0 / np.sqrt(ch * k / u)))
         ch //= 2
     # source_downs: strides = cumprod([1] + ups[::-1][:-1])[::-1]   (generator.py:443-455)
     rates = np.cumprod([1] + cfg.ups[::-1][:-1])[::-1]
@@ -256,7 +259,7 @@ def make_hift(cfg: HiftConfig, seed=1988):
     cin = cfg.mel
     for j in range(5):
         sd["f0_predictor.condnet.%d.bias" % (2 * j)] = g.normal((cfg.f0_ch,), 0.05)
-        wn("f0_predictor.condnet.%d." % (2 * j), g.conv(cfg.f0_ch, cin, 3, gain=1.4))
+        wn("f0_predictor.condnet.%d." % (2 * j), g.conv(cfg.f0_ch, cin, 4 if (cfg.causal and j == 0) else 3, gain=1.4))
         cin = cfg.f0_ch
     sd["f0_predictor.classifier.weight"] = g.linear(1, cfg.f0_ch, gain=30.0)
     sd["f0_predictor.classifier.bias"] = g.normal((1,), 1.0)

@@ -202,6 +202,9 @@ def pack_hift(sd, cfg, device):
     out["source.b"] = _f32(sd["m_source.l_linear.bias"], device)
     _conv(out, "conv_pre", _conv_w(sd, "conv_pre."), sd["conv_pre.bias"], device, f32)
     for i, (u, k) in enumerate(zip(cfg.ups, cfg.up_k)):
+        if cfg.causal:                                       # CausalConv1dUpsample (transformer/convolution.py:226-259): a stride-1 Conv1d
+            _conv(out, "ups.%d" % i, _conv_w(sd, "ups.%d." % i), sd["ups.%d.bias" % i], device, f32)
+            continue
         w = _conv_w(sd, "ups.%d." % i)                       # ConvTranspose1d weight [Cin, Cout, k]
         cin, cout, _ = w.shape
         q = (k + u - 1) // u

@@ -188,6 +188,8 @@ typedef struct cv_hift_config {
     int32_t n_dil, dil[4];
     int32_t n_fft, hop, f0_ch;
     float nsf_alpha, nsf_sigma, voiced_thr, lrelu, audio_limit;
+    int32_t causal;        /* 1: CausalHiFTGenerator / CausalConvRNNF0Predictor (Fun-CosyVoice3; hifigan/generator.py:572-726, f0_predictor.py:62-103) */
+    int32_t look_right;    /* conv_pre_look_right (causal only; cosyvoice3.yaml: 4) */
 } cv_hift_config;
 int cv_hift_create(cv_hift** out, const cv_hift_config* cfg);
 int cv_hift_set_tensor(cv_hift* m, const char* name, const void* dev_ptr, int32_t dtype, int64_t numel);
@@ -201,6 +203,18 @@ int cv_hift_decode(cv_hift* m, const float* speech_feat, int32_t frames, const f
  * noise: optional dev [480m, 9] N(0,1) variates for SineGen2 (parity tests); NULL -> in-kernel counter RNG keyed by `seed`. */
 int cv_hift_inference(cv_hift* m, const float* speech_feat, int32_t frames, const float* cache_source, int32_t cache_len,
                       const float* noise, uint64_t seed, float* speech_out, float* source_out, void* stream);
+/* Fun-CosyVoice3 (handle created with causal = 1).  `finalize` = 0: a streaming chunk whose trailing frames are look-ahead context only.
+ * cv_hift_causal_f0: CausalConvRNNF0Predictor.forward(x, finalize) -> f0 [frames] or [frames - 3] (f0_predictor.py:94-103; fp32 here, float64 in
+ * the reference generator.py:716-717).  cv_hift_causal_decode: CausalHiFTGenerator.decode(x, s, finalize) (generator.py:684-711): speech_feat dev
+ * [80, frames], source dev [480 frames] -> 480 frames samples, or 480 (frames - look_right - 1) when not final.  cv_hift_causal_inference:
+ * CausalHiFTGenerator.inference(speech_feat, finalize) (generator.py:713-726) -> speech (480 frames | 480 (frames - 8)) and source (480 frames |
+ * 480 (frames - 3)); noise: optional dev [>= n_source, 9] uniform [0, 1) variates standing in for the model's fixed SineGen2 buffer, NULL -> counter RNG. */
+int cv_hift_causal_f0(cv_hift* m, const float* speech_feat, int32_t frames, int32_t finalize, float* f0_out, int32_t* n_out, void* stream);
+int cv_hift_causal_decode(cv_hift* m, const float* speech_feat, int32_t frames, const float* source, int32_t finalize, float* speech_out, int64_t* n_out,
+                          void* stream);
+int cv_hift_causal_inference(cv_hift* m, const float* speech_feat, int32_t frames, int32_t finalize, const float* noise, uint64_t seed,
+                             float* speech_out, int64_t* n_speech, float* source_out, int64_t* n_source, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------------------
  * Glue of CosyVoice2Model.token2wav (boundary B1, cosyvoice/cli/model.py:292-326)

@@ -121,3 +121,115 @@ def inference(sd, cfg, speech_feat, cache_source=None, rand_ini=None, noise=None
     if cache_source is not None and cache_source.shape[2] != 0:
         s[:, :, : cache_source.shape[2]] = cache_source
     return decode(sd, cfg, speech_feat, s), s
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# CausalHiFTGenerator (Fun-CosyVoice3): cosyvoice/hifigan/generator.py:572-726, hifigan/f0_predictor.py:62-103, transformer/convolution.py:150-259.
+# `finalize=False` = a streaming chunk whose last frames are only look-ahead context.  The reference runs the f0 predictor in float64
+# (generator.py:716-717); `f0_dtype` selects that (the oracle default) or float32 (what the device computes).
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _causal_conv(x, w, b, dilation=1, right=False, cache=None):
+    """CausalConv1d.forward (convolution.py:176-187): pad causal_padding zeros (or `cache`) on the left ('left') or right ('right')."""
+    k = w.shape[2]
+    pad = int((k * dilation - dilation) / 2) * 2 + (k + 1) % 2
+    c = torch.zeros(x.shape[0], x.shape[1], pad, dtype=x.dtype) if cache is None else cache
+    assert c.shape[2] == pad
+    x = torch.cat([x, c], 2) if right else torch.cat([c, x], 2)
+    return F.conv1d(x, w, b, dilation=dilation)
+
+
+def causal_f0_predictor(sd, mel, finalize=True, dtype=torch.float64):
+    x = mel.to(dtype)
+    for j in range(5):
+        p = "f0_predictor.condnet.%d." % (2 * j)
+        w, b = fold_weight_norm(sd, p).to(dtype), sd[p + "bias"].to(dtype)
+        if j == 0:
+            pad = w.shape[2] - 1                              # causal_padding of the k = 4 'right' conv = 3
+            x = _causal_conv(x, w, b, right=True) if finalize else _causal_conv(x[:, :, :-pad], w, b, right=True, cache=x[:, :, -pad:])
+        else:
+            x = _causal_conv(x, w, b)
+        x = F.elu(x)
+    return torch.abs(F.linear(x.transpose(1, 2), sd["f0_predictor.classifier.weight"].to(dtype), sd["f0_predictor.classifier.bias"].to(dtype)).squeeze(-1)).float()
+
+
+def causal_sine_gen2(cfg, f0, rand_ini, noise):
+    """SineGen2 with causal=True in eval mode (generator.py:233-258, 289-317): fixed rand_ini / uniform noise buffers, NEAREST phase upsampling."""
+    H = cfg.harmonics + 1
+    scale = int(np.prod(cfg.ups) * cfg.hop)
+    fn = f0 * torch.arange(1, H + 1, dtype=torch.float32).reshape(1, 1, H)
+    rad = (fn / cfg.sr) % 1
+    rad[:, 0, :] = rad[:, 0, :] + rand_ini
+    rad = F.interpolate(rad.transpose(1, 2), scale_factor=1 / scale, mode="linear").transpose(1, 2)
+    phase = torch.cumsum(rad, dim=1) * 2 * np.pi
+    phase = F.interpolate(phase.transpose(1, 2) * scale, scale_factor=scale, mode="nearest").transpose(1, 2)
+    sines = torch.sin(phase) * cfg.nsf_alpha
+    uv = (f0 > cfg.voiced_thr).float()
+    noise_amp = uv * cfg.nsf_sigma + (1 - uv) * cfg.nsf_alpha / 3
+    return sines * uv + noise_amp * noise
+
+
+def causal_resblock(sd, cfg, p, x, k):
+    for j, d in enumerate(cfg.res_d):
+        xt = snake(x, sd[p + "activations1.%d.alpha" % j])
+        xt = _causal_conv(xt, fold_weight_norm(sd, p + "convs1.%d." % j), sd[p + "convs1.%d.bias" % j], dilation=d)
+        xt = snake(xt, sd[p + "activations2.%d.alpha" % j])
+        xt = _causal_conv(xt, fold_weight_norm(sd, p + "convs2.%d." % j), sd[p + "convs2.%d.bias" % j])
+        x = xt + x
+    return x
+
+
+def causal_decode(sd, cfg, x, s, finalize=True):
+    """CausalHiFTGenerator.decode (generator.py:684-726)."""
+    win = hann16()
+    spec = torch.view_as_real(torch.stft(s.squeeze(1), cfg.n_fft, cfg.hop, cfg.n_fft, window=win, return_complex=True))
+    re, im = spec[..., 0], spec[..., 1]
+    lr, up = cfg.look_right, int(np.prod(cfg.ups))
+    w, b = fold_weight_norm(sd, "conv_pre."), sd["conv_pre.bias"]
+    if finalize:
+        x = _causal_conv(x, w, b, right=True)
+    else:
+        x = _causal_conv(x[:, :, :-lr], w, b, right=True, cache=x[:, :, -lr:])
+        re, im = re[:, :, :-up * lr], im[:, :, :-up * lr]
+    s_stft = torch.cat([re, im], dim=1)
+    rates = np.cumprod([1] + cfg.ups[::-1][:-1])[::-1]
+    nk = len(cfg.res_k)
+    for i, (u, k) in enumerate(zip(cfg.ups, cfg.up_k)):
+        x = F.leaky_relu(x, cfg.lrelu)
+        x = F.interpolate(x, scale_factor=float(u), mode="nearest")                       # CausalConv1dUpsample (convolution.py:248-259)
+        x = F.conv1d(F.pad(x, (k - 1, 0)), fold_weight_norm(sd, "ups.%d." % i), sd["ups.%d.bias" % i])
+        if i == len(cfg.ups) - 1:
+            x = F.pad(x, (1, 0), mode="reflect")
+        r = int(rates[i])
+        if r == 1:
+            si = F.conv1d(s_stft, sd["source_downs.%d.weight" % i], sd["source_downs.%d.bias" % i])
+        else:                                                                             # CausalConv1dDownSample: left pad stride - 1
+            si = F.conv1d(F.pad(s_stft, (r - 1, 0)), sd["source_downs.%d.weight" % i], sd["source_downs.%d.bias" % i], stride=r)
+        si = causal_resblock(sd, cfg, "source_resblocks.%d." % i, si, cfg.src_k[i])
+        x = x + si
+        xs = None
+        for j in range(nk):
+            y = causal_resblock(sd, cfg, "resblocks.%d." % (i * nk + j), x, cfg.res_k[j])
+            xs = y if xs is None else xs + y
+        x = xs / nk
+    x = F.leaky_relu(x)
+    x = _causal_conv(x, fold_weight_norm(sd, "conv_post."), sd["conv_post.bias"])
+    nb = cfg.n_fft // 2 + 1
+    mag = torch.clip(torch.exp(x[:, :nb, :]), max=1e2)
+    phase = torch.sin(x[:, nb:, :])
+    y = torch.istft(torch.complex(mag * torch.cos(phase), mag * torch.sin(phase)), cfg.n_fft, cfg.hop, cfg.n_fft, window=win)
+    if not finalize:
+        y = y[:, :-up * cfg.hop]
+    return torch.clamp(y, -cfg.audio_limit, cfg.audio_limit)
+
+
+def causal_inference(sd, cfg, speech_feat, finalize=True, rand_ini=None, noise=None, f0_dtype=torch.float64):
+    """CausalHiFTGenerator.inference (generator.py:713-726) -> (speech, source [1,1,L]).  noise [1, >= L, 9] = the model's fixed uniform buffer."""
+    scale = int(np.prod(cfg.ups) * cfg.hop)
+    f0 = causal_f0_predictor(sd, speech_feat, finalize, f0_dtype)
+    L = f0.shape[1] * scale
+    f0_up = F.interpolate(f0[:, None], scale_factor=float(scale), mode="nearest").transpose(1, 2)
+    rand_ini = torch.zeros(1, cfg.harmonics + 1) if rand_ini is None else rand_ini
+    noise = torch.zeros(1, L, cfg.harmonics + 1) if noise is None else noise[:, :L]
+    s = torch.tanh(F.linear(causal_sine_gen2(cfg, f0_up, rand_ini, noise), sd["m_source.l_linear.weight"], sd["m_source.l_linear.bias"])).transpose(1, 2)
+    x = speech_feat if finalize else speech_feat[:, :, :-3]
+    return causal_decode(sd, cfg, x, s, finalize), s

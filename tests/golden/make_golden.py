@@ -363,6 +363,89 @@ def golden_dit():
          est_x=x, est_mu=mu, est_cond=cond, est_spk=spk, est_t=t, est_full=e_full, est_stream=e_stream)
 
 
+def build_ref_causal_hift(cfg):
+    from cosyvoice.hifigan.f0_predictor import CausalConvRNNF0Predictor
+    from cosyvoice.hifigan.generator import CausalHiFTGenerator
+    import cosyvoice.hifigan.generator as GEN
+    # the generator allocates 300 s x 24 kHz uniform noise buffers at construction (generator.py:223-226, 355-356): shrink them for the fixture
+    orig_rand = torch.rand
+    torch.rand = lambda *shape, **kw: orig_rand(*[min(int(x), 48000) if i == 1 and len(shape) == 3 else x for i, x in enumerate(shape)], **kw)
+    try:
+        torch.manual_seed(1234)
+        hift = CausalHiFTGenerator(in_channels=cfg.mel, base_channels=cfg.base, nb_harmonics=cfg.harmonics, sampling_rate=cfg.sr,
+                                   nsf_alpha=cfg.nsf_alpha, nsf_sigma=cfg.nsf_sigma, nsf_voiced_threshold=cfg.voiced_thr,
+                                   upsample_rates=cfg.ups, upsample_kernel_sizes=cfg.up_k, istft_params={"n_fft": cfg.n_fft, "hop_len": cfg.hop},
+                                   resblock_kernel_sizes=cfg.res_k, resblock_dilation_sizes=[cfg.res_d] * 3,
+                                   source_resblock_kernel_sizes=cfg.src_k, source_resblock_dilation_sizes=[cfg.res_d] * 3,
+                                   lrelu_slope=cfg.lrelu, audio_limit=cfg.audio_limit, conv_pre_look_right=cfg.look_right,
+                                   f0_predictor=CausalConvRNNF0Predictor(num_class=1, in_channels=cfg.mel, cond_channels=cfg.f0_ch))
+    finally:
+        torch.rand = orig_rand
+    hift.load_state_dict(W.make_hift(cfg), strict=True)
+    return hift.eval()
+
+
+def golden_causal_hift():
+    """a17: the REAL CausalHiFTGenerator + CausalConvRNNF0Predictor (float64 f0, fixed SineGen2 buffers): one-shot and a non-final chunk."""
+    import dataclasses
+    cfg = dataclasses.replace(W.tiny()[2], causal=True)
+    hift = build_ref_causal_hift(cfg)
+    g = torch.Generator().manual_seed(15)
+    m = 17
+    mel = torch.randn(1, 80, m, generator=g) * 2 - 5
+    with torch.inference_mode():
+        speech, source = hift.inference(speech_feat=mel, finalize=True)
+        speech_c, source_c = hift.inference(speech_feat=mel[:, :, :13], finalize=False)
+        f0 = hift.f0_predictor(mel.to(torch.float64), finalize=True).float()
+    sg = hift.m_source.l_sin_gen
+    save("causal_hift_tiny", mel=mel, f0=f0, speech=speech, source=source, speech_c=speech_c, source_c=source_c,
+         rand_ini=sg.rand_ini, noise=sg.sine_waves[:, : 480 * m])
+
+
+def golden_model_cv3():
+    """a17 / B1 for CosyVoice3: the REAL cosyvoice.cli.model.CosyVoice3Model (token2wav with the accumulating mel cache + speech offsets, inherited
+    streaming loop, silent-token filter) over the real tiny CausalMaskedDiffWithDiT + CausalHiFTGenerator and a scripted LLM."""
+    import dataclasses
+    import cosyvoice.cli.model as M
+    lc, _, hc0 = W.tiny()
+    fc = W.tiny_cv3_flow()
+    hc = dataclasses.replace(hc0, causal=True)
+    flow, hift = build_ref_dit_flow(fc), build_ref_causal_hift(hc)
+    hift.m_source.l_sin_gen.sine_waves.zero_()                  # the fixed SineGen2 noise buffer is a construction-time draw: zeros keep the fixture small
+    u = W.synthetic_utterance(lc, dataclasses.replace(fc, spk_dim=fc.spk_dim), n_prompt_tok=8, n_prompt_text=4, n_text=2, seed=21)
+    g = torch.Generator().manual_seed(32)
+    tokens = torch.randint(0, fc.vocab, (41,), generator=g).tolist()
+    tokens[5:13] = [1, 2, 1, 2, 28, 1, 2, 1]                    # a run of silent tokens longer than 5: the filter drops the tail of it
+
+    class ScriptedLLM:
+        def inference(self, **kw):
+            for t in tokens:
+                yield t
+
+    orig_fwd = type(flow.decoder).forward
+
+    def fwd(self, mu, mask, spks, cond, n_timesteps=10, **kw):
+        return orig_fwd(self, mu=mu, mask=mask, spks=spks, cond=cond, n_timesteps=fc.n_timesteps, **kw)
+    type(flow.decoder).forward = fwd
+    M.time.sleep = lambda s: None
+    try:
+        out = {}
+        for stream in (False, True):
+            m = M.CosyVoice3Model(ScriptedLLM(), flow, hift)
+            m.token_hop_len, m.token_max_hop_len = 5, 20
+            with torch.inference_mode():
+                chunks = [o["tts_speech"] for o in m.tts(text=u["text"], flow_embedding=u["flow_embedding"], llm_embedding=u["llm_embedding"],
+                                                        prompt_text=u["prompt_text"], llm_prompt_speech_token=u["llm_prompt_speech_token"],
+                                                        flow_prompt_speech_token=u["flow_prompt_speech_token"], prompt_speech_feat=u["prompt_speech_feat"],
+                                                        stream=stream)]
+            key = "stream" if stream else "offline"
+            out[key + "_n"] = np.array([c.shape[1] for c in chunks])
+            out[key] = torch.cat(chunks, 1)
+    finally:
+        type(flow.decoder).forward = orig_fwd
+    save("model_cv3_tiny", tokens=np.array(tokens), **out)
+
+
 def golden_model():
     """B1 / a1 / a16: the REAL cosyvoice.cli.model.CosyVoice2Model (token2wav + the streaming tts loop with its hop doubling, mel / source /
     speech caches and fade_in_out) around the real tiny flow + HiFT modules and a scripted LLM.  Pins oracle/model.py.  SineGen2's additive

@@ -168,3 +168,43 @@ def test_dit_flow_matches_reference():
     torch.testing.assert_close(mel, g["mel_full"], rtol=1e-3, atol=1e-3)
     mel = OD.inference(sd, cfg, g["token"], g["prompt_token"], g["prompt_feat"], g["embedding"], streaming=True, finalize=False, n_timesteps=cfg.n_timesteps)
     torch.testing.assert_close(mel, g["mel_stream"], rtol=1e-3, atol=1e-3)
+
+
+def test_causal_hift_matches_reference():
+    """a17: oracle causal HiFT (oracle/hift.py causal_*) against the REAL CausalHiFTGenerator / CausalConvRNNF0Predictor: float64 f0, source (phase
+    integration amplifies round-off: 2e-3 as for HiFT v2), decoder pinned tightly by feeding it the reference's own source; one-shot and a non-final chunk."""
+    import dataclasses
+    g = load("causal_hift_tiny")
+    cfg = dataclasses.replace(W.tiny()[2], causal=True)
+    sd = W.make_hift(cfg)
+    torch.testing.assert_close(OH.causal_f0_predictor(sd, g["mel"], True), g["f0"], rtol=1e-5, atol=1e-4)
+    speech, source = OH.causal_inference(sd, cfg, g["mel"], True, g["rand_ini"], g["noise"])
+    torch.testing.assert_close(source, g["source"], rtol=0, atol=2e-3)
+    torch.testing.assert_close(OH.causal_decode(sd, cfg, g["mel"], g["source"], True), g["speech"], rtol=1e-4, atol=1e-4)
+    assert speech.shape == g["speech"].shape
+    speech_c, source_c = OH.causal_inference(sd, cfg, g["mel"][:, :, :13], False, g["rand_ini"], g["noise"])
+    torch.testing.assert_close(source_c, g["source_c"], rtol=0, atol=2e-3)
+    torch.testing.assert_close(OH.causal_decode(sd, cfg, g["mel"][:, :, :10], g["source_c"], False), g["speech_c"], rtol=1e-4, atol=1e-4)
+    assert speech_c.shape == g["speech_c"].shape == (1, 480 * (13 - 8))
+    # the streaming invariance the reference prints (generator.py:729-746): the chunk reproduces the head of the one-shot waveform
+    torch.testing.assert_close(g["speech_c"], g["speech"][:, : g["speech_c"].shape[1]], rtol=0, atol=1e-4)
+
+
+def test_cv3_pipeline_matches_reference_model():
+    """oracle.model.Pipeline3 against the REAL cosyvoice.cli.model.CosyVoice3Model (silent-token filter, accumulating mel cache, speech offsets,
+    inherited streaming loop) over the real tiny DiT flow + causal HiFT (tests/golden/make_golden.py::golden_model_cv3)."""
+    import dataclasses
+    from oracle import model as OM
+    g = load("model_cv3_tiny")
+    lc, _, hc0 = W.tiny()
+    fc, hc = W.tiny_cv3_flow(), dataclasses.replace(hc0, causal=True)
+    sds = (None, W.make_flow_dit(fc), W.make_hift(hc))
+    u = W.synthetic_utterance(lc, fc, n_prompt_tok=8, n_prompt_text=4, n_text=2, seed=21)
+    pipe = OM.Pipeline3(sds, (lc, fc, hc), token_hop_len=5)
+    tokens = g["tokens"].tolist()
+    assert len(pipe.filter_silent(tokens)) == len(tokens) - 3
+    for key, stream in (("offline", False), ("stream", True)):
+        outs = pipe.tts(tokens, u, stream=stream)
+        assert [o.shape[1] for o in outs] == g[key + "_n"].tolist()
+        torch.testing.assert_close(torch.cat(outs, 1), g[key], rtol=0, atol=5e-3)
+    assert len(g["stream_n"]) == 3
