@@ -35,6 +35,9 @@ struct cv_llm {
     int fused_qkv_attn = 0;
     int head_rows = 1;                                // rows per 16-lane group of the head GEMV (1: 411 workgroups, 2: 206)
     int attn_splits = 8;
+    // option "prefetch" (env CV_DECODE_PREFETCH): bit 0 = gate/up, bit 1 = down weights of a layer warmed into L2 by l2_prefetch_kernel on a
+    // forked branch of the decode graph while the layer's qkv / attention / o_proj run (llm_kernels.h)
+    int prefetch = 0; hipStream_t pf_stream = nullptr; hipEvent_t pf_fork = nullptr, pf_join = nullptr; DevBuf pf_sink;
     int only_cat = -1;                  // cv_llm_profile_chain: enqueue only the launches of this category (-1 = all)
     DevBuf pf_x, pf_xn, pf_qkv, pf_attn, pf_gu, pf_act; // prefill activations (grown on demand)
     int pf_rows = 0;
@@ -45,7 +48,7 @@ struct cv_llm {
     // lock-step batched decode (llm_batch_kernels.h): nb slots, each with its own KV cache / state / token history
     struct Batch {
         int nb = 0;
-        DevBuf kcache, vcache, state, tokens, sparams, uniforms, h, qkv, act, logits, part;
+        DevBuf kcache, vcache, state, tokens, sparams, uniforms, h, qkv, act, logits, attn, dpart;   // attn: merged attention [nb][heads*64]; dpart: split-K partials of down
         std::vector<DecodeState> host_state; std::vector<int> host_tokens; std::vector<SampleParams> host_sp;
         hipGraphExec_t graph = nullptr; hipStream_t graph_stream = nullptr; int graph_nb = 0;
     } bt;
@@ -57,6 +60,9 @@ struct cv_llm {
         if (graph) (void)hipGraphExecDestroy(graph);
         if (bt.graph) (void)hipGraphExecDestroy(bt.graph);
         if (own_stream) (void)hipStreamDestroy(own_stream);
+        if (pf_stream) (void)hipStreamDestroy(pf_stream);
+        if (pf_fork) (void)hipEventDestroy(pf_fork);
+        if (pf_join) (void)hipEventDestroy(pf_join);
         if (host_tokens) (void)hipHostFree(host_tokens);
         if (host_state) (void)hipHostFree(host_state);
         if (host_sp) (void)hipHostFree(host_sp);
@@ -108,6 +114,8 @@ static void llm_finalize(cv_llm* m) {
     m->attn_part.ensure((size_t)c.heads * 16 * ATTN_PART * 4);
     m->newtok.ensure((size_t)(c.heads + 2 * c.kv_heads) * 64 * 4);
     if (const char* e = getenv("CV_DECODE_FUSED_QKV")) m->fused_qkv_attn = e[0] != '0';     // dev knob for A/B runs (also: option "fused_qkv_attn")
+    if (const char* e = getenv("CV_DECODE_PREFETCH")) m->prefetch = atoi(e);
+    m->pf_sink.ensure(64);
     m->act.ensure((size_t)c.inter * 4); m->logits.ensure((size_t)m->V * 4);
     CV_HIP(hipHostMalloc((void**)&m->host_tokens, (size_t)c.max_len * sizeof(int)));
     CV_HIP(hipHostMalloc((void**)&m->host_state, sizeof(DecodeState)));
@@ -232,9 +240,23 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
     sa.st = m->state.as<DecodeState>(); sa.tokens = m->tokens.as<int>(); sa.max_tokens = c.max_len;
     sa.emb_table = m->speech_emb; sa.emb_dim = c.hidden; sa.h_out = h;             // sampling + embedding of the sampled token: one launch
     if (want(6)) { ProfScope ps(m, s, 6); hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, s, sa); }
+    const bool pf = m->prefetch && m->only_cat < 0 && !m->profiling && g_gemv_shared_norm && c.hidden / 128 <= 7;
+    if (pf && !m->pf_stream) {
+        CV_HIP(hipStreamCreateWithFlags(&m->pf_stream, hipStreamNonBlocking));
+        CV_HIP(hipEventCreateWithFlags(&m->pf_fork, hipEventDisableTiming)); CV_HIP(hipEventCreateWithFlags(&m->pf_join, hipEventDisableTiming));
+    }
     for (int i = 0; i < c.layers; ++i) {
         const auto& L = m->layers[i];
         const int nsp = m->attn_splits;
+        if (pf) {                                                   // fork: warm this layer's gate/up (+ down) weights while qkv / attention / o_proj run
+            // consumer grids (gemv() above): gate/up = gemv_norm_kernel<7,2>, 32 rows per workgroup; down = gemv_kernel<10,1,4>, 4 rows per workgroup
+            PrefetchArgs pa{};
+            pa.a = L.wgu; pa.a_per_wg = 32LL * c.hidden * 2; pa.a_wgs = (m->prefetch & 1) ? (2 * c.inter) / 32 : 0;
+            pa.b = L.wdown; pa.b_per_wg = 4LL * c.inter * 2; pa.b_wgs = (m->prefetch & 2) ? c.hidden / 4 : 0;
+            pa.sink = m->pf_sink.as<unsigned>();
+            CV_HIP(hipEventRecord(m->pf_fork, s)); CV_HIP(hipStreamWaitEvent(m->pf_stream, m->pf_fork, 0));
+            hipLaunchKernelGGL(l2_prefetch_kernel, dim3(std::max(pa.a_wgs, pa.b_wgs)), dim3(256), 0, m->pf_stream, pa);
+        }
         GemvArgs go{L.wo, nullptr, nullptr, h, c.hidden, c.heads * 64, nullptr, 0.f, h, 0, st};
         go.part = m->attn_part.as<float>();
         if (m->fused_qkv_attn) {
@@ -257,6 +279,7 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
         if (i == c.layers - 1 && m->only_cat < 0) gd.advance = m->state.as<DecodeState>();     // the step's last kernel also advances the KV length
         if (want(4)) { ProfScope ps(m, s, 4); gemv(gd, 1, s); }
     }
+    if (pf) { CV_HIP(hipEventRecord(m->pf_join, m->pf_stream)); CV_HIP(hipStreamWaitEvent(s, m->pf_join, 0)); }      // join the branch
 }
 
 static bool same_sampling(const cv_sampling& a, const cv_sampling& b) {
@@ -309,7 +332,7 @@ static void llm_decode(cv_llm* m, int n_steps, const cv_sampling* sp, int32_t* o
 // ---------------------------------------------------------------------------------------------------------------------------------
 static void batch_begin(cv_llm* m, int nb, hipStream_t s) {
     CV_CHECK(m->finalized, "llm: call cv_llm_finalize first");
-    CV_CHECK(nb >= 1 && nb <= MAX_NB, "cv_llm_batch_begin: batch size must be 1..8");
+    CV_CHECK(nb >= 1 && nb <= MAX_NB, "cv_llm_batch_begin: batch size must be 1..16");
     const auto& c = m->cfg; auto& b = m->bt;
     std::lock_guard<std::recursive_mutex> lk(runtime_lock());
     CV_HIP(hipStreamSynchronize(s));
@@ -318,7 +341,7 @@ static void batch_begin(cv_llm* m, int nb, hipStream_t s) {
     b.state.ensure((size_t)nb * sizeof(DecodeState)); b.tokens.ensure((size_t)nb * c.max_len * sizeof(int));
     b.sparams.ensure((size_t)nb * sizeof(SampleParams)); b.uniforms.ensure((size_t)nb * 2 * c.max_len * 4);
     b.h.ensure((size_t)nb * c.hidden * 4); b.qkv.ensure((size_t)nb * m->qkv_dim * 4); b.act.ensure((size_t)nb * c.inter * 4);
-    b.logits.ensure((size_t)nb * m->V * 4); b.part.ensure((size_t)nb * c.heads * 16 * ATTN_PART * 4);
+    b.logits.ensure((size_t)nb * m->V * 4); b.attn.ensure((size_t)nb * c.heads * 64 * 4); b.dpart.ensure((size_t)8 * nb * c.hidden * 4);
     b.host_state.assign(nb, DecodeState{}); b.host_tokens.assign((size_t)nb * c.max_len, 0); b.host_sp.assign(nb, SampleParams{});
     for (auto& st : b.host_state) { st.done = 1; st.stop_token = -1; }           // empty slots are "finished"
     CV_HIP(hipMemcpyAsync(b.state.p, b.host_state.data(), (size_t)nb * sizeof(DecodeState), hipMemcpyHostToDevice, s));
@@ -350,58 +373,58 @@ static void batch_prefill(cv_llm* m, int slot, const float* lm_input, int L0, co
     CV_HIP(hipStreamSynchronize(s));
 }
 
-static void gemv_batch(const GemvBatchArgs& a, int rows, hipStream_t s, int nsp = 0) {
-    const int steps = a.K / 128;
-    if (nsp > 0) {
-        CV_CHECK(steps <= 8 && rows == 1 && a.mode == 0 && !a.gamma && a.part && nsp == 8, "gemv_batch: partial-combine prologue is for o_proj with 8 slices");
-        hipLaunchKernelGGL((gemv_batch_kernel<2, 1, 4, 8>), dim3((a.N + 3) / 4), dim3(256), 0, s, a);
-        return;
-    }
-    CV_CHECK(a.K % 128 == 0 && steps >= 1 && steps <= 40, "gemv_batch: K must be a multiple of 128 and at most 5120");
-    const int units = a.mode == 1 ? a.N / 2 : (a.N + rows - 1) / rows;
-    const dim3 grid((units + 3) / 4);
-    if (a.mode == 1) rows = 2;
-    if (steps <= 7) {
-        if (rows == 2) hipLaunchKernelGGL((gemv_batch_kernel<7, 2, 1>), grid, dim3(64), 0, s, a);
-        else           hipLaunchKernelGGL((gemv_batch_kernel<7, 1, 1>), grid, dim3(64), 0, s, a);
-    } else {
-        CV_CHECK(!a.gamma, "gemv_batch: fused RMSNorm needs the whole row in one wave (K <= 896)");
-        if (rows == 2) hipLaunchKernelGGL((gemv_batch_kernel<10, 2, 4>), grid, dim3(256), 0, s, a);
-        else           hipLaunchKernelGGL((gemv_batch_kernel<10, 1, 4>), grid, dim3(256), 0, s, a);
-    }
+// skinny GEMM of the batched decode (llm_batch_kernels.h): rt = row tiles (16 rows) per workgroup, ksplit = K ranges across workgroups
+static void skinny(const SkinnyArgs& a, int rt, hipStream_t s) {
+    const int tiles = a.K / 32 / a.ksplit, row_tiles = (a.N + 15) / 16;
+    CV_CHECK(a.K % (32 * a.ksplit) == 0 && tiles >= 1 && (tiles + 3) / 4 <= 7 && (a.mode == 0 || a.N % 4 == 0), "skinny: K range must be a multiple of 32 and at most 28 tiles per workgroup");
+    CV_CHECK(!(a.gamma && a.ksplit != 1) && (a.mode == 2) == (a.ksplit > 1), "skinny: split-K workgroups leave raw partials (mode 2), the fused norm needs the whole row");
+    const dim3 grid(((row_tiles + rt - 1) / rt) * a.ksplit);
+    const bool deep = (tiles + 3) / 4 > 5;
+    if (rt == 1) hipLaunchKernelGGL((skinny_mfma_kernel<1, 7>), grid, dim3(256), 0, s, a);
+    else if (deep) hipLaunchKernelGGL((skinny_mfma_kernel<2, 7>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((skinny_mfma_kernel<2, 5>), grid, dim3(256), 0, s, a);
 }
 
-// one token for every slot: the launch sequence of llm_enqueue_step with the weight-streaming kernels batched
+// K ranges of the down projection: the largest split <= 8 that keeps >= 2 k-tiles per workgroup (CosyVoice2: 152 tiles -> 8 x 19)
+static int down_ksplit(int inter) {
+    const int tiles = inter / 32;
+    for (int ks = 8; ks > 1; ks >>= 1) if (tiles % ks == 0 && tiles / ks >= 2) return ks;
+    return 1;
+}
+
+// one token for every slot: the launch sequence of llm_enqueue_step on the multi-sequence kernels
 static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
     const auto& c = m->cfg; auto& b = m->bt; const int nb = b.nb;
-    const long long H = c.hidden, Q = m->qkv_dim, I = c.inter, V = m->V;
+    const long long H = c.hidden, Q = m->qkv_dim, I = c.inter, V = m->V, A = c.heads * 64;
     DecodeState* st = b.state.as<DecodeState>();
     float* h = b.h.as<float>(); float* qkv = b.qkv.as<float>(); float* act = b.act.as<float>(); float* logits = b.logits.as<float>();
-    const long long ldpart = (long long)c.heads * 16 * ATTN_PART;
-    GemvBatchArgs hd{m->head_w, m->head_b, h, H, logits, V, (int)V, c.hidden, m->norm, c.rms_eps, nullptr, 0, 0, nb, nullptr, 0};
-    gemv_batch(hd, 2, s);
-    for (int i = 0; i < nb; ++i) {                                // per-slot sampler + embedding of the sampled token (no weights streamed)
+    float* att = b.attn.as<float>(); float* dpart = b.dpart.as<float>();
+    const int ks = down_ksplit(c.inter);
+    skinny(SkinnyArgs{m->head_w, m->head_b, h, H, logits, V, (int)V, c.hidden, m->norm, c.rms_eps, nullptr, 0, 0, nb, 1}, 2, s);
+    {                                                             // every slot's sampler + embedding of the sampled token: one launch, one workgroup per slot
         SampleArgs sa{};
-        sa.logits = logits + i * V; sa.V = (int)V; sa.sp = b.sparams.as<SampleParams>() + i; sa.uniforms = b.uniforms.as<float>() + (size_t)i * 2 * c.max_len;
-        sa.st = st + i; sa.tokens = b.tokens.as<int>() + (size_t)i * c.max_len; sa.max_tokens = c.max_len;
-        sa.emb_table = m->speech_emb; sa.emb_dim = c.hidden; sa.h_out = h + i * H;
-        hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, s, sa);
+        sa.logits = logits; sa.V = (int)V; sa.sp = b.sparams.as<SampleParams>(); sa.uniforms = b.uniforms.as<float>();
+        sa.st = st; sa.tokens = b.tokens.as<int>(); sa.max_tokens = c.max_len;
+        sa.emb_table = m->speech_emb; sa.emb_dim = c.hidden; sa.h_out = h;
+        sa.slot_logits = V; sa.slot_uniforms = 2LL * c.max_len; sa.slot_tokens = c.max_len; sa.slot_h = H;
+        hipLaunchKernelGGL(sample_kernel, dim3(nb), dim3(1024), 0, s, sa);
     }
     for (int l = 0; l < c.layers; ++l) {
         const auto& L = m->layers[l];
-        GemvBatchArgs q{L.wqkv, L.bqkv, h, H, qkv, Q, (int)Q, c.hidden, L.ln1, c.rms_eps, nullptr, 0, 0, nb, nullptr, 0};
-        gemv_batch(q, 1, s);
+        skinny(SkinnyArgs{L.wqkv, L.bqkv, h, H, qkv, Q, (int)Q, c.hidden, L.ln1, c.rms_eps, nullptr, 0, 0, nb, 1}, 1, s);
         AttnDecodeBatchArgs ad{qkv, Q, b.kcache.as<float>() + m->layer_cache() * l, b.vcache.as<float>() + m->layer_cache() * l, (long long)m->slot_cache(),
-                               m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st, b.part.as<float>(), ldpart, 8};
-        hipLaunchKernelGGL(attn_decode_batch_kernel, dim3(c.heads * 8, nb), dim3(64), 0, s, ad);
-        GemvBatchArgs o{L.wo, nullptr, nullptr, 0, h, H, c.hidden, c.heads * 64, nullptr, 0.f, h, H, 0, nb, b.part.as<float>(), ldpart};
-        gemv_batch(o, 1, s, 8);
-        GemvBatchArgs gu{L.wgu, nullptr, h, H, act, I, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 0, 1, nb, nullptr, 0};
-        gemv_batch(gu, 2, s);
-        GemvBatchArgs dn{L.wdown, nullptr, act, I, h, H, c.hidden, c.inter, nullptr, 0.f, h, H, 0, nb, nullptr, 0};
-        gemv_batch(dn, 1, s);
+                               m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st, att, A};
+        hipLaunchKernelGGL(attn_decode_batch_kernel, dim3(c.heads, nb), dim3(256), 0, s, ad);
+        skinny(SkinnyArgs{L.wo, nullptr, att, A, h, H, c.hidden, (int)A, nullptr, 0.f, h, H, 0, nb, 1}, 1, s);
+        skinny(SkinnyArgs{L.wgu, nullptr, h, H, act, I, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 0, 1, nb, 1}, 2, s);
+        if (ks > 1) {
+            skinny(SkinnyArgs{L.wdown, nullptr, act, I, dpart, H, c.hidden, c.inter, nullptr, 0.f, nullptr, 0, 2, nb, ks}, 2, s);
+            hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((nb * H / 4 + 255) / 256)), dim3(256), 0, s, dpart, ks, nb, c.hidden, h, H, h, H);
+        } else {
+            skinny(SkinnyArgs{L.wdown, nullptr, act, I, h, H, c.hidden, c.inter, nullptr, 0.f, h, H, 0, nb, 1}, 2, s);
+        }
     }
-    for (int i = 0; i < nb; ++i) hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, s, st + i);
+    hipLaunchKernelGGL(advance_pos_batch_kernel, dim3(1), dim3(64), 0, s, st, nb);
 }
 
 static void batch_decode(cv_llm* m, int n_steps, int32_t* out_tokens, int32_t* n_out, int32_t* finished, hipStream_t s) {
@@ -470,6 +493,10 @@ int cv_llm_set_option(cv_llm* m, const char* name, int32_t value) {
         else if (std::string(name) == "attn_splits") {       // key-range slices per head in the decode attention (4, 8 or 16)
             CV_CHECK(value == 4 || value == 8 || value == 16, "attn_splits must be 4, 8 or 16");
             m->attn_splits = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+        }
+        else if (std::string(name) == "prefetch") {          // bit 0: gate/up, bit 1: down weights warmed into L2 on a forked graph branch
+            CV_CHECK(value >= 0 && value <= 3, "prefetch must be 0..3");
+            m->prefetch = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
         }
         else throw Error(std::string("unknown option ") + name);
     });

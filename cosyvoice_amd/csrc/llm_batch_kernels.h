@@ -1,209 +1,221 @@
-// Lock-step batched decode (BASELINE.json configs[2]/[3], SURVEY.md §8e "LLM continuous batching"): NB sequences advance by one token
-// per step and every weight matrix is streamed from HBM ONCE per step for all of them - the batch-1 GEMVs are bound by that stream
-// (llm_kernels.h), so the cost of a step grows only by the per-sequence activations.
+// Lock-step batched decode (BASELINE.json configs[2]/[3]/[4], SURVEY.md §8e "LLM continuous batching"): up to 16 sequences advance by
+// one token per step and every weight matrix is streamed from HBM ONCE per step for all of them.
 //
-// The arithmetic of each sequence is the arithmetic of the single-sequence kernels (same lane mapping, same summation order), so a
-// sequence decoded in a batch yields bit-identical logits - and therefore the same tokens - as the same sequence decoded alone.
-// Per-sequence kernels that do not touch weights (sampler, embedding of the sampled token, position advance) are the single-sequence
-// kernels launched per slot; the weight-streaming GEMVs and the attention get batched kernels here.
+// With nb sequences a decode "GEMV" is a skinny GEMM  Y[b][n] = sum_k W[n][k] X[b][k]  (b < 16): it goes on the exact-fp32 matrix
+// pipe, v_mfma_f32_16x16x4_f32 (products and accumulation in fp32, bit-identical to an fma chain in a fixed order), with the weight
+// tile as the MFMA "A" operand (16 weight rows) and the sequences as the 16 "B" columns - one MFMA instruction serves all 16 sequences,
+// so a step costs the weight stream once plus the per-sequence activations (the first version of this file looped the batch-1 VALU GEMV
+// over the sequences: 256 VGPRs, one dependent L2 round trip per sequence, 32 us per gate/up launch at nb = 8 against 6 us for nb = 1).
+//
+//   * Every column (sequence) of an MFMA is an independent fp32 dot product in a fixed k order: what a sequence computes does not depend
+//     on its slot nor on what the other slots hold (SURVEY.md §8e determinism requirement).  The summation ORDER differs from the
+//     batch-1 kernels (llm_kernels.h), so logits agree with them to rounding (1e-6 relative), not bit for bit; greedy tokens are
+//     compared with the single path and with the oracle in tests/test_zz_llm_batch.py.
+//   * Latency structure as in llm_kernels.h: a wave first requests ALL of its weight fragments (non-temporal); the workgroup then stages
+//     its X slice through LDS once.  The 4 waves of a workgroup split K; their accumulators are combined through LDS in a fixed order.
+//   * The binding resource of these kernels is what one CU can ingest (a few tens of bytes per cycle): every workgroup needs the X
+//     columns of its K range for all sequences, so the shapes are cut so that X bytes per workgroup stay close to its weight bytes -
+//     down (K = 4864) is split 8 ways over K across workgroups, its partial sums are combined (fixed order, + residual) by
+//     sum_partials_kernel.
 #pragma once
 #include "llm_kernels.h"
 
 namespace cv {
 
-constexpr int MAX_NB = 8;
+constexpr int MAX_NB = 16;
 
-struct GemvBatchArgs {
-    const bf16_t* W; const float* bias; const float* x; long long ldx; float* y; long long ldy; int N, K;
-    const float* gamma; float eps; const float* res; long long ldres; int mode; int nb;
-    const float* part; long long ldpart;      // NSP > 0: x of slot b = merge of its split-attention partials at part + b * ldpart
+struct SkinnyArgs {
+    const bf16_t* W; const float* bias;
+    const float* x; long long ldx;            // X [nb][K] fp32
+    float* y; long long ldy;                  // mode 0: [nb][N]   mode 1: [nb][N/2]   mode 2: [ksplit][nb][N] (ldy = N)
+    int N, K;
+    const float* gamma; float eps;            // fused Qwen2RMSNorm over the whole row (ksplit must be 1)
+    const float* res; long long ldres;
+    int mode;                                 // 0: acc + bias + res   1: rows interleaved (gate_j, up_j): silu(gate) * up   2: raw split-K partial
+    int nb, ksplit;
 };
 
-// gemv_kernel (llm_kernels.h) with a loop over the nb sequences around everything that depends on x: the weight registers are
-// loaded once, x_b / partials_b come from L2 per sequence.
-template <int STEPS, int ROWS, int WAVES, int NSP = 0>
-__global__ __launch_bounds__(WAVES * 64) void gemv_batch_kernel(GemvBatchArgs p) {
-    __shared__ float part[WAVES][4][ROWS][MAX_NB];
-    __shared__ __attribute__((aligned(16))) float xs[NSP > 0 ? 1024 : 4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
-    const int steps = p.K / 128;
-    const int s0 = wave * steps / WAVES, s1 = (wave + 1) * steps / WAVES;
-    const int row0 = (blockIdx.x * 4 + grp) * ROWS;
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
-    u32x4 w[ROWS][STEPS];
+// Workgroup = 4 waves sharing RT row tiles (16 weight rows each) and one K range (K / ksplit); wave w takes the k-tiles (32 columns)
+// [w * T / 4, (w + 1) * T / 4) of the range, at most KTW of them.  Lane l: weight row l % 16 (A operand), sequence l % 16 (B operand),
+// k slot group g = l / 16: 8 consecutive k per 32-wide tile -> one 16-byte weight load (8 bf16) and two float4 X loads per tile feed 8
+// MFMAs.  D: lane l holds y[seq l % 16][row 4 * (l / 16) + i], i = 0..3: one float4 store per sequence.
+// (Staging X through LDS - one coalesced fetch per workgroup, conflict-free fragment reads - was built and measured SLOWER on the
+// MI355X: 15.9 vs 12.8 us for gate/up at nb = 8, 8.3 vs 5.6 us for qkv / o_proj: two more barriers in front of the MFMA chain cost more
+// than the 28 extra L2 load instructions per lane; profiles/r2_batch_decode_ab.txt.)
+template <int RT, int KTW>
+__global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs p) {
+    static_assert(RT >= 1 && RT <= 4, "the final combine hands one row tile to each wave");
+    __shared__ __attribute__((aligned(16))) float red[4 * RT * 256];
+    __shared__ float ssq[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int ks = blockIdx.x % p.ksplit, rg = blockIdx.x / p.ksplit;
+    const int krange = p.K / p.ksplit, tiles = krange / 32;
+    const int t0 = wave * tiles / 4, t1 = (wave + 1) * tiles / 4;
+    const int kbase = ks * krange + t0 * 32 + g * 8;
+    const int n_base = rg * RT * 16;
+
+    u32x4 w[RT][KTW];
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        const int row = min(row0 + r, p.N - 1);
-        const bf16_t* wr = p.W + (long long)row * p.K + sub * 8;
+    for (int rt = 0; rt < RT; ++rt) {
+        const int row = min(n_base + rt * 16 + c, p.N - 1);            // clamped: ragged last tile (stores are masked)
+        const bf16_t* wr = p.W + (long long)row * p.K + kbase;
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            const bool ok = s0 + s < s1;
-            u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + (ok ? (s0 + s) : s0) * 128));
-            if (!ok) t = (u32x4){0u, 0u, 0u, 0u};
-            w[r][s] = t;
+        for (int t = 0; t < KTW; ++t) {
+            const bool ok = t0 + t < t1;
+            u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + (ok ? t : 0) * 32));
+            if (!ok) v = (u32x4){0u, 0u, 0u, 0u};
+            w[rt][t] = v;
         }
     }
-    float4 ga[STEPS], gb[STEPS];
-    if (p.gamma) {
+    float4 xa[KTW], xb[KTW];
+    {
+        const float* xp = p.x + (long long)min(c, p.nb - 1) * p.ldx + kbase;   // columns >= nb recompute the last sequence (never stored)
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            const int so = (s0 + s < s1) ? (s0 + s) : s0;
-            ga[s] = *reinterpret_cast<const float4*>(p.gamma + so * 128 + sub * 8);
-            gb[s] = *reinterpret_cast<const float4*>(p.gamma + so * 128 + sub * 8 + 4);
+        for (int t = 0; t < KTW; ++t) {
+            const bool ok = t0 + t < t1;
+            xa[t] = *reinterpret_cast<const float4*>(xp + (ok ? t : 0) * 32);
+            xb[t] = *reinterpret_cast<const float4*>(xp + (ok ? t : 0) * 32 + 4);
+            if (!ok) { xa[t] = make_float4(0.f, 0.f, 0.f, 0.f); xb[t] = xa[t]; }
         }
     }
-    // the loops over the sequences are fully unrolled (compile-time b, uniform `b < nb` guards): acc[][] stays in registers
-    float acc[MAX_NB][ROWS];
+    if (p.gamma) {                                                      // Qwen2RMSNorm of every sequence, statistics over the whole workgroup
+        float4 ga[KTW], gb[KTW];
 #pragma unroll
-    for (int b = 0; b < MAX_NB; ++b) {
-        if (b >= p.nb) break;
-        float4 xa[STEPS], xb[STEPS];
-        if constexpr (NSP == 0) {
-            const float* xp = p.x + (long long)b * p.ldx;
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                const bool ok = s0 + s < s1;
-                const int so = ok ? (s0 + s) : s0;
-                xa[s] = *reinterpret_cast<const float4*>(xp + so * 128 + sub * 8);
-                xb[s] = *reinterpret_cast<const float4*>(xp + so * 128 + sub * 8 + 4);
-                if (!ok) { xa[s] = make_float4(0.f, 0.f, 0.f, 0.f); xb[s] = xa[s]; }
-            }
-        } else {
-            static_assert(NSP == 0 || WAVES == 4, "partial-combine prologue: 256 threads cover K <= 1024");
-            if (b > 0) __syncthreads();                       // xs of the previous sequence has been consumed
-            if (tid * 4 < p.K) {
-                const float* ph = p.part + (long long)b * p.ldpart + (long long)(tid >> 4) * NSP * ATTN_PART;
-                float4 pa[NSP > 0 ? NSP : 1]; float2 ml[NSP > 0 ? NSP : 1];
-#pragma unroll
-                for (int q = 0; q < NSP; ++q) {
-                    pa[q] = *reinterpret_cast<const float4*>(ph + q * ATTN_PART + (tid & 15) * 4);
-                    ml[q] = *reinterpret_cast<const float2*>(ph + q * ATTN_PART + 64);
-                }
-                float M = ml[0].x;
-#pragma unroll
-                for (int q = 1; q < NSP; ++q) M = fmaxf(M, ml[q].x);
-                float den = 0.f; float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int q = 0; q < NSP; ++q) {
-                    const float wq = (ml[q].y > 0.f) ? expf(ml[q].x - M) : 0.f;
-                    den += wq * ml[q].y;
-                    a.x += wq * pa[q].x; a.y += wq * pa[q].y; a.z += wq * pa[q].z; a.w += wq * pa[q].w;
-                }
-                const float inv = 1.f / den;
-                *reinterpret_cast<float4*>(&xs[tid * 4]) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                const bool ok = s0 + s < s1;
-                const int so = ok ? (s0 + s) : s0;
-                xa[s] = *reinterpret_cast<const float4*>(&xs[so * 128 + sub * 8]);
-                xb[s] = *reinterpret_cast<const float4*>(&xs[so * 128 + sub * 8 + 4]);
-                if (!ok) { xa[s] = make_float4(0.f, 0.f, 0.f, 0.f); xb[s] = xa[s]; }
-            }
+        for (int t = 0; t < KTW; ++t) {
+            const int tt = (t0 + t < t1) ? t : 0;
+            ga[t] = *reinterpret_cast<const float4*>(p.gamma + kbase + tt * 32);
+            gb[t] = *reinterpret_cast<const float4*>(p.gamma + kbase + tt * 32 + 4);
         }
-        if (p.gamma) {                                        // fused Qwen2RMSNorm of sequence b (WAVES == 1)
-            float ss = 0.f;
+        float ss = 0.f;
 #pragma unroll
-            for (int s = 0; s < STEPS; ++s)
-                ss += xa[s].x * xa[s].x + xa[s].y * xa[s].y + xa[s].z * xa[s].z + xa[s].w * xa[s].w +
-                      xb[s].x * xb[s].x + xb[s].y * xb[s].y + xb[s].z * xb[s].z + xb[s].w * xb[s].w;
-            ss = group16_sum(ss);
-            const float rstd = rsqrtf(ss / (float)p.K + p.eps);
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                xa[s].x = xa[s].x * rstd * ga[s].x; xa[s].y = xa[s].y * rstd * ga[s].y; xa[s].z = xa[s].z * rstd * ga[s].z; xa[s].w = xa[s].w * rstd * ga[s].w;
-                xb[s].x = xb[s].x * rstd * gb[s].x; xb[s].y = xb[s].y * rstd * gb[s].y; xb[s].z = xb[s].z * rstd * gb[s].z; xb[s].w = xb[s].w * rstd * gb[s].w;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            float a = 0.f;
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                const u32x4 u = w[r][s];
-                a += __uint_as_float(u[0] << 16) * xa[s].x;          a += __uint_as_float(u[0] & 0xffff0000u) * xa[s].y;
-                a += __uint_as_float(u[1] << 16) * xa[s].z;          a += __uint_as_float(u[1] & 0xffff0000u) * xa[s].w;
-                a += __uint_as_float(u[2] << 16) * xb[s].x;          a += __uint_as_float(u[2] & 0xffff0000u) * xb[s].y;
-                a += __uint_as_float(u[3] << 16) * xb[s].z;          a += __uint_as_float(u[3] & 0xffff0000u) * xb[s].w;
-            }
-            acc[b][r] = group16_sum(a);
-        }
-    }
-    if (WAVES > 1) {                                          // split-K inside the workgroup, combined in fixed order (as gemv_kernel)
-        if (sub == 0) {
-#pragma unroll
-            for (int b = 0; b < MAX_NB; ++b)
-                if (b < p.nb) {
-#pragma unroll
-                    for (int r = 0; r < ROWS; ++r) part[wave][grp][r][b] = acc[b][r];
-                }
-        }
+        for (int t = 0; t < KTW; ++t)
+            ss += xa[t].x * xa[t].x + xa[t].y * xa[t].y + xa[t].z * xa[t].z + xa[t].w * xa[t].w +
+                  xb[t].x * xb[t].x + xb[t].y * xb[t].y + xb[t].z * xb[t].z + xb[t].w * xb[t].w;
+        ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);            // over the 4 k-slot groups of the wave
+        if (g == 0) ssq[wave][c] = ss;
         __syncthreads();
-        if (wave != 0) return;
+        ss = (ssq[0][c] + ssq[1][c]) + (ssq[2][c] + ssq[3][c]);
+        const float rstd = rsqrtf(ss / (float)p.K + p.eps);
 #pragma unroll
-        for (int b = 0; b < MAX_NB; ++b)
-            if (b < p.nb) {
-#pragma unroll
-                for (int r = 0; r < ROWS; ++r) { float t = 0.f; for (int ww = 0; ww < WAVES; ++ww) t += part[ww][grp][r][b]; acc[b][r] = t; }
-            }
+        for (int t = 0; t < KTW; ++t) {
+            xa[t].x = xa[t].x * rstd * ga[t].x; xa[t].y = xa[t].y * rstd * ga[t].y; xa[t].z = xa[t].z * rstd * ga[t].z; xa[t].w = xa[t].w * rstd * ga[t].w;
+            xb[t].x = xb[t].x * rstd * gb[t].x; xb[t].y = xb[t].y * rstd * gb[t].y; xb[t].z = xb[t].z * rstd * gb[t].z; xb[t].w = xb[t].w * rstd * gb[t].w;
+        }
     }
-    if (sub != 0) return;
+    v4f acc[RT];
 #pragma unroll
-    for (int b = 0; b < MAX_NB; ++b) {
-        if (b >= p.nb) break;
-        float* yb = p.y + (long long)b * p.ldy;
-        if (p.mode == 1) {                                    // ROWS == 2: (gate_j, up_j)
-            const int j = blockIdx.x * 4 + grp;
-            if (row0 + 1 < p.N) { const float g = acc[b][0]; yb[j] = (g / (1.f + expf(-g))) * acc[b][ROWS - 1]; }
-        } else {
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const int row = row0 + r;
-                if (row < p.N) {
-                    float v = acc[b][r];
-                    if (p.bias) v += p.bias[row];
-                    if (p.res) v += p.res[(long long)b * p.ldres + row];
-                    yb[row] = v;
-                }
+    for (int t = 0; t < KTW; ++t) {
+        if (t0 + t < t1) {                                              // wave-uniform
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const u32x4 u = w[rt][t];
+                v4f a = acc[rt];
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_lo(u[0]), xa[t].x, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_hi(u[0]), xa[t].y, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_lo(u[1]), xa[t].z, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_hi(u[1]), xa[t].w, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_lo(u[2]), xb[t].x, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_hi(u[2]), xb[t].y, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_lo(u[3]), xb[t].z, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_hi(u[3]), xb[t].w, a, 0, 0, 0);
+                acc[rt] = a;
             }
         }
+    }
+    // split-K over the 4 waves, combined in fixed order; wave rt finishes row tile rt  [4 waves][RT][64 lanes][4]
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<float4*>(&red[((wave * RT + rt) * 64 + lane) * 4]) = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
+    __syncthreads();
+    if (wave >= RT) return;
+    const int rt = wave;
+    float4 v = *reinterpret_cast<const float4*>(&red[(rt * 64 + lane) * 4]);
+#pragma unroll
+    for (int ww = 1; ww < 4; ++ww) {
+        const float4 o = *reinterpret_cast<const float4*>(&red[((ww * RT + rt) * 64 + lane) * 4]);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    const int n = n_base + rt * 16 + g * 4;                             // 4 consecutive weight rows of sequence c
+    if (c >= p.nb || n >= p.N) return;
+    if (p.mode == 1) {                                                  // (gate_j, up_j) row pairs -> two activations
+        const float2 o = make_float2((v.x / (1.f + expf(-v.x))) * v.y, (v.z / (1.f + expf(-v.z))) * v.w);
+        *reinterpret_cast<float2*>(p.y + (long long)c * p.ldy + (n >> 1)) = o;
+    } else if (p.mode == 2) {
+        *reinterpret_cast<float4*>(p.y + ((long long)ks * p.nb + c) * p.ldy + n) = v;
+    } else if ((p.N & 3) == 0) {
+        if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+        if (p.res) { const float4 r4 = *reinterpret_cast<const float4*>(p.res + (long long)c * p.ldres + n); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+        *reinterpret_cast<float4*>(p.y + (long long)c * p.ldy + n) = v;
+    } else {                                                            // ragged N (the 6761-wide CosyVoice3 head): rows are not 16-byte aligned
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (n + i < p.N) {
+                float o = e[i];
+                if (p.bias) o += p.bias[n + i];
+                if (p.res) o += p.res[(long long)c * p.ldres + n + i];
+                p.y[(long long)c * p.ldy + n + i] = o;
+            }
     }
 }
 
-// attn_decode_kernel (llm_kernels.h) with the sequence index in blockIdx.y: own qkv row, own KV cache region, own state, own partials
+// y[b][n] = res[b][n] + sum_ks part[ks][b][n]   (fixed order; the split-K combine of the down projection + residual)
+static __global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, int ksplit, int nb, int N, const float* res, long long ldres,
+                                                               float* y, long long ldy) {
+    const int i = blockIdx.x * 256 + threadIdx.x;                       // float4 index over [nb][N / 4]
+    const int per = N >> 2;
+    if (i >= nb * per) return;
+    const int b = i / per, n = (i % per) * 4;
+    float4 v = *reinterpret_cast<const float4*>(part + (long long)b * N + n);
+    for (int s = 1; s < ksplit; ++s) {
+        const float4 o = *reinterpret_cast<const float4*>(part + ((long long)s * nb + b) * N + n);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    if (res) { const float4 r = *reinterpret_cast<const float4*>(res + (long long)b * ldres + n); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    *reinterpret_cast<float4*>(y + (long long)b * ldy + n) = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Decode attention of one new position per sequence: workgroup (head h, sequence b), 4 waves over the keys, normalised output.
+// With >= 8 sequences there are >= 112 (b, h) pairs, so the keys are not split across workgroups (the batch-1 kernel needs 8 slices
+// per head to occupy the chip and leaves the merge to o_proj); rotate-half RoPE on q / new k in registers, KV append, online softmax
+// per wave (12 slots x 4 key rows per pass and wave), waves merged through LDS in fixed order.
+// ---------------------------------------------------------------------------------------------------------------------------------
 struct AttnDecodeBatchArgs {
     const float* qkv; long long ldqkv; float* kcache; float* vcache; long long cache_stride;      // per-sequence strides
     const float* rope_cos; const float* rope_sin; int heads, kv_heads, max_len;
-    const DecodeState* st; float* part; long long ldpart; int nsplit;
+    const DecodeState* st; float* out; long long ldo;
 };
 
-static __global__ __launch_bounds__(64) void attn_decode_batch_kernel(AttnDecodeBatchArgs p) {
-    constexpr int NS = 12, PASS = 4 * NS;
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x, sub = lane & 15, grp = lane >> 4;
-    const int h = blockIdx.x / p.nsplit, sp = blockIdx.x % p.nsplit, gsz = p.heads / p.kv_heads, g = h / gsz;
+static __global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnDecodeBatchArgs p) {
+    constexpr int NS = 12, WPASS = 4 * NS, PASS = 4 * WPASS;
+    __shared__ __attribute__((aligned(16))) float pw[4][ATTN_PART];
+    const int b = blockIdx.y, h = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15, grp = lane >> 4;
+    const int gsz = p.heads / p.kv_heads, g = h / gsz;
     const DecodeState* st = p.st + b;
     const float* qkv = p.qkv + (long long)b * p.ldqkv;
     float* kcache = p.kcache + (long long)b * p.cache_stride;
     float* vcache = p.vcache + (long long)b * p.cache_stride;
-    const int pos = st->pos;
+    const int pos = st->pos;                         // the new token sits at index `pos`
     const int L = pos + 1;
-    const int per = ((L + p.nsplit * 4 - 1) / (p.nsplit * 4)) * 4;
-    const int kb = sp * per, ke = min(L, kb + per);
     const float* kc = kcache + (long long)g * p.max_len * 64;
     const float* vc = vcache + (long long)g * p.max_len * 64;
     float4 k4[NS], v4[NS];
     auto load_pass = [&](int base) {
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
-            const int j = base + sl * 4 + grp;
-            const long long o = (long long)((j < pos && j < ke) ? j : 0) * 64 + sub * 4;
+            const int j = base + wave * WPASS + sl * 4 + grp;
+            const long long o = (long long)(j < pos ? j : 0) * 64 + sub * 4;      // unconditional, clamped
             k4[sl] = *reinterpret_cast<const float4*>(kc + o);
             v4[sl] = *reinterpret_cast<const float4*>(vc + o);
         }
     };
-    load_pass(kb);
+    load_pass(0);
     const float* qraw = qkv + h * 64;
     const float* kq = qkv + p.heads * 64 + g * 64;
     const float* vq = qkv + (p.heads + p.kv_heads) * 64 + g * 64;
@@ -216,48 +228,70 @@ static __global__ __launch_bounds__(64) void attn_decode_batch_kernel(AttnDecode
     const float sg = d0 < 32 ? -1.f : 1.f;
     const float4 q4 = make_float4(qa.x * c4.x + sg * qb.x * s4.x, qa.y * c4.y + sg * qb.y * s4.y, qa.z * c4.z + sg * qb.z * s4.z, qa.w * c4.w + sg * qb.w * s4.w);
     const float4 kn4 = make_float4(ka.x * c4.x + sg * kp.x * s4.x, ka.y * c4.y + sg * kp.y * s4.y, ka.z * c4.z + sg * kp.z * s4.z, ka.w * c4.w + sg * kp.w * s4.w);
-    if (!st->done && sp == 0 && h % gsz == 0 && grp == 0) {
+    if (!st->done && h % gsz == 0 && wave == 0 && grp == 0) {            // KV-cache append: one wave per kv head
         *reinterpret_cast<float4*>(kcache + ((long long)g * p.max_len + pos) * 64 + d0) = kn4;
         *reinterpret_cast<float4*>(vcache + ((long long)g * p.max_len + pos) * 64 + d0) = vn4;
     }
     const float NEG = -__builtin_huge_valf();
     float m_run = NEG, l_run = 0.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = kb; base < ke; base += PASS) {
-        if (base != kb) load_pass(base);
+    for (int base = 0; base < L; base += PASS) {     // workgroup-uniform
+        if (base != 0) load_pass(base);
         float sc[NS];
         float mt = NEG;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
-            const int j = base + sl * 4 + grp;
+            const int j = base + wave * WPASS + sl * 4 + grp;
             const float4 kk = (j == pos) ? kn4 : k4[sl];
             float a = q4.x * kk.x + q4.y * kk.y + q4.z * kk.z + q4.w * kk.w;
             a = group16_sum(a) * 0.125f;
-            sc[sl] = j < ke ? a : NEG;
+            sc[sl] = j < L ? a : NEG;
             mt = fmaxf(mt, sc[sl]);
         }
         mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));
+        if (mt == NEG) continue;                     // wave-uniform: this wave holds no key of the pass
         const float m_new = fmaxf(m_run, mt);
         const float scale = (m_run == NEG) ? 0.f : expf(m_run - m_new);
         acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
         float lt = 0.f;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
-            const int j = base + sl * 4 + grp;
+            const int j = base + wave * WPASS + sl * 4 + grp;
             const float e = (sc[sl] == NEG) ? 0.f : expf(sc[sl] - m_new);
             const float4 vv = (j == pos) ? vn4 : v4[sl];
             acc.x += e * vv.x; acc.y += e * vv.y; acc.z += e * vv.z; acc.w += e * vv.w;
             lt += e;
         }
-        l_run = l_run * scale + lt;
+        l_run = l_run * scale + lt;                  // per-group partial (identical on the 16 lanes of a group)
         m_run = m_new;
     }
     acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
     acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
     l_run += __shfl_xor(l_run, 16); l_run += __shfl_xor(l_run, 32);
-    float* pr = p.part + (long long)b * p.ldpart + (long long)blockIdx.x * ATTN_PART;
-    if (grp == 0) *reinterpret_cast<float4*>(pr + d0) = acc;
-    if (lane == 0) { pr[64] = (l_run > 0.f) ? m_run : 0.f; pr[65] = l_run; }
+    if (grp == 0) *reinterpret_cast<float4*>(&pw[wave][sub * 4]) = acc;
+    if (lane == 0) { pw[wave][64] = (l_run > 0.f) ? m_run : 0.f; pw[wave][65] = l_run; }
+    __syncthreads();
+    if (tid < 16) {                                  // merge the 4 waves (fixed order), normalise
+        float M = NEG;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) if (pw[ww][65] > 0.f) M = fmaxf(M, pw[ww][64]);
+        float den = 0.f; float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const float wgt = (pw[ww][65] > 0.f) ? expf(pw[ww][64] - M) : 0.f;
+            const float4 t = *reinterpret_cast<const float4*>(&pw[ww][tid * 4]);
+            den += wgt * pw[ww][65];
+            a.x += wgt * t.x; a.y += wgt * t.y; a.z += wgt * t.z; a.w += wgt * t.w;
+        }
+        const float inv = 1.f / den;
+        *reinterpret_cast<float4*>(p.out + (long long)b * p.ldo + h * 64 + tid * 4) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+    }
+}
+
+// advance the KV length of every slot after a backbone step
+static __global__ void advance_pos_batch_kernel(DecodeState* st, int nb) {
+    const int b = threadIdx.x;
+    if (b < nb && !st[b].done) st[b].pos += 1;
 }
 
 }  // namespace cv

@@ -138,8 +138,8 @@ void run_block(int nthreads) {
 struct Node { dim3 grid, block; std::function<void()> body; int kind; void* dst; const void* src; size_t n; int val; };
 }  // namespace
 
-struct emuStream_ { bool capturing = false; std::vector<Node>* cap = nullptr; };
-struct emuEvent_ { std::chrono::steady_clock::time_point t; };
+struct emuStream_ { bool capturing = false; std::vector<Node>* cap = nullptr; emuStream_* origin = nullptr; std::vector<emuStream_*> joined; };
+struct emuEvent_ { std::chrono::steady_clock::time_point t; emuStream_* cap_src = nullptr; };
 struct emuGraph_ { std::vector<Node> nodes; };
 struct emuGraphExec_ { std::vector<Node> nodes; };
 static emuStream_ g_null_stream;
@@ -323,7 +323,20 @@ hipError_t hipStreamCreate(hipStream_t* s) { *s = new emuStream_(); return hipSu
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = new emuEvent_(); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+    e->t = std::chrono::steady_clock::now();
+    e->cap_src = S(s)->capturing ? (S(s)->origin ? S(s)->origin : S(s)) : nullptr;      // recorded inside a capture: a dependency marker
+    return hipSuccess;
+}
+// cross-stream capture (fork / join through events): a stream that waits on an event recorded in a capturing stream joins that capture -
+// its launches are appended to the same node list (the emulator executes a graph in capture order, which respects every dependency)
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
+    emuStream_* st = S(s);
+    if (e->cap_src && e->cap_src->capturing && !st->capturing) {
+        st->capturing = true; st->cap = e->cap_src->cap; st->origin = e->cap_src; e->cap_src->joined.push_back(st);
+    }
+    return hipSuccess;
+}
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess;
@@ -332,6 +345,8 @@ hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) {
     S(s)->capturing = true; S(s)->cap = new std::vector<Node>(); return hipSuccess;
 }
 hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g) {
+    for (emuStream_* j : S(s)->joined) { j->capturing = false; j->cap = nullptr; j->origin = nullptr; }
+    S(s)->joined.clear();
     *g = new emuGraph_(); (*g)->nodes = std::move(*S(s)->cap); delete S(s)->cap; S(s)->cap = nullptr; S(s)->capturing = false; return hipSuccess;
 }
 hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t) { *e = new emuGraphExec_(); (*e)->nodes = g->nodes; return hipSuccess; }

@@ -84,11 +84,16 @@ hipError_t hipGetLastError();
 hipError_t hipPeekAtLastError();
 const char* hipGetErrorString(hipError_t e);
 hipError_t hipStreamCreate(hipStream_t* s);
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+constexpr unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2;
+hipError_t hipEventCreate(hipEvent_t* e);
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipEventCreate(hipEvent_t* e);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags = 0);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode m);
 hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g);

@@ -1,5 +1,5 @@
-"""Lock-step batched decode (llm_batch_kernels.h): a sequence decoded in a batch must yield exactly the tokens it yields alone - and
-exactly the oracle's.  Runs under the CPU emulator (guard-page memory) and on the MI355X."""
+"""Lock-step batched decode (llm_batch_kernels.h, skinny GEMMs on the exact-fp32 MFMA): a sequence decoded in a batch must yield exactly
+the tokens it yields alone - and exactly the oracle's - whatever its slot and whatever the other slots hold.  Runs under the CPU emulator (guard-page memory) and on the MI355X."""
 import pytest
 import torch
 
@@ -49,7 +49,7 @@ def test_batch_of_eight_and_long_context(lib):
     for r, g in zip(reqs, got):
         assert g == OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=3, min_token_text_ratio=2)
     with pytest.raises(AssertionError):
-        lm.inference_batch(reqs + reqs[:1])
+        lm.inference_batch(reqs + reqs + reqs[:1])                    # 17 > MAX_NB
 
 
 def test_continuous_batching(lib):
