@@ -95,7 +95,7 @@ class _CFM:
 
 
 class CausalMaskedDiffWithXvec:
-    def __init__(self, state_dict, cfg, lib=None, weight_dtype=torch.bfloat16, n_timesteps=None, precision="fp32"):
+    def __init__(self, state_dict, cfg, lib=None, weight_dtype=torch.bfloat16, n_timesteps=None, precision="fp32", _tensors=None):
         """precision: "fp32" = W16A32, every product on the exact-fp32 MFMA; "bf16" = the Linear / Conv1d operands are rounded to
         bf16 when staged into LDS and multiplied on the bf16 MFMA with fp32 accumulation (the reference's fp16 / TensorRT flow,
         cli/model.py:83-92, is the analogous mode; BASELINE.json configs[1] is quoted in bf16).  Attention, norms, the Euler update
@@ -112,7 +112,8 @@ class CausalMaskedDiffWithXvec:
         self.vocab_size = cfg.vocab
         self.n_timesteps = n_timesteps or cfg.n_timesteps
         pack = Wt.pack_flow_dit if cfg.estimator == "dit" else Wt.pack_flow
-        self._tensors = {k: self.lib.hook(v) for k, v in pack(state_dict, cfg, self.device, weight_dtype).items()}
+        # `_tensors`: the packed device weights of another instance (clone()): a new library handle = own workspaces / graphs, same weights
+        self._tensors = _tensors if _tensors is not None else {k: self.lib.hook(v) for k, v in pack(state_dict, cfg, self.device, weight_dtype).items()}
         c = FlowConfigC(cfg.vocab, cfg.dim, cfg.enc_heads, cfg.ffn, cfg.enc_blocks, cfg.up_blocks, cfg.spk_dim, cfg.mel, cfg.est_ch,
                         cfg.est_heads, cfg.est_blocks, cfg.est_mid, cfg.pre_lookahead, cfg.chunk, cfg.cfg_rate, 1 if cfg.estimator == "dit" else 0)
         self._h = C.c_void_p()
@@ -124,6 +125,11 @@ class CausalMaskedDiffWithXvec:
         self.encoder = _Encoder(self)
         # channel-last copy of the fixed CFM noise, made once (not on the hot path)
         self._noise_cl = self.lib.hook(self.decoder.rand_noise[0].t().contiguous().to(self.device))
+
+    def clone(self):
+        """A second instance over the SAME device weights with its own library handle (workspaces, Euler graphs): one per token2wav lane
+        of CosyVoice2Model, so that flow inferences of different requests run concurrently on different HIP streams."""
+        return type(self)(None, self.cfg, lib=self.lib, n_timesteps=self.n_timesteps, precision=self.precision, _tensors=self._tensors)
 
     def __del__(self):
         try:

@@ -40,17 +40,18 @@ class _F0Predictor:
 
 
 class HiFTGenerator:
-    def __init__(self, state_dict, cfg, lib=None, seed=1986):
+    def __init__(self, state_dict, cfg, lib=None, seed=1986, _tensors=None):
         self.lib = lib or get_lib()
         self.cfg = cfg
         self.device = torch.device(self.lib.device)
         self.sampling_rate = cfg.sr
         self.seed = seed
         self._calls = 0
+        self._next_seed = None                 # set by CosyVoice2Model.token2wav: RNG key of the next inference() call (see inference)
         self.upsample_scale = cfg.hop
         for u in cfg.ups:
             self.upsample_scale *= u
-        self._tensors = {k: self.lib.hook(v) for k, v in Wt.pack_hift(state_dict, cfg, self.device).items()}
+        self._tensors = _tensors if _tensors is not None else {k: self.lib.hook(v) for k, v in Wt.pack_hift(state_dict, cfg, self.device).items()}
         c = HiftConfigC(cfg.mel, cfg.base, cfg.harmonics, cfg.sr, len(cfg.ups), _arr4(cfg.ups), _arr4(cfg.up_k), len(cfg.res_k), _arr4(cfg.res_k),
                         _arr4(cfg.src_k), len(cfg.res_d), _arr4(cfg.res_d), cfg.n_fft, cfg.hop, cfg.f0_ch, cfg.nsf_alpha, cfg.nsf_sigma,
                         cfg.voiced_thr, cfg.lrelu, cfg.audio_limit, int(cfg.causal), cfg.look_right)
@@ -59,6 +60,10 @@ class HiFTGenerator:
         register_tensors(self.lib, "cv_hift_set_tensor", self._h, self._tensors)
         self.lib.cv_hift_finalize(self._h)
         self.f0_predictor = _F0Predictor(self)
+
+    def clone(self):
+        """Same device weights, own library handle (workspaces): one per token2wav lane of CosyVoice2Model."""
+        return type(self)(None, self.cfg, lib=self.lib, seed=self.seed, _tensors=self._tensors)
 
     def __del__(self):
         try:
@@ -80,9 +85,11 @@ class HiFTGenerator:
         return out
 
     @torch.inference_mode()
-    def inference(self, speech_feat, cache_source=None, noise=None):
+    def inference(self, speech_feat, cache_source=None, noise=None, seed=None):
         """-> (generated_speech[1,480m], source[1,1,480m]).  `noise` ([480m,9] N(0,1)) is a parity hook; by default the SineGen2
-        noise comes from an in-kernel counter RNG (the reference consumes the global device RNG, generator.py:312)."""
+        noise comes from an in-kernel counter RNG (the reference consumes the global device RNG, generator.py:312).  `seed`: the counter
+        RNG's key for this call (CosyVoice2Model.token2wav derives it from the request's tokens, so a request's audio does not depend on
+        the lane / rank / order it was served in); default: model seed + call count."""
         m = speech_feat.shape[2]
         L = m * self.upsample_scale
         x = self.lib.hook(speech_feat.to(self.device, torch.float32).contiguous())
@@ -93,9 +100,11 @@ class HiFTGenerator:
             cs = self.lib.hook(cache_source.to(self.device, torch.float32).contiguous())
             cl = cs.shape[2]
         nz = None if noise is None else self.lib.hook(noise.to(self.device, torch.float32).reshape(L, -1).contiguous())
+        if seed is None:
+            seed, self._next_seed = self._next_seed, None
         self._calls += 1
         self.lib.cv_hift_inference(self._h, C.c_void_p(x.data_ptr()), C.c_int32(m), C.c_void_p(cs.data_ptr()) if cs is not None else None, C.c_int32(cl),
-                                   C.c_void_p(nz.data_ptr()) if nz is not None else None, C.c_uint64(self.seed + self._calls),
+                                   C.c_void_p(nz.data_ptr()) if nz is not None else None, C.c_uint64((self.seed + self._calls) if seed is None else int(seed)),
                                    C.c_void_p(speech.data_ptr()), C.c_void_p(source.data_ptr()), stream_ptr(self.lib))
         return speech, source
 

@@ -7,10 +7,12 @@ Differences that are deliberate:
   * C.12 `fade_in_out` stays on the device (cv_fade_in_out) and there is no per-request `empty_cache()`.
 """
 import ctypes as C
+import queue
 import threading
+import zlib
 from types import GeneratorType
 import uuid as uuid_mod
-from contextlib import nullcontext
+from contextlib import contextmanager, nullcontext
 
 import numpy as np
 import torch
@@ -19,6 +21,15 @@ from ._lib import get_lib, stream_ptr
 from .flow import CausalMaskedDiffWithDiT, CausalMaskedDiffWithXvec
 from .hift import CausalHiFTGenerator, HiFTGenerator
 from .llm import CosyVoice3LM, Qwen2LM
+
+
+class _Lane:
+    """One token2wav lane: a flow + HiFT instance (own library handles = own workspaces and graphs, weights shared with lane 0) and the HIP
+    stream its kernels go to (None = the caller's current stream, the single-lane default)."""
+    __slots__ = ("flow", "hift", "stream")
+
+    def __init__(self, flow, hift, stream):
+        self.flow, self.hift, self.stream = flow, hift, stream
 
 
 class CosyVoice2Model:
@@ -38,14 +49,56 @@ class CosyVoice2Model:
         self.speech_window = np.hamming(2 * self.source_cache_len)
         self._window_dev = self.lib.hook(torch.from_numpy(self.speech_window.astype(np.float32)).to(self.device))
         use_cuda = self.device.type == "cuda"
-        self.llm_stream = torch.cuda.Stream(self.device) if use_cuda else None
+        # high priority: with several token2wav lanes the LM decode chain (one short kernel after another) must not queue behind the
+        # flow / vocoder kernels of other requests - it sets every request's token rate and first-chunk latency
+        self.llm_stream = torch.cuda.Stream(self.device, priority=-1) if use_cuda else None
         self.llm_context = torch.cuda.stream(self.llm_stream) if use_cuda else nullcontext()
         self.lock = threading.Lock()
-        self.t2w_lock = threading.Lock()       # flow / hift handles own their workspaces: one token2wav at a time per model
+        # token2wav lanes: flow / hift handles own their workspaces, so a lane serves one token2wav at a time; `set_lanes(n)` adds lanes
+        # (cloned handles over the same weights, one HIP stream each) and concurrent token2wav calls then overlap on the GPU - the flow and
+        # the vocoder are chains of small latency-bound kernels that leave most of the 256 CUs idle
+        self.n_lanes, self._lane_q = 0, queue.Queue()
+        self.set_lanes(1)
         self.tts_speech_token_dict, self.llm_end_dict, self.hift_cache_dict, self._cond = {}, {}, {}, {}
         self._llm_error = {}                   # uuid -> exception raised on the LLM thread, re-raised by tts() on the caller's thread
         self.silent_tokens = []
         self._warmup()
+
+    def set_lanes(self, n):
+        """n >= 1 token2wav lanes.  Call while no request is in flight."""
+        assert n >= 1
+        while not self._lane_q.empty():
+            self._lane_q.get_nowait()
+        use_cuda = self.device.type == "cuda"
+        for i in range(n):
+            own = i == 0 or self.flow is None
+            flow = self.flow if own else self.flow.clone()
+            hift = self.hift if own else self.hift.clone()
+            self._lane_q.put(_Lane(flow, hift, torch.cuda.Stream(self.device) if (use_cuda and n > 1) else None))
+            if self.flow is None:
+                break
+        self.n_lanes = n
+
+    @contextmanager
+    def _lane(self):
+        """Check a lane out for one token2wav (blocks while all are busy); with several lanes the work runs on the lane's stream and is
+        complete when the context exits (per-uuid cache tensors are then safe to read from any other lane)."""
+        lane = self._lane_q.get()
+        try:
+            if lane.stream is None:
+                yield lane
+            else:
+                with torch.cuda.stream(lane.stream):
+                    yield lane
+                    lane.stream.synchronize()
+        finally:
+            self._lane_q.put(lane)
+
+    @staticmethod
+    def _noise_key(token, token_offset):
+        """Key of the vocoder's counter RNG for one token2wav call, derived from the request's own tokens: the audio of a request does not
+        depend on the lane, rank or order it is served in (SURVEY.md section 8e determinism requirement)."""
+        return (zlib.crc32(token.to(torch.int32).cpu().contiguous().numpy().tobytes()) << 8) + int(token_offset)
 
     def _warmup(self):
         if self.llm is not None:
@@ -72,6 +125,7 @@ class CosyVoice2Model:
         self.llm = Qwen2LM(llm_sd, lc, lib=self.lib, **llm_kw)
         self.flow = CausalMaskedDiffWithXvec(flow_sd, fc, lib=self.lib, precision="bf16" if self.fp16 else "fp32")
         self.hift = HiFTGenerator(hift_sd, hc, lib=self.lib)
+        self.set_lanes(max(1, self.n_lanes))
         self._warmup()
 
     # the reference's accelerator hooks are meaningless here: the MI355X kernels ARE the accelerated path
@@ -134,19 +188,21 @@ class CosyVoice2Model:
     @torch.inference_mode()
     def token2wav(self, token, prompt_token, prompt_feat, embedding, token_offset, uuid, stream=False, finalize=False, speed=1.0):
         """cli/model.py:292-326."""
-        with self.t2w_lock:
+        with self._lane() as lane:
+            flow, hift = lane.flow, lane.hift
             t = lambda n: torch.tensor([n], dtype=torch.int32)
-            tts_mel, _ = self.flow.inference(token=token.to(torch.int32), token_len=t(token.shape[1]), prompt_token=prompt_token, prompt_token_len=t(prompt_token.shape[1]),
-                                             prompt_feat=prompt_feat, prompt_feat_len=t(prompt_feat.shape[1]), embedding=embedding, streaming=stream, finalize=finalize)
-            tts_mel = tts_mel[:, :, token_offset * self.flow.token_mel_ratio:]
+            tts_mel, _ = flow.inference(token=token.to(torch.int32), token_len=t(token.shape[1]), prompt_token=prompt_token, prompt_token_len=t(prompt_token.shape[1]),
+                                        prompt_feat=prompt_feat, prompt_feat_len=t(prompt_feat.shape[1]), embedding=embedding, streaming=stream, finalize=finalize)
+            tts_mel = tts_mel[:, :, token_offset * flow.token_mel_ratio:]
             cache = self.hift_cache_dict.get(uuid)
             if cache is not None:
                 tts_mel = torch.concat([cache["mel"], tts_mel], dim=2)
                 hift_cache_source = cache["source"]
             else:
                 hift_cache_source = torch.zeros(1, 1, 0)
+            hift._next_seed = self._noise_key(token, token_offset)
             if finalize is False:
-                tts_speech, tts_source = self.hift.inference(speech_feat=tts_mel, cache_source=hift_cache_source)
+                tts_speech, tts_source = hift.inference(speech_feat=tts_mel, cache_source=hift_cache_source)
                 if cache is not None:
                     tts_speech = self._fade(tts_speech, cache["speech"])
                 self.hift_cache_dict[uuid] = {"mel": tts_mel[:, :, -self.mel_cache_len:].clone(), "source": tts_source[:, :, -self.source_cache_len:].clone(),
@@ -160,30 +216,58 @@ class CosyVoice2Model:
                     dst = torch.empty(1, src.shape[1], tn, dtype=torch.float32, device=self.device)
                     self.lib.cv_interp_linear(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_int32(src.shape[1]), C.c_int32(src.shape[2]), C.c_int32(tn), stream_ptr(self.lib))
                     tts_mel = dst
-                tts_speech, tts_source = self.hift.inference(speech_feat=tts_mel, cache_source=hift_cache_source)
+                tts_speech, tts_source = hift.inference(speech_feat=tts_mel, cache_source=hift_cache_source)
                 if cache is not None:
                     tts_speech = self._fade(tts_speech, cache["speech"])
             return tts_speech
 
+    def _vocode_all(self, jobs, speed):
+        """jobs: iterable of (index, request, tokens) -> yields (index, {'tts_speech'}) as they complete; one worker thread per lane."""
+        def one(job):
+            i, r, toks = job
+            uid = str(uuid_mod.uuid1())
+            self.hift_cache_dict[uid] = None
+            try:
+                wav = self.token2wav(token=torch.tensor(toks).unsqueeze(0), prompt_token=r["flow_prompt_speech_token"], prompt_feat=r["prompt_speech_feat"],
+                                     embedding=r["flow_embedding"], token_offset=0, uuid=uid, finalize=True, speed=speed)
+                return i, {"tts_speech": wav.cpu()}
+            finally:
+                self.hift_cache_dict.pop(uid, None)
+        if self.n_lanes == 1:
+            for job in jobs:
+                yield one(job)
+            return
+        from concurrent.futures import ThreadPoolExecutor, FIRST_COMPLETED, wait
+        with ThreadPoolExecutor(max_workers=self.n_lanes) as ex:
+            pending = set()
+            for job in jobs:                                    # `jobs` may block (tts_queue: tokens arrive from the LM thread)
+                pending.add(ex.submit(one, job))
+                while len(pending) >= 2 * self.n_lanes:
+                    done, pending = wait(pending, return_when=FIRST_COMPLETED)
+                    for f in done:
+                        yield f.result()
+                done = {f for f in pending if f.done()}
+                pending -= done
+                for f in done:
+                    yield f.result()
+            while pending:
+                done, pending = wait(pending, return_when=FIRST_COMPLETED)
+                for f in done:
+                    yield f.result()
+
     def tts_batch(self, requests, speed=1.0):
-        """Offline synthesis of up to 8 requests (dicts with the keyword arguments of tts()): the speech-token LM runs lock-step
-        batched (Qwen2LM.inference_batch: weights streamed once per step for all requests), flow + HiFT then run per utterance.
+        """Offline synthesis of up to 16 requests (dicts with the keyword arguments of tts()): the speech-token LM runs lock-step
+        batched (Qwen2LM.inference_batch: weights streamed once per step for all requests), flow + HiFT then run per utterance, `n_lanes`
+        utterances at a time (set_lanes).
         Returns one {'tts_speech': [1, S]} per request, equal to what tts(**request, stream=False) yields for it."""
         reqs = [dict(text=r["text"], prompt_text=r["prompt_text"], prompt_speech_token=r["llm_prompt_speech_token"]) for r in requests]
         with self.llm_context:
             tokens = self.llm.inference_batch(reqs)
         if self.device.type == "cuda":
             self.llm_stream.synchronize()
-        outs = []
-        for r, toks in zip(requests, tokens):
-            uid = str(uuid_mod.uuid1())
-            self.hift_cache_dict[uid] = None
-            try:
-                wav = self.token2wav(token=torch.tensor(toks).unsqueeze(0), prompt_token=r["flow_prompt_speech_token"], prompt_feat=r["prompt_speech_feat"],
-                                     embedding=r["flow_embedding"], token_offset=0, uuid=uid, finalize=True, speed=speed)
-                outs.append({"tts_speech": wav.cpu()})
-            finally:
-                self.hift_cache_dict.pop(uid, None)
+        outs = [None] * len(requests)
+        for i, o in self._vocode_all(((i, r, toks) for i, (r, toks) in enumerate(zip(requests, tokens))), speed):
+            outs[i] = o
         return outs
 
     def tts_queue(self, requests, slots=8, speed=1.0):
@@ -207,22 +291,19 @@ class CosyVoice2Model:
 
         th = threading.Thread(target=produce, daemon=True)
         th.start()
-        try:
+
+        def finished():
             while True:
                 item = q.get()
                 if item is None:
-                    break
+                    return
                 if isinstance(item, BaseException):
                     raise item
                 i, toks = item
-                r, uid = requests[i], str(uuid_mod.uuid1())
-                self.hift_cache_dict[uid] = None
-                try:
-                    wav = self.token2wav(token=torch.tensor(toks).unsqueeze(0), prompt_token=r["flow_prompt_speech_token"], prompt_feat=r["prompt_speech_feat"],
-                                         embedding=r["flow_embedding"], token_offset=0, uuid=uid, finalize=True, speed=speed)
-                    yield i, {"tts_speech": wav.cpu()}
-                finally:
-                    self.hift_cache_dict.pop(uid, None)
+                yield i, requests[i], toks
+
+        try:
+            yield from self._vocode_all(finished(), speed)
         finally:
             th.join()
 
@@ -319,16 +400,18 @@ class CosyVoice3Model(CosyVoice2Model):
         self.llm = CosyVoice3LM(llm_sd, lc, lib=self.lib, **llm_kw)
         self.flow = CausalMaskedDiffWithDiT(flow_sd, fc, lib=self.lib, precision="bf16" if self.fp16 else "fp32")
         self.hift = CausalHiFTGenerator(hift_sd, hc, lib=self.lib)
+        self.set_lanes(max(1, self.n_lanes))
         self._warmup()
 
     @torch.inference_mode()
     def token2wav(self, token, prompt_token, prompt_feat, embedding, token_offset, uuid, stream=False, finalize=False, speed=1.0):
         """cli/model.py:425-450."""
-        with self.t2w_lock:
+        with self._lane() as lane:
+            flow, hift = lane.flow, lane.hift
             t = lambda n: torch.tensor([n], dtype=torch.int32)
-            tts_mel, _ = self.flow.inference(token=token.to(torch.int32), token_len=t(token.shape[1]), prompt_token=prompt_token, prompt_token_len=t(prompt_token.shape[1]),
-                                             prompt_feat=prompt_feat, prompt_feat_len=t(prompt_feat.shape[1]), embedding=embedding, streaming=stream, finalize=finalize)
-            tts_mel = tts_mel[:, :, token_offset * self.flow.token_mel_ratio:]
+            tts_mel, _ = flow.inference(token=token.to(torch.int32), token_len=t(token.shape[1]), prompt_token=prompt_token, prompt_token_len=t(prompt_token.shape[1]),
+                                        prompt_feat=prompt_feat, prompt_feat_len=t(prompt_feat.shape[1]), embedding=embedding, streaming=stream, finalize=finalize)
+            tts_mel = tts_mel[:, :, token_offset * flow.token_mel_ratio:]
             cache = self.hift_cache_dict.get(uuid)
             if cache is not None:
                 tts_mel = torch.concat([cache["mel"], tts_mel], dim=2)
@@ -342,7 +425,7 @@ class CosyVoice3Model(CosyVoice2Model):
                 dst = torch.empty(1, src.shape[1], tn, dtype=torch.float32, device=self.device)
                 self.lib.cv_interp_linear(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_int32(src.shape[1]), C.c_int32(src.shape[2]), C.c_int32(tn), stream_ptr(self.lib))
                 tts_mel = dst
-            tts_speech, _ = self.hift.inference(speech_feat=tts_mel, finalize=finalize)
+            tts_speech, _ = hift.inference(speech_feat=tts_mel, finalize=finalize)
             tts_speech = tts_speech[:, cache["speech_offset"]:]
             cache["speech_offset"] += tts_speech.shape[1]
             return tts_speech

@@ -22,14 +22,14 @@ import torch
 
 
 class _Request:
-    __slots__ = ("key", "req", "tokens", "llm_done", "error", "out", "token_offset", "hop", "chunk_index", "t_submit", "t_first", "stream", "pad", "closed")
+    __slots__ = ("key", "req", "tokens", "llm_done", "error", "out", "token_offset", "hop", "chunk_index", "t_submit", "t_first", "stream", "pad", "closed", "busy")
 
     def __init__(self, key, req, stream, hop, pad):
         self.key, self.req, self.stream = key, req, stream
         self.tokens, self.llm_done, self.error = [], False, None
         self.out = queue.Queue()
         self.token_offset, self.hop, self.chunk_index, self.pad = 0, hop, 0, pad
-        self.t_submit, self.t_first, self.closed = time.perf_counter(), None, False
+        self.t_submit, self.t_first, self.closed, self.busy = time.perf_counter(), None, False, False
 
 
 class StreamScheduler:
@@ -41,8 +41,14 @@ class StreamScheduler:
         self._reqs = {}
         self._stop = False
         self._llm_thread = threading.Thread(target=self._llm_loop, daemon=True)
-        self._voc_thread = threading.Thread(target=self._vocoder_loop, daemon=True)
-        self._llm_thread.start(); self._voc_thread.start()
+        # one vocoder thread per token2wav lane of the model (CosyVoice2Model.set_lanes): chunks of DIFFERENT requests are vocoded concurrently
+        # on different HIP streams, the chunks of one request stay sequential (`busy`).  With >= 3 lanes the first thread takes FIRST chunks only:
+        # they are short (T = 2 * (prompt + 38 tokens)) and are what a listener waits for, so they never queue behind a 40 ms late-chunk flow.
+        n_voc = max(1, getattr(model, "n_lanes", 1))
+        self._voc_threads = [threading.Thread(target=self._vocoder_loop, args=(n_voc >= 3 and i == 0,), daemon=True) for i in range(n_voc)]
+        self._llm_thread.start()
+        for t in self._voc_threads:
+            t.start()
 
     # ---- client side ---------------------------------------------------------------------------------------------------------
     def submit(self, stream=True, **req):
@@ -84,7 +90,9 @@ class StreamScheduler:
             self._stop = True
             self._cv.notify_all()
         self._src.put(None)
-        self._llm_thread.join(); self._voc_thread.join()
+        self._llm_thread.join()
+        for t in self._voc_threads:
+            t.join()
 
     # ---- LLM thread: continuous batching, tokens streamed per decode chunk ------------------------------------------------------------
     def _on_tokens(self, key, toks, finished, error):
@@ -122,7 +130,7 @@ class StreamScheduler:
             return "final"
         return None
 
-    def _vocoder_loop(self):
+    def _vocoder_loop(self, first_only=False):
         m = self.model
         la = m.flow.pre_lookahead_len
         while True:
@@ -132,7 +140,7 @@ class StreamScheduler:
                     # for (first-chunk latency), while its later chunks only have to arrive before the audio already delivered runs out.
                     pick, best = None, None
                     for r in self._reqs.values():
-                        what = self._ready(r)
+                        what = None if (r.busy or (first_only and r.chunk_index > 0)) else self._ready(r)
                         if what is not None and (best is None or r.chunk_index < best):
                             pick, best = (r, what, list(r.tokens)), r.chunk_index
                             if best == 0:
@@ -142,6 +150,7 @@ class StreamScheduler:
                     self._cv.wait(timeout=0.5)
                 if pick is None:
                     return
+                pick[0].busy = True
             r, what, toks = pick
             rq = r.req
             finished = True
@@ -179,9 +188,12 @@ class StreamScheduler:
                     r.out.put(None)
             except BaseException as e:
                 r.out.put(e)
-            if finished:                                    # done or failed: drop the per-request state (cli/model.py:388-391)
-                with self._cv:
+            with self._cv:
+                r.busy = False
+                if finished:                                # done or failed: drop the per-request state (cli/model.py:388-391)
                     self._reqs.pop(r.key, None)
+                self._cv.notify_all()
+            if finished:
                 with m.lock:
                     m.hift_cache_dict.pop(r.key, None)
 

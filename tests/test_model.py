@@ -121,6 +121,30 @@ def test_two_concurrent_streaming_requests(lib, setup):
     assert not m.tts_speech_token_dict and not m.hift_cache_dict
 
 
+def test_token2wav_lanes(lib, setup):
+    """set_lanes(n): token2wav calls of different requests run concurrently on cloned flow / HiFT handles (same weights, own workspaces,
+    one HIP stream each).  Every waveform - harmonic-source noise included (its RNG key comes from the request's tokens) - must equal the
+    single-lane result bit for bit, whatever lane served it and in whatever order."""
+    cfgs, sds, u = setup
+    lc, fc, hc = cfgs
+    fc1 = dataclasses.replace(fc, n_timesteps=1)
+    m = CosyVoice2Model.from_state_dicts(sds[0], sds[1], sds[2], (lc, fc1, hc), lib=lib, max_len=160, sampling="greedy")
+    inf_b = m.llm.inference_batch
+    m.llm.inference_batch = lambda reqs: inf_b(reqs, max_token_text_ratio=4, min_token_text_ratio=2)
+    us = [W.synthetic_utterance(lc, fc, n_prompt_tok=5 + i, n_prompt_text=2, n_text=1 + i % 2, seed=60 + i) for i in range(3)]
+    keys = ("text", "flow_embedding", "llm_embedding", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat")
+    reqs = [{k: x[k] for k in keys} for x in us]
+    one = m.tts_batch(reqs)
+    m.set_lanes(2)
+    assert m.n_lanes == 2 and m._lane_q.qsize() == 2
+    two = m.tts_batch(reqs)
+    rev = m.tts_batch(reqs[::-1])[::-1]
+    for a, b, c in zip(one, two, rev):
+        assert a["tts_speech"].abs().max() > 0
+        assert torch.equal(a["tts_speech"], b["tts_speech"]) and torch.equal(a["tts_speech"], c["tts_speech"])
+    assert not m.hift_cache_dict and m._lane_q.qsize() == 2
+
+
 def test_llm_job_silent_token_filter(lib, setup):
     """cli/model.py:101-129: tokens listed in `silent_tokens` (CosyVoice3: FSQ silence / breath ids, :423) are kept for the first
     5 consecutive occurrences and dropped beyond that; any other token resets the run.  Host logic, driven with a stub generator."""
