@@ -73,6 +73,45 @@ class HiftConfig:                     # Appendix A.4 (cosyvoice2.yaml:89-111)
     look_right: int = 4
 
 
+@dataclass
+class CV1Config:                      # CosyVoice-300M (examples/libritts/cosyvoice/conf/cosyvoice.yaml), SURVEY.md section 8 row a18
+    text_vocab: int = 51866
+    speech_token_size: int = 4096
+    text_enc_in: int = 512            # text_encoder_input_size
+    llm_dim: int = 1024               # text encoder output = llm_input_size = llm_output_size
+    text_heads: int = 16
+    text_ffn: int = 4096
+    text_blocks: int = 6
+    llm_heads: int = 16
+    llm_ffn: int = 4096
+    llm_blocks: int = 14
+    spk_dim: int = 192
+    flow_dim: int = 512               # MaskedDiffWithXvec input_size = encoder output
+    flow_heads: int = 8
+    flow_ffn: int = 2048
+    flow_blocks: int = 6
+    mel: int = 80
+    regulator_layers: int = 4         # InterpolateRegulator sampling_ratios [1, 1, 1, 1]
+    est_ch: List[int] = field(default_factory=lambda: [256, 256])
+    est_heads: int = 8
+    est_head_dim: int = 64
+    est_blocks: int = 4
+    est_mid: int = 12
+    input_frame_rate: int = 50
+
+
+def cv1():
+    """CosyVoice-300M: (CV1Config, HiftConfig of the 22.05 kHz HiFTGenerator, cosyvoice.yaml:113-140)."""
+    return CV1Config(), HiftConfig(sr=22050, ups=[8, 8], up_k=[16, 16], src_k=[7, 11])
+
+
+def tiny_cv1():
+    return (CV1Config(text_vocab=50, speech_token_size=40, text_enc_in=32, llm_dim=64, text_heads=4, text_ffn=128, text_blocks=2, llm_heads=4, llm_ffn=128,
+                      llm_blocks=3, spk_dim=16, flow_dim=64, flow_heads=4, flow_ffn=128, flow_blocks=2, est_ch=[32, 32], est_heads=2, est_head_dim=16,
+                      est_blocks=1, est_mid=2),
+            HiftConfig(sr=22050, ups=[8, 8], up_k=[16, 16], src_k=[7, 11], base=32, f0_ch=32))
+
+
 def cv2():
     return LLMConfig(), FlowConfig(), HiftConfig()
 

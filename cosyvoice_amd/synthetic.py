@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 
-from .configs import FlowConfig, HiftConfig, LLMConfig, cv2, cv3_flow, cv3_llm, tiny, tiny_cv3_flow, tiny_cv3_llm  # noqa: F401
+from .configs import CV1Config, FlowConfig, HiftConfig, LLMConfig, cv1, cv2, cv3_flow, cv3_llm, tiny, tiny_cv1, tiny_cv3_flow, tiny_cv3_llm  # noqa: F401
 
 
 class _Gen:
@@ -285,3 +285,102 @@ def ref_small_flow():
     PreLookaheadLayer / Upsample1D (upsample_encoder.py:203,217), so dim stays 512; everything else is shrunk."""
     return FlowConfig(vocab=60, dim=512, enc_heads=8, ffn=256, enc_blocks=1, up_blocks=1, spk_dim=192, est_ch=64, est_heads=1,
                       est_blocks=1, est_mid=1)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# CosyVoice-300M (cosyvoice_amd/cosyvoice1.py): reference key names of TransformerLM / MaskedDiffWithXvec; the 22.05 kHz HiFTGenerator comes
+# from make_hift(configs.cv1()[1]).  Validated by strict=True loads into the real classes (tests/golden/make_golden_cv1.py).
+# ------------------------------------------------------------------------------------------------------------------------------------
+def _espnet_encoder(g, sd, p, kind, d_in, d, heads, ffn, blocks):
+    """ConformerEncoder (no CNN module, no macaron) / TransformerEncoder with rel_pos_espnet + rel_selfattn (transformer/encoder.py:330-474)."""
+    sd[p + "embed.out.0.weight"], sd[p + "embed.out.0.bias"] = g.linear(d, d_in), g.beta(d)
+    sd[p + "embed.out.1.weight"], sd[p + "embed.out.1.bias"] = g.gamma(d), g.beta(d)
+    n_att, n_ff = ("norm_mha", "norm_ff") if kind == "conformer" else ("norm1", "norm2")
+    for i in range(blocks):
+        q = p + "encoders.%d." % i
+        for n in ("linear_q", "linear_k", "linear_v", "linear_out"):
+            sd[q + "self_attn.%s.weight" % n], sd[q + "self_attn.%s.bias" % n] = g.linear(d, d), g.beta(d)
+        sd[q + "self_attn.linear_pos.weight"] = g.linear(d, d)
+        sd[q + "self_attn.pos_bias_u"], sd[q + "self_attn.pos_bias_v"] = g.normal((heads, d // heads), 0.3), g.normal((heads, d // heads), 0.3)
+        sd[q + "feed_forward.w_1.weight"], sd[q + "feed_forward.w_1.bias"] = g.linear(ffn, d), g.beta(ffn)
+        sd[q + "feed_forward.w_2.weight"], sd[q + "feed_forward.w_2.bias"] = g.linear(d, ffn, gain=0.5), g.beta(d)
+        for n in (n_ff, n_att):
+            sd[q + n + ".weight"], sd[q + n + ".bias"] = g.gamma(d), g.beta(d)
+    sd[p + "after_norm.weight"], sd[p + "after_norm.bias"] = g.gamma(d), g.beta(d)
+
+
+def make_cv1_llm(cfg: CV1Config, seed=2001):
+    """cosyvoice.llm.llm.TransformerLM (llm/llm.py:35-82)."""
+    g, sd = _Gen(seed), {}
+    D = cfg.llm_dim
+    sd["text_embedding.weight"] = g.normal((cfg.text_vocab, cfg.text_enc_in), 1.0)
+    _espnet_encoder(g, sd, "text_encoder.", "conformer", cfg.text_enc_in, D, cfg.text_heads, cfg.text_ffn, cfg.text_blocks)
+    sd["text_encoder_affine_layer.weight"], sd["text_encoder_affine_layer.bias"] = g.linear(D, D), g.beta(D)
+    sd["llm_embedding.weight"] = g.normal((2, D), 1.0)
+    _espnet_encoder(g, sd, "llm.", "transformer", D, D, cfg.llm_heads, cfg.llm_ffn, cfg.llm_blocks)
+    sd["llm_decoder.weight"], sd["llm_decoder.bias"] = g.linear(cfg.speech_token_size + 1, D, gain=6.0), g.normal((cfg.speech_token_size + 1,), 0.1)
+    sd["speech_embedding.weight"] = g.normal((cfg.speech_token_size, D), 1.0)
+    sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"] = g.linear(D, cfg.spk_dim), g.beta(D)
+    return sd
+
+
+def make_cv1_flow(cfg: CV1Config, seed=2002):
+    """cosyvoice.flow.flow.MaskedDiffWithXvec (flow/flow.py:25-61) with InterpolateRegulator, ConditionalCFM and the U-Net ConditionalDecoder
+    (flow/decoder.py:88-205; Matcha ResnetBlock1D / Block1D / Downsample1D / Upsample1D / BasicTransformerBlock keys)."""
+    g, sd = _Gen(seed), {}
+    mel = cfg.mel
+    sd["input_embedding.weight"] = g.normal((cfg.speech_token_size, cfg.flow_dim), 1.0)
+    sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"] = g.linear(mel, cfg.spk_dim), g.beta(mel)
+    _espnet_encoder(g, sd, "encoder.", "conformer", cfg.flow_dim, cfg.flow_dim, cfg.flow_heads, cfg.flow_ffn, cfg.flow_blocks)
+    sd["encoder_proj.weight"], sd["encoder_proj.bias"] = g.linear(mel, cfg.flow_dim), g.beta(mel)
+    r = "length_regulator.model."
+    for i in range(cfg.regulator_layers):
+        sd[r + "%d.weight" % (3 * i)], sd[r + "%d.bias" % (3 * i)] = g.conv(mel, mel, 3), g.beta(mel)
+        sd[r + "%d.weight" % (3 * i + 1)], sd[r + "%d.bias" % (3 * i + 1)] = g.gamma(mel), g.beta(mel)
+    sd[r + "%d.weight" % (3 * cfg.regulator_layers)], sd[r + "%d.bias" % (3 * cfg.regulator_layers)] = g.conv(mel, mel, 1), g.beta(mel)
+    e = "decoder.estimator."
+    temb = cfg.est_ch[0] * 4
+    sd[e + "time_mlp.linear_1.weight"], sd[e + "time_mlp.linear_1.bias"] = g.linear(temb, 4 * mel), g.beta(temb)
+    sd[e + "time_mlp.linear_2.weight"], sd[e + "time_mlp.linear_2.bias"] = g.linear(temb, temb), g.beta(temb)
+    inner = cfg.est_heads * cfg.est_head_dim
+
+    def block1d(p, cin, cout):
+        sd[p + "block.0.weight"], sd[p + "block.0.bias"] = g.conv(cout, cin, 3), g.beta(cout)
+        sd[p + "block.1.weight"], sd[p + "block.1.bias"] = g.gamma(cout), g.beta(cout)
+
+    def stage(p, cin, cout):
+        block1d(p + "0.block1.", cin, cout)
+        block1d(p + "0.block2.", cout, cout)
+        sd[p + "0.mlp.1.weight"], sd[p + "0.mlp.1.bias"] = g.linear(cout, temb), g.beta(cout)
+        sd[p + "0.res_conv.weight"], sd[p + "0.res_conv.bias"] = g.conv(cout, cin, 1), g.beta(cout)
+        for j in range(cfg.est_blocks):
+            t = p + "1.%d." % j
+            sd[t + "norm1.weight"], sd[t + "norm1.bias"] = g.gamma(cout), g.beta(cout)
+            for n in ("to_q", "to_k", "to_v"):
+                sd[t + "attn1.%s.weight" % n] = g.linear(inner, cout)
+            sd[t + "attn1.to_out.0.weight"], sd[t + "attn1.to_out.0.bias"] = g.linear(cout, inner, gain=0.5), g.beta(cout)
+            sd[t + "norm3.weight"], sd[t + "norm3.bias"] = g.gamma(cout), g.beta(cout)
+            sd[t + "ff.net.0.proj.weight"], sd[t + "ff.net.0.proj.bias"] = g.linear(4 * cout, cout), g.beta(4 * cout)
+            sd[t + "ff.net.2.weight"], sd[t + "ff.net.2.bias"] = g.linear(cout, 4 * cout, gain=0.5), g.beta(cout)
+
+    ch, cout = cfg.est_ch, 4 * mel
+    for i, c in enumerate(ch):
+        cin, cout = cout, c
+        stage(e + "down_blocks.%d." % i, cin, cout)
+        if i < len(ch) - 1:                                   # Downsample1D: Conv1d(c, c, 3, stride 2)
+            sd[e + "down_blocks.%d.2.conv.weight" % i], sd[e + "down_blocks.%d.2.conv.bias" % i] = g.conv(c, c, 3), g.beta(c)
+        else:
+            sd[e + "down_blocks.%d.2.weight" % i], sd[e + "down_blocks.%d.2.bias" % i] = g.conv(c, c, 3), g.beta(c)
+    for i in range(cfg.est_mid):
+        stage(e + "mid_blocks.%d." % i, ch[-1], ch[-1])
+    up = ch[::-1] + [ch[0]]
+    for i in range(len(up) - 1):
+        stage(e + "up_blocks.%d." % i, 2 * up[i], up[i + 1])
+        c = up[i + 1]
+        if i < len(up) - 2:                                   # Upsample1D: ConvTranspose1d(c, c, 4, 2, 1), weight [in, out, k]
+            sd[e + "up_blocks.%d.2.conv.weight" % i], sd[e + "up_blocks.%d.2.conv.bias" % i] = g.normal((c, c, 4), 1.0 / np.sqrt(2 * c)), g.beta(c)
+        else:
+            sd[e + "up_blocks.%d.2.weight" % i], sd[e + "up_blocks.%d.2.bias" % i] = g.conv(c, c, 3), g.beta(c)
+    block1d(e + "final_block.", up[-1], up[-1])
+    sd[e + "final_proj.weight"], sd[e + "final_proj.bias"] = g.conv(mel, up[-1], 1), g.beta(mel)
+    return sd
