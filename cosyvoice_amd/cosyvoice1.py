@@ -183,7 +183,9 @@ class TransformerLM:
     def inference(self, text, text_len, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len, embedding,
                   sampling=25, max_token_text_ratio=20, min_token_text_ratio=2, uuid=""):
         sd = self.sd
-        ids = torch.cat([prompt_text, text], dim=1).reshape(-1).long()
+        dev = sd["llm_embedding.weight"].device
+        ids = torch.cat([prompt_text, text], dim=1).reshape(-1).long().to(dev)
+        embedding, prompt_speech_token = embedding.to(dev), prompt_speech_token.to(dev)
         n_text = int(text.shape[1])                          # (text_len + prompt_text_len) - prompt_text_len, llm.py:196-197
         x = self.text_encoder.forward(F.embedding(ids, sd["text_embedding.weight"]))
         x = _linear(_P(sd, "text_encoder_affine_layer."), x)
@@ -198,7 +200,7 @@ class TransformerLM:
         out_tokens, caches = [], None
         for i in range(max_len):
             y, caches = self.llm.forward_chunk(lm_input, caches)
-            logp = _linear(_P(sd, "llm_decoder."), y[-1]).log_softmax(dim=-1)
+            logp = _linear(_P(sd, "llm_decoder."), y[-1]).log_softmax(dim=-1).cpu()    # the sampler draws from the host RNG (same tokens on every device)
             if i < min_len:
                 logp[self.speech_token_size] = -float("inf")
             top = self.sampling(logp, out_tokens, sampling)
@@ -294,8 +296,8 @@ class ConditionalCFM:
 
     @torch.inference_mode()
     def __call__(self, mu, mask, n_timesteps, temperature=1.0, spks=None, cond=None, prompt_len=0, cache=None):
-        z = torch.randn_like(mu) * temperature
-        cache = torch.zeros(1, mu.shape[1], 0, 2) if cache is None else cache
+        z = torch.randn(mu.shape, dtype=mu.dtype).to(mu.device) * temperature     # drawn on the host: the same stream on every device
+        cache = (torch.zeros(1, mu.shape[1], 0, 2) if cache is None else cache).to(mu.device)
         n_cache = cache.shape[2]
         if n_cache != 0:                                      # keep the prompt and the overlap region on their previous trajectory (:53-56)
             z[:, :, :n_cache] = cache[:, :, :, 0]
@@ -350,6 +352,8 @@ class MaskedDiffWithXvec:
     def inference(self, token, token_len, prompt_token, prompt_token_len, prompt_feat, prompt_feat_len, embedding, flow_cache):
         assert token.shape[0] == 1
         sd = self.sd
+        dev = sd["input_embedding.weight"].device
+        token, prompt_token, prompt_feat, embedding = token.to(dev), prompt_token.to(dev), prompt_feat.to(dev), embedding.to(dev)
         spk = _linear(_P(sd, "spk_embed_affine_layer."), F.normalize(embedding.float(), dim=1))
         n1, n2 = int(prompt_token.shape[1]), int(token.shape[1])
         ids = torch.cat([prompt_token.reshape(-1), token.reshape(-1)]).long().clamp(min=0)
@@ -410,9 +414,9 @@ class HiFTGenerator:
         phase[:, 0, :] = 0
         sine = self.sine_amp * torch.sin(theta + phase.to(f0.device))
         uv = (f0 > self.voiced_thr).float()
-        sine = sine * uv + (uv * self.noise_std + (1 - uv) * self.sine_amp / 3) * torch.randn_like(sine)
+        sine = sine * uv + (uv * self.noise_std + (1 - uv) * self.sine_amp / 3) * torch.randn(sine.shape).to(sine.device)
         merged = torch.tanh(_linear(self.p.sub("m_source.l_linear."), sine.transpose(1, 2)))
-        torch.randn_like(uv)                                   # the reference draws (and discards) the noise branch here: keep the RNG in step
+        torch.randn(uv.shape)                                  # the reference draws (and discards) the noise branch here: keep the RNG in step
         return merged
 
     def _resblock(self, p, x, k, dils):
@@ -450,10 +454,11 @@ class HiFTGenerator:
 
     @torch.inference_mode()
     def inference(self, speech_feat, cache_source=torch.zeros(1, 1, 0)):
+        speech_feat = speech_feat.to(self.p("conv_pre.bias").device)
         f0 = self.f0_predictor(speech_feat)
         s = self._source(F.interpolate(f0[:, None], scale_factor=float(self.scale), mode="nearest").transpose(1, 2)).transpose(1, 2)
         if cache_source.shape[2] != 0:
-            s[:, :, :cache_source.shape[2]] = cache_source
+            s[:, :, :cache_source.shape[2]] = cache_source.to(s.device)
         return self.decode(speech_feat, s), s
 
 
@@ -491,9 +496,10 @@ class CosyVoiceModel:
         self._llm_error = {}
         self.silent_tokens = []
 
-    def load(self, llm_model, flow_model, hift_model, **kw):
-        """cli/model.py:65-73: the three state-dict files of a CosyVoice-300M model directory."""
-        ld = lambda f: {k: v.float() for k, v in torch.load(f, map_location="cpu", weights_only=True).items()}
+    def load(self, llm_model, flow_model, hift_model, device="cpu", **kw):
+        """cli/model.py:65-73: the three state-dict files of a CosyVoice-300M model directory.  `device`: where the weights (and the compute)
+        live - "cpu" is BASELINE.json configs[0]; "cuda" runs the same torch ops through PyTorch-ROCm."""
+        ld = lambda f: {k: v.float().to(device) for k, v in torch.load(f, map_location="cpu", weights_only=True).items()}
         self.llm = TransformerLM(ld(llm_model), **{k: kw[k] for k in ("text_heads", "llm_heads") if k in kw})
         self.flow = MaskedDiffWithXvec(ld(flow_model), **{k: kw[k] for k in ("enc_heads", "est_heads", "input_frame_rate") if k in kw})
         self.hift = HiFTGenerator({k.replace("generator.", ""): v for k, v in ld(hift_model).items()}, **kw.get("hift", {}))

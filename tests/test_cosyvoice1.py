@@ -126,3 +126,32 @@ def test_load_takes_reference_state_dict_files(tmp_path):
     torch.manual_seed(1)
     out = next(iter(m.tts(text=g["text"], flow_embedding=g["embedding"], llm_embedding=g["embedding"], stream=False)))["tts_speech"]   # inference_sft-shaped request
     assert out.shape == (1, int(42 / 50 * 22050 / 256) * 256) and torch.isfinite(out).all() and float(out.abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_cosyvoice_300m_on_the_gpu_matches_the_cpu_goldens():
+    """the same CosyVoice-300M plumbing with its weights on cuda:0 (torch ops through PyTorch-ROCm; random draws stay on
+    the host RNG, so the CPU goldens of the real reference apply unchanged)."""
+    dev = "cuda"
+    mv = lambda sd: {k: v.to(dev) for k, v in sd.items()}
+    g = gold("cv1_llm")
+    lm = C1.TransformerLM(mv(W.make_cv1_llm(CFG)), text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling=C1.ras_sampling)
+    torch.manual_seed(7)
+    got = list(lm.inference(text=g["text"], text_len=t(7), prompt_text=g["prompt_text"], prompt_text_len=t(4), prompt_speech_token=g["prompt_speech_token"],
+                            prompt_speech_token_len=t(9), embedding=g["embedding"], max_token_text_ratio=6, min_token_text_ratio=2))
+    assert got == g["tokens_ras"].tolist()
+    g = gold("cv1_model")
+    tokens = g["tokens"].tolist()
+
+    class ScriptedLLM:
+        def inference(self, **kw):
+            yield from tokens
+
+    flow = C1.MaskedDiffWithXvec(mv(W.make_cv1_flow(CFG)), enc_heads=CFG.flow_heads, est_heads=CFG.est_heads, input_frame_rate=CFG.input_frame_rate)
+    hift = C1.HiFTGenerator(mv(W.make_hift(HCFG)), sampling_rate=HCFG.sr, upsample_rates=HCFG.ups, upsample_kernel_sizes=HCFG.up_k, source_resblock_kernel_sizes=HCFG.src_k)
+    m = C1.CosyVoiceModel(ScriptedLLM(), flow, hift)
+    torch.manual_seed(55)
+    chunks = [o["tts_speech"] for o in m.tts(text=torch.zeros(1, 3, dtype=torch.int32), flow_embedding=g["embedding"], llm_embedding=g["embedding"],
+                                            flow_prompt_speech_token=g["prompt_token"], prompt_speech_feat=g["prompt_feat"], stream=True)]
+    assert [c.shape[1] for c in chunks] == g["stream_n"].tolist()
+    torch.testing.assert_close(torch.cat(chunks, 1), g["stream"], rtol=0, atol=1e-2)
