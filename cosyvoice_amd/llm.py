@@ -153,8 +153,11 @@ class Qwen2LM:
 
     @torch.inference_mode()
     def inference(self, text, text_len, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len, embedding=None,
-                  sampling=25, max_token_text_ratio=20, min_token_text_ratio=2, uuid=""):
-        """Generator of Python ints, one per speech token (llm/llm.py:458-502, 535-549)."""
+                  sampling=25, max_token_text_ratio=20, min_token_text_ratio=2, uuid="", first_chunk=None):
+        """Generator of Python ints, one per speech token (llm/llm.py:458-502, 535-549).  `first_chunk` (not in the reference): how many
+        tokens the caller needs before it can do anything (tts(stream=True): hop + prompt pad + look-ahead) - the device loop hands tokens
+        back in chunks of `decode_chunk` steps, and the first hand-back is cut to exactly that count instead of making the first audio
+        chunk wait for a full decode chunk."""
         n_text = int(text.shape[1])
         min_len = int(n_text * min_token_text_ratio)
         max_len = int(n_text * max_token_text_ratio)
@@ -165,7 +168,8 @@ class Qwen2LM:
             sp = self.make_sampling(min_len, max_len)
             emitted = 0
             while emitted < max_len:
-                toks, fin = self.decode(min(self.decode_chunk, max_len - emitted + 1), sp)
+                chunk = self.decode_chunk if (first_chunk is None or emitted > 0) else max(1, min(int(first_chunk), self.decode_chunk))
+                toks, fin = self.decode(min(chunk, max_len - emitted + 1), sp)
                 for t in toks:
                     yield int(t)
                 emitted += len(toks)

@@ -139,7 +139,7 @@ class CosyVoice2Model:
         raise NotImplementedError("vLLM is replaced by the native LLM decode loop (cv_llm_decode)")
 
     # ------------------------------------------------------------------------------------------------ llm_job / vc_job
-    def llm_job(self, text, prompt_text, llm_prompt_speech_token, llm_embedding, uuid):
+    def llm_job(self, text, prompt_text, llm_prompt_speech_token, llm_embedding, uuid, first_chunk=None):
         """cli/model.py:101-129: `text` is a tensor (offline text) or a generator of [1, n] id tensors (streaming text ->
         Qwen2LM.inference_bistream)."""
         cur_silent_token_num, max_silent_token_num = 0, 5
@@ -154,7 +154,7 @@ class CosyVoice2Model:
                 else:
                     gen = self.llm.inference(text=text, text_len=t(text.shape[1]), prompt_text=prompt_text, prompt_text_len=t(prompt_text.shape[1]),
                                              prompt_speech_token=llm_prompt_speech_token, prompt_speech_token_len=t(llm_prompt_speech_token.shape[1]),
-                                             embedding=llm_embedding, uuid=uuid)
+                                             embedding=llm_embedding, uuid=uuid, **({} if first_chunk is None else {"first_chunk": first_chunk}))
                 for i in gen:
                     if i in self.silent_tokens:
                         cur_silent_token_num += 1
@@ -319,7 +319,11 @@ class CosyVoice2Model:
             self._cond[this_uuid] = threading.Condition()
         cond = self._cond[this_uuid]
         if source_speech_token.shape[1] == 0:
-            p = threading.Thread(target=self.llm_job, args=(text, prompt_text, llm_prompt_speech_token, llm_embedding, this_uuid))
+            first_need = None
+            if stream is True and self.flow is not None:       # tokens the first audio chunk waits for (cli/model.py:345-349)
+                hop0 = self.token_hop_len
+                first_need = int(np.ceil(flow_prompt_speech_token.shape[1] / hop0) * hop0 - flow_prompt_speech_token.shape[1]) + hop0 + self.flow.pre_lookahead_len
+            p = threading.Thread(target=self.llm_job, args=(text, prompt_text, llm_prompt_speech_token, llm_embedding, this_uuid, first_need))
         else:
             p = threading.Thread(target=self.vc_job, args=(source_speech_token, this_uuid))
         p.start()
