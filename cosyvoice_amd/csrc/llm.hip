@@ -35,9 +35,6 @@ struct cv_llm {
     int fused_qkv_attn = 0;
     int head_rows = 1;                                // rows per 16-lane group of the head GEMV (1: 411 workgroups, 2: 206)
     int attn_splits = 8;
-    // option "prefetch" (env CV_DECODE_PREFETCH): bit 0 = gate/up, bit 1 = down weights of a layer warmed into L2 by l2_prefetch_kernel on a
-    // forked branch of the decode graph while the layer's qkv / attention / o_proj run (llm_kernels.h)
-    int prefetch = 0; hipStream_t pf_stream = nullptr; hipEvent_t pf_fork = nullptr, pf_join = nullptr; DevBuf pf_sink;
     int only_cat = -1;                  // cv_llm_profile_chain: enqueue only the launches of this category (-1 = all)
     DevBuf pf_x, pf_xn, pf_qkv, pf_attn, pf_gu, pf_act; // prefill activations (grown on demand)
     int pf_rows = 0;
@@ -60,9 +57,6 @@ struct cv_llm {
         if (graph) (void)hipGraphExecDestroy(graph);
         if (bt.graph) (void)hipGraphExecDestroy(bt.graph);
         if (own_stream) (void)hipStreamDestroy(own_stream);
-        if (pf_stream) (void)hipStreamDestroy(pf_stream);
-        if (pf_fork) (void)hipEventDestroy(pf_fork);
-        if (pf_join) (void)hipEventDestroy(pf_join);
         if (host_tokens) (void)hipHostFree(host_tokens);
         if (host_state) (void)hipHostFree(host_state);
         if (host_sp) (void)hipHostFree(host_sp);
@@ -114,8 +108,6 @@ static void llm_finalize(cv_llm* m) {
     m->attn_part.ensure((size_t)c.heads * 16 * ATTN_PART * 4);
     m->newtok.ensure((size_t)(c.heads + 2 * c.kv_heads) * 64 * 4);
     if (const char* e = getenv("CV_DECODE_FUSED_QKV")) m->fused_qkv_attn = e[0] != '0';     // dev knob for A/B runs (also: option "fused_qkv_attn")
-    if (const char* e = getenv("CV_DECODE_PREFETCH")) m->prefetch = atoi(e);
-    m->pf_sink.ensure(64);
     m->act.ensure((size_t)c.inter * 4); m->logits.ensure((size_t)m->V * 4);
     CV_HIP(hipHostMalloc((void**)&m->host_tokens, (size_t)c.max_len * sizeof(int)));
     CV_HIP(hipHostMalloc((void**)&m->host_state, sizeof(DecodeState)));
@@ -135,6 +127,49 @@ static hipStream_t resolve(cv_llm* m, void* s) {
 
 static LinearW lw(const bf16_t* w, const float* b, int N, int K) { LinearW l; l.w = w; l.b = b; l.N = N; l.K = K; l.Kp = round_up32(K); l.bf16 = true; return l; }
 
+// One prompt segment of a prefill: rows [row0, row0 + L) of the stacked input are the positions pos0 .. pos0 + L - 1 of a sequence whose KV cache
+// (layout [layers][kv_heads][max_len][64]) starts at kc / vc.  The GEMMs / norms of a prefill run over ALL rows of all segments at once
+// (M = sum of the prompt lengths: the weights are read once and the tiles are fuller), RoPE + cache write and the causal attention per segment.
+struct PrefillSeg { int row0, L, pos0; float* kc; float* vc; };
+
+static void llm_prefill_rows(cv_llm* m, const float* x_in, int R, const std::vector<PrefillSeg>& segs, hipStream_t s) {
+    const auto& c = m->cfg;
+    const int H = c.hidden, Q = m->qkv_dim, A = c.heads * 64;
+    if (R > m->pf_rows) {
+        m->pf_x.ensure((size_t)R * H * 4); m->pf_xn.ensure((size_t)R * H * 4); m->pf_qkv.ensure((size_t)R * Q * 4);
+        m->pf_attn.ensure((size_t)R * A * 4); m->pf_gu.ensure((size_t)R * 2 * c.inter * 4); m->pf_act.ensure((size_t)R * c.inter * 4);
+        m->pf_rows = R;
+    }
+    float* x = m->pf_x.as<float>(); float* xn = m->pf_xn.as<float>(); float* qkv = m->pf_qkv.as<float>();
+    float* at = m->pf_attn.as<float>(); float* gu = m->pf_gu.as<float>(); float* act = m->pf_act.as<float>();
+    CV_HIP(hipMemcpyAsync(x, x_in, (size_t)R * H * 4, hipMemcpyDeviceToDevice, s));
+    for (int i = 0; i < c.layers; ++i) {
+        const auto& L = m->layers[i];
+        norm_rows(NormArgs{x, xn, R, H, L.ln1, nullptr, c.rms_eps, 1, ACT_NONE, 1.f, nullptr, nullptr, R}, s);
+        linear(xn, R, lw(L.wqkv, L.bqkv, Q, H), qkv, ACT_NONE, nullptr, s);
+        for (const auto& g : segs) {
+            float* kc = g.kc + m->layer_cache() * i; float* vc = g.vc + m->layer_cache() * i;
+            float* q = qkv + (size_t)g.row0 * Q;
+            hipLaunchKernelGGL(rope_store_kernel, dim3(g.L), dim3(256), 0, s, q, g.L, c.heads, c.kv_heads, g.pos0,
+                               m->rope_cos.as<float>(), m->rope_sin.as<float>(), kc, vc, c.max_len);
+            AttnArgs a{};
+            a.q = q; a.q_batch = 0; a.q_row = Q; a.q_head = 64;
+            a.k = kc; a.k_batch = 0; a.k_row = 64; a.k_head = c.max_len * 64;
+            a.v = vc; a.v_batch = 0; a.v_row = 64; a.v_head = c.max_len * 64;
+            a.o = at + (size_t)g.row0 * A; a.o_batch = 0; a.o_row = A; a.o_head = 64;
+            a.B = 1; a.H = c.heads; a.kv_group = c.heads / c.kv_heads; a.Tq = g.L; a.Tk = g.pos0 + g.L;      // causal with offset Tk - Tq
+            a.scale = 0.125f; a.mask_mode = MASK_CAUSAL; a.chunk = 0; a.rel_bd = nullptr;
+            attention(a, s);
+        }
+        linear(at, R, lw(L.wo, nullptr, H, A), x, ACT_NONE, x, s);
+        norm_rows(NormArgs{x, xn, R, H, L.ln2, nullptr, c.rms_eps, 1, ACT_NONE, 1.f, nullptr, nullptr, R}, s);
+        linear(xn, R, lw(L.wgu, nullptr, 2 * c.inter, H), gu, ACT_NONE, nullptr, s);
+        const long long n_out = (long long)R * c.inter;
+        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, gu, act, n_out);
+        linear(act, R, lw(L.wdown, nullptr, H, c.inter), x, ACT_NONE, x, s);
+    }
+}
+
 // append = false: a new request, the rows become positions 0 .. L0-1.  append = true (inference_bistream, llm/llm.py:551-661): the rows
 // are forwarded on top of the positions already cached, exactly like `forward_one_step(lm_input, cache=cache)` with a multi-row lm_input;
 // the running request (tokens emitted so far, step counter) continues and a `done` left by a fill token is cleared.
@@ -143,39 +178,8 @@ static void llm_prefill(cv_llm* m, const float* x_in, int L0, hipStream_t s, boo
     CV_CHECK(m->finalized, "llm: call cv_llm_finalize first");
     const int pos0 = append ? m->host_state->pos : 0;
     CV_CHECK(L0 > 0 && pos0 + L0 < c.max_len, "llm_prefill: prompt length out of range (KV capacity max_len)");
-    const int H = c.hidden, Q = m->qkv_dim, A = c.heads * 64;
-    if (L0 > m->pf_rows) {
-        m->pf_x.ensure((size_t)L0 * H * 4); m->pf_xn.ensure((size_t)L0 * H * 4); m->pf_qkv.ensure((size_t)L0 * Q * 4);
-        m->pf_attn.ensure((size_t)L0 * A * 4); m->pf_gu.ensure((size_t)L0 * 2 * c.inter * 4); m->pf_act.ensure((size_t)L0 * c.inter * 4);
-        m->pf_rows = L0;
-    }
-    float* x = m->pf_x.as<float>(); float* xn = m->pf_xn.as<float>(); float* qkv = m->pf_qkv.as<float>();
-    float* at = m->pf_attn.as<float>(); float* gu = m->pf_gu.as<float>(); float* act = m->pf_act.as<float>();
-    CV_HIP(hipMemcpyAsync(x, x_in, (size_t)L0 * H * 4, hipMemcpyDeviceToDevice, s));
-    for (int i = 0; i < c.layers; ++i) {
-        const auto& L = m->layers[i];
-        float* kc = m->kcache.as<float>() + m->layer_cache() * i;
-        float* vc = m->vcache.as<float>() + m->layer_cache() * i;
-        norm_rows(NormArgs{x, xn, L0, H, L.ln1, nullptr, c.rms_eps, 1, ACT_NONE, 1.f, nullptr, nullptr, L0}, s);
-        linear(xn, L0, lw(L.wqkv, L.bqkv, Q, H), qkv, ACT_NONE, nullptr, s);
-        hipLaunchKernelGGL(rope_store_kernel, dim3(L0), dim3(256), 0, s, qkv, L0, c.heads, c.kv_heads, pos0,
-                           m->rope_cos.as<float>(), m->rope_sin.as<float>(), kc, vc, c.max_len);
-        AttnArgs a{};
-        a.q = qkv; a.q_batch = 0; a.q_row = Q; a.q_head = 64;
-        a.k = kc; a.k_batch = 0; a.k_row = 64; a.k_head = c.max_len * 64;
-        a.v = vc; a.v_batch = 0; a.v_row = 64; a.v_head = c.max_len * 64;
-        a.o = at; a.o_batch = 0; a.o_row = A; a.o_head = 64;
-        a.B = 1; a.H = c.heads; a.kv_group = c.heads / c.kv_heads; a.Tq = L0; a.Tk = pos0 + L0;      // causal with offset Tk - Tq
-        a.scale = 0.125f; a.mask_mode = MASK_CAUSAL; a.chunk = 0; a.rel_bd = nullptr;
-        attention(a, s);
-        linear(at, L0, lw(L.wo, nullptr, H, A), x, ACT_NONE, x, s);
-        norm_rows(NormArgs{x, xn, L0, H, L.ln2, nullptr, c.rms_eps, 1, ACT_NONE, 1.f, nullptr, nullptr, L0}, s);
-        linear(xn, L0, lw(L.wgu, nullptr, 2 * c.inter, H), gu, ACT_NONE, nullptr, s);
-        const long long n_out = (long long)L0 * c.inter;
-        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, gu, act, n_out);
-        linear(act, L0, lw(L.wdown, nullptr, H, c.inter), x, ACT_NONE, x, s);
-    }
-    CV_HIP(hipMemcpyAsync(m->h.p, x + (size_t)(L0 - 1) * H, (size_t)H * 4, hipMemcpyDeviceToDevice, s));
+    llm_prefill_rows(m, x_in, L0, {PrefillSeg{0, L0, pos0, m->kcache.as<float>(), m->vcache.as<float>()}}, s);
+    CV_HIP(hipMemcpyAsync(m->h.p, m->pf_x.as<float>() + (size_t)(L0 - 1) * c.hidden, (size_t)c.hidden * 4, hipMemcpyDeviceToDevice, s));
     DecodeState st{}; st.pos = pos0 + L0; st.step = 0; st.done = 0; st.n_tokens = 0; st.last_token = 0; st.stop_token = -1;
     if (append) { st.step = m->host_state->step; st.n_tokens = m->host_state->n_tokens; st.last_token = m->host_state->last_token; }
     *m->host_state = st;
@@ -215,7 +219,9 @@ static void gemv(const GemvArgs& a, int rows, hipStream_t s, int nsp = 0) {
     if (steps <= 7) {
         if (a.gamma && g_gemv_shared_norm) {                 // 4 waves share the normalised input through LDS (gemv_norm_kernel)
             const dim3 g16((units + 15) / 16);
-            if (rows == 2) hipLaunchKernelGGL((gemv_norm_kernel<7, 2>), g16, dim3(256), 0, s, a);
+            static const bool five = [] { const char* e = getenv("CV_GEMV_GATEUP_WAVES"); return !(e && e[0] == '4'); }();   // dev knob for A/B runs
+            if (rows == 2 && five) hipLaunchKernelGGL((gemv_norm_kernel<7, 2, 5>), dim3((units + 19) / 20), dim3(320), 0, s, a);
+            else if (rows == 2) hipLaunchKernelGGL((gemv_norm_kernel<7, 2>), g16, dim3(256), 0, s, a);
             else           hipLaunchKernelGGL((gemv_norm_kernel<7, 1>), g16, dim3(256), 0, s, a);
             return;
         }
@@ -228,7 +234,9 @@ static void gemv(const GemvArgs& a, int rows, hipStream_t s, int nsp = 0) {
     }
 }
 
-// one token: head + sample, then (unless done) embed + backbone for the sampled token
+// one token: head + sample, then (unless done) embed + backbone for the sampled token.  The graph is ONE chain on purpose: a forked branch
+// (an L2 warm-up kernel per layer next to qkv / attention / o_proj) was measured at +21 us per layer for the fork / join edges alone on this
+// runtime (profiles/r2_batch_decode_ab.txt), and early-launched dependents on a second stream deadlock under hipGraph scheduling.
 static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
     const auto& c = m->cfg;
     const DecodeState* st = m->state.as<DecodeState>();
@@ -240,23 +248,9 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
     sa.st = m->state.as<DecodeState>(); sa.tokens = m->tokens.as<int>(); sa.max_tokens = c.max_len;
     sa.emb_table = m->speech_emb; sa.emb_dim = c.hidden; sa.h_out = h;             // sampling + embedding of the sampled token: one launch
     if (want(6)) { ProfScope ps(m, s, 6); hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, s, sa); }
-    const bool pf = m->prefetch && m->only_cat < 0 && !m->profiling && g_gemv_shared_norm && c.hidden / 128 <= 7;
-    if (pf && !m->pf_stream) {
-        CV_HIP(hipStreamCreateWithFlags(&m->pf_stream, hipStreamNonBlocking));
-        CV_HIP(hipEventCreateWithFlags(&m->pf_fork, hipEventDisableTiming)); CV_HIP(hipEventCreateWithFlags(&m->pf_join, hipEventDisableTiming));
-    }
     for (int i = 0; i < c.layers; ++i) {
         const auto& L = m->layers[i];
         const int nsp = m->attn_splits;
-        if (pf) {                                                   // fork: warm this layer's gate/up (+ down) weights while qkv / attention / o_proj run
-            // consumer grids (gemv() above): gate/up = gemv_norm_kernel<7,2>, 32 rows per workgroup; down = gemv_kernel<10,1,4>, 4 rows per workgroup
-            PrefetchArgs pa{};
-            pa.a = L.wgu; pa.a_per_wg = 32LL * c.hidden * 2; pa.a_wgs = (m->prefetch & 1) ? (2 * c.inter) / 32 : 0;
-            pa.b = L.wdown; pa.b_per_wg = 4LL * c.inter * 2; pa.b_wgs = (m->prefetch & 2) ? c.hidden / 4 : 0;
-            pa.sink = m->pf_sink.as<unsigned>();
-            CV_HIP(hipEventRecord(m->pf_fork, s)); CV_HIP(hipStreamWaitEvent(m->pf_stream, m->pf_fork, 0));
-            hipLaunchKernelGGL(l2_prefetch_kernel, dim3(std::max(pa.a_wgs, pa.b_wgs)), dim3(256), 0, m->pf_stream, pa);
-        }
         GemvArgs go{L.wo, nullptr, nullptr, h, c.hidden, c.heads * 64, nullptr, 0.f, h, 0, st};
         go.part = m->attn_part.as<float>();
         if (m->fused_qkv_attn) {
@@ -279,7 +273,6 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
         if (i == c.layers - 1 && m->only_cat < 0) gd.advance = m->state.as<DecodeState>();     // the step's last kernel also advances the KV length
         if (want(4)) { ProfScope ps(m, s, 4); gemv(gd, 1, s); }
     }
-    if (pf) { CV_HIP(hipEventRecord(m->pf_join, m->pf_stream)); CV_HIP(hipStreamWaitEvent(s, m->pf_join, 0)); }      // join the branch
 }
 
 static bool same_sampling(const cv_sampling& a, const cv_sampling& b) {
@@ -370,6 +363,37 @@ static void batch_prefill(cv_llm* m, int slot, const float* lm_input, int L0, co
                                    (unsigned long long)sp->seed};
     CV_HIP(hipMemcpyAsync(b.state.as<DecodeState>() + slot, &b.host_state[slot], sizeof(DecodeState), hipMemcpyHostToDevice, s));
     CV_HIP(hipMemcpyAsync(b.sparams.as<SampleParams>() + slot, &b.host_sp[slot], sizeof(SampleParams), hipMemcpyHostToDevice, s));
+    CV_HIP(hipStreamSynchronize(s));
+}
+
+// Several slots filled by ONE prefill pass: the prompts are stacked row-wise (rows_in: [sum L0][hidden], slot j's rows follow slot j-1's), every
+// GEMM runs once over all rows, K / V go straight into the slots' caches.  Arithmetic per row = the single-sequence prefill's.
+static void batch_prefill_many(cv_llm* m, int n, const int32_t* slots, const float* rows_in, const int32_t* L0s, const cv_sampling* sps, hipStream_t s) {
+    auto& b = m->bt; const auto& c = m->cfg;
+    CV_CHECK(m->finalized && n >= 1 && n <= b.nb && slots && rows_in && L0s && sps, "cv_llm_batch_prefill_many: bad arguments (call cv_llm_batch_begin first)");
+    std::vector<PrefillSeg> segs; int R = 0;
+    for (int j = 0; j < n; ++j) {
+        const cv_sampling* sp = sps + j;
+        CV_CHECK(slots[j] >= 0 && slots[j] < b.nb, "cv_llm_batch_prefill_many: slot out of range");
+        for (int k = 0; k < j; ++k) CV_CHECK(slots[k] != slots[j], "cv_llm_batch_prefill_many: a slot is listed twice");
+        CV_CHECK(L0s[j] > 0 && L0s[j] < c.max_len, "cv_llm_batch_prefill_many: prompt length out of range (KV capacity max_len)");
+        CV_CHECK(sp->max_len > 0 && sp->eos >= 0 && sp->eos + sp->n_stop <= m->V && !sp->use_uniforms, "cv_llm_batch_prefill_many: bad sampling parameters");
+        CV_CHECK(sp->mode == 0 || (sp->top_k > 0 && sp->top_k <= 64 && sp->win_size >= 0), "cv_llm_batch_prefill_many: bad RAS parameters");
+        segs.push_back(PrefillSeg{R, L0s[j], 0, b.kcache.as<float>() + (size_t)slots[j] * m->slot_cache(), b.vcache.as<float>() + (size_t)slots[j] * m->slot_cache()});
+        R += L0s[j];
+    }
+    llm_prefill_rows(m, rows_in, R, segs, s);
+    for (int j = 0; j < n; ++j) {
+        const int slot = slots[j]; const cv_sampling* sp = sps + j;
+        CV_HIP(hipMemcpyAsync(b.h.as<float>() + (size_t)slot * c.hidden, m->pf_x.as<float>() + (size_t)(segs[j].row0 + segs[j].L - 1) * c.hidden,
+                              (size_t)c.hidden * 4, hipMemcpyDeviceToDevice, s));
+        DecodeState st{}; st.pos = L0s[j]; st.stop_token = -1;
+        b.host_state[slot] = st;
+        b.host_sp[slot] = SampleParams{sp->mode, sp->eos, sp->n_stop, sp->min_len, sp->max_len, sp->top_p, sp->top_k, sp->win_size, sp->tau_r, 0,
+                                       (unsigned long long)sp->seed};
+        CV_HIP(hipMemcpyAsync(b.state.as<DecodeState>() + slot, &b.host_state[slot], sizeof(DecodeState), hipMemcpyHostToDevice, s));
+        CV_HIP(hipMemcpyAsync(b.sparams.as<SampleParams>() + slot, &b.host_sp[slot], sizeof(SampleParams), hipMemcpyHostToDevice, s));
+    }
     CV_HIP(hipStreamSynchronize(s));
 }
 
@@ -494,10 +518,6 @@ int cv_llm_set_option(cv_llm* m, const char* name, int32_t value) {
             CV_CHECK(value == 4 || value == 8 || value == 16, "attn_splits must be 4, 8 or 16");
             m->attn_splits = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
         }
-        else if (std::string(name) == "prefetch") {          // bit 0: gate/up, bit 1: down weights warmed into L2 on a forked graph branch
-            CV_CHECK(value >= 0 && value <= 3, "prefetch must be 0..3");
-            m->prefetch = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
-        }
         else throw Error(std::string("unknown option ") + name);
     });
 }
@@ -591,6 +611,9 @@ int cv_llm_batch_begin(cv_llm* m, int32_t nb, void* stream) {
 }
 int cv_llm_batch_prefill(cv_llm* m, int32_t slot, const float* lm_input, int32_t L0, const cv_sampling* sp, void* stream) {
     return guarded([&] { CV_CHECK(m && lm_input, "null argument"); batch_prefill(m, slot, lm_input, L0, sp, resolve(m, stream)); });
+}
+int cv_llm_batch_prefill_many(cv_llm* m, int32_t n, const int32_t* slots, const float* rows, const int32_t* L0s, const cv_sampling* sps, void* stream) {
+    return guarded([&] { CV_CHECK(m, "null handle"); batch_prefill_many(m, n, slots, rows, L0s, sps, resolve(m, stream)); });
 }
 int cv_llm_batch_decode(cv_llm* m, int32_t n_steps, int32_t* out_tokens, int32_t* n_out, int32_t* finished, void* stream) {
     return guarded([&] { CV_CHECK(m, "null handle"); batch_decode(m, n_steps, out_tokens, n_out, finished, resolve(m, stream)); });

@@ -202,13 +202,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
 // sum of squares is reduced over the workgroup in a fixed order, x * rstd * gamma is parked in LDS (3.5 KB) and every lane reads its 14
 // float4 from there.  The weight loads stay in flight across both barriers.  Same row -> lane mapping, same FMA order as gemv_kernel.
 // ---------------------------------------------------------------------------------------------------------------
-template <int STEPS, int ROWS>
-__global__ __launch_bounds__(256) void gemv_norm_kernel(GemvArgs p) {
+// WAVES = 5 for gate / up: 4864 row pairs over 20 groups per workgroup = 244 workgroups, one per CU in a single balanced round (with 4 waves
+// the 304 workgroups leave 48 of the 256 CUs with two each - the tail of the launch).
+template <int STEPS, int ROWS, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64) void gemv_norm_kernel(GemvArgs p) {
     __shared__ __attribute__((aligned(16))) float xs[STEPS * 128];
-    __shared__ float red[4];
+    __shared__ float red[WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
     const int steps = p.K / 128;
-    const int unit = (blockIdx.x * 4 + wave) * 4 + grp;      // 16-lane group index: ROWS consecutive rows
+    const int unit = (blockIdx.x * WAVES + wave) * 4 + grp;  // 16-lane group index: ROWS consecutive rows
     const int row0 = unit * ROWS;
 
     u32x4 w[ROWS][STEPS];
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void gemv_norm_kernel(GemvArgs p) {
         float ss = wave_sum(xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w);
         if (lane == 0) red[wave] = ss;
         __syncthreads();
-        ss = (red[0] + red[1]) + (red[2] + red[3]);
+        ss = (red[0] + red[1]) + (red[2] + red[3]);            // K <= 896: the elements live in waves 0..3 (a fifth wave holds zeros)
         const float rstd = rsqrtf(ss / (float)p.K + p.eps);
         if (have) *reinterpret_cast<float4*>(&xs[k]) = make_float4(xv.x * rstd * gv.x, xv.y * rstd * gv.y, xv.z * rstd * gv.z, xv.w * rstd * gv.w);
         __syncthreads();
@@ -756,31 +758,6 @@ static __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs a) {
     }
     if (a.h_out && !stop)                                     // input of the backbone step that follows in the same graph replay
         for (int c = tid; c < a.emb_dim; c += 1024) a.h_out[c] = bf16_to_f32(a.emb_table[(long long)tok * a.emb_dim + c]);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// L2 warm-up of the big weight matrices of a decode layer, launched on a forked graph branch while the layer's small kernels (qkv,
-// attention, o_proj: ~11 us with the memory system nearly idle) run on the main branch.  Workgroup b reads exactly the bytes the
-// consumer's workgroup b will read (same 1-D grid order -> same XCD -> same L2 slice: workgroups are dealt round-robin to the 8 XCDs),
-// with the default cache policy so the lines stay; the consumer's non-temporal loads then hit in L2 instead of HBM.  It never waits on
-// anything, so it cannot stall the main branch; it is pure hint traffic (correctness does not depend on it).
-// ---------------------------------------------------------------------------------------------------------------
-struct PrefetchArgs { const void* a; long long a_per_wg; int a_wgs; const void* b; long long b_per_wg; int b_wgs; unsigned* sink; };
-
-static __global__ __launch_bounds__(256) void l2_prefetch_kernel(PrefetchArgs p) {
-    unsigned acc = 0;
-    const int bid = blockIdx.x, tid = threadIdx.x;
-    if (bid < p.a_wgs) {
-        const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.a) + (long long)bid * p.a_per_wg);
-        const int n = (int)(p.a_per_wg >> 4);
-        for (int i = tid; i < n; i += 256) { const u32x4 v = src[i]; acc ^= v[0] ^ v[1] ^ v[2] ^ v[3]; }
-    }
-    if (bid < p.b_wgs) {
-        const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.b) + (long long)bid * p.b_per_wg);
-        const int n = (int)(p.b_per_wg >> 4);
-        for (int i = tid; i < n; i += 256) { const u32x4 v = src[i]; acc ^= v[0] ^ v[1] ^ v[2] ^ v[3]; }
-    }
-    if (acc == 0x9E3779B9u && p.sink) *p.sink = acc;          // keeps the loads alive; practically never taken
 }
 
 // advance the KV length after a backbone step

@@ -190,7 +190,7 @@ class Qwen2LM:
         with self.lock:
             st = stream_ptr(self.lib)
             self.lib.cv_llm_batch_begin(self._h, C.c_int32(nb), st)
-            max_lens = []
+            max_lens, inputs, sps = [], [], []
             for i, r in enumerate(requests):
                 lm_input = self.build_lm_input(r["text"], r["prompt_text"], r["prompt_speech_token"])
                 n_text = int(r["text"].shape[1])
@@ -198,9 +198,9 @@ class Qwen2LM:
                 max_len = int(n_text * r.get("max_token_text_ratio", max_token_text_ratio))
                 if max_len > 0:
                     max_len = self.clamp_max_len(lm_input.shape[0], min_len, max_len, "request %d" % i)
-                sp = self.make_sampling(min_len, max(max_len, 1))
-                self.lib.cv_llm_batch_prefill(self._h, C.c_int32(i), C.c_void_p(lm_input.data_ptr()), C.c_int32(lm_input.shape[0]), C.byref(sp), st)
+                inputs.append(lm_input); sps.append(self.make_sampling(min_len, max(max_len, 1)))
                 max_lens.append(max_len)
+            self._prefill_slots(list(range(nb)), inputs, sps, st)
             outs, fin = [[] for _ in range(nb)], [m == 0 for m in max_lens]
             chunk = self.decode_chunk
             while not all(fin):
@@ -212,6 +212,16 @@ class Qwen2LM:
                     fin[i] = fin[i] or bool(f[i]) or len(outs[i]) >= max_lens[i]
             return [o[:m] for o, m in zip(outs, max_lens)]
 
+
+    def _prefill_slots(self, slots, inputs, sps, st):
+        """One prefill pass for several slots (cv_llm_batch_prefill_many): the prompts are stacked row-wise, every GEMM of the prefill sees
+        M = sum of the prompt lengths and the weights are read once."""
+        if not slots:
+            return
+        rows = self.lib.hook(torch.cat(inputs, 0).contiguous()) if len(inputs) > 1 else inputs[0]
+        n = len(slots)
+        self.lib.cv_llm_batch_prefill_many(self._h, C.c_int32(n), (C.c_int32 * n)(*slots), C.c_void_p(rows.data_ptr()),
+                                           (C.c_int32 * n)(*[int(x.shape[0]) for x in inputs]), (SamplingC * n)(*sps), st)
 
     @torch.inference_mode()
     def inference_queue(self, requests, slots=8, max_token_text_ratio=20, min_token_text_ratio=2):
@@ -229,6 +239,8 @@ class Qwen2LM:
             owner, outs, limit = [None] * nb, {}, {}
             nxt = 0
 
+            pending = []                                      # (slot, lm_input, sampling) admitted but not yet prefilled
+
             def fill(slot):
                 nonlocal nxt
                 while nxt < n:
@@ -242,15 +254,20 @@ class Qwen2LM:
                         done.append((i, []))
                         continue
                     max_len = self.clamp_max_len(lm_input.shape[0], min_len, max_len, "request %d" % i)
-                    sp = self.make_sampling(min_len, max_len)
-                    self.lib.cv_llm_batch_prefill(self._h, C.c_int32(slot), C.c_void_p(lm_input.data_ptr()), C.c_int32(lm_input.shape[0]), C.byref(sp), st)
+                    pending.append((slot, lm_input, self.make_sampling(min_len, max_len)))
                     owner[slot], outs[i], limit[i] = i, [], max_len
                     return
                 owner[slot] = None
 
+            def flush():                                      # every slot freed in the same decode chunk is re-filled by one prefill pass
+                if pending:
+                    self._prefill_slots([p[0] for p in pending], [p[1] for p in pending], [p[2] for p in pending], st)
+                    pending.clear()
+
             done = []
             for s_ in range(nb):
                 fill(s_)
+            flush()
             chunk = self.decode_chunk
             while True:
                 for item in done:
@@ -269,6 +286,7 @@ class Qwen2LM:
                     if bool(f[s_]) or len(outs[i]) >= limit[i]:
                         done.append((i, outs.pop(i)[: limit[i]]))
                         fill(s_)
+                flush()
 
 
     @torch.inference_mode()

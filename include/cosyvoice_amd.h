@@ -134,13 +134,16 @@ int cv_llm_profile_step(cv_llm* m, const cv_sampling* sp, int32_t* counts8, floa
 /* one kernel class (category as above, 0..5) as a dependent chain of its real launches (one per layer) in a hipGraph, `reps` replays
  * between ONE event pair: total duration and number of launches — the per-launch duration bench.py prices against the HBM roofline */
 int cv_llm_profile_chain(cv_llm* m, int32_t category, int32_t reps, float* total_ms, int32_t* launches, void* stream);
-/* Lock-step batched decode (BASELINE.json configs[2]/[3]; the reference batches through vLLM, cli/model.py:281-290): up to 8 sequences
- * advance one token per step and every weight matrix is streamed once per step for all of them.  cv_llm_batch_begin sizes the slots,
- * cv_llm_batch_prefill runs the normal prefill for one request and parks its KV prefix / state / sampling parameters in `slot`,
+/* Lock-step batched decode (BASELINE.json configs[2]/[3]; the reference batches through vLLM, cli/model.py:281-290): up to 16 sequences
+ * advance one token per step and every weight matrix is streamed once per step for all of them (skinny GEMMs on the exact-fp32 MFMA).
+ * cv_llm_batch_begin sizes the slots, cv_llm_batch_prefill runs the normal prefill for one request and parks its KV prefix / state /
+ * sampling parameters in `slot`; cv_llm_batch_prefill_many fills n slots with ONE prefill pass over the row-stacked prompts (rows: dev
+ * [sum L0s][hidden], slot j's rows after slot j-1's; sps: n sampling structs) - the GEMMs see M = sum of the prompt lengths;
  * cv_llm_batch_decode runs n_steps steps and returns, per slot, the tokens emitted by this call (out_tokens[slot * n_steps + k]),
  * their count and whether the slot has finished.  A sequence decoded in a batch gives the same tokens as decoded alone. */
 int cv_llm_batch_begin(cv_llm* m, int32_t nb, void* stream);
 int cv_llm_batch_prefill(cv_llm* m, int32_t slot, const float* lm_input, int32_t L0, const cv_sampling* sp, void* stream);
+int cv_llm_batch_prefill_many(cv_llm* m, int32_t n, const int32_t* slots, const float* rows, const int32_t* L0s, const cv_sampling* sps, void* stream);
 int cv_llm_batch_decode(cv_llm* m, int32_t n_steps, int32_t* out_tokens, int32_t* n_out, int32_t* finished, void* stream);
 int cv_llm_last_logits(cv_llm* m, float* host_out, void* stream);
 int cv_llm_last_hidden(cv_llm* m, float* host_out, void* stream);
