@@ -424,7 +424,10 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
     float* h = b.h.as<float>(); float* qkv = b.qkv.as<float>(); float* act = b.act.as<float>(); float* logits = b.logits.as<float>();
     float* att = b.attn.as<float>(); float* dpart = b.dpart.as<float>();
     const int ks = down_ksplit(c.inter);
-    skinny(SkinnyArgs{m->head_w, m->head_b, h, H, logits, V, (int)V, c.hidden, m->norm, c.rms_eps, nullptr, 0, 0, nb, 1}, 2, s);
+    // 2 row tiles per workgroup for the two wide GEMMs (gate/up: 304 workgroups, head: 206); 3 (203 / 137 workgroups, at most 3 tiles per CU instead
+    // of 4 on 48 CUs) measured the same step time (profiles/r2_batch_decode_ab.txt): the launch is not bound by the busiest CU's MFMA share
+    const int wide_rt = 2;
+    skinny(SkinnyArgs{m->head_w, m->head_b, h, H, logits, V, (int)V, c.hidden, m->norm, c.rms_eps, nullptr, 0, 0, nb, 1}, wide_rt, s);
     {                                                             // every slot's sampler + embedding of the sampled token: one launch, one workgroup per slot
         SampleArgs sa{};
         sa.logits = logits; sa.V = (int)V; sa.sp = b.sparams.as<SampleParams>(); sa.uniforms = b.uniforms.as<float>();
@@ -440,7 +443,7 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
                                m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st, att, A};
         hipLaunchKernelGGL(attn_decode_batch_kernel, dim3(c.heads, nb), dim3(256), 0, s, ad);
         skinny(SkinnyArgs{L.wo, nullptr, att, A, h, H, c.hidden, (int)A, nullptr, 0.f, h, H, 0, nb, 1}, 1, s);
-        skinny(SkinnyArgs{L.wgu, nullptr, h, H, act, I, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 0, 1, nb, 1}, 2, s);
+        skinny(SkinnyArgs{L.wgu, nullptr, h, H, act, I, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 0, 1, nb, 1}, wide_rt, s);
         if (ks > 1) {
             skinny(SkinnyArgs{L.wdown, nullptr, act, I, dpart, H, c.hidden, c.inter, nullptr, 0.f, nullptr, 0, 2, nb, ks}, 2, s);
             hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((nb * H / 4 + 255) / 256)), dim3(256), 0, s, dpart, ks, nb, c.hidden, h, H, h, H);

@@ -41,7 +41,8 @@ __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 
 // Workgroup = 4 waves sharing RT row tiles (16 weight rows each) and one K range (K / ksplit); wave w takes the k-tiles (32 columns)
 // [w * T / 4, (w + 1) * T / 4) of the range, at most KTW of them.  Lane l: weight row l % 16 (A operand), sequence l % 16 (B operand),
 // k slot group g = l / 16: 8 consecutive k per 32-wide tile -> one 16-byte weight load (8 bf16) and two float4 X loads per tile feed 8
-// MFMAs.  D: lane l holds y[seq l % 16][row 4 * (l / 16) + i], i = 0..3: one float4 store per sequence.
+// MFMAs.  D: lane l holds y[seq l % 16][row 4 * (l / 16) + i], i = 0..3: one float4 store per sequence.  No barrier before the MFMA chain:
+// the RMSNorm scale is applied to the accumulators (see below), the only barrier is the cross-wave combine at the end.
 // (Staging X through LDS - one coalesced fetch per workgroup, conflict-free fragment reads - was built and measured SLOWER on the
 // MI355X: 15.9 vs 12.8 us for gate/up at nb = 8, 8.3 vs 5.6 us for qkv / o_proj: two more barriers in front of the MFMA chain cost more
 // than the 28 extra L2 load instructions per lane; profiles/r2_batch_decode_ab.txt.)
@@ -57,75 +58,66 @@ __global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs p) {
     const int kbase = ks * krange + t0 * 32 + g * 8;
     const int n_base = rg * RT * 16;
 
+    // every load of the wave is requested up front, tile by tile in the order the MFMA loop consumes them (W, X, gamma of tile 0, then tile 1 ...):
+    // the counted vmcnt waits the compiler places in front of each tile's MFMAs then let tile t compute while tiles t+1 .. are still in flight
     u32x4 w[RT][KTW];
+    float4 xa[KTW], xb[KTW], ga[KTW], gb[KTW];
+    const bf16_t* wr[RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const int row = min(n_base + rt * 16 + c, p.N - 1);            // clamped: ragged last tile (stores are masked)
-        const bf16_t* wr = p.W + (long long)row * p.K + kbase;
+    for (int rt = 0; rt < RT; ++rt) wr[rt] = p.W + (long long)min(n_base + rt * 16 + c, p.N - 1) * p.K + kbase;   // clamped: ragged last tile (stores are masked)
+    const float* xp = p.x + (long long)min(c, p.nb - 1) * p.ldx + kbase;       // columns >= nb recompute the last sequence (never stored)
 #pragma unroll
-        for (int t = 0; t < KTW; ++t) {
-            const bool ok = t0 + t < t1;
-            u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + (ok ? t : 0) * 32));
+    for (int t = 0; t < KTW; ++t) {
+        const bool ok = t0 + t < t1;
+        const int tt = ok ? t : 0;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr[rt] + tt * 32));
             if (!ok) v = (u32x4){0u, 0u, 0u, 0u};
             w[rt][t] = v;
         }
-    }
-    float4 xa[KTW], xb[KTW];
-    {
-        const float* xp = p.x + (long long)min(c, p.nb - 1) * p.ldx + kbase;   // columns >= nb recompute the last sequence (never stored)
-#pragma unroll
-        for (int t = 0; t < KTW; ++t) {
-            const bool ok = t0 + t < t1;
-            xa[t] = *reinterpret_cast<const float4*>(xp + (ok ? t : 0) * 32);
-            xb[t] = *reinterpret_cast<const float4*>(xp + (ok ? t : 0) * 32 + 4);
-            if (!ok) { xa[t] = make_float4(0.f, 0.f, 0.f, 0.f); xb[t] = xa[t]; }
-        }
-    }
-    if (p.gamma) {                                                      // Qwen2RMSNorm of every sequence, statistics over the whole workgroup
-        float4 ga[KTW], gb[KTW];
-#pragma unroll
-        for (int t = 0; t < KTW; ++t) {
-            const int tt = (t0 + t < t1) ? t : 0;
+        xa[t] = *reinterpret_cast<const float4*>(xp + tt * 32);
+        xb[t] = *reinterpret_cast<const float4*>(xp + tt * 32 + 4);
+        if (!ok) { xa[t] = make_float4(0.f, 0.f, 0.f, 0.f); xb[t] = xa[t]; }
+        if (p.gamma) {
             ga[t] = *reinterpret_cast<const float4*>(p.gamma + kbase + tt * 32);
             gb[t] = *reinterpret_cast<const float4*>(p.gamma + kbase + tt * 32 + 4);
         }
-        float ss = 0.f;
-#pragma unroll
-        for (int t = 0; t < KTW; ++t)
-            ss += xa[t].x * xa[t].x + xa[t].y * xa[t].y + xa[t].z * xa[t].z + xa[t].w * xa[t].w +
-                  xb[t].x * xb[t].x + xb[t].y * xb[t].y + xb[t].z * xb[t].z + xb[t].w * xb[t].w;
-        ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);            // over the 4 k-slot groups of the wave
-        if (g == 0) ssq[wave][c] = ss;
-        __syncthreads();
-        ss = (ssq[0][c] + ssq[1][c]) + (ssq[2][c] + ssq[3][c]);
-        const float rstd = rsqrtf(ss / (float)p.K + p.eps);
-#pragma unroll
-        for (int t = 0; t < KTW; ++t) {
-            xa[t].x = xa[t].x * rstd * ga[t].x; xa[t].y = xa[t].y * rstd * ga[t].y; xa[t].z = xa[t].z * rstd * ga[t].z; xa[t].w = xa[t].w * rstd * ga[t].w;
-            xb[t].x = xb[t].x * rstd * gb[t].x; xb[t].y = xb[t].y * rstd * gb[t].y; xb[t].z = xb[t].z * rstd * gb[t].z; xb[t].w = xb[t].w * rstd * gb[t].w;
-        }
     }
+    // Fused Qwen2RMSNorm: y = W (x * rstd * gamma) = rstd * (W (x * gamma)) per sequence - the MFMAs run on x * gamma while the sum of squares is
+    // still being gathered, and rstd (one scalar per sequence = per MFMA column) is applied to the accumulators at the end.
+    float ss = 0.f;
     v4f acc[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[rt] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < KTW; ++t) {
         if (t0 + t < t1) {                                              // wave-uniform
+            float4 a4 = xa[t], b4 = xb[t];
+            if (p.gamma) {
+                ss += a4.x * a4.x + a4.y * a4.y + a4.z * a4.z + a4.w * a4.w + b4.x * b4.x + b4.y * b4.y + b4.z * b4.z + b4.w * b4.w;
+                a4.x *= ga[t].x; a4.y *= ga[t].y; a4.z *= ga[t].z; a4.w *= ga[t].w;
+                b4.x *= gb[t].x; b4.y *= gb[t].y; b4.z *= gb[t].z; b4.w *= gb[t].w;
+            }
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 const u32x4 u = w[rt][t];
                 v4f a = acc[rt];
-                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_lo(u[0]), xa[t].x, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_hi(u[0]), xa[t].y, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_lo(u[1]), xa[t].z, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_hi(u[1]), xa[t].w, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_lo(u[2]), xb[t].x, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_hi(u[2]), xb[t].y, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_lo(u[3]), xb[t].z, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_hi(u[3]), xb[t].w, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_lo(u[0]), a4.x, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_hi(u[0]), a4.y, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_lo(u[1]), a4.z, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_hi(u[1]), a4.w, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_lo(u[2]), b4.x, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_hi(u[2]), b4.y, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_lo(u[3]), b4.z, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_hi(u[3]), b4.w, a, 0, 0, 0);
                 acc[rt] = a;
             }
         }
+    }
+    if (p.gamma) {
+        ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);            // over the 4 k-slot groups of the wave
+        if (g == 0) ssq[wave][c] = ss;
     }
     // split-K over the 4 waves, combined in fixed order; wave rt finishes row tile rt  [4 waves][RT][64 lanes][4]
 #pragma unroll
@@ -138,6 +130,11 @@ __global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs p) {
     for (int ww = 1; ww < 4; ++ww) {
         const float4 o = *reinterpret_cast<const float4*>(&red[((ww * RT + rt) * 64 + lane) * 4]);
         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    if (p.gamma) {                                                      // statistics over the whole row: the 4 waves' shares, fixed order
+        const float tot = (ssq[0][c] + ssq[1][c]) + (ssq[2][c] + ssq[3][c]);
+        const float rstd = rsqrtf(tot / (float)p.K + p.eps);
+        v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
     }
     const int n = n_base + rt * 16 + g * 4;                             // 4 consecutive weight rows of sequence c
     if (c >= p.nb || n >= p.N) return;
