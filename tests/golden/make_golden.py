@@ -1,9 +1,9 @@
 """Generate tests/golden/*.npz by running the REAL reference (/root/reference) on seeded inputs.
 
 Run in the build container only:  python tests/golden/make_golden.py
-The reference modules are instantiated with small dims, loaded (strict=True) with oracle.weights' seeded state dicts —
+The reference modules are instantiated with small dims, loaded (strict=True) with cosyvoice_amd.synthetic's seeded state dicts —
 which also validates the factory's key names/shapes against the reference — and their outputs are stored.  Weights are
-NOT stored: oracle/weights.py regenerates them from the seed (numpy PCG64).
+NOT stored: cosyvoice_amd/synthetic.py regenerates them from the seed (numpy PCG64).
 """
 import os
 import sys
@@ -18,7 +18,7 @@ sys.path.insert(0, HERE)
 import ref_import  # noqa: E402
 
 ref_import.install()
-from oracle import weights as W  # noqa: E402
+from cosyvoice_amd import synthetic as W  # noqa: E402
 
 
 def save(name, **arrs):

@@ -15,7 +15,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import llm as OL  # noqa: E402
-from oracle import weights as W  # noqa: E402
+from cosyvoice_amd import synthetic as W  # noqa: E402
 
 N_GEN, N_TEXT, N_PROMPT_TEXT, N_PROMPT_TOK = 250, 30, 12, 87
 

@@ -9,7 +9,7 @@ import torch
 from cosyvoice_amd.flow import CausalMaskedDiffWithDiT
 from oracle import dit as OD
 from oracle import flow as OF
-from oracle import weights as W
+from cosyvoice_amd import synthetic as W
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 

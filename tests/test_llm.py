@@ -6,7 +6,7 @@ import torch
 from cosyvoice_amd.llm import CosyVoice3LM, Qwen2LM
 from oracle import llm as OL
 from oracle import sampling as OS
-from oracle import weights as W
+from cosyvoice_amd import synthetic as W
 
 
 @pytest.fixture(scope="module")

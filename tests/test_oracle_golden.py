@@ -10,7 +10,7 @@ from oracle import flow as OF
 from oracle import hift as OH
 from oracle import llm as OL
 from oracle import sampling as OS
-from oracle import weights as W
+from cosyvoice_amd import synthetic as W
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 

@@ -11,7 +11,7 @@ import torch
 
 from cosyvoice_amd.model import CosyVoice2Model
 from cosyvoice_amd.serving import Engine, StreamScheduler, create_app, pcm16_stream
-from oracle import weights as W
+from cosyvoice_amd import synthetic as W
 
 
 @pytest.fixture(scope="module")

@@ -16,7 +16,7 @@ from cosyvoice_amd.llm import Qwen2LM
 from oracle import flow as OF
 from oracle import hift as OH
 from oracle import llm as OL
-from oracle import weights as W
+from cosyvoice_amd import synthetic as W
 
 
 def _cfgs(lib):

@@ -5,7 +5,7 @@ import torch
 
 from cosyvoice_amd.llm import Qwen2LM
 from oracle import llm as OL
-from oracle import weights as W
+from cosyvoice_amd import synthetic as W
 
 
 def _req(cfg, seed, n_text, n_prompt_text, n_prompt_tok):
