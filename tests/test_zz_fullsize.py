@@ -249,3 +249,85 @@ def test_hift_u10(lib):
     assert out.shape == ref.shape == (1, 480 * m) and err < 8e-6, err       # measured 2.4e-6 on the MI355X
     assert speech.shape == (1, 480 * m) and torch.isfinite(speech).all()
     assert f0_ref.shape[-1] == m
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# Fun-CosyVoice3-0.5B (BASELINE.json configs[4]) at its real dimensions: DiT with 22 blocks of width 1024,
+# 16 heads; CosyVoice3LM (6561 + 200 head rows); the causal HiFT generator.
+# ------------------------------------------------------------------------------------------------------------------------------------
+def _cv3_cfgs(lib):
+    from cosyvoice_amd import configs as CF
+    if lib.emulated:
+        return CF.tiny_cv3_llm(), CF.tiny_cv3_flow(), None
+    return CF.cv3_llm(), CF.cv3_flow(), CF.cv3_hift()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_cv3_dit_estimator_fullsize(lib, precision):
+    """DiT.forward (flow/DiT/dit.py:145-176) as solve_euler calls it: CFG batch 2, T = 674, both mask modes, against the fp32 oracle."""
+    from cosyvoice_amd.flow import CausalMaskedDiffWithDiT
+    from oracle import dit as OD
+    fc = _cv3_cfgs(lib)[1]
+    sd = W.make_flow_dit(fc)
+    flow = CausalMaskedDiffWithDiT(sd, fc, lib=lib, precision=precision)
+    g = torch.Generator().manual_seed(23)
+    T = 41 if lib.emulated else 674
+    x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g); cond = torch.randn(2, 80, T, generator=g)
+    spk = torch.randn(2, 80, generator=g); t = torch.tensor([0.35, 0.35]); mask = torch.ones(2, 1, T)
+    mu[1] = 0; cond[1] = 0; spk[1] = 0
+    for streaming in (False, True):
+        out = flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu()
+        ref = OD.estimator(sd, fc, x, mask, mu, t, spk, cond, streaming)
+        err = _rel(out, ref)
+        _record(lib, "cv3_dit_T674_%s_streaming%d_rel_l2" % (precision, int(streaming)), err)
+        _record(lib, "cv3_dit_T674_%s_streaming%d_max_abs" % (precision, int(streaming)), (out - ref).abs().max().item())
+        # measured on the MI355X (profiles/r2_fullsize_errors.json): fp32 1.4e-6 (summation order only), bf16 2.8e-3 (operand rounding through 22
+        # blocks; max |diff| 1.3e-2) -> bounds at 3x
+        assert err < (5e-6 if precision == "fp32" else 9e-3), (precision, streaming, err)
+
+
+def test_cv3_llm_tokens_fullsize(lib):
+    """CosyVoice3LM at the real dimensions: instruct-style request (prompt text with <|endofprompt|>, no speech prompt - what frontend_instruct2
+    leaves, cli/frontend.py:209-213), greedy ids against the oracle."""
+    from cosyvoice_amd.llm import CosyVoice3LM
+    lc = _cv3_cfgs(lib)[0]
+    sd = W.make_llm(lc)
+    n_gen = 8 if lib.emulated else 48
+    lm = CosyVoice3LM(sd, lc, lib=lib, max_len=256, sampling="greedy", decode_chunk=16)
+    g = torch.Generator().manual_seed(31)
+    text = torch.randint(0, 1000, (1, 6), generator=g, dtype=torch.int32)
+    prompt_text = torch.cat([torch.randint(0, 1000, (1, 5), generator=g, dtype=torch.int32), torch.tensor([[lc.endofprompt_id]], dtype=torch.int32)], 1)
+    e0 = torch.zeros(1, 0, dtype=torch.int32)
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    ratio = n_gen / 6
+    got = list(lm.inference(text=text, text_len=t(6), prompt_text=prompt_text, prompt_text_len=t(6), prompt_speech_token=e0, prompt_speech_token_len=t(0),
+                            max_token_text_ratio=ratio, min_token_text_ratio=ratio))
+    want = OL.inference(sd, lc, text, prompt_text, e0, max_token_text_ratio=ratio, min_token_text_ratio=ratio)
+    assert len(got) == len(want) == n_gen
+    div = next((i for i, (a, b) in enumerate(zip(got, want)) if a != b), None)
+    _record(lib, "cv3_llm_first_divergence_index", float(n_gen if div is None else div))
+    assert div is None, (div, got[div], want[div])
+
+
+def test_cv3_causal_hift_fullsize(lib):
+    """CausalHiFTGenerator at the real dimensions, 200 frames: decoder against the oracle given the oracle's source; a non-final chunk's samples
+    equal the one-shot waveform (generator.py:729-746)."""
+    from cosyvoice_amd.hift import CausalHiFTGenerator
+    hc = _cv3_cfgs(lib)[2]
+    if hc is None:
+        pytest.skip("hardware only: the tiny causal generator is covered by tests/test_causal_hift.py")
+    sd = W.make_hift(hc)
+    h = CausalHiFTGenerator(sd, hc, lib=lib)
+    gen = torch.Generator().manual_seed(19)
+    m = 200
+    mel = torch.randn(1, 80, m, generator=gen) * 2 - 5
+    noise = torch.zeros(480 * m, hc.harmonics + 1)
+    _, src_ref = OH.causal_inference(sd, hc, mel, True, None, noise.unsqueeze(0))
+    out = h.decode(mel, src_ref, True).cpu()
+    ref = OH.causal_decode(sd, hc, mel, src_ref, True)
+    err = _rel(out, ref)
+    _record(lib, "cv3_causal_hift_decode_200f_rel_l2", err)
+    assert out.shape == ref.shape == (1, 480 * m) and err < 1.6e-5, err      # measured 5.2e-6 on the MI355X
+    full, _ = h.inference(mel, True)
+    part, _ = h.inference(mel[:, :, :108], False)
+    assert part.shape[1] == 480 * 100 and torch.equal(part.cpu(), full.cpu()[:, : part.shape[1]])
