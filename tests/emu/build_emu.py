@@ -23,6 +23,15 @@ def _run(cmd):
 
 
 def build_emu(force=False):
+    """Serialised across processes (pytest-xdist workers start together on a fresh checkout): one builds, the others wait and find it up to date."""
+    import fcntl
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with open(os.path.join(OBJ_DIR, ".lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        return _build_emu(force)
+
+
+def _build_emu(force=False):
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
     srcs.append(os.path.join(HERE, "emu_runtime.cpp"))
     newest = 0.0
