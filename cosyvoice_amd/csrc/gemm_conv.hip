@@ -46,13 +46,20 @@ void launch_gemm_conv(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t
     // bf16 tiles are small (LDS and registers) and their launches are latency-bound: ask for ~3 co-resident workgroups per CU (A/B on MI355X: 240 -> 480 -> 720 -> 1024 minimum workgroups gave 238 -> 224 -> 221 -> 226 ms per utterance), so one
     // workgroup's load wait overlaps another's LDS / MFMA phases; the fp32 tiles keep ~1 per CU.
     const bool bf16_path = a.a_bf16 && w_bf16 && a.a_vec;
-    const long long min_blocks = bf16_path ? 720 : 240;
+    long long min_blocks = bf16_path ? 720 : 240;
+    // A tile taller than 32 rows may not pad M by more than 25 %: the LLM prefill of U10 has M = 131 = 128 + 3, and the 128-row tile ran half of its
+    // workgroups on 3 useful rows (prefill 5.14 -> 4.38 ms with this rule; asking for more workgroups on top gave 4.2: profiles/r2_batch_decode_ab.txt).
+    // CV_GEMM_MAX_WASTE / CV_GEMM_MIN_BLOCKS_F32: dev knobs for such sweeps, read at every launch.
+    double max_waste = 1.25;
+    if (const char* e = getenv("CV_GEMM_MIN_BLOCKS_F32"); e && !bf16_path) min_blocks = atoll(e);
+    if (const char* e = getenv("CV_GEMM_MAX_WASTE")) max_waste = atof(e);
     const int ncfg = (bf16_path && a.Kp >= 128 && use_two_wave_tile()) ? 6 : 5;   // the 16 x 32 two-wave tile exists for the bf16 path only
     int pick = ncfg - 1;                             // nothing reaches the target: the smallest tile = the most workgroups
     for (int c = 0; c < ncfg; ++c) {
         const long long blocks = (long long)((a.M + cfgs[c].bm - 1) / cfgs[c].bm) * ((a.N + cfgs[c].bn - 1) / cfgs[c].bn) * batch;
         if (cfgs[c].bn > 32 && a.N <= cfgs[c].bn / 2) continue;       // don't pad N by 2x or more
         if (cfgs[c].bm > 32 && a.M <= cfgs[c].bm / 2) continue;
+        if (cfgs[c].bm > 32 && (double)((a.M + cfgs[c].bm - 1) / cfgs[c].bm * cfgs[c].bm) > max_waste * a.M) continue;
         if (blocks >= min_blocks) { pick = c; break; }
     }
     if (const int f = forced_tile(); f >= 0) { if (f == 5 && !(bf16_path && a.Kp >= 128)) throw Error("CV_GEMM_FORCE_TILE=5 needs the bf16 path and Kp >= 128"); pick = f; }
