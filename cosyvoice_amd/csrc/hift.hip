@@ -147,7 +147,7 @@ static int hift_f0(cv_hift* m, const float* mel_cl, int frames, hipStream_t s, b
 
 static void hift_source(cv_hift* m, int frames, const float* noise, unsigned long long seed, hipStream_t s) {
     const auto& c = m->cfg; const int H = c.harmonics + 1;
-    hipLaunchKernelGGL(hift_phase_kernel, dim3(1), dim3(64), 0, s, m->f0.as<float>(), m->P.as<float>(), frames, H, (float)c.sr, (float)m->scale);
+    hipLaunchKernelGGL(hift_phase_kernel, dim3(1), dim3(256), 0, s, m->f0.as<float>(), m->P.as<float>(), frames, H, (float)c.sr, (float)m->scale);
     const long long L = (long long)frames * m->scale;
     hipLaunchKernelGGL(hift_source_kernel, dim3(nblk(L)), dim3(256), 0, s, m->f0.as<float>(), m->P.as<float>(), noise, seed, m->src_w, m->src_b,
                        m->s.as<float>(), frames, H, m->scale, c.nsf_alpha, c.nsf_sigma, c.voiced_thr, c.causal ? 1 : 0);
