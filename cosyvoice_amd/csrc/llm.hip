@@ -22,6 +22,10 @@ struct cv_llm {
     bool finalized = false;
     struct Layer { const float* ln1; const bf16_t* wqkv; const float* bqkv; const bf16_t* wo; const float* ln2; const bf16_t* wgu; const bf16_t* wdown; };
     std::vector<Layer> layers;
+    // optional fp8 (e4m3 + one fp32 scale per row) copies of the matrices for the batched decode ("<name>.f8" / "<name>.f8s", option "batch_fp8")
+    struct F8 { const unsigned char* w = nullptr; const float* s = nullptr; };
+    struct LayerF8 { F8 qkv, o, gu, down; };
+    std::vector<LayerF8> layers_f8; F8 head_f8; bool have_fp8 = false; int batch_fp8 = 0;
     const float* norm = nullptr; const bf16_t* head_w = nullptr; const float* head_b = nullptr; const bf16_t* speech_emb = nullptr;
     int V = 0, qkv_dim = 0;
     // device state
@@ -84,6 +88,20 @@ static void llm_finalize(cv_llm* m) {
         L.ln2 = m->tm.f32(p + "ln2", H);
         L.wgu = m->tm.bf16(p + "wgu", 2LL * c.inter * H);
         L.wdown = m->tm.bf16(p + "wdown", H * c.inter);
+    }
+    m->have_fp8 = m->tm.has("head.w.f8");
+    if (m->have_fp8) {
+        auto f8 = [&](const std::string& name, long long rows, long long cols) {
+            cv_llm::F8 f; f.w = reinterpret_cast<const unsigned char*>(m->tm.get(name + ".f8", CV_U8, rows * cols).p); f.s = m->tm.f32(name + ".f8s", rows); return f;
+        };
+        CV_CHECK(H % 64 == 0 && c.inter % 64 == 0 && c.heads * 64 % 64 == 0, "llm(fp8): K must be a multiple of 64");
+        m->layers_f8.resize(c.layers);
+        for (int i = 0; i < c.layers; ++i) {
+            const std::string p = "layers." + std::to_string(i) + ".";
+            m->layers_f8[i].qkv = f8(p + "wqkv", m->qkv_dim, H); m->layers_f8[i].o = f8(p + "wo", H, c.heads * 64);
+            m->layers_f8[i].gu = f8(p + "wgu", 2LL * c.inter, H); m->layers_f8[i].down = f8(p + "wdown", H, c.inter);
+        }
+        m->head_f8 = f8("head.w", m->V, H);
     }
     m->norm = m->tm.f32("norm", H);
     m->head_w = m->tm.bf16("head.w", (long long)m->V * H);
@@ -409,6 +427,29 @@ static void skinny(const SkinnyArgs& a, int rt, hipStream_t s) {
     else hipLaunchKernelGGL((skinny_mfma_kernel<2, 5>), grid, dim3(256), 0, s, a);
 }
 
+static void skinny_f8(const SkinnyF8Args& a, int rt, hipStream_t s) {
+    const int tiles = a.K / 64 / a.ksplit, row_tiles = (a.N + 15) / 16;
+    CV_CHECK(a.K % (64 * a.ksplit) == 0 && tiles >= 1 && (tiles + 3) / 4 <= 5 && (a.mode == 0 || a.N % 4 == 0), "skinny_f8: K range must be a multiple of 64 and at most 20 tiles per workgroup");
+    CV_CHECK(!(a.gamma && a.ksplit != 1) && (a.mode == 2) == (a.ksplit > 1), "skinny_f8: split-K workgroups leave raw partials (mode 2), the fused norm needs the whole row");
+    const dim3 grid(((row_tiles + rt - 1) / rt) * a.ksplit);
+    const bool deep = (tiles + 3) / 4 > 4;
+    CV_CHECK(!(a.gamma && deep), "skinny_f8: the fused norm covers rows of at most 16 tiles (K <= 1024)");
+    if (a.gamma) {
+        if (rt == 1) hipLaunchKernelGGL((skinny_fp8_kernel<1, 4, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((skinny_fp8_kernel<2, 4, true>), grid, dim3(256), 0, s, a);
+    } else {
+        if (rt == 1) hipLaunchKernelGGL((skinny_fp8_kernel<1, 4, false>), grid, dim3(256), 0, s, a);
+        else if (deep) hipLaunchKernelGGL((skinny_fp8_kernel<2, 5, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((skinny_fp8_kernel<2, 4, false>), grid, dim3(256), 0, s, a);
+    }
+}
+// K ranges of the fp8 down projection (64-column tiles): CosyVoice2 / 3: 76 tiles -> 4 x 19
+static int down_ksplit_f8(int inter) {
+    const int tiles = inter / 64;
+    for (int ks = 8; ks > 1; ks >>= 1) if (tiles % ks == 0 && tiles / ks >= 2 && (tiles / ks + 3) / 4 <= 5) return ks;
+    return 1;
+}
+
 // K ranges of the down projection: the largest split <= 8 that keeps >= 2 k-tiles per workgroup (CosyVoice2: 152 tiles -> 8 x 19)
 static int down_ksplit(int inter) {
     const int tiles = inter / 32;
@@ -423,6 +464,36 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
     DecodeState* st = b.state.as<DecodeState>();
     float* h = b.h.as<float>(); float* qkv = b.qkv.as<float>(); float* act = b.act.as<float>(); float* logits = b.logits.as<float>();
     float* att = b.attn.as<float>(); float* dpart = b.dpart.as<float>();
+    if (m->batch_fp8) {                                            // opt-in fp8 weights + activations (llm_batch_kernels.h, skinny_fp8_kernel)
+        CV_CHECK(m->have_fp8, "llm: option batch_fp8 needs the '<name>.f8' / '<name>.f8s' tensors (Qwen2LM(..., batch_fp8=True))");
+        const int k8 = down_ksplit_f8(c.inter);
+        skinny_f8(SkinnyF8Args{m->head_f8.w, m->head_f8.s, m->head_b, h, H, logits, V, (int)V, c.hidden, m->norm, c.rms_eps, nullptr, 0, 0, nb, 1}, 2, s);
+        {
+            SampleArgs sa{};
+            sa.logits = logits; sa.V = (int)V; sa.sp = b.sparams.as<SampleParams>(); sa.uniforms = b.uniforms.as<float>();
+            sa.st = st; sa.tokens = b.tokens.as<int>(); sa.max_tokens = c.max_len;
+            sa.emb_table = m->speech_emb; sa.emb_dim = c.hidden; sa.h_out = h;
+            sa.slot_logits = V; sa.slot_uniforms = 2LL * c.max_len; sa.slot_tokens = c.max_len; sa.slot_h = H;
+            hipLaunchKernelGGL(sample_kernel, dim3(nb), dim3(1024), 0, s, sa);
+        }
+        for (int l = 0; l < c.layers; ++l) {
+            const auto& L = m->layers[l]; const auto& F = m->layers_f8[l];
+            skinny_f8(SkinnyF8Args{F.qkv.w, F.qkv.s, L.bqkv, h, H, qkv, Q, (int)Q, c.hidden, L.ln1, c.rms_eps, nullptr, 0, 0, nb, 1}, 1, s);
+            AttnDecodeBatchArgs ad{qkv, Q, b.kcache.as<float>() + m->layer_cache() * l, b.vcache.as<float>() + m->layer_cache() * l, (long long)m->slot_cache(),
+                                   m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st, att, A};
+            hipLaunchKernelGGL(attn_decode_batch_kernel, dim3(c.heads, nb), dim3(256), 0, s, ad);
+            skinny_f8(SkinnyF8Args{F.o.w, F.o.s, nullptr, att, A, h, H, c.hidden, (int)A, nullptr, 0.f, h, H, 0, nb, 1}, 1, s);
+            skinny_f8(SkinnyF8Args{F.gu.w, F.gu.s, nullptr, h, H, act, I, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 0, 1, nb, 1}, 2, s);
+            if (k8 > 1) {
+                skinny_f8(SkinnyF8Args{F.down.w, F.down.s, nullptr, act, I, dpart, H, c.hidden, c.inter, nullptr, 0.f, nullptr, 0, 2, nb, k8}, 2, s);
+                hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((nb * H / 4 + 255) / 256)), dim3(256), 0, s, dpart, k8, nb, c.hidden, h, H, h, H);
+            } else {
+                skinny_f8(SkinnyF8Args{F.down.w, F.down.s, nullptr, act, I, h, H, c.hidden, c.inter, nullptr, 0.f, h, H, 0, nb, 1}, 2, s);
+            }
+        }
+        hipLaunchKernelGGL(advance_pos_batch_kernel, dim3(1), dim3(64), 0, s, st, nb);
+        return;
+    }
     const int ks = down_ksplit(c.inter);
     // 2 row tiles per workgroup for the two wide GEMMs (gate/up: 304 workgroups, head: 206); 3 (203 / 137 workgroups, at most 3 tiles per CU instead
     // of 4 on 48 CUs) measured the same step time (profiles/r2_batch_decode_ab.txt): the launch is not bound by the busiest CU's MFMA share
@@ -521,6 +592,10 @@ int cv_llm_set_option(cv_llm* m, const char* name, int32_t value) {
             CV_CHECK(value == 4 || value == 8 || value == 16, "attn_splits must be 4, 8 or 16");
             m->attn_splits = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
         }
+        else if (std::string(name) == "batch_fp8") {         // batched decode on the fp8 copies of the weights (needs the .f8 / .f8s tensors)
+            CV_CHECK(value == 0 || m->have_fp8, "batch_fp8: the fp8 tensors were not registered");
+            m->batch_fp8 = value != 0; if (m->bt.graph) { (void)hipGraphExecDestroy(m->bt.graph); m->bt.graph = nullptr; }
+        }
         else throw Error(std::string("unknown option ") + name);
     });
 }
@@ -618,8 +693,25 @@ int cv_llm_batch_prefill(cv_llm* m, int32_t slot, const float* lm_input, int32_t
 int cv_llm_batch_prefill_many(cv_llm* m, int32_t n, const int32_t* slots, const float* rows, const int32_t* L0s, const cv_sampling* sps, void* stream) {
     return guarded([&] { CV_CHECK(m, "null handle"); batch_prefill_many(m, n, slots, rows, L0s, sps, resolve(m, stream)); });
 }
+/* test hook: one fp8 skinny GEMM (the kernel of the opt-in fp8 batched decode) on caller-provided operands */
+int cv_skinny_fp8(const void* w8, const float* wscale, const float* bias, const float* x, int64_t ldx, float* y, int64_t ldy, int32_t N, int32_t K,
+                  const float* gamma, float eps, const float* res, int64_t ldres, int32_t mode, int32_t nb, int32_t ksplit, int32_t rt, void* stream) {
+    return guarded([&] {
+        CV_CHECK(w8 && wscale && x && y && nb >= 1 && nb <= MAX_NB && (rt == 1 || rt == 2), "cv_skinny_fp8: bad arguments");
+        skinny_f8(SkinnyF8Args{reinterpret_cast<const unsigned char*>(w8), wscale, bias, x, ldx, y, ldy, N, K, gamma, eps, res, ldres, mode, nb, ksplit}, rt, as_stream(stream));
+    });
+}
 int cv_llm_batch_decode(cv_llm* m, int32_t n_steps, int32_t* out_tokens, int32_t* n_out, int32_t* finished, void* stream) {
     return guarded([&] { CV_CHECK(m, "null handle"); batch_decode(m, n_steps, out_tokens, n_out, finished, resolve(m, stream)); });
+}
+/* logits of one slot of the batched decode as left by the last step's head GEMM (test hook) */
+int cv_llm_batch_logits(cv_llm* m, int32_t slot, float* host_out, void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && host_out && slot >= 0 && slot < m->bt.nb, "cv_llm_batch_logits: bad arguments");
+        hipStream_t s = resolve(m, stream);
+        CV_HIP(hipMemcpyAsync(host_out, m->bt.logits.as<float>() + (size_t)slot * m->V, (size_t)m->V * 4, hipMemcpyDeviceToHost, s));
+        CV_HIP(hipStreamSynchronize(s));
+    });
 }
 int cv_llm_last_logits(cv_llm* m, float* host_out, void* stream) {
     return guarded([&] { CV_CHECK(m && host_out, "null argument");

@@ -160,6 +160,141 @@ __global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// fp8 variant of the skinny GEMM (BASELINE.json configs[4]: "fp8 MFMA LLM path"; opt-in, batched decode only).  Weights: OCP e4m3 with one fp32
+// scale per output row (quantised once at load, cosyvoice_amd/weights.py::quantize_fp8_rows).  Activations: quantised in the kernel, one
+// scale per sequence and workgroup K range (absmax / 448), after the RMSNorm gamma.  Products on v_mfma_f32_16x16x32_fp8_fp8 (exact in fp32,
+// fp32 accumulate): y[b][n] = acc * sx[b] * rstd[b] * sw[n].  Half the weight bytes of the bf16 kernel and 1/16 of its MFMA time; the price is
+// the e4m3 rounding of both operands - there is no reference for this mode, it is held to an oracle that mirrors the
+// same quantisation (tests/test_llm_fp8.py) and reported separately by bench.py.
+// Lane l: weight row l % 16, sequence l % 16, k block g = l / 16: 16 consecutive k per 64-wide tile -> one 16-byte weight load (16 fp8) and
+// four float4 X loads feed two MFMAs.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct SkinnyF8Args {
+    const unsigned char* W; const float* wscale; const float* bias;
+    const float* x; long long ldx; float* y; long long ldy; int N, K;
+    const float* gamma; float eps; const float* res; long long ldres; int mode; int nb, ksplit;      // as SkinnyArgs
+};
+
+__device__ __forceinline__ long pack8_fp8(float4 a, float4 b, float inv) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(a.x * inv, a.y * inv, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(a.z * inv, a.w * inv, lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(b.x * inv, b.y * inv, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(b.z * inv, b.w * inv, hi, true);
+    return (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+template <int RT, int KTW, bool GAMMA>
+__global__ __launch_bounds__(256) void skinny_fp8_kernel(SkinnyF8Args p) {
+    static_assert(RT >= 1 && RT <= 4, "the final combine hands one row tile to each wave");
+    __shared__ __attribute__((aligned(16))) float red[4 * RT * 256];
+    __shared__ float ssq[4][16];
+    __shared__ float amx[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int ks = blockIdx.x % p.ksplit, rg = blockIdx.x / p.ksplit;
+    const int krange = p.K / p.ksplit, tiles = krange / 64;
+    const int t0 = wave * tiles / 4, t1 = (wave + 1) * tiles / 4;
+    const int kbase = ks * krange + t0 * 64 + g * 16;
+    const int n_base = rg * RT * 16;
+
+    u32x4 w[RT][KTW];
+    float4 xv[KTW][4], gv[GAMMA ? KTW : 1][4];
+    const unsigned char* wr[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) wr[rt] = p.W + (long long)min(n_base + rt * 16 + c, p.N - 1) * p.K + kbase;
+    const float* xp = p.x + (long long)min(c, p.nb - 1) * p.ldx + kbase;
+#pragma unroll
+    for (int t = 0; t < KTW; ++t) {
+        const bool ok = t0 + t < t1;
+        const int tt = ok ? t : 0;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr[rt] + tt * 64));
+            if (!ok) v = (u32x4){0u, 0u, 0u, 0u};
+            w[rt][t] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xv[t][j] = *reinterpret_cast<const float4*>(xp + tt * 64 + 4 * j);
+            if (!ok) xv[t][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (GAMMA) gv[t][j] = *reinterpret_cast<const float4*>(p.gamma + kbase + tt * 64 + 4 * j);
+        }
+    }
+    // statistics of this workgroup's K range per sequence: sum of squares (RMSNorm: the range is the whole row when gamma is set) and absmax of
+    // x * gamma (the fp8 scale)
+    float ss = 0.f, am = 0.f;
+#pragma unroll
+    for (int t = 0; t < KTW; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 a = xv[t][j];
+            ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+            if constexpr (GAMMA) { a.x *= gv[t][j].x; a.y *= gv[t][j].y; a.z *= gv[t][j].z; a.w *= gv[t][j].w; xv[t][j] = a; }
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+        }
+    ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+    am = fmaxf(am, __shfl_xor(am, 16)); am = fmaxf(am, __shfl_xor(am, 32));
+    if (g == 0) { ssq[wave][c] = ss; amx[wave][c] = am; }
+    __syncthreads();
+    const float amax = fmaxf(fmaxf(amx[0][c], amx[1][c]), fmaxf(amx[2][c], amx[3][c]));
+    const float sx = amax > 0.f ? amax / 448.f : 1.f;          // e4m3: largest finite value 448
+    const float inv = 1.f / sx;
+    v4f acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < KTW; ++t) {
+        if (t0 + t < t1) {                                              // wave-uniform
+            const long b0 = pack8_fp8(xv[t][0], xv[t][1], inv), b1 = pack8_fp8(xv[t][2], xv[t][3], inv);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const u32x4 u = w[rt][t];
+                const long a0 = (long)(((unsigned long long)u[1] << 32) | u[0]), a1 = (long)(((unsigned long long)u[3] << 32) | u[2]);
+                v4f a = acc[rt];
+                a = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, a, 0, 0, 0);
+                acc[rt] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<float4*>(&red[((wave * RT + rt) * 64 + lane) * 4]) = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
+    __syncthreads();
+    if (wave >= RT) return;
+    const int rt = wave;
+    float4 v = *reinterpret_cast<const float4*>(&red[(rt * 64 + lane) * 4]);
+#pragma unroll
+    for (int ww = 1; ww < 4; ++ww) {
+        const float4 o = *reinterpret_cast<const float4*>(&red[((ww * RT + rt) * 64 + lane) * 4]);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    const int n = n_base + rt * 16 + g * 4;
+    if (c >= p.nb || n >= p.N) return;
+    float sc = sx;
+    if constexpr (GAMMA) {
+        const float tot = (ssq[0][c] + ssq[1][c]) + (ssq[2][c] + ssq[3][c]);
+        sc = sx * rsqrtf(tot / (float)p.K + p.eps);
+    }
+    const float e[4] = {v.x * sc * p.wscale[min(n, p.N - 1)], v.y * sc * p.wscale[min(n + 1, p.N - 1)], v.z * sc * p.wscale[min(n + 2, p.N - 1)],
+                        v.w * sc * p.wscale[min(n + 3, p.N - 1)]};
+    if (p.mode == 1) {
+        const float2 o = make_float2((e[0] / (1.f + expf(-e[0]))) * e[1], (e[2] / (1.f + expf(-e[2]))) * e[3]);
+        *reinterpret_cast<float2*>(p.y + (long long)c * p.ldy + (n >> 1)) = o;
+    } else if (p.mode == 2) {
+        *reinterpret_cast<float4*>(p.y + ((long long)ks * p.nb + c) * p.ldy + n) = make_float4(e[0], e[1], e[2], e[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (n + i < p.N) {
+                float o = e[i];
+                if (p.bias) o += p.bias[n + i];
+                if (p.res) o += p.res[(long long)c * p.ldres + n + i];
+                p.y[(long long)c * p.ldy + n + i] = o;
+            }
+    }
+}
+
 // y[b][n] = res[b][n] + sum_ks part[ks][b][n]   (fixed order; the split-K combine of the down projection + residual)
 static __global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, int ksplit, int nb, int N, const float* res, long long ldres,
                                                                float* y, long long ldy) {

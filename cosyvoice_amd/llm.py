@@ -28,7 +28,7 @@ class SamplingC(C.Structure):
 
 def register_tensors(lib, set_fn, handle, tensors):
     for name, t in tensors.items():
-        dt = {torch.float32: 0, torch.bfloat16: 1, torch.int32: 2}[t.dtype]
+        dt = {torch.float32: 0, torch.bfloat16: 1, torch.int32: 2, torch.uint8: 3}[t.dtype]
         getattr(lib, set_fn)(handle, name.encode(), C.c_void_p(t.data_ptr()), C.c_int32(dt), C.c_int64(t.numel()))
 
 
@@ -37,7 +37,11 @@ class Qwen2LM:
     'greedy' (the sampler north-star parity is defined on)."""
 
     def __init__(self, state_dict, cfg, lib=None, max_len=2048, sampling="ras", top_p=0.8, top_k=25, win_size=10, tau_r=0.1,
-                 seed=1986, decode_chunk=16, use_graph=True, attn_splits=8):
+                 seed=1986, decode_chunk=16, use_graph=True, attn_splits=8, batch_fp8=False):
+        """batch_fp8 (opt-in, BASELINE.json configs[4] "fp8 MFMA LLM path"): the BATCHED decode (inference_batch / _queue / serve_stream) runs on OCP
+        e4m3 copies of the weight matrices (one fp32 scale per row) with the activations quantised per sequence in the kernel and
+        v_mfma_f32_16x16x32_fp8_fp8 products; prefill and the single-sequence path keep the bf16 weights.  Token ids are then no longer the fp32
+        oracle's - the mode is held to an oracle that mirrors the quantisation (tests/test_llm_fp8.py)."""
         self.lib = lib or get_lib()
         self.cfg = cfg
         self.device = torch.device(self.lib.device)
@@ -52,6 +56,8 @@ class Qwen2LM:
         self.max_len = max_len
         self.lock = threading.Lock()             # one KV cache per handle: requests on one object are serialised
         self._tensors, self._host = Wt.pack_llm(state_dict, cfg, self.device)
+        if batch_fp8:
+            self._tensors.update(Wt.quantize_llm_fp8(self._tensors, cfg))
         self._tensors = {k: self.lib.hook(v) for k, v in self._tensors.items()}
         self._host = {k: self.lib.hook(v) for k, v in self._host.items()}
         c = LLMConfigC(cfg.hidden, cfg.layers, cfg.heads, cfg.kv_heads, cfg.inter, cfg.speech_token_size + cfg.n_special, max_len, cfg.rms_eps, cfg.rope_theta)
@@ -61,6 +67,9 @@ class Qwen2LM:
         self.lib.cv_llm_finalize(self._h)
         self.lib.cv_llm_set_option(self._h, b"use_graph", C.c_int32(int(use_graph)))
         self.lib.cv_llm_set_option(self._h, b"attn_splits", C.c_int32(int(attn_splits)))   # key-range slices per head in decode attention
+        self.batch_fp8 = bool(batch_fp8)
+        if batch_fp8:
+            self.lib.cv_llm_set_option(self._h, b"batch_fp8", C.c_int32(1))
         self._uniforms = None
         self._request = 0
 

@@ -48,6 +48,27 @@ def pack_llm(sd, cfg, device):
     return out, host_only
 
 
+FP8_MAX = 448.0                        # largest finite OCP e4m3 value
+
+
+def quantize_fp8_rows(w):
+    """w [N, K] (any float dtype) -> (uint8 [N, K] of OCP e4m3 bit patterns, fp32 [N] scales): w ~= fp8 * scale[:, None], scale = rowwise absmax / 448,
+    round to nearest even (torch.float8_e4m3fn - the format gfx950's v_mfma_*_fp8_fp8 reads)."""
+    wf = w.float()
+    scale = wf.abs().amax(dim=1).clamp_min(1e-30) / FP8_MAX
+    q = (wf / scale[:, None]).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), scale.contiguous()
+
+
+def quantize_llm_fp8(packed, cfg):
+    """fp8 copies of the decode matrices of pack_llm()'s output ("<name>.f8" / "<name>.f8s"), for Qwen2LM(batch_fp8=True)."""
+    out = {}
+    names = ["head.w"] + ["layers.%d.%s" % (i, n) for i in range(cfg.layers) for n in ("wqkv", "wo", "wgu", "wdown")]
+    for n in names:
+        out[n + ".f8"], out[n + ".f8s"] = quantize_fp8_rows(packed[n])
+    return out
+
+
 def _lin(out, name, w, b, device, dtype):
     wp, _ = pack_weight(w.to(device).float(), dtype)
     out[name + ".w"] = wp

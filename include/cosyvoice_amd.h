@@ -22,7 +22,7 @@ typedef struct cv_llm cv_llm;
 typedef struct cv_flow cv_flow;
 typedef struct cv_hift cv_hift;
 
-enum { CV_F32 = 0, CV_BF16 = 1, CV_I32 = 2 };
+enum { CV_F32 = 0, CV_BF16 = 1, CV_I32 = 2, CV_U8 = 3 };      /* CV_U8: OCP fp8 e4m3 bit patterns (the opt-in fp8 weights of the batched LLM decode) */
 enum { CV_ACT_NONE = 0, CV_ACT_SILU = 1, CV_ACT_GELU_ERF = 2, CV_ACT_ELU = 3, CV_ACT_LEAKY = 4, CV_ACT_TANH = 5,
        CV_ACT_MISH = 6, CV_ACT_ABS = 7, CV_ACT_SNAKE = 8, CV_ACT_LOGCLAMP = 9 /* log(max(x, act_p)) */, CV_ACT_GELU_TANH = 10 };
 enum { CV_MASK_NONE = 0, CV_MASK_CAUSAL = 1, CV_MASK_CHUNK = 2 };
@@ -145,7 +145,15 @@ int cv_llm_batch_begin(cv_llm* m, int32_t nb, void* stream);
 int cv_llm_batch_prefill(cv_llm* m, int32_t slot, const float* lm_input, int32_t L0, const cv_sampling* sp, void* stream);
 int cv_llm_batch_prefill_many(cv_llm* m, int32_t n, const int32_t* slots, const float* rows, const int32_t* L0s, const cv_sampling* sps, void* stream);
 int cv_llm_batch_decode(cv_llm* m, int32_t n_steps, int32_t* out_tokens, int32_t* n_out, int32_t* finished, void* stream);
+/* Opt-in fp8 batched decode (BASELINE.json configs[4] "fp8 MFMA LLM path"; cv_llm_set_option(m, "batch_fp8", 1) after registering "<matrix>.f8"
+ * (CV_U8: OCP e4m3 bit patterns, same row-major layout as the bf16 matrix) and "<matrix>.f8s" (fp32 scale per row) for wqkv / wo / wgu / wdown of
+ * every layer and head.w).  cv_skinny_fp8 is the test hook of its one kernel: y[b][n] = epi(sum_k W8[n][k] * q(x[b][k] * gamma[k])) with the
+ * activations quantised per sequence inside the kernel; mode 0: + bias + res, 1: silu(gate) * up over interleaved rows, 2: split-K partials
+ * [ksplit][nb][N]; rt = row tiles (16 rows) per workgroup. */
+int cv_skinny_fp8(const void* w8, const float* wscale, const float* bias, const float* x, int64_t ldx, float* y, int64_t ldy, int32_t N, int32_t K,
+                  const float* gamma, float eps, const float* res, int64_t ldres, int32_t mode, int32_t nb, int32_t ksplit, int32_t rt, void* stream);
 int cv_llm_last_logits(cv_llm* m, float* host_out, void* stream);
+int cv_llm_batch_logits(cv_llm* m, int32_t slot, float* host_out, void* stream);      /* test hook: one slot's logits after the last batched step */
 int cv_llm_last_hidden(cv_llm* m, float* host_out, void* stream);
 /* out[r][:] = table[ids[r]][:] * scale  (nn.Embedding lookups that build lm_input / flow token embeddings) */
 int cv_gather_rows(const void* table, int32_t dtype, int64_t table_rows, int32_t dim, const int32_t* ids_dev, int32_t n, float* out, float scale, void* stream);

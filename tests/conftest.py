@@ -18,7 +18,7 @@ def pytest_cmdline_main(config):
         import xdist  # noqa: F401
     except ImportError:
         return None
-    if (config.getoption("markexpr", "") or "").strip() == "not gpu" and not getattr(config.option, "numprocesses", None) \
+    if (config.getoption("markexpr", "") or "").strip() == "not gpu" and getattr(config.option, "numprocesses", None) is None \
             and not os.environ.get("CV_TEST_SERIAL") and not os.environ.get("PYTEST_XDIST_WORKER"):
         config.option.numprocesses = 4
         config.option.dist = "loadfile"

@@ -260,6 +260,48 @@ emu_v4f emu_mfma_f32_16x16x32_bf16(emu_v8s a, emu_v8s b, emu_v4f c) {
     return out;
 }
 
+// ---- OCP fp8 e4m3 (the gfx950 format of v_cvt_pk_fp8_f32 / v_mfma_f32_16x16x32_fp8_fp8): 1 sign, 4 exponent (bias 7), 3 mantissa bits, no infinities,
+// 0x7f / 0xff = NaN, largest finite value 448
+float emu_fp8_to_f32(unsigned char v) {
+    const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
+    float r;
+    if (e == 15 && m == 7) r = NAN;
+    else if (e == 0) r = ldexpf((float)m / 8.0f, -6);
+    else r = ldexpf(1.0f + (float)m / 8.0f, e - 7);
+    return s ? -r : r;
+}
+unsigned char emu_f32_to_fp8(float x) {                       // round to nearest even, saturating to +-448
+    if (x != x) return 0x7f;
+    const unsigned char sign = std::signbit(x) ? 0x80 : 0;
+    const float a = fabsf(x);
+    if (a >= 448.0f) return sign | 0x7e;
+    int best = 0; float bd = a;                               // code 0 = +0
+    for (int code = 1; code <= 0x7e; ++code) {
+        const float d = fabsf(emu_fp8_to_f32((unsigned char)code) - a);
+        if (d < bd || (d == bd && (code & 1) == 0)) { bd = d; best = code; }
+    }
+    return sign | (unsigned char)best;
+}
+int emu_cvt_pk_fp8_f32(float a, float b, int old, bool word_sel) {
+    const unsigned pair = (unsigned)emu_f32_to_fp8(a) | ((unsigned)emu_f32_to_fp8(b) << 8);
+    const unsigned o = (unsigned)old;
+    return (int)(word_sel ? ((o & 0x0000ffffu) | (pair << 16)) : ((o & 0xffff0000u) | pair));
+}
+struct DepF8 { unsigned char a[8], b[8]; float c[4]; };
+emu_v4f emu_mfma_f32_16x16x32_fp8_fp8(long a, long b, emu_v4f c) {
+    DepF8 d; memcpy(d.a, &a, 8); memcpy(d.b, &b, 8); for (int i = 0; i < 4; ++i) d.c[i] = c[i];
+    char* base = (char*)emu::wave_exchange(&d, sizeof d);
+    int l = emu::lane_id();
+    emu_v4f out;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r, col = l & 15;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) acc += emu_fp8_to_f32(dep<DepF8>(base, row + 16 * (k >> 3)).a[k & 7]) * emu_fp8_to_f32(dep<DepF8>(base, col + 16 * (k >> 3)).b[k & 7]);
+        out[r] = acc;
+    }
+    return out;
+}
+
 emu_v16f emu_mfma_f32_32x32x16_bf16(emu_v8s a, emu_v8s b, emu_v16f c) {
     DepB16 d; for (int i = 0; i < 8; ++i) { d.a[i] = a[i]; d.b[i] = b[i]; } for (int i = 0; i < 16; ++i) d.c[i] = c[i];
     char* base = (char*)emu::wave_exchange(&d, sizeof d);

@@ -172,6 +172,10 @@ emu_v4f emu_mfma_f32_16x16x4f32(float a, float b, emu_v4f c);
 emu_v16f emu_mfma_f32_32x32x2f32(float a, float b, emu_v16f c);
 emu_v4f emu_mfma_f32_16x16x32_bf16(emu_v8s a, emu_v8s b, emu_v4f c);
 emu_v16f emu_mfma_f32_32x32x16_bf16(emu_v8s a, emu_v8s b, emu_v16f c);
+emu_v4f emu_mfma_f32_16x16x32_fp8_fp8(long a, long b, emu_v4f c);
+int emu_cvt_pk_fp8_f32(float a, float b, int old, bool word_sel);
+#define __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, x, y, z) emu_mfma_f32_16x16x32_fp8_fp8((a), (b), (c))
+#define __builtin_amdgcn_cvt_pk_fp8_f32(a, b, old, sel) emu_cvt_pk_fp8_f32((a), (b), (old), (sel))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_f32_16x16x4f32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_f32_32x32x2f32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_f32_16x16x32_bf16(__builtin_bit_cast(emu_v8s, (a)), __builtin_bit_cast(emu_v8s, (b)), (c))
