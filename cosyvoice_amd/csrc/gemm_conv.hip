@@ -44,9 +44,9 @@ void launch_gemm_conv(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t
     struct Cfg { int bm, bn; };
     static const Cfg cfgs[] = {{128, 128}, {128, 64}, {64, 64}, {32, 64}, {32, 32}, {16, 32}};
     // bf16 tiles are small (LDS and registers) and their launches are latency-bound: ask for ~3 co-resident workgroups per CU (A/B on MI355X: 240 -> 480 -> 720 -> 1024 minimum workgroups gave 238 -> 224 -> 221 -> 226 ms per utterance), so one
-    // workgroup's load wait overlaps another's LDS / MFMA phases; the fp32 tiles keep ~1 per CU.
+    // workgroup's load wait overlaps another's LDS / MFMA phases; the fp32 tiles ask for ~2 per CU.
     const bool bf16_path = a.a_bf16 && w_bf16 && a.a_vec;
-    long long min_blocks = bf16_path ? 720 : 240;
+    long long min_blocks = bf16_path ? 720 : 480;     // fp32 tiles: ~2 per CU (HiFT, 500 frames: 10.05 ms at 240, 8.66 at 480, 9.03 at 720, 9.23 at 1500: profiles/r2_batch_decode_ab.txt)
     // A tile taller than 32 rows may not pad M by more than 25 %: the LLM prefill of U10 has M = 131 = 128 + 3, and the 128-row tile ran half of its
     // workgroups on 3 useful rows (prefill 5.14 -> 4.38 ms with this rule; asking for more workgroups on top gave 4.2: profiles/r2_batch_decode_ab.txt).
     // CV_GEMM_MAX_WASTE / CV_GEMM_MIN_BLOCKS_F32: dev knobs for such sweeps, read at every launch.

@@ -39,7 +39,7 @@ static void hift_finalize(cv_hift* m) {
     const auto& c = m->cfg;
     CV_CHECK(c.n_ups >= 1 && c.n_ups <= 4 && c.n_res >= 1 && c.n_res <= 4 && c.n_dil >= 1 && c.n_dil <= 4, "hift: bad config counts");
     CV_CHECK(c.n_fft == 16 && c.hop == 4, "hift: the STFT/iSTFT kernels are specialised for n_fft 16 / hop 4 (cosyvoice2.yaml:100-102)");
-    CV_CHECK(c.harmonics + 1 <= 64, "hift: too many harmonics");
+    CV_CHECK(c.harmonics + 1 <= 16, "hift: at most 15 harmonics (hift_phase_kernel keeps 16 phase increments per frame in LDS)");
     m->scale = c.hop;
     for (int i = 0; i < c.n_ups; ++i) m->scale *= c.ups[i];
     int cin = c.mel;

@@ -20,21 +20,25 @@ static __global__ __launch_bounds__(256) void to_channel_last_kernel(const float
 // (torch.cumsum order).  f0 is piecewise constant over a frame, so the 1/480 linear down-interpolation of `rad` returns the
 // frame value exactly (and never samples t = 0, where rand_ini is added: the initial phase noise has no effect on this path).
 //   P[i][h] = ((cumsum_i( ((f0_i*(h+1))/sr) mod 1 ) * 2) * pi) * scale
-// The walk stays sequential per harmonic (the summation order is part of the result: the phase reaches thousands of radians), but f0 is staged
-// through LDS in coalesced chunks first - one dependent global load per frame made this kernel 59 us for 500 frames.
+// The walk stays sequential per harmonic (the summation order is part of the result: the phase reaches thousands of radians); what is parallel is
+// everything around it: f0 is fetched in coalesced chunks and the per-frame increment ((f0 * (h + 1)) / sr) mod 1 - the expensive part, fmodf - is
+// computed by all 256 threads into LDS, so the serial loop is one add and one store per frame (65 us -> a few us for 500 frames).
 static __global__ __launch_bounds__(256) void hift_phase_kernel(const float* f0, float* P, int m, int H, float sr, float scale) {
-    __shared__ float fs[1024];
+    constexpr int CH = 512;                                   // frames per chunk; H <= 16 harmonics
+    __shared__ float rad[CH * 16];
     const int h = threadIdx.x;
     float c = 0.f;
-    for (int base = 0; base < m; base += 1024) {
-        const int n = min(1024, m - base);
-        for (int i = threadIdx.x; i < n; i += 256) fs[i] = f0[base + i];
+    for (int base = 0; base < m; base += CH) {
+        const int n = min(CH, m - base);
+        for (int i = threadIdx.x; i < n * H; i += 256) {
+            const int fr = i / H, hh = i - fr * H;
+            const float fn = f0[base + fr] * (float)(hh + 1);
+            rad[fr * 16 + hh] = fmodf(fn / sr, 1.0f);
+        }
         __syncthreads();
         if (h < H)
             for (int i = 0; i < n; ++i) {
-                const float fn = fs[i] * (float)(h + 1);
-                const float rad = fmodf(fn / sr, 1.0f);
-                c += rad;
+                c += rad[i * 16 + h];
                 P[(long long)(base + i) * H + h] = ((c * 2.f) * CV_PI_F) * scale;
             }
         __syncthreads();
