@@ -60,7 +60,7 @@ struct cv_flow {
     int flow_tile = 0, attn_waves = 4, attn_kt = 1, attn_ks = 2;   // "attn_ks": key splits inside a 64-query workgroup (2 = 8 waves, 128 keys per iteration)
     DevBuf t_val, t_sin, t_h, t_emb, t_mlp;                                                   // time embeddings
     DevBuf f_tok, f_h, f_mu, f_spk, f_spkn, f_cond, f_x, f_ones;                              // inference glue
-    int enc_cap = 0, est_cap = 0, t_cap = 0, inf_cap = 0;
+    int enc_cap = 0, est_cap = 0, est_nz = 0, t_cap = 0, inf_cap = 0; long long inf_rows = 0;
     // hipGraph cache of the whole Euler solve, keyed by (T, n_steps, streaming): ~5000 launches per utterance become one replay.
     // A key is captured the second time it is seen (streaming requests change T every chunk and would only pay the instantiation).
     bool use_graph = true;
@@ -282,21 +282,23 @@ static void flow_encoder(cv_flow* m, const float* tok_emb, int T, const float* c
 // ---- estimator ---------------------------------------------------------------------------------------------------------
 static void drop_graphs(cv_flow* m) { std::lock_guard<std::recursive_mutex> lk(runtime_lock()); for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second); m->graphs.clear(); m->seen.clear(); }
 
-static void est_reserve(cv_flow* m, int T) {
-    if (T <= m->est_cap) return;
+// nz = batch rows of the estimator: 2 (the CFG pair of one utterance) or 2 x the utterances of a batched solve
+static void est_reserve(cv_flow* m, int T, int nz = 2) {
+    if (T <= m->est_cap && nz <= m->est_nz) return;
     drop_graphs(m);                       // captured kernels hold the old workspace addresses
-    const auto& c = m->cfg; const size_t R = 2 * (size_t)T, C = c.est_ch, f = 4;
+    T = std::max(T, m->est_cap); nz = std::max(nz, m->est_nz);
+    const auto& c = m->cfg; const size_t R = (size_t)nz * T, C = c.est_ch, f = 4;
     m->s_in.ensure(R * 4 * c.mel * f); m->s_a.ensure(R * C * f); m->s_b.ensure(R * C * f); m->s_c.ensure(R * C * f); m->s_n.ensure(R * C * f);
     m->s_qkv.ensure(R * 3 * c.est_heads * 64 * f); m->s_att.ensure(R * c.est_heads * 64 * f); m->s_ff.ensure(R * 4 * C * f);
     m->s_skip.ensure(R * C * f); m->s_cat.ensure(R * 2 * C * f); m->s_out.ensure(R * c.mel * f);
-    {   // bf16 activations of the fused pipeline; V^T is [2][heads * 64][pitch] and its never-written pad columns must stay finite (0 x P)
+    {   // bf16 activations of the fused pipeline; V^T is [nz][heads * 64][pitch] and its never-written pad columns must stay finite (0 x P)
         const size_t inner = (size_t)c.est_heads * 64, pitch = (size_t)(T + T / 2 + 63) / 64 * 64;
         m->h_qk.ensure(R * 2 * inner * 2); m->h_att.ensure(R * inner * 2); m->h_ff.ensure(R * 4 * C * 2);
         const size_t before = m->h_vt.bytes;
-        m->h_vt.ensure(2 * inner * pitch * 2);
-        if (m->h_vt.bytes != before) { CV_HIP(hipMemset(m->h_vt.p, 0, m->h_vt.bytes)); m->vt_pitch = (int)(m->h_vt.bytes / (2 * inner * 2) / 64 * 64); }
+        m->h_vt.ensure((size_t)nz * inner * pitch * 2);
+        if (m->h_vt.bytes != before || nz != m->est_nz) { CV_HIP(hipMemset(m->h_vt.p, 0, m->h_vt.bytes)); m->vt_pitch = (int)(m->h_vt.bytes / ((size_t)nz * inner * 2) / 64 * 64); }
     }
-    m->est_cap = T;
+    m->est_cap = T; m->est_nz = nz;
 }
 static void time_reserve(cv_flow* m, int n) {
     if (n <= m->t_cap) return;
@@ -367,8 +369,8 @@ static void attn_flow(const bf16_t* qk, int ld, int inner, const bf16_t* vt, lon
 // s_in: packed [2][T][4*mel]; t_row: which row of the time tables; t_shared: both CFG rows use the same row;
 // result in s_out [2][T][mel] (not masked).  Buffer discipline: a stage never writes the buffer it reads its input from
 // (res_conv re-reads the stage input after block1/block2), outputs ping-pong between s_a and s_c, s_b is scratch.
-static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bool t_shared, int streaming, hipStream_t s) {
-    const auto& c = m->cfg; const int C = c.est_ch, H = c.est_heads, inner = H * 64; const long long R = 2LL * T;
+static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bool t_shared, int streaming, hipStream_t s, int nz = 2) {
+    const auto& c = m->cfg; const int C = c.est_ch, H = c.est_heads, inner = H * 64; const long long R = (long long)nz * T;
     float* pp[2] = {m->s_a.as<float>(), m->s_c.as<float>()};
     float* xb = m->s_b.as<float>(); float* n = m->s_n.as<float>(); float* qkv = m->s_qkv.as<float>();
     float* att = m->s_att.as<float>(); float* ff = m->s_ff.as<float>(); float* skip = m->s_skip.as<float>(); float* cat = m->s_cat.as<float>();
@@ -382,18 +384,18 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
         const long long rpb = t_shared ? R : T;          // rows per time-embedding row
         float* x = pp[flip];                             // stage output (cur never aliases it)
         // CausalResnetBlock1D (decoder.py:65-85 + matcha ResnetBlock1D): block1 -> + mlp(t) -> block2 -> + res_conv(x)
-        conv_cl(st.res.conv1, cur, T, T, 2, 2, 1, x, ACT_NONE, 0.f, nullptr, s);
+        conv_cl(st.res.conv1, cur, T, T, nz, 2, 1, x, ACT_NONE, 0.f, nullptr, s);
         ln_rows(st.res.ln1, x, xb, R, C, 1e-5f, s, ACT_MISH, 1.f, tm, rpb);
-        conv_cl(st.res.conv2, xb, T, T, 2, 2, 1, x, ACT_NONE, 0.f, nullptr, s);
+        conv_cl(st.res.conv2, xb, T, T, nz, 2, 1, x, ACT_NONE, 0.f, nullptr, s);
         ln_rows(st.res.ln2, x, xb, R, C, 1e-5f, s, ACT_MISH);
-        conv_cl(st.res.res, cur, T, T, 2, 0, 1, x, ACT_NONE, 0.f, xb, s);           // x = res_conv(input) + h
+        conv_cl(st.res.res, cur, T, T, nz, 0, 1, x, ACT_NONE, 0.f, xb, s);           // x = res_conv(input) + h
         const bool fused = tl_bf16_mfma && m->fused && C <= 256 && m->wbf16;
         for (const TBlockW& t : st.tf) {      // matcha BasicTransformerBlock (self-attention + exact-erf GELU feed-forward)
             if (fused) {                      // flow_fused.h: 5 launches, bf16 activations, same rounding points as the path below
                 bf16_t* qk = m->h_qk.as<bf16_t>(); bf16_t* vt = m->h_vt.as<bf16_t>(); bf16_t* ab = m->h_att.as<bf16_t>(); bf16_t* fb = m->h_ff.as<bf16_t>();
                 const long long vt_batch = (long long)inner * m->vt_pitch;
                 ln_gemm_bf16(t.qkv, &t.norm1, 1e-5f, x, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
-                attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, 2, H, T, chunk, s);
+                attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s);
                 gemm_bf16_res(t.out, ab, inner, (int)R, x, x, s);
                 ln_gemm_bf16(t.ff1, &t.norm3, 1e-5f, x, (int)R, ACT_GELU_ERF, fb, 4 * C, 4 * C, nullptr, 0, 0, 0, s);
                 gemm_bf16_res(t.ff2, fb, 4 * C, (int)R, x, x, s);
@@ -406,7 +408,7 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
             at.k = qkv + inner; at.k_batch = at.q_batch; at.k_row = 3 * inner; at.k_head = 64;
             at.v = qkv + 2 * inner; at.v_batch = at.q_batch; at.v_row = 3 * inner; at.v_head = 64;
             at.o = att; at.o_batch = (long long)T * inner; at.o_row = inner; at.o_head = 64;
-            at.B = 2; at.H = H; at.kv_group = 1; at.Tq = T; at.Tk = T; at.scale = 0.125f;
+            at.B = nz; at.H = H; at.kv_group = 1; at.Tq = T; at.Tk = T; at.scale = 0.125f;
             at.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; at.chunk = chunk; at.rel_bd = nullptr;
             at.bf16 = tl_bf16_mfma;
             attention(at, s);
@@ -418,13 +420,13 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
         flip ^= 1;
         if (si == 0) {                         // keep the skip, then the stride-1 "downsample" CausalConv1d (decoder.py:452-453)
             CV_HIP(hipMemcpyAsync(skip, x, (size_t)R * C * 4, hipMemcpyDeviceToDevice, s));
-            conv_cl(m->down_conv, x, T, T, 2, 2, 1, pp[flip], ACT_NONE, 0.f, nullptr, s);
+            conv_cl(m->down_conv, x, T, T, nz, 2, 1, pp[flip], ACT_NONE, 0.f, nullptr, s);
             cur = pp[flip]; flip ^= 1;
         } else if (si == nst - 2) {            // last mid block: concat with the skip for the up block (decoder.py:476)
             hipLaunchKernelGGL(concat_cols_kernel, dim3(nblk(R * 2 * C)), dim3(256), 0, s, x, C, skip, C, cat, R);
             cur = cat;
         } else if (si == nst - 1) {            // up block's trailing CausalConv1d (decoder.py:490)
-            conv_cl(m->up_conv, x, T, T, 2, 2, 1, pp[flip], ACT_NONE, 0.f, nullptr, s);
+            conv_cl(m->up_conv, x, T, T, nz, 2, 1, pp[flip], ACT_NONE, 0.f, nullptr, s);
             cur = pp[flip]; flip ^= 1;
         } else {
             cur = x;
@@ -432,9 +434,9 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
     }
     // final_block (CausalBlock1D) + final_proj (decoder.py:492-494)
     float* y = pp[flip];
-    conv_cl(m->final_conv, cur, T, T, 2, 2, 1, y, ACT_NONE, 0.f, nullptr, s);
+    conv_cl(m->final_conv, cur, T, T, nz, 2, 1, y, ACT_NONE, 0.f, nullptr, s);
     ln_rows(m->final_ln, y, xb, R, C, 1e-5f, s, ACT_MISH);
-    conv_cl(m->final_proj, xb, T, T, 2, 0, 1, m->s_out.as<float>(), ACT_NONE, 0.f, nullptr, s);
+    conv_cl(m->final_proj, xb, T, T, nz, 0, 1, m->s_out.as<float>(), ACT_NONE, 0.f, nullptr, s);
 }
 
 
@@ -565,11 +567,14 @@ static void dit_front(cv_flow* m, const float* tok_emb, int n_enc, const float* 
 }
 
 // ---- solve_euler + inference -------------------------------------------------------------------------------------------
-static void solve_euler(cv_flow* m, float* x /*[T][mel] in/out*/, const float* mu, const float* spk, const float* cond, int T,
-                        int n_steps, int streaming, hipStream_t s) {
+// nu utterances of the same length solved together (x, mu, cond [nu][T][mel], spk [nu][mel]): the estimator sees 2 * nu batch rows, every GEMM
+// of a step runs once over all of them (same arithmetic per row as nu separate solves: rows never mix outside their own attention / conv window)
+static void solve_euler(cv_flow* m, float* x /*[nu][T][mel] in/out*/, const float* mu, const float* spk, const float* cond, int T,
+                        int n_steps, int streaming, hipStream_t s, int nu = 1) {
     const auto& c = m->cfg;
     const bool dit = c.estimator == 1;
-    if (dit) { dit_reserve(m, T); dit_time_reserve(m, n_steps); } else { est_reserve(m, T); time_reserve(m, n_steps); }
+    CV_CHECK(nu == 1 || !dit, "solve_euler: batched solves are built for the CausalConditionalDecoder estimator");
+    if (dit) { dit_reserve(m, T); dit_time_reserve(m, n_steps); } else { est_reserve(m, T, 2 * nu); time_reserve(m, n_steps); }
     // cosine schedule and the t / dt recurrences of solve_euler, in fp32 like torch (flow_matching.py:89-122, 223-226)
     std::vector<float> span(n_steps + 1), tv(n_steps), dts(n_steps);
     for (int i = 0; i <= n_steps; ++i) {
@@ -584,16 +589,16 @@ static void solve_euler(cv_flow* m, float* x /*[T][mel] in/out*/, const float* m
     }
     m->host_t = tv;                           // kept alive for the async copy
     CV_HIP(hipMemcpyAsync(m->t_val.p, m->host_t.data(), (size_t)n_steps * 4, hipMemcpyHostToDevice, s));
-    const long long n = (long long)T * c.mel;
+    const long long n = (long long)nu * T * c.mel;
     auto body = [&]() {
         if (dit) dit_time_embed(m, n_steps, s); else time_embed(m, n_steps, s);
         for (int st = 0; st < n_steps; ++st) {
-            hipLaunchKernelGGL(pack_est_input_kernel, dim3(nblk(2 * n * 4)), dim3(256), 0, s, x, mu, spk, cond, m->s_in.as<float>(), T, c.mel, 1);
-            if (dit) dit_forward(m, T, st, n_steps, true, streaming, s); else estimator_forward(m, T, st, n_steps, true, streaming, s);
+            hipLaunchKernelGGL(pack_est_input_kernel, dim3(nblk(2 * n * 4)), dim3(256), 0, s, x, mu, spk, cond, m->s_in.as<float>(), T, c.mel, 1, nu);
+            if (dit) dit_forward(m, T, st, n_steps, true, streaming, s); else estimator_forward(m, T, st, n_steps, true, streaming, s, 2 * nu);
             hipLaunchKernelGGL(cfg_euler_kernel, dim3(nblk(n)), dim3(256), 0, s, x, m->s_out.as<float>(), n, dts[st], c.cfg_rate);
         }
     };
-    const auto key = std::make_tuple(T, n_steps, streaming ? 1 : 0);
+    const auto key = std::make_tuple(T, n_steps, (streaming ? 1 : 0) + 2 * nu);
     auto it = m->graphs.find(key);
     if (m->use_graph && it != m->graphs.end() && x == m->f_x.as<float>()) {
         { std::lock_guard<std::recursive_mutex> lk(runtime_lock()); CV_HIP(hipGraphLaunch(it->second, s)); }
@@ -663,49 +668,71 @@ int cv_flow_estimator(cv_flow* m, const float* x, const float* mask, const float
         if (dit) { dit_reserve(m, T); dit_time_reserve(m, 2); } else { est_reserve(m, T); time_reserve(m, 2); }
         CV_HIP(hipMemcpyAsync(m->t_val.p, t, 8, hipMemcpyDeviceToDevice, s));
         if (dit) dit_time_embed(m, 2, s); else time_embed(m, 2, s);
-        hipLaunchKernelGGL(pack_est_input_kernel, dim3(nblk(2LL * T * 4 * c.mel)), dim3(256), 0, s, x, mu, spks, cond, m->s_in.as<float>(), T, c.mel, 0);
+        hipLaunchKernelGGL(pack_est_input_kernel, dim3(nblk(2LL * T * 4 * c.mel)), dim3(256), 0, s, x, mu, spks, cond, m->s_in.as<float>(), T, c.mel, 0, 1);
         if (dit) dit_forward(m, T, 0, 2, false, streaming, s); else estimator_forward(m, T, 0, 2, false, streaming, s);
         // `mask` must be all ones for the in-kernel (index-computed) attention masks to be exact; it is applied to the output
         hipLaunchKernelGGL(to_channel_first_kernel, dim3(nblk(2LL * T * c.mel)), dim3(256), 0, s, m->s_out.as<float>(), out, 2, T, c.mel, 0, mask);
     });
 }
 
+// nu utterances with the SAME token count and prompt length through one flow pass: x-vector projection, token embedding and encoder per utterance
+// (the encoder is ~8 % of the stage), the CFM Euler solve over all of them at once.  token_ids [nu][n_tok], prompt_feat [nu][mel_len1][mel],
+// embedding [nu][spk_dim], mel_out [nu][mel][T - mel_len1].  nu = 1 is cv_flow_inference.
+static void flow_inference(cv_flow* m, int nu, const int32_t* token_ids, int n_tok, const float* prompt_feat, int mel_len1, const float* embedding,
+                           const float* noise_cl, int streaming, int finalize, int n_timesteps, float* mel_out, int32_t* mel_len2_out, void* stream) {
+    PrecisionScope prec(m);
+    const auto& c = m->cfg; const int d = c.dim;
+    hipStream_t s = resolve(m, stream);
+    void* stream_r = reinterpret_cast<void*>(s);
+    const int n_enc = finalize ? n_tok : n_tok - c.pre_lookahead;
+    CV_CHECK(n_enc > 0 && n_timesteps > 0, "cv_flow_inference: too few tokens");
+    const int T = 2 * n_enc, mel_len2 = T - mel_len1;
+    CV_CHECK(mel_len2 > 0 && mel_len1 >= 0, "cv_flow_inference: prompt longer than the sequence");
+    CV_CHECK(nu >= 1 && nu <= 8 && (nu == 1 || c.estimator == 0), "cv_flow_inference_batch: 1..8 utterances (CausalConditionalDecoder estimator)");
+    if (n_tok > m->inf_cap || (long long)n_tok * nu > m->inf_rows) {        // per-utterance buffers follow n_tok, the stacked ones n_tok * nu
+        drop_graphs(m);
+        const size_t tk = (size_t)std::max(n_tok, m->inf_cap), rows = std::max((size_t)n_tok * nu, (size_t)m->inf_rows);
+        m->f_tok.ensure(tk * d * 4); m->f_h.ensure(2 * tk * d * 4);
+        m->f_mu.ensure(2 * rows * c.mel * 4); m->f_cond.ensure(2 * rows * c.mel * 4); m->f_x.ensure(2 * rows * c.mel * 4);
+        m->f_spk.ensure((size_t)8 * c.mel * 4); m->f_spkn.ensure((size_t)c.spk_dim * 4);
+        m->inf_cap = (int)tk; m->inf_rows = (long long)rows;
+    }
+    const size_t per = (size_t)T * c.mel;
+    for (int u = 0; u < nu; ++u) {
+        // x-vector: F.normalize -> Linear(192, 80)  (flow.py:248-249)
+        hipLaunchKernelGGL(l2_normalize_kernel, dim3(1), dim3(256), 0, s, embedding + (size_t)u * c.spk_dim, m->f_spkn.as<float>(), c.spk_dim);
+        lin_cl(m->spk_affine, m->f_spkn.as<float>(), 1, m->f_spk.as<float>() + (size_t)u * c.mel, ACT_NONE, nullptr, s);
+        // token embedding (mask is all ones for batch 1, flow.py:252-254); gather_rows_kernel lives in llm_kernels.h -> reuse via C ABI
+        CV_CHECK(cv_gather_rows(m->input_embedding, m->wbf16 ? CV_BF16 : CV_F32, c.vocab, d, token_ids + (size_t)u * n_tok, n_tok, m->f_tok.as<float>(), 1.f, stream_r) == 0, cv_last_error());
+        const float* ctx = finalize ? nullptr : m->f_tok.as<float>() + (size_t)n_enc * d;
+        float* mu = m->f_mu.as<float>() + u * per;
+        if (c.estimator == 1) dit_front(m, m->f_tok.as<float>(), n_enc, ctx, mu, s);
+        else {
+            flow_encoder(m, m->f_tok.as<float>(), n_enc, ctx, streaming, m->f_h.as<float>(), s);
+            lin_cl(m->enc_proj, m->f_h.as<float>(), T, mu, ACT_NONE, nullptr, s);
+        }
+        hipLaunchKernelGGL(copy_rows_zero_tail_kernel, dim3(nblk((long long)per)), dim3(256), 0, s, prompt_feat + (size_t)u * mel_len1 * c.mel, m->f_cond.as<float>() + u * per,
+                           (long long)mel_len1 * c.mel, (long long)per);
+        CV_HIP(hipMemcpyAsync(m->f_x.as<float>() + u * per, noise_cl, per * 4, hipMemcpyDeviceToDevice, s));       // every utterance starts from the same fixed noise
+    }
+    solve_euler(m, m->f_x.as<float>(), m->f_mu.as<float>(), m->f_spk.as<float>(), m->f_cond.as<float>(), T, n_timesteps, streaming, s, nu);
+    hipLaunchKernelGGL(to_channel_first_kernel, dim3(nblk((long long)nu * mel_len2 * c.mel)), dim3(256), 0, s, m->f_x.as<float>(), mel_out, nu, T, c.mel, mel_len1, (const float*)nullptr);
+    *mel_len2_out = mel_len2;
+}
+
 int cv_flow_inference(cv_flow* m, const int32_t* token_ids, int32_t n_tok, const float* prompt_feat, int32_t mel_len1, const float* embedding,
                       const float* noise_cl, int32_t streaming, int32_t finalize, int32_t n_timesteps, float* mel_out, int32_t* mel_len2_out, void* stream) {
     return guarded([&] {
         CV_CHECK(m && m->finalized && token_ids && embedding && noise_cl && mel_out && mel_len2_out, "cv_flow_inference: bad arguments");
-        PrecisionScope prec(m);
-        const auto& c = m->cfg; const int d = c.dim;
-        hipStream_t s = resolve(m, stream);
-        void* stream_r = reinterpret_cast<void*>(s);
-        const int n_enc = finalize ? n_tok : n_tok - c.pre_lookahead;
-        CV_CHECK(n_enc > 0 && n_timesteps > 0, "cv_flow_inference: too few tokens");
-        const int T = 2 * n_enc, mel_len2 = T - mel_len1;
-        CV_CHECK(mel_len2 > 0 && mel_len1 >= 0, "cv_flow_inference: prompt longer than the sequence");
-        if (n_tok > m->inf_cap) {
-            drop_graphs(m);
-            m->f_tok.ensure((size_t)n_tok * d * 4); m->f_h.ensure((size_t)2 * n_tok * d * 4); m->f_mu.ensure((size_t)2 * n_tok * c.mel * 4);
-            m->f_cond.ensure((size_t)2 * n_tok * c.mel * 4); m->f_x.ensure((size_t)2 * n_tok * c.mel * 4);
-            m->f_spk.ensure((size_t)c.mel * 4); m->f_spkn.ensure((size_t)c.spk_dim * 4);
-            m->inf_cap = n_tok;
-        }
-        // x-vector: F.normalize -> Linear(192, 80)  (flow.py:248-249)
-        hipLaunchKernelGGL(l2_normalize_kernel, dim3(1), dim3(256), 0, s, embedding, m->f_spkn.as<float>(), c.spk_dim);
-        lin_cl(m->spk_affine, m->f_spkn.as<float>(), 1, m->f_spk.as<float>(), ACT_NONE, nullptr, s);
-        // token embedding (mask is all ones for batch 1, flow.py:252-254); gather_rows_kernel lives in llm_kernels.h -> reuse via C ABI
-        CV_CHECK(cv_gather_rows(m->input_embedding, m->wbf16 ? CV_BF16 : CV_F32, c.vocab, d, token_ids, n_tok, m->f_tok.as<float>(), 1.f, stream_r) == 0, cv_last_error());
-        const float* ctx = finalize ? nullptr : m->f_tok.as<float>() + (size_t)n_enc * d;
-        if (c.estimator == 1) dit_front(m, m->f_tok.as<float>(), n_enc, ctx, m->f_mu.as<float>(), s);
-        else {
-            flow_encoder(m, m->f_tok.as<float>(), n_enc, ctx, streaming, m->f_h.as<float>(), s);
-            lin_cl(m->enc_proj, m->f_h.as<float>(), T, m->f_mu.as<float>(), ACT_NONE, nullptr, s);
-        }
-        hipLaunchKernelGGL(copy_rows_zero_tail_kernel, dim3(nblk((long long)T * c.mel)), dim3(256), 0, s, prompt_feat, m->f_cond.as<float>(),
-                           (long long)mel_len1 * c.mel, (long long)T * c.mel);
-        CV_HIP(hipMemcpyAsync(m->f_x.p, noise_cl, (size_t)T * c.mel * 4, hipMemcpyDeviceToDevice, s));
-        solve_euler(m, m->f_x.as<float>(), m->f_mu.as<float>(), m->f_spk.as<float>(), m->f_cond.as<float>(), T, n_timesteps, streaming, s);
-        hipLaunchKernelGGL(to_channel_first_kernel, dim3(nblk((long long)mel_len2 * c.mel)), dim3(256), 0, s, m->f_x.as<float>(), mel_out, 1, T, c.mel, mel_len1, (const float*)nullptr);
-        *mel_len2_out = mel_len2;
+        flow_inference(m, 1, token_ids, n_tok, prompt_feat, mel_len1, embedding, noise_cl, streaming, finalize, n_timesteps, mel_out, mel_len2_out, stream);
+    });
+}
+
+int cv_flow_inference_batch(cv_flow* m, int32_t n_utt, const int32_t* token_ids, int32_t n_tok, const float* prompt_feat, int32_t mel_len1, const float* embedding,
+                            const float* noise_cl, int32_t streaming, int32_t finalize, int32_t n_timesteps, float* mel_out, int32_t* mel_len2_out, void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && m->finalized && token_ids && embedding && noise_cl && mel_out && mel_len2_out, "cv_flow_inference_batch: bad arguments");
+        flow_inference(m, n_utt, token_ids, n_tok, prompt_feat, mel_len1, embedding, noise_cl, streaming, finalize, n_timesteps, mel_out, mel_len2_out, stream);
     });
 }
 

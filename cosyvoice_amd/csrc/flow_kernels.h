@@ -57,26 +57,29 @@ static __global__ __launch_bounds__(256) void time_sinusoid_kernel(const float* 
     }
 }
 
-// Estimator input  h[b][t][0:4*mel] = [x | mu | spks | cond]  (flow/decoder.py:425-431: pack([x, mu]), spks, cond)
-//   cl = 1: internal solve_euler form — x,mu,cond channel-last [T][mel], spks [mel]; batch row 1 gets zeros for mu/spks/cond
-//           (classifier-free guidance pair, flow_matching.py:101-108)
-//   cl = 0: API form (boundary B3) — x,mu,cond [2][mel][T], spks [2][mel]
+// Estimator input  h[z][t][0:4*mel] = [x | mu | spks | cond]  (flow/decoder.py:425-431: pack([x, mu]), spks, cond)
+//   cl = 1: internal solve_euler form - nu utterances of equal length: x, mu, cond channel-last [nu][T][mel], spks [nu][mel]; batch row
+//           z = g * nu + u is utterance u of the conditioned (g = 0) or unconditioned (g = 1: zeros for mu / spks / cond) half of the
+//           classifier-free guidance pair (flow_matching.py:101-108)
+//   cl = 0: API form (boundary B3, nu = 1) - x, mu, cond [2][mel][T], spks [2][mel]
 static __global__ __launch_bounds__(256) void pack_est_input_kernel(const float* x, const float* mu, const float* spks, const float* cond,
-                                                                     float* h, int T, int mel, int cl) {
+                                                                     float* h, int T, int mel, int cl, int nu) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long per = (long long)T * 4 * mel;
-    if (i >= 2 * per) return;
-    const int b = (int)(i / per);
+    if (i >= 2 * nu * per) return;
+    const int z = (int)(i / per);
     const long long r = i % per;
     const int t = (int)(r / (4 * mel)), c4 = (int)(r % (4 * mel)), seg = c4 / mel, c = c4 % mel;
     float v;
     if (cl) {
-        if (seg == 0) v = x[(long long)t * mel + c];
-        else if (b == 1) v = 0.f;
-        else v = seg == 1 ? mu[(long long)t * mel + c] : (seg == 2 ? spks[c] : cond[(long long)t * mel + c]);
+        const int g = z / nu, u = z % nu;
+        const long long tc = ((long long)u * T + t) * mel + c;
+        if (seg == 0) v = x[tc];
+        else if (g == 1) v = 0.f;
+        else v = seg == 1 ? mu[tc] : (seg == 2 ? spks[u * mel + c] : cond[tc]);
     } else {
-        const long long cf = ((long long)b * mel + c) * T + t;
-        v = seg == 0 ? x[cf] : (seg == 1 ? mu[cf] : (seg == 2 ? spks[b * mel + c] : cond[cf]));
+        const long long cf = ((long long)z * mel + c) * T + t;
+        v = seg == 0 ? x[cf] : (seg == 1 ? mu[cf] : (seg == 2 ? spks[z * mel + c] : cond[cf]));
     }
     h[i] = v;
 }

@@ -163,6 +163,37 @@ class CausalMaskedDiffWithXvec:
         return out, None
 
 
+    @torch.inference_mode()
+    def inference_batch(self, items, streaming=False, finalize=True):
+        """`items`: up to 8 dicts(token [1, n], prompt_token [1, p], prompt_feat [1, 2p', 80], embedding [1, spk]) of EQUAL shapes -> list of mel
+        [1, 80, 2 * n_new] tensors, each equal to what `inference()` returns for that item alone (flow/flow.py:246: "identical to running each
+        utterance alone" is the reference's own contract for its batched flow).  One pass: the CFM Euler solve runs once over all items
+        (estimator batch rows = 2 x items), so every GEMM of a step covers all of them."""
+        nu = len(items)
+        assert 1 <= nu <= 8
+        n_tok = int(items[0]["prompt_token"].shape[1] + items[0]["token"].shape[1])
+        mel_len1 = int(items[0]["prompt_feat"].shape[1])
+        assert all(int(it["prompt_token"].shape[1] + it["token"].shape[1]) == n_tok and int(it["prompt_feat"].shape[1]) == mel_len1 for it in items), "equal shapes only"
+        dev = self.device
+        ids = self.lib.hook(torch.stack([torch.cat([it["prompt_token"].reshape(-1).to(dev, torch.int32), it["token"].reshape(-1).to(dev, torch.int32)]).clamp(min=0)
+                                         for it in items]).contiguous())
+        pf = self.lib.hook(torch.stack([it["prompt_feat"].to(dev, torch.float32).reshape(mel_len1, -1) for it in items]).contiguous())
+        emb = self.lib.hook(torch.stack([it["embedding"].to(dev, torch.float32).reshape(-1) for it in items]).contiguous())
+        n_enc = n_tok if finalize else n_tok - self.pre_lookahead_len
+        mel_len2 = 2 * n_enc - mel_len1
+        if mel_len2 <= 0:
+            raise ValueError("no new frames to generate")
+        if 2 * n_enc > self._noise_cl.shape[0]:
+            raise ValueError("%d mel frames exceed the fixed CFM noise buffer (%d frames)" % (2 * n_enc, self._noise_cl.shape[0]))
+        out = self.lib.hook(torch.empty(nu, self.cfg.mel, mel_len2, dtype=torch.float32, device=dev))
+        got = C.c_int32(0)
+        self.lib.cv_flow_inference_batch(self._h, C.c_int32(nu), C.c_void_p(ids.data_ptr()), C.c_int32(n_tok), C.c_void_p(pf.data_ptr()) if mel_len1 else C.c_void_p(out.data_ptr()),
+                                         C.c_int32(mel_len1), C.c_void_p(emb.data_ptr()), C.c_void_p(self._noise_cl.data_ptr()), C.c_int32(int(streaming)),
+                                         C.c_int32(int(finalize)), C.c_int32(self.n_timesteps), C.c_void_p(out.data_ptr()), C.byref(got), stream_ptr(self.lib))
+        assert got.value == mel_len2
+        return [out[i:i + 1] for i in range(nu)]
+
+
 class CausalMaskedDiffWithDiT(CausalMaskedDiffWithXvec):
     """cosyvoice.flow.flow.CausalMaskedDiffWithDiT for inference (flow/flow.py:284-414; Fun-CosyVoice3): the same
     `inference(...)` surface and the same CFM solver (CausalConditionalCFM.solve_euler with classifier-free guidance), with PreLookaheadLayer +

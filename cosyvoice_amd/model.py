@@ -58,6 +58,7 @@ class CosyVoice2Model:
         # (cloned handles over the same weights, one HIP stream each) and concurrent token2wav calls then overlap on the GPU - the flow and
         # the vocoder are chains of small latency-bound kernels that leave most of the 256 CUs idle
         self.n_lanes, self._lane_q = 0, queue.Queue()
+        self.flow_batch = 4                    # offline batch paths (tts_batch / tts_queue): sequences of equal shape share one flow pass
         self.set_lanes(1)
         self.tts_speech_token_dict, self.llm_end_dict, self.hift_cache_dict, self._cond = {}, {}, {}, {}
         self._llm_error = {}                   # uuid -> exception raised on the LLM thread, re-raised by tts() on the caller's thread
@@ -221,39 +222,70 @@ class CosyVoice2Model:
                     tts_speech = self._fade(tts_speech, cache["speech"])
             return tts_speech
 
-    def _vocode_all(self, jobs, speed):
-        """jobs: iterable of (index, request, tokens) -> yields (index, {'tts_speech'}) as they complete; one worker thread per lane."""
-        def one(job):
-            i, r, toks = job
-            uid = str(uuid_mod.uuid1())
-            self.hift_cache_dict[uid] = None
-            try:
-                wav = self.token2wav(token=torch.tensor(toks).unsqueeze(0), prompt_token=r["flow_prompt_speech_token"], prompt_feat=r["prompt_speech_feat"],
-                                     embedding=r["flow_embedding"], token_offset=0, uuid=uid, finalize=True, speed=speed)
-                return i, {"tts_speech": wav.cpu()}
-            finally:
-                self.hift_cache_dict.pop(uid, None)
+    def _vocode_group(self, group, speed):
+        """Offline vocoding of one group of finished sequences [(index, request, tokens)] on ONE lane.  Groups of equal shape (token count, prompt
+        tokens, prompt frames) of a CosyVoice2 model go through the flow in one pass (CausalMaskedDiffWithXvec.inference_batch: the Euler solve
+        covers all of them, each result identical to the utterance alone), then through HiFT one by one."""
+        if len(group) == 1 or not hasattr(self.flow, "inference_batch") or self.flow.cfg.estimator == "dit" or type(self).token2wav is not CosyVoice2Model.token2wav:
+            outs = []
+            for i, r, toks in group:
+                uid = str(uuid_mod.uuid1())
+                self.hift_cache_dict[uid] = None
+                try:
+                    wav = self.token2wav(token=torch.tensor(toks).unsqueeze(0), prompt_token=r["flow_prompt_speech_token"], prompt_feat=r["prompt_speech_feat"],
+                                         embedding=r["flow_embedding"], token_offset=0, uuid=uid, finalize=True, speed=speed)
+                    outs.append((i, {"tts_speech": wav.cpu()}))
+                finally:
+                    self.hift_cache_dict.pop(uid, None)
+            return outs
+        with self._lane() as lane, torch.inference_mode():
+            toks_t = [torch.tensor(toks, dtype=torch.int32).unsqueeze(0) for _, _, toks in group]
+            mels = lane.flow.inference_batch([dict(token=t, prompt_token=r["flow_prompt_speech_token"], prompt_feat=r["prompt_speech_feat"], embedding=r["flow_embedding"])
+                                              for (_, r, _), t in zip(group, toks_t)], streaming=False, finalize=True)
+            outs = []
+            for (i, r, _), t, mel in zip(group, toks_t, mels):
+                if speed != 1.0:
+                    tn = int(mel.shape[2] / speed)
+                    src = mel.contiguous()
+                    dst = torch.empty(1, src.shape[1], tn, dtype=torch.float32, device=self.device)
+                    self.lib.cv_interp_linear(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_int32(src.shape[1]), C.c_int32(src.shape[2]), C.c_int32(tn), stream_ptr(self.lib))
+                    mel = dst
+                lane.hift._next_seed = self._noise_key(t, 0)
+                speech, _ = lane.hift.inference(speech_feat=mel, cache_source=torch.zeros(1, 1, 0))
+                outs.append((i, {"tts_speech": speech.cpu()}))
+            return outs
+
+    def _vocode_all(self, job_lists, speed):
+        """job_lists: iterable of lists of (index, request, tokens) - each list holds the sequences that became available together; yields
+        (index, {'tts_speech'}) as they complete.  A list is cut into groups of up to `flow_batch` sequences of equal shape; the groups run on
+        the token2wav lanes, one worker thread per lane."""
+        def groups(jobs):
+            by_shape = {}
+            for j in jobs:
+                r = j[1]
+                by_shape.setdefault((len(j[2]), int(r["flow_prompt_speech_token"].shape[1]), int(r["prompt_speech_feat"].shape[1])), []).append(j)
+            for same in by_shape.values():
+                for k in range(0, len(same), max(1, self.flow_batch)):
+                    yield same[k:k + max(1, self.flow_batch)]
         if self.n_lanes == 1:
-            for job in jobs:
-                yield one(job)
+            for jobs in job_lists:
+                for grp in groups(jobs):
+                    yield from self._vocode_group(grp, speed)
             return
         from concurrent.futures import ThreadPoolExecutor, FIRST_COMPLETED, wait
         with ThreadPoolExecutor(max_workers=self.n_lanes) as ex:
             pending = set()
-            for job in jobs:                                    # `jobs` may block (tts_queue: tokens arrive from the LM thread)
-                pending.add(ex.submit(one, job))
-                while len(pending) >= 2 * self.n_lanes:
-                    done, pending = wait(pending, return_when=FIRST_COMPLETED)
-                    for f in done:
-                        yield f.result()
+            for jobs in job_lists:                              # may block (tts_queue: tokens arrive from the LM thread)
+                for grp in groups(jobs):
+                    pending.add(ex.submit(self._vocode_group, grp, speed))
                 done = {f for f in pending if f.done()}
                 pending -= done
                 for f in done:
-                    yield f.result()
+                    yield from f.result()
             while pending:
                 done, pending = wait(pending, return_when=FIRST_COMPLETED)
                 for f in done:
-                    yield f.result()
+                    yield from f.result()
 
     def tts_batch(self, requests, speed=1.0):
         """Offline synthesis of up to 16 requests (dicts with the keyword arguments of tts()): the speech-token LM runs lock-step
@@ -266,7 +298,7 @@ class CosyVoice2Model:
         if self.device.type == "cuda":
             self.llm_stream.synchronize()
         outs = [None] * len(requests)
-        for i, o in self._vocode_all(((i, r, toks) for i, (r, toks) in enumerate(zip(requests, tokens))), speed):
+        for i, o in self._vocode_all([[(i, r, toks) for i, (r, toks) in enumerate(zip(requests, tokens))]], speed):
             outs[i] = o
         return outs
 
@@ -292,15 +324,25 @@ class CosyVoice2Model:
         th = threading.Thread(target=produce, daemon=True)
         th.start()
 
-        def finished():
-            while True:
-                item = q.get()
-                if item is None:
-                    return
-                if isinstance(item, BaseException):
-                    raise item
-                i, toks = item
-                yield i, requests[i], toks
+        def finished():                                        # lists of the sequences that finished together (the same decode chunk)
+            closed = False
+            while not closed:
+                items = [q.get()]
+                while True:
+                    try:
+                        items.append(q.get_nowait())
+                    except queue.Empty:
+                        break
+                jobs = []
+                for item in items:
+                    if item is None:
+                        closed = True
+                    elif isinstance(item, BaseException):
+                        raise item
+                    else:
+                        jobs.append((item[0], requests[item[0]], item[1]))
+                if jobs:
+                    yield jobs
 
         try:
             yield from self._vocode_all(finished(), speed)

@@ -188,6 +188,12 @@ int cv_flow_estimator(cv_flow* m, const float* x, const float* mask, const float
  * transposed to channel-last; mel_out: dev [80, T - mel_len1] (channel-first like the reference). */
 int cv_flow_inference(cv_flow* m, const int32_t* token_ids, int32_t n_tok, const float* prompt_feat, int32_t mel_len1, const float* embedding,
                       const float* noise_cl, int32_t streaming, int32_t finalize, int32_t n_timesteps, float* mel_out, int32_t* mel_len2_out, void* stream);
+/* The same for n_utt (1..8) utterances of EQUAL shape (token count, prompt frames) in one pass: token_ids dev [n_utt][n_tok], prompt_feat dev
+ * [n_utt][mel_len1][80], embedding dev [n_utt][spk_dim], mel_out dev [n_utt][80][T - mel_len1].  The encoder runs per utterance, the CFM Euler solve
+ * once over all of them (estimator batch rows = 2 x n_utt); each utterance's result is what cv_flow_inference gives for it alone
+ * (the reference's own contract for batched flow, flow/flow.py:246).  CausalConditionalDecoder estimator only. */
+int cv_flow_inference_batch(cv_flow* m, int32_t n_utt, const int32_t* token_ids, int32_t n_tok, const float* prompt_feat, int32_t mel_len1, const float* embedding,
+                            const float* noise_cl, int32_t streaming, int32_t finalize, int32_t n_timesteps, float* mel_out, int32_t* mel_len2_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Stage B6 — HiFT vocoder.  Weight names: cosyvoice_amd/weights.py:pack_hift (weight-norm folded, fp32).

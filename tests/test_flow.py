@@ -301,3 +301,40 @@ def test_fused_transformer_blocks_match_unfused(lib, tile, waves, kt, ks):
             assert torch.isfinite(outs[1]).all()
             assert e_fu.mean().item() < 1.3 * e_un.mean().item() + 1e-5 and e_fu.max().item() < 1.6 * e_un.max().item() + 1e-4, \
                 (T, streaming, e_fu.mean().item(), e_un.mean().item(), e_fu.max().item(), e_un.max().item())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_flow_inference_batch_equals_single(lib, precision):
+    """cv_flow_inference_batch: utterances of equal shape solved in one pass (estimator batch rows = 2 x utterances) give, each, exactly the mel
+    `inference()` gives for it alone - the reference's contract for batched flow (flow/flow.py:246)."""
+    import dataclasses
+    cfg = dataclasses.replace(W.tiny()[1], n_timesteps=2)
+    sd = W.make_flow(cfg)
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision=precision)
+    g = torch.Generator().manual_seed(71)
+    n = lambda k: torch.tensor([k], dtype=torch.int32)
+    items = []
+    for _ in range(3):
+        items.append(dict(token=torch.randint(0, cfg.vocab, (1, 9), generator=g, dtype=torch.int32), prompt_token=torch.randint(0, cfg.vocab, (1, 5), generator=g, dtype=torch.int32),
+                          prompt_feat=torch.randn(1, 10, cfg.mel, generator=g) * 2 - 5, embedding=torch.randn(1, cfg.spk_dim, generator=g)))
+    alone = [flow.inference(token=it["token"], token_len=n(9), prompt_token=it["prompt_token"], prompt_token_len=n(5), prompt_feat=it["prompt_feat"],
+                            prompt_feat_len=n(10), embedding=it["embedding"], streaming=False, finalize=True)[0].cpu() for it in items]
+    assert not torch.equal(alone[0], alone[1])
+    for rep in range(3):                                          # the third call replays the captured graph of the batched solve
+        got = flow.inference_batch(items)
+        for a, b in zip(alone, got):
+            assert torch.equal(a, b.cpu())
+    got2 = flow.inference_batch(items[1:])                        # another batch size on the same handle, then the single path again
+    assert torch.equal(alone[2], got2[1].cpu())
+    again = flow.inference(token=items[0]["token"], token_len=n(9), prompt_token=items[0]["prompt_token"], prompt_token_len=n(5), prompt_feat=items[0]["prompt_feat"],
+                           prompt_feat_len=n(10), embedding=items[0]["embedding"], streaming=False, finalize=True)[0].cpu()
+    assert torch.equal(again, alone[0])
+    # a LONGER single request on the handle that served batches: the per-utterance buffers must follow its token count, not the batch's row count
+    tok_long = torch.randint(0, cfg.vocab, (1, 9 * 3), generator=g, dtype=torch.int32)
+    it = items[0]
+    long1 = flow.inference(token=tok_long, token_len=n(27), prompt_token=it["prompt_token"], prompt_token_len=n(5), prompt_feat=it["prompt_feat"], prompt_feat_len=n(10),
+                           embedding=it["embedding"], streaming=False, finalize=True)[0].cpu()
+    fresh = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision=precision)
+    long2 = fresh.inference(token=tok_long, token_len=n(27), prompt_token=it["prompt_token"], prompt_token_len=n(5), prompt_feat=it["prompt_feat"], prompt_feat_len=n(10),
+                            embedding=it["embedding"], streaming=False, finalize=True)[0].cpu()
+    assert torch.equal(long1, long2)

@@ -145,6 +145,31 @@ def test_token2wav_lanes(lib, setup):
     assert not m.hift_cache_dict and m._lane_q.qsize() == 2
 
 
+def test_tts_batch_shares_one_flow_pass_between_equal_shapes(lib, setup):
+    """tts_batch groups finished sequences of equal shape (token count, prompt tokens, prompt frames) into ONE flow pass
+    (CausalMaskedDiffWithXvec.inference_batch, cv_flow_inference_batch); every waveform must equal tts() of that request alone bit for bit."""
+    cfgs, sds, u = setup
+    lc, fc, hc = cfgs
+    fc1 = dataclasses.replace(fc, n_timesteps=1)
+    m = CosyVoice2Model.from_state_dicts(sds[0], sds[1], sds[2], (lc, fc1, hc), lib=lib, max_len=160, sampling="greedy")
+    inf_b, inf_1 = m.llm.inference_batch, m.llm.inference
+    m.llm.inference_batch = lambda reqs: inf_b(reqs, max_token_text_ratio=3, min_token_text_ratio=3)      # 6 tokens each: equal shapes
+    m.llm.inference = lambda **kw: inf_1(**{**kw, "max_token_text_ratio": 3, "min_token_text_ratio": 3})
+    us = [W.synthetic_utterance(lc, fc, n_prompt_tok=6, n_prompt_text=2, n_text=2, seed=80 + i) for i in range(3)]
+    keys = ("text", "flow_embedding", "llm_embedding", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat")
+    reqs = [{k: x[k] for k in keys} for x in us]
+    calls = []
+    fb = m.flow.inference_batch
+    m.flow.inference_batch = lambda items, **kw: (calls.append(len(items)), fb(items, **kw))[1]
+    got = m.tts_batch(reqs)
+    lens = [g["tts_speech"].shape[1] for g in got]
+    assert sum(calls) >= 2 and sorted(calls) == sorted(n for n in (lens.count(v) for v in set(lens)) if n > 1)      # equal shapes shared a pass (a stop id other than eos may end a sequence early)
+    alone = [next(iter(m.tts(**r, stream=False)))["tts_speech"] for r in reqs]
+    for a, g in zip(alone, got):
+        assert torch.equal(a, g["tts_speech"])
+    assert not torch.equal(alone[0], alone[1]) and not m.hift_cache_dict
+
+
 def test_llm_job_silent_token_filter(lib, setup):
     """cli/model.py:101-129: tokens listed in `silent_tokens` (CosyVoice3: FSQ silence / breath ids, :423) are kept for the first
     5 consecutive occurrences and dropped beyond that; any other token resets the run.  Host logic, driven with a stub generator."""
