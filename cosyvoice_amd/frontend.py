@@ -91,3 +91,159 @@ class MelSpectrogram:
     def __call__(self, y):
         """matcha's contract: [B = 1, L] -> [1, n_mels, T]."""
         return self.frames(y).t().unsqueeze(0)
+
+
+# -----------------------------------------------------------------------------------------------------------------------------------
+# SURVEY.md section 8f item 2: the feature front ends of the two ONNX extractors (cosyvoice/cli/frontend.py:95-118)
+# -----------------------------------------------------------------------------------------------------------------------------------
+def _dft_basis(n_fft, n_in, kp, op=None):
+    """[2 bins][kp] float32: rows = (cos | -sin) of an n_fft-point DFT over the first n_in samples, right-multiplied by the n_in x n_in operator
+    `op` (float64; window, pre-emphasis, ...) that the reference applies to every frame before the FFT; columns >= n_in are zero."""
+    bins = n_fft // 2 + 1
+    ang = 2.0 * np.pi * np.outer(np.arange(bins, dtype=np.float64), np.arange(n_in, dtype=np.float64)) / n_fft
+    f = np.concatenate([np.cos(ang), -np.sin(ang)], 0)
+    if op is not None:
+        f = f @ op
+    out = np.zeros((2 * bins, kp), dtype=np.float32)
+    out[:, :n_in] = f.astype(np.float32)
+    return out
+
+
+class _FramedSpectrum:
+    """Shared device pipeline: frames of `win` samples every `hop` samples of a 1-D signal -> power spectrum of an n_fft-point DFT -> filterbank
+    with log(max(., floor)).  The framing is the strided A operand of ONE exact-fp32 MFMA GEMM (lda = hop, K = win padded to 32), the filterbank
+    a second one; no FFT library, nothing leaves the device."""
+
+    def _setup(self, lib, n_fft, win, hop, basis_op, bank, floor):
+        self.lib = lib or get_lib()
+        self.device = torch.device(self.lib.device)
+        self.n_fft, self.win, self.hop, self.bins, self.floor = n_fft, win, hop, n_fft // 2 + 1, floor
+        self.kp = ops.round_up(win, 32)
+        self._dft = self.lib.hook(torch.from_numpy(_dft_basis(n_fft, win, self.kp, basis_op)).to(self.device).contiguous())
+        self.ldm = ops.round_up(self.bins, 32)
+        self.n_out = bank.shape[0]
+        b = np.zeros((self.n_out, self.ldm), dtype=np.float32)
+        b[:, :bank.shape[1]] = bank
+        self._bank = self.lib.hook(torch.from_numpy(b).to(self.device).contiguous())
+
+    def _log_bank(self, sig, T):
+        """sig: device fp32 signal holding at least (T - 1) * hop + kp samples -> [T, n_out] = log(max(bank @ |DFT(frame)|^2, floor))."""
+        lib, st = self.lib, stream_ptr(self.lib)
+        assert sig.numel() >= (T - 1) * self.hop + self.kp
+        spec = lib.hook(torch.empty(T, 2 * self.bins, dtype=torch.float32, device=self.device))
+        ops.gemm_conv(lib, sig, self._dft, self.kp, M=T, N=2 * self.bins, K=self.kp, lda=self.hop, a_len=sig.numel(), out=spec)
+        pw = lib.hook(torch.empty(T, self.ldm, dtype=torch.float32, device=self.device))
+        lib.cv_stft_power(C.c_void_p(spec.data_ptr()), C.c_void_p(pw.data_ptr()), C.c_int32(T), C.c_int32(self.bins), C.c_int32(self.ldm), st)
+        out = lib.hook(torch.empty(T, self.n_out, dtype=torch.float32, device=self.device))
+        ops.gemm_conv(lib, pw, self._bank, self.ldm, M=T, N=self.n_out, K=self.ldm, out=out, act="logclamp", act_p=self.floor)
+        return out
+
+
+class WhisperLogMel(_FramedSpectrum):
+    """`whisper.log_mel_spectrogram(speech, n_mels=128)` as `_extract_speech_token` calls it (cli/frontend.py:98): 16 kHz, n_fft 400, hop 160,
+    periodic Hann, torch.stft(center=True) = reflect padding by 200, the last frame dropped, |.|^2, librosa mel bank (Slaney, 128), log10 with a
+    1e-10 floor, dynamic range clipped 8 below the utterance maximum, (x + 4) / 4.  Returns [1, n_mels, L // 160] on the device - the
+    `feat` the speech-tokenizer session is fed."""
+
+    def __init__(self, n_mels=128, lib=None):
+        n = np.arange(400, dtype=np.float64)
+        self.n_mels = n_mels
+        self._setup(lib, 400, 400, 160, np.diag(0.5 - 0.5 * np.cos(2.0 * np.pi * n / 400)), mel_filterbank(16000, 400, n_mels, 0.0, None), 1e-10)
+
+    @torch.inference_mode()
+    def __call__(self, speech):
+        lib, st = self.lib, stream_ptr(self.lib)
+        y = lib.hook(speech.reshape(-1).to(self.device, torch.float32).contiguous())
+        L = y.numel()
+        T = L // self.hop                                            # 1 + L // hop frames of the centred STFT, minus the dropped last one
+        if T <= 0 or L <= 200:
+            raise ValueError("waveform too short (%d samples)" % L)
+        yp = lib.hook(torch.zeros(L + 400 + (self.kp - self.win), dtype=torch.float32, device=self.device))
+        lib.cv_reflect_pad(C.c_void_p(y.data_ptr()), C.c_void_p(yp.data_ptr()), C.c_int32(L), C.c_int32(200), st)
+        ln = self._log_bank(yp, T)
+        out = lib.hook(torch.empty(self.n_mels, T, dtype=torch.float32, device=self.device))
+        lib.cv_whisper_lognorm(C.c_void_p(ln.data_ptr()), C.c_void_p(out.data_ptr()), C.c_int32(T), C.c_int32(self.n_mels), st)
+        return out.unsqueeze(0)
+
+
+def kaldi_mel_banks(num_bins, padded_window, sample_freq, low_freq, high_freq):
+    """torchaudio.compliance.kaldi.get_mel_banks (vtln_warp 1.0): triangles on the HTK-style scale 1127 ln(1 + f / 700), evaluated in the mel
+    domain, over the first padded_window / 2 FFT bins; one zero column appended for the Nyquist bin (kaldi.fbank pads it the same way)."""
+    nfb = padded_window // 2
+    nyq = 0.5 * sample_freq
+    if high_freq <= 0.0:
+        high_freq += nyq
+    mel = lambda f: 1127.0 * np.log(1.0 + np.asarray(f, dtype=np.float64) / 700.0)
+    lo, hi = mel(low_freq), mel(high_freq)
+    delta = (hi - lo) / (num_bins + 1)
+    b = np.arange(num_bins, dtype=np.float64)[:, None]
+    left, center, right = lo + b * delta, lo + (b + 1.0) * delta, lo + (b + 2.0) * delta
+    m = mel(sample_freq / padded_window * np.arange(nfb, dtype=np.float64))[None, :]
+    w = np.maximum(0.0, np.minimum((m - left) / (center - left), (right - m) / (right - center)))
+    return np.concatenate([w, np.zeros((num_bins, 1))], 1).astype(np.float32)
+
+
+class KaldiFbank(_FramedSpectrum):
+    """`torchaudio.compliance.kaldi.fbank(speech, num_mel_bins=80, dither=0, sample_frequency=16000)` (cli/frontend.py:109-112) with the
+    remaining arguments at their defaults: 25 ms frames every 10 ms with snip_edges, DC removal, pre-emphasis 0.97 (first sample against
+    itself), Povey window, zero padding to 512, power spectrum, 80 triangular mel bins from 20 Hz to Nyquist, log with a float32-epsilon floor.
+    DC removal, pre-emphasis and window are linear maps of a frame: they are folded (in float64) into the DFT basis, so a frame costs one
+    row of the STFT GEMM.  `__call__` -> [T, 80]; `cmn=True` subtracts the mean over frames (frontend.py:113), the CAM++ session's input."""
+
+    def __init__(self, num_mel_bins=80, sample_frequency=16000, frame_length=25.0, frame_shift=10.0, preemphasis_coefficient=0.97,
+                 low_freq=20.0, high_freq=0.0, lib=None):
+        win, hop = int(sample_frequency * frame_length * 0.001), int(sample_frequency * frame_shift * 0.001)
+        n_fft = 1 << (win - 1).bit_length()                         # round_to_power_of_two
+        dc = np.eye(win) - np.full((win, win), 1.0 / win)            # remove_dc_offset
+        pre = np.eye(win) - preemphasis_coefficient * np.eye(win, k=-1)
+        pre[0, 0] -= preemphasis_coefficient                         # replicate padding: x[0] - c x[0]
+        povey = (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win, dtype=np.float64) / (win - 1))) ** 0.85
+        self.num_mel_bins = num_mel_bins
+        self._setup(lib, n_fft, win, hop, np.diag(povey) @ pre @ dc, kaldi_mel_banks(num_mel_bins, n_fft, sample_frequency, low_freq, high_freq),
+                    float(np.finfo(np.float32).eps))
+
+    @torch.inference_mode()
+    def __call__(self, speech, cmn=False):
+        lib = self.lib
+        y = speech.reshape(-1).to(self.device, torch.float32)
+        L = y.numel()
+        if L < self.win:
+            return torch.empty(0, self.num_mel_bins, device=self.device)          # kaldi: fewer samples than one frame -> no frames
+        T = 1 + (L - self.win) // self.hop
+        sig = lib.hook(torch.zeros(L + (self.kp - self.win), dtype=torch.float32, device=self.device))
+        sig[:L] = y
+        out = self._log_bank(sig, T)
+        if cmn:
+            lib.cv_sub_col_mean(C.c_void_p(out.data_ptr()), C.c_int32(T), C.c_int32(self.num_mel_bins), stream_ptr(lib))
+        return out
+
+
+class PromptExtractors:
+    """The three prompt extractors of `CosyVoiceFrontEnd` (cosyvoice/cli/frontend.py:95-125) with their signal processing on the device and the
+    two ONNX networks left where the reference has them: `speech_tokenizer_session` / `campplus_session` are onnxruntime.InferenceSession objects
+    (anything with `.get_inputs()` and `.run(None, feeds)`) the caller creates exactly as frontend.py:42-48 does.  The methods take the decoded
+    waveform ([1, L] float in [-1, 1], 16 kHz for the first two, the flow's rate for the third) instead of a path - `load_wav` (torchaudio file
+    decoding + resampling) is the caller's."""
+
+    def __init__(self, feat_extractor, campplus_session, speech_tokenizer_session, lib=None):
+        self.lib = lib or get_lib()
+        self.device = torch.device(self.lib.device)
+        self.feat_extractor, self.campplus_session, self.speech_tokenizer_session = feat_extractor, campplus_session, speech_tokenizer_session
+        self.whisper_mel, self.fbank = WhisperLogMel(128, lib=self.lib), KaldiFbank(80, 16000, lib=self.lib)
+
+    def _extract_speech_token(self, speech):
+        assert speech.shape[1] / 16000 <= 30, 'do not support extract speech token for audio longer than 30s'
+        feat = self.whisper_mel(speech)
+        ins = self.speech_tokenizer_session.get_inputs()
+        tok = self.speech_tokenizer_session.run(None, {ins[0].name: feat.cpu().numpy(), ins[1].name: np.array([feat.shape[2]], dtype=np.int32)})[0].flatten().tolist()
+        speech_token = torch.tensor([tok], dtype=torch.int32).to(self.device)
+        return speech_token, torch.tensor([speech_token.shape[1]], dtype=torch.int32).to(self.device)
+
+    def _extract_spk_embedding(self, speech):
+        feat = self.fbank(speech, cmn=True)
+        emb = self.campplus_session.run(None, {self.campplus_session.get_inputs()[0].name: feat.unsqueeze(dim=0).cpu().numpy()})[0].flatten().tolist()
+        return torch.tensor([emb]).to(self.device)
+
+    def _extract_speech_feat(self, speech):
+        speech_feat = self.feat_extractor(speech).squeeze(dim=0).transpose(0, 1).to(self.device).unsqueeze(dim=0)
+        return speech_feat, torch.tensor([speech_feat.shape[1]], dtype=torch.int32).to(self.device)

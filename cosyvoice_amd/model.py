@@ -8,6 +8,7 @@ Differences that are deliberate:
 """
 import ctypes as C
 import queue
+import os
 import threading
 import zlib
 from types import GeneratorType
@@ -29,6 +30,8 @@ class _Lane:
     __slots__ = ("flow", "hift", "stream")
 
     def __init__(self, flow, hift, stream):
+        # all lanes at normal priority: putting FIRST chunks on a high-priority stream (the LM's level) starves the LM decode chain - at 8
+        # streaming clients the time until a request's first 41 tokens exist went 94 -> 243 ms (profiles/r2_first_chunk_priority_ab.txt)
         self.flow, self.hift, self.stream = flow, hift, stream
 
 
@@ -86,12 +89,13 @@ class CosyVoice2Model:
         complete when the context exits (per-uuid cache tensors are then safe to read from any other lane)."""
         lane = self._lane_q.get()
         try:
-            if lane.stream is None:
+            st = lane.stream
+            if st is None:
                 yield lane
             else:
-                with torch.cuda.stream(lane.stream):
+                with torch.cuda.stream(st):
                     yield lane
-                    lane.stream.synchronize()
+                    st.synchronize()
         finally:
             self._lane_q.put(lane)
 

@@ -12,6 +12,7 @@
   tokenizer, CAM++) are the reference front end's job (`cosyvoice/cli/frontend.py`, out of scope here - SURVEY.md section 8f item 2): `Engine`
   takes such a front end as an object and only replaces its mel extractor and the model underneath.
 """
+import collections
 import queue
 import threading
 import time
@@ -22,7 +23,7 @@ import torch
 
 
 class _Request:
-    __slots__ = ("key", "req", "tokens", "llm_done", "error", "out", "token_offset", "hop", "chunk_index", "t_submit", "t_first", "stream", "pad", "closed", "busy")
+    __slots__ = ("key", "req", "tokens", "llm_done", "error", "out", "token_offset", "hop", "chunk_index", "t_submit", "t_first", "stream", "pad", "closed", "busy", "t_ready", "t_pick")
 
     def __init__(self, key, req, stream, hop, pad):
         self.key, self.req, self.stream = key, req, stream
@@ -30,6 +31,7 @@ class _Request:
         self.out = queue.Queue()
         self.token_offset, self.hop, self.chunk_index, self.pad = 0, hop, 0, pad
         self.t_submit, self.t_first, self.closed, self.busy = time.perf_counter(), None, False, False
+        self.t_ready = self.t_pick = None
 
 
 class StreamScheduler:
@@ -40,6 +42,8 @@ class StreamScheduler:
         self._cv = threading.Condition()
         self._reqs = {}
         self._stop = False
+        # (LM ms until the first chunk's tokens exist, ms waiting for a vocoder lane, ms of the first token2wav) of the last requests
+        self.first_chunk_stats = collections.deque(maxlen=4096)
         self._llm_thread = threading.Thread(target=self._llm_loop, daemon=True)
         # one vocoder thread per token2wav lane of the model (CosyVoice2Model.set_lanes): chunks of DIFFERENT requests are vocoded concurrently
         # on different HIP streams, the chunks of one request stay sequential (`busy`).  With >= 3 lanes the first thread takes FIRST chunks only:
@@ -105,6 +109,8 @@ class StreamScheduler:
                 r.error = error
             if finished:
                 r.llm_done = True
+            if r.t_ready is None and r.token_offset == 0 and self._ready(r) is not None:
+                r.t_ready = time.perf_counter()
             self._cv.notify_all()
 
     def _llm_loop(self):
@@ -151,6 +157,8 @@ class StreamScheduler:
                 if pick is None:
                     return
                 pick[0].busy = True
+                if pick[0].t_pick is None:
+                    pick[0].t_pick = time.perf_counter()
             r, what, toks = pick
             rq = r.req
             finished = True
@@ -175,6 +183,8 @@ class StreamScheduler:
                     out = {"tts_speech": wav.cpu()}
                     if r.t_first is None:
                         r.t_first = time.perf_counter()
+                        if r.t_ready is not None:
+                            self.first_chunk_stats.append(((r.t_ready - r.t_submit) * 1e3, (r.t_pick - r.t_ready) * 1e3, (r.t_first - r.t_pick) * 1e3))
                     r.out.put(out)
                     finished = False
                 else:

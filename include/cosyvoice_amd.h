@@ -250,6 +250,18 @@ int cv_interp_linear(const float* x, float* y, int32_t C, int32_t T, int32_t Tn,
 int cv_reflect_pad(const float* x, float* y, int32_t L, int32_t pad, void* stream);
 int cv_stft_magnitude(const float* spec, float* mag, int32_t T, int32_t bins, int32_t ldm, float eps, void* stream);
 
+/* Feature front ends of the two ONNX extractors (cosyvoice/cli/frontend.py:95-118).  The networks themselves
+ * (speech_tokenizer_v2.onnx, campplus.onnx) stay onnxruntime sessions of the caller; what runs here is what the reference computes on the CPU in
+ * front of them: `whisper.log_mel_spectrogram(speech, n_mels=128)` (frontend.py:98) and `kaldi.fbank(speech, num_mel_bins=80, dither=0,
+ * sample_frequency=16000)` minus its mean over frames (frontend.py:109-113).  Both are cv_gemm_conv over the (padded) signal against a DFT basis
+ * (for the fbank: with DC removal, pre-emphasis and the Povey window folded into it), cv_stft_power, and a second cv_gemm_conv against the mel bank
+ * with act = CV_ACT_LOGCLAMP; then
+ * cv_whisper_lognorm: lnmel [T][n_mels] = ln(max(mel, 1e-10)) -> out [n_mels][T] = (max(log10 mel, max over everything - 8) + 4) / 4;
+ * cv_sub_col_mean:    x [T][C] -= its mean over T (in place).  Host side: cosyvoice_amd/frontend.py (WhisperLogMel, KaldiFbank). */
+int cv_stft_power(const float* spec, float* pw, int32_t T, int32_t bins, int32_t ldm, void* stream);
+int cv_whisper_lognorm(const float* lnmel, float* out, int32_t T, int32_t n_mels, void* stream);
+int cv_sub_col_mean(float* x, int32_t T, int32_t C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,3 +48,48 @@ def mel_spectrogram(y, n_fft=1920, num_mels=80, sampling_rate=24000, hop_size=48
                                          pad_mode="reflect", normalized=False, onesided=True, return_complex=True))
     spec = torch.sqrt(spec.pow(2).sum(-1) + 1e-9)
     return torch.log(torch.clamp(torch.matmul(basis, spec), min=1e-5))
+
+
+# ---- whisper log-mel and kaldi fbank (cosyvoice/cli/frontend.py:98, :109-113) -----------------------------------
+# PARITY UNPINNED as well: neither `openai-whisper` nor `torchaudio` is installed here.  Restated from their published sources, step by step in
+# the order those sources compute (no folding of the per-frame linear steps, torch.stft / torch.fft.rfft instead of a DFT matrix).
+def whisper_log_mel(audio, n_mels=128):
+    """whisper/audio.py log_mel_spectrogram: audio [1, L] (16 kHz) -> [1, n_mels, L // 160].  `mel_filters` there loads
+    librosa.filters.mel(sr=16000, n_fft=400, n_mels=n_mels) from an .npz asset."""
+    stft = torch.stft(audio, 400, 160, window=torch.hann_window(400), return_complex=True)
+    magnitudes = stft[..., :-1].abs() ** 2
+    filters = torch.from_numpy(librosa_mel(16000, 400, n_mels, 0.0, None)).float()
+    log_spec = torch.clamp(filters @ magnitudes, min=1e-10).log10()
+    log_spec = torch.maximum(log_spec, log_spec.max() - 8.0)
+    return (log_spec + 4.0) / 4.0
+
+
+def kaldi_fbank(waveform, num_mel_bins=80, sample_frequency=16000.0, frame_length=25.0, frame_shift=10.0, preemphasis=0.97, low_freq=20.0, high_freq=0.0):
+    """torchaudio/compliance/kaldi.py fbank with dither=0 and every other argument at its default (snip_edges, remove_dc_offset, povey window,
+    round_to_power_of_two, use_power, use_log_fbank, no energy, no vtln): waveform [1, L] -> [m, num_mel_bins]."""
+    x = waveform[0]
+    win, hop = int(sample_frequency * frame_length * 0.001), int(sample_frequency * frame_shift * 0.001)
+    padded = 1 << (win - 1).bit_length()
+    if x.numel() < win:
+        return torch.empty(0, num_mel_bins)
+    m = 1 + (x.numel() - win) // hop
+    frames = x.as_strided((m, win), (hop, 1)).clone()
+    frames = frames - frames.mean(dim=1, keepdim=True)                                      # remove_dc_offset
+    prev = torch.nn.functional.pad(frames.unsqueeze(0), (1, 0), mode="replicate").squeeze(0)
+    frames = frames - preemphasis * prev[:, :-1]
+    frames = frames * torch.hann_window(win, periodic=False).pow(0.85).unsqueeze(0)        # povey
+    frames = torch.nn.functional.pad(frames, (0, padded - win))
+    power = torch.fft.rfft(frames).abs().pow(2.0)
+    nyq = 0.5 * sample_frequency
+    hi = high_freq + nyq if high_freq <= 0.0 else high_freq
+    mel = lambda f: 1127.0 * math.log(1.0 + f / 700.0)
+    mlo, mhi = mel(low_freq), mel(hi)
+    delta = (mhi - mlo) / (num_mel_bins + 1)
+    banks = torch.zeros(num_mel_bins, padded // 2 + 1)
+    for b in range(num_mel_bins):
+        left, center, right = mlo + b * delta, mlo + (b + 1) * delta, mlo + (b + 2) * delta
+        for k in range(padded // 2):
+            mk = mel(sample_frequency / padded * k)
+            banks[b, k] = max(0.0, min((mk - left) / (center - left), (right - mk) / (right - center)))
+    e = torch.mm(power, banks.T)
+    return torch.max(e, torch.tensor(torch.finfo(torch.float).eps)).log()

@@ -41,3 +41,110 @@ def test_prompt_mel_matches_oracle(lib, fmax):
     # front-end layout (frontend.py:122-123): [1, T, 80]
     feat = fe(y).squeeze(dim=0).transpose(0, 1).unsqueeze(dim=0)
     assert feat.shape == (1, L // 480, 80)
+
+
+# ---- feature front ends of the speech tokenizer and the CAM++ speaker network (cli/frontend.py:95-118) ----------
+from cosyvoice_amd.frontend import KaldiFbank, PromptExtractors, WhisperLogMel, kaldi_mel_banks
+
+
+def _speechlike(L, sr, seed):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(L) / float(sr)
+    y = 0.25 * torch.sin(2 * np.pi * 180.0 * t) + 0.1 * torch.sin(2 * np.pi * 2300.0 * t * (1 + 0.3 * t)) + 0.02 * torch.randn(L, generator=g) + 0.01
+    return y.unsqueeze(0).clamp(-1, 1)
+
+
+def test_kaldi_mel_banks_anchors():
+    """The vectorised bank of the product equals the oracle's loop restatement; closed-form anchors of Kaldi's scale: mel(700 (e - 1)) = 1127,
+    the first triangle starts at low_freq = 20 Hz, the last one ends at Nyquist, the appended Nyquist column is zero, and neighbouring
+    triangles sum to one between their centres (they are NOT area-normalised, unlike librosa's)."""
+    a = kaldi_mel_banks(80, 512, 16000.0, 20.0, 0.0)
+    assert a.shape == (80, 257) and (a >= 0).all() and a[:, 256].max() == 0.0
+    mel = lambda f: 1127.0 * np.log(1.0 + f / 700.0)
+    assert abs(mel(700.0 * (np.e - 1.0)) - 1127.0) < 1e-9
+    f = 16000.0 / 512 * np.arange(257)
+    assert a[0, f <= 20.0].max() == 0.0 and a[-1, 255] > 0.0
+    centre = lambda b: 700.0 * (np.exp((mel(20.0) + (b + 1) * (mel(8000.0) - mel(20.0)) / 81) / 1127.0) - 1.0)
+    inner = (f > centre(0)) & (f < centre(79))
+    np.testing.assert_allclose(a[:, inner].sum(0), 1.0, atol=1e-5)
+    # the oracle builds its bank inside kaldi_fbank; compare through a flat power spectrum instead: log of the row sums
+    flat = OFE.kaldi_fbank(torch.zeros(1, 400))                      # silence: DC removal leaves zeros -> every bin sits on the epsilon floor
+    np.testing.assert_allclose(flat.numpy(), np.full((1, 80), np.log(np.finfo(np.float32).eps)), rtol=0, atol=0)
+
+
+def test_whisper_log_mel_matches_oracle(lib):
+    L = 16000 * 3 // (10 if lib.emulated else 1) + 77                # not a multiple of the hop
+    y = _speechlike(L, 16000, 5)
+    got = WhisperLogMel(128, lib=lib)(y).cpu()
+    want = OFE.whisper_log_mel(y, 128)
+    assert got.shape == want.shape == (1, 128, L // 160)
+    # fp32 DFT-as-GEMM vs torch's fp32 FFT: absolute error ~1e-6 of the frame energy per bin, magnified by the log for bins far below the
+    # frame's peak.  Measured under the emulator: 4e-6 / 6e-6.  Stated tolerance on the (log10 + 4) / 4 scale: 1e-4 within 5 decades of the
+    # utterance maximum, 1e-3 down to the 8-decade clip.
+    top = want.max()
+    loud = want > top - 5.0 / 4.0
+    d = (got - want).abs()
+    assert d[loud].max().item() < 1e-4 and d.max().item() < 1e-3
+    assert abs(got.min().item() - (top.item() - 2.0)) < 1e-3 or got.min().item() > top.item() - 2.0       # the 8-decade clip, 8 / 4 = 2
+
+
+def test_kaldi_fbank_matches_oracle(lib):
+    L = 16000 * 3 // (10 if lib.emulated else 1) + 123
+    y = _speechlike(L, 16000, 6)
+    fb = KaldiFbank(80, 16000, lib=lib)
+    got = fb(y).cpu()
+    want = OFE.kaldi_fbank(y)
+    assert got.shape == want.shape == (1 + (L - 400) // 160, 80)
+    # same error model as above, natural-log scale; the folded (DC removal, pre-emphasis, window) basis is built in float64.  Measured under the
+    # emulator: 8e-6 within 10 nepers of the maximum, 2.4e-4 over everything.
+    loud = want > want.max() - 10.0
+    d = (got - want).abs()
+    assert d[loud].max().item() < 2e-4 and d.max().item() < 3e-3
+    cm = fb(y, cmn=True).cpu()
+    np.testing.assert_allclose(cm.numpy(), (got - got.mean(dim=0, keepdim=True)).numpy(), atol=2e-5)
+    assert cm.mean(dim=0).abs().max().item() < 1e-5
+    assert fb(y[:, :399]).shape == (0, 80)                           # shorter than one frame: no frames, like kaldi
+    one = fb(y[:, :400]).cpu()
+    np.testing.assert_allclose(one.numpy(), want[:1].numpy(), atol=3e-3)
+
+
+class _FakeSession:
+    """Stands in for onnxruntime.InferenceSession (no ONNX graphs offline): records its feeds, returns a fixed result."""
+    class _In:
+        def __init__(self, name):
+            self.name = name
+
+    def __init__(self, names, result):
+        self._ins, self._result, self.feeds = [self._In(n) for n in names], result, None
+
+    def get_inputs(self):
+        return self._ins
+
+    def run(self, outputs, feeds):
+        assert outputs is None
+        self.feeds = feeds
+        return [self._result]
+
+
+def test_prompt_extractors_feed_the_sessions_like_the_reference(lib):
+    """cli/frontend.py:95-125: what reaches the two ONNX sessions (names, shapes, dtypes, values) and what comes back."""
+    y16 = _speechlike(16000 // (4 if lib.emulated else 1), 16000, 7)
+    y24 = _speechlike(24000 // (4 if lib.emulated else 1), 24000, 8)
+    tok = _FakeSession(["feats", "feats_length"], np.array([[5, 17, 4000]], dtype=np.int64))
+    spk = _FakeSession(["input"], np.linspace(-1, 1, 192, dtype=np.float32)[None])
+    fe = PromptExtractors(MelSpectrogram(lib=lib), spk, tok, lib=lib)
+    speech_token, speech_token_len = fe._extract_speech_token(y16)
+    assert speech_token.dtype == torch.int32 and speech_token.tolist() == [[5, 17, 4000]] and speech_token_len.tolist() == [3]
+    T = y16.shape[1] // 160
+    assert tok.feeds["feats"].shape == (1, 128, T) and tok.feeds["feats"].dtype == np.float32
+    assert tok.feeds["feats_length"].dtype == np.int32 and tok.feeds["feats_length"].tolist() == [T]
+    np.testing.assert_allclose(tok.feeds["feats"], OFE.whisper_log_mel(y16, 128).numpy(), atol=1e-3)
+    emb = fe._extract_spk_embedding(y16)
+    assert emb.shape == (1, 192) and emb.dtype == torch.float32
+    want = OFE.kaldi_fbank(y16)
+    assert spk.feeds["input"].shape == (1,) + tuple(want.shape)
+    np.testing.assert_allclose(spk.feeds["input"][0], (want - want.mean(dim=0, keepdim=True)).numpy(), atol=3e-3)
+    feat, feat_len = fe._extract_speech_feat(y24)
+    assert feat.shape == (1, y24.shape[1] // 480, 80) and feat_len.tolist() == [y24.shape[1] // 480]
+    with pytest.raises(AssertionError):
+        fe._extract_speech_token(torch.zeros(1, 16000 * 30 + 1))
