@@ -50,16 +50,24 @@ struct GemmConvArgs {
 // WM x WN = wave grid of a workgroup (64 * WM * WN threads); a wave owns a (BM / WM) x (BN / WN) sub-tile.  The default 2 x 2 serves
 // every tile from 32 x 32 up; 1 x 2 makes the 16 x 32 tile (two-wave workgroups) that lets the N = 256 GEMMs of the flow run ~3
 // workgroups per CU (680 instead of 344 launches' worth at M = 1348).
-template <int BM, int BN, int BK, bool WBF16, bool AVEC, int STAGES = 2, bool ABF16 = false, int WM = 2, int WN = 2>
+// AX3 ("exact fp32 on the bf16 pipe", bf16 weights only): an fp32 activation is the exact sum of three bf16 numbers (x1 = bf16(x), x2 = bf16(x - x1),
+// x3 = x - x1 - x2: 3 x 8 mantissa bits, every residual exact in fp32), so  x . w = x1 . w + x2 . w + x3 . w  with every product exact and fp32
+// accumulation - the accuracy of the fp32 MFMA chain for 3 x 16 cycles per 32 k instead of 8 x 32 (the fp32 tiles are MFMA-bound: one wave per
+// SIMD, ~1300 cycles of v_mfma_f32_16x16x4_f32 per 128-wide k-step).  The activation is split ONCE, when it is staged: three bf16 planes in LDS
+// (6 bytes per element instead of 4), the weights staged as the raw bf16 they are.  This is what the LLM prefill and the fp32 mode of the flow run on.
+template <int BM, int BN, int BK, bool WBF16, bool AVEC, int STAGES = 2, bool ABF16 = false, int WM = 2, int WN = 2, bool AX3 = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p) {
     static_assert(!ABF16 || WBF16, "the bf16 MFMA path takes bf16 weights");
+    static_assert(!AX3 || (WBF16 && !ABF16), "the three-term split is the exact path for bf16 weights");
     constexpr int NT = 64 * WM * WN;
+    constexpr bool BFT = ABF16 || AX3;                                    // bf16 tiles in LDS, products on v_mfma_f32_16x16x32_bf16
     // LD = LDS row pitch in dwords.  fp32 tiles: BK + 4.  bf16 tiles hold BK/2 packed pairs + 4 dwords of padding.
-    constexpr int LD = ABF16 ? BK / 2 + 4 : BK + 4, KV = BK / 4;         // KV = groups of 4 k-values per tile row
+    constexpr int LD = BFT ? BK / 2 + 4 : BK + 4, KV = BK / 4;           // KV = groups of 4 k-values per tile row
+    constexpr int APL = BM * LD;                                          // dwords per A plane (AX3: three of them)
     constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN);   // 16x16 tiles per wave (wave tile = BM/WM x BN/WN)
     constexpr int AV = BM * KV / NT, WV = BN * KV / NT;       // float4 groups per thread per k-step
     static_assert(TM >= 1 && TN >= 1 && AV >= 1 && WV >= 1 && BM * KV % NT == 0 && BN * KV % NT == 0, "tile does not divide over the workgroup");
-    __shared__ __attribute__((aligned(16))) float As[BM * LD];
+    __shared__ __attribute__((aligned(16))) float As[(AX3 ? 3 : 1) * APL];
     __shared__ __attribute__((aligned(16))) float Ws[BN * LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
                 const int off = ok ? w_boff[i] + (int)w_off * WE : BUF_OOB;
                 if (WBF16) {
                     const uint2 u = buf_load_u2(rsW, off);
-                    if (ABF16) wv = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+                    if (BFT) wv = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
                     else wv = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
                                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
                 } else {
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
             const long long idx = ok ? w_base[i] + w_off : w_base[i];
             if (WBF16) {
                 const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.W) + idx);
-                if (ABF16) wv = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);      // raw pairs, staged as they are
+                if (BFT) wv = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);      // raw pairs, staged as they are
                 else wv = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
                                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
             } else {
@@ -180,17 +188,51 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
                     x = apply_act4(p.pro, x, p.pro_p);
                 }
             }
-            if (ABF16) *reinterpret_cast<uint2*>(&As[(v / KV) * LD + a_c4[i] / 2]) = make_uint2(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w));
+            if constexpr (AX3) {
+                const unsigned a0 = pack_bf16x2(x.x, x.y), a1 = pack_bf16x2(x.z, x.w);
+                x.x -= __uint_as_float(a0 << 16); x.y -= __uint_as_float(a0 & 0xffff0000u); x.z -= __uint_as_float(a1 << 16); x.w -= __uint_as_float(a1 & 0xffff0000u);
+                const unsigned b0 = pack_bf16x2(x.x, x.y), b1 = pack_bf16x2(x.z, x.w);
+                x.x -= __uint_as_float(b0 << 16); x.y -= __uint_as_float(b0 & 0xffff0000u); x.z -= __uint_as_float(b1 << 16); x.w -= __uint_as_float(b1 & 0xffff0000u);
+                const int o = (v / KV) * LD + a_c4[i] / 2;
+                *reinterpret_cast<uint2*>(&As[o]) = make_uint2(a0, a1);
+                *reinterpret_cast<uint2*>(&As[APL + o]) = make_uint2(b0, b1);
+                *reinterpret_cast<uint2*>(&As[2 * APL + o]) = make_uint2(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w));
+            } else if (ABF16) *reinterpret_cast<uint2*>(&As[(v / KV) * LD + a_c4[i] / 2]) = make_uint2(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w));
             else *reinterpret_cast<float4*>(&As[(v / KV) * LD + a_c4[i]]) = x;
         }
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const int v = tid + i * NT;
-            if (ABF16) *reinterpret_cast<uint2*>(&Ws[(v / KV) * LD + w_c4[i] / 2]) = make_uint2(__float_as_uint(rw[i].x), __float_as_uint(rw[i].y));
+            if (BFT) *reinterpret_cast<uint2*>(&Ws[(v / KV) * LD + w_c4[i] / 2]) = make_uint2(__float_as_uint(rw[i].x), __float_as_uint(rw[i].y));
             else *reinterpret_cast<float4*>(&Ws[(v / KV) * LD + w_c4[i]]) = rw[i];
         }
     };
     auto compute_tile = [&]() {
+        if constexpr (AX3) {
+#pragma unroll
+            for (int kg = 0; kg < BK / 32; ++kg) {
+                uint4 af[3][TM], wf[TN];
+                const int kd = kg * 16 + (lane >> 4) * 4;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        af[pl][i] = *reinterpret_cast<const uint4*>(&As[pl * APL + (wm * (BM / WM) + i * 16 + (lane & 15)) * LD + kd]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    wf[j] = *reinterpret_cast<const uint4*>(&Ws[(wn * (BN / WN) + j * 16 + (lane & 15)) * LD + kd]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {              // smallest term first
+                        const v8bf w8 = __builtin_bit_cast(v8bf, wf[j]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w8, __builtin_bit_cast(v8bf, af[2][i]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w8, __builtin_bit_cast(v8bf, af[1][i]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w8, __builtin_bit_cast(v8bf, af[0][i]), acc[i][j], 0, 0, 0);
+                    }
+            }
+            return;
+        }
         if constexpr (ABF16) {
             // v_mfma_f32_16x16x32_bf16: lane (r = lane & 15, g = lane >> 4) supplies k = 8g .. 8g+7 of row r for both operands
 #pragma unroll

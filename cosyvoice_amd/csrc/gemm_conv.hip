@@ -15,6 +15,12 @@ static void launch_cfg(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_
         hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, true, true, ST, true>), grid, block, 0, stream, a);
         return;
     }
+    // fp32 activations x bf16 weights: the exact three-term split on the bf16 matrix pipe (gemm_conv.h, AX3).  CV_GEMM_X3=0 pins the fp32 MFMA chain
+    // (A/B knob, read at every launch); results agree to fp32 rounding either way.
+    if (a.a_vec && w_bf16) {
+        const char* e = getenv("CV_GEMM_X3");
+        if (!(e && e[0] == '0')) { hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, true, true, ST, false, 2, 2, true>), grid, block, 0, stream, a); return; }
+    }
     if (a.a_vec) {
         if (w_bf16) hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, true, true, ST>), grid, block, 0, stream, a);
         else        hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, false, true, ST>), grid, block, 0, stream, a);

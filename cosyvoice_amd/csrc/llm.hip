@@ -422,9 +422,17 @@ static void skinny(const SkinnyArgs& a, int rt, hipStream_t s) {
     CV_CHECK(!(a.gamma && a.ksplit != 1) && (a.mode == 2) == (a.ksplit > 1), "skinny: split-K workgroups leave raw partials (mode 2), the fused norm needs the whole row");
     const dim3 grid(((row_tiles + rt - 1) / rt) * a.ksplit);
     const bool deep = (tiles + 3) / 4 > 5;
-    if (rt == 1) hipLaunchKernelGGL((skinny_mfma_kernel<1, 7>), grid, dim3(256), 0, s, a);
-    else if (deep) hipLaunchKernelGGL((skinny_mfma_kernel<2, 7>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((skinny_mfma_kernel<2, 5>), grid, dim3(256), 0, s, a);
+    // CV_SKINNY_X3=0: the products on the fp32 matrix pipe (8 v_mfma_f32_16x16x4_f32 per tile) instead of the exact three-term bf16 split (A/B knob)
+    static const bool x3 = [] { const char* e = getenv("CV_SKINNY_X3"); return !(e && e[0] == '0'); }();
+    if (x3) {
+        if (rt == 1) hipLaunchKernelGGL((skinny_mfma_kernel<1, 7, true>), grid, dim3(256), 0, s, a);
+        else if (deep) hipLaunchKernelGGL((skinny_mfma_kernel<2, 7, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((skinny_mfma_kernel<2, 5, true>), grid, dim3(256), 0, s, a);
+    } else {
+        if (rt == 1) hipLaunchKernelGGL((skinny_mfma_kernel<1, 7, false>), grid, dim3(256), 0, s, a);
+        else if (deep) hipLaunchKernelGGL((skinny_mfma_kernel<2, 7, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((skinny_mfma_kernel<2, 5, false>), grid, dim3(256), 0, s, a);
+    }
 }
 
 static void skinny_f8(const SkinnyF8Args& a, int rt, hipStream_t s) {
@@ -457,6 +465,12 @@ static int down_ksplit(int inter) {
     return 1;
 }
 
+// 4 waves = 192 keys per pass.  8 waves (384 keys: the whole context of a 10 s utterance in one load round) measured SLOWER: LM step 1013 -> 1111 us at 8
+// sequences (profiles/r2_batch_decode_ab.txt) - twice the waves per (head, sequence) cost more in the merge and in CU occupancy than the second round does.
+static void launch_attn_batch(const AttnDecodeBatchArgs& ad, int heads, int nb, hipStream_t s) {
+    hipLaunchKernelGGL(attn_decode_batch_kernel<4>, dim3(heads, nb), dim3(256), 0, s, ad);
+}
+
 // one token for every slot: the launch sequence of llm_enqueue_step on the multi-sequence kernels
 static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
     const auto& c = m->cfg; auto& b = m->bt; const int nb = b.nb;
@@ -481,7 +495,7 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
             skinny_f8(SkinnyF8Args{F.qkv.w, F.qkv.s, L.bqkv, h, H, qkv, Q, (int)Q, c.hidden, L.ln1, c.rms_eps, nullptr, 0, 0, nb, 1}, 1, s);
             AttnDecodeBatchArgs ad{qkv, Q, b.kcache.as<float>() + m->layer_cache() * l, b.vcache.as<float>() + m->layer_cache() * l, (long long)m->slot_cache(),
                                    m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st, att, A};
-            hipLaunchKernelGGL(attn_decode_batch_kernel, dim3(c.heads, nb), dim3(256), 0, s, ad);
+            launch_attn_batch(ad, c.heads, nb, s);
             skinny_f8(SkinnyF8Args{F.o.w, F.o.s, nullptr, att, A, h, H, c.hidden, (int)A, nullptr, 0.f, h, H, 0, nb, 1}, 1, s);
             skinny_f8(SkinnyF8Args{F.gu.w, F.gu.s, nullptr, h, H, act, I, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 0, 1, nb, 1}, 2, s);
             if (k8 > 1) {
@@ -512,7 +526,7 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
         skinny(SkinnyArgs{L.wqkv, L.bqkv, h, H, qkv, Q, (int)Q, c.hidden, L.ln1, c.rms_eps, nullptr, 0, 0, nb, 1}, 1, s);
         AttnDecodeBatchArgs ad{qkv, Q, b.kcache.as<float>() + m->layer_cache() * l, b.vcache.as<float>() + m->layer_cache() * l, (long long)m->slot_cache(),
                                m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st, att, A};
-        hipLaunchKernelGGL(attn_decode_batch_kernel, dim3(c.heads, nb), dim3(256), 0, s, ad);
+        launch_attn_batch(ad, c.heads, nb, s);
         skinny(SkinnyArgs{L.wo, nullptr, att, A, h, H, c.hidden, (int)A, nullptr, 0.f, h, H, 0, nb, 1}, 1, s);
         skinny(SkinnyArgs{L.wgu, nullptr, h, H, act, I, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 0, 1, nb, 1}, wide_rt, s);
         if (ks > 1) {

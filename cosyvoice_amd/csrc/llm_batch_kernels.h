@@ -16,7 +16,9 @@
 //   * The binding resource of these kernels is what one CU can ingest (a few tens of bytes per cycle): every workgroup needs the X
 //     columns of its K range for all sequences, so the shapes are cut so that X bytes per workgroup stay close to its weight bytes -
 //     down (K = 4864) is split 8 ways over K across workgroups, its partial sums are combined (fixed order, + residual) by
-//     sum_partials_kernel.
+//     sum_partials_kernel.  (Letting the LAST workgroup of a row group to arrive do that combine inside the same launch - partials, device-scope
+//     fence, arrival counter - was built and measured: the two fences per workgroup write back / invalidate an XCD's L2 each and the step went
+//     1064 -> 1642 us at 8 sequences; profiles/r2_batch_decode_ab.txt.  A second launch is the cheap way to make partials visible across XCDs.)
 #pragma once
 #include "llm_kernels.h"
 
@@ -38,23 +40,49 @@ struct SkinnyArgs {
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
-// Workgroup = 4 waves sharing RT row tiles (16 weight rows each) and one K range (K / ksplit); wave w takes the k-tiles (32 columns)
-// [w * T / 4, (w + 1) * T / 4) of the range, at most KTW of them.  Lane l: weight row l % 16 (A operand), sequence l % 16 (B operand),
+// Workgroup = NW waves sharing RT row tiles (16 weight rows each) and one K range (K / ksplit); wave w takes the k-tiles (32 columns)
+// [w * T / NW, (w + 1) * T / NW) of the range, at most KTW of them.  Lane l: weight row l % 16 (A operand), sequence l % 16 (B operand),
 // k slot group g = l / 16: 8 consecutive k per 32-wide tile -> one 16-byte weight load (8 bf16) and two float4 X loads per tile feed 8
 // MFMAs.  D: lane l holds y[seq l % 16][row 4 * (l / 16) + i], i = 0..3: one float4 store per sequence.  No barrier before the MFMA chain:
 // the RMSNorm scale is applied to the accumulators (see below), the only barrier is the cross-wave combine at the end.
 // (Staging X through LDS - one coalesced fetch per workgroup, conflict-free fragment reads - was built and measured SLOWER on the
 // MI355X: 15.9 vs 12.8 us for gate/up at nb = 8, 8.3 vs 5.6 us for qkv / o_proj: two more barriers in front of the MFMA chain cost more
 // than the 28 extra L2 load instructions per lane; profiles/r2_batch_decode_ab.txt.)
-template <int RT, int KTW>
-__global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs p) {
-    static_assert(RT >= 1 && RT <= 4, "the final combine hands one row tile to each wave");
-    __shared__ __attribute__((aligned(16))) float red[4 * RT * 256];
-    __shared__ float ssq[4][16];
+//
+// X3 (default): the products run on v_mfma_f32_16x16x32_bf16 instead of eight v_mfma_f32_16x16x4_f32 per tile.  The weights ARE bf16 - the 16-byte
+// load is the A operand as it stands, no unpacking - and an fp32 activation is the exact sum of three bf16 numbers (x1 = bf16(x), x2 = bf16(x - x1),
+// x3 = x - x1 - x2: 3 x 8 mantissa bits, the residuals are exact in fp32), so  W x = W x1 + W x2 + W x3  with every product exact and the
+// accumulation in fp32: the same accuracy as the fp32 pipe for 3 MFMA issues of 32 cycles per row tile and k-tile instead of 8.  The fp32 MFMA
+// chain was the longest thing a workgroup does once its loads arrive (gate/up: 112 x 32 cycles per wave, twice that on a CU that holds two
+// workgroups).  Still a fixed order per sequence, independent of the slot and of the other slots.
+__device__ __forceinline__ void split3_bf16(const float4 a, const float4 b, u32x4& h1, u32x4& h2, u32x4& h3) {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float r[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned u = pack_bf16x2(x[2 * i], x[2 * i + 1]);
+        h1[i] = u; r[2 * i] = x[2 * i] - bf_lo(u); r[2 * i + 1] = x[2 * i + 1] - bf_hi(u);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned u = pack_bf16x2(r[2 * i], r[2 * i + 1]);
+        h2[i] = u; r[2 * i] -= bf_lo(u); r[2 * i + 1] -= bf_hi(u);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h3[i] = pack_bf16x2(r[2 * i], r[2 * i + 1]);
+}
+
+// NW = waves per workgroup (they split the K range).  4 everywhere: 8-wave workgroups for the narrow GEMMs (qkv, o_proj: only 72 / 56 workgroups of
+// one row tile exist; 4 k-tiles per wave instead of 7) measured no better - LM step 1013 -> 1032 us at 8 sequences, profiles/r2_batch_decode_ab.txt.
+template <int RT, int KTW, bool X3 = true, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void skinny_mfma_kernel(SkinnyArgs p) {
+    static_assert(RT >= 1 && RT <= 4 && RT <= NW, "the final combine hands one row tile to each wave");
+    __shared__ __attribute__((aligned(16))) float red[NW * RT * 256];
+    __shared__ float ssq[NW][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int ks = blockIdx.x % p.ksplit, rg = blockIdx.x / p.ksplit;
     const int krange = p.K / p.ksplit, tiles = krange / 32;
-    const int t0 = wave * tiles / 4, t1 = (wave + 1) * tiles / 4;
+    const int t0 = wave * tiles / NW, t1 = (wave + 1) * tiles / NW;
     const int kbase = ks * krange + t0 * 32 + g * 8;
     const int n_base = rg * RT * 16;
 
@@ -99,6 +127,20 @@ __global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs p) {
                 a4.x *= ga[t].x; a4.y *= ga[t].y; a4.z *= ga[t].z; a4.w *= ga[t].w;
                 b4.x *= gb[t].x; b4.y *= gb[t].y; b4.z *= gb[t].z; b4.w *= gb[t].w;
             }
+            if constexpr (X3) {
+                u32x4 h1, h2, h3;
+                split3_bf16(a4, b4, h1, h2, h3);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {                       // smallest term first: the order in which a compensated sum would add them
+                    const v8bf wf = __builtin_bit_cast(v8bf, w[rt][t]);
+                    v4f a = acc[rt];
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(v8bf, h3), a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(v8bf, h2), a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(v8bf, h1), a, 0, 0, 0);
+                    acc[rt] = a;
+                }
+                continue;
+            }
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 const u32x4 u = w[rt][t];
@@ -127,12 +169,13 @@ __global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs p) {
     const int rt = wave;
     float4 v = *reinterpret_cast<const float4*>(&red[(rt * 64 + lane) * 4]);
 #pragma unroll
-    for (int ww = 1; ww < 4; ++ww) {
+    for (int ww = 1; ww < NW; ++ww) {
         const float4 o = *reinterpret_cast<const float4*>(&red[((ww * RT + rt) * 64 + lane) * 4]);
         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
     }
-    if (p.gamma) {                                                      // statistics over the whole row: the 4 waves' shares, fixed order
-        const float tot = (ssq[0][c] + ssq[1][c]) + (ssq[2][c] + ssq[3][c]);
+    if (p.gamma) {                                                      // statistics over the whole row: the waves' shares, fixed order
+        float tot = (ssq[0][c] + ssq[1][c]) + (ssq[2][c] + ssq[3][c]);
+        if constexpr (NW == 8) tot += (ssq[4][c] + ssq[5][c]) + (ssq[6][c] + ssq[7][c]);
         const float rstd = rsqrtf(tot / (float)p.K + p.eps);
         v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
     }
@@ -312,10 +355,10 @@ static __global__ __launch_bounds__(256) void sum_partials_kernel(const float* p
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Decode attention of one new position per sequence: workgroup (head h, sequence b), 4 waves over the keys, normalised output.
+// Decode attention of one new position per sequence: workgroup (head h, sequence b), NW waves over the keys, normalised output.
 // With >= 8 sequences there are >= 112 (b, h) pairs, so the keys are not split across workgroups (the batch-1 kernel needs 8 slices
 // per head to occupy the chip and leaves the merge to o_proj); rotate-half RoPE on q / new k in registers, KV append, online softmax
-// per wave (12 slots x 4 key rows per pass and wave), waves merged through LDS in fixed order.
+// per wave (12 slots x 4 key rows per pass and wave, the next pass prefetched), waves merged through LDS in fixed order.
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct AttnDecodeBatchArgs {
     const float* qkv; long long ldqkv; float* kcache; float* vcache; long long cache_stride;      // per-sequence strides
@@ -323,9 +366,10 @@ struct AttnDecodeBatchArgs {
     const DecodeState* st; float* out; long long ldo;
 };
 
-static __global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnDecodeBatchArgs p) {
-    constexpr int NS = 12, WPASS = 4 * NS, PASS = 4 * WPASS;
-    __shared__ __attribute__((aligned(16))) float pw[4][ATTN_PART];
+template <int NW>
+static __global__ __launch_bounds__(NW * 64) void attn_decode_batch_kernel(AttnDecodeBatchArgs p) {
+    constexpr int NS = 12, WPASS = 4 * NS, PASS = NW * WPASS;
+    __shared__ __attribute__((aligned(16))) float pw[NW][ATTN_PART];
     const int b = blockIdx.y, h = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15, grp = lane >> 4;
     const int gsz = p.heads / p.kv_heads, g = h / gsz;
@@ -337,17 +381,17 @@ static __global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnDecod
     const int L = pos + 1;
     const float* kc = kcache + (long long)g * p.max_len * 64;
     const float* vc = vcache + (long long)g * p.max_len * 64;
-    float4 k4[NS], v4[NS];
-    auto load_pass = [&](int base) {
+    float4 k4[NS], v4[NS], kn[NS], vn[NS];
+    auto load_pass = [&](int base, float4* kd, float4* vd) {
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
             const int j = base + wave * WPASS + sl * 4 + grp;
             const long long o = (long long)(j < pos ? j : 0) * 64 + sub * 4;      // unconditional, clamped
-            k4[sl] = *reinterpret_cast<const float4*>(kc + o);
-            v4[sl] = *reinterpret_cast<const float4*>(vc + o);
+            kd[sl] = *reinterpret_cast<const float4*>(kc + o);
+            vd[sl] = *reinterpret_cast<const float4*>(vc + o);
         }
     };
-    load_pass(0);
+    load_pass(0, k4, v4);
     const float* qraw = qkv + h * 64;
     const float* kq = qkv + p.heads * 64 + g * 64;
     const float* vq = qkv + (p.heads + p.kv_heads) * 64 + g * 64;
@@ -368,7 +412,8 @@ static __global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnDecod
     float m_run = NEG, l_run = 0.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int base = 0; base < L; base += PASS) {     // workgroup-uniform
-        if (base != 0) load_pass(base);
+        const bool more = base + PASS < L;
+        if (more) load_pass(base + PASS, kn, vn);     // longer contexts: the next pass is in flight under this pass's arithmetic
         float sc[NS];
         float mt = NEG;
 #pragma unroll
@@ -381,21 +426,26 @@ static __global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnDecod
             mt = fmaxf(mt, sc[sl]);
         }
         mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));
-        if (mt == NEG) continue;                     // wave-uniform: this wave holds no key of the pass
-        const float m_new = fmaxf(m_run, mt);
-        const float scale = (m_run == NEG) ? 0.f : expf(m_run - m_new);
-        acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
-        float lt = 0.f;
+        if (mt != NEG) {                             // wave-uniform: false when this wave holds no key of the pass
+            const float m_new = fmaxf(m_run, mt);
+            const float scale = (m_run == NEG) ? 0.f : expf(m_run - m_new);
+            acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+            float lt = 0.f;
 #pragma unroll
-        for (int sl = 0; sl < NS; ++sl) {
-            const int j = base + wave * WPASS + sl * 4 + grp;
-            const float e = (sc[sl] == NEG) ? 0.f : expf(sc[sl] - m_new);
-            const float4 vv = (j == pos) ? vn4 : v4[sl];
-            acc.x += e * vv.x; acc.y += e * vv.y; acc.z += e * vv.z; acc.w += e * vv.w;
-            lt += e;
+            for (int sl = 0; sl < NS; ++sl) {
+                const int j = base + wave * WPASS + sl * 4 + grp;
+                const float e = (sc[sl] == NEG) ? 0.f : expf(sc[sl] - m_new);
+                const float4 vv = (j == pos) ? vn4 : v4[sl];
+                acc.x += e * vv.x; acc.y += e * vv.y; acc.z += e * vv.z; acc.w += e * vv.w;
+                lt += e;
+            }
+            l_run = l_run * scale + lt;              // per-group partial (identical on the 16 lanes of a group)
+            m_run = m_new;
         }
-        l_run = l_run * scale + lt;                  // per-group partial (identical on the 16 lanes of a group)
-        m_run = m_new;
+        if (more) {
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) { k4[sl] = kn[sl]; v4[sl] = vn[sl]; }
+        }
     }
     acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
     acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
@@ -403,13 +453,13 @@ static __global__ __launch_bounds__(256) void attn_decode_batch_kernel(AttnDecod
     if (grp == 0) *reinterpret_cast<float4*>(&pw[wave][sub * 4]) = acc;
     if (lane == 0) { pw[wave][64] = (l_run > 0.f) ? m_run : 0.f; pw[wave][65] = l_run; }
     __syncthreads();
-    if (tid < 16) {                                  // merge the 4 waves (fixed order), normalise
+    if (tid < 16) {                                  // merge the waves (fixed order), normalise
         float M = NEG;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) if (pw[ww][65] > 0.f) M = fmaxf(M, pw[ww][64]);
+        for (int ww = 0; ww < NW; ++ww) if (pw[ww][65] > 0.f) M = fmaxf(M, pw[ww][64]);
         float den = 0.f; float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
+        for (int ww = 0; ww < NW; ++ww) {
             const float wgt = (pw[ww][65] > 0.f) ? expf(pw[ww][64] - M) : 0.f;
             const float4 t = *reinterpret_cast<const float4*>(&pw[ww][tid * 4]);
             den += wgt * pw[ww][65];

@@ -303,7 +303,8 @@ class Qwen2LM:
         """Continuous batching with STREAMED tokens, the LLM half of a Triton-free serving scheduler (the reference gets this from vLLM /
         TensorRT-LLM: cli/model.py:281-290, runtime/triton_trtllm/model_repo/cosyvoice2/1/model.py:307-313).  `source` is a queue.Queue of
         (key, request) items - requests as for inference_batch - closed by a None item; `on_tokens(key, new_tokens, finished, error)` is called
-        from this thread after every decode chunk of `step_chunk` lock-step steps for every sequence that produced tokens or finished.  Free
+        from this thread after every decode chunk of `step_chunk` lock-step steps (shorter when a request's optional "first_chunk" token count falls
+        inside the chunk) for every sequence that produced tokens or finished.  Free
         slots are re-filled as soon as a sequence ends (a normal prefill parked into the slot); with nothing in flight the call blocks on the
         queue.  Every sequence yields exactly the tokens `inference()` yields for its request alone."""
         import queue as _q
@@ -312,7 +313,7 @@ class Qwen2LM:
         with self.lock:
             st = stream_ptr(self.lib)
             self.lib.cv_llm_batch_begin(self._h, C.c_int32(slots), st)
-            owner, emitted, limit = [None] * slots, {}, {}
+            owner, emitted, limit, first = [None] * slots, {}, {}, {}
             closed = False
 
             def admit(slot, item):
@@ -331,7 +332,7 @@ class Qwen2LM:
                 except Exception as e:                      # a bad request must not take the server down: report it on its own channel
                     on_tokens(key, [], True, e)
                     return False
-                owner[slot], emitted[key], limit[key] = key, 0, max_len
+                owner[slot], emitted[key], limit[key], first[key] = key, 0, max_len, int(r.get("first_chunk", 0))
                 return True
 
             while True:
@@ -351,22 +352,28 @@ class Qwen2LM:
                     if closed:
                         return
                     continue
-                buf = (C.c_int32 * (slots * chunk))()
+                # a request that announced the token count of its FIRST audio chunk gets its tokens handed over the moment that count is
+                # reached, not at the end of a full decode chunk (up to chunk - 1 steps later)
+                n = chunk
+                for key in owner:
+                    if key is not None and 0 < first[key] - emitted[key] < n:
+                        n = first[key] - emitted[key]
+                buf = (C.c_int32 * (slots * n))()
                 n_out, f = (C.c_int32 * slots)(), (C.c_int32 * slots)()
-                self.lib.cv_llm_batch_decode(self._h, C.c_int32(chunk), buf, n_out, f, st)
+                self.lib.cv_llm_batch_decode(self._h, C.c_int32(n), buf, n_out, f, st)
                 for s_ in range(slots):
                     key = owner[s_]
                     if key is None:
                         continue
                     room = limit[key] - emitted[key]
-                    toks = [int(buf[s_ * chunk + k]) for k in range(min(n_out[s_], room))]
+                    toks = [int(buf[s_ * n + k]) for k in range(min(n_out[s_], room))]
                     emitted[key] += len(toks)
                     fin = bool(f[s_]) or emitted[key] >= limit[key]
                     if toks or fin:
                         on_tokens(key, toks, fin, None)
                     if fin:
                         owner[s_] = None
-                        emitted.pop(key), limit.pop(key)
+                        emitted.pop(key), limit.pop(key), first.pop(key)
 
     # ------------------------------------------------------------------------------------------------ bi-directional streaming
     def _rows(self, table, ids):

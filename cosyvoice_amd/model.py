@@ -69,7 +69,9 @@ class CosyVoice2Model:
         self._warmup()
 
     def set_lanes(self, n):
-        """n >= 1 token2wav lanes.  Call while no request is in flight."""
+        """n >= 1 token2wav lanes.  Call while no request is in flight.  (Lane streams restricted to a subset of the CUs with
+        hipExtStreamCreateWithCUMask, to keep CUs free for the LM chain, were measured: every mask - even 224 of 256 CUs - more than doubled
+        both the LM's and the vocoder's latency at 8 streaming clients, profiles/r2_lane_cu_mask_ab.txt.  Plain streams.)"""
         assert n >= 1
         while not self._lane_q.empty():
             self._lane_q.get_nowait()

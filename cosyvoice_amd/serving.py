@@ -71,6 +71,8 @@ class StreamScheduler:
             m.hift_cache_dict[key] = None
         lm_req = dict(text=req["text"], prompt_text=req["prompt_text"], prompt_speech_token=req["llm_prompt_speech_token"],
                       **{k: req[k] for k in ("min_token_text_ratio", "max_token_text_ratio") if k in req})
+        if stream:
+            lm_req["first_chunk"] = m.token_hop_len + pad + m.flow.pre_lookahead_len
         self._src.put((key, lm_req))
         return self._drain(r)
 

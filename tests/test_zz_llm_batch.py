@@ -43,8 +43,9 @@ def test_batch_matches_single_and_oracle(lib, use_graph):
 def test_batch_of_eight_and_long_context(lib):
     cfg = W.tiny()[0]
     sd = W.make_llm(cfg)
-    lm = Qwen2LM(sd, cfg, lib=lib, max_len=256, sampling="greedy", decode_chunk=8)
-    reqs = [_req(cfg, 100 + i, 3 + (i % 3), 2, 10 + 25 * i) for i in range(8)]      # contexts from 15 to ~200 keys: several attention passes per slice
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=512, sampling="greedy", decode_chunk=8)
+    # contexts from 15 to ~420 keys: one and two attention passes (384 keys each), the second one with a partly filled last wave
+    reqs = [_req(cfg, 100 + i, 3 + (i % 3), 2, 10 + 25 * i if i < 6 else 300 + 50 * (i - 5)) for i in range(8)]
     got = lm.inference_batch(reqs, max_token_text_ratio=3, min_token_text_ratio=2)
     for r, g in zip(reqs, got):
         assert g == OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=3, min_token_text_ratio=2)

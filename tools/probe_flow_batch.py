@@ -20,3 +20,23 @@ for nu in (1, 2, 4, 8):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 4 * 1e3
     print("flow pass over %d utterance(s): %.2f ms = %.2f ms per utterance" % (nu, ms, ms / nu), flush=True)
+
+# tile / attention variants at 4 utterances per pass (M = 4 x 1348 rows: enough workgroups that bigger tiles may pay)
+if len(sys.argv) > 1 and sys.argv[1] == "sweep":
+    import ctypes as C
+    def opt(name, v):
+        flow.lib.cv_flow_set_option(flow._h, name.encode(), C.c_int32(v))
+    for nu in (4, 8):
+        for name, sets in (("default", {}), ("tile 64x64", {"flow_tile": 1}), ("tile 64x128", {"flow_tile": 2}), ("attn ks=1 kt=2", {"attn_ks": 1, "attn_kt": 2}),
+                           ("attn ks=1 kt=1", {"attn_ks": 1, "attn_kt": 1})):
+            for k, v in sets.items():
+                opt(k, v)
+            for _ in range(2):
+                flow.inference_batch([item] * nu)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(4):
+                flow.inference_batch([item] * nu)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 4 * 1e3
+            print("nu=%d %-16s %.2f ms = %.2f ms per utterance" % (nu, name, ms, ms / nu), flush=True)
+            opt("flow_tile", 0); opt("attn_ks", 2); opt("attn_kt", 1)
