@@ -460,14 +460,15 @@ static __global__ __launch_bounds__(256) void repeat2_rows_kernel(const float* x
     y[i] = x[(i / C / 2) * C + i % C];
 }
 
-static void dit_reserve(cv_flow* m, int T) {
-    const auto& c = m->cfg; const size_t R = 2 * (size_t)T, D = c.est_ch, f = 4;
-    if ((size_t)T <= (size_t)m->est_cap && m->d_x.p) return;
+static void dit_reserve(cv_flow* m, int T, int nz = 2) {
+    if (T <= m->est_cap && nz <= m->est_nz && m->d_x.p) return;
+    T = std::max(T, m->est_cap); nz = std::max(nz, m->est_nz);
+    const auto& c = m->cfg; const size_t R = (size_t)nz * T, D = c.est_ch, f = 4;
     drop_graphs(m);
     m->s_in.ensure(R * 4 * c.mel * f); m->s_out.ensure(R * c.mel * f);
     m->d_x.ensure(R * D * f); m->d_y.ensure(R * D * f); m->d_n.ensure(R * D * f); m->d_qkv.ensure(R * 3 * D * f); m->d_att.ensure(R * D * f);
     m->d_ff.ensure(R * c.est_mid * D * f);
-    m->est_cap = T;
+    m->est_cap = T; m->est_nz = nz;
 }
 static void dit_time_reserve(cv_flow* m, int n) {
     if (n <= m->t_cap && m->d_mod.p) return;
@@ -511,16 +512,18 @@ static void lin_gated(const Lin& l, const float* A, long long rows, float* C, co
     a.a_bf16 = tl_bf16_mfma && l.bf16;
     gemm_conv(a, l.bf16, 1, s);
 }
-// s_in packed [2][T][4 mel] as [x | mu | spks | cond] (the in_proj columns are permuted to this order by the repacker) -> s_out [2][T][mel]
-static void dit_forward(cv_flow* m, int T, int t_row, int t_rows_total, bool t_shared, int streaming, hipStream_t s) {
-    const auto& c = m->cfg; const int D = c.est_ch, H = c.est_heads; const long long R = 2LL * T;
+// s_in packed [nz][T][4 mel] as [x | mu | spks | cond] (the in_proj columns are permuted to this order by the repacker) -> s_out [nz][T][mel];
+// nz = 2 (conditional | unconditional) x the utterances solved together: rows never mix outside their own attention / position-conv window
+static void dit_forward(cv_flow* m, int T, int t_row, int t_rows_total, bool t_shared, int streaming, hipStream_t s, int nz = 2) {
+    const auto& c = m->cfg; const int D = c.est_ch, H = c.est_heads; const long long R = (long long)nz * T;
+    CV_CHECK(t_shared || nz == 2, "dit_forward: per-row time steps are the two-row estimator call only");
     float* x = m->d_x.as<float>(); float* y = m->d_y.as<float>(); float* n = m->d_n.as<float>(); float* qkv = m->d_qkv.as<float>();
     float* att = m->d_att.as<float>(); float* ff = m->d_ff.as<float>();
     const int chunk = streaming ? 2 * c.chunk : 0;
     const long long rpb = t_shared ? R : T, gbs = t_shared ? 0 : 6LL * D;          // rows per modulation row; stride between the two rows' modulations
     // InputEmbedding (dit.py:76-98): proj, then x + CausalConvPositionEmbedding(x)
     lin_cl(m->d_inproj, m->s_in.as<float>(), R, x, ACT_NONE, nullptr, s);
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < nz; ++b) {
         dit_group_conv(m->d_pos1, x + (size_t)b * T * D, y + (size_t)b * T * D, nullptr, T, D, s);
         dit_group_conv(m->d_pos2, y + (size_t)b * T * D, n + (size_t)b * T * D, x + (size_t)b * T * D, T, D, s);     // n = Mish(conv2) + x
     }
@@ -537,7 +540,7 @@ static void dit_forward(cv_flow* m, int T, int t_row, int t_rows_total, bool t_s
         at.k = qkv + D; at.k_batch = at.q_batch; at.k_row = 3 * D; at.k_head = 64;
         at.v = qkv + 2 * D; at.v_batch = at.q_batch; at.v_row = 3 * D; at.v_head = 64;
         at.o = att; at.o_batch = (long long)T * D; at.o_row = D; at.o_head = 64;
-        at.B = 2; at.H = H; at.kv_group = 1; at.Tq = T; at.Tk = T; at.scale = 0.125f;
+        at.B = nz; at.H = H; at.kv_group = 1; at.Tq = T; at.Tk = T; at.scale = 0.125f;
         at.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; at.chunk = chunk; at.rel_bd = nullptr; at.bf16 = tl_bf16_mfma;
         attention(at, s);
         lin_gated(w.out, att, R, other, cur, mod + 2 * D, rpb, gbs, s);              // x + gate_msa * to_out(attn)
@@ -573,8 +576,7 @@ static void solve_euler(cv_flow* m, float* x /*[nu][T][mel] in/out*/, const floa
                         int n_steps, int streaming, hipStream_t s, int nu = 1) {
     const auto& c = m->cfg;
     const bool dit = c.estimator == 1;
-    CV_CHECK(nu == 1 || !dit, "solve_euler: batched solves are built for the CausalConditionalDecoder estimator");
-    if (dit) { dit_reserve(m, T); dit_time_reserve(m, n_steps); } else { est_reserve(m, T, 2 * nu); time_reserve(m, n_steps); }
+    if (dit) { dit_reserve(m, T, 2 * nu); dit_time_reserve(m, n_steps); } else { est_reserve(m, T, 2 * nu); time_reserve(m, n_steps); }
     // cosine schedule and the t / dt recurrences of solve_euler, in fp32 like torch (flow_matching.py:89-122, 223-226)
     std::vector<float> span(n_steps + 1), tv(n_steps), dts(n_steps);
     for (int i = 0; i <= n_steps; ++i) {
@@ -594,7 +596,7 @@ static void solve_euler(cv_flow* m, float* x /*[nu][T][mel] in/out*/, const floa
         if (dit) dit_time_embed(m, n_steps, s); else time_embed(m, n_steps, s);
         for (int st = 0; st < n_steps; ++st) {
             hipLaunchKernelGGL(pack_est_input_kernel, dim3(nblk(2 * n * 4)), dim3(256), 0, s, x, mu, spk, cond, m->s_in.as<float>(), T, c.mel, 1, nu);
-            if (dit) dit_forward(m, T, st, n_steps, true, streaming, s); else estimator_forward(m, T, st, n_steps, true, streaming, s, 2 * nu);
+            if (dit) dit_forward(m, T, st, n_steps, true, streaming, s, 2 * nu); else estimator_forward(m, T, st, n_steps, true, streaming, s, 2 * nu);
             hipLaunchKernelGGL(cfg_euler_kernel, dim3(nblk(n)), dim3(256), 0, s, x, m->s_out.as<float>(), n, dts[st], c.cfg_rate);
         }
     };
@@ -688,7 +690,7 @@ static void flow_inference(cv_flow* m, int nu, const int32_t* token_ids, int n_t
     CV_CHECK(n_enc > 0 && n_timesteps > 0, "cv_flow_inference: too few tokens");
     const int T = 2 * n_enc, mel_len2 = T - mel_len1;
     CV_CHECK(mel_len2 > 0 && mel_len1 >= 0, "cv_flow_inference: prompt longer than the sequence");
-    CV_CHECK(nu >= 1 && nu <= 8 && (nu == 1 || c.estimator == 0), "cv_flow_inference_batch: 1..8 utterances (CausalConditionalDecoder estimator)");
+    CV_CHECK(nu >= 1 && nu <= 8, "cv_flow_inference_batch: 1..8 utterances");
     if (n_tok > m->inf_cap || (long long)n_tok * nu > m->inf_rows) {        // per-utterance buffers follow n_tok, the stacked ones n_tok * nu
         drop_graphs(m);
         const size_t tk = (size_t)std::max(n_tok, m->inf_cap), rows = std::max((size_t)n_tok * nu, (size_t)m->inf_rows);

@@ -230,9 +230,9 @@ class CosyVoice2Model:
 
     def _vocode_group(self, group, speed):
         """Offline vocoding of one group of finished sequences [(index, request, tokens)] on ONE lane.  Groups of equal shape (token count, prompt
-        tokens, prompt frames) of a CosyVoice2 model go through the flow in one pass (CausalMaskedDiffWithXvec.inference_batch: the Euler solve
-        covers all of them, each result identical to the utterance alone), then through HiFT one by one."""
-        if len(group) == 1 or not hasattr(self.flow, "inference_batch") or self.flow.cfg.estimator == "dit" or type(self).token2wav is not CosyVoice2Model.token2wav:
+        tokens, prompt frames) go through the flow in one pass (CausalMaskedDiffWithXvec / WithDiT.inference_batch: the Euler solve covers all of
+        them, each result identical to the utterance alone), then through HiFT one by one."""
+        if len(group) == 1 or not hasattr(self.flow, "inference_batch") or type(self).token2wav not in (CosyVoice2Model.token2wav, CosyVoice3Model.token2wav):
             outs = []
             for i, r, toks in group:
                 uid = str(uuid_mod.uuid1())
@@ -256,10 +256,13 @@ class CosyVoice2Model:
                     dst = torch.empty(1, src.shape[1], tn, dtype=torch.float32, device=self.device)
                     self.lib.cv_interp_linear(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_int32(src.shape[1]), C.c_int32(src.shape[2]), C.c_int32(tn), stream_ptr(self.lib))
                     mel = dst
-                lane.hift._next_seed = self._noise_key(t, 0)
-                speech, _ = lane.hift.inference(speech_feat=mel, cache_source=torch.zeros(1, 1, 0))
-                outs.append((i, {"tts_speech": speech.cpu()}))
+                outs.append((i, {"tts_speech": self._vocode_mel(lane, mel, t).cpu()}))
             return outs
+
+    def _vocode_mel(self, lane, mel, token):
+        """HiFT half of a one-shot token2wav on `lane` (cli/model.py:319-325 with an empty cache)."""
+        lane.hift._next_seed = self._noise_key(token, 0)
+        return lane.hift.inference(speech_feat=mel, cache_source=torch.zeros(1, 1, 0))[0]
 
     def _vocode_all(self, job_lists, speed):
         """job_lists: iterable of lists of (index, request, tokens) - each list holds the sequences that became available together; yields
@@ -456,6 +459,10 @@ class CosyVoice3Model(CosyVoice2Model):
         self._warmup()
 
     @torch.inference_mode()
+    def _vocode_mel(self, lane, mel, token):
+        """cli/model.py:446-449 for a one-shot request (speech_offset 0)."""
+        return lane.hift.inference(speech_feat=mel, finalize=True)[0]
+
     def token2wav(self, token, prompt_token, prompt_feat, embedding, token_offset, uuid, stream=False, finalize=False, speed=1.0):
         """cli/model.py:425-450."""
         with self._lane() as lane:

@@ -97,3 +97,31 @@ def test_dit_streaming_equals_one_shot_on_finished_chunks(lib, tiny):
         part, _ = flow.inference(token=token[:, : i + chunk + la], token_len=n(min(n_t, i + chunk + la)), streaming=True, finalize=fin, **common)
         part = part.cpu()[:, :, 2 * i:]
         torch.testing.assert_close(full[:, :, 2 * i: 2 * i + part.shape[2]], part, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_dit_inference_batch_equals_single(lib, tiny, precision):
+    """cv_flow_inference_batch on the DiT estimator: utterances of equal shape solved in one pass (estimator batch rows = 2 x utterances) give, each,
+    exactly the mel `inference()` gives for it alone (flow/flow.py:246); then the single path and a longer request on the same handle."""
+    import dataclasses
+    cfg, sd = tiny
+    cfg = dataclasses.replace(cfg, n_timesteps=2)
+    flow = CausalMaskedDiffWithDiT(sd, cfg, lib=lib, precision=precision)
+    g = torch.Generator().manual_seed(72)
+    n = lambda k: torch.tensor([k], dtype=torch.int32)
+    items = [dict(token=torch.randint(0, cfg.vocab, (1, 9), generator=g, dtype=torch.int32), prompt_token=torch.randint(0, cfg.vocab, (1, 5), generator=g, dtype=torch.int32),
+                  prompt_feat=torch.randn(1, 10, cfg.mel, generator=g) * 2 - 5, embedding=torch.randn(1, cfg.spk_dim, generator=g)) for _ in range(3)]
+    single = lambda it, tok: flow.inference(token=tok, token_len=n(tok.shape[1]), prompt_token=it["prompt_token"], prompt_token_len=n(5), prompt_feat=it["prompt_feat"],
+                                            prompt_feat_len=n(10), embedding=it["embedding"], streaming=False, finalize=True)[0].cpu()
+    alone = [single(it, it["token"]) for it in items]
+    assert not torch.equal(alone[0], alone[1])
+    for rep in range(3):                                          # the third call replays the captured graph of the batched solve
+        for a, b in zip(alone, flow.inference_batch(items)):
+            assert torch.equal(a, b.cpu())
+    assert torch.equal(alone[2], flow.inference_batch(items[1:])[1].cpu())
+    assert torch.equal(single(items[0], items[0]["token"]), alone[0])
+    tok_long = torch.randint(0, cfg.vocab, (1, 27), generator=g, dtype=torch.int32)
+    fresh = CausalMaskedDiffWithDiT(sd, cfg, lib=lib, precision=precision)
+    assert torch.equal(single(items[0], tok_long), fresh.inference(token=tok_long, token_len=n(27), prompt_token=items[0]["prompt_token"], prompt_token_len=n(5),
+                                                                  prompt_feat=items[0]["prompt_feat"], prompt_feat_len=n(10), embedding=items[0]["embedding"],
+                                                                  streaming=False, finalize=True)[0].cpu())
