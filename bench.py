@@ -69,6 +69,45 @@ def one_utterance(model, u, keep=None):
     return out
 
 
+def stage_split(model, u, reps=3):
+    """Outside the timed region: where one U10 utterance spends its time, with a device synchronisation between the stages (so the sum is a
+    little above `ms_per_step`), and the stage-level roofline figures of SURVEY.md section 8d: LLM decode = 727.57 MB of weights + KV per token
+    against the HBM peak, flow estimator = 2.827 TFLOP per utterance (T = 674, 10 steps, both CFG rows) against the dense bf16 MFMA peak."""
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    ratio = N_GEN / N_TEXT
+    acc = {"llm": 0.0, "flow": 0.0, "hift": 0.0}
+    flow_inf, hift_inf = model.flow.inference, model.hift.inference
+
+    def timed(name, fn):
+        def w(*a, **k):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            r = fn(*a, **k)
+            torch.cuda.synchronize(); acc[name] += time.perf_counter() - t0
+            return r
+        return w
+    model.flow.inference, model.hift.inference = timed("flow", flow_inf), timed("hift", hift_inf)
+    try:
+        for _ in range(reps):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            with model.llm_context:
+                tokens = list(model.llm.inference(text=u["text"], text_len=t(N_TEXT), prompt_text=u["prompt_text"], prompt_text_len=t(N_PROMPT_TEXT),
+                                                  prompt_speech_token=u["llm_prompt_speech_token"], prompt_speech_token_len=t(N_PROMPT_TOK),
+                                                  embedding=u["llm_embedding"], max_token_text_ratio=ratio, min_token_text_ratio=ratio))
+            torch.cuda.synchronize(); acc["llm"] += time.perf_counter() - t0
+            model.hift_cache_dict["stage"] = None
+            model.token2wav(token=torch.tensor(tokens).unsqueeze(0), prompt_token=u["flow_prompt_speech_token"], prompt_feat=u["prompt_speech_feat"],
+                            embedding=u["flow_embedding"], token_offset=0, uuid="stage", finalize=True).cpu()
+            model.hift_cache_dict.pop("stage", None)
+    finally:
+        model.flow.inference, model.hift.inference = flow_inf, hift_inf
+    ms = {k: 1e3 * v / reps for k, v in acc.items()}
+    return {"llm_prefill_plus_250_tokens_ms": round(ms["llm"], 2), "flow_inference_ms": round(ms["flow"], 2), "hift_inference_ms": round(ms["hift"], 2),
+            "llm_GBps_of_727.57MB_per_token": round(N_GEN * 727.57e6 / (ms["llm"] * 1e-3) / 1e9, 1),
+            "llm_frac_of_hbm_peak": round(N_GEN * 727.57e6 / (ms["llm"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "flow_TFLOPs_of_2.827TFLOP": round(2.827 / (ms["flow"] * 1e-3), 1), "flow_frac_of_bf16_mfma_peak_2500": round(2.827 / (ms["flow"] * 1e-3) / 2500.0, 4),
+            "note": "one synchronisation per stage; flow_inference includes the encoder, hift_inference the f0 predictor and source"}
+
+
 def self_check(model, u):
     """Outside the timed region: the tokens the timed path produces for U10 must be the CPU oracle's greedy tokens, committed as
     tests/golden/u10_oracle_tokens.json (generated by tests/golden/make_u10.py; nothing from oracle/ is imported here), and the waveform must be
@@ -603,6 +642,9 @@ def main():
             out["utterance_hashes_sha1"] = hashlib.sha1("".join(all_hashes[i] for i in range(len(costs))).encode()).hexdigest()
         out["self_check"] = self_check(model, u)                 # U10 through the same model object, whatever the workload
         log("self-check passed: %s" % out["self_check"])
+        if world == 1 and args.workload == "u10":
+            out["stages"] = stage_split(model, u)
+            log("stage split: %s" % out["stages"])
         if world == 1 and (args.batch > 0 or args.stream_clients > 0):
             model.set_lanes(args.lanes)
         if world == 1 and args.batch > 0:
