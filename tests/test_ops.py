@@ -278,3 +278,28 @@ def test_every_gemm_tile_shape(lib, tile, bf16, monkeypatch):
         xa = x.bfloat16().float() if bf16 else x
         ref = sum(xa[j:j + M] @ W[:, j].t() for j in range(taps)) + b + res
         torch.testing.assert_close(out[0].cpu(), ref.cpu(), rtol=3e-5, atol=3e-5)
+
+
+@pytest.mark.parametrize("M,N,K,taps", [(37, 48, 64, 1), (131, 200, 896, 1), (70, 96, 320, 3)])
+def test_linear_three_term_split_is_fp32_exact(lib, M, N, K, taps, monkeypatch):
+    """fp32 activations x bf16 weights: the three-term bf16 split on v_mfma_f32_16x16x32_bf16 (gemm_conv.h AX3, the default) against a float64
+    reference and against the fp32 MFMA chain (CV_GEMM_X3=0, read at every launch).  The split is exact (x1 + x2 + x3 == x, every product exact),
+    so both differ from float64 only by fp32 accumulation: errors of the same size, far below the bf16-activation mode's."""
+    dev = _dev(lib)
+    x = _rand((M + taps - 1, K), dev, 21, 3.0)
+    W = _rand((N, taps, K), dev, 22, 0.2).bfloat16().float()
+    Wp, Kp = ops.pack_weight(W if taps > 1 else W[:, 0], torch.bfloat16)
+    run = lambda: ops.gemm_conv(lib, x, Wp, Kp, M=M, N=N, K=K, taps=taps, lda=K, tap_step=K, a_len=x.numel())[0].cpu().double()
+    monkeypatch.delenv("CV_GEMM_X3", raising=False)
+    split = run(); _sync(lib)
+    monkeypatch.setenv("CV_GEMM_X3", "0")
+    chain = run(); _sync(lib)
+    ref = sum(x.cpu().double()[j:j + M] @ W.cpu().double()[:, j].t() for j in range(taps))
+    scale = ref.abs().max().item()
+    e_split, e_chain = (split - ref).abs().max().item() / scale, (chain - ref).abs().max().item() / scale
+    assert e_split < 2e-6 and e_chain < 2e-6 and e_split < 4 * e_chain + 1e-7, (e_split, e_chain)
+    # the three planes really carry the whole fp32 value: activations with a tiny component next to a large one keep it
+    y = x.clone(); y[:, 0] = 1000.0; y[:, 1] = 1e-3
+    out = ops.gemm_conv(lib, y, Wp, Kp, M=M, N=N, K=K, taps=taps, lda=K, tap_step=K, a_len=y.numel())[0].cpu().double()
+    refy = sum(y.cpu().double()[j:j + M] @ W.cpu().double()[:, j].t() for j in range(taps))
+    assert (out - refy).abs().max().item() / refy.abs().max().item() < 2e-6
