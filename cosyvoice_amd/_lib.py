@@ -40,6 +40,7 @@ class AttnArgs(C.Structure):
         ("B", C.c_int32), ("H", C.c_int32), ("kv_group", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32),
         ("scale", C.c_float), ("mask_mode", C.c_int32), ("chunk", C.c_int32),
         ("rel_bd", C.c_void_p), ("bd_batch", C.c_int64), ("bd_head", C.c_int64), ("bd_row", C.c_int32), ("bf16", C.c_int32),
+        ("klen", C.c_void_p),
     ]
 
 

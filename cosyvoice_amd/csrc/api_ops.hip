@@ -116,7 +116,7 @@ int cv_attention(const cv_attn_args* g, void* stream) {
         a.o = g->o; a.o_batch = g->o_batch; a.o_row = g->o_row; a.o_head = g->o_head;
         a.B = g->B; a.H = g->H; a.kv_group = g->kv_group; a.Tq = g->Tq; a.Tk = g->Tk;
         a.scale = g->scale; a.mask_mode = g->mask_mode; a.chunk = g->chunk;
-        a.rel_bd = g->rel_bd; a.bd_batch = g->bd_batch; a.bd_head = g->bd_head; a.bd_row = g->bd_row; a.bf16 = g->bf16;
+        a.rel_bd = g->rel_bd; a.bd_batch = g->bd_batch; a.bd_head = g->bd_head; a.bd_row = g->bd_row; a.bf16 = g->bf16; a.klen = g->klen;
         cv::attention(a, cv::as_stream(stream));
     });
 }

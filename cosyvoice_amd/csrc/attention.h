@@ -20,6 +20,8 @@ struct AttnArgs {
     int B, H, kv_group, Tq, Tk;
     float scale; int mask_mode; int chunk;
     const float* rel_bd; long long bd_batch; long long bd_head; int bd_row;
+    const int* klen;   // optional [B]: batch row b attends keys < min(Tk, klen[b]) - the padded rows of a batch of unequal lengths are never keys.
+                       // The key loop of a row then ends where it would end for that row alone (same tiles, same order: bit-identical results).
     int bf16;      // 1 (2, 3: forced workgroup shape): q, k, v and the probabilities are rounded to bf16 and both products run on v_mfma_f32_16x16x32_bf16 (fp32 softmax / accumulate)
 };
 
@@ -53,12 +55,13 @@ static __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
         }
     }
     const int qmax_blk = min(p.Tq - 1, qb * BQ + BQ - 1);
-    int kend = p.Tk;
-    if (p.mask_mode == MASK_CAUSAL) kend = min(p.Tk, qmax_blk + (p.Tk - p.Tq) + 1);
-    else if (p.mask_mode == MASK_CHUNK) kend = min(p.Tk, (qmax_blk / p.chunk + 1) * p.chunk);
-    int klim = p.Tk;   // per-query key limit (exclusive)
-    if (p.mask_mode == MASK_CAUSAL) klim = min(p.Tk, qi + (p.Tk - p.Tq) + 1);
-    else if (p.mask_mode == MASK_CHUNK) klim = min(p.Tk, (qi / p.chunk + 1) * p.chunk);
+    const int Tkb = p.klen ? min(p.Tk, p.klen[b]) : p.Tk;      // keys of THIS batch row (padded batches: rows of different lengths share a launch)
+    int kend = Tkb;
+    if (p.mask_mode == MASK_CAUSAL) kend = min(Tkb, qmax_blk + (p.Tk - p.Tq) + 1);
+    else if (p.mask_mode == MASK_CHUNK) kend = min(Tkb, (qmax_blk / p.chunk + 1) * p.chunk);
+    int klim = Tkb;    // per-query key limit (exclusive)
+    if (p.mask_mode == MASK_CAUSAL) klim = min(Tkb, qi + (p.Tk - p.Tq) + 1);
+    else if (p.mask_mode == MASK_CHUNK) klim = min(Tkb, (qi / p.chunk + 1) * p.chunk);
     if (!qvalid) klim = 0;
 
     const float* kb = p.k + (long long)b * p.k_batch + (long long)hk * p.k_head;
@@ -211,12 +214,13 @@ __global__ __launch_bounds__(NW * 64) CV_WAVES_PER_EU(1, 2) void attention_bf16_
         }
     }
     const int qmax_blk = min(p.Tq - 1, qb * BQ + BQ - 1);
-    int kend = p.Tk;
-    if (p.mask_mode == MASK_CAUSAL) kend = min(p.Tk, qmax_blk + (p.Tk - p.Tq) + 1);
-    else if (p.mask_mode == MASK_CHUNK) kend = min(p.Tk, (qmax_blk / p.chunk + 1) * p.chunk);
-    int klim = p.Tk;   // per-query key limit (exclusive)
-    if (p.mask_mode == MASK_CAUSAL) klim = min(p.Tk, qi + (p.Tk - p.Tq) + 1);
-    else if (p.mask_mode == MASK_CHUNK) klim = min(p.Tk, (qi / p.chunk + 1) * p.chunk);
+    const int Tkb = p.klen ? min(p.Tk, p.klen[b]) : p.Tk;      // keys of THIS batch row (padded batches: rows of different lengths share a launch)
+    int kend = Tkb;
+    if (p.mask_mode == MASK_CAUSAL) kend = min(Tkb, qmax_blk + (p.Tk - p.Tq) + 1);
+    else if (p.mask_mode == MASK_CHUNK) kend = min(Tkb, (qmax_blk / p.chunk + 1) * p.chunk);
+    int klim = Tkb;    // per-query key limit (exclusive)
+    if (p.mask_mode == MASK_CAUSAL) klim = min(Tkb, qi + (p.Tk - p.Tq) + 1);
+    else if (p.mask_mode == MASK_CHUNK) klim = min(Tkb, (qi / p.chunk + 1) * p.chunk);
     if (!qvalid) klim = 0;
 
     const float* kb = p.k + (long long)b * p.k_batch + (long long)hk * p.k_head;

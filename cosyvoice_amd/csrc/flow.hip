@@ -61,6 +61,8 @@ struct cv_flow {
     DevBuf t_val, t_sin, t_h, t_emb, t_mlp;                                                   // time embeddings
     DevBuf f_tok, f_h, f_mu, f_spk, f_spkn, f_cond, f_x, f_ones;                              // inference glue
     int enc_cap = 0, est_cap = 0, est_nz = 0, t_cap = 0, inf_cap = 0; long long inf_rows = 0;
+    // padded batches (cv_flow_inference_ragged): key counts per estimator batch row, fixed device address (captured graphs read the current content)
+    DevBuf klen; std::vector<int> host_klen; const int* cur_klen = nullptr;
     // hipGraph cache of the whole Euler solve, keyed by (T, n_steps, streaming): ~5000 launches per utterance become one replay.
     // A key is captured the second time it is seen (streaming requests change T every chunk and would only pay the instantiation).
     bool use_graph = true;
@@ -351,8 +353,9 @@ static void gemm_bf16_res(const Lin& l, const bf16_t* A, int lda, int M, float* 
     const unsigned g = ((M + 31) / 32) * ((l.N + 63) / 64);
     hipLaunchKernelGGL((flow_gemm_kernel<32, 64, 0, 1>), dim3(g), dim3(256), 0, s, a);
 }
-static void attn_flow(const bf16_t* qk, int ld, int inner, const bf16_t* vt, long long vt_batch, int ldt, bf16_t* o, int B, int H, int T, int chunk, hipStream_t s) {
+static void attn_flow(const bf16_t* qk, int ld, int inner, const bf16_t* vt, long long vt_batch, int ldt, bf16_t* o, int B, int H, int T, int chunk, hipStream_t s, const int* klen = nullptr) {
     AttnFlowArgs a{};
+    a.klen = klen;
     a.q = qk; a.k = qk + inner; a.ld = ld; a.vt = vt; a.vt_batch = vt_batch; a.ldt = ldt; a.o = o; a.ldo = inner;
     a.B = B; a.H = H; a.T = T; a.scale = 0.125f; a.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; a.chunk = chunk;
     const dim3 g2((unsigned)(((T + 31) / 32) * H * B)), g4((unsigned)(((T + 63) / 64) * H * B));
@@ -395,7 +398,7 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
                 bf16_t* qk = m->h_qk.as<bf16_t>(); bf16_t* vt = m->h_vt.as<bf16_t>(); bf16_t* ab = m->h_att.as<bf16_t>(); bf16_t* fb = m->h_ff.as<bf16_t>();
                 const long long vt_batch = (long long)inner * m->vt_pitch;
                 ln_gemm_bf16(t.qkv, &t.norm1, 1e-5f, x, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
-                attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s);
+                attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, m->cur_klen);
                 gemm_bf16_res(t.out, ab, inner, (int)R, x, x, s);
                 ln_gemm_bf16(t.ff1, &t.norm3, 1e-5f, x, (int)R, ACT_GELU_ERF, fb, 4 * C, 4 * C, nullptr, 0, 0, 0, s);
                 gemm_bf16_res(t.ff2, fb, 4 * C, (int)R, x, x, s);
@@ -410,7 +413,7 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
             at.o = att; at.o_batch = (long long)T * inner; at.o_row = inner; at.o_head = 64;
             at.B = nz; at.H = H; at.kv_group = 1; at.Tq = T; at.Tk = T; at.scale = 0.125f;
             at.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; at.chunk = chunk; at.rel_bd = nullptr;
-            at.bf16 = tl_bf16_mfma;
+            at.bf16 = tl_bf16_mfma; at.klen = m->cur_klen;
             attention(at, s);
             lin_cl(t.out, att, R, x, ACT_NONE, x, s);
             ln_rows(t.norm3, x, n, R, C, 1e-5f, s);
@@ -541,7 +544,7 @@ static void dit_forward(cv_flow* m, int T, int t_row, int t_rows_total, bool t_s
         at.v = qkv + 2 * D; at.v_batch = at.q_batch; at.v_row = 3 * D; at.v_head = 64;
         at.o = att; at.o_batch = (long long)T * D; at.o_row = D; at.o_head = 64;
         at.B = nz; at.H = H; at.kv_group = 1; at.Tq = T; at.Tk = T; at.scale = 0.125f;
-        at.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; at.chunk = chunk; at.rel_bd = nullptr; at.bf16 = tl_bf16_mfma;
+        at.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; at.chunk = chunk; at.rel_bd = nullptr; at.bf16 = tl_bf16_mfma; at.klen = m->cur_klen;
         attention(at, s);
         lin_gated(w.out, att, R, other, cur, mod + 2 * D, rpb, gbs, s);              // x + gate_msa * to_out(attn)
         std::swap(cur, other);
@@ -600,7 +603,7 @@ static void solve_euler(cv_flow* m, float* x /*[nu][T][mel] in/out*/, const floa
             hipLaunchKernelGGL(cfg_euler_kernel, dim3(nblk(n)), dim3(256), 0, s, x, m->s_out.as<float>(), n, dts[st], c.cfg_rate);
         }
     };
-    const auto key = std::make_tuple(T, n_steps, (streaming ? 1 : 0) + 2 * nu);
+    const auto key = std::make_tuple(T, n_steps, (streaming ? 1 : 0) + 2 * nu + (m->cur_klen ? 64 : 0));     // a padded batch bakes the klen pointer into its launches
     auto it = m->graphs.find(key);
     if (m->use_graph && it != m->graphs.end() && x == m->f_x.as<float>()) {
         { std::lock_guard<std::recursive_mutex> lk(runtime_lock()); CV_HIP(hipGraphLaunch(it->second, s)); }
@@ -720,6 +723,82 @@ static void flow_inference(cv_flow* m, int nu, const int32_t* token_ids, int n_t
     solve_euler(m, m->f_x.as<float>(), m->f_mu.as<float>(), m->f_spk.as<float>(), m->f_cond.as<float>(), T, n_timesteps, streaming, s, nu);
     hipLaunchKernelGGL(to_channel_first_kernel, dim3(nblk((long long)nu * mel_len2 * c.mel)), dim3(256), 0, s, m->f_x.as<float>(), mel_out, nu, T, c.mel, mel_len1, (const float*)nullptr);
     *mel_len2_out = mel_len2;
+}
+
+// Utterances of DIFFERENT lengths in one pass (the reference's padded batch with `mask`, flow/flow.py:236-281, "identical to running each utterance
+// alone"): every utterance occupies a block of Tm = max T rows in the stacked [nu][Tm][mel] buffers, zero beyond its own T.  What keeps the padding out
+// of the result: the estimator's convolutions are causal (a row only sees rows before it), norms and linears are per row, and attention - the one
+// operator that looks to the right - takes a key count per batch row (AttnArgs::klen), ending a row's key loop exactly where it ends for the
+// utterance alone.  The valid rows are therefore bit-identical to the single pass; the padded rows compute finite values nobody reads.
+static void flow_inference_ragged(cv_flow* m, int nu, const int32_t* token_ids, const int32_t* n_tok, const float* prompt_feat, const int32_t* mel_len1, const float* embedding,
+                                  const float* noise_cl, int streaming, int finalize, int n_timesteps, float* mel_out, int32_t* mel_len2_out, void* stream) {
+    PrecisionScope prec(m);
+    const auto& c = m->cfg; const int d = c.dim;
+    hipStream_t s = resolve(m, stream);
+    void* stream_r = reinterpret_cast<void*>(s);
+    CV_CHECK(nu >= 1 && nu <= 8 && n_timesteps > 0, "cv_flow_inference_ragged: 1..8 utterances");
+    std::vector<int> n_enc(nu), T(nu);
+    int Tm = 0, tok_max = 0;
+    for (int u = 0; u < nu; ++u) {
+        n_enc[u] = finalize ? n_tok[u] : n_tok[u] - c.pre_lookahead;
+        CV_CHECK(n_enc[u] > 0, "cv_flow_inference_ragged: too few tokens");
+        T[u] = 2 * n_enc[u];
+        CV_CHECK(mel_len1[u] >= 0 && T[u] - mel_len1[u] > 0, "cv_flow_inference_ragged: prompt longer than the sequence");
+        Tm = std::max(Tm, T[u]); tok_max = std::max(tok_max, n_tok[u]);
+    }
+    if (tok_max > m->inf_cap || (long long)tok_max * nu > m->inf_rows) {
+        drop_graphs(m);
+        const size_t tk = (size_t)std::max(tok_max, m->inf_cap), rows = std::max((size_t)tok_max * nu, (size_t)m->inf_rows);
+        m->f_tok.ensure(tk * d * 4); m->f_h.ensure(2 * tk * d * 4);
+        m->f_mu.ensure(2 * rows * c.mel * 4); m->f_cond.ensure(2 * rows * c.mel * 4); m->f_x.ensure(2 * rows * c.mel * 4);
+        m->f_spk.ensure((size_t)8 * c.mel * 4); m->f_spkn.ensure((size_t)c.spk_dim * 4);
+        m->inf_cap = (int)tk; m->inf_rows = (long long)rows;
+    }
+    m->klen.ensure(64 * sizeof(int));
+    const size_t per = (size_t)Tm * c.mel;
+    CV_HIP(hipMemsetAsync(m->f_mu.p, 0, (size_t)nu * per * 4, s));
+    CV_HIP(hipMemsetAsync(m->f_x.p, 0, (size_t)nu * per * 4, s));
+    size_t tok_off = 0, feat_off = 0;
+    for (int u = 0; u < nu; ++u) {
+        hipLaunchKernelGGL(l2_normalize_kernel, dim3(1), dim3(256), 0, s, embedding + (size_t)u * c.spk_dim, m->f_spkn.as<float>(), c.spk_dim);
+        lin_cl(m->spk_affine, m->f_spkn.as<float>(), 1, m->f_spk.as<float>() + (size_t)u * c.mel, ACT_NONE, nullptr, s);
+        CV_CHECK(cv_gather_rows(m->input_embedding, m->wbf16 ? CV_BF16 : CV_F32, c.vocab, d, token_ids + tok_off, n_tok[u], m->f_tok.as<float>(), 1.f, stream_r) == 0, cv_last_error());
+        const float* ctx = finalize ? nullptr : m->f_tok.as<float>() + (size_t)n_enc[u] * d;
+        float* mu = m->f_mu.as<float>() + u * per;
+        if (c.estimator == 1) dit_front(m, m->f_tok.as<float>(), n_enc[u], ctx, mu, s);
+        else {
+            flow_encoder(m, m->f_tok.as<float>(), n_enc[u], ctx, streaming, m->f_h.as<float>(), s);
+            lin_cl(m->enc_proj, m->f_h.as<float>(), T[u], mu, ACT_NONE, nullptr, s);
+        }
+        hipLaunchKernelGGL(copy_rows_zero_tail_kernel, dim3(nblk((long long)per)), dim3(256), 0, s, prompt_feat + feat_off, m->f_cond.as<float>() + u * per,
+                           (long long)mel_len1[u] * c.mel, (long long)per);
+        CV_HIP(hipMemcpyAsync(m->f_x.as<float>() + u * per, noise_cl, (size_t)T[u] * c.mel * 4, hipMemcpyDeviceToDevice, s));
+        tok_off += (size_t)n_tok[u]; feat_off += (size_t)mel_len1[u] * c.mel;
+    }
+    m->host_klen.assign(2 * nu, 0);
+    for (int z = 0; z < 2 * nu; ++z) m->host_klen[z] = T[z % nu];                  // estimator batch row z = (cond | uncond) * nu + utterance
+    CV_HIP(hipMemcpyAsync(m->klen.p, m->host_klen.data(), (size_t)2 * nu * sizeof(int), hipMemcpyHostToDevice, s));
+    m->cur_klen = m->klen.as<int>();
+    try {
+        solve_euler(m, m->f_x.as<float>(), m->f_mu.as<float>(), m->f_spk.as<float>(), m->f_cond.as<float>(), Tm, n_timesteps, streaming, s, nu);
+    } catch (...) { m->cur_klen = nullptr; throw; }
+    m->cur_klen = nullptr;
+    size_t out_off = 0;
+    for (int u = 0; u < nu; ++u) {
+        const int len2 = T[u] - mel_len1[u];
+        hipLaunchKernelGGL(to_channel_first_kernel, dim3(nblk((long long)len2 * c.mel)), dim3(256), 0, s, m->f_x.as<float>() + u * per, mel_out + out_off, 1, T[u], c.mel,
+                           mel_len1[u], (const float*)nullptr);
+        mel_len2_out[u] = len2; out_off += (size_t)len2 * c.mel;
+    }
+}
+
+int cv_flow_inference_ragged(cv_flow* m, int32_t n_utt, const int32_t* token_ids, const int32_t* n_tok, const float* prompt_feat, const int32_t* mel_len1,
+                             const float* embedding, const float* noise_cl, int32_t streaming, int32_t finalize, int32_t n_timesteps, float* mel_out,
+                             int32_t* mel_len2_out, void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && m->finalized && token_ids && n_tok && mel_len1 && embedding && noise_cl && mel_out && mel_len2_out, "cv_flow_inference_ragged: bad arguments");
+        flow_inference_ragged(m, n_utt, token_ids, n_tok, prompt_feat, mel_len1, embedding, noise_cl, streaming, finalize, n_timesteps, mel_out, mel_len2_out, stream);
+    });
 }
 
 int cv_flow_inference(cv_flow* m, const int32_t* token_ids, int32_t n_tok, const float* prompt_feat, int32_t mel_len1, const float* embedding,

@@ -240,6 +240,7 @@ struct AttnFlowArgs {
     const bf16_t* vt; long long vt_batch; int ldt;        // vt: [B][H * 64][ldt]
     bf16_t* o; int ldo;                                   // [B * T][ldo]
     int B, H, T; float scale; int mask_mode; int chunk;
+    const int* klen;                                      // optional [B] key counts of a padded batch
 };
 
 template <int NW, int KT, int KS = 1>
@@ -269,11 +270,12 @@ __global__ __launch_bounds__(NW * KS * 64) void attn_flow_kernel(AttnFlowArgs p)
 
     const bf16_t* kb = p.k + (long long)b * p.T * p.ld + h * 64;
     const bf16_t* vb = p.vt + (long long)b * p.vt_batch + (long long)h * 64 * p.ldt;
-    int kend = p.T;
+    const int Tkb = p.klen ? min(p.T, p.klen[b]) : p.T;        // keys of THIS batch row (see AttnArgs::klen)
+    int kend = Tkb;
     const int qmax_blk = min(p.T - 1, qb * BQ + BQ - 1);
-    if (p.mask_mode == MASK_CHUNK) kend = min(p.T, (qmax_blk / p.chunk + 1) * p.chunk);
-    int klim = p.T;
-    if (p.mask_mode == MASK_CHUNK) klim = min(p.T, (qi / p.chunk + 1) * p.chunk);
+    if (p.mask_mode == MASK_CHUNK) kend = min(Tkb, (qmax_blk / p.chunk + 1) * p.chunk);
+    int klim = Tkb;
+    if (p.mask_mode == MASK_CHUNK) klim = min(Tkb, (qi / p.chunk + 1) * p.chunk);
     if (!qvalid) klim = 0;
 
     // stage pieces: K piece v -> key row v / 8, 8 bf16 at column 8 (v % 8);  V^T piece v -> d row v / (BKV / 8), 8 keys at column 8 (v % (BKV / 8))

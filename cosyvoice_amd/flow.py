@@ -165,7 +165,7 @@ class CausalMaskedDiffWithXvec:
 
     @torch.inference_mode()
     def inference_batch(self, items, streaming=False, finalize=True):
-        """`items`: up to 8 dicts(token [1, n], prompt_token [1, p], prompt_feat [1, 2p', 80], embedding [1, spk]) of EQUAL shapes -> list of mel
+        """`items`: up to 8 dicts(token [1, n], prompt_token [1, p], prompt_feat [1, 2p', 80], embedding [1, spk]) -> list of mel
         [1, 80, 2 * n_new] tensors, each equal to what `inference()` returns for that item alone (flow/flow.py:246: "identical to running each
         utterance alone" is the reference's own contract for its batched flow).  One pass: the CFM Euler solve runs once over all items
         (estimator batch rows = 2 x items), so every GEMM of a step covers all of them."""
@@ -173,7 +173,8 @@ class CausalMaskedDiffWithXvec:
         assert 1 <= nu <= 8
         n_tok = int(items[0]["prompt_token"].shape[1] + items[0]["token"].shape[1])
         mel_len1 = int(items[0]["prompt_feat"].shape[1])
-        assert all(int(it["prompt_token"].shape[1] + it["token"].shape[1]) == n_tok and int(it["prompt_feat"].shape[1]) == mel_len1 for it in items), "equal shapes only"
+        if not all(int(it["prompt_token"].shape[1] + it["token"].shape[1]) == n_tok and int(it["prompt_feat"].shape[1]) == mel_len1 for it in items):
+            return self._inference_ragged(items, streaming, finalize)
         dev = self.device
         ids = self.lib.hook(torch.stack([torch.cat([it["prompt_token"].reshape(-1).to(dev, torch.int32), it["token"].reshape(-1).to(dev, torch.int32)]).clamp(min=0)
                                          for it in items]).contiguous())
@@ -192,6 +193,35 @@ class CausalMaskedDiffWithXvec:
                                          C.c_int32(int(finalize)), C.c_int32(self.n_timesteps), C.c_void_p(out.data_ptr()), C.byref(got), stream_ptr(self.lib))
         assert got.value == mel_len2
         return [out[i:i + 1] for i in range(nu)]
+
+
+    def _inference_ragged(self, items, streaming, finalize):
+        """Items of DIFFERENT lengths in one pass (cv_flow_inference_ragged): padded to the longest, attention limited to every item's own frames;
+        each result is still bit-identical to `inference()` of the item alone."""
+        dev, nu = self.device, len(items)
+        toks = [torch.cat([it["prompt_token"].reshape(-1).to(dev, torch.int32), it["token"].reshape(-1).to(dev, torch.int32)]).clamp(min=0) for it in items]
+        n_tok = [int(t.numel()) for t in toks]
+        len1 = [int(it["prompt_feat"].shape[1]) for it in items]
+        n_enc = [n if finalize else n - self.pre_lookahead_len for n in n_tok]
+        len2 = [2 * e - l for e, l in zip(n_enc, len1)]
+        if min(len2) <= 0:
+            raise ValueError("no new frames to generate")
+        if 2 * max(n_enc) > self._noise_cl.shape[0]:
+            raise ValueError("%d mel frames exceed the fixed CFM noise buffer (%d frames)" % (2 * max(n_enc), self._noise_cl.shape[0]))
+        ids = self.lib.hook(torch.cat(toks).contiguous())
+        pf = self.lib.hook(torch.cat([it["prompt_feat"].to(dev, torch.float32).reshape(-1, self.cfg.mel) for it in items] + [torch.zeros(1, self.cfg.mel, device=dev)]).contiguous())
+        emb = self.lib.hook(torch.stack([it["embedding"].to(dev, torch.float32).reshape(-1) for it in items]).contiguous())
+        out = self.lib.hook(torch.empty(self.cfg.mel * sum(len2), dtype=torch.float32, device=dev))
+        got = (C.c_int32 * nu)()
+        self.lib.cv_flow_inference_ragged(self._h, C.c_int32(nu), C.c_void_p(ids.data_ptr()), (C.c_int32 * nu)(*n_tok), C.c_void_p(pf.data_ptr()), (C.c_int32 * nu)(*len1),
+                                          C.c_void_p(emb.data_ptr()), C.c_void_p(self._noise_cl.data_ptr()), C.c_int32(int(streaming)), C.c_int32(int(finalize)),
+                                          C.c_int32(self.n_timesteps), C.c_void_p(out.data_ptr()), got, stream_ptr(self.lib))
+        assert list(got) == len2
+        res, off = [], 0
+        for l in len2:
+            res.append(out[off:off + self.cfg.mel * l].view(1, self.cfg.mel, l))
+            off += self.cfg.mel * l
+        return res
 
 
 class CausalMaskedDiffWithDiT(CausalMaskedDiffWithXvec):

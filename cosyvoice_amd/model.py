@@ -61,7 +61,8 @@ class CosyVoice2Model:
         # (cloned handles over the same weights, one HIP stream each) and concurrent token2wav calls then overlap on the GPU - the flow and
         # the vocoder are chains of small latency-bound kernels that leave most of the 256 CUs idle
         self.n_lanes, self._lane_q = 0, queue.Queue()
-        self.flow_batch = 4                    # offline batch paths (tts_batch / tts_queue): sequences of equal shape share one flow pass
+        self.flow_batch = 4                    # offline batch paths (tts_batch / tts_queue): up to this many sequences share one flow pass ...
+        self.flow_pad = 1.25                   # ... when the longest of them has at most this many times the frames of the shortest (padded pass)
         self.set_lanes(1)
         self.tts_speech_token_dict, self.llm_end_dict, self.hift_cache_dict, self._cond = {}, {}, {}, {}
         self._llm_error = {}                   # uuid -> exception raised on the LLM thread, re-raised by tts() on the caller's thread
@@ -266,16 +267,20 @@ class CosyVoice2Model:
 
     def _vocode_all(self, job_lists, speed):
         """job_lists: iterable of lists of (index, request, tokens) - each list holds the sequences that became available together; yields
-        (index, {'tts_speech'}) as they complete.  A list is cut into groups of up to `flow_batch` sequences of equal shape; the groups run on
-        the token2wav lanes, one worker thread per lane."""
+        (index, {'tts_speech'}) as they complete.  A list is cut into groups of up to `flow_batch` sequences of similar length (equal shapes share an
+        unpadded pass); the groups run on the token2wav lanes, one worker thread per lane."""
         def groups(jobs):
-            by_shape = {}
-            for j in jobs:
-                r = j[1]
-                by_shape.setdefault((len(j[2]), int(r["flow_prompt_speech_token"].shape[1]), int(r["prompt_speech_feat"].shape[1])), []).append(j)
-            for same in by_shape.values():
-                for k in range(0, len(same), max(1, self.flow_batch)):
-                    yield same[k:k + max(1, self.flow_batch)]
+            # longest first; a group takes the next sequences while their frame count stays within 1 / flow_pad of the group's longest: the padded pass
+            # (cv_flow_inference_ragged) computes every member at the longest length, so at most flow_pad - 1 of a member's work is padding
+            n_tok = lambda j: len(j[2]) + int(j[1]["flow_prompt_speech_token"].shape[1])
+            order = sorted(jobs, key=lambda j: (-n_tok(j), j[0]))
+            k, cap = 0, max(1, self.flow_batch)
+            while k < len(order):
+                e = k + 1
+                while e < len(order) and e - k < cap and n_tok(order[e]) * self.flow_pad >= n_tok(order[k]):
+                    e += 1
+                yield order[k:e]
+                k = e
         if self.n_lanes == 1:
             for jobs in job_lists:
                 for grp in groups(jobs):

@@ -65,8 +65,9 @@ def norm_rows(lib, x, gamma=None, beta=None, eps=1e-5, rms=False, act="none", sc
     return y
 
 
-def attention(lib, q, k, v, *, scale, mask="none", chunk=0, kv_group=1, rel_bd=None, bf16=False):
-    """q [B,Tq,H,64], k/v [B,Tk,Hkv,64] (any strides that are multiples of 4 floats) -> o [B,Tq,H,64]."""
+def attention(lib, q, k, v, *, scale, mask="none", chunk=0, kv_group=1, rel_bd=None, bf16=False, klen=None):
+    """q [B,Tq,H,64], k/v [B,Tk,Hkv,64] (any strides that are multiples of 4 floats) -> o [B,Tq,H,64].  klen: optional int32 [B] on the device, batch
+    row b attends keys < klen[b] only."""
     B, Tq, H, D = q.shape
     Tk = k.shape[1]
     assert D == 64
@@ -82,5 +83,6 @@ def attention(lib, q, k, v, *, scale, mask="none", chunk=0, kv_group=1, rel_bd=N
         assert rel_bd.shape == (B, H, Tq, 2 * Tq - 1) and rel_bd.is_contiguous()
         a.rel_bd = rel_bd.data_ptr(); a.bd_batch = rel_bd.stride(0); a.bd_head = rel_bd.stride(1); a.bd_row = rel_bd.stride(2)
     a.bf16 = int(bf16)
+    a.klen = klen.data_ptr() if klen is not None else None
     lib.cv_attention(C.byref(a), stream_ptr(lib))
     return o

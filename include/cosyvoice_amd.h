@@ -83,6 +83,8 @@ typedef struct cv_attn_args {
     const float* rel_bd; int64_t bd_batch; int64_t bd_head; int32_t bd_row;
     int32_t bf16;        /* 1: q, k, v and the probabilities rounded to bf16, both products on the bf16 MFMA (fp32 softmax and accumulate);
                             workgroup shape chosen from the problem size (2 / 3 force the 64- / 32-query variant) */
+    const int32_t* klen; /* optional dev [B]: batch row b attends keys < min(Tk, klen[b]) (a padded batch of unequal lengths, the reference's
+                            `mask` of flow/flow.py:236-281); null = every row attends Tk keys.  A row's result is bit-identical to the row alone. */
 } cv_attn_args;
 int cv_attention(const cv_attn_args* args, void* stream);
 
@@ -192,6 +194,13 @@ int cv_flow_inference(cv_flow* m, const int32_t* token_ids, int32_t n_tok, const
  * [n_utt][mel_len1][80], embedding dev [n_utt][spk_dim], mel_out dev [n_utt][80][T - mel_len1].  The encoder runs per utterance, the CFM Euler solve
  * once over all of them (estimator batch rows = 2 x n_utt); each utterance's result is what cv_flow_inference gives for it alone
  * (the reference's own contract for batched flow, flow/flow.py:246).  CausalConditionalDecoder estimator only. */
+/* The same for utterances of DIFFERENT lengths (the reference's padded batch with `mask`, flow/flow.py:236-281): token_ids dev, the utterances'
+ * ids one after the other; n_tok / mel_len1 HOST arrays [n_utt]; prompt_feat dev, the prompts' [mel_len1[u]][80] blocks one after the other;
+ * mel_out dev, the results' [80][mel_len2[u]] blocks one after the other; mel_len2_out HOST [n_utt].  Each result is bit-identical to the
+ * utterance alone: convolutions are causal, attention takes a key count per batch row (cv_attn_args.klen). */
+int cv_flow_inference_ragged(cv_flow* m, int32_t n_utt, const int32_t* token_ids, const int32_t* n_tok, const float* prompt_feat, const int32_t* mel_len1,
+                             const float* embedding, const float* noise_cl, int32_t streaming, int32_t finalize, int32_t n_timesteps, float* mel_out,
+                             int32_t* mel_len2_out, void* stream);
 int cv_flow_inference_batch(cv_flow* m, int32_t n_utt, const int32_t* token_ids, int32_t n_tok, const float* prompt_feat, int32_t mel_len1, const float* embedding,
                             const float* noise_cl, int32_t streaming, int32_t finalize, int32_t n_timesteps, float* mel_out, int32_t* mel_len2_out, void* stream);
 

@@ -125,3 +125,24 @@ def test_dit_inference_batch_equals_single(lib, tiny, precision):
     assert torch.equal(single(items[0], tok_long), fresh.inference(token=tok_long, token_len=n(27), prompt_token=items[0]["prompt_token"], prompt_token_len=n(5),
                                                                   prompt_feat=items[0]["prompt_feat"], prompt_feat_len=n(10), embedding=items[0]["embedding"],
                                                                   streaming=False, finalize=True)[0].cpu())
+
+
+def test_dit_inference_ragged_equals_single(lib, tiny):
+    """The DiT estimator in a padded batch of different lengths (cv_flow_inference_ragged): causal position convs, per-row norms, attention with a key
+    count per batch row - every utterance bit-identical to itself alone."""
+    import dataclasses
+    cfg, sd = tiny
+    cfg = dataclasses.replace(cfg, n_timesteps=2)
+    flow = CausalMaskedDiffWithDiT(sd, cfg, lib=lib, precision="bf16")
+    g = torch.Generator().manual_seed(74)
+    n = lambda k: torch.tensor([k], dtype=torch.int32)
+    shapes = [(13, 5, 10), (8, 6, 12), (19, 4, 8)]
+    items = [dict(token=torch.randint(0, cfg.vocab, (1, a), generator=g, dtype=torch.int32), prompt_token=torch.randint(0, cfg.vocab, (1, b), generator=g, dtype=torch.int32),
+                  prompt_feat=torch.randn(1, c, cfg.mel, generator=g) * 2 - 5, embedding=torch.randn(1, cfg.spk_dim, generator=g)) for a, b, c in shapes]
+    for streaming, finalize in ((False, True), (True, False)):
+        alone = [flow.inference(token=it["token"], token_len=n(it["token"].shape[1]), prompt_token=it["prompt_token"], prompt_token_len=n(it["prompt_token"].shape[1]),
+                                prompt_feat=it["prompt_feat"], prompt_feat_len=n(it["prompt_feat"].shape[1]), embedding=it["embedding"], streaming=streaming,
+                                finalize=finalize)[0].cpu() for it in items]
+        for rep in range(3):
+            for a, b in zip(alone, flow.inference_batch(items, streaming=streaming, finalize=finalize)):
+                assert a.shape == b.shape and torch.equal(a, b.cpu())

@@ -338,3 +338,35 @@ def test_flow_inference_batch_equals_single(lib, precision):
     long2 = fresh.inference(token=tok_long, token_len=n(27), prompt_token=it["prompt_token"], prompt_token_len=n(5), prompt_feat=it["prompt_feat"], prompt_feat_len=n(10),
                             embedding=it["embedding"], streaming=False, finalize=True)[0].cpu()
     assert torch.equal(long1, long2)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("streaming,finalize", [(False, True), (True, False)])
+def test_flow_inference_ragged_equals_single(lib, precision, streaming, finalize):
+    """cv_flow_inference_ragged: utterances of DIFFERENT lengths (tokens, prompt tokens, prompt frames) padded into one pass give, each, exactly the mel
+    `inference()` gives for it alone - the reference's contract for its masked, padded batch (flow/flow.py:236-281).  Convolutions are causal, norms
+    per row, attention takes the key count of every batch row; then equal-shape and single calls on the same handle."""
+    import dataclasses
+    cfg = dataclasses.replace(W.tiny()[1], n_timesteps=2)
+    sd = W.make_flow(cfg)
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision=precision)
+    g = torch.Generator().manual_seed(73)
+    n = lambda k: torch.tensor([k], dtype=torch.int32)
+    shapes = [(14, 5, 10), (9, 7, 12), (21, 4, 6)]                 # (new tokens, prompt tokens, prompt frames)
+    items = [dict(token=torch.randint(0, cfg.vocab, (1, a), generator=g, dtype=torch.int32), prompt_token=torch.randint(0, cfg.vocab, (1, b), generator=g, dtype=torch.int32),
+                  prompt_feat=torch.randn(1, c, cfg.mel, generator=g) * 2 - 5, embedding=torch.randn(1, cfg.spk_dim, generator=g)) for a, b, c in shapes]
+    single = lambda it: flow.inference(token=it["token"], token_len=n(it["token"].shape[1]), prompt_token=it["prompt_token"], prompt_token_len=n(it["prompt_token"].shape[1]),
+                                       prompt_feat=it["prompt_feat"], prompt_feat_len=n(it["prompt_feat"].shape[1]), embedding=it["embedding"],
+                                       streaming=streaming, finalize=finalize)[0].cpu()
+    alone = [single(it) for it in items]
+    assert len({a.shape[2] for a in alone}) == 3
+    for rep in range(3):                                          # the third call replays the captured graph of the padded solve
+        got = flow.inference_batch(items, streaming=streaming, finalize=finalize)
+        for a, b in zip(alone, got):
+            assert a.shape == b.shape and torch.equal(a, b.cpu())
+    got = flow.inference_batch(items[::-1], streaming=streaming, finalize=finalize)       # another order: another padding pattern
+    for a, b in zip(alone[::-1], got):
+        assert torch.equal(a, b.cpu())
+    assert torch.equal(single(items[0]), alone[0])
+    same = flow.inference_batch([items[1], items[1]], streaming=streaming, finalize=finalize)   # the equal-shape path after a padded one
+    assert torch.equal(same[0].cpu(), alone[1]) and torch.equal(same[1].cpu(), alone[1])

@@ -324,8 +324,8 @@ def test_cosyvoice3_model_matches_reference_golden(lib):
 
 
 def test_cosyvoice3_tts_batch_shares_one_flow_pass(lib):
-    """CosyVoice3Model.tts_batch: finished sequences of equal shape go through the DiT flow in ONE pass (cv_flow_inference_batch, estimator batch rows
-    2 x utterances), then through the causal HiFT one by one; every waveform equals tts() of that request alone bit for bit."""
+    """CosyVoice3Model.tts_batch: finished sequences of similar length go through the DiT flow in ONE padded pass (cv_flow_inference_ragged, estimator
+    batch rows 2 x utterances), then through the causal HiFT one by one; every waveform equals tts() of that request alone bit for bit."""
     from cosyvoice_amd.flow import CausalMaskedDiffWithDiT
     from cosyvoice_amd.hift import CausalHiFTGenerator
     from cosyvoice_amd.model import CosyVoice3Model
@@ -352,8 +352,41 @@ def test_cosyvoice3_tts_batch_shares_one_flow_pass(lib):
     fb = m.flow.inference_batch
     m.flow.inference_batch = lambda items, **kw: (calls.append(len(items)), fb(items, **kw))[1]
     got = m.tts_batch(reqs)
-    assert calls == [3]                                           # the three 12-token requests shared a pass, the 9-token one went alone
+    assert calls == [4]                                           # one padded pass: the 9-token request is within flow_pad of the three 12-token ones
     alone = [next(iter(m.tts(**r, stream=False)))["tts_speech"] for r in reqs]
     for a, b in zip(alone, got):
         assert torch.equal(a, b["tts_speech"])
     assert not torch.equal(alone[0], alone[1]) and not m.hift_cache_dict
+
+
+def test_tts_batch_pads_similar_lengths_into_one_flow_pass(lib, setup):
+    """tts_batch buckets finished sequences by length: sequences within `flow_pad` of the group's longest share ONE padded flow pass
+    (cv_flow_inference_ragged), a much shorter one goes alone; every waveform equals tts() of that request alone bit for bit."""
+    cfgs, sds, u = setup
+    lc, fc, hc = cfgs
+    fc1 = dataclasses.replace(fc, n_timesteps=1)
+    m = CosyVoice2Model.from_state_dicts(sds[0], sds[1], sds[2], (lc, fc1, hc), lib=lib, max_len=160, sampling="greedy")
+    g = torch.Generator().manual_seed(41)
+    lens = [20, 18, 17, 6]
+    scripts = [torch.randint(0, fc.vocab, (k,), generator=g).tolist() for k in lens]
+    us = [W.synthetic_utterance(lc, fc, n_prompt_tok=6 + (i % 2), n_prompt_text=2, n_text=2, seed=60 + i) for i in range(4)]
+    keys = ("text", "flow_embedding", "llm_embedding", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat")
+    reqs = [{k: x[k] for k in keys} for x in us]
+    which = lambda text: next(i for i, r in enumerate(reqs) if torch.equal(r["text"].cpu(), text.cpu()))
+
+    class ScriptedLLM:
+        def inference_batch(self, rs):
+            return [list(scripts[which(r["text"])]) for r in rs]
+
+        def inference(self, **kw):
+            yield from scripts[which(kw["text"])]
+    m.llm = ScriptedLLM()
+    calls = []
+    fb = m.flow.inference_batch
+    m.flow.inference_batch = lambda items, **kw: (calls.append(sorted(int(it["token"].shape[1]) for it in items)), fb(items, **kw))[1]
+    got = m.tts_batch(reqs)
+    assert calls == [[17, 18, 20]]                                # (26 + 1.25 x ...) the 6-token request is too short for the group and goes alone
+    alone = [next(iter(m.tts(**r, stream=False)))["tts_speech"] for r in reqs]
+    for a, b, k in zip(alone, got, lens):
+        assert a.shape[1] == k * 2 * 480 and torch.equal(a, b["tts_speech"])
+    assert not m.hift_cache_dict

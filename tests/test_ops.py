@@ -303,3 +303,23 @@ def test_linear_three_term_split_is_fp32_exact(lib, M, N, K, taps, monkeypatch):
     out = ops.gemm_conv(lib, y, Wp, Kp, M=M, N=N, K=K, taps=taps, lda=K, tap_step=K, a_len=y.numel())[0].cpu().double()
     refy = sum(y.cpu().double()[j:j + M] @ W.cpu().double()[:, j].t() for j in range(taps))
     assert (out - refy).abs().max().item() / refy.abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("mode,chunk", [("none", 0), ("chunk", 16)])
+def test_attention_key_counts_per_batch_row(lib, bf16, mode, chunk):
+    """cv_attn_args.klen: in a padded batch, row b attends only its own klen[b] keys - and its valid queries get EXACTLY (bit for bit) what the same
+    row gets alone in a batch of its own length: the key loop ends where it ends for the row alone."""
+    dev = _dev(lib)
+    B, H, T = 3, 2, 150
+    lens = [150, 97, 33]
+    q = _rand((B, T, H, 64), dev, 31); k = _rand((B, T, H, 64), dev, 32); v = _rand((B, T, H, 64), dev, 33)
+    klen = lib.hook(torch.tensor(lens, dtype=torch.int32).to(dev))
+    got = ops.attention(lib, q, k, v, scale=0.125, mask=mode, chunk=chunk, bf16=bf16, klen=klen)
+    _sync(lib)
+    for b, n in enumerate(lens):
+        alone = ops.attention(lib, lib.hook(q[b:b + 1, :n].contiguous()), lib.hook(k[b:b + 1, :n].contiguous()), lib.hook(v[b:b + 1, :n].contiguous()),
+                              scale=0.125, mask=mode, chunk=chunk, bf16=bf16)
+        _sync(lib)
+        assert torch.equal(got[b, :n].cpu(), alone[0].cpu())
+        assert bool(torch.isfinite(got[b]).all())

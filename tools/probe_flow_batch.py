@@ -40,3 +40,26 @@ if len(sys.argv) > 1 and sys.argv[1] == "sweep":
             ms = (time.perf_counter() - t0) / 4 * 1e3
             print("nu=%d %-16s %.2f ms = %.2f ms per utterance" % (nu, name, ms, ms / nu), flush=True)
             opt("flow_tile", 0); opt("attn_ks", 2); opt("attn_kt", 1)
+
+# padded pass over utterances of different lengths (cv_flow_inference_ragged) vs the same utterances one by one
+if len(sys.argv) > 1 and sys.argv[1] == "ragged":
+    for lens in ((250, 235, 220, 205), (250, 250, 200, 200), (500, 450, 420, 400), (125, 120, 110, 100)):
+        its = [dict(item, token=torch.randint(0, fc.vocab, (1, k), generator=g, dtype=torch.int32)) for k in lens]
+        def one_by_one():
+            for it in its:
+                flow.inference_batch([it])
+        def padded():
+            flow.inference_batch(its)
+        res = []
+        for fn in (one_by_one, padded):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(4):
+                fn()
+            torch.cuda.synchronize()
+            res.append((time.perf_counter() - t0) / 4 * 1e3)
+        a = [flow.inference_batch([it])[0].clone() for it in its]
+        b = flow.inference_batch(its)
+        same = all(torch.equal(x, y) for x, y in zip(a, b))
+        print("tokens %s: one by one %.2f ms, one padded pass %.2f ms (x%.2f), bit-identical %s" % (lens, res[0], res[1], res[0] / res[1], same), flush=True)
