@@ -8,7 +8,8 @@
   cli/model.py:345-360 - the default) or `time_based` (model.py:410-426) hop growth.  Every request's audio equals `tts(stream=True)` of
   that request alone under `exponential` (chunk boundaries depend only on token counts).
 * `create_app(engine)` - the FastAPI surface of `runtime/python/fastapi/server.py:46-86` (same routes, int16 PCM `StreamingResponse`)
-  over any engine exposing the `CosyVoice2.inference_*` generators.  Text normalisation / tokenisation and the ONNX extractors (speech
+  over any engine exposing the `CosyVoice2.inference_*` generators; `create_grpc_server(engine)` - the `CosyVoice.Inference` service of
+  `runtime/python/grpc/server.py:34-77`, wire-compatible with the reference's cosyvoice.proto.  Text normalisation / tokenisation and the ONNX extractors (speech
   tokenizer, CAM++) are the reference front end's job (`cosyvoice/cli/frontend.py`, out of scope here - SURVEY.md section 8f item 2): `Engine`
   takes such a front end as an object and only replaces its mel extractor and the model underneath.
 """
@@ -326,3 +327,84 @@ def create_app(engine, load_wav=None):
         return StreamingResponse(pcm16_stream(engine.inference_instruct2(tts_text, instruct_text, wav)))
 
     return app
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# gRPC adapter (runtime/python/grpc/server.py + cosyvoice.proto)
+# ---------------------------------------------------------------------------------------------------------------------------------
+_GRPC_MESSAGES = None
+
+
+def grpc_messages():
+    """(Request, Response) message classes of runtime/python/grpc/cosyvoice.proto (package `cosyvoice`: Request = oneof {sft_request = 1,
+    zero_shot_request = 2, cross_lingual_request = 3, instruct_request = 4}, Response{bytes tts_audio = 1}), built from a descriptor at import
+    time - the image has grpcio and protobuf but no protoc plugin.  Same field names and numbers, so the reference's client.py talks to it."""
+    global _GRPC_MESSAGES
+    if _GRPC_MESSAGES is not None:
+        return _GRPC_MESSAGES
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    f = descriptor_pb2.FileDescriptorProto(name="cosyvoice_amd/cosyvoice.proto", package="cosyvoice", syntax="proto3")
+    STR, BYTES, MSG = (descriptor_pb2.FieldDescriptorProto.TYPE_STRING, descriptor_pb2.FieldDescriptorProto.TYPE_BYTES,
+                       descriptor_pb2.FieldDescriptorProto.TYPE_MESSAGE)
+
+    def message(name, fields):
+        m = f.message_type.add(name=name)
+        for i, (fname, ftype) in enumerate(fields, 1):
+            m.field.add(name=fname, number=i, type=ftype, label=descriptor_pb2.FieldDescriptorProto.LABEL_OPTIONAL)
+        return m
+    message("sftRequest", [("spk_id", STR), ("tts_text", STR)])
+    message("zeroshotRequest", [("tts_text", STR), ("prompt_text", STR), ("prompt_audio", BYTES)])
+    message("crosslingualRequest", [("tts_text", STR), ("prompt_audio", BYTES)])
+    message("instructRequest", [("tts_text", STR), ("spk_id", STR), ("instruct_text", STR)])
+    message("Response", [("tts_audio", BYTES)])
+    req = f.message_type.add(name="Request")
+    req.oneof_decl.add(name="RequestPayload")
+    for i, (fname, tname) in enumerate([("sft_request", "sftRequest"), ("zero_shot_request", "zeroshotRequest"),
+                                        ("cross_lingual_request", "crosslingualRequest"), ("instruct_request", "instructRequest")], 1):
+        req.field.add(name=fname, number=i, type=MSG, type_name=".cosyvoice." + tname, label=descriptor_pb2.FieldDescriptorProto.LABEL_OPTIONAL, oneof_index=0)
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(f)
+    get = lambda n: message_factory.GetMessageClass(pool.FindMessageTypeByName("cosyvoice." + n))
+    _GRPC_MESSAGES = (get("Request"), get("Response"))
+    return _GRPC_MESSAGES
+
+
+GRPC_METHOD = "/cosyvoice.CosyVoice/Inference"
+
+
+def _pcm16_prompt(raw):
+    """server.py:47-48: the prompt travels as raw little-endian int16 samples at 16 kHz."""
+    return torch.from_numpy(np.array(np.frombuffer(raw, dtype=np.int16))).unsqueeze(dim=0).float() / (2 ** 15)
+
+
+def create_grpc_server(engine, port=50000, max_conc=4, host="0.0.0.0"):
+    """The `CosyVoice.Inference` service of runtime/python/grpc/server.py:34-77 (one request message, a stream of int16 PCM responses) over any
+    engine exposing the `inference_*` generators.  Returns (grpc.Server - not started -, bound port)."""
+    from concurrent import futures
+    import grpc
+    Request, Response = grpc_messages()
+
+    def inference(request, context):
+        kind = request.WhichOneof("RequestPayload")
+        if kind == "sft_request":
+            out = engine.inference_sft(request.sft_request.tts_text, request.sft_request.spk_id)
+        elif kind == "zero_shot_request":
+            r = request.zero_shot_request
+            out = engine.inference_zero_shot(r.tts_text, r.prompt_text, _pcm16_prompt(r.prompt_audio))
+        elif kind == "cross_lingual_request":
+            r = request.cross_lingual_request
+            out = engine.inference_cross_lingual(r.tts_text, _pcm16_prompt(r.prompt_audio))
+        elif kind == "instruct_request" and hasattr(engine, "inference_instruct"):
+            r = request.instruct_request
+            out = engine.inference_instruct(r.tts_text, r.spk_id, r.instruct_text)
+        else:       # CosyVoice2 / 3 engines have inference_instruct2 (needs a prompt wav, which this message does not carry): say so instead of guessing
+            context.abort(grpc.StatusCode.UNIMPLEMENTED, "this engine has no inference_instruct (instructRequest carries no prompt audio)" if kind else "empty request")
+            return
+        for chunk in pcm16_stream(out):
+            yield Response(tts_audio=chunk)
+    handler = grpc.method_handlers_generic_handler("cosyvoice.CosyVoice", {"Inference": grpc.unary_stream_rpc_method_handler(
+        inference, request_deserializer=Request.FromString, response_serializer=Response.SerializeToString)})
+    server = grpc.server(futures.ThreadPoolExecutor(max_workers=max_conc), maximum_concurrent_rpcs=max_conc)
+    server.add_generic_rpc_handlers((handler,))
+    bound = server.add_insecure_port("%s:%d" % (host, port))
+    return server, bound

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
     """The CPU suite (`-m "not gpu"`) is dominated by kernel tests under the HIP-execution-model emulator, single-threaded per test: run the test
-    files on 4 pytest-xdist workers (13.5 -> 5.5 min on the 8-core build container).  GPU runs (`-m gpu`) stay in ONE process: one model at a time on
+    files on 6 pytest-xdist workers (13.5 -> 5.5 min on the 8-core build container with the round-2 test set).  GPU runs (`-m gpu`) stay in ONE process: one model at a time on
     the device, and the process that loads libcosyvoice_amd.so is the pytest process itself.  `CV_TEST_SERIAL=1` or an explicit `-n` overrides."""
     try:
         import xdist  # noqa: F401
@@ -20,7 +20,7 @@ def pytest_cmdline_main(config):
         return None
     if (config.getoption("markexpr", "") or "").strip() == "not gpu" and getattr(config.option, "numprocesses", None) is None \
             and not os.environ.get("CV_TEST_SERIAL") and not os.environ.get("PYTEST_XDIST_WORKER"):
-        config.option.numprocesses = 4
+        config.option.numprocesses = 6
         config.option.dist = "loadfile"
     return None
 
@@ -28,10 +28,10 @@ def pytest_cmdline_main(config):
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     if os.environ.get("PYTEST_XDIST_WORKER"):
-        # CPU suite under pytest-xdist (pytest.ini: -n 4): the emulator is single-threaded and the oracle's torch ops are small, so a few intra-op
-        # threads per worker are enough - 4 workers x all cores each only fight over the machine
+        # CPU suite under pytest-xdist (6 workers): the emulator is single-threaded and the oracle's torch ops are small, so one or two intra-op
+        # threads per worker are enough - 6 workers x all cores each only fight over the machine
         import torch
-        torch.set_num_threads(max(1, min(4, (os.cpu_count() or 4) // 4)))
+        torch.set_num_threads(max(1, min(2, (os.cpu_count() or 6) // 6)))
 
 
 @pytest.fixture(scope="session")

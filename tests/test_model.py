@@ -121,55 +121,6 @@ def test_two_concurrent_streaming_requests(lib, setup):
     assert not m.tts_speech_token_dict and not m.hift_cache_dict
 
 
-def test_token2wav_lanes(lib, setup):
-    """set_lanes(n): token2wav calls of different requests run concurrently on cloned flow / HiFT handles (same weights, own workspaces,
-    one HIP stream each).  Every waveform - harmonic-source noise included (its RNG key comes from the request's tokens) - must equal the
-    single-lane result bit for bit, whatever lane served it and in whatever order."""
-    cfgs, sds, u = setup
-    lc, fc, hc = cfgs
-    fc1 = dataclasses.replace(fc, n_timesteps=1)
-    m = CosyVoice2Model.from_state_dicts(sds[0], sds[1], sds[2], (lc, fc1, hc), lib=lib, max_len=160, sampling="greedy")
-    inf_b = m.llm.inference_batch
-    m.llm.inference_batch = lambda reqs: inf_b(reqs, max_token_text_ratio=4, min_token_text_ratio=2)
-    us = [W.synthetic_utterance(lc, fc, n_prompt_tok=5 + i, n_prompt_text=2, n_text=1 + i % 2, seed=60 + i) for i in range(3 if not lib.emulated else 2)]
-    keys = ("text", "flow_embedding", "llm_embedding", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat")
-    reqs = [{k: x[k] for k in keys} for x in us]
-    one = m.tts_batch(reqs)
-    m.set_lanes(2)
-    assert m.n_lanes == 2 and m._lane_q.qsize() == 2
-    two = m.tts_batch(reqs)
-    rev = m.tts_batch(reqs[::-1])[::-1] if not lib.emulated else two      # (the emulator run is kept short)
-    for a, b, c in zip(one, two, rev):
-        assert a["tts_speech"].abs().max() > 0
-        assert torch.equal(a["tts_speech"], b["tts_speech"]) and torch.equal(a["tts_speech"], c["tts_speech"])
-    assert not m.hift_cache_dict and m._lane_q.qsize() == 2
-
-
-def test_tts_batch_shares_one_flow_pass_between_equal_shapes(lib, setup):
-    """tts_batch groups finished sequences of equal shape (token count, prompt tokens, prompt frames) into ONE flow pass
-    (CausalMaskedDiffWithXvec.inference_batch, cv_flow_inference_batch); every waveform must equal tts() of that request alone bit for bit."""
-    cfgs, sds, u = setup
-    lc, fc, hc = cfgs
-    fc1 = dataclasses.replace(fc, n_timesteps=1)
-    m = CosyVoice2Model.from_state_dicts(sds[0], sds[1], sds[2], (lc, fc1, hc), lib=lib, max_len=160, sampling="greedy")
-    inf_b, inf_1 = m.llm.inference_batch, m.llm.inference
-    m.llm.inference_batch = lambda reqs: inf_b(reqs, max_token_text_ratio=3, min_token_text_ratio=3)      # 6 tokens each: equal shapes
-    m.llm.inference = lambda **kw: inf_1(**{**kw, "max_token_text_ratio": 3, "min_token_text_ratio": 3})
-    us = [W.synthetic_utterance(lc, fc, n_prompt_tok=6, n_prompt_text=2, n_text=2, seed=80 + i) for i in range(3)]
-    keys = ("text", "flow_embedding", "llm_embedding", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat")
-    reqs = [{k: x[k] for k in keys} for x in us]
-    calls = []
-    fb = m.flow.inference_batch
-    m.flow.inference_batch = lambda items, **kw: (calls.append(len(items)), fb(items, **kw))[1]
-    got = m.tts_batch(reqs)
-    lens = [g["tts_speech"].shape[1] for g in got]
-    assert sum(calls) >= 2 and sorted(calls) == sorted(n for n in (lens.count(v) for v in set(lens)) if n > 1)      # equal shapes shared a pass (a stop id other than eos may end a sequence early)
-    alone = [next(iter(m.tts(**r, stream=False)))["tts_speech"] for r in reqs]
-    for a, g in zip(alone, got):
-        assert torch.equal(a, g["tts_speech"])
-    assert not torch.equal(alone[0], alone[1]) and not m.hift_cache_dict
-
-
 def test_llm_job_silent_token_filter(lib, setup):
     """cli/model.py:101-129: tokens listed in `silent_tokens` (CosyVoice3: FSQ silence / breath ids, :423) are kept for the first
     5 consecutive occurrences and dropped beyond that; any other token resets the run.  Host logic, driven with a stub generator."""
@@ -290,103 +241,3 @@ def test_max_len_is_clamped_to_kv_capacity(lib, setup):
     with pytest.raises(ValueError, match="KV capacity"):
         list(lm.inference(text=u["text"], text_len=t(2), prompt_text=u["prompt_text"], prompt_text_len=t(4), prompt_speech_token=u["llm_prompt_speech_token"],
                           prompt_speech_token_len=t(8), max_token_text_ratio=40, min_token_text_ratio=20))
-
-
-def test_cosyvoice3_model_matches_reference_golden(lib):
-    """a17: CosyVoice3Model.tts / token2wav on the device (CausalMaskedDiffWithDiT + CausalHiFTGenerator, accumulating mel cache, speech offsets,
-    silent-token filter) against the REAL cosyvoice.cli.model.CosyVoice3Model driving the real tiny modules with the same scripted tokens."""
-    import os
-    from cosyvoice_amd.flow import CausalMaskedDiffWithDiT
-    from cosyvoice_amd.hift import CausalHiFTGenerator
-    from cosyvoice_amd.model import CosyVoice3Model
-    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(os.path.dirname(__file__), "golden", "model_cv3_tiny.npz")).items()}
-    lc, _, hc0 = W.tiny()
-    fc, hc = W.tiny_cv3_flow(), dataclasses.replace(hc0, causal=True)
-    u = W.synthetic_utterance(lc, fc, n_prompt_tok=8, n_prompt_text=4, n_text=2, seed=21)
-    tokens = g["tokens"].tolist()
-    m = CosyVoice3Model(None, CausalMaskedDiffWithDiT(W.make_flow_dit(fc), fc, lib=lib), CausalHiFTGenerator(W.make_hift(hc), hc, lib=lib), lib=lib)
-    assert m.silent_tokens == [1, 2, 28, 29, 55, 248, 494, 2241, 2242, 2322, 2323]
-
-    class ScriptedLLM:
-        def inference(self, **kw):
-            yield from tokens
-    m.llm = ScriptedLLM()
-    m.token_hop_len, m.token_max_hop_len = 5, 20
-    inf = m.hift.inference
-    m.hift.inference = lambda speech_feat, finalize=True: inf(speech_feat, finalize, noise=torch.zeros(speech_feat.shape[2] * 480, 9))
-    for key, stream in (("offline", False), ("stream", True)):
-        outs = [o["tts_speech"] for o in m.tts(text=u["text"], flow_embedding=u["flow_embedding"], llm_embedding=u["llm_embedding"], prompt_text=u["prompt_text"],
-                                               llm_prompt_speech_token=u["llm_prompt_speech_token"], flow_prompt_speech_token=u["flow_prompt_speech_token"],
-                                               prompt_speech_feat=u["prompt_speech_feat"], stream=stream)]
-        assert [o.shape[1] for o in outs] == g[key + "_n"].tolist()
-        torch.testing.assert_close(torch.cat(outs, 1), g[key], rtol=0, atol=5e-3)
-        assert not m.hift_cache_dict and not m.tts_speech_token_dict
-
-
-def test_cosyvoice3_tts_batch_shares_one_flow_pass(lib):
-    """CosyVoice3Model.tts_batch: finished sequences of similar length go through the DiT flow in ONE padded pass (cv_flow_inference_ragged, estimator
-    batch rows 2 x utterances), then through the causal HiFT one by one; every waveform equals tts() of that request alone bit for bit."""
-    from cosyvoice_amd.flow import CausalMaskedDiffWithDiT
-    from cosyvoice_amd.hift import CausalHiFTGenerator
-    from cosyvoice_amd.model import CosyVoice3Model
-    lc, _, hc0 = W.tiny()
-    fc, hc = dataclasses.replace(W.tiny_cv3_flow(), n_timesteps=1), dataclasses.replace(hc0, causal=True)
-    m = CosyVoice3Model(None, CausalMaskedDiffWithDiT(W.make_flow_dit(fc), fc, lib=lib), CausalHiFTGenerator(W.make_hift(hc), hc, lib=lib), lib=lib)
-    g = torch.Generator().manual_seed(31)
-    scripts = [torch.randint(3, fc.vocab, (12,), generator=g).tolist() for _ in range(3)] + [torch.randint(3, fc.vocab, (9,), generator=g).tolist()]
-    us = [W.synthetic_utterance(lc, fc, n_prompt_tok=6, n_prompt_text=2, n_text=2, seed=90 + i) for i in range(4)]
-    keys = ("text", "flow_embedding", "llm_embedding", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat")
-    reqs = [{k: x[k] for k in keys} for x in us]
-
-    class ScriptedLLM:                                            # request i is recognised by its text tensor
-        def _which(self, text):
-            return next(i for i, r in enumerate(reqs) if torch.equal(r["text"], text))
-
-        def inference_batch(self, rs):
-            return [list(scripts[self._which(r["text"])]) for r in rs]
-
-        def inference(self, **kw):
-            yield from scripts[self._which(kw["text"])]
-    m.llm = ScriptedLLM()
-    calls = []
-    fb = m.flow.inference_batch
-    m.flow.inference_batch = lambda items, **kw: (calls.append(len(items)), fb(items, **kw))[1]
-    got = m.tts_batch(reqs)
-    assert calls == [4]                                           # one padded pass: the 9-token request is within flow_pad of the three 12-token ones
-    alone = [next(iter(m.tts(**r, stream=False)))["tts_speech"] for r in reqs]
-    for a, b in zip(alone, got):
-        assert torch.equal(a, b["tts_speech"])
-    assert not torch.equal(alone[0], alone[1]) and not m.hift_cache_dict
-
-
-def test_tts_batch_pads_similar_lengths_into_one_flow_pass(lib, setup):
-    """tts_batch buckets finished sequences by length: sequences within `flow_pad` of the group's longest share ONE padded flow pass
-    (cv_flow_inference_ragged), a much shorter one goes alone; every waveform equals tts() of that request alone bit for bit."""
-    cfgs, sds, u = setup
-    lc, fc, hc = cfgs
-    fc1 = dataclasses.replace(fc, n_timesteps=1)
-    m = CosyVoice2Model.from_state_dicts(sds[0], sds[1], sds[2], (lc, fc1, hc), lib=lib, max_len=160, sampling="greedy")
-    g = torch.Generator().manual_seed(41)
-    lens = [20, 18, 17, 6]
-    scripts = [torch.randint(0, fc.vocab, (k,), generator=g).tolist() for k in lens]
-    us = [W.synthetic_utterance(lc, fc, n_prompt_tok=6 + (i % 2), n_prompt_text=2, n_text=2, seed=60 + i) for i in range(4)]
-    keys = ("text", "flow_embedding", "llm_embedding", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat")
-    reqs = [{k: x[k] for k in keys} for x in us]
-    which = lambda text: next(i for i, r in enumerate(reqs) if torch.equal(r["text"].cpu(), text.cpu()))
-
-    class ScriptedLLM:
-        def inference_batch(self, rs):
-            return [list(scripts[which(r["text"])]) for r in rs]
-
-        def inference(self, **kw):
-            yield from scripts[which(kw["text"])]
-    m.llm = ScriptedLLM()
-    calls = []
-    fb = m.flow.inference_batch
-    m.flow.inference_batch = lambda items, **kw: (calls.append(sorted(int(it["token"].shape[1]) for it in items)), fb(items, **kw))[1]
-    got = m.tts_batch(reqs)
-    assert calls == [[17, 18, 20]]                                # (26 + 1.25 x ...) the 6-token request is too short for the group and goes alone
-    alone = [next(iter(m.tts(**r, stream=False)))["tts_speech"] for r in reqs]
-    for a, b, k in zip(alone, got, lens):
-        assert a.shape[1] == k * 2 * 480 and torch.equal(a, b["tts_speech"])
-    assert not m.hift_cache_dict

@@ -238,3 +238,51 @@ def test_fastapi_adapter_with_stub_engine():
     assert r.status_code == 200 and np.frombuffer(r.content, dtype=np.int16).tolist() == [97] * 3 + [98] * 3
     r = client.post("/inference_instruct2", params={"tts_text": "ab", "instruct_text": "i"}, content=buf.getvalue())
     assert r.status_code == 200 and np.frombuffer(r.content, dtype=np.int16).tolist() == [8192, 8192]
+
+
+@pytest.mark.timeout(120)
+def test_grpc_adapter_with_stub_engine():
+    """runtime/python/grpc/server.py:34-77 + cosyvoice.proto over a stub engine: the four request kinds, the raw int16 prompt, the PCM16 response
+    stream, and the wire format (field numbers of the reference's .proto, checked against hand-encoded bytes)."""
+    import grpc
+    from cosyvoice_amd.serving import GRPC_METHOD, create_grpc_server, grpc_messages
+    Request, Response = grpc_messages()
+    # wire compatibility: zero_shot_request is field 2 of Request; tts_text / prompt_text / prompt_audio are fields 1 / 2 / 3 of zeroshotRequest
+    r = Request(); r.zero_shot_request.tts_text = "ab"; r.zero_shot_request.prompt_text = "p"; r.zero_shot_request.prompt_audio = b"\x01\x02"
+    assert r.SerializeToString() == b"\x12\x0b" + b"\x0a\x02ab" + b"\x12\x01p" + b"\x1a\x02\x01\x02"
+    assert Response(tts_audio=b"xy").SerializeToString() == b"\x0a\x02xy"
+    seen = {}
+
+    class Stub:
+        def inference_sft(self, tts_text, spk_id):
+            seen["sft"] = (tts_text, spk_id)
+            yield {"tts_speech": torch.full((1, 4), 0.5)}
+
+        def inference_zero_shot(self, tts_text, prompt_text, prompt_wav):
+            seen["zs"] = (prompt_text, tuple(prompt_wav.shape), float(prompt_wav[0, 1]))
+            for ch in tts_text:
+                yield {"tts_speech": torch.full((1, 3), ord(ch) / 32768.0)}
+
+        def inference_cross_lingual(self, tts_text, prompt_wav):
+            yield {"tts_speech": torch.zeros(1, 2)}
+
+    server, port = create_grpc_server(Stub(), port=0, max_conc=2, host="127.0.0.1")
+    server.start()
+    try:
+        with grpc.insecure_channel("127.0.0.1:%d" % port) as ch:
+            call = ch.unary_stream(GRPC_METHOD, request_serializer=Request.SerializeToString, response_deserializer=Response.FromString)
+            q = Request(); q.sft_request.spk_id = "s"; q.sft_request.tts_text = "hello"
+            out = [np.frombuffer(x.tts_audio, dtype=np.int16).tolist() for x in call(q)]
+            assert out == [[16384] * 4] and seen["sft"] == ("hello", "s")
+            q = Request(); q.zero_shot_request.tts_text = "ab"; q.zero_shot_request.prompt_text = "p"
+            q.zero_shot_request.prompt_audio = np.array([0, 16384, -32768], dtype=np.int16).tobytes()
+            out = [np.frombuffer(x.tts_audio, dtype=np.int16).tolist() for x in call(q)]
+            assert out == [[97] * 3, [98] * 3] and seen["zs"] == ("p", (1, 3), 0.5)                     # one response per yielded chunk
+            q = Request(); q.cross_lingual_request.tts_text = "c"; q.cross_lingual_request.prompt_audio = b"\x00\x00"
+            assert [x.tts_audio for x in call(q)] == [b"\x00\x00\x00\x00"]
+            q = Request(); q.instruct_request.tts_text = "t"; q.instruct_request.spk_id = "s"; q.instruct_request.instruct_text = "i"
+            with pytest.raises(grpc.RpcError) as e:
+                list(call(q))
+            assert e.value.code() == grpc.StatusCode.UNIMPLEMENTED
+    finally:
+        server.stop(0)
