@@ -523,7 +523,7 @@ def main():
     ap.add_argument("--first-chunk-reps", type=int, default=9)
     ap.add_argument("--flow-precision", choices=("bf16", "fp32"), default="bf16",
                     help="operand precision of the flow's Linear/Conv1d products (BASELINE.json configs[1] is a bf16 configuration); "
-                         "fp32 = exact-fp32 MFMA everywhere")
+                         "fp32 = fp32 accuracy everywhere (three-term split / fp32 MFMA chain)")
     ap.add_argument("--batch", type=int, default=0, help="extra (not `value`): NB requests through CosyVoice2Model.tts_batch - lock-step batched "
                     "LM decode (weights streamed once per step for all of them), flow + HiFT per utterance; reported as `batched_decode`")
     ap.add_argument("--streams", type=int, default=1, help="extra (not `value`): S independent model instances on this GPU, one host thread + HIP "

@@ -66,7 +66,7 @@ struct cv_flow {
     // hipGraph cache of the whole Euler solve, keyed by (T, n_steps, streaming): ~5000 launches per utterance become one replay.
     // A key is captured the second time it is seen (streaming requests change T every chunk and would only pay the instantiation).
     bool use_graph = true;
-    int bf16_mfma = 0;                 // 1: Linear / Conv1d products on the bf16 MFMA (activations rounded to bf16 in LDS), 0: exact fp32 MFMA
+    int bf16_mfma = 0;                 // 1: Linear / Conv1d products on the bf16 MFMA (activations rounded to bf16 in LDS), 0: fp32-accurate (three-term split for bf16 weights, fp32 MFMA chain otherwise)
     std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
     std::map<std::tuple<int, int, int>, int> seen;
     hipStream_t own_stream = nullptr;

@@ -1,4 +1,4 @@
-// Implicit-GEMM linear / conv1d / transposed-conv kernel for gfx950 (exact-fp32 MFMA).
+// Implicit-GEMM linear / conv1d / transposed-conv kernel for gfx950 (fp32-accurate: fp32 MFMA chain, or - bf16 weights - the exact three-term split, AX3).
 //
 //   C[b][m][n] = epi( sum_{tap<taps} sum_{k<K}  pro(A_b[m*lda + a_off0 + tap*tap_step + k]) * W[n][tap*Kp + k] )
 //
@@ -37,7 +37,7 @@ struct GemmConvArgs {
     float out_scale;
     const float* row_scale; long long row_scale_batch;  // per-row multiplier (time mask), null = none
     int accumulate;                 // C += result
-    int a_bf16;                     // 1: bf16 x bf16 MFMA (needs bf16 weights); 0: exact-fp32 MFMA
+    int a_bf16;                     // 1: bf16 x bf16 MFMA (needs bf16 weights); 0: fp32-accurate (fp32 MFMA chain / three-term split)
     long long bias_batch;           // float offset of the bias per batch (grouped convolutions: one bias slice per group); 0 = shared
     const float* col_scale; int col_scale_rows; long long col_scale_stride;   // per-(row block, column) multiplier applied to act(acc + bias) BEFORE the residual:
                                     // the adaLN-zero gates of the DiT (x + gate[b] * f(x), flow/DiT/modules.py:523-528); row m uses block m / col_scale_rows

@@ -11,7 +11,7 @@ namespace cv {
 template <int BM, int BN, int BK, int ST = 2>
 static void launch_cfg(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t stream) {
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, batch), block(256);
-    if (a.a_bf16 && w_bf16 && a.a_vec) {        // bf16 x bf16 MFMA (fp32 accumulate); other layouts keep the exact-fp32 path
+    if (a.a_bf16 && w_bf16 && a.a_vec) {        // bf16 x bf16 MFMA (fp32 accumulate); other layouts keep the fp32-accurate paths
         hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, true, true, ST, true>), grid, block, 0, stream, a);
         return;
     }

@@ -1,7 +1,7 @@
 // Stage driver: Qwen2LM speech-token language model (replaces Qwen2LM.inference / inference_wrapper and
 // Qwen2Encoder.forward_one_step of cosyvoice/llm/llm.py:242-254,458-549 behind boundary B2 of SURVEY.md §8b).
 //
-// prefill: M = L0 rows through the exact-fp32 MFMA GEMM + flash attention, K/V written to a resident fp32 cache.
+// prefill: M = L0 rows through the fp32-accurate GEMM (three-term bf16 split of the activations, gemm_conv.h AX3) + fp32 flash attention, K/V written to a resident fp32 cache.
 // decode : one captured hipGraph per handle = {head GEMV + on-device sampling, embed, 24 x (5 kernels), advance};
 //          it is replayed once per token; the loop state lives in device memory (DecodeState), so no host sync is
 //          needed per token — tokens are read back in chunks.

@@ -1,8 +1,9 @@
 // Lock-step batched decode (BASELINE.json configs[2]/[3]/[4], SURVEY.md §8e "LLM continuous batching"): up to 16 sequences advance by
 // one token per step and every weight matrix is streamed from HBM ONCE per step for all of them.
 //
-// With nb sequences a decode "GEMV" is a skinny GEMM  Y[b][n] = sum_k W[n][k] X[b][k]  (b < 16): it goes on the exact-fp32 matrix
-// pipe, v_mfma_f32_16x16x4_f32 (products and accumulation in fp32, bit-identical to an fma chain in a fixed order), with the weight
+// With nb sequences a decode "GEMV" is a skinny GEMM  Y[b][n] = sum_k W[n][k] X[b][k]  (b < 16): it goes on the matrix pipe at fp32 accuracy -
+// v_mfma_f32_16x16x32_bf16 on the exact three-term bf16 split of the fp32 activations (X3, see below; the fp32 chain v_mfma_f32_16x16x4_f32 is
+// kept as the A/B variant) - with the weight
 // tile as the MFMA "A" operand (16 weight rows) and the sequences as the 16 "B" columns - one MFMA instruction serves all 16 sequences,
 // so a step costs the weight stream once plus the per-sequence activations (the first version of this file looped the batch-1 VALU GEMV
 // over the sequences: 256 VGPRs, one dependent L2 round trip per sequence, 32 us per gate/up launch at nb = 8 against 6 us for nb = 1).
@@ -11,8 +12,8 @@
 //     on its slot nor on what the other slots hold (SURVEY.md §8e determinism requirement).  The summation ORDER differs from the
 //     batch-1 kernels (llm_kernels.h), so logits agree with them to rounding (1e-6 relative), not bit for bit; greedy tokens are
 //     compared with the single path and with the oracle in tests/test_zz_llm_batch.py.
-//   * Latency structure as in llm_kernels.h: a wave first requests ALL of its weight fragments (non-temporal); the workgroup then stages
-//     its X slice through LDS once.  The 4 waves of a workgroup split K; their accumulators are combined through LDS in a fixed order.
+//   * Latency structure as in llm_kernels.h: a wave first requests ALL of its weight and activation fragments (weights non-temporal, activations
+//     straight from L2).  The 4 waves of a workgroup split K; their accumulators are combined through LDS in a fixed order.
 //   * The binding resource of these kernels is what one CU can ingest (a few tens of bytes per cycle): every workgroup needs the X
 //     columns of its K range for all sequences, so the shapes are cut so that X bytes per workgroup stay close to its weight bytes -
 //     down (K = 4864) is split 8 ways over K across workgroups, its partial sums are combined (fixed order, + residual) by

@@ -96,7 +96,7 @@ class _CFM:
 
 class CausalMaskedDiffWithXvec:
     def __init__(self, state_dict, cfg, lib=None, weight_dtype=torch.bfloat16, n_timesteps=None, precision="fp32", _tensors=None):
-        """precision: "fp32" = W16A32, every product on the exact-fp32 MFMA; "bf16" = the Linear / Conv1d operands are rounded to
+        """precision: "fp32" = W16A32 at fp32 accuracy (the exact three-term bf16 split of the activations on the bf16 matrix pipe, gemm_conv.h AX3; attention on the fp32 MFMA); "bf16" = the Linear / Conv1d operands are rounded to
         bf16 when staged into LDS and multiplied on the bf16 MFMA with fp32 accumulation (the reference's fp16 / TensorRT flow,
         cli/model.py:83-92, is the analogous mode; BASELINE.json configs[1] is quoted in bf16).  Attention, norms, the Euler update
         and every tensor in HBM stay fp32 in both modes."""

@@ -265,22 +265,26 @@ class CosyVoice2Model:
         lane.hift._next_seed = self._noise_key(token, 0)
         return lane.hift.inference(speech_feat=mel, cache_source=torch.zeros(1, 1, 0))[0]
 
+    def _flow_groups(self, jobs):
+        """Cut a list of finished sequences [(index, request, tokens)] into the groups that share a flow pass: longest first; a group takes the
+        next sequences while their frame count stays within 1 / flow_pad of the group's longest and it has fewer than flow_batch members.  The
+        padded pass (cv_flow_inference_ragged) computes every member at the longest length, so at most flow_pad - 1 of a member's work is
+        padding; equal shapes need none."""
+        n_tok = lambda j: len(j[2]) + int(j[1]["flow_prompt_speech_token"].shape[1])
+        order = sorted(jobs, key=lambda j: (-n_tok(j), j[0]))
+        k, cap = 0, max(1, self.flow_batch)
+        while k < len(order):
+            e = k + 1
+            while e < len(order) and e - k < cap and n_tok(order[e]) * self.flow_pad >= n_tok(order[k]):
+                e += 1
+            yield order[k:e]
+            k = e
+
     def _vocode_all(self, job_lists, speed):
         """job_lists: iterable of lists of (index, request, tokens) - each list holds the sequences that became available together; yields
         (index, {'tts_speech'}) as they complete.  A list is cut into groups of up to `flow_batch` sequences of similar length (equal shapes share an
         unpadded pass); the groups run on the token2wav lanes, one worker thread per lane."""
-        def groups(jobs):
-            # longest first; a group takes the next sequences while their frame count stays within 1 / flow_pad of the group's longest: the padded pass
-            # (cv_flow_inference_ragged) computes every member at the longest length, so at most flow_pad - 1 of a member's work is padding
-            n_tok = lambda j: len(j[2]) + int(j[1]["flow_prompt_speech_token"].shape[1])
-            order = sorted(jobs, key=lambda j: (-n_tok(j), j[0]))
-            k, cap = 0, max(1, self.flow_batch)
-            while k < len(order):
-                e = k + 1
-                while e < len(order) and e - k < cap and n_tok(order[e]) * self.flow_pad >= n_tok(order[k]):
-                    e += 1
-                yield order[k:e]
-                k = e
+        groups = self._flow_groups
         if self.n_lanes == 1:
             for jobs in job_lists:
                 for grp in groups(jobs):

@@ -53,7 +53,8 @@ typedef struct cv_gemm_conv_args {
     const float* row_scale; int64_t row_scale_batch;
     int32_t accumulate;
     int32_t a_bf16;      /* 1: round the (prologue'd) activations to bf16 and multiply on the bf16 MFMA with fp32 accumulate (needs bf16 W,
-                            16-byte aligned A layout; otherwise the exact-fp32 MFMA path runs); 0: exact fp32 */
+                            16-byte aligned A layout; otherwise the fp32-accurate path runs); 0: fp32 accuracy - the fp32 MFMA chain for fp32 weights, the exact three-term bf16
+                            split of the activations on the bf16 matrix pipe for bf16 weights */
 } cv_gemm_conv_args;
 int cv_gemm_conv(const cv_gemm_conv_args* args, void* stream);
 
@@ -137,7 +138,7 @@ int cv_llm_profile_step(cv_llm* m, const cv_sampling* sp, int32_t* counts8, floa
  * between ONE event pair: total duration and number of launches — the per-launch duration bench.py prices against the HBM roofline */
 int cv_llm_profile_chain(cv_llm* m, int32_t category, int32_t reps, float* total_ms, int32_t* launches, void* stream);
 /* Lock-step batched decode (BASELINE.json configs[2]/[3]; the reference batches through vLLM, cli/model.py:281-290): up to 16 sequences
- * advance one token per step and every weight matrix is streamed once per step for all of them (skinny GEMMs on the exact-fp32 MFMA).
+ * advance one token per step and every weight matrix is streamed once per step for all of them (skinny GEMMs on the matrix pipe at fp32 accuracy: exact three-term bf16 split of the activations).
  * cv_llm_batch_begin sizes the slots, cv_llm_batch_prefill runs the normal prefill for one request and parks its KV prefix / state /
  * sampling parameters in `slot`; cv_llm_batch_prefill_many fills n slots with ONE prefill pass over the row-stacked prompts (rows: dev
  * [sum L0s][hidden], slot j's rows after slot j-1's; sps: n sampling structs) - the GEMMs see M = sum of the prompt lengths;

@@ -100,3 +100,27 @@ def test_mixed64_workload_is_seeded_and_fully_assigned():
         assert sorted(i for s in shards for i in s) == list(range(64))
         loads = [sum(costs[i] for i in s) for s in shards]
         assert max(loads) - min(loads) <= 125
+
+
+def test_flow_groups_bucket_by_length():
+    """CosyVoice2Model._flow_groups (host logic, no device): finished sequences are cut into flow passes longest-first, a pass holds at most
+    `flow_batch` sequences whose shortest has at least 1 / flow_pad of the longest's tokens (prompt + generated); equal lengths always fit."""
+    import types
+    import torch
+    from cosyvoice_amd.model import CosyVoice2Model
+    me = types.SimpleNamespace(flow_batch=4, flow_pad=1.25)
+    req = lambda p: {"flow_prompt_speech_token": torch.zeros(1, p, dtype=torch.int32)}
+    job = lambda i, n, p=87: (i, req(p), [0] * n)
+    groups = lambda jobs: [[j[0] for j in g] for g in CosyVoice2Model._flow_groups(me, jobs)]
+    # the mixed64 lengths: 500 / 375 are more than 25 % apart (587 vs 462 tokens with the prompt), so are 250 / 125
+    jobs = [job(i, n) for i, n in enumerate([125, 500, 250, 375] * 3)]
+    assert groups(jobs) == [[1, 5, 9], [3, 7, 11], [2, 6, 10], [0, 4, 8]]
+    # similar lengths share a pass, at most flow_batch of them, longest first, ties by submission order
+    jobs = [job(0, 250), job(1, 230), job(2, 215), job(3, 205), job(4, 200), job(5, 120)]
+    assert groups(jobs) == [[0, 1, 2, 3], [4], [5]]
+    me.flow_batch = 8
+    assert groups(jobs) == [[0, 1, 2, 3, 4], [5]]                    # (120 + 87) * 1.25 < 250 + 87
+    me.flow_pad = 1.0
+    assert groups([job(0, 100), job(1, 100, 80), job(2, 93), job(3, 100)]) == [[0, 3], [1, 2]]     # equal token totals only (prompt included)
+    me.flow_batch = 1
+    assert groups([job(0, 10), job(1, 10)]) == [[0], [1]]
