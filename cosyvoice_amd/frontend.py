@@ -247,3 +247,75 @@ class PromptExtractors:
     def _extract_speech_feat(self, speech):
         speech_feat = self.feat_extractor(speech).squeeze(dim=0).transpose(0, 1).to(self.device).unsqueeze(dim=0)
         return speech_feat, torch.tensor([speech_feat.shape[1]], dtype=torch.int32).to(self.device)
+
+
+# -----------------------------------------------------------------------------------------------------------------------------------
+# load_wav's resampling (cosyvoice/utils/file_utils.py:44-50): torchaudio.transforms.Resample(orig_freq, new_freq) with its defaults
+# -----------------------------------------------------------------------------------------------------------------------------------
+def sinc_resample_kernel(orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
+    """torchaudio.functional.resample's `sinc_interp_hann` filter bank (torchaudio/functional/functional.py::_get_sinc_resample_kernel, the
+    transform's defaults): after dividing both rates by their gcd, new_freq windowed-sinc filters of 2 * width + orig_freq taps, one per output
+    phase, cut off at rolloff x the lower Nyquist.  Returns (float32 [new][taps], width, orig, new) with the reduced rates."""
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base = min(orig, new) * rolloff
+    width = int(math.ceil(lowpass_filter_width * orig / base))
+    idx = np.arange(-width, width + orig, dtype=np.float64)[None, :] / orig
+    t = (np.arange(0, -new, -1, dtype=np.float64)[:, None] / new + idx) * base
+    t = np.clip(t, -lowpass_filter_width, lowpass_filter_width)
+    window = np.cos(t * math.pi / lowpass_filter_width / 2.0) ** 2
+    t = t * math.pi
+    with np.errstate(invalid="ignore", divide="ignore"):
+        k = np.where(t == 0.0, 1.0, np.sin(t) / t)
+    return (k * window * (base / orig)).astype(np.float32), width, orig, new
+
+
+class Resample:
+    """`torchaudio.transforms.Resample(orig_freq, new_freq)` as `load_wav` applies it to a prompt (file_utils.py:49): pad (width, width + orig),
+    a strided convolution with the filter bank, the phases interleaved, cut to ceil(new * L / orig) samples.  On the device that is ONE implicit
+    GEMM of the fp32 MFMA kernel: the window of output group n starts at n * orig in the padded signal (lda = orig), the filter bank is W
+    [new][taps], and the row-major result [groups][new] IS the interleaved output.  `__call__(waveform[1, L]) -> [1, ceil(new * L / orig)]`."""
+
+    def __init__(self, orig_freq, new_freq, lib=None):
+        self.lib = lib or get_lib()
+        self.device = torch.device(self.lib.device)
+        self.orig_freq, self.new_freq = int(orig_freq), int(new_freq)
+        k, self.width, self.orig, self.new = sinc_resample_kernel(orig_freq, new_freq)
+        self.taps = k.shape[1]
+        self.kp = ops.round_up(self.taps, 32)
+        w = np.zeros((self.new, self.kp), dtype=np.float32)
+        w[:, :self.taps] = k
+        self._w = self.lib.hook(torch.from_numpy(w).to(self.device).contiguous())
+
+    @torch.inference_mode()
+    def __call__(self, waveform):
+        if self.orig_freq == self.new_freq:
+            return waveform.to(self.device, torch.float32)
+        lib = self.lib
+        y = waveform.reshape(-1).to(self.device, torch.float32)
+        L = y.numel()
+        groups = (L + self.orig - 1) // self.orig + 1               # conv1d output length over the padded signal: L // orig + 1 (+ a partly covered one)
+        target = -(-self.new * L // self.orig)                      # ceil(new * L / orig)
+        groups = max(groups, -(-target // self.new))
+        sig = lib.hook(torch.zeros(self.width + (groups - 1) * self.orig + self.kp, dtype=torch.float32, device=self.device))
+        sig[self.width:self.width + L] = y
+        out = lib.hook(torch.empty(groups, self.new, dtype=torch.float32, device=self.device))
+        ops.gemm_conv(lib, sig, self._w, self.kp, M=groups, N=self.new, K=self.kp, lda=self.orig, a_len=sig.numel(), out=out)
+        return out.reshape(1, -1)[:, :target]
+
+
+def load_wav(wav, target_sr, min_sr=16000, lib=None):
+    """cosyvoice/utils/file_utils.py:44-50 for 16-bit PCM WAV files (the reference decodes with torchaudio + soundfile, absent here; other formats
+    are the caller's to decode): channel mean, then `Resample(sample_rate, target_sr)` on the device when the rates differ."""
+    import wave
+    with wave.open(wav, "rb") as w:
+        assert w.getsampwidth() == 2, "16-bit PCM WAV expected"
+        sample_rate = w.getframerate()
+        data = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float32) / 32768.0
+        if w.getnchannels() > 1:
+            data = data.reshape(-1, w.getnchannels()).mean(1)
+    speech = torch.from_numpy(data).unsqueeze(0)
+    if sample_rate != target_sr:
+        assert sample_rate >= min_sr, 'wav sample rate {} must be greater than {}'.format(sample_rate, target_sr)
+        speech = Resample(sample_rate, target_sr, lib=lib)(speech)
+    return speech

@@ -93,3 +93,28 @@ def kaldi_fbank(waveform, num_mel_bins=80, sample_frequency=16000.0, frame_lengt
             banks[b, k] = max(0.0, min((mk - left) / (center - left), (right - mk) / (right - center)))
     e = torch.mm(power, banks.T)
     return torch.max(e, torch.tensor(torch.finfo(torch.float).eps)).log()
+
+
+def sinc_resample(waveform, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
+    """torchaudio.functional.resample(waveform[1, L], orig_freq, new_freq) with the transform's defaults (sinc_interp_hann), restated from
+    torchaudio/functional/functional.py (_get_sinc_resample_kernel + _apply_sinc_resample_kernel).  PARITY UNPINNED (torchaudio is not installed)."""
+    if orig_freq == new_freq:
+        return waveform
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base_freq = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base_freq)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t *= base_freq
+    t = t.clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t *= math.pi
+    scale = base_freq / orig
+    kernels = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t)
+    kernels = (kernels * window * scale).float()
+    length = waveform.shape[-1]
+    x = torch.nn.functional.pad(waveform, (width, width + orig))
+    res = torch.nn.functional.conv1d(x[:, None], kernels, stride=orig)
+    res = res.transpose(1, 2).reshape(waveform.shape[0], -1)
+    return res[..., :math.ceil(new * length / orig)]

@@ -1,5 +1,7 @@
 """on-device 24 kHz prompt log-mel (cosyvoice/cli/frontend.py:120-125) vs the oracle restatement of
 matcha.utils.audio.mel_spectrogram (parity unpinned: the Matcha submodule and librosa are absent, see oracle/frontend.py)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -148,3 +150,53 @@ def test_prompt_extractors_feed_the_sessions_like_the_reference(lib):
     assert feat.shape == (1, y24.shape[1] // 480, 80) and feat_len.tolist() == [y24.shape[1] // 480]
     with pytest.raises(AssertionError):
         fe._extract_speech_token(torch.zeros(1, 16000 * 30 + 1))
+
+
+# ---- load_wav's resampler (utils/file_utils.py:44-50 -> torchaudio.transforms.Resample) ------------------------------------------------
+from cosyvoice_amd.frontend import Resample, load_wav, sinc_resample_kernel
+
+
+@pytest.mark.parametrize("orig,new", [(16000, 24000), (24000, 16000), (44100, 16000), (22050, 24000)])
+def test_resample_matches_oracle(lib, orig, new):
+    L = (orig // 4 if lib.emulated and orig != 44100 else orig // 10 if lib.emulated else orig) + 37
+    y = _speechlike(L, orig, 9)
+    got = Resample(orig, new, lib=lib)(y).cpu()
+    want = OFE.sinc_resample(y, orig, new)
+    assert got.shape == want.shape == (1, -(-new * L // orig))
+    torch.testing.assert_close(got, want, rtol=0, atol=2e-6)       # the same fp32 filter taps, summation order only
+
+
+def test_resample_properties():
+    """Closed-form anchors of the filter bank (host only): every output phase is a unit-gain low-pass (taps of a phase sum to ~1), the pass band keeps
+    a tone's amplitude and frequency, the stop band (above the lower Nyquist) is suppressed, equal rates are the identity."""
+    k, width, orig, new = sinc_resample_kernel(16000, 24000)
+    assert (orig, new, k.shape) == (2, 3, (3, 2 * width + 2)) and width == math.ceil(6 * 2 / (2 * 0.99))
+    np.testing.assert_allclose(k.sum(1), np.ones(3), atol=2e-3)
+    t = torch.arange(16000) / 16000.0
+    tone = torch.sin(2 * np.pi * 1000.0 * t).unsqueeze(0)
+    up = OFE.sinc_resample(tone, 16000, 24000)
+    ref = torch.sin(2 * np.pi * 1000.0 * torch.arange(24000) / 24000.0)
+    assert (up[0, 200:-200] - ref[200:-200]).abs().max().item() < 1e-2       # a 6-zero-crossing Hann-windowed sinc: ~0.5 % pass-band ripple
+    hi = torch.sin(2 * np.pi * 11000.0 * torch.arange(24000) / 24000.0).unsqueeze(0)       # above the 8 kHz Nyquist of the target
+    assert OFE.sinc_resample(hi, 24000, 16000)[0, 200:-200].abs().max().item() < 2e-2
+    assert OFE.sinc_resample(tone, 16000, 16000) is tone
+
+
+def test_load_wav_reads_pcm16_and_resamples(lib, tmp_path):
+    import wave
+    sr = 22050
+    x = (_speechlike(sr // 5, sr, 10)[0] * 32767).round().to(torch.int16)
+    p = str(tmp_path / "p.wav")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(sr)
+        w.writeframes(torch.stack([x, x], 1).numpy().tobytes())                            # stereo, both channels equal -> the mean is the signal
+    mono = (x.float() / 32768.0).unsqueeze(0)
+    got = load_wav(p, 16000, lib=lib).cpu()
+    torch.testing.assert_close(got, OFE.sinc_resample(mono, sr, 16000), rtol=0, atol=2e-6)
+    same = load_wav(p, sr, lib=lib)
+    assert torch.equal(same, mono)
+    with pytest.raises(AssertionError):
+        p8 = str(tmp_path / "p8.wav")
+        with wave.open(p8, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(8000); w.writeframes(x.numpy().tobytes())
+        load_wav(p8, 16000, lib=lib)
