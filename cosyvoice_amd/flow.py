@@ -62,16 +62,25 @@ class EstimatorModule(torch.nn.Module):
         return out.to(device=x.device, dtype=x.dtype)
 
 
-class _Encoder:
-    """flow.encoder: (token_emb[1,n,dim], token_len, context=[1,3,dim] | empty, streaming) -> (h[1,2n,dim], mask[1,1,2n])."""
+class _Encoder(torch.nn.Module):
+    """flow.encoder: (token_emb[1,n,dim], token_len, context=[1,3,dim] | empty, streaming) -> (h[1,2n,dim], mask[1,1,2n]).
+
+    An `nn.Module` (without parameters: the weights live in the flow's library handle) because the reference's flow IS one: `model.flow.encoder = x`
+    on a `torch.nn.Module` refuses anything that is not a Module for a registered child name (boundary B4, the reference's own TorchScript encoder
+    swap cli/model.py:277-279 assigns a ScriptModule); tests/test_dropin_reference.py performs the swap inside the real class."""
 
     def __init__(self, flow):
-        self.flow = flow
+        super().__init__()
+        self._flow = [flow]                    # kept out of nn.Module's attribute registration (and no reference cycle through _modules)
+
+    @property
+    def flow(self):
+        return self._flow[0]
 
     def output_size(self):
         return self.flow.cfg.dim
 
-    def __call__(self, xs, xs_lens, context=None, streaming=False):
+    def forward(self, xs, xs_lens, context=None, streaming=False):
         f = self.flow
         assert xs.shape[0] == 1
         n = xs.shape[1]

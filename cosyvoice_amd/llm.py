@@ -304,7 +304,8 @@ class Qwen2LM:
         TensorRT-LLM: cli/model.py:281-290, runtime/triton_trtllm/model_repo/cosyvoice2/1/model.py:307-313).  `source` is a queue.Queue of
         (key, request) items - requests as for inference_batch - closed by a None item; `on_tokens(key, new_tokens, finished, error)` is called
         from this thread after every decode chunk of `step_chunk` lock-step steps (shorter when a request's optional "first_chunk" token count falls
-        inside the chunk) for every sequence that produced tokens or finished.  Free
+        inside the chunk) for every sequence that produced tokens or finished; a callback that returns True cancels the sequence (its slot is
+        re-filled like a finished one's).  Free
         slots are re-filled as soon as a sequence ends (a normal prefill parked into the slot); with nothing in flight the call blocks on the
         queue.  Every sequence yields exactly the tokens `inference()` yields for its request alone."""
         import queue as _q
@@ -369,9 +370,10 @@ class Qwen2LM:
                     toks = [int(buf[s_ * n + k]) for k in range(min(n_out[s_], room))]
                     emitted[key] += len(toks)
                     fin = bool(f[s_]) or emitted[key] >= limit[key]
+                    cancel = False
                     if toks or fin:
-                        on_tokens(key, toks, fin, None)
-                    if fin:
+                        cancel = on_tokens(key, toks, fin, None) is True     # the client went away: the slot is handed to the next request
+                    if fin or cancel:
                         owner[s_] = None
                         emitted.pop(key), limit.pop(key), first.pop(key)
 

@@ -35,6 +35,29 @@ class _Lane:
         self.flow, self.hift, self.stream = flow, hift, stream
 
 
+class SilentTokenFilter:
+    """The silent / breath-token rule of llm_job (cli/model.py:122-128) as a reusable, stateful filter: a token of `silent_tokens` is dropped once
+    more than `max_run` of them came in a row; any other token resets the run.  One instance per request (the run count carries over the
+    chunks a request's tokens arrive in), shared by llm_job, tts_batch, tts_queue and the serving scheduler so that every path feeds the
+    vocoder exactly what tts() would."""
+    __slots__ = ("silent", "max_run", "run")
+
+    def __init__(self, silent_tokens, max_run=5):
+        self.silent, self.max_run, self.run = frozenset(int(t) for t in silent_tokens), max_run, 0
+
+    def keep(self, tok):
+        if tok in self.silent:
+            self.run += 1
+            return self.run <= self.max_run
+        self.run = 0
+        return True
+
+    def __call__(self, tokens):
+        if not self.silent:
+            return list(tokens)
+        return [t for t in tokens if self.keep(t)]
+
+
 class CosyVoice2Model:
     def __init__(self, llm, flow, hift, fp16=False, lib=None):
         """llm / flow / hift: cosyvoice_amd.{llm.Qwen2LM, flow.CausalMaskedDiffWithXvec, hift.HiFTGenerator} (or None before load())."""
@@ -96,9 +119,12 @@ class CosyVoice2Model:
             if st is None:
                 yield lane
             else:
-                with torch.cuda.stream(st):
-                    yield lane
-                    st.synchronize()
+                st.wait_stream(torch.cuda.current_stream(self.device))   # inputs produced on the caller's stream (front-end mel, ...) are complete first
+                try:
+                    with torch.cuda.stream(st):
+                        yield lane
+                finally:
+                    st.synchronize()                                     # also when the body raised: the lane goes back idle
         finally:
             self._lane_q.put(lane)
 
@@ -150,7 +176,7 @@ class CosyVoice2Model:
     def llm_job(self, text, prompt_text, llm_prompt_speech_token, llm_embedding, uuid, first_chunk=None):
         """cli/model.py:101-129: `text` is a tensor (offline text) or a generator of [1, n] id tensors (streaming text ->
         Qwen2LM.inference_bistream)."""
-        cur_silent_token_num, max_silent_token_num = 0, 5
+        keep = SilentTokenFilter(self.silent_tokens).keep
         cond = self._cond[uuid]
         try:
             with self.llm_context:
@@ -164,12 +190,8 @@ class CosyVoice2Model:
                                              prompt_speech_token=llm_prompt_speech_token, prompt_speech_token_len=t(llm_prompt_speech_token.shape[1]),
                                              embedding=llm_embedding, uuid=uuid, **({} if first_chunk is None else {"first_chunk": first_chunk}))
                 for i in gen:
-                    if i in self.silent_tokens:
-                        cur_silent_token_num += 1
-                        if cur_silent_token_num > max_silent_token_num:
-                            continue
-                    else:
-                        cur_silent_token_num = 0
+                    if not keep(i):
+                        continue
                     with cond:
                         self.tts_speech_token_dict[uuid].append(i)
                         cond.notify_all()
@@ -290,20 +312,45 @@ class CosyVoice2Model:
                 for grp in groups(jobs):
                     yield from self._vocode_group(grp, speed)
             return
-        from concurrent.futures import ThreadPoolExecutor, FIRST_COMPLETED, wait
+        from concurrent.futures import ThreadPoolExecutor
+        # `job_lists` may block (tts_queue: token sequences arrive from the LM thread), so it is drained by a feeder thread and the results come
+        # back through one queue: finished audio is yielded the moment its lane is done, not when the LM next hands something over.
+        res = queue.Queue()
+        END = object()
+
+        def run(grp):
+            try:
+                res.put(self._vocode_group(grp, speed))
+            except BaseException as e:
+                res.put(e)
+
+        def feed(ex):
+            n = 0
+            try:
+                for jobs in job_lists:
+                    for grp in groups(jobs):
+                        ex.submit(run, grp)
+                        n += 1
+                res.put((END, n))
+            except BaseException as e:
+                res.put(e)
+
         with ThreadPoolExecutor(max_workers=self.n_lanes) as ex:
-            pending = set()
-            for jobs in job_lists:                              # may block (tts_queue: tokens arrive from the LM thread)
-                for grp in groups(jobs):
-                    pending.add(ex.submit(self._vocode_group, grp, speed))
-                done = {f for f in pending if f.done()}
-                pending -= done
-                for f in done:
-                    yield from f.result()
-            while pending:
-                done, pending = wait(pending, return_when=FIRST_COMPLETED)
-                for f in done:
-                    yield from f.result()
+            feeder = threading.Thread(target=feed, args=(ex,), daemon=True)
+            feeder.start()
+            submitted, got = None, 0
+            try:
+                while submitted is None or got < submitted:
+                    item = res.get()
+                    if isinstance(item, BaseException):
+                        raise item
+                    if isinstance(item, tuple) and len(item) == 2 and item[0] is END:
+                        submitted = item[1]
+                        continue
+                    got += 1
+                    yield from item
+            finally:
+                feeder.join()
 
     def tts_batch(self, requests, speed=1.0):
         """Offline synthesis of up to 16 requests (dicts with the keyword arguments of tts()): the speech-token LM runs lock-step
@@ -316,6 +363,7 @@ class CosyVoice2Model:
         if self.device.type == "cuda":
             self.llm_stream.synchronize()
         outs = [None] * len(requests)
+        tokens = [SilentTokenFilter(self.silent_tokens)(toks) for toks in tokens]          # what llm_job would have handed to token2wav
         for i, o in self._vocode_all([[(i, r, toks) for i, (r, toks) in enumerate(zip(requests, tokens))]], speed):
             outs[i] = o
         return outs
@@ -358,7 +406,7 @@ class CosyVoice2Model:
                     elif isinstance(item, BaseException):
                         raise item
                     else:
-                        jobs.append((item[0], requests[item[0]], item[1]))
+                        jobs.append((item[0], requests[item[0]], SilentTokenFilter(self.silent_tokens)(item[1])))
                 if jobs:
                     yield jobs
 

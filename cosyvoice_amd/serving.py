@@ -24,10 +24,13 @@ import torch
 
 
 class _Request:
-    __slots__ = ("key", "req", "tokens", "llm_done", "error", "out", "token_offset", "hop", "chunk_index", "t_submit", "t_first", "stream", "pad", "closed", "busy", "t_ready", "t_pick")
+    __slots__ = ("key", "req", "tokens", "llm_done", "error", "out", "token_offset", "hop", "chunk_index", "t_submit", "t_first", "stream", "pad", "closed", "busy", "t_ready", "t_pick",
+                 "filt")
 
-    def __init__(self, key, req, stream, hop, pad):
+    def __init__(self, key, req, stream, hop, pad, silent_tokens=()):
+        from .model import SilentTokenFilter
         self.key, self.req, self.stream = key, req, stream
+        self.filt = SilentTokenFilter(silent_tokens)     # llm_job's silent / breath-token rule, run count carried over the decode chunks
         self.tokens, self.llm_done, self.error = [], False, None
         self.out = queue.Queue()
         self.token_offset, self.hop, self.chunk_index, self.pad = 0, hop, 0, pad
@@ -43,6 +46,7 @@ class StreamScheduler:
         self._cv = threading.Condition()
         self._reqs = {}
         self._stop = False
+        self._dead = None                               # exception that ended the LM thread, if any (submit() re-raises it)
         # (LM ms until the first chunk's tokens exist, ms waiting for a vocoder lane, ms of the first token2wav) of the last requests
         self.first_chunk_stats = collections.deque(maxlen=4096)
         self._llm_thread = threading.Thread(target=self._llm_loop, daemon=True)
@@ -63,10 +67,12 @@ class StreamScheduler:
         key = str(uuid_mod.uuid1())
         n_prompt = int(req["flow_prompt_speech_token"].shape[1])
         pad = int(np.ceil(n_prompt / m.token_hop_len) * m.token_hop_len - n_prompt)
-        r = _Request(key, req, stream, m.token_hop_len, pad)
+        r = _Request(key, req, stream, m.token_hop_len, pad, getattr(m, "silent_tokens", ()))
         with self._cv:
             if self._stop:
                 raise RuntimeError("scheduler is shut down")
+            if self._dead is not None:                    # the LM thread is gone: refuse instead of queueing a request nobody will serve
+                raise RuntimeError("scheduler: the LM thread died: %r" % (self._dead,)) from self._dead
             self._reqs[key] = r
         with m.lock:
             m.hift_cache_dict[key] = None
@@ -87,7 +93,9 @@ class StreamScheduler:
                     raise item
                 yield item
         finally:
-            r.closed = True
+            with self._cv:
+                r.closed = True                           # a client that stopped listening: _ready() turns the request into a "cancel"
+                self._cv.notify_all()
 
     def first_chunk_latency(self, key_request):
         return None if key_request.t_first is None else key_request.t_first - key_request.t_submit
@@ -105,9 +113,9 @@ class StreamScheduler:
     def _on_tokens(self, key, toks, finished, error):
         with self._cv:
             r = self._reqs.get(key)
-            if r is None:
-                return
-            r.tokens.extend(toks)
+            if r is None or r.closed:
+                return True                              # unknown / abandoned request: serve_stream frees its slot
+            r.tokens.extend(r.filt(toks))
             if error is not None:
                 r.error = error
             if finished:
@@ -123,6 +131,7 @@ class StreamScheduler:
                 m.llm.serve_stream(self._src, self._on_tokens, slots=self.slots, step_chunk=self.step_chunk)
         except BaseException as e:                   # the LM thread died: fail every open request instead of hanging its client
             with self._cv:
+                self._dead = e
                 for r in self._reqs.values():
                     r.error, r.llm_done = r.error or e, True
                 self._cv.notify_all()
@@ -130,6 +139,8 @@ class StreamScheduler:
     # ---- vocoder thread: chunk rules of cli/model.py:341-371 per request, first-come first-served over ready requests -----------------
     def _ready(self, r):
         la = self.model.flow.pre_lookahead_len
+        if r.closed:
+            return "cancel"                               # the client closed its generator: drop the request, free its lane and caches
         if r.error is not None:
             return "error"
         hop = r.hop + r.pad if r.token_offset == 0 else r.hop
@@ -166,9 +177,11 @@ class StreamScheduler:
             rq = r.req
             finished = True
             try:
-                if what == "error":
+                if what == "cancel":
+                    pass
+                elif what == "error":
                     raise r.error
-                if what == "chunk":
+                elif what == "chunk":
                     hop = r.hop + r.pad if r.token_offset == 0 else r.hop
                     n = r.token_offset + hop + la
                     wav = m.token2wav(token=torch.tensor(toks[:n]).unsqueeze(0), prompt_token=rq["flow_prompt_speech_token"], prompt_feat=rq["prompt_speech_feat"],

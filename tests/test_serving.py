@@ -186,6 +186,102 @@ def test_scheduler_logic_with_fake_model():
         sch.shutdown()
 
 
+def _fake_req(n_text, n_prompt=8):
+    return dict(text=torch.zeros(1, n_text, dtype=torch.int32), prompt_text=torch.zeros(1, 2, dtype=torch.int32),
+                llm_prompt_speech_token=torch.zeros(1, n_prompt, dtype=torch.int32), flow_prompt_speech_token=torch.zeros(1, n_prompt, dtype=torch.int32),
+                prompt_speech_feat=torch.zeros(1, 2 * n_prompt, 80), llm_embedding=torch.zeros(1, 192), flow_embedding=torch.zeros(1, 192))
+
+
+@pytest.mark.timeout(120)
+def test_scheduler_time_based_strategy():
+    """strategy="time_based" (runtime/triton_trtllm/model_repo/cosyvoice2/1/model.py:410-426): after every chunk the next hop is chosen from how far
+    synthesis runs ahead of playback - the base hop when it does not (multiplier <= 2), all pending whole hops when it does.  Whatever hops
+    are chosen, the chunks must tile the token sequence exactly once: offsets chain, every non-final call sees hop + lookahead tokens past its offset,
+    the final call sees everything; every hop is a positive multiple of the base hop (the static chunk size the flow was trained with)."""
+    import time as _time
+    n_tok, n_calls = 60, {}
+    for slow in (False, True):
+        fm = _FakeModel({1: list(range(n_tok))})
+        if slow:                                            # synthesis slower than playback: multiplier < 0 -> the hop stays at the base
+            inner = fm.token2wav
+            fm.token2wav = lambda **kw: (_time.sleep(0.3), inner(**kw))[1]      # 0.3 s per 5-token (0.2 s of audio) chunk
+        sch = StreamScheduler(fm, slots=2, strategy="time_based", step_chunk=64)
+        try:
+            outs = [o["tts_speech"] for o in sch.submit(stream=True, **_fake_req(1))]
+        finally:
+            sch.shutdown()
+        calls = [c[1:] for c in fm.calls]
+        assert calls[-1][0] == n_tok and calls[-1][3] is True and all(c[3] is False and c[2] is True for c in calls[:-1])
+        offs = [c[1] for c in calls]
+        hops = [b - a for a, b in zip(offs[:-1], offs[1:])]
+        assert offs[0] == 0 and hops[0] == 5 + 2                                     # first hop = base + prompt pad (prompt 8 -> pad 2)
+        assert all(h > 0 and h % 5 == 0 for h in hops[1:]), hops
+        assert all(c[0] == c[1] + h + 3 for c, h in zip(calls[:-1], hops)), (calls, hops)   # tokens seen = offset + hop + lookahead
+        assert sum(o.shape[1] for o in outs) == n_tok * 960                          # every token vocoded exactly once
+        n_calls[slow] = len(calls)
+        if slow:
+            assert all(h == 5 for h in hops[1:4]), hops                             # behind real time: the base hop
+        else:
+            assert all(h > 5 for h in hops[1:]), hops                               # far ahead of real time: every later hop takes all pending whole hops (+ 1)
+        assert not sch._reqs and not fm.hift_cache_dict
+    assert n_calls[False] < n_calls[True], n_calls                                  # running ahead means fewer, longer chunks
+
+
+@pytest.mark.timeout(120)
+def test_scheduler_silent_filter_abandoned_client_and_dead_lm():
+    """(1) The silent / breath-token rule of llm_job (cli/model.py:122-128) applies to scheduler-served requests, with the run count carried
+    across decode chunks.  (2) A client that stops listening frees its request state, its LM sequence is cancelled.  (3) When the LM thread
+    dies, open requests fail and submit() refuses new ones instead of queueing them forever."""
+    from cosyvoice_amd.model import SilentTokenFilter
+    script = [7, 1, 1, 2, 1, 2, 1, 1, 2, 9, 1, 1, 1, 1, 1, 1, 1, 4]            # a run of 8 silent ids straddling the 4-step chunks, then a run of 7
+    want = SilentTokenFilter([1, 2])(script)
+    assert want == [7, 1, 1, 2, 1, 2, 9, 1, 1, 1, 1, 1, 4]
+    fm = _FakeModel({1: script, 2: list(range(400))})
+    fm.silent_tokens = [1, 2]
+    seen = []
+    inner = fm.token2wav
+    fm.token2wav = lambda **kw: (seen.append(kw["token"].flatten().tolist()), inner(**kw))[1]
+    sch = StreamScheduler(fm, slots=2, step_chunk=4)
+    try:
+        list(sch.submit(stream=False, **_fake_req(1)))
+        assert seen == [want]
+        # (2) abandon a long streaming request after its first chunk
+        cancelled = []
+        on = sch._on_tokens
+        sch._on_tokens = lambda key, toks, fin, err: cancelled.append(on(key, toks, fin, err)) or cancelled[-1]
+        sch.model.llm_on = None
+        gen = sch.submit(stream=True, **_fake_req(2))
+        next(gen)
+        gen.close()
+        for _ in range(200):
+            if not sch._reqs and not fm.hift_cache_dict:
+                break
+            threading.Event().wait(0.02)
+        assert not sch._reqs and not fm.hift_cache_dict
+    finally:
+        sch.shutdown()
+
+    class _Boom(_FakeModel._LLM):
+        def serve_stream(self, source, on_tokens, **kw):
+            source.get()
+            raise RuntimeError("LM thread exploded")
+    fm = _FakeModel({1: [1, 2, 3]})
+    fm.llm = _Boom({})
+    sch = StreamScheduler(fm, slots=2)
+    try:
+        with pytest.raises(RuntimeError, match="exploded"):
+            list(sch.submit(stream=True, **_fake_req(1)))
+        sch._llm_thread.join(5)
+        with pytest.raises(RuntimeError, match="LM thread died"):
+            sch.submit(stream=True, **_fake_req(1))
+    finally:
+        sch._stop = True
+        with sch._cv:
+            sch._cv.notify_all()
+        for t in sch._voc_threads:
+            t.join(5)
+
+
 def test_fastapi_adapter_streams_pcm16(lib, setup):
     from starlette.testclient import TestClient
     if lib.emulated:
