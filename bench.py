@@ -196,8 +196,18 @@ def cv3_workload(args):
     req = {k: u[k] for k in keys}
     ratio = N_GEN / N_TEXT
     inf_1, inf_b = m.llm.inference, m.llm.inference_batch
-    m.llm.inference = lambda **kw: inf_1(**dict(kw, max_token_text_ratio=ratio, min_token_text_ratio=ratio))
-    m.llm.inference_batch = lambda r: inf_b(r, max_token_text_ratio=ratio, min_token_text_ratio=ratio)
+    seen = {"single": None, "batch": None}                          # token self-check: what the two LM paths handed to the vocoder
+
+    def inference_spy(**kw):
+        seen["single"] = []
+        for tok in inf_1(**dict(kw, max_token_text_ratio=ratio, min_token_text_ratio=ratio)):
+            seen["single"].append(int(tok))
+            yield tok
+
+    def batch_spy(r):
+        seen["batch"] = [[int(x) for x in t] for t in inf_b(r, max_token_text_ratio=ratio, min_token_text_ratio=ratio)]
+        return seen["batch"]
+    m.llm.inference, m.llm.inference_batch = inference_spy, batch_spy
     one = lambda: next(iter(m.tts(**req, stream=False)))["tts_speech"]
     for _ in range(2):
         wav = one()
@@ -219,10 +229,19 @@ def cv3_workload(args):
     torch.cuda.synchronize()
     batch_s = time.perf_counter() - t0
     assert all(o["tts_speech"].shape[1] == N_GEN * 2 * 480 for o in outs)
+    check = {"checked": False}
+    gpath = os.path.join(ROOT, "tests", "golden", "cv3_u10_oracle_tokens.json")
+    if os.path.exists(gpath) and not args.llm_fp8:
+        gold = json.load(open(gpath))
+        for name, toks in [("single", seen["single"])] + [("slot %d" % i, t) for i, t in enumerate(seen["batch"])]:
+            div = next((k for k, (a, b) in enumerate(zip(toks, gold["tokens"])) if a != b), None)
+            if len(toks) != len(gold["tokens"]) or (div is not None and gold["top2_margin"][div] > 1e-3):
+                raise RuntimeError("bench cosyvoice3: %s does not reproduce the oracle's tokens (first difference at step %s)" % (name, div))
+        check = {"checked": True, "tokens_equal_oracle_single_and_16_slots": True, "oracle_min_top2_margin": gold["min_margin"]}
     return {"model": "Fun-CosyVoice3-0.5B dimensions (CosyVoice3LM, DiT 22 x 1024, CausalHiFTGenerator), seeded random weights", "cfm_steps": args.cv3_steps,
             "flow_precision": args.flow_precision, "llm": ("batch of 16: fp8 e4m3 weights + activations on the fp8 MFMA; single request: W16A32" if args.llm_fp8 else "W16A32"),
             "batch1_audio_s_per_s": round(AUDIO_S / single, 3), "batch1_ms_per_utterance": round(1e3 * single, 2),
-            "batch16_audio_s_per_s": round(nb * AUDIO_S / batch_s, 3), "batch16_ms_per_batch": round(1e3 * batch_s, 2), "lanes": args.lanes, "flow_batch": args.flow_batch}
+            "batch16_audio_s_per_s": round(nb * AUDIO_S / batch_s, 3), "batch16_ms_per_batch": round(1e3 * batch_s, 2), "lanes": args.lanes, "flow_batch": args.flow_batch, "token_check": check}
 
 
 def streaming_clients(model, u, clients, n_requests):
@@ -236,6 +255,13 @@ def streaming_clients(model, u, clients, n_requests):
     req["min_token_text_ratio"] = req["max_token_text_ratio"] = N_GEN / N_TEXT
     sch = StreamScheduler(model, slots=min(8, clients), step_chunk=8)
     lat, samples, errs, lock, todo = [], [0], [], threading.Lock(), [n_requests]
+    got_tokens = {}                                               # self-check: every request's speech tokens as the LM thread delivered them
+    on_tokens = sch._on_tokens
+
+    def spy(key, toks, finished, error):
+        got_tokens.setdefault(key, []).extend(int(t) for t in toks)
+        return on_tokens(key, toks, finished, error)
+    sch._on_tokens = spy
 
     def client():
         while True:
@@ -274,9 +300,13 @@ def streaming_clients(model, u, clients, n_requests):
     lat.sort()
     pct = lambda q: round(lat[min(len(lat) - 1, int(q * len(lat)))], 2)
     assert samples[0] == n_requests * N_GEN * 2 * 480
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "u10_oracle_tokens.json")))["tokens"]
+    bad = [k for k, t in got_tokens.items() if t != gold]
+    if bad or len(got_tokens) != n_requests + 1:                  # + the warm-up request
+        raise RuntimeError("bench streaming clients: %d of %d requests did not reproduce the oracle's U10 tokens" % (len(bad), len(got_tokens)))
     st = list(sch.first_chunk_stats)[1:]                         # without the warm-up request
     med = lambda i: round(sorted(x[i] for x in st)[len(st) // 2], 2) if st else None
-    return {"clients": clients, "requests": n_requests, "first_chunk_ms_p50": pct(0.5), "first_chunk_ms_p90": pct(0.9), "first_chunk_ms_max": round(lat[-1], 2),
+    return {"clients": clients, "requests": n_requests, "tokens_equal_oracle_all_requests": True, "first_chunk_ms_p50": pct(0.5), "first_chunk_ms_p90": pct(0.9), "first_chunk_ms_max": round(lat[-1], 2),
             "first_chunk_split_ms_p50": {"lm_until_tokens": med(0), "wait_for_lane": med(1), "token2wav": med(2)},
             "audio_s_per_s": round(samples[0] / 24000.0 / el, 3), "wall_s": round(el, 2)}
 
@@ -383,13 +413,18 @@ def roofline_llm(model, u, cfgs):
     # HBM traffic per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run, x1024 B, x2 for
     # the gfx950 wide-read under-count — MI355X_MICROARCH.md §HBM); PMC cannot be collected from inside this process, hence the file.
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r2_pmc_gemv_fetch.json")
-    if os.path.exists(pmc):
-        d = json.load(open(pmc))
+    pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r3_pmc_gemv_fetch.json", "r2_pmc_gemv_fetch.json")) if os.path.exists(f)), None)
+    if pmc is not None:
+        import hashlib
+        raw = open(pmc, "rb").read()
+        d = json.loads(raw)
         sel = [v for k, v in d.items() if "gemv_norm_kernel<7, 2" in k]
         if sel:
             traffic = int(sum(v["n"] * v["hbm_read_bytes_corrected"] for v in sel) / sum(v["n"] for v in sel))
-            traffic_src = "profiles/r2_pmc_gemv_fetch.json (rocprofv3 --pmc FETCH_SIZE in its own run, x1024 x2 for the gfx950 wide-read under-count; mean over the gemv_norm_kernel<7,2,5> (gate/up) launches of tools/profile_small.py llm, summarised by tools/pmc_summary.py)"
+            traffic_src = ("REPLAYED PMC RECORD, not measured by this run (PMC counters cannot be collected from inside the benchmark process): %s, sha1 %s - "
+                           "rocprofv3 --pmc FETCH_SIZE in its own run (tools/gpu_pmc.sh), x1024 B, x2 for the gfx950 wide-read under-count; mean over the "
+                           "gemv_norm_kernel<7,2,5> (gate/up) launches of tools/profile_small.py llm, summarised by tools/pmc_summary.py"
+                           % (os.path.relpath(pmc, ROOT), hashlib.sha1(raw).hexdigest()[:16]))
     step_us = sum(chain[k] * lc.layers for k in (0, 1, 2, 3, 4)) + chain[5]
     stage_gbps = (2 * 363786020 + 381 * 12288 * 2) / (step_us * 1e-6) / 1e9      # bf16 weight bytes per token (+ fp32 KV at the final context)
     return dict(bound="hbm", kernel="gemv_norm_kernel<7,2,5> (LLM decode, gate_up weight stream: 2 x 4864 x 896 bf16 per launch)", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
@@ -420,16 +455,22 @@ def cpu_stage(stage):
             sd = W.make_llm(lc)
             x = OL.build_lm_input(sd, lc, u["text"], u["prompt_text"], u["llm_prompt_speech_token"])
             tok = sd["speech_embedding.weight"][5].reshape(1, -1)
+            fill = sd["speech_embedding.weight"][torch.arange(7, 7 + 121)]          # 121 more cached positions per hop: contexts 131 -> 256 -> 381
             for t in sweep:
                 torch.set_num_threads(t)
                 m = OL.Qwen2Oracle(sd, lc)
                 t0 = time.perf_counter(); m.forward(x); t_prefill = time.perf_counter() - t0
                 m.forward(tok)
-                t0 = time.perf_counter()
-                for _ in range(4):
-                    y = m.forward(tok)
-                    torch.nn.functional.linear(y[-1], sd["llm_decoder.weight"], sd["llm_decoder.bias"]).log_softmax(-1)
-                res[t] = {"llm_prefill": t_prefill, "llm_per_token": (time.perf_counter() - t0) / 4}
+                per = []
+                for hop in range(3):                             # 4 timed decode steps at context ~131, ~256 and ~381: the range U10's 250 steps cover
+                    if hop:
+                        m.forward(fill)
+                    t0 = time.perf_counter()
+                    for _ in range(4):
+                        y = m.forward(tok)
+                        torch.nn.functional.linear(y[-1], sd["llm_decoder.weight"], sd["llm_decoder.bias"]).log_softmax(-1)
+                    per.append((time.perf_counter() - t0) / 4)
+                res[t] = {"llm_prefill": t_prefill, "llm_per_token": sum(per) / len(per)}
         elif stage == "flow":
             fsd = W.make_flow(fc)
             T = 2 * (N_PROMPT_TOK + N_GEN)
@@ -467,9 +508,10 @@ def cpu_baseline(cfgs):
             best = min(d, key=lambda t: d[t][key])
             stage_s[key], threads[key] = d[best][key], int(best)
     total = stage_s["llm_prefill"] + N_GEN * stage_s["llm_per_token"] + stage_s["flow_encoder"] + fc.n_timesteps * stage_s["flow_estimator_step"] + stage_s["hift_500_frames"]
-    return dict(value=round(AUDIO_S / total, 4), unit="audio_s/s", cores=max(threads.values()), kind="port", host_cores=os.cpu_count(),
-                sample="oracle/ (torch fp32 eager), one fresh process per stage, best of a thread sweep per stage: LLM prefill(131) + 4 decode steps, "
-                       "flow encoder(337 tok) + 1 of 10 estimator steps at T=674, HiFT 100 of 500 frames; per-stage times extrapolated to the full U10 utterance",
+    return dict(value=round(AUDIO_S / total, 4), unit="audio_s/s", cores=max(threads.values()), kind="port (sampled: bounded sample of U10 per stage, extrapolated)", host_cores=os.cpu_count(),
+                sample="oracle/ (torch fp32 eager, the CPU restatement of the reference - not the reference modules), one fresh process per stage, best of a thread sweep per "
+                       "stage: LLM prefill(131) + 12 decode steps (4 each at context 131 / 256 / 381, averaged: the range U10's 250 steps cover), flow encoder(337 tok) + 1 of 10 "
+                       "estimator steps at T=674, HiFT 100 of 500 frames; per-stage times extrapolated to the full U10 utterance",
                 threads_used=threads, stage_seconds={k: round(v, 4) for k, v in stage_s.items()})
 
 
@@ -494,6 +536,63 @@ def run_mixed(model, reqs, mine, slots=8):
     for j, res in model.tts_queue([reqs[i] for i in mine], slots=slots):
         out[mine[j]] = hashlib.sha1(res["tts_speech"].numpy().tobytes()).hexdigest()
     return out
+
+
+def check_mixed_tokens(tokens_by_index):
+    """tokens_by_index: {utterance index: tokens}.  Each must follow tests/golden/mixed64_oracle_tokens.json (the CPU oracle's greedy tokens,
+    tests/golden/make_mixed64.py) up to the first step where the ORACLE's own top-2 margin is a near-tie (<= 1e-3 in log-prob): there two correct
+    fp32 implementations may legitimately part, and the sequences are free-running from then on.  Returns a summary; raises on a divergence at a clear margin."""
+    path = os.path.join(ROOT, "tests", "golden", "mixed64_oracle_tokens.json")
+    if not os.path.exists(path):
+        return {"checked": False, "why": "tests/golden/mixed64_oracle_tokens.json not present"}
+    gold = {g["index"]: g for g in json.load(open(path))["utterances"]}
+    full, at_tie, bad = 0, [], []
+    for i, toks in sorted(tokens_by_index.items()):
+        g = gold[i]
+        toks = [int(t) for t in toks]
+        if len(toks) != g["n_gen"]:
+            bad.append((i, "length", len(toks), g["n_gen"]))
+            continue
+        div = next((k for k, (a, b) in enumerate(zip(toks, g["tokens"])) if a != b), None)
+        if div is None:
+            full += 1
+        elif any(k == div and m <= 1e-3 for k, m in g["near_ties"]):
+            at_tie.append((i, div))
+        else:
+            bad.append((i, "diverged at a clear margin", div, toks[div], g["tokens"][div]))
+    if bad:
+        raise RuntimeError("bench mixed64: speech tokens differ from the oracle's: %s" % (bad[:5],))
+    return {"checked": True, "utterances": len(tokens_by_index), "identical_to_oracle": full, "parted_at_an_oracle_near_tie": [list(x) for x in at_tie]}
+
+
+def mixed64_extra(model, cfgs, lanes):
+    """BASELINE.json configs[3] on ONE GPU as an extra of the default line: the 64 mixed-length utterances through tts_queue (16 sequences in
+    flight), one untimed pass then one timed pass; per-utterance waveform hashes and the token check against the oracle."""
+    import hashlib
+    reqs, costs = mixed_requests(cfgs, model.device)
+    mine = list(range(len(reqs)))
+    toks = {}
+    inf_q = model.llm.inference_queue
+
+    def spy(r, slots=8, **kw):
+        for j, t in inf_q(r, slots=slots, **kw):
+            toks[mine[j]] = list(t)
+            yield j, t
+    model.llm.inference_queue = spy
+    try:
+        run_mixed(model, reqs, mine, slots=16)
+        torch.cuda.synchronize()
+        toks.clear()
+        t0 = time.perf_counter()
+        hashes = run_mixed(model, reqs, mine, slots=16)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    finally:
+        model.llm.inference_queue = inf_q
+    assert sorted(hashes) == mine
+    return {"workload": "64 seeded utterances, 125/250/375/500 generated tokens in equal mix (800 s of audio), one GPU, 16 sequences in flight", "audio_s_per_s": round(sum(costs) / 25.0 / el, 3),
+            "wall_s": round(el, 2), "lanes": lanes, "utterance_hashes_sha1": hashlib.sha1("".join(hashes[i] for i in mine).encode()).hexdigest(),
+            "token_check": check_mixed_tokens(toks)}
 
 
 def spawn_ranks(n):
@@ -543,6 +642,9 @@ def main():
     ap.add_argument("--llm-fp8", action="store_true", help="extras only: the BATCHED LM decode of --batch / --cv3 on the opt-in fp8 path (e4m3 weights + activations, "
                     "v_mfma_f32_16x16x32_fp8_fp8); the headline batch-1 workload always runs W16A32")
     ap.add_argument("--cv3-steps", type=int, default=4, help="CFM Euler steps of the --cv3 extra (configs[4] names 4; the reference hard-codes 10)")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1 only: skip the extra keys the default line carries next to `value` - `batched_decode` (8 and 16 "
+                    "sequences), `streaming_clients` (8 clients, 104 requests: BASELINE.json configs[2]), `mixed64` (configs[3] on one GPU) and `cosyvoice3` (configs[4] shape) - "
+                    "each with its own token self-check; they add about two minutes")
     ap.add_argument("--cpu-stage", choices=CPU_STAGES, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_stage:
@@ -645,17 +747,28 @@ def main():
         if world == 1 and args.workload == "u10":
             out["stages"] = stage_split(model, u)
             log("stage split: %s" % out["stages"])
-        if world == 1 and (args.batch > 0 or args.stream_clients > 0):
+        # Extras of the default N = 1 line (not `value`): the other BASELINE.json configurations under the same clock, each with its own token check.
+        extras = world == 1 and args.workload == "u10" and not args.no_extras
+        batches = [args.batch] if args.batch > 0 else ([8, 16] if extras else [])
+        clients = args.stream_clients if args.stream_clients > 0 else (8 if extras else 0)
+        if world == 1 and (batches or clients):
             model.set_lanes(args.lanes)
-        if world == 1 and args.batch > 0:
-            out["batched_decode"] = dict(batched_decode(model, u, args.batch, max(1, args.steps // 2)), lanes=args.lanes, flow_batch=args.flow_batch)
-            log("batched decode done")
-        if world == 1 and args.stream_clients > 0:
-            out["streaming_clients"] = dict(streaming_clients(model, u, args.stream_clients, args.stream_requests), lanes=args.lanes)
+        for nb in batches:
+            res = dict(batched_decode(model, u, nb, max(1, args.steps // 2)), lanes=args.lanes, flow_batch=args.flow_batch)
+            out["batched_decode" if nb == batches[0] else "batched_decode_%d" % nb] = res
+            log("batched decode %d done: %s" % (nb, res))
+        if world == 1 and clients:
+            if extras and args.stream_clients == 0:
+                model.set_lanes(4)                               # configs[2]: 8 streaming clients on 4 token2wav lanes (profiles/r2_lanes_ab.txt)
+            out["streaming_clients"] = dict(streaming_clients(model, u, clients, args.stream_requests), lanes=model.n_lanes)
             log("streaming clients done: %s" % out["streaming_clients"])
-        if world == 1 and (args.batch > 0 or args.stream_clients > 0):
+        if extras:
+            model.set_lanes(args.lanes)
+            out["mixed64"] = mixed64_extra(model, cfgs, args.lanes)
+            log("mixed64 done: %s" % out["mixed64"])
+        if world == 1 and (batches or clients):
             model.set_lanes(1)
-        if world == 1 and args.cv3:
+        if world == 1 and (args.cv3 or extras):
             out["cosyvoice3"] = cv3_workload(args)
             log("cosyvoice3 done: %s" % out["cosyvoice3"])
         if world == 1 and args.streams > 1:

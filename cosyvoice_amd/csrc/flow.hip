@@ -14,6 +14,7 @@
 #include "tensor_map.h"
 #include "flow_kernels.h"
 #include "flow_fused.h"
+#include "flow_tail.h"
 
 using namespace cv;
 
@@ -24,7 +25,7 @@ struct LN { const float* g = nullptr; const float* b = nullptr; };
 
 struct ConformerW { LN norm_mha, norm_ff; Lin qkv, pos, out, ff1, ff2; const float* bias_u; const float* bias_v; };
 struct ResnetW { Lin mlp, conv1, conv2, res; LN ln1, ln2; };
-struct TBlockW { LN norm1, norm3; Lin qkv, out, ff1, ff2; };
+struct TBlockW { LN norm1, norm3; Lin qkv, out, ff1, ff2; const u32x4_t* tail = nullptr; bool tail_qkv = false; };   // tail: fragment-ordered stream of flow_tail_kernel (+ the next block's QKV)
 struct StageW { ResnetW res; std::vector<TBlockW> tf; };
 struct DitBlockW { Lin mod, qkv, out, ff1, ff2; };       // DiTBlock (flow/DiT/modules.py:500-530)
 
@@ -54,6 +55,8 @@ struct cv_flow {
     DevBuf s_in, s_a, s_b, s_c, s_n, s_qkv, s_att, s_ff, s_skip, s_cat, s_out;                    // estimator
     DevBuf h_qk, h_vt, h_att, h_ff;                                                           // estimator, fused bf16 pipeline (flow_fused.h)
     int vt_pitch = 0;                  // row pitch of V^T = round_up(T capacity, 64)
+    int tail_ring = 8;                 // weight fragments (1 KB each) a wave of flow_tail_kernel keeps in flight: 8 or 16 (option "tail_ring", env CV_FLOW_TAIL_RING)
+    int fused_tail = 1;                // bf16 mode: everything after a block's attention in ONE launch per 16-row band (flow_tail.h); 0 = the 5-launch form of round 2
     int fused = 1;                     // bf16 mode: LN-prologue GEMMs + bf16 activations + bf16 flash attention for the transformer blocks
     // tuning knobs of the fused pipeline.  "flow_tile": 0 = by size (one round of workgroups, see ln_gemm_bf16), 1 = 64x64, 2 = 64x128, 3 = 32x64,
     // 4 = 64x192; "attn_waves": 2 | 4 waves (32 | 64 queries) per workgroup; "attn_kt": 64-key tiles per iteration (1 | 2)
@@ -155,10 +158,18 @@ static void flow_finalize(cv_flow* m) {
             t.norm1 = get_ln(m, q + "norm1", C); t.norm3 = get_ln(m, q + "norm3", C);
             t.qkv = get_lin(m, q + "qkv", 3 * inner, C, 1, false); t.out = get_lin(m, q + "out", C, inner, 1, true);
             t.ff1 = get_lin(m, q + "ff1", 4 * C, C, 1, true); t.ff2 = get_lin(m, q + "ff2", C, 4 * C, 1, true);
+            if (m->wbf16 && m->tm.has(q + "tail") && ((C == 256 && inner == 512) || (C == 64 && inner == 64))) {
+                t.tail_qkv = j + 1 < c.est_blocks;
+                const long long frags = (long long)(C / 64) * (inner / 32) + (long long)(4 * C / 64) * (C / 32) + (long long)(C / 64) * (4 * C / 32) +
+                                        (t.tail_qkv ? 3LL * (inner / 64) * (C / 32) : 0);
+                t.tail = reinterpret_cast<const u32x4_t*>(m->tm.get(q + "tail", CV_BF16, 4 * frags * 64 * 8).p);
+            }
             st.tf.push_back(t);
         }
         m->stages.push_back(st);
     }
+    if (const char* e = getenv("CV_FLOW_TAIL")) m->fused_tail = e[0] != '0';        // dev knob for A/B runs (also: option "fused_tail")
+    if (const char* e = getenv("CV_FLOW_TAIL_RING")) m->tail_ring = atoi(e) == 16 ? 16 : 8;
     m->down_conv = get_lin(m, "est.down_conv", C, C, 3, true); m->up_conv = get_lin(m, "est.up_conv", C, C, 3, true);
     m->final_conv = get_lin(m, "est.final.conv", C, C, 3, true); m->final_ln = get_ln(m, "est.final.ln", C);
     m->final_proj = get_lin(m, "est.final_proj", c.mel, C, 1, true);
@@ -353,6 +364,22 @@ static void gemm_bf16_res(const Lin& l, const bf16_t* A, int lda, int M, float* 
     const unsigned g = ((M + 31) / 32) * ((l.N + 63) / 64);
     hipLaunchKernelGGL((flow_gemm_kernel<32, 64, 0, 1>), dim3(g), dim3(256), 0, s, a);
 }
+// everything after the attention of block `t` (+ LayerNorm and QKV of `next`) in one launch, 16 rows per workgroup (flow_tail.h)
+static void flow_tail(const TBlockW& t, const TBlockW* next, const bf16_t* att, int inner, float* x, int C, int M, bf16_t* qk, bf16_t* vt, long long vt_batch, int ldt,
+                      int rows_per_batch, int depth, hipStream_t s) {
+    FlowTailArgs a{};
+    a.att = att; a.ld_att = inner; a.x = x; a.ldx = C; a.wstream = t.tail;
+    a.b_out = t.out.b; a.g3 = t.norm3.g; a.be3 = t.norm3.b; a.b_ff1 = t.ff1.b; a.b_ff2 = t.ff2.b; a.eps = 1e-5f; a.M = M;
+    CV_CHECK(t.tail && t.tail_qkv == (next != nullptr) && t.out.b && t.ff1.b && t.ff2.b, "flow_tail: block was not packed for this call");
+    if (next) { a.g1n = next->norm1.g; a.be1n = next->norm1.b; a.qk = qk; a.ld_qk = 2 * inner; a.vt = vt; a.vt_batch = vt_batch; a.ldt = ldt; a.rows_per_batch = rows_per_batch; }
+    const dim3 g((unsigned)((M + 15) / 16));
+    if (C == 256 && inner == 512) {
+        if (depth == 16) { if (next) hipLaunchKernelGGL((flow_tail_kernel<256, 512, 1024, true, 16>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((flow_tail_kernel<256, 512, 1024, false, 16>), g, dim3(256), 0, s, a); }
+        else { if (next) hipLaunchKernelGGL((flow_tail_kernel<256, 512, 1024, true, 8>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((flow_tail_kernel<256, 512, 1024, false, 8>), g, dim3(256), 0, s, a); }
+    } else if (C == 64 && inner == 64) {
+        if (next) hipLaunchKernelGGL((flow_tail_kernel<64, 64, 256, true, 8>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((flow_tail_kernel<64, 64, 256, false, 8>), g, dim3(256), 0, s, a);
+    } else throw Error("flow_tail: no instantiation for these dimensions");
+}
 static void attn_flow(const bf16_t* qk, int ld, int inner, const bf16_t* vt, long long vt_batch, int ldt, bf16_t* o, int B, int H, int T, int chunk, hipStream_t s, const int* klen = nullptr) {
     AttnFlowArgs a{};
     a.klen = klen;
@@ -393,7 +420,16 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
         ln_rows(st.res.ln2, x, xb, R, C, 1e-5f, s, ACT_MISH);
         conv_cl(st.res.res, cur, T, T, nz, 0, 1, x, ACT_NONE, 0.f, xb, s);           // x = res_conv(input) + h
         const bool fused = tl_bf16_mfma && m->fused && C <= 256 && m->wbf16;
-        for (const TBlockW& t : st.tf) {      // matcha BasicTransformerBlock (self-attention + exact-erf GELU feed-forward)
+        for (size_t ti = 0; ti < st.tf.size(); ++ti) {      // matcha BasicTransformerBlock (self-attention + exact-erf GELU feed-forward)
+            const TBlockW& t = st.tf[ti];
+            if (fused && m->fused_tail && t.tail) {   // flow_tail.h: LN + QKV once per stage, then attention + ONE row-band launch per block
+                bf16_t* qk = m->h_qk.as<bf16_t>(); bf16_t* vt = m->h_vt.as<bf16_t>(); bf16_t* ab = m->h_att.as<bf16_t>();
+                const long long vt_batch = (long long)inner * m->vt_pitch;
+                if (ti == 0) ln_gemm_bf16(t.qkv, &t.norm1, 1e-5f, x, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
+                attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, m->cur_klen);
+                flow_tail(t, ti + 1 < st.tf.size() ? &st.tf[ti + 1] : nullptr, ab, inner, x, C, (int)R, qk, vt, vt_batch, m->vt_pitch, T, m->tail_ring, s);
+                continue;
+            }
             if (fused) {                      // flow_fused.h: 5 launches, bf16 activations, same rounding points as the path below
                 bf16_t* qk = m->h_qk.as<bf16_t>(); bf16_t* vt = m->h_vt.as<bf16_t>(); bf16_t* ab = m->h_att.as<bf16_t>(); bf16_t* fb = m->h_ff.as<bf16_t>();
                 const long long vt_batch = (long long)inner * m->vt_pitch;
@@ -642,6 +678,8 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "attn_ks") { CV_CHECK(value == 1 || value == 2, "attn_ks must be 1 or 2"); m->attn_ks = value; drop_graphs(m); }
         else if (std::string(name) == "attn_kt") { CV_CHECK(value == 1 || value == 2, "attn_kt must be 1 or 2"); m->attn_kt = value; drop_graphs(m); }
         else if (std::string(name) == "attn_waves") { CV_CHECK(value == 2 || value == 4, "attn_waves must be 2 or 4"); m->attn_waves = value; drop_graphs(m); }
+        else if (std::string(name) == "fused_tail") { m->fused_tail = value != 0; drop_graphs(m); }
+        else if (std::string(name) == "tail_ring") { m->tail_ring = value == 16 ? 16 : 8; drop_graphs(m); }      // bf16 mode: one row-band launch after each attention (flow_tail.h) on / off
         else if (std::string(name) == "fused") { m->fused = value != 0; drop_graphs(m); }              // bf16 mode: fused transformer blocks (flow_fused.h) on / off
         else throw Error(std::string("unknown option ") + name);
     });

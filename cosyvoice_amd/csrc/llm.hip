@@ -509,6 +509,9 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
         return;
     }
     const int ks = down_ksplit(c.inter);
+    // CV_DOWN_DEEP=0: the round-2 form of the down projection (8 K ranges across workgroups + sum_partials_kernel) for A/B runs
+    static const bool deep_knob = [] { const char* e = getenv("CV_DOWN_DEEP"); return !(e && e[0] == '0'); }();
+    const bool deep_down = deep_knob && (c.inter / 32 + 15) / 16 <= 10 && c.hidden % 4 == 0;
     // 2 row tiles per workgroup for the two wide GEMMs (gate/up: 304 workgroups, head: 206); 3 (203 / 137 workgroups, at most 3 tiles per CU instead
     // of 4 on 48 CUs) measured the same step time (profiles/r2_batch_decode_ab.txt): the launch is not bound by the busiest CU's MFMA share
     const int wide_rt = 2;
@@ -529,7 +532,10 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
         launch_attn_batch(ad, c.heads, nb, s);
         skinny(SkinnyArgs{L.wo, nullptr, att, A, h, H, c.hidden, (int)A, nullptr, 0.f, h, H, 0, nb, 1}, 1, s);
         skinny(SkinnyArgs{L.wgu, nullptr, h, H, act, I, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 0, 1, nb, 1}, wide_rt, s);
-        if (ks > 1) {
+        if (deep_down) {                                          // one launch: 16-wave workgroups over the whole K (skinny_deep_kernel)
+            hipLaunchKernelGGL((skinny_deep_kernel<16, 5>), dim3((unsigned)((H + 15) / 16)), dim3(1024), 0, s,
+                               SkinnyArgs{L.wdown, nullptr, act, I, h, H, c.hidden, c.inter, nullptr, 0.f, h, H, 0, nb, 1});
+        } else if (ks > 1) {
             skinny(SkinnyArgs{L.wdown, nullptr, act, I, dpart, H, c.hidden, c.inter, nullptr, 0.f, nullptr, 0, 2, nb, ks}, 2, s);
             hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((nb * H / 4 + 255) / 256)), dim3(256), 0, s, dpart, ks, nb, c.hidden, h, H, h, H);
         } else {

@@ -339,6 +339,71 @@ __global__ __launch_bounds__(256) void skinny_fp8_kernel(SkinnyF8Args p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The DEEP skinny GEMM: the down projection (K = inter = 4864, N = hidden = 896) of the batched decode in ONE launch.
+// Round 2 cut K 8 ways across workgroups (448 workgroups, raw partials) and combined them in a second launch (sum_partials_kernel):
+// 5.7 + 4.8 us per layer, the second launch pure boundary + latency.  Here one workgroup of NW = 16 waves owns a 16-row tile over the
+// WHOLE K: wave w takes k-tiles [w T / NW, (w + 1) T / NW) (9 or 10 of the 152), keeps a ring of D = 5 tiles in registers (weights
+// non-temporal, activations from L2), and re-requests a slot the moment it has been multiplied - two memory round trips per wave instead of
+// one plus a kernel boundary; the 16 accumulators meet in LDS in a fixed order and wave 0 adds the residual.  56 workgroups: the launch is
+// bound by what 56 CUs ingest (155 KB of weights + nb x 19 KB of activations each), not by the chip - still less than the boundary it removes.
+// Arithmetic per sequence: the three-term split products of skinny_mfma_kernel, k-tiles summed in ascending order inside a wave, waves in
+// ascending order: fixed, independent of the slot and of the other slots.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int NW, int D>
+__global__ __launch_bounds__(NW * 64) void skinny_deep_kernel(SkinnyArgs p) {
+    __shared__ __attribute__((aligned(16))) float red[NW * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int tiles = p.K / 32;
+    const int t0 = wave * tiles / NW, nt = (wave + 1) * tiles / NW - t0;          // <= 2 D (host check)
+    const int kbase = t0 * 32 + g * 8;
+    const int n_base = blockIdx.x * 16;
+    const bf16_t* wr = p.W + (long long)min(n_base + c, p.N - 1) * p.K + kbase;
+    const float* xp = p.x + (long long)min(c, p.nb - 1) * p.ldx + kbase;
+    u32x4 w[D];
+    float4 xa[D], xb[D];
+    auto request = [&](int slot, int t) {                                         // tile t of this wave into ring slot `slot` (unconditional, clamped)
+        const bool ok = t < nt;
+        const int tt = ok ? t : 0;
+        u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + tt * 32));
+        float4 a = *reinterpret_cast<const float4*>(xp + tt * 32), b = *reinterpret_cast<const float4*>(xp + tt * 32 + 4);
+        if (!ok) { v = (u32x4){0u, 0u, 0u, 0u}; a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+        w[slot] = v; xa[slot] = a; xb[slot] = b;
+    };
+#pragma unroll
+    for (int t = 0; t < D; ++t) request(t, t);
+    v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int t = 0; t < D; ++t) {
+            if (r * D + t < nt) {                                               // wave-uniform
+                u32x4 h1, h2, h3;
+                split3_bf16(xa[t], xb[t], h1, h2, h3);
+                const v8bf wf = __builtin_bit_cast(v8bf, w[t]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(v8bf, h3), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(v8bf, h2), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(v8bf, h1), acc, 0, 0, 0);
+            }
+            if (r == 0) request(t, D + t);
+        }
+    }
+    *reinterpret_cast<float4*>(&red[(wave * 64 + lane) * 4]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+    if (wave != 0) return;
+    float4 v = *reinterpret_cast<const float4*>(&red[lane * 4]);
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) {
+        const float4 o = *reinterpret_cast<const float4*>(&red[(ww * 64 + lane) * 4]);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    const int n = n_base + g * 4;                                               // 4 consecutive weight rows of sequence c (N % 4 == 0: host check)
+    if (c >= p.nb || n >= p.N) return;
+    if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+    if (p.res) { const float4 r4 = *reinterpret_cast<const float4*>(p.res + (long long)c * p.ldres + n); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+    *reinterpret_cast<float4*>(p.y + (long long)c * p.ldy + n) = v;
+}
+
 // y[b][n] = res[b][n] + sum_ks part[ks][b][n]   (fixed order; the split-K combine of the down projection + residual)
 static __global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, int ksplit, int nb, int N, const float* res, long long ldres,
                                                                float* y, long long ldy) {

@@ -204,7 +204,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
 // ---------------------------------------------------------------------------------------------------------------
 // WAVES = 5 for gate / up: 4864 row pairs over 20 groups per workgroup = 244 workgroups, one per CU in a single balanced round (with 4 waves
 // the 304 workgroups leave 48 of the 256 CUs with two each - the tail of the launch).
-template <int STEPS, int ROWS, int WAVES = 4>
+// XFIRST (round 3): x and gamma are requested BEFORE the weight rows.  vmcnt retires loads in issue order, so with x behind the weight stream
+// (round 2) the normalisation - and both of its barriers - could only start once the workgroup's last weight byte had landed; requested ahead of
+// the stream (two L2 hits), x is normalised and parked in LDS while the weights are still in flight and the FMAs start on the first row that lands.
+template <int STEPS, int ROWS, int WAVES = 4, bool XFIRST = true>
 __global__ __launch_bounds__(WAVES * 64) void gemv_norm_kernel(GemvArgs p) {
     __shared__ __attribute__((aligned(16))) float xs[STEPS * 128];
     __shared__ float red[WAVES];
@@ -212,6 +215,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_norm_kernel(GemvArgs p) {
     const int steps = p.K / 128;
     const int unit = (blockIdx.x * WAVES + wave) * 4 + grp;  // 16-lane group index: ROWS consecutive rows
     const int row0 = unit * ROWS;
+    const bool have = tid * 4 < p.K;
+    float4 xv, gv;
+    if constexpr (XFIRST) {
+        xv = *reinterpret_cast<const float4*>(p.x + (have ? tid * 4 : 0)); gv = *reinterpret_cast<const float4*>(p.gamma + (have ? tid * 4 : 0));
+    }
 
     u32x4 w[ROWS][STEPS];
 #pragma unroll
@@ -227,9 +235,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_norm_kernel(GemvArgs p) {
         }
     }
     {
-        const bool have = tid * 4 < p.K;
         const int k = have ? tid * 4 : 0;
-        float4 xv = *reinterpret_cast<const float4*>(p.x + k), gv = *reinterpret_cast<const float4*>(p.gamma + k);
+        if constexpr (!XFIRST) { xv = *reinterpret_cast<const float4*>(p.x + k); gv = *reinterpret_cast<const float4*>(p.gamma + k); }
         if (!have) xv = make_float4(0.f, 0.f, 0.f, 0.f);
         float ss = wave_sum(xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w);
         if (lane == 0) red[wave] = ss;

@@ -84,6 +84,39 @@ def _conv(out, name, w, b, device, dtype):
         out[name + ".b"] = _f32(b, device)
 
 
+def _mfma_fragments(w):
+    """bf16 matrix [N][K] (N % 16 == 0, K % 32 == 0) -> [N/16][K/32][64 lanes][8]: the operand fragment of v_mfma_f32_16x16x32_bf16 for the 16-row
+    tile nt and k-step ks - lane l holds row 16 nt + l % 16, columns 32 ks + 8 (l / 16) .. + 7 - as one contiguous 1 KB block."""
+    N, K = w.shape
+    return w.reshape(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(N // 16, K // 32, 64, 8)
+
+
+def pack_flow_tail(w_out, w_ff1, w_ff2, w_qkv_next=None, waves=4):
+    """The weight stream of flow_tail_kernel (csrc/flow_tail.h) for one transformer block: every matrix cut into MFMA fragments and laid out in the
+    exact order each of the 4 waves consumes them - out-projection, FF1 (passes of <= 8 tiles), FF2, then Q, K and V of the NEXT block - k-step
+    major, tile minor inside a pass, wave w owning tiles w, w + 4, w + 8, ...  Returns bf16 [4][fragments per wave][64][8]."""
+    def wave_part(fr, w, lo, hi, per_pass):
+        mine = fr[lo:hi][w::waves]                                 # [tiles of this wave][KS][64][8]
+        parts = []
+        for p0 in range(0, mine.shape[0], per_pass):
+            parts.append(mine[p0:p0 + per_pass].permute(1, 0, 2, 3).reshape(-1, 64, 8))       # k-step major, tile minor
+        return torch.cat(parts, 0)
+
+    fo, f1, f2 = _mfma_fragments(w_out), _mfma_fragments(w_ff1), _mfma_fragments(w_ff2)
+    fq = _mfma_fragments(w_qkv_next) if w_qkv_next is not None else None
+    tc = f1.shape[0] // waves
+    pc = 8 if tc > 8 else tc
+    out = []
+    for w in range(waves):
+        parts = [wave_part(fo, w, 0, fo.shape[0], fo.shape[0] // waves), wave_part(f1, w, 0, f1.shape[0], pc), wave_part(f2, w, 0, f2.shape[0], f2.shape[0] // waves)]
+        if fq is not None:
+            ni = fq.shape[0] // 3
+            for which in range(3):
+                parts.append(wave_part(fq, w, which * ni, (which + 1) * ni, ni // waves))
+        out.append(torch.cat(parts, 0))
+    return torch.stack(out, 0).contiguous()
+
+
 def pack_flow(sd, cfg, device, dtype=torch.bfloat16):
     """sd: CausalMaskedDiffWithXvec state dict (cosyvoice/flow/flow.py:150-186)."""
     out = {}
@@ -143,10 +176,18 @@ def pack_flow(sd, cfg, device, dtype=torch.bfloat16):
     stages = [(s + "down_blocks.0.", "est.stage.0.")]
     stages += [(s + "mid_blocks.%d." % i, "est.stage.%d." % (i + 1)) for i in range(cfg.est_mid)]
     stages += [(s + "up_blocks.0.", "est.stage.%d." % (cfg.est_mid + 1))]
+    inner = cfg.est_heads * 64
+    tail_ok = dtype == torch.bfloat16 and (cfg.est_ch, inner) in ((256, 512), (64, 64))      # the instantiations of flow_tail_kernel (csrc/flow.hip)
     for src, dst in stages:
         resnet(src + "0.", dst + "res.")
         for j in range(cfg.est_blocks):
             tblock(src + "1.%d." % j, dst + "tf.%d." % j)
+        if tail_ok:                                                 # the fused row-local tail of every block (csrc/flow_tail.h): a second, fragment-ordered copy
+            for j in range(cfg.est_blocks):
+                q = dst + "tf.%d." % j
+                nxt = out[dst + "tf.%d.qkv.w" % (j + 1)].reshape(3 * inner, cfg.est_ch) if j + 1 < cfg.est_blocks else None
+                out[q + "tail"] = pack_flow_tail(out[q + "out.w"].reshape(cfg.est_ch, inner), out[q + "ff1.w"].reshape(4 * cfg.est_ch, cfg.est_ch),
+                                                 out[q + "ff2.w"].reshape(cfg.est_ch, 4 * cfg.est_ch), nxt)
     _conv(out, "est.down_conv", sd[s + "down_blocks.0.2.weight"], sd[s + "down_blocks.0.2.bias"], device, dtype)
     _conv(out, "est.up_conv", sd[s + "up_blocks.0.2.weight"], sd[s + "up_blocks.0.2.bias"], device, dtype)
     _conv(out, "est.final.conv", sd[s + "final_block.block.0.weight"], sd[s + "final_block.block.0.bias"], device, dtype)

@@ -303,6 +303,49 @@ def test_fused_transformer_blocks_match_unfused(lib, tile, waves, kt, ks):
                 (T, streaming, e_fu.mean().item(), e_un.mean().item(), e_fu.max().item(), e_un.max().item())
 
 
+@pytest.mark.parametrize("est_blocks", [1, 3])
+def test_fused_tail_matches_five_launch_blocks(lib, est_blocks):
+    """bf16 mode, round 3: everything after a block's attention as ONE launch per 16-row band (flow_tail.h: out-projection + residual -> LayerNorm ->
+    FF1 + GELU -> FF2 + residual -> the next block's LayerNorm -> Q | K | V^T) against the five-launch form of round 2 (option fused_tail = 0) and
+    the fp32 oracle.  The rounding points are the same, so the criterion is the mode's own (see the test above): as close to the oracle as the
+    five-launch path, and close to it.  est_blocks = 3 exercises the chained variant (tail + next QKV, twice) and the closing one; a time axis that is
+    not a multiple of 16 (ragged last band) nor of 4 (V^T groups straddling), CFG batch rows, both mask modes, graph replay through inference()."""
+    import ctypes as C
+    import dataclasses
+    cfg = dataclasses.replace(W.tiny()[1], est_blocks=est_blocks, est_mid=1, chunk=13, n_timesteps=2)
+    sd = W.make_flow(cfg)
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision="bf16")
+    assert any(k.endswith(".tail") for k in flow._tensors), "weights.pack_flow did not produce the fragment-ordered tail streams"
+    g = torch.Generator().manual_seed(5)
+    for T in (45, 150):
+        x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g); cond = torch.randn(2, 80, T, generator=g)
+        spk = torch.randn(2, 80, generator=g); t = torch.tensor([0.4, 0.4]); mask = torch.ones(2, 1, T)
+        for streaming in (False, True):
+            outs = []
+            for tail in (0, 1):
+                lib.cv_flow_set_option(flow._h, b"fused_tail", C.c_int32(tail))
+                outs.append(flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu())
+            ref = OF.estimator(sd, cfg, x, mask, mu, t, spk, cond, streaming)
+            e_5, e_t, d = (outs[0] - ref).abs(), (outs[1] - ref).abs(), (outs[1] - outs[0]).abs()
+            assert torch.isfinite(outs[1]).all()
+            assert e_t.mean().item() < 1.3 * e_5.mean().item() + 1e-5 and e_t.max().item() < 1.6 * e_5.max().item() + 1e-4, \
+                (T, streaming, e_t.mean().item(), e_5.mean().item(), e_t.max().item(), e_5.max().item())
+            assert d.mean().item() < 1.5 * e_5.mean().item() + 1e-5, (T, streaming, d.mean().item(), e_5.mean().item())
+            if lib.emulated:        # same rounding points, same k order in every MFMA chain, same bias / residual order: under one libm the two forms agree bit for bit
+                assert torch.equal(outs[0], outs[1])
+    # the whole inference (encoder + Euler loop, captured graph on the second sighting) with the tail on stays inside the mode's stated tolerance
+    lib.cv_flow_set_option(flow._h, b"fused_tail", C.c_int32(1))
+    u = _inputs(cfg)
+    n = lambda k: torch.tensor([k], dtype=torch.int32)
+    kw = dict(token=u["token"], token_len=n(13), prompt_token=u["prompt_token"], prompt_token_len=n(7), prompt_feat=u["prompt_feat"], prompt_feat_len=n(14),
+              embedding=u["embedding"], streaming=False, finalize=True)
+    mels = [flow.inference(**kw)[0].cpu() for _ in range(3)]
+    assert torch.equal(mels[0], mels[1]) and torch.equal(mels[1], mels[2])                       # eager == graph replay
+    refm = OF.inference(sd, cfg, u["token"], u["prompt_token"], u["prompt_feat"], u["embedding"], streaming=False, finalize=True, n_timesteps=2)
+    dm = (mels[0] - refm).abs()
+    assert dm.max() < 5e-2 and dm.mean() < 1e-2, (dm.max().item(), dm.mean().item())
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_flow_inference_batch_equals_single(lib, precision):
     """cv_flow_inference_batch: utterances of equal shape solved in one pass (estimator batch rows = 2 x utterances) give, each, exactly the mel

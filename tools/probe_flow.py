@@ -44,7 +44,14 @@ if "all" in which:
         opt(b"flow_tile", tile); opt(b"attn_waves", waves); opt(b"attn_kt", kt); opt(b"attn_ks", ks)
         mel = bench("fused tile=%d attn_waves=%d attn_kt=%d attn_ks=%d" % (tile, waves, kt, ks))
         print("    max |fused - unfused| = %.3e (mel std %.2f)" % ((mel - ref).abs().max().item(), ref.std().item()), flush=True)
+elif "tail" in which:                # round 3: the one-launch block tail (flow_tail.h) against the five-launch block, ring depth 8 / 16
+    opt(b"fused", 1); opt(b"fused_tail", 0); ref = bench("five launches per block (round 2)")
+    for ring in (8, 16):
+        opt(b"fused_tail", 1); opt(b"tail_ring", ring)
+        mel = bench("attention + ONE tail launch per block, ring %d" % ring)
+        print("    max |tail - five-launch| = %.3e, bit-identical %s (mel std %.2f)" % ((mel - ref).abs().max().item(), bool(torch.equal(mel, ref)), ref.std().item()), flush=True)
 else:
     opt(b"fused", int(os.environ.get("FUSED", "1"))); opt(b"flow_tile", int(os.environ.get("TILE", "0"))); opt(b"attn_waves", int(os.environ.get("WAVES", "4"))); opt(b"attn_kt", int(os.environ.get("KT", "1"))); opt(b"attn_ks", int(os.environ.get("KS", "2")))
+    opt(b"fused_tail", int(os.environ.get("TAIL", "1")))
     opt(b"use_graph", 0)
     bench("profile run", reps=1)
