@@ -255,13 +255,7 @@ def streaming_clients(model, u, clients, n_requests):
     req["min_token_text_ratio"] = req["max_token_text_ratio"] = N_GEN / N_TEXT
     sch = StreamScheduler(model, slots=min(8, clients), step_chunk=8)
     lat, samples, errs, lock, todo = [], [0], [], threading.Lock(), [n_requests]
-    got_tokens = {}                                               # self-check: every request's speech tokens as the LM thread delivered them
-    on_tokens = sch._on_tokens
-
-    def spy(key, toks, finished, error):
-        got_tokens.setdefault(key, []).extend(int(t) for t in toks)
-        return on_tokens(key, toks, finished, error)
-    sch._on_tokens = spy
+    got_tokens = sch.token_log = {}                               # self-check: every request's speech tokens as the LM thread delivered them
 
     def client():
         while True:

@@ -27,7 +27,7 @@ class GemmConvArgs(C.Structure):
         ("res", C.c_void_p), ("res_batch", C.c_int64),
         ("out_scale", C.c_float),
         ("row_scale", C.c_void_p), ("row_scale_batch", C.c_int64),
-        ("accumulate", C.c_int32), ("a_bf16", C.c_int32),
+        ("accumulate", C.c_int32), ("a_bf16", C.c_int32), ("W3", C.c_void_p),
     ]
 
 

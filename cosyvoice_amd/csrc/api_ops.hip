@@ -94,6 +94,8 @@ int cv_gemm_conv(const cv_gemm_conv_args* g, void* stream) {
         a.M = g->M; a.N = g->N; a.act = g->act; a.act_p = g->act_p; a.res = g->res; a.res_batch = g->res_batch;
         a.out_scale = g->out_scale; a.row_scale = g->row_scale; a.row_scale_batch = g->row_scale_batch; a.accumulate = g->accumulate; a.a_bf16 = g->a_bf16;
         CV_CHECK(g->w_dtype == CV_F32 || g->w_dtype == CV_BF16, "cv_gemm_conv: w_dtype");
+        CV_CHECK(!g->W3 || (g->w_dtype == CV_F32 && g->ldw == 0 && g->w_batch == 0 && cv::aligned16(g->W3)), "cv_gemm_conv: W3 planes go with plain fp32 weights (no row pitch / batch offset)");
+        a.W3 = g->W3;
         cv::gemm_conv(a, g->w_dtype == CV_BF16, g->batch, cv::as_stream(stream));
     });
 }

@@ -25,7 +25,7 @@ struct LN { const float* g = nullptr; const float* b = nullptr; };
 
 struct ConformerW { LN norm_mha, norm_ff; Lin qkv, pos, out, ff1, ff2; const float* bias_u; const float* bias_v; };
 struct ResnetW { Lin mlp, conv1, conv2, res; LN ln1, ln2; };
-struct TBlockW { LN norm1, norm3; Lin qkv, out, ff1, ff2; const u32x4_t* tail = nullptr; bool tail_qkv = false; };   // tail: fragment-ordered stream of flow_tail_kernel (+ the next block's QKV)
+struct TBlockW { LN norm1, norm3; Lin qkv, out, ff1, ff2; const u32x4_t* tail = nullptr; const float* tail_prm = nullptr; bool tail_qkv = false; };   // tail: fragment-ordered stream of flow_tail_kernel (+ the next block's QKV)
 struct StageW { ResnetW res; std::vector<TBlockW> tf; };
 struct DitBlockW { Lin mod, qkv, out, ff1, ff2; };       // DiTBlock (flow/DiT/modules.py:500-530)
 
@@ -163,6 +163,7 @@ static void flow_finalize(cv_flow* m) {
                 const long long frags = (long long)(C / 64) * (inner / 32) + (long long)(4 * C / 64) * (C / 32) + (long long)(C / 64) * (4 * C / 32) +
                                         (t.tail_qkv ? 3LL * (inner / 64) * (C / 32) : 0);
                 t.tail = reinterpret_cast<const u32x4_t*>(m->tm.get(q + "tail", CV_BF16, 4 * frags * 64 * 8).p);
+                t.tail_prm = m->tm.f32(q + "tail_prm", 6LL * C + 4 * C);
             }
             st.tf.push_back(t);
         }
@@ -369,9 +370,9 @@ static void flow_tail(const TBlockW& t, const TBlockW* next, const bf16_t* att, 
                       int rows_per_batch, int depth, hipStream_t s) {
     FlowTailArgs a{};
     a.att = att; a.ld_att = inner; a.x = x; a.ldx = C; a.wstream = t.tail;
-    a.b_out = t.out.b; a.g3 = t.norm3.g; a.be3 = t.norm3.b; a.b_ff1 = t.ff1.b; a.b_ff2 = t.ff2.b; a.eps = 1e-5f; a.M = M;
-    CV_CHECK(t.tail && t.tail_qkv == (next != nullptr) && t.out.b && t.ff1.b && t.ff2.b, "flow_tail: block was not packed for this call");
-    if (next) { a.g1n = next->norm1.g; a.be1n = next->norm1.b; a.qk = qk; a.ld_qk = 2 * inner; a.vt = vt; a.vt_batch = vt_batch; a.ldt = ldt; a.rows_per_batch = rows_per_batch; }
+    a.prm = t.tail_prm; a.eps = 1e-5f; a.M = M;
+    CV_CHECK(t.tail && t.tail_prm && t.tail_qkv == (next != nullptr), "flow_tail: block was not packed for this call");
+    if (next) { a.qk = qk; a.ld_qk = 2 * inner; a.vt = vt; a.vt_batch = vt_batch; a.ldt = ldt; a.rows_per_batch = rows_per_batch; }
     const dim3 g((unsigned)((M + 15) / 16));
     if (C == 256 && inner == 512) {
         if (depth == 16) { if (next) hipLaunchKernelGGL((flow_tail_kernel<256, 512, 1024, true, 16>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((flow_tail_kernel<256, 512, 1024, false, 16>), g, dim3(256), 0, s, a); }

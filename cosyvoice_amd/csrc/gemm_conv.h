@@ -41,6 +41,8 @@ struct GemmConvArgs {
     long long bias_batch;           // float offset of the bias per batch (grouped convolutions: one bias slice per group); 0 = shared
     const float* col_scale; int col_scale_rows; long long col_scale_stride;   // per-(row block, column) multiplier applied to act(acc + bias) BEFORE the residual:
                                     // the adaLN-zero gates of the DiT (x + gate[b] * f(x), flow/DiT/modules.py:523-528); row m uses block m / col_scale_rows
+    const void* W3;                 // optional: the SAME fp32 weights pre-split into three bf16 planes, rows [3 N][taps * Kp] with row 3 n + p = plane p of row n
+                                    // (w = w1 + w2 + w3 exactly, weights.py::split3_planes).  With fp32 weights and a_vec the products then run on the bf16 pipe (WX3 below).
     long long* dbg;                 // dev tool (tools/ubench/gemm_probe.hip): per-phase clock64() stamps of wave 0, 64 slots per workgroup; null in production
 };
 
@@ -55,20 +57,27 @@ struct GemmConvArgs {
 // accumulation - the accuracy of the fp32 MFMA chain for 3 x 16 cycles per 32 k instead of 8 x 32 (the fp32 tiles are MFMA-bound: one wave per
 // SIMD, ~1300 cycles of v_mfma_f32_16x16x4_f32 per 128-wide k-step).  The activation is split ONCE, when it is staged: three bf16 planes in LDS
 // (6 bytes per element instead of 4), the weights staged as the raw bf16 they are.  This is what the LLM prefill and the fp32 mode of the flow run on.
-template <int BM, int BN, int BK, bool WBF16, bool AVEC, int STAGES = 2, bool ABF16 = false, int WM = 2, int WN = 2, bool AX3 = false>
+// WX3 (round 3, fp32 WEIGHTS - HiFT): both operands split, x = x1 + x2 + x3 and w = w1 + w2 + w3 (the weight planes are prepared once at load time and arrive
+// as a [3 N][taps Kp] bf16 matrix, GemmConvArgs::W3).  Of the nine plane products the six of relative weight >= 2^-16 are kept (x1 w1; x1 w2, x2 w1; x2 w2,
+// x1 w3, x3 w1), every one exact, accumulated in fp32 smallest first; the dropped x2 w3 + x3 w2 + x3 w3 are <= 2^-23 of a product - the size of ONE fp32
+// rounding of it, so the result is as accurate as the fp32 MFMA chain (whose own accumulation error is ~ sqrt(K) roundings) for 6 x 16 instead of
+// 8 x 32 matrix-pipe cycles per 32 k.  A WX3 kernel is an AX3 kernel whose weight tile has 3 BN rows.
+template <int BM, int BN, int BK, bool WBF16, bool AVEC, int STAGES = 2, bool ABF16 = false, int WM = 2, int WN = 2, bool AX3 = false, bool WX3 = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p) {
     static_assert(!ABF16 || WBF16, "the bf16 MFMA path takes bf16 weights");
     static_assert(!AX3 || (WBF16 && !ABF16), "the three-term split is the exact path for bf16 weights");
+    static_assert(!WX3 || (AX3 && AVEC), "the two-sided split is an AX3 kernel over pre-split weight planes");
     constexpr int NT = 64 * WM * WN;
+    constexpr int WR = WX3 ? 3 : 1;                                        // weight-tile rows per output column
     constexpr bool BFT = ABF16 || AX3;                                    // bf16 tiles in LDS, products on v_mfma_f32_16x16x32_bf16
     // LD = LDS row pitch in dwords.  fp32 tiles: BK + 4.  bf16 tiles hold BK/2 packed pairs + 4 dwords of padding.
     constexpr int LD = BFT ? BK / 2 + 4 : BK + 4, KV = BK / 4;           // KV = groups of 4 k-values per tile row
     constexpr int APL = BM * LD;                                          // dwords per A plane (AX3: three of them)
     constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN);   // 16x16 tiles per wave (wave tile = BM/WM x BN/WN)
-    constexpr int AV = BM * KV / NT, WV = BN * KV / NT;       // float4 groups per thread per k-step
-    static_assert(TM >= 1 && TN >= 1 && AV >= 1 && WV >= 1 && BM * KV % NT == 0 && BN * KV % NT == 0, "tile does not divide over the workgroup");
+    constexpr int AV = BM * KV / NT, WV = WR * BN * KV / NT;  // float4 groups per thread per k-step
+    static_assert(TM >= 1 && TN >= 1 && AV >= 1 && WV >= 1 && BM * KV % NT == 0 && WR * BN * KV % NT == 0, "tile does not divide over the workgroup");
     __shared__ __attribute__((aligned(16))) float As[(AX3 ? 3 : 1) * APL];
-    __shared__ __attribute__((aligned(16))) float Ws[BN * LD];
+    __shared__ __attribute__((aligned(16))) float Ws[WR * BN * LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
@@ -102,7 +111,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
     constexpr int WE = WBF16 ? 2 : 4;                 // bytes per weight element
     int a_boff[AV], w_boff[WV];
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(Ab, (unsigned)(p.a_len * 4));
-    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(reinterpret_cast<const char*>(p.W) + wb * WE, (unsigned)(((long long)(p.N - 1) * ldw + (long long)p.taps * p.Kp) * WE));
+    const void* Wp = WX3 ? p.W3 : p.W;
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(reinterpret_cast<const char*>(Wp) + wb * WE, (unsigned)(((long long)(WR * p.N - 1) * ldw + (long long)p.taps * p.Kp) * WE));
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
         const int v = tid + i * NT, m = m0 + v / KV;
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
         const int v = tid + i * NT;
-        int n = n0 + v / KV; n = n < p.N ? n : p.N - 1;
+        int n = WR * n0 + v / KV; n = n < WR * p.N ? n : WR * p.N - 1;      // WX3: row 3 n + plane
         w_c4[i] = (v % KV) * 4;
         w_base[i] = wb + (long long)n * ldw + w_c4[i];
         w_boff[i] = (int)(((long long)n * ldw + w_c4[i]) * WE);
@@ -208,6 +218,37 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
         }
     };
     auto compute_tile = [&]() {
+        if constexpr (WX3) {
+#pragma unroll
+            for (int kg = 0; kg < BK / 32; ++kg) {
+                uint4 af[3][TM], wf[3][TN];
+                const int kd = kg * 16 + (lane >> 4) * 4;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        af[pl][i] = *reinterpret_cast<const uint4*>(&As[pl * APL + (wm * (BM / WM) + i * 16 + (lane & 15)) * LD + kd]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        wf[pl][j] = *reinterpret_cast<const uint4*>(&Ws[((wn * (BN / WN) + j * 16 + (lane & 15)) * 3 + pl) * LD + kd]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {              // smallest terms first
+                        v4f a = acc[i][j];
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, wf[0][j]), __builtin_bit_cast(v8bf, af[2][i]), a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, wf[2][j]), __builtin_bit_cast(v8bf, af[0][i]), a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, wf[1][j]), __builtin_bit_cast(v8bf, af[1][i]), a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, wf[0][j]), __builtin_bit_cast(v8bf, af[1][i]), a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, wf[1][j]), __builtin_bit_cast(v8bf, af[0][i]), a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, wf[0][j]), __builtin_bit_cast(v8bf, af[0][i]), a, 0, 0, 0);
+                        acc[i][j] = a;
+                    }
+            }
+            return;
+        }
         if constexpr (AX3) {
 #pragma unroll
             for (int kg = 0; kg < BK / 32; ++kg) {

@@ -15,6 +15,16 @@ static void launch_cfg(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_
         hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK, true, true, ST, true>), grid, block, 0, stream, a);
         return;
     }
+    // fp32 activations x fp32 weights whose three bf16 planes were prepared at load time (HiFT): both operands split, six exact products per k on the bf16
+    // matrix pipe (gemm_conv.h, WX3).  BK <= 64: the weight tile has 3 BN rows.  CV_GEMM_WX3=0 pins the fp32 MFMA chain (A/B knob, read at every launch).
+    if (a.a_vec && !w_bf16 && a.W3) {
+        const char* e = getenv("CV_GEMM_WX3");
+        if (!(e && e[0] == '0')) {
+            constexpr int BK3 = BK > 64 ? 64 : BK;
+            hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK3, true, true, ST, false, 2, 2, true, true>), grid, block, 0, stream, a);
+            return;
+        }
+    }
     // fp32 activations x bf16 weights: the exact three-term split on the bf16 matrix pipe (gemm_conv.h, AX3).  CV_GEMM_X3=0 pins the fp32 MFMA chain
     // (A/B knob, read at every launch); results agree to fp32 rounding either way.
     if (a.a_vec && w_bf16) {

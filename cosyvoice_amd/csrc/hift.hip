@@ -11,7 +11,7 @@
 using namespace cv;
 
 namespace {
-struct Conv { const float* w = nullptr; const float* b = nullptr; int N = 0, K = 0, Kp = 0, taps = 1; };
+struct Conv { const float* w = nullptr; const float* b = nullptr; int N = 0, K = 0, Kp = 0, taps = 1; const void* w3 = nullptr; };   // w3: the three bf16 planes of w ([3 N][taps Kp], weights.py::split3_planes)
 struct ResBlockW { Conv c1[4], c2[4]; const float* a1[4]; const float* a2[4]; int k = 3; };
 inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 }  // namespace
@@ -32,6 +32,7 @@ static Conv get_conv(const cv_hift* m, const std::string& name, int N, int K, in
     Conv c; c.N = N; c.K = K; c.Kp = round_up32(K); c.taps = taps;
     c.w = m->tm.f32(name + ".w", (long long)N * taps * c.Kp);
     c.b = m->tm.f32(name + ".b", N);
+    if (m->tm.has(name + ".w3")) c.w3 = m->tm.get(name + ".w3", CV_BF16, 3LL * N * taps * c.Kp).p;
     return c;
 }
 
@@ -100,7 +101,7 @@ static void conv(const Conv& w, const float* A, long long a_rows, long long M, i
     GemmConvArgs a{};
     a.A = A; a.a_batch = 0; a.a_len = a_rows * w.K; a.lda = w.K; a.a_off0 = -pad * w.K; a.tap_step = dil * w.K; a.taps = w.taps; a.K = w.K;
     a.pro = pro; a.pro_p = pro_p; a.pro_alpha = alpha;
-    a.W = w.w; a.Kp = w.Kp; a.ldw = 0; a.w_batch = 0; a.bias = w.b;
+    a.W = w.w; a.W3 = w.w3; a.Kp = w.Kp; a.ldw = 0; a.w_batch = 0; a.bias = w.b;
     a.C = C; a.c_batch = 0; a.c_len = M * w.N; a.ldc = w.N; a.c_off = 0; a.M = (int)M; a.N = w.N;
     a.act = act; a.act_p = 0.f; a.res = res; a.res_batch = 0; a.out_scale = out_scale; a.row_scale = nullptr; a.accumulate = accumulate ? 1 : 0;
     gemm_conv(a, false, 1, s);

@@ -509,8 +509,11 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
         return;
     }
     const int ks = down_ksplit(c.inter);
-    // CV_DOWN_DEEP=0: the round-2 form of the down projection (8 K ranges across workgroups + sum_partials_kernel) for A/B runs
-    static const bool deep_knob = [] { const char* e = getenv("CV_DOWN_DEEP"); return !(e && e[0] == '0'); }();
+    // CV_DOWN_DEEP=1: the down projection as ONE launch of 56 sixteen-wave workgroups over the whole K (skinny_deep_kernel) instead of 8 K ranges across
+    // 448 workgroups + sum_partials_kernel.  Measured on MI355X (profiles/r3_batch_decode_ab.txt): 1086 vs 975 us per 8-sequence step - the weight
+    // stream comes from HBM at ~25 GB/s per CU, so 56 CUs cannot pull 8.7 MB in the time 448 workgroups on 256 CUs do; the removed launch (4.8 us) does
+    // not pay for that.  Kept, tested, off.
+    const bool deep_knob = [] { const char* e = getenv("CV_DOWN_DEEP"); return e && e[0] == '1'; }();       // read when a step is enqueued / captured
     const bool deep_down = deep_knob && (c.inter / 32 + 15) / 16 <= 10 && c.hidden % 4 == 0;
     // 2 row tiles per workgroup for the two wide GEMMs (gate/up: 304 workgroups, head: 206); 3 (203 / 137 workgroups, at most 3 tiles per CU instead
     // of 4 on 48 CUs) measured the same step time (profiles/r2_batch_decode_ab.txt): the launch is not bound by the busiest CU's MFMA share

@@ -346,7 +346,9 @@ __global__ __launch_bounds__(256) void skinny_fp8_kernel(SkinnyF8Args p) {
 // WHOLE K: wave w takes k-tiles [w T / NW, (w + 1) T / NW) (9 or 10 of the 152), keeps a ring of D = 5 tiles in registers (weights
 // non-temporal, activations from L2), and re-requests a slot the moment it has been multiplied - two memory round trips per wave instead of
 // one plus a kernel boundary; the 16 accumulators meet in LDS in a fixed order and wave 0 adds the residual.  56 workgroups: the launch is
-// bound by what 56 CUs ingest (155 KB of weights + nb x 19 KB of activations each), not by the chip - still less than the boundary it removes.
+// bound by what 56 CUs ingest (155 KB of weights + nb x 19 KB of activations each).  MEASURED SLOWER (profiles/r3_batch_decode_ab.txt: 8-sequence
+// step 975 -> 1086 us): an HBM weight stream reaches a CU at ~25 GB/s, so only the whole chip pulls 8.7 MB in a few microseconds.  Opt-in
+// (CV_DOWN_DEEP=1), kept as the measured alternative.
 // Arithmetic per sequence: the three-term split products of skinny_mfma_kernel, k-tiles summed in ascending order inside a wave, waves in
 // ascending order: fixed, independent of the slot and of the other slots.
 // ---------------------------------------------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ def pack_weight(w, dtype=torch.bfloat16):
 def gemm_conv(lib, A, Wp, Kp, *, M, N, K, taps=1, lda=None, a_off0=0, tap_step=0, a_len=None, a_batch=0,
               bias=None, out=None, ldc=None, c_off=0, c_len=None, c_batch=0, batch=1,
               pro="none", pro_p=0.0, pro_alpha=None, act="none", act_p=0.0, res=None, res_batch=0,
-              out_scale=1.0, row_scale=None, row_scale_batch=0, accumulate=False, ldw=0, w_batch=0, a_bf16=False):
+              out_scale=1.0, row_scale=None, row_scale_batch=0, accumulate=False, ldw=0, w_batch=0, a_bf16=False, w3=None):
     lda = K if lda is None else lda
     ldc = N if ldc is None else ldc
     if a_len is None:
@@ -50,6 +50,7 @@ def gemm_conv(lib, A, Wp, Kp, *, M, N, K, taps=1, lda=None, a_off0=0, tap_step=0
     g.row_scale = row_scale.data_ptr() if row_scale is not None else None; g.row_scale_batch = row_scale_batch
     g.accumulate = int(accumulate)
     g.a_bf16 = int(a_bf16)
+    g.W3 = w3.data_ptr() if w3 is not None else None          # fp32 weights pre-split into three bf16 planes (weights.split3_planes): two-sided split GEMM
     lib.cv_gemm_conv(C.byref(g), stream_ptr(lib))
     return out
 

@@ -47,6 +47,7 @@ class StreamScheduler:
         self._reqs = {}
         self._stop = False
         self._dead = None                               # exception that ended the LM thread, if any (submit() re-raises it)
+        self.token_log = None                            # optional dict key -> every token the LM delivered for the request (bench.py's self-check sets it)
         # (LM ms until the first chunk's tokens exist, ms waiting for a vocoder lane, ms of the first token2wav) of the last requests
         self.first_chunk_stats = collections.deque(maxlen=4096)
         self._llm_thread = threading.Thread(target=self._llm_loop, daemon=True)
@@ -112,6 +113,8 @@ class StreamScheduler:
     # ---- LLM thread: continuous batching, tokens streamed per decode chunk ------------------------------------------------------------
     def _on_tokens(self, key, toks, finished, error):
         with self._cv:
+            if self.token_log is not None:
+                self.token_log.setdefault(key, []).extend(int(t) for t in toks)
             r = self._reqs.get(key)
             if r is None or r.closed:
                 return True                              # unknown / abandoned request: serve_stream frees its slot

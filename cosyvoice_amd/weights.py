@@ -186,6 +186,9 @@ def pack_flow(sd, cfg, device, dtype=torch.bfloat16):
             for j in range(cfg.est_blocks):
                 q = dst + "tf.%d." % j
                 nxt = out[dst + "tf.%d.qkv.w" % (j + 1)].reshape(3 * inner, cfg.est_ch) if j + 1 < cfg.est_blocks else None
+                z = torch.zeros(cfg.est_ch, device=device)
+                out[q + "tail_prm"] = torch.cat([out[q + "out.b"], out[q + "norm3.g"], out[q + "norm3.b"], out[q + "ff1.b"], out[q + "ff2.b"],
+                                                 out[dst + "tf.%d.norm1.g" % (j + 1)] if nxt is not None else z, out[dst + "tf.%d.norm1.b" % (j + 1)] if nxt is not None else z]).contiguous()
                 out[q + "tail"] = pack_flow_tail(out[q + "out.w"].reshape(cfg.est_ch, inner), out[q + "ff1.w"].reshape(4 * cfg.est_ch, cfg.est_ch),
                                                  out[q + "ff2.w"].reshape(cfg.est_ch, 4 * cfg.est_ch), nxt)
     _conv(out, "est.down_conv", sd[s + "down_blocks.0.2.weight"], sd[s + "down_blocks.0.2.bias"], device, dtype)
@@ -251,6 +254,20 @@ def _conv_w(sd, p):
     return sd[p + "weight"].float()
 
 
+def split3_planes(w):
+    """fp32 matrix [N][K] -> bf16 [3 N][K], row 3 n + p = plane p of row n, with w = w1 + w2 + w3 EXACTLY (w1 = bf16(w), w2 = bf16(w - w1),
+    w3 = w - w1 - w2: 3 x 8 mantissa bits cover the 24 of an fp32 number; every residual is exact in fp32).  Operand of the two-sided split GEMM
+    (csrc/gemm_conv.h, WX3): fp32-accurate products on the bf16 matrix pipe."""
+    w = w.float()
+    w1 = w.to(torch.bfloat16)
+    r1 = w - w1.float()
+    w2 = r1.to(torch.bfloat16)
+    r2 = r1 - w2.float()
+    w3 = r2.to(torch.bfloat16)
+    assert torch.equal(w3.float(), r2) or not torch.isfinite(w).all() or (r2 - w3.float()).abs().max() <= 2.0 ** -126, "split3_planes: residual not representable"
+    return torch.stack([w1, w2, w3], 1).reshape(3 * w.shape[0], w.shape[1]).contiguous()
+
+
 def pack_hift(sd, cfg, device):
     """sd: HiFTGenerator state dict (cosyvoice/hifigan/generator.py:378-476), `generator.` prefix already stripped
     (cli/model.py:70-71)."""
@@ -302,4 +319,7 @@ def pack_hift(sd, cfg, device):
             n = i * len(cfg.res_k) + j
             resblock("resblocks.%d." % n, "resblocks.%d." % n)
     _conv(out, "conv_post", _conv_w(sd, "conv_post."), sd["conv_post.bias"], device, f32)
+    # the convolutions that carry the FLOPs (ResBlocks, upsamplers, conv_pre / conv_post) also get their three bf16 planes: csrc/gemm_conv.h WX3
+    for name in [k[:-2] for k in out if k.endswith(".w") and (k.startswith(("resblocks.", "source_resblocks.", "ups.", "conv_pre", "conv_post")))]:      # (the f0 predictor stays on the fp32 chain: its output is integrated into a phase)
+        out[name + ".w3"] = split3_planes(out[name + ".w"])
     return out

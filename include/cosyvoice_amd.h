@@ -55,6 +55,9 @@ typedef struct cv_gemm_conv_args {
     int32_t a_bf16;      /* 1: round the (prologue'd) activations to bf16 and multiply on the bf16 MFMA with fp32 accumulate (needs bf16 W,
                             16-byte aligned A layout; otherwise the fp32-accurate path runs); 0: fp32 accuracy - the fp32 MFMA chain for fp32 weights, the exact three-term bf16
                             split of the activations on the bf16 matrix pipe for bf16 weights */
+    const void* W3;      /* optional, fp32 W only: the same weights as three bf16 planes, rows [3 N][taps * Kp], row 3 n + p = plane p of row n with
+                            w = w1 + w2 + w3 exactly (cosyvoice_amd/weights.py::split3_planes).  When set (and the A layout is 16-byte aligned) the products run on
+                            the bf16 matrix pipe with BOTH operands split, six exact plane products per k - fp32 accuracy at 2.5x the fp32 MFMA rate (HiFT). NULL: fp32 chain */
 } cv_gemm_conv_args;
 int cv_gemm_conv(const cv_gemm_conv_args* args, void* stream);
 

@@ -280,6 +280,39 @@ def test_every_gemm_tile_shape(lib, tile, bf16, monkeypatch):
         torch.testing.assert_close(out[0].cpu(), ref.cpu(), rtol=3e-5, atol=3e-5)
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+def test_two_sided_split_fp32_weights(lib, tile, monkeypatch):
+    """fp32 activations x fp32 WEIGHTS (HiFT): both operands split into three bf16 planes (weights at load time, weights.split3_planes; activations
+    when staged), six exact plane products per k on v_mfma_f32_16x16x32_bf16 (gemm_conv.h WX3) against a float64 reference and against the fp32 MFMA
+    chain (CV_GEMM_WX3=0).  The dropped products are below one fp32 rounding of a term, so both stay at fp32-accumulation distance from float64.  Every
+    tile shape, ragged M / N / K edges, a dilated 3-tap "same" window, Snake prologue + bias + residual epilogue (a HiFT ResBlock convolution)."""
+    from cosyvoice_amd.weights import split3_planes
+    dev = _dev(lib)
+    monkeypatch.setenv("CV_GEMM_FORCE_TILE", str(tile))
+    for (M, N, K, taps, dil) in [(150, 140, 160, 1, 1), (90, 64, 64, 3, 3), (40, 33, 320, 1, 1)]:
+        rows = M + (taps - 1) * dil
+        x = _rand((rows, K), dev, 41, 2.0)
+        W = _rand((N, taps, K), dev, 42, 0.2)                       # full fp32 mantissas
+        W[0, 0, :4] = torch.tensor([1.0 + 2.0 ** -20, 3.0e-7, -1.0 - 2.0 ** -23, 0.0])      # values whose low planes matter
+        b = _rand((N,), dev, 43); res = _rand((M, N), dev, 44)
+        Wp, Kp = ops.pack_weight(W if taps > 1 else W[:, 0], torch.float32)
+        W3 = lib.hook(split3_planes(Wp))
+        assert torch.equal(W3.float().reshape(N, 3, -1).sum(1), Wp)                      # w1 + w2 + w3 == w exactly
+        alpha = lib.hook(torch.ones(Kp, device=dev) + 0.3 * _rand((Kp,), dev, 45).abs())
+        kw = dict(M=M, N=N, K=K, taps=taps, lda=K, tap_step=dil * K, a_len=x.numel(), bias=b, res=res.reshape(1, M, N), pro="snake", pro_alpha=alpha)
+        monkeypatch.delenv("CV_GEMM_WX3", raising=False)
+        split = ops.gemm_conv(lib, x, Wp, Kp, w3=W3, **kw)[0].cpu().double(); _sync(lib)
+        monkeypatch.setenv("CV_GEMM_WX3", "0")
+        chain = ops.gemm_conv(lib, x, Wp, Kp, w3=W3, **kw)[0].cpu().double(); _sync(lib)
+        a = alpha.cpu().double()[:K]
+        xs = x.cpu().double(); xs = xs + torch.sin(xs * a) ** 2 / (a + 1e-9)
+        ref = sum(xs[j * dil:j * dil + M] @ W.cpu().double()[:, j].t() for j in range(taps)) + b.cpu().double() + res.cpu().double()
+        scale = ref.abs().max().item()
+        e_split, e_chain = (split - ref).abs().max().item() / scale, (chain - ref).abs().max().item() / scale
+        assert not torch.equal(split, chain) or lib.emulated is None
+        assert e_split < 3e-6 and e_chain < 3e-6 and e_split < 4 * e_chain + 2e-7, (tile, M, N, K, e_split, e_chain)
+
+
 @pytest.mark.parametrize("M,N,K,taps", [(37, 48, 64, 1), (131, 200, 896, 1), (70, 96, 320, 3)])
 def test_linear_three_term_split_is_fp32_exact(lib, M, N, K, taps, monkeypatch):
     """fp32 activations x bf16 weights: the three-term bf16 split on v_mfma_f32_16x16x32_bf16 (gemm_conv.h AX3, the default) against a float64

@@ -126,7 +126,8 @@ def test_hift_decode_fullsize(lib):
 # the estimator at T = 674, flow.inference with 10 Euler steps at 337 tokens, HiFT at 500 frames.
 # ---------------------------------------------------------------------------------------------------------------------------------
 N_GEN, N_TEXT, N_PROMPT_TEXT, N_PROMPT_TOK = 250, 30, 12, 87
-E2E_MIN_SNR_DB = 20.0      # device f0 -> phase -> source -> waveform vs the oracle's, 500 frames (calibrated on the MI355X, see test_hift_u10)
+E2E_MIN_SNR_DB = 42.0      # device f0 -> phase -> source -> waveform vs the oracle's, 500 frames: measured 52.3 dB (HiFT v2) / 51.6 dB (causal, vs the float64 f0) on the
+                           # MI355X (profiles/r3_fullsize_errors.json); the bound allows 3x the measured error amplitude
 
 
 def _u10(lib):
@@ -237,7 +238,7 @@ def test_flow_inference_u10(lib):
     m = ref.shape[2]
     _, src_ref = OH.inference(hsd, hc, ref, None, None, torch.zeros(1, 480 * m, hc.harmonics + 1))
     w_ref = OH.decode(hsd, hc, ref, src_ref)
-    for precision, min_snr in (("fp32", 80.0), ("bf16", 30.0)):
+    for precision, min_snr in (("fp32", 100.0), ("bf16", 30.0)):                 # measured 114 dB / 52 dB on the MI355X; 30 dB is the stated bf16 tolerance
         w = hift.decode(mels[precision], src_ref).cpu()
         snr = (10 * torch.log10(w_ref.pow(2).sum() / (w_ref - w).pow(2).sum().clamp_min(1e-30))).item()
         _record(lib, "u10_waveform_snr_db_%s_flow_same_source" % precision, snr)
@@ -273,7 +274,7 @@ def test_hift_u10(lib):
     f0_dev = hift.f0_predictor(mel).cpu()
     f0_err = (f0_dev - f0_ref).abs().max().item()
     _record(lib, "hift_f0_500f_max_abs_hz", f0_err)
-    assert f0_dev.shape == f0_ref.shape and f0_ref.shape[-1] == m and f0_err < 1e-3 * max(1.0, f0_ref.abs().max().item()), f0_err
+    assert f0_dev.shape == f0_ref.shape and f0_ref.shape[-1] == m and f0_err < (2.5e-3 if not lib.emulated else 1e-3 * max(1.0, f0_ref.abs().max().item())), f0_err   # measured 7.9e-4 Hz
     # ... and the end-to-end waveform of the device chain against the oracle's end-to-end waveform (bounded by the source error above)
     e2e = _rel(speech.cpu(), speech_ref)
     snr = (10 * torch.log10(speech_ref.pow(2).sum() / (speech_ref - speech.cpu()).pow(2).sum().clamp_min(1e-30))).item()
@@ -373,12 +374,12 @@ def test_cv3_causal_hift_fullsize(lib):
     f0_err = (f0_dev - f0_64).abs().max().item()
     _record(lib, "cv3_f0_fp32_vs_float64_500f_max_abs_hz", f0_err)
     _record(lib, "cv3_f0_500f_max_hz", f0_64.abs().max().item())
-    assert f0_dev.shape == f0_64.shape and f0_err < 1e-3 * max(1.0, f0_64.abs().max().item()), f0_err
+    assert f0_dev.shape == f0_64.shape and f0_err < 2.5e-3, f0_err                         # measured 8.3e-4 Hz on f0 values up to 303 Hz
     speech64, src64 = OH.causal_inference(sd, hc, mel5, True, None, noise5.unsqueeze(0), f0_dtype=torch.float64)
     speech_dev, src_dev = h.inference(mel5, True, noise=noise5)
     src_err = (src_dev.cpu() - src64).abs().max().item()
     snr = (10 * torch.log10(speech64.pow(2).sum() / (speech64 - speech_dev.cpu()).pow(2).sum().clamp_min(1e-30))).item()
     _record(lib, "cv3_source_fp32f0_vs_float64f0_500f_max_abs", src_err)
     _record(lib, "cv3_e2e_fp32f0_vs_float64f0_500f_snr_db", snr)
-    assert src_dev.shape == src64.shape and src_err < 2.5e-2, src_err          # same bound as HiFT v2's fp32-vs-fp32 source (test_hift_u10)
+    assert src_dev.shape == src64.shape and src_err < 9e-3, src_err            # measured 2.8e-3
     assert speech_dev.shape == speech64.shape and snr >= E2E_MIN_SNR_DB, snr

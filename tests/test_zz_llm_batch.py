@@ -40,6 +40,20 @@ def test_batch_matches_single_and_oracle(lib, use_graph):
         assert g == OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=3, min_token_text_ratio=1)
 
 
+def test_deep_down_projection_variant(lib, monkeypatch):
+    """CV_DOWN_DEEP=1: the down projection of the batched step as ONE launch (skinny_deep_kernel: 16-wave workgroups over the whole K, a ring of
+    k-tiles per wave) instead of split-K partials + sum_partials_kernel.  Measured slower on the MI355X and off by default (llm.hip), but a kept
+    alternative stays a tested one: same tokens as the oracle."""
+    monkeypatch.setenv("CV_DOWN_DEEP", "1")
+    cfg = W.tiny()[0]
+    sd = W.make_llm(cfg)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=160, sampling="greedy", decode_chunk=5)
+    reqs = [_req(cfg, 1986, 6, 5, 11), _req(cfg, 7, 4, 3, 20), _req(cfg, 23, 3, 2, 33)]
+    got = lm.inference_batch(reqs, max_token_text_ratio=4, min_token_text_ratio=1)
+    for r, g in zip(reqs, got):
+        assert g == OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=4, min_token_text_ratio=1)
+
+
 def test_batch_of_eight_and_long_context(lib):
     cfg = W.tiny()[0]
     sd = W.make_llm(cfg)
