@@ -56,7 +56,10 @@ struct cv_flow {
     DevBuf h_qk, h_vt, h_att, h_ff;                                                           // estimator, fused bf16 pipeline (flow_fused.h)
     int vt_pitch = 0;                  // row pitch of V^T = round_up(T capacity, 64)
     int tail_ring = 8;                 // weight fragments (1 KB each) a wave of flow_tail_kernel keeps in flight: 8 or 16 (option "tail_ring", env CV_FLOW_TAIL_RING)
-    int fused_tail = 1;                // bf16 mode: everything after a block's attention in ONE launch per 16-row band (flow_tail.h); 0 = the 5-launch form of round 2
+    int fused_tail = 0;                // bf16 mode: 1 = everything after a block's attention in ONE launch per 16-row band (flow_tail.h).  Measured on MI355X
+                                       // (profiles/r3_flow_tail_ab.txt): 46.3 vs 38.5 ms per flow.inference at batch 1 - a workgroup pulls its 2 MB of weights through one CU's
+                                       // L1 at ~45 B/clk (~32 KB in flight, ~700 cycles), 33-40 us per launch whatever the band count, against 37 us for the four launches it
+                                       // replaces.  Off by default; bit-identical to the five-launch form, tested both ways.
     int fused = 1;                     // bf16 mode: LN-prologue GEMMs + bf16 activations + bf16 flash attention for the transformer blocks
     // tuning knobs of the fused pipeline.  "flow_tile": 0 = by size (one round of workgroups, see ln_gemm_bf16), 1 = 64x64, 2 = 64x128, 3 = 32x64,
     // 4 = 64x192; "attn_waves": 2 | 4 waves (32 | 64 queries) per workgroup; "attn_kt": 64-key tiles per iteration (1 | 2)
@@ -388,6 +391,9 @@ static void attn_flow(const bf16_t* qk, int ld, int inner, const bf16_t* vt, lon
     a.B = B; a.H = H; a.T = T; a.scale = 0.125f; a.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; a.chunk = chunk;
     const dim3 g2((unsigned)(((T + 31) / 32) * H * B)), g4((unsigned)(((T + 63) / 64) * H * B));
     if (tl_attn_ks == 2) { hipLaunchKernelGGL((attn_flow_kernel<4, 2, 2>), g4, dim3(512), 0, s, a); return; }
+    // 3 / 4 key splits: 12 / 16 waves on the same 64 queries, 192 / 256 keys per iteration - 4 / 3 iterations instead of 6 at T = 674 (round 3 probe)
+    if (tl_attn_ks == 3) { hipLaunchKernelGGL((attn_flow_kernel<4, 3, 3>), g4, dim3(768), 0, s, a); return; }
+    if (tl_attn_ks == 4) { hipLaunchKernelGGL((attn_flow_kernel<4, 4, 4>), g4, dim3(1024), 0, s, a); return; }
     if (tl_attn_waves == 2) {
         if (tl_attn_kt == 2) hipLaunchKernelGGL((attn_flow_kernel<2, 2>), g2, dim3(128), 0, s, a);
         else hipLaunchKernelGGL((attn_flow_kernel<2, 1>), g2, dim3(128), 0, s, a);
@@ -676,7 +682,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         if (std::string(name) == "use_graph") { m->use_graph = value != 0; drop_graphs(m); }
         else if (std::string(name) == "bf16_mfma") { m->bf16_mfma = value != 0; drop_graphs(m); }      // captured graphs bake the kernel choice
         else if (std::string(name) == "flow_tile") { CV_CHECK(value >= 0 && value <= 4, "flow_tile must be 0..4"); m->flow_tile = value; drop_graphs(m); }
-        else if (std::string(name) == "attn_ks") { CV_CHECK(value == 1 || value == 2, "attn_ks must be 1 or 2"); m->attn_ks = value; drop_graphs(m); }
+        else if (std::string(name) == "attn_ks") { CV_CHECK(value >= 1 && value <= 4, "attn_ks must be 1 .. 4"); m->attn_ks = value; drop_graphs(m); }
         else if (std::string(name) == "attn_kt") { CV_CHECK(value == 1 || value == 2, "attn_kt must be 1 or 2"); m->attn_kt = value; drop_graphs(m); }
         else if (std::string(name) == "attn_waves") { CV_CHECK(value == 2 || value == 4, "attn_waves must be 2 or 4"); m->attn_waves = value; drop_graphs(m); }
         else if (std::string(name) == "fused_tail") { m->fused_tail = value != 0; drop_graphs(m); }

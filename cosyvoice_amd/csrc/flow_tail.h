@@ -34,6 +34,7 @@ struct FlowTailArgs {
     float eps; int M;
     bf16_t* qk; int ld_qk;                    // HAS_QKV: Q | K [M][2 INNER] bf16
     bf16_t* vt; long long vt_batch; int ldt; int rows_per_batch;      // HAS_QKV: V^T [B][INNER][ldt] bf16, key-permuted (vt_col)
+    long long* dbg;                           // dev tool (tools/ubench/tail_probe.hip): clock64() of thread 0 at the phase boundaries, 16 slots per workgroup; null in production
 };
 
 // One pass of PT 16-column tiles over KS k-steps of 32: operands A[16 rows][32 KS] in LDS (bf16 pairs, row pitch `pitch` dwords) against the next
@@ -111,6 +112,10 @@ __global__ __launch_bounds__(256) void flow_tail_kernel(FlowTailArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane & 15, lg = lane >> 4;
     const int m0 = blockIdx.x * BM;
     const int mrow = min(m0 + lq, p.M - 1);                                 // the band row this lane's accumulators belong to (clamped; stores are masked)
+    long long* dbg = p.dbg ? p.dbg + (long long)blockIdx.x * 16 : nullptr;
+    int dn = 0;
+    auto stamp = [&]() { if (dbg && tid == 0) dbg[dn++] = clock64(); };
+    stamp();
 
     // ---- every small operand FIRST (vmcnt retires in order: what is requested behind the ring can only be had by draining it)
     constexpr int NPV = NPRM / 4, PPT = (NPV + 255) / 256;                  // float4 pieces of the parameter block per thread
@@ -141,6 +146,7 @@ __global__ __launch_bounds__(256) void flow_tail_kernel(FlowTailArgs p) {
         if (v < PIECES) *reinterpret_cast<u32x4_t*>(&A0[(v / (INNER / 8)) * PA0 + (v % (INNER / 8)) * 4]) = av[i];
     }
     __syncthreads();
+    stamp();
 
     // ---- A: out-projection + bias + residual -> X1 (fp32)
     {
@@ -154,9 +160,11 @@ __global__ __launch_bounds__(256) void flow_tail_kernel(FlowTailArgs p) {
         }
     }
     __syncthreads();
+    stamp();
     // ---- B: LayerNorm(norm3) -> A1 (bf16)
     tail_layernorm<C, PX>(X1, A1, PA1, &prm[O_G3], &prm[O_BE3], p.eps, tid);
     __syncthreads();
+    stamp();
     // ---- C: FF1 + bias + GELU -> A2 (bf16)
 #pragma unroll
     for (int ps = 0; ps < S::TC / S::PC; ++ps) {
@@ -173,6 +181,7 @@ __global__ __launch_bounds__(256) void flow_tail_kernel(FlowTailArgs p) {
     }
     static_assert(S::TC / S::PC <= 2, "flow_tail: FF1 runs in at most two passes");
     __syncthreads();
+    stamp();
     // ---- D: FF2 + bias + residual -> X1 (the new residual stream: written to memory at the END, and the next block's LayerNorm input)
     {
         v4f acc[S::TD];
@@ -186,10 +195,12 @@ __global__ __launch_bounds__(256) void flow_tail_kernel(FlowTailArgs p) {
         }
     }
     __syncthreads();
+    stamp();
     if constexpr (HAS_QKV) {
         // ---- E: LayerNorm(norm1 of the next block) -> A1
         tail_layernorm<C, PX>(X1, A1, PA1, &prm[O_G1N], &prm[O_BE1N], p.eps, tid);
         __syncthreads();
+        stamp();
         // ---- F: Q, K (row-major bf16, parked in A2 - free since FF2 - until the write-out) and V^T of the next block
         constexpr int BQ = S::FA + S::FC + S::FD;
         constexpr int PQK = 2 * INNER / 2 + 4;                            // row pitch (dwords) of the parked Q | K tile
@@ -224,6 +235,7 @@ __global__ __launch_bounds__(256) void flow_tail_kernel(FlowTailArgs p) {
             }
         }
         __syncthreads();
+        stamp();
         // write-out of the parked Q | K tile: 16-byte pieces, whole rows (4 KB at INNER = 512) per 256 consecutive lanes
         constexpr int QP = BM * 2 * INNER / 8;
 #pragma unroll
@@ -239,6 +251,7 @@ __global__ __launch_bounds__(256) void flow_tail_kernel(FlowTailArgs p) {
         const int v = tid + 256 * i, r = v / (C / 4), c = v % (C / 4);
         if (v < XP && m0 + r < p.M) *reinterpret_cast<float4*>(p.x + (long long)(m0 + r) * p.ldx + c * 4) = *reinterpret_cast<const float4*>(&X1[r * PX + c * 4]);
     }
+    stamp();
 }
 
 }  // namespace cv

@@ -41,6 +41,9 @@ struct GemmConvArgs {
     long long bias_batch;           // float offset of the bias per batch (grouped convolutions: one bias slice per group); 0 = shared
     const float* col_scale; int col_scale_rows; long long col_scale_stride;   // per-(row block, column) multiplier applied to act(acc + bias) BEFORE the residual:
                                     // the adaLN-zero gates of the DiT (x + gate[b] * f(x), flow/DiT/modules.py:523-528); row m uses block m / col_scale_rows
+    const float* act_alpha;         // act == ACT_SNAKE in the EPILOGUE: Snake(acc + bias) with alpha[n] per output column (HiFT ResBlocks, round 3: the activation
+                                    // is applied ONCE where a value is produced instead of in the prologue of every tap / N-tile that consumes it)
+    float* C2; const float* c2_alpha;   // optional second output, indexed like C: C2 = Snake(final value, c2_alpha[n]) - the next convolution's operand
     const void* W3;                 // optional: the SAME fp32 weights pre-split into three bf16 planes, rows [3 N][taps * Kp] with row 3 n + p = plane p of row n
                                     // (w = w1 + w2 + w3 exactly, weights.py::split3_planes).  With fp32 weights and a_vec the products then run on the bf16 pipe (WX3 below).
     long long* dbg;                 // dev tool (tools/ubench/gemm_probe.hip): per-phase clock64() stamps of wave 0, 64 slots per workgroup; null in production
@@ -408,7 +411,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += bb[e];
-            if (p.act != ACT_NONE) {                         // the only activation site of the epilogue
+            if (p.act == ACT_SNAKE) {                        // Snake with a per-column alpha (padded to a multiple of 32 by the host: n + 3 is readable)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = snake_f(v[e], p.act_alpha[n + e]);
+            } else if (p.act != ACT_NONE) {                  // the only activation site of the epilogue
                 const float4 t = apply_act4(p.act, make_float4(v[0], v[1], v[2], v[3]), p.act_p);
                 v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
             }
@@ -419,6 +425,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (ok[e]) Cb[idx + e] = v[e];
+            }
+            if (p.C2) {                                      // the same values, activated for their consumer
+                float* C2b = p.C2 + (long long)b * p.c_batch;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (ok[e]) C2b[idx + e] = snake_f(v[e], p.c2_alpha[n + e]);
             }
         }
     }

@@ -4,6 +4,7 @@
 // is the exact-fp32 MFMA implicit GEMM with Snake / leaky-ReLU fused as prologue and bias / residual / (1/3) average
 // fused as epilogue, so a ResBlock iteration is two launches instead of the reference's six.
 #include <vector>
+#include <cstdlib>
 #include "ops.h"
 #include "tensor_map.h"
 #include "hift_kernels.h"
@@ -24,7 +25,7 @@ struct cv_hift {
     const float* f0_cls_w = nullptr; const float* f0_cls_b = nullptr; const float* src_w = nullptr; const float* src_b = nullptr;
     ResBlockW src_rb[4]; std::vector<ResBlockW> rb;
     int scale = 480, sd_rate[4] = {1, 1, 1, 1};
-    DevBuf mel_cl, fa, fb, f0, P, s, sst, x, xs, t1, r0, r1, si, y_spec, xu;
+    DevBuf mel_cl, fa, fb, f0, P, s, sst, x, xs, t1, r0, r1, si, y_spec, xu, sn;
     int cap_m = 0;
 };
 
@@ -90,20 +91,22 @@ static void reserve(cv_hift* m, int frames) {
     big = std::max(big, mm * (size_t)std::max(c.base, c.f0_ch));
     m->mel_cl.ensure(mm * c.mel * 4); m->fa.ensure(mm * c.f0_ch * 4); m->fb.ensure(mm * c.f0_ch * 4); m->f0.ensure((mm + 4) * 4);
     m->P.ensure(mm * (c.harmonics + 1) * 4); m->s.ensure(L * 4); m->sst.ensure(F * 18 * 4); m->y_spec.ensure(F * 18 * 4);
-    for (DevBuf* b : {&m->x, &m->xs, &m->t1, &m->r0, &m->r1, &m->si}) b->ensure(big * 4);
+    for (DevBuf* b : {&m->x, &m->xs, &m->t1, &m->r0, &m->r1, &m->si, &m->sn}) b->ensure(big * 4);
     if (c.causal) m->xu.ensure(2 * big * 4);               // nearest-upsampled input of a CausalConv1dUpsample (twice the channels of its output)
     m->cap_m = frames;
 }
 
 // Conv1d on channel-last rows: tap j reads row (t + j*dil - pad)
 static void conv(const Conv& w, const float* A, long long a_rows, long long M, int pad, int dil, float* C, hipStream_t s, int pro, float pro_p,
-                 const float* alpha, int act, const float* res, float out_scale, bool accumulate) {
+                 const float* alpha, int act, const float* res, float out_scale, bool accumulate, const float* act_alpha = nullptr, float* C2 = nullptr,
+                 const float* c2_alpha = nullptr) {
     GemmConvArgs a{};
     a.A = A; a.a_batch = 0; a.a_len = a_rows * w.K; a.lda = w.K; a.a_off0 = -pad * w.K; a.tap_step = dil * w.K; a.taps = w.taps; a.K = w.K;
     a.pro = pro; a.pro_p = pro_p; a.pro_alpha = alpha;
     a.W = w.w; a.W3 = w.w3; a.Kp = w.Kp; a.ldw = 0; a.w_batch = 0; a.bias = w.b;
     a.C = C; a.c_batch = 0; a.c_len = M * w.N; a.ldc = w.N; a.c_off = 0; a.M = (int)M; a.N = w.N;
     a.act = act; a.act_p = 0.f; a.res = res; a.res_batch = 0; a.out_scale = out_scale; a.row_scale = nullptr; a.accumulate = accumulate ? 1 : 0;
+    a.act_alpha = act_alpha; a.C2 = C2; a.c2_alpha = c2_alpha;
     gemm_conv(a, false, 1, s);
 }
 
@@ -113,13 +116,34 @@ static void resblock(cv_hift* m, const ResBlockW& w, const float* in, long long 
     const auto& c = m->cfg;
     float* t1 = m->t1.as<float>(); float* r[2] = {m->r0.as<float>(), m->r1.as<float>()};
     const float* cur = in;
+    // Snake is applied ONCE per value, where the value is produced (round 3): the block input by one elementwise pass, conv1's output in conv1's
+    // epilogue, conv2's output (the next iteration's input) as conv2's second output.  As a PROLOGUE of the consuming convolution (rounds 1-2) every
+    // element was activated once per tap and per N-tile - a k = 11 convolution over four 64-column tiles evaluated sinf 44 times per element, and the
+    // HiFT convolutions were bound by that, not by the matrix pipe (profiles/r3_hift_ab.txt).  Same fp32 values either way: results are bit-identical.
+    const bool once = [] { const char* e = getenv("CV_HIFT_SNAKE_ONCE"); return !(e && e[0] == '0'); }();              // A/B knob, read at every call
+    if (!once) {
+        for (int j = 0; j < c.n_dil; ++j) {
+            const int d = c.dil[j], k = w.k;
+            conv(w.c1[j], cur, T, T, c.causal ? (k - 1) * d : (k * d - d) / 2, d, t1, s, ACT_SNAKE, 0.f, w.a1[j], ACT_NONE, nullptr, 1.f, false);
+            const bool last = j == c.n_dil - 1;
+            float* out = last ? dest : r[j & 1];
+            conv(w.c2[j], t1, T, T, c.causal ? k - 1 : (k - 1) / 2, 1, out, s, ACT_SNAKE, 0.f, w.a2[j], ACT_NONE, cur, last ? out_scale : 1.f, last && accumulate);
+            cur = out;
+        }
+        return;
+    }
+    const int C = w.c1[0].K;
+    CV_CHECK(C % 4 == 0, "hift: ResBlock channels must be a multiple of 4");
+    float* sn = m->sn.as<float>();
+    hipLaunchKernelGGL(snake_rows_kernel, dim3(nblk(T * C / 4)), dim3(256), 0, s, in, sn, w.a1[0], T * C / 4, C);
     for (int j = 0; j < c.n_dil; ++j) {
         const int d = c.dil[j], k = w.k;
         // padding: "same" for HiFTGenerator, all on the left for the causal generator (CausalConv1d 'left': (k - 1) * dilation, convolution.py:172)
-        conv(w.c1[j], cur, T, T, c.causal ? (k - 1) * d : (k * d - d) / 2, d, t1, s, ACT_SNAKE, 0.f, w.a1[j], ACT_NONE, nullptr, 1.f, false);
+        conv(w.c1[j], sn, T, T, c.causal ? (k - 1) * d : (k * d - d) / 2, d, t1, s, ACT_NONE, 0.f, nullptr, ACT_SNAKE, nullptr, 1.f, false, w.a2[j]);
         const bool last = j == c.n_dil - 1;
         float* out = last ? dest : r[j & 1];
-        conv(w.c2[j], t1, T, T, c.causal ? k - 1 : (k - 1) / 2, 1, out, s, ACT_SNAKE, 0.f, w.a2[j], ACT_NONE, cur, last ? out_scale : 1.f, last && accumulate);
+        conv(w.c2[j], t1, T, T, c.causal ? k - 1 : (k - 1) / 2, 1, out, s, ACT_NONE, 0.f, nullptr, ACT_NONE, cur, last ? out_scale : 1.f, last && accumulate,
+             nullptr, last ? nullptr : sn, last ? nullptr : w.a1[j + 1]);
         cur = out;
     }
 }

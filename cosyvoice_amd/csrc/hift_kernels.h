@@ -167,4 +167,14 @@ static __global__ __launch_bounds__(256) void hift_istft_kernel(const float* spe
     y[t] = fminf(fmaxf(o, -limit), limit);
 }
 
+// y[t][c] = Snake(x[t][c], alpha[c]): the operand of a ResBlock's first convolution, activated once (round 3) instead of in the prologue of every
+// tap and N-tile of that convolution (an 11-tap conv over 4 N-tiles evaluated sinf 44 times per element)
+static __global__ __launch_bounds__(256) void snake_rows_kernel(const float* x, float* y, const float* alpha, long long n4, int C) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // float4 index over [rows][C / 4]
+    if (i >= n4) return;
+    const int c = (int)((i * 4) % C);
+    const float4 v = *reinterpret_cast<const float4*>(x + i * 4), a = *reinterpret_cast<const float4*>(alpha + c);
+    *reinterpret_cast<float4*>(y + i * 4) = make_float4(snake_f(v.x, a.x), snake_f(v.y, a.y), snake_f(v.z, a.z), snake_f(v.w, a.w));
+}
+
 }  // namespace cv

@@ -58,6 +58,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     const int s0 = wave * steps / WAVES, s1 = (wave + 1) * steps / WAVES;
     const int row0 = (blockIdx.x * 4 + grp) * ROWS;
 
+    // NSP > 0 (o_proj over split-attention partials): the partials are requested BEFORE the weight rows (round 3).  vmcnt retires in issue order, so
+    // behind the weight stream the merge below could only start once the workgroup's last weight byte had landed; ahead of it, the merge and its
+    // barrier run while the weights are in flight.  Unconditional, clamped loads (a load in a divergent branch costs the compiler its vmcnt count).
+    constexpr int NQ = NSP > 0 ? NSP : 1;
+    float4 pa[NQ]; float2 ml[NQ];
+    if constexpr (NSP > 0) {
+        const int t4 = min(tid, p.K / 4 - 1);                 // thread t owns dims 4t .. 4t+3 of x (head t / 16)
+        const float* ph = p.part + (long long)(t4 >> 4) * NSP * ATTN_PART;
+#pragma unroll
+        for (int q = 0; q < NSP; ++q) {
+            pa[q] = *reinterpret_cast<const float4*>(ph + q * ATTN_PART + (t4 & 15) * 4);
+            ml[q] = *reinterpret_cast<const float2*>(ph + q * ATTN_PART + 64);
+        }
+    }
     u32x4 w[ROWS][STEPS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
@@ -99,13 +113,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
             s_new = group16_sum(qn.x * kn.x + qn.y * kn.y + qn.z * kn.z + qn.w * kn.w) * 0.125f;
         }
         if (tid * 4 < p.K) {
-            const float* ph = p.part + (long long)(tid >> 4) * NSP * ATTN_PART;
-            float4 pa[NSP]; float2 ml[NSP];
-#pragma unroll
-            for (int q = 0; q < NSP; ++q) {
-                pa[q] = *reinterpret_cast<const float4*>(ph + q * ATTN_PART + (tid & 15) * 4);
-                ml[q] = *reinterpret_cast<const float2*>(ph + q * ATTN_PART + 64);
-            }
             float M = p.qnew ? s_new : ml[0].x;
 #pragma unroll
             for (int q = 0; q < NSP; ++q) if (ml[q].y > 0.f || !p.qnew) M = fmaxf(M, ml[q].x);

@@ -268,7 +268,7 @@ def test_estimator_module_contract(lib):
     torch.testing.assert_close(x, g["out"], rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("tile,waves,kt,ks", [(0, 4, 2, 2), (1, 2, 1, 1), (2, 4, 1, 1), (3, 2, 2, 1), (4, 4, 2, 1)])
+@pytest.mark.parametrize("tile,waves,kt,ks", [(0, 4, 2, 2), (1, 2, 1, 1), (2, 4, 1, 1), (3, 2, 2, 1), (4, 4, 2, 1), (0, 4, 1, 3), (0, 4, 1, 4)])
 def test_fused_transformer_blocks_match_unfused(lib, tile, waves, kt, ks):
     """bf16 mode: the fused pipeline of the estimator's transformer blocks (flow_fused.h: LayerNorm in the GEMM prologue, bf16 Q / K / V^T /
     attention output / FF hidden between kernels, bf16-in flash attention) rounds the same operands at the same points as the unfused

@@ -70,3 +70,28 @@ def test_single_frame_and_f0_boundary(lib, tiny):
         s = torch.tanh(torch.randn(1, 1, 480 * m, generator=gen))
         torch.testing.assert_close(hift.decode(mel, s).cpu(), OH.decode(sd, cfg, mel, s), rtol=2e-4, atol=2e-4)
         torch.testing.assert_close(hift.f0_predictor(mel).cpu(), OH.f0_predictor(sd, mel), rtol=1e-4, atol=1e-3)
+
+
+def test_snake_once_and_two_sided_split_variants(lib, tiny, monkeypatch):
+    """Round 3, the two changes to the ResBlock convolutions, each against its predecessor on the same input:
+      * Snake applied once per value (elementwise pass / conv epilogue / second output) instead of in the prologue of every tap and N-tile of the consuming
+        convolution (CV_HIFT_SNAKE_ONCE=0): the same fp32 values enter the same products -> bit-identical waveform;
+      * both operands split into bf16 planes, six exact products per k on the bf16 matrix pipe (gemm_conv.h WX3) instead of the fp32 MFMA chain
+        (CV_GEMM_WX3=0): fp32-rounding distance, far inside the oracle tolerance."""
+    cfg, sd = tiny
+    hift = HiFTGenerator(sd, cfg, lib=lib)
+    gen = torch.Generator().manual_seed(12)
+    m = 9
+    mel = torch.randn(1, 80, m, generator=gen) * 2 - 5
+    s = torch.tanh(torch.randn(1, 1, 480 * m, generator=gen))
+    ref = OH.decode(sd, cfg, mel, s)
+    base = hift.decode(mel, s).cpu()
+    monkeypatch.setenv("CV_HIFT_SNAKE_ONCE", "0")
+    pro = hift.decode(mel, s).cpu()
+    assert torch.equal(base, pro)
+    monkeypatch.delenv("CV_HIFT_SNAKE_ONCE")
+    monkeypatch.setenv("CV_GEMM_WX3", "0")
+    chain = hift.decode(mel, s).cpu()
+    assert not torch.equal(base, chain)                                # the split path really ran
+    e_split, e_chain = (base - ref).abs().max().item(), (chain - ref).abs().max().item()
+    assert e_split < 2e-4 and e_chain < 2e-4 and (base - chain).abs().max().item() < 2e-5, (e_split, e_chain)

@@ -44,6 +44,17 @@ if "all" in which:
         opt(b"flow_tile", tile); opt(b"attn_waves", waves); opt(b"attn_kt", kt); opt(b"attn_ks", ks)
         mel = bench("fused tile=%d attn_waves=%d attn_kt=%d attn_ks=%d" % (tile, waves, kt, ks))
         print("    max |fused - unfused| = %.3e (mel std %.2f)" % ((mel - ref).abs().max().item(), ref.std().item()), flush=True)
+elif "attn" in which:                # round 3: key splits inside the 64-query attention workgroup (8 / 12 / 16 waves)
+    opt(b"fused", 1); opt(b"fused_tail", 0)
+    ref = None
+    for ks, kt in ((2, 1), (3, 1), (4, 1), (1, 2)):
+        opt(b"attn_ks", ks); opt(b"attn_kt", kt)
+        mel = bench("attention key splits %d (kt %d)" % (ks, kt))
+        if ref is None:
+            ref = mel
+        else:
+            print("    max |this - ks 2| = %.3e (mel std %.2f)" % ((mel - ref).abs().max().item(), ref.std().item()), flush=True)
+    opt(b"attn_ks", 2); opt(b"attn_kt", 1)
 elif "tail" in which:                # round 3: the one-launch block tail (flow_tail.h) against the five-launch block, ring depth 8 / 16
     opt(b"fused", 1); opt(b"fused_tail", 0); ref = bench("five launches per block (round 2)")
     for ring in (8, 16):

@@ -21,6 +21,22 @@ for nu in (1, 2, 4, 8):
     ms = (time.perf_counter() - t0) / 4 * 1e3
     print("flow pass over %d utterance(s): %.2f ms = %.2f ms per utterance" % (nu, ms, ms / nu), flush=True)
 
+# round 3: the one-launch block tail (flow_tail.h) against the five-launch block when 4 / 8 utterances share a pass (M = 5392 / 10784 rows)
+if len(sys.argv) > 1 and sys.argv[1] == "tail":
+    import ctypes as C
+    for nu in (1, 4, 8):
+        for tail in (0, 1):
+            flow.lib.cv_flow_set_option(flow._h, b"fused_tail", C.c_int32(tail))
+            for _ in range(2):
+                flow.inference_batch([item] * nu)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(4):
+                flow.inference_batch([item] * nu)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 4 * 1e3
+            print("nu=%d fused_tail=%d  %.2f ms = %.2f ms per utterance" % (nu, tail, ms, ms / nu), flush=True)
+    flow.lib.cv_flow_set_option(flow._h, b"fused_tail", C.c_int32(0))
+
 # tile / attention variants at 4 utterances per pass (M = 4 x 1348 rows: enough workgroups that bigger tiles may pay)
 if len(sys.argv) > 1 and sys.argv[1] == "sweep":
     import ctypes as C
