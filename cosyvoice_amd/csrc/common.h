@@ -150,6 +150,20 @@ __device__ __forceinline__ float group16_max(float v) {
     return v;
 }
 
+// Scheduling fence: the machine scheduler moves no instruction across it (no instruction is emitted).  Used where the ORDER of independent global
+// loads matters - the vector-memory counter retires in issue order, so what is requested first can be waited for first.  (An asm "memory" clobber would
+// do the same to the loads but forces register arrays that live across it into scratch.)
+__device__ __forceinline__ void order_memory() { __builtin_amdgcn_sched_barrier(0); }
+
+// LDS hand-off between the lanes of ONE wave (a region no other wave touches): a wave's DS operations execute in issue order, so all that is needed
+// is that every lane has issued its writes and that the compiler keeps the order - a wave barrier, no s_barrier, no drain of the vector-memory counter
+// (loads requested before the hand-off stay in flight).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // block-wide sum for blocks of up to 16 waves; `red` is an LDS scratch of >= 16 floats.
 __device__ __forceinline__ float block_sum(float v, float* red) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = (blockDim.x + 63) >> 6;

@@ -76,9 +76,19 @@ struct cv_flow {
     std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
     std::map<std::tuple<int, int, int>, int> seen;
     hipStream_t own_stream = nullptr;
+    // Round 3, est_streams = 2: the estimator's batch rows as TWO launch chains (rows only meet in the CFG combine of an Euler step) - the second half of
+    // the batch rows is forked onto side_stream for every estimator evaluation and joined before the Euler update (graph edges inside a captured solve).
+    // Same kernels on the same rows: bit-identical to one chain (tests/test_flow.py).  Measured on MI355X (profiles/r3_flow_two_stream_ab.txt): an isolated
+    // pass gains 1 % at batch 1 (38.8 -> 38.4 ms), 7 - 10 % for 2 - 8 utterances per pass, but a hipGraph with parallel branches leaves the runtime's
+    // single-batch replay path: hipGraphLaunch then costs ~40 ms of HOST time per solve (bench step 178 -> 218 ms once nothing overlaps it).  Off by default.
+    int est_streams = 1;
+    hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<float> host_t;
     ~cv_flow() {
         for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
         if (own_stream) (void)hipStreamDestroy(own_stream);
     }
 };
@@ -406,18 +416,22 @@ static void attn_flow(const bf16_t* qk, int ld, int inner, const bf16_t* vt, lon
 // s_in: packed [2][T][4*mel]; t_row: which row of the time tables; t_shared: both CFG rows use the same row;
 // result in s_out [2][T][mel] (not masked).  Buffer discipline: a stage never writes the buffer it reads its input from
 // (res_conv re-reads the stage input after block1/block2), outputs ping-pong between s_a and s_c, s_b is scratch.
-static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bool t_shared, int streaming, hipStream_t s, int nz = 2) {
+// nz batch rows starting at batch row b0 of the packed workspaces (b0 > 0: the second half of a two-stream evaluation, estimator_eval)
+static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bool t_shared, int streaming, hipStream_t s, int nz = 2, int b0 = 0) {
     const auto& c = m->cfg; const int C = c.est_ch, H = c.est_heads, inner = H * 64; const long long R = (long long)nz * T;
-    float* pp[2] = {m->s_a.as<float>(), m->s_c.as<float>()};
-    float* xb = m->s_b.as<float>(); float* n = m->s_n.as<float>(); float* qkv = m->s_qkv.as<float>();
-    float* att = m->s_att.as<float>(); float* ff = m->s_ff.as<float>(); float* skip = m->s_skip.as<float>(); float* cat = m->s_cat.as<float>();
+    const long long r0 = (long long)b0 * T;              // first row of this call in every [batch rows x T][...] workspace
+    float* pp[2] = {m->s_a.as<float>() + r0 * C, m->s_c.as<float>() + r0 * C};
+    float* xb = m->s_b.as<float>() + r0 * C; float* n = m->s_n.as<float>() + r0 * C; float* qkv = m->s_qkv.as<float>() + r0 * 3 * inner;
+    float* att = m->s_att.as<float>() + r0 * inner; float* ff = m->s_ff.as<float>() + r0 * 4 * C; float* skip = m->s_skip.as<float>() + r0 * C;
+    float* cat = m->s_cat.as<float>() + r0 * 2 * C;
+    const int* klen = m->cur_klen ? m->cur_klen + b0 : nullptr;
     const int chunk = streaming ? 2 * c.chunk : 0;
-    const float* cur = m->s_in.as<float>();
+    const float* cur = m->s_in.as<float>() + r0 * 4 * c.mel;
     int flip = 0;
     const int nst = (int)m->stages.size();
     for (int si = 0; si < nst; ++si) {
         const StageW& st = m->stages[si];
-        const float* tm = m->t_mlp.as<float>() + ((size_t)si * t_rows_total + t_row) * C;
+        const float* tm = m->t_mlp.as<float>() + ((size_t)si * t_rows_total + t_row + (t_shared ? 0 : b0)) * C;
         const long long rpb = t_shared ? R : T;          // rows per time-embedding row
         float* x = pp[flip];                             // stage output (cur never aliases it)
         // CausalResnetBlock1D (decoder.py:65-85 + matcha ResnetBlock1D): block1 -> + mlp(t) -> block2 -> + res_conv(x)
@@ -430,18 +444,19 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
         for (size_t ti = 0; ti < st.tf.size(); ++ti) {      // matcha BasicTransformerBlock (self-attention + exact-erf GELU feed-forward)
             const TBlockW& t = st.tf[ti];
             if (fused && m->fused_tail && t.tail) {   // flow_tail.h: LN + QKV once per stage, then attention + ONE row-band launch per block
-                bf16_t* qk = m->h_qk.as<bf16_t>(); bf16_t* vt = m->h_vt.as<bf16_t>(); bf16_t* ab = m->h_att.as<bf16_t>();
                 const long long vt_batch = (long long)inner * m->vt_pitch;
+                bf16_t* qk = m->h_qk.as<bf16_t>() + r0 * 2 * inner; bf16_t* vt = m->h_vt.as<bf16_t>() + b0 * vt_batch; bf16_t* ab = m->h_att.as<bf16_t>() + r0 * inner;
                 if (ti == 0) ln_gemm_bf16(t.qkv, &t.norm1, 1e-5f, x, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
-                attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, m->cur_klen);
+                attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, klen);
                 flow_tail(t, ti + 1 < st.tf.size() ? &st.tf[ti + 1] : nullptr, ab, inner, x, C, (int)R, qk, vt, vt_batch, m->vt_pitch, T, m->tail_ring, s);
                 continue;
             }
             if (fused) {                      // flow_fused.h: 5 launches, bf16 activations, same rounding points as the path below
-                bf16_t* qk = m->h_qk.as<bf16_t>(); bf16_t* vt = m->h_vt.as<bf16_t>(); bf16_t* ab = m->h_att.as<bf16_t>(); bf16_t* fb = m->h_ff.as<bf16_t>();
                 const long long vt_batch = (long long)inner * m->vt_pitch;
+                bf16_t* qk = m->h_qk.as<bf16_t>() + r0 * 2 * inner; bf16_t* vt = m->h_vt.as<bf16_t>() + b0 * vt_batch; bf16_t* ab = m->h_att.as<bf16_t>() + r0 * inner;
+                bf16_t* fb = m->h_ff.as<bf16_t>() + r0 * 4 * C;
                 ln_gemm_bf16(t.qkv, &t.norm1, 1e-5f, x, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
-                attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, m->cur_klen);
+                attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, klen);
                 gemm_bf16_res(t.out, ab, inner, (int)R, x, x, s);
                 ln_gemm_bf16(t.ff1, &t.norm3, 1e-5f, x, (int)R, ACT_GELU_ERF, fb, 4 * C, 4 * C, nullptr, 0, 0, 0, s);
                 gemm_bf16_res(t.ff2, fb, 4 * C, (int)R, x, x, s);
@@ -456,7 +471,7 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
             at.o = att; at.o_batch = (long long)T * inner; at.o_row = inner; at.o_head = 64;
             at.B = nz; at.H = H; at.kv_group = 1; at.Tq = T; at.Tk = T; at.scale = 0.125f;
             at.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; at.chunk = chunk; at.rel_bd = nullptr;
-            at.bf16 = tl_bf16_mfma; at.klen = m->cur_klen;
+            at.bf16 = tl_bf16_mfma; at.klen = klen;
             attention(at, s);
             lin_cl(t.out, att, R, x, ACT_NONE, x, s);
             ln_rows(t.norm3, x, n, R, C, 1e-5f, s);
@@ -482,7 +497,21 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
     float* y = pp[flip];
     conv_cl(m->final_conv, cur, T, T, nz, 2, 1, y, ACT_NONE, 0.f, nullptr, s);
     ln_rows(m->final_ln, y, xb, R, C, 1e-5f, s, ACT_MISH);
-    conv_cl(m->final_proj, xb, T, T, nz, 0, 1, m->s_out.as<float>(), ACT_NONE, 0.f, nullptr, s);
+    conv_cl(m->final_proj, xb, T, T, nz, 0, 1, m->s_out.as<float>() + r0 * c.mel, ACT_NONE, 0.f, nullptr, s);
+}
+
+// One estimator evaluation over nz batch rows: with est_streams = 2 (and an even nz) the two halves of the batch rows run as independent launch chains
+// on `s` and on the handle's side stream, forked and joined through events (graph edges when `s` is being captured).
+static void estimator_eval(cv_flow* m, int T, int t_row, int t_rows_total, bool t_shared, int streaming, hipStream_t s, int nz = 2) {
+    if (m->est_streams < 2 || nz < 2 || (nz & 1)) { estimator_forward(m, T, t_row, t_rows_total, t_shared, streaming, s, nz, 0); return; }
+    if (!m->side_stream) {
+        CV_HIP(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+        CV_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming)); CV_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    }
+    CV_HIP(hipEventRecord(m->ev_fork, s)); CV_HIP(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
+    estimator_forward(m, T, t_row, t_rows_total, t_shared, streaming, s, nz / 2, 0);
+    estimator_forward(m, T, t_row, t_rows_total, t_shared, streaming, m->side_stream, nz / 2, nz / 2);
+    CV_HIP(hipEventRecord(m->ev_join, m->side_stream)); CV_HIP(hipStreamWaitEvent(s, m->ev_join, 0));
 }
 
 
@@ -642,7 +671,7 @@ static void solve_euler(cv_flow* m, float* x /*[nu][T][mel] in/out*/, const floa
         if (dit) dit_time_embed(m, n_steps, s); else time_embed(m, n_steps, s);
         for (int st = 0; st < n_steps; ++st) {
             hipLaunchKernelGGL(pack_est_input_kernel, dim3(nblk(2 * n * 4)), dim3(256), 0, s, x, mu, spk, cond, m->s_in.as<float>(), T, c.mel, 1, nu);
-            if (dit) dit_forward(m, T, st, n_steps, true, streaming, s, 2 * nu); else estimator_forward(m, T, st, n_steps, true, streaming, s, 2 * nu);
+            if (dit) dit_forward(m, T, st, n_steps, true, streaming, s, 2 * nu); else estimator_eval(m, T, st, n_steps, true, streaming, s, 2 * nu);
             hipLaunchKernelGGL(cfg_euler_kernel, dim3(nblk(n)), dim3(256), 0, s, x, m->s_out.as<float>(), n, dts[st], c.cfg_rate);
         }
     };
@@ -685,6 +714,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "attn_ks") { CV_CHECK(value >= 1 && value <= 4, "attn_ks must be 1 .. 4"); m->attn_ks = value; drop_graphs(m); }
         else if (std::string(name) == "attn_kt") { CV_CHECK(value == 1 || value == 2, "attn_kt must be 1 or 2"); m->attn_kt = value; drop_graphs(m); }
         else if (std::string(name) == "attn_waves") { CV_CHECK(value == 2 || value == 4, "attn_waves must be 2 or 4"); m->attn_waves = value; drop_graphs(m); }
+        else if (std::string(name) == "est_streams") { CV_CHECK(value == 1 || value == 2, "est_streams must be 1 or 2"); m->est_streams = value; drop_graphs(m); }
         else if (std::string(name) == "fused_tail") { m->fused_tail = value != 0; drop_graphs(m); }
         else if (std::string(name) == "tail_ring") { m->tail_ring = value == 16 ? 16 : 8; drop_graphs(m); }      // bf16 mode: one row-band launch after each attention (flow_tail.h) on / off
         else if (std::string(name) == "fused") { m->fused = value != 0; drop_graphs(m); }              // bf16 mode: fused transformer blocks (flow_fused.h) on / off
@@ -719,7 +749,7 @@ int cv_flow_estimator(cv_flow* m, const float* x, const float* mask, const float
         CV_HIP(hipMemcpyAsync(m->t_val.p, t, 8, hipMemcpyDeviceToDevice, s));
         if (dit) dit_time_embed(m, 2, s); else time_embed(m, 2, s);
         hipLaunchKernelGGL(pack_est_input_kernel, dim3(nblk(2LL * T * 4 * c.mel)), dim3(256), 0, s, x, mu, spks, cond, m->s_in.as<float>(), T, c.mel, 0, 1);
-        if (dit) dit_forward(m, T, 0, 2, false, streaming, s); else estimator_forward(m, T, 0, 2, false, streaming, s);
+        if (dit) dit_forward(m, T, 0, 2, false, streaming, s); else estimator_eval(m, T, 0, 2, false, streaming, s);
         // `mask` must be all ones for the in-kernel (index-computed) attention masks to be exact; it is applied to the output
         hipLaunchKernelGGL(to_channel_first_kernel, dim3(nblk(2LL * T * c.mel)), dim3(256), 0, s, m->s_out.as<float>(), out, 2, T, c.mel, 0, mask);
     });

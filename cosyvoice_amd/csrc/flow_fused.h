@@ -25,6 +25,7 @@ struct FlowGemmArgs {
     bf16_t* out; int ldo; int n_row;              // OMODE 0: columns [0, n_row) -> out[m][n] (row-major bf16)
     bf16_t* outT; long long t_batch; int ldt; int rows_per_batch;   // columns [n_row, N) -> outT[m / rpb][n - n_row][perm(m % rpb)]
     float* C; int ldc; const float* res;          // OMODE 1: C[m][n] = acc + bias (+ res[m][n]), fp32
+    long long* dbg;                               // dev tool (tools/ubench/flow_gemm_probe.hip): clock64() of thread 0 at the phase boundaries, 8 slots per workgroup; null in production
 };
 
 // key (time) index -> column of the transposed V tile: inside every 32-key block, key 16 s + 4 g + r sits at column 8 g + 4 s + r, which
@@ -47,6 +48,10 @@ __global__ __launch_bounds__(256) void flow_gemm_kernel(FlowGemmArgs p) {
     const int bl = xcd_remap((int)blockIdx.x, (int)gridDim.x);        // an XCD walks the N tiles of a band of rows: A crosses the fabric once
     const int m0 = (bl / ntn) * BM, n0 = (bl % ntn) * BN;
     const int nchunks = (p.K + KC - 1) / KC;
+    long long* dbg = p.dbg ? p.dbg + (long long)blockIdx.x * 8 : nullptr;
+    int dn = 0;
+    auto stamp = [&]() { if (dbg && tid == 0) dbg[dn++] = clock64(); };
+    stamp();
     // V^T section (OMODE 0): decided per 16-column MFMA tile (wave-uniform), so that n_row only has to be a multiple of 16
     bool tr[TN];
 #pragma unroll
@@ -162,7 +167,9 @@ __global__ __launch_bounds__(256) void flow_gemm_kernel(FlowGemmArgs p) {
                 *reinterpret_cast<uint2*>(&As[(grp + 16 * r) * LDK + 2 * sub + 32 * j]) = make_uint2(pack_bf16x2(x[r][j].x, x[r][j].y), pack_bf16x2(x[r][j].z, x[r][j].w));
         }
         store_w();
+        stamp();
         __syncthreads();
+        stamp();
         compute(p.K / 32);
     } else {
         // K streamed in chunks of 256: the next chunk's loads are in flight under the MFMAs of the current one (register prefetch)
@@ -174,7 +181,9 @@ __global__ __launch_bounds__(256) void flow_gemm_kernel(FlowGemmArgs p) {
             compute(min(KC, p.K - c * KC) / 32);
             __syncthreads();
         }
+        stamp(); stamp();
     }
+    stamp();
 
     // ---- epilogue
     if constexpr (OMODE == 1) {
@@ -226,6 +235,7 @@ __global__ __launch_bounds__(256) void flow_gemm_kernel(FlowGemmArgs p) {
             }
         }
     }
+    stamp();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------

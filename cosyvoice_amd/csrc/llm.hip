@@ -6,6 +6,8 @@
 //          it is replayed once per token; the loop state lives in device memory (DecodeState), so no host sync is
 //          needed per token — tokens are read back in chunks.
 #include <vector>
+#include <memory>
+#include <map>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -53,6 +55,12 @@ struct cv_llm {
         std::vector<DecodeState> host_state; std::vector<int> host_tokens; std::vector<SampleParams> host_sp;
         hipGraphExec_t graph = nullptr; hipStream_t graph_stream = nullptr; int graph_nb = 0;
     } bt;
+    // Round 3: fragment-ordered copies of the matrices for the batched decode (skinny_pk_kernel, llm_batch_kernels.h), made on the device the first time
+    // the batch path is used: [row tile][k tile][lane][8 bf16], so that one wave load is 1 KB contiguous.  Keyed by the row-major tensor's address.
+    // +0.73 GB of HBM for Qwen2-0.5B (the 288 GB of an MI355X are what the batched path is sized for).  Option "batch_packed" (default 1).
+    std::map<const void*, std::unique_ptr<DevBuf>> packed;
+    int batch_packed = [] { const char* e = getenv("CV_BATCH_PACKED"); return (e && e[0] == '0') ? 0 : 1; }();        // env: A/B knob for bench runs
+    const bf16_t* pk(const bf16_t* w) const { if (!batch_packed) return nullptr; auto it = packed.find(w); return it == packed.end() ? nullptr : it->second->as<bf16_t>(); }
     size_t slot_cache() const { return layer_cache() * cfg.layers; }
     // optional per-kernel HIP-event timing of one eager decode step (bench.py roofline)
     bool profiling = false; std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
@@ -358,6 +366,21 @@ static void batch_begin(cv_llm* m, int nb, hipStream_t s) {
     CV_HIP(hipMemcpyAsync(b.state.p, b.host_state.data(), (size_t)nb * sizeof(DecodeState), hipMemcpyHostToDevice, s));
     CV_HIP(hipStreamSynchronize(s));
     if (b.graph && b.graph_nb != nb) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
+    if (m->batch_packed && m->packed.empty()) {                                   // fragment-ordered weight copies, once per handle
+        auto pack = [&](const bf16_t* w, long long N, long long K) {
+            if (!w || K % 32 != 0 || m->packed.count(w)) return;
+            const long long pieces = ((N + 15) / 16) * (K / 32) * 64;
+            auto buf = std::make_unique<DevBuf>(); buf->ensure((size_t)pieces * 16);
+            bf16_t* dst = buf->as<bf16_t>();
+            hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, w, dst, (int)N, (int)K);
+            m->packed[w] = std::move(buf);
+        };
+        const long long H = c.hidden, A = c.heads * 64;
+        pack(m->head_w, m->V, H);
+        for (const auto& L : m->layers) { pack(L.wqkv, m->qkv_dim, H); pack(L.wo, H, A); pack(L.wgu, 2LL * c.inter, H); pack(L.wdown, H, c.inter); }
+        CV_HIP(hipStreamSynchronize(s));
+        CV_HIP(hipGetLastError());
+    }
 }
 
 static void batch_prefill(cv_llm* m, int slot, const float* lm_input, int L0, const cv_sampling* sp, hipStream_t s) {
@@ -416,8 +439,20 @@ static void batch_prefill_many(cv_llm* m, int n, const int32_t* slots, const flo
 }
 
 // skinny GEMM of the batched decode (llm_batch_kernels.h): rt = row tiles (16 rows) per workgroup, ksplit = K ranges across workgroups
-static void skinny(const SkinnyArgs& a, int rt, hipStream_t s) {
+static void skinny(const SkinnyArgs& a, int rt, hipStream_t s, const bf16_t* wp = nullptr) {
     const int tiles = a.K / 32 / a.ksplit, row_tiles = (a.N + 15) / 16;
+    if (wp && tiles >= 4 && (tiles + 3) / 4 <= 7) {          // fragment-ordered weights + wave-private activation staging (round 3); same arithmetic, same bits
+        CV_CHECK(a.K % (32 * a.ksplit) == 0 && (a.mode == 0 || a.N % 4 == 0), "skinny: K range must be a multiple of 32");
+        CV_CHECK(!(a.gamma && a.ksplit != 1) && (a.mode == 2) == (a.ksplit > 1), "skinny: split-K workgroups leave raw partials (mode 2), the fused norm needs the whole row");
+        SkinnyArgs b = a; b.W = wp;
+        const dim3 grid(((row_tiles + rt - 1) / rt) * a.ksplit);
+        const bool deep = (tiles + 3) / 4 > 5;
+        if (rt == 1) hipLaunchKernelGGL((skinny_pk_kernel<1, 7>), grid, dim3(256), 0, s, b);
+        else if (rt == 4) { CV_CHECK(deep || tiles <= 28, "skinny: four row tiles per workgroup are for K ranges of up to 28 tiles"); hipLaunchKernelGGL((skinny_pk_kernel<4, 7>), grid, dim3(256), 0, s, b); }
+        else if (deep) hipLaunchKernelGGL((skinny_pk_kernel<2, 7>), grid, dim3(256), 0, s, b);
+        else hipLaunchKernelGGL((skinny_pk_kernel<2, 5>), grid, dim3(256), 0, s, b);
+        return;
+    }
     CV_CHECK(a.K % (32 * a.ksplit) == 0 && tiles >= 1 && (tiles + 3) / 4 <= 7 && (a.mode == 0 || a.N % 4 == 0), "skinny: K range must be a multiple of 32 and at most 28 tiles per workgroup");
     CV_CHECK(!(a.gamma && a.ksplit != 1) && (a.mode == 2) == (a.ksplit > 1), "skinny: split-K workgroups leave raw partials (mode 2), the fused norm needs the whole row");
     const dim3 grid(((row_tiles + rt - 1) / rt) * a.ksplit);
@@ -518,7 +553,7 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
     // 2 row tiles per workgroup for the two wide GEMMs (gate/up: 304 workgroups, head: 206); 3 (203 / 137 workgroups, at most 3 tiles per CU instead
     // of 4 on 48 CUs) measured the same step time (profiles/r2_batch_decode_ab.txt): the launch is not bound by the busiest CU's MFMA share
     const int wide_rt = 2;
-    skinny(SkinnyArgs{m->head_w, m->head_b, h, H, logits, V, (int)V, c.hidden, m->norm, c.rms_eps, nullptr, 0, 0, nb, 1}, wide_rt, s);
+    skinny(SkinnyArgs{m->head_w, m->head_b, h, H, logits, V, (int)V, c.hidden, m->norm, c.rms_eps, nullptr, 0, 0, nb, 1}, wide_rt, s, m->pk(m->head_w));
     {                                                             // every slot's sampler + embedding of the sampled token: one launch, one workgroup per slot
         SampleArgs sa{};
         sa.logits = logits; sa.V = (int)V; sa.sp = b.sparams.as<SampleParams>(); sa.uniforms = b.uniforms.as<float>();
@@ -529,20 +564,21 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
     }
     for (int l = 0; l < c.layers; ++l) {
         const auto& L = m->layers[l];
-        skinny(SkinnyArgs{L.wqkv, L.bqkv, h, H, qkv, Q, (int)Q, c.hidden, L.ln1, c.rms_eps, nullptr, 0, 0, nb, 1}, 1, s);
+        skinny(SkinnyArgs{L.wqkv, L.bqkv, h, H, qkv, Q, (int)Q, c.hidden, L.ln1, c.rms_eps, nullptr, 0, 0, nb, 1}, 1, s, m->pk(L.wqkv));
         AttnDecodeBatchArgs ad{qkv, Q, b.kcache.as<float>() + m->layer_cache() * l, b.vcache.as<float>() + m->layer_cache() * l, (long long)m->slot_cache(),
                                m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st, att, A};
         launch_attn_batch(ad, c.heads, nb, s);
-        skinny(SkinnyArgs{L.wo, nullptr, att, A, h, H, c.hidden, (int)A, nullptr, 0.f, h, H, 0, nb, 1}, 1, s);
-        skinny(SkinnyArgs{L.wgu, nullptr, h, H, act, I, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 0, 1, nb, 1}, wide_rt, s);
+        skinny(SkinnyArgs{L.wo, nullptr, att, A, h, H, c.hidden, (int)A, nullptr, 0.f, h, H, 0, nb, 1}, 1, s, m->pk(L.wo));
+        // packed: four row tiles per workgroup (152 workgroups) measured 7.3 us against 8.0 for two and 8.7 for one (profiles/r3_skinny_probe.txt)
+        skinny(SkinnyArgs{L.wgu, nullptr, h, H, act, I, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 0, 1, nb, 1}, m->pk(L.wgu) ? 4 : wide_rt, s, m->pk(L.wgu));
         if (deep_down) {                                          // one launch: 16-wave workgroups over the whole K (skinny_deep_kernel)
             hipLaunchKernelGGL((skinny_deep_kernel<16, 5>), dim3((unsigned)((H + 15) / 16)), dim3(1024), 0, s,
                                SkinnyArgs{L.wdown, nullptr, act, I, h, H, c.hidden, c.inter, nullptr, 0.f, h, H, 0, nb, 1});
         } else if (ks > 1) {
-            skinny(SkinnyArgs{L.wdown, nullptr, act, I, dpart, H, c.hidden, c.inter, nullptr, 0.f, nullptr, 0, 2, nb, ks}, 2, s);
+            skinny(SkinnyArgs{L.wdown, nullptr, act, I, dpart, H, c.hidden, c.inter, nullptr, 0.f, nullptr, 0, 2, nb, ks}, 2, s, m->pk(L.wdown));
             hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((nb * H / 4 + 255) / 256)), dim3(256), 0, s, dpart, ks, nb, c.hidden, h, H, h, H);
         } else {
-            skinny(SkinnyArgs{L.wdown, nullptr, act, I, h, H, c.hidden, c.inter, nullptr, 0.f, h, H, 0, nb, 1}, 2, s);
+            skinny(SkinnyArgs{L.wdown, nullptr, act, I, h, H, c.hidden, c.inter, nullptr, 0.f, h, H, 0, nb, 1}, 2, s, m->pk(L.wdown));
         }
     }
     hipLaunchKernelGGL(advance_pos_batch_kernel, dim3(1), dim3(64), 0, s, st, nb);
@@ -614,6 +650,9 @@ int cv_llm_set_option(cv_llm* m, const char* name, int32_t value) {
         else if (std::string(name) == "attn_splits") {       // key-range slices per head in the decode attention (4, 8 or 16)
             CV_CHECK(value == 4 || value == 8 || value == 16, "attn_splits must be 4, 8 or 16");
             m->attn_splits = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+        }
+        else if (std::string(name) == "batch_packed") {      // batched decode on the fragment-ordered weight copies (skinny_pk_kernel) or on the row-major tensors (round 2)
+            m->batch_packed = value != 0; if (m->bt.graph) { (void)hipGraphExecDestroy(m->bt.graph); m->bt.graph = nullptr; }
         }
         else if (std::string(name) == "batch_fp8") {         // batched decode on the fp8 copies of the weights (needs the .f8 / .f8s tensors)
             CV_CHECK(value == 0 || m->have_fp8, "batch_fp8: the fp8 tensors were not registered");

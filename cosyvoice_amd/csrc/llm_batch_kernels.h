@@ -36,6 +36,7 @@ struct SkinnyArgs {
     const float* res; long long ldres;
     int mode;                                 // 0: acc + bias + res   1: rows interleaved (gate_j, up_j): silu(gate) * up   2: raw split-K partial
     int nb, ksplit;
+    long long* dbg;                           // dev tool (tools/ubench/skinny_probe.hip): clock64() of thread 0 at the phase boundaries, 8 slots per workgroup; null in production
 };
 
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
@@ -86,6 +87,10 @@ __global__ __launch_bounds__(NW * 64) void skinny_mfma_kernel(SkinnyArgs p) {
     const int t0 = wave * tiles / NW, t1 = (wave + 1) * tiles / NW;
     const int kbase = ks * krange + t0 * 32 + g * 8;
     const int n_base = rg * RT * 16;
+    long long* dbg = p.dbg ? p.dbg + (long long)blockIdx.x * 8 : nullptr;
+    int dn = 0;
+    auto stamp = [&]() { if (dbg && tid == 0) dbg[dn++] = clock64(); };
+    stamp();
 
     // every load of the wave is requested up front, tile by tile in the order the MFMA loop consumes them (W, X, gamma of tile 0, then tile 1 ...):
     // the counted vmcnt waits the compiler places in front of each tile's MFMAs then let tile t compute while tiles t+1 .. are still in flight
@@ -140,6 +145,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_mfma_kernel(SkinnyArgs p) {
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(v8bf, h1), a, 0, 0, 0);
                     acc[rt] = a;
                 }
+                if (t == 0) stamp();
                 continue;
             }
 #pragma unroll
@@ -165,7 +171,9 @@ __global__ __launch_bounds__(NW * 64) void skinny_mfma_kernel(SkinnyArgs p) {
     // split-K over the 4 waves, combined in fixed order; wave rt finishes row tile rt  [4 waves][RT][64 lanes][4]
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<float4*>(&red[((wave * RT + rt) * 64 + lane) * 4]) = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
+    stamp();
     __syncthreads();
+    stamp();
     if (wave >= RT) return;
     const int rt = wave;
     float4 v = *reinterpret_cast<const float4*>(&red[(rt * 64 + lane) * 4]);
@@ -202,6 +210,163 @@ __global__ __launch_bounds__(NW * 64) void skinny_mfma_kernel(SkinnyArgs p) {
                 p.y[(long long)c * p.ldy + n + i] = o;
             }
     }
+    stamp();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 3: the same skinny GEMM with both operands fetched as WHOLE cache lines (skinny_pk_kernel).
+//
+// What bound skinny_mfma_kernel (tools/ubench/skinny_probe.hip, profiles/r3_skinny_probe.txt): not HBM - the launch takes as long with the weights
+// L2-warm - but the number of cache-line requests a CU's vector memory pipe has to walk.  With row-major operands a lane's fragment is 16 bytes of ITS
+// row, so one wave load touches 16 rows = 16 half-used lines for the weights and 16 more for each half of the activations: ~700 line requests per
+// wave for 28 KB of payload, and the first k-tile of a workgroup was multiplied 8 900 clocks after entry.  Here
+//   * the weights are read from a FRAGMENT-ORDERED copy (pack_frag_kernel, made once per matrix when the batch path is first used):
+//     [row tile][k tile][lane][8 bf16] - one wave load = 1 KB contiguous, a wave's k range = one contiguous run;
+//   * each wave fetches the activations of ITS k range row by row (one coalesced 16-byte-per-lane load per sequence: 896 B contiguous) into a wave-
+//     private LDS slab and reads its B fragments from there; gamma likewise.  No workgroup barrier is involved (a wave's DS operations execute in
+//     order; wave_lds_sync only pins the compiler), which is what made the round-2 LDS staging lose.
+// Same products in the same order as skinny_mfma_kernel<.., X3 = true>: bit-identical output (tests/test_zz_llm_batch.py runs both).
+// ---------------------------------------------------------------------------------------------------------------------------------
+// W [N][K] row-major bf16 -> Wp [ceil(N / 16)][K / 32][64 lanes][8]: lane l = 16 g + c holds W[16 R + c][32 t + 8 g .. + 7] (rows >= N: zeros)
+static __global__ __launch_bounds__(256) void pack_frag_kernel(const bf16_t* W, bf16_t* Wp, int N, int K) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;           // one 16-byte piece each
+    const int tilesK = K / 32;
+    const long long pieces = (long long)((N + 15) / 16) * tilesK * 64;
+    if (i >= pieces) return;
+    const int lane = (int)(i & 63), g = lane >> 4, c = lane & 15;
+    const long long frag = i >> 6;
+    const int t = (int)(frag % tilesK), row = (int)(frag / tilesK) * 16 + c;
+    u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+    if (row < N) v = *reinterpret_cast<const u32x4*>(W + (long long)row * K + t * 32 + g * 8);
+    *reinterpret_cast<u32x4*>(Wp + i * 8) = v;
+}
+
+template <int RT, int KTW, int NW = 4>
+__global__ __launch_bounds__(NW * 64) CV_WAVES_PER_EU(1, 2) void skinny_pk_kernel(SkinnyArgs p) {          // p.W = the fragment-ordered copy
+    static_assert(RT >= 1 && RT <= 4 && RT <= NW && KTW <= 8, "one row tile per combining wave; a wave's k range is at most 256 columns (one 16-byte piece per lane)");
+    constexpr int XP = KTW * 32 + 4;                                                  // floats per staged activation row (+4: rows start 16 bytes apart in the banks)
+    __shared__ __attribute__((aligned(16))) float red[NW * RT * 256];
+    __shared__ float ssq[NW][16];
+    __shared__ __attribute__((aligned(16))) float xs[NW][16 * XP];
+    __shared__ __attribute__((aligned(16))) float gs[NW][KTW * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int ks = blockIdx.x % p.ksplit, rg = blockIdx.x / p.ksplit;
+    const int tilesK = p.K / 32, tiles = tilesK / p.ksplit;
+    const int t0 = wave * tiles / NW, t1 = (wave + 1) * tiles / NW, nt = t1 - t0;       // nt >= 1 (host check)
+    const int kt0 = ks * tiles + t0;                                                  // first k tile of this wave in the whole K
+    const int n_base = rg * RT * 16, row_tiles = (p.N + 15) / 16;
+    long long* dbg = p.dbg ? p.dbg + (long long)blockIdx.x * 8 : nullptr;
+    int dn = 0;
+    auto stamp = [&]() { if (dbg && tid == 0) dbg[dn++] = clock64(); };
+    stamp();
+
+    // ---- activations and gamma of the wave's k range FIRST (vmcnt retires in order: what is requested behind the weights waits for all of them)
+    const int kx = kt0 * 32 + min(4 * lane, nt * 32 - 4);                             // lanes beyond the range re-read its last piece (not staged)
+    // (16 named registers, not an array: with the scheduling fence below an array stays in scratch memory on this compiler)
+#define CV_XROW(b) const float4 xr##b = *reinterpret_cast<const float4*>(p.x + (long long)min(b, p.nb - 1) * p.ldx + kx);   /* rows >= nb repeat the last sequence (never stored) */
+    CV_XROW(0) CV_XROW(1) CV_XROW(2) CV_XROW(3) CV_XROW(4) CV_XROW(5) CV_XROW(6) CV_XROW(7) CV_XROW(8) CV_XROW(9) CV_XROW(10) CV_XROW(11) CV_XROW(12) CV_XROW(13) CV_XROW(14) CV_XROW(15)
+#undef CV_XROW
+    const float4 gr = *reinterpret_cast<const float4*>((p.gamma ? p.gamma : p.x) + kx);           // unconditional: a load in a branch splits the block the scheduler orders
+    order_memory();                                                                   // keep these requests AHEAD of the weight stream (the scheduler would sink them behind it)
+    // ---- the weight fragments: one contiguous run per row tile
+    u32x4 w[RT][KTW];
+    const bf16_t* wr[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) wr[rt] = p.W + (((long long)min(rg * RT + rt, row_tiles - 1) * tilesK + kt0) * 64 + lane) * 8;
+#pragma unroll
+    for (int t = 0; t < KTW; ++t) {                                                   // tile by tile, in the order the MFMA loop consumes them
+        const bool ok = t < nt;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr[rt] + (ok ? t : 0) * 512));
+            if (!ok) v = (u32x4){0u, 0u, 0u, 0u};
+            w[rt][t] = v;
+        }
+    }
+    // ---- stage the activations (the weights stay in flight)
+    if (4 * lane < nt * 32) {
+#define CV_XST(b) *reinterpret_cast<float4*>(&xs[wave][b * XP + 4 * lane]) = xr##b;
+        CV_XST(0) CV_XST(1) CV_XST(2) CV_XST(3) CV_XST(4) CV_XST(5) CV_XST(6) CV_XST(7) CV_XST(8) CV_XST(9) CV_XST(10) CV_XST(11) CV_XST(12) CV_XST(13) CV_XST(14) CV_XST(15)
+#undef CV_XST
+        *reinterpret_cast<float4*>(&gs[wave][4 * lane]) = gr;
+    }
+    wave_lds_sync();
+
+    float ss = 0.f;
+    v4f acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < KTW; ++t) {
+        if (t < nt) {                                                   // wave-uniform
+            float4 a4 = *reinterpret_cast<const float4*>(&xs[wave][c * XP + t * 32 + g * 8]);
+            float4 b4 = *reinterpret_cast<const float4*>(&xs[wave][c * XP + t * 32 + g * 8 + 4]);
+            if (p.gamma) {
+                const float4 ga = *reinterpret_cast<const float4*>(&gs[wave][t * 32 + g * 8]), gb = *reinterpret_cast<const float4*>(&gs[wave][t * 32 + g * 8 + 4]);
+                ss += a4.x * a4.x + a4.y * a4.y + a4.z * a4.z + a4.w * a4.w + b4.x * b4.x + b4.y * b4.y + b4.z * b4.z + b4.w * b4.w;
+                a4.x *= ga.x; a4.y *= ga.y; a4.z *= ga.z; a4.w *= ga.w;
+                b4.x *= gb.x; b4.y *= gb.y; b4.z *= gb.z; b4.w *= gb.w;
+            }
+            u32x4 h1, h2, h3;
+            split3_bf16(a4, b4, h1, h2, h3);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {                           // smallest term first (as skinny_mfma_kernel)
+                const v8bf wf = __builtin_bit_cast(v8bf, w[rt][t]);
+                v4f a = acc[rt];
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(v8bf, h3), a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(v8bf, h2), a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(v8bf, h1), a, 0, 0, 0);
+                acc[rt] = a;
+            }
+            if (t == 0) stamp();
+        }
+    }
+    if (p.gamma) {
+        ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);            // over the 4 k-slot groups of the wave
+        if (g == 0) ssq[wave][c] = ss;
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<float4*>(&red[((wave * RT + rt) * 64 + lane) * 4]) = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
+    stamp();
+    __syncthreads();
+    stamp();
+    if (wave >= RT) return;
+    const int rt = wave;
+    float4 v = *reinterpret_cast<const float4*>(&red[(rt * 64 + lane) * 4]);
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) {
+        const float4 o = *reinterpret_cast<const float4*>(&red[((ww * RT + rt) * 64 + lane) * 4]);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    if (p.gamma) {
+        float tot = (ssq[0][c] + ssq[1][c]) + (ssq[2][c] + ssq[3][c]);
+        if constexpr (NW == 8) tot += (ssq[4][c] + ssq[5][c]) + (ssq[6][c] + ssq[7][c]);
+        const float rstd = rsqrtf(tot / (float)p.K + p.eps);
+        v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
+    }
+    const int n = n_base + rt * 16 + g * 4;
+    if (c >= p.nb || n >= p.N) return;
+    if (p.mode == 1) {
+        const float2 o = make_float2((v.x / (1.f + expf(-v.x))) * v.y, (v.z / (1.f + expf(-v.z))) * v.w);
+        *reinterpret_cast<float2*>(p.y + (long long)c * p.ldy + (n >> 1)) = o;
+    } else if (p.mode == 2) {
+        *reinterpret_cast<float4*>(p.y + ((long long)ks * p.nb + c) * p.ldy + n) = v;
+    } else if ((p.N & 3) == 0) {
+        if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+        if (p.res) { const float4 r4 = *reinterpret_cast<const float4*>(p.res + (long long)c * p.ldres + n); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+        *reinterpret_cast<float4*>(p.y + (long long)c * p.ldy + n) = v;
+    } else {
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (n + i < p.N) {
+                float o = e[i];
+                if (p.bias) o += p.bias[n + i];
+                if (p.res) o += p.res[(long long)c * p.ldres + n + i];
+                p.y[(long long)c * p.ldy + n + i] = o;
+            }
+    }
+    stamp();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------

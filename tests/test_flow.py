@@ -413,3 +413,46 @@ def test_flow_inference_ragged_equals_single(lib, precision, streaming, finalize
     assert torch.equal(single(items[0]), alone[0])
     same = flow.inference_batch([items[1], items[1]], streaming=streaming, finalize=finalize)   # the equal-shape path after a padded one
     assert torch.equal(same[0].cpu(), alone[1]) and torch.equal(same[1].cpu(), alone[1])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_two_stream_estimator_is_bit_identical(lib, precision):
+    """Round 3: the estimator's batch rows as two launch chains on two HIP streams (option est_streams = 2, the default: fork / join through events,
+    graph edges inside a captured solve) against one chain over all rows (est_streams = 1).  Same kernels on the same rows -> the same bits: through
+    the estimator boundary with a DIFFERENT time value per batch row (the second half must pick its own time-embedding row), through inference()
+    eager / captured / replayed, through an equal-shape batch and a padded batch (key counts per batch row follow the half)."""
+    import ctypes as C
+    import dataclasses
+    cfg = dataclasses.replace(W.tiny()[1], n_timesteps=2)
+    sd = W.make_flow(cfg)
+    flows = []
+    for streams in (1, 2):
+        f = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision=precision)
+        lib.cv_flow_set_option(f._h, b"est_streams", C.c_int32(streams))
+        flows.append(f)
+    g = torch.Generator().manual_seed(91)
+    T = 37
+    x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g); cond = torch.randn(2, 80, T, generator=g)
+    spk = torch.randn(2, 80, generator=g); t = torch.tensor([0.3, 0.8]); mask = torch.ones(2, 1, T)
+    for streaming in (False, True):
+        a, b = (f.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu() for f in flows)
+        assert torch.equal(a, b)
+        if precision == "fp32":
+            torch.testing.assert_close(b, OF.estimator(sd, cfg, x, mask, mu, t, spk, cond, streaming), rtol=1e-3, atol=1e-3)
+    n = lambda k: torch.tensor([k], dtype=torch.int32)
+    shapes = [(14, 5, 10), (9, 7, 12), (21, 4, 6), (14, 5, 10)]
+    items = [dict(token=torch.randint(0, cfg.vocab, (1, a), generator=g, dtype=torch.int32), prompt_token=torch.randint(0, cfg.vocab, (1, b), generator=g, dtype=torch.int32),
+                  prompt_feat=torch.randn(1, c, cfg.mel, generator=g) * 2 - 5, embedding=torch.randn(1, cfg.spk_dim, generator=g)) for a, b, c in shapes]
+    it = items[0]
+    kw = dict(token=it["token"], token_len=n(14), prompt_token=it["prompt_token"], prompt_token_len=n(5), prompt_feat=it["prompt_feat"], prompt_feat_len=n(10),
+              embedding=it["embedding"], streaming=False, finalize=True)
+    single = [[f.inference(**kw)[0].cpu().clone() for _ in range(3)] for f in flows]          # eager, capture + launch, replay
+    for m in single[0] + single[1]:
+        assert torch.equal(m, single[0][0])
+    for rep in range(3):
+        ra, rb = (f.inference_batch(items[:3]) for f in flows)                  # different lengths: the padded pass
+        for p, q in zip(ra, rb):
+            assert torch.equal(p.cpu(), q.cpu())
+    ea, eb = (f.inference_batch([items[0], items[3]]) for f in flows)
+    for p, q in zip(ea, eb):
+        assert torch.equal(p.cpu(), q.cpu())

@@ -54,6 +54,23 @@ def test_deep_down_projection_variant(lib, monkeypatch):
         assert g == OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=4, min_token_text_ratio=1)
 
 
+def test_row_major_skinny_variant(lib):
+    """Option batch_packed = 0: the batched GEMMs on the row-major weight tensors (skinny_mfma_kernel, round 2) instead of the fragment-ordered copies +
+    wave-private activation staging (skinny_pk_kernel, round 3, the default).  Same products in the same order: the same tokens, and the oracle's."""
+    import ctypes as C
+    cfg = W.tiny()[0]
+    sd = W.make_llm(cfg)
+    reqs = [_req(cfg, 1986, 6, 5, 11), _req(cfg, 7, 4, 3, 20), _req(cfg, 23, 3, 2, 33)]
+    outs = []
+    for packed in (1, 0):
+        lm = Qwen2LM(sd, cfg, lib=lib, max_len=160, sampling="greedy", decode_chunk=5)
+        lib.cv_llm_set_option(lm._h, b"batch_packed", C.c_int32(packed))
+        outs.append(lm.inference_batch(reqs, max_token_text_ratio=4, min_token_text_ratio=1))
+    assert outs[0] == outs[1]
+    for r, g in zip(reqs, outs[0]):
+        assert g == OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=4, min_token_text_ratio=1)
+
+
 def test_batch_of_eight_and_long_context(lib):
     cfg = W.tiny()[0]
     sd = W.make_llm(cfg)

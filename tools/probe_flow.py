@@ -44,6 +44,32 @@ if "all" in which:
         opt(b"flow_tile", tile); opt(b"attn_waves", waves); opt(b"attn_kt", kt); opt(b"attn_ks", ks)
         mel = bench("fused tile=%d attn_waves=%d attn_kt=%d attn_ks=%d" % (tile, waves, kt, ks))
         print("    max |fused - unfused| = %.3e (mel std %.2f)" % ((mel - ref).abs().max().item(), ref.std().item()), flush=True)
+elif "streams" in which:             # round 3: the estimator's batch rows as one launch chain or as two chains on two streams (est_streams)
+    opt(b"fused", 1); opt(b"fused_tail", 0)
+    ref = None
+    for streams in (1, 2, 1, 2):
+        opt(b"est_streams", streams)
+        mel = bench("estimator batch rows on %d stream(s)" % streams)
+        if ref is None:
+            ref = mel
+        else:
+            print("    bit-identical to the first run: %s" % torch.equal(mel, ref), flush=True)
+    # first-chunk-sized streaming request (87 prompt + 41 tokens)
+    tok1 = tok[:, :41]
+    def run1():
+        mel, _ = flow.inference(token=tok1, token_len=t(41), prompt_token=u["flow_prompt_speech_token"], prompt_token_len=t(87), prompt_feat=u["prompt_speech_feat"],
+                                prompt_feat_len=t(174), embedding=u["flow_embedding"], streaming=True, finalize=False)
+        return mel
+    for streams in (1, 2):
+        opt(b"est_streams", streams)
+        for _ in range(3):
+            run1()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(8):
+            run1()
+        torch.cuda.synchronize()
+        print("first streaming chunk (128 tokens)  %d stream(s)  %7.2f ms per flow.inference" % (streams, (time.perf_counter() - t0) / 8 * 1e3), flush=True)
+    opt(b"est_streams", 2)
 elif "attn" in which:                # round 3: key splits inside the 64-query attention workgroup (8 / 12 / 16 waves)
     opt(b"fused", 1); opt(b"fused_tail", 0)
     ref = None
