@@ -254,6 +254,8 @@ def streaming_clients(model, u, clients, n_requests):
     req = {k: u[k] for k in keys}
     req["min_token_text_ratio"] = req["max_token_text_ratio"] = N_GEN / N_TEXT
     sch = StreamScheduler(model, slots=min(8, clients), step_chunk=8)
+    if os.environ.get("CV_SWITCH_INTERVAL"):                      # dev knob: the interpreter's thread switch interval in seconds (default 0.005)
+        sys.setswitchinterval(float(os.environ["CV_SWITCH_INTERVAL"]))
     lat, samples, errs, lock, todo = [], [0], [], threading.Lock(), [n_requests]
     got_tokens = sch.token_log = {}                               # self-check: every request's speech tokens as the LM thread delivered them
 
@@ -302,7 +304,8 @@ def streaming_clients(model, u, clients, n_requests):
     med = lambda i: round(sorted(x[i] for x in st)[len(st) // 2], 2) if st else None
     return {"clients": clients, "requests": n_requests, "tokens_equal_oracle_all_requests": True, "first_chunk_ms_p50": pct(0.5), "first_chunk_ms_p90": pct(0.9), "first_chunk_ms_max": round(lat[-1], 2),
             "first_chunk_split_ms_p50": {"lm_until_tokens": med(0), "wait_for_lane": med(1), "token2wav": med(2)},
-            "audio_s_per_s": round(samples[0] / 24000.0 / el, 3), "wall_s": round(el, 2)}
+            "audio_s_per_s": round(samples[0] / 24000.0 / el, 3), "wall_s": round(el, 2),
+            "shared_flow_passes": {"chunk_batch": sch.chunk_batch, "passes": sch.batched_passes, "requests_in_them": sch.batched_jobs}}
 
 
 def concurrent_streams(model0, u, n_streams, steps):

@@ -41,6 +41,10 @@ struct cv_llm {
     int fused_qkv_attn = 0;
     int head_rows = 1;                                // rows per 16-lane group of the head GEMV (1: 411 workgroups, 2: 206)
     int attn_splits = 8;
+    // option "prefetch" (env CV_DECODE_PREFETCH): extra workgroups of the short decode kernels read the weights the bandwidth-bound kernels behind them
+    // will stream (llm_kernels.h PrefetchArgs).  0 = off; 1 = attention fetches gate / up, o_proj fetches down; 2 = qkv fetches gate / up, attention
+    // fetches down.  "prefetch_shift": dev knob (fetch for another consumer workgroup: breaks the XCD match).
+    int prefetch = 0, prefetch_shift = 0; DevBuf pf_sink;
     int only_cat = -1;                  // cv_llm_profile_chain: enqueue only the launches of this category (-1 = all)
     DevBuf pf_x, pf_xn, pf_qkv, pf_attn, pf_gu, pf_act; // prefill activations (grown on demand)
     int pf_rows = 0;
@@ -134,6 +138,9 @@ static void llm_finalize(cv_llm* m) {
     m->attn_part.ensure((size_t)c.heads * 16 * ATTN_PART * 4);
     m->newtok.ensure((size_t)(c.heads + 2 * c.kv_heads) * 64 * 4);
     if (const char* e = getenv("CV_DECODE_FUSED_QKV")) m->fused_qkv_attn = e[0] != '0';     // dev knob for A/B runs (also: option "fused_qkv_attn")
+    if (const char* e = getenv("CV_DECODE_PREFETCH")) m->prefetch = atoi(e);                 // dev knobs for A/B runs (also: options "prefetch", "prefetch_shift")
+    if (const char* e = getenv("CV_DECODE_PREFETCH_SHIFT")) m->prefetch_shift = atoi(e);
+    m->pf_sink.ensure(64);
     m->act.ensure((size_t)c.inter * 4); m->logits.ensure((size_t)m->V * 4);
     CV_HIP(hipHostMalloc((void**)&m->host_tokens, (size_t)c.max_len * sizeof(int)));
     CV_HIP(hipHostMalloc((void**)&m->host_state, sizeof(DecodeState)));
@@ -231,7 +238,8 @@ static void gemv(const GemvArgs& a, int rows, hipStream_t s, int nsp = 0) {
     const int steps = a.K / 128;
     if (nsp > 0) {                                   // o_proj over split-attention partials (rows == 1, K = heads * 64 <= 1024)
         CV_CHECK(steps <= 8 && rows == 1 && a.mode == 0 && !a.gamma && a.part, "gemv: partial-combine prologue is for the o_proj shape only");
-        const dim3 g4((a.N + 3) / 4);
+        const dim3 g4(a.pf.p ? a.pf.first + prefetch_groups(a.pf.cons_bytes, 4, 10) * a.pf.stride : (a.N + 3) / 4);
+        CV_CHECK(!a.pf.p || a.pf.first >= (a.N + 3) / 4, "gemv: prefetch workgroups must follow the GEMV's own");
         if (nsp == 4) hipLaunchKernelGGL((gemv_kernel<2, 1, 4, 4>), g4, dim3(256), 0, s, a);
         else if (nsp == 8) hipLaunchKernelGGL((gemv_kernel<2, 1, 4, 8>), g4, dim3(256), 0, s, a);
         else if (nsp == 16) hipLaunchKernelGGL((gemv_kernel<2, 1, 4, 16>), g4, dim3(256), 0, s, a);
@@ -248,6 +256,10 @@ static void gemv(const GemvArgs& a, int rows, hipStream_t s, int nsp = 0) {
             static const bool five = [] { const char* e = getenv("CV_GEMV_GATEUP_WAVES"); return !(e && e[0] == '4'); }();   // dev knob for A/B runs
             if (rows == 2 && five) hipLaunchKernelGGL((gemv_norm_kernel<7, 2, 5>), dim3((units + 19) / 20), dim3(320), 0, s, a);
             else if (rows == 2) hipLaunchKernelGGL((gemv_norm_kernel<7, 2>), g16, dim3(256), 0, s, a);
+            else if (a.pf.p) {                               // rows == 1 host (qkv): own workgroups, padding, then the prefetch workgroups
+                CV_CHECK(a.pf.first >= (int)g16.x, "gemv: prefetch workgroups must follow the GEMV's own");
+                hipLaunchKernelGGL((gemv_norm_kernel<7, 1>), dim3(a.pf.first + prefetch_groups(a.pf.cons_bytes, 4, 9) * a.pf.stride), dim3(256), 0, s, a);
+            }
             else           hipLaunchKernelGGL((gemv_norm_kernel<7, 1>), g16, dim3(256), 0, s, a);
             return;
         }
@@ -279,6 +291,18 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
         const int nsp = m->attn_splits;
         GemvArgs go{L.wo, nullptr, nullptr, h, c.hidden, c.heads * 64, nullptr, 0.f, h, 0, st};
         go.part = m->attn_part.as<float>();
+        // weight prefetch by the short kernels (PrefetchArgs): consumer geometry of gate / up (gemv_norm_kernel<7,2,5>: 20 row pairs per workgroup) and
+        // down (gemv_kernel<10,1,4>: 4 rows per workgroup)
+        auto round8 = [](int v) { return (v + 7) / 8 * 8; };
+        PrefetchArgs pgu{}, pdn{};
+        if (m->prefetch && !m->fused_qkv_attn) {
+            const bool five = !(getenv("CV_GEMV_GATEUP_WAVES") && getenv("CV_GEMV_GATEUP_WAVES")[0] == '4');
+            const int gu_rows = !g_gemv_shared_norm ? 8 : five ? 40 : 32;
+            pgu.p = reinterpret_cast<const char*>(L.wgu); pgu.bytes = 2LL * c.inter * c.hidden * 2; pgu.cons_bytes = gu_rows * c.hidden * 2;
+            pgu.n_cons = (2 * c.inter + gu_rows - 1) / gu_rows; pgu.stride = round8(pgu.n_cons); pgu.shift = m->prefetch_shift; pgu.sink = m->pf_sink.as<unsigned>();
+            pdn.p = reinterpret_cast<const char*>(L.wdown); pdn.bytes = 2LL * c.hidden * c.inter; pdn.cons_bytes = 4 * c.inter * 2;
+            pdn.n_cons = (c.hidden + 3) / 4; pdn.stride = round8(pdn.n_cons); pdn.shift = m->prefetch_shift; pdn.sink = pgu.sink;
+        }
         if (m->fused_qkv_attn) {
             float* qn = m->newtok.as<float>(); float* kn = qn + c.heads * 64; float* vn = kn + c.kv_heads * 64;
             QkvAttnArgs qa{L.wqkv, L.bqkv, h, L.ln1, c.rms_eps, c.hidden, m->kcache.as<float>() + m->layer_cache() * i, m->vcache.as<float>() + m->layer_cache() * i,
@@ -287,11 +311,19 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
             if (want(0)) { ProfScope ps(m, s, 0); hipLaunchKernelGGL((qkv_attn_kernel<7>), dim3(c.heads * nsp + 2 * c.kv_heads), dim3(256), 0, s, qa); }
             go.qnew = qn; go.knew = kn; go.vnew = vn; go.kv_group = c.heads / c.kv_heads;
         } else {
-            if (want(0)) { ProfScope ps(m, s, 0); gemv(GemvArgs{L.wqkv, L.bqkv, h, qkv, m->qkv_dim, c.hidden, L.ln1, c.rms_eps, nullptr, 0, st}, 1, s); }
+            GemvArgs gq{L.wqkv, L.bqkv, h, qkv, m->qkv_dim, c.hidden, L.ln1, c.rms_eps, nullptr, 0, st};
+            if (m->prefetch == 2 && pgu.p) { gq.pf = pgu; gq.pf.first = round8((m->qkv_dim + 15) / 16); }
+            if (want(0)) { ProfScope ps(m, s, 0); gemv(gq, 1, s); }
             AttnDecodeArgs ad{qkv, m->kcache.as<float>() + m->layer_cache() * i, m->vcache.as<float>() + m->layer_cache() * i,
                               m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st,
                               m->attn_part.as<float>(), nsp};
-            if (want(1)) { ProfScope ps(m, s, 1); hipLaunchKernelGGL(attn_decode_kernel, dim3(c.heads * nsp), dim3(64), 0, s, ad); }
+            int attn_grid = c.heads * nsp;
+            if (pgu.p) {
+                ad.pf = m->prefetch == 2 ? pdn : pgu; ad.pf.first = round8(attn_grid);
+                attn_grid = ad.pf.first + prefetch_groups(ad.pf.cons_bytes, 1, 14) * ad.pf.stride;
+            }
+            if (want(1)) { ProfScope ps(m, s, 1); hipLaunchKernelGGL(attn_decode_kernel, dim3(attn_grid), dim3(64), 0, s, ad); }
+            if (m->prefetch == 1 && pdn.p) { go.pf = pdn; go.pf.first = round8((c.hidden + 3) / 4); }
         }
         if (want(2)) { ProfScope ps(m, s, 2); gemv(go, 1, s, nsp); }
         if (want(3)) { ProfScope ps(m, s, 3); gemv(GemvArgs{L.wgu, nullptr, h, act, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 1, st}, 2, s); }
@@ -647,6 +679,10 @@ int cv_llm_set_option(cv_llm* m, const char* name, int32_t value) {
         if (std::string(name) == "use_graph") { m->use_graph = value != 0; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; } }
         else if (std::string(name) == "head_rows") { CV_CHECK(value == 1 || value == 2, "head_rows must be 1 or 2"); m->head_rows = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; } }
         else if (std::string(name) == "fused_qkv_attn") { m->fused_qkv_attn = value != 0; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; } }
+        else if (std::string(name) == "prefetch" || std::string(name) == "prefetch_shift") {
+            CV_CHECK(std::string(name) != "prefetch" || (value >= 0 && value <= 2), "prefetch must be 0, 1 or 2");
+            (std::string(name) == "prefetch" ? m->prefetch : m->prefetch_shift) = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+        }
         else if (std::string(name) == "attn_splits") {       // key-range slices per head in the decode attention (4, 8 or 16)
             CV_CHECK(value == 4 || value == 8 || value == 16, "attn_splits must be 4, 8 or 16");
             m->attn_splits = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }

@@ -8,6 +8,8 @@
 
 namespace cv {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 struct DecodeState {       // lives in device memory (one per cv_llm handle)
     int pos;               // number of positions already in the KV cache
     int step;              // index i of the reference loop `for i in range(max_len)` (llm/llm.py:538)
@@ -18,6 +20,48 @@ struct DecodeState {       // lives in device memory (one per cv_llm handle)
                            // tell a fill token (more text is due) from eos
     int pad[2];
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// Next-kernel weight prefetch (round 3).  A decode layer is a chain of five dependent launches; three of them (qkv, attention, o_proj) move
+// 3.6 MB in ~11 us - they are bound by the launch boundary and one memory round trip, and HBM idles while they run - and the two that follow
+// (gate / up 17.4 MB, down 8.7 MB) then wait for HBM.  A forked graph branch that warms L2 costs more than it saves (+21 us per layer for the
+// fork / join edges, profiles/r2_batch_decode_ab.txt); extra WORKGROUPS appended to the short kernels cost no boundary at all: workgroups
+// [first, first + groups * stride) of the host launch only read (default cache policy: the lines are left in the XCD's L2 and in the memory-side
+// cache) the bytes a LATER kernel of the chain will stream, and exit.  Consumer workgroup b of that kernel reads the contiguous range
+// [b * cons_bytes, (b + 1) * cons_bytes); it is fetched by host workgroups first + j * stride + b, j = 0 .. groups - 1 (`first` and `stride` are
+// multiples of 8: with workgroups dealt round-robin to the 8 XCDs, fetcher and consumer share an L2).  Purely a hint: results do not depend on it.
+// ---------------------------------------------------------------------------------------------------------------
+struct PrefetchArgs {
+    const char* p = nullptr;          // start of the region (null = off)
+    long long bytes = 0;              // its size (loads are clamped to it)
+    int cons_bytes = 0, n_cons = 0;   // bytes per consumer workgroup, number of consumer workgroups
+    int stride = 0, first = 0;        // round_up(n_cons, 8); index of the first prefetch workgroup in the host launch (multiple of 8)
+    int shift = 0;                    // dev knob: fetch for consumer b + shift instead (breaks the XCD match on purpose, A/B runs)
+    unsigned* sink = nullptr;         // never written in practice: keeps the loads alive
+};
+// U wave-loads (64 lanes x 16 B = 1 KB each) per wave; `wave` of `nw` waves in the workgroup, prefetch-workgroup index pw (0-based)
+template <int U>
+__device__ __forceinline__ void prefetch_role(const PrefetchArgs& f, int pw, int wave, int nw, int lane) {
+    const int j = pw / f.stride;
+    int b = pw % f.stride;
+    if (b >= f.n_cons) return;
+    b = (b + f.shift) % f.n_cons;
+    const long long base = (long long)b * f.cons_bytes;
+    const int kb0 = (j * nw + wave) * U;                                   // first 1 KB unit of this wave inside the consumer's range
+    if (kb0 * 1024 >= f.cons_bytes) return;
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        long long o = base + min((kb0 + u) * 1024 + lane * 16, f.cons_bytes - 16);
+        o = o < f.bytes - 16 ? o : f.bytes - 16;
+        v[u] = *reinterpret_cast<const u32x4*>(f.p + o);
+    }
+    unsigned a = 0u;
+#pragma unroll
+    for (int u = 0; u < U; ++u) a |= v[u][0] ^ v[u][3];
+    if (a == 0x9e3779b9u && f.sink) f.sink[0] = a;                         // bf16 weight words never form this pattern in all lanes' OR; a hit would only touch the sink
+}
+inline int prefetch_groups(int cons_bytes, int nw, int U) { return ((cons_bytes + 1023) / 1024 + nw * U - 1) / (nw * U); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // y[n] = epi( sum_k W[n][k] * xn[k] ),  W bf16 [N][K] row-major, K % 128 == 0.
@@ -37,11 +81,11 @@ struct GemvArgs {
     // it as one more partial: score = q_new . k_new / 8, value = v_new.  qnew [K/64][64], knew / vnew [kv heads][64]; null = not used.
     const float* qnew = nullptr; const float* knew = nullptr; const float* vnew = nullptr; int kv_group = 1;
     DecodeState* advance = nullptr;   // last GEMV of a backbone step: also advances the KV length (no kernel of the step reads `pos` after it)
+    PrefetchArgs pf;                  // workgroups >= pf.first of the launch only prefetch a later kernel's weights (prefetch_role)
 };
 
 constexpr int ATTN_PART = 68;      // 64 unnormalised numerators + running max + denominator (+2 pad: rows stay 16-byte aligned)
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Latency structure (batch-1 decode is a chain of ~125 short kernels, each bounded by ONE memory round trip if written so):
 // every lane first issues ALL of its weight loads (ROWS x STEPS x 16 B, non-temporal: each byte is read once per token),
@@ -53,6 +97,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     // no `done` test here: it would put a dependent load in front of the weight stream; a finished request simply recomputes
     // into buffers nobody reads (sample / embed / advance are the kernels that honour `done`).
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
+    if constexpr (NSP > 0) {                                 // o_proj hosts the prefetch of the down projection's weights
+        if (p.pf.p && (int)blockIdx.x >= p.pf.first) { prefetch_role<10>(p.pf, blockIdx.x - p.pf.first, wave, WAVES, lane); return; }
+    }
     if (p.advance && blockIdx.x == 0 && tid == 0 && !p.advance->done) p.advance->pos += 1;
     const int steps = p.K / 128;
     const int s0 = wave * steps / WAVES, s1 = (wave + 1) * steps / WAVES;
@@ -219,6 +266,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_norm_kernel(GemvArgs p) {
     __shared__ __attribute__((aligned(16))) float xs[STEPS * 128];
     __shared__ float red[WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
+    if constexpr (ROWS == 1) {                               // qkv (and head) can host a prefetch of later weights
+        if (p.pf.p && (int)blockIdx.x >= p.pf.first) { prefetch_role<9>(p.pf, blockIdx.x - p.pf.first, wave, WAVES, lane); return; }
+    }
     const int steps = p.K / 128;
     const int unit = (blockIdx.x * WAVES + wave) * 4 + grp;  // 16-lane group index: ROWS consecutive rows
     const int row0 = unit * ROWS;
@@ -300,6 +350,7 @@ struct AttnDecodeArgs {
     const float* qkv; float* kcache; float* vcache; const float* rope_cos; const float* rope_sin;
     int heads, kv_heads, max_len; const DecodeState* st;
     float* part; int nsplit;      // wave (h, s) covers the s-th contiguous slice of the keys and writes part[h][s][ATTN_PART]
+    PrefetchArgs pf;              // workgroups >= pf.first only prefetch a later kernel's weights (prefetch_role)
 };
 
 // ONE WAVE per (query head, key slice) - the structure the decode GEMVs proved on this chip: single-wave workgroups, no LDS, no
@@ -314,6 +365,8 @@ struct AttnDecodeArgs {
 static __global__ __launch_bounds__(64) void attn_decode_kernel(AttnDecodeArgs p) {
     constexpr int NS = 12, PASS = 4 * NS;
     const int lane = threadIdx.x, sub = lane & 15, grp = lane >> 4;
+    if (p.pf.p && (int)blockIdx.x >= p.pf.first) { prefetch_role<14>(p.pf, blockIdx.x - p.pf.first, 0, 1, lane); return; }
+    if ((int)blockIdx.x >= p.heads * p.nsplit) return;                     // padding up to pf.first
     const int h = blockIdx.x / p.nsplit, sp = blockIdx.x % p.nsplit, gsz = p.heads / p.kv_heads, g = h / gsz;
     const int pos = p.st->pos;                       // the new token sits at index `pos`
     const int L = pos + 1;

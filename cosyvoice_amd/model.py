@@ -219,37 +219,66 @@ class CosyVoice2Model:
     def token2wav(self, token, prompt_token, prompt_feat, embedding, token_offset, uuid, stream=False, finalize=False, speed=1.0):
         """cli/model.py:292-326."""
         with self._lane() as lane:
-            flow, hift = lane.flow, lane.hift
             t = lambda n: torch.tensor([n], dtype=torch.int32)
-            tts_mel, _ = flow.inference(token=token.to(torch.int32), token_len=t(token.shape[1]), prompt_token=prompt_token, prompt_token_len=t(prompt_token.shape[1]),
-                                        prompt_feat=prompt_feat, prompt_feat_len=t(prompt_feat.shape[1]), embedding=embedding, streaming=stream, finalize=finalize)
-            tts_mel = tts_mel[:, :, token_offset * flow.token_mel_ratio:]
-            cache = self.hift_cache_dict.get(uuid)
+            tts_mel, _ = lane.flow.inference(token=token.to(torch.int32), token_len=t(token.shape[1]), prompt_token=prompt_token, prompt_token_len=t(prompt_token.shape[1]),
+                                             prompt_feat=prompt_feat, prompt_feat_len=t(prompt_feat.shape[1]), embedding=embedding, streaming=stream, finalize=finalize)
+            return self._t2w_tail(lane, tts_mel, token, token_offset, uuid, finalize, speed)
+
+    @torch.inference_mode()
+    def token2wav_batch(self, jobs, stream=False, finalize=False, on_ready=None):
+        """token2wav for several requests at once (round 3; the serving scheduler's chunk batches): `jobs` = dicts(token, prompt_token, prompt_feat,
+        embedding, token_offset, uuid [, speed]) that share `stream` / `finalize`.  ONE flow pass over all of them (inference_batch: equal shapes
+        unpadded, different lengths as the padded pass of cv_flow_inference_ragged - every mel bit-identical to the request alone), then each
+        request's own HiFT call with its own cache, exactly as token2wav does.  Returns the list of tts_speech tensors, in job order;
+        `on_ready(i, wav)` (optional) is called the moment job i's audio has been enqueued - a serving scheduler hands it to its listener while the
+        other members of the batch are still in the vocoder (a `.cpu()` inside the callback waits on the lane's stream only)."""
+        if len(jobs) == 1 or not hasattr(self.flow, "inference_batch"):
+            outs = []
+            for i, j in enumerate(jobs):
+                outs.append(self.token2wav(stream=stream, finalize=finalize, **j))
+                if on_ready is not None:
+                    on_ready(i, outs[-1])
+            return outs
+        with self._lane() as lane:
+            mels = lane.flow.inference_batch([dict(token=j["token"].to(torch.int32), prompt_token=j["prompt_token"], prompt_feat=j["prompt_feat"], embedding=j["embedding"])
+                                              for j in jobs], streaming=stream, finalize=finalize)
+            outs = []
+            for i, (j, mel) in enumerate(zip(jobs, mels)):
+                outs.append(self._t2w_tail(lane, mel, j["token"], j["token_offset"], j["uuid"], finalize, j.get("speed", 1.0)))
+                if on_ready is not None:
+                    on_ready(i, outs[-1])
+            return outs
+
+    def _t2w_tail(self, lane, tts_mel, token, token_offset, uuid, finalize, speed):
+        """Everything of token2wav after the flow (cli/model.py:301-326): new frames -> mel / source caches -> HiFT -> fade."""
+        flow, hift = lane.flow, lane.hift
+        tts_mel = tts_mel[:, :, token_offset * flow.token_mel_ratio:]
+        cache = self.hift_cache_dict.get(uuid)
+        if cache is not None:
+            tts_mel = torch.concat([cache["mel"], tts_mel], dim=2)
+            hift_cache_source = cache["source"]
+        else:
+            hift_cache_source = torch.zeros(1, 1, 0)
+        hift._next_seed = self._noise_key(token, token_offset)
+        if finalize is False:
+            tts_speech, tts_source = hift.inference(speech_feat=tts_mel, cache_source=hift_cache_source)
             if cache is not None:
-                tts_mel = torch.concat([cache["mel"], tts_mel], dim=2)
-                hift_cache_source = cache["source"]
-            else:
-                hift_cache_source = torch.zeros(1, 1, 0)
-            hift._next_seed = self._noise_key(token, token_offset)
-            if finalize is False:
-                tts_speech, tts_source = hift.inference(speech_feat=tts_mel, cache_source=hift_cache_source)
-                if cache is not None:
-                    tts_speech = self._fade(tts_speech, cache["speech"])
-                self.hift_cache_dict[uuid] = {"mel": tts_mel[:, :, -self.mel_cache_len:].clone(), "source": tts_source[:, :, -self.source_cache_len:].clone(),
-                                              "speech": tts_speech[:, -self.source_cache_len:].clone()}
-                tts_speech = tts_speech[:, :-self.source_cache_len]
-            else:
-                if speed != 1.0:
-                    assert cache is None, "speed change only support non-stream inference mode"
-                    tn = int(tts_mel.shape[2] / speed)
-                    src = tts_mel.contiguous()
-                    dst = torch.empty(1, src.shape[1], tn, dtype=torch.float32, device=self.device)
-                    self.lib.cv_interp_linear(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_int32(src.shape[1]), C.c_int32(src.shape[2]), C.c_int32(tn), stream_ptr(self.lib))
-                    tts_mel = dst
-                tts_speech, tts_source = hift.inference(speech_feat=tts_mel, cache_source=hift_cache_source)
-                if cache is not None:
-                    tts_speech = self._fade(tts_speech, cache["speech"])
-            return tts_speech
+                tts_speech = self._fade(tts_speech, cache["speech"])
+            self.hift_cache_dict[uuid] = {"mel": tts_mel[:, :, -self.mel_cache_len:].clone(), "source": tts_source[:, :, -self.source_cache_len:].clone(),
+                                          "speech": tts_speech[:, -self.source_cache_len:].clone()}
+            tts_speech = tts_speech[:, :-self.source_cache_len]
+        else:
+            if speed != 1.0:
+                assert cache is None, "speed change only support non-stream inference mode"
+                tn = int(tts_mel.shape[2] / speed)
+                src = tts_mel.contiguous()
+                dst = torch.empty(1, src.shape[1], tn, dtype=torch.float32, device=self.device)
+                self.lib.cv_interp_linear(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_int32(src.shape[1]), C.c_int32(src.shape[2]), C.c_int32(tn), stream_ptr(self.lib))
+                tts_mel = dst
+            tts_speech, tts_source = hift.inference(speech_feat=tts_mel, cache_source=hift_cache_source)
+            if cache is not None:
+                tts_speech = self._fade(tts_speech, cache["speech"])
+        return tts_speech
 
     def _vocode_group(self, group, speed):
         """Offline vocoding of one group of finished sequences [(index, request, tokens)] on ONE lane.  Groups of equal shape (token count, prompt
@@ -523,25 +552,30 @@ class CosyVoice3Model(CosyVoice2Model):
     def token2wav(self, token, prompt_token, prompt_feat, embedding, token_offset, uuid, stream=False, finalize=False, speed=1.0):
         """cli/model.py:425-450."""
         with self._lane() as lane:
-            flow, hift = lane.flow, lane.hift
             t = lambda n: torch.tensor([n], dtype=torch.int32)
-            tts_mel, _ = flow.inference(token=token.to(torch.int32), token_len=t(token.shape[1]), prompt_token=prompt_token, prompt_token_len=t(prompt_token.shape[1]),
-                                        prompt_feat=prompt_feat, prompt_feat_len=t(prompt_feat.shape[1]), embedding=embedding, streaming=stream, finalize=finalize)
-            tts_mel = tts_mel[:, :, token_offset * flow.token_mel_ratio:]
-            cache = self.hift_cache_dict.get(uuid)
-            if cache is not None:
-                tts_mel = torch.concat([cache["mel"], tts_mel], dim=2)
-                cache["mel"] = tts_mel
-            else:
-                cache = self.hift_cache_dict[uuid] = {"mel": tts_mel, "speech_offset": 0}
-            if speed != 1.0:
-                assert token_offset == 0 and finalize is True, "speed change only support non-stream inference mode"
-                tn = int(tts_mel.shape[2] / speed)
-                src = tts_mel.contiguous()
-                dst = torch.empty(1, src.shape[1], tn, dtype=torch.float32, device=self.device)
-                self.lib.cv_interp_linear(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_int32(src.shape[1]), C.c_int32(src.shape[2]), C.c_int32(tn), stream_ptr(self.lib))
-                tts_mel = dst
-            tts_speech, _ = hift.inference(speech_feat=tts_mel, finalize=finalize)
-            tts_speech = tts_speech[:, cache["speech_offset"]:]
-            cache["speech_offset"] += tts_speech.shape[1]
-            return tts_speech
+            tts_mel, _ = lane.flow.inference(token=token.to(torch.int32), token_len=t(token.shape[1]), prompt_token=prompt_token, prompt_token_len=t(prompt_token.shape[1]),
+                                             prompt_feat=prompt_feat, prompt_feat_len=t(prompt_feat.shape[1]), embedding=embedding, streaming=stream, finalize=finalize)
+            return self._t2w_tail(lane, tts_mel, token, token_offset, uuid, finalize, speed)
+
+    @torch.inference_mode()
+    def _t2w_tail(self, lane, tts_mel, token, token_offset, uuid, finalize, speed):
+        """cli/model.py:432-450: the request's whole mel accumulates in the cache, the causal HiFT re-runs over it and the new samples are cut out."""
+        flow, hift = lane.flow, lane.hift
+        tts_mel = tts_mel[:, :, token_offset * flow.token_mel_ratio:]
+        cache = self.hift_cache_dict.get(uuid)
+        if cache is not None:
+            tts_mel = torch.concat([cache["mel"], tts_mel], dim=2)
+            cache["mel"] = tts_mel
+        else:
+            cache = self.hift_cache_dict[uuid] = {"mel": tts_mel, "speech_offset": 0}
+        if speed != 1.0:
+            assert token_offset == 0 and finalize is True, "speed change only support non-stream inference mode"
+            tn = int(tts_mel.shape[2] / speed)
+            src = tts_mel.contiguous()
+            dst = torch.empty(1, src.shape[1], tn, dtype=torch.float32, device=self.device)
+            self.lib.cv_interp_linear(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_int32(src.shape[1]), C.c_int32(src.shape[2]), C.c_int32(tn), stream_ptr(self.lib))
+            tts_mel = dst
+        tts_speech, _ = hift.inference(speech_feat=tts_mel, finalize=finalize)
+        tts_speech = tts_speech[:, cache["speech_offset"]:]
+        cache["speech_offset"] += tts_speech.shape[1]
+        return tts_speech

@@ -14,6 +14,7 @@
   takes such a front end as an object and only replaces its mel extractor and the model underneath.
 """
 import collections
+import os
 import queue
 import threading
 import time
@@ -39,9 +40,14 @@ class _Request:
 
 
 class StreamScheduler:
-    def __init__(self, model, slots=8, strategy="exponential", step_chunk=8):
+    def __init__(self, model, slots=8, strategy="exponential", step_chunk=8, chunk_batch=None):
         assert strategy in ("exponential", "time_based")
         self.model, self.slots, self.strategy, self.step_chunk = model, slots, strategy, step_chunk
+        # up to this many ready requests share one flow pass (_mates); None = the model's offline flow_batch when it can batch, 1 = one by one (round 2)
+        if chunk_batch is None and os.environ.get("CV_CHUNK_BATCH"):                       # dev knob for A/B runs
+            chunk_batch = int(os.environ["CV_CHUNK_BATCH"])
+        self.chunk_batch = (getattr(model, "flow_batch", 1) if hasattr(model, "token2wav_batch") else 1) if chunk_batch is None else chunk_batch
+        self.batched_passes = self.batched_jobs = 0     # passes that carried more than one request, and the requests in them
         self._src = queue.Queue()
         self._cv = threading.Condition()
         self._reqs = {}
@@ -153,6 +159,105 @@ class StreamScheduler:
             return "final"
         return None
 
+    def _job_tokens(self, r, what):
+        """Token count (prompt included) of the flow pass the ready work of `r` needs - what decides which requests may share a padded pass."""
+        la = self.model.flow.pre_lookahead_len
+        n_prompt = int(r.req["flow_prompt_speech_token"].shape[1])
+        if what == "chunk":
+            return n_prompt + r.token_offset + (r.hop + r.pad if r.token_offset == 0 else r.hop) + la
+        return n_prompt + len(r.tokens)
+
+    def _mates(self, pick, first_only):
+        """Called under the lock with `pick` = (request, 'chunk' | 'final', tokens) already chosen: other ready, idle requests whose work is of the
+        SAME kind and whose flow pass is of similar length (the model's offline grouping rule: within 1 / flow_pad of the longest, at most
+        chunk_batch members) - they go through the flow together (CosyVoice2Model.token2wav_batch: one Euler solve over all of them, every mel
+        bit-identical to the request alone), so a loaded GPU runs one pass of 2-4 x the rows instead of 2-4 passes side by side."""
+        r0, what, _ = pick
+        if what == "final" and not r0.stream and r0.req.get("speed", 1.0) != 1.0:
+            return []
+        n0, pad = self._job_tokens(r0, what), getattr(self.model, "flow_pad", 1.25)
+        out = []
+        for r in self._reqs.values():
+            if len(out) + 1 >= self.chunk_batch:
+                break
+            if r is r0 or r.busy or (first_only and r.chunk_index > 0) or self._ready(r) != what:
+                continue
+            if what == "final" and not r.stream and r.req.get("speed", 1.0) != 1.0:
+                continue
+            n = self._job_tokens(r, what)
+            if min(n, n0) * pad < max(n, n0):
+                continue
+            r.busy = True
+            if r.t_pick is None:
+                r.t_pick = time.perf_counter()
+            out.append((r, what, list(r.tokens)))
+        return out
+
+    def _vocode_together(self, picks):
+        """The 'chunk' / 'final' branch of _vocoder_loop for several requests in one token2wav_batch call; per-request bookkeeping as there."""
+        m = self.model
+        la = m.flow.pre_lookahead_len
+        what = picks[0][1]
+        jobs = []
+        for r, _, toks in picks:
+            rq = r.req
+            if what == "chunk":
+                hop = r.hop + r.pad if r.token_offset == 0 else r.hop
+                toks = toks[:r.token_offset + hop + la]
+            jobs.append(dict(token=torch.tensor(toks).unsqueeze(0), prompt_token=rq["flow_prompt_speech_token"], prompt_feat=rq["prompt_speech_feat"],
+                             embedding=rq["flow_embedding"], token_offset=r.token_offset, uuid=r.key))
+        delivered = set()
+
+        def deliver(i, wav):                     # called inside token2wav_batch right after request i's HiFT: its listener does not wait for the others
+            r = picks[i][0]
+            out = {"tts_speech": wav.cpu()}
+            if what == "chunk":
+                hop = r.hop + r.pad if r.token_offset == 0 else r.hop
+                r.token_offset += hop
+                r.chunk_index += 1
+                self._next_hop(r)
+            if r.t_first is None:
+                r.t_first = time.perf_counter()
+                if what == "chunk" and r.t_ready is not None:
+                    self.first_chunk_stats.append(((r.t_ready - r.t_submit) * 1e3, (r.t_pick - r.t_ready) * 1e3, (r.t_first - r.t_pick) * 1e3))
+            r.out.put(out)
+            if what == "final":
+                r.out.put(None)
+            delivered.add(i)
+        err = None
+        try:
+            m.token2wav_batch(jobs, stream=(what == "chunk"), finalize=(what == "final"), on_ready=deliver)
+        except BaseException as e:
+            err = e
+            for i, (r, _, _) in enumerate(picks):
+                if i not in delivered:
+                    r.out.put(e)
+        done = what == "final" or err is not None
+        self.batched_passes += 1
+        self.batched_jobs += len(picks)
+        with self._cv:
+            for r, _, _ in picks:
+                r.busy = False
+                if done:
+                    self._reqs.pop(r.key, None)
+            self._cv.notify_all()
+        if done:
+            with m.lock:
+                for r, _, _ in picks:
+                    m.hift_cache_dict.pop(r.key, None)
+
+    def _next_hop(self, r):
+        """Hop growth after a chunk (cli/model.py:360 `exponential`; triton model.py:410-426 `time_based`)."""
+        m = self.model
+        if self.strategy == "exponential":
+            r.hop = min(m.token_max_hop_len, r.hop * m.stream_scale_factor)
+        else:                                   # time_based: grow the hop while synthesis runs ahead of playback
+            cost, dur = time.perf_counter() - r.t_submit, r.token_offset / 25.0
+            mult = (dur - cost) / max(cost / r.chunk_index, 1e-6)
+            pend = len(r.tokens) - r.token_offset
+            base = m.token_hop_len
+            r.hop = max(base, (pend // base + 1) * base if mult > 4 else (pend // base) * base if mult > 2 else base)
+
     def _vocoder_loop(self, first_only=False):
         m = self.model
         la = m.flow.pre_lookahead_len
@@ -176,6 +281,10 @@ class StreamScheduler:
                 pick[0].busy = True
                 if pick[0].t_pick is None:
                     pick[0].t_pick = time.perf_counter()
+                mates = self._mates(pick, first_only) if self.chunk_batch > 1 and pick[1] in ("chunk", "final") else []
+            if mates:
+                self._vocode_together([pick] + mates)
+                continue
             r, what, toks = pick
             rq = r.req
             finished = True
@@ -191,14 +300,7 @@ class StreamScheduler:
                                       embedding=rq["flow_embedding"], token_offset=r.token_offset, uuid=r.key, stream=True, finalize=False)
                     r.token_offset += hop
                     r.chunk_index += 1
-                    if self.strategy == "exponential":
-                        r.hop = min(m.token_max_hop_len, r.hop * m.stream_scale_factor)
-                    else:                                   # time_based (triton model.py:410-426): grow the hop while synthesis runs ahead of playback
-                        cost, dur = time.perf_counter() - r.t_submit, r.token_offset / 25.0
-                        mult = (dur - cost) / max(cost / r.chunk_index, 1e-6)
-                        pend = len(r.tokens) - r.token_offset
-                        base = m.token_hop_len
-                        r.hop = max(base, (pend // base + 1) * base if mult > 4 else (pend // base) * base if mult > 2 else base)
+                    self._next_hop(r)
                     out = {"tts_speech": wav.cpu()}
                     if r.t_first is None:
                         r.t_first = time.perf_counter()

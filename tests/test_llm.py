@@ -228,6 +228,27 @@ def test_fused_qkv_attention_variant(lib, tiny_sd, splits, n_prompt):
         torch.testing.assert_close(lm.last_logits().log_softmax(-1), trace["logp"][i], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("mode,shift", [(1, 0), (2, 0), (1, 3)])
+def test_decode_weight_prefetch_is_only_a_hint(lib, tiny_sd, mode, shift):
+    """Option prefetch = 1 / 2 (round 3): extra workgroups of the short decode kernels (qkv / attention / o_proj) read the weights the gate / up and
+    down GEMVs behind them will stream (llm_kernels.h PrefetchArgs).  Nothing but loads: tokens and log-probabilities are those of the plain chain,
+    with and without the graph, whatever consumer the fetchers are pointed at."""
+    import ctypes as C
+    cfg, sd = tiny_sd
+    u = _utt(cfg, n_prompt_tok=37)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=256, sampling="greedy", decode_chunk=5)
+    ref = list(lm.inference(**_kw(u), max_token_text_ratio=2, min_token_text_ratio=2))
+    lm.prefill(lm.build_lm_input(u["text"], u["prompt_text"], u["llm_prompt_speech_token"]))
+    lm.decode(2, lm.make_sampling(6, 12)); ref_logits = lm.last_logits().clone()
+    lib.cv_llm_set_option(lm._h, b"prefetch", C.c_int32(mode))
+    lib.cv_llm_set_option(lm._h, b"prefetch_shift", C.c_int32(shift))
+    assert list(lm.inference(**_kw(u), max_token_text_ratio=2, min_token_text_ratio=2)) == ref
+    lm.prefill(lm.build_lm_input(u["text"], u["prompt_text"], u["llm_prompt_speech_token"]))
+    lm.decode(2, lm.make_sampling(6, 12))
+    assert torch.equal(lm.last_logits(), ref_logits)
+    assert ref == OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=2, min_token_text_ratio=2)
+
+
 def _device_rng_draws(lib, cfg, sd, logits, n_draws, tau_r, per_request=256):
     """Tokens drawn by the device sampler (sample_kernel on its own counter RNG, no injected uniforms) from a FIXED distribution: the head's weight
     is zeroed and its bias carries `logits`, so every step samples softmax(logits) whatever the hidden state; each request gets a fresh RNG key

@@ -186,6 +186,58 @@ def test_scheduler_logic_with_fake_model():
         sch.shutdown()
 
 
+@pytest.mark.timeout(120)
+def test_scheduler_batches_ready_requests_into_one_flow_pass():
+    """Round 3: ready work of the same kind and similar length goes through token2wav_batch together (StreamScheduler._mates): with ONE vocoder
+    lane that takes 50 ms per call, the requests that become ready while it is busy share the next call; every request still gets exactly its
+    own chunks (offsets chain, the final call sees everything), requests of very different length or kind are never put together, and
+    chunk_batch = 1 restores the one-by-one behaviour."""
+    import time as _t
+    scripts = {1: list(range(47)), 2: list(range(9)), 3: list(range(47))}
+
+    class Fm(_FakeModel):
+        flow_batch, flow_pad = 4, 1.25
+
+        def token2wav(self, **kw):
+            _t.sleep(0.05)
+            return super().token2wav(**kw)
+
+        def token2wav_batch(self, jobs, stream=False, finalize=False, on_ready=None):
+            _t.sleep(0.05)
+            self.batches.append([(j["uuid"], j["token"].shape[1], j["token_offset"], stream, finalize) for j in jobs])
+            n = [j["token"].shape[1] + j["prompt_token"].shape[1] for j in jobs]
+            assert max(n) <= 1.25 * min(n), "requests of too different length in one pass"
+            for i, j in enumerate(jobs):
+                on_ready(i, _FakeModel.token2wav(self, stream=stream, finalize=finalize, **j))
+
+    for chunk_batch in (None, 1):
+        fm = Fm(scripts); fm.batches = []
+        sch = StreamScheduler(fm, slots=8, step_chunk=4, chunk_batch=chunk_batch)
+        try:
+            got = [None] * 6
+            kinds = [(1, True), (3, True), (1, True), (2, False), (3, True), (2, False)]        # (text length -> script, stream)
+            th = [threading.Thread(target=lambda i=i, k=k: got.__setitem__(i, [o["tts_speech"].shape[1] // 960 for o in sch.submit(stream=k[1], **_fake_req(k[0]))]))
+                  for i, k in enumerate(kinds)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            for g, k in zip(got, kinds):
+                assert g == ([7, 10, 20, 10] if k[1] else [9]), (g, k)
+            per = {}
+            for c in fm.calls:
+                per.setdefault(c[0], []).append(c[1:])
+            for key, calls in per.items():                       # every request saw exactly its own schedule, whoever it shared a pass with
+                assert calls in ([(10, 0, True, False), (20, 7, True, False), (40, 17, True, False), (47, 37, False, True)], [(9, 0, False, True)]), calls
+            assert not sch._reqs and not fm.hift_cache_dict
+            if chunk_batch == 1:
+                assert not fm.batches and sch.batched_jobs == 0
+            else:
+                assert sch.batched_jobs >= 2 and all(len(b) >= 2 and len({(x[3], x[4]) for x in b}) == 1 for b in fm.batches)
+        finally:
+            sch.shutdown()
+
+
 def _fake_req(n_text, n_prompt=8):
     return dict(text=torch.zeros(1, n_text, dtype=torch.int32), prompt_text=torch.zeros(1, 2, dtype=torch.int32),
                 llm_prompt_speech_token=torch.zeros(1, n_prompt, dtype=torch.int32), flow_prompt_speech_token=torch.zeros(1, n_prompt, dtype=torch.int32),
