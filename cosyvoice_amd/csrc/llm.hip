@@ -40,11 +40,15 @@ struct cv_llm {
     // 8 different XCDs, so the PMC shows 13.7 MB of HBM reads per launch instead of 2.1 MB.  Kept, tested, off by default.
     int fused_qkv_attn = 0;
     int head_rows = 1;                                // rows per 16-lane group of the head GEMV (1: 411 workgroups, 2: 206)
+    int head_waves = 4;                               // head_rows == 1: waves per workgroup of the head GEMV (4: 411 workgroups = 1.6 per CU; 7: 235 workgroups, one per CU) - option "head_waves" / CV_HEAD_WAVES
     int attn_splits = 8;
     // option "prefetch" (env CV_DECODE_PREFETCH): extra workgroups of the short decode kernels read the weights the bandwidth-bound kernels behind them
     // will stream (llm_kernels.h PrefetchArgs).  0 = off; 1 = attention fetches gate / up, o_proj fetches down; 2 = qkv fetches gate / up, attention
     // fetches down.  "prefetch_shift": dev knob (fetch for another consumer workgroup: breaks the XCD match).
     int prefetch = 0, prefetch_shift = 0; DevBuf pf_sink;
+    // option "fused_attn_oproj" (env CV_DECODE_FUSED_O): attention + o_proj in one launch (attn_oproj_kernel: the o_proj GEMV split by head, the per-head
+    // contributions summed into the residual by gate / up's prologue) - 4 launches per layer.  "oproj_rblocks": row blocks per head (4 | 8).
+    int fused_attn_oproj = 0, oproj_rblocks = 4, oproj_waves = 8; DevBuf opart, h2;
     int only_cat = -1;                  // cv_llm_profile_chain: enqueue only the launches of this category (-1 = all)
     DevBuf pf_x, pf_xn, pf_qkv, pf_attn, pf_gu, pf_act; // prefill activations (grown on demand)
     int pf_rows = 0;
@@ -138,9 +142,14 @@ static void llm_finalize(cv_llm* m) {
     m->attn_part.ensure((size_t)c.heads * 16 * ATTN_PART * 4);
     m->newtok.ensure((size_t)(c.heads + 2 * c.kv_heads) * 64 * 4);
     if (const char* e = getenv("CV_DECODE_FUSED_QKV")) m->fused_qkv_attn = e[0] != '0';     // dev knob for A/B runs (also: option "fused_qkv_attn")
+    if (const char* e = getenv("CV_HEAD_WAVES")) m->head_waves = atoi(e) == 7 ? 7 : 4;
     if (const char* e = getenv("CV_DECODE_PREFETCH")) m->prefetch = atoi(e);                 // dev knobs for A/B runs (also: options "prefetch", "prefetch_shift")
     if (const char* e = getenv("CV_DECODE_PREFETCH_SHIFT")) m->prefetch_shift = atoi(e);
     m->pf_sink.ensure(64);
+    if (const char* e = getenv("CV_DECODE_FUSED_O")) m->fused_attn_oproj = e[0] != '0';      // dev knobs for A/B runs (also: options "fused_attn_oproj", "oproj_rblocks")
+    if (const char* e = getenv("CV_OPROJ_RBLOCKS")) m->oproj_rblocks = atoi(e) == 8 ? 8 : 4;
+    if (const char* e = getenv("CV_OPROJ_WAVES")) m->oproj_waves = atoi(e) == 16 ? 16 : 8;
+    m->opart.ensure((size_t)16 * H * 4); m->h2.ensure(H * 4);
     m->act.ensure((size_t)c.inter * 4); m->logits.ensure((size_t)m->V * 4);
     CV_HIP(hipHostMalloc((void**)&m->host_tokens, (size_t)c.max_len * sizeof(int)));
     CV_HIP(hipHostMalloc((void**)&m->host_state, sizeof(DecodeState)));
@@ -234,7 +243,7 @@ struct ProfScope {
 static const bool g_gemv_shared_norm = [] { const char* e = getenv("CV_GEMV_SHARED_NORM"); return !(e && e[0] == '0'); }();
 
 // picks the instantiation from K (= 128 * steps): <=7 steps -> one wave per 4*ROWS rows; <=40 steps -> 4-way split-K
-static void gemv(const GemvArgs& a, int rows, hipStream_t s, int nsp = 0) {
+static void gemv(const GemvArgs& a, int rows, hipStream_t s, int nsp = 0, int waves = 4) {
     const int steps = a.K / 128;
     if (nsp > 0) {                                   // o_proj over split-attention partials (rows == 1, K = heads * 64 <= 1024)
         CV_CHECK(steps <= 8 && rows == 1 && a.mode == 0 && !a.gamma && a.part, "gemv: partial-combine prologue is for the o_proj shape only");
@@ -254,8 +263,13 @@ static void gemv(const GemvArgs& a, int rows, hipStream_t s, int nsp = 0) {
         if (a.gamma && g_gemv_shared_norm) {                 // 4 waves share the normalised input through LDS (gemv_norm_kernel)
             const dim3 g16((units + 15) / 16);
             static const bool five = [] { const char* e = getenv("CV_GEMV_GATEUP_WAVES"); return !(e && e[0] == '4'); }();   // dev knob for A/B runs
-            if (rows == 2 && five) hipLaunchKernelGGL((gemv_norm_kernel<7, 2, 5>), dim3((units + 19) / 20), dim3(320), 0, s, a);
+            if (a.opart) {                                   // gate / up behind attn_oproj_kernel: the per-head o_proj contributions join the residual in the prologue
+                CV_CHECK(rows == 2 && a.n_opart >= 1 && a.n_opart <= 16, "gemv: the o_proj-contribution prologue is for the gate / up shape, <= 16 heads");
+                hipLaunchKernelGGL((gemv_norm_kernel<7, 2, 5, true, true>), dim3((units + 19) / 20), dim3(320), 0, s, a);
+            }
+            else if (rows == 2 && five) hipLaunchKernelGGL((gemv_norm_kernel<7, 2, 5>), dim3((units + 19) / 20), dim3(320), 0, s, a);
             else if (rows == 2) hipLaunchKernelGGL((gemv_norm_kernel<7, 2>), g16, dim3(256), 0, s, a);
+            else if (waves == 7) hipLaunchKernelGGL((gemv_norm_kernel<7, 1, 7>), dim3((units + 27) / 28), dim3(448), 0, s, a);   // the head: 6564 rows as 235 seven-wave workgroups, one balanced round
             else if (a.pf.p) {                               // rows == 1 host (qkv): own workgroups, padding, then the prefetch workgroups
                 CV_CHECK(a.pf.first >= (int)g16.x, "gemv: prefetch workgroups must follow the GEMV's own");
                 hipLaunchKernelGGL((gemv_norm_kernel<7, 1>), dim3(a.pf.first + prefetch_groups(a.pf.cons_bytes, 4, 9) * a.pf.stride), dim3(256), 0, s, a);
@@ -280,7 +294,7 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
     const DecodeState* st = m->state.as<DecodeState>();
     float* h = m->h.as<float>(); float* qkv = m->qkv.as<float>(); float* act = m->act.as<float>();
     auto want = [&](int cat) { return m->only_cat < 0 || m->only_cat == cat; };
-    if (want(5)) { ProfScope ps(m, s, 5); gemv(GemvArgs{m->head_w, m->head_b, h, m->logits.as<float>(), m->V, c.hidden, m->norm, c.rms_eps, nullptr, 0, st}, m->head_rows, s); }
+    if (want(5)) { ProfScope ps(m, s, 5); gemv(GemvArgs{m->head_w, m->head_b, h, m->logits.as<float>(), m->V, c.hidden, m->norm, c.rms_eps, nullptr, 0, st}, m->head_rows, s, 0, m->head_rows == 1 ? m->head_waves : 4); }
     SampleArgs sa{};
     sa.logits = m->logits.as<float>(); sa.V = m->V; sa.sp = m->sparams.as<SampleParams>(); sa.uniforms = m->uniforms.as<float>();
     sa.st = m->state.as<DecodeState>(); sa.tokens = m->tokens.as<int>(); sa.max_tokens = c.max_len;
@@ -302,6 +316,26 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
             pgu.n_cons = (2 * c.inter + gu_rows - 1) / gu_rows; pgu.stride = round8(pgu.n_cons); pgu.shift = m->prefetch_shift; pgu.sink = m->pf_sink.as<unsigned>();
             pdn.p = reinterpret_cast<const char*>(L.wdown); pdn.bytes = 2LL * c.hidden * c.inter; pdn.cons_bytes = 4 * c.inter * 2;
             pdn.n_cons = (c.hidden + 3) / 4; pdn.stride = round8(pdn.n_cons); pdn.shift = m->prefetch_shift; pdn.sink = pgu.sink;
+        }
+        if (m->fused_attn_oproj && !m->fused_qkv_attn) {
+            // qkv -> attention + per-head o_proj contributions -> gate / up (residual + contributions in its prologue, h2 = the new residual) -> down (+ h2)
+            if (want(0)) { ProfScope ps(m, s, 0); gemv(GemvArgs{L.wqkv, L.bqkv, h, qkv, m->qkv_dim, c.hidden, L.ln1, c.rms_eps, nullptr, 0, st}, 1, s); }
+            const int R = m->oproj_rblocks, rpb = ((c.hidden + R - 1) / R + 7) / 8 * 8;
+            CV_CHECK(rpb <= 256 && c.heads <= 16, "fused_attn_oproj: hidden / oproj_rblocks must be <= 256 rows, heads <= 16");
+            AttnOprojArgs ao{qkv, m->kcache.as<float>() + m->layer_cache() * i, m->vcache.as<float>() + m->layer_cache() * i, m->rope_cos.as<float>(), m->rope_sin.as<float>(),
+                             c.heads, c.kv_heads, c.max_len, st, L.wo, c.hidden, m->opart.as<float>(), (c.hidden + rpb - 1) / rpb, rpb};
+            if (want(1)) {
+                ProfScope ps(m, s, 1);
+                if (m->oproj_waves == 16) hipLaunchKernelGGL((attn_oproj_kernel<16, 2, 6>), dim3(c.heads * ao.rblocks), dim3(1024), 0, s, ao);   // 384 keys per pass
+                else hipLaunchKernelGGL((attn_oproj_kernel<8, 4, 10>), dim3(c.heads * ao.rblocks), dim3(512), 0, s, ao);                         // 320 keys per pass
+            }
+            GemvArgs gg{L.wgu, nullptr, h, act, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 1, st};
+            gg.opart = m->opart.as<float>(); gg.n_opart = c.heads; gg.x_out = m->h2.as<float>();
+            if (want(3)) { ProfScope ps(m, s, 3); gemv(gg, 2, s); }
+            GemvArgs gd2{L.wdown, nullptr, act, h, c.hidden, c.inter, nullptr, 0.f, m->h2.as<float>(), 0, st};
+            if (i == c.layers - 1 && m->only_cat < 0) gd2.advance = m->state.as<DecodeState>();
+            if (want(4)) { ProfScope ps(m, s, 4); gemv(gd2, 1, s); }
+            continue;
         }
         if (m->fused_qkv_attn) {
             float* qn = m->newtok.as<float>(); float* kn = qn + c.heads * 64; float* vn = kn + c.kv_heads * 64;
@@ -678,6 +712,13 @@ int cv_llm_set_option(cv_llm* m, const char* name, int32_t value) {
         std::lock_guard<std::recursive_mutex> lk(runtime_lock());
         if (std::string(name) == "use_graph") { m->use_graph = value != 0; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; } }
         else if (std::string(name) == "head_rows") { CV_CHECK(value == 1 || value == 2, "head_rows must be 1 or 2"); m->head_rows = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; } }
+        else if (std::string(name) == "fused_attn_oproj" || std::string(name) == "oproj_rblocks" || std::string(name) == "oproj_waves") {
+            CV_CHECK(std::string(name) != "oproj_rblocks" || value == 4 || value == 8, "oproj_rblocks must be 4 or 8");
+            CV_CHECK(std::string(name) != "oproj_waves" || value == 8 || value == 16, "oproj_waves must be 8 or 16");
+            (std::string(name) == "fused_attn_oproj" ? m->fused_attn_oproj : std::string(name) == "oproj_rblocks" ? m->oproj_rblocks : m->oproj_waves) = value;
+            if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+        }
+        else if (std::string(name) == "head_waves") { CV_CHECK(value == 4 || value == 7, "head_waves must be 4 or 7"); m->head_waves = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; } }
         else if (std::string(name) == "fused_qkv_attn") { m->fused_qkv_attn = value != 0; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; } }
         else if (std::string(name) == "prefetch" || std::string(name) == "prefetch_shift") {
             CV_CHECK(std::string(name) != "prefetch" || (value >= 0 && value <= 2), "prefetch must be 0, 1 or 2");

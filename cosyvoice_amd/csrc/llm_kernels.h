@@ -82,6 +82,9 @@ struct GemvArgs {
     const float* qnew = nullptr; const float* knew = nullptr; const float* vnew = nullptr; int kv_group = 1;
     DecodeState* advance = nullptr;   // last GEMV of a backbone step: also advances the KV length (no kernel of the step reads `pos` after it)
     PrefetchArgs pf;                  // workgroups >= pf.first of the launch only prefetch a later kernel's weights (prefetch_role)
+    // gemv_norm_kernel only (attn_oproj_kernel upstream): the input is x + sum_{j < n_opart} opart[j][K] (per-head o_proj contributions added to
+    // the residual in a fixed order); workgroup 0 also stores that sum to x_out (the residual the down projection adds to).
+    const float* opart = nullptr; int n_opart = 0; float* x_out = nullptr;
 };
 
 constexpr int ATTN_PART = 68;      // 64 unnormalised numerators + running max + denominator (+2 pad: rows stay 16-byte aligned)
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
 // XFIRST (round 3): x and gamma are requested BEFORE the weight rows.  vmcnt retires loads in issue order, so with x behind the weight stream
 // (round 2) the normalisation - and both of its barriers - could only start once the workgroup's last weight byte had landed; requested ahead of
 // the stream (two L2 hits), x is normalised and parked in LDS while the weights are still in flight and the FMAs start on the first row that lands.
-template <int STEPS, int ROWS, int WAVES = 4, bool XFIRST = true>
+template <int STEPS, int ROWS, int WAVES = 4, bool XFIRST = true, bool OPART = false>
 __global__ __launch_bounds__(WAVES * 64) void gemv_norm_kernel(GemvArgs p) {
     __shared__ __attribute__((aligned(16))) float xs[STEPS * 128];
     __shared__ float red[WAVES];
@@ -276,6 +279,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_norm_kernel(GemvArgs p) {
     float4 xv, gv;
     if constexpr (XFIRST) {
         xv = *reinterpret_cast<const float4*>(p.x + (have ? tid * 4 : 0)); gv = *reinterpret_cast<const float4*>(p.gamma + (have ? tid * 4 : 0));
+    }
+    constexpr int MAXP = 16;                                 // per-head o_proj contributions (attn_oproj_kernel), requested ahead of the weight stream like x
+    float4 op[OPART ? MAXP : 1];
+    if constexpr (OPART) {
+        static_assert(XFIRST, "the o_proj contributions are requested with x");
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) op[j] = *reinterpret_cast<const float4*>(p.opart + (long long)min(j, p.n_opart - 1) * p.K + (have ? tid * 4 : 0));
     }
 
     u32x4 w[ROWS][STEPS];
@@ -294,6 +304,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_norm_kernel(GemvArgs p) {
     {
         const int k = have ? tid * 4 : 0;
         if constexpr (!XFIRST) { xv = *reinterpret_cast<const float4*>(p.x + k); gv = *reinterpret_cast<const float4*>(p.gamma + k); }
+        if constexpr (OPART) {
+#pragma unroll
+            for (int j = 0; j < MAXP; ++j) if (j < p.n_opart) { xv.x += op[j].x; xv.y += op[j].y; xv.z += op[j].z; xv.w += op[j].w; }
+            if (blockIdx.x == 0 && have && p.x_out) *reinterpret_cast<float4*>(p.x_out + k) = xv;
+        }
         if (!have) xv = make_float4(0.f, 0.f, 0.f, 0.f);
         float ss = wave_sum(xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w);
         if (lane == 0) red[wave] = ss;
@@ -440,6 +455,149 @@ static __global__ __launch_bounds__(64) void attn_decode_kernel(AttnDecodeArgs p
     float* pr = p.part + (long long)blockIdx.x * ATTN_PART;
     if (grp == 0) *reinterpret_cast<float4*>(pr + d0) = acc;
     if (lane == 0) { pr[64] = (l_run > 0.f) ? m_run : 0.f; pr[65] = l_run; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Decode attention + o_proj in ONE launch (round 3): the o_proj GEMV split over K by HEAD instead of over rows only.
+//   y = h + Wo . a,  a = [a_0 .. a_{H-1}]   =>   y = h + sum_h  Wo[:, 64 h : 64 h + 64] . a_h
+// Workgroup (head h, row block rb) runs the whole attention of head h - NW waves, wave w over the w-th key slice exactly like
+// attn_decode_kernel's single wave (RoPE in registers, online softmax, KV append by slice 0), merged through LDS - and then multiplies its
+// rows of Wo's 64-column slice of head h with a_h: an un-summed per-head contribution  opart[h][row].  The H contributions are added to the
+// residual by the NEXT kernel's prologue (gemv_norm_kernel, GemvArgs::opart: 14 more float4 per thread, requested ahead of its weight
+// stream), in a fixed order.  One launch boundary and one global round trip (attention partials -> o_proj) less per layer; the price is that
+// the R row blocks of a head each read the head's whole K / V range (R x 2 x L x 256 B through one CU instead of 1 / 8 of it per wave).
+// The Wo fragment of a workgroup is requested first (ITERS x 16 B per lane), so the GEMV needs no further round trip after the merge.
+// ---------------------------------------------------------------------------------------------------------------
+struct AttnOprojArgs {
+    const float* qkv; float* kcache; float* vcache; const float* rope_cos; const float* rope_sin;
+    int heads, kv_heads, max_len; const DecodeState* st;
+    const bf16_t* wo; int hidden;        // Wo [hidden][heads * 64] bf16 row-major
+    float* opart;                        // [heads][hidden] fp32
+    int rblocks, rows_per_block;         // gridDim.x = heads * rblocks; rows_per_block <= 8 * NW * ITERS
+};
+
+template <int NW, int ITERS, int NS>                // NS key slots per lane group and pass: a wave takes 4 * NS keys per pass (<8, 4, 10>: 224 registers, <16, 2, 6>: 128 - no scratch)
+__global__ __launch_bounds__(NW * 64) void attn_oproj_kernel(AttnOprojArgs p) {
+    constexpr int PASS = 4 * NS;
+    __shared__ __attribute__((aligned(16))) float pw[NW][ATTN_PART];
+    __shared__ __attribute__((aligned(16))) float as[64];
+    __shared__ u32x4 wlds[ITERS][NW * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15, grp = lane >> 4;
+    const int h = blockIdx.x / p.rblocks, rb = blockIdx.x % p.rblocks, gsz = p.heads / p.kv_heads, g = h / gsz;
+    // this workgroup's rows of Wo[:, 64 h .. 64 h + 63]: 8 lanes per row (16 B each), 8 rows per wave and iteration - requested before anything else
+    const int sub8 = lane & 7, rgrp = lane >> 3;
+    const int row_lo = rb * p.rows_per_block, row_hi = min(p.hidden, row_lo + p.rows_per_block);
+    u32x4 wv[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int row = min(row_lo + (it * NW + wave) * 8 + rgrp, p.hidden - 1);
+        wv[it] = *reinterpret_cast<const u32x4*>(p.wo + (long long)row * (p.heads * 64) + h * 64 + sub8 * 8);
+    }
+    const int pos = p.st->pos;                       // the new token sits at index `pos`
+    const int L = pos + 1;
+    const int per = ((L + NW * 4 - 1) / (NW * 4)) * 4;                       // keys per slice (multiple of 4)
+    const int kb = wave * per, ke = min(L, kb + per);
+    const float* kc = p.kcache + (long long)g * p.max_len * 64;
+    const float* vc = p.vcache + (long long)g * p.max_len * 64;
+    float4 k4[NS], v4[NS];
+    auto load_pass = [&](int base) {
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            const int j = base + sl * 4 + grp;
+            const unsigned o = (unsigned)(((j < pos && j < ke) ? j : 0) * 64 + sub * 4);      // unconditional, clamped; 32-bit offset from a uniform base (saddr form: no 64-bit address pair per load)
+            k4[sl] = *reinterpret_cast<const float4*>(kc + o);
+            v4[sl] = *reinterpret_cast<const float4*>(vc + o);
+        }
+    };
+    load_pass(kb);
+    // the Wo fragment was requested first, so it lands first (vmcnt retires in order): park it in LDS (each lane its own slots, no barrier) - 16
+    // registers less across the attention, and the K / V loads stay in flight behind the counted wait
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) wlds[it][tid] = wv[it];
+    const float* qraw = p.qkv + h * 64;
+    const float* kq = p.qkv + p.heads * 64 + g * 64;
+    const float* vq = p.qkv + (p.heads + p.kv_heads) * 64 + g * 64;
+    const int d0 = sub * 4, dp = (d0 + 32) & 63;
+    const float4 c4 = *reinterpret_cast<const float4*>(p.rope_cos + pos * 32 + (d0 & 31));
+    const float4 s4 = *reinterpret_cast<const float4*>(p.rope_sin + pos * 32 + (d0 & 31));
+    const float4 qa = *reinterpret_cast<const float4*>(qraw + d0), qb = *reinterpret_cast<const float4*>(qraw + dp);
+    const float4 ka = *reinterpret_cast<const float4*>(kq + d0), kp = *reinterpret_cast<const float4*>(kq + dp);
+    const float4 vn4 = *reinterpret_cast<const float4*>(vq + d0);
+    const float sg = d0 < 32 ? -1.f : 1.f;
+    const float4 q4 = make_float4(qa.x * c4.x + sg * qb.x * s4.x, qa.y * c4.y + sg * qb.y * s4.y, qa.z * c4.z + sg * qb.z * s4.z, qa.w * c4.w + sg * qb.w * s4.w);
+    const float4 kn4 = make_float4(ka.x * c4.x + sg * kp.x * s4.x, ka.y * c4.y + sg * kp.y * s4.y, ka.z * c4.z + sg * kp.z * s4.z, ka.w * c4.w + sg * kp.w * s4.w);
+    if (!p.st->done && wave == 0 && rb == 0 && h % gsz == 0 && grp == 0) {  // KV-cache append: one wave per kv head
+        *reinterpret_cast<float4*>(p.kcache + ((long long)g * p.max_len + pos) * 64 + d0) = kn4;
+        *reinterpret_cast<float4*>(p.vcache + ((long long)g * p.max_len + pos) * 64 + d0) = vn4;
+    }
+    const float NEG = -__builtin_huge_valf();
+    float m_run = NEG, l_run = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = kb; base < ke; base += PASS) {   // wave-uniform
+        if (base != kb) load_pass(base);
+        float sc[NS];
+        float mt = NEG;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            const int j = base + sl * 4 + grp;
+            const float4 kk = (j == pos) ? kn4 : k4[sl];
+            float a = q4.x * kk.x + q4.y * kk.y + q4.z * kk.z + q4.w * kk.w;
+            a = group16_sum(a) * 0.125f;
+            sc[sl] = j < ke ? a : NEG;
+            mt = fmaxf(mt, sc[sl]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        const float scale = (m_run == NEG) ? 0.f : expf(m_run - m_new);
+        acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+        float lt = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            const int j = base + sl * 4 + grp;
+            const float e = (sc[sl] == NEG) ? 0.f : expf(sc[sl] - m_new);
+            const float4 vv = (j == pos) ? vn4 : v4[sl];
+            acc.x += e * vv.x; acc.y += e * vv.y; acc.z += e * vv.z; acc.w += e * vv.w;
+            lt += e;
+        }
+        l_run = l_run * scale + lt;
+        m_run = m_new;
+    }
+    acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
+    acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+    l_run += __shfl_xor(l_run, 16); l_run += __shfl_xor(l_run, 32);
+    if (grp == 0) *reinterpret_cast<float4*>(&pw[wave][d0]) = acc;
+    if (lane == 0) { pw[wave][64] = (l_run > 0.f) ? m_run : 0.f; pw[wave][65] = l_run; }
+    __syncthreads();
+    if (tid < 16) {                                  // flash-decoding merge of the NW slices (fixed order), normalised: a_h
+        float M = NEG;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) if (pw[w][65] > 0.f) M = fmaxf(M, pw[w][64]);
+        float den = 0.f; float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float wgt = (pw[w][65] > 0.f) ? expf(pw[w][64] - M) : 0.f;
+            const float4 t = *reinterpret_cast<const float4*>(&pw[w][tid * 4]);
+            den += wgt * pw[w][65];
+            a.x += wgt * t.x; a.y += wgt * t.y; a.z += wgt * t.z; a.w += wgt * t.w;
+        }
+        const float inv = 1.f / den;
+        *reinterpret_cast<float4*>(&as[tid * 4]) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+    }
+    __syncthreads();
+    const float4 xa = *reinterpret_cast<const float4*>(&as[sub8 * 8]), xb = *reinterpret_cast<const float4*>(&as[sub8 * 8 + 4]);
+    float* out = p.opart + (long long)h * p.hidden;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const u32x4 u = wlds[it][tid];
+        float a = 0.f;
+        a += __uint_as_float(u[0] << 16) * xa.x;          a += __uint_as_float(u[0] & 0xffff0000u) * xa.y;
+        a += __uint_as_float(u[1] << 16) * xa.z;          a += __uint_as_float(u[1] & 0xffff0000u) * xa.w;
+        a += __uint_as_float(u[2] << 16) * xb.x;          a += __uint_as_float(u[2] & 0xffff0000u) * xb.y;
+        a += __uint_as_float(u[3] << 16) * xb.z;          a += __uint_as_float(u[3] & 0xffff0000u) * xb.w;
+        a += dpp_row<0xB1>(a); a += dpp_row<0x4E>(a); a += dpp_row<0x141>(a);           // sum over the 8 lanes of a row
+        const int row = row_lo + (it * NW + wave) * 8 + rgrp;
+        if (sub8 == 0 && row < row_hi) out[row] = a;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

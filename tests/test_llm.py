@@ -228,6 +228,32 @@ def test_fused_qkv_attention_variant(lib, tiny_sd, splits, n_prompt):
         torch.testing.assert_close(lm.last_logits().log_softmax(-1), trace["logp"][i], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("rblocks,waves,n_prompt", [(4, 8, 11), (8, 8, 430), (4, 16, 430)])
+def test_fused_attention_oproj_variant(lib, tiny_sd, rblocks, waves, n_prompt):
+    """Option fused_attn_oproj = 1 (round 3, attn_oproj_kernel): attention and the o_proj GEMV in one launch, o_proj split by head, the per-head
+    contributions summed into the residual by gate / up's prologue (gemv_norm_kernel<.., OPART>) - 4 launches per layer instead of 5.  Same tokens
+    as the oracle and the same log-probabilities within the usual bound, for a one-pass context and for one whose key slices take several passes
+    (430 + keys over 8 slices of 40 or 16 slices of 24 per pass), 4 and 8 row blocks per head; the KV cache it appends to serves the plain chain afterwards."""
+    import ctypes as C
+    cfg, sd = tiny_sd
+    u = _utt(cfg, n_prompt_tok=n_prompt)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=512, sampling="greedy", decode_chunk=6)
+    lib.cv_llm_set_option(lm._h, b"fused_attn_oproj", C.c_int32(1))
+    lib.cv_llm_set_option(lm._h, b"oproj_rblocks", C.c_int32(rblocks))
+    lib.cv_llm_set_option(lm._h, b"oproj_waves", C.c_int32(waves))
+    got = list(lm.inference(**_kw(u), max_token_text_ratio=2, min_token_text_ratio=2))
+    trace = {}
+    want = OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=2, min_token_text_ratio=2, trace=trace)
+    assert got == want
+    lm.prefill(lm.build_lm_input(u["text"], u["prompt_text"], u["llm_prompt_speech_token"]))
+    sp = lm.make_sampling(6, 12)
+    for i in range(min(3, len(want) + 1)):
+        if i == 2:                                                 # the third step on the plain five-launch chain, over the cache the fused launches appended to
+            lib.cv_llm_set_option(lm._h, b"fused_attn_oproj", C.c_int32(0))
+        lm.decode(1, sp)
+        torch.testing.assert_close(lm.last_logits().log_softmax(-1), trace["logp"][i], rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("mode,shift", [(1, 0), (2, 0), (1, 3)])
 def test_decode_weight_prefetch_is_only_a_hint(lib, tiny_sd, mode, shift):
     """Option prefetch = 1 / 2 (round 3): extra workgroups of the short decode kernels (qkv / attention / o_proj) read the weights the gate / up and
@@ -242,6 +268,8 @@ def test_decode_weight_prefetch_is_only_a_hint(lib, tiny_sd, mode, shift):
     lm.decode(2, lm.make_sampling(6, 12)); ref_logits = lm.last_logits().clone()
     lib.cv_llm_set_option(lm._h, b"prefetch", C.c_int32(mode))
     lib.cv_llm_set_option(lm._h, b"prefetch_shift", C.c_int32(shift))
+    if mode == 2:                                                  # and the head as seven-wave workgroups (option head_waves): same rows, same FMA order
+        lib.cv_llm_set_option(lm._h, b"head_waves", C.c_int32(7))
     assert list(lm.inference(**_kw(u), max_token_text_ratio=2, min_token_text_ratio=2)) == ref
     lm.prefill(lm.build_lm_input(u["text"], u["prompt_text"], u["llm_prompt_speech_token"]))
     lm.decode(2, lm.make_sampling(6, 12))
