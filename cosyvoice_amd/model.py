@@ -89,6 +89,8 @@ class CosyVoice2Model:
         self.set_lanes(1)
         self.tts_speech_token_dict, self.llm_end_dict, self.hift_cache_dict, self._cond = {}, {}, {}, {}
         self._llm_error = {}                   # uuid -> exception raised on the LLM thread, re-raised by tts() on the caller's thread
+        self.first_chunk_exclusive = True      # tts(stream=True): the LM pauses after the first chunk's tokens until that chunk has been vocoded (llm_job)
+        self._first_gate = {}                  # uuid -> threading.Event
         self.silent_tokens = []
         self._warmup()
 
@@ -189,12 +191,20 @@ class CosyVoice2Model:
                     gen = self.llm.inference(text=text, text_len=t(text.shape[1]), prompt_text=prompt_text, prompt_text_len=t(prompt_text.shape[1]),
                                              prompt_speech_token=llm_prompt_speech_token, prompt_speech_token_len=t(llm_prompt_speech_token.shape[1]),
                                              embedding=llm_embedding, uuid=uuid, **({} if first_chunk is None else {"first_chunk": first_chunk}))
+                gate = self._first_gate.get(uuid)
                 for i in gen:
                     if not keep(i):
                         continue
                     with cond:
                         self.tts_speech_token_dict[uuid].append(i)
                         cond.notify_all()
+                        n = len(self.tts_speech_token_dict[uuid])
+                    if gate is not None and first_chunk is not None and n >= first_chunk:
+                        # first_chunk_exclusive: the tokens of the first audio chunk are out; the decode chain steps aside until that chunk's flow + HiFT
+                        # have run (tts() sets the gate), so the listener's first audio is not stretched by the LM racing ahead on the same GPU.  The LM
+                        # runs ~5x faster than playback: the tokens of the second chunk are still there long before they are needed.
+                        gate.wait(timeout=30.0)          # (always set by tts(): after the first chunk, or in its finally)
+                        gate = None
         except BaseException as e:             # a thread's exception would only reach threading.excepthook: hand it to tts()
             self._llm_error[uuid] = e
         finally:
@@ -460,6 +470,8 @@ class CosyVoice2Model:
             if stream is True and self.flow is not None:       # tokens the first audio chunk waits for (cli/model.py:345-349)
                 hop0 = self.token_hop_len
                 first_need = int(np.ceil(flow_prompt_speech_token.shape[1] / hop0) * hop0 - flow_prompt_speech_token.shape[1]) + hop0 + self.flow.pre_lookahead_len
+                if self.first_chunk_exclusive and not isinstance(text, GeneratorType):
+                    self._first_gate[this_uuid] = threading.Event()
             p = threading.Thread(target=self.llm_job, args=(text, prompt_text, llm_prompt_speech_token, llm_embedding, this_uuid, first_need))
         else:
             p = threading.Thread(target=self.vc_job, args=(source_speech_token, this_uuid))
@@ -488,7 +500,11 @@ class CosyVoice2Model:
                                                          embedding=flow_embedding, token_offset=token_offset, uuid=this_uuid, stream=stream, finalize=False)
                         token_offset += this_token_hop_len
                         token_hop_len = min(self.token_max_hop_len, token_hop_len * self.stream_scale_factor)
-                        yield {"tts_speech": this_tts_speech.cpu()}
+                        out = {"tts_speech": this_tts_speech.cpu()}
+                        gate = self._first_gate.get(this_uuid)
+                        if gate is not None:
+                            gate.set()                         # first chunk is on the host: the LM carries on
+                        yield out
                     elif ended:
                         break
                 p.join()
@@ -505,6 +521,9 @@ class CosyVoice2Model:
                                                  embedding=flow_embedding, token_offset=0, uuid=this_uuid, finalize=True, speed=speed)
                 yield {"tts_speech": this_tts_speech.cpu()}
         finally:
+            gate = self._first_gate.pop(this_uuid, None)
+            if gate is not None:
+                gate.set()
             p.join()
             with self.lock:
                 self.tts_speech_token_dict.pop(this_uuid, None)

@@ -33,6 +33,9 @@ def test_tts_matches_oracle(lib, setup, stream):
     cfgs, sds, u = setup
     lc, fc, hc = cfgs
     m = _build(lib, cfgs, sds)
+    seen = []                                  # tokens the LM had delivered when each token2wav call returned
+    t2w = m.token2wav
+    m.token2wav = lambda **kw: (t2w(**kw), seen.append(len(m.tts_speech_token_dict[kw["uuid"]])))[0]
     # the ratio arguments are fixed inside llm_job (20 / 2), so the length is set through the text: 2 text tokens -> 4..40 tokens
     outs = [o["tts_speech"] for o in m.tts(text=u["text"], flow_embedding=u["flow_embedding"], llm_embedding=u["llm_embedding"], prompt_text=u["prompt_text"],
                                            llm_prompt_speech_token=u["llm_prompt_speech_token"], flow_prompt_speech_token=u["flow_prompt_speech_token"],
@@ -48,6 +51,9 @@ def test_tts_matches_oracle(lib, setup, stream):
         torch.testing.assert_close(a, b, rtol=0, atol=5e-3)
     assert sum(o.shape[1] for o in outs) == len(tokens) * 2 * 480
     assert not m.tts_speech_token_dict and not m.hift_cache_dict             # per-request state is cleaned up (cli/model.py:388-391)
+    if stream:                                 # first_chunk_exclusive: the LM stood still while the first chunk was vocoded (hop 5 + pad 5 - 4 + look-ahead 3 tokens)
+        first_need = 5 + (-u["flow_prompt_speech_token"].shape[1]) % 5 + m.flow.pre_lookahead_len
+        assert seen[0] == first_need and seen[-1] == len(tokens) and not m._first_gate
 
 
 def test_speed_and_vc(lib, setup):
