@@ -63,6 +63,7 @@ struct cv_flow {
     int fused = 1;                     // bf16 mode: LN-prologue GEMMs + bf16 activations + bf16 flash attention for the transformer blocks
     // tuning knobs of the fused pipeline.  "flow_tile": 0 = by size (one round of workgroups, see ln_gemm_bf16), 1 = 64x64, 2 = 64x128, 3 = 32x64,
     // 4 = 64x192; "attn_waves": 2 | 4 waves (32 | 64 queries) per workgroup; "attn_kt": 64-key tiles per iteration (1 | 2)
+    int flow_ntile = 0;                // "flow_ntile": N tiles per workgroup of the LayerNorm-prologue GEMMs: 0 = by grid size (two when that makes one round), 1, 2 (env CV_FLOW_NTILE)
     int flow_tile = 0, attn_waves = 4, attn_kt = 1, attn_ks = 2;   // "attn_ks": key splits inside a 64-query workgroup (2 = 8 waves, 128 keys per iteration)
     DevBuf t_val, t_sin, t_h, t_emb, t_mlp;                                                   // time embeddings
     DevBuf f_tok, f_h, f_mu, f_spk, f_spkn, f_cond, f_x, f_ones;                              // inference glue
@@ -182,6 +183,7 @@ static void flow_finalize(cv_flow* m) {
         }
         m->stages.push_back(st);
     }
+    if (const char* e = getenv("CV_FLOW_NTILE")) m->flow_ntile = atoi(e);
     if (const char* e = getenv("CV_FLOW_TAIL")) m->fused_tail = e[0] != '0';        // dev knob for A/B runs (also: option "fused_tail")
     if (const char* e = getenv("CV_FLOW_TAIL_RING")) m->tail_ring = atoi(e) == 16 ? 16 : 8;
     m->down_conv = get_lin(m, "est.down_conv", C, C, 3, true); m->up_conv = get_lin(m, "est.up_conv", C, C, 3, true);
@@ -192,13 +194,13 @@ static void flow_finalize(cv_flow* m) {
 
 // precision of the Linear / Conv1d products issued by the current entry point (set from the handle's option for the duration of a call)
 static thread_local int tl_bf16_mfma = 0;
-static thread_local int tl_flow_tile = 0, tl_attn_waves = 4, tl_attn_kt = 2, tl_attn_ks = 1;     // tuning knobs of the fused pipeline, per call like the precision
+static thread_local int tl_flow_tile = 0, tl_attn_waves = 4, tl_attn_kt = 2, tl_attn_ks = 1, tl_flow_ntile = 0;     // tuning knobs of the fused pipeline, per call like the precision
 struct PrecisionScope {
-    int prev, pt, pw, pk, ps;
-    explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves), pk(tl_attn_kt), ps(tl_attn_ks) {
-        tl_bf16_mfma = m->bf16_mfma; tl_flow_tile = m->flow_tile; tl_attn_waves = m->attn_waves; tl_attn_kt = m->attn_kt; tl_attn_ks = m->attn_ks;
+    int prev, pt, pw, pk, ps, pn;
+    explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves), pk(tl_attn_kt), ps(tl_attn_ks), pn(tl_flow_ntile) {
+        tl_bf16_mfma = m->bf16_mfma; tl_flow_tile = m->flow_tile; tl_attn_waves = m->attn_waves; tl_attn_kt = m->attn_kt; tl_attn_ks = m->attn_ks; tl_flow_ntile = m->flow_ntile;
     }
-    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; tl_attn_ks = ps; }
+    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; tl_attn_ks = ps; tl_flow_ntile = pn; }
 };
 
 // ---- generic conv/linear on channel-last activations -----------------------------------------------------------------
@@ -366,7 +368,14 @@ static void ln_gemm_bf16(const Lin& l, const LN* ln, float eps, const float* x, 
     auto grid = [&](int bm, int bn) { return dim3((unsigned)(((M + bm - 1) / bm) * ((l.N + bn - 1) / bn))); };
     if (tile == 1) hipLaunchKernelGGL((flow_gemm_kernel<64, 64, 1, 0>), grid(64, 64), dim3(256), 0, s, a);
     else if (tile == 2) hipLaunchKernelGGL((flow_gemm_kernel<64, 128, 1, 0>), grid(64, 128), dim3(256), 0, s, a);
-    else if (tile == 3) hipLaunchKernelGGL((flow_gemm_kernel<32, 64, 1, 0>), grid(32, 64), dim3(256), 0, s, a);
+    else if (tile == 3) {
+        // two N tiles per workgroup when the single-tile grid would not fit the 768 resident workgroups (3 per CU) in one round but half of it does
+        // (QKV at T = 674: 1032 -> 516 workgroups; FF1 has 688 and stays single-tile): the LayerNorm prologue is paid once per pair
+        const unsigned g1 = grid(32, 64).x;
+        if (tl_flow_ntile != 1 && (tl_flow_ntile == 2 || (g1 > 768 && g1 <= 1536)) && l.N % 128 == 0)
+            hipLaunchKernelGGL((flow_gemm_kernel<32, 64, 1, 0, 2>), grid(32, 128), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((flow_gemm_kernel<32, 64, 1, 0>), grid(32, 64), dim3(256), 0, s, a);
+    }
     else hipLaunchKernelGGL((flow_gemm_kernel<64, 192, 1, 0>), grid(64, 192), dim3(256), 0, s, a);
 }
 // C = A_bf16 W^T + b (+ res), fp32
@@ -716,6 +725,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "attn_waves") { CV_CHECK(value == 2 || value == 4, "attn_waves must be 2 or 4"); m->attn_waves = value; drop_graphs(m); }
         else if (std::string(name) == "est_streams") { CV_CHECK(value == 1 || value == 2, "est_streams must be 1 or 2"); m->est_streams = value; drop_graphs(m); }
         else if (std::string(name) == "fused_tail") { m->fused_tail = value != 0; drop_graphs(m); }
+        else if (std::string(name) == "flow_ntile") { CV_CHECK(value >= 0 && value <= 2, "flow_ntile must be 0, 1 or 2"); m->flow_ntile = value; drop_graphs(m); }
         else if (std::string(name) == "tail_ring") { m->tail_ring = value == 16 ? 16 : 8; drop_graphs(m); }      // bf16 mode: one row-band launch after each attention (flow_tail.h) on / off
         else if (std::string(name) == "fused") { m->fused = value != 0; drop_graphs(m); }              // bf16 mode: fused transformer blocks (flow_fused.h) on / off
         else throw Error(std::string("unknown option ") + name);

@@ -33,7 +33,10 @@ struct FlowGemmArgs {
 __device__ __forceinline__ int vt_col(int t) { return (t & ~31) + ((t >> 2) & 3) * 8 + ((t >> 4) & 1) * 4 + (t & 3); }
 
 // BM x BN output tile per workgroup (256 threads, 2 x 2 waves), K staged in chunks of 256 (the whole K for the LN-prologue GEMMs).
-template <int BM, int BN, int AMODE, int OMODE>
+// NTILE (AMODE 1 only, round 3): a workgroup walks NTILE consecutive BN-column tiles of the SAME rows - the LayerNorm prologue and the A tile in LDS
+// are paid once, the next tile's weights are requested before the current tile's MFMAs and land under them and under its epilogue.  The QKV GEMM
+// at T = 674 (1032 single-tile workgroups = 1.34 rounds of the 768 resident ones) becomes 516 two-tile workgroups in ONE round.
+template <int BM, int BN, int AMODE, int OMODE, int NTILE = 1>
 __global__ __launch_bounds__(256) void flow_gemm_kernel(FlowGemmArgs p) {
     constexpr int KC = 256, LDK = KC / 2 + 4;                 // LDS row pitch in dwords (bf16 pairs + 4 dwords of padding)
     constexpr int TM = BM / 32, TN = BN / 32;                 // 16 x 16 MFMA tiles per wave (wave tile = BM/2 x BN/2)
@@ -44,9 +47,11 @@ __global__ __launch_bounds__(256) void flow_gemm_kernel(FlowGemmArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned Ws[BN * LDK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
-    const int ntn = (p.N + BN - 1) / BN;
+    static_assert(NTILE == 1 || AMODE == 1, "several N tiles per workgroup: LayerNorm-prologue GEMMs only");
+    const int ntn = (p.N + BN * NTILE - 1) / (BN * NTILE);
     const int bl = xcd_remap((int)blockIdx.x, (int)gridDim.x);        // an XCD walks the N tiles of a band of rows: A crosses the fabric once
-    const int m0 = (bl / ntn) * BM, n0 = (bl % ntn) * BN;
+    const int m0 = (bl / ntn) * BM;
+    int n0 = (bl % ntn) * BN * NTILE;                                 // first column of the CURRENT tile
     const int nchunks = (p.K + KC - 1) / KC;
     long long* dbg = p.dbg ? p.dbg + (long long)blockIdx.x * 8 : nullptr;
     int dn = 0;
@@ -54,21 +59,24 @@ __global__ __launch_bounds__(256) void flow_gemm_kernel(FlowGemmArgs p) {
     stamp();
     // V^T section (OMODE 0): decided per 16-column MFMA tile (wave-uniform), so that n_row only has to be a multiple of 16
     bool tr[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) tr[j] = OMODE == 0 && n0 + wn * (BN / 2) + j * 16 >= p.n_row;
-
     v4f acc[TM][TN];
+    auto begin_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) tr[j] = OMODE == 0 && n0 + wn * (BN / 2) + j * 16 >= p.n_row;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+    };
+    begin_tile();
 
     // ---- W chunk: thread t stages 16-byte pieces v = t + 256 i: row v / 32, k = 8 (v % 32)
     u32x4_t rw[WV];
-    auto load_w = [&](int kc0) {
+    auto load_w = [&](int kc0, int nb = -1) {
+        const int nbase = nb < 0 ? n0 : nb;
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
-            const int v = tid + 256 * i, n = min(n0 + v / 32, p.N - 1), k = kc0 + 8 * (v % 32);
+            const int v = tid + 256 * i, n = min(nbase + v / 32, p.N - 1), k = kc0 + 8 * (v % 32);
             rw[i] = *reinterpret_cast<const u32x4_t*>(p.W + (long long)n * p.Kp + min(k, p.Kp - 8));      // clamped: steps beyond Kp are never multiplied
         }
     };
@@ -111,6 +119,59 @@ __global__ __launch_bounds__(256) void flow_gemm_kernel(FlowGemmArgs p) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, wf[j]), __builtin_bit_cast(v8bf, af[i]), acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- epilogue (of the current tile: n0)
+    auto epilogue = [&]() {
+        if constexpr (OMODE == 1) {
+    #pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+                if (m >= p.M) continue;
+    #pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+                    if (n >= p.N) continue;                       // N % 4 == 0 (host check): a group of 4 columns is entirely in or out
+                    float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                    const long long idx = (long long)m * p.ldc + n;
+                    if (p.res) { const float4 r = *reinterpret_cast<const float4*>(p.res + idx); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+                    *reinterpret_cast<float4*>(p.C + idx) = v;
+                }
+            }
+        } else {
+    #pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (!tr[j]) {
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+                        const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+                        if (m >= p.M || n >= p.N) continue;
+                        float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                        if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                        v = apply_act4(p.act, v, 0.f);
+                        *reinterpret_cast<uint2*>(p.out + (long long)m * p.ldo + n) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                    }
+                } else {
+                    // V^T section: lane holds rows m .. m + 3 of column n.  Rows of one request are consecutive (m = b rows_per_batch + t) but a group
+                    // of four may straddle a 4-aligned key group or two requests when rows_per_batch % 4 != 0, so every element finds its own slot.
+                    const int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+                    if (n >= p.N) continue;
+                    const float bn = p.bias ? p.bias[n] : 0.f;
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+                            if (m >= p.M) continue;
+                            const int b = m / p.rows_per_batch, t = m - b * p.rows_per_batch;
+                            const unsigned u = pack_bf16x2(acc[i][j][r] + bn, 0.f);
+                            p.outT[(long long)b * p.t_batch + (long long)(n - p.n_row) * p.ldt + vt_col(t)] = (bf16_t)(u & 0xffffu);
+                        }
                 }
             }
         }
@@ -170,6 +231,19 @@ __global__ __launch_bounds__(256) void flow_gemm_kernel(FlowGemmArgs p) {
         stamp();
         __syncthreads();
         stamp();
+        if constexpr (NTILE > 1) {
+#pragma unroll
+            for (int t = 0; t + 1 < NTILE; ++t) {
+                load_w(0, n0 + BN);                           // the next tile's weights: in flight under this tile's MFMAs and epilogue
+                compute(p.K / 32);
+                epilogue();
+                __syncthreads();                              // every wave has read this tile's Ws
+                store_w();
+                n0 += BN;
+                begin_tile();
+                __syncthreads();
+            }
+        }
         compute(p.K / 32);
     } else {
         // K streamed in chunks of 256: the next chunk's loads are in flight under the MFMAs of the current one (register prefetch)
@@ -185,56 +259,7 @@ __global__ __launch_bounds__(256) void flow_gemm_kernel(FlowGemmArgs p) {
     }
     stamp();
 
-    // ---- epilogue
-    if constexpr (OMODE == 1) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
-                if (n >= p.N) continue;                       // N % 4 == 0 (host check): a group of 4 columns is entirely in or out
-                float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-                const long long idx = (long long)m * p.ldc + n;
-                if (p.res) { const float4 r = *reinterpret_cast<const float4*>(p.res + idx); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-                *reinterpret_cast<float4*>(p.C + idx) = v;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            if (!tr[j]) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
-                    const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
-                    if (m >= p.M || n >= p.N) continue;
-                    float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                    if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-                    v = apply_act4(p.act, v, 0.f);
-                    *reinterpret_cast<uint2*>(p.out + (long long)m * p.ldo + n) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
-                }
-            } else {
-                // V^T section: lane holds rows m .. m + 3 of column n.  Rows of one request are consecutive (m = b rows_per_batch + t) but a group
-                // of four may straddle a 4-aligned key group or two requests when rows_per_batch % 4 != 0, so every element finds its own slot.
-                const int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
-                if (n >= p.N) continue;
-                const float bn = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
-                        if (m >= p.M) continue;
-                        const int b = m / p.rows_per_batch, t = m - b * p.rows_per_batch;
-                        const unsigned u = pack_bf16x2(acc[i][j][r] + bn, 0.f);
-                        p.outT[(long long)b * p.t_batch + (long long)(n - p.n_row) * p.ldt + vt_col(t)] = (bf16_t)(u & 0xffffu);
-                    }
-            }
-        }
-    }
+    epilogue();
     stamp();
 }
 

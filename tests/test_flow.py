@@ -303,6 +303,30 @@ def test_fused_transformer_blocks_match_unfused(lib, tile, waves, kt, ks):
                 (T, streaming, e_fu.mean().item(), e_un.mean().item(), e_fu.max().item(), e_un.max().item())
 
 
+def test_two_n_tiles_per_workgroup_is_bit_identical(lib):
+    """bf16 mode, round 3: flow_gemm_kernel<.., NTILE = 2> (option flow_ntile = 2: a workgroup of the LayerNorm-prologue GEMMs walks two 64-column tiles
+    of the same rows - LayerNorm and the A tile once, the second tile's weights in flight under the first's MFMAs) computes every output element
+    exactly as the single-tile launch does: Q | K rows, the V^T section (a pair that straddles n_row and one entirely inside it), FF1 + GELU; a
+    ragged last row tile, both mask modes."""
+    import ctypes as C
+    import dataclasses
+    cfg = dataclasses.replace(W.tiny()[1], est_ch=128, est_heads=2, est_mid=1, chunk=13)
+    sd = W.make_flow(cfg)
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision="bf16")
+    g = torch.Generator().manual_seed(4)
+    for T in (45, 150):
+        x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g); cond = torch.randn(2, 80, T, generator=g)
+        spk = torch.randn(2, 80, generator=g); t = torch.tensor([0.3, 0.3]); mask = torch.ones(2, 1, T)
+        for streaming in (False, True):
+            outs = []
+            for ntile in (1, 2):
+                lib.cv_flow_set_option(flow._h, b"flow_ntile", C.c_int32(ntile))
+                outs.append(flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu().clone())
+            assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
+            assert torch.equal(outs[0], outs[1]), (T, streaming, (outs[0] - outs[1]).abs().max().item())
+    lib.cv_flow_set_option(flow._h, b"flow_ntile", C.c_int32(0))
+
+
 @pytest.mark.parametrize("est_blocks", [1, 3])
 def test_fused_tail_matches_five_launch_blocks(lib, est_blocks):
     """bf16 mode, round 3: everything after a block's attention as ONE launch per 16-row band (flow_tail.h: out-projection + residual -> LayerNorm ->

@@ -81,6 +81,14 @@ elif "attn" in which:                # round 3: key splits inside the 64-query a
         else:
             print("    max |this - ks 2| = %.3e (mel std %.2f)" % ((mel - ref).abs().max().item(), ref.std().item()), flush=True)
     opt(b"attn_ks", 2); opt(b"attn_kt", 1)
+elif "ntile" in which:               # round 3: one or two N tiles per workgroup of the LayerNorm-prologue GEMMs (flow_gemm_kernel<.., NTILE>)
+    opt(b"fused", 1); opt(b"fused_tail", 0)
+    opt(b"flow_ntile", 1); ref = bench("one N tile per workgroup (round 2)")
+    for nt, label in ((2, "two N tiles per workgroup, QKV and FF1"), (0, "two where that makes one round (QKV only at T = 674)"), (1, "one again")):
+        opt(b"flow_ntile", nt)
+        mel = bench(label)
+        print("    bit-identical %s" % bool(torch.equal(mel, ref)), flush=True)
+    opt(b"flow_ntile", 0)
 elif "tail" in which:                # round 3: the one-launch block tail (flow_tail.h) against the five-launch block, ring depth 8 / 16
     opt(b"fused", 1); opt(b"fused_tail", 0); ref = bench("five launches per block (round 2)")
     for ring in (8, 16):
