@@ -50,7 +50,8 @@ struct cv_llm {
     // contributions summed into the residual by gate / up's prologue) - 4 launches per layer.  "oproj_rblocks": row blocks per head (4 | 8).
     int fused_attn_oproj = 0, oproj_rblocks = 4, oproj_waves = 8; DevBuf opart, h2;
     int only_cat = -1;                  // cv_llm_profile_chain: enqueue only the launches of this category (-1 = all)
-    DevBuf pf_x, pf_xn, pf_qkv, pf_attn, pf_gu, pf_act; // prefill activations (grown on demand)
+    DevBuf pf_x, pf_xn, pf_qkv, pf_attn, pf_gu, pf_act, pf_part; // prefill activations (grown on demand; pf_part: split-K partials of down on the weight-stationary path)
+    int prefill_rows = [] { const char* e = getenv("CV_PREFILL_ROWS"); return (e && e[0] == '1') ? 1 : 0; }();   // option "prefill_rows" = 1: prompts of <= 160 rows on skinny_rows_kernel (measured neutral: off)
     int pf_rows = 0;
     // decode graph
     hipGraphExec_t graph = nullptr; hipStream_t graph_stream = nullptr; hipStream_t own_stream = nullptr;
@@ -169,6 +170,45 @@ static hipStream_t resolve(cv_llm* m, void* s) {
 
 static LinearW lw(const bf16_t* w, const float* b, int N, int K) { LinearW l; l.w = w; l.b = b; l.N = N; l.K = K; l.Kp = round_up32(K); l.bf16 = true; return l; }
 
+// Fragment-ordered copies of the matrices ([row tile][k tile][lane][8 bf16]: one wave load = 1 KB contiguous) for skinny_pk_kernel (batched decode) and
+// skinny_rows_kernel (prefill), made on the device once per handle, the first time either path runs.
+static void ensure_packed(cv_llm* m, hipStream_t s) {
+    if (!m->batch_packed || !m->packed.empty()) return;
+    const auto& c = m->cfg;
+    auto pack = [&](const bf16_t* w, long long N, long long K) {
+        if (!w || K % 32 != 0 || m->packed.count(w)) return;
+        const long long pieces = ((N + 15) / 16) * (K / 32) * 64;
+        auto buf = std::make_unique<DevBuf>(); buf->ensure((size_t)pieces * 16);
+        bf16_t* dst = buf->as<bf16_t>();
+        hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, w, dst, (int)N, (int)K);
+        m->packed[w] = std::move(buf);
+    };
+    const long long H = c.hidden, A = c.heads * 64;
+    pack(m->head_w, m->V, H);
+    for (const auto& L : m->layers) { pack(L.wqkv, m->qkv_dim, H); pack(L.wo, H, A); pack(L.wgu, 2LL * c.inter, H); pack(L.wdown, H, c.inter); }
+    CV_HIP(hipStreamSynchronize(s));
+    CV_HIP(hipGetLastError());
+}
+
+// the weight-stationary GEMM over the rows of a prefill (skinny_rows_kernel): geometry rules of skinny() for the fragment-ordered path
+static bool skinny_rows_fits(int N, int K, int ksplit) {
+    const int tiles = K / 32 / ksplit;
+    return K % (32 * ksplit) == 0 && tiles >= 4 && (tiles + 3) / 4 <= 7 && N % 4 == 0;
+}
+static void skinny_rows(const SkinnyArgs& a, int rt, hipStream_t s, const bf16_t* wp) {
+    const int tiles = a.K / 32 / a.ksplit, row_tiles = (a.N + 15) / 16;
+    CV_CHECK(wp && skinny_rows_fits(a.N, a.K, a.ksplit), "skinny_rows: needs the fragment-ordered weights and a K range of 4 .. 28 tiles per workgroup");
+    CV_CHECK(!(a.gamma && a.ksplit != 1) && (a.mode == 2) == (a.ksplit > 1), "skinny_rows: split-K workgroups leave raw partials (mode 2), the fused norm needs the whole row");
+    SkinnyArgs b = a; b.W = wp;
+    const dim3 grid(((row_tiles + rt - 1) / rt) * a.ksplit);
+    const bool deep = (tiles + 3) / 4 > 5;
+    if (rt == 1) hipLaunchKernelGGL((skinny_rows_kernel<1, 7>), grid, dim3(256), 0, s, b);
+    else if (rt == 4) hipLaunchKernelGGL((skinny_rows_kernel<4, 7>), grid, dim3(256), 0, s, b);
+    else if (deep) hipLaunchKernelGGL((skinny_rows_kernel<2, 7>), grid, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((skinny_rows_kernel<2, 5>), grid, dim3(256), 0, s, b);
+}
+static int down_ksplit(int inter);
+
 // One prompt segment of a prefill: rows [row0, row0 + L) of the stacked input are the positions pos0 .. pos0 + L - 1 of a sequence whose KV cache
 // (layout [layers][kv_heads][max_len][64]) starts at kc / vc.  The GEMMs / norms of a prefill run over ALL rows of all segments at once
 // (M = sum of the prompt lengths: the weights are read once and the tiles are fuller), RoPE + cache write and the causal attention per segment.
@@ -185,10 +225,24 @@ static void llm_prefill_rows(cv_llm* m, const float* x_in, int R, const std::vec
     float* x = m->pf_x.as<float>(); float* xn = m->pf_xn.as<float>(); float* qkv = m->pf_qkv.as<float>();
     float* at = m->pf_attn.as<float>(); float* gu = m->pf_gu.as<float>(); float* act = m->pf_act.as<float>();
     CV_HIP(hipMemcpyAsync(x, x_in, (size_t)R * H * 4, hipMemcpyDeviceToDevice, s));
+    // Round 3, opt-in (prefill_rows): up to 160 rows (one prompt) the GEMMs run weight-stationary on the fragment-ordered copies (skinny_rows_kernel: RMSNorm
+    // in the prologue, SiLU * up in the epilogue, split-K down + sum_partials) - 7 launches per layer instead of 9.  Measured 2.95 vs 2.99 ms: off by default.
+    int dks = down_ksplit(c.inter);
+    if (!skinny_rows_fits(H, c.inter, dks) && skinny_rows_fits(H, c.inter, 1)) dks = 1;       // small models: the whole K in one workgroup
+    const bool rows_path = m->prefill_rows && m->batch_packed && R <= 160 && skinny_rows_fits(Q, H, 1) && skinny_rows_fits(H, A, 1) &&
+                           skinny_rows_fits(2 * c.inter, H, 1) && skinny_rows_fits(H, c.inter, dks);
+    if (rows_path) {
+        ensure_packed(m, s);
+        if (dks > 1) m->pf_part.ensure((size_t)dks * R * H * 4);
+    }
     for (int i = 0; i < c.layers; ++i) {
         const auto& L = m->layers[i];
-        norm_rows(NormArgs{x, xn, R, H, L.ln1, nullptr, c.rms_eps, 1, ACT_NONE, 1.f, nullptr, nullptr, R}, s);
-        linear(xn, R, lw(L.wqkv, L.bqkv, Q, H), qkv, ACT_NONE, nullptr, s);
+        if (rows_path) {
+            skinny_rows(SkinnyArgs{L.wqkv, L.bqkv, x, H, qkv, Q, Q, H, L.ln1, c.rms_eps, nullptr, 0, 0, R, 1}, 1, s, m->pk(L.wqkv));
+        } else {
+            norm_rows(NormArgs{x, xn, R, H, L.ln1, nullptr, c.rms_eps, 1, ACT_NONE, 1.f, nullptr, nullptr, R}, s);
+            linear(xn, R, lw(L.wqkv, L.bqkv, Q, H), qkv, ACT_NONE, nullptr, s);
+        }
         for (const auto& g : segs) {
             float* kc = g.kc + m->layer_cache() * i; float* vc = g.vc + m->layer_cache() * i;
             float* q = qkv + (size_t)g.row0 * Q;
@@ -202,6 +256,18 @@ static void llm_prefill_rows(cv_llm* m, const float* x_in, int R, const std::vec
             a.B = 1; a.H = c.heads; a.kv_group = c.heads / c.kv_heads; a.Tq = g.L; a.Tk = g.pos0 + g.L;      // causal with offset Tk - Tq
             a.scale = 0.125f; a.mask_mode = MASK_CAUSAL; a.chunk = 0; a.rel_bd = nullptr;
             attention(a, s);
+        }
+        if (rows_path) {
+            skinny_rows(SkinnyArgs{L.wo, nullptr, at, A, x, H, H, A, nullptr, 0.f, x, H, 0, R, 1}, 1, s, m->pk(L.wo));
+            skinny_rows(SkinnyArgs{L.wgu, nullptr, x, H, act, c.inter, 2 * c.inter, H, L.ln2, c.rms_eps, nullptr, 0, 1, R, 1}, 4, s, m->pk(L.wgu));
+            if (dks > 1) {
+                float* part = m->pf_part.as<float>();
+                skinny_rows(SkinnyArgs{L.wdown, nullptr, act, c.inter, part, H, H, c.inter, nullptr, 0.f, nullptr, 0, 2, R, dks}, 2, s, m->pk(L.wdown));
+                hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)(((long long)R * H / 4 + 255) / 256)), dim3(256), 0, s, part, dks, R, H, x, (long long)H, x, (long long)H);
+            } else {
+                skinny_rows(SkinnyArgs{L.wdown, nullptr, act, c.inter, x, H, H, c.inter, nullptr, 0.f, x, H, 0, R, 1}, 2, s, m->pk(L.wdown));
+            }
+            continue;
         }
         linear(at, R, lw(L.wo, nullptr, H, A), x, ACT_NONE, x, s);
         norm_rows(NormArgs{x, xn, R, H, L.ln2, nullptr, c.rms_eps, 1, ACT_NONE, 1.f, nullptr, nullptr, R}, s);
@@ -432,21 +498,7 @@ static void batch_begin(cv_llm* m, int nb, hipStream_t s) {
     CV_HIP(hipMemcpyAsync(b.state.p, b.host_state.data(), (size_t)nb * sizeof(DecodeState), hipMemcpyHostToDevice, s));
     CV_HIP(hipStreamSynchronize(s));
     if (b.graph && b.graph_nb != nb) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
-    if (m->batch_packed && m->packed.empty()) {                                   // fragment-ordered weight copies, once per handle
-        auto pack = [&](const bf16_t* w, long long N, long long K) {
-            if (!w || K % 32 != 0 || m->packed.count(w)) return;
-            const long long pieces = ((N + 15) / 16) * (K / 32) * 64;
-            auto buf = std::make_unique<DevBuf>(); buf->ensure((size_t)pieces * 16);
-            bf16_t* dst = buf->as<bf16_t>();
-            hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, w, dst, (int)N, (int)K);
-            m->packed[w] = std::move(buf);
-        };
-        const long long H = c.hidden, A = c.heads * 64;
-        pack(m->head_w, m->V, H);
-        for (const auto& L : m->layers) { pack(L.wqkv, m->qkv_dim, H); pack(L.wo, H, A); pack(L.wgu, 2LL * c.inter, H); pack(L.wdown, H, c.inter); }
-        CV_HIP(hipStreamSynchronize(s));
-        CV_HIP(hipGetLastError());
-    }
+    ensure_packed(m, s);
 }
 
 static void batch_prefill(cv_llm* m, int slot, const float* lm_input, int L0, const cv_sampling* sp, hipStream_t s) {
@@ -718,6 +770,7 @@ int cv_llm_set_option(cv_llm* m, const char* name, int32_t value) {
             (std::string(name) == "fused_attn_oproj" ? m->fused_attn_oproj : std::string(name) == "oproj_rblocks" ? m->oproj_rblocks : m->oproj_waves) = value;
             if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
         }
+        else if (std::string(name) == "prefill_rows") m->prefill_rows = value != 0;
         else if (std::string(name) == "head_waves") { CV_CHECK(value == 4 || value == 7, "head_waves must be 4 or 7"); m->head_waves = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; } }
         else if (std::string(name) == "fused_qkv_attn") { m->fused_qkv_attn = value != 0; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; } }
         else if (std::string(name) == "prefetch" || std::string(name) == "prefetch_shift") {

@@ -370,6 +370,135 @@ __global__ __launch_bounds__(NW * 64) CV_WAVES_PER_EU(1, 2) void skinny_pk_kerne
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// The same weight-stationary GEMM over MANY rows (round 3: the prefill of one prompt, M = 131 rows for the benchmark utterance).
+// The tiled GEMM the prefill ran on (gemm_conv_kernel, AX3) restages a 32-row x 128-k tile seven times per output tile at M = 131: 22 us per
+// launch for GEMMs whose weights a decode GEMV streams in 3-6 us.  Here a workgroup is what it is in skinny_pk_kernel - RT row tiles of the
+// fragment-ordered weights, requested ONCE and kept in registers - and walks the rows of X in groups of 16 (the MFMA's B columns): group i + 1
+// is requested while group i is multiplied, combined and stored.  What a workgroup ingests is its weight fragments plus ALL rows of X over its
+// k range (M x K x 4 B, from L2); per output element the arithmetic (three-term split, k order, cross-wave order) is exactly the batched
+// decode's, so a row's result does not depend on M or on its position.  Modes / epilogues as SkinnyArgs (nb = number of rows).
+// MEASURED on the MI355X (profiles/r3_prefill_rows_ab.txt): 2.95 ms per 131-row prefill against 2.99 ms on the tiled GEMMs - the nine groups of a launch are a
+// serial chain of LDS staging, MFMAs, cross-wave combine and two barriers (~2.4 us each), which is what the tiled kernel's seven k steps cost as well.  A second
+// form (waves own different row tiles over the whole K, X shared through a double-buffered LDS tile, no cross-wave combine) measured 4.9-7.1 ms and was removed.
+// Opt-in (option prefill_rows / CV_PREFILL_ROWS=1); the tiled path stays the default.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int RT, int KTW, int NW = 4>
+__global__ __launch_bounds__(NW * 64) CV_WAVES_PER_EU(1, 2) void skinny_rows_kernel(SkinnyArgs p) {          // p.W = the fragment-ordered copy
+    static_assert(RT >= 1 && RT <= 4 && RT <= NW && KTW <= 8, "one row tile per combining wave; a wave's k range is at most 256 columns (one 16-byte piece per lane)");
+    constexpr int XP = KTW * 32 + 4;
+    __shared__ __attribute__((aligned(16))) float red[NW * RT * 256];
+    __shared__ float ssq[NW][16];
+    __shared__ __attribute__((aligned(16))) float xs[NW][16 * XP];
+    __shared__ __attribute__((aligned(16))) float gs[NW][KTW * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int ks = blockIdx.x % p.ksplit, rg = blockIdx.x / p.ksplit;
+    const int tilesK = p.K / 32, tiles = tilesK / p.ksplit;
+    const int t0 = wave * tiles / NW, t1 = (wave + 1) * tiles / NW, nt = t1 - t0;       // nt >= 1 (host check)
+    const int kt0 = ks * tiles + t0;
+    const int n_base = rg * RT * 16, row_tiles = (p.N + 15) / 16;
+    const int ngroups = (p.nb + 15) / 16;
+    const int kx = kt0 * 32 + min(4 * lane, nt * 32 - 4);
+    // (16 named registers, not an array: next to the scheduling fence an array stays in scratch memory on this compiler - as in skinny_pk_kernel)
+    float4 xr0, xr1, xr2, xr3, xr4, xr5, xr6, xr7, xr8, xr9, xr10, xr11, xr12, xr13, xr14, xr15;
+#define CV_XROW(b) xr##b = *reinterpret_cast<const float4*>(p.x + (long long)min(gq * 16 + b, p.nb - 1) * p.ldx + kx);   /* rows >= nb repeat the last row (never stored) */
+#define CV_XLOAD_GROUP(G) { const int gq = (G); CV_XROW(0) CV_XROW(1) CV_XROW(2) CV_XROW(3) CV_XROW(4) CV_XROW(5) CV_XROW(6) CV_XROW(7) CV_XROW(8) CV_XROW(9) CV_XROW(10) CV_XROW(11) CV_XROW(12) CV_XROW(13) CV_XROW(14) CV_XROW(15) }
+    CV_XLOAD_GROUP(0)
+    const float4 gr = *reinterpret_cast<const float4*>((p.gamma ? p.gamma : p.x) + kx);
+    order_memory();                                                                   // the first group and gamma AHEAD of the weight stream
+    u32x4 w[RT][KTW];
+    const bf16_t* wr[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) wr[rt] = p.W + (((long long)min(rg * RT + rt, row_tiles - 1) * tilesK + kt0) * 64 + lane) * 8;
+#pragma unroll
+    for (int t = 0; t < KTW; ++t) {
+        const bool ok = t < nt;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            u32x4 v = *reinterpret_cast<const u32x4*>(wr[rt] + (ok ? t : 0) * 512);   // default cache policy: the other row-group workgroups of the launch do not share these, but a
+            if (!ok) v = (u32x4){0u, 0u, 0u, 0u};                                     // second prompt's prefill right behind this one does
+            w[rt][t] = v;
+        }
+    }
+    if (4 * lane < nt * 32) *reinterpret_cast<float4*>(&gs[wave][4 * lane]) = gr;
+    for (int grp = 0; grp < ngroups; ++grp) {
+        if (4 * lane < nt * 32) {
+#define CV_XST(b) *reinterpret_cast<float4*>(&xs[wave][b * XP + 4 * lane]) = xr##b;
+            CV_XST(0) CV_XST(1) CV_XST(2) CV_XST(3) CV_XST(4) CV_XST(5) CV_XST(6) CV_XST(7) CV_XST(8) CV_XST(9) CV_XST(10) CV_XST(11) CV_XST(12) CV_XST(13) CV_XST(14) CV_XST(15)
+#undef CV_XST
+        }
+        wave_lds_sync();
+        if (grp + 1 < ngroups) CV_XLOAD_GROUP(grp + 1)                    // in flight under this group's MFMAs, combine and stores
+        float ss = 0.f;
+        v4f acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < KTW; ++t) {
+            if (t < nt) {                                                   // wave-uniform
+                float4 a4 = *reinterpret_cast<const float4*>(&xs[wave][c * XP + t * 32 + g * 8]);
+                float4 b4 = *reinterpret_cast<const float4*>(&xs[wave][c * XP + t * 32 + g * 8 + 4]);
+                if (p.gamma) {
+                    const float4 ga = *reinterpret_cast<const float4*>(&gs[wave][t * 32 + g * 8]), gb = *reinterpret_cast<const float4*>(&gs[wave][t * 32 + g * 8 + 4]);
+                    ss += a4.x * a4.x + a4.y * a4.y + a4.z * a4.z + a4.w * a4.w + b4.x * b4.x + b4.y * b4.y + b4.z * b4.z + b4.w * b4.w;
+                    a4.x *= ga.x; a4.y *= ga.y; a4.z *= ga.z; a4.w *= ga.w;
+                    b4.x *= gb.x; b4.y *= gb.y; b4.z *= gb.z; b4.w *= gb.w;
+                }
+                u32x4 h1, h2, h3;
+                split3_bf16(a4, b4, h1, h2, h3);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {                           // smallest term first (as skinny_mfma_kernel)
+                    const v8bf wf = __builtin_bit_cast(v8bf, w[rt][t]);
+                    v4f a = acc[rt];
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(v8bf, h3), a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(v8bf, h2), a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(v8bf, h1), a, 0, 0, 0);
+                    acc[rt] = a;
+                }
+            }
+        }
+        if (p.gamma) {
+            ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+            if (g == 0) ssq[wave][c] = ss;
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<float4*>(&red[((wave * RT + rt) * 64 + lane) * 4]) = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
+        __syncthreads();
+        if (wave < RT) {
+            const int rt = wave;
+            float4 v = *reinterpret_cast<const float4*>(&red[(rt * 64 + lane) * 4]);
+#pragma unroll
+            for (int ww = 1; ww < NW; ++ww) {
+                const float4 o = *reinterpret_cast<const float4*>(&red[((ww * RT + rt) * 64 + lane) * 4]);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            if (p.gamma) {
+                const float tot = (ssq[0][c] + ssq[1][c]) + (ssq[2][c] + ssq[3][c]);
+                const float rstd = rsqrtf(tot / (float)p.K + p.eps);
+                v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
+            }
+            const int n = n_base + rt * 16 + g * 4;
+            const int row = grp * 16 + c;
+            if (row < p.nb && n < p.N) {
+                if (p.mode == 1) {
+                    const float2 o = make_float2((v.x / (1.f + expf(-v.x))) * v.y, (v.z / (1.f + expf(-v.z))) * v.w);
+                    *reinterpret_cast<float2*>(p.y + (long long)row * p.ldy + (n >> 1)) = o;
+                } else if (p.mode == 2) {
+                    *reinterpret_cast<float4*>(p.y + ((long long)ks * p.nb + row) * p.ldy + n) = v;
+                } else {                                                    // N % 4 == 0 (host check)
+                    if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+                    if (p.res) { const float4 r4 = *reinterpret_cast<const float4*>(p.res + (long long)row * p.ldres + n); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+                    *reinterpret_cast<float4*>(p.y + (long long)row * p.ldy + n) = v;
+                }
+            }
+        }
+        __syncthreads();                                                     // red / ssq are rewritten by the next group
+    }
+}
+
+#undef CV_XLOAD_GROUP
+#undef CV_XROW
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // fp8 variant of the skinny GEMM (BASELINE.json configs[4]: "fp8 MFMA LLM path"; opt-in, batched decode only).  Weights: OCP e4m3 with one fp32
 // scale per output row (quantised once at load, cosyvoice_amd/weights.py::quantize_fp8_rows).  Activations: quantised in the kernel, one
 // scale per sequence and workgroup K range (absmax / 448), after the RMSNorm gamma.  Products on v_mfma_f32_16x16x32_fp8_fp8 (exact in fp32,

@@ -228,6 +228,32 @@ def test_fused_qkv_attention_variant(lib, tiny_sd, splits, n_prompt):
         torch.testing.assert_close(lm.last_logits().log_softmax(-1), trace["logp"][i], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("n_prompt", [9, 120])
+def test_prefill_weight_stationary_rows_path(lib, tiny_sd, n_prompt):
+    """Round 3, option prefill_rows = 1: prompts of up to 160 rows run their GEMMs weight-stationary on the fragment-ordered copies (skinny_rows_kernel:
+    RMSNorm in the prologue, SiLU * up in the epilogue, rows of X walked in groups of 16 - two groups with a ragged last one, nine groups) instead of the
+    tiled GEMMs (the default; measured equally fast on the MI355X).  Both give the oracle's first-step log-probabilities and greedy tokens, and the K / V
+    they leave serve the same decode."""
+    import ctypes as C
+    cfg, sd = tiny_sd
+    u = _utt(cfg, n_prompt_tok=n_prompt)
+    trace = {}
+    want = OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=2, min_token_text_ratio=2, trace=trace)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=256, sampling="greedy", decode_chunk=5)
+    logits = []
+    for rows in (1, 0):
+        lib.cv_llm_set_option(lm._h, b"prefill_rows", C.c_int32(rows))
+        x = lm.build_lm_input(u["text"], u["prompt_text"], u["llm_prompt_speech_token"])
+        assert x.shape[0] <= 160
+        lm.prefill(x)
+        lm.decode(1, lm.make_sampling(6, 12))
+        logits.append(lm.last_logits().clone())
+        torch.testing.assert_close(logits[-1].log_softmax(-1), trace["logp"][0], rtol=1e-4, atol=1e-4)
+        assert list(lm.inference(**_kw(u), max_token_text_ratio=2, min_token_text_ratio=2)) == want
+    torch.testing.assert_close(logits[0], logits[1], rtol=1e-4, atol=1e-4)
+    assert not torch.equal(logits[0], logits[1])                  # (two different summation orders really ran)
+
+
 @pytest.mark.parametrize("rblocks,waves,n_prompt", [(4, 8, 11), (8, 8, 430), (4, 16, 430)])
 def test_fused_attention_oproj_variant(lib, tiny_sd, rblocks, waves, n_prompt):
     """Option fused_attn_oproj = 1 (round 3, attn_oproj_kernel): attention and the o_proj GEMV in one launch, o_proj split by head, the per-head
