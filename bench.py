@@ -419,7 +419,7 @@ def roofline_llm(model, u, cfgs):
         if sel:
             traffic = int(sum(v["n"] * v["hbm_read_bytes_corrected"] for v in sel) / sum(v["n"] for v in sel))
             traffic_src = ("REPLAYED PMC RECORD, not measured by this run (PMC counters cannot be collected from inside the benchmark process): %s, sha1 %s - "
-                           "rocprofv3 --pmc FETCH_SIZE in its own run (tools/gpu_pmc.sh), x1024 B, x2 for the gfx950 wide-read under-count; mean over the "
+                           "rocprofv3 --pmc FETCH_SIZE in its own run (tools/gpu_r3_validate.sh), x1024 B, x2 for the gfx950 wide-read under-count; mean over the "
                            "gemv_norm_kernel<7,2,5> (gate/up) launches of tools/profile_small.py llm, summarised by tools/pmc_summary.py"
                            % (os.path.relpath(pmc, ROOT), hashlib.sha1(raw).hexdigest()[:16]))
     step_us = sum(chain[k] * lc.layers for k in (0, 1, 2, 3, 4)) + chain[5]
