@@ -75,6 +75,8 @@ struct cv_flow {
     bool use_graph = true;
     int bf16_mfma = 0;                 // 1: Linear / Conv1d products on the bf16 MFMA (activations rounded to bf16 in LDS), 0: fp32-accurate (three-term split for bf16 weights, fp32 MFMA chain otherwise)
     std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
+    std::map<std::tuple<int, int, int>, unsigned long long> graph_used; unsigned long long graph_clock = 0;   // last use per key (least-recently-used eviction)
+    static constexpr size_t GRAPH_CAP = 32;   // shared passes of a serving scheduler see (utterances per pass) x (chunk shapes) keys per lane: 16 for U10-like traffic
     std::map<std::tuple<int, int, int>, int> seen;
     hipStream_t own_stream = nullptr;
     // Round 3, est_streams = 2: the estimator's batch rows as TWO launch chains (rows only meet in the CFG combine of an Euler step) - the second half of
@@ -309,7 +311,7 @@ static void flow_encoder(cv_flow* m, const float* tok_emb, int T, const float* c
 }
 
 // ---- estimator ---------------------------------------------------------------------------------------------------------
-static void drop_graphs(cv_flow* m) { std::lock_guard<std::recursive_mutex> lk(runtime_lock()); for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second); m->graphs.clear(); m->seen.clear(); }
+static void drop_graphs(cv_flow* m) { std::lock_guard<std::recursive_mutex> lk(runtime_lock()); for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second); m->graphs.clear(); m->seen.clear(); m->graph_used.clear(); }
 
 // nz = batch rows of the estimator: 2 (the CFG pair of one utterance) or 2 x the utterances of a batched solve
 static void est_reserve(cv_flow* m, int T, int nz = 2) {
@@ -687,18 +689,24 @@ static void solve_euler(cv_flow* m, float* x /*[nu][T][mel] in/out*/, const floa
     const auto key = std::make_tuple(T, n_steps, (streaming ? 1 : 0) + 2 * nu + (m->cur_klen ? 64 : 0));     // a padded batch bakes the klen pointer into its launches
     auto it = m->graphs.find(key);
     if (m->use_graph && it != m->graphs.end() && x == m->f_x.as<float>()) {
+        m->graph_used[key] = ++m->graph_clock;
         { std::lock_guard<std::recursive_mutex> lk(runtime_lock()); CV_HIP(hipGraphLaunch(it->second, s)); }
         return;
     }
     // buffers may have been re-allocated by *_reserve since a capture: graphs are dropped whenever a workspace grows (see est_reserve)
     if (m->use_graph && x == m->f_x.as<float>() && ++m->seen[key] == 2) {
-        if (m->graphs.size() >= 8) { for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second); m->graphs.clear(); }
         std::lock_guard<std::recursive_mutex> lk(runtime_lock());
+        if (m->graphs.size() >= cv_flow::GRAPH_CAP) {          // evict the least recently used shape; it may be captured again later (its sighting count restarts)
+            auto victim = m->graphs.begin();
+            for (auto g = m->graphs.begin(); g != m->graphs.end(); ++g) if (m->graph_used[g->first] < m->graph_used[victim->first]) victim = g;
+            (void)hipGraphExecDestroy(victim->second);
+            m->seen.erase(victim->first); m->graph_used.erase(victim->first); m->graphs.erase(victim);
+        }
         hipGraphExec_t ge = nullptr;
         hipGraph_t g = capture_graph(s, body);
         CV_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         CV_HIP(hipGraphDestroy(g));
-        m->graphs[key] = ge;
+        m->graphs[key] = ge; m->graph_used[key] = ++m->graph_clock;
         CV_HIP(hipGraphLaunch(ge, s));
         return;
     }
