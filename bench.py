@@ -750,15 +750,21 @@ def main():
         clients = args.stream_clients if args.stream_clients > 0 else (8 if extras else 0)
         if world == 1 and (batches or clients):
             model.set_lanes(args.lanes)
-        for nb in batches:
-            res = dict(batched_decode(model, u, nb, max(1, args.steps // 2)), lanes=args.lanes, flow_batch=args.flow_batch)
-            out["batched_decode" if nb == batches[0] else "batched_decode_%d" % nb] = res
-            log("batched decode %d done: %s" % (nb, res))
+        # The streaming clients run BEFORE the offline batch extras: a process that has just run batched_decode(16) serves the same 8 clients with a first-chunk
+        # p50 of 140-163 ms instead of 120 (the first token2wav under load takes 100 instead of 61 ms; the same calls on an idle GPU, the LM alone, tts_batch alone
+        # and tts_queue alone leave no trace - profiles/r3_stream_after_batch.txt).  Unexplained; the order is stated in the line (`extras_order`).
         if world == 1 and clients:
             if extras and args.stream_clients == 0:
                 model.set_lanes(4)                               # configs[2]: 8 streaming clients on 4 token2wav lanes (profiles/r2_lanes_ab.txt)
             out["streaming_clients"] = dict(streaming_clients(model, u, clients, args.stream_requests), lanes=model.n_lanes)
             log("streaming clients done: %s" % out["streaming_clients"])
+            model.set_lanes(args.lanes)
+        for nb in batches:
+            res = dict(batched_decode(model, u, nb, max(1, args.steps // 2)), lanes=args.lanes, flow_batch=args.flow_batch)
+            out["batched_decode" if nb == batches[0] else "batched_decode_%d" % nb] = res
+            log("batched decode %d done: %s" % (nb, res))
+        if extras:
+            out["extras_order"] = "streaming_clients, batched_decode 8, 16, mixed64, cosyvoice3 (streaming measured first: see bench.py)"
         if extras:
             model.set_lanes(args.lanes)
             out["mixed64"] = mixed64_extra(model, cfgs, args.lanes)
