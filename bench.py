@@ -610,6 +610,46 @@ def spawn_ranks(n):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+DEFAULT_EXTRAS = ("streaming_clients", "batched_decode", "batched_decode_16", "mixed64", "cosyvoice3")
+
+
+def run_extra(name, args):
+    """Child process of the default N = 1 line: ONE extra workload (another BASELINE.json configuration) on a model of its own, in a process of its own.
+    The extras used to share the headline's process; a process that has run one of them serves the next one measurably worse (8 streaming clients after
+    batched_decode(16): first-chunk p50 120 -> 140-163 ms; the other order costs the batch runs 5-10 % instead; profiles/r3_stream_after_batch.txt - bisected,
+    not understood), so every configuration now gets the same clean state the headline has."""
+    if name == "cosyvoice3":
+        res = cv3_workload(args)
+    else:
+        model, u, cfgs = build_model(args.flow_precision, batch_fp8=args.llm_fp8)
+        model.flow_batch = args.flow_batch
+        for _ in range(2):
+            one_utterance(model, u)
+        if name == "streaming_clients":
+            model.set_lanes(4)                                    # configs[2]: 8 streaming clients on 4 token2wav lanes (profiles/r2_lanes_ab.txt)
+            res = dict(streaming_clients(model, u, 8, args.stream_requests), lanes=model.n_lanes)
+        elif name in ("batched_decode", "batched_decode_16"):
+            model.set_lanes(args.lanes)
+            res = dict(batched_decode(model, u, 16 if name.endswith("16") else 8, max(1, args.steps // 2)), lanes=args.lanes, flow_batch=args.flow_batch)
+        elif name == "mixed64":
+            model.set_lanes(args.lanes)
+            res = mixed64_extra(model, cfgs, args.lanes)
+        else:
+            raise SystemExit("bench.py: unknown extra %r" % name)
+    print(json.dumps({"extra": name, "result": res}), flush=True)
+
+
+def spawn_extra(name, args):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--only-extra", name, "--steps", str(args.steps), "--lanes", str(args.lanes), "--flow-batch", str(args.flow_batch),
+           "--stream-requests", str(args.stream_requests), "--flow-precision", args.flow_precision, "--cv3-steps", str(args.cv3_steps)] + (["--llm-fp8"] if args.llm_fp8 else [])
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    for line in reversed(p.stdout.splitlines()):
+        if line.startswith("{\"extra\""):
+            return json.loads(line)["result"]
+    raise RuntimeError("bench extra %s failed (rc %s): %s" % (name, p.returncode, p.stderr[-2000:]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -643,9 +683,15 @@ def main():
                     "sequences), `streaming_clients` (8 clients, 104 requests: BASELINE.json configs[2]), `mixed64` (configs[3] on one GPU) and `cosyvoice3` (configs[4] shape) - "
                     "each with its own token self-check; they add about two minutes")
     ap.add_argument("--cpu-stage", choices=CPU_STAGES, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--only-extra", choices=DEFAULT_EXTRAS, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_stage:
         cpu_stage(args.cpu_stage)
+        return
+    if args.only_extra:
+        torch.cuda.set_device(0)
+        torch.set_num_threads(max(1, min(8, os.cpu_count() or 8)))
+        run_extra(args.only_extra, args)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)                     # never returns
@@ -744,36 +790,33 @@ def main():
         if world == 1 and args.workload == "u10":
             out["stages"] = stage_split(model, u)
             log("stage split: %s" % out["stages"])
-        # Extras of the default N = 1 line (not `value`): the other BASELINE.json configurations under the same clock, each with its own token check.
+        # Extras of the default N = 1 line (not `value`): the other BASELINE.json configurations under the same clock, each with its own token check and each in a
+        # process of its own (run_extra).  Explicit --batch / --stream-clients / --cv3 requests run in THIS process, on the headline's model.
         extras = world == 1 and args.workload == "u10" and not args.no_extras
-        batches = [args.batch] if args.batch > 0 else ([8, 16] if extras else [])
-        clients = args.stream_clients if args.stream_clients > 0 else (8 if extras else 0)
+        batches = [args.batch] if args.batch > 0 else []
+        clients = args.stream_clients
         if world == 1 and (batches or clients):
             model.set_lanes(args.lanes)
-        # The streaming clients run BEFORE the offline batch extras: a process that has just run batched_decode(16) serves the same 8 clients with a first-chunk
-        # p50 of 140-163 ms instead of 120 (the first token2wav under load takes 100 instead of 61 ms; the same calls on an idle GPU, the LM alone, tts_batch alone
-        # and tts_queue alone leave no trace - profiles/r3_stream_after_batch.txt).  Unexplained; the order is stated in the line (`extras_order`).
         if world == 1 and clients:
-            if extras and args.stream_clients == 0:
-                model.set_lanes(4)                               # configs[2]: 8 streaming clients on 4 token2wav lanes (profiles/r2_lanes_ab.txt)
             out["streaming_clients"] = dict(streaming_clients(model, u, clients, args.stream_requests), lanes=model.n_lanes)
             log("streaming clients done: %s" % out["streaming_clients"])
-            model.set_lanes(args.lanes)
         for nb in batches:
             res = dict(batched_decode(model, u, nb, max(1, args.steps // 2)), lanes=args.lanes, flow_batch=args.flow_batch)
-            out["batched_decode" if nb == batches[0] else "batched_decode_%d" % nb] = res
+            out["batched_decode"] = res
             log("batched decode %d done: %s" % (nb, res))
-        if extras:
-            out["extras_order"] = "streaming_clients, batched_decode 8, 16, mixed64, cosyvoice3 (streaming measured first: see bench.py)"
-        if extras:
-            model.set_lanes(args.lanes)
-            out["mixed64"] = mixed64_extra(model, cfgs, args.lanes)
-            log("mixed64 done: %s" % out["mixed64"])
         if world == 1 and (batches or clients):
             model.set_lanes(1)
-        if world == 1 and (args.cv3 or extras):
+        if world == 1 and args.cv3 and not extras:
             out["cosyvoice3"] = cv3_workload(args)
             log("cosyvoice3 done: %s" % out["cosyvoice3"])
+        if extras:
+            torch.cuda.synchronize()
+            for name in DEFAULT_EXTRAS:
+                if name in out:
+                    continue                                     # asked for explicitly: measured above
+                out[name] = spawn_extra(name, args)
+                log("%s done: %s" % (name, out[name]))
+            out["extras_note"] = "each extra ran in a process of its own on a model of its own (bench.py run_extra)"
         if world == 1 and args.streams > 1:
             out["concurrent_streams"] = concurrent_streams(model, u, args.streams, args.steps)
             log("concurrent streams done")
