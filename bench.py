@@ -616,8 +616,9 @@ DEFAULT_EXTRAS = ("streaming_clients", "batched_decode", "batched_decode_16", "m
 def run_extra(name, args):
     """Child process of the default N = 1 line: ONE extra workload (another BASELINE.json configuration) on a model of its own, in a process of its own.
     The extras used to share the headline's process; a process that has run one of them serves the next one measurably worse (8 streaming clients after
-    batched_decode(16): first-chunk p50 120 -> 140-163 ms; the other order costs the batch runs 5-10 % instead; profiles/r3_stream_after_batch.txt - bisected,
-    not understood), so every configuration now gets the same clean state the headline has."""
+    batched_decode(16): first-chunk p50 120 -> 140-163 ms; the other order costs the batch runs 5-10 % instead; profiles/r3_stream_after_batch.txt: with more busy
+    HIP streams than hardware queues the stream -> queue assignment depends on the process's history), so every configuration gets the same clean state the
+    headline has, and none uses more than 2 lanes."""
     if name == "cosyvoice3":
         res = cv3_workload(args)
     else:
@@ -626,7 +627,11 @@ def run_extra(name, args):
         for _ in range(2):
             one_utterance(model, u)
         if name == "streaming_clients":
-            model.set_lanes(4)                                    # configs[2]: 8 streaming clients on 4 token2wav lanes (profiles/r2_lanes_ab.txt)
+            # configs[2]: 8 streaming clients on 2 token2wav lanes.  With shared flow passes (4 requests per pass) two lanes carry the eight clients, and - what
+            # decides it - the process then has no more BUSY HIP streams than the runtime has hardware queues (ROCm: 4 per process; 2 lanes + the LM stream + the
+            # default stream).  With 4 lanes two busy lane streams can land on one hardware queue, depending on the order in which streams and host threads were
+            # created before: their passes then serialise and the first token2wav under load takes 100 instead of 61 ms (profiles/r3_stream_after_batch.txt).
+            model.set_lanes(2)
             res = dict(streaming_clients(model, u, 8, args.stream_requests), lanes=model.n_lanes)
         elif name in ("batched_decode", "batched_decode_16"):
             model.set_lanes(args.lanes)
@@ -669,7 +674,7 @@ def main():
     ap.add_argument("--stream-requests", type=int, default=104)
     ap.add_argument("--flow-batch", type=int, default=4, help="offline batch paths: up to this many finished sequences of equal shape share one flow pass "
                     "(CosyVoice2Model.flow_batch; 1 = one flow inference per utterance)")
-    ap.add_argument("--lanes", type=int, default=3, help="token2wav lanes (CosyVoice2Model.set_lanes) used by the serving-style extras and the mixed64 workload: "
+    ap.add_argument("--lanes", type=int, default=2, help="token2wav lanes (CosyVoice2Model.set_lanes) used by the serving-style extras and the mixed64 workload: "
                     "flow + HiFT of that many requests overlap on the GPU; the headline batch-1 workload has one request in flight and is not affected")
     ap.add_argument("--workload", choices=("u10", "mixed64"), default="u10",
                     help="u10 (default, the headline: BASELINE.json configs[1], every rank synthesises U10 per step - weak scaling) | mixed64 "

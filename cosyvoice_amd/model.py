@@ -95,7 +95,9 @@ class CosyVoice2Model:
         self._warmup()
 
     def set_lanes(self, n):
-        """n >= 1 token2wav lanes.  Call while no request is in flight.  (Lane streams restricted to a subset of the CUs with
+        """n >= 1 token2wav lanes.  Call while no request is in flight.  Keep lanes + 2 (the LM stream, the default stream) within the runtime's hardware queues
+        (ROCm: 4 per process): beyond that, which streams share a queue depends on the process's history and two busy lanes may serialise
+        (profiles/r3_stream_after_batch.txt).  With shared flow passes (flow_batch = 4) two lanes serve eight streaming clients.  (Lane streams restricted to a subset of the CUs with
         hipExtStreamCreateWithCUMask, to keep CUs free for the LM chain, were measured: every mask - even 224 of 256 CUs - more than doubled
         both the LM's and the vocoder's latency at 8 streaming clients, profiles/r2_lane_cu_mask_ab.txt.  Plain streams.)"""
         assert n >= 1

@@ -7,7 +7,7 @@ import bench as B
 
 model, u, cfgs = B.build_model("bf16")
 model.flow_batch = 4
-model.set_lanes(4)
+model.set_lanes(int(os.environ.get("LANES", "4")))
 B.one_utterance(model, u)
 def show(tag):
     r = B.streaming_clients(model, u, 8, 104)
