@@ -227,10 +227,10 @@ class StreamScheduler:
         err = None
         try:
             m.token2wav_batch(jobs, stream=(what == "chunk"), finalize=(what == "final"), on_ready=deliver)
-        except BaseException as e:
-            err = e
+        except BaseException as e:                # the pass (or one member's vocoder call) failed: every member's request ends with the error - also the ones
+            err = e                                # that already got this chunk (their state is dropped below; a listener must not wait for more)
             for i, (r, _, _) in enumerate(picks):
-                if i not in delivered:
+                if not (what == "final" and i in delivered):
                     r.out.put(e)
         done = what == "final" or err is not None
         self.batched_passes += 1

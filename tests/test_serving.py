@@ -234,6 +234,28 @@ def test_scheduler_batches_ready_requests_into_one_flow_pass():
                 assert not fm.batches and sch.batched_jobs == 0
             else:
                 assert sch.batched_jobs >= 2 and all(len(b) >= 2 and len({(x[3], x[4]) for x in b}) == 1 for b in fm.batches)
+                # a shared pass that fails ends EVERY member's request with the error (also a member that had already been handed its chunk), and the server goes on
+                boom = RuntimeError("flow pass failed")
+
+                def failing(jobs, stream=False, finalize=False, on_ready=None):
+                    on_ready(0, _FakeModel.token2wav(fm, stream=stream, finalize=finalize, **jobs[0]))
+                    raise boom
+                fm.token2wav_batch = failing
+                errs = []
+
+                def one():
+                    try:
+                        list(sch.submit(stream=False, **_fake_req(2)))
+                    except RuntimeError as e:
+                        errs.append(e)
+                th = [threading.Thread(target=one) for _ in range(3)]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                assert not sch._reqs and not fm.hift_cache_dict
+                del fm.token2wav_batch                                # back to the class's method
+                assert [o["tts_speech"].shape[1] // 960 for o in sch.submit(stream=False, **_fake_req(2))] == [9]
         finally:
             sch.shutdown()
 
