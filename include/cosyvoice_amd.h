@@ -118,7 +118,11 @@ int cv_llm_create(cv_llm** out, const cv_llm_config* cfg);
 int cv_llm_set_tensor(cv_llm* m, const char* name, const void* dev_ptr, int32_t dtype, int64_t numel);
 int cv_llm_finalize(cv_llm* m);
 void cv_llm_destroy(cv_llm* m);
-int cv_llm_set_option(cv_llm* m, const char* name, int32_t value);            /* "use_graph" */
+/* Options (all optional; defaults are the fastest measured forms): "use_graph" (decode hipGraph, 1), "attn_splits" (4 | 8 | 16 key slices per
+ * head, 8), "batch_fp8" (0), "batch_packed" (batched decode on fragment-ordered weight copies, 1).  Measured alternatives kept for A/B runs, all default 0:
+ * "fused_qkv_attn", "fused_attn_oproj" (+ "oproj_rblocks" 4 | 8, "oproj_waves" 8 | 16), "prefetch" (1 | 2, + "prefetch_shift"), "prefill_rows", "head_rows" (1 | 2),
+ * "head_waves" (4 | 7). */
+int cv_llm_set_option(cv_llm* m, const char* name, int32_t value);
 /* lm_input: dev fp32 [L0, hidden] = [sos | text emb | task_id | prompt speech emb] (llm.py:494). Resets the KV cache. */
 int cv_llm_prefill(cv_llm* m, const float* lm_input, int32_t L0, void* stream);
 /* Qwen2LM.inference_bistream (llm/llm.py:551-661): forward `n_rows` more input rows on top of the cached positions - the reference's
@@ -178,7 +182,10 @@ typedef struct cv_flow_config {
 int cv_flow_create(cv_flow** out, const cv_flow_config* cfg);
 int cv_flow_set_tensor(cv_flow* m, const char* name, const void* dev_ptr, int32_t dtype, int64_t numel);
 int cv_flow_finalize(cv_flow* m);
-int cv_flow_set_option(cv_flow* m, const char* name, int32_t value);           /* "use_graph" (Euler-solve hipGraph cache, default on) */
+/* Options: "use_graph" (Euler-solve hipGraph cache: up to 32 shapes per handle, least recently used evicted; default on), "bf16_mfma" (precision mode), "fused" (bf16
+ * mode: fused transformer blocks, 1), "flow_tile" / "flow_ntile" / "attn_waves" / "attn_kt" / "attn_ks" (tile choices, 0 = by size).  Measured alternatives, default off:
+ * "fused_tail" (+ "tail_ring" 8 | 16), "est_streams" (1 | 2). */
+int cv_flow_set_option(cv_flow* m, const char* name, int32_t value);
 void cv_flow_destroy(cv_flow* m);
 /* B4: flow.encoder(token_emb[1,n,dim], token_len, context=[1,3,dim] or empty, streaming) -> h[1,2n,dim]
  * (cosyvoice/flow/flow.py:258-261, transformer/upsample_encoder.py:244-307).  tok_emb / context / h_out: dev fp32, row-major. */
