@@ -7,7 +7,6 @@ import torch
 
 from cosyvoice_amd import synthetic as W
 
-
 def test_cosyvoice3_model_matches_reference_golden(lib):
     """a17: CosyVoice3Model.tts / token2wav on the device (CausalMaskedDiffWithDiT + CausalHiFTGenerator, accumulating mel cache, speech offsets,
     silent-token filter) against the REAL cosyvoice.cli.model.CosyVoice3Model driving the real tiny modules with the same scripted tokens."""
@@ -37,104 +36,3 @@ def test_cosyvoice3_model_matches_reference_golden(lib):
         assert [o.shape[1] for o in outs] == g[key + "_n"].tolist()
         torch.testing.assert_close(torch.cat(outs, 1), g[key], rtol=0, atol=5e-3)
         assert not m.hift_cache_dict and not m.tts_speech_token_dict
-
-
-def test_cosyvoice3_tts_batch_shares_one_flow_pass(lib):
-    """CosyVoice3Model.tts_batch: finished sequences of similar length go through the DiT flow in ONE padded pass (cv_flow_inference_ragged, estimator
-    batch rows 2 x utterances), then through the causal HiFT one by one; every waveform equals tts() of that request alone bit for bit."""
-    from cosyvoice_amd.flow import CausalMaskedDiffWithDiT
-    from cosyvoice_amd.hift import CausalHiFTGenerator
-    from cosyvoice_amd.model import CosyVoice3Model
-    lc, _, hc0 = W.tiny()
-    fc, hc = dataclasses.replace(W.tiny_cv3_flow(), n_timesteps=1), dataclasses.replace(hc0, causal=True)
-    m = CosyVoice3Model(None, CausalMaskedDiffWithDiT(W.make_flow_dit(fc), fc, lib=lib), CausalHiFTGenerator(W.make_hift(hc), hc, lib=lib), lib=lib)
-    g = torch.Generator().manual_seed(31)
-    scripts = [torch.randint(3, fc.vocab, (6,), generator=g).tolist() for _ in range(3)] + [torch.randint(3, fc.vocab, (5,), generator=g).tolist()]
-    us = [W.synthetic_utterance(lc, fc, n_prompt_tok=6, n_prompt_text=2, n_text=2, seed=90 + i) for i in range(4)]
-    keys = ("text", "flow_embedding", "llm_embedding", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat")
-    reqs = [{k: x[k] for k in keys} for x in us]
-
-    class ScriptedLLM:                                            # request i is recognised by its text tensor
-        def _which(self, text):
-            return next(i for i, r in enumerate(reqs) if torch.equal(r["text"], text))
-
-        def inference_batch(self, rs):
-            return [list(scripts[self._which(r["text"])]) for r in rs]
-
-        def inference(self, **kw):
-            yield from scripts[self._which(kw["text"])]
-    m.llm = ScriptedLLM()
-    calls = []
-    fb = m.flow.inference_batch
-    m.flow.inference_batch = lambda items, **kw: (calls.append(len(items)), fb(items, **kw))[1]
-    got = m.tts_batch(reqs)
-    assert calls == [4]                                           # one padded pass: the 5-token request is within flow_pad of the three 6-token ones
-    alone = [next(iter(m.tts(**r, stream=False)))["tts_speech"] for r in reqs]
-    for a, b in zip(alone, got):
-        assert torch.equal(a, b["tts_speech"])
-    assert not torch.equal(alone[0], alone[1]) and not m.hift_cache_dict
-
-
-def test_cosyvoice3_silent_token_runs_filtered_on_every_path(lib):
-    """the silent / breath-token rule of llm_job (cli/model.py:122-128: a token of silent_tokens is dropped once more than 5 came in a
-    row) must also hold where the tokens do not pass through llm_job - tts_batch, tts_queue and the serving scheduler - or their audio differs
-    from tts() whenever the LM emits a run of silence.  Scripts with runs of 8 and 7 silent ids; every path must equal tts() bit for bit, and
-    tts() must have vocoded the FILTERED sequence."""
-    from cosyvoice_amd.flow import CausalMaskedDiffWithDiT
-    from cosyvoice_amd.hift import CausalHiFTGenerator
-    from cosyvoice_amd.model import CosyVoice3Model, SilentTokenFilter
-    from cosyvoice_amd.serving import StreamScheduler
-    lc, _, hc0 = W.tiny()
-    fc, hc = dataclasses.replace(W.tiny_cv3_flow(), n_timesteps=1), dataclasses.replace(hc0, causal=True)
-    m = CosyVoice3Model(None, CausalMaskedDiffWithDiT(W.make_flow_dit(fc), fc, lib=lib), CausalHiFTGenerator(W.make_hift(hc), hc, lib=lib), lib=lib)
-    sil = [t for t in m.silent_tokens if t < fc.vocab]
-    assert len(sil) >= 2
-    a, b = sil[0], sil[1]
-    scripts = [[40, a, a, b, a, b, a, a, b, 41, 42], [43, b, b, b, b, b, b, b, 44, a, 45]]
-    want = [SilentTokenFilter(m.silent_tokens)(s) for s in scripts]
-    assert [len(w) for w in want] == [8, 9]
-    us = [W.synthetic_utterance(lc, fc, n_prompt_tok=6, n_prompt_text=2, n_text=2, seed=190 + i) for i in range(2)]
-    keys = ("text", "flow_embedding", "llm_embedding", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat")
-    reqs = [{k: x[k] for k in keys} for x in us]
-
-    class ScriptedLLM:
-        def _which(self, text):
-            return next(i for i, r in enumerate(reqs) if torch.equal(r["text"], text))
-
-        def inference_batch(self, rs):
-            return [list(scripts[self._which(r["text"])]) for r in rs]
-
-        def inference_queue(self, rs, slots=8):
-            for i, r in enumerate(rs):
-                yield i, list(scripts[self._which(r["text"])])
-
-        def inference(self, **kw):
-            yield from scripts[self._which(kw["text"])]
-
-        def serve_stream(self, source, on_tokens, slots=8, step_chunk=3, **kw):      # tokens arrive 3 at a time: the runs straddle the chunks
-            while True:
-                item = source.get()
-                if item is None:
-                    return
-                key, r = item
-                s = scripts[self._which(r["text"])]
-                for k in range(0, len(s), 3):
-                    on_tokens(key, s[k:k + 3], k + 3 >= len(s), None)
-    m.llm = ScriptedLLM()
-    seen = []
-    t2w = m.token2wav
-    m.token2wav = lambda **kw: (seen.append(kw["token"].flatten().tolist()), t2w(**kw))[1]
-    alone = [next(iter(m.tts(**r, stream=False)))["tts_speech"] for r in reqs]
-    assert seen == want
-    m.token2wav = t2w
-    for got in (m.tts_batch(reqs), [o for _, o in sorted(m.tts_queue(reqs, slots=2), key=lambda x: x[0])]):
-        for x, y in zip(alone, got):
-            assert torch.equal(x, y["tts_speech"])
-    sch = StreamScheduler(m, slots=2, step_chunk=3)
-    try:
-        for x, r in zip(alone, reqs):
-            outs = [o["tts_speech"] for o in sch.submit(stream=False, **r)]
-            assert len(outs) == 1 and torch.equal(outs[0], x)
-    finally:
-        sch.shutdown()
-    assert not m.hift_cache_dict

@@ -1,27 +1,27 @@
 #!/bin/bash
-# One gpurun call for the start of a round: validates the tree on hardware and collects the reference numbers of every bench leg
-# (round-2 end values in brackets):
+# One gpurun call for the start of a round: validates the tree on hardware and collects the reference numbers (round-3 end values in brackets):
 #   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/gpu_checklist.sh'
 # Writes under gpurun_out/checklist/.  Order: cheapest / most important first; every step has its own timeout.  ~7 GPU-minutes.
 set -u
 O=gpurun_out/checklist; mkdir -p $O
+R=$GRAFT_REPO_ROOT
 run() { local name=$1; shift; echo "== $name"; timeout -k 5 "$@" > $O/$name.log 2>&1; echo "   rc=$? ($(tail -1 $O/$name.log | cut -c1-150))"; }
-run pytest_gpu            400 python -X faulthandler -m pytest tests -q -m gpu                         # [166 passed, 2 skipped, ~3 min]
+run pytest_gpu            500 python -X faulthandler -m pytest tests -q -m gpu -p no:cacheprovider         # [197 passed, 2 skipped, ~3.5 min]
 run smoke                  60 python -c "import __graft_entry__ as g; g.smoke()"
-run bench_default         240 python bench.py                                                          # [54.0 audio-s/s, first chunk 66.6 ms, gate/up 0.397]
-run bench_serving         240 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --first-chunk-reps 3 --batch 8 --lanes 4 --stream-clients 8 --stream-requests 104   # [189 / 203; 105 audio-s/s, p50 176 ms]
-run bench_batch16         200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --first-chunk-reps 1 --batch 16 --lanes 3    # [251 / 271]
-run bench_mixed64         240 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --first-chunk-reps 1 --workload mixed64 --lanes 3   # [249]
-run bench_cv3             240 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --first-chunk-reps 1 --cv3 --cv3-steps 4     # [55 alone, 278 at 16]
-run probe_flow_ragged     120 python tools/probe_flow_batch.py ragged                                  # [x1.5 - x2.3, bit-identical]
-run probe_prefill_x3      120 python tools/probe_prefill_x3.py                                         # [4.36 -> 3.07 ms]
-( cd /tmp && export TMPDIR=/tmp && timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof_bench -- \
-    python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --first-chunk-reps 1 > $OLDPWD/$O/prof_bench.log 2>&1; echo "== rocprof bench rc=$?" )
-for f in bench_default bench_serving bench_batch16 bench_mixed64 bench_cv3; do python - "$O/$f.log" <<'PY'
+# the driver's command; the line carries every other BASELINE.json configuration as an extra (each in a process of its own, 2 lanes):
+# [55.4 audio-s/s, first chunk 58.9 ms, gate/up 0.39; 8 streaming clients 150 audio-s/s at p50 120 ms; batch 8 / 16 216 / 296; mixed64 292; cosyvoice3 61 / 350]
+run bench_driver          600 python bench.py --gpus 1 --steps 20 --warmup 5
+python - "$O/bench_driver.log" <<'PY'
 import json, sys
 for line in open(sys.argv[1]):
     if line.startswith("{"):
         d = json.loads(line)
-        print(sys.argv[1].split("/")[-1], d["value"], d["ms_per_step"], d.get("first_chunk_ms_p50"), d.get("batched_decode"), d.get("streaming_clients"), d.get("cosyvoice3"))
+        print("bench", d["value"], d["ms_per_step"], "first chunk", d.get("first_chunk_ms_p50"), d.get("stages"))
+        for k in ("streaming_clients", "batched_decode", "batched_decode_16", "mixed64", "cosyvoice3"):
+            print("  ", k, d.get(k))
+        r = d["roofline"]; print("   roofline", {k: r.get(k) for k in ("achieved", "frac", "avg_launch_us", "decode_step_us_from_chains")})
 PY
-done
+run probe_flow_ragged     120 python tools/probe_flow_batch.py ragged                                  # [x1.5 - x2.3, bit-identical]
+( cd /tmp && export TMPDIR=/tmp && timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_utt -- python $R/tools/profile_utt.py > $R/$O/prof_utt.log 2>&1; echo "== rocprof hot path rc=$?" )
+f=$(find $O/prof_utt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/rocprof_utt_kernel_stats.csv && head -12 "$f" | cut -c1-170
+rm -rf $O/prof_utt
