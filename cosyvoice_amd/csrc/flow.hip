@@ -76,7 +76,8 @@ struct cv_flow {
     int bf16_mfma = 0;                 // 1: Linear / Conv1d products on the bf16 MFMA (activations rounded to bf16 in LDS), 0: fp32-accurate (three-term split for bf16 weights, fp32 MFMA chain otherwise)
     std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
     std::map<std::tuple<int, int, int>, unsigned long long> graph_used; unsigned long long graph_clock = 0;   // last use per key (least-recently-used eviction)
-    static constexpr size_t GRAPH_CAP = 32;   // shared passes of a serving scheduler see (utterances per pass) x (chunk shapes) keys per lane: 16 for U10-like traffic
+    size_t graph_cap = 32;             // option "graph_cap": shared passes of a serving scheduler see (utterances per pass) x (chunk shapes) keys per lane: 16 for U10-like traffic
+    int graph_captures = 0;            // captures so far (cv_flow_get_stat: tests of the eviction rule)
     std::map<std::tuple<int, int, int>, int> seen;
     hipStream_t own_stream = nullptr;
     // Round 3, est_streams = 2: the estimator's batch rows as TWO launch chains (rows only meet in the CFG combine of an Euler step) - the second half of
@@ -696,7 +697,7 @@ static void solve_euler(cv_flow* m, float* x /*[nu][T][mel] in/out*/, const floa
     // buffers may have been re-allocated by *_reserve since a capture: graphs are dropped whenever a workspace grows (see est_reserve)
     if (m->use_graph && x == m->f_x.as<float>() && ++m->seen[key] == 2) {
         std::lock_guard<std::recursive_mutex> lk(runtime_lock());
-        if (m->graphs.size() >= cv_flow::GRAPH_CAP) {          // evict the least recently used shape; it may be captured again later (its sighting count restarts)
+        if (m->graphs.size() >= m->graph_cap) {          // evict the least recently used shape; it may be captured again later (its sighting count restarts)
             auto victim = m->graphs.begin();
             for (auto g = m->graphs.begin(); g != m->graphs.end(); ++g) if (m->graph_used[g->first] < m->graph_used[victim->first]) victim = g;
             (void)hipGraphExecDestroy(victim->second);
@@ -706,7 +707,7 @@ static void solve_euler(cv_flow* m, float* x /*[nu][T][mel] in/out*/, const floa
         hipGraph_t g = capture_graph(s, body);
         CV_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         CV_HIP(hipGraphDestroy(g));
-        m->graphs[key] = ge; m->graph_used[key] = ++m->graph_clock;
+        m->graphs[key] = ge; m->graph_used[key] = ++m->graph_clock; ++m->graph_captures;
         CV_HIP(hipGraphLaunch(ge, s));
         return;
     }
@@ -732,11 +733,20 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "attn_kt") { CV_CHECK(value == 1 || value == 2, "attn_kt must be 1 or 2"); m->attn_kt = value; drop_graphs(m); }
         else if (std::string(name) == "attn_waves") { CV_CHECK(value == 2 || value == 4, "attn_waves must be 2 or 4"); m->attn_waves = value; drop_graphs(m); }
         else if (std::string(name) == "est_streams") { CV_CHECK(value == 1 || value == 2, "est_streams must be 1 or 2"); m->est_streams = value; drop_graphs(m); }
+        else if (std::string(name) == "graph_cap") { CV_CHECK(value >= 1 && value <= 256, "graph_cap must be 1 .. 256"); drop_graphs(m); m->graph_cap = (size_t)value; }
         else if (std::string(name) == "fused_tail") { m->fused_tail = value != 0; drop_graphs(m); }
         else if (std::string(name) == "flow_ntile") { CV_CHECK(value >= 0 && value <= 2, "flow_ntile must be 0, 1 or 2"); m->flow_ntile = value; drop_graphs(m); }
         else if (std::string(name) == "tail_ring") { m->tail_ring = value == 16 ? 16 : 8; drop_graphs(m); }      // bf16 mode: one row-band launch after each attention (flow_tail.h) on / off
         else if (std::string(name) == "fused") { m->fused = value != 0; drop_graphs(m); }              // bf16 mode: fused transformer blocks (flow_fused.h) on / off
         else throw Error(std::string("unknown option ") + name);
+    });
+}
+int cv_flow_get_stat(cv_flow* m, const char* name, int64_t* value) {
+    return guarded([&] {
+        CV_CHECK(m && name && value, "null argument");
+        if (std::string(name) == "graph_captures") *value = m->graph_captures;
+        else if (std::string(name) == "graphs_cached") *value = (int64_t)m->graphs.size();
+        else throw Error(std::string("unknown statistic ") + name);
     });
 }
 void cv_flow_destroy(cv_flow* m) {

@@ -184,8 +184,10 @@ int cv_flow_set_tensor(cv_flow* m, const char* name, const void* dev_ptr, int32_
 int cv_flow_finalize(cv_flow* m);
 /* Options: "use_graph" (Euler-solve hipGraph cache: up to 32 shapes per handle, least recently used evicted; default on), "bf16_mfma" (precision mode), "fused" (bf16
  * mode: fused transformer blocks, 1), "flow_tile" / "flow_ntile" / "attn_waves" / "attn_kt" / "attn_ks" (tile choices, 0 = by size).  Measured alternatives, default off:
- * "fused_tail" (+ "tail_ring" 8 | 16), "est_streams" (1 | 2). */
+ * "fused_tail" (+ "tail_ring" 8 | 16), "est_streams" (1 | 2); "graph_cap" (1 .. 256 cached shapes). */
 int cv_flow_set_option(cv_flow* m, const char* name, int32_t value);
+/* "graph_captures" (Euler-solve graphs captured so far), "graphs_cached" (held now; option "graph_cap", default 32) - test / monitoring hook, no reference counterpart */
+int cv_flow_get_stat(cv_flow* m, const char* name, int64_t* value);
 void cv_flow_destroy(cv_flow* m);
 /* B4: flow.encoder(token_emb[1,n,dim], token_len, context=[1,3,dim] or empty, streaming) -> h[1,2n,dim]
  * (cosyvoice/flow/flow.py:258-261, transformer/upsample_encoder.py:244-307).  tok_emb / context / h_out: dev fp32, row-major. */

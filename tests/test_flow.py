@@ -132,6 +132,38 @@ def test_graph_replay_is_identical_to_eager(lib, tiny):
     assert other.shape[2] == 18
 
 
+def test_graph_cache_evicts_least_recently_used(lib, tiny):
+    """Round 3: the Euler-solve graph cache holds `graph_cap` shapes (32; 2 here) and evicts the least recently used one when a new shape is captured - before, the
+    ninth shape dropped ALL graphs and none of them was ever captured again (a serving scheduler's shared passes see ~16 shapes per lane).  Three shapes in rotation:
+    results never change, an evicted shape is captured again on its second new sighting, a shape that stays in use is not."""
+    import ctypes as C
+    cfg, sd = tiny
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, n_timesteps=2)
+    lib.cv_flow_set_option(flow._h, b"graph_cap", C.c_int32(2))
+    u = _inputs(cfg)
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    kw = dict(prompt_token=u["prompt_token"], prompt_token_len=t(7), prompt_feat=u["prompt_feat"], prompt_feat_len=t(14), embedding=u["embedding"],
+              streaming=False, finalize=True)
+
+    def stat(name):
+        v = C.c_int64(0)
+        lib.cv_flow_get_stat(flow._h, name, C.byref(v))
+        return v.value
+    run = lambda n: flow.inference(token=u["token"][:, :n], token_len=t(n), **kw)[0].cpu().clone()
+    flow.inference(token=u["token"], token_len=t(13), **kw)                       # the workspaces reach their final size before anything is captured
+    first = {}
+    for n in (13, 11, 13, 11):                                                    # both shapes captured on their second sighting
+        o = run(n); first.setdefault(n, o); assert torch.equal(o, first[n])
+    assert stat(b"graphs_cached") == 2 and stat(b"graph_captures") == 2
+    for n in (9, 13, 9):                                                          # third shape: captured on ITS second sighting, evicting 11 (13 was used since)
+        o = run(n); first.setdefault(n, o); assert torch.equal(o, first[n])
+    assert stat(b"graphs_cached") == 2 and stat(b"graph_captures") == 3
+    assert torch.equal(run(13), first[13]) and stat(b"graph_captures") == 3      # 13 still replays its graph
+    assert torch.equal(run(11), first[11]) and stat(b"graph_captures") == 3      # 11 was evicted: eager now (first new sighting) ...
+    assert torch.equal(run(11), first[11]) and stat(b"graph_captures") == 4      # ... captured again on the second, evicting the least recently used of {9, 13}
+    assert torch.equal(run(9), first[9]) and torch.equal(run(13), first[13]) and stat(b"graphs_cached") == 2
+
+
 def test_no_prompt_and_single_token(lib, tiny):
     """Edge cases of flow.inference: empty prompt (mel_len1 = 0, cross-lingual style call) and the shortest legal input."""
     cfg, sd = tiny
