@@ -137,6 +137,8 @@ def test_graph_cache_evicts_least_recently_used(lib, tiny):
     ninth shape dropped ALL graphs and none of them was ever captured again (a serving scheduler's shared passes see ~16 shapes per lane).  Three shapes in rotation:
     results never change, an evicted shape is captured again on its second new sighting, a shape that stays in use is not."""
     import ctypes as C
+    if not lib.emulated:
+        pytest.skip("host logic of the stage driver (which graph is kept): exercised under the emulator; graph replay itself runs on hardware in the tests around it")
     cfg, sd = tiny
     flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, n_timesteps=2)
     lib.cv_flow_set_option(flow._h, b"graph_cap", C.c_int32(2))
