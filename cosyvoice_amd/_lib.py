@@ -45,7 +45,7 @@ class AttnArgs(C.Structure):
 
 
 CV_F32, CV_BF16, CV_I32, CV_U8 = 0, 1, 2, 3
-ACT = dict(none=0, silu=1, gelu_erf=2, elu=3, leaky=4, tanh=5, mish=6, abs=7, snake=8, logclamp=9, gelu_tanh=10)
+ACT = dict(none=0, silu=1, gelu_erf=2, elu=3, leaky=4, tanh=5, mish=6, abs=7, snake=8, logclamp=9, gelu_tanh=10, relu=11)
 MASK = dict(none=0, causal=1, chunk=2)
 
 

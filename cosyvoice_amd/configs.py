@@ -112,6 +112,15 @@ def tiny_cv1():
             HiftConfig(sr=22050, ups=[8, 8], up_k=[16, 16], src_k=[7, 11], base=32, f0_ch=32))
 
 
+def tiny_cv1_k():
+    """tiny_cv1 with 64-wide attention heads everywhere (what cv_attention serves, and what CosyVoice-300M has: 1024 / 16, 512 / 8, head_dim 64):
+    the emulator-sized configuration of the kernel-backed path (cosyvoice1_hip.py)."""
+    return (CV1Config(text_vocab=50, speech_token_size=40, text_enc_in=32, llm_dim=128, text_heads=2, text_ffn=128, text_blocks=2, llm_heads=2, llm_ffn=128,
+                      llm_blocks=2, spk_dim=16, flow_dim=128, flow_heads=2, flow_ffn=128, flow_blocks=2, est_ch=[32, 32], est_heads=1, est_head_dim=64,
+                      est_blocks=1, est_mid=2),
+            HiftConfig(sr=22050, ups=[8, 8], up_k=[16, 16], src_k=[7, 11], base=32, f0_ch=32))
+
+
 def cv2():
     return LLMConfig(), FlowConfig(), HiftConfig()
 

@@ -1,0 +1,554 @@
+"""CosyVoice-300M (first-generation CosyVoice) on the hand-written gfx950 kernels - SURVEY.md section 8 row f4, second half.
+
+`cosyvoice1.py` is the torch-eager plumbing of BASELINE.json configs[0] (CPU, no HIP library).  This module is the same model with every tensor
+operation of the three stages behind the C ABI of libcosyvoice_amd.so; the host code below only sequences launches and keeps the request state:
+
+  TransformerLM.inference      llm/llm.py:162-223        ConformerEncoder text encoder + 14-block TransformerEncoder stepped with a KV cache:
+                                                          cv_gemm_conv (fp32-exact GEMMs; q + pos_bias_u | q + pos_bias_v | k | v from ONE GEMM over stacked
+                                                          weights, written straight into the layer's cache rows), cv_norm_rows, cv_attention with the
+                                                          relative-position term (matrix_bd of attention.py:318 as a batched GEMM over heads against a
+                                                          per-layer table of linear_pos(pe) that is computed once, not once per step like the reference)
+  MaskedDiffWithXvec.inference flow/flow.py:102-146      ConformerEncoder, InterpolateRegulator (cv_interp_rows, conv + cv_group_norm), ConditionalCFM with
+                                                          the flow cache, the U-Net ConditionalDecoder flow/decoder.py:88-291: Block1D = conv GEMM +
+                                                          cv_group_norm (Mish and the time projection fused), stride-2 Downsample1D and polyphase
+                                                          ConvTranspose Upsample1D as cv_gemm_conv index forms, BasicTransformerBlock on cv_attention;
+                                                          classifier-free guidance + Euler update in cv_cfg_euler
+  HiFTGenerator.inference      hifigan/generator.py:378-569 at 22.05 kHz: cv_hift_f0, the type-1 SineGen source (cv_sinegen1_source), cv_hift_decode
+
+Activations are fp32, channel-last [time][channel] (batch rows stacked); weights are the reference's state-dict tensors repacked once at load time
+(fp32, K padded to 32).  Random draws: the sampler and the CFM noise use the host torch RNG in the reference's order (so the goldens of the real
+classes apply, tests/test_cosyvoice1_hip.py); the SineGen noise does too when `rng="host"` (parity) and comes from the kernel's counter RNG otherwise.
+There is no CPU fallback: without the HIP library `get_lib()` raises.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import cosyvoice1 as C1
+from ._lib import ACT, CV_F32, MASK, AttnArgs, get_lib, stream_ptr
+from .hift import HiFTGenerator as _KernelHiFT
+from .ops import gemm_conv, norm_rows, pack_weight
+
+F32 = torch.float32
+
+
+class _Mat:
+    """A GEMM weight operand: fp32 [N][taps * Kp] on the device (+ bias)."""
+    __slots__ = ("w", "kp", "n", "k", "taps", "b")
+
+    def __init__(self, w, kp, n, k, taps, b):
+        self.w, self.kp, self.n, self.k, self.taps, self.b = w, kp, n, k, taps, b
+
+
+class Kernels:
+    """Launch helpers over the operator-level C ABI for channel-last fp32 activations."""
+
+    def __init__(self, lib=None):
+        self.lib = lib or get_lib()
+        self.dev = torch.device(self.lib.device)
+        self._gn_ws = self.lib.hook(torch.zeros(64 * 64 * 2 * 8, dtype=torch.float64, device=self.dev))      # cv_group_norm partial sums: B * G * 64 doubles
+
+    # ---- memory ----
+    def new(self, *shape):
+        return self.lib.hook(torch.empty(*shape, dtype=F32, device=self.dev))
+
+    def zeros(self, *shape):
+        return self.lib.hook(torch.zeros(*shape, dtype=F32, device=self.dev))
+
+    def put(self, t, dtype=F32):
+        return self.lib.hook(t.detach().to(self.dev, dtype).contiguous())
+
+    def mat(self, w, bias=None):
+        """w: [N, K] or [N, taps, K] (tap-major, channel-minor: the order a channel-last activation window has in memory)."""
+        w = w.detach().float()
+        n, taps, k = (w.shape[0], 1, w.shape[1]) if w.dim() == 2 else w.shape
+        wp, kp = pack_weight(w.to(self.dev), F32)
+        return _Mat(self.lib.hook(wp), kp, n, k, taps, None if bias is None else self.put(bias))
+
+    def conv_mat(self, w, bias=None):
+        """torch Conv1d weight [C_out, C_in, k] -> taps form."""
+        return self.mat(w.permute(0, 2, 1), bias)
+
+    # ---- launches ----
+    def linear(self, x, m, M, *, lda=None, act="none", res=None, out=None, ldc=None, out_scale=1.0):
+        """out[M, N] = act(x[M, K] W^T + b) * out_scale (+ res).  x / out / res may be row-pitched views (lda / ldc; res is indexed like out)."""
+        lda = m.k if lda is None else lda
+        ldc = m.n if ldc is None else ldc
+        if out is None:
+            out = self.new(M, m.n)
+        gemm_conv(self.lib, x, m.w, m.kp, M=M, N=m.n, K=m.k, lda=lda, a_len=(M - 1) * lda + m.k, bias=m.b, out=out, ldc=ldc, c_len=(M - 1) * ldc + m.n,
+                  act=act, res=res, out_scale=out_scale)
+        return out
+
+    def conv(self, x, m, B, T, *, pad, dil=1, act="none", res=None):
+        """Conv1d(stride 1) over [B][T][C_in] -> [B][T_out][N]; zero padding is the range check of the flat index."""
+        t_out = T + 2 * pad - dil * (m.taps - 1)
+        out = self.new(B, t_out, m.n)
+        gemm_conv(self.lib, x, m.w, m.kp, M=t_out, N=m.n, K=m.k, taps=m.taps, lda=m.k, a_off0=-pad * m.k, tap_step=dil * m.k, a_len=T * m.k, a_batch=T * m.k,
+                  bias=m.b, out=out, c_len=t_out * m.n, c_batch=t_out * m.n, batch=B, act=act, res=res, res_batch=t_out * m.n)
+        return out
+
+    def conv_stride(self, x, m, B, T, c_in, *, k, stride, pad):
+        """Strided Conv1d: the im2col window of a channel-last sequence is contiguous, so it is a Linear over rows of pitch stride * C_in (m.k = k * C_in)."""
+        t_out = (T + 2 * pad - k) // stride + 1
+        out = self.new(B, t_out, m.n)
+        gemm_conv(self.lib, x, m.w, m.kp, M=t_out, N=m.n, K=m.k, lda=stride * c_in, a_off0=-pad * c_in, a_len=T * c_in, a_batch=T * c_in, bias=m.b, out=out,
+                  c_len=t_out * m.n, c_batch=t_out * m.n, batch=B)
+        return out, t_out
+
+    def conv_transpose(self, x, m, B, T, c_in, c_out, *, k, stride, pad):
+        """ConvTranspose1d in polyphase form (weights packed by `tconv_mat`): GEMM row j produces output rows j * stride - pad ... + stride - 1."""
+        t_out = (T - 1) * stride - 2 * pad + k
+        out = self.new(B, t_out, c_out)
+        gemm_conv(self.lib, x, m.w, m.kp, M=T + m.taps - 1, N=stride * c_out, K=c_in, taps=m.taps, lda=c_in, a_off0=0, tap_step=-c_in, a_len=T * c_in, a_batch=T * c_in,
+                  bias=m.b, out=out, ldc=stride * c_out, c_off=-pad * c_out, c_len=t_out * c_out, c_batch=t_out * c_out, batch=B)
+        return out, t_out
+
+    def tconv_mat(self, w, bias, stride):
+        """torch ConvTranspose1d weight [C_in, C_out, k] -> [stride * C_out][q taps][C_in] (phase r, tap j holds kernel element r + stride * j)."""
+        w = w.detach().float()
+        cin, cout, k = w.shape
+        q = (k + stride - 1) // stride
+        wp = torch.zeros(stride, cout, q, cin)
+        for r in range(stride):
+            for j in range(q):
+                if r + stride * j < k:
+                    wp[r, :, j, :] = w[:, :, r + stride * j].t()
+        return self.mat(wp.reshape(stride * cout, q, cin), bias.detach().float().repeat(stride))
+
+    def layer_norm(self, x, g, b, eps, act="none", scale=1.0):
+        return norm_rows(self.lib, x, g, b, eps=eps, act=act, scale=scale)
+
+    def group_norm(self, x, B, T, Cc, G, g, b, act="none", col_add=None, eps=1e-5):
+        assert B * G * 64 * 2 <= self._gn_ws.numel()
+        y = self.new(B, T, Cc)
+        self.lib.cv_group_norm(_p(x), _p(y), C.c_int32(B), C.c_int32(T), C.c_int32(Cc), C.c_int32(G), _p(g), _p(b), C.c_float(eps), C.c_int32(ACT[act]),
+                               _p(col_add), C.c_int64(0), _p(self._gn_ws), stream_ptr(self.lib))
+        return y
+
+    def attention(self, q, k, v, *, Tq, Tk, H, B=1, scale, causal=False, rel_bd=None, bd_row=0):
+        """q/k/v: 4-D views [B, T, H, 64] (any row / head / batch pitch that is a multiple of 4 floats) -> o [B, Tq, H, 64] contiguous."""
+        o = self.new(B, Tq, H, 64)
+        a = AttnArgs()
+        for name, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+            assert t.stride(3) == 1 and t.shape[3] == 64
+            setattr(a, name, t.data_ptr())
+            setattr(a, name + "_batch", t.stride(0)); setattr(a, name + "_row", t.stride(1)); setattr(a, name + "_head", t.stride(2))
+        a.B, a.H, a.kv_group, a.Tq, a.Tk = B, H, 1, Tq, Tk
+        a.scale, a.mask_mode, a.chunk = scale, MASK["causal" if causal else "none"], 0
+        if rel_bd is not None:
+            a.rel_bd, a.bd_batch, a.bd_head, a.bd_row = rel_bd.data_ptr(), 0, Tq * bd_row, bd_row
+        a.bf16, a.klen = 0, None
+        self.lib.cv_attention(C.byref(a), stream_ptr(self.lib))
+        return o
+
+    def gather(self, table, ids):
+        """rows of an fp32 [V, D] device table for int ids (host list / tensor) -> [n, D]."""
+        ids = self.put(torch.as_tensor(ids).reshape(-1), torch.int32)
+        out = self.new(ids.numel(), table.shape[1])
+        self.lib.cv_gather_rows(_p(table), C.c_int32(CV_F32), C.c_int64(table.shape[0]), C.c_int32(table.shape[1]), _p(ids), C.c_int32(ids.numel()), _p(out),
+                                C.c_float(1.0), stream_ptr(self.lib))
+        return out
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# espnet encoders with relative positions (transformer/encoder.py, encoder_layer.py, attention.py:249-330, embedding.py:201-302)
+# ------------------------------------------------------------------------------------------------------------------------------------
+class _KVState:
+    """Per-layer rows [cap, 4 d] = (q + u | q + v | k | v) of everything forwarded so far (forward_chunk's att_cache, kept in place)."""
+
+    def __init__(self, kern, n_layers, d, cap):
+        self.kern, self.d, self.len, self.cap = kern, d, 0, cap
+        self.rows = [kern.zeros(cap, 4 * d) for _ in range(n_layers)]
+
+    def reserve(self, n):
+        if n <= self.cap:
+            return
+        cap = max(n, 2 * self.cap)
+        for i, old in enumerate(self.rows):
+            new = self.kern.zeros(cap, 4 * self.d)
+            new[: self.len].copy_(old[: self.len])
+            self.rows[i] = new
+        self.cap = cap
+
+
+class EspnetEncoder(C1.EspnetEncoder):
+    """cosyvoice1.EspnetEncoder with every operation on the kernels.  Head size must be 64 (cv_attention): 1024 / 16 and 512 / 8 in CosyVoice-300M."""
+
+    def __init__(self, sd, prefix, heads, kind, causal=False, kern=None):
+        super().__init__(sd, prefix, heads, kind, causal)
+        self.k = kern or Kernels()
+        assert self.d == heads * 64, "cv_attention serves 64-wide heads"
+        p, K = self.p, self.k
+        self.embed = K.mat(p("embed.out.0.weight"), p("embed.out.0.bias"))
+        self.embed_ln = (K.put(p("embed.out.1.weight")), K.put(p("embed.out.1.bias")))
+        self.after = (K.put(p("after_norm.weight")), K.put(p("after_norm.bias")))
+        n_att, n_ff = ("norm_mha.", "norm_ff.") if kind == "conformer" else ("norm1.", "norm2.")
+        self.layers = []
+        for i in range(self.n_layers):
+            L = p.sub("encoders.%d." % i)
+            a = L.sub("self_attn.")
+            u, v = a("pos_bias_u").reshape(-1), a("pos_bias_v").reshape(-1)
+            wq, bq = a("linear_q.weight"), a("linear_q.bias")
+            w4 = torch.cat([wq, wq, a("linear_k.weight"), a("linear_v.weight")], 0)
+            b4 = torch.cat([bq + u, bq + v, a("linear_k.bias"), a("linear_v.bias")], 0)
+            self.layers.append(dict(
+                ln1=(K.put(L(n_att + "weight")), K.put(L(n_att + "bias"))), ln2=(K.put(L(n_ff + "weight")), K.put(L(n_ff + "bias"))),
+                qkv=K.mat(w4, b4), pos=K.mat(a("linear_pos.weight")), out=K.mat(a("linear_out.weight"), a("linear_out.bias")),
+                w1=K.mat(L("feed_forward.w_1.weight"), L("feed_forward.w_1.bias")), w2=K.mat(L("feed_forward.w_2.weight"), L("feed_forward.w_2.bias"))))
+        self._pos_n, self._pos_tab = 0, None
+
+    # linear_pos(pe) for every relative position of a window of `n` keys, per layer: row m of the table is relative position n_tab - 1 - m
+    def _pos_tables(self, n_keys):
+        if n_keys > self._pos_n:
+            n = max(64, self._pos_n)
+            while n < n_keys:
+                n *= 2
+            pe = self.k.put(C1.EspnetEncoder._pos(self, n, torch.zeros(1)))
+            self._pos_tab = [self.k.linear(pe, L["pos"], 2 * n - 1) for L in self.layers]
+            self._pos_n = n
+        return self._pos_n, self._pos_tab
+
+    def _embed(self, xs, M):
+        y = self.k.linear(xs, self.embed, M)
+        return self.k.layer_norm(y, *self.embed_ln, 1e-5, act="relu" if self.kind == "transformer" else "none", scale=math.sqrt(self.d))
+
+    def _layer(self, i, x, t1, rows, t0, causal):
+        """x [t1, d]; rows: the layer's [cap, 4 d] buffer holding t0 earlier positions."""
+        K, L, d, H = self.k, self.layers[i], self.d, self.heads
+        n_keys = t0 + t1
+        K.linear(K.layer_norm(x, *L["ln1"], 1e-12), L["qkv"], t1, out=rows[t0:], ldc=4 * d)
+        n_tab, tabs = self._pos_tables(n_keys)
+        P = t1 - 1 + n_keys                                    # columns rel_shift can reach: bd[i][c] is relative position n_keys - 1 - c
+        Pp = (P + 3) // 4 * 4
+        bd = K.new(H, t1, Pp)
+        pp = tabs[i][n_tab - n_keys:]
+        gemm_conv(K.lib, rows[t0:, d:], pp, 64, M=t1, N=P, K=64, lda=4 * d, a_batch=64, a_len=(t1 - 1) * 4 * d + 64, ldw=d, w_batch=64,
+                  out=bd, ldc=Pp, c_batch=t1 * Pp, c_len=t1 * Pp, batch=H)
+        heads = lambda t: t.unflatten(1, (H, 64)).unsqueeze(0)
+        o = K.attention(heads(rows[t0:n_keys, 0:d]), heads(rows[:n_keys, 2 * d:3 * d]), heads(rows[:n_keys, 3 * d:4 * d]), Tq=t1, Tk=n_keys, H=H, scale=0.125,
+                        causal=causal and t1 > 1, rel_bd=bd, bd_row=Pp)
+        x = K.linear(o, L["out"], t1, res=x)
+        y = K.linear(K.layer_norm(x, *L["ln2"], 1e-12), L["w1"], t1, act="silu" if self.kind == "conformer" else "relu")
+        return K.linear(y, L["w2"], t1, res=x)
+
+    def forward(self, xs):
+        """xs [T, d_in] on the device -> [T, d]."""
+        T = xs.shape[0]
+        x = self._embed(xs, T)
+        for i in range(self.n_layers):
+            x = self._layer(i, x, T, self.k.new(T, 4 * self.d), 0, self.causal)
+        return self.k.layer_norm(x, *self.after, 1e-5)
+
+    def forward_chunk(self, xs, state):
+        """BaseEncoder.forward_chunk with the whole history kept: xs [t1, d_in] (a view is fine), state = _KVState or None -> (ys [t1, d], state)."""
+        t1 = xs.shape[0]
+        if state is None:
+            state = _KVState(self.k, self.n_layers, self.d, max(256, 2 * t1))
+        state.reserve(state.len + t1)
+        x = self._embed(xs, t1)
+        for i in range(self.n_layers):
+            x = self._layer(i, x, t1, state.rows[i], state.len, True)
+        state.len += t1
+        return self.k.layer_norm(x, *self.after, 1e-5), state
+
+
+class TransformerLM(C1.TransformerLM):
+    """cosyvoice.llm.llm.TransformerLM.inference (llm/llm.py:162-223) on the kernels; sampling decisions on the host like the reference's python sampler."""
+
+    def __init__(self, sd, text_heads=16, llm_heads=16, sampling=C1.ras_sampling, lib=None):
+        self.k = K = Kernels(lib)
+        self.sd = sd
+        self.text_encoder = EspnetEncoder(sd, "text_encoder.", text_heads, "conformer", causal=True, kern=K)
+        self.llm = EspnetEncoder(sd, "llm.", llm_heads, "transformer", kern=K)
+        self.speech_token_size = sd["llm_decoder.weight"].shape[0] - 1
+        self.llm_input_size = sd["llm_embedding.weight"].shape[1]
+        self.sos, self.task_id, self.eos_token = 0, 1, self.speech_token_size
+        self.sampling = sampling
+        self.text_emb, self.llm_emb, self.speech_emb = K.put(sd["text_embedding.weight"]), K.put(sd["llm_embedding.weight"]), K.put(sd["speech_embedding.weight"])
+        self.affine = K.mat(sd["text_encoder_affine_layer.weight"], sd["text_encoder_affine_layer.bias"])
+        self.spk_affine = K.mat(sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"])
+        self.decoder = K.mat(sd["llm_decoder.weight"], sd["llm_decoder.bias"])
+
+    def encode_text(self, ids):
+        """text_encoder + text_encoder_affine_layer (llm.py:84-91) for one unpadded id sequence -> [n, D] on the device."""
+        x = self.text_encoder.forward(self.k.gather(self.text_emb, ids))
+        return self.k.linear(x, self.affine, x.shape[0])
+
+    @torch.inference_mode()
+    def inference(self, text, text_len, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len, embedding,
+                  sampling=25, max_token_text_ratio=20, min_token_text_ratio=2, uuid=""):
+        K, D = self.k, self.llm_input_size
+        ids = torch.cat([prompt_text, text], dim=1).reshape(-1).to(torch.int32)
+        n_text, n_prompt = int(text.shape[1]), int(prompt_speech_token.shape[1])
+        has_spk = embedding.shape[0] != 0
+        L = 1 + int(has_spk) + ids.numel() + 1 + n_prompt
+        lm_input = K.new(L, D)                                  # [sos | speaker | encoded text | task id | prompt speech tokens]
+        r = 0
+        lm_input[r:r + 1].copy_(self.llm_emb[self.sos:self.sos + 1]); r += 1
+        if has_spk:
+            e = torch.nn.functional.normalize(embedding.float().cpu(), dim=1)     # 192 numbers: normalised on the host
+            K.linear(K.put(e), self.spk_affine, 1, out=lm_input[r:]); r += 1
+        enc = self.encode_text(ids)
+        lm_input[r:r + ids.numel()].copy_(enc); r += ids.numel()
+        lm_input[r:r + 1].copy_(self.llm_emb[self.task_id:self.task_id + 1]); r += 1
+        if n_prompt:
+            lm_input[r:r + n_prompt].copy_(K.gather(self.speech_emb, prompt_speech_token))
+        min_len, max_len = int(n_text * min_token_text_ratio), int(n_text * max_token_text_ratio)
+        out_tokens, state, x = [], None, lm_input
+        for i in range(max_len):
+            y, state = self.llm.forward_chunk(x, state)
+            logits = K.linear(y[-1:], self.decoder, 1)
+            logp = logits.reshape(-1).cpu().log_softmax(dim=-1)    # the sampler draws from the host RNG, like the reference's python sampler
+            if i < min_len:
+                logp[self.speech_token_size] = -float("inf")
+            top = self.sampling(logp, out_tokens, sampling)
+            if top == self.eos_token:
+                break
+            yield top
+            out_tokens.append(top)
+            x = self.speech_emb[top:top + 1]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# flow: MaskedDiffWithXvec (flow/flow.py:25-146)
+# ------------------------------------------------------------------------------------------------------------------------------------
+class ConditionalDecoder:
+    """flow/decoder.py:88-291 (the non-causal U-Net estimator) for the classifier-free-guidance pair: activations [2][T][C] channel-last."""
+
+    def __init__(self, sd, prefix, heads, kern):
+        self.k = K = kern
+        p = self.p = C1._P(sd, prefix)
+        self.heads = heads
+        self.in_channels = p("time_mlp.linear_1.weight").shape[1]
+        self.t1, self.t2 = K.mat(p("time_mlp.linear_1.weight"), p("time_mlp.linear_1.bias")), K.mat(p("time_mlp.linear_2.weight"), p("time_mlp.linear_2.bias"))
+        self.resnets = []                                       # every ResnetBlock1D in execution order (their time projections are batched over the Euler steps)
+        self.down = [self._stage(p.sub("down_blocks.%d." % i), "down") for i in range(p.count("down_blocks."))]
+        self.mid = [self._stage(p.sub("mid_blocks.%d." % i), "mid") for i in range(p.count("mid_blocks."))]
+        self.up = [self._stage(p.sub("up_blocks.%d." % i), "up") for i in range(p.count("up_blocks."))]
+        self.final = self._block(p.sub("final_block."))
+        self.proj = K.conv_mat(p("final_proj.weight"), p("final_proj.bias"))
+
+    def _block(self, p):
+        return dict(conv=self.k.conv_mat(p("block.0.weight"), p("block.0.bias")), g=self.k.put(p("block.1.weight")), b=self.k.put(p("block.1.bias")))
+
+    def _stage(self, p, kind):
+        K, r = self.k, p.sub("0.")
+        res = dict(b1=self._block(r.sub("block1.")), b2=self._block(r.sub("block2.")), mlp=K.mat(r("mlp.1.weight"), r("mlp.1.bias")),
+                   rc=K.conv_mat(r("res_conv.weight"), r("res_conv.bias")), idx=len(self.resnets))
+        self.resnets.append(res)
+        blocks = []
+        for j in range(p.count("1.")):
+            t = p.sub("1.%d." % j)
+            inner = t("attn1.to_q.weight").shape[0]
+            assert inner == self.heads * 64, "cv_attention serves 64-wide heads"
+            blocks.append(dict(ln1=(K.put(t("norm1.weight")), K.put(t("norm1.bias"))), ln3=(K.put(t("norm3.weight")), K.put(t("norm3.bias"))),
+                               qkv=K.mat(torch.cat([t("attn1.to_q.weight"), t("attn1.to_k.weight"), t("attn1.to_v.weight")], 0)),
+                               out=K.mat(t("attn1.to_out.0.weight"), t("attn1.to_out.0.bias")), inner=inner,
+                               ff1=K.mat(t("ff.net.0.proj.weight"), t("ff.net.0.proj.bias")), ff2=K.mat(t("ff.net.2.weight"), t("ff.net.2.bias"))))
+        st = dict(res=res, blocks=blocks, kind=kind)
+        if kind == "mid":
+            return st
+        if p.get("2.conv.weight") is not None:                   # Downsample1D: Conv1d(k 3, stride 2, pad 1) / Upsample1D: ConvTranspose1d(k 4, stride 2, pad 1)
+            w, b = p("2.conv.weight"), p("2.conv.bias")
+            st["resample"] = K.mat(w.permute(0, 2, 1).reshape(w.shape[0], -1), b) if kind == "down" else K.tconv_mat(w, b, 2)
+            st["ch"] = (w.shape[1], w.shape[0]) if kind == "down" else (w.shape[0], w.shape[1])
+        else:
+            st["plain"] = K.conv_mat(p("2.weight"), p("2.bias"))
+        return st
+
+    def prepare(self, t_host):
+        """time_mlp(SinusoidalPosEmb(t)) for every Euler step at once, then every ResnetBlock1D's Linear(Mish(t_emb)): [n_steps, C] per block."""
+        K, n = self.k, len(t_host)
+        emb = K.new(n, self.in_channels)
+        K.lib.cv_time_sinusoid(_p(K.put(torch.tensor(t_host, dtype=F32))), _p(emb), C.c_int32(n), C.c_int32(self.in_channels), stream_ptr(K.lib))
+        temb = K.linear(K.linear(emb, self.t1, n, act="silu"), self.t2, n, act="mish")       # t_emb only ever enters through Mish (matcha ResnetBlock1D.mlp)
+        return [K.linear(temb, r["mlp"], n) for r in self.resnets]
+
+    def _run_block(self, blk, x, T, col_add=None):
+        K = self.k
+        return K.group_norm(K.conv(x, blk["conv"], 2, T, pad=1), 2, T, blk["conv"].n, 8, blk["g"], blk["b"], act="mish", col_add=col_add)
+
+    def _run_stage(self, st, x, T, tproj, step):
+        K, r = self.k, st["res"]
+        h = self._run_block(r["b1"], x, T, col_add=tproj[r["idx"]][step])
+        h = self._run_block(r["b2"], h, T)
+        x = K.linear(x, r["rc"], 2 * T, res=h)                                                # res_conv (1 x 1) + block2's output
+        Cc = r["rc"].n
+        for b in st["blocks"]:
+            inner, H = b["inner"], self.heads
+            qkv = K.linear(K.layer_norm(x, *b["ln1"], 1e-5), b["qkv"], 2 * T)
+            v4 = lambda j: qkv.view(2, T, 3 * inner)[:, :, j * inner:(j + 1) * inner].unflatten(2, (H, 64))
+            o = K.attention(v4(0), v4(1), v4(2), Tq=T, Tk=T, H=H, B=2, scale=0.125)
+            x = K.linear(o, b["out"], 2 * T, res=x)
+            y = K.linear(K.layer_norm(x, *b["ln3"], 1e-5), b["ff1"], 2 * T, act="gelu_erf")
+            x = K.linear(y, b["ff2"], 2 * T, res=x)
+        return x, Cc
+
+    def __call__(self, h, T, tproj, step):
+        """h: packed input [2][T][in_channels] -> [2][T][mel] (the mask of an unpadded batch-1 request is all ones)."""
+        K, x, hiddens = self.k, h, []
+        for st in self.down:
+            x, Cc = self._run_stage(st, x, T, tproj, step)
+            hiddens.append((x, T, Cc))
+            if "resample" in st:
+                x, T = K.conv_stride(x, st["resample"], 2, T, Cc, k=3, stride=2, pad=1)
+            else:
+                x = K.conv(x, st["plain"], 2, T, pad=1)
+        for st in self.mid:
+            x, Cc = self._run_stage(st, x, T, tproj, step)
+        for st in self.up:
+            skip, Ts, Cs = hiddens.pop()
+            cat = K.new(2, Ts, Cc + Cs)                                                       # x[:, :, :Ts] ++ skip along channels
+            K.lib.cv_concat_cols(_p(x), C.c_int32(Cc), C.c_int64(T * Cc), _p(skip), C.c_int32(Cs), C.c_int64(Ts * Cs), _p(cat), C.c_int32(Ts), C.c_int32(2), stream_ptr(K.lib))
+            x, Cc = self._run_stage(st, cat, Ts, tproj, step)
+            T = Ts
+            if "resample" in st:
+                x, T = K.conv_transpose(x, st["resample"], 2, T, st["ch"][0], st["ch"][1], k=4, stride=2, pad=1)
+                Cc = st["ch"][1]
+            else:
+                x = K.conv(x, st["plain"], 2, T, pad=1)
+        x = self._run_block(self.final, x, T)
+        return K.linear(x, self.proj, 2 * T), T
+
+
+class MaskedDiffWithXvec(C1.MaskedDiffWithXvec):
+    def __init__(self, sd, enc_heads=8, est_heads=8, input_frame_rate=50, n_timesteps=10, inference_cfg_rate=0.7, lib=None):
+        self.k = K = Kernels(lib)
+        self.sd, self.input_frame_rate, self.n_timesteps, self.cfg_rate = sd, input_frame_rate, n_timesteps, inference_cfg_rate
+        self.encoder = EspnetEncoder(sd, "encoder.", enc_heads, "conformer", kern=K)
+        self.estimator = ConditionalDecoder(sd, "decoder.estimator.", est_heads, K)
+        self.output_size = sd["encoder_proj.weight"].shape[0]
+        self.input_emb = K.put(sd["input_embedding.weight"])
+        self.spk_affine = K.mat(sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"])
+        self.enc_proj = K.mat(sd["encoder_proj.weight"], sd["encoder_proj.bias"])
+        p = C1._P(sd, "length_regulator.model.")
+        last = max(int(k[len(p.prefix):].split(".")[0]) for k in sd if k.startswith(p.prefix))
+        self.reg = [(K.conv_mat(p("%d.weight" % i), p("%d.bias" % i)), K.put(p("%d.weight" % (i + 1))), K.put(p("%d.bias" % (i + 1)))) for i in range(0, last, 3)]
+        self.reg_out = K.conv_mat(p("%d.weight" % last), p("%d.bias" % last))
+
+    def _interp(self, h, a, b, out, row, size):
+        """out[row : row + size] = F.interpolate(h[a:b] over time, size) (length_regulator.py:52-70), channel-last rows."""
+        K, Cc = self.k, h.shape[1]
+        K.lib.cv_interp_rows(_p(h[a:]), _p(out[row:]), C.c_int32(Cc), C.c_int32(b - a), C.c_int32(size), C.c_int32(Cc), stream_ptr(K.lib))
+
+    def _regulate(self, x, T):
+        K = self.k
+        for conv, g, b in self.reg:
+            x = K.group_norm(K.conv(x, conv, 1, T, pad=1), 1, T, conv.n, 1, g, b, act="mish")
+        return K.linear(x, self.reg_out, T)
+
+    @torch.inference_mode()
+    def inference(self, token, token_len, prompt_token, prompt_token_len, prompt_feat, prompt_feat_len, embedding, flow_cache):
+        assert token.shape[0] == 1
+        K, mel = self.k, self.output_size
+        e = torch.nn.functional.normalize(embedding.float().cpu(), dim=1)
+        spk = K.linear(K.put(e), self.spk_affine, 1)                                           # [1, 80]
+        n1, n2 = int(prompt_token.shape[1]), int(token.shape[1])
+        ids = torch.cat([prompt_token.reshape(-1), token.reshape(-1)]).long().clamp(min=0)
+        enc = self.encoder.forward(K.gather(self.input_emb, ids))
+        h = K.linear(enc, self.enc_proj, n1 + n2)                                              # [n1 + n2, 80]
+        mel_len1, mel_len2 = int(prompt_feat.shape[1]), int(n2 / self.input_frame_rate * 22050 / 256)
+        T = mel_len1 + mel_len2
+        x = K.new(T, mel)
+        if n1 != 0:
+            self._interp(h, 0, n1, x, 0, mel_len1)
+        edge = int(20 / self.input_frame_rate * 22050 / 256)
+        if n2 > 40:                                            # head / middle / tail stretched separately: the 20-token overlap of consecutive chunks maps to the same frames
+            self._interp(h, n1, n1 + 20, x, mel_len1, edge)
+            self._interp(h, n1 + 20, n1 + n2 - 20, x, mel_len1 + edge, mel_len2 - 2 * edge)
+            self._interp(h, n1 + n2 - 20, n1 + n2, x, T - edge, edge)
+        else:
+            self._interp(h, n1, n1 + n2, x, mel_len1, mel_len2)
+        mu = self._regulate(x, T)                                                              # [T, 80]
+        cond = K.zeros(T, mel)
+        if mel_len1:
+            cond[:mel_len1].copy_(prompt_feat.reshape(mel_len1, mel).to(K.dev, F32))
+        feat, flow_cache = self._cfm(mu, spk, cond, T, mel_len1, flow_cache)
+        out = K.new(mel, mel_len2)                                                             # [T][80] rows mel_len1.. -> the reference's [1, 80, mel_len2]
+        K.lib.cv_transpose(_p(feat[mel_len1:]), _p(out), C.c_int32(mel_len2), C.c_int32(mel), stream_ptr(K.lib))
+        return out.unsqueeze(0), flow_cache
+
+    def _cfm(self, mu, spk, cond, T, prompt_len, cache):
+        """ConditionalCFM.forward + solve_euler (flow/flow_matching.py:36-124) with the prompt / overlap flow cache of CosyVoice-300M."""
+        K, mel = self.k, self.output_size
+        z = torch.randn(1, mel, T)                               # drawn on the host like the reference's `.to(mu.device)`: same stream on every device
+        cache = torch.zeros(1, mel, 0, 2) if cache is None else cache.cpu()
+        n_cache = cache.shape[2]
+        if n_cache != 0:
+            z[:, :, :n_cache] = cache[:, :, :, 0]
+            mu[:n_cache].copy_(cache[0, :, :, 1].t().to(K.dev))
+        mu_cf = mu.cpu().t().unsqueeze(0)
+        keep = lambda a: torch.cat([a[:, :, :prompt_len], a[:, :, -34:]], dim=2)
+        new_cache = torch.stack([keep(z), keep(mu_cf)], dim=-1)
+        t_span = torch.linspace(0, 1, self.n_timesteps + 1, dtype=F32)
+        t_span = 1 - torch.cos(t_span * 0.5 * torch.pi)
+        ts, dts = [], []
+        t, dt = t_span[0], t_span[1] - t_span[0]                  # the reference's fp32 running sums (flow_matching.py:94-123)
+        for step in range(1, len(t_span)):
+            ts.append(float(t)); dts.append(float(dt))
+            t = t + dt
+            if step < len(t_span) - 1:
+                dt = t_span[step + 1] - t
+        tproj = self.estimator.prepare(ts)
+        x = K.put(z[0].t())                                                                    # [T, 80]
+        h = K.new(2, T, 4 * mel)
+        for step in range(len(ts)):
+            K.lib.cv_pack_cfg_input(_p(x), _p(mu), _p(spk), _p(cond), _p(h), C.c_int32(T), C.c_int32(mel), stream_ptr(K.lib))
+            d, _ = self.estimator(h, T, tproj, step)
+            K.lib.cv_cfg_euler(_p(x), _p(d), C.c_int64(T * mel), C.c_float(dts[step]), C.c_float(self.cfg_rate), stream_ptr(K.lib))
+        return x, new_cache
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# HiFTGenerator at 22.05 kHz (hifigan/generator.py:378-569): the shared vocoder handle (f0 predictor, conv stack, iSTFT) + the type-1 SineGen source
+# ------------------------------------------------------------------------------------------------------------------------------------
+class HiFTGenerator(_KernelHiFT):
+    def __init__(self, state_dict, cfg, lib=None, seed=1986, rng="device", _tensors=None):
+        """rng: "host" draws the SineGen phases AND noise from the global torch RNG in the reference's order (parity with the goldens of the real class);
+        "device": phases from the host RNG (9 numbers), noise from the kernel's counter RNG keyed by seed + call count."""
+        super().__init__(state_dict, cfg, lib=lib, seed=seed, _tensors=_tensors)
+        assert cfg.sr == 22050 and not cfg.causal, "the 24 kHz generators (SineGen2) are cosyvoice_amd.hift.HiFTGenerator / CausalHiFTGenerator"
+        self.rng = rng
+        self._ws = None
+
+    @torch.inference_mode()
+    def inference(self, speech_feat, cache_source=None):
+        lib, cfg, m = self.lib, self.cfg, speech_feat.shape[2]
+        L, H1 = m * self.upsample_scale, cfg.harmonics + 1
+        f0 = self.f0_predictor(speech_feat)                                                    # [1, m] on the device
+        phase = -np.pi + torch.rand(1, H1, 1) * (2 * np.pi)                                     # Uniform(-pi, pi).sample() of SineGen.forward
+        phase[:, 0, :] = 0
+        noise = None
+        if self.rng == "host":
+            noise = lib.hook(torch.randn(1, H1, L).to(self.device).contiguous())
+            torch.randn(1, 1, L)                                                               # the reference draws (and discards) the noise branch: keep the RNG in step
+        self._calls += 1
+        if self._ws is None or self._ws.numel() < m * H1 * 2:
+            self._ws = lib.hook(torch.zeros(max(256, m) * H1 * 2, dtype=torch.float64, device=self.device))
+        s = lib.hook(torch.empty(1, 1, L, dtype=F32, device=self.device))
+        ph = lib.hook(phase.reshape(-1).to(self.device, F32).contiguous())
+        lib.cv_sinegen1_source(_p(f0), C.c_int32(m), C.c_int32(self.upsample_scale), C.c_int32(cfg.harmonics), C.c_float(cfg.sr), _p(ph), _p(noise),
+                               C.c_uint64(self.seed + self._calls), _p(self._tensors["source.w"]), _p(self._tensors["source.b"]), C.c_float(cfg.nsf_alpha),
+                               C.c_float(cfg.nsf_sigma), C.c_float(cfg.voiced_thr), _p(s), _p(self._ws), stream_ptr(lib))
+        if cache_source is not None and cache_source.shape[2] != 0:
+            s[:, :, :cache_source.shape[2]] = cache_source.to(self.device)
+        return self.decode(speech_feat, s), s
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+class CosyVoiceModel(C1.CosyVoiceModel):
+    """cli.model.CosyVoiceModel (cli/model.py:27-242) over the kernel-backed stages: same `load`, `tts`, `token2wav`, per-uuid state."""
+
+    def load(self, llm_model, flow_model, hift_model, hift_cfg=None, lib=None, **kw):
+        from .configs import cv1
+        ld = lambda f: {k: v.float() for k, v in torch.load(f, map_location="cpu", weights_only=True).items()}
+        self.llm = TransformerLM(ld(llm_model), lib=lib, **{k: kw[k] for k in ("text_heads", "llm_heads") if k in kw})
+        self.flow = MaskedDiffWithXvec(ld(flow_model), lib=lib, **{k: kw[k] for k in ("enc_heads", "est_heads", "input_frame_rate") if k in kw})
+        self.hift = HiFTGenerator({k.replace("generator.", ""): v for k, v in ld(hift_model).items()}, hift_cfg or cv1()[1], lib=lib, **kw.get("hift", {}))

@@ -24,6 +24,7 @@ enum Act : int {
     ACT_MISH = 6, ACT_ABS = 7, ACT_SNAKE = 8,
     ACT_LOGCLAMP = 9,      // log(max(x, p)): log-mel of matcha.utils.audio.mel_spectrogram
     ACT_GELU_TANH = 10,    // nn.GELU(approximate='tanh'): the DiT feed-forward (flow/DiT/modules.py:514)
+    ACT_RELU = 11,         // CosyVoice-300M: LegacyLinearNoSubsampling and the TransformerEncoder feed-forward (transformer/subsampling.py:338-383)
 };
 
 // Activations.  At ~1 workgroup per CU nothing hides VALU work, and libm's erff / tanhf / log1pf expand to 40-150 instructions per
@@ -64,6 +65,7 @@ __device__ __forceinline__ float4 apply_act4(int act, float4 v, float p) {
     if (act == ACT_NONE) return v;
     if (act == ACT_LEAKY) return make_float4(v.x > 0.f ? v.x : v.x * p, v.y > 0.f ? v.y : v.y * p, v.z > 0.f ? v.z : v.z * p, v.w > 0.f ? v.w : v.w * p);
     if (act == ACT_ABS) return make_float4(fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w));
+    if (act == ACT_RELU) return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
     if (act == ACT_LOGCLAMP) return make_float4(logf(fmaxf(v.x, p)), logf(fmaxf(v.y, p)), logf(fmaxf(v.z, p)), logf(fmaxf(v.w, p)));
     return act4_call(act, v);
 }
@@ -71,6 +73,7 @@ __device__ __forceinline__ float apply_act(int act, float v, float p) {      // 
     if (act == ACT_NONE) return v;
     if (act == ACT_LEAKY) return v > 0.f ? v : v * p;
     if (act == ACT_ABS) return fabsf(v);
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
     if (act == ACT_LOGCLAMP) return logf(fmaxf(v, p));
     return act4_call(act, make_float4(v, 0.f, 0.f, 0.f)).x;
 }

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 
-from .configs import CV1Config, FlowConfig, HiftConfig, LLMConfig, cv1, cv2, cv3_flow, cv3_llm, tiny, tiny_cv1, tiny_cv3_flow, tiny_cv3_llm  # noqa: F401
+from .configs import CV1Config, FlowConfig, HiftConfig, LLMConfig, cv1, cv2, cv3_flow, cv3_llm, tiny, tiny_cv1, tiny_cv1_k, tiny_cv3_flow, tiny_cv3_llm  # noqa: F401
 
 
 class _Gen:

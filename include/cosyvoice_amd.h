@@ -24,7 +24,7 @@ typedef struct cv_hift cv_hift;
 
 enum { CV_F32 = 0, CV_BF16 = 1, CV_I32 = 2, CV_U8 = 3 };      /* CV_U8: OCP fp8 e4m3 bit patterns (the opt-in fp8 weights of the batched LLM decode) */
 enum { CV_ACT_NONE = 0, CV_ACT_SILU = 1, CV_ACT_GELU_ERF = 2, CV_ACT_ELU = 3, CV_ACT_LEAKY = 4, CV_ACT_TANH = 5,
-       CV_ACT_MISH = 6, CV_ACT_ABS = 7, CV_ACT_SNAKE = 8, CV_ACT_LOGCLAMP = 9 /* log(max(x, act_p)) */, CV_ACT_GELU_TANH = 10 };
+       CV_ACT_MISH = 6, CV_ACT_ABS = 7, CV_ACT_SNAKE = 8, CV_ACT_LOGCLAMP = 9 /* log(max(x, act_p)) */, CV_ACT_GELU_TANH = 10, CV_ACT_RELU = 11 };
 enum { CV_MASK_NONE = 0, CV_MASK_CAUSAL = 1, CV_MASK_CHUNK = 2 };
 
 const char* cv_last_error(void);
@@ -283,6 +283,40 @@ int cv_stft_magnitude(const float* spec, float* mag, int32_t T, int32_t bins, in
 int cv_stft_power(const float* spec, float* pw, int32_t T, int32_t bins, int32_t ldm, void* stream);
 int cv_whisper_lognorm(const float* lnmel, float* out, int32_t T, int32_t n_mels, void* stream);
 int cv_sub_col_mean(float* x, int32_t T, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * SURVEY.md section 8 row f4 - CosyVoice-300M (first generation) on the kernels.  Its three stages are sequenced by the host side
+ * (cosyvoice_amd/cosyvoice1_hip.py: TransformerLM.inference llm/llm.py:162-223, MaskedDiffWithXvec.inference flow/flow.py:102-146,
+ * HiFTGenerator.inference at 22.05 kHz hifigan/generator.py:557-569) over the operator-level entry points above (cv_gemm_conv, cv_norm_rows,
+ * cv_attention, cv_gather_rows, cv_hift_f0, cv_hift_decode) plus the operators below.  Activations: dev fp32, channel-last [batch][time][channel].
+ * ---------------------------------------------------------------------------------------------------- */
+/* torch.nn.GroupNorm(G, C) over a [B, C, T] tensor held channel-last, with the activation and a per-(batch, channel) addend fused:
+ * y = act((x - mean_bg) * rstd_bg * gamma[c] + beta[c]) + col_add[b * col_add_batch + c]   (Matcha Block1D: Conv1d -> GroupNorm(8) -> Mish, and the
+ * ResnetBlock1D's `+ mlp(t_emb)` - flow/decoder.py:88-205 via matcha.models.components.decoder; InterpolateRegulator's GroupNorm(1), length_regulator.py:36-44).
+ * Statistics are accumulated in double.  workspace: dev, B * G * 64 doubles.  gamma / beta / col_add may be NULL. */
+int cv_group_norm(const float* x, float* y, int32_t B, int32_t T, int32_t C, int32_t G, const float* gamma, const float* beta, float eps, int32_t act,
+                  const float* col_add, int64_t col_add_batch, double* workspace, void* stream);
+/* SourceModuleHnNSF over SineGen (the 22.05 kHz generator's harmonic source, hifigan/generator.py:125-186, 318-375): f0 dev [frames] (one value per mel
+ * frame; the reference's nearest up-sampling by `scale` is implicit) -> source_out dev [frames * scale] = tanh(l_linear(sine waves)).  phase0: dev
+ * [harmonics + 1] initial phases (the reference draws Uniform(-pi, pi), first entry 0); noise: dev [harmonics + 1][frames * scale] N(0, 1) variates
+ * (parity hook) or NULL -> in-kernel counter RNG keyed by `seed`.  The running phase is the exact per-frame closed form of the reference's fp32 cumsum.
+ * workspace: dev, frames * (harmonics + 1) * 12 bytes, 8-byte aligned. */
+int cv_sinegen1_source(const float* f0, int32_t frames, int32_t scale, int32_t harmonics, float sr, const float* phase0, const float* noise, uint64_t seed,
+                       const float* lin_w, const float* lin_b, float amp, float sigma, float thr, float* source_out, void* workspace, void* stream);
+/* One Euler step of ConditionalCFM.solve_euler with classifier-free guidance (flow/flow_matching.py:94-123): x[i] += dt * ((1 + rate) * d[i] - rate * d[n + i]). */
+int cv_cfg_euler(float* x, const float* d, int64_t n, float dt, float rate, void* stream);
+/* The estimator's input for the guidance pair (flow_matching.py:101-108 + decoder.py:225-231): x, mu, cond dev [T][mel], spks dev [mel] ->
+ * h dev [2][T][4 mel] = (x | mu | spks | cond) for row 0 and (x | 0 | 0 | 0) for row 1. */
+int cv_pack_cfg_input(const float* x, const float* mu, const float* spks, const float* cond, float* h, int32_t T, int32_t mel, void* stream);
+/* matcha SinusoidalPosEmb(dim)(t, scale = 1000): t dev [n] -> out dev [n][dim] = (sin | cos). */
+int cv_time_sinusoid(const float* t, float* out, int32_t n, int32_t dim, void* stream);
+/* out[b][t] = (a[b][t][0:ca] | bb[b][t][0:cb]) for t < T; a_batch / b_batch: floats between the batch rows of a / bb (their own lengths may exceed T:
+ * the U-Net cuts the up-sampled stream to the skip connection's length, flow/decoder.py:275). */
+int cv_concat_cols(const float* a, int32_t ca, int64_t a_batch, const float* b, int32_t cb, int64_t b_batch, float* out, int32_t T, int32_t B, void* stream);
+/* F.interpolate(mode="linear") over time for channel-last rows: x dev [T][C] -> y rows 0 .. Tn - 1 of pitch ldy (length_regulator.py:52-70). */
+int cv_interp_rows(const float* x, float* y, int32_t C, int32_t T, int32_t Tn, int32_t ldy, void* stream);
+/* out [cols][rows] = in [rows][cols] transposed (channel-last <-> channel-first at the API boundary). */
+int cv_transpose(const float* in, float* out, int32_t rows, int32_t cols, void* stream);
 
 #ifdef __cplusplus
 }

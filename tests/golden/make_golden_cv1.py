@@ -23,7 +23,11 @@ import ref_import  # noqa: E402
 ref_import.install()
 from cosyvoice_amd import synthetic as W  # noqa: E402
 
-CFG, HCFG = W.tiny_cv1()
+# `--k`: the same vectors at configs.tiny_cv1_k() (64-wide heads) for the kernel-backed path, written as cv1k_*.npz
+KMODE = "--k" in sys.argv
+CFG, HCFG = W.tiny_cv1_k() if KMODE else W.tiny_cv1()
+TAG = "cv1k" if KMODE else "cv1"
+N_MODEL_TOKENS = 150 if KMODE else 270      # cv1k: one streamed chunk + the final one (the emulator runs every Euler step of both)
 
 
 def save(name, **arrs):
@@ -73,7 +77,7 @@ def golden_llm():
                                                   prompt_speech_token_len=t(0), embedding=emb, max_token_text_ratio=5, min_token_text_ratio=2)))
     with torch.inference_mode():
         enc, _ = m.encode(m.text_embedding(torch.cat([prompt_text, text], 1)), t(11))
-    save("cv1_llm", text=text, prompt_text=prompt_text, prompt_speech_token=prompt_speech, embedding=emb, text_encoded=enc[0], **out)
+    save(TAG + "_llm", text=text, prompt_text=prompt_text, prompt_speech_token=prompt_speech, embedding=emb, text_encoded=enc[0], **out)
 
 
 def build_flow():
@@ -113,7 +117,7 @@ def golden_flow():
         feat, cache = flow.inference(token=token, token_len=t(n), prompt_token=prompt_token, prompt_token_len=t(12), prompt_feat=prompt_feat,
                                      prompt_feat_len=t(25), embedding=emb, flow_cache=cache)
         out["token_" + name], out["feat_" + name], out["cache_" + name] = token, feat, cache
-    save("cv1_flow", prompt_token=prompt_token, prompt_feat=prompt_feat, embedding=emb, **out)
+    save(TAG + "_flow", prompt_token=prompt_token, prompt_feat=prompt_feat, embedding=emb, **out)
 
 
 def build_hift():
@@ -138,7 +142,7 @@ def golden_hift():
     speech2, source2 = h.inference(speech_feat=feat, cache_source=cs)
     with torch.inference_mode():
         f0 = h.f0_predictor(feat)
-    save("cv1_hift", feat=feat, f0=f0, speech=speech, source=source, cache_source=cs, speech2=speech2, source2=source2)
+    save(TAG + "_hift", feat=feat, f0=f0, speech=speech, source=source, cache_source=cs, speech2=speech2, source2=source2)
     return h
 
 
@@ -147,7 +151,7 @@ def golden_model():
     import cosyvoice.cli.model as M
     flow, hift = build_flow(), build_hift()
     g = torch.Generator().manual_seed(13)
-    tokens = torch.randint(0, 40, (270,), generator=g).tolist()           # hop 100 + overlap 20: two streamed chunks and a final one
+    tokens = torch.randint(0, 40, (N_MODEL_TOKENS,), generator=g).tolist()  # hop 100 + overlap 20: two streamed chunks and a final one (270 tokens)
     prompt_token = torch.randint(0, 40, (1, 10), generator=g, dtype=torch.int32)
     prompt_feat = torch.randn(1, 17, 80, generator=g) * 2 - 5
     emb = torch.randn(1, 16, generator=g)
@@ -169,11 +173,11 @@ def golden_model():
         out[key + "_n"] = np.array([c.shape[1] for c in chunks])
         out[key] = torch.cat(chunks, 1)
     out["offline"] = out["offline"][:, :30000]                   # one-shot synthesis has no chunk seams: its head pins it (keeps the fixture small)
-    save("cv1_model", tokens=np.array(tokens), prompt_token=prompt_token, prompt_feat=prompt_feat,
+    save(TAG + "_model", tokens=np.array(tokens), prompt_token=prompt_token, prompt_feat=prompt_feat,
          embedding=emb, **out)
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["llm", "flow", "hift", "model"]
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or (["llm", "flow", "model"] if KMODE else ["llm", "flow", "hift", "model"])
     for w in which:
         globals()["golden_" + w]()

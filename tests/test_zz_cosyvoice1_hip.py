@@ -1,0 +1,115 @@
+"""SURVEY.md section 8 row f4 (second half): CosyVoice-300M on the hand-written kernels (cosyvoice_amd/cosyvoice1_hip.py) against golden vectors made
+by the REAL reference classes (tests/golden/make_golden_cv1.py --k: TransformerLM, MaskedDiffWithXvec, cli.model.CosyVoiceModel at configs.tiny_cv1_k(),
+the 22.05 kHz HiFTGenerator at configs.tiny_cv1()'s vocoder) on the same seeded weights and the same host-RNG seeds.  Every test runs under the emulator
+(`-m "not gpu"`) and on the MI355X (`-m gpu`).  The vocoder and the two CosyVoiceModel tests live in files of their own (test_zz_cosyvoice1_hip_*.py):
+under the emulator each is minutes of work, and pytest-xdist hands out whole files.  (File names: they sort after the CosyVoice2 / CosyVoice3 suites.)"""
+import torch
+
+from cosyvoice_amd import cosyvoice1 as C1
+from cosyvoice_amd import cosyvoice1_hip as CK
+from cosyvoice_amd import synthetic as W
+from cv1k_common import CFG, HCFG, build_flow, gold, greedy, t
+
+
+def test_group_norm_matches_torch(lib):
+    """cv_group_norm (+ Mish, + per-channel add) against torch.nn.functional.group_norm on the channel-first view, incl. a group that spans the whole utterance."""
+    K = CK.Kernels(lib)
+    g = torch.Generator().manual_seed(3)
+    for B, T, Cc, G in ((2, 37, 32, 8), (1, 211, 80, 1), (2, 9000, 8, 2)):
+        x = torch.randn(B, T, Cc, generator=g) * 2 + 0.7
+        gamma, beta, add = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+        want = torch.nn.functional.mish(torch.nn.functional.group_norm(x.transpose(1, 2), G, gamma, beta)).transpose(1, 2) + add
+        got = K.group_norm(K.put(x), B, T, Cc, G, K.put(gamma), K.put(beta), act="mish", col_add=K.put(add)).cpu()
+        torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
+
+
+def test_conv_index_forms_match_torch(lib):
+    """Strided Conv1d, ConvTranspose1d (polyphase) and `same` Conv1d of the U-Net as cv_gemm_conv index forms, batch of two channel-last sequences."""
+    K = CK.Kernels(lib)
+    g = torch.Generator().manual_seed(4)
+    F = torch.nn.functional
+    for T in (21, 22):
+        x = torch.randn(2, T, 32, generator=g)
+        w, b = torch.randn(32, 32, 3, generator=g) * 0.1, torch.randn(32, generator=g)
+        want = F.conv1d(x.transpose(1, 2), w, b, stride=2, padding=1).transpose(1, 2)
+        got, t_out = K.conv_stride(K.put(x), K.mat(w.permute(0, 2, 1).reshape(32, -1), b), 2, T, 32, k=3, stride=2, pad=1)
+        assert t_out == want.shape[1]
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
+        wt = torch.randn(32, 24, 4, generator=g) * 0.1
+        bt = torch.randn(24, generator=g)
+        want = F.conv_transpose1d(x.transpose(1, 2), wt, bt, stride=2, padding=1).transpose(1, 2)
+        got, t_out = K.conv_transpose(K.put(x), K.tconv_mat(wt, bt, 2), 2, T, 32, 24, k=4, stride=2, pad=1)
+        assert t_out == want.shape[1] == 2 * T
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
+        want = F.relu(F.conv1d(x.transpose(1, 2), w, b, padding=1)).transpose(1, 2)
+        torch.testing.assert_close(K.conv(K.put(x), K.conv_mat(w, b), 2, T, pad=1, act="relu").cpu(), want, rtol=1e-5, atol=1e-5)
+
+
+def test_transformer_lm_tokens_match_reference(lib):
+    g = gold("cv1k_llm")
+    kw = dict(text=g["text"], text_len=t(7), prompt_text=g["prompt_text"], prompt_text_len=t(4), prompt_speech_token=g["prompt_speech_token"],
+              prompt_speech_token_len=t(9), embedding=g["embedding"])
+    sd = W.make_cv1_llm(CFG)
+    lm = CK.TransformerLM(sd, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling=greedy, lib=lib)
+    ids = torch.cat([g["prompt_text"], g["text"]], 1).reshape(-1)
+    torch.testing.assert_close(lm.encode_text(ids).cpu(), g["text_encoded"], rtol=1e-4, atol=1e-4)          # causal ConformerEncoder + affine
+    assert list(lm.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw)) == g["tokens_greedy"].tolist()      # prefill + stepped KV cache
+    e0 = torch.zeros(1, 0, dtype=torch.int32)
+    sft = dict(kw, prompt_text=e0, prompt_text_len=t(0), prompt_speech_token=e0, prompt_speech_token_len=t(0))
+    assert list(lm.inference(max_token_text_ratio=5, min_token_text_ratio=2, **sft)) == g["tokens_sft"].tolist()
+    lm.sampling = C1.ras_sampling                                  # repetition-aware sampling on the host RNG: same seed -> the reference's tokens
+    torch.manual_seed(7)
+    got = list(lm.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw))
+    assert got == g["tokens_ras"].tolist() and 14 <= len(got) <= 42
+    # the torch-eager plumbing (configs[0]) agrees at this configuration too
+    ref = C1.TransformerLM(sd, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling=greedy)
+    assert list(ref.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw)) == g["tokens_greedy"].tolist()
+
+
+def test_kv_state_grows_in_place(lib):
+    """forward_chunk's cache rows are reallocated (doubling) when a request outgrows them: stepping row by row equals one causal pass."""
+    sd = W.make_cv1_llm(CFG)
+    K = CK.Kernels(lib)
+    enc = CK.EspnetEncoder(sd, "llm.", CFG.llm_heads, "transformer", kern=K)
+    x = torch.randn(9, CFG.llm_dim, generator=torch.Generator().manual_seed(1))
+    xd = K.put(x)
+    whole, _ = enc.forward_chunk(xd, None)
+    state = CK._KVState(K, enc.n_layers, enc.d, 4)                 # cap 4 < 9 rows
+    rows = []
+    for i in range(9):
+        y, state = enc.forward_chunk(xd[i:i + 1], state)
+        rows.append(y.cpu())
+    assert state.cap >= 9 and state.len == 9
+    torch.testing.assert_close(torch.cat(rows), whole.cpu(), rtol=1e-4, atol=1e-4)
+    ref, _ = C1.EspnetEncoder(sd, "llm.", CFG.llm_heads, "transformer").forward_chunk(x, None)
+    torch.testing.assert_close(whole.cpu(), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_flow_inference_with_flow_cache_matches_reference(lib):
+    g = gold("cv1k_flow")
+    flow = build_flow(lib)
+    cache = torch.zeros(1, 80, 0, 2)
+    for name, n in (("a", 50), ("b", 30)):                         # 50 tokens: head / middle / tail interpolation; "b" runs on "a"'s flow cache
+        torch.manual_seed(40 + n)
+        feat, cache = flow.inference(token=g["token_" + name], token_len=t(n), prompt_token=g["prompt_token"], prompt_token_len=t(12), prompt_feat=g["prompt_feat"],
+                                     prompt_feat_len=t(25), embedding=g["embedding"], flow_cache=cache)
+        assert feat.shape == g["feat_" + name].shape == (1, 80, int(n / 50 * 22050 / 256))
+        torch.testing.assert_close(feat.cpu(), g["feat_" + name], rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(cache.cpu(), g["cache_" + name], rtol=1e-4, atol=1e-4)
+
+
+def test_load_takes_reference_state_dict_files(lib, tmp_path):
+    """CosyVoiceModel.load(llm.pt, flow.pt, hift.pt) (cli/model.py:65-73) into the kernel-backed stages; an inference_sft-shaped request end to end."""
+    torch.save(W.make_cv1_llm(CFG), tmp_path / "llm.pt")
+    torch.save(W.make_cv1_flow(CFG), tmp_path / "flow.pt")
+    torch.save({"generator." + k: v for k, v in W.make_hift(HCFG).items()}, tmp_path / "hift.pt")
+    m = CK.CosyVoiceModel()
+    m.load(str(tmp_path / "llm.pt"), str(tmp_path / "flow.pt"), str(tmp_path / "hift.pt"), hift_cfg=HCFG, lib=lib, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads,
+           enc_heads=CFG.flow_heads, est_heads=CFG.est_heads)
+    m.llm.sampling = greedy
+    g = gold("cv1k_llm")
+    inf = m.llm.inference
+    m.llm.inference = lambda **kw: inf(**dict(kw, max_token_text_ratio=3, min_token_text_ratio=3))
+    torch.manual_seed(1)
+    out = next(iter(m.tts(text=g["text"], flow_embedding=g["embedding"], llm_embedding=g["embedding"], stream=False)))["tts_speech"]
+    assert out.shape == (1, int(21 / 50 * 22050 / 256) * 256) and torch.isfinite(out).all() and float(out.abs().max()) > 0
