@@ -1,4 +1,4 @@
-"""Shared helpers of the kernel-backed CosyVoice-300M tests (tests/test_zz_cosyvoice1_hip*.py; TEST INFRASTRUCTURE)."""
+"""Shared helpers of the kernel-backed CosyVoice-300M tests (tests/test_zzz_cosyvoice1_hip*.py; TEST INFRASTRUCTURE)."""
 import os
 
 import numpy as np

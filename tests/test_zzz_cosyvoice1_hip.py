@@ -1,7 +1,7 @@
 """SURVEY.md section 8 row f4 (second half): CosyVoice-300M on the hand-written kernels (cosyvoice_amd/cosyvoice1_hip.py) against golden vectors made
 by the REAL reference classes (tests/golden/make_golden_cv1.py --k: TransformerLM, MaskedDiffWithXvec, cli.model.CosyVoiceModel at configs.tiny_cv1_k(),
 the 22.05 kHz HiFTGenerator at configs.tiny_cv1()'s vocoder) on the same seeded weights and the same host-RNG seeds.  Every test runs under the emulator
-(`-m "not gpu"`) and on the MI355X (`-m gpu`).  The vocoder and the two CosyVoiceModel tests live in files of their own (test_zz_cosyvoice1_hip_*.py):
+(`-m "not gpu"`) and on the MI355X (`-m gpu`).  The vocoder and the two CosyVoiceModel tests live in files of their own (test_zzz_cosyvoice1_hip_*.py):
 under the emulator each is minutes of work, and pytest-xdist hands out whole files.  (File names: they sort after the CosyVoice2 / CosyVoice3 suites.)"""
 import torch
 

@@ -1,4 +1,4 @@
-"""Kernel-backed CosyVoice-300M, the 22.05 kHz HiFTGenerator (see tests/test_zz_cosyvoice1_hip.py)."""
+"""Kernel-backed CosyVoice-300M, the 22.05 kHz HiFTGenerator (see tests/test_zzz_cosyvoice1_hip.py)."""
 import torch
 
 from cv1k_common import build_hift, gold
