@@ -32,6 +32,41 @@ def register_tensors(lib, set_fn, handle, tensors):
         getattr(lib, set_fn)(handle, name.encode(), C.c_void_p(t.data_ptr()), C.c_int32(dt), C.c_int64(t.numel()))
 
 
+class Qwen2Encoder:
+    """Boundary B2, the finer hook: `Qwen2LM.llm.forward_one_step(xs, masks, cache)` of the reference (cosyvoice/llm/llm.py:242-254) over the handle's device KV
+    cache, so that the reference's OWN decode loop (llm.py:535-549: forward_one_step -> llm_decoder -> sampling_ids -> speech_embedding) can run unchanged on top of
+    the kernels - with `Qwen2LM.llm_decoder` and `Qwen2LM.speech_embedding` below.  The device loop of `Qwen2LM.inference` is the fast path; this one costs a
+    host round trip per token, exactly like the reference.
+
+    xs: [1, n, hidden] fp32 (n >= 1: a prompt, an appended text / speech mix, or one token embedding).  cache: None starts a new sequence; otherwise the object the
+    previous call returned (the KV cache lives in the handle: one live sequence per Qwen2LM object, a stale cache object is refused).  masks: accepted and
+    ignored - the reference always passes the lower-triangular mask of everything forwarded so far (llm.py:540), which is what the kernels compute.
+    Returns (y [1, 1, hidden], cache): the final-norm hidden state of the LAST position - the only row the reference's callers read (`y_pred[:, -1]`)."""
+
+    def __init__(self, lm):
+        self.lm, self._gen, self._pos = lm, 0, 0
+
+    @torch.inference_mode()
+    def forward_one_step(self, xs, masks=None, cache=None):
+        from .ops import norm_rows
+        lm = self.lm
+        rows = lm.lib.hook(xs.reshape(-1, lm.cfg.hidden).to(lm.device, torch.float32).contiguous())
+        n = rows.shape[0]
+        with lm.lock:
+            if cache is None:
+                self._gen, self._pos = self._gen + 1, 0
+            elif cache != ("cv_llm_kv", id(self), self._gen):
+                raise ValueError("forward_one_step: this cache belongs to a sequence that was replaced (one live KV cache per Qwen2LM handle)")
+            if self._pos + n + 2 >= lm.max_len:
+                raise ValueError("forward_one_step: KV capacity %d exhausted" % lm.max_len)
+            fn = lm.lib.cv_llm_prefill if cache is None else lm.lib.cv_llm_prefill_append
+            fn(lm._h, C.c_void_p(rows.data_ptr()), C.c_int32(n), stream_ptr(lm.lib))
+            self._pos += n
+            h = lm.lib.hook(lm.last_hidden().to(lm.device).reshape(1, -1))             # last row of the residual stream (the final norm is fused into the head GEMV of the device loop)
+            y = norm_rows(lm.lib, h, gamma=lm._tensors["norm"], eps=lm.cfg.rms_eps, rms=True)
+        return y.reshape(1, 1, -1), ("cv_llm_kv", id(self), self._gen)
+
+
 class Qwen2LM:
     """cosyvoice/llm/llm.py:257-549 (inference side).  `sampling` is 'ras' (the yaml default, cosyvoice2.yaml:32-36) or
     'greedy' (the sampler north-star parity is defined on)."""
@@ -133,6 +168,28 @@ class Qwen2LM:
         out = torch.empty(self.cfg.hidden, dtype=torch.float32)
         self.lib.cv_llm_last_hidden(self._h, C.c_void_p(out.data_ptr()), stream_ptr(self.lib))
         return out
+
+    # ---- the reference's module attributes used by its own decode loop (llm/llm.py:535-549); see Qwen2Encoder
+    @property
+    def llm(self):
+        if getattr(self, "_encoder", None) is None:
+            self._encoder = Qwen2Encoder(self)
+        return self._encoder
+
+    @torch.inference_mode()
+    def llm_decoder(self, y):
+        """nn.Linear(hidden, speech_token_size + specials) (llm.py:283): y [..., hidden] -> logits [..., V] on the device (bf16 weights, fp32-exact product)."""
+        from .ops import gemm_conv
+        w, H = self._tensors["head.w"], self.cfg.hidden
+        rows = self.lib.hook(y.reshape(-1, H).to(self.device, torch.float32).contiguous())
+        out = gemm_conv(self.lib, rows, w, w.shape[1], M=rows.shape[0], N=w.shape[0], K=H, bias=self._tensors["head.b"])
+        return out.reshape(*y.shape[:-1], w.shape[0])
+
+    @torch.inference_mode()
+    def speech_embedding(self, ids):
+        """nn.Embedding(speech_token_size + specials, hidden) (llm.py:287): int ids [...] -> [..., hidden] fp32 on the device."""
+        ids = torch.as_tensor(ids)
+        return self._rows(self._tensors["embed.speech"], ids.reshape(-1)).reshape(*ids.shape, self.cfg.hidden)
 
     def decode(self, n_steps, sp, stream=None):
         buf = (C.c_int32 * max(n_steps, 1))()
