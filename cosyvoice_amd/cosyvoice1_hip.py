@@ -30,24 +30,29 @@ from . import cosyvoice1 as C1
 from ._lib import ACT, CV_F32, MASK, AttnArgs, get_lib, stream_ptr
 from .hift import HiFTGenerator as _KernelHiFT
 from .ops import gemm_conv, norm_rows, pack_weight
+from .weights import split3_planes
 
 F32 = torch.float32
 
 
 class _Mat:
     """A GEMM weight operand: fp32 [N][taps * Kp] on the device (+ bias)."""
-    __slots__ = ("w", "kp", "n", "k", "taps", "b")
+    __slots__ = ("w", "kp", "n", "k", "taps", "b", "w3")
 
-    def __init__(self, w, kp, n, k, taps, b):
-        self.w, self.kp, self.n, self.k, self.taps, self.b = w, kp, n, k, taps, b
+    def __init__(self, w, kp, n, k, taps, b, w3=None):
+        self.w, self.kp, self.n, self.k, self.taps, self.b, self.w3 = w, kp, n, k, taps, b, w3
 
 
 class Kernels:
     """Launch helpers over the operator-level C ABI for channel-last fp32 activations."""
 
-    def __init__(self, lib=None):
+    def __init__(self, lib=None, split3=False):
+        """split3: every weight matrix also as three bf16 planes (weights.split3_planes), so that the GEMMs run both operands split on the bf16 matrix pipe
+        (csrc/gemm_conv.h WX3: six exact plane products per k, fp32 accuracy) instead of the fp32 MFMA chain.  Same results to fp32 rounding; which one is
+        faster at these shapes is a measurement for the first MI355X run of this path (HiFT: neutral), so it is an option."""
         self.lib = lib or get_lib()
         self.dev = torch.device(self.lib.device)
+        self.split3 = bool(split3)
         self._gn_ws = self.lib.hook(torch.zeros(64 * 64 * 2 * 8, dtype=torch.float64, device=self.dev))      # cv_group_norm partial sums: B * G * 64 doubles
 
     # ---- memory ----
@@ -67,7 +72,8 @@ class Kernels:
         w = w.detach().float()
         n, taps, k = (w.shape[0], 1, w.shape[1]) if w.dim() == 2 else w.shape
         wp, kp = pack_weight(w.to(self.dev), F32)
-        return _Mat(self.lib.hook(wp), kp, n, k, taps, None if bias is None else self.put(bias))
+        w3 = self.lib.hook(split3_planes(wp)) if self.split3 else None
+        return _Mat(self.lib.hook(wp), kp, n, k, taps, None if bias is None else self.put(bias), w3)
 
     def conv_mat(self, w, bias=None):
         """torch Conv1d weight [C_out, C_in, k] -> taps form."""
@@ -81,7 +87,7 @@ class Kernels:
         if out is None:
             out = self.new(M, m.n)
         gemm_conv(self.lib, x, m.w, m.kp, M=M, N=m.n, K=m.k, lda=lda, a_len=(M - 1) * lda + m.k, bias=m.b, out=out, ldc=ldc, c_len=(M - 1) * ldc + m.n,
-                  act=act, res=res, out_scale=out_scale)
+                  act=act, res=res, out_scale=out_scale, w3=m.w3)
         return out
 
     def conv(self, x, m, B, T, *, pad, dil=1, act="none", res=None):
@@ -89,7 +95,7 @@ class Kernels:
         t_out = T + 2 * pad - dil * (m.taps - 1)
         out = self.new(B, t_out, m.n)
         gemm_conv(self.lib, x, m.w, m.kp, M=t_out, N=m.n, K=m.k, taps=m.taps, lda=m.k, a_off0=-pad * m.k, tap_step=dil * m.k, a_len=T * m.k, a_batch=T * m.k,
-                  bias=m.b, out=out, c_len=t_out * m.n, c_batch=t_out * m.n, batch=B, act=act, res=res, res_batch=t_out * m.n)
+                  bias=m.b, out=out, c_len=t_out * m.n, c_batch=t_out * m.n, batch=B, act=act, res=res, res_batch=t_out * m.n, w3=m.w3)
         return out
 
     def conv_stride(self, x, m, B, T, c_in, *, k, stride, pad):
@@ -97,7 +103,7 @@ class Kernels:
         t_out = (T + 2 * pad - k) // stride + 1
         out = self.new(B, t_out, m.n)
         gemm_conv(self.lib, x, m.w, m.kp, M=t_out, N=m.n, K=m.k, lda=stride * c_in, a_off0=-pad * c_in, a_len=T * c_in, a_batch=T * c_in, bias=m.b, out=out,
-                  c_len=t_out * m.n, c_batch=t_out * m.n, batch=B)
+                  c_len=t_out * m.n, c_batch=t_out * m.n, batch=B, w3=m.w3)
         return out, t_out
 
     def conv_transpose(self, x, m, B, T, c_in, c_out, *, k, stride, pad):
@@ -105,7 +111,7 @@ class Kernels:
         t_out = (T - 1) * stride - 2 * pad + k
         out = self.new(B, t_out, c_out)
         gemm_conv(self.lib, x, m.w, m.kp, M=T + m.taps - 1, N=stride * c_out, K=c_in, taps=m.taps, lda=c_in, a_off0=0, tap_step=-c_in, a_len=T * c_in, a_batch=T * c_in,
-                  bias=m.b, out=out, ldc=stride * c_out, c_off=-pad * c_out, c_len=t_out * c_out, c_batch=t_out * c_out, batch=B)
+                  bias=m.b, out=out, ldc=stride * c_out, c_off=-pad * c_out, c_len=t_out * c_out, c_batch=t_out * c_out, batch=B, w3=m.w3)
         return out, t_out
 
     def tconv_mat(self, w, bias, stride):
@@ -264,8 +270,8 @@ class EspnetEncoder(C1.EspnetEncoder):
 class TransformerLM(C1.TransformerLM):
     """cosyvoice.llm.llm.TransformerLM.inference (llm/llm.py:162-223) on the kernels; sampling decisions on the host like the reference's python sampler."""
 
-    def __init__(self, sd, text_heads=16, llm_heads=16, sampling=C1.ras_sampling, lib=None):
-        self.k = K = Kernels(lib)
+    def __init__(self, sd, text_heads=16, llm_heads=16, sampling=C1.ras_sampling, lib=None, split3=False):
+        self.k = K = Kernels(lib, split3)
         self.sd = sd
         self.text_encoder = EspnetEncoder(sd, "text_encoder.", text_heads, "conformer", causal=True, kern=K)
         self.llm = EspnetEncoder(sd, "llm.", llm_heads, "transformer", kern=K)
@@ -421,8 +427,8 @@ class ConditionalDecoder:
 
 
 class MaskedDiffWithXvec(C1.MaskedDiffWithXvec):
-    def __init__(self, sd, enc_heads=8, est_heads=8, input_frame_rate=50, n_timesteps=10, inference_cfg_rate=0.7, lib=None):
-        self.k = K = Kernels(lib)
+    def __init__(self, sd, enc_heads=8, est_heads=8, input_frame_rate=50, n_timesteps=10, inference_cfg_rate=0.7, lib=None, split3=False):
+        self.k = K = Kernels(lib, split3)
         self.sd, self.input_frame_rate, self.n_timesteps, self.cfg_rate = sd, input_frame_rate, n_timesteps, inference_cfg_rate
         self.encoder = EspnetEncoder(sd, "encoder.", enc_heads, "conformer", kern=K)
         self.estimator = ConditionalDecoder(sd, "decoder.estimator.", est_heads, K)

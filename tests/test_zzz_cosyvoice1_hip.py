@@ -113,3 +113,20 @@ def test_load_takes_reference_state_dict_files(lib, tmp_path):
     torch.manual_seed(1)
     out = next(iter(m.tts(text=g["text"], flow_embedding=g["embedding"], llm_embedding=g["embedding"], stream=False)))["tts_speech"]
     assert out.shape == (1, int(21 / 50 * 22050 / 256) * 256) and torch.isfinite(out).all() and float(out.abs().max()) > 0
+
+
+def test_split3_weights_option(lib):
+    """Kernels(split3=True): every weight GEMM with both operands split on the bf16 matrix pipe (gemm_conv.h WX3) - the same tokens and the same mel to fp32
+    rounding as the fp32 MFMA chain."""
+    g = gold("cv1k_llm")
+    kw = dict(text=g["text"], text_len=t(7), prompt_text=g["prompt_text"], prompt_text_len=t(4), prompt_speech_token=g["prompt_speech_token"],
+              prompt_speech_token_len=t(9), embedding=g["embedding"])
+    lm = CK.TransformerLM(W.make_cv1_llm(CFG), text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling=greedy, lib=lib, split3=True)
+    assert lm.affine.w3 is not None and lm.affine.w3.dtype == torch.bfloat16
+    assert list(lm.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw)) == g["tokens_greedy"].tolist()
+    g = gold("cv1k_flow")
+    flow = CK.MaskedDiffWithXvec(W.make_cv1_flow(CFG), enc_heads=CFG.flow_heads, est_heads=CFG.est_heads, input_frame_rate=CFG.input_frame_rate, lib=lib, split3=True)
+    torch.manual_seed(90)
+    feat, _ = flow.inference(token=g["token_a"], token_len=t(50), prompt_token=g["prompt_token"], prompt_token_len=t(12), prompt_feat=g["prompt_feat"],
+                             prompt_feat_len=t(25), embedding=g["embedding"], flow_cache=torch.zeros(1, 80, 0, 2))
+    torch.testing.assert_close(feat.cpu(), g["feat_a"], rtol=1e-3, atol=1e-3)

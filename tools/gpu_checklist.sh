@@ -1,12 +1,12 @@
 #!/bin/bash
 # One gpurun call for the start of a round: validates the tree on hardware and collects the reference numbers (round-3 end values in brackets):
-#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/gpu_checklist.sh'
-# Writes under gpurun_out/checklist/.  Order: cheapest / most important first; every step has its own timeout.  ~7 GPU-minutes.
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_checklist.sh'
+# Writes under gpurun_out/checklist/.  Order: cheapest / most important first; every step has its own timeout.  ~12 GPU-minutes.
 set -u
 O=gpurun_out/checklist; mkdir -p $O
 R=$GRAFT_REPO_ROOT
 run() { local name=$1; shift; echo "== $name"; timeout -k 5 "$@" > $O/$name.log 2>&1; echo "   rc=$? ($(tail -1 $O/$name.log | cut -c1-150))"; }
-run pytest_gpu            500 python -X faulthandler -m pytest tests -q -m gpu -p no:cacheprovider         # [197 passed, 2 skipped, ~3.5 min]
+run pytest_gpu            800 python -X faulthandler -m pytest tests -q -m gpu -p no:cacheprovider         # [197 passed, 2 skipped, ~3.5 min]
 run smoke                  60 python -c "import __graft_entry__ as g; g.smoke()"
 # the driver's command; the line carries every other BASELINE.json configuration as an extra (each in a process of its own, 2 lanes):
 # [55.4 audio-s/s, first chunk 58.9 ms, gate/up 0.39; 8 streaming clients 150 audio-s/s at p50 120 ms; batch 8 / 16 216 / 296; mixed64 292; cosyvoice3 61 / 350]
@@ -17,11 +17,18 @@ for line in open(sys.argv[1]):
     if line.startswith("{"):
         d = json.loads(line)
         print("bench", d["value"], d["ms_per_step"], "first chunk", d.get("first_chunk_ms_p50"), d.get("stages"))
-        for k in ("streaming_clients", "batched_decode", "batched_decode_16", "mixed64", "cosyvoice3"):
+        for k in ("streaming_clients", "batched_decode", "batched_decode_16", "mixed64", "cosyvoice3", "cosyvoice300m"):
             print("  ", k, d.get(k))
         r = d["roofline"]; print("   roofline", {k: r.get(k) for k in ("achieved", "frac", "avg_launch_us", "decode_step_us_from_chains")})
 PY
+# CosyVoice-300M on the kernels (first hardware run at the start of round 4: no reference values yet): stage times, host share, fp32 chain vs split3
+run probe_cv1             300 python tools/probe_cv1.py
+run probe_cv1_split3      300 python tools/probe_cv1.py split3
 run probe_flow_ragged     120 python tools/probe_flow_batch.py ragged                                  # [x1.5 - x2.3, bit-identical]
 ( cd /tmp && export TMPDIR=/tmp && timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_utt -- python $R/tools/profile_utt.py > $R/$O/prof_utt.log 2>&1; echo "== rocprof hot path rc=$?" )
 f=$(find $O/prof_utt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/rocprof_utt_kernel_stats.csv && head -12 "$f" | cut -c1-170
 rm -rf $O/prof_utt
+( cd /tmp && export TMPDIR=/tmp && timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_cv1 -- python $R/tools/probe_cv1.py profile > $R/$O/prof_cv1.log 2>&1; echo "== rocprof cosyvoice-300m rc=$?" )
+f=$(find $O/prof_cv1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/rocprof_cv1_kernel_stats.csv && head -12 "$f" | cut -c1-170
+rm -rf $O/prof_cv1
+[ -f gpurun_out/r3_cv1_fullsize_errors.json ] && cp gpurun_out/r3_cv1_fullsize_errors.json $O/   # measured full-size errors of tests/test_zzzz_cosyvoice1_fullsize.py: tighten its bounds to 3x these
