@@ -43,6 +43,51 @@ class _Mat:
         self.w, self.kp, self.n, self.k, self.taps, self.b, self.w3 = w, kp, n, k, taps, b, w3
 
 
+class LaunchTape:
+    """A recorded sequence of library launches with the buffers they touch.  The host side of this model is python: issuing a launch costs ~20 us of
+    interpreter time (argument structs, output allocation, views) against 3-10 us of kernel time, so a sequence that repeats - the estimator of every Euler
+    step after the first, the LM decode step - is recorded once and then replayed as bare ctypes calls on the SAME buffers (~2 us per launch); what changes
+    between replays is patched into the recorded argument structs (`structs`).  The role a hipGraph plays for the CosyVoice2 path, kept on the host side so
+    that the CPU emulator exercises it too."""
+
+    def __init__(self, lib):
+        self.lib, self.calls, self.keep, self.stream = lib, [], [], None
+
+    def replay(self):
+        for fn, args in self.calls:
+            if fn(*args) != 0:
+                self.lib.check(1)
+
+    @property
+    def structs(self):
+        """the argument struct of every call that takes one (cv_gemm_conv, cv_attention), None for the others - in call order"""
+        return [getattr(a[0], "_obj", None) if a else None for _, a in self.calls]
+
+
+class _Recorder:
+    """Stands in for the Lib handle while a LaunchTape is recorded: every cv_* call is executed AND appended, every tensor that passes through hook() - which is
+    every buffer the launch helpers allocate - is kept alive with the tape."""
+
+    def __init__(self, lib, tape):
+        self._lib, self._tape = lib, tape
+
+    def hook(self, t):
+        r = self._lib.hook(t)
+        if r is not None:
+            self._tape.keep.append(r)
+        return r
+
+    def __getattr__(self, name):
+        if not name.startswith("cv_"):
+            return getattr(self._lib, name)
+        raw = self._lib.raw(name)
+
+        def call(*args):
+            self._lib.check(raw(*args))
+            self._tape.calls.append((raw, args))
+        return call
+
+
 class Kernels:
     """Launch helpers over the operator-level C ABI for channel-last fp32 activations."""
 
@@ -54,6 +99,28 @@ class Kernels:
         self.dev = torch.device(self.lib.device)
         self.split3 = bool(split3)
         self._gn_ws = self.lib.hook(torch.zeros(64 * 64 * 2 * 8, dtype=torch.float64, device=self.dev))      # cv_group_norm partial sums: B * G * 64 doubles
+        self.use_tapes = True                                   # False: every launch sequenced from scratch (A/B and test knob)
+
+    def record(self):
+        """`with K.record() as tape:` - the launches issued inside are executed and recorded (LaunchTape)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            real = self.lib
+            tape = LaunchTape(real)
+            sp = stream_ptr(real)
+            tape.stream = None if sp is None else sp.value
+            self.lib = _Recorder(real, tape)
+            try:
+                yield tape
+            finally:
+                self.lib = real
+        return cm()
+
+    def same_stream(self, tape):
+        sp = stream_ptr(self.lib)
+        return tape.stream == (None if sp is None else sp.value)
 
     # ---- memory ----
     def new(self, *shape):
@@ -227,14 +294,15 @@ class EspnetEncoder(C1.EspnetEncoder):
         y = self.k.linear(xs, self.embed, M)
         return self.k.layer_norm(y, *self.embed_ln, 1e-5, act="relu" if self.kind == "transformer" else "none", scale=math.sqrt(self.d))
 
-    def _layer(self, i, x, t1, rows, t0, causal):
-        """x [t1, d]; rows: the layer's [cap, 4 d] buffer holding t0 earlier positions."""
+    def _layer(self, i, x, t1, rows, t0, causal, bd_cols=0):
+        """x [t1, d]; rows: the layer's [cap, 4 d] buffer holding t0 earlier positions.  bd_cols: row pitch of matrix_bd (0: what this call needs; forward_chunk
+        passes what the cache's capacity will ever need, so that the recorded decode step keeps its geometry while the context grows)."""
         K, L, d, H = self.k, self.layers[i], self.d, self.heads
         n_keys = t0 + t1
         K.linear(K.layer_norm(x, *L["ln1"], 1e-12), L["qkv"], t1, out=rows[t0:], ldc=4 * d)
         n_tab, tabs = self._pos_tables(n_keys)
         P = t1 - 1 + n_keys                                    # columns rel_shift can reach: bd[i][c] is relative position n_keys - 1 - c
-        Pp = (P + 3) // 4 * 4
+        Pp = (max(P, bd_cols) + 3) // 4 * 4
         bd = K.new(H, t1, Pp)
         pp = tabs[i][n_tab - n_keys:]
         gemm_conv(K.lib, rows[t0:, d:], pp, 64, M=t1, N=P, K=64, lda=4 * d, a_batch=64, a_len=(t1 - 1) * 4 * d + 64, ldw=d, w_batch=64,
@@ -255,16 +323,53 @@ class EspnetEncoder(C1.EspnetEncoder):
         return self.k.layer_norm(x, *self.after, 1e-5)
 
     def forward_chunk(self, xs, state):
-        """BaseEncoder.forward_chunk with the whole history kept: xs [t1, d_in] (a view is fine), state = _KVState or None -> (ys [t1, d], state)."""
+        """BaseEncoder.forward_chunk with the whole history kept: xs [t1, d_in] (a view is fine), state = _KVState or None -> (ys [t1, d], state).
+        One-row calls (the decode step) after the first are replays of a recorded step with the position-dependent arguments patched (LaunchTape); the ys of such
+        a call is the recorded step's output buffer - valid until the next call on this state."""
         t1 = xs.shape[0]
         if state is None:
             state = _KVState(self.k, self.n_layers, self.d, max(256, 2 * t1))
         state.reserve(state.len + t1)
+        K, t0 = self.k, state.len
+        self._pos_tables(t0 + t1)                               # (a table that has to grow does so here, outside any recording)
+        step = t1 == 1 and t0 >= 1 and K.use_tapes
+        plan = getattr(state, "plan", None)
+        if step and plan is not None and plan["cap"] == state.cap and plan["pos_n"] == self._pos_n and K.same_stream(plan["tape"]):
+            self._patch_step(plan, xs, state, t0)
+            plan["tape"].replay()
+            state.len += 1
+            return plan["y"], state
+        state.plan = None
+        if step:
+            with K.record() as tape:
+                y = self._forward_rows(xs, t1, state, t0)
+            state.plan = dict(tape=tape, y=y, cap=state.cap, pos_n=self._pos_n, structs=tape.structs)
+            assert len(tape.calls) == 3 + 8 * self.n_layers, len(tape.calls)
+        else:
+            y = self._forward_rows(xs, t1, state, t0)
+        state.len += t1
+        return y, state
+
+    def _forward_rows(self, xs, t1, state, t0):
         x = self._embed(xs, t1)
         for i in range(self.n_layers):
-            x = self._layer(i, x, t1, state.rows[i], state.len, True)
-        state.len += t1
-        return self.k.layer_norm(x, *self.after, 1e-5), state
+            x = self._layer(i, x, t1, state.rows[i], t0, True, bd_cols=t1 - 1 + state.cap)
+        return self.k.layer_norm(x, *self.after, 1e-5)
+
+    def _patch_step(self, plan, xs, state, t0):
+        """The recorded one-row step at position t0: launches in order [embed GEMM, embed LN] + per layer [LN, qkv4 GEMM, matrix_bd GEMM, attention, out GEMM, LN,
+        w1 GEMM, w2 GEMM] + [after_norm].  What depends on the position: where the new row (q + u | q + v | k | v) goes and is read from, the first table row of
+        the relative positions, and the key count."""
+        st, d, n_keys = plan["structs"], self.d, t0 + 1
+        st[0].A = xs.data_ptr()
+        row = 4 * (t0 * 4 * d)                                  # byte offset of row t0 in a layer's [cap][4 d] buffer
+        tab0 = 4 * (self._pos_n - n_keys) * d
+        for i in range(self.n_layers):
+            base, rows = 2 + 8 * i, state.rows[i].data_ptr()
+            qkv, bd, at = st[base + 1], st[base + 2], st[base + 3]
+            qkv.C = rows + row
+            bd.A, bd.W, bd.N = rows + row + 4 * d, self._pos_tab[i].data_ptr() + tab0, n_keys
+            at.q, at.Tk = rows + row, n_keys
 
 
 class TransformerLM(C1.TransformerLM):

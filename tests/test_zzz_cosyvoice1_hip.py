@@ -78,7 +78,7 @@ def test_kv_state_grows_in_place(lib):
     rows = []
     for i in range(9):
         y, state = enc.forward_chunk(xd[i:i + 1], state)
-        rows.append(y.cpu())
+        rows.append(y.cpu().clone())                                # (a replayed step returns the recorded step's output buffer: consume it before the next call)
     assert state.cap >= 9 and state.len == 9
     torch.testing.assert_close(torch.cat(rows), whole.cpu(), rtol=1e-4, atol=1e-4)
     ref, _ = C1.EspnetEncoder(sd, "llm.", CFG.llm_heads, "transformer").forward_chunk(x, None)

@@ -78,6 +78,9 @@ if not profile:
         def __init__(self, lib):
             self._lib = lib
 
+        def raw(self, name, restype=None):                      # what a LaunchTape records and replays
+            return lambda *a: 0
+
         def __getattr__(self, name):
             if name.startswith("cv_"):
                 return lambda *a: None
