@@ -482,15 +482,24 @@ class ConditionalDecoder:
         emb = K.new(n, self.in_channels)
         K.lib.cv_time_sinusoid(_p(K.put(torch.tensor(t_host, dtype=F32))), _p(emb), C.c_int32(n), C.c_int32(self.in_channels), stream_ptr(K.lib))
         temb = K.linear(K.linear(emb, self.t1, n, act="silu"), self.t2, n, act="mish")       # t_emb only ever enters through Mish (matcha ResnetBlock1D.mlp)
-        return [K.linear(temb, r["mlp"], n) for r in self.resnets]
+        # one row per Euler step, the blocks' projections side by side: the estimator reads its step's row from a FIXED buffer (`tcur`, see __call__), so that the
+        # launches of one step can be recorded and replayed for the others
+        offs, total = [], 0
+        for r in self.resnets:
+            offs.append(total)
+            total += (r["mlp"].n + 3) // 4 * 4
+        tall = K.zeros(n, total)
+        for r, off in zip(self.resnets, offs):
+            K.linear(temb, r["mlp"], n, out=tall[:, off:], ldc=total)
+        return tall, offs
 
     def _run_block(self, blk, x, T, col_add=None):
         K = self.k
         return K.group_norm(K.conv(x, blk["conv"], 2, T, pad=1), 2, T, blk["conv"].n, 8, blk["g"], blk["b"], act="mish", col_add=col_add)
 
-    def _run_stage(self, st, x, T, tproj, step):
+    def _run_stage(self, st, x, T, tcur, offs):
         K, r = self.k, st["res"]
-        h = self._run_block(r["b1"], x, T, col_add=tproj[r["idx"]][step])
+        h = self._run_block(r["b1"], x, T, col_add=tcur[offs[r["idx"]]:])
         h = self._run_block(r["b2"], h, T)
         x = K.linear(x, r["rc"], 2 * T, res=h)                                                # res_conv (1 x 1) + block2's output
         Cc = r["rc"].n
@@ -504,23 +513,24 @@ class ConditionalDecoder:
             x = K.linear(y, b["ff2"], 2 * T, res=x)
         return x, Cc
 
-    def __call__(self, h, T, tproj, step):
-        """h: packed input [2][T][in_channels] -> [2][T][mel] (the mask of an unpadded batch-1 request is all ones)."""
+    def __call__(self, h, T, tcur, offs):
+        """h: packed input [2][T][in_channels] -> [2][T][mel] (the mask of an unpadded batch-1 request is all ones).  tcur: this step's row of prepare()'s
+        matrix (a fixed buffer the caller refreshes per step), offs: where each ResnetBlock1D's projection starts in it."""
         K, x, hiddens = self.k, h, []
         for st in self.down:
-            x, Cc = self._run_stage(st, x, T, tproj, step)
+            x, Cc = self._run_stage(st, x, T, tcur, offs)
             hiddens.append((x, T, Cc))
             if "resample" in st:
                 x, T = K.conv_stride(x, st["resample"], 2, T, Cc, k=3, stride=2, pad=1)
             else:
                 x = K.conv(x, st["plain"], 2, T, pad=1)
         for st in self.mid:
-            x, Cc = self._run_stage(st, x, T, tproj, step)
+            x, Cc = self._run_stage(st, x, T, tcur, offs)
         for st in self.up:
             skip, Ts, Cs = hiddens.pop()
             cat = K.new(2, Ts, Cc + Cs)                                                       # x[:, :, :Ts] ++ skip along channels
             K.lib.cv_concat_cols(_p(x), C.c_int32(Cc), C.c_int64(T * Cc), _p(skip), C.c_int32(Cs), C.c_int64(Ts * Cs), _p(cat), C.c_int32(Ts), C.c_int32(2), stream_ptr(K.lib))
-            x, Cc = self._run_stage(st, cat, Ts, tproj, step)
+            x, Cc = self._run_stage(st, cat, Ts, tcur, offs)
             T = Ts
             if "resample" in st:
                 x, T = K.conv_transpose(x, st["resample"], 2, T, st["ch"][0], st["ch"][1], k=4, stride=2, pad=1)
@@ -609,12 +619,21 @@ class MaskedDiffWithXvec(C1.MaskedDiffWithXvec):
             t = t + dt
             if step < len(t_span) - 1:
                 dt = t_span[step + 1] - t
-        tproj = self.estimator.prepare(ts)
+        tall, offs = self.estimator.prepare(ts)
+        tcur = K.new(tall.shape[1])
         x = K.put(z[0].t())                                                                    # [T, 80]
         h = K.new(2, T, 4 * mel)
+        tape = None
         for step in range(len(ts)):
+            tcur.copy_(tall[step])
             K.lib.cv_pack_cfg_input(_p(x), _p(mu), _p(spk), _p(cond), _p(h), C.c_int32(T), C.c_int32(mel), stream_ptr(K.lib))
-            d, _ = self.estimator(h, T, tproj, step)
+            if tape is not None:                                 # the estimator's ~700 launches: recorded at the first step, replayed on the same buffers after
+                tape.replay()
+            elif K.use_tapes:
+                with K.record() as tape:
+                    d, _ = self.estimator(h, T, tcur, offs)
+            else:
+                d, _ = self.estimator(h, T, tcur, offs)
             K.lib.cv_cfg_euler(_p(x), _p(d), C.c_int64(T * mel), C.c_float(dts[step]), C.c_float(self.cfg_rate), stream_ptr(K.lib))
         return x, new_cache
 

@@ -130,3 +130,31 @@ def test_split3_weights_option(lib):
     feat, _ = flow.inference(token=g["token_a"], token_len=t(50), prompt_token=g["prompt_token"], prompt_token_len=t(12), prompt_feat=g["prompt_feat"],
                              prompt_feat_len=t(25), embedding=g["embedding"], flow_cache=torch.zeros(1, 80, 0, 2))
     torch.testing.assert_close(feat.cpu(), g["feat_a"], rtol=1e-3, atol=1e-3)
+
+
+def test_launch_tapes_are_bit_identical_to_eager_sequencing(lib):
+    """LaunchTape replays (the estimator of Euler steps 2..n, the LM decode step) against the same launches sequenced from scratch (Kernels.use_tapes = False):
+    the same kernels on the same operands, so the mel and the decode rows are equal bit for bit."""
+    g = gold("cv1k_flow")
+    flow = build_flow(lib)
+    out = {}
+    for tapes in (True, False):
+        flow.k.use_tapes = tapes
+        torch.manual_seed(41)
+        feat, cache = flow.inference(token=g["token_b"], token_len=t(30), prompt_token=g["prompt_token"], prompt_token_len=t(12), prompt_feat=g["prompt_feat"],
+                                     prompt_feat_len=t(25), embedding=g["embedding"], flow_cache=torch.zeros(1, 80, 0, 2))
+        out[tapes] = (feat.cpu().clone(), cache.cpu().clone())
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+    K = CK.Kernels(lib)
+    enc = CK.EspnetEncoder(W.make_cv1_llm(CFG), "llm.", CFG.llm_heads, "transformer", kern=K)
+    xd = K.put(torch.randn(7, CFG.llm_dim, generator=torch.Generator().manual_seed(2)))
+    rows = {}
+    for tapes in (True, False):
+        K.use_tapes = tapes
+        y, state = enc.forward_chunk(xd[:3], None)                  # a 3-row prompt, then four single steps
+        rows[tapes] = [y.cpu().clone()]
+        for i in range(3, 7):
+            y, state = enc.forward_chunk(xd[i:i + 1], state)
+            rows[tapes].append(y.cpu().clone())
+        assert (getattr(state, "plan", None) is not None) == tapes
+    assert all(torch.equal(a, b) for a, b in zip(rows[True], rows[False]))
