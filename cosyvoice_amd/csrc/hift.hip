@@ -26,6 +26,8 @@ struct cv_hift {
     ResBlockW src_rb[4]; std::vector<ResBlockW> rb;
     int scale = 480, sd_rate[4] = {1, 1, 1, 1};
     DevBuf mel_cl, fa, fb, f0, P, s, sst, x, xs, t1, r0, r1, si, y_spec, xu, sn;
+    bool f0_f64 = false;          // option "f0_float64": the f0 predictor in double (the reference's mode for the causal generator, generator.py:716-717)
+    DevBuf fa64, fb64;
     int cap_m = 0;
 };
 
@@ -152,12 +154,30 @@ static void resblock(cv_hift* m, const ResBlockW& w, const float* in, long long 
 // - zeros after the last frame when `finalize`, otherwise the last 3 frames are only context and frames - 3 values come out - the other four
 // are causal to the left.  Returns the number of f0 values.  (The reference runs this predictor in float64, generator.py:716-717; here it is fp32
 // on the exact-fp32 MFMA: every output row sums its taps in the same order whatever the chunk, so chunked and one-shot calls agree bit for bit.)
+static void conv64(const Conv& w, const void* in, bool in_f32, int in_rows, int M, int pad, void* out, bool out_f32, int act, hipStream_t s) {
+    hipLaunchKernelGGL(conv_f64_kernel, dim3((M + 15) / 16, (w.N + 63) / 64), dim3(256), 0, s, in, in_f32 ? 1 : 0, in_rows, w.K, w.w, w.Kp, w.b, out, out_f32 ? 1 : 0, M, w.N, w.taps,
+                       pad, act);
+}
+
 static int hift_f0(cv_hift* m, const float* mel_cl, int frames, hipStream_t s, bool finalize = true) {
     float* a = m->fa.as<float>(); float* b = m->fb.as<float>();
     const float* cur = mel_cl;
     const bool causal = m->cfg.causal != 0;
     const int out_frames = (causal && !finalize) ? frames - 3 : frames;
     CV_CHECK(out_frames > 0, "hift: too few frames for a non-final causal chunk");
+    if (m->f0_f64) {                                         // the same five convolutions + classifier, every sum in double, f0 rounded to fp32 at the end
+        m->fa64.ensure((size_t)frames * m->cfg.f0_ch * 8); m->fb64.ensure((size_t)frames * m->cfg.f0_ch * 8);
+        const void* c64 = mel_cl; bool f32 = true;
+        for (int j = 0; j < 5; ++j) {
+            void* out = (j & 1) ? m->fb64.p : m->fa64.p;
+            if (causal && j == 0) conv64(m->f0c[j], c64, f32, frames, out_frames, 0, out, false, 1, s);
+            else conv64(m->f0c[j], c64, f32, out_frames, out_frames, causal ? 2 : 1, out, false, 1, s);
+            c64 = out; f32 = false;
+        }
+        Conv cls; cls.w = m->f0_cls_w; cls.b = m->f0_cls_b; cls.N = 1; cls.K = m->cfg.f0_ch; cls.Kp = m->cfg.f0_ch; cls.taps = 1;
+        conv64(cls, c64, false, out_frames, out_frames, 0, m->f0.p, true, 2, s);
+        return out_frames;
+    }
     for (int j = 0; j < 5; ++j) {
         float* out = (j & 1) ? b : a;
         if (causal && j == 0) conv(m->f0c[j], cur, frames, out_frames, 0, 1, out, s, ACT_NONE, 0.f, nullptr, ACT_ELU, nullptr, 1.f, false);
@@ -296,6 +316,13 @@ int cv_hift_set_tensor(cv_hift* m, const char* name, const void* dev_ptr, int32_
     return guarded([&] { CV_CHECK(m, "null handle"); m->tm.set(name, dev_ptr, dtype, numel); });
 }
 int cv_hift_finalize(cv_hift* m) { return guarded([&] { CV_CHECK(m, "null handle"); hift_finalize(m); }); }
+int cv_hift_set_option(cv_hift* m, const char* name, int32_t value) {
+    return guarded([&] {
+        CV_CHECK(m && name, "cv_hift_set_option: null argument");
+        if (std::string(name) == "f0_float64") m->f0_f64 = value != 0;
+        else throw Error(std::string("cv_hift_set_option: unknown option ") + name);
+    });
+}
 void cv_hift_destroy(cv_hift* m) {
     if (!m) return;
     // may be called from a garbage-collector finaliser on ANY thread while another thread drives a different handle: quiesce the

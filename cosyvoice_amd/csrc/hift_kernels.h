@@ -177,4 +177,51 @@ static __global__ __launch_bounds__(256) void snake_rows_kernel(const float* x, 
     *reinterpret_cast<float4*>(y + i * 4) = make_float4(snake_f(v.x, a.x), snake_f(v.y, a.y), snake_f(v.z, a.z), snake_f(v.w, a.w));
 }
 
+
+// Conv1d in DOUBLE over channel-last rows - the float64 mode of the f0 predictor (the reference runs CausalConvRNNF0Predictor in float64, generator.py:716-717:
+// its module is converted with .to(torch.float64), i.e. fp32 weights widened exactly, and so are they here).  out[t][n] = act(b[n] + sum_{j, c} in[t + j - pad][c] *
+// W[n][j * Kp + c]), rows outside [0, in_rows) read as zero.  One workgroup = 16 rows x 64 columns, k in steps of 32 through LDS; a thread owns 4 rows of one
+// column.  The network is small (5 x 512 channels): ~3 GFLOP per 500 frames on the fp64 vector pipe.  act: 0 none, 1 ELU, 2 abs; in_f32 / out_f32: element type.
+static __global__ __launch_bounds__(256) void conv_f64_kernel(const void* in, int in_f32, int in_rows, int Cin, const float* W, int Kp, const float* bias, void* out, int out_f32,
+                                                               int M, int N, int taps, int pad, int act) {
+    __shared__ double As[16][33];
+    __shared__ double Ws[64][33];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int t0 = blockIdx.x * 16, n0 = blockIdx.y * 64;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < taps; ++j)
+        for (int c0 = 0; c0 < Cin; c0 += 32) {
+            for (int e = threadIdx.x; e < 16 * 32; e += 256) {
+                const int r = e >> 5, c = c0 + (e & 31), row = t0 + r + j - pad;
+                double v = 0.0;
+                if (row >= 0 && row < in_rows && c < Cin && t0 + r < M)
+                    v = in_f32 ? (double)reinterpret_cast<const float*>(in)[(long long)row * Cin + c] : reinterpret_cast<const double*>(in)[(long long)row * Cin + c];
+                As[r][e & 31] = v;
+            }
+            for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+                const int n = n0 + (e >> 5), c = c0 + (e & 31);
+                Ws[e >> 5][e & 31] = (n < N && c < Cin) ? (double)W[(long long)n * taps * Kp + (long long)j * Kp + c] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int kk = 0; kk < 32; ++kk) {
+                const double w = Ws[tx][kk];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] += As[ty * 4 + r][kk] * w;
+            }
+            __syncthreads();
+        }
+    const int n = n0 + tx;
+    if (n >= N) return;
+    for (int r = 0; r < 4; ++r) {
+        const int t = t0 + ty * 4 + r;
+        if (t >= M) continue;
+        double v = acc[r] + (bias ? (double)bias[n] : 0.0);
+        if (act == 1) v = v > 0.0 ? v : expm1(v);
+        else if (act == 2) v = fabs(v);
+        if (out_f32) reinterpret_cast<float*>(out)[(long long)t * N + n] = (float)v;
+        else reinterpret_cast<double*>(out)[(long long)t * N + n] = v;
+    }
+}
+
 }  // namespace cv

@@ -40,7 +40,9 @@ class _F0Predictor:
 
 
 class HiFTGenerator:
-    def __init__(self, state_dict, cfg, lib=None, seed=1986, _tensors=None):
+    def __init__(self, state_dict, cfg, lib=None, seed=1986, _tensors=None, f0_float64=False):
+        """f0_float64: the f0 predictor with every sum in double (cv_hift_set_option "f0_float64") - the mode the reference runs the causal generator's
+        predictor in (generator.py:716-717); default off: fp32 on the exact-fp32 matrix pipe (bounds against float64: tests/test_zz_fullsize.py)."""
         self.lib = lib or get_lib()
         self.cfg = cfg
         self.device = torch.device(self.lib.device)
@@ -59,11 +61,14 @@ class HiFTGenerator:
         self.lib.cv_hift_create(C.byref(self._h), C.byref(c))
         register_tensors(self.lib, "cv_hift_set_tensor", self._h, self._tensors)
         self.lib.cv_hift_finalize(self._h)
+        self.f0_float64 = bool(f0_float64)
+        if self.f0_float64:
+            self.lib.cv_hift_set_option(self._h, b"f0_float64", C.c_int32(1))
         self.f0_predictor = _F0Predictor(self)
 
     def clone(self):
         """Same device weights, own library handle (workspaces): one per token2wav lane of CosyVoice2Model."""
-        return type(self)(None, self.cfg, lib=self.lib, seed=self.seed, _tensors=self._tensors)
+        return type(self)(None, self.cfg, lib=self.lib, seed=self.seed, _tensors=self._tensors, f0_float64=self.f0_float64)
 
     def __del__(self):
         try:
@@ -115,7 +120,7 @@ class CausalHiFTGenerator(HiFTGenerator):
     only: 3 for the f0 predictor, 4 more for conv_pre, and withholds one more frame of samples, so m frames give 480 (m - 8) samples - every
     sample a chunk emits equals the one-shot result (the reference's own invariance check, generator.py:729-746).
 
-    Differences from the reference, stated: the f0 predictor runs in fp32 (the reference converts it to float64 on every call, :716-717, because
+    Differences from the reference, stated: the f0 predictor runs in fp32 by default (`f0_float64=True` selects the reference's mode; the reference converts it to float64 on every call, :716-717, because
     its fp32 cuDNN results depend on the chunk; here each f0 value is the same fp32 sum whatever the chunk, so chunked = one-shot bit for bit,
     and against the float64 reference the harmonic phase agrees to the same 2e-3 as for HiFT v2); the SineGen2 noise comes from a counter RNG
     (uniform, like the reference's fixed `torch.rand` buffer - 260 MB there) unless `noise` is given."""
