@@ -42,30 +42,6 @@ def test_causal_hift_matches_reference_golden(lib, tiny):
     torch.testing.assert_close(source_c.cpu(), g["source_c"], rtol=0, atol=5e-3)
 
 
-def test_f0_float64_option_matches_the_reference_mode(lib, tiny):
-    """`f0_float64=True`: the predictor with every sum in double, like the reference (generator.py:716-717) - the golden f0 of the REAL class (made in float64,
-    returned in fp32) is met to fp32 rounding instead of the fp32 mode's 2e-3; the non-final chunk (3 look-ahead frames) against the float64 oracle; and the
-    non-causal HiFTGenerator's predictor takes the same option."""
-    from oracle import hift as OH
-    cfg, sd = tiny
-    g = _gold()
-    h = CausalHiFTGenerator(sd, cfg, lib=lib, f0_float64=True)
-    f0 = h.f0(g["mel"], True).cpu()
-    torch.testing.assert_close(f0, g["f0"], rtol=2e-7, atol=1e-5)
-    assert (h.f0(g["mel"], True).cpu() - g["f0"]).abs().max() <= (CausalHiFTGenerator(sd, cfg, lib=lib).f0(g["mel"], True).cpu() - g["f0"]).abs().max()
-    want = OH.causal_f0_predictor(sd, g["mel"][:, :, :13], False, torch.float64).float()
-    torch.testing.assert_close(h.f0(g["mel"][:, :, :13], False).cpu(), want.reshape(1, -1), rtol=2e-7, atol=1e-5)
-    assert h.clone().f0_float64
-    speech, source = h.inference(g["mel"], True, noise=g["noise"])             # the whole chain on the float64 f0
-    torch.testing.assert_close(source.cpu(), g["source"], rtol=0, atol=5e-3)
-    c2 = W.tiny()[2]
-    sd2 = W.make_hift(c2)
-    mel = torch.randn(1, 80, 21, generator=torch.Generator().manual_seed(5)) * 2 - 5
-    from cosyvoice_amd.hift import HiFTGenerator
-    ref64 = OH.f0_predictor({k: v.double() for k, v in sd2.items()}, mel.double()).float()
-    torch.testing.assert_close(HiFTGenerator(sd2, c2, lib=lib, f0_float64=True).f0_predictor(mel).cpu(), ref64.reshape(1, -1), rtol=2e-7, atol=1e-5)
-
-
 def test_causal_hift_streaming_equals_one_shot(lib, tiny):
     """The reference's own invariance check (generator.py:729-746, print-only there): every sample a non-final chunk emits equals the one-shot
     waveform - here exactly (the fp32 f0 / phase of a frame do not depend on the chunk), with the default counter-RNG noise."""

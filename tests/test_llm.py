@@ -302,39 +302,3 @@ def test_decode_weight_prefetch_is_only_a_hint(lib, tiny_sd, mode, shift):
     assert torch.equal(lm.last_logits(), ref_logits)
     assert ref == OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=2, min_token_text_ratio=2)
 
-
-def test_reference_decode_loop_on_forward_one_step(lib, tiny_sd):
-    """Boundary B2, the finer hook: the reference's OWN decode loop (llm/llm.py:535-549: llm.forward_one_step -> llm_decoder -> log_softmax -> sampling ->
-    speech_embedding) written out here over Qwen2LM.llm / llm_decoder / speech_embedding gives the oracle's greedy tokens, and the per-step log-probabilities
-    of the oracle's trace; a second sequence on the same handle invalidates the first one's cache object."""
-    cfg, sd = tiny_sd
-    u = _utt(cfg, seed=7)
-    lm = Qwen2LM(sd, cfg, lib=lib, max_len=128, sampling="greedy")
-    trace = {}
-    want = OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=3, min_token_text_ratio=2, trace=trace)
-    n_text = u["text"].shape[1]
-    min_len, max_len = 2 * n_text, 3 * n_text
-    lm_input = lm.build_lm_input(u["text"], u["prompt_text"], u["llm_prompt_speech_token"]).unsqueeze(0)
-    out, cache, first_cache = [], None, None
-    for i in range(max_len):
-        masks = torch.tril(torch.ones(1, lm_input.shape[1], lm_input.shape[1], dtype=torch.bool))                  # what the reference passes (ignored here)
-        y_pred, cache = lm.llm.forward_one_step(lm_input, masks=masks, cache=cache)
-        first_cache = first_cache or cache
-        logp = lm.llm_decoder(y_pred[:, -1]).log_softmax(dim=-1).cpu()
-        torch.testing.assert_close(logp.reshape(-1), trace["logp"][i], rtol=1e-4, atol=1e-4)
-        scores = logp.reshape(-1).clone()
-        if i < min_len:
-            scores[cfg.speech_token_size] = -float("inf")
-        top = int(scores.argmax())
-        if top >= cfg.speech_token_size:
-            break
-        out.append(top)
-        lm_input = lm.speech_embedding(torch.tensor([[top]]))
-        assert lm_input.shape == (1, 1, cfg.hidden)
-    assert out == want and len(out) >= 12
-    _, other = lm.llm.forward_one_step(lm.speech_embedding(torch.tensor([[1, 2, 3]])), cache=None)                      # a new sequence on the handle
-    assert other != first_cache
-    with pytest.raises(ValueError):
-        lm.llm.forward_one_step(lm_input, cache=first_cache)
-    # the device loop still works on the same handle afterwards
-    assert list(lm.inference(**_kw(u), max_token_text_ratio=3, min_token_text_ratio=2)) == want
