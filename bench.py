@@ -759,8 +759,8 @@ def main():
                     "v_mfma_f32_16x16x32_fp8_fp8); the headline batch-1 workload always runs W16A32")
     ap.add_argument("--cv3-steps", type=int, default=4, help="CFM Euler steps of the --cv3 extra (configs[4] names 4; the reference hard-codes 10)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1 only: skip the extra keys the default line carries next to `value` - `batched_decode` (8 and 16 "
-                    "sequences), `streaming_clients` (8 clients, 104 requests: BASELINE.json configs[2]), `mixed64` (configs[3] on one GPU) and `cosyvoice3` (configs[4] shape) - "
-                    "each with its own token self-check; they add about two minutes")
+                    "sequences), `streaming_clients` (8 clients, 104 requests: BASELINE.json configs[2]), `mixed64` (configs[3] on one GPU), `cosyvoice3` (configs[4] shape) and `cosyvoice300m` "
+                    "(CosyVoice-300M dimensions on the kernels, SURVEY 8 row f4) - each with its own token self-check; they add about four minutes")
     ap.add_argument("--cpu-stage", choices=CPU_STAGES, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--only-extra", choices=DEFAULT_EXTRAS, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
