@@ -102,3 +102,48 @@ def test_f0_float64_option_matches_the_reference_mode(lib, tiny):
     from cosyvoice_amd.hift import HiFTGenerator
     ref64 = OH.f0_predictor({k: v.double() for k, v in sd2.items()}, mel.double()).float()
     torch.testing.assert_close(HiFTGenerator(sd2, c2, lib=lib, f0_float64=True).f0_predictor(mel).cpu(), ref64.reshape(1, -1), rtol=2e-7, atol=1e-5)
+
+
+def test_ras_sampling_teacher_forced_at_full_size(lib):
+    """A NON-greedy decode of the benchmark utterance at the real CosyVoice2-0.5B dimensions (under the emulator: tiny dims): repetition-aware sampling on the
+    device with injected uniform variates, 250 sampled tokens - a sequence that does not fall into the short loop greedy decoding of random weights ends in.
+    Checked teacher-forced: the oracle scores the device's own sequence in ONE causal pass, and its sampler (oracle/sampling.py, the restated ras_sampling of
+    utils/common.py:138-167) replays every decision with the same variates and the same history.  A step may differ from the device's token only where the decision
+    is borderline (moving the variates or top_p by 2e-4 reproduces the device's choice: a CDF / nucleus boundary within fp32 summation noise)."""
+    from oracle import sampling as OS
+    if lib.emulated:
+        lc, fc, _ = W.tiny()
+        u, n_gen, max_kv = W.synthetic_utterance(lc, fc, n_prompt_tok=9, n_prompt_text=3, n_text=4, seed=3), 28, 128
+    else:
+        lc, fc, _ = W.cv2()
+        u, n_gen, max_kv = W.synthetic_utterance(lc, fc, n_prompt_tok=87, n_prompt_text=12, n_text=30), 250, 1024
+    sd = W.make_llm(lc)
+    us = np.random.default_rng(11).random(2 * n_gen + 4).astype(np.float32)
+    lm = Qwen2LM(sd, lc, lib=lib, max_len=max_kv, sampling="ras", decode_chunk=64)
+    lm.set_uniforms(us)
+    n_text = u["text"].shape[1]
+    ratio = n_gen / n_text
+    got = list(lm.inference(**_kw(u), max_token_text_ratio=ratio, min_token_text_ratio=ratio))
+    n = len(got)
+    stop = [lc.speech_token_size + i for i in range(lc.n_special)]
+    assert 0 < n <= n_gen and all(t < lc.speech_token_size for t in got)
+    x = torch.cat([OL.build_lm_input(sd, lc, u["text"], u["prompt_text"], u["llm_prompt_speech_token"]), sd["speech_embedding.weight"][torch.tensor(got)]], 0)
+    with torch.no_grad():
+        y = OL.Qwen2Oracle(sd, lc).forward(x)[-(n + 1):]
+        logp_all = torch.nn.functional.linear(y, sd["llm_decoder.weight"], sd.get("llm_decoder.bias")).log_softmax(-1)
+    clip = lambda v: float(min(max(v, 0.0), 1.0 - 1e-7))
+    exact = borderline = 0
+    for i in range(n + (1 if n < n_gen else 0)):                    # (a sequence that ended early ended on a sampled stop id: that decision is replayed too)
+        def decide(du, dp):
+            scores = logp_all[i].clone()
+            scores[lc.speech_token_size] = -float("inf")            # ignore_eos below min_len (= every step of this workload)
+            return OS.ras_sampling(scores, got[:i], 25, top_p=0.8 + dp, u=(clip(us[2 * i] + du), clip(us[2 * i + 1] + du)))
+        hit = lambda t: (t == got[i]) if i < n else (t in stop)
+        if hit(decide(0.0, 0.0)):
+            exact += 1
+        else:
+            assert any(hit(decide(du, dp)) for du in (0.0, -2e-4, 2e-4) for dp in (0.0, -2e-4, 2e-4)), ("step %d: the device's token %s is not a decision of the oracle's sampler"
+                                                                                                       % (i, got[i] if i < n else "stop"))
+            borderline += 1
+    print("ras teacher-forced: %d tokens, %d distinct, %d exact decisions, %d borderline" % (n, len(set(got)), exact, borderline))
+    assert borderline <= max(2, n // 50) and len(set(got)) > min(20, n // 2)
