@@ -299,13 +299,17 @@ def cv1_workload(args):
     # token check against the torch-eager plumbing on the host cores (first 50 ids: eos is masked in both, so they are the first 50 of the forced-length run)
     n_chk = min(50, n_gen)
     ref = C1.TransformerLM(sd_llm, text_heads=cfg.text_heads, llm_heads=cfg.llm_heads, sampling=greedy)
+    t0 = time.perf_counter()
     want = list(ref.inference(max_token_text_ratio=n_chk / n_text, min_token_text_ratio=n_chk / n_text, **lm_kw))
+    cpu_lm_s = time.perf_counter() - t0
     div = next((k for k, (a, b) in enumerate(zip(tokens, want)) if a != b), None)
     return {"model": "CosyVoice-300M dimensions (TransformerLM 14 x 1024 + conformer text encoder, MaskedDiffWithXvec with the U-Net ConditionalDecoder, HiFTGenerator 22.05 kHz), "
                      "seeded random weights, fp32", "request": "inference_sft shape: 25 text ids, 500 generated tokens = %.2f s of audio, greedy, 10 Euler steps" % audio_s,
             "host": "python sequencing over the operator-level C ABI (cosyvoice1_hip.py), no hipGraph", "audio_s_per_s": round(audio_s / per, 3),
             "ms_per_utterance": round(1e3 * per, 2), "stages": stages,
-            "token_check": {"checked": n_chk, "equal_torch_eager_cpu": div is None, "first_difference": div}}
+            "token_check": {"checked": n_chk, "equal_torch_eager_cpu": div is None, "first_difference": div},
+            # the same LM on the host cores (cosyvoice1.py, torch fp32 eager = the configs[0] plumbing; text encoder + prompt pass + n_chk decode steps, sampled)
+            "cpu_lm": {"kind": "port (torch eager), sampled", "tokens": n_chk, "ms_per_token_incl_prompt_pass": round(1e3 * cpu_lm_s / max(1, n_chk), 2), "threads": torch.get_num_threads()}}
 
 
 def streaming_clients(model, u, clients, n_requests):
