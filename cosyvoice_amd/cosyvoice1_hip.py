@@ -53,10 +53,25 @@ class LaunchTape:
     def __init__(self, lib):
         self.lib, self.calls, self.keep, self.stream = lib, [], [], None
 
-    def replay(self):
+    def replay(self, stream=None):
+        """stream: a c_void_p to launch on instead of the recorded stream (every entry point takes the stream as its LAST argument) - what a capture needs."""
         for fn, args in self.calls:
+            if stream is not None:
+                args = args[:-1] + (stream,)
             if fn(*args) != 0:
                 self.lib.check(1)
+
+    def capture(self):
+        """The tape as a hipGraph (torch.cuda.CUDAGraph around one replay on the capture stream; thread-local capture mode: the LM thread of a streaming
+        request keeps making synchronous calls).  Opt-in (Kernels.use_graphs) until its first MI355X run: returns None when the capture fails."""
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self.replay(stream=C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            return g
+        except Exception as e:                                  # noqa: BLE001 - reported, and the eager replay keeps serving
+            self.capture_error = repr(e)
+            return None
 
     @property
     def structs(self):
@@ -100,6 +115,8 @@ class Kernels:
         self.split3 = bool(split3)
         self._gn_ws = self.lib.hook(torch.zeros(64 * 64 * 2 * 8, dtype=torch.float64, device=self.dev))      # cv_group_norm partial sums: B * G * 64 doubles
         self.use_tapes = True                                   # False: every launch sequenced from scratch (A/B and test knob)
+        self.use_graphs = False                                 # True (MI355X only): a fixed tape - the estimator of one solve - is replayed as a hipGraph (LaunchTape.capture)
+        self.graph_replays = 0
 
     def record(self):
         """`with K.record() as tape:` - the launches issued inside are executed and recorded (LaunchTape)."""
@@ -623,12 +640,18 @@ class MaskedDiffWithXvec(C1.MaskedDiffWithXvec):
         tcur = K.new(tall.shape[1])
         x = K.put(z[0].t())                                                                    # [T, 80]
         h = K.new(2, T, 4 * mel)
-        tape = None
+        tape = graph = None
         for step in range(len(ts)):
             tcur.copy_(tall[step])
             K.lib.cv_pack_cfg_input(_p(x), _p(mu), _p(spk), _p(cond), _p(h), C.c_int32(T), C.c_int32(mel), stream_ptr(K.lib))
             if tape is not None:                                 # the estimator's ~700 launches: recorded at the first step, replayed on the same buffers after
-                tape.replay()
+                if graph is None and K.use_graphs and not K.lib.emulated and step == 1:
+                    graph = tape.capture()
+                if graph is not None:
+                    graph.replay()
+                    K.graph_replays += 1
+                else:
+                    tape.replay()
             elif K.use_tapes:
                 with K.record() as tape:
                     d, _ = self.estimator(h, T, tcur, offs)

@@ -24,6 +24,7 @@ PY
 # CosyVoice-300M on the kernels (first hardware run at the start of round 4: no reference values yet): stage times, host share, fp32 chain vs split3
 run probe_cv1             300 python tools/probe_cv1.py
 run probe_cv1_split3      300 python tools/probe_cv1.py split3
+run probe_cv1_graphs      300 python tools/probe_cv1.py graphs                                      # the estimator tape as a hipGraph (opt-in, never run on hardware yet)
 run probe_flow_ragged     120 python tools/probe_flow_batch.py ragged                                  # [x1.5 - x2.3, bit-identical]
 ( cd /tmp && export TMPDIR=/tmp && timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_utt -- python $R/tools/profile_utt.py > $R/$O/prof_utt.log 2>&1; echo "== rocprof hot path rc=$?" )
 f=$(find $O/prof_utt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/rocprof_utt_kernel_stats.csv && head -12 "$f" | cut -c1-170

@@ -1,6 +1,6 @@
 """CosyVoice-300M on the kernels at its real dimensions (cosyvoice_amd/cosyvoice1_hip.py): where the time goes, on the MI355X.
 
-    gpurun -- python tools/probe_cv1.py [split3] [profile]
+    gpurun -- python tools/probe_cv1.py [split3] [graphs] [profile]
 
 Per stage, with one synchronisation per measurement: LM prefill (text encoder + 132-row forward_chunk) and decode step (ms per token over 200 steps), one flow
 pass (ms per Euler step at T = 861), one HiFT pass (861 frames), and the host's share: the same python sequencing with the launches replaced by no-ops
@@ -16,7 +16,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cosyvoice_amd import cosyvoice1_hip as CK, synthetic as W   # noqa: E402
 
-split3, profile = "split3" in sys.argv, "profile" in sys.argv
+split3, profile, graphs = "split3" in sys.argv, "profile" in sys.argv, "graphs" in sys.argv
 cfg, hcfg = W.cv1()
 t0 = time.time()
 sd_llm, sd_flow, sd_hift = W.make_cv1_llm(cfg), W.make_cv1_flow(cfg), W.make_hift(hcfg)
@@ -25,6 +25,7 @@ greedy = lambda scores, decoded, sampling: int(scores.argmax().item())
 lm = CK.TransformerLM(sd_llm, text_heads=cfg.text_heads, llm_heads=cfg.llm_heads, sampling=greedy, split3=split3)
 flow = CK.MaskedDiffWithXvec(sd_flow, enc_heads=cfg.flow_heads, est_heads=cfg.est_heads, input_frame_rate=cfg.input_frame_rate, split3=split3)
 hift = CK.HiFTGenerator(sd_hift, hcfg)
+flow.k.use_graphs = graphs                                   # `graphs`: the estimator tape of a solve as a hipGraph (LaunchTape.capture), opt-in until measured
 tl = lambda n: torch.tensor([n], dtype=torch.int32)
 g = torch.Generator().manual_seed(300)
 text = torch.randint(0, cfg.text_vocab, (1, 25), generator=g, dtype=torch.int32)
@@ -60,7 +61,7 @@ mel, _ = flow.inference(**fkw)
 sync(); t0 = time.perf_counter()
 mel, _ = flow.inference(**fkw)
 sync(); ft = 1e3 * (time.perf_counter() - t0)
-print("flow: %.1f ms for T = %d, %d Euler steps (%.2f ms per step incl. encoder / regulator share)" % (ft, mel.shape[2], flow.n_timesteps, ft / flow.n_timesteps), flush=True)
+print("flow: %.1f ms for T = %d, %d Euler steps (%.2f ms per step incl. encoder / regulator share); graph replays so far %d" % (ft, mel.shape[2], flow.n_timesteps, ft / flow.n_timesteps, flow.k.graph_replays), flush=True)
 hift.inference(speech_feat=mel)
 sync(); t0 = time.perf_counter()
 hift.inference(speech_feat=mel)
