@@ -547,13 +547,14 @@ class CosyVoice3Model(CosyVoice2Model):
         self.silent_tokens = [1, 2, 28, 29, 55, 248, 494, 2241, 2242, 2322, 2323]
 
     @classmethod
-    def from_state_dicts(cls, llm_sd, flow_sd, hift_sd, cfgs, lib=None, fp16=False, **llm_kw):
+    def from_state_dicts(cls, llm_sd, flow_sd, hift_sd, cfgs, lib=None, fp16=False, f0_float64=False, **llm_kw):
+        """f0_float64: the vocoder's f0 predictor in double, the reference's mode (hifigan/generator.py:716-717; CausalHiFTGenerator(f0_float64=True)); default fp32."""
         lc, fc, hc = cfgs
         lib = lib or get_lib()
         flow = CausalMaskedDiffWithDiT(flow_sd, fc, lib=lib, precision="bf16" if fp16 else "fp32")
-        return cls(CosyVoice3LM(llm_sd, lc, lib=lib, **llm_kw), flow, CausalHiFTGenerator(hift_sd, hc, lib=lib), fp16=fp16)
+        return cls(CosyVoice3LM(llm_sd, lc, lib=lib, **llm_kw), flow, CausalHiFTGenerator(hift_sd, hc, lib=lib, f0_float64=f0_float64), fp16=fp16)
 
-    def load(self, llm_model, flow_model, hift_model, cfgs=None, **llm_kw):
+    def load(self, llm_model, flow_model, hift_model, cfgs=None, f0_float64=False, **llm_kw):
         from .configs import cv3_flow, cv3_hift, cv3_llm
         lc, fc, hc = cfgs or (cv3_llm(), cv3_flow(), cv3_hift())
         llm_sd = torch.load(llm_model, map_location="cpu", weights_only=True)
@@ -561,7 +562,7 @@ class CosyVoice3Model(CosyVoice2Model):
         hift_sd = {k.replace("generator.", ""): v for k, v in torch.load(hift_model, map_location="cpu", weights_only=True).items()}
         self.llm = CosyVoice3LM(llm_sd, lc, lib=self.lib, **llm_kw)
         self.flow = CausalMaskedDiffWithDiT(flow_sd, fc, lib=self.lib, precision="bf16" if self.fp16 else "fp32")
-        self.hift = CausalHiFTGenerator(hift_sd, hc, lib=self.lib)
+        self.hift = CausalHiFTGenerator(hift_sd, hc, lib=self.lib, f0_float64=f0_float64)
         self.set_lanes(max(1, self.n_lanes))
         self._warmup()
 
