@@ -22,6 +22,7 @@ There is no CPU fallback: without the HIP library `get_lib()` raises.
 """
 import ctypes as C
 import math
+import threading
 
 import numpy as np
 import torch
@@ -405,6 +406,7 @@ class TransformerLM(C1.TransformerLM):
         self.affine = K.mat(sd["text_encoder_affine_layer.weight"], sd["text_encoder_affine_layer.bias"])
         self.spk_affine = K.mat(sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"])
         self.decoder = K.mat(sd["llm_decoder.weight"], sd["llm_decoder.bias"])
+        self.lock = threading.Lock()                             # one Kernels object (its recorder, its workspaces) per stage: requests on one stage object are serialised
 
     def encode_text(self, ids):
         """text_encoder + text_encoder_affine_layer (llm.py:84-91) for one unpadded id sequence -> [n, D] on the device."""
@@ -414,36 +416,37 @@ class TransformerLM(C1.TransformerLM):
     @torch.inference_mode()
     def inference(self, text, text_len, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len, embedding,
                   sampling=25, max_token_text_ratio=20, min_token_text_ratio=2, uuid=""):
-        K, D = self.k, self.llm_input_size
-        ids = torch.cat([prompt_text, text], dim=1).reshape(-1).to(torch.int32)
-        n_text, n_prompt = int(text.shape[1]), int(prompt_speech_token.shape[1])
-        has_spk = embedding.shape[0] != 0
-        L = 1 + int(has_spk) + ids.numel() + 1 + n_prompt
-        lm_input = K.new(L, D)                                  # [sos | speaker | encoded text | task id | prompt speech tokens]
-        r = 0
-        lm_input[r:r + 1].copy_(self.llm_emb[self.sos:self.sos + 1]); r += 1
-        if has_spk:
-            e = torch.nn.functional.normalize(embedding.float().cpu(), dim=1)     # 192 numbers: normalised on the host
-            K.linear(K.put(e), self.spk_affine, 1, out=lm_input[r:]); r += 1
-        enc = self.encode_text(ids)
-        lm_input[r:r + ids.numel()].copy_(enc); r += ids.numel()
-        lm_input[r:r + 1].copy_(self.llm_emb[self.task_id:self.task_id + 1]); r += 1
-        if n_prompt:
-            lm_input[r:r + n_prompt].copy_(K.gather(self.speech_emb, prompt_speech_token))
-        min_len, max_len = int(n_text * min_token_text_ratio), int(n_text * max_token_text_ratio)
-        out_tokens, state, x = [], None, lm_input
-        for i in range(max_len):
-            y, state = self.llm.forward_chunk(x, state)
-            logits = K.linear(y[-1:], self.decoder, 1)
-            logp = logits.reshape(-1).cpu().log_softmax(dim=-1)    # the sampler draws from the host RNG, like the reference's python sampler
-            if i < min_len:
-                logp[self.speech_token_size] = -float("inf")
-            top = self.sampling(logp, out_tokens, sampling)
-            if top == self.eos_token:
-                break
-            yield top
-            out_tokens.append(top)
-            x = self.speech_emb[top:top + 1]
+        with self.lock:
+            K, D = self.k, self.llm_input_size
+            ids = torch.cat([prompt_text, text], dim=1).reshape(-1).to(torch.int32)
+            n_text, n_prompt = int(text.shape[1]), int(prompt_speech_token.shape[1])
+            has_spk = embedding.shape[0] != 0
+            L = 1 + int(has_spk) + ids.numel() + 1 + n_prompt
+            lm_input = K.new(L, D)                                  # [sos | speaker | encoded text | task id | prompt speech tokens]
+            r = 0
+            lm_input[r:r + 1].copy_(self.llm_emb[self.sos:self.sos + 1]); r += 1
+            if has_spk:
+                e = torch.nn.functional.normalize(embedding.float().cpu(), dim=1)     # 192 numbers: normalised on the host
+                K.linear(K.put(e), self.spk_affine, 1, out=lm_input[r:]); r += 1
+            enc = self.encode_text(ids)
+            lm_input[r:r + ids.numel()].copy_(enc); r += ids.numel()
+            lm_input[r:r + 1].copy_(self.llm_emb[self.task_id:self.task_id + 1]); r += 1
+            if n_prompt:
+                lm_input[r:r + n_prompt].copy_(K.gather(self.speech_emb, prompt_speech_token))
+            min_len, max_len = int(n_text * min_token_text_ratio), int(n_text * max_token_text_ratio)
+            out_tokens, state, x = [], None, lm_input
+            for i in range(max_len):
+                y, state = self.llm.forward_chunk(x, state)
+                logits = K.linear(y[-1:], self.decoder, 1)
+                logp = logits.reshape(-1).cpu().log_softmax(dim=-1)    # the sampler draws from the host RNG, like the reference's python sampler
+                if i < min_len:
+                    logp[self.speech_token_size] = -float("inf")
+                top = self.sampling(logp, out_tokens, sampling)
+                if top == self.eos_token:
+                    break
+                yield top
+                out_tokens.append(top)
+                x = self.speech_emb[top:top + 1]
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------
@@ -572,6 +575,7 @@ class MaskedDiffWithXvec(C1.MaskedDiffWithXvec):
         last = max(int(k[len(p.prefix):].split(".")[0]) for k in sd if k.startswith(p.prefix))
         self.reg = [(K.conv_mat(p("%d.weight" % i), p("%d.bias" % i)), K.put(p("%d.weight" % (i + 1))), K.put(p("%d.bias" % (i + 1)))) for i in range(0, last, 3)]
         self.reg_out = K.conv_mat(p("%d.weight" % last), p("%d.bias" % last))
+        self.lock = threading.Lock()
 
     def _interp(self, h, a, b, out, row, size):
         """out[row : row + size] = F.interpolate(h[a:b] over time, size) (length_regulator.py:52-70), channel-last rows."""
@@ -586,6 +590,10 @@ class MaskedDiffWithXvec(C1.MaskedDiffWithXvec):
 
     @torch.inference_mode()
     def inference(self, token, token_len, prompt_token, prompt_token_len, prompt_feat, prompt_feat_len, embedding, flow_cache):
+        with self.lock:                                          # concurrent requests of one CosyVoiceModel share this stage object
+            return self._inference(token, prompt_token, prompt_feat, embedding, flow_cache)
+
+    def _inference(self, token, prompt_token, prompt_feat, embedding, flow_cache):
         assert token.shape[0] == 1
         K, mel = self.k, self.output_size
         e = torch.nn.functional.normalize(embedding.float().cpu(), dim=1)
@@ -672,9 +680,14 @@ class HiFTGenerator(_KernelHiFT):
         assert cfg.sr == 22050 and not cfg.causal, "the 24 kHz generators (SineGen2) are cosyvoice_amd.hift.HiFTGenerator / CausalHiFTGenerator"
         self.rng = rng
         self._ws = None
+        self.lock = threading.Lock()                             # the handle's workspaces serve one call at a time
 
     @torch.inference_mode()
     def inference(self, speech_feat, cache_source=None):
+        with self.lock:
+            return self._inference(speech_feat, cache_source)
+
+    def _inference(self, speech_feat, cache_source):
         lib, cfg, m = self.lib, self.cfg, speech_feat.shape[2]
         L, H1 = m * self.upsample_scale, cfg.harmonics + 1
         f0 = self.f0_predictor(speech_feat)                                                    # [1, m] on the device

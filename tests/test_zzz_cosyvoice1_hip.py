@@ -158,3 +158,39 @@ def test_launch_tapes_are_bit_identical_to_eager_sequencing(lib):
             rows[tapes].append(y.cpu().clone())
         assert (getattr(state, "plan", None) is not None) == tapes
     assert all(torch.equal(a, b) for a, b in zip(rows[True], rows[False]))
+
+
+def test_concurrent_requests_on_one_stage_object_are_serialised(lib, monkeypatch):
+    """Two threads inside one MaskedDiffWithXvec (what two concurrent tts() calls of one CosyVoiceModel do): the stage lock keeps one request's recording from
+    swallowing the other's launches - each result equals the request alone.  (The CFM noise comes from the global host RNG, whose draws would depend on the
+    interleaving: for this test it is a fixed tensor per request length.)"""
+    import threading
+    g = gold("cv1k_flow")
+    flow = build_flow(lib)
+    gen = torch.Generator().manual_seed(17)
+    reqs = {n: torch.randint(0, 40, (1, n), generator=gen, dtype=torch.int32) for n in (24, 30)}
+    noise = {25 + int(n / 50 * 22050 / 256): torch.randn(1, 80, 25 + int(n / 50 * 22050 / 256), generator=gen) for n in reqs}
+
+    class _Torch:                                                   # the module's `torch` with randn answering from the table
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def randn(*shape, **kw):
+            return noise[shape[-1]].clone()
+    monkeypatch.setattr(CK, "torch", _Torch())
+
+    def run(n, out):
+        feat, _ = flow.inference(token=reqs[n], token_len=t(n), prompt_token=g["prompt_token"], prompt_token_len=t(12), prompt_feat=g["prompt_feat"],
+                                 prompt_feat_len=t(25), embedding=g["embedding"], flow_cache=torch.zeros(1, 80, 0, 2))
+        out[n] = feat.cpu().clone()
+
+    alone, both = {}, {}
+    for n in reqs:
+        run(n, alone)
+    ths = [threading.Thread(target=run, args=(n, both)) for n in reqs]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert set(both) == set(reqs) and all(torch.equal(alone[n], both[n]) for n in reqs)
