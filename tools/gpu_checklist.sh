@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call for the start of a round: validates the tree on hardware and collects the reference numbers (round-3 end values in brackets):
-#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_checklist.sh'
-# Writes under gpurun_out/checklist/.  Order: cheapest / most important first; every step has its own timeout.  ~12 GPU-minutes.
+#   /usr/local/graft/bin/gpurun --timeout 2000 -- 'bash tools/gpu_checklist.sh'
+# Writes under gpurun_out/checklist/.  Order: cheapest / most important first; every step has its own timeout.  ~20 GPU-minutes (pytest ~5, bench ~7 with the cosyvoice300m extra, the CosyVoice-300M probes ~6).
 set -u
 O=gpurun_out/checklist; mkdir -p $O
 R=$GRAFT_REPO_ROOT
