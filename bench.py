@@ -695,6 +695,7 @@ def run_extra(name, args):
     else:
         model, u, cfgs = build_model(args.flow_precision, batch_fp8=args.llm_fp8)
         model.flow_batch = args.flow_batch
+        model.hift_batch = bool(getattr(args, "hift_batch", False))
         for _ in range(2):
             one_utterance(model, u)
         if name == "streaming_clients":
@@ -718,7 +719,7 @@ def run_extra(name, args):
 def spawn_extra(name, args):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--only-extra", name, "--steps", str(args.steps), "--lanes", str(args.lanes), "--flow-batch", str(args.flow_batch),
-           "--stream-requests", str(args.stream_requests), "--flow-precision", args.flow_precision, "--cv3-steps", str(args.cv3_steps)] + (["--llm-fp8"] if args.llm_fp8 else [])
+           "--stream-requests", str(args.stream_requests), "--flow-precision", args.flow_precision, "--cv3-steps", str(args.cv3_steps)] + (["--llm-fp8"] if args.llm_fp8 else []) + (["--hift-batch"] if args.hift_batch else [])
     try:
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600 if name in SOFT_EXTRAS else 1200)
     except subprocess.TimeoutExpired:
@@ -761,6 +762,8 @@ def main():
                     "alone and 16 per GPU; reported as `cosyvoice3`")
     ap.add_argument("--llm-fp8", action="store_true", help="extras only: the BATCHED LM decode of --batch / --cv3 on the opt-in fp8 path (e4m3 weights + activations, "
                     "v_mfma_f32_16x16x32_fp8_fp8); the headline batch-1 workload always runs W16A32")
+    ap.add_argument("--hift-batch", action="store_true", help="extras only (A/B knob, off by default until measured): the equal-length members of a flow group share one "
+                    "HiFT launch sequence in tts_batch / tts_queue (CosyVoice2Model.hift_batch, cv_hift_inference_batch; bit-identical per utterance)")
     ap.add_argument("--cv3-steps", type=int, default=4, help="CFM Euler steps of the --cv3 extra (configs[4] names 4; the reference hard-codes 10)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1 only: skip the extra keys the default line carries next to `value` - `batched_decode` (8 and 16 "
                     "sequences), `streaming_clients` (8 clients, 104 requests: BASELINE.json configs[2]), `mixed64` (configs[3] on one GPU), `cosyvoice3` (configs[4] shape) and `cosyvoice300m` "
@@ -884,7 +887,8 @@ def main():
             out["streaming_clients"] = dict(streaming_clients(model, u, clients, args.stream_requests), lanes=model.n_lanes)
             log("streaming clients done: %s" % out["streaming_clients"])
         for nb in batches:
-            res = dict(batched_decode(model, u, nb, max(1, args.steps // 2)), lanes=args.lanes, flow_batch=args.flow_batch)
+            model.hift_batch = args.hift_batch
+            res = dict(batched_decode(model, u, nb, max(1, args.steps // 2)), lanes=args.lanes, flow_batch=args.flow_batch, hift_batch=args.hift_batch)
             out["batched_decode"] = res
             log("batched decode %d done: %s" % (nb, res))
         if world == 1 and (batches or clients):

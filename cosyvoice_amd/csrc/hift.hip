@@ -15,6 +15,10 @@ namespace {
 struct Conv { const float* w = nullptr; const float* b = nullptr; int N = 0, K = 0, Kp = 0, taps = 1; const void* w3 = nullptr; };   // w3: the three bf16 planes of w ([3 N][taps Kp], weights.py::split3_planes)
 struct ResBlockW { Conv c1[4], c2[4]; const float* a1[4]; const float* a2[4]; int k = 3; };
 inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
+// utterances of EQUAL length that share one launch sequence (cv_hift_inference_batch): every activation buffer then holds nb dense blocks one after the other and
+// every convolution runs with batch = nb (zero padding per block: the range check of gemm_conv is per batch base).  1 everywhere else - the single-utterance
+// launches are exactly what they were.
+thread_local int tl_nb = 1;
 }  // namespace
 
 struct cv_hift {
@@ -109,7 +113,8 @@ static void conv(const Conv& w, const float* A, long long a_rows, long long M, i
     a.C = C; a.c_batch = 0; a.c_len = M * w.N; a.ldc = w.N; a.c_off = 0; a.M = (int)M; a.N = w.N;
     a.act = act; a.act_p = 0.f; a.res = res; a.res_batch = 0; a.out_scale = out_scale; a.row_scale = nullptr; a.accumulate = accumulate ? 1 : 0;
     a.act_alpha = act_alpha; a.C2 = C2; a.c2_alpha = c2_alpha;
-    gemm_conv(a, false, 1, s);
+    if (tl_nb > 1) { a.a_batch = a_rows * w.K; a.c_batch = M * w.N; a.res_batch = res ? M * w.N : 0; }
+    gemm_conv(a, false, tl_nb, s);
 }
 
 // ResBlock (generator.py:46-122): for each dilation: xt = conv2(snake(conv1(snake(x)))) ; x = xt + x.
@@ -137,7 +142,7 @@ static void resblock(cv_hift* m, const ResBlockW& w, const float* in, long long 
     const int C = w.c1[0].K;
     CV_CHECK(C % 4 == 0, "hift: ResBlock channels must be a multiple of 4");
     float* sn = m->sn.as<float>();
-    hipLaunchKernelGGL(snake_rows_kernel, dim3(nblk(T * C / 4)), dim3(256), 0, s, in, sn, w.a1[0], T * C / 4, C);
+    hipLaunchKernelGGL(snake_rows_kernel, dim3(nblk(tl_nb * T * C / 4)), dim3(256), 0, s, in, sn, w.a1[0], tl_nb * T * C / 4, C);
     for (int j = 0; j < c.n_dil; ++j) {
         const int d = c.dil[j], k = w.k;
         // padding: "same" for HiFTGenerator, all on the left for the causal generator (CausalConv1d 'left': (k - 1) * dilation, convolution.py:172)
@@ -190,12 +195,15 @@ static int hift_f0(cv_hift* m, const float* mel_cl, int frames, hipStream_t s, b
     return frames;
 }
 
-static void hift_source(cv_hift* m, int frames, const float* noise, unsigned long long seed, hipStream_t s) {
+static void hift_source(cv_hift* m, int frames, const float* noise, unsigned long long seed, hipStream_t s, const unsigned long long* seeds = nullptr) {
     const auto& c = m->cfg; const int H = c.harmonics + 1;
-    hipLaunchKernelGGL(hift_phase_kernel, dim3(1), dim3(256), 0, s, m->f0.as<float>(), m->P.as<float>(), frames, H, (float)c.sr, (float)m->scale);
     const long long L = (long long)frames * m->scale;
-    hipLaunchKernelGGL(hift_source_kernel, dim3(nblk(L)), dim3(256), 0, s, m->f0.as<float>(), m->P.as<float>(), noise, seed, m->src_w, m->src_b,
-                       m->s.as<float>(), frames, H, m->scale, c.nsf_alpha, c.nsf_sigma, c.voiced_thr, c.causal ? 1 : 0);
+    for (int b = 0; b < tl_nb; ++b) {                        // the phase walk and the RNG key are per utterance (seeds: one key per block of a batch)
+        const float* f0 = m->f0.as<float>() + (size_t)b * frames; float* P = m->P.as<float>() + (size_t)b * frames * H;
+        hipLaunchKernelGGL(hift_phase_kernel, dim3(1), dim3(256), 0, s, f0, P, frames, H, (float)c.sr, (float)m->scale);
+        hipLaunchKernelGGL(hift_source_kernel, dim3(nblk(L)), dim3(256), 0, s, f0, P, noise ? noise + (size_t)b * L * H : nullptr, seeds ? seeds[b] : seed, m->src_w, m->src_b,
+                           m->s.as<float>() + (size_t)b * L, frames, H, m->scale, c.nsf_alpha, c.nsf_sigma, c.voiced_thr, c.causal ? 1 : 0);
+    }
 }
 
 // decode(x = mel, s = source) -> waveform   (generator.py:507-539)
@@ -203,7 +211,7 @@ static void hift_decode(cv_hift* m, const float* mel_cl, int frames, const float
     const auto& c = m->cfg;
     const long long L = (long long)frames * m->scale, F = L / 4 + 1;
     float* sst = m->sst.as<float>();
-    hipLaunchKernelGGL(hift_stft_kernel, dim3(nblk(F)), dim3(256), 0, s, src, sst, L, F);
+    for (int b = 0; b < tl_nb; ++b) hipLaunchKernelGGL(hift_stft_kernel, dim3(nblk(F)), dim3(256), 0, s, src + (size_t)b * L, sst + (size_t)b * F * 18, L, F);
     float* x = m->x.as<float>(); float* xs = m->xs.as<float>(); float* si = m->si.as<float>();
     conv(m->conv_pre, mel_cl, frames, frames, 3, 1, x, s, ACT_NONE, 0.f, nullptr, ACT_NONE, nullptr, 1.f, false);
     long long T = frames; int ch = c.base;
@@ -219,8 +227,9 @@ static void hift_decode(cv_hift* m, const float* mel_cl, int frames, const float
             a.W = w.w; a.Kp = w.Kp; a.ldw = 0; a.w_batch = 0; a.bias = w.b;
             a.C = xs; a.c_batch = 0; a.c_len = rows * cout; a.ldc = u * cout; a.c_off = (long long)(-p + (last ? 1 : 0)) * cout;
             a.M = (int)(T + w.taps - 1); a.N = u * cout; a.act = ACT_NONE; a.res = nullptr; a.out_scale = 1.f; a.row_scale = nullptr; a.accumulate = 0;
-            gemm_conv(a, false, 1, s);
-            if (last) hipLaunchKernelGGL(reflect_row0_kernel, dim3(1), dim3(256), 0, s, xs, cout);       // ReflectionPad1d((1, 0))
+            if (tl_nb > 1) { a.a_batch = T * ch; a.c_batch = rows * cout; }
+            gemm_conv(a, false, tl_nb, s);
+            if (last) for (int b = 0; b < tl_nb; ++b) hipLaunchKernelGGL(reflect_row0_kernel, dim3(1), dim3(256), 0, s, xs + (size_t)b * rows * cout, cout);       // ReflectionPad1d((1, 0))
         }
         std::swap(x, xs);
         T = rows; ch = cout;
@@ -234,7 +243,8 @@ static void hift_decode(cv_hift* m, const float* mel_cl, int frames, const float
             a.pro = ACT_NONE; a.W = w.w; a.Kp = w.Kp; a.ldw = 0; a.w_batch = 0; a.bias = w.b;
             a.C = si; a.c_batch = 0; a.c_len = T * ch; a.ldc = ch; a.c_off = 0; a.M = (int)T; a.N = ch;
             a.act = ACT_NONE; a.res = nullptr; a.out_scale = 1.f; a.row_scale = nullptr; a.accumulate = 0;
-            gemm_conv(a, false, 1, s);
+            if (tl_nb > 1) { a.a_batch = F * 18; a.c_batch = T * ch; }
+            gemm_conv(a, false, tl_nb, s);
             resblock(m, m->src_rb[i], si, T, x, 1.f, true, s);
         }
         for (int j = 0; j < c.n_res; ++j)      // xs = sum_j resblock_j(x) / n_res   (generator.py:523-529)
@@ -244,8 +254,8 @@ static void hift_decode(cv_hift* m, const float* mel_cl, int frames, const float
     CV_CHECK(T == F, "hift: frame bookkeeping mismatch");
     float* spec = m->y_spec.as<float>();
     conv(m->conv_post, x, T, T, 3, 1, spec, s, ACT_LEAKY, 0.01f, nullptr, ACT_NONE, nullptr, 1.f, false);    // F.leaky_relu default slope
-    hipLaunchKernelGGL(hift_spec_kernel, dim3(nblk(F * 9)), dim3(256), 0, s, spec, F);
-    hipLaunchKernelGGL(hift_istft_kernel, dim3(nblk(L)), dim3(256), 0, s, spec, speech, F, L, c.audio_limit);
+    hipLaunchKernelGGL(hift_spec_kernel, dim3(nblk(tl_nb * F * 9)), dim3(256), 0, s, spec, tl_nb * F);
+    for (int b = 0; b < tl_nb; ++b) hipLaunchKernelGGL(hift_istft_kernel, dim3(nblk(L)), dim3(256), 0, s, spec + (size_t)b * F * 18, speech + (size_t)b * L, F, L, c.audio_limit);
 }
 
 
@@ -366,6 +376,26 @@ int cv_hift_inference(cv_hift* m, const float* speech_feat, int32_t frames, cons
         hift_source(m, frames, noise, seed, s);
         if (cache_len > 0) CV_HIP(hipMemcpyAsync(m->s.p, cache_source, (size_t)cache_len * 4, hipMemcpyDeviceToDevice, s));   // generator.py:566-567
         CV_HIP(hipMemcpyAsync(source_out, m->s.p, (size_t)L * 4, hipMemcpyDeviceToDevice, s));
+        hift_decode(m, m->mel_cl.as<float>(), frames, m->s.as<float>(), speech_out, s);
+    });
+}
+
+int cv_hift_inference_batch(cv_hift* m, int32_t n_utt, const float* speech_feat, int32_t frames, const float* noise, const uint64_t* seeds, float* speech_out,
+                            float* source_out, void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && m->finalized && !m->cfg.causal && !m->f0_f64 && speech_feat && seeds && speech_out && source_out && frames > 0 && n_utt >= 1 && n_utt <= 16,
+                 "cv_hift_inference_batch: bad arguments (HiFTGenerator handle, fp32 f0 mode, 1..16 utterances)");
+        hipStream_t s = as_stream(stream);
+        reserve(m, (frames + 1) * n_utt);                    // every buffer is linear in the frame count (+ the reflection row of the last up-sampling stage per utterance)
+        const long long L = (long long)frames * m->scale;
+        for (int b = 0; b < n_utt; ++b)
+            hipLaunchKernelGGL(to_channel_last_kernel, dim3(nblk((long long)frames * m->cfg.mel)), dim3(256), 0, s, speech_feat + (size_t)b * m->cfg.mel * frames,
+                               m->mel_cl.as<float>() + (size_t)b * frames * m->cfg.mel, m->cfg.mel, frames);
+        std::vector<unsigned long long> keys(seeds, seeds + n_utt);
+        struct Scope { Scope(int n) { tl_nb = n; } ~Scope() { tl_nb = 1; } } scope(n_utt);
+        hift_f0(m, m->mel_cl.as<float>(), frames, s);
+        hift_source(m, frames, noise, 0, s, keys.data());
+        CV_HIP(hipMemcpyAsync(source_out, m->s.p, (size_t)n_utt * L * 4, hipMemcpyDeviceToDevice, s));
         hift_decode(m, m->mel_cl.as<float>(), frames, m->s.as<float>(), speech_out, s);
     });
 }

@@ -114,6 +114,26 @@ class HiFTGenerator:
         return speech, source
 
 
+    @torch.inference_mode()
+    def inference_batch(self, speech_feats, seeds, noise=None):
+        """n one-shot utterances of EQUAL length through ONE launch sequence (cv_hift_inference_batch; the reference's high-throughput runtime batches
+        token2wav, runtime/triton_trtllm/token2wav.py:20-22): speech_feats [n, 80, m], seeds: n counter-RNG keys (what `inference(seed=...)` takes per
+        utterance), noise: optional [n, 480 m, 9] parity hook -> (speech [n, 480 m], source [n, 1, 480 m]); row i is bit-identical to
+        `inference(speech_feats[i:i+1], seed=seeds[i])`."""
+        n, _, m = speech_feats.shape
+        assert 1 <= n <= 16 and len(seeds) == n
+        L = m * self.upsample_scale
+        x = self.lib.hook(speech_feats.to(self.device, torch.float32).contiguous())
+        speech = self.lib.hook(torch.empty(n, L, dtype=torch.float32, device=self.device))
+        source = self.lib.hook(torch.empty(n, 1, L, dtype=torch.float32, device=self.device))
+        nz = None if noise is None else self.lib.hook(noise.to(self.device, torch.float32).reshape(n, L, -1).contiguous())
+        keys = (C.c_uint64 * n)(*[int(k) for k in seeds])
+        self._calls += n
+        self.lib.cv_hift_inference_batch(self._h, C.c_int32(n), C.c_void_p(x.data_ptr()), C.c_int32(m), C.c_void_p(nz.data_ptr()) if nz is not None else None, keys,
+                                         C.c_void_p(speech.data_ptr()), C.c_void_p(source.data_ptr()), stream_ptr(self.lib))
+        return speech, source
+
+
 class CausalHiFTGenerator(HiFTGenerator):
     """cosyvoice.hifigan.generator.CausalHiFTGenerator for inference (generator.py:572-726; Fun-CosyVoice3):
     `inference(speech_feat[1,80,m], finalize=True) -> (speech, source)`.  A non-final chunk (finalize=False) treats its last frames as look-ahead

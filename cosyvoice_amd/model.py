@@ -86,6 +86,9 @@ class CosyVoice2Model:
         self.n_lanes, self._lane_q = 0, queue.Queue()
         self.flow_batch = 4                    # offline batch paths (tts_batch / tts_queue): up to this many sequences share one flow pass ...
         self.flow_pad = 1.25                   # ... when the longest of them has at most this many times the frames of the shortest (padded pass)
+        # ... and, opt-in until measured on the MI355X (bench.py --hift-batch / CV_HIFT_BATCH=1), the equal-length members of such a group share ONE HiFT launch
+        # sequence as well (HiFTGenerator.inference_batch; bit-identical per utterance)
+        self.hift_batch = os.environ.get("CV_HIFT_BATCH", "0") == "1"
         self.set_lanes(1)
         self.tts_speech_token_dict, self.llm_end_dict, self.hift_cache_dict, self._cond = {}, {}, {}, {}
         self._llm_error = {}                   # uuid -> exception raised on the LLM thread, re-raised by tts() on the caller's thread
@@ -313,6 +316,13 @@ class CosyVoice2Model:
             mels = lane.flow.inference_batch([dict(token=t, prompt_token=r["flow_prompt_speech_token"], prompt_feat=r["prompt_speech_feat"], embedding=r["flow_embedding"])
                                               for (_, r, _), t in zip(group, toks_t)], streaming=False, finalize=True)
             outs = []
+            if (self.hift_batch and speed == 1.0 and len(mels) > 1 and hasattr(lane.hift, "inference_batch") and not lane.hift.cfg.causal
+                    and len({m_.shape[2] for m_ in mels}) == 1):
+                # batched vocoding (cv_hift_inference_batch): utterances of equal length share ONE HiFT launch sequence; each waveform is bit-identical to
+                # _vocode_mel of it alone (its own RNG key)
+                speech, _ = lane.hift.inference_batch(torch.cat(list(mels), 0), [self._noise_key(t, 0) for t in toks_t])
+                wav = speech.cpu()
+                return [(i, {"tts_speech": wav[k:k + 1]}) for k, (i, _, _) in enumerate(group)]
             for (i, r, _), t, mel in zip(group, toks_t, mels):
                 if speed != 1.0:
                     tn = int(mel.shape[2] / speed)

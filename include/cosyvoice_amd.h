@@ -245,6 +245,12 @@ int cv_hift_decode(cv_hift* m, const float* speech_feat, int32_t frames, const f
  * noise: optional dev [480m, 9] N(0,1) variates for SineGen2 (parity tests); NULL -> in-kernel counter RNG keyed by `seed`. */
 int cv_hift_inference(cv_hift* m, const float* speech_feat, int32_t frames, const float* cache_source, int32_t cache_len,
                       const float* noise, uint64_t seed, float* speech_out, float* source_out, void* stream);
+/* The same for n_utt (1..16) utterances of EQUAL length in ONE launch sequence - the batched vocoding of the reference's high-throughput runtime
+ * (runtime/triton_trtllm/token2wav.py:20-22 batches token2wav): speech_feat dev [n_utt][80][frames], noise dev [n_utt][480 frames][9] or NULL, seeds HOST
+ * [n_utt] (one counter-RNG key per utterance), speech_out / source_out dev [n_utt][480 frames].  Every utterance's result is bit-identical to
+ * cv_hift_inference of it alone with its key (convolutions pad per utterance, the phase walk and the iSTFT run per utterance).  No cache_source: one-shot requests. */
+int cv_hift_inference_batch(cv_hift* m, int32_t n_utt, const float* speech_feat, int32_t frames, const float* noise, const uint64_t* seeds, float* speech_out,
+                            float* source_out, void* stream);
 /* Fun-CosyVoice3 (handle created with causal = 1).  `finalize` = 0: a streaming chunk whose trailing frames are look-ahead context only.
  * cv_hift_causal_f0: CausalConvRNNF0Predictor.forward(x, finalize) -> f0 [frames] or [frames - 3] (f0_predictor.py:94-103; fp32 here, float64 in
  * the reference generator.py:716-717).  cv_hift_causal_decode: CausalHiFTGenerator.decode(x, s, finalize) (generator.py:684-711): speech_feat dev

@@ -147,3 +147,53 @@ def test_ras_sampling_teacher_forced_at_full_size(lib):
             borderline += 1
     print("ras teacher-forced: %d tokens, %d distinct, %d exact decisions, %d borderline" % (n, len(set(got)), exact, borderline))
     assert borderline <= max(2, n // 50) and len(set(got)) > min(20, n // 2)
+
+
+def test_hift_inference_batch_is_bit_identical_per_utterance(lib):
+    """cv_hift_inference_batch: three utterances of equal length through one launch sequence (every convolution with batch = 3, the phase walk / STFT / iSTFT per
+    utterance) - each row equals cv_hift_inference of that utterance alone with its RNG key, bit for bit; with injected noise too; and a single-utterance call
+    afterwards is unchanged."""
+    from cosyvoice_amd.hift import HiFTGenerator
+    cfg = W.tiny()[2]
+    h = HiFTGenerator(W.make_hift(cfg), cfg, lib=lib)
+    gen = torch.Generator().manual_seed(8)
+    mels = torch.randn(3, 80, 9, generator=gen) * 2 - 5
+    seeds = [101, 202, 303]
+    alone = [h.inference(mels[i:i + 1], seed=seeds[i]) for i in range(3)]
+    speech, source = h.inference_batch(mels, seeds)
+    assert speech.shape == (3, 9 * 480) and source.shape == (3, 1, 9 * 480)
+    for i in range(3):
+        assert torch.equal(speech[i:i + 1].cpu(), alone[i][0].cpu()) and torch.equal(source[i:i + 1].cpu(), alone[i][1].cpu()), i
+    assert not torch.equal(speech[0], speech[1])
+    noise = torch.randn(3, 9 * 480, 9, generator=gen)
+    sp_n, so_n = h.inference_batch(mels, seeds, noise=noise)
+    one = h.inference(mels[1:2], noise=noise[1])
+    assert torch.equal(sp_n[1:2].cpu(), one[0].cpu()) and torch.equal(so_n[1:2].cpu(), one[1].cpu())
+    again = h.inference(mels[2:3], seed=seeds[2])
+    assert torch.equal(again[0].cpu(), alone[2][0].cpu())
+
+
+def test_tts_batch_with_batched_vocoding(lib):
+    """CosyVoice2Model.hift_batch (opt-in): the equal-length members of a flow group go through HiFT in one launch sequence; every waveform equals the one the
+    per-utterance vocoding gives, bit for bit."""
+    import dataclasses
+    from cosyvoice_amd.model import CosyVoice2Model
+    lc, fc, hc = W.tiny()
+    fc = dataclasses.replace(fc, chunk=5, n_timesteps=1)
+    m = CosyVoice2Model.from_state_dicts(W.make_llm(lc), W.make_flow(fc), W.make_hift(hc), (lc, fc, hc), lib=lib, max_len=160, sampling="greedy")
+    inf_b = m.llm.inference_batch
+    m.llm.inference_batch = lambda reqs: inf_b(reqs, max_token_text_ratio=3, min_token_text_ratio=3)      # 6 tokens each: equal shapes
+    us = [W.synthetic_utterance(lc, fc, n_prompt_tok=6, n_prompt_text=2, n_text=2, seed=80 + i) for i in range(3)]
+    keys = ("text", "flow_embedding", "llm_embedding", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat")
+    reqs = [{k: x[k] for k in keys} for x in us]
+    assert m.hift_batch is False                                    # off until measured on the hardware
+    one_by_one = m.tts_batch(reqs)
+    calls = []
+    hb = m.hift.inference_batch
+    m.hift.inference_batch = lambda mels, seeds, **kw: (calls.append(mels.shape[0]), hb(mels, seeds, **kw))[1]
+    m.hift_batch = True
+    batched = m.tts_batch(reqs)
+    lens = [g["tts_speech"].shape[1] for g in batched]
+    assert calls and sum(calls) == sum(n for n in (lens.count(v) for v in set(lens)) if n > 1)
+    for a, b in zip(one_by_one, batched):
+        assert torch.equal(a["tts_speech"], b["tts_speech"]) and a["tts_speech"].abs().max() > 0

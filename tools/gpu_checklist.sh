@@ -21,6 +21,9 @@ for line in open(sys.argv[1]):
             print("  ", k, d.get(k))
         r = d["roofline"]; print("   roofline", {k: r.get(k) for k in ("achieved", "frac", "avg_launch_us", "decode_step_us_from_chains")})
 PY
+# batched vocoding A/B (cv_hift_inference_batch, opt-in since the last session of round 3: bit-identical per utterance, never timed): batch 16 with and without
+run bench_b16_hift_batch  300 python bench.py --gpus 1 --steps 6 --warmup 2 --no-extras --no-cpu-baseline --batch 16 --hift-batch
+run bench_b16_hift_single 300 python bench.py --gpus 1 --steps 6 --warmup 2 --no-extras --no-cpu-baseline --batch 16
 # CosyVoice-300M on the kernels (first hardware run at the start of round 4: no reference values yet): stage times, host share, fp32 chain vs split3
 run probe_cv1             300 python tools/probe_cv1.py
 run probe_cv1_split3      300 python tools/probe_cv1.py split3
