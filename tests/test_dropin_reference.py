@@ -23,6 +23,16 @@ from cosyvoice_amd import synthetic as W  # noqa: E402
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.environ.get("COSYVOICE_REFERENCE", "/root/reference")),
                                 reason="the reference tree is only present in the build container")
 
+class _NoSleepTime:
+    """Stands in for the `time` module INSIDE cosyvoice.cli.model only (its tts() polls with time.sleep(0.1)).  Assigning to `M.time.sleep` would patch the
+    stdlib module for the whole process - and the pytest-xdist worker goes on to run other files (a sleep-based scheduler test failed that way)."""
+    sleep = staticmethod(lambda s: None)
+
+    def __getattr__(self, name):
+        import time
+        return getattr(time, name)
+
+
 N_STEPS = 2          # Euler steps of the tiny fixtures (the reference hard-codes 10, flow/flow.py:278; patched like tests/golden/make_golden.py)
 
 
@@ -37,7 +47,7 @@ def ref():
     fc = dataclasses.replace(W.ref_small_flow(), chunk=5, n_timesteps=N_STEPS)
     u = W.synthetic_utterance(lc, fc, n_prompt_tok=8, n_prompt_text=4, n_text=2, seed=21)
     tokens = torch.randint(0, fc.vocab, (24,), generator=torch.Generator().manual_seed(31)).tolist()
-    M.time.sleep = lambda s: None                             # the reference polls with sleep(0.1)
+    M.time = _NoSleepTime()                                   # the reference polls with sleep(0.1)
     ctx = dict(M=M, MG=MG, cfgs=(lc, fc, hc), u=u, tokens=tokens)
     ctx["base"] = {stream: _run(ctx, _real_model(ctx), stream) for stream in (False, True)}
     assert len(ctx["base"][False]) == 1 and len(ctx["base"][True]) >= 3          # one-shot: one waveform; streaming: hops 5 + pad, 10, rest

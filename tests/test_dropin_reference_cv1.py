@@ -18,11 +18,21 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(os.environ.get("COSYVOICE_REFE
                                 reason="the reference tree is only present in the build container")
 
 
+class _NoSleepTime:
+    """Stands in for the `time` module INSIDE cosyvoice.cli.model only (its tts() polls with time.sleep(0.1)).  Assigning to `M.time.sleep` would patch the
+    stdlib module for the whole process - and the pytest-xdist worker goes on to run other files (a sleep-based scheduler test failed that way)."""
+    sleep = staticmethod(lambda s: None)
+
+    def __getattr__(self, name):
+        import time
+        return getattr(time, name)
+
+
 def test_kernel_backed_flow_and_hift_inside_the_real_cosyvoice_model(emu_lib):
     import ref_import
     ref_import.install()
     import cosyvoice.cli.model as M
-    M.time.sleep = lambda s: None                                  # the reference polls with sleep(0.1)
+    M.time = _NoSleepTime()                                        # the reference polls with sleep(0.1)
     g = gold("cv1k_model")
     tokens = g["tokens"].tolist()
 
