@@ -14,6 +14,7 @@
 #include "tensor_map.h"
 #include "flow_kernels.h"
 #include "flow_fused.h"
+#include "flow_big.h"
 #include "flow_tail.h"
 
 using namespace cv;
@@ -54,6 +55,11 @@ struct cv_flow {
     DevBuf e_x, e_xe, e_n, e_qkv, e_qu, e_qv, e_pe, e_p, e_bd, e_att, e_ff, e_x2, e_ctx;    // encoder
     DevBuf s_in, s_a, s_b, s_c, s_n, s_qkv, s_att, s_ff, s_skip, s_cat, s_out;                    // estimator
     DevBuf h_qk, h_vt, h_att, h_ff;                                                           // estimator, fused bf16 pipeline (flow_fused.h)
+    DevBuf h_xn, h_cur;                                                                       // LayerNorm'd rows / a ResNet block's input as bf16 (flow_big.h)
+    // Round 4, bf16 mode: the large-M kernel set of flow_big.h for passes of at least `big_rows` estimator rows (0 = never) - LayerNorm once per row,
+    // 128-wide GEMM tiles, 128-query attention (`attn2_rows`, same unit).  Bit-identical to the small-tile path, so the thresholds are pure speed knobs.
+    // "big_tile0" / "big_tile1": tile of the bf16-out / fp32-residual GEMMs, 0 = by shape, 1 = 128x128, 2 = 128x64, 3 = 64x64.
+    int big_rows = 2500, attn2_rows = 2500, big_tile0 = 0, big_tile1 = 0;
     int vt_pitch = 0;                  // row pitch of V^T = round_up(T capacity, 64)
     int tail_ring = 8;                 // weight fragments (1 KB each) a wave of flow_tail_kernel keeps in flight: 8 or 16 (option "tail_ring", env CV_FLOW_TAIL_RING)
     int fused_tail = 0;                // bf16 mode: 1 = everything after a block's attention in ONE launch per 16-row band (flow_tail.h).  Measured on MI355X
@@ -198,12 +204,14 @@ static void flow_finalize(cv_flow* m) {
 // precision of the Linear / Conv1d products issued by the current entry point (set from the handle's option for the duration of a call)
 static thread_local int tl_bf16_mfma = 0;
 static thread_local int tl_flow_tile = 0, tl_attn_waves = 4, tl_attn_kt = 2, tl_attn_ks = 1, tl_flow_ntile = 0;     // tuning knobs of the fused pipeline, per call like the precision
+static thread_local int tl_big_tile0 = 0, tl_big_tile1 = 0;
 struct PrecisionScope {
-    int prev, pt, pw, pk, ps, pn;
-    explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves), pk(tl_attn_kt), ps(tl_attn_ks), pn(tl_flow_ntile) {
+    int prev, pt, pw, pk, ps, pn, pb0, pb1;
+    explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves), pk(tl_attn_kt), ps(tl_attn_ks), pn(tl_flow_ntile), pb0(tl_big_tile0), pb1(tl_big_tile1) {
         tl_bf16_mfma = m->bf16_mfma; tl_flow_tile = m->flow_tile; tl_attn_waves = m->attn_waves; tl_attn_kt = m->attn_kt; tl_attn_ks = m->attn_ks; tl_flow_ntile = m->flow_ntile;
+        tl_big_tile0 = m->big_tile0; tl_big_tile1 = m->big_tile1;
     }
-    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; tl_attn_ks = ps; tl_flow_ntile = pn; }
+    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; tl_attn_ks = ps; tl_flow_ntile = pn; tl_big_tile0 = pb0; tl_big_tile1 = pb1; }
 };
 
 // ---- generic conv/linear on channel-last activations -----------------------------------------------------------------
@@ -325,7 +333,7 @@ static void est_reserve(cv_flow* m, int T, int nz = 2) {
     m->s_skip.ensure(R * C * f); m->s_cat.ensure(R * 2 * C * f); m->s_out.ensure(R * c.mel * f);
     {   // bf16 activations of the fused pipeline; V^T is [nz][heads * 64][pitch] and its never-written pad columns must stay finite (0 x P)
         const size_t inner = (size_t)c.est_heads * 64, pitch = (size_t)(T + T / 2 + 63) / 64 * 64;
-        m->h_qk.ensure(R * 2 * inner * 2); m->h_att.ensure(R * inner * 2); m->h_ff.ensure(R * 4 * C * 2);
+        m->h_qk.ensure(R * 2 * inner * 2); m->h_att.ensure(R * inner * 2); m->h_ff.ensure(R * 4 * C * 2); m->h_xn.ensure(R * C * 2); m->h_cur.ensure(R * std::max((size_t)4 * c.mel, 2 * C) * 2);
         const size_t before = m->h_vt.bytes;
         m->h_vt.ensure((size_t)nz * inner * pitch * 2);
         if (m->h_vt.bytes != before || nz != m->est_nz) { CV_HIP(hipMemset(m->h_vt.p, 0, m->h_vt.bytes)); m->vt_pitch = (int)(m->h_vt.bytes / ((size_t)nz * inner * 2) / 64 * 64); }
@@ -390,6 +398,48 @@ static void gemm_bf16_res(const Lin& l, const bf16_t* A, int lda, int M, float* 
     const unsigned g = ((M + 31) / 32) * ((l.N + 63) / 64);
     hipLaunchKernelGGL((flow_gemm_kernel<32, 64, 0, 1>), dim3(g), dim3(256), 0, s, a);
 }
+// ---- large-M forms (flow_big.h): LayerNorm -> bf16 once per row, then plain bf16 GEMMs on 128-wide tiles
+static void ln_bf16(const LN& ln, float eps, const float* x, int M, int K, bf16_t* y, hipStream_t s) {
+    CV_CHECK(K % 4 == 0 && K <= 256, "ln_bf16: K % 4 == 0, K <= 256");
+    LnBf16Args a{x, K, ln.g, ln.b, eps, y, K, M, K};
+    hipLaunchKernelGGL(ln_bf16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, s, a);
+}
+template <int OMODE>
+static void gemm_big_launch(const FlowGemmArgs& a, int tile, hipStream_t s) {
+    auto grid = [&](int bm, int bn) { return dim3((unsigned)(((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn))); };
+    if (tile == 1) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 128, OMODE>), grid(128, 128), dim3(256), 0, s, a);
+    else if (tile == 2) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 64, OMODE>), grid(128, 64), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((flow_gemm_big_kernel<64, 64, OMODE>), grid(64, 64), dim3(256), 0, s, a);
+}
+// out = act(A W^T + b) as bf16 (columns >= n_row to the transposed, key-permuted V^T), A = bf16 rows (LayerNorm already applied)
+static void gemm_big_bf16(const Lin& l, const bf16_t* A, int M, int act, bf16_t* out, int ldo, int n_row, bf16_t* outT, long long t_batch, int ldt, int rows_per_batch,
+                          hipStream_t s) {
+    CV_CHECK(l.bf16 && l.K % 32 == 0 && l.taps == 1 && l.N % 4 == 0 && n_row % 16 == 0, "gemm_big_bf16: needs bf16 weights, K % 32 == 0");
+    FlowGemmArgs a{};
+    a.A = A; a.lda = l.K; a.W = reinterpret_cast<const bf16_t*>(l.w); a.Kp = l.Kp; a.bias = l.b; a.M = M; a.N = l.N; a.K = l.K; a.act = act;
+    a.out = out; a.ldo = ldo; a.n_row = n_row; a.outT = outT; a.t_batch = t_batch; a.ldt = ldt; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
+    gemm_big_launch<0>(a, tl_big_tile0 ? tl_big_tile0 : 1, s);
+}
+// C = A_bf16 W^T + b (+ res), fp32 (N = est_ch: 128 x 64 tiles keep ~1.3 workgroups per CU at M = 10 784)
+static void gemm_big_res(const Lin& l, const bf16_t* A, int lda, int M, float* C, const float* res, hipStream_t s) {
+    CV_CHECK(l.bf16 && l.K % 32 == 0 && l.taps == 1 && l.N % 4 == 0 && lda % 8 == 0, "gemm_big_res: needs bf16 weights, K % 32 == 0");
+    FlowGemmArgs a{};
+    a.A = A; a.lda = lda; a.W = reinterpret_cast<const bf16_t*>(l.w); a.Kp = l.Kp; a.bias = l.b; a.M = M; a.N = l.N; a.K = l.K;
+    a.C = C; a.ldc = l.N; a.res = res; a.n_row = l.N;
+    gemm_big_launch<1>(a, tl_big_tile1 ? tl_big_tile1 : 2, s);
+}
+// causal Conv1d / Linear over bf16 rows of nz requests of T rows each (ResNet blocks of a large pass): C = conv(A) + b (+ res), fp32
+static void conv_big(const Lin& l, const bf16_t* A, int T, int nz, int pad_left, float* C, const float* res, hipStream_t s) {
+    CV_CHECK(l.bf16 && l.K % 64 == 0 && l.N % 4 == 0 && l.Kp == l.K, "conv_big: needs bf16 weights and K % 64 == 0");
+    FlowGemmArgs a{};
+    a.A = A; a.lda = l.K; a.W = reinterpret_cast<const bf16_t*>(l.w); a.Kp = l.Kp; a.bias = l.b; a.M = nz * T; a.N = l.N; a.K = l.K;
+    a.C = C; a.ldc = l.N; a.res = res; a.n_row = l.N; a.taps = l.taps; a.pad_left = pad_left; a.rows_per_batch = T;
+    auto grid = [&](int bm, int bn) { return dim3((unsigned)(((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn))); };
+    const int tile = tl_big_tile1 ? tl_big_tile1 : 2;
+    if (tile == 1) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 128, 1, true>), grid(128, 128), dim3(256), 0, s, a);
+    else if (tile == 2) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 64, 1, true>), grid(128, 64), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((flow_gemm_big_kernel<64, 64, 1, true>), grid(64, 64), dim3(256), 0, s, a);
+}
 // everything after the attention of block `t` (+ LayerNorm and QKV of `next`) in one launch, 16 rows per workgroup (flow_tail.h)
 static void flow_tail(const TBlockW& t, const TBlockW* next, const bf16_t* att, int inner, float* x, int C, int M, bf16_t* qk, bf16_t* vt, long long vt_batch, int ldt,
                       int rows_per_batch, int depth, hipStream_t s) {
@@ -406,12 +456,15 @@ static void flow_tail(const TBlockW& t, const TBlockW* next, const bf16_t* att, 
         if (next) hipLaunchKernelGGL((flow_tail_kernel<64, 64, 256, true, 8>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((flow_tail_kernel<64, 64, 256, false, 8>), g, dim3(256), 0, s, a);
     } else throw Error("flow_tail: no instantiation for these dimensions");
 }
-static void attn_flow(const bf16_t* qk, int ld, int inner, const bf16_t* vt, long long vt_batch, int ldt, bf16_t* o, int B, int H, int T, int chunk, hipStream_t s, const int* klen = nullptr) {
+static void attn_flow(const bf16_t* qk, int ld, int inner, const bf16_t* vt, long long vt_batch, int ldt, bf16_t* o, int B, int H, int T, int chunk, hipStream_t s, const int* klen = nullptr,
+                      bool big = false) {
     AttnFlowArgs a{};
     a.klen = klen;
     a.q = qk; a.k = qk + inner; a.ld = ld; a.vt = vt; a.vt_batch = vt_batch; a.ldt = ldt; a.o = o; a.ldo = inner;
     a.B = B; a.H = H; a.T = T; a.scale = 0.125f; a.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; a.chunk = chunk;
     const dim3 g2((unsigned)(((T + 31) / 32) * H * B)), g4((unsigned)(((T + 63) / 64) * H * B));
+    // 128-query workgroups (QG = 2): the same arithmetic per query as attn_flow_kernel<4, 2, 2>, so only that default may be replaced
+    if (big && tl_attn_ks == 2) { hipLaunchKernelGGL((attn_flow_kernel<4, 2, 2, 2>), dim3((unsigned)(((T + 127) / 128) * H * B)), dim3(512), 0, s, a); return; }
     if (tl_attn_ks == 2) { hipLaunchKernelGGL((attn_flow_kernel<4, 2, 2>), g4, dim3(512), 0, s, a); return; }
     // 3 / 4 key splits: 12 / 16 waves on the same 64 queries, 192 / 256 keys per iteration - 4 / 3 iterations instead of 6 at T = 674 (round 3 probe)
     if (tl_attn_ks == 3) { hipLaunchKernelGGL((attn_flow_kernel<4, 3, 3>), g4, dim3(768), 0, s, a); return; }
@@ -447,12 +500,25 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
         const long long rpb = t_shared ? R : T;          // rows per time-embedding row
         float* x = pp[flip];                             // stage output (cur never aliases it)
         // CausalResnetBlock1D (decoder.py:65-85 + matcha ResnetBlock1D): block1 -> + mlp(t) -> block2 -> + res_conv(x)
+        const bool fused = tl_bf16_mfma && m->fused && C <= 256 && m->wbf16;
+        const int din = st.res.conv1.K;
+        if (fused && m->big_rows > 0 && R >= m->big_rows && din % 64 == 0 && C % 64 == 0) {
+            // large pass (flow_big.h): the block's input and Mish(LN(block1)) are rounded to bf16 ONCE (the small bf16 tiles round them per tap and per N tile
+            // when they stage them - same values), the convolutions run on 128-row tiles: bit-identical to the five launches below
+            bf16_t* cb = m->h_cur.as<bf16_t>() + r0 * din; bf16_t* hb = m->h_xn.as<bf16_t>() + r0 * C;
+            hipLaunchKernelGGL(cvt_bf16_kernel, dim3(nblk(R * din / 8)), dim3(256), 0, s, cur, cb, R * din / 8);
+            conv_big(st.res.conv1, cb, T, nz, 2, x, nullptr, s);
+            { NormArgs na{x, nullptr, R, C, st.res.ln1.g, st.res.ln1.b, 1e-5f, 0, ACT_MISH, 1.f, nullptr, tm, rpb}; na.y16 = hb; norm_rows(na, s); }
+            conv_big(st.res.conv2, hb, T, nz, 2, x, nullptr, s);
+            ln_rows(st.res.ln2, x, xb, R, C, 1e-5f, s, ACT_MISH);
+            conv_big(st.res.res, cb, T, nz, 0, x, xb, s);
+        } else {
         conv_cl(st.res.conv1, cur, T, T, nz, 2, 1, x, ACT_NONE, 0.f, nullptr, s);
         ln_rows(st.res.ln1, x, xb, R, C, 1e-5f, s, ACT_MISH, 1.f, tm, rpb);
         conv_cl(st.res.conv2, xb, T, T, nz, 2, 1, x, ACT_NONE, 0.f, nullptr, s);
         ln_rows(st.res.ln2, x, xb, R, C, 1e-5f, s, ACT_MISH);
         conv_cl(st.res.res, cur, T, T, nz, 0, 1, x, ACT_NONE, 0.f, xb, s);           // x = res_conv(input) + h
-        const bool fused = tl_bf16_mfma && m->fused && C <= 256 && m->wbf16;
+        }
         for (size_t ti = 0; ti < st.tf.size(); ++ti) {      // matcha BasicTransformerBlock (self-attention + exact-erf GELU feed-forward)
             const TBlockW& t = st.tf[ti];
             if (fused && m->fused_tail && t.tail) {   // flow_tail.h: LN + QKV once per stage, then attention + ONE row-band launch per block
@@ -467,8 +533,20 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
                 const long long vt_batch = (long long)inner * m->vt_pitch;
                 bf16_t* qk = m->h_qk.as<bf16_t>() + r0 * 2 * inner; bf16_t* vt = m->h_vt.as<bf16_t>() + b0 * vt_batch; bf16_t* ab = m->h_att.as<bf16_t>() + r0 * inner;
                 bf16_t* fb = m->h_ff.as<bf16_t>() + r0 * 4 * C;
+                const bool big = m->big_rows > 0 && R >= m->big_rows, big_attn = m->attn2_rows > 0 && R >= m->attn2_rows;
+                if (big) {                    // flow_big.h: 7 launches of large tiles, bit-identical to the 5 below
+                    bf16_t* xn = m->h_xn.as<bf16_t>() + r0 * C;
+                    ln_bf16(t.norm1, 1e-5f, x, (int)R, C, xn, s);
+                    gemm_big_bf16(t.qkv, xn, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
+                    attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, klen, big_attn);
+                    gemm_big_res(t.out, ab, inner, (int)R, x, x, s);
+                    ln_bf16(t.norm3, 1e-5f, x, (int)R, C, xn, s);
+                    gemm_big_bf16(t.ff1, xn, (int)R, ACT_GELU_ERF, fb, 4 * C, 4 * C, nullptr, 0, 0, 0, s);
+                    gemm_big_res(t.ff2, fb, 4 * C, (int)R, x, x, s);
+                    continue;
+                }
                 ln_gemm_bf16(t.qkv, &t.norm1, 1e-5f, x, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
-                attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, klen);
+                attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, klen, big_attn);
                 gemm_bf16_res(t.out, ab, inner, (int)R, x, x, s);
                 ln_gemm_bf16(t.ff1, &t.norm3, 1e-5f, x, (int)R, ACT_GELU_ERF, fb, 4 * C, 4 * C, nullptr, 0, 0, 0, s);
                 gemm_bf16_res(t.ff2, fb, 4 * C, (int)R, x, x, s);
@@ -737,6 +815,10 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "fused_tail") { m->fused_tail = value != 0; drop_graphs(m); }
         else if (std::string(name) == "flow_ntile") { CV_CHECK(value >= 0 && value <= 2, "flow_ntile must be 0, 1 or 2"); m->flow_ntile = value; drop_graphs(m); }
         else if (std::string(name) == "tail_ring") { m->tail_ring = value == 16 ? 16 : 8; drop_graphs(m); }      // bf16 mode: one row-band launch after each attention (flow_tail.h) on / off
+        else if (std::string(name) == "big_rows") { CV_CHECK(value >= 0, "big_rows must be >= 0"); m->big_rows = value; drop_graphs(m); }
+        else if (std::string(name) == "attn2_rows") { CV_CHECK(value >= 0, "attn2_rows must be >= 0"); m->attn2_rows = value; drop_graphs(m); }
+        else if (std::string(name) == "big_tile0") { CV_CHECK(value >= 0 && value <= 3, "big_tile0 must be 0..3"); m->big_tile0 = value; drop_graphs(m); }
+        else if (std::string(name) == "big_tile1") { CV_CHECK(value >= 0 && value <= 3, "big_tile1 must be 0..3"); m->big_tile1 = value; drop_graphs(m); }
         else if (std::string(name) == "fused") { m->fused = value != 0; drop_graphs(m); }              // bf16 mode: fused transformer blocks (flow_fused.h) on / off
         else throw Error(std::string("unknown option ") + name);
     });

@@ -26,6 +26,8 @@ struct FlowGemmArgs {
     bf16_t* outT; long long t_batch; int ldt; int rows_per_batch;   // columns [n_row, N) -> outT[m / rpb][n - n_row][perm(m % rpb)]
     float* C; int ldc; const float* res;          // OMODE 1: C[m][n] = acc + bias (+ res[m][n]), fp32
     long long* dbg;                               // dev tool (tools/ubench/flow_gemm_probe.hip): clock64() of thread 0 at the phase boundaries, 8 slots per workgroup; null in production
+    int taps, pad_left;                           // flow_gemm_big_kernel<.., CONV>: causal Conv1d over channel-last rows, W rows [taps][Kp]; tap j of output row m reads input row
+                                                  // m + j - pad_left of the SAME request (rows_per_batch rows each), zero before the request's first row
 };
 
 // key (time) index -> column of the transposed V tile: inside every 32-key block, key 16 s + 4 g + r sits at column 8 g + 4 s + r, which
@@ -38,7 +40,7 @@ __device__ __forceinline__ int vt_col(int t) { return (t & ~31) + ((t >> 2) & 3)
 // at T = 674 (1032 single-tile workgroups = 1.34 rounds of the 768 resident ones) becomes 516 two-tile workgroups in ONE round.
 template <int BM, int BN, int AMODE, int OMODE, int NTILE = 1>
 __global__ __launch_bounds__(256) void flow_gemm_kernel(FlowGemmArgs p) {
-    constexpr int KC = 256, LDK = KC / 2 + 4;                 // LDS row pitch in dwords (bf16 pairs + 4 dwords of padding)
+    constexpr int KC = 256, LDK = KC / 2 + LDS_PAD;           // LDS row pitch in dwords (bf16 pairs + padding: 8 mod 16, common.h)
     constexpr int TM = BM / 32, TN = BN / 32;                 // 16 x 16 MFMA tiles per wave (wave tile = BM/2 x BN/2)
     constexpr int AR = BM / 16;                               // AMODE 1: rows per 16-lane group
     constexpr int AV = BM / 8, WV = BN / 8;                   // 16-byte chunks per thread and K chunk (AMODE 0 A tile / W tile)
@@ -278,7 +280,7 @@ struct AttnFlowArgs {
     const int* klen;                                      // optional [B] key counts of a padded batch
 };
 
-template <int NW, int KT, int KS = 1>
+template <int NW, int KT, int KS = 1, int QG = 1>
 __global__ __launch_bounds__(NW * KS * 64) void attn_flow_kernel(AttnFlowArgs p) {
     // KT = 64-key tiles per iteration: with one workgroup per CU (176 of them at T = 674) each SIMD runs ONE wave, so nothing overlaps the
     // dependent chain MFMA -> scale -> row max (2 cross-lane exchanges) -> exp2 -> pack -> MFMA of a tile but the tile's own independent
@@ -286,10 +288,15 @@ __global__ __launch_bounds__(NW * KS * 64) void attn_flow_kernel(AttnFlowArgs p)
     // KS = key splits inside the workgroup: the KT tiles of an iteration are shared out over KS wave sets (wave = query group + NW * split), each
     // running its own online softmax over its tiles; the sets are merged through LDS at the end.  The problem is too small for the chip
     // (674 query waves for 1024 SIMDs at T = 674), so the way to shorten a workgroup's serial chain is to put MORE waves on the same queries.
-    constexpr int NT = NW * KS * 64, BQ = NW * 16, BKV = 64 * KT, LDH = 36, LDV = BKV / 2 + 4;     // LDS row pitches in dwords
+    // QG (round 4) = groups of 16 queries per wave.  At QG = 1 a wave fetches 16 KB of K / V^T fragments from LDS per 16 MFMAs: with every CU busy (passes
+    // shared by several utterances) the kernel is bound by LDS reads, not by the matrix pipe.  QG = 2 gives each fragment to two MFMAs (two query groups'
+    // B operands): 128 queries per workgroup, half the LDS bytes per flop.  Per query the operations and their order do not depend on QG - a wave stops
+    // its key loop where the 64-query workgroup of QG = 1 holding the same queries would (kend_w) - so results are bit-identical across QG.
+    constexpr int NT = NW * KS * 64, BQ = NW * 16 * QG, BKV = 64 * KT, LDH = 32 + LDS_PAD, LDV = BKV / 2 + LDS_PAD;     // LDS row pitches in dwords (8 mod 16: conflict-free fragment reads)
     constexpr int KTW = KT / KS;                          // 64-key tiles per wave and iteration
     constexpr int NI = BKV * 8 / NT;                      // 16-byte pieces per thread and operand tile (BKV x 64 bf16 each)
     static_assert(KT % KS == 0 && KTW >= 1 && BKV * 8 % NT == 0, "attn_flow_kernel: tile / split configuration");
+    static_assert(QG == 1 || (QG == 2 && NW == 4), "attn_flow_kernel: QG = 2 pairs the two 64-query blocks of the QG = 1 workgroup shape (4 waves)");
     __shared__ __attribute__((aligned(16))) unsigned Ks[2][BKV * LDH];
     __shared__ __attribute__((aligned(16))) unsigned Vt[2][64 * LDV];
 
@@ -298,20 +305,35 @@ __global__ __launch_bounds__(NW * KS * 64) void attn_flow_kernel(AttnFlowArgs p)
     const int nqb = (p.T + BQ - 1) / BQ, nbl = gridDim.x;
     const int bl = xcd_remap((int)blockIdx.x, nbl);       // the query tiles of one (request, head) share an XCD: its K / V^T stream through ONE L2
     const int qb = bl % nqb, h = (bl / nqb) % p.H, b = bl / (nqb * p.H);
-    const int qi = qb * BQ + wave * 16 + lq;
-    const bool qvalid = qi < p.T;
     const float NEG_INF = -__builtin_huge_valf();
     const float scale2 = p.scale * 1.4426950408889634f;
 
     const bf16_t* kb = p.k + (long long)b * p.T * p.ld + h * 64;
     const bf16_t* vb = p.vt + (long long)b * p.vt_batch + (long long)h * 64 * p.ldt;
     const int Tkb = p.klen ? min(p.T, p.klen[b]) : p.T;        // keys of THIS batch row (see AttnArgs::klen)
-    int kend = Tkb;
-    const int qmax_blk = min(p.T - 1, qb * BQ + BQ - 1);
-    if (p.mask_mode == MASK_CHUNK) kend = min(Tkb, (qmax_blk / p.chunk + 1) * p.chunk);
-    int klim = Tkb;
-    if (p.mask_mode == MASK_CHUNK) klim = min(Tkb, (qi / p.chunk + 1) * p.chunk);
-    if (!qvalid) klim = 0;
+    // end of the key loop of the QG = 1 workgroup (NW * 16 queries from q0) - the unit the tile sequence of a query is defined by
+    auto kend_of = [&](int q0) {
+        if (q0 >= p.T) return 0;
+        return p.mask_mode == MASK_CHUNK ? min(Tkb, (min(p.T - 1, q0 + NW * 16 - 1) / p.chunk + 1) * p.chunk) : Tkb;
+    };
+    int kend = kend_of(qb * BQ), kend_w = kend;            // workgroup / this wave
+    if constexpr (QG == 2) { kend_w = kend_of(qb * BQ + (wave >> 1) * 64); kend = max(kend, kend_of(qb * BQ + 64)); }
+    int qi[QG], klim[QG]; bool qvalid[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        qi[g] = qb * BQ + (wave * QG + g) * 16 + lq;
+        qvalid[g] = qi[g] < p.T;
+        klim[g] = Tkb;
+        if (p.mask_mode == MASK_CHUNK) klim[g] = min(Tkb, (qi[g] / p.chunk + 1) * p.chunk);
+        if (!qvalid[g]) klim[g] = 0;
+    }
+
+    int klim_min_w = klim[0];                              // smallest key limit of the wave's queries: tiles that end below it need no per-element mask
+#pragma unroll
+    for (int g = 1; g < QG; ++g) klim_min_w = min(klim_min_w, klim[g]);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) klim_min_w = min(klim_min_w, __shfl_xor(klim_min_w, o));
+    klim_min_w = __builtin_amdgcn_readfirstlane(klim_min_w);       // uniform after the reduction: in a scalar register the tile test below is a scalar branch
 
     // stage pieces: K piece v -> key row v / 8, 8 bf16 at column 8 (v % 8);  V^T piece v -> d row v / (BKV / 8), 8 keys at column 8 (v % (BKV / 8))
     u32x4_t rk[NI], rv[NI];
@@ -334,81 +356,129 @@ __global__ __launch_bounds__(NW * KS * 64) void attn_flow_kernel(AttnFlowArgs p)
     };
     if (kend > 0) load_kv(0);
     // Q as the B operand of S^T = K.Q^T: lane (q = lq, g = lg) supplies d = 32 dg + 8 g .. + 7
-    uint4 qf[2];
-    {
-        const bf16_t* qp = p.q + ((long long)b * p.T + (qvalid ? qi : 0)) * p.ld + h * 64;
+    uint4 qf[QG][2];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const bf16_t* qp = p.q + ((long long)b * p.T + (qvalid[g] ? qi[g] : 0)) * p.ld + h * 64;
 #pragma unroll
         for (int dg = 0; dg < 2; ++dg) {
             uint4 t = *reinterpret_cast<const uint4*>(qp + dg * 32 + lg * 8);
-            if (!qvalid) t = make_uint4(0u, 0u, 0u, 0u);
-            qf[dg] = t;
+            if (!qvalid[g]) t = make_uint4(0u, 0u, 0u, 0u);
+            qf[g][dg] = t;
         }
     }
-    float m_run = NEG_INF, l_run = 0.f;
-    v4f acc[4];
+    float m_run[QG], l_run[QG];
+    v4f acc[QG][4];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) acc[d] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < QG; ++g) {
+        m_run[g] = NEG_INF; l_run[g] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[g][d] = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
 
     auto compute = [&](int kt0, int buf) {
         const int koff = ks * KTW * 64;                    // this wave set's keys inside the staged block
-        v4f s[4 * KTW];                                    // s[kt][r] <-> key kt0 + koff + kt*16 + lg*4 + r, query lq
+        v4f s[QG][4 * KTW];                                // s[g][kt][r] <-> key kt0 + koff + kt*16 + lg*4 + r, query lq of group g
 #pragma unroll
         for (int kt = 0; kt < 4 * KTW; ++kt) {
-            v4f sa = (v4f){0.f, 0.f, 0.f, 0.f};
+            v4f sa[QG];
+#pragma unroll
+            for (int g = 0; g < QG; ++g) sa[g] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int dg = 0; dg < 2; ++dg) {
                 const uint4 kf = *reinterpret_cast<const uint4*>(&Ks[buf][(koff + kt * 16 + lq) * LDH + dg * 16 + lg * 4]);
-                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, kf), __builtin_bit_cast(v8bf, qf[dg]), sa, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < QG; ++g)
+                    sa[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, kf), __builtin_bit_cast(v8bf, qf[g][dg]), sa[g], 0, 0, 0);
             }
-            s[kt] = sa;
+#pragma unroll
+            for (int g = 0; g < QG; ++g) s[g][kt] = sa[g];
         }
-        float mt = NEG_INF;
+        uint4 pb[QG][2 * KTW];
+        // Softmax arithmetic, round 4: the VALUES are those of rounds 2-3 (x = masked ? -inf : s * scale2; e = exp2f(x - m), 0 for a masked key or an all-masked
+        // row), computed with ~5 instead of ~14 VALU instructions per score - the kernel was bound by them, not by the matrix pipe:
+        //  * a tile entirely below every query's key limit (wave-uniform test) skips the per-element compare + select;
+        //  * a masked key needs no test of its own in the exponential: x = -inf gives exp2f(-inf - m) = +0 by itself, and an all-masked row (m = -inf, x - m = NaN)
+        //    subtracts 0 instead;
+        //  * exp2f() is v_exp_f32 wrapped in a range fix for results below 2^-126 (compare, two selects, add, ldexp per element): when no score of the
+        //    wave is more than 126 below its row maximum (one min per row, one vote per tile) the bare v_exp_f32 returns the same bits.
+        const bool edge = kt0 + koff + KTW * 64 > klim_min_w;
 #pragma unroll
-        for (int kt = 0; kt < 4 * KTW; ++kt)
+        for (int g = 0; g < QG; ++g) {
+            float mt = NEG_INF, mn = -NEG_INF;
+            if (edge) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt0 + koff + kt * 16 + lg * 4 + r;
-                const float x = key < klim ? s[kt][r] * scale2 : NEG_INF;     // log2 units: softmax on v_exp_f32
-                s[kt][r] = x;
-                mt = fmaxf(mt, x);
+                for (int kt = 0; kt < 4 * KTW; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt0 + koff + kt * 16 + lg * 4 + r;
+                        const float x = key < klim[g] ? s[g][kt][r] * scale2 : NEG_INF;     // log2 units: softmax on v_exp_f32
+                        s[g][kt][r] = x;
+                        mt = fmaxf(mt, x); mn = fminf(mn, x);
+                    }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 4 * KTW; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = s[g][kt][r] * scale2;
+                        s[g][kt][r] = x;
+                        mt = fmaxf(mt, x); mn = fminf(mn, x);
+                    }
             }
-        mt = fmaxf(mt, __shfl_xor(mt, 16));
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = (m_run == NEG_INF) ? 0.f : exp2f(m_run - m_new);
-        float rsum = 0.f;
+            mt = fmaxf(mt, __shfl_xor(mt, 16));
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float m_new = fmaxf(m_run[g], mt);
+            const float alpha = (m_run[g] == NEG_INF) ? 0.f : exp2f(m_run[g] - m_new);
+            const float m_sub = (m_new == NEG_INF) ? 0.f : m_new;
+            float rsum = 0.f;
+            if (__any(mn - m_sub < -126.f)) {
 #pragma unroll
-        for (int kt = 0; kt < 4 * KTW; ++kt)
+                for (int kt = 0; kt < 4 * KTW; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float x = s[kt][r];
-                const float e = (x == NEG_INF || m_new == NEG_INF) ? 0.f : exp2f(x - m_new);
-                s[kt][r] = e;
-                rsum += e;                                 // the denominator sums the UNROUNDED probabilities
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = exp2f(s[g][kt][r] - m_sub);
+                        s[g][kt][r] = e;
+                        rsum += e;                         // the denominator sums the UNROUNDED probabilities
+                    }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 4 * KTW; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(s[g][kt][r] - m_sub);
+                        s[g][kt][r] = e;
+                        rsum += e;
+                    }
             }
-        rsum += __shfl_xor(rsum, 16);
-        rsum += __shfl_xor(rsum, 32);
-        l_run = l_run * alpha + rsum;
-        m_run = m_new;
+            rsum += __shfl_xor(rsum, 16);
+            rsum += __shfl_xor(rsum, 32);
+            l_run[g] = l_run[g] * alpha + rsum;
+            m_run[g] = m_new;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) acc[d] = acc[d] * alpha;
+            for (int d = 0; d < 4; ++d) acc[g][d] = acc[g][d] * alpha;
 #pragma unroll
-        for (int blk = 0; blk < 2 * KTW; ++blk) {          // k-slot (g, 4 s + r) of 32-key block blk is key 32 blk + 16 s + 4 g + r on both operands
-            const uint4 pb = make_uint4(pack_bf16x2(s[2 * blk][0], s[2 * blk][1]), pack_bf16x2(s[2 * blk][2], s[2 * blk][3]),
-                                        pack_bf16x2(s[2 * blk + 1][0], s[2 * blk + 1][1]), pack_bf16x2(s[2 * blk + 1][2], s[2 * blk + 1][3]));
+            for (int blk = 0; blk < 2 * KTW; ++blk)        // k-slot (g, 4 s + r) of 32-key block blk is key 32 blk + 16 s + 4 g + r on both operands
+                pb[g][blk] = make_uint4(pack_bf16x2(s[g][2 * blk][0], s[g][2 * blk][1]), pack_bf16x2(s[g][2 * blk][2], s[g][2 * blk][3]),
+                                        pack_bf16x2(s[g][2 * blk + 1][0], s[g][2 * blk + 1][1]), pack_bf16x2(s[g][2 * blk + 1][2], s[g][2 * blk + 1][3]));
+            if constexpr (QG > 1) __builtin_amdgcn_sched_barrier(0);     // one query group's softmax at a time: interleaved, the two keep 64 compare masks and both score sets live
+        }
+#pragma unroll
+        for (int blk = 0; blk < 2 * KTW; ++blk)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const uint4 vf = *reinterpret_cast<const uint4*>(&Vt[buf][(dt * 16 + lq) * LDV + (ks * 2 * KTW + blk) * 16 + lg * 4]);
-                acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, vf), __builtin_bit_cast(v8bf, pb), acc[dt], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < QG; ++g)
+                    acc[g][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, vf), __builtin_bit_cast(v8bf, pb[g][blk]), acc[g][dt], 0, 0, 0);
             }
-        }
     };
 
     // ring: tile t is multiplied out of buffer t & 1 while tile t + 1 is parked in the other buffer and tile t + 2 is in flight in registers
     if (kend > 0) { store_kv(0); if (BKV < kend) load_kv(BKV); }
     __syncthreads();
     for (int kt0 = 0, t = 0; kt0 < kend; kt0 += BKV, ++t) {
-        compute(kt0, t & 1);
+        if (QG == 1 || kt0 < kend_w) compute(kt0, t & 1);  // QG = 2: wave-uniform - the 64-query workgroup of these queries ends its loop here
         if (kt0 + BKV < kend) {
             store_kv((t + 1) & 1);                          // every wave left buffer (t + 1) & 1 before the barrier that ended iteration t - 1
             if (kt0 + 2 * BKV < kend) load_kv(kt0 + 2 * BKV);
@@ -418,39 +488,46 @@ __global__ __launch_bounds__(NW * KS * 64) void attn_flow_kernel(AttnFlowArgs p)
 
     if constexpr (KS > 1) {
         // merge the key splits of every query group (fixed order): sets 1 .. KS-1 park (max, denominator, numerators) in LDS - the K ring is free
-        // after the loop's last barrier - and set 0 combines.  Row pitch 19 floats per lane.
+        // after the loop's last barrier - and set 0 combines.  Row pitch 19 floats per lane and query group.
         float* mg = reinterpret_cast<float*>(&Ks[0][0]);
-        static_assert(2 * BKV * LDH >= (KS - 1) * NW * 64 * 19, "merge scratch does not fit the K ring");
+        static_assert(2 * BKV * LDH >= (KS - 1) * NW * 64 * 19 * QG, "merge scratch does not fit the K ring");
         if (ks > 0) {
-            float* d = mg + ((ks - 1) * NW * 64 + wave * 64 + lane) * 19;
-            d[0] = m_run; d[1] = l_run;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) { d[2 + dt * 4 + 0] = acc[dt][0]; d[2 + dt * 4 + 1] = acc[dt][1]; d[2 + dt * 4 + 2] = acc[dt][2]; d[2 + dt * 4 + 3] = acc[dt][3]; }
+            for (int g = 0; g < QG; ++g) {
+                float* d = mg + (((ks - 1) * NW * 64 + wave * 64 + lane) * QG + g) * 19;
+                d[0] = m_run[g]; d[1] = l_run[g];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { d[2 + dt * 4 + 0] = acc[g][dt][0]; d[2 + dt * 4 + 1] = acc[g][dt][1]; d[2 + dt * 4 + 2] = acc[g][dt][2]; d[2 + dt * 4 + 3] = acc[g][dt][3]; }
+            }
         }
         __syncthreads();
         if (ks > 0) return;
 #pragma unroll
-        for (int o2 = 1; o2 < KS; ++o2) {
-            const float* d = mg + ((o2 - 1) * NW * 64 + wave * 64 + lane) * 19;
-            const float m2 = d[0], l2 = d[1];
-            const float m_new = fmaxf(m_run, m2);
-            const float a1 = (m_run == NEG_INF) ? 0.f : exp2f(m_run - m_new), a2 = (m2 == NEG_INF) ? 0.f : exp2f(m2 - m_new);
-            l_run = l_run * a1 + l2 * a2;
+        for (int g = 0; g < QG; ++g)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                acc[dt][0] = acc[dt][0] * a1 + d[2 + dt * 4 + 0] * a2; acc[dt][1] = acc[dt][1] * a1 + d[2 + dt * 4 + 1] * a2;
-                acc[dt][2] = acc[dt][2] * a1 + d[2 + dt * 4 + 2] * a2; acc[dt][3] = acc[dt][3] * a1 + d[2 + dt * 4 + 3] * a2;
+            for (int o2 = 1; o2 < KS; ++o2) {
+                const float* d = mg + (((o2 - 1) * NW * 64 + wave * 64 + lane) * QG + g) * 19;
+                const float m2 = d[0], l2 = d[1];
+                const float m_new = fmaxf(m_run[g], m2);
+                const float a1 = (m_run[g] == NEG_INF) ? 0.f : exp2f(m_run[g] - m_new), a2 = (m2 == NEG_INF) ? 0.f : exp2f(m2 - m_new);
+                l_run[g] = l_run[g] * a1 + l2 * a2;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    acc[g][dt][0] = acc[g][dt][0] * a1 + d[2 + dt * 4 + 0] * a2; acc[g][dt][1] = acc[g][dt][1] * a1 + d[2 + dt * 4 + 1] * a2;
+                    acc[g][dt][2] = acc[g][dt][2] * a1 + d[2 + dt * 4 + 2] * a2; acc[g][dt][3] = acc[g][dt][3] * a1 + d[2 + dt * 4 + 3] * a2;
+                }
+                m_run[g] = m_new;
             }
-            m_run = m_new;
-        }
     }
-    if (qvalid) {
-        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-        bf16_t* op = p.o + ((long long)b * p.T + qi) * p.ldo + h * 64;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-            *reinterpret_cast<uint2*>(op + dt * 16 + lg * 4) = make_uint2(pack_bf16x2(acc[dt][0] * inv, acc[dt][1] * inv), pack_bf16x2(acc[dt][2] * inv, acc[dt][3] * inv));
-    }
+    for (int g = 0; g < QG; ++g)
+        if (qvalid[g]) {
+            const float inv = l_run[g] > 0.f ? 1.f / l_run[g] : 0.f;
+            bf16_t* op = p.o + ((long long)b * p.T + qi[g]) * p.ldo + h * 64;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<uint2*>(op + dt * 16 + lg * 4) = make_uint2(pack_bf16x2(acc[g][dt][0] * inv, acc[g][dt][1] * inv), pack_bf16x2(acc[g][dt][2] * inv, acc[g][dt][3] * inv));
+        }
 }
 
 }  // namespace cv

@@ -92,6 +92,15 @@ static __global__ __launch_bounds__(256) void cfg_euler_kernel(float* x, const f
     x[i] = x[i] + dt * v;
 }
 
+// fp32 -> bf16 (round to nearest even), 8 values per thread: the operand of the large-M convolutions (flow_big.h), rounded once where the small bf16 tiles
+// round it every time they stage it
+static __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* x, unsigned short* y, long long n8) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const float4 a = *reinterpret_cast<const float4*>(x + 8 * i), b = *reinterpret_cast<const float4*>(x + 8 * i + 4);
+    *reinterpret_cast<uint4*>(y + 8 * i) = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+}
+
 // out[r][0:ca] = a[r], out[r][ca:ca+cb] = b[r]   (skip connection concat, flow/decoder.py:476)
 static __global__ __launch_bounds__(256) void concat_cols_kernel(const float* a, int ca, const float* b, int cb, float* out, long long rows) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;

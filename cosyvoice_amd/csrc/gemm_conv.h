@@ -73,8 +73,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
     constexpr int NT = 64 * WM * WN;
     constexpr int WR = WX3 ? 3 : 1;                                        // weight-tile rows per output column
     constexpr bool BFT = ABF16 || AX3;                                    // bf16 tiles in LDS, products on v_mfma_f32_16x16x32_bf16
-    // LD = LDS row pitch in dwords.  fp32 tiles: BK + 4.  bf16 tiles hold BK/2 packed pairs + 4 dwords of padding.
-    constexpr int LD = BFT ? BK / 2 + 4 : BK + 4, KV = BK / 4;           // KV = groups of 4 k-values per tile row
+    // LD = LDS row pitch in dwords.  fp32 tiles: BK + LDS_PAD.  bf16 tiles hold BK/2 packed pairs + LDS_PAD dwords of padding.
+    constexpr int LD = BFT ? BK / 2 + LDS_PAD : BK + LDS_PAD, KV = BK / 4;   // pitch 8 (mod 16) dwords: conflict-free fragment reads (common.h); KV = groups of 4 k-values per tile row
     constexpr int APL = BM * LD;                                          // dwords per A plane (AX3: three of them)
     constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN);   // 16x16 tiles per wave (wave tile = BM/WM x BN/WN)
     constexpr int AV = BM * KV / NT, WV = WR * BN * KV / NT;  // float4 groups per thread per k-step

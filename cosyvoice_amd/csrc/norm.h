@@ -13,6 +13,7 @@ struct NormArgs {
     const float* gamma; const float* beta; float eps; int rms;
     int act; float scale; const float* row_scale; const float* col_add; long long rows_per_batch;
     long long gb_batch = 0;     // float offset of gamma / beta per batch of rows_per_batch rows (adaLN modulation: LN(x) * (1 + scale[b]) + shift[b]); 0 = shared
+    unsigned short* y16 = nullptr;   // optional: the result rounded to bf16 (what a bf16-MFMA consumer would round it to when staging it), rows of C; y may then be null (C % 4 == 0, C <= 1024)
 };
 
 static __global__ __launch_bounds__(256) void norm_rows_kernel(NormArgs p) {
@@ -60,7 +61,8 @@ static __global__ __launch_bounds__(256) void norm_rows_kernel(NormArgs p) {
             if (beta_p) { const float4 b = *reinterpret_cast<const float4*>(beta_p + c); o[0] += b.x; o[1] += b.y; o[2] += b.z; o[3] += b.w; }
             { const float4 t = apply_act4(p.act, make_float4(o[0], o[1], o[2], o[3]), 0.f); o[0] = t.x * rs; o[1] = t.y * rs; o[2] = t.z * rs; o[3] = t.w * rs; }
             if (ca) { const float4 a = *reinterpret_cast<const float4*>(ca + c); o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
-            *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
+            if (p.y) *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
+            if (p.y16) *reinterpret_cast<uint2*>(p.y16 + row * p.C + c) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
         }
         return;
     }
