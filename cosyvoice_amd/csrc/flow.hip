@@ -56,10 +56,15 @@ struct cv_flow {
     DevBuf s_in, s_a, s_b, s_c, s_n, s_qkv, s_att, s_ff, s_skip, s_cat, s_out;                    // estimator
     DevBuf h_qk, h_vt, h_att, h_ff;                                                           // estimator, fused bf16 pipeline (flow_fused.h)
     DevBuf h_xn, h_cur;                                                                       // LayerNorm'd rows / a ResNet block's input as bf16 (flow_big.h)
-    // Round 4, bf16 mode: the large-M kernel set of flow_big.h for passes of at least `big_rows` estimator rows (0 = never) - LayerNorm once per row,
-    // 128-wide GEMM tiles, 128-query attention (`attn2_rows`, same unit).  Bit-identical to the small-tile path, so the thresholds are pure speed knobs.
-    // "big_tile0" / "big_tile1": tile of the bf16-out / fp32-residual GEMMs, 0 = by shape, 1 = 128x128, 2 = 128x64, 3 = 64x64.
-    int big_rows = 2500, attn2_rows = 2500, big_tile0 = 0, big_tile1 = 0;
+    // Round 4, bf16 mode: the large-M kernel set of flow_big.h for passes of at least `big_rows` estimator rows (0 = never) - LayerNorm once per row -> bf16,
+    // bf16 GEMMs with K streamed through a swizzled LDS ring, the ResNet convolutions on the same tiles.  Bit-identical to the small-tile path, so the threshold is
+    // a pure speed knob.  Measured on MI355X (profiles/r4_flow_big_ab.txt, ms per shared pass small -> big): 2 utterances (M = 2696) 49.8 -> 66.9 with 128-wide
+    // tiles, 4 (M = 5392) 77.9 -> 74.4, 8 (M = 10 784) 135.0 -> 109.4 with 64 x 64 tiles - which beat 128 x 64 (116.8) and 128 x 128 (136.6): these launches
+    // are bound by per-workgroup latency chains (load -> LDS -> MFMA -> epilogue stores), not by re-read traffic, and more, smaller workgroups overlap them better.
+    // "big_tile0" / "big_tile1": tile of the bf16-out / fp32-residual GEMMs, 0 = by measurement (64 x 64), 1 = 128x128, 2 = 128x64, 3 = 64x64.
+    // `attn2_rows`: attention with 32 queries per wave (attn_flow_kernel<.., QG = 2>) from that many rows on; 0 = never, the default: at M = 10 784 it measured
+    // 54.1 us per launch against 43.0 for QG = 1 (164 registers: one 8-wave workgroup per CU instead of two).
+    int big_rows = 5000, attn2_rows = 0, big_tile0 = 0, big_tile1 = 0;
     int vt_pitch = 0;                  // row pitch of V^T = round_up(T capacity, 64)
     int tail_ring = 8;                 // weight fragments (1 KB each) a wave of flow_tail_kernel keeps in flight: 8 or 16 (option "tail_ring", env CV_FLOW_TAIL_RING)
     int fused_tail = 0;                // bf16 mode: 1 = everything after a block's attention in ONE launch per 16-row band (flow_tail.h).  Measured on MI355X
@@ -418,15 +423,15 @@ static void gemm_big_bf16(const Lin& l, const bf16_t* A, int M, int act, bf16_t*
     FlowGemmArgs a{};
     a.A = A; a.lda = l.K; a.W = reinterpret_cast<const bf16_t*>(l.w); a.Kp = l.Kp; a.bias = l.b; a.M = M; a.N = l.N; a.K = l.K; a.act = act;
     a.out = out; a.ldo = ldo; a.n_row = n_row; a.outT = outT; a.t_batch = t_batch; a.ldt = ldt; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
-    gemm_big_launch<0>(a, tl_big_tile0 ? tl_big_tile0 : 1, s);
+    gemm_big_launch<0>(a, tl_big_tile0 ? tl_big_tile0 : 3, s);
 }
-// C = A_bf16 W^T + b (+ res), fp32 (N = est_ch: 128 x 64 tiles keep ~1.3 workgroups per CU at M = 10 784)
+// C = A_bf16 W^T + b (+ res), fp32
 static void gemm_big_res(const Lin& l, const bf16_t* A, int lda, int M, float* C, const float* res, hipStream_t s) {
     CV_CHECK(l.bf16 && l.K % 32 == 0 && l.taps == 1 && l.N % 4 == 0 && lda % 8 == 0, "gemm_big_res: needs bf16 weights, K % 32 == 0");
     FlowGemmArgs a{};
     a.A = A; a.lda = lda; a.W = reinterpret_cast<const bf16_t*>(l.w); a.Kp = l.Kp; a.bias = l.b; a.M = M; a.N = l.N; a.K = l.K;
     a.C = C; a.ldc = l.N; a.res = res; a.n_row = l.N;
-    gemm_big_launch<1>(a, tl_big_tile1 ? tl_big_tile1 : 2, s);
+    gemm_big_launch<1>(a, tl_big_tile1 ? tl_big_tile1 : 3, s);
 }
 // causal Conv1d / Linear over bf16 rows of nz requests of T rows each (ResNet blocks of a large pass): C = conv(A) + b (+ res), fp32
 static void conv_big(const Lin& l, const bf16_t* A, int T, int nz, int pad_left, float* C, const float* res, hipStream_t s) {
@@ -435,7 +440,7 @@ static void conv_big(const Lin& l, const bf16_t* A, int T, int nz, int pad_left,
     a.A = A; a.lda = l.K; a.W = reinterpret_cast<const bf16_t*>(l.w); a.Kp = l.Kp; a.bias = l.b; a.M = nz * T; a.N = l.N; a.K = l.K;
     a.C = C; a.ldc = l.N; a.res = res; a.n_row = l.N; a.taps = l.taps; a.pad_left = pad_left; a.rows_per_batch = T;
     auto grid = [&](int bm, int bn) { return dim3((unsigned)(((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn))); };
-    const int tile = tl_big_tile1 ? tl_big_tile1 : 2;
+    const int tile = tl_big_tile1 ? tl_big_tile1 : 3;
     if (tile == 1) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 128, 1, true>), grid(128, 128), dim3(256), 0, s, a);
     else if (tile == 2) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 64, 1, true>), grid(128, 64), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((flow_gemm_big_kernel<64, 64, 1, true>), grid(64, 64), dim3(256), 0, s, a);

@@ -140,13 +140,15 @@ class CausalHiFTGenerator(HiFTGenerator):
     only: 3 for the f0 predictor, 4 more for conv_pre, and withholds one more frame of samples, so m frames give 480 (m - 8) samples - every
     sample a chunk emits equals the one-shot result (the reference's own invariance check, generator.py:729-746).
 
-    Differences from the reference, stated: the f0 predictor runs in fp32 by default (`f0_float64=True` selects the reference's mode; the reference converts it to float64 on every call, :716-717, because
-    its fp32 cuDNN results depend on the chunk; here each f0 value is the same fp32 sum whatever the chunk, so chunked = one-shot bit for bit,
-    and against the float64 reference the harmonic phase agrees to the same 2e-3 as for HiFT v2); the SineGen2 noise comes from a counter RNG
+    The f0 predictor runs with every sum in double by default, like the reference (which converts the predictor to float64 on every call, :716-717, because its
+    fp32 cuDNN results depend on the chunk): `f0_float64=True`, the golden f0 of the real class is met to fp32 rounding.  `f0_float64=False` selects fp32 sums
+    (each f0 value the same sum whatever the chunk, so chunked = one-shot bit for bit there too; against the float64 reference the harmonic phase then agrees
+    to 2e-3 like HiFT v2; measured cost of the default on the MI355X: INTEGRATION.md section 4).  Stated difference: the SineGen2 noise comes from a counter RNG
     (uniform, like the reference's fixed `torch.rand` buffer - 260 MB there) unless `noise` is given."""
 
     def __init__(self, state_dict, cfg, **kw):
         assert cfg.causal, "CausalHiFTGenerator needs a causal HiftConfig (configs.cv3_hift())"
+        kw.setdefault("f0_float64", True)       # the reference's arithmetic for this predictor (generator.py:716-717) is the default since round 4; False = the fp32 sums
         super().__init__(state_dict, cfg, **kw)
         self.conv_pre_look_right = cfg.look_right
 

@@ -317,7 +317,7 @@ class CosyVoice2Model:
                                               for (_, r, _), t in zip(group, toks_t)], streaming=False, finalize=True)
             outs = []
             if (self.hift_batch and speed == 1.0 and len(mels) > 1 and hasattr(lane.hift, "inference_batch") and not lane.hift.cfg.causal
-                    and len({m_.shape[2] for m_ in mels}) == 1):
+                    and not getattr(lane.hift, "f0_float64", False) and len({m_.shape[2] for m_ in mels}) == 1):
                 # batched vocoding (cv_hift_inference_batch): utterances of equal length share ONE HiFT launch sequence; each waveform is bit-identical to
                 # _vocode_mel of it alone (its own RNG key)
                 speech, _ = lane.hift.inference_batch(torch.cat(list(mels), 0), [self._noise_key(t, 0) for t in toks_t])
@@ -557,14 +557,14 @@ class CosyVoice3Model(CosyVoice2Model):
         self.silent_tokens = [1, 2, 28, 29, 55, 248, 494, 2241, 2242, 2322, 2323]
 
     @classmethod
-    def from_state_dicts(cls, llm_sd, flow_sd, hift_sd, cfgs, lib=None, fp16=False, f0_float64=False, **llm_kw):
-        """f0_float64: the vocoder's f0 predictor in double, the reference's mode (hifigan/generator.py:716-717; CausalHiFTGenerator(f0_float64=True)); default fp32."""
+    def from_state_dicts(cls, llm_sd, flow_sd, hift_sd, cfgs, lib=None, fp16=False, f0_float64=True, **llm_kw):
+        """f0_float64: the vocoder's f0 predictor in double, the reference's mode (hifigan/generator.py:716-717) - the default since round 4; False = fp32 sums."""
         lc, fc, hc = cfgs
         lib = lib or get_lib()
         flow = CausalMaskedDiffWithDiT(flow_sd, fc, lib=lib, precision="bf16" if fp16 else "fp32")
         return cls(CosyVoice3LM(llm_sd, lc, lib=lib, **llm_kw), flow, CausalHiFTGenerator(hift_sd, hc, lib=lib, f0_float64=f0_float64), fp16=fp16)
 
-    def load(self, llm_model, flow_model, hift_model, cfgs=None, f0_float64=False, **llm_kw):
+    def load(self, llm_model, flow_model, hift_model, cfgs=None, f0_float64=True, **llm_kw):
         from .configs import cv3_flow, cv3_hift, cv3_llm
         lc, fc, hc = cfgs or (cv3_llm(), cv3_flow(), cv3_hift())
         llm_sd = torch.load(llm_model, map_location="cpu", weights_only=True)

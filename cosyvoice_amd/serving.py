@@ -47,6 +47,7 @@ class StreamScheduler:
         if chunk_batch is None and os.environ.get("CV_CHUNK_BATCH"):                       # dev knob for A/B runs
             chunk_batch = int(os.environ["CV_CHUNK_BATCH"])
         self.chunk_batch = (getattr(model, "flow_batch", 1) if hasattr(model, "token2wav_batch") else 1) if chunk_batch is None else chunk_batch
+        self.chunk_batch = max(1, min(8, int(self.chunk_batch)))       # a flow pass takes at most 8 utterances (cv_flow_inference_batch / _ragged)
         self.batched_passes = self.batched_jobs = 0     # passes that carried more than one request, and the requests in them
         self._src = queue.Queue()
         self._cv = threading.Condition()
@@ -224,26 +225,33 @@ class StreamScheduler:
             if what == "final":
                 r.out.put(None)
             delivered.add(i)
-        err = None
+        failed = {}
         try:
             m.token2wav_batch(jobs, stream=(what == "chunk"), finalize=(what == "final"), on_ready=deliver)
-        except BaseException as e:                # the pass (or one member's vocoder call) failed: every member's request ends with the error - also the ones
-            err = e                                # that already got this chunk (their state is dropped below; a listener must not wait for more)
+        except BaseException:
+            # The shared pass (or one member's vocoder call) failed.  A request must not pay for a neighbour it happened to share a pass with:
+            # members that already got this chunk carry on untouched (their caches were updated by their own, finished HiFT call); the others are vocoded
+            # again ONE BY ONE - a request's caches only change at the end of its own successful call - and only those that fail alone end with their error.
             for i, (r, _, _) in enumerate(picks):
-                if not (what == "final" and i in delivered):
+                if i in delivered:
+                    continue
+                try:
+                    deliver(i, m.token2wav(stream=(what == "chunk"), finalize=(what == "final"), **jobs[i]))
+                except BaseException as e:                  # noqa: BLE001 - handed to the request's listener
+                    failed[i] = e
                     r.out.put(e)
-        done = what == "final" or err is not None
         self.batched_passes += 1
         self.batched_jobs += len(picks)
+        gone = [r for i, (r, _, _) in enumerate(picks) if what == "final" or i in failed]
         with self._cv:
             for r, _, _ in picks:
                 r.busy = False
-                if done:
-                    self._reqs.pop(r.key, None)
+            for r in gone:
+                self._reqs.pop(r.key, None)
             self._cv.notify_all()
-        if done:
+        if gone:
             with m.lock:
-                for r, _, _ in picks:
+                for r in gone:
                     m.hift_cache_dict.pop(r.key, None)
 
     def _next_hop(self, r):

@@ -391,7 +391,7 @@ def test_big_m_kernels_are_bit_identical(lib, tile0, tile1):
                 for k in (1, 2, 3):
                     assert torch.equal(outs[0], outs[k]), (T, streaming, k, (outs[0] - outs[k]).abs().max().item())
     finally:
-        opt(2500, 2500)
+        opt(5000, 0)
         lib.cv_flow_set_option(flow._h, b"big_tile0", C.c_int32(0)); lib.cv_flow_set_option(flow._h, b"big_tile1", C.c_int32(0))
 
 
@@ -418,8 +418,7 @@ def test_big_m_pass_equals_single_passes(lib):
         for a, b in zip(single, together):
             assert a.shape == b.shape and torch.equal(a, b), (a.shape, (a - b).abs().max().item())
     finally:
-        for k in ("big_rows", "attn2_rows"):
-            lib.cv_flow_set_option(flow._h, k.encode(), C.c_int32(2500))
+        lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(5000)); lib.cv_flow_set_option(flow._h, b"attn2_rows", C.c_int32(0))
 
 
 @pytest.mark.parametrize("est_blocks", [1, 3])

@@ -363,9 +363,10 @@ def test_cv3_causal_hift_fullsize(lib):
     full, _ = h.inference(mel, True)
     part, _ = h.inference(mel[:, :, :108], False)
     assert part.shape[1] == 480 * 100 and torch.equal(part.cpu(), full.cpu()[:, : part.shape[1]])
-    # The stated deviation (cosyvoice_amd/hift.py, CausalHiFTGenerator): the device f0 predictor is fp32, the reference runs it in float64
-    # (hifigan/generator.py:716-717).  Bounded here against the FLOAT64 oracle at the benchmark's 500 frames: f0 itself, then what the f0 error
+    # The fp32 OPTION of the f0 predictor (f0_float64=False; the default since round 4 is the reference's float64, hifigan/generator.py:716-717).
+    # Bounded here against the FLOAT64 oracle at the benchmark's 500 frames: f0 itself, then what the f0 error
     # becomes once integrated into the harmonic phase (the device's own source against the float64-f0 oracle's source), then the waveform.
+    h = CausalHiFTGenerator(sd, hc, lib=lib, f0_float64=False)
     m5 = 500
     mel5 = torch.randn(1, 80, m5, generator=gen) * 2 - 5
     noise5 = torch.zeros(480 * m5, hc.harmonics + 1)

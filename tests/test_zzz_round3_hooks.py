@@ -90,10 +90,10 @@ def test_f0_float64_option_matches_the_reference_mode(lib, tiny):
     h = CausalHiFTGenerator(sd, cfg, lib=lib, f0_float64=True)
     f0 = h.f0(g["mel"], True).cpu()
     torch.testing.assert_close(f0, g["f0"], rtol=2e-7, atol=1e-5)
-    assert (h.f0(g["mel"], True).cpu() - g["f0"]).abs().max() <= (CausalHiFTGenerator(sd, cfg, lib=lib).f0(g["mel"], True).cpu() - g["f0"]).abs().max()
+    assert (h.f0(g["mel"], True).cpu() - g["f0"]).abs().max() <= (CausalHiFTGenerator(sd, cfg, lib=lib, f0_float64=False).f0(g["mel"], True).cpu() - g["f0"]).abs().max()
     want = OH.causal_f0_predictor(sd, g["mel"][:, :, :13], False, torch.float64).float()
     torch.testing.assert_close(h.f0(g["mel"][:, :, :13], False).cpu(), want.reshape(1, -1), rtol=2e-7, atol=1e-5)
-    assert h.clone().f0_float64
+    assert h.clone().f0_float64 and CausalHiFTGenerator(sd, cfg, lib=lib).f0_float64        # the reference's arithmetic is the default since round 4
     speech, source = h.inference(g["mel"], True, noise=g["noise"])             # the whole chain on the float64 f0
     torch.testing.assert_close(source.cpu(), g["source"], rtol=0, atol=5e-3)
     c2 = W.tiny()[2]

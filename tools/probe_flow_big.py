@@ -47,4 +47,4 @@ for nu in ((8,) if profile else (1, 2, 4, 8)):
 for nu in ((8,) if profile else (4, 8)):
     for t0, t1 in ((1, 1), (2, 2), (3, 3), (1, 3), (2, 3)):
         run(nu, "big GEMMs tile0=%d tile1=%d + attn2" % (t0, t1), big_rows=1, attn2_rows=1, big_tile0=t0, big_tile1=t1)
-opt(big_rows=2500, attn2_rows=2500, big_tile0=0, big_tile1=0)
+opt(big_rows=5000, attn2_rows=0, big_tile0=0, big_tile1=0)
