@@ -65,6 +65,8 @@ struct cv_flow {
     // `attn2_rows`: attention with 32 queries per wave (attn_flow_kernel<.., QG = 2>) from that many rows on; 0 = never, the default: at M = 10 784 it measured
     // 54.1 us per launch against 43.0 for QG = 1 (164 registers: one 8-wave workgroup per CU instead of two).
     int big_rows = 5000, attn2_rows = 0, big_tile0 = 0, big_tile1 = 0;
+    int big_grid_cap = 0;              // "big_grid_cap": test hook - at most this many workgroups per persistent launch (0 = no cap)
+    int big_persist = 0;               // "big_persist": workgroups per CU of the persistent large-M GEMMs (0 = what the LDS admits, at most 4; -1 = one tile per workgroup)
     int vt_pitch = 0;                  // row pitch of V^T = round_up(T capacity, 64)
     int tail_ring = 8;                 // weight fragments (1 KB each) a wave of flow_tail_kernel keeps in flight: 8 or 16 (option "tail_ring", env CV_FLOW_TAIL_RING)
     int fused_tail = 0;                // bf16 mode: 1 = everything after a block's attention in ONE launch per 16-row band (flow_tail.h).  Measured on MI355X
@@ -209,14 +211,14 @@ static void flow_finalize(cv_flow* m) {
 // precision of the Linear / Conv1d products issued by the current entry point (set from the handle's option for the duration of a call)
 static thread_local int tl_bf16_mfma = 0;
 static thread_local int tl_flow_tile = 0, tl_attn_waves = 4, tl_attn_kt = 2, tl_attn_ks = 1, tl_flow_ntile = 0;     // tuning knobs of the fused pipeline, per call like the precision
-static thread_local int tl_big_tile0 = 0, tl_big_tile1 = 0;
+static thread_local int tl_big_tile0 = 0, tl_big_tile1 = 0, tl_big_persist = 0, tl_big_grid_cap = 0;
 struct PrecisionScope {
-    int prev, pt, pw, pk, ps, pn, pb0, pb1;
-    explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves), pk(tl_attn_kt), ps(tl_attn_ks), pn(tl_flow_ntile), pb0(tl_big_tile0), pb1(tl_big_tile1) {
+    int prev, pt, pw, pk, ps, pn, pb0, pb1, pbp, pbc;
+    explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves), pk(tl_attn_kt), ps(tl_attn_ks), pn(tl_flow_ntile), pb0(tl_big_tile0), pb1(tl_big_tile1), pbp(tl_big_persist), pbc(tl_big_grid_cap) {
         tl_bf16_mfma = m->bf16_mfma; tl_flow_tile = m->flow_tile; tl_attn_waves = m->attn_waves; tl_attn_kt = m->attn_kt; tl_attn_ks = m->attn_ks; tl_flow_ntile = m->flow_ntile;
-        tl_big_tile0 = m->big_tile0; tl_big_tile1 = m->big_tile1;
+        tl_big_tile0 = m->big_tile0; tl_big_tile1 = m->big_tile1; tl_big_persist = m->big_persist; tl_big_grid_cap = m->big_grid_cap;
     }
-    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; tl_attn_ks = ps; tl_flow_ntile = pn; tl_big_tile0 = pb0; tl_big_tile1 = pb1; }
+    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; tl_attn_ks = ps; tl_flow_ntile = pn; tl_big_tile0 = pb0; tl_big_tile1 = pb1; tl_big_persist = pbp; tl_big_grid_cap = pbc; }
 };
 
 // ---- generic conv/linear on channel-last activations -----------------------------------------------------------------
@@ -409,12 +411,20 @@ static void ln_bf16(const LN& ln, float eps, const float* x, int M, int K, bf16_
     LnBf16Args a{x, K, ln.g, ln.b, eps, y, K, M, K};
     hipLaunchKernelGGL(ln_bf16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, s, a);
 }
+// persistent grid (flow_big.h): at most the workgroups that are resident at once - a workgroup then walks its run of tiles with the stage pipeline running across them
+static unsigned big_grid(int M, int N, int bm, int bn) {
+    const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    if (tl_big_persist < 0) return (unsigned)tiles;            // option big_persist = -1: one tile per workgroup (the first form, kept for A/B runs)
+    const int lds = 2 * (bm + bn) * 32 * 4;
+    const int per_cu = tl_big_persist > 0 ? tl_big_persist : std::max(1, std::min(160 * 1024 / lds, 4));       // 0: LDS-limited residency, at most 4 (16 waves) per CU
+    const long long g = std::min<long long>(tiles, (long long)per_cu * 256);
+    return (unsigned)(tl_big_grid_cap > 0 ? std::min<long long>(g, tl_big_grid_cap) : g);     // test hook: a handful of workgroups walk many tiles each
+}
 template <int OMODE>
 static void gemm_big_launch(const FlowGemmArgs& a, int tile, hipStream_t s) {
-    auto grid = [&](int bm, int bn) { return dim3((unsigned)(((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn))); };
-    if (tile == 1) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 128, OMODE>), grid(128, 128), dim3(256), 0, s, a);
-    else if (tile == 2) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 64, OMODE>), grid(128, 64), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((flow_gemm_big_kernel<64, 64, OMODE>), grid(64, 64), dim3(256), 0, s, a);
+    if (tile == 1) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 128, OMODE>), dim3(big_grid(a.M, a.N, 128, 128)), dim3(256), 0, s, a);
+    else if (tile == 2) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 64, OMODE>), dim3(big_grid(a.M, a.N, 128, 64)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((flow_gemm_big_kernel<64, 64, OMODE>), dim3(big_grid(a.M, a.N, 64, 64)), dim3(256), 0, s, a);
 }
 // out = act(A W^T + b) as bf16 (columns >= n_row to the transposed, key-permuted V^T), A = bf16 rows (LayerNorm already applied)
 static void gemm_big_bf16(const Lin& l, const bf16_t* A, int M, int act, bf16_t* out, int ldo, int n_row, bf16_t* outT, long long t_batch, int ldt, int rows_per_batch,
@@ -439,11 +449,10 @@ static void conv_big(const Lin& l, const bf16_t* A, int T, int nz, int pad_left,
     FlowGemmArgs a{};
     a.A = A; a.lda = l.K; a.W = reinterpret_cast<const bf16_t*>(l.w); a.Kp = l.Kp; a.bias = l.b; a.M = nz * T; a.N = l.N; a.K = l.K;
     a.C = C; a.ldc = l.N; a.res = res; a.n_row = l.N; a.taps = l.taps; a.pad_left = pad_left; a.rows_per_batch = T;
-    auto grid = [&](int bm, int bn) { return dim3((unsigned)(((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn))); };
     const int tile = tl_big_tile1 ? tl_big_tile1 : 3;
-    if (tile == 1) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 128, 1, true>), grid(128, 128), dim3(256), 0, s, a);
-    else if (tile == 2) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 64, 1, true>), grid(128, 64), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((flow_gemm_big_kernel<64, 64, 1, true>), grid(64, 64), dim3(256), 0, s, a);
+    if (tile == 1) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 128, 1, true>), dim3(big_grid(a.M, a.N, 128, 128)), dim3(256), 0, s, a);
+    else if (tile == 2) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 64, 1, true>), dim3(big_grid(a.M, a.N, 128, 64)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((flow_gemm_big_kernel<64, 64, 1, true>), dim3(big_grid(a.M, a.N, 64, 64)), dim3(256), 0, s, a);
 }
 // everything after the attention of block `t` (+ LayerNorm and QKV of `next`) in one launch, 16 rows per workgroup (flow_tail.h)
 static void flow_tail(const TBlockW& t, const TBlockW* next, const bf16_t* att, int inner, float* x, int C, int M, bf16_t* qk, bf16_t* vt, long long vt_batch, int ldt,
@@ -823,6 +832,8 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "big_rows") { CV_CHECK(value >= 0, "big_rows must be >= 0"); m->big_rows = value; drop_graphs(m); }
         else if (std::string(name) == "attn2_rows") { CV_CHECK(value >= 0, "attn2_rows must be >= 0"); m->attn2_rows = value; drop_graphs(m); }
         else if (std::string(name) == "big_tile0") { CV_CHECK(value >= 0 && value <= 3, "big_tile0 must be 0..3"); m->big_tile0 = value; drop_graphs(m); }
+        else if (std::string(name) == "big_persist") { CV_CHECK(value >= -1 && value <= 8, "big_persist must be -1..8"); m->big_persist = value; drop_graphs(m); }
+        else if (std::string(name) == "big_grid_cap") { CV_CHECK(value >= 0, "big_grid_cap must be >= 0"); m->big_grid_cap = value; drop_graphs(m); }
         else if (std::string(name) == "big_tile1") { CV_CHECK(value >= 0 && value <= 3, "big_tile1 must be 0..3"); m->big_tile1 = value; drop_graphs(m); }
         else if (std::string(name) == "fused") { m->fused = value != 0; drop_graphs(m); }              // bf16 mode: fused transformer blocks (flow_fused.h) on / off
         else throw Error(std::string("unknown option ") + name);

@@ -71,10 +71,15 @@ __global__ __launch_bounds__(256) void ln_bf16_kernel(LnBf16Args p) {
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // out = epi(A W^T): A bf16 [M][lda], W bf16 [N][Kp] (FlowGemmArgs, AMODE 0 fields; OMODE as in flow_gemm_kernel).  CONV: a causal Conv1d over the rows of every
-// request (taps x K contraction, tap-major like gemm_conv_kernel's bf16 tiles, which this form replaces for the ResNet convolutions of a large pass).  BM x BN tile per workgroup of
-// 2 x 2 waves; K in stages of 64: stage c is multiplied out of LDS buffer c & 1 while stage c + 1 is written into the other buffer and stage c + 2 is
-// in flight in registers - one barrier per stage.  LDS rows are 64 bf16 = eight 16-byte slots without padding, slot s of row r stored at s ^ ((r >> 1) & 7):
-// the fragment reads (row r, slot 4 kg + g) of a 16-lane LDS group then cover all 64 banks once (common.h, LDS_PAD note), and so does a row's store.
+// request (taps x K contraction, tap-major like gemm_conv_kernel's bf16 tiles, which this form replaces for the ResNet convolutions of a large pass).
+// BM x BN tile per 2 x 2 waves; K in stages of 64 through a two-buffer LDS ring: stage g is multiplied out of buffer g & 1 while stage g + 1 is written into the
+// other buffer and stage g + 2 is in flight in registers - one barrier per stage.  LDS rows are 64 bf16 = eight 16-byte slots without padding, slot s of row r
+// stored at s ^ ((r >> 1) & 7): the fragment reads (row r, slot 4 kg + g) of a 16-lane LDS group then cover all 64 banks once (common.h, LDS_PAD note), and so
+// does a row's store.
+// PERSISTENT: a workgroup owns a run of consecutive tiles (the N tiles of a band of rows, then the next band) and its stage sequence runs ACROSS them - the
+// first stages of tile t + 1 are loaded and parked under the last MFMAs and the epilogue of tile t.  With K = 256 a tile is four stages: launched one tile per
+// workgroup (first form of this kernel, profiles/r4_flow_big_ab.txt) a tile was a latency chain of first-load wait -> 4 stages -> epilogue stores, 26 - 37 us
+// per launch at M = 10 784 whatever the tile.  The grid is what fits the chip at once (host: resident workgroups per CU x 256), not the tile count.
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int BM, int BN, int OMODE, bool CONV = false>
 __global__ __launch_bounds__(256) void flow_gemm_big_kernel(FlowGemmArgs p) {
@@ -86,54 +91,57 @@ __global__ __launch_bounds__(256) void flow_gemm_big_kernel(FlowGemmArgs p) {
     unsigned* const As0 = Ls; unsigned* const Ws0 = Ls + 2 * BM * RP;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
-    const int ntn = (p.N + BN - 1) / BN;
-    const int bl = xcd_remap((int)blockIdx.x, (int)gridDim.x);        // an XCD walks the N tiles of a band of rows: A crosses the fabric once
-    const int m0 = (bl / ntn) * BM, n0 = (bl % ntn) * BN;
+    const int ntn = (p.N + BN - 1) / BN, ntiles = ((p.M + BM - 1) / BM) * ntn;
+    // this workgroup's run of tiles: consecutive in (row band, N tile) order, runs handed out in XCD order (an XCD's workgroups walk neighbouring bands: A crosses
+    // the fabric once, the weights stay in its L2)
+    const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int tq = ntiles / (int)gridDim.x, trm = ntiles % (int)gridDim.x;
+    const int t_begin = wg * tq + min(wg, trm), t_count = tq + (wg < trm ? 1 : 0);
     const int spt = (p.K + BK - 1) / BK;                       // stages per tap
-    const int nst = CONV ? p.taps * spt : spt;
+    const int nst = CONV ? p.taps * spt : spt;                 // stages per tile
+    const int total = t_count * nst;
+    const long long wpitch = CONV ? (long long)p.taps * p.Kp : p.Kp;
 
-    bool tr[TN];
     v4f acc[TM][TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) tr[j] = OMODE == 0 && n0 + wn * (BN / 2) + j * 16 >= p.n_row;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    // piece v = tid + 256 i of a stage: row v / 8, slot v % 8 (k = 8 (v % 8)); row bases once, a stage adds its uniform k offset
-    const bf16_t* a_ptr[AV]; const bf16_t* w_ptr[WV]; int a_lds[AV], w_lds[WV], a_t[CONV ? AV : 1];
-    const long long wpitch = CONV ? (long long)p.taps * p.Kp : p.Kp;
+    // piece v = tid + 256 i of a stage: row v / 8, slot v % 8 (k = 8 (v % 8))
+    int a_lds[AV], w_lds[WV];
 #pragma unroll
-    for (int i = 0; i < AV; ++i) {
-        const int v = tid + 256 * i, r = v >> 3, s = v & 7, m = min(m0 + r, p.M - 1);
-        a_ptr[i] = reinterpret_cast<const bf16_t*>(p.A) + (long long)m * p.lda + 8 * s;
-        a_lds[i] = r * RP + ((s ^ ((r >> 1) & 7)) << 2);
-        if constexpr (CONV) a_t[i] = m % p.rows_per_batch;   // row of its request: taps never reach into the previous request
-    }
+    for (int i = 0; i < AV; ++i) { const int v = tid + 256 * i, r = v >> 3, s = v & 7; a_lds[i] = r * RP + ((s ^ ((r >> 1) & 7)) << 2); }
 #pragma unroll
-    for (int i = 0; i < WV; ++i) {
-        const int v = tid + 256 * i, r = v >> 3, s = v & 7;
-        w_ptr[i] = p.W + (long long)min(n0 + r, p.N - 1) * wpitch + 8 * s;
-        w_lds[i] = r * RP + ((s ^ ((r >> 1) & 7)) << 2);
-    }
+    for (int i = 0; i < WV; ++i) { const int v = tid + 256 * i, r = v >> 3, s = v & 7; w_lds[i] = r * RP + ((s ^ ((r >> 1) & 7)) << 2); }
+    const int ps8 = 8 * (tid & 7), pr = tid >> 3;             // this thread's slot (in bf16) and first piece row; piece i is row pr + 32 i
     u32x4_t ra[AV], rw[WV];
-    auto load = [&](int c) {
-        int tap = 0, kc = c;
-        if constexpr (CONV) { tap = c / spt; kc = c - tap * spt; }
+    int a_t[CONV ? AV : 1];                                   // CONV: row of its request of every A piece of the tile being loaded (one modulo per tile, not per stage)
+    // (tile, stage) of the NEXT load, advanced incrementally: no division in the loop
+    int l_tile = t_begin, l_c = 0;
+    auto load = [&]() {
+        const int m0 = (l_tile / ntn) * BM, n0 = (l_tile % ntn) * BN;
+        int tap = 0, kc = l_c;
+        if constexpr (CONV) { tap = l_c / spt; kc = l_c - tap * spt; }
         const int k0 = kc * BK, dr = tap - p.pad_left;        // uniform
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
-            const int s8 = 8 * ((tid + 256 * i) & 7);
+            const int m = min(m0 + pr + 32 * i, p.M - 1);
+            const bf16_t* ap = reinterpret_cast<const bf16_t*>(p.A) + (long long)m * p.lda + ps8;
             if constexpr (CONV) {                             // unconditional load (clamped row) + select: the zero padding before a request's first row
-                const int tr_ = a_t[i] + dr;
-                u32x4_t v = *reinterpret_cast<const u32x4_t*>(a_ptr[i] + (long long)(max(tr_, 0) - a_t[i]) * p.lda + min(k0, p.K - 8 - s8));
+                if (l_c == 0) a_t[i] = m % p.rows_per_batch;          // (uniform branch)
+                const int t = a_t[i], tr_ = t + dr;                   // row of its request: taps never reach into the previous request
+                u32x4_t v = *reinterpret_cast<const u32x4_t*>(ap + (long long)(max(tr_, 0) - t) * p.lda + min(k0, p.K - 8 - ps8));
                 if (tr_ < 0) v = (u32x4_t){0u, 0u, 0u, 0u};
                 ra[i] = v;
-            } else ra[i] = *reinterpret_cast<const u32x4_t*>(a_ptr[i] + min(k0, p.K - 8 - s8));      // clamped: steps beyond K are never multiplied
+            } else ra[i] = *reinterpret_cast<const u32x4_t*>(ap + min(k0, p.K - 8 - ps8));      // clamped: steps beyond K are never multiplied
         }
 #pragma unroll
-        for (int i = 0; i < WV; ++i) { const int s8 = 8 * ((tid + 256 * i) & 7); rw[i] = *reinterpret_cast<const u32x4_t*>(w_ptr[i] + (CONV ? tap * p.Kp : 0) + min(k0, p.Kp - 8 - s8)); }
+        for (int i = 0; i < WV; ++i) {
+            const int n = min(n0 + pr + 32 * i, p.N - 1);
+            rw[i] = *reinterpret_cast<const u32x4_t*>(p.W + (long long)n * wpitch + ps8 + (CONV ? tap * p.Kp : 0) + min(k0, p.Kp - 8 - ps8));
+        }
+        if (++l_c == nst) { l_c = 0; ++l_tile; }
     };
     auto store = [&](int buf) {
 #pragma unroll
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256) void flow_gemm_big_kernel(FlowGemmArgs p) {
     };
     // fragment address of this lane: row (lane & 15) of a 16-row tile, slot 4 kg + (lane >> 4), swizzled by the row (tile bases are multiples of 16)
     const int fr = lane & 15, fx = (fr >> 1) & 7, fg = lane >> 4;
-    auto compute = [&](int buf, int ksteps) {
+    auto compute = [&](int buf, int ksteps, int n0) {
         const unsigned* Ab = &As0[buf * BM * RP + (wm * (BM / 2) + fr) * RP];
         const unsigned* Wb = &Ws0[buf * BN * RP + (wn * (BN / 2) + fr) * RP];
 #pragma unroll
@@ -157,7 +165,8 @@ __global__ __launch_bounds__(256) void flow_gemm_big_kernel(FlowGemmArgs p) {
             for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const uint4*>(Wb + j * 16 * RP + so);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if (tr[j]) {
+                // V^T section (OMODE 0): decided per 16-column MFMA tile (wave-uniform).  Activations as the MFMA "A": a lane ends with 4 consecutive ROWS of one column
+                if (OMODE == 0 && n0 + wn * (BN / 2) + j * 16 >= p.n_row) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, af[i]), __builtin_bit_cast(v8bf, wf[j]), acc[i][j], 0, 0, 0);
@@ -169,80 +178,88 @@ __global__ __launch_bounds__(256) void flow_gemm_big_kernel(FlowGemmArgs p) {
             }
         }
     };
-
-    load(0);
-    store(0);
-    if (nst > 1) load(1);
-    __syncthreads();
-    for (int c = 0; c < nst; ++c) {
-        if (c + 1 < nst) {
-            store((c + 1) & 1);                               // buffer (c + 1) & 1 was last read by stage c - 1: every wave left it before the barrier that ended it
-            if (c + 2 < nst) load(c + 2);
-        }
-        compute(c & 1, min(BK, p.K - (CONV ? c % spt : c) * BK) / 32);
-        __syncthreads();
-    }
-
-    // ---- epilogues: the expressions of flow_gemm_kernel, element for element
-    if constexpr (OMODE == 1) {
+    // ---- epilogues: the expressions of flow_gemm_kernel, element for element; the accumulators are cleared for the next tile
+    auto epilogue = [&](int m0, int n0) {
+        if constexpr (OMODE == 1) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
-            if (m >= p.M) continue;
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+                    if (m < p.M && n < p.N) {
+                        float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                        if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                        const long long idx = (long long)m * p.ldc + n;
+                        if (p.res) { const float4 r = *reinterpret_cast<const float4*>(p.res + idx); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+                        if constexpr (CONV) { v.x += 0.f; v.y += 0.f; v.z += 0.f; v.w += 0.f; }      // gemm_conv_kernel's epilogue ends in "+ 0" (its accumulate term): a -0 result becomes +0 there
+                        *reinterpret_cast<float4*>(p.C + idx) = v;
+                    }
+                    acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        } else {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
-                if (n >= p.N) continue;
-                float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-                const long long idx = (long long)m * p.ldc + n;
-                if (p.res) { const float4 r = *reinterpret_cast<const float4*>(p.res + idx); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-                if constexpr (CONV) { v.x += 0.f; v.y += 0.f; v.z += 0.f; v.w += 0.f; }      // gemm_conv_kernel's epilogue ends in "+ 0" (its accumulate term): a -0 result becomes +0 there
-                *reinterpret_cast<float4*>(p.C + idx) = v;
-            }
-        }
-    } else {
+                if (!(n0 + wn * (BN / 2) + j * 16 >= p.n_row)) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            if (!tr[j]) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
-                    const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
-                    if (m >= p.M || n >= p.N) continue;
-                    float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                    if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-                    v = apply_act4(p.act, v, 0.f);
-                    *reinterpret_cast<uint2*>(p.out + (long long)m * p.ldo + n) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
-                }
-            } else {
-                // V^T section: the lane holds rows m .. m + 3 (m % 4 == 0) of column n.  Same values as flow_gemm_kernel, wider stores: a 4-aligned key
-                // group of one request is 4 consecutive V^T columns (vt_col) -> one 8-byte store; an even-aligned pair 2 columns -> one 4-byte store.
-                const int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
-                if (n >= p.N) continue;
-                const float bn = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4;
-                    if (m >= p.M) continue;
-                    const int b = m / p.rows_per_batch, t = m - b * p.rows_per_batch;
-                    const unsigned lo = pack_bf16x2(acc[i][j][0] + bn, acc[i][j][1] + bn), hi = pack_bf16x2(acc[i][j][2] + bn, acc[i][j][3] + bn);
-                    bf16_t* row = p.outT + (long long)b * p.t_batch + (long long)(n - p.n_row) * p.ldt;
-                    if (m + 3 < p.M && t + 3 < p.rows_per_batch && (t & 3) == 0) { *reinterpret_cast<uint2*>(row + vt_col(t)) = make_uint2(lo, hi); continue; }
-                    if (m + 3 < p.M && t + 3 < p.rows_per_batch && (t & 1) == 0) {
-                        *reinterpret_cast<unsigned*>(row + vt_col(t)) = lo; *reinterpret_cast<unsigned*>(row + vt_col(t + 2)) = hi; continue;
+                    for (int i = 0; i < TM; ++i) {
+                        const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+                        const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+                        if (m < p.M && n < p.N) {
+                            float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                            if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                            v = apply_act4(p.act, v, 0.f);
+                            *reinterpret_cast<uint2*>(p.out + (long long)m * p.ldo + n) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                        }
+                        acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
                     }
+                } else {
+                    // V^T section: the lane holds rows m .. m + 3 (m % 4 == 0) of column n.  Same values as flow_gemm_kernel, wider stores: a 4-aligned key
+                    // group of one request is 4 consecutive V^T columns (vt_col) -> one 8-byte store; an even-aligned pair 2 columns -> one 4-byte store.
+                    const int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+                    const float bn = (p.bias && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int mr = m + r;
-                        if (mr >= p.M) continue;
-                        const int br = mr / p.rows_per_batch, tr_ = mr - br * p.rows_per_batch;
-                        const unsigned u = r < 2 ? lo : hi;
-                        p.outT[(long long)br * p.t_batch + (long long)(n - p.n_row) * p.ldt + vt_col(tr_)] = (bf16_t)((r & 1) ? (u >> 16) : (u & 0xffffu));
+                    for (int i = 0; i < TM; ++i) {
+                        const int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4;
+                        const unsigned lo = pack_bf16x2(acc[i][j][0] + bn, acc[i][j][1] + bn), hi = pack_bf16x2(acc[i][j][2] + bn, acc[i][j][3] + bn);
+                        acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+                        if (m >= p.M || n >= p.N) continue;
+                        const int b = m / p.rows_per_batch, t = m - b * p.rows_per_batch;
+                        bf16_t* row = p.outT + (long long)b * p.t_batch + (long long)(n - p.n_row) * p.ldt;
+                        if (m + 3 < p.M && t + 3 < p.rows_per_batch && (t & 3) == 0) { *reinterpret_cast<uint2*>(row + vt_col(t)) = make_uint2(lo, hi); continue; }
+                        if (m + 3 < p.M && t + 3 < p.rows_per_batch && (t & 1) == 0) {
+                            *reinterpret_cast<unsigned*>(row + vt_col(t)) = lo; *reinterpret_cast<unsigned*>(row + vt_col(t + 2)) = hi; continue;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int mr = m + r;
+                            if (mr >= p.M) continue;
+                            const int br = mr / p.rows_per_batch, tr_ = mr - br * p.rows_per_batch;
+                            const unsigned u = r < 2 ? lo : hi;
+                            p.outT[(long long)br * p.t_batch + (long long)(n - p.n_row) * p.ldt + vt_col(tr_)] = (bf16_t)((r & 1) ? (u >> 16) : (u & 0xffffu));
+                        }
                     }
                 }
             }
         }
+    };
+
+    if (total == 0) return;
+    load();
+    store(0);
+    if (total > 1) load();
+    __syncthreads();
+    int c = 0, tile = t_begin;                                 // (tile, stage) being multiplied
+    for (int g = 0; g < total; ++g) {
+        if (g + 1 < total) {
+            store((g + 1) & 1);                               // buffer (g + 1) & 1 was last read by stage g - 1: every wave left it before the barrier that ended it
+            if (g + 2 < total) load();
+        }
+        const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+        compute(g & 1, min(BK, p.K - (CONV ? c % spt : c) * BK) / 32, n0);
+        if (++c == nst) { epilogue(m0, n0); c = 0; ++tile; }   // stores only: the next tile's first stages are already parked / in flight
+        __syncthreads();
     }
 }
 

@@ -375,8 +375,8 @@ def test_big_m_kernels_are_bit_identical(lib, tile0, tile1):
     flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision="bf16")
     g = torch.Generator().manual_seed(14)
 
-    def opt(big, attn2):
-        for k, v in (("big_rows", big), ("attn2_rows", attn2), ("big_tile0", tile0), ("big_tile1", tile1)):
+    def opt(big, attn2, cap=0):
+        for k, v in (("big_rows", big), ("attn2_rows", attn2), ("big_tile0", tile0), ("big_tile1", tile1), ("big_grid_cap", cap)):
             lib.cv_flow_set_option(flow._h, k.encode(), C.c_int32(v))
     try:
         for T in (45, 150, 281):
@@ -384,15 +384,16 @@ def test_big_m_kernels_are_bit_identical(lib, tile0, tile1):
             spk = torch.randn(2, 80, generator=g); t = torch.tensor([0.3, 0.3]); mask = torch.ones(2, 1, T)
             for streaming in (False, True):
                 outs = []
-                for big, attn2 in ((0, 0), (1, 0), (0, 1), (1, 1)):
-                    opt(big, attn2)
+                # cap = 3 / 1: the persistent form proper - three workgroups (one) walk all the tiles of a launch, the stage pipeline running across tile boundaries
+                for big, attn2, cap in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (1, 0, 3), (1, 1, 1)):
+                    opt(big, attn2, cap)
                     outs.append(flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu().clone())
                 assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
-                for k in (1, 2, 3):
+                for k in (1, 2, 3, 4, 5):
                     assert torch.equal(outs[0], outs[k]), (T, streaming, k, (outs[0] - outs[k]).abs().max().item())
     finally:
         opt(5000, 0)
-        lib.cv_flow_set_option(flow._h, b"big_tile0", C.c_int32(0)); lib.cv_flow_set_option(flow._h, b"big_tile1", C.c_int32(0))
+        lib.cv_flow_set_option(flow._h, b"big_tile0", C.c_int32(0)); lib.cv_flow_set_option(flow._h, b"big_tile1", C.c_int32(0)); lib.cv_flow_set_option(flow._h, b"big_grid_cap", C.c_int32(0))
 
 
 def test_big_m_pass_equals_single_passes(lib):
