@@ -159,6 +159,17 @@ __device__ __forceinline__ float group16_max(float v) {
     return v;
 }
 
+// LDS-DMA: 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4, cdna_hip_programming.md section 5): no staging registers, no
+// ds_write pass.  The LDS destination is WAVE-UNIFORM base + lane * 16 (the hardware adds the lane part; `lds_wave_base` must be the same in every lane), the global
+// source is per lane - a swizzled LDS image is obtained by permuting the SOURCE addresses.  Completion is counted by vmcnt; with a DMA in flight hipcc's
+// __syncthreads() carries the vmcnt(0), so "issue the next stage, compute the current one, barrier" needs no explicit wait.  The CPU emulator's hip_runtime.h
+// supplies its own CV_GLDS16 (a 16-byte copy per lane).
+#ifndef CV_GLDS16
+#define CV_GLDS16(gptr, lds_wave_base)                                                                                  \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                             \
+                                     (__attribute__((address_space(3))) void*)(unsigned)(unsigned long long)(lds_wave_base), 16, 0, 0)
+#endif
+
 // Scheduling fence: the machine scheduler moves no instruction across it (no instruction is emitted).  Used where the ORDER of independent global
 // loads matters - the vector-memory counter retires in issue order, so what is requested first can be waited for first.  (An asm "memory" clobber would
 // do the same to the loads but forces register arrays that live across it into scratch.)

@@ -65,8 +65,13 @@ struct cv_flow {
     // `attn2_rows`: attention with 32 queries per wave (attn_flow_kernel<.., QG = 2>) from that many rows on; 0 = never, the default: at M = 10 784 it measured
     // 54.1 us per launch against 43.0 for QG = 1 (164 registers: one 8-wave workgroup per CU instead of two).
     int big_rows = 5000, attn2_rows = 0, big_tile0 = 0, big_tile1 = 0;
+    int big_glds = 0;                  // "big_glds": the large-M GEMM stages go global -> LDS by DMA (1: global_load_lds_dwordx4, common.h CV_GLDS16) or through registers + ds_write (0).
+                                       // Off: as hipcc compiles it the DMA does not overlap the MFMAs (a vmcnt(0) lands in front of the fragment reads, flow_big.h)
     int big_grid_cap = 0;              // "big_grid_cap": test hook - at most this many workgroups per persistent launch (0 = no cap)
-    int big_persist = 0;               // "big_persist": workgroups per CU of the persistent large-M GEMMs (0 = what the LDS admits, at most 4; -1 = one tile per workgroup)
+    int big_persist = -1;              // "big_persist": -1 = one tile per workgroup; 0 = persistent workgroups, as many as the LDS admits per CU (at most 4), each walking a run of tiles with
+                                       // the stage pipeline running across tile boundaries; n > 0 = n per CU.  Measured on MI355X at 8 utterances per pass (profiles/r4_flow_big_ab.txt):
+                                       // 108.5 ms (-1) / 110.7 (0) / 173.8 (1) / 136.2 (2) / 116.8 (3) with 64 x 64 tiles - a tile's first-load wait and store tail are NOT what bounds these
+                                       // launches (removing them bought nothing); what does is the staging itself, which more co-resident waves overlap better.
     int vt_pitch = 0;                  // row pitch of V^T = round_up(T capacity, 64)
     int tail_ring = 8;                 // weight fragments (1 KB each) a wave of flow_tail_kernel keeps in flight: 8 or 16 (option "tail_ring", env CV_FLOW_TAIL_RING)
     int fused_tail = 0;                // bf16 mode: 1 = everything after a block's attention in ONE launch per 16-row band (flow_tail.h).  Measured on MI355X
@@ -211,14 +216,14 @@ static void flow_finalize(cv_flow* m) {
 // precision of the Linear / Conv1d products issued by the current entry point (set from the handle's option for the duration of a call)
 static thread_local int tl_bf16_mfma = 0;
 static thread_local int tl_flow_tile = 0, tl_attn_waves = 4, tl_attn_kt = 2, tl_attn_ks = 1, tl_flow_ntile = 0;     // tuning knobs of the fused pipeline, per call like the precision
-static thread_local int tl_big_tile0 = 0, tl_big_tile1 = 0, tl_big_persist = 0, tl_big_grid_cap = 0;
+static thread_local int tl_big_tile0 = 0, tl_big_tile1 = 0, tl_big_persist = -1, tl_big_grid_cap = 0, tl_big_glds = 0;
 struct PrecisionScope {
-    int prev, pt, pw, pk, ps, pn, pb0, pb1, pbp, pbc;
-    explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves), pk(tl_attn_kt), ps(tl_attn_ks), pn(tl_flow_ntile), pb0(tl_big_tile0), pb1(tl_big_tile1), pbp(tl_big_persist), pbc(tl_big_grid_cap) {
+    int prev, pt, pw, pk, ps, pn, pb0, pb1, pbp, pbc, pbg;
+    explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves), pk(tl_attn_kt), ps(tl_attn_ks), pn(tl_flow_ntile), pb0(tl_big_tile0), pb1(tl_big_tile1), pbp(tl_big_persist), pbc(tl_big_grid_cap), pbg(tl_big_glds) {
         tl_bf16_mfma = m->bf16_mfma; tl_flow_tile = m->flow_tile; tl_attn_waves = m->attn_waves; tl_attn_kt = m->attn_kt; tl_attn_ks = m->attn_ks; tl_flow_ntile = m->flow_ntile;
-        tl_big_tile0 = m->big_tile0; tl_big_tile1 = m->big_tile1; tl_big_persist = m->big_persist; tl_big_grid_cap = m->big_grid_cap;
+        tl_big_tile0 = m->big_tile0; tl_big_tile1 = m->big_tile1; tl_big_persist = m->big_persist; tl_big_grid_cap = m->big_grid_cap; tl_big_glds = m->big_glds;
     }
-    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; tl_attn_ks = ps; tl_flow_ntile = pn; tl_big_tile0 = pb0; tl_big_tile1 = pb1; tl_big_persist = pbp; tl_big_grid_cap = pbc; }
+    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; tl_attn_ks = ps; tl_flow_ntile = pn; tl_big_tile0 = pb0; tl_big_tile1 = pb1; tl_big_persist = pbp; tl_big_grid_cap = pbc; tl_big_glds = pbg; }
 };
 
 // ---- generic conv/linear on channel-last activations -----------------------------------------------------------------
@@ -420,11 +425,15 @@ static unsigned big_grid(int M, int N, int bm, int bn) {
     const long long g = std::min<long long>(tiles, (long long)per_cu * 256);
     return (unsigned)(tl_big_grid_cap > 0 ? std::min<long long>(g, tl_big_grid_cap) : g);     // test hook: a handful of workgroups walk many tiles each
 }
+template <int OMODE, bool GLDS>
+static void gemm_big_launch2(const FlowGemmArgs& a, int tile, hipStream_t s) {
+    if (tile == 1) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 128, OMODE, false, GLDS>), dim3(big_grid(a.M, a.N, 128, 128)), dim3(256), 0, s, a);
+    else if (tile == 2) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 64, OMODE, false, GLDS>), dim3(big_grid(a.M, a.N, 128, 64)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((flow_gemm_big_kernel<64, 64, OMODE, false, GLDS>), dim3(big_grid(a.M, a.N, 64, 64)), dim3(256), 0, s, a);
+}
 template <int OMODE>
 static void gemm_big_launch(const FlowGemmArgs& a, int tile, hipStream_t s) {
-    if (tile == 1) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 128, OMODE>), dim3(big_grid(a.M, a.N, 128, 128)), dim3(256), 0, s, a);
-    else if (tile == 2) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 64, OMODE>), dim3(big_grid(a.M, a.N, 128, 64)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((flow_gemm_big_kernel<64, 64, OMODE>), dim3(big_grid(a.M, a.N, 64, 64)), dim3(256), 0, s, a);
+    if (tl_big_glds) gemm_big_launch2<OMODE, true>(a, tile, s); else gemm_big_launch2<OMODE, false>(a, tile, s);
 }
 // out = act(A W^T + b) as bf16 (columns >= n_row to the transposed, key-permuted V^T), A = bf16 rows (LayerNorm already applied)
 static void gemm_big_bf16(const Lin& l, const bf16_t* A, int M, int act, bf16_t* out, int ldo, int n_row, bf16_t* outT, long long t_batch, int ldt, int rows_per_batch,
@@ -833,6 +842,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "attn2_rows") { CV_CHECK(value >= 0, "attn2_rows must be >= 0"); m->attn2_rows = value; drop_graphs(m); }
         else if (std::string(name) == "big_tile0") { CV_CHECK(value >= 0 && value <= 3, "big_tile0 must be 0..3"); m->big_tile0 = value; drop_graphs(m); }
         else if (std::string(name) == "big_persist") { CV_CHECK(value >= -1 && value <= 8, "big_persist must be -1..8"); m->big_persist = value; drop_graphs(m); }
+        else if (std::string(name) == "big_glds") { m->big_glds = value != 0; drop_graphs(m); }
         else if (std::string(name) == "big_grid_cap") { CV_CHECK(value >= 0, "big_grid_cap must be >= 0"); m->big_grid_cap = value; drop_graphs(m); }
         else if (std::string(name) == "big_tile1") { CV_CHECK(value >= 0 && value <= 3, "big_tile1 must be 0..3"); m->big_tile1 = value; drop_graphs(m); }
         else if (std::string(name) == "fused") { m->fused = value != 0; drop_graphs(m); }              // bf16 mode: fused transformer blocks (flow_fused.h) on / off
@@ -863,22 +873,38 @@ int cv_flow_encoder(cv_flow* m, const float* tok_emb, int32_t n_tok, const float
                          flow_encoder(m, tok_emb, n_tok, context, streaming, h_out, as_stream(stream)); });
 }
 
-int cv_flow_estimator(cv_flow* m, const float* x, const float* mask, const float* mu, const float* t, const float* spks, const float* cond,
-                      int32_t T, int32_t streaming, float* out, void* stream) {
-    return guarded([&] {
-        CV_CHECK(m && m->finalized && x && mu && t && spks && cond && out && T > 0, "cv_flow_estimator: bad arguments");
-        PrecisionScope prec(m);
-        hipStream_t s = as_stream(stream);
-        const auto& c = m->cfg;
-        const bool dit = c.estimator == 1;
-        if (dit) { dit_reserve(m, T); dit_time_reserve(m, 2); } else { est_reserve(m, T); time_reserve(m, 2); }
+static void flow_estimator_call(cv_flow* m, const float* x, const float* mask, const int32_t* key_len, const float* mu, const float* t, const float* spks,
+                                const float* cond, int32_t T, int32_t streaming, float* out, void* stream) {
+    CV_CHECK(m && m->finalized && x && mu && t && spks && cond && out && T > 0, "cv_flow_estimator: bad arguments");
+    PrecisionScope prec(m);
+    hipStream_t s = as_stream(stream);
+    const auto& c = m->cfg;
+    const bool dit = c.estimator == 1;
+    if (dit) { dit_reserve(m, T); dit_time_reserve(m, 2); } else { est_reserve(m, T); time_reserve(m, 2); }
+    if (key_len) {                         // padded mask: the rows' key counts, read by the attention kernels (AttnArgs::klen) - what a padded pass of several utterances uses
+        CV_CHECK(mask && key_len[0] >= 1 && key_len[0] <= T && key_len[1] >= 1 && key_len[1] <= T, "cv_flow_estimator_masked: key_len must be 1..T and needs the mask");
+        m->klen.ensure(64 * sizeof(int));
+        m->host_klen.assign(key_len, key_len + 2);
+        CV_HIP(hipMemcpyAsync(m->klen.p, m->host_klen.data(), 2 * sizeof(int), hipMemcpyHostToDevice, s));
+        m->cur_klen = m->klen.as<int>();
+    }
+    try {
         CV_HIP(hipMemcpyAsync(m->t_val.p, t, 8, hipMemcpyDeviceToDevice, s));
         if (dit) dit_time_embed(m, 2, s); else time_embed(m, 2, s);
         hipLaunchKernelGGL(pack_est_input_kernel, dim3(nblk(2LL * T * 4 * c.mel)), dim3(256), 0, s, x, mu, spks, cond, m->s_in.as<float>(), T, c.mel, 0, 1);
         if (dit) dit_forward(m, T, 0, 2, false, streaming, s); else estimator_eval(m, T, 0, 2, false, streaming, s);
-        // `mask` must be all ones for the in-kernel (index-computed) attention masks to be exact; it is applied to the output
-        hipLaunchKernelGGL(to_channel_first_kernel, dim3(nblk(2LL * T * c.mel)), dim3(256), 0, s, m->s_out.as<float>(), out, 2, T, c.mel, 0, mask);
-    });
+    } catch (...) { m->cur_klen = nullptr; throw; }
+    m->cur_klen = nullptr;
+    // without key_len `mask` must be all ones for the in-kernel (index-computed) attention masks to be exact; either way it is applied to the output
+    hipLaunchKernelGGL(to_channel_first_kernel, dim3(nblk(2LL * T * c.mel)), dim3(256), 0, s, m->s_out.as<float>(), out, 2, T, c.mel, 0, mask);
+}
+int cv_flow_estimator(cv_flow* m, const float* x, const float* mask, const float* mu, const float* t, const float* spks, const float* cond,
+                      int32_t T, int32_t streaming, float* out, void* stream) {
+    return guarded([&] { flow_estimator_call(m, x, mask, nullptr, mu, t, spks, cond, T, streaming, out, stream); });
+}
+int cv_flow_estimator_masked(cv_flow* m, const float* x, const float* mask, const int32_t* key_len, const float* mu, const float* t, const float* spks,
+                             const float* cond, int32_t T, int32_t streaming, float* out, void* stream) {
+    return guarded([&] { flow_estimator_call(m, x, mask, key_len, mu, t, spks, cond, T, streaming, out, stream); });
 }
 
 // nu utterances with the SAME token count and prompt length through one flow pass: x-vector projection, token embedding and encoder per utterance

@@ -27,21 +27,31 @@ def cfm_rand_noise():
 
 
 class _Estimator:
-    """flow.decoder.estimator: (x[2,80,T], mask[2,1,T], mu[2,80,T], t[2], spks[2,80], cond[2,80,T], streaming) -> [2,80,T]."""
+    """flow.decoder.estimator: (x[2,80,T], mask[2,1,T], mu[2,80,T], t[2], spks[2,80], cond[2,80,T], streaming) -> [2,80,T] (boundary B3)."""
 
     def __init__(self, flow):
         self.flow = flow
 
     def __call__(self, x, mask, mu, t, spks, cond, streaming=False):
+        """mask: all ones (batch-1 inference, flow/flow.py:270), or the reference's PADDED mask - per row, ones for the valid frames then zeros
+        (flow/decoder.py:405-494 multiplies every block by it and builds the attention bias from it).  A padded row comes out as the reference computes
+        it: its valid frames as for that row alone at its own length, zeros behind (cv_flow_estimator_masked)."""
         f = self.flow
-        if not bool((mask == 1).all()):
-            raise NotImplementedError("the MI355X estimator computes attention masks from indices and needs an all-ones mask "
-                                      "(batch-1 inference, flow/flow.py:270)")
         T = x.shape[2]
+        m2 = mask.reshape(2, T).to("cpu", torch.float32)
+        lens = m2.sum(dim=1).to(torch.int64)
+        prefix = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).to(torch.float32)
+        if not torch.equal(m2, prefix) or int(lens.min()) < 1:
+            raise NotImplementedError("the MI355X estimator computes attention masks from indices: a mask row must be ones for its valid frames followed by zeros "
+                                      "(the padded-batch mask of flow/flow.py:236-281), at least one valid frame")
         args = [f.lib.hook(a.to(f.device, torch.float32).contiguous()) for a in (x, mask, mu, t, spks, cond)]
         out = f.lib.hook(torch.empty(2, f.cfg.mel, T, dtype=torch.float32, device=f.device))
-        f.lib.cv_flow_estimator(f._h, *[C.c_void_p(a.data_ptr()) for a in args], C.c_int32(T), C.c_int32(int(streaming)),
-                                C.c_void_p(out.data_ptr()), stream_ptr(f.lib))
+        ptr = [C.c_void_p(a.data_ptr()) for a in args]
+        if int(lens.min()) == T:
+            f.lib.cv_flow_estimator(f._h, *ptr, C.c_int32(T), C.c_int32(int(streaming)), C.c_void_p(out.data_ptr()), stream_ptr(f.lib))
+        else:
+            kl = (C.c_int32 * 2)(int(lens[0]), int(lens[1]))
+            f.lib.cv_flow_estimator_masked(f._h, ptr[0], ptr[1], kl, *ptr[2:], C.c_int32(T), C.c_int32(int(streaming)), C.c_void_p(out.data_ptr()), stream_ptr(f.lib))
         return out
 
 

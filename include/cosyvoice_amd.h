@@ -197,6 +197,12 @@ int cv_flow_encoder(cv_flow* m, const float* tok_emb, int32_t n_tok, const float
  * mask must be all ones (batch-1 inference, flow.py:270); it is applied to the output like the reference's `output * mask`. */
 int cv_flow_estimator(cv_flow* m, const float* x, const float* mask, const float* mu, const float* t, const float* spks, const float* cond,
                       int32_t T, int32_t streaming, float* out, void* stream);
+/* The same with a PADDED mask (the reference's estimator takes one, flow/decoder.py:405-494: every block multiplies by it, the attention bias is built
+ * from it): mask row b = key_len[b] ones followed by zeros (HOST int32 [2], 1..T).  A row's valid positions come out as they would for that row alone
+ * at its own length - the convolutions are causal, norms / linears per position, and the attention takes key_len[b] as the row's key count - and the
+ * padded positions are zero (`output * mask`).  key_len == NULL: cv_flow_estimator. */
+int cv_flow_estimator_masked(cv_flow* m, const float* x, const float* mask, const int32_t* key_len, const float* mu, const float* t, const float* spks,
+                             const float* cond, int32_t T, int32_t streaming, float* out, void* stream);
 /* B5: flow.inference(token ++ prompt_token, prompt_feat, embedding, streaming, finalize) -> mel[1,80,mel_len2]
  * (flow/flow.py:235-281 + flow_matching.py:71-124,203-227).  token_ids: dev int32 [n_tok] = prompt tokens then new tokens;
  * prompt_feat: dev [mel_len1,80]; embedding: dev [spk_dim]; noise_cl: dev [>=T,80] = CausalConditionalCFM.rand_noise

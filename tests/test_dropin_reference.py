@@ -129,6 +129,28 @@ def test_b3_estimator_swap_inside_the_real_model(emu_lib, ref):
         _same(ref, _run(ref, m, stream), stream)
 
 
+def test_b3_estimator_with_a_padded_mask_inside_the_real_cfm(emu_lib, ref):
+    """B3 with the reference's padded `mask`: the REAL CausalConditionalCFM (forward -> solve_euler -> forward_estimator,
+    flow_matching.py:71-153,203-227) solves a sequence whose mask ends 9 frames before the tensors do - once around the real estimator, once around
+    EstimatorModule.  The valid frames agree; the reference multiplies by the mask inside every block, the product ends the key loops at the mask's length."""
+    from cosyvoice_amd.flow import EstimatorModule
+    fc = ref["cfgs"][1]
+    g = torch.Generator().manual_seed(77)
+    T, n = 64, 55
+    mu, cond, spks = torch.randn(1, 80, T, generator=g), torch.randn(1, 80, T, generator=g), torch.randn(1, 80, generator=g)
+    mask = torch.zeros(1, 1, T); mask[:, :, :n] = 1
+    outs = []
+    for swap in (False, True):
+        flow = ref["MG"].build_ref_flow(fc)
+        if swap:
+            flow.decoder.estimator = EstimatorModule(_amd_flow(ref, emu_lib))
+        with torch.inference_mode():
+            y, _ = flow.decoder(mu=mu * mask, mask=mask, spks=spks, cond=cond * mask, n_timesteps=N_STEPS)
+        outs.append(y.cpu())
+    torch.testing.assert_close(outs[1][:, :, :n], outs[0][:, :, :n], rtol=2e-4, atol=2e-4)
+    assert float(outs[0][:, :, :n].abs().max()) > 0.1
+
+
 def test_b4_encoder_swap_inside_the_real_model(emu_lib, ref):
     """B4: `model.flow.encoder = amd_flow.encoder`, the contract of the reference's own TorchScript encoder swap (cli/model.py:277-279)."""
     for stream in (False, True):

@@ -56,6 +56,37 @@ def test_estimator_boundary(lib, tiny, streaming, T):
     torch.testing.assert_close(out.cpu(), ref, rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("streaming", [False, True])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_estimator_padded_mask(lib, tiny, streaming, precision):
+    """B3 with the reference's PADDED mask (flow/decoder.py:405-494 takes mask [B,1,T]; round 4): rows of different valid length in one
+    call.  Valid frames = the oracle's with the same mask (which zeroes the padding before every block and masks it out of the attention); the padding comes
+    out exactly zero; and a row's valid frames are BIT-identical to the same row called alone at its own length (the contract of the padded passes).  A mask
+    that is not 'ones then zeros' is refused."""
+    cfg, sd = tiny
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision=precision)
+    g = torch.Generator().manual_seed(12)
+    T, lens = 70, (70, 52)
+    x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g); cond = torch.randn(2, 80, T, generator=g)
+    spk = torch.randn(2, 80, generator=g); t = torch.tensor([0.3, 0.7])
+    mask = torch.zeros(2, 1, T)
+    for b, n in enumerate(lens):
+        mask[b, 0, :n] = 1
+    out = flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu()
+    assert torch.equal(out[1, :, lens[1]:], torch.zeros(80, T - lens[1]))
+    if precision == "fp32":
+        ref = OF.estimator(sd, cfg, x, mask, mu, t, spk, cond, streaming)
+        torch.testing.assert_close(out, ref, rtol=2e-4, atol=2e-4)
+    n = lens[1]                                              # row 1 alone at its own length, as both rows of an unpadded call
+    pair = lambda a: torch.stack([a[1], a[1]])
+    alone = flow.decoder.estimator(pair(x)[:, :, :n].contiguous(), torch.ones(2, 1, n), pair(mu)[:, :, :n].contiguous(), torch.tensor([0.7, 0.7]), pair(spk),
+                                   pair(cond)[:, :, :n].contiguous(), streaming=streaming).cpu()
+    assert torch.equal(out[1, :, :n], alone[1])
+    bad = mask.clone(); bad[1, 0, 3] = 0
+    with pytest.raises(NotImplementedError):
+        flow.decoder.estimator(x, bad, mu, t, spk, cond, streaming=streaming)
+
+
 def test_estimator_like_export_onnx_check(lib, tiny):
     """The reference's only numeric self-check (cosyvoice/bin/export_onnx.py:89-109): 10 random inputs, B = 2, T drawn from [16, 512],
     estimator output of the accelerated backend vs PyTorch at rtol 1e-2 / atol 1e-4 - here the HIP estimator vs the oracle, same
@@ -375,8 +406,8 @@ def test_big_m_kernels_are_bit_identical(lib, tile0, tile1):
     flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision="bf16")
     g = torch.Generator().manual_seed(14)
 
-    def opt(big, attn2, cap=0):
-        for k, v in (("big_rows", big), ("attn2_rows", attn2), ("big_tile0", tile0), ("big_tile1", tile1), ("big_grid_cap", cap)):
+    def opt(big, attn2, cap=0, glds=0):
+        for k, v in (("big_rows", big), ("attn2_rows", attn2), ("big_tile0", tile0), ("big_tile1", tile1), ("big_grid_cap", cap), ("big_glds", glds)):
             lib.cv_flow_set_option(flow._h, k.encode(), C.c_int32(v))
     try:
         for T in (45, 150, 281):
@@ -385,11 +416,12 @@ def test_big_m_kernels_are_bit_identical(lib, tile0, tile1):
             for streaming in (False, True):
                 outs = []
                 # cap = 3 / 1: the persistent form proper - three workgroups (one) walk all the tiles of a launch, the stage pipeline running across tile boundaries
-                for big, attn2, cap in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (1, 0, 3), (1, 1, 1)):
-                    opt(big, attn2, cap)
+                # glds = 1: the stages by LDS-DMA (global_load_lds) instead of registers + ds_write
+                for big, attn2, cap, glds in ((0, 0, 0, 0), (1, 0, 0, 0), (0, 1, 0, 0), (1, 1, 0, 0), (1, 0, 3, 0), (1, 1, 1, 0), (1, 0, 0, 1), (1, 0, 2, 1)):
+                    opt(big, attn2, cap, glds)
                     outs.append(flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu().clone())
                 assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
-                for k in (1, 2, 3, 4, 5):
+                for k in range(1, len(outs)):
                     assert torch.equal(outs[0], outs[k]), (T, streaming, k, (outs[0] - outs[k]).abs().max().item())
     finally:
         opt(5000, 0)
