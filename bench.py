@@ -129,6 +129,38 @@ def self_check(model, u):
             "wav_rms": round(float(wav.pow(2).mean().sqrt()), 5)}
 
 
+def ras_check(model, u):
+    """Outside the timed region, second parity workload (greedy decoding of random weights ends in a short loop - 65 distinct ids in U10): the SAME
+    utterance decoded with repetition-aware sampling on the device from FIXED uniform variates must reproduce the CPU oracle's sampled sequence, committed as
+    tests/golden/u10_ras_oracle_tokens.json (tests/golden/make_u10_ras.py: 250 tokens, ~150 distinct ids, ~20 fallback draws; nothing from oracle/ is
+    imported here).  The decode chain, the sampler's sort / nucleus / window / fallback logic and the history all have to be right for 250 dependent decisions.  The variates
+    were chosen so that every decision keeps a margin of 1e-3 to its nearest alternative: any difference is an error."""
+    import numpy as np
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "u10_ras_oracle_tokens.json")))
+    us = np.asarray(gold["variates"], dtype=np.float32)
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    ratio = N_GEN / N_TEXT
+    lm = model.llm
+    prev = lm.sampling
+    lm.sampling = "ras"
+    lm.set_uniforms(us)
+    try:
+        with model.llm_context:
+            toks = [int(x) for x in lm.inference(text=u["text"], text_len=t(N_TEXT), prompt_text=u["prompt_text"], prompt_text_len=t(N_PROMPT_TEXT),
+                                                 prompt_speech_token=u["llm_prompt_speech_token"], prompt_speech_token_len=t(N_PROMPT_TOK),
+                                                 embedding=u["llm_embedding"], max_token_text_ratio=ratio, min_token_text_ratio=ratio)]
+    finally:
+        lm.sampling = prev
+        lm.set_uniforms(None)
+    want = gold["tokens"]
+    div = next((i for i, (a, b) in enumerate(zip(toks, want)) if a != b), None if len(toks) == len(want) else min(len(toks), len(want)))
+    if div is not None:
+        raise RuntimeError("bench RAS check: the device's sampled tokens leave the oracle's at step %s (device %s, oracle %s) where the decision margin is %s"
+                           % (div, toks[div] if div < len(toks) else None, want[div] if div < len(want) else None, gold["margin"][div] if div < len(gold["margin"]) else None))
+    return {"ras_tokens_equal_oracle": div is None, "first_divergence": div, "margin_there": None if div is None else gold["margin"][div], "n_tokens": len(toks),
+            "distinct_ids": len(set(want)), "fallback_draws": gold["fallback_draws"], "oracle_min_margin": gold["min_margin"]}
+
+
 def batched_decode(model, u, nb, reps):
     """Serving-style extra (BASELINE.json configs[2]/[3]): NB copies of the U10 request through tts_batch.  The LM step streams every
     weight matrix once for all NB sequences; flow and HiFT still run per utterance.  Also reports the LM part alone."""
@@ -186,8 +218,13 @@ def cv3_workload(args):
     from cosyvoice_amd import configs as CF, synthetic as W
     from cosyvoice_amd.model import CosyVoice3Model
     lc, fc, hc = CF.cv3_llm(), dataclasses.replace(CF.cv3_flow(), n_timesteps=args.cv3_steps), CF.cv3_hift()
+    import ctypes as C
+    # the e4m3 weight copies are always registered (batch_fp8=True); the handle's option decides which path the batched decode takes - W16A32 for the lines the
+    # oracle's tokens are checked on, fp8 for the `fp8` sub-line below (or everywhere with --llm-fp8)
     m = CosyVoice3Model.from_state_dicts(W.make_llm(lc), W.make_flow_dit(fc), W.make_hift(hc), (lc, fc, hc), max_len=1024, sampling="greedy", decode_chunk=64,
-                                         fp16=(args.flow_precision == "bf16"), batch_fp8=args.llm_fp8)
+                                         fp16=(args.flow_precision == "bf16"), batch_fp8=True)
+    set_fp8 = lambda on: m.llm.lib.cv_llm_set_option(m.llm._h, b"batch_fp8", C.c_int32(int(on)))
+    set_fp8(args.llm_fp8)
     u = W.synthetic_utterance(lc, fc, n_prompt_tok=N_PROMPT_TOK, n_prompt_text=24, n_text=N_TEXT, seed=2025)
     u["prompt_text"][0, 11] = lc.endofprompt_id
     u["llm_prompt_speech_token"] = torch.zeros(1, 0, dtype=torch.int32)
@@ -238,7 +275,46 @@ def cv3_workload(args):
             if len(toks) != len(gold["tokens"]) or (div is not None and gold["top2_margin"][div] > 1e-3):
                 raise RuntimeError("bench cosyvoice3: %s does not reproduce the oracle's tokens (first difference at step %s)" % (name, div))
         check = {"checked": True, "tokens_equal_oracle_single_and_16_slots": True, "oracle_min_top2_margin": gold["min_margin"]}
-    return {"model": "Fun-CosyVoice3-0.5B dimensions (CosyVoice3LM, DiT 22 x 1024, CausalHiFTGenerator), seeded random weights", "cfm_steps": args.cv3_steps,
+    fp8 = None
+    if os.path.exists(gpath) and not args.llm_fp8:
+        # BASELINE.json configs[4] AS QUOTED ("fp8 MFMA LLM path + 4-step CFM", 16 requests per GPU) under the same clock: the batched decode on e4m3 weight copies
+        # (per-row scales) with per-sequence activation quantisation on v_mfma_f32_16x16x32_fp8_fp8.  THE REFERENCE HAS NO fp8 PATH: there is nothing to be equal to -
+        # the line reports how far the quantised decode is from the fp32 oracle's tokens and, at the first step, from the W16A32 log-probabilities
+        # (which themselves sit within 1e-3 of the oracle's: tests/test_zz_fullsize.py).
+        gold = json.load(open(gpath))
+        lm = m.llm
+
+        def first_step_logp(on):
+            set_fp8(on)
+            with lm.lock:
+                st = stream_ptr(lm.lib)
+                lm._kv_gen += 1
+                lm.lib.cv_llm_batch_begin(lm._h, C.c_int32(1), st)
+                x = lm.build_lm_input(req["text"], req["prompt_text"], req["llm_prompt_speech_token"])
+                lm._prefill_slots([0], [x], [lm.make_sampling(N_GEN, N_GEN)], st)
+                buf, n_out, f = (C.c_int32 * 1)(), (C.c_int32 * 1)(), (C.c_int32 * 1)()
+                lm.lib.cv_llm_batch_decode(lm._h, C.c_int32(1), buf, n_out, f, st)
+                out = torch.empty(lc.speech_token_size + lc.n_special, dtype=torch.float32)
+                lm.lib.cv_llm_batch_logits(lm._h, C.c_int32(0), C.c_void_p(out.data_ptr()), st)
+            return out[: lc.speech_token_size].log_softmax(-1), int(buf[0])
+        from cosyvoice_amd._lib import stream_ptr
+        lp16, t16 = first_step_logp(False)
+        lp8, t8 = first_step_logp(True)
+        m.tts_batch([req] * nb)                                   # warm-up on the fp8 path (its own graphs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs8 = m.tts_batch([req] * nb)
+        torch.cuda.synchronize()
+        fp8_s = time.perf_counter() - t0
+        set_fp8(False)
+        assert all(o["tts_speech"].shape[1] == N_GEN * 2 * 480 and bool(torch.isfinite(o["tts_speech"]).all()) for o in outs8)
+        divs = [next((k for k, (a, b) in enumerate(zip(t, gold["tokens"])) if a != b), len(gold["tokens"])) for t in seen["batch"]]
+        fp8 = {"config": "BASELINE.json configs[4] as quoted: fp8 MFMA LLM path + %d-step CFM, 16 requests per GPU; NO REFERENCE exists for this arithmetic" % args.cv3_steps,
+               "batch16_audio_s_per_s": round(nb * AUDIO_S / fp8_s, 3), "batch16_ms_per_batch": round(1e3 * fp8_s, 2),
+               "first_divergence_from_fp32_oracle_tokens_min_over_slots": min(divs), "slots_identical_to_each_other": len({tuple(t) for t in seen["batch"]}) == 1,
+               "first_step_max_abs_dlogp_vs_w16a32": round(float((lp8 - lp16).abs().max()), 5), "first_step_token_equal": t8 == t16,
+               "oracle_top2_margin_at_divergence": None if min(divs) >= len(gold["top2_margin"]) else gold["top2_margin"][min(divs)]}
+    return {"fp8": fp8, "model": "Fun-CosyVoice3-0.5B dimensions (CosyVoice3LM, DiT 22 x 1024, CausalHiFTGenerator), seeded random weights", "cfm_steps": args.cv3_steps,
             "flow_precision": args.flow_precision, "llm": ("batch of 16: fp8 e4m3 weights + activations on the fp8 MFMA; single request: W16A32" if args.llm_fp8 else "W16A32"),
             "batch1_audio_s_per_s": round(AUDIO_S / single, 3), "batch1_ms_per_utterance": round(1e3 * single, 2),
             "batch16_audio_s_per_s": round(nb * AUDIO_S / batch_s, 3), "batch16_ms_per_batch": round(1e3 * batch_s, 2), "lanes": args.lanes, "flow_batch": args.flow_batch, "token_check": check}
@@ -873,6 +949,8 @@ def main():
             out["utterance_hashes_sha1"] = hashlib.sha1("".join(all_hashes[i] for i in range(len(costs))).encode()).hexdigest()
         out["self_check"] = self_check(model, u)                 # U10 through the same model object, whatever the workload
         log("self-check passed: %s" % out["self_check"])
+        out["self_check"]["ras"] = ras_check(model, u)           # ... and a sampled, non-degenerate sequence of the same utterance
+        log("RAS check passed: %s" % out["self_check"]["ras"])
         if world == 1 and args.workload == "u10":
             out["stages"] = stage_split(model, u)
             log("stage split: %s" % out["stages"])

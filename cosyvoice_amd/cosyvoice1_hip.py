@@ -416,8 +416,10 @@ class TransformerLM(C1.TransformerLM):
     @torch.inference_mode()
     def inference(self, text, text_len, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len, embedding,
                   sampling=25, max_token_text_ratio=20, min_token_text_ratio=2, uuid=""):
+        # The stage lock is taken PER STEP, never across a yield: a request's state is its own (_KVState, the recorded step with its buffers), so
+        # another request may prefill or step between two of this one's tokens, and a consumer that stops reading blocks nobody.
+        K, D = self.k, self.llm_input_size
         with self.lock:
-            K, D = self.k, self.llm_input_size
             ids = torch.cat([prompt_text, text], dim=1).reshape(-1).to(torch.int32)
             n_text, n_prompt = int(text.shape[1]), int(prompt_speech_token.shape[1])
             has_spk = embedding.shape[0] != 0
@@ -433,20 +435,21 @@ class TransformerLM(C1.TransformerLM):
             lm_input[r:r + 1].copy_(self.llm_emb[self.task_id:self.task_id + 1]); r += 1
             if n_prompt:
                 lm_input[r:r + n_prompt].copy_(K.gather(self.speech_emb, prompt_speech_token))
-            min_len, max_len = int(n_text * min_token_text_ratio), int(n_text * max_token_text_ratio)
-            out_tokens, state, x = [], None, lm_input
-            for i in range(max_len):
+        min_len, max_len = int(n_text * min_token_text_ratio), int(n_text * max_token_text_ratio)
+        out_tokens, state, x = [], None, lm_input
+        for i in range(max_len):
+            with self.lock:
                 y, state = self.llm.forward_chunk(x, state)
                 logits = K.linear(y[-1:], self.decoder, 1)
                 logp = logits.reshape(-1).cpu().log_softmax(dim=-1)    # the sampler draws from the host RNG, like the reference's python sampler
-                if i < min_len:
-                    logp[self.speech_token_size] = -float("inf")
-                top = self.sampling(logp, out_tokens, sampling)
-                if top == self.eos_token:
-                    break
-                yield top
-                out_tokens.append(top)
-                x = self.speech_emb[top:top + 1]
+            if i < min_len:
+                logp[self.speech_token_size] = -float("inf")
+            top = self.sampling(logp, out_tokens, sampling)
+            if top == self.eos_token:
+                break
+            yield top
+            out_tokens.append(top)
+            x = self.speech_emb[top:top + 1]
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------

@@ -13,6 +13,8 @@ void gemm_conv(GemmConvArgs a, bool w_bf16, int batch, hipStream_t s) {
     a.a_vec = aligned16(a.A) && (a.lda % 4 == 0) && (a.a_off0 % 4 == 0) && (a.tap_step % 4 == 0) &&
               (a.a_batch % 4 == 0) && (a.a_len % 4 == 0) && (a.K % 4 == 0) && a.a_len >= 4;
     CV_CHECK(a.a_len >= 1, "gemm_conv: empty A operand");
+    CV_CHECK(a.act != ACT_SNAKE || a.act_alpha, "gemm_conv: a Snake epilogue needs act_alpha[N] (the kernel dereferences it)");
+    CV_CHECK(!a.C2 || a.c2_alpha, "gemm_conv: the second (Snake-activated) output needs c2_alpha[N]");
     {   // the vectorised kernels address both operands with 32-bit byte offsets (buffer loads): keep them under 1.75 GiB, else scalar path
         const long long ldw = a.ldw ? a.ldw : (long long)a.taps * a.Kp;
         const long long w_bytes = ((long long)(a.N - 1) * ldw + (long long)a.taps * a.Kp) * (w_bf16 ? 2 : 4);
@@ -94,6 +96,8 @@ int cv_gemm_conv(const cv_gemm_conv_args* g, void* stream) {
         a.M = g->M; a.N = g->N; a.act = g->act; a.act_p = g->act_p; a.res = g->res; a.res_batch = g->res_batch;
         a.out_scale = g->out_scale; a.row_scale = g->row_scale; a.row_scale_batch = g->row_scale_batch; a.accumulate = g->accumulate; a.a_bf16 = g->a_bf16;
         CV_CHECK(g->w_dtype == CV_F32 || g->w_dtype == CV_BF16, "cv_gemm_conv: w_dtype");
+        CV_CHECK(g->act != cv::ACT_SNAKE, "cv_gemm_conv: CV_ACT_SNAKE is a PROLOGUE activation at this boundary (pro / pro_alpha); the Snake epilogue of the HiFT ResBlocks "
+                                          "takes a per-column alpha this struct does not carry");
         CV_CHECK(!g->W3 || (g->w_dtype == CV_F32 && g->ldw == 0 && g->w_batch == 0 && cv::aligned16(g->W3)), "cv_gemm_conv: W3 planes go with plain fp32 weights (no row pitch / batch offset)");
         a.W3 = g->W3;
         cv::gemm_conv(a, g->w_dtype == CV_BF16, g->batch, cv::as_stream(stream));

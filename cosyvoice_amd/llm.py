@@ -54,8 +54,9 @@ class Qwen2Encoder:
         n = rows.shape[0]
         with lm.lock:
             if cache is None:
-                self._gen, self._pos = self._gen + 1, 0
-            elif cache != ("cv_llm_kv", id(self), self._gen):
+                lm._kv_gen += 1
+                self._gen, self._pos = lm._kv_gen, 0
+            elif cache != ("cv_llm_kv", id(self), self._gen) or self._gen != lm._kv_gen:      # replaced by another forward_one_step sequence, or by inference() / inference_batch() / prefill() on the same handle
                 raise ValueError("forward_one_step: this cache belongs to a sequence that was replaced (one live KV cache per Qwen2LM handle)")
             if self._pos + n + 2 >= lm.max_len:
                 raise ValueError("forward_one_step: KV capacity %d exhausted" % lm.max_len)
@@ -107,6 +108,7 @@ class Qwen2LM:
             self.lib.cv_llm_set_option(self._h, b"batch_fp8", C.c_int32(1))
         self._uniforms = None
         self._request = 0
+        self._kv_gen = 0                                     # bumped by everything that resets the handle's KV cache (a stale forward_one_step cache must be refused whoever replaced it)
 
     def __del__(self):
         try:
@@ -157,6 +159,7 @@ class Qwen2LM:
 
     def prefill(self, lm_input, stream=None):
         st = stream if stream is not None else stream_ptr(self.lib)
+        self._kv_gen += 1                                # a new sequence takes the handle's KV cache: caches handed out by forward_one_step go stale
         self.lib.cv_llm_prefill(self._h, C.c_void_p(lm_input.data_ptr()), C.c_int32(lm_input.shape[0]), st)
 
     def last_logits(self):
@@ -255,6 +258,7 @@ class Qwen2LM:
         assert 1 <= nb <= 16, "1..16 requests per batch"
         with self.lock:
             st = stream_ptr(self.lib)
+            self._kv_gen += 1
             self.lib.cv_llm_batch_begin(self._h, C.c_int32(nb), st)
             max_lens, inputs, sps = [], [], []
             for i, r in enumerate(requests):
@@ -301,6 +305,7 @@ class Qwen2LM:
         with self.lock:
             st = stream_ptr(self.lib)
             nb = min(slots, n)
+            self._kv_gen += 1
             self.lib.cv_llm_batch_begin(self._h, C.c_int32(nb), st)
             owner, outs, limit = [None] * nb, {}, {}
             nxt = 0
@@ -370,6 +375,7 @@ class Qwen2LM:
         chunk = step_chunk or min(self.decode_chunk, 8)
         with self.lock:
             st = stream_ptr(self.lib)
+            self._kv_gen += 1
             self.lib.cv_llm_batch_begin(self._h, C.c_int32(slots), st)
             owner, emitted, limit, first = [None] * slots, {}, {}, {}
             closed = False
@@ -450,6 +456,7 @@ class Qwen2LM:
         if self._bistream_pos + rows.shape[0] + 2 >= self.max_len:
             raise ValueError("inference_bistream: KV capacity %d exhausted" % self.max_len)
         if first:
+            self._kv_gen += 1
             self.lib.cv_llm_prefill(self._h, C.c_void_p(rows.data_ptr()), C.c_int32(rows.shape[0]), stream_ptr(self.lib))
         else:
             self.lib.cv_llm_prefill_append(self._h, C.c_void_p(rows.data_ptr()), C.c_int32(rows.shape[0]), stream_ptr(self.lib))

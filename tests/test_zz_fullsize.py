@@ -140,6 +140,27 @@ def _u10(lib):
     return lc, fc, W.synthetic_utterance(lc, fc, n_prompt_tok=N_PROMPT_TOK, n_prompt_text=N_PROMPT_TEXT, n_text=N_TEXT), N_GEN, gold
 
 
+def test_llm_u10_ras_replay(lib):
+    """The second parity workload of the benchmark (round 4): U10 decoded with repetition-aware sampling from FIXED variates - 250 dependent decisions, ~150
+    distinct ids, ~14 fallback draws - must reproduce the oracle's sampled sequence committed as tests/golden/u10_ras_oracle_tokens.json
+    (tests/golden/make_u10_ras.py; every decision keeps a margin of 1e-3 by construction of the variates).  Hardware only: the file is at the real dimensions."""
+    import json, numpy as np
+    if lib.emulated:
+        pytest.skip("hardware only: 250 sampled tokens at the real CosyVoice2-0.5B dimensions (the emulator runs the sampler's logic in tests/test_llm_ras.py)")
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "u10_ras_oracle_tokens.json")))
+    lc, fc, u, n_gen, _ = _u10(lib)
+    lm = Qwen2LM(W.make_llm(lc), lc, lib=lib, max_len=1024, sampling="ras", decode_chunk=64)
+    lm.set_uniforms(np.asarray(gold["variates"], dtype=np.float32))
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    ratio = n_gen / u["text"].shape[1]
+    got = list(lm.inference(text=u["text"], text_len=t(u["text"].shape[1]), prompt_text=u["prompt_text"], prompt_text_len=t(u["prompt_text"].shape[1]),
+                            prompt_speech_token=u["llm_prompt_speech_token"], prompt_speech_token_len=t(u["llm_prompt_speech_token"].shape[1]),
+                            max_token_text_ratio=ratio, min_token_text_ratio=ratio))
+    div = next((i for i, (a, b) in enumerate(zip(got, gold["tokens"])) if a != b), None)
+    _record(lib, "llm_u10_ras_first_divergence_index", float(n_gen if div is None else div))
+    assert len(got) == len(gold["tokens"]) == n_gen and div is None, (div, got[div], gold["tokens"][div], gold["margin"][div])
+
+
 def test_llm_u10_all_tokens(lib):
     """Greedy ids of the whole benchmark decode (north_star: "speech-token ids bit-exact under greedy decode"), evaluated the way SURVEY.md
     section 8c prescribes: free-running first-divergence index against the oracle's committed tokens, and teacher-forced on the tokens the

@@ -76,8 +76,11 @@ def test_reference_decode_loop_on_forward_one_step(lib, tiny_sd):
     assert other != first_cache
     with pytest.raises(ValueError):
         lm.llm.forward_one_step(lm_input, cache=first_cache)
-    # the device loop still works on the same handle afterwards
+    # the device loop still works on the same handle afterwards - and it takes the KV cache too: the live forward_one_step cache goes stale (only a
+    # replacing forward_one_step sequence used to be noticed; an interleaved inference() silently left the old cache object appending onto a foreign sequence)
     assert list(lm.inference(**_kw(u), max_token_text_ratio=3, min_token_text_ratio=2)) == want
+    with pytest.raises(ValueError):
+        lm.llm.forward_one_step(lm.speech_embedding(torch.tensor([[4]])), cache=other)
 
 
 def test_f0_float64_option_matches_the_reference_mode(lib, tiny):
