@@ -325,7 +325,7 @@ def cv1_workload(args):
     non-causal U-Net estimator, 22.05 kHz HiFT) at its real dimensions on the hand-written kernels, sequenced by the host (cosyvoice_amd/cosyvoice1_hip.py: one
     ctypes call per launch, no graph yet - the number below is the first cut of this row, not a tuned one).  One inference_sft-shaped request (cli/frontend.py
     frontend_sft: text + speaker embedding, no prompts): 25 text ids, the length forced to 500 speech tokens = 10.0 s at 22.05 kHz, greedy on the host like the
-    reference's python sampler, 10 CFM Euler steps, fp32 throughout (the reference's default for this model).  Token check: the first 50 ids against the
+    reference's python sampler, 10 CFM Euler steps, fp32 throughout (the reference's default for this model).  Token check: every id against the
     torch-eager plumbing of the same weights on the HOST cores (cosyvoice1.py, the configs[0] path that the reference goldens pin)."""
     from cosyvoice_amd import cosyvoice1 as C1, cosyvoice1_hip as CK, synthetic as W
     cfg, hcfg = W.cv1()
@@ -372,8 +372,8 @@ def cv1_workload(args):
     torch.cuda.synchronize(); stages["flow_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
     t0 = time.perf_counter(); m.hift.inference(speech_feat=mel); torch.cuda.synchronize(); stages["hift_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
     stages["llm_us_per_token"] = round(1e3 * stages["llm_ms"] / n_gen, 1)
-    # token check against the torch-eager plumbing on the host cores (first 50 ids: eos is masked in both, so they are the first 50 of the forced-length run)
-    n_chk = min(50, n_gen)
+    # token check against the torch-eager plumbing on the host cores (every id of the forced-length run: eos is masked in both)
+    n_chk = min(int(os.environ.get("CV_BENCH_CV1_CHECK", n_gen)), n_gen)          # all 500 since round 4 (~30 s of host time outside the timed region)
     ref = C1.TransformerLM(sd_llm, text_heads=cfg.text_heads, llm_heads=cfg.llm_heads, sampling=greedy)
     t0 = time.perf_counter()
     want = list(ref.inference(max_token_text_ratio=n_chk / n_text, min_token_text_ratio=n_chk / n_text, **lm_kw))

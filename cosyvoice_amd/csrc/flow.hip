@@ -205,6 +205,13 @@ static void flow_finalize(cv_flow* m) {
         m->stages.push_back(st);
     }
     if (const char* e = getenv("CV_FLOW_NTILE")) m->flow_ntile = atoi(e);
+    // dev knobs of the large-M kernel set for A/B runs through bench.py (options of the same names without the prefix)
+    if (const char* e = getenv("CV_FLOW_BIG_ROWS")) m->big_rows = atoi(e);
+    if (const char* e = getenv("CV_FLOW_BIG_PERSIST")) m->big_persist = atoi(e);
+    if (const char* e = getenv("CV_FLOW_BIG_TILE0")) m->big_tile0 = atoi(e);
+    if (const char* e = getenv("CV_FLOW_BIG_TILE1")) m->big_tile1 = atoi(e);
+    if (const char* e = getenv("CV_FLOW_BIG_GLDS")) m->big_glds = atoi(e) != 0;
+    if (const char* e = getenv("CV_FLOW_ATTN2_ROWS")) m->attn2_rows = atoi(e);
     if (const char* e = getenv("CV_FLOW_TAIL")) m->fused_tail = e[0] != '0';        // dev knob for A/B runs (also: option "fused_tail")
     if (const char* e = getenv("CV_FLOW_TAIL_RING")) m->tail_ring = atoi(e) == 16 ? 16 : 8;
     m->down_conv = get_lin(m, "est.down_conv", C, C, 3, true); m->up_conv = get_lin(m, "est.up_conv", C, C, 3, true);

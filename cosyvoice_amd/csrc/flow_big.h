@@ -24,7 +24,7 @@ namespace cv {
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct LnBf16Args { const float* x; int ldx; const float* gamma; const float* beta; float eps; bf16_t* y; int ldy; int M, K; };
 
-__global__ __launch_bounds__(256) void ln_bf16_kernel(LnBf16Args p) {
+static __global__ __launch_bounds__(256) void ln_bf16_kernel(LnBf16Args p) {
     const int tid = threadIdx.x, grp = tid >> 4, sub = tid & 15;
     const int m = blockIdx.x * 16 + grp;
     const float* xr = p.x + (long long)min(m, p.M - 1) * p.ldx;

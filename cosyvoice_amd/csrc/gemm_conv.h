@@ -436,6 +436,53 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
     stamp();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// M = 1 with fp32 weights: y[n] = epi(sum_k x[k] W[n][k]) - the decode step of CosyVoice-300M's TransformerLM (llm/llm.py:162-223: 14 x (qkv4, out, w1, w2) + the
+// decoder, 176 M fp32 parameters = 705 MB per token).  Round 3 ran these on the tiled GEMM above: a 16- or 32-row tile with ONE useful row, 64-128 workgroups
+// per launch, 1.84 ms per token (0.38 TB/s).  Here a 16-lane group owns an output row and reads it in 256-byte steps (16 B per lane, non-temporal: every
+// weight byte is read once per token); the four waves of a workgroup split K between them and combine through LDS in a fixed order; a workgroup = 4 rows, so
+// N = 1024 is already 256 workgroups.  All of a wave's weight loads of an 8-step group are requested before the first FMA (gemv_kernel's latency structure,
+// llm_kernels.h).  The k order differs from the MFMA chain's, like any other summation order: results agree to fp32 rounding.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct GemvF32Args {
+    const float* x; const float* W; long long ldw; const float* bias; const float* res; float* y;
+    int N, K, Kp, act; float act_p, out_scale;
+};
+static __global__ __launch_bounds__(256) void gemv_f32_kernel(GemvF32Args p) {
+    constexpr int U = 8;                                        // 64-float steps in flight per lane group
+    __shared__ float part[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
+    const int row = min((int)blockIdx.x * 4 + grp, p.N - 1);      // clamped: the reductions are wave collectives
+    const int steps = (p.Kp + 63) / 64, s0 = wave * steps / 4, s1 = (wave + 1) * steps / 4;
+    const float* wr = p.W + (long long)row * p.ldw;
+    float acc = 0.f;
+    for (int sb = s0; sb < s1; sb += U) {
+        v4f w[U]; float4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)                             // unconditional loads (clamped step) + select keep the vmcnt bookkeeping exact
+            w[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(wr + min(min(sb + u, s1 - 1) * 64 + sub * 4, p.Kp - 4)));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = min(sb + u, s1 - 1) * 64 + sub * 4;
+            x[u] = *reinterpret_cast<const float4*>(p.x + min(k, p.K - 4));
+            if (sb + u >= s1 || k >= p.K) x[u] = make_float4(0.f, 0.f, 0.f, 0.f);          // beyond the wave's range / beyond K (the weights are zero padded to Kp, x is not)
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { acc += w[u][0] * x[u].x; acc += w[u][1] * x[u].y; acc += w[u][2] * x[u].z; acc += w[u][3] * x[u].w; }
+    }
+    acc = group16_sum(acc);
+    if (sub == 0) part[wave][grp] = acc;
+    __syncthreads();
+    if (wave != 0 || sub != 0) return;
+    const int n = (int)blockIdx.x * 4 + grp;
+    if (n >= p.N) return;
+    float v = ((part[0][grp] + part[1][grp]) + part[2][grp]) + part[3][grp];
+    if (p.bias) v += p.bias[n];
+    v = apply_act(p.act, v, p.act_p);
+    if (p.res) v += p.res[n];
+    p.y[n] = v * p.out_scale;
+}
+
 // host-side dispatch (gemm_conv.hip)
 void launch_gemm_conv(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t stream);
 

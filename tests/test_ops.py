@@ -41,6 +41,28 @@ def test_linear(lib, M, N, K, wdt):
     torch.testing.assert_close(out[0].cpu(), ref.cpu(), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("N,K,act", [(7, 36, "none"), (1030, 1024, "relu"), (200, 4096, "silu"), (64, 96, "none")])
+def test_single_row_gemv_fp32_weights(lib, N, K, act, monkeypatch):
+    """Round 4: one output row over fp32 weights goes to gemv_f32_kernel (the decode step of CosyVoice-300M's LM) instead of a GEMM tile with one useful row -
+    same epilogue contract as the tiled kernel ((act(x W^T + b) + res) * out_scale), K not a multiple of the 64-float step, N not a multiple of a workgroup's
+    4 rows, a row-pitched weight view; and the tiled kernel (CV_GEMV_F32=0) agrees to fp32 rounding."""
+    dev = _dev(lib)
+    A = _rand((1, K), dev, 11)
+    W = _rand((N, K), dev, 12, 0.2)
+    b, res = _rand((N,), dev, 13), _rand((1, N), dev, 14)
+    Wp, Kp = ops.pack_weight(W, torch.float32)
+    ref = {"none": lambda v: v, "relu": F.relu, "silu": F.silu}[act](A @ W.t() + b)
+    ref = (ref + res) * 0.5
+    outs = []
+    for knob in ("1", "0"):
+        monkeypatch.setenv("CV_GEMV_F32", knob)
+        out = ops.gemm_conv(lib, A, Wp, Kp, M=1, N=N, K=K, bias=b, act=act, res=res.reshape(1, 1, N), out_scale=0.5)
+        _sync(lib)
+        outs.append(out[0].cpu())
+        torch.testing.assert_close(outs[-1], ref.cpu(), rtol=3e-5, atol=3e-5)
+    torch.testing.assert_close(outs[0], outs[1], rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize("M,N,K,taps", [(37, 48, 64, 1), (130, 200, 96, 1), (300, 256, 1024, 1), (70, 96, 320, 3), (33, 40, 36, 1)])
 def test_linear_bf16_mfma(lib, M, N, K, taps):
     """a_bf16 = 1: activations (after the fused input activation) are rounded to bf16 round-to-nearest-even and multiplied with
