@@ -159,15 +159,21 @@ __device__ __forceinline__ float group16_max(float v) {
     return v;
 }
 
-// LDS-DMA: 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4, cdna_hip_programming.md section 5): no staging registers, no
-// ds_write pass.  The LDS destination is WAVE-UNIFORM base + lane * 16 (the hardware adds the lane part; `lds_wave_base` must be the same in every lane), the global
-// source is per lane - a swizzled LDS image is obtained by permuting the SOURCE addresses.  Completion is counted by vmcnt; with a DMA in flight hipcc's
-// __syncthreads() carries the vmcnt(0), so "issue the next stage, compute the current one, barrier" needs no explicit wait.  The CPU emulator's hip_runtime.h
-// supplies its own CV_GLDS16 (a 16-byte copy per lane).
+// LDS-DMA: 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4, cdna_hip_programming.md sections 5 and 5.7): no staging registers,
+// no ds_write pass.  The LDS destination is WAVE-UNIFORM base + lane * 16 (M0; `lds_wave_base` must be the same in every lane), the global source is per lane - a
+// swizzled LDS image is obtained by permuting the SOURCE addresses.  Issued through inline asm ON PURPOSE: the compiler's own builtin is counted by its waitcnt
+// pass, which cannot tell the DMA's destination from the LDS buffer being read and puts a vmcnt(0) in front of every fragment read (the DMA then never overlaps
+// the MFMAs; measured round 4).  Hidden in asm the DMA is not counted at all: the kernel waits for it itself - CV_VMCNT0() before the barrier that publishes the
+// stage (a __syncthreads() does NOT wait for it).  M0 is saved and restored inside the statement (guide 5.7).  The CPU emulator's hip_runtime.h supplies its own
+// CV_GLDS16 (a 16-byte copy per lane) and an empty CV_VMCNT0.
 #ifndef CV_GLDS16
-#define CV_GLDS16(gptr, lds_wave_base)                                                                                  \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                             \
-                                     (__attribute__((address_space(3))) void*)(unsigned)(unsigned long long)(lds_wave_base), 16, 0, 0)
+__device__ __forceinline__ void cv_glds16(const void* gsrc, const void* lds_wave_base) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)lds_wave_base);     // low 32 bits of a flat LDS address = the LDS byte offset
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+#define CV_GLDS16(gptr, lds_wave_base) cv_glds16((gptr), (lds_wave_base))
+#define CV_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 
 // Scheduling fence: the machine scheduler moves no instruction across it (no instruction is emitted).  Used where the ORDER of independent global

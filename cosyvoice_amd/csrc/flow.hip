@@ -55,6 +55,7 @@ struct cv_flow {
     DevBuf e_x, e_xe, e_n, e_qkv, e_qu, e_qv, e_pe, e_p, e_bd, e_att, e_ff, e_x2, e_ctx;    // encoder
     DevBuf s_in, s_a, s_b, s_c, s_n, s_qkv, s_att, s_ff, s_skip, s_cat, s_out;                    // estimator
     DevBuf h_qk, h_vt, h_att, h_ff;                                                           // estimator, fused bf16 pipeline (flow_fused.h)
+    DevBuf h_zero;                                                                            // 64 zero bytes (the LDS-DMA source of a convolution's padded rows)
     DevBuf h_xn, h_cur;                                                                       // LayerNorm'd rows / a ResNet block's input as bf16 (flow_big.h)
     // Round 4, bf16 mode: the large-M kernel set of flow_big.h for passes of at least `big_rows` estimator rows (0 = never) - LayerNorm once per row -> bf16,
     // bf16 GEMMs with K streamed through a swizzled LDS ring, the ResNet convolutions on the same tiles.  Bit-identical to the small-tile path, so the threshold is
@@ -91,6 +92,7 @@ struct cv_flow {
     // hipGraph cache of the whole Euler solve, keyed by (T, n_steps, streaming): ~5000 launches per utterance become one replay.
     // A key is captured the second time it is seen (streaming requests change T every chunk and would only pay the instantiation).
     bool use_graph = true;
+    int graph_max_rows = 3000;         // "graph_max_rows": passes of at least this many estimator rows (2 x utterances x T) are not captured (0 = capture everything); CV_FLOW_GRAPH_MAX_ROWS
     int bf16_mfma = 0;                 // 1: Linear / Conv1d products on the bf16 MFMA (activations rounded to bf16 in LDS), 0: fp32-accurate (three-term split for bf16 weights, fp32 MFMA chain otherwise)
     std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
     std::map<std::tuple<int, int, int>, unsigned long long> graph_used; unsigned long long graph_clock = 0;   // last use per key (least-recently-used eviction)
@@ -206,6 +208,7 @@ static void flow_finalize(cv_flow* m) {
     }
     if (const char* e = getenv("CV_FLOW_NTILE")) m->flow_ntile = atoi(e);
     // dev knobs of the large-M kernel set for A/B runs through bench.py (options of the same names without the prefix)
+    if (const char* e = getenv("CV_FLOW_GRAPH_MAX_ROWS")) m->graph_max_rows = atoi(e);
     if (const char* e = getenv("CV_FLOW_BIG_ROWS")) m->big_rows = atoi(e);
     if (const char* e = getenv("CV_FLOW_BIG_PERSIST")) m->big_persist = atoi(e);
     if (const char* e = getenv("CV_FLOW_BIG_TILE0")) m->big_tile0 = atoi(e);
@@ -352,7 +355,8 @@ static void est_reserve(cv_flow* m, int T, int nz = 2) {
     m->s_skip.ensure(R * C * f); m->s_cat.ensure(R * 2 * C * f); m->s_out.ensure(R * c.mel * f);
     {   // bf16 activations of the fused pipeline; V^T is [nz][heads * 64][pitch] and its never-written pad columns must stay finite (0 x P)
         const size_t inner = (size_t)c.est_heads * 64, pitch = (size_t)(T + T / 2 + 63) / 64 * 64;
-        m->h_qk.ensure(R * 2 * inner * 2); m->h_att.ensure(R * inner * 2); m->h_ff.ensure(R * 4 * C * 2); m->h_xn.ensure(R * C * 2); m->h_cur.ensure(R * std::max((size_t)4 * c.mel, 2 * C) * 2);
+        m->h_qk.ensure(R * 2 * inner * 2); m->h_att.ensure(R * inner * 2); m->h_ff.ensure(R * 4 * C * 2); if (!m->h_zero.p) { m->h_zero.ensure(64); CV_HIP(hipMemset(m->h_zero.p, 0, 64)); }
+        m->h_xn.ensure(R * C * 2); m->h_cur.ensure(R * std::max((size_t)4 * c.mel, 2 * C) * 2);
         const size_t before = m->h_vt.bytes;
         m->h_vt.ensure((size_t)nz * inner * pitch * 2);
         if (m->h_vt.bytes != before || nz != m->est_nz) { CV_HIP(hipMemset(m->h_vt.p, 0, m->h_vt.bytes)); m->vt_pitch = (int)(m->h_vt.bytes / ((size_t)nz * inner * 2) / 64 * 64); }
@@ -460,15 +464,19 @@ static void gemm_big_res(const Lin& l, const bf16_t* A, int lda, int M, float* C
     gemm_big_launch<1>(a, tl_big_tile1 ? tl_big_tile1 : 3, s);
 }
 // causal Conv1d / Linear over bf16 rows of nz requests of T rows each (ResNet blocks of a large pass): C = conv(A) + b (+ res), fp32
-static void conv_big(const Lin& l, const bf16_t* A, int T, int nz, int pad_left, float* C, const float* res, hipStream_t s) {
+template <bool GLDS>
+static void conv_big_launch(const FlowGemmArgs& a, int tile, hipStream_t s) {
+    if (tile == 1) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 128, 1, true, GLDS>), dim3(big_grid(a.M, a.N, 128, 128)), dim3(256), 0, s, a);
+    else if (tile == 2) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 64, 1, true, GLDS>), dim3(big_grid(a.M, a.N, 128, 64)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((flow_gemm_big_kernel<64, 64, 1, true, GLDS>), dim3(big_grid(a.M, a.N, 64, 64)), dim3(256), 0, s, a);
+}
+static void conv_big(const Lin& l, const bf16_t* A, int T, int nz, int pad_left, float* C, const float* res, const void* zeros, hipStream_t s) {
     CV_CHECK(l.bf16 && l.K % 64 == 0 && l.N % 4 == 0 && l.Kp == l.K, "conv_big: needs bf16 weights and K % 64 == 0");
     FlowGemmArgs a{};
     a.A = A; a.lda = l.K; a.W = reinterpret_cast<const bf16_t*>(l.w); a.Kp = l.Kp; a.bias = l.b; a.M = nz * T; a.N = l.N; a.K = l.K;
-    a.C = C; a.ldc = l.N; a.res = res; a.n_row = l.N; a.taps = l.taps; a.pad_left = pad_left; a.rows_per_batch = T;
+    a.C = C; a.ldc = l.N; a.res = res; a.n_row = l.N; a.taps = l.taps; a.pad_left = pad_left; a.rows_per_batch = T; a.zeros = zeros;
     const int tile = tl_big_tile1 ? tl_big_tile1 : 3;
-    if (tile == 1) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 128, 1, true>), dim3(big_grid(a.M, a.N, 128, 128)), dim3(256), 0, s, a);
-    else if (tile == 2) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 64, 1, true>), dim3(big_grid(a.M, a.N, 128, 64)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((flow_gemm_big_kernel<64, 64, 1, true>), dim3(big_grid(a.M, a.N, 64, 64)), dim3(256), 0, s, a);
+    if (tl_big_glds) conv_big_launch<true>(a, tile, s); else conv_big_launch<false>(a, tile, s);
 }
 // everything after the attention of block `t` (+ LayerNorm and QKV of `next`) in one launch, 16 rows per workgroup (flow_tail.h)
 static void flow_tail(const TBlockW& t, const TBlockW* next, const bf16_t* att, int inner, float* x, int C, int M, bf16_t* qk, bf16_t* vt, long long vt_batch, int ldt,
@@ -537,11 +545,11 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
             // when they stage them - same values), the convolutions run on 128-row tiles: bit-identical to the five launches below
             bf16_t* cb = m->h_cur.as<bf16_t>() + r0 * din; bf16_t* hb = m->h_xn.as<bf16_t>() + r0 * C;
             hipLaunchKernelGGL(cvt_bf16_kernel, dim3(nblk(R * din / 8)), dim3(256), 0, s, cur, cb, R * din / 8);
-            conv_big(st.res.conv1, cb, T, nz, 2, x, nullptr, s);
+            conv_big(st.res.conv1, cb, T, nz, 2, x, nullptr, m->h_zero.p, s);
             { NormArgs na{x, nullptr, R, C, st.res.ln1.g, st.res.ln1.b, 1e-5f, 0, ACT_MISH, 1.f, nullptr, tm, rpb}; na.y16 = hb; norm_rows(na, s); }
-            conv_big(st.res.conv2, hb, T, nz, 2, x, nullptr, s);
+            conv_big(st.res.conv2, hb, T, nz, 2, x, nullptr, m->h_zero.p, s);
             ln_rows(st.res.ln2, x, xb, R, C, 1e-5f, s, ACT_MISH);
-            conv_big(st.res.res, cb, T, nz, 0, x, xb, s);
+            conv_big(st.res.res, cb, T, nz, 0, x, xb, m->h_zero.p, s);
         } else {
         conv_cl(st.res.conv1, cur, T, T, nz, 2, 1, x, ACT_NONE, 0.f, nullptr, s);
         ln_rows(st.res.ln1, x, xb, R, C, 1e-5f, s, ACT_MISH, 1.f, tm, rpb);
@@ -796,14 +804,18 @@ static void solve_euler(cv_flow* m, float* x /*[nu][T][mel] in/out*/, const floa
         }
     };
     const auto key = std::make_tuple(T, n_steps, (streaming ? 1 : 0) + 2 * nu + (m->cur_klen ? 64 : 0));     // a padded batch bakes the klen pointer into its launches
+    // Graphs pay where the launches are short next to the host's ~4 us per launch (one utterance: 3640 launches of ~10 us).  A shared pass over several
+    // utterances is GPU-bound launch by launch - the host stays ahead - while capturing and instantiating its ~5000 nodes costs tens of milliseconds per new
+    // shape, and offline batches bring a new Tmax with almost every group: passes of at least graph_max_rows estimator rows run eager.
+    const bool graphable = m->use_graph && (m->graph_max_rows <= 0 || 2LL * nu * T < m->graph_max_rows);
     auto it = m->graphs.find(key);
-    if (m->use_graph && it != m->graphs.end() && x == m->f_x.as<float>()) {
+    if (graphable && it != m->graphs.end() && x == m->f_x.as<float>()) {
         m->graph_used[key] = ++m->graph_clock;
         { std::lock_guard<std::recursive_mutex> lk(runtime_lock()); CV_HIP(hipGraphLaunch(it->second, s)); }
         return;
     }
     // buffers may have been re-allocated by *_reserve since a capture: graphs are dropped whenever a workspace grows (see est_reserve)
-    if (m->use_graph && x == m->f_x.as<float>() && ++m->seen[key] == 2) {
+    if (graphable && x == m->f_x.as<float>() && ++m->seen[key] == 2) {
         std::lock_guard<std::recursive_mutex> lk(runtime_lock());
         if (m->graphs.size() >= m->graph_cap) {          // evict the least recently used shape; it may be captured again later (its sighting count restarts)
             auto victim = m->graphs.begin();
@@ -841,6 +853,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "attn_kt") { CV_CHECK(value == 1 || value == 2, "attn_kt must be 1 or 2"); m->attn_kt = value; drop_graphs(m); }
         else if (std::string(name) == "attn_waves") { CV_CHECK(value == 2 || value == 4, "attn_waves must be 2 or 4"); m->attn_waves = value; drop_graphs(m); }
         else if (std::string(name) == "est_streams") { CV_CHECK(value == 1 || value == 2, "est_streams must be 1 or 2"); m->est_streams = value; drop_graphs(m); }
+        else if (std::string(name) == "graph_max_rows") { CV_CHECK(value >= 0, "graph_max_rows must be >= 0"); m->graph_max_rows = value; drop_graphs(m); }
         else if (std::string(name) == "graph_cap") { CV_CHECK(value >= 1 && value <= 256, "graph_cap must be 1 .. 256"); drop_graphs(m); m->graph_cap = (size_t)value; }
         else if (std::string(name) == "fused_tail") { m->fused_tail = value != 0; drop_graphs(m); }
         else if (std::string(name) == "flow_ntile") { CV_CHECK(value >= 0 && value <= 2, "flow_ntile must be 0, 1 or 2"); m->flow_ntile = value; drop_graphs(m); }

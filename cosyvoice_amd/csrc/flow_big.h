@@ -82,9 +82,8 @@ static __global__ __launch_bounds__(256) void ln_bf16_kernel(LnBf16Args p) {
 // workgroup (first form of this kernel, profiles/r4_flow_big_ab.txt) a tile was a latency chain of first-load wait -> 4 stages -> epilogue stores, 26 - 37 us
 // per launch at M = 10 784 whatever the tile.  The grid is what fits the chip at once (host: resident workgroups per CU x 256), not the tile count.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int OMODE, bool CONV = false, bool GLDS = !CONV>
+template <int BM, int BN, int OMODE, bool CONV = false, bool GLDS = false>
 __global__ __launch_bounds__(256) void flow_gemm_big_kernel(FlowGemmArgs p) {
-    static_assert(!(CONV && GLDS), "the zero padding of a convolution is a select on the staged registers");
     constexpr int BK = 64, RP = BK / 2;                       // row pitch in dwords
     constexpr int TM = BM / 32, TN = BN / 32;                 // 16 x 16 MFMA tiles per wave (wave tile = BM/2 x BN/2)
     constexpr int AV = BM * 8 / 256, WV = BN * 8 / 256;       // 16-byte pieces per thread and stage
@@ -250,16 +249,24 @@ __global__ __launch_bounds__(256) void flow_gemm_big_kernel(FlowGemmArgs p) {
     // GLDS: the stage goes from global memory straight into LDS (common.h, CV_GLDS16): piece v of a stage lands at LDS offset 16 v - row v / 8, PHYSICAL slot
     // v % 8 - so the lane fetches the logical slot that belongs there, (v % 8) ^ ((row >> 1) & 7): the swizzle sits on the source address (the same 128-byte line)
     auto stage = [&](int buf) {
-        const int m0 = (l_tile / ntn) * BM, n0 = (l_tile % ntn) * BN, k0 = l_c * BK;
+        const int m0 = (l_tile / ntn) * BM, n0 = (l_tile % ntn) * BN;
+        int tap = 0, kc = l_c;
+        if constexpr (CONV) { tap = l_c / spt; kc = l_c - tap * spt; }
+        const int k0 = kc * BK, dr = tap - p.pad_left;        // uniform
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
-            const int r = pr + 32 * i, ks = k0 + 8 * ((tid & 7) ^ ((r >> 1) & 7));
-            CV_GLDS16(reinterpret_cast<const bf16_t*>(p.A) + (long long)min(m0 + r, p.M - 1) * p.lda + min(ks, p.K - 8), &As0[buf * BM * RP + (i * 256 + wave * 64) * 4]);
+            const int r = pr + 32 * i, ks = min(k0 + 8 * ((tid & 7) ^ ((r >> 1) & 7)), p.K - 8), m = min(m0 + r, p.M - 1);
+            const bf16_t* src = reinterpret_cast<const bf16_t*>(p.A) + (long long)m * p.lda + ks;
+            if constexpr (CONV) {                             // a row before its request's first one: the DMA fetches zeros
+                if (l_c == 0) a_t[i] = m % p.rows_per_batch;
+                src = a_t[i] + dr < 0 ? reinterpret_cast<const bf16_t*>(p.zeros) : src + (long long)dr * p.lda;
+            }
+            CV_GLDS16(src, &As0[buf * BM * RP + (i * 256 + wave * 64) * 4]);
         }
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
-            const int r = pr + 32 * i, ks = k0 + 8 * ((tid & 7) ^ ((r >> 1) & 7));
-            CV_GLDS16(p.W + (long long)min(n0 + r, p.N - 1) * wpitch + min(ks, p.Kp - 8), &Ws0[buf * BN * RP + (i * 256 + wave * 64) * 4]);
+            const int r = pr + 32 * i, ks = min(k0 + 8 * ((tid & 7) ^ ((r >> 1) & 7)), p.Kp - 8);
+            CV_GLDS16(p.W + (long long)min(n0 + r, p.N - 1) * wpitch + (CONV ? tap * p.Kp : 0) + ks, &Ws0[buf * BN * RP + (i * 256 + wave * 64) * 4]);
         }
         if (++l_c == nst) { l_c = 0; ++l_tile; }
     };
@@ -267,21 +274,16 @@ __global__ __launch_bounds__(256) void flow_gemm_big_kernel(FlowGemmArgs p) {
     if (total == 0) return;
     int c = 0, tile = t_begin;                                 // (tile, stage) being multiplied
     if constexpr (GLDS) {
-        // two stages per trip with the buffer indices as compile-time constants: with a runtime index the compiler cannot tell the DMA's destination buffer from
-        // the one being read and puts a vmcnt(0) in front of every fragment read (the DMA would never overlap the MFMAs)
-        auto step = [&](auto BUF, bool more) {
-            constexpr int b = decltype(BUF)::value;
-            if (more) stage(1 - b);                           // buffer 1 - b was last read by the previous stage: every wave left it before the barrier that ended it
-            const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-            compute(b, min(BK, p.K - c * BK) / 32, n0);
-            if (++c == nst) { epilogue(m0, n0); c = 0; ++tile; }
-            __syncthreads();                                  // (a DMA in flight: the barrier carries its vmcnt(0))
-        };
         stage(0);
+        CV_VMCNT0();
         __syncthreads();
-        for (int g = 0; g < total; g += 2) {
-            step(std::integral_constant<int, 0>{}, g + 1 < total);
-            if (g + 1 < total) step(std::integral_constant<int, 1>{}, g + 2 < total);
+        for (int g = 0; g < total; ++g) {
+            if (g + 1 < total) stage((g + 1) & 1);            // buffer (g + 1) & 1 was last read by stage g - 1: every wave left it before the barrier that ended it
+            const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+            compute(g & 1, min(BK, p.K - (CONV ? c % spt : c) * BK) / 32, n0);
+            if (++c == nst) { epilogue(m0, n0); c = 0; ++tile; }
+            CV_VMCNT0();                                      // the DMA of the next stage (requested before this stage's MFMAs) has landed; the barrier publishes it
+            __syncthreads();
         }
         return;
     }

@@ -7,6 +7,8 @@ Criteria are relative L2 errors, calibrated on the MI355X: the errors measured t
 profiles/r2_fullsize_errors.json) and every bound below is <= 3x the recorded value (fp32 mode ~2e-6: summation order only; bf16 mode
 ~6e-3: the operand rounding, equal to the distance of the oracle's own bf16 mirror from its fp32 result).  Greedy ids must match
 wherever the oracle's own top-2 margin is clear."""
+import os
+
 import pytest
 import torch
 
