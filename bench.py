@@ -721,11 +721,12 @@ def mixed64_extra(model, cfgs, lanes):
             yield j, t
     model.llm.inference_queue = spy
     try:
-        run_mixed(model, reqs, mine, slots=16)
+        slots = int(os.environ.get("CV_BENCH_MIXED_SLOTS", 16))       # sequences in flight on the one GPU (A/B knob; up to 32 since round 4)
+        run_mixed(model, reqs, mine, slots=slots)
         torch.cuda.synchronize()
         toks.clear()
         t0 = time.perf_counter()
-        hashes = run_mixed(model, reqs, mine, slots=16)
+        hashes = run_mixed(model, reqs, mine, slots=slots)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
     finally:
@@ -754,7 +755,7 @@ def spawn_ranks(n):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-DEFAULT_EXTRAS = ("streaming_clients", "batched_decode", "batched_decode_16", "mixed64", "cosyvoice3", "cosyvoice300m")
+DEFAULT_EXTRAS = ("streaming_clients", "batched_decode", "batched_decode_16", "batched_decode_32", "mixed64", "cosyvoice3", "cosyvoice300m")
 SOFT_EXTRAS = ("cosyvoice300m",)        # reported as {"error": ...} instead of failing the line (first round on the hardware)
 
 
@@ -781,9 +782,9 @@ def run_extra(name, args):
             # created before: their passes then serialise and the first token2wav under load takes 100 instead of 61 ms (profiles/r3_stream_after_batch.txt).
             model.set_lanes(2)
             res = dict(streaming_clients(model, u, 8, args.stream_requests), lanes=model.n_lanes)
-        elif name in ("batched_decode", "batched_decode_16"):
+        elif name in ("batched_decode", "batched_decode_16", "batched_decode_32"):
             model.set_lanes(args.lanes)
-            res = dict(batched_decode(model, u, 16 if name.endswith("16") else 8, max(1, args.steps // 2)), lanes=args.lanes, flow_batch=args.flow_batch)
+            res = dict(batched_decode(model, u, 32 if name.endswith("32") else 16 if name.endswith("16") else 8, max(1, args.steps // 2)), lanes=args.lanes, flow_batch=args.flow_batch)
         elif name == "mixed64":
             model.set_lanes(args.lanes)
             res = mixed64_extra(model, cfgs, args.lanes)
@@ -827,7 +828,7 @@ def main():
     ap.add_argument("--stream-clients", type=int, default=0, help="extra (not `value`, BASELINE.json configs[2]): this many concurrent streaming U10 requests "
                     "through the serving scheduler; first-chunk p50 / p90 over --stream-requests requests, reported as `streaming_clients`")
     ap.add_argument("--stream-requests", type=int, default=104)
-    ap.add_argument("--flow-batch", type=int, default=4, help="offline batch paths: up to this many finished sequences of equal shape share one flow pass "
+    ap.add_argument("--flow-batch", type=int, default=8, help="offline batch paths: up to this many finished sequences of similar length share one flow pass (8 since round 4: with the large-M kernels 13.6 ms per utterance against 18.6 at 4) "
                     "(CosyVoice2Model.flow_batch; 1 = one flow inference per utterance)")
     ap.add_argument("--lanes", type=int, default=2, help="token2wav lanes (CosyVoice2Model.set_lanes) used by the serving-style extras and the mixed64 workload: "
                     "flow + HiFT of that many requests overlap on the GPU; the headline batch-1 workload has one request in flight and is not affected")

@@ -66,6 +66,7 @@ struct cv_flow {
     // `attn2_rows`: attention with 32 queries per wave (attn_flow_kernel<.., QG = 2>) from that many rows on; 0 = never, the default: at M = 10 784 it measured
     // 54.1 us per launch against 43.0 for QG = 1 (164 registers: one 8-wave workgroup per CU instead of two).
     int big_rows = 5000, attn2_rows = 0, big_tile0 = 0, big_tile1 = 0;
+    int big_lds_epi = 1;               // "big_lds_epi": the large-M GEMMs store their output tile row-wise through LDS (flow_big.h, epilogue_lds); 0 = per-lane stores from the accumulator layout
     int big_glds = 0;                  // "big_glds": the large-M GEMM stages go global -> LDS by DMA (1: global_load_lds_dwordx4, common.h CV_GLDS16) or through registers + ds_write (0).
                                        // Off: as hipcc compiles it the DMA does not overlap the MFMAs (a vmcnt(0) lands in front of the fragment reads, flow_big.h)
     int big_grid_cap = 0;              // "big_grid_cap": test hook - at most this many workgroups per persistent launch (0 = no cap)
@@ -214,6 +215,7 @@ static void flow_finalize(cv_flow* m) {
     if (const char* e = getenv("CV_FLOW_BIG_TILE0")) m->big_tile0 = atoi(e);
     if (const char* e = getenv("CV_FLOW_BIG_TILE1")) m->big_tile1 = atoi(e);
     if (const char* e = getenv("CV_FLOW_BIG_GLDS")) m->big_glds = atoi(e) != 0;
+    if (const char* e = getenv("CV_FLOW_BIG_LDS_EPI")) m->big_lds_epi = atoi(e) != 0;
     if (const char* e = getenv("CV_FLOW_ATTN2_ROWS")) m->attn2_rows = atoi(e);
     if (const char* e = getenv("CV_FLOW_TAIL")) m->fused_tail = e[0] != '0';        // dev knob for A/B runs (also: option "fused_tail")
     if (const char* e = getenv("CV_FLOW_TAIL_RING")) m->tail_ring = atoi(e) == 16 ? 16 : 8;
@@ -226,14 +228,14 @@ static void flow_finalize(cv_flow* m) {
 // precision of the Linear / Conv1d products issued by the current entry point (set from the handle's option for the duration of a call)
 static thread_local int tl_bf16_mfma = 0;
 static thread_local int tl_flow_tile = 0, tl_attn_waves = 4, tl_attn_kt = 2, tl_attn_ks = 1, tl_flow_ntile = 0;     // tuning knobs of the fused pipeline, per call like the precision
-static thread_local int tl_big_tile0 = 0, tl_big_tile1 = 0, tl_big_persist = -1, tl_big_grid_cap = 0, tl_big_glds = 0;
+static thread_local int tl_big_tile0 = 0, tl_big_tile1 = 0, tl_big_persist = -1, tl_big_grid_cap = 0, tl_big_glds = 0, tl_big_lds_epi = 1;
 struct PrecisionScope {
-    int prev, pt, pw, pk, ps, pn, pb0, pb1, pbp, pbc, pbg;
-    explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves), pk(tl_attn_kt), ps(tl_attn_ks), pn(tl_flow_ntile), pb0(tl_big_tile0), pb1(tl_big_tile1), pbp(tl_big_persist), pbc(tl_big_grid_cap), pbg(tl_big_glds) {
+    int prev, pt, pw, pk, ps, pn, pb0, pb1, pbp, pbc, pbg, pbe;
+    explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves), pk(tl_attn_kt), ps(tl_attn_ks), pn(tl_flow_ntile), pb0(tl_big_tile0), pb1(tl_big_tile1), pbp(tl_big_persist), pbc(tl_big_grid_cap), pbg(tl_big_glds), pbe(tl_big_lds_epi) {
         tl_bf16_mfma = m->bf16_mfma; tl_flow_tile = m->flow_tile; tl_attn_waves = m->attn_waves; tl_attn_kt = m->attn_kt; tl_attn_ks = m->attn_ks; tl_flow_ntile = m->flow_ntile;
-        tl_big_tile0 = m->big_tile0; tl_big_tile1 = m->big_tile1; tl_big_persist = m->big_persist; tl_big_grid_cap = m->big_grid_cap; tl_big_glds = m->big_glds;
+        tl_big_tile0 = m->big_tile0; tl_big_tile1 = m->big_tile1; tl_big_persist = m->big_persist; tl_big_grid_cap = m->big_grid_cap; tl_big_glds = m->big_glds; tl_big_lds_epi = m->big_lds_epi;
     }
-    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; tl_attn_ks = ps; tl_flow_ntile = pn; tl_big_tile0 = pb0; tl_big_tile1 = pb1; tl_big_persist = pbp; tl_big_grid_cap = pbc; tl_big_glds = pbg; }
+    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; tl_attn_ks = ps; tl_flow_ntile = pn; tl_big_tile0 = pb0; tl_big_tile1 = pb1; tl_big_persist = pbp; tl_big_grid_cap = pbc; tl_big_glds = pbg; tl_big_lds_epi = pbe; }
 };
 
 // ---- generic conv/linear on channel-last activations -----------------------------------------------------------------
@@ -453,6 +455,7 @@ static void gemm_big_bf16(const Lin& l, const bf16_t* A, int M, int act, bf16_t*
     FlowGemmArgs a{};
     a.A = A; a.lda = l.K; a.W = reinterpret_cast<const bf16_t*>(l.w); a.Kp = l.Kp; a.bias = l.b; a.M = M; a.N = l.N; a.K = l.K; a.act = act;
     a.out = out; a.ldo = ldo; a.n_row = n_row; a.outT = outT; a.t_batch = t_batch; a.ldt = ldt; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
+    a.lds_epilogue = tl_big_lds_epi;
     gemm_big_launch<0>(a, tl_big_tile0 ? tl_big_tile0 : 3, s);
 }
 // C = A_bf16 W^T + b (+ res), fp32
@@ -460,7 +463,7 @@ static void gemm_big_res(const Lin& l, const bf16_t* A, int lda, int M, float* C
     CV_CHECK(l.bf16 && l.K % 32 == 0 && l.taps == 1 && l.N % 4 == 0 && lda % 8 == 0, "gemm_big_res: needs bf16 weights, K % 32 == 0");
     FlowGemmArgs a{};
     a.A = A; a.lda = lda; a.W = reinterpret_cast<const bf16_t*>(l.w); a.Kp = l.Kp; a.bias = l.b; a.M = M; a.N = l.N; a.K = l.K;
-    a.C = C; a.ldc = l.N; a.res = res; a.n_row = l.N;
+    a.C = C; a.ldc = l.N; a.res = res; a.n_row = l.N; a.lds_epilogue = tl_big_lds_epi;
     gemm_big_launch<1>(a, tl_big_tile1 ? tl_big_tile1 : 3, s);
 }
 // causal Conv1d / Linear over bf16 rows of nz requests of T rows each (ResNet blocks of a large pass): C = conv(A) + b (+ res), fp32
@@ -474,7 +477,7 @@ static void conv_big(const Lin& l, const bf16_t* A, int T, int nz, int pad_left,
     CV_CHECK(l.bf16 && l.K % 64 == 0 && l.N % 4 == 0 && l.Kp == l.K, "conv_big: needs bf16 weights and K % 64 == 0");
     FlowGemmArgs a{};
     a.A = A; a.lda = l.K; a.W = reinterpret_cast<const bf16_t*>(l.w); a.Kp = l.Kp; a.bias = l.b; a.M = nz * T; a.N = l.N; a.K = l.K;
-    a.C = C; a.ldc = l.N; a.res = res; a.n_row = l.N; a.taps = l.taps; a.pad_left = pad_left; a.rows_per_batch = T; a.zeros = zeros;
+    a.C = C; a.ldc = l.N; a.res = res; a.n_row = l.N; a.taps = l.taps; a.pad_left = pad_left; a.rows_per_batch = T; a.zeros = zeros; a.lds_epilogue = tl_big_lds_epi;
     const int tile = tl_big_tile1 ? tl_big_tile1 : 3;
     if (tl_big_glds) conv_big_launch<true>(a, tile, s); else conv_big_launch<false>(a, tile, s);
 }
@@ -862,6 +865,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "attn2_rows") { CV_CHECK(value >= 0, "attn2_rows must be >= 0"); m->attn2_rows = value; drop_graphs(m); }
         else if (std::string(name) == "big_tile0") { CV_CHECK(value >= 0 && value <= 3, "big_tile0 must be 0..3"); m->big_tile0 = value; drop_graphs(m); }
         else if (std::string(name) == "big_persist") { CV_CHECK(value >= -1 && value <= 8, "big_persist must be -1..8"); m->big_persist = value; drop_graphs(m); }
+        else if (std::string(name) == "big_lds_epi") { m->big_lds_epi = value != 0; drop_graphs(m); }
         else if (std::string(name) == "big_glds") { m->big_glds = value != 0; drop_graphs(m); }
         else if (std::string(name) == "big_grid_cap") { CV_CHECK(value >= 0, "big_grid_cap must be >= 0"); m->big_grid_cap = value; drop_graphs(m); }
         else if (std::string(name) == "big_tile1") { CV_CHECK(value >= 0 && value <= 3, "big_tile1 must be 0..3"); m->big_tile1 = value; drop_graphs(m); }

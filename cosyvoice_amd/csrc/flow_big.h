@@ -271,6 +271,81 @@ __global__ __launch_bounds__(256) void flow_gemm_big_kernel(FlowGemmArgs p) {
         if (++l_c == nst) { l_c = 0; ++l_tile; }
     };
 
+    // ---- the same epilogues with the tile staged through LDS (one tile per workgroup: the ring is free after the last stage) and stored ROW-WISE: 16 bytes per
+    // lane, a tile row's 128 / 256 bytes contiguous.  Round-4 measurement (profiles/r4_flow_big_ab.txt): these launches take the time of their OUTPUT - 30 us
+    // for the 33 / 22 MB of the bf16-out GEMMs, 15 us for the 11 MB of the residual ones whatever their K, tile or staging - because the accumulator layout
+    // hands a lane 4 columns of one row: 8-byte stores to 16 rows per instruction, 32-byte runs (store-issue bound, guide T21).  Values unchanged.
+    constexpr int CP = OMODE == 1 ? BN + 4 : BN / 2 + 4;       // dwords per staged row: fp32, or packed bf16 pairs (+4: rows stay 16-byte aligned)
+    constexpr bool LDS_EPI = BM * CP <= 2 * (BM + BN) * RP;    // the staged tile fits the ring
+    auto epilogue_lds = [&](int m0, int n0) {
+        unsigned* Cs = Ls;
+        // which 16-column MFMA tiles of this wave are row-major (the V^T section keeps its direct stores)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const bool trj = OMODE == 0 && n0 + wn * (BN / 2) + j * 16 >= p.n_row;
+            if (trj) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int rl = wm * (BM / 2) + i * 16 + (lane & 15), cl = wn * (BN / 2) + j * 16 + (lane >> 4) * 4, n = n0 + cl;
+                float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                if (p.bias && n < p.N) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                if constexpr (OMODE == 1) *reinterpret_cast<float4*>(&Cs[rl * CP + cl]) = v;
+                else { v = apply_act4(p.act, v, 0.f); *reinterpret_cast<uint2*>(&Cs[rl * CP + cl / 2]) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
+            }
+        }
+        __syncthreads();
+        if constexpr (OMODE == 1) {
+            constexpr int CH = BN / 4;                        // 16-byte chunks (4 floats) per row
+#pragma unroll
+            for (int q = tid; q < BM * CH; q += 256) {
+                const int rl = q / CH, cl = (q % CH) * 4, m = m0 + rl, n = n0 + cl;
+                if (m >= p.M || n >= p.N) continue;
+                float4 v = *reinterpret_cast<const float4*>(&Cs[rl * CP + cl]);
+                const long long idx = (long long)m * p.ldc + n;
+                if (p.res) { const float4 r = *reinterpret_cast<const float4*>(p.res + idx); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+                if constexpr (CONV) { v.x += 0.f; v.y += 0.f; v.z += 0.f; v.w += 0.f; }
+                *reinterpret_cast<float4*>(p.C + idx) = v;
+            }
+        } else {
+            constexpr int CH = BN / 8;                        // 16-byte chunks (8 bf16) per row
+            const int n_lim = min(p.N, p.n_row);              // row-major columns end here (multiple of 16)
+#pragma unroll
+            for (int q = tid; q < BM * CH; q += 256) {
+                const int rl = q / CH, cl = (q % CH) * 8, m = m0 + rl, n = n0 + cl;
+                if (m >= p.M || n >= n_lim) continue;
+                *reinterpret_cast<uint4*>(p.out + (long long)m * p.ldo + n) = *reinterpret_cast<const uint4*>(&Cs[rl * CP + cl / 2]);
+            }
+            // V^T section: direct stores, as in epilogue()
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (!(n0 + wn * (BN / 2) + j * 16 >= p.n_row)) continue;
+                const int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+                const float bn = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4;
+                    const unsigned lo = pack_bf16x2(acc[i][j][0] + bn, acc[i][j][1] + bn), hi = pack_bf16x2(acc[i][j][2] + bn, acc[i][j][3] + bn);
+                    if (m >= p.M || n >= p.N) continue;
+                    const int b = m / p.rows_per_batch, t = m - b * p.rows_per_batch;
+                    bf16_t* row = p.outT + (long long)b * p.t_batch + (long long)(n - p.n_row) * p.ldt;
+                    if (m + 3 < p.M && t + 3 < p.rows_per_batch && (t & 3) == 0) { *reinterpret_cast<uint2*>(row + vt_col(t)) = make_uint2(lo, hi); continue; }
+                    if (m + 3 < p.M && t + 3 < p.rows_per_batch && (t & 1) == 0) {
+                        *reinterpret_cast<unsigned*>(row + vt_col(t)) = lo; *reinterpret_cast<unsigned*>(row + vt_col(t + 2)) = hi; continue;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int mr = m + r;
+                        if (mr >= p.M) continue;
+                        const int br = mr / p.rows_per_batch, tr_ = mr - br * p.rows_per_batch;
+                        const unsigned u = r < 2 ? lo : hi;
+                        p.outT[(long long)br * p.t_batch + (long long)(n - p.n_row) * p.ldt + vt_col(tr_)] = (bf16_t)((r & 1) ? (u >> 16) : (u & 0xffffu));
+                    }
+                }
+            }
+        }
+    };
+    const bool lds_epi = LDS_EPI && t_count == 1 && p.lds_epilogue;     // (uniform; persistent runs keep the next tile's stages in the ring)
+
     if (total == 0) return;
     int c = 0, tile = t_begin;                                 // (tile, stage) being multiplied
     if constexpr (GLDS) {
@@ -281,10 +356,11 @@ __global__ __launch_bounds__(256) void flow_gemm_big_kernel(FlowGemmArgs p) {
             if (g + 1 < total) stage((g + 1) & 1);            // buffer (g + 1) & 1 was last read by stage g - 1: every wave left it before the barrier that ended it
             const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
             compute(g & 1, min(BK, p.K - (CONV ? c % spt : c) * BK) / 32, n0);
-            if (++c == nst) { epilogue(m0, n0); c = 0; ++tile; }
+            if (++c == nst) { if (!lds_epi) epilogue(m0, n0); c = 0; ++tile; }
             CV_VMCNT0();                                      // the DMA of the next stage (requested before this stage's MFMAs) has landed; the barrier publishes it
             __syncthreads();
         }
+        if (lds_epi) epilogue_lds((t_begin / ntn) * BM, (t_begin % ntn) * BN);
         return;
     }
     load();
@@ -298,9 +374,10 @@ __global__ __launch_bounds__(256) void flow_gemm_big_kernel(FlowGemmArgs p) {
         }
         const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
         compute(g & 1, min(BK, p.K - (CONV ? c % spt : c) * BK) / 32, n0);
-        if (++c == nst) { epilogue(m0, n0); c = 0; ++tile; }   // stores only: the next tile's first stages are already parked / in flight
+        if (++c == nst) { if (!lds_epi) epilogue(m0, n0); c = 0; ++tile; }   // stores only: the next tile's first stages are already parked / in flight
         __syncthreads();
     }
+    if (lds_epi) epilogue_lds((t_begin / ntn) * BM, (t_begin % ntn) * BN);
 }
 
 }  // namespace cv

@@ -26,6 +26,7 @@ struct FlowGemmArgs {
     bf16_t* outT; long long t_batch; int ldt; int rows_per_batch;   // columns [n_row, N) -> outT[m / rpb][n - n_row][perm(m % rpb)]
     float* C; int ldc; const float* res;          // OMODE 1: C[m][n] = acc + bias (+ res[m][n]), fp32
     long long* dbg;                               // dev tool (tools/ubench/flow_gemm_probe.hip): clock64() of thread 0 at the phase boundaries, 8 slots per workgroup; null in production
+    int lds_epilogue;                             // flow_gemm_big_kernel: 1 = the output tile goes through LDS and is stored row-wise, 16 bytes per lane (one tile per workgroup only)
     const void* zeros;                            // flow_gemm_big_kernel<.., CONV, GLDS>: 16 readable zero bytes (what the DMA of a padded row fetches)
     int taps, pad_left;                           // flow_gemm_big_kernel<.., CONV>: causal Conv1d over channel-last rows, W rows [taps][Kp]; tap j of output row m reads input row
                                                   // m + j - pad_left of the SAME request (rows_per_batch rows each), zero before the request's first row

@@ -483,7 +483,7 @@ static void llm_decode(cv_llm* m, int n_steps, const cv_sampling* sp, int32_t* o
 // ---------------------------------------------------------------------------------------------------------------------------------
 static void batch_begin(cv_llm* m, int nb, hipStream_t s) {
     CV_CHECK(m->finalized, "llm: call cv_llm_finalize first");
-    CV_CHECK(nb >= 1 && nb <= MAX_NB, "cv_llm_batch_begin: batch size must be 1..16");
+    CV_CHECK(nb >= 1 && nb <= MAX_NB, "cv_llm_batch_begin: batch size must be 1..32");
     const auto& c = m->cfg; auto& b = m->bt;
     std::lock_guard<std::recursive_mutex> lk(runtime_lock());
     CV_HIP(hipStreamSynchronize(s));
@@ -565,12 +565,20 @@ static void skinny(const SkinnyArgs& a, int rt, hipStream_t s, const bf16_t* wp 
         SkinnyArgs b = a; b.W = wp;
         const dim3 grid(((row_tiles + rt - 1) / rt) * a.ksplit);
         const bool deep = (tiles + 3) / 4 > 5;
+        if (a.nb > 16) {                                       // 17 .. 32 sequences: two MFMA column tiles per weight fragment (skinny_pk2_kernel)
+            if (rt == 1) hipLaunchKernelGGL((skinny_pk2_kernel<1, 7>), grid, dim3(256), 0, s, b);
+            else if (rt == 4) { CV_CHECK(deep || tiles <= 28, "skinny: four row tiles per workgroup are for K ranges of up to 28 tiles"); hipLaunchKernelGGL((skinny_pk2_kernel<4, 7>), grid, dim3(256), 0, s, b); }
+            else if (deep) hipLaunchKernelGGL((skinny_pk2_kernel<2, 7>), grid, dim3(256), 0, s, b);
+            else hipLaunchKernelGGL((skinny_pk2_kernel<2, 5>), grid, dim3(256), 0, s, b);
+            return;
+        }
         if (rt == 1) hipLaunchKernelGGL((skinny_pk_kernel<1, 7>), grid, dim3(256), 0, s, b);
         else if (rt == 4) { CV_CHECK(deep || tiles <= 28, "skinny: four row tiles per workgroup are for K ranges of up to 28 tiles"); hipLaunchKernelGGL((skinny_pk_kernel<4, 7>), grid, dim3(256), 0, s, b); }
         else if (deep) hipLaunchKernelGGL((skinny_pk_kernel<2, 7>), grid, dim3(256), 0, s, b);
         else hipLaunchKernelGGL((skinny_pk_kernel<2, 5>), grid, dim3(256), 0, s, b);
         return;
     }
+    CV_CHECK(a.nb <= 16, "skinny: more than 16 sequences per step need the fragment-ordered weight copies (K ranges of 4 .. 28 tiles per workgroup)");
     CV_CHECK(a.K % (32 * a.ksplit) == 0 && tiles >= 1 && (tiles + 3) / 4 <= 7 && (a.mode == 0 || a.N % 4 == 0), "skinny: K range must be a multiple of 32 and at most 28 tiles per workgroup");
     CV_CHECK(!(a.gamma && a.ksplit != 1) && (a.mode == 2) == (a.ksplit > 1), "skinny: split-K workgroups leave raw partials (mode 2), the fused norm needs the whole row");
     const dim3 grid(((row_tiles + rt - 1) / rt) * a.ksplit);
@@ -632,6 +640,7 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
     float* h = b.h.as<float>(); float* qkv = b.qkv.as<float>(); float* act = b.act.as<float>(); float* logits = b.logits.as<float>();
     float* att = b.attn.as<float>(); float* dpart = b.dpart.as<float>();
     if (m->batch_fp8) {                                            // opt-in fp8 weights + activations (llm_batch_kernels.h, skinny_fp8_kernel)
+        CV_CHECK(nb <= 16, "llm: the fp8 batched decode takes at most 16 sequences per step");
         CV_CHECK(m->have_fp8, "llm: option batch_fp8 needs the '<name>.f8' / '<name>.f8s' tensors (Qwen2LM(..., batch_fp8=True))");
         const int k8 = down_ksplit_f8(c.inter);
         skinny_f8(SkinnyF8Args{m->head_f8.w, m->head_f8.s, m->head_b, h, H, logits, V, (int)V, c.hidden, m->norm, c.rms_eps, nullptr, 0, 0, nb, 1}, 2, s);
@@ -661,13 +670,14 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
         hipLaunchKernelGGL(advance_pos_batch_kernel, dim3(1), dim3(64), 0, s, st, nb);
         return;
     }
-    const int ks = down_ksplit(c.inter);
+    int ks = down_ksplit(c.inter);
+    if (nb > 16) while (ks > 1 && c.inter / 32 / ks < 4) ks >>= 1;     // more than 16 sequences run on the fragment-ordered weights only: K ranges of >= 4 tiles (small test models)
     // CV_DOWN_DEEP=1: the down projection as ONE launch of 56 sixteen-wave workgroups over the whole K (skinny_deep_kernel) instead of 8 K ranges across
     // 448 workgroups + sum_partials_kernel.  Measured on MI355X (profiles/r3_batch_decode_ab.txt): 1086 vs 975 us per 8-sequence step - the weight
     // stream comes from HBM at ~25 GB/s per CU, so 56 CUs cannot pull 8.7 MB in the time 448 workgroups on 256 CUs do; the removed launch (4.8 us) does
     // not pay for that.  Kept, tested, off.
     const bool deep_knob = [] { const char* e = getenv("CV_DOWN_DEEP"); return e && e[0] == '1'; }();       // read when a step is enqueued / captured
-    const bool deep_down = deep_knob && (c.inter / 32 + 15) / 16 <= 10 && c.hidden % 4 == 0;
+    const bool deep_down = deep_knob && nb <= 16 && (c.inter / 32 + 15) / 16 <= 10 && c.hidden % 4 == 0;
     // 2 row tiles per workgroup for the two wide GEMMs (gate/up: 304 workgroups, head: 206); 3 (203 / 137 workgroups, at most 3 tiles per CU instead
     // of 4 on 48 CUs) measured the same step time (profiles/r2_batch_decode_ab.txt): the launch is not bound by the busiest CU's MFMA share
     const int wide_rt = 2;
@@ -889,7 +899,7 @@ int cv_llm_batch_prefill_many(cv_llm* m, int32_t n, const int32_t* slots, const 
 int cv_skinny_fp8(const void* w8, const float* wscale, const float* bias, const float* x, int64_t ldx, float* y, int64_t ldy, int32_t N, int32_t K,
                   const float* gamma, float eps, const float* res, int64_t ldres, int32_t mode, int32_t nb, int32_t ksplit, int32_t rt, void* stream) {
     return guarded([&] {
-        CV_CHECK(w8 && wscale && x && y && nb >= 1 && nb <= MAX_NB && (rt == 1 || rt == 2), "cv_skinny_fp8: bad arguments");
+        CV_CHECK(w8 && wscale && x && y && nb >= 1 && nb <= 16 && (rt == 1 || rt == 2), "cv_skinny_fp8: bad arguments");
         skinny_f8(SkinnyF8Args{reinterpret_cast<const unsigned char*>(w8), wscale, bias, x, ldx, y, ldy, N, K, gamma, eps, res, ldres, mode, nb, ksplit}, rt, as_stream(stream));
     });
 }

@@ -25,7 +25,7 @@
 
 namespace cv {
 
-constexpr int MAX_NB = 16;
+constexpr int MAX_NB = 32;        // lock-step slots: 16 per MFMA column tile, two column tiles per weight fragment (skinny_pk2_kernel)
 
 struct SkinnyArgs {
     const bf16_t* W; const float* bias;
@@ -367,6 +367,142 @@ __global__ __launch_bounds__(NW * 64) CV_WAVES_PER_EU(1, 2) void skinny_pk_kerne
             }
     }
     stamp();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// skinny_pk_kernel for 17 .. 32 sequences (round 4: 32 lock-step slots).  The MFMA takes 16 sequences as its B columns; the weight fragments a wave holds in
+// registers are the expensive operand (streamed from HBM once per step), so a second COLUMN TILE reuses them: sequences 16 .. 31 are requested when the first
+// sixteen have been parked in LDS (the same registers; their loads queue behind the weight stream and land about when it does), multiplied against the same
+// w[][] and combined / stored by a second pass of the epilogue.  Per sequence the products, their order and the cross-wave order are those of
+// skinny_pk_kernel: a sequence's result does not depend on its slot or on how many slots are in use (tests/test_zz_llm_batch.py).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int RT, int KTW, int NW = 4>
+__global__ __launch_bounds__(NW * 64) CV_WAVES_PER_EU(1, 2) void skinny_pk2_kernel(SkinnyArgs p) {          // p.W = the fragment-ordered copy
+    static_assert(RT >= 1 && RT <= 4 && RT <= NW && KTW <= 8, "one row tile per combining wave; a wave's k range is at most 256 columns (one 16-byte piece per lane)");
+    constexpr int XP = KTW * 32 + 4;
+    __shared__ __attribute__((aligned(16))) float red[NW * RT * 256];
+    __shared__ float ssq[NW][16];
+    __shared__ __attribute__((aligned(16))) float xs[NW][16 * XP];
+    __shared__ __attribute__((aligned(16))) float gs[NW][KTW * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int ks = blockIdx.x % p.ksplit, rg = blockIdx.x / p.ksplit;
+    const int tilesK = p.K / 32, tiles = tilesK / p.ksplit;
+    const int t0 = wave * tiles / NW, t1 = (wave + 1) * tiles / NW, nt = t1 - t0;       // nt >= 1 (host check)
+    const int kt0 = ks * tiles + t0;
+    const int n_base = rg * RT * 16, row_tiles = (p.N + 15) / 16;
+
+    const int kx = kt0 * 32 + min(4 * lane, nt * 32 - 4);
+    float4 xr0, xr1, xr2, xr3, xr4, xr5, xr6, xr7, xr8, xr9, xr10, xr11, xr12, xr13, xr14, xr15;
+#define CV_XROW(b, base) xr##b = *reinterpret_cast<const float4*>(p.x + (long long)min((base) + b, p.nb - 1) * p.ldx + kx);   /* rows >= nb repeat the last sequence (never stored) */
+#define CV_XROWS(base) CV_XROW(0, base) CV_XROW(1, base) CV_XROW(2, base) CV_XROW(3, base) CV_XROW(4, base) CV_XROW(5, base) CV_XROW(6, base) CV_XROW(7, base) \
+                       CV_XROW(8, base) CV_XROW(9, base) CV_XROW(10, base) CV_XROW(11, base) CV_XROW(12, base) CV_XROW(13, base) CV_XROW(14, base) CV_XROW(15, base)
+    CV_XROWS(0)
+    const float4 gr = *reinterpret_cast<const float4*>((p.gamma ? p.gamma : p.x) + kx);
+    order_memory();                                                                   // keep these requests AHEAD of the weight stream
+    u32x4 w[RT][KTW];
+    const bf16_t* wr[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) wr[rt] = p.W + (((long long)min(rg * RT + rt, row_tiles - 1) * tilesK + kt0) * 64 + lane) * 8;
+#pragma unroll
+    for (int t = 0; t < KTW; ++t) {
+        const bool ok = t < nt;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr[rt] + (ok ? t : 0) * 512));
+            if (!ok) v = (u32x4){0u, 0u, 0u, 0u};
+            w[rt][t] = v;
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        if (ct * 16 >= p.nb) break;                                                   // (uniform)
+        // ---- stage this column tile's activations (the weights stay in flight / in registers)
+        if (4 * lane < nt * 32) {
+#define CV_XST(b) *reinterpret_cast<float4*>(&xs[wave][b * XP + 4 * lane]) = xr##b;
+            CV_XST(0) CV_XST(1) CV_XST(2) CV_XST(3) CV_XST(4) CV_XST(5) CV_XST(6) CV_XST(7) CV_XST(8) CV_XST(9) CV_XST(10) CV_XST(11) CV_XST(12) CV_XST(13) CV_XST(14) CV_XST(15)
+#undef CV_XST
+            if (ct == 0) *reinterpret_cast<float4*>(&gs[wave][4 * lane]) = gr;
+        }
+        wave_lds_sync();
+        if (ct == 0 && p.nb > 16) { CV_XROWS(16) }                                    // the second column tile: requested behind the weight stream, lands about when it does
+
+        float ss = 0.f;
+        v4f acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < KTW; ++t) {
+            if (t < nt) {                                                   // wave-uniform
+                float4 a4 = *reinterpret_cast<const float4*>(&xs[wave][c * XP + t * 32 + g * 8]);
+                float4 b4 = *reinterpret_cast<const float4*>(&xs[wave][c * XP + t * 32 + g * 8 + 4]);
+                if (p.gamma) {
+                    const float4 ga = *reinterpret_cast<const float4*>(&gs[wave][t * 32 + g * 8]), gb = *reinterpret_cast<const float4*>(&gs[wave][t * 32 + g * 8 + 4]);
+                    ss += a4.x * a4.x + a4.y * a4.y + a4.z * a4.z + a4.w * a4.w + b4.x * b4.x + b4.y * b4.y + b4.z * b4.z + b4.w * b4.w;
+                    a4.x *= ga.x; a4.y *= ga.y; a4.z *= ga.z; a4.w *= ga.w;
+                    b4.x *= gb.x; b4.y *= gb.y; b4.z *= gb.z; b4.w *= gb.w;
+                }
+                u32x4 h1, h2, h3;
+                split3_bf16(a4, b4, h1, h2, h3);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {                           // smallest term first (as skinny_mfma_kernel)
+                    const v8bf wf = __builtin_bit_cast(v8bf, w[rt][t]);
+                    v4f a = acc[rt];
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(v8bf, h3), a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(v8bf, h2), a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(v8bf, h1), a, 0, 0, 0);
+                    acc[rt] = a;
+                }
+            }
+        }
+        if (p.gamma) {
+            ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);            // over the 4 k-slot groups of the wave
+            if (g == 0) ssq[wave][c] = ss;
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<float4*>(&red[((wave * RT + rt) * 64 + lane) * 4]) = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
+        __syncthreads();
+        if (wave < RT) {
+            const int rt = wave, seq = ct * 16 + c;
+            float4 v = *reinterpret_cast<const float4*>(&red[(rt * 64 + lane) * 4]);
+#pragma unroll
+            for (int ww = 1; ww < NW; ++ww) {
+                const float4 o = *reinterpret_cast<const float4*>(&red[((ww * RT + rt) * 64 + lane) * 4]);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            if (p.gamma) {
+                float tot = (ssq[0][c] + ssq[1][c]) + (ssq[2][c] + ssq[3][c]);
+                if constexpr (NW == 8) tot += (ssq[4][c] + ssq[5][c]) + (ssq[6][c] + ssq[7][c]);
+                const float rstd = rsqrtf(tot / (float)p.K + p.eps);
+                v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
+            }
+            const int n = n_base + rt * 16 + g * 4;
+            if (seq < p.nb && n < p.N) {
+                if (p.mode == 1) {
+                    const float2 o = make_float2((v.x / (1.f + expf(-v.x))) * v.y, (v.z / (1.f + expf(-v.z))) * v.w);
+                    *reinterpret_cast<float2*>(p.y + (long long)seq * p.ldy + (n >> 1)) = o;
+                } else if (p.mode == 2) {
+                    *reinterpret_cast<float4*>(p.y + ((long long)ks * p.nb + seq) * p.ldy + n) = v;
+                } else if ((p.N & 3) == 0) {
+                    if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+                    if (p.res) { const float4 r4 = *reinterpret_cast<const float4*>(p.res + (long long)seq * p.ldres + n); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+                    *reinterpret_cast<float4*>(p.y + (long long)seq * p.ldy + n) = v;
+                } else {
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (n + i < p.N) {
+                            float o = e[i];
+                            if (p.bias) o += p.bias[n + i];
+                            if (p.res) o += p.res[(long long)seq * p.ldres + n + i];
+                            p.y[(long long)seq * p.ldy + n + i] = o;
+                        }
+                }
+            }
+        }
+        __syncthreads();                                                              // red / ssq / xs are reused by the second column tile
+    }
+#undef CV_XROWS
+#undef CV_XROW
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------

@@ -255,7 +255,7 @@ class Qwen2LM:
         `max_token_text_ratio`.  Returns one token list per request - the
         same tokens `inference()` yields for that request alone (the per-sequence arithmetic is identical)."""
         nb = len(requests)
-        assert 1 <= nb <= 16, "1..16 requests per batch"
+        assert 1 <= nb <= (16 if self.batch_fp8 else 32), "1..32 requests per batch (16 on the fp8 path)"
         with self.lock:
             st = stream_ptr(self.lib)
             self._kv_gen += 1
@@ -298,7 +298,7 @@ class Qwen2LM:
         """Continuous batching over the lock-step decoder: any number of requests, at most `slots` (<= 8) in flight; when a
         sequence finishes its slot is re-filled from the queue (a normal prefill parked into the free slot) while the other sequences keep
         decoding.  Yields (request_index, token_list) in completion order; every token list equals `inference()` of that request alone."""
-        assert 1 <= slots <= 16
+        assert 1 <= slots <= (16 if self.batch_fp8 else 32)
         n = len(requests)
         if n == 0:
             return
@@ -371,7 +371,7 @@ class Qwen2LM:
         slots are re-filled as soon as a sequence ends (a normal prefill parked into the slot); with nothing in flight the call blocks on the
         queue.  Every sequence yields exactly the tokens `inference()` yields for its request alone."""
         import queue as _q
-        assert 1 <= slots <= 16
+        assert 1 <= slots <= (16 if self.batch_fp8 else 32)
         chunk = step_chunk or min(self.decode_chunk, 8)
         with self.lock:
             st = stream_ptr(self.lib)

@@ -144,8 +144,8 @@ int cv_llm_profile_step(cv_llm* m, const cv_sampling* sp, int32_t* counts8, floa
 /* one kernel class (category as above, 0..5) as a dependent chain of its real launches (one per layer) in a hipGraph, `reps` replays
  * between ONE event pair: total duration and number of launches — the per-launch duration bench.py prices against the HBM roofline */
 int cv_llm_profile_chain(cv_llm* m, int32_t category, int32_t reps, float* total_ms, int32_t* launches, void* stream);
-/* Lock-step batched decode (BASELINE.json configs[2]/[3]; the reference batches through vLLM, cli/model.py:281-290): up to 16 sequences
- * advance one token per step and every weight matrix is streamed once per step for all of them (skinny GEMMs on the matrix pipe at fp32 accuracy: exact three-term bf16 split of the activations).
+/* Lock-step batched decode (BASELINE.json configs[2]/[3]; the reference batches through vLLM, cli/model.py:281-290): up to 32 sequences
+ * (16 on the fp8 path) advance one token per step and every weight matrix is streamed once per step for all of them (skinny GEMMs on the matrix pipe at fp32 accuracy: exact three-term bf16 split of the activations).
  * cv_llm_batch_begin sizes the slots, cv_llm_batch_prefill runs the normal prefill for one request and parks its KV prefix / state /
  * sampling parameters in `slot`; cv_llm_batch_prefill_many fills n slots with ONE prefill pass over the row-stacked prompts (rows: dev
  * [sum L0s][hidden], slot j's rows after slot j-1's; sps: n sampling structs) - the GEMMs see M = sum of the prompt lengths;

@@ -406,8 +406,8 @@ def test_big_m_kernels_are_bit_identical(lib, tile0, tile1):
     flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision="bf16")
     g = torch.Generator().manual_seed(14)
 
-    def opt(big, attn2, cap=0, glds=0):
-        for k, v in (("big_rows", big), ("attn2_rows", attn2), ("big_tile0", tile0), ("big_tile1", tile1), ("big_grid_cap", cap), ("big_glds", glds)):
+    def opt(big, attn2, cap=0, glds=0, epi=1):
+        for k, v in (("big_rows", big), ("attn2_rows", attn2), ("big_tile0", tile0), ("big_tile1", tile1), ("big_grid_cap", cap), ("big_glds", glds), ("big_lds_epi", epi)):
             lib.cv_flow_set_option(flow._h, k.encode(), C.c_int32(v))
     try:
         for T in (45, 150, 281):
@@ -417,8 +417,10 @@ def test_big_m_kernels_are_bit_identical(lib, tile0, tile1):
                 outs = []
                 # cap = 3 / 1: the persistent form proper - three workgroups (one) walk all the tiles of a launch, the stage pipeline running across tile boundaries
                 # glds = 1: the stages by LDS-DMA (global_load_lds) instead of registers + ds_write
-                for big, attn2, cap, glds in ((0, 0, 0, 0), (1, 0, 0, 0), (0, 1, 0, 0), (1, 1, 0, 0), (1, 0, 3, 0), (1, 1, 1, 0), (1, 0, 0, 1), (1, 0, 2, 1)):
-                    opt(big, attn2, cap, glds)
+                # epi = 0: per-lane stores from the accumulator layout instead of the row-wise stores through LDS (the default of the one-tile-per-workgroup form)
+                for big, attn2, cap, glds, epi in ((0, 0, 0, 0, 1), (1, 0, 0, 0, 1), (0, 1, 0, 0, 1), (1, 1, 0, 0, 1), (1, 0, 3, 0, 1), (1, 1, 1, 0, 1), (1, 0, 0, 1, 1), (1, 0, 2, 1, 1),
+                                                   (1, 0, 0, 0, 0), (1, 0, 0, 1, 0)):
+                    opt(big, attn2, cap, glds, epi)
                     outs.append(flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu().clone())
                 assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
                 for k in range(1, len(outs)):

@@ -81,7 +81,25 @@ def test_batch_of_eight_and_long_context(lib):
     for r, g in zip(reqs, got):
         assert g == OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=3, min_token_text_ratio=2)
     with pytest.raises(AssertionError):
-        lm.inference_batch(reqs + reqs + reqs[:1])                    # 17 > MAX_NB
+        lm.inference_batch(reqs * 4 + reqs[:1])                       # 33 > MAX_NB
+
+
+@pytest.mark.parametrize("nb", [17, 32])
+def test_more_than_sixteen_slots(lib, nb):
+    """Round 4: 17 .. 32 sequences per lock-step step - a second MFMA column tile per weight fragment (skinny_pk2_kernel): every slot still yields exactly the
+    tokens of its request alone (= the oracle's), whatever its column tile, with different prompt lengths and early stops; then a smaller batch and a
+    continuous-batching queue over 20 slots on the same handle."""
+    cfg = W.tiny()[0]
+    sd = W.make_llm(cfg)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=160, sampling="greedy", decode_chunk=6)
+    reqs = [_req(cfg, 300 + i, 2 + (i % 4), 2 + (i % 3), 4 + 5 * (i % 7)) for i in range(nb)]
+    want = [OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=3, min_token_text_ratio=1) for r in reqs]
+    got = lm.inference_batch(reqs, max_token_text_ratio=3, min_token_text_ratio=1)
+    assert got == want and len({len(g) for g in got}) > 1
+    assert lm.inference_batch(reqs[:5], max_token_text_ratio=3, min_token_text_ratio=1) == want[:5]
+    if nb == 32:
+        q = dict(lm.inference_queue(reqs, slots=20, max_token_text_ratio=3, min_token_text_ratio=1))
+        assert [q[i] for i in range(nb)] == want
 
 
 def test_continuous_batching(lib):
