@@ -222,7 +222,8 @@ def cv3_workload(args):
     # the e4m3 weight copies are always registered (batch_fp8=True); the handle's option decides which path the batched decode takes - W16A32 for the lines the
     # oracle's tokens are checked on, fp8 for the `fp8` sub-line below (or everywhere with --llm-fp8)
     m = CosyVoice3Model.from_state_dicts(W.make_llm(lc), W.make_flow_dit(fc), W.make_hift(hc), (lc, fc, hc), max_len=1024, sampling="greedy", decode_chunk=64,
-                                         fp16=(args.flow_precision == "bf16"), batch_fp8=True)
+                                         fp16=(args.flow_precision == "bf16"), batch_fp8=True,
+                                         f0_float64=os.environ.get("CV_BENCH_CV3_F0_F64", "1") != "0")     # (A/B knob: the reference's float64 f0 predictor is the default)
     set_fp8 = lambda on: m.llm.lib.cv_llm_set_option(m.llm._h, b"batch_fp8", C.c_int32(int(on)))
     set_fp8(args.llm_fp8)
     u = W.synthetic_utterance(lc, fc, n_prompt_tok=N_PROMPT_TOK, n_prompt_text=24, n_text=N_TEXT, seed=2025)

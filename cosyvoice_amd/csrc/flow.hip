@@ -55,6 +55,7 @@ struct cv_flow {
     DevBuf e_x, e_xe, e_n, e_qkv, e_qu, e_qv, e_pe, e_p, e_bd, e_att, e_ff, e_x2, e_ctx;    // encoder
     DevBuf s_in, s_a, s_b, s_c, s_n, s_qkv, s_att, s_ff, s_skip, s_cat, s_out;                    // estimator
     DevBuf h_qk, h_vt, h_att, h_ff;                                                           // estimator, fused bf16 pipeline (flow_fused.h)
+    DevBuf attn_dbg; int attn_dbg_on = 0, attn_dbg_blocks = 0;                                  // dev tool: phase stamps of the LAST attention launch (option attn_dbg, stats attn_phase_<k>)
     DevBuf h_zero;                                                                            // 64 zero bytes (the LDS-DMA source of a convolution's padded rows)
     DevBuf h_xn, h_cur;                                                                       // LayerNorm'd rows / a ResNet block's input as bf16 (flow_big.h)
     // Round 4, bf16 mode: the large-M kernel set of flow_big.h for passes of at least `big_rows` estimator rows (0 = never) - LayerNorm once per row -> bf16,
@@ -228,14 +229,15 @@ static void flow_finalize(cv_flow* m) {
 // precision of the Linear / Conv1d products issued by the current entry point (set from the handle's option for the duration of a call)
 static thread_local int tl_bf16_mfma = 0;
 static thread_local int tl_flow_tile = 0, tl_attn_waves = 4, tl_attn_kt = 2, tl_attn_ks = 1, tl_flow_ntile = 0;     // tuning knobs of the fused pipeline, per call like the precision
+static thread_local long long* tl_attn_dbg = nullptr;
 static thread_local int tl_big_tile0 = 0, tl_big_tile1 = 0, tl_big_persist = -1, tl_big_grid_cap = 0, tl_big_glds = 0, tl_big_lds_epi = 1;
 struct PrecisionScope {
     int prev, pt, pw, pk, ps, pn, pb0, pb1, pbp, pbc, pbg, pbe;
     explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves), pk(tl_attn_kt), ps(tl_attn_ks), pn(tl_flow_ntile), pb0(tl_big_tile0), pb1(tl_big_tile1), pbp(tl_big_persist), pbc(tl_big_grid_cap), pbg(tl_big_glds), pbe(tl_big_lds_epi) {
         tl_bf16_mfma = m->bf16_mfma; tl_flow_tile = m->flow_tile; tl_attn_waves = m->attn_waves; tl_attn_kt = m->attn_kt; tl_attn_ks = m->attn_ks; tl_flow_ntile = m->flow_ntile;
-        tl_big_tile0 = m->big_tile0; tl_big_tile1 = m->big_tile1; tl_big_persist = m->big_persist; tl_big_grid_cap = m->big_grid_cap; tl_big_glds = m->big_glds; tl_big_lds_epi = m->big_lds_epi;
+        tl_big_tile0 = m->big_tile0; tl_big_tile1 = m->big_tile1; tl_big_persist = m->big_persist; tl_big_grid_cap = m->big_grid_cap; tl_big_glds = m->big_glds; tl_big_lds_epi = m->big_lds_epi; tl_attn_dbg = m->attn_dbg_on ? const_cast<cv_flow*>(m)->attn_dbg.as<long long>() : nullptr;
     }
-    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; tl_attn_ks = ps; tl_flow_ntile = pn; tl_big_tile0 = pb0; tl_big_tile1 = pb1; tl_big_persist = pbp; tl_big_grid_cap = pbc; tl_big_glds = pbg; tl_big_lds_epi = pbe; }
+    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; tl_attn_ks = ps; tl_flow_ntile = pn; tl_big_tile0 = pb0; tl_big_tile1 = pb1; tl_big_persist = pbp; tl_big_grid_cap = pbc; tl_big_glds = pbg; tl_big_lds_epi = pbe; tl_attn_dbg = nullptr; }
 };
 
 // ---- generic conv/linear on channel-last activations -----------------------------------------------------------------
@@ -500,7 +502,7 @@ static void flow_tail(const TBlockW& t, const TBlockW* next, const bf16_t* att, 
 static void attn_flow(const bf16_t* qk, int ld, int inner, const bf16_t* vt, long long vt_batch, int ldt, bf16_t* o, int B, int H, int T, int chunk, hipStream_t s, const int* klen = nullptr,
                       bool big = false) {
     AttnFlowArgs a{};
-    a.klen = klen;
+    a.klen = klen; a.dbg = tl_attn_dbg;
     a.q = qk; a.k = qk + inner; a.ld = ld; a.vt = vt; a.vt_batch = vt_batch; a.ldt = ldt; a.o = o; a.ldo = inner;
     a.B = B; a.H = H; a.T = T; a.scale = 0.125f; a.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; a.chunk = chunk;
     const dim3 g2((unsigned)(((T + 31) / 32) * H * B)), g4((unsigned)(((T + 63) / 64) * H * B));
@@ -865,6 +867,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "attn2_rows") { CV_CHECK(value >= 0, "attn2_rows must be >= 0"); m->attn2_rows = value; drop_graphs(m); }
         else if (std::string(name) == "big_tile0") { CV_CHECK(value >= 0 && value <= 3, "big_tile0 must be 0..3"); m->big_tile0 = value; drop_graphs(m); }
         else if (std::string(name) == "big_persist") { CV_CHECK(value >= -1 && value <= 8, "big_persist must be -1..8"); m->big_persist = value; drop_graphs(m); }
+        else if (std::string(name) == "attn_dbg") { m->attn_dbg_on = value != 0; if (value) { m->attn_dbg.ensure((size_t)65536 * 8 * 8); CV_HIP(hipMemset(m->attn_dbg.p, 0, m->attn_dbg.bytes)); } drop_graphs(m); }
         else if (std::string(name) == "big_lds_epi") { m->big_lds_epi = value != 0; drop_graphs(m); }
         else if (std::string(name) == "big_glds") { m->big_glds = value != 0; drop_graphs(m); }
         else if (std::string(name) == "big_grid_cap") { CV_CHECK(value >= 0, "big_grid_cap must be >= 0"); m->big_grid_cap = value; drop_graphs(m); }
@@ -878,6 +881,19 @@ int cv_flow_get_stat(cv_flow* m, const char* name, int64_t* value) {
         CV_CHECK(m && name && value, "null argument");
         if (std::string(name) == "graph_captures") *value = m->graph_captures;
         else if (std::string(name) == "graphs_cached") *value = (int64_t)m->graphs.size();
+        else if (std::string(name).rfind("attn_phase_", 0) == 0) {
+            // dev tool: mean shader clocks between stamps k and k + 1 of the LAST attention launch over its workgroups (up to 65536); k = 9: mean start offset
+            // of a workgroup after the first one (how the workgroups of the launch are spread in time), k = 8: first start -> last end
+            CV_CHECK(m->attn_dbg_on && m->attn_dbg.p, "attn_phase_<k>: set option attn_dbg first");
+            CV_HIP(hipDeviceSynchronize());
+            std::vector<long long> h(65536 * 8);
+            CV_HIP(hipMemcpy(h.data(), m->attn_dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
+            const int k = atoi(name + 11);
+            long long t0 = 0, tend = 0, n = 0; double acc = 0.0, acc_start = 0.0;
+            for (int w = 0; w < 65536; ++w) { if (!h[(size_t)w * 8 + 4]) continue; if (!n || h[(size_t)w * 8] < t0) t0 = h[(size_t)w * 8]; tend = std::max(tend, h[(size_t)w * 8 + 4]); ++n; }
+            for (int w = 0; w < 65536; ++w) { if (!h[(size_t)w * 8 + 4]) continue; acc_start += (double)(h[(size_t)w * 8] - t0); if (k >= 0 && k < 4) acc += (double)(h[(size_t)w * 8 + k + 1] - h[(size_t)w * 8 + k]); }
+            *value = n == 0 ? 0 : k == 8 ? tend - t0 : k == 9 ? (long long)(acc_start / n) : k == 7 ? n : (long long)(acc / n);
+        }
         else throw Error(std::string("unknown statistic ") + name);
     });
 }

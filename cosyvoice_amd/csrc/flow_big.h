@@ -116,39 +116,46 @@ __global__ __launch_bounds__(256) void flow_gemm_big_kernel(FlowGemmArgs p) {
 #pragma unroll
     for (int i = 0; i < WV; ++i) { const int v = tid + 256 * i, r = v >> 3, s = v & 7; w_lds[i] = r * RP + ((s ^ ((r >> 1) & 7)) << 2); }
     const int ps8 = 8 * (tid & 7), pr = tid >> 3;             // this thread's slot (in bf16) and first piece row; piece i is row pr + 32 i
-    u32x4_t ra[AV], rw[WV];
+    // Register ring: the loads of D stages are in flight at once.  Round-4 finding (profiles/r4_flow_big_ab.txt): with ONE stage ahead a K stage cost ~1.2 us whatever it
+    // did - 8 MFMAs per wave do not cover an L2 round trip under load - and tile shape, persistence, LDS-DMA staging and row-wise stores all measured neutral.
+    constexpr int D = GLDS ? 1 : (BM * BN >= 128 * 128 ? 2 : 4);      // (128 x 128: eight 16-byte pieces per stage - four stages of them spill)
+    u32x4_t ra[D][AV], rw[D][WV];
     int a_t[CONV ? AV : 1];                                   // CONV: row of its request of every A piece of the tile being loaded (one modulo per tile, not per stage)
     // (tile, stage) of the NEXT load, advanced incrementally: no division in the loop
     int l_tile = t_begin, l_c = 0;
-    auto load = [&]() {
-        const int m0 = (l_tile / ntn) * BM, n0 = (l_tile % ntn) * BN;
-        int tap = 0, kc = l_c;
-        if constexpr (CONV) { tap = l_c / spt; kc = l_c - tap * spt; }
+    int a_tile = -1;                                          // CONV: the tile a_t[] belongs to
+    auto load = [&](int slot) {                                // `slot` is a compile-time constant after unrolling (the ring stays in registers)
+        const bool past = l_tile >= t_begin + t_count;        // beyond the last stage: re-request it (no branch around a load: the vmcnt bookkeeping stays exact)
+        const int lt = past ? t_begin + t_count - 1 : l_tile, lc = past ? nst - 1 : l_c;
+        const int m0 = (lt / ntn) * BM, n0 = (lt % ntn) * BN;
+        int tap = 0, kc = lc;
+        if constexpr (CONV) { tap = lc / spt; kc = lc - tap * spt; }
         const int k0 = kc * BK, dr = tap - p.pad_left;        // uniform
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const int m = min(m0 + pr + 32 * i, p.M - 1);
             const bf16_t* ap = reinterpret_cast<const bf16_t*>(p.A) + (long long)m * p.lda + ps8;
             if constexpr (CONV) {                             // unconditional load (clamped row) + select: the zero padding before a request's first row
-                if (l_c == 0) a_t[i] = m % p.rows_per_batch;          // (uniform branch)
+                if (a_tile != lt) a_t[i] = m % p.rows_per_batch;      // (uniform branch, once per tile)
                 const int t = a_t[i], tr_ = t + dr;                   // row of its request: taps never reach into the previous request
                 u32x4_t v = *reinterpret_cast<const u32x4_t*>(ap + (long long)(max(tr_, 0) - t) * p.lda + min(k0, p.K - 8 - ps8));
                 if (tr_ < 0) v = (u32x4_t){0u, 0u, 0u, 0u};
-                ra[i] = v;
-            } else ra[i] = *reinterpret_cast<const u32x4_t*>(ap + min(k0, p.K - 8 - ps8));      // clamped: steps beyond K are never multiplied
+                ra[slot][i] = v;
+            } else ra[slot][i] = *reinterpret_cast<const u32x4_t*>(ap + min(k0, p.K - 8 - ps8));      // clamped: steps beyond K are never multiplied
         }
+        if constexpr (CONV) a_tile = lt;
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const int n = min(n0 + pr + 32 * i, p.N - 1);
-            rw[i] = *reinterpret_cast<const u32x4_t*>(p.W + (long long)n * wpitch + ps8 + (CONV ? tap * p.Kp : 0) + min(k0, p.Kp - 8 - ps8));
+            rw[slot][i] = *reinterpret_cast<const u32x4_t*>(p.W + (long long)n * wpitch + ps8 + (CONV ? tap * p.Kp : 0) + min(k0, p.Kp - 8 - ps8));
         }
-        if (++l_c == nst) { l_c = 0; ++l_tile; }
+        if (!past && ++l_c == nst) { l_c = 0; ++l_tile; }
     };
-    auto store = [&](int buf) {
+    auto store = [&](int slot, int buf) {
 #pragma unroll
-        for (int i = 0; i < AV; ++i) *reinterpret_cast<u32x4_t*>(&As0[buf * BM * RP + a_lds[i]]) = ra[i];
+        for (int i = 0; i < AV; ++i) *reinterpret_cast<u32x4_t*>(&As0[buf * BM * RP + a_lds[i]]) = ra[slot][i];
 #pragma unroll
-        for (int i = 0; i < WV; ++i) *reinterpret_cast<u32x4_t*>(&Ws0[buf * BN * RP + w_lds[i]]) = rw[i];
+        for (int i = 0; i < WV; ++i) *reinterpret_cast<u32x4_t*>(&Ws0[buf * BN * RP + w_lds[i]]) = rw[slot][i];
     };
     // fragment address of this lane: row (lane & 15) of a 16-row tile, slot 4 kg + (lane >> 4), swizzled by the row (tile bases are multiples of 16)
     const int fr = lane & 15, fx = (fr >> 1) & 7, fg = lane >> 4;
@@ -363,19 +370,27 @@ __global__ __launch_bounds__(256) void flow_gemm_big_kernel(FlowGemmArgs p) {
         if (lds_epi) epilogue_lds((t_begin / ntn) * BM, (t_begin % ntn) * BN);
         return;
     }
-    load();
-    store(0);
-    if (total > 1) load();
-    __syncthreads();
-    for (int g = 0; g < total; ++g) {
-        if (g + 1 < total) {
-            store((g + 1) & 1);                               // buffer (g + 1) & 1 was last read by stage g - 1: every wave left it before the barrier that ended it
-            if (g + 2 < total) load();
+    if constexpr (!GLDS) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) load(k);                      // stages 0 .. D - 1 requested at once
+        // stage g: its registers (ring slot g % D, requested D stages ago) -> LDS buffer g & 1, stage g + D requested into the freed slot, barrier, MFMAs.  Buffer g & 1
+        // was last read by stage g - 2, which every wave finished before the barrier of stage g - 1.  The stage count is rounded up to D: the extra ones
+        // re-request the last stage, park it and multiply nothing.
+        for (int g0 = 0; g0 < total; g0 += D) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const int g = g0 + k;
+                store(k, g & 1);
+                load(k);
+                __syncthreads();
+                if (g < total) {
+                    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+                    compute(g & 1, min(BK, p.K - (CONV ? c % spt : c) * BK) / 32, n0);
+                    if (++c == nst) { if (!lds_epi) epilogue(m0, n0); c = 0; ++tile; }   // stores only: the next tile's stages are already in flight
+                }
+            }
         }
-        const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-        compute(g & 1, min(BK, p.K - (CONV ? c % spt : c) * BK) / 32, n0);
-        if (++c == nst) { if (!lds_epi) epilogue(m0, n0); c = 0; ++tile; }   // stores only: the next tile's first stages are already parked / in flight
-        __syncthreads();
+        __syncthreads();                                          // every wave has left the ring (the staged epilogue reuses it)
     }
     if (lds_epi) epilogue_lds((t_begin / ntn) * BM, (t_begin % ntn) * BN);
 }

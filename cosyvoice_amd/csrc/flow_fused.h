@@ -280,6 +280,7 @@ struct AttnFlowArgs {
     bf16_t* o; int ldo;                                   // [B * T][ldo]
     int B, H, T; float scale; int mask_mode; int chunk;
     const int* klen;                                      // optional [B] key counts of a padded batch
+    long long* dbg;                                       // dev tool (flow option attn_dbg): clock64() of thread 0 at the phase boundaries, 8 slots per workgroup; null in production
 };
 
 template <int NW, int KT, int KS = 1, int QG = 1>
@@ -309,6 +310,10 @@ __global__ __launch_bounds__(NW * KS * 64) void attn_flow_kernel(AttnFlowArgs p)
     const int qb = bl % nqb, h = (bl / nqb) % p.H, b = bl / (nqb * p.H);
     const float NEG_INF = -__builtin_huge_valf();
     const float scale2 = p.scale * 1.4426950408889634f;
+    long long* dbg = p.dbg ? p.dbg + (long long)blockIdx.x * 8 : nullptr;
+    int dn = 0;
+    auto stamp = [&]() { if (dbg && tid == 0) dbg[dn++] = clock64(); };
+    stamp();                                               // 0: start
 
     const bf16_t* kb = p.k + (long long)b * p.T * p.ld + h * 64;
     const bf16_t* vb = p.vt + (long long)b * p.vt_batch + (long long)h * 64 * p.ldt;
@@ -479,8 +484,10 @@ __global__ __launch_bounds__(NW * KS * 64) void attn_flow_kernel(AttnFlowArgs p)
     // ring: tile t is multiplied out of buffer t & 1 while tile t + 1 is parked in the other buffer and tile t + 2 is in flight in registers
     if (kend > 0) { store_kv(0); if (BKV < kend) load_kv(BKV); }
     __syncthreads();
+    stamp();                                               // 1: the first K / V^T tile is parked (first-load latency)
     for (int kt0 = 0, t = 0; kt0 < kend; kt0 += BKV, ++t) {
-        if (QG == 1 || kt0 < kend_w) compute(kt0, t & 1);  // QG = 2: wave-uniform - the 64-query workgroup of these queries ends its loop here
+        if (QG == 1 || kt0 < kend_w) compute(kt0, t & 1);
+        if (t == 0) stamp();                               // 2: first tile multiplied  // QG = 2: wave-uniform - the 64-query workgroup of these queries ends its loop here
         if (kt0 + BKV < kend) {
             store_kv((t + 1) & 1);                          // every wave left buffer (t + 1) & 1 before the barrier that ended iteration t - 1
             if (kt0 + 2 * BKV < kend) load_kv(kt0 + 2 * BKV);
@@ -488,6 +495,7 @@ __global__ __launch_bounds__(NW * KS * 64) void attn_flow_kernel(AttnFlowArgs p)
         __syncthreads();
     }
 
+    stamp();                                               // 3: key loop done
     if constexpr (KS > 1) {
         // merge the key splits of every query group (fixed order): sets 1 .. KS-1 park (max, denominator, numerators) in LDS - the K ring is free
         // after the loop's last barrier - and set 0 combines.  Row pitch 19 floats per lane and query group.
@@ -530,6 +538,7 @@ __global__ __launch_bounds__(NW * KS * 64) void attn_flow_kernel(AttnFlowArgs p)
             for (int dt = 0; dt < 4; ++dt)
                 *reinterpret_cast<uint2*>(op + dt * 16 + lg * 4) = make_uint2(pack_bf16x2(acc[g][dt][0] * inv, acc[g][dt][1] * inv), pack_bf16x2(acc[g][dt][2] * inv, acc[g][dt][3] * inv));
         }
+    stamp();                                               // 4: merged and stored
 }
 
 }  // namespace cv

@@ -36,7 +36,10 @@ for k, cs in sorted(acc.items()):
         d["fetch_size_kb"] = d["FETCH_SIZE"]
         d["hbm_read_bytes_corrected"] = d["FETCH_SIZE"] * 1024 * 2
     if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d and d["GRBM_GUI_ACTIVE"] > 0:
-        d["mfma_busy_frac_of_chip"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] * 1024.0)      # 256 CUs x 4 SIMDs
+        # rocprofv3 reports GRBM_GUI_ACTIVE SUMMED over the 8 XCDs on gfx950 (a 54 us kernel reads 1.19 M "cycles"): per-XCD cycles = / 8.  Rounds 2-3 divided by the
+        # raw sum, which made every fraction ~8 x too small (round-4 finding; cross-check: MFMA count x 16 cycles / (kernel-trace duration x clock x 1024 SIMDs)).
+        d["mfma_busy_frac_of_chip"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)      # 256 CUs x 4 SIMDs
+        d["mfma_busy_frac_of_chip_rounds_2_3_formula"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] * 1024.0)
     res[k] = d
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: {c: round(v, 1) for c, v in d.items()} for k, d in res.items()}, indent=1)[:6000])
