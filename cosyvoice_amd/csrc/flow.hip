@@ -55,6 +55,7 @@ struct cv_flow {
     DevBuf e_x, e_xe, e_n, e_qkv, e_qu, e_qv, e_pe, e_p, e_bd, e_att, e_ff, e_x2, e_ctx;    // encoder
     DevBuf s_in, s_a, s_b, s_c, s_n, s_qkv, s_att, s_ff, s_skip, s_cat, s_out;                    // estimator
     DevBuf h_qk, h_vt, h_att, h_ff;                                                           // estimator, fused bf16 pipeline (flow_fused.h)
+    DevBuf gemm_dbg; int gemm_dbg_on = 0;                                                     // dev tool: the same for the large-M GEMMs (option gemm_dbg = 1 QKV | 2 FF1 | 3 out-projection | 4 FF2; stats gemm_phase_<k>)
     DevBuf attn_dbg; int attn_dbg_on = 0, attn_dbg_blocks = 0;                                  // dev tool: phase stamps of the LAST attention launch (option attn_dbg, stats attn_phase_<k>)
     DevBuf h_zero;                                                                            // 64 zero bytes (the LDS-DMA source of a convolution's padded rows)
     DevBuf h_xn, h_cur;                                                                       // LayerNorm'd rows / a ResNet block's input as bf16 (flow_big.h)
@@ -229,15 +230,16 @@ static void flow_finalize(cv_flow* m) {
 // precision of the Linear / Conv1d products issued by the current entry point (set from the handle's option for the duration of a call)
 static thread_local int tl_bf16_mfma = 0;
 static thread_local int tl_flow_tile = 0, tl_attn_waves = 4, tl_attn_kt = 2, tl_attn_ks = 1, tl_flow_ntile = 0;     // tuning knobs of the fused pipeline, per call like the precision
-static thread_local long long* tl_attn_dbg = nullptr;
+static thread_local long long* tl_attn_dbg = nullptr; static thread_local long long* tl_gemm_dbg = nullptr; static thread_local int tl_gemm_dbg_which = 0;
 static thread_local int tl_big_tile0 = 0, tl_big_tile1 = 0, tl_big_persist = -1, tl_big_grid_cap = 0, tl_big_glds = 0, tl_big_lds_epi = 1;
 struct PrecisionScope {
     int prev, pt, pw, pk, ps, pn, pb0, pb1, pbp, pbc, pbg, pbe;
     explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves), pk(tl_attn_kt), ps(tl_attn_ks), pn(tl_flow_ntile), pb0(tl_big_tile0), pb1(tl_big_tile1), pbp(tl_big_persist), pbc(tl_big_grid_cap), pbg(tl_big_glds), pbe(tl_big_lds_epi) {
         tl_bf16_mfma = m->bf16_mfma; tl_flow_tile = m->flow_tile; tl_attn_waves = m->attn_waves; tl_attn_kt = m->attn_kt; tl_attn_ks = m->attn_ks; tl_flow_ntile = m->flow_ntile;
         tl_big_tile0 = m->big_tile0; tl_big_tile1 = m->big_tile1; tl_big_persist = m->big_persist; tl_big_grid_cap = m->big_grid_cap; tl_big_glds = m->big_glds; tl_big_lds_epi = m->big_lds_epi; tl_attn_dbg = m->attn_dbg_on ? const_cast<cv_flow*>(m)->attn_dbg.as<long long>() : nullptr;
+        tl_gemm_dbg = m->gemm_dbg_on ? const_cast<cv_flow*>(m)->gemm_dbg.as<long long>() : nullptr; tl_gemm_dbg_which = m->gemm_dbg_on;
     }
-    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; tl_attn_ks = ps; tl_flow_ntile = pn; tl_big_tile0 = pb0; tl_big_tile1 = pb1; tl_big_persist = pbp; tl_big_grid_cap = pbc; tl_big_glds = pbg; tl_big_lds_epi = pbe; tl_attn_dbg = nullptr; }
+    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; tl_attn_ks = ps; tl_flow_ntile = pn; tl_big_tile0 = pb0; tl_big_tile1 = pb1; tl_big_persist = pbp; tl_big_grid_cap = pbc; tl_big_glds = pbg; tl_big_lds_epi = pbe; tl_attn_dbg = nullptr; tl_gemm_dbg = nullptr; tl_gemm_dbg_which = 0; }
 };
 
 // ---- generic conv/linear on channel-last activations -----------------------------------------------------------------
@@ -458,6 +460,7 @@ static void gemm_big_bf16(const Lin& l, const bf16_t* A, int M, int act, bf16_t*
     a.A = A; a.lda = l.K; a.W = reinterpret_cast<const bf16_t*>(l.w); a.Kp = l.Kp; a.bias = l.b; a.M = M; a.N = l.N; a.K = l.K; a.act = act;
     a.out = out; a.ldo = ldo; a.n_row = n_row; a.outT = outT; a.t_batch = t_batch; a.ldt = ldt; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
     a.lds_epilogue = tl_big_lds_epi;
+    if (tl_gemm_dbg && tl_gemm_dbg_which == (outT ? 1 : 2)) a.dbg = tl_gemm_dbg;
     gemm_big_launch<0>(a, tl_big_tile0 ? tl_big_tile0 : 3, s);
 }
 // C = A_bf16 W^T + b (+ res), fp32
@@ -466,6 +469,7 @@ static void gemm_big_res(const Lin& l, const bf16_t* A, int lda, int M, float* C
     FlowGemmArgs a{};
     a.A = A; a.lda = lda; a.W = reinterpret_cast<const bf16_t*>(l.w); a.Kp = l.Kp; a.bias = l.b; a.M = M; a.N = l.N; a.K = l.K;
     a.C = C; a.ldc = l.N; a.res = res; a.n_row = l.N; a.lds_epilogue = tl_big_lds_epi;
+    if (tl_gemm_dbg && tl_gemm_dbg_which == (l.K <= 512 ? 3 : 4)) a.dbg = tl_gemm_dbg;
     gemm_big_launch<1>(a, tl_big_tile1 ? tl_big_tile1 : 3, s);
 }
 // causal Conv1d / Linear over bf16 rows of nz requests of T rows each (ResNet blocks of a large pass): C = conv(A) + b (+ res), fp32
@@ -867,6 +871,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "attn2_rows") { CV_CHECK(value >= 0, "attn2_rows must be >= 0"); m->attn2_rows = value; drop_graphs(m); }
         else if (std::string(name) == "big_tile0") { CV_CHECK(value >= 0 && value <= 3, "big_tile0 must be 0..3"); m->big_tile0 = value; drop_graphs(m); }
         else if (std::string(name) == "big_persist") { CV_CHECK(value >= -1 && value <= 8, "big_persist must be -1..8"); m->big_persist = value; drop_graphs(m); }
+        else if (std::string(name) == "gemm_dbg") { m->gemm_dbg_on = value; if (value) { m->gemm_dbg.ensure((size_t)65536 * 8 * 8); CV_HIP(hipMemset(m->gemm_dbg.p, 0, m->gemm_dbg.bytes)); } drop_graphs(m); }
         else if (std::string(name) == "attn_dbg") { m->attn_dbg_on = value != 0; if (value) { m->attn_dbg.ensure((size_t)65536 * 8 * 8); CV_HIP(hipMemset(m->attn_dbg.p, 0, m->attn_dbg.bytes)); } drop_graphs(m); }
         else if (std::string(name) == "big_lds_epi") { m->big_lds_epi = value != 0; drop_graphs(m); }
         else if (std::string(name) == "big_glds") { m->big_glds = value != 0; drop_graphs(m); }
@@ -881,18 +886,23 @@ int cv_flow_get_stat(cv_flow* m, const char* name, int64_t* value) {
         CV_CHECK(m && name && value, "null argument");
         if (std::string(name) == "graph_captures") *value = m->graph_captures;
         else if (std::string(name) == "graphs_cached") *value = (int64_t)m->graphs.size();
-        else if (std::string(name).rfind("attn_phase_", 0) == 0) {
-            // dev tool: mean shader clocks between stamps k and k + 1 of the LAST attention launch over its workgroups (up to 65536); k = 9: mean start offset
-            // of a workgroup after the first one (how the workgroups of the launch are spread in time), k = 8: first start -> last end
-            CV_CHECK(m->attn_dbg_on && m->attn_dbg.p, "attn_phase_<k>: set option attn_dbg first");
+        else if (std::string(name).rfind("attn_phase_", 0) == 0 || std::string(name).rfind("gemm_phase_", 0) == 0) {
+            // dev tool: mean shader clocks between stamps k and k + 1 of the LAST stamped launch over its workgroups (up to 65536); k = 7: workgroups,
+            // k = 8: first start -> last end, k = 9: mean start offset of a workgroup after the first one, k = 10: mean end offset
+            const bool at = name[0] == 'a';
+            CV_CHECK(at ? (m->attn_dbg_on && m->attn_dbg.p) : (m->gemm_dbg_on && m->gemm_dbg.p), "<attn|gemm>_phase_<k>: set option attn_dbg / gemm_dbg first");
             CV_HIP(hipDeviceSynchronize());
             std::vector<long long> h(65536 * 8);
-            CV_HIP(hipMemcpy(h.data(), m->attn_dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
-            const int k = atoi(name + 11);
-            long long t0 = 0, tend = 0, n = 0; double acc = 0.0, acc_start = 0.0;
-            for (int w = 0; w < 65536; ++w) { if (!h[(size_t)w * 8 + 4]) continue; if (!n || h[(size_t)w * 8] < t0) t0 = h[(size_t)w * 8]; tend = std::max(tend, h[(size_t)w * 8 + 4]); ++n; }
-            for (int w = 0; w < 65536; ++w) { if (!h[(size_t)w * 8 + 4]) continue; acc_start += (double)(h[(size_t)w * 8] - t0); if (k >= 0 && k < 4) acc += (double)(h[(size_t)w * 8 + k + 1] - h[(size_t)w * 8 + k]); }
-            *value = n == 0 ? 0 : k == 8 ? tend - t0 : k == 9 ? (long long)(acc_start / n) : k == 7 ? n : (long long)(acc / n);
+            CV_HIP(hipMemcpy(h.data(), at ? m->attn_dbg.p : m->gemm_dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
+            const int k = atoi(name + 11), last = 4;
+            long long t0 = 0, tend = 0, n = 0; double acc = 0.0, acc_start = 0.0, acc_end = 0.0;
+            for (int w = 0; w < 65536; ++w) { if (!h[(size_t)w * 8 + last]) continue; if (!n || h[(size_t)w * 8] < t0) t0 = h[(size_t)w * 8]; tend = std::max(tend, h[(size_t)w * 8 + last]); ++n; }
+            for (int w = 0; w < 65536; ++w) {
+                if (!h[(size_t)w * 8 + last]) continue;
+                acc_start += (double)(h[(size_t)w * 8] - t0); acc_end += (double)(h[(size_t)w * 8 + last] - t0);
+                if (k >= 0 && k < 4) acc += (double)(h[(size_t)w * 8 + k + 1] - h[(size_t)w * 8 + k]);
+            }
+            *value = n == 0 ? 0 : k == 8 ? tend - t0 : k == 9 ? (long long)(acc_start / n) : k == 10 ? (long long)(acc_end / n) : k == 7 ? n : (long long)(acc / n);
         }
         else throw Error(std::string("unknown statistic ") + name);
     });

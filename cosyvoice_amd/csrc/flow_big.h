@@ -96,6 +96,10 @@ __global__ __launch_bounds__(256) void flow_gemm_big_kernel(FlowGemmArgs p) {
     // this workgroup's run of tiles: consecutive in (row band, N tile) order, runs handed out in XCD order (an XCD's workgroups walk neighbouring bands: A crosses
     // the fabric once, the weights stay in its L2)
     const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    long long* dbg = p.dbg ? p.dbg + (long long)blockIdx.x * 8 : nullptr;       // dev tool (flow option gemm_dbg): clock64() of thread 0 at the phase boundaries
+    int dn = 0;
+    auto stamp = [&]() { if (dbg && threadIdx.x == 0) dbg[dn++] = clock64(); };
+    stamp();                                                                       // 0: start
     const int tq = ntiles / (int)gridDim.x, trm = ntiles % (int)gridDim.x;
     const int t_begin = wg * tq + min(wg, trm), t_count = tq + (wg < trm ? 1 : 0);
     const int spt = (p.K + BK - 1) / BK;                       // stages per tap
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(256) void flow_gemm_big_kernel(FlowGemmArgs p) {
     const int ps8 = 8 * (tid & 7), pr = tid >> 3;             // this thread's slot (in bf16) and first piece row; piece i is row pr + 32 i
     // Register ring: the loads of D stages are in flight at once.  Round-4 finding (profiles/r4_flow_big_ab.txt): with ONE stage ahead a K stage cost ~1.2 us whatever it
     // did - 8 MFMAs per wave do not cover an L2 round trip under load - and tile shape, persistence, LDS-DMA staging and row-wise stores all measured neutral.
-    constexpr int D = GLDS ? 1 : (BM * BN >= 128 * 128 ? 2 : 4);      // (128 x 128: eight 16-byte pieces per stage - four stages of them spill)
+    constexpr int D = GLDS ? 1 : 2;                            // (four stages in flight measured WORSE: 118.5 vs 107 ms per pass at 8 utterances - 122 registers, three workgroups per CU instead of five)
     u32x4_t ra[D][AV], rw[D][WV];
     int a_t[CONV ? AV : 1];                                   // CONV: row of its request of every A piece of the tile being loaded (one modulo per tile, not per stage)
     // (tile, stage) of the NEXT load, advanced incrementally: no division in the loop
@@ -383,6 +387,7 @@ __global__ __launch_bounds__(256) void flow_gemm_big_kernel(FlowGemmArgs p) {
                 store(k, g & 1);
                 load(k);
                 __syncthreads();
+                if (g == 0) stamp();                                  // 1: first stage parked (first-load latency)
                 if (g < total) {
                     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
                     compute(g & 1, min(BK, p.K - (CONV ? c % spt : c) * BK) / 32, n0);
@@ -391,8 +396,11 @@ __global__ __launch_bounds__(256) void flow_gemm_big_kernel(FlowGemmArgs p) {
             }
         }
         __syncthreads();                                          // every wave has left the ring (the staged epilogue reuses it)
+        stamp();                                                  // 2: all stages multiplied
     }
     if (lds_epi) epilogue_lds((t_begin / ntn) * BM, (t_begin % ntn) * BN);
+    stamp();                                                      // 3: output stored (with per-lane stores the epilogue sits inside the stage loop: 2 -> 3 is empty)
+    stamp();
 }
 
 }  // namespace cv
