@@ -50,20 +50,35 @@ __device__ __forceinline__ float fast_erf(float x) {
 }
 // ONE out-of-line copy per kernel, four elements per call: inlined at every unrolled prologue / epilogue site the activation code
 // bloats the GEMM k-loop past the instruction cache again (measured: +8..15 us per launch on the 64x64 / 128x64 tiles).
-__device__ __noinline__ float4 act4_call(int act, float4 x) {
+// The activation id is uniform over a launch but arrives in a VECTOR register (a function argument): compared there, every `if (act == ...)` becomes an
+// exec-mask region and all seven candidates are walked per element (945 instructions for four values; measured round 4: the GELU epilogue of a 64 x 64 FF1 tile
+// cost 7600 clocks per wave against 2900 for the same tile without activation).  Read into a scalar register first, the chain is seven scalar compares and ONE
+// body.  Same expressions per element as before: same bits.
+__device__ __noinline__ float4 act4_call(int act_v, float4 x) {
+    const int act = __builtin_amdgcn_readfirstlane(act_v);
     float v[4] = {x.x, x.y, x.z, x.w};
+    if (act == ACT_SILU) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float t = v[e];
-        float r;
-        if (act == ACT_SILU) r = t * fast_rcp(1.f + fast_exp(-t));
-        else if (act == ACT_GELU_ERF) r = 0.5f * t * (1.f + fast_erf(t * 0.70710678118654752440f));
-        else if (act == ACT_MISH) { const float n = fast_exp(fminf(t, 20.f)), w = n * (n + 2.f); r = t > 20.f ? t : t * w * fast_rcp(w + 2.f); }
-        else if (act == ACT_TANH) { const float e2 = fast_exp(2.f * fminf(fmaxf(t, -15.f), 15.f)); r = 1.f - 2.f * fast_rcp(e2 + 1.f); }
-        else if (act == ACT_ELU) r = t > 0.f ? t : expm1f(t);
-        else if (act == ACT_GELU_TANH) { const float u = 0.7978845608028654f * (t + 0.044715f * t * t * t), e2 = fast_exp(2.f * fminf(fmaxf(u, -15.f), 15.f)); r = 0.5f * t * (2.f - 2.f * fast_rcp(e2 + 1.f)); }
-        else r = t;
-        v[e] = r;
+        for (int e = 0; e < 4; ++e) { const float t = v[e]; v[e] = t * fast_rcp(1.f + fast_exp(-t)); }
+    } else if (act == ACT_GELU_ERF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = v[e]; v[e] = 0.5f * t * (1.f + fast_erf(t * 0.70710678118654752440f)); }
+    } else if (act == ACT_MISH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = v[e]; const float n = fast_exp(fminf(t, 20.f)), w = n * (n + 2.f); v[e] = t > 20.f ? t : t * w * fast_rcp(w + 2.f); }
+    } else if (act == ACT_TANH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = v[e]; const float e2 = fast_exp(2.f * fminf(fmaxf(t, -15.f), 15.f)); v[e] = 1.f - 2.f * fast_rcp(e2 + 1.f); }
+    } else if (act == ACT_ELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = v[e]; v[e] = t > 0.f ? t : expm1f(t); }
+    } else if (act == ACT_GELU_TANH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = v[e];
+            const float u = 0.7978845608028654f * (t + 0.044715f * t * t * t), e2 = fast_exp(2.f * fminf(fmaxf(u, -15.f), 15.f));
+            v[e] = 0.5f * t * (2.f - 2.f * fast_rcp(e2 + 1.f));
+        }
     }
     return make_float4(v[0], v[1], v[2], v[3]);
 }

@@ -209,7 +209,7 @@ static inline emu_u32x2 emu_buf_load_b64(emu_rsrc rs, int voff, int soff) {
 #define __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, aux) emu_buf_load_b128((rs), (voff), (soff))
 #define __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, aux) emu_buf_load_b64((rs), (voff), (soff))
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
-#define __builtin_amdgcn_readfirstlane(x) __shfl((x), 0)
+#define __builtin_amdgcn_readfirstlane(x) (x)      /* callers pass wave-uniform values (also inside divergent regions, where a fibre rendezvous would not complete) */
 /* global_load_lds_dwordx4: LDS destination = wave-uniform base + lane * 16 */
 #define CV_GLDS16(gptr, lds_wave_base) memcpy((char*)(lds_wave_base) + 16 * emu::lane_id(), (const void*)(gptr), 16)
 #define CV_VMCNT0() ((void)0)
