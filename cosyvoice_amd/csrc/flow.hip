@@ -89,6 +89,7 @@ struct cv_flow {
     int flow_tile = 0, attn_waves = 4, attn_kt = 1, attn_ks = 2;   // "attn_ks": key splits inside a 64-query workgroup (2 = 8 waves, 128 keys per iteration)
     DevBuf t_val, t_sin, t_h, t_emb, t_mlp;                                                   // time embeddings
     DevBuf f_tok, f_h, f_mu, f_spk, f_spkn, f_cond, f_x, f_ones;                              // inference glue
+    int enc_nu = 0, enc_batch = 1;        // enc_batch: encode the utterances of an equal-length pass together (option "enc_batch", CV_FLOW_ENC_BATCH)
     int enc_cap = 0, est_cap = 0, est_nz = 0, t_cap = 0, inf_cap = 0; long long inf_rows = 0;
     // padded batches (cv_flow_inference_ragged): key counts per estimator batch row, fixed device address (captured graphs read the current content)
     DevBuf klen; std::vector<int> host_klen; const int* cur_klen = nullptr;
@@ -218,6 +219,7 @@ static void flow_finalize(cv_flow* m) {
     if (const char* e = getenv("CV_FLOW_BIG_TILE1")) m->big_tile1 = atoi(e);
     if (const char* e = getenv("CV_FLOW_BIG_GLDS")) m->big_glds = atoi(e) != 0;
     if (const char* e = getenv("CV_FLOW_BIG_LDS_EPI")) m->big_lds_epi = atoi(e) != 0;
+    if (const char* e = getenv("CV_FLOW_ENC_BATCH")) m->enc_batch = atoi(e) != 0;
     if (const char* e = getenv("CV_FLOW_ATTN2_ROWS")) m->attn2_rows = atoi(e);
     if (const char* e = getenv("CV_FLOW_TAIL")) m->fused_tail = e[0] != '0';        // dev knob for A/B runs (also: option "fused_tail")
     if (const char* e = getenv("CV_FLOW_TAIL_RING")) m->tail_ring = atoi(e) == 16 ? 16 : 8;
@@ -266,85 +268,106 @@ static void ln_rows(const LN& n, const float* x, float* y, long long rows, int C
 }
 
 // ---- encoder ---------------------------------------------------------------------------------------------------------
-static void enc_reserve(cv_flow* m, int T) {      // T = token count before upsampling
-    if (T <= m->enc_cap) return;
-    const auto& c = m->cfg; const size_t d = c.dim, T2 = 2 * (size_t)T, f = 4;
-    m->e_x.ensure(T2 * d * f); m->e_xe.ensure((T2 + 8) * d * f); m->e_n.ensure(T2 * d * f); m->e_qkv.ensure(T2 * 3 * d * f);
-    m->e_qu.ensure(T2 * d * f); m->e_qv.ensure(T2 * d * f); m->e_pe.ensure((2 * T2) * d * f); m->e_p.ensure((2 * T2) * d * f);
-    m->e_bd.ensure((size_t)c.enc_heads * T2 * (2 * T2) * f); m->e_att.ensure(T2 * d * f); m->e_ff.ensure(T2 * c.ffn * f);
-    m->e_x2.ensure(T2 * d * f); m->e_ctx.ensure(8 * d * f);
-    m->enc_cap = T;
+static void enc_reserve(cv_flow* m, int T, int nu = 1) {      // T = token count before upsampling, nu = utterances of that length encoded together
+    if (T <= m->enc_cap && nu <= m->enc_nu) return;
+    T = std::max(T, m->enc_cap); nu = std::max(nu, m->enc_nu);
+    const auto& c = m->cfg; const size_t d = c.dim, T2 = 2 * (size_t)T, R2 = T2 * nu, f = 4;
+    m->e_x.ensure(R2 * d * f); m->e_xe.ensure((R2 + 8 * nu) * d * f); m->e_n.ensure(R2 * d * f); m->e_qkv.ensure(R2 * 3 * d * f);
+    m->e_qu.ensure(R2 * d * f); m->e_qv.ensure(R2 * d * f); m->e_pe.ensure((2 * T2) * d * f); m->e_p.ensure((2 * T2) * d * f);
+    m->e_bd.ensure((size_t)c.enc_heads * T2 * (2 * T2) * f); m->e_att.ensure(R2 * d * f); m->e_ff.ensure(R2 * c.ffn * f);
+    m->e_x2.ensure(R2 * d * f); m->e_ctx.ensure(8 * nu * d * f);
+    m->enc_cap = T; m->enc_nu = nu;
 }
 
-static void conformer_layer(cv_flow* m, const ConformerW& w, float* x, int T, const float* pe, int chunk, hipStream_t s) {
-    const auto& c = m->cfg; const int d = c.dim, H = c.enc_heads, P = 2 * T - 1;
+// x: [nu][T][d] stacked.  Everything row-wise runs ONCE over the nu * T rows; linear_pos(pe) once per layer (the reference recomputes it per call); matrix_bd and
+// the attention per utterance (one [H][T][2T-1] score-bias tensor at a time: 58 MB at T = 674).  Per row the arithmetic is the single-utterance call's.
+static void conformer_layer(cv_flow* m, const ConformerW& w, float* x, int T, const float* pe, int chunk, hipStream_t s, int nu = 1) {
+    const auto& c = m->cfg; const int d = c.dim, H = c.enc_heads, P = 2 * T - 1; const long long R = (long long)nu * T;
     float* n = m->e_n.as<float>(); float* qkv = m->e_qkv.as<float>(); float* qu = m->e_qu.as<float>(); float* qv = m->e_qv.as<float>();
     float* pp = m->e_p.as<float>(); float* bd = m->e_bd.as<float>(); float* att = m->e_att.as<float>(); float* ff = m->e_ff.as<float>();
-    ln_rows(w.norm_mha, x, n, T, d, 1e-12f, s);
-    lin_cl(w.qkv, n, T, qkv, ACT_NONE, nullptr, s);
+    ln_rows(w.norm_mha, x, n, R, d, 1e-12f, s);
+    lin_cl(w.qkv, n, R, qkv, ACT_NONE, nullptr, s);
     lin_cl(w.pos, pe, P, pp, ACT_NONE, nullptr, s);
-    hipLaunchKernelGGL(add_pos_bias_kernel, dim3(nblk((long long)T * d)), dim3(256), 0, s, qkv, 3 * d, w.bias_u, w.bias_v, qu, qv, T, d);
-    {   // matrix_bd[h] = (q + v)[h] @ p[h]^T  -> [H][T][2T-1]   (attention.py:318)
-        GemmConvArgs a{};
-        a.A = qv; a.a_batch = 64; a.a_len = (long long)T * d; a.lda = d; a.a_off0 = 0; a.tap_step = 0; a.taps = 1; a.K = 64;
-        a.pro = ACT_NONE; a.W = pp; a.Kp = 64; a.ldw = d; a.w_batch = 64; a.bias = nullptr;
-        a.C = bd; a.c_batch = (long long)T * P; a.c_len = (long long)T * P; a.ldc = P; a.c_off = 0; a.M = T; a.N = P;
-        a.act = ACT_NONE; a.res = nullptr; a.out_scale = 1.f; a.row_scale = nullptr; a.accumulate = 0;
-        // a_len is a range check on the flat index of batch b (base + b*64): the last head reads up to T*d - 1 from ITS base
-        a.a_len = (long long)(T - 1) * d + 64;
-        gemm_conv(a, false, H, s);
+    hipLaunchKernelGGL(add_pos_bias_kernel, dim3(nblk(R * d)), dim3(256), 0, s, qkv, 3 * d, w.bias_u, w.bias_v, qu, qv, (int)R, d);
+    for (int u = 0; u < nu; ++u) {
+        const long long r0 = (long long)u * T;
+        {   // matrix_bd[h] = (q + v)[h] @ p[h]^T  -> [H][T][2T-1]   (attention.py:318)
+            GemmConvArgs a{};
+            a.A = qv + r0 * d; a.a_batch = 64; a.a_len = (long long)T * d; a.lda = d; a.a_off0 = 0; a.tap_step = 0; a.taps = 1; a.K = 64;
+            a.pro = ACT_NONE; a.W = pp; a.Kp = 64; a.ldw = d; a.w_batch = 64; a.bias = nullptr;
+            a.C = bd; a.c_batch = (long long)T * P; a.c_len = (long long)T * P; a.ldc = P; a.c_off = 0; a.M = T; a.N = P;
+            a.act = ACT_NONE; a.res = nullptr; a.out_scale = 1.f; a.row_scale = nullptr; a.accumulate = 0;
+            // a_len is a range check on the flat index of batch b (base + b*64): the last head reads up to T*d - 1 from ITS base
+            a.a_len = (long long)(T - 1) * d + 64;
+            gemm_conv(a, false, H, s);
+        }
+        AttnArgs at{};
+        at.q = qu + r0 * d; at.q_batch = 0; at.q_row = d; at.q_head = 64;
+        at.k = qkv + r0 * 3 * d + d; at.k_batch = 0; at.k_row = 3 * d; at.k_head = 64;
+        at.v = qkv + r0 * 3 * d + 2 * d; at.v_batch = 0; at.v_row = 3 * d; at.v_head = 64;
+        at.o = att + r0 * d; at.o_batch = 0; at.o_row = d; at.o_head = 64;
+        at.B = 1; at.H = H; at.kv_group = 1; at.Tq = T; at.Tk = T; at.scale = 0.125f;
+        at.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; at.chunk = chunk;
+        at.rel_bd = bd; at.bd_batch = 0; at.bd_head = (long long)T * P; at.bd_row = P;
+        at.bf16 = tl_bf16_mfma;
+        attention(at, s);
     }
-    AttnArgs at{};
-    at.q = qu; at.q_batch = 0; at.q_row = d; at.q_head = 64;
-    at.k = qkv + d; at.k_batch = 0; at.k_row = 3 * d; at.k_head = 64;
-    at.v = qkv + 2 * d; at.v_batch = 0; at.v_row = 3 * d; at.v_head = 64;
-    at.o = att; at.o_batch = 0; at.o_row = d; at.o_head = 64;
-    at.B = 1; at.H = H; at.kv_group = 1; at.Tq = T; at.Tk = T; at.scale = 0.125f;
-    at.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; at.chunk = chunk;
-    at.rel_bd = bd; at.bd_batch = 0; at.bd_head = (long long)T * P; at.bd_row = P;
-    at.bf16 = tl_bf16_mfma;
-    attention(at, s);
-    lin_cl(w.out, att, T, x, ACT_NONE, x, s);
-    ln_rows(w.norm_ff, x, n, T, d, 1e-12f, s);
-    lin_cl(w.ff1, n, T, ff, ACT_SILU, nullptr, s);
-    lin_cl(w.ff2, ff, T, x, ACT_NONE, x, s);
+    lin_cl(w.out, att, R, x, ACT_NONE, x, s);
+    ln_rows(w.norm_ff, x, n, R, d, 1e-12f, s);
+    lin_cl(w.ff1, n, R, ff, ACT_SILU, nullptr, s);
+    lin_cl(w.ff2, ff, R, x, ACT_NONE, x, s);
 }
 
-// tok_emb [T][d] (already masked), ctx [pre_lookahead][d] or null  ->  h_out [2T][d]
-static void flow_encoder(cv_flow* m, const float* tok_emb, int T, const float* ctx, int streaming, float* h_out, hipStream_t s) {
+// tok_emb [nu][tok_pitch rows][d] (already masked; the first T rows of every utterance are encoded), ctx: the pre_lookahead rows that follow them (row T .. T + la - 1
+// of every utterance) when `has_ctx`, zeros otherwise  ->  h_out [nu][2T][d]
+static void flow_encoder(cv_flow* m, const float* tok_emb, int T, const float* ctx, int streaming, float* h_out, hipStream_t s, int nu = 1, int tok_pitch = 0) {
     const auto& c = m->cfg; const int d = c.dim, la = c.pre_lookahead;
-    CV_CHECK(T > 0, "flow_encoder: empty input");
-    enc_reserve(m, T);
+    CV_CHECK(T > 0 && nu >= 1, "flow_encoder: empty input");
+    if (tok_pitch <= 0) tok_pitch = T;
+    enc_reserve(m, T, nu);
     float* x = m->e_x.as<float>(); float* xe = m->e_xe.as<float>(); float* n = m->e_n.as<float>(); float* pe = m->e_pe.as<float>();
     const float xscale = sqrtf((float)d);
+    const long long R = (long long)nu * T;
+    const size_t rowb = (size_t)d * 4;
     // embed: Linear -> LayerNorm(1e-5) -> * sqrt(d)     (subsampling.py:83-113, embedding.py:256-270)
-    lin_cl(m->embed_lin, tok_emb, T, n, ACT_NONE, nullptr, s);
-    ln_rows(m->embed_ln, n, x, T, d, 1e-5f, s, ACT_NONE, xscale);
+    const float* in = tok_emb;
+    if (nu > 1 && tok_pitch != T) {        // compact the utterances' first T rows (the GEMM takes contiguous rows)
+        CV_HIP(hipMemcpy2DAsync(m->e_x2.p, (size_t)T * rowb, tok_emb, (size_t)tok_pitch * rowb, (size_t)T * rowb, nu, hipMemcpyDeviceToDevice, s));
+        in = m->e_x2.as<float>();
+    }
+    lin_cl(m->embed_lin, in, R, n, ACT_NONE, nullptr, s);
+    ln_rows(m->embed_ln, n, x, R, d, 1e-5f, s, ACT_NONE, xscale);
     hipLaunchKernelGGL(rel_pos_emb_kernel, dim3(2 * T - 1), dim3(256), 0, s, pe, T, d);
-    // PreLookaheadLayer (upsample_encoder.py:82-103): xe = [x ; ctx or zeros], conv1 k=la+1 looks right, leaky_relu(0.01),
+    // PreLookaheadLayer (upsample_encoder.py:82-103): xe = [x ; ctx or zeros] per utterance, conv1 k=la+1 looks right, leaky_relu(0.01),
     // causal conv2 k3, + residual
-    CV_HIP(hipMemcpyAsync(xe, x, (size_t)T * d * 4, hipMemcpyDeviceToDevice, s));
+    CV_HIP(hipMemcpy2DAsync(xe, (size_t)(T + la) * rowb, x, (size_t)T * rowb, (size_t)T * rowb, nu, hipMemcpyDeviceToDevice, s));
     if (ctx) {
-        lin_cl(m->embed_lin, ctx, la, n, ACT_NONE, nullptr, s);
-        ln_rows(m->embed_ln, n, xe + (size_t)T * d, la, d, 1e-5f, s, ACT_NONE, xscale);
+        float* cx = m->e_ctx.as<float>();
+        if (nu > 1) { CV_HIP(hipMemcpy2DAsync(cx, (size_t)la * rowb, ctx, (size_t)tok_pitch * rowb, (size_t)la * rowb, nu, hipMemcpyDeviceToDevice, s)); }
+        lin_cl(m->embed_lin, nu > 1 ? cx : ctx, (long long)nu * la, n, ACT_NONE, nullptr, s);
+        if (nu == 1) ln_rows(m->embed_ln, n, xe + (size_t)T * d, la, d, 1e-5f, s, ACT_NONE, xscale);
+        else {
+            ln_rows(m->embed_ln, n, cx, (long long)nu * la, d, 1e-5f, s, ACT_NONE, xscale);
+            CV_HIP(hipMemcpy2DAsync(xe + (size_t)T * d, (size_t)(T + la) * rowb, cx, (size_t)la * rowb, (size_t)la * rowb, nu, hipMemcpyDeviceToDevice, s));
+        }
     } else {
-        CV_HIP(hipMemsetAsync(xe + (size_t)T * d, 0, (size_t)la * d * 4, s));
+        CV_HIP(hipMemset2DAsync(xe + (size_t)T * d, (size_t)(T + la) * rowb, 0, (size_t)la * rowb, nu, s));
     }
     float* y1 = m->e_x2.as<float>();
-    conv_cl(m->pre1, xe, T + la, T, 1, 0, 1, y1, ACT_LEAKY, 0.01f, nullptr, s);
-    conv_cl(m->pre2, y1, T, T, 1, 2, 1, x, ACT_NONE, 0.f, x, s);          // in-place residual: each element read once, then written
+    conv_cl(m->pre1, xe, T + la, T, nu, 0, 1, y1, ACT_LEAKY, 0.01f, nullptr, s);
+    conv_cl(m->pre2, y1, T, T, nu, 2, 1, x, ACT_NONE, 0.f, x, s);          // in-place residual: each element read once, then written
     const int chunk1 = streaming ? c.chunk : 0;
-    for (auto& w : m->enc) conformer_layer(m, w, x, T, pe, chunk1, s);
-    // Upsample1D: nearest x2 -> left pad 4 -> Conv1d k5  (upsample_encoder.py:59-63)
+    for (auto& w : m->enc) conformer_layer(m, w, x, T, pe, chunk1, s, nu);
+    // Upsample1D: nearest x2 -> left pad 4 -> Conv1d k5  (upsample_encoder.py:59-63); stacked utterances of equal length: output row 2 r + k <- row r
     const int T2 = 2 * T;
-    hipLaunchKernelGGL(upsample2x_kernel, dim3(nblk((long long)T2 * d)), dim3(256), 0, s, x, xe, T, d);
-    conv_cl(m->upconv, xe, T2, T2, 1, 4, 1, n, ACT_NONE, 0.f, nullptr, s);
-    lin_cl(m->up_embed_lin, n, T2, xe, ACT_NONE, nullptr, s);
-    ln_rows(m->up_embed_ln, xe, x, T2, d, 1e-5f, s, ACT_NONE, xscale);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(nblk(2 * R * d)), dim3(256), 0, s, x, xe, (int)R, d);
+    conv_cl(m->upconv, xe, T2, T2, nu, 4, 1, n, ACT_NONE, 0.f, nullptr, s);
+    lin_cl(m->up_embed_lin, n, 2 * R, xe, ACT_NONE, nullptr, s);
+    ln_rows(m->up_embed_ln, xe, x, 2 * R, d, 1e-5f, s, ACT_NONE, xscale);
     hipLaunchKernelGGL(rel_pos_emb_kernel, dim3(2 * T2 - 1), dim3(256), 0, s, pe, T2, d);
     const int chunk2 = streaming ? 2 * c.chunk : 0;
-    for (auto& w : m->enc_up) conformer_layer(m, w, x, T2, pe, chunk2, s);
-    ln_rows(m->after_norm, x, h_out, T2, d, 1e-5f, s);
+    for (auto& w : m->enc_up) conformer_layer(m, w, x, T2, pe, chunk2, s, nu);
+    ln_rows(m->after_norm, x, h_out, 2 * R, d, 1e-5f, s);
 }
 
 // ---- estimator ---------------------------------------------------------------------------------------------------------
@@ -874,6 +897,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "gemm_dbg") { m->gemm_dbg_on = value; if (value) { m->gemm_dbg.ensure((size_t)65536 * 8 * 8); CV_HIP(hipMemset(m->gemm_dbg.p, 0, m->gemm_dbg.bytes)); } drop_graphs(m); }
         else if (std::string(name) == "attn_dbg") { m->attn_dbg_on = value != 0; if (value) { m->attn_dbg.ensure((size_t)65536 * 8 * 8); CV_HIP(hipMemset(m->attn_dbg.p, 0, m->attn_dbg.bytes)); } drop_graphs(m); }
         else if (std::string(name) == "big_lds_epi") { m->big_lds_epi = value != 0; drop_graphs(m); }
+        else if (std::string(name) == "enc_batch") m->enc_batch = value != 0;
         else if (std::string(name) == "big_glds") { m->big_glds = value != 0; drop_graphs(m); }
         else if (std::string(name) == "big_grid_cap") { CV_CHECK(value >= 0, "big_grid_cap must be >= 0"); m->big_grid_cap = value; drop_graphs(m); }
         else if (std::string(name) == "big_tile1") { CV_CHECK(value >= 0 && value <= 3, "big_tile1 must be 0..3"); m->big_tile1 = value; drop_graphs(m); }
@@ -974,24 +998,34 @@ static void flow_inference(cv_flow* m, int nu, const int32_t* token_ids, int n_t
     if (n_tok > m->inf_cap || (long long)n_tok * nu > m->inf_rows) {        // per-utterance buffers follow n_tok, the stacked ones n_tok * nu
         drop_graphs(m);
         const size_t tk = (size_t)std::max(n_tok, m->inf_cap), rows = std::max((size_t)n_tok * nu, (size_t)m->inf_rows);
-        m->f_tok.ensure(tk * d * 4); m->f_h.ensure(2 * tk * d * 4);
+        m->f_tok.ensure(rows * d * 4); m->f_h.ensure(2 * rows * d * 4);          // stacked: the encoder takes all utterances of a pass at once
         m->f_mu.ensure(2 * rows * c.mel * 4); m->f_cond.ensure(2 * rows * c.mel * 4); m->f_x.ensure(2 * rows * c.mel * 4);
         m->f_spk.ensure((size_t)8 * c.mel * 4); m->f_spkn.ensure((size_t)c.spk_dim * 4);
         m->inf_cap = (int)tk; m->inf_rows = (long long)rows;
     }
     const size_t per = (size_t)T * c.mel;
+    // the conformer encoder over all utterances at once (rows stacked; its attention per utterance): same arithmetic per row as the loop below, 1/nu of the launches
+    const bool enc_together = nu > 1 && c.estimator != 1 && m->enc_batch;
+    if (enc_together) {
+        CV_CHECK(cv_gather_rows(m->input_embedding, m->wbf16 ? CV_BF16 : CV_F32, c.vocab, d, token_ids, (long long)nu * n_tok, m->f_tok.as<float>(), 1.f, stream_r) == 0, cv_last_error());
+        const float* ctx = finalize ? nullptr : m->f_tok.as<float>() + (size_t)n_enc * d;
+        flow_encoder(m, m->f_tok.as<float>(), n_enc, ctx, streaming, m->f_h.as<float>(), s, nu, n_tok);
+        lin_cl(m->enc_proj, m->f_h.as<float>(), (long long)nu * T, m->f_mu.as<float>(), ACT_NONE, nullptr, s);
+    }
     for (int u = 0; u < nu; ++u) {
         // x-vector: F.normalize -> Linear(192, 80)  (flow.py:248-249)
         hipLaunchKernelGGL(l2_normalize_kernel, dim3(1), dim3(256), 0, s, embedding + (size_t)u * c.spk_dim, m->f_spkn.as<float>(), c.spk_dim);
         lin_cl(m->spk_affine, m->f_spkn.as<float>(), 1, m->f_spk.as<float>() + (size_t)u * c.mel, ACT_NONE, nullptr, s);
-        // token embedding (mask is all ones for batch 1, flow.py:252-254); gather_rows_kernel lives in llm_kernels.h -> reuse via C ABI
-        CV_CHECK(cv_gather_rows(m->input_embedding, m->wbf16 ? CV_BF16 : CV_F32, c.vocab, d, token_ids + (size_t)u * n_tok, n_tok, m->f_tok.as<float>(), 1.f, stream_r) == 0, cv_last_error());
-        const float* ctx = finalize ? nullptr : m->f_tok.as<float>() + (size_t)n_enc * d;
-        float* mu = m->f_mu.as<float>() + u * per;
-        if (c.estimator == 1) dit_front(m, m->f_tok.as<float>(), n_enc, ctx, mu, s);
-        else {
-            flow_encoder(m, m->f_tok.as<float>(), n_enc, ctx, streaming, m->f_h.as<float>(), s);
-            lin_cl(m->enc_proj, m->f_h.as<float>(), T, mu, ACT_NONE, nullptr, s);
+        if (!enc_together) {
+            // token embedding (mask is all ones for batch 1, flow.py:252-254); gather_rows_kernel lives in llm_kernels.h -> reuse via C ABI
+            CV_CHECK(cv_gather_rows(m->input_embedding, m->wbf16 ? CV_BF16 : CV_F32, c.vocab, d, token_ids + (size_t)u * n_tok, n_tok, m->f_tok.as<float>(), 1.f, stream_r) == 0, cv_last_error());
+            const float* ctx = finalize ? nullptr : m->f_tok.as<float>() + (size_t)n_enc * d;
+            float* mu = m->f_mu.as<float>() + u * per;
+            if (c.estimator == 1) dit_front(m, m->f_tok.as<float>(), n_enc, ctx, mu, s);
+            else {
+                flow_encoder(m, m->f_tok.as<float>(), n_enc, ctx, streaming, m->f_h.as<float>(), s);
+                lin_cl(m->enc_proj, m->f_h.as<float>(), T, mu, ACT_NONE, nullptr, s);
+            }
         }
         hipLaunchKernelGGL(copy_rows_zero_tail_kernel, dim3(nblk((long long)per)), dim3(256), 0, s, prompt_feat + (size_t)u * mel_len1 * c.mel, m->f_cond.as<float>() + u * per,
                            (long long)mel_len1 * c.mel, (long long)per);
@@ -1026,7 +1060,7 @@ static void flow_inference_ragged(cv_flow* m, int nu, const int32_t* token_ids, 
     if (tok_max > m->inf_cap || (long long)tok_max * nu > m->inf_rows) {
         drop_graphs(m);
         const size_t tk = (size_t)std::max(tok_max, m->inf_cap), rows = std::max((size_t)tok_max * nu, (size_t)m->inf_rows);
-        m->f_tok.ensure(tk * d * 4); m->f_h.ensure(2 * tk * d * 4);
+        m->f_tok.ensure(rows * d * 4); m->f_h.ensure(2 * rows * d * 4);          // inf_rows promises the stacked size to flow_inference as well
         m->f_mu.ensure(2 * rows * c.mel * 4); m->f_cond.ensure(2 * rows * c.mel * 4); m->f_x.ensure(2 * rows * c.mel * 4);
         m->f_spk.ensure((size_t)8 * c.mel * 4); m->f_spkn.ensure((size_t)c.spk_dim * 4);
         m->inf_cap = (int)tk; m->inf_rows = (long long)rows;

@@ -355,6 +355,14 @@ hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st) {
     if (S(st)->capturing) { S(st)->cap->push_back(Node{dim3(), dim3(), nullptr, 2, d, nullptr, n, v}); return hipSuccess; }
     memset(d, v, n); return hipSuccess;
 }
+hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind k, hipStream_t st) {
+    for (size_t r = 0; r < h; ++r) hipMemcpyAsync((char*)d + r * dp, (const char*)s + r * sp, w, k, st);
+    return hipSuccess;
+}
+hipError_t hipMemset2DAsync(void* d, size_t dp, int v, size_t w, size_t h, hipStream_t st) {
+    for (size_t r = 0; r < h; ++r) hipMemsetAsync((char*)d + r * dp, v, w, st);
+    return hipSuccess;
+}
 hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }

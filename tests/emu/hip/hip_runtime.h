@@ -77,6 +77,8 @@ hipError_t hipHostFree(void* p);
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);
+hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind k, hipStream_t st);
+hipError_t hipMemset2DAsync(void* d, size_t dpitch, int v, size_t width, size_t height, hipStream_t st);
 hipError_t hipMemset(void* d, int v, size_t n);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipDeviceSynchronize();

@@ -536,6 +536,29 @@ def test_flow_inference_batch_equals_single(lib, precision):
     assert torch.equal(long1, long2)
 
 
+@pytest.mark.parametrize("streaming,finalize", [(True, False), (False, False), (True, True)])
+def test_flow_inference_batch_encoder_together(lib, streaming, finalize):
+    """Round 4: the conformer encoder runs ONCE over the stacked rows of an equal-shape pass (option enc_batch, default on; flow.hip flow_encoder nu > 1):
+    chunk masks, the pre-lookahead context rows that follow every utterance's encoded tokens (finalize = False), and the per-utterance
+    relative-position attention all give each utterance the mel of its single call; enc_batch = 0 (the per-utterance loop) gives the same bits."""
+    import dataclasses
+    cfg = dataclasses.replace(W.tiny()[1], n_timesteps=2)
+    sd = W.make_flow(cfg)
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision="bf16")
+    g = torch.Generator().manual_seed(79)
+    n = lambda k: torch.tensor([k], dtype=torch.int32)
+    items = [dict(token=torch.randint(0, cfg.vocab, (1, 11), generator=g, dtype=torch.int32), prompt_token=torch.randint(0, cfg.vocab, (1, 6), generator=g, dtype=torch.int32),
+                  prompt_feat=torch.randn(1, 12, cfg.mel, generator=g) * 2 - 5, embedding=torch.randn(1, cfg.spk_dim, generator=g)) for _ in range(3)]
+    alone = [flow.inference(token=it["token"], token_len=n(11), prompt_token=it["prompt_token"], prompt_token_len=n(6), prompt_feat=it["prompt_feat"],
+                            prompt_feat_len=n(12), embedding=it["embedding"], streaming=streaming, finalize=finalize)[0].cpu() for it in items]
+    assert not torch.equal(alone[0], alone[1])
+    for on in (1, 0, 1):
+        flow.lib.cv_flow_set_option(flow._h, b"enc_batch", on)
+        got = flow.inference_batch(items, streaming=streaming, finalize=finalize)
+        for a, b in zip(alone, got):
+            assert a.shape == b.shape and torch.equal(a, b.cpu())
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("streaming,finalize", [(False, True), (True, False)])
 def test_flow_inference_ragged_equals_single(lib, precision, streaming, finalize):
