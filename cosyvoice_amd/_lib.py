@@ -44,6 +44,17 @@ class AttnArgs(C.Structure):
     ]
 
 
+class Lm1LayerWeights(C.Structure):
+    """cv_lm1_layer_weights (include/cosyvoice_amd.h)"""
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_out", "b_out", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2")]
+
+
+class Lm1Config(C.Structure):
+    """cv_lm1_config (include/cosyvoice_amd.h)"""
+    _fields_ = [("n_layers", C.c_int32), ("d", C.c_int32), ("heads", C.c_int32), ("ffn", C.c_int32), ("d_in", C.c_int32), ("n_out", C.c_int32),
+                ("act", C.c_int32), ("xscale", C.c_float)] + [(n, C.c_void_p) for n in ("embed_w", "embed_b", "embed_g", "embed_beta", "after_g", "after_b", "dec_w", "dec_b")]
+
+
 CV_F32, CV_BF16, CV_I32, CV_U8 = 0, 1, 2, 3
 ACT = dict(none=0, silu=1, gelu_erf=2, elu=3, leaky=4, tanh=5, mish=6, abs=7, snake=8, logclamp=9, gelu_tanh=10, relu=11)
 MASK = dict(none=0, causal=1, chunk=2)

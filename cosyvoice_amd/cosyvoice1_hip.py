@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from . import cosyvoice1 as C1
-from ._lib import ACT, CV_F32, MASK, AttnArgs, get_lib, stream_ptr
+from ._lib import ACT, CV_F32, MASK, AttnArgs, Lm1Config, Lm1LayerWeights, get_lib, stream_ptr
 from .hift import HiFTGenerator as _KernelHiFT
 from .ops import gemm_conv, norm_rows, pack_weight
 from .weights import split3_planes
@@ -271,6 +271,22 @@ class _KVState:
         self.cap = cap
 
 
+class _FusedStep:
+    """A cv_lm1 handle with the buffers it points into (weights are the encoder's own tensors; `keep` holds the argument structs and the decoder matrix)."""
+
+    def __init__(self, lib, h, logits, keep):
+        self.lib, self.h, self.logits, self.keep, self.bound = lib, h, logits, keep, None
+
+    def stat(self, name):
+        return int(self.lib.raw("cv_lm1_stat", C.c_int64)(self.h, name.encode()))
+
+    def __del__(self):
+        try:
+            self.lib.raw("cv_lm1_destroy", None)(self.h)
+        except Exception:                                       # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 class EspnetEncoder(C1.EspnetEncoder):
     """cosyvoice1.EspnetEncoder with every operation on the kernels.  Head size must be 64 (cv_attention): 1024 / 16 and 512 / 8 in CosyVoice-300M."""
 
@@ -368,6 +384,48 @@ class EspnetEncoder(C1.EspnetEncoder):
         state.len += t1
         return y, state
 
+    # ---- the decode step as ONE library call (csrc/lm1.hip: 3 + 5 launches per layer inside a hipGraph instead of 3 + 8 per layer replayed from here) -----------
+    def make_step(self, decoder):
+        """cv_lm1 handle over this encoder's weights + the LM's decoder matrix (`decoder`: _Mat [n_out, d]).  None when the shapes are outside what the fused
+        step serves (it is an acceleration of forward_chunk + decoder, not another model): d > 1024, feed-forward > 4096."""
+        K, L0 = self.k, self.layers[0]
+        if self.kind != "transformer" or self.d > 1024 or L0["w1"].n > 4096 or self.embed.k > 4096 or self.embed.k % 4 or K.split3:
+            return None
+        lw = (Lm1LayerWeights * self.n_layers)()
+        for i, L in enumerate(self.layers):
+            for name, t in (("ln1_g", L["ln1"][0]), ("ln1_b", L["ln1"][1]), ("w_qkv", L["qkv"].w), ("b_qkv", L["qkv"].b), ("w_out", L["out"].w), ("b_out", L["out"].b),
+                            ("ln2_g", L["ln2"][0]), ("ln2_b", L["ln2"][1]), ("w1", L["w1"].w), ("b1", L["w1"].b), ("w2", L["w2"].w), ("b2", L["w2"].b)):
+                setattr(lw[i], name, t.data_ptr())
+        c = Lm1Config()
+        c.n_layers, c.d, c.heads, c.ffn, c.d_in, c.n_out = self.n_layers, self.d, self.heads, L0["w1"].n, self.embed.k, decoder.n
+        c.act, c.xscale = ACT["relu"], math.sqrt(self.d)
+        for name, t in (("embed_w", self.embed.w), ("embed_b", self.embed.b), ("embed_g", self.embed_ln[0]), ("embed_beta", self.embed_ln[1]),
+                        ("after_g", self.after[0]), ("after_b", self.after[1]), ("dec_w", decoder.w), ("dec_b", decoder.b)):
+            setattr(c, name, t.data_ptr())
+        real = getattr(K.lib, "_lib", K.lib)
+        h = real.raw("cv_lm1_create", C.c_void_p)(C.byref(c), lw)
+        if not h:
+            real.check(1)
+        step = _FusedStep(real, C.c_void_p(h), K.new(decoder.n), (c, lw, decoder))
+        return step
+
+    def fused_step(self, step, xs, state):
+        """One decode row through `step` (make_step): cache row state.len of every layer is written, logits land in step.logits (valid until the next call)."""
+        K, t0 = self.k, state.len
+        state.reserve(t0 + 1)
+        self._pos_tables(state.cap)                             # the tables cover every position the cache can hold: n_tab >= cap
+        key = (state.cap, self._pos_n) + tuple(r.data_ptr() for r in state.rows)
+        if step.bound != key:
+            n = self.n_layers
+            rows = (C.c_void_p * n)(*[r.data_ptr() for r in state.rows])
+            tabs = (C.c_void_p * n)(*[t.data_ptr() for t in self._pos_tab])
+            step.lib.cv_lm1_bind(step.h, rows, tabs, C.c_int32(self._pos_n), C.c_int32(state.cap), stream_ptr(step.lib))
+            step.bound = key
+        step.lib.cv_lm1_step(step.h, C.c_void_p(xs.data_ptr()), C.c_int32(t0), C.c_void_p(step.logits.data_ptr()), stream_ptr(step.lib))
+        state.len += 1
+        state.plan = None
+        return step.logits
+
     def _forward_rows(self, xs, t1, state, t0):
         x = self._embed(xs, t1)
         for i in range(self.n_layers):
@@ -406,6 +464,9 @@ class TransformerLM(C1.TransformerLM):
         self.affine = K.mat(sd["text_encoder_affine_layer.weight"], sd["text_encoder_affine_layer.bias"])
         self.spk_affine = K.mat(sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"])
         self.decoder = K.mat(sd["llm_decoder.weight"], sd["llm_decoder.bias"])
+        # the decode step behind one C entry point (cv_lm1_step); fused_step = False keeps the launch-per-operator tape (A/B and test knob)
+        self.step = self.llm.make_step(self.decoder)
+        self.fused_step = self.step is not None
         self.lock = threading.Lock()                             # one Kernels object (its recorder, its workspaces) per stage: requests on one stage object are serialised
 
     def encode_text(self, ids):
@@ -439,8 +500,11 @@ class TransformerLM(C1.TransformerLM):
         out_tokens, state, x = [], None, lm_input
         for i in range(max_len):
             with self.lock:
-                y, state = self.llm.forward_chunk(x, state)
-                logits = K.linear(y[-1:], self.decoder, 1)
+                if self.fused_step and state is not None and x.shape[0] == 1 and x.is_contiguous():
+                    logits = self.llm.fused_step(self.step, x, state)
+                else:
+                    y, state = self.llm.forward_chunk(x, state)
+                    logits = K.linear(y[-1:], self.decoder, 1)
                 logp = logits.reshape(-1).cpu().log_softmax(dim=-1)    # the sampler draws from the host RNG, like the reference's python sampler
             if i < min_len:
                 logp[self.speech_token_size] = -float("inf")

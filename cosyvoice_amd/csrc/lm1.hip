@@ -1,0 +1,400 @@
+// CosyVoice-300M TransformerLM decode step behind ONE C entry point (reference: cosyvoice/llm/llm.py:162-223 TransformerLM.inference ->
+// cosyvoice/transformer/encoder.py:267-327 forward_chunk -> encoder_layer.py:60-119 -> attention.py:200-330 RelPositionMultiHeadedAttention with its key / value cache).
+//
+// The step is one output row through 14 pre-norm layers over fp32 weights: 734 MB of weights per token, nothing else of size.  Until round 4 the host side
+// (cosyvoice1_hip.py) replayed it as 115 launches of the general operators (LayerNorm, tiled GEMM -> GEMV, the [H][1][n] matrix_bd GEMM, the MFMA attention
+// with one useful query row); what bounded it was the NUMBER of dependent launches, not their bytes.  Here the step is 73 launches inside one hipGraph:
+//     per layer   [LayerNorm + (q+u | q+v | k | v) GEMV -> the layer's cache row]  [one-query relative-position attention, keys split over 4 workgroups per head]
+//                 [merge of the 4 partial softmaxes + output GEMV + residual]  [LayerNorm + w_1 GEMV + ReLU]  [w_2 GEMV + residual]
+//     around it   [embed GEMV] [LayerNorm + ReLU, * sqrt(d)] ... [after_norm + decoder GEMV -> logits]
+// The GEMV is gemm_conv.h's gemv_f32_kernel (same lane / wave / k order, same four-way combine) with its input vector staged in LDS by a prologue; the LayerNorm
+// prologue repeats norm_rows_kernel's register path arithmetic, so every product of the step has the bits of the launch-per-operator path.  The attention is a
+// new summation order (exact fp32 dot products per key instead of the MFMA chain): results agree to fp32 rounding.
+// What changes from token to token - the position, i.e. the cache row written, the key count and the first row of the relative-position table - is read by
+// the kernels from a device block (Lm1Dyn) that the step's FIRST kernel (launched outside the graph, it also takes the input row's address) updates; what
+// changes from request to request - the cache and table buffers - is rebound there by cv_lm1_bind.  One captured graph therefore serves every step of every request.
+#include "api_common.h"
+#include "common.h"
+#include <vector>
+
+namespace cv {
+
+constexpr int LM1_MAX_LAYERS = 32;
+constexpr int LM1_SPLITS = 4;                 // key ranges per head in the decode attention
+constexpr int LM1_MAX_KEYS_PER_SPLIT = 2048;  // scores of one split live in LDS
+#define LM1_NEG_INF (-__builtin_huge_valf())
+constexpr int LM1_MAX_K = 4096;               // longest GEMV input (the feed-forward width)
+
+struct Lm1Dyn {
+    int pos, n_tab, pad0, pad1;
+    float* rows[LM1_MAX_LAYERS];              // per layer [cap][4 d]: (q + u | q + v | k | v) of every position so far
+    const float* tabs[LM1_MAX_LAYERS];        // per layer [2 n_tab - 1][d]: linear_pos(pe), row m = relative position n_tab - 1 - m
+};
+
+enum { LM1_PRO_NONE = 0, LM1_PRO_LN = 1, LM1_PRO_MERGE = 2 };
+
+struct Lm1GemvArgs {
+    const float* x;                            // [K] (NONE / LN) or the attention partials [heads][LM1_SPLITS][66] (MERGE)
+    const float* g; const float* b; float eps; // LN prologue
+    const float* W; long long ldw; const float* bias; const float* res; float* y;
+    Lm1Dyn* dyn; int layer;                    // layer >= 0: y = dyn->rows[layer] + pos * N   (the cache row of this position)
+    int set_pos;                               // >= 0: block 0 publishes the step's position (first kernel of a step)
+    int N, K, Kp, act, pro;
+};
+
+// y[N] = act(pro(x)[K] . W[N][K]^T + bias) (+ res).  4 output rows per workgroup, a 16-lane group per row, the 4 waves split K (gemv_f32_kernel).
+// U: 64-float steps a lane group has in flight (a wave's share of K = 1024 is 4 steps).  The wave's FIRST group of weight loads is issued before the prologue:
+// the weights do not depend on the previous kernel's output, the input vector does, so the prologue's dependent loads (x, gamma, beta) wait under them.
+template <int U>
+static __global__ __launch_bounds__(256) void lm1_gemv_kernel(Lm1GemvArgs p) {
+    __shared__ float xs[LM1_MAX_K + 64];
+    __shared__ float part[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
+    const int steps = (p.Kp + 63) / 64;
+    if (p.set_pos >= 0 && blockIdx.x == 0 && tid == 0) p.dyn->pos = p.set_pos;
+    const int row = min((int)blockIdx.x * 4 + grp, p.N - 1);      // clamped: the reductions are wave collectives
+    const int s0 = wave * steps / 4, s1 = (wave + 1) * steps / 4;
+    const float* wr = p.W + (long long)row * p.ldw;
+    v4f w[U], wn[U];
+    auto load_w = [&](v4f (&dst)[U], int sb) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)                             // unconditional loads (clamped step) keep the vmcnt bookkeeping exact
+            dst[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(wr + min(min(sb + u, s1 - 1) * 64 + sub * 4, p.Kp - 4)));
+    };
+    if (s0 < s1) load_w(w, s0);
+    // ---- prologue: the input vector into LDS, zero beyond K up to the last 64-float step
+    if (p.pro == LM1_PRO_LN) {
+        // norm_rows_kernel's register path (C <= 1024, C % 4 == 0), every wave on the whole row; wave w parks chunk w
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = lane * 4 + k * 256;
+            const float4 t = *reinterpret_cast<const float4*>(p.x + min(c, p.K - 4));        // unconditional (clamped) loads: all four in flight together
+            const bool ok = c < p.K;
+            v[k] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+        }
+        const int cw = lane * 4 + wave * 256;                   // gamma / beta of the wave's chunk travel with the row, not after the statistics
+        const float4 gw = *reinterpret_cast<const float4*>(p.g + min(cw, p.K - 4)), bw = *reinterpret_cast<const float4*>(p.b + min(cw, p.K - 4));
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (lane * 4 + k * 256 < p.K) s += v[k].x + v[k].y + v[k].z + v[k].w;
+        s = wave_sum(s);
+        const float mean = s / (float)p.K;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (lane * 4 + k * 256 < p.K) { const float a = v[k].x - mean, b = v[k].y - mean, cc = v[k].z - mean, d = v[k].w - mean; q += a * a + b * b + cc * cc + d * d; }
+        q = wave_sum(q);
+        const float rstd = rsqrtf(q / (float)p.K + p.eps);
+        {
+            // the chunk this wave parks (same expressions as norm_rows_kernel's epilogue)
+            const float4 vw = make_float4(wave == 0 ? v[0].x : wave == 1 ? v[1].x : wave == 2 ? v[2].x : v[3].x, wave == 0 ? v[0].y : wave == 1 ? v[1].y : wave == 2 ? v[2].y : v[3].y,
+                                          wave == 0 ? v[0].z : wave == 1 ? v[1].z : wave == 2 ? v[2].z : v[3].z, wave == 0 ? v[0].w : wave == 1 ? v[1].w : wave == 2 ? v[2].w : v[3].w);
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            if (cw < p.K) {
+                o[0] = (vw.x - mean) * rstd; o[1] = (vw.y - mean) * rstd; o[2] = (vw.z - mean) * rstd; o[3] = (vw.w - mean) * rstd;
+                o[0] *= gw.x; o[1] *= gw.y; o[2] *= gw.z; o[3] *= gw.w;
+                o[0] += bw.x; o[1] += bw.y; o[2] += bw.z; o[3] += bw.w;
+            }
+            if (cw < steps * 64) *reinterpret_cast<float4*>(&xs[cw]) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    } else if (p.pro == LM1_PRO_MERGE) {
+        // x[h * 64 + d] = sum_s acc_s[d] e^(m_s - M) / sum_s l_s e^(m_s - M): the key splits of one head's softmax, in split order
+        for (int e = tid; e < steps * 64; e += 256) {
+            float o = 0.f;
+            if (e < p.K) {
+                const float* ph = p.x + (long long)(e >> 6) * LM1_SPLITS * 66;
+                float ms[LM1_SPLITS], ls[LM1_SPLITS], as[LM1_SPLITS];
+#pragma unroll
+                for (int s = 0; s < LM1_SPLITS; ++s) { ms[s] = ph[s * 66]; ls[s] = ph[s * 66 + 1]; as[s] = ph[s * 66 + 2 + (e & 63)]; }
+                float M = LM1_NEG_INF;
+#pragma unroll
+                for (int s = 0; s < LM1_SPLITS; ++s) M = fmaxf(M, ms[s]);
+                float L = 0.f, a = 0.f;
+#pragma unroll
+                for (int s = 0; s < LM1_SPLITS; ++s) {
+                    const float w = (ms[s] == LM1_NEG_INF) ? 0.f : expf(ms[s] - M);
+                    L += ls[s] * w; a += as[s] * w;
+                }
+                o = a / L;
+            }
+            xs[e] = o;
+        }
+    } else {
+        for (int e = tid * 4; e < steps * 64; e += 1024) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < p.K) t = *reinterpret_cast<const float4*>(p.x + e);           // K % 4 == 0
+            *reinterpret_cast<float4*>(&xs[e]) = t;
+        }
+    }
+    __syncthreads();
+    // ---- the rows' dot products (gemv_f32_kernel: same loads, same order)
+    float acc = 0.f;
+    for (int sb = s0; sb < s1; sb += U) {
+        const bool more = sb + U < s1;
+        if (more) load_w(wn, sb + U);                           // the next group is requested before this one is consumed
+        float4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = min(sb + u, s1 - 1) * 64 + sub * 4;
+            x[u] = *reinterpret_cast<const float4*>(&xs[k]);
+            if (sb + u >= s1) x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { acc += w[u][0] * x[u].x; acc += w[u][1] * x[u].y; acc += w[u][2] * x[u].z; acc += w[u][3] * x[u].w; }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) w[u] = wn[u];
+        }
+    }
+    acc = group16_sum(acc);
+    if (sub == 0) part[wave][grp] = acc;
+    __syncthreads();
+    if (wave != 0 || sub != 0) return;
+    const int n = (int)blockIdx.x * 4 + grp;
+    if (n >= p.N) return;
+    float v = ((part[0][grp] + part[1][grp]) + part[2][grp]) + part[3][grp];
+    if (p.bias) v += p.bias[n];
+    v = apply_act(p.act, v, 0.f);
+    if (p.res) v += p.res[n];
+    float* y = p.layer >= 0 ? p.dyn->rows[p.layer] + (long long)p.dyn->pos * p.N : p.y;
+    y[n] = v;
+}
+
+// LayerNorm -> activation -> * scale of one row (the input layer's norm; its output is the residual stream, so it is materialised)
+struct Lm1NormArgs { const float* x; float* y; const float* g; const float* b; float eps, scale; int C, act; };
+static __global__ __launch_bounds__(64) void lm1_norm_kernel(Lm1NormArgs p) {
+    const int lane = threadIdx.x;
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = lane * 4 + k * 256;
+        v[k] = c < p.C ? *reinterpret_cast<const float4*>(p.x + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (lane * 4 + k * 256 < p.C) s += v[k].x + v[k].y + v[k].z + v[k].w;
+    s = wave_sum(s);
+    const float mean = s / (float)p.C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (lane * 4 + k * 256 < p.C) { const float a = v[k].x - mean, b = v[k].y - mean, cc = v[k].z - mean, d = v[k].w - mean; q += a * a + b * b + cc * cc + d * d; }
+    q = wave_sum(q);
+    const float rstd = rsqrtf(q / (float)p.C + p.eps);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = lane * 4 + k * 256;
+        if (c >= p.C) continue;
+        float o[4] = {(v[k].x - mean) * rstd, (v[k].y - mean) * rstd, (v[k].z - mean) * rstd, (v[k].w - mean) * rstd};
+        const float4 g = *reinterpret_cast<const float4*>(p.g + c); o[0] *= g.x; o[1] *= g.y; o[2] *= g.z; o[3] *= g.w;
+        const float4 b = *reinterpret_cast<const float4*>(p.b + c); o[0] += b.x; o[1] += b.y; o[2] += b.z; o[3] += b.w;
+        const float4 t = apply_act4(p.act, make_float4(o[0], o[1], o[2], o[3]), 0.f);
+        *reinterpret_cast<float4*>(p.y + c) = make_float4(t.x * p.scale, t.y * p.scale, t.z * p.scale, t.w * p.scale);
+    }
+}
+
+// One query (the row at `pos`), head h, key range s of LM1_SPLITS:  score_j = ((q + u) . k_j + (q + v) . p_(n - 1 - j)) * scale  (attention.py:300-326; for the last
+// query rel_shift leaves column j = relative position n - 1 - j), partial softmax (m, l, acc[64]) over the range -> part[h][s][66].
+struct Lm1AttnArgs { const Lm1Dyn* dyn; int layer, d, heads; float scale; float* part; };
+static __global__ __launch_bounds__(256) void lm1_attn_kernel(Lm1AttnArgs p) {
+    __shared__ float sc[LM1_MAX_KEYS_PER_SPLIT];
+    __shared__ float red[16];
+    __shared__ float accs[4][64];
+    const int h = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, sub = tid & 15, kg = tid >> 4;
+    const int pos = p.dyn->pos, n = pos + 1, d = p.d;
+    const int per = (n + LM1_SPLITS - 1) / LM1_SPLITS, j0 = min(n, s * per), j1 = min(n, j0 + per), cnt = j1 - j0;
+    const float* rows = p.dyn->rows[p.layer];
+    const float* qrow = rows + (long long)pos * 4 * d + h * 64;
+    const float* tab = p.dyn->tabs[p.layer] + (long long)(p.dyn->n_tab - n) * d + h * 64;
+    float* out = p.part + ((long long)h * LM1_SPLITS + s) * 66;
+    const float4 qu = *reinterpret_cast<const float4*>(qrow + sub * 4), qv = *reinterpret_cast<const float4*>(qrow + d + sub * 4);
+    // pass 1: scores of the range, 16 keys per sweep (a 16-lane group per key, 4 of the 64 dimensions per lane), 2 sweeps in flight
+    float mt = LM1_NEG_INF;
+    for (int i0 = 0; i0 < cnt; i0 += 32) {
+        float4 kx[2], px[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = j0 + min(i0 + u * 16 + kg, cnt - 1);
+            kx[u] = *reinterpret_cast<const float4*>(rows + (long long)j * 4 * d + 2 * d + h * 64 + sub * 4);
+            px[u] = *reinterpret_cast<const float4*>(tab + (long long)j * d + sub * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float a = qu.x * kx[u].x; a += qu.y * kx[u].y; a += qu.z * kx[u].z; a += qu.w * kx[u].w;
+            float b = qv.x * px[u].x; b += qv.y * px[u].y; b += qv.z * px[u].z; b += qv.w * px[u].w;
+            const float sc_j = (group16_sum(a) + group16_sum(b)) * p.scale;
+            const int i = i0 + u * 16 + kg;
+            if (i < cnt) { if (sub == 0) sc[i] = sc_j; mt = fmaxf(mt, sc_j); }
+        }
+    }
+    const float m = block_max(mt, red);
+    __syncthreads();
+    float lt = 0.f;
+    for (int i = tid; i < cnt; i += 256) { const float e = expf(sc[i] - m); sc[i] = e; lt += e; }
+    const float l = block_sum(lt, red);
+    __syncthreads();
+    // pass 2: acc[dd] = sum_j e_j v_j[dd]: thread = (key residue of 4, dimension), rows of 256 B
+    const int dd = tid & 63, kr = tid >> 6;
+    float a = 0.f;
+    for (int i = kr; i < cnt; i += 4) a += sc[i] * rows[(long long)(j0 + i) * 4 * d + 3 * d + h * 64 + dd];
+    accs[kr][dd] = a;
+    __syncthreads();
+    if (tid < 64) out[2 + tid] = ((accs[0][tid] + accs[1][tid]) + accs[2][tid]) + accs[3][tid];
+    if (tid == 0) { out[0] = cnt > 0 ? m : LM1_NEG_INF; out[1] = cnt > 0 ? l : 0.f; }
+}
+
+static __global__ void lm1_bind_kernel(Lm1Dyn* dyn, Lm1Dyn v) { if (threadIdx.x == 0 && blockIdx.x == 0) *dyn = v; }
+
+struct Lm1Layer {
+    const float *ln1_g, *ln1_b, *w_qkv, *b_qkv, *w_out, *b_out, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2;
+};
+
+}  // namespace cv
+
+using namespace cv;
+
+struct cv_lm1 {
+    int n_layers = 0, d = 0, heads = 0, ffn = 0, d_in = 0, n_out = 0, act = 0, cap = 0;
+    float xscale = 1.f;
+    std::vector<Lm1Layer> L;
+    const float *embed_w = nullptr, *embed_b = nullptr, *embed_g = nullptr, *embed_beta = nullptr, *after_g = nullptr, *after_b = nullptr, *dec_w = nullptr, *dec_b = nullptr;
+    DevBuf dyn, x0, x1, h, ff, part;
+    hipGraphExec_t graph = nullptr; float* graph_logits = nullptr; hipStream_t graph_stream = nullptr;
+    hipStream_t own_stream = nullptr;          // a NULL stream argument means this (blocking) stream: it orders itself against the legacy default stream, and it can be captured
+    int use_graph = 1, bound = 0;
+    long long steps = 0, graph_replays = 0;
+    ~cv_lm1() { if (graph) (void)hipGraphExecDestroy(graph); if (own_stream) (void)hipStreamDestroy(own_stream); }
+};
+
+namespace {
+
+inline int kp_of(int K) { return (K + 31) / 32 * 32; }
+
+hipStream_t resolve(cv_lm1* m, void* s) {
+    if (s) return as_stream(s);
+    if (!m->own_stream) CV_HIP(hipStreamCreate(&m->own_stream));
+    return m->own_stream;
+}
+
+void gemv(cv_lm1* m, int pro, const float* x, const float* g, const float* b, float eps, const float* W, const float* bias, const float* res, float* y, int layer,
+          int set_pos, int N, int K, int act, hipStream_t s) {
+    CV_CHECK(K % 4 == 0 && K <= LM1_MAX_K && (pro != LM1_PRO_LN || K <= 1024), "cv_lm1: a GEMV input of up to 4096 floats (1024 under the LayerNorm prologue), K % 4 == 0");
+    Lm1GemvArgs a{x, g, b, eps, W, (long long)kp_of(K), bias, res, y, m->dyn.as<Lm1Dyn>(), layer, set_pos, N, K, kp_of(K), act, pro};
+    if ((kp_of(K) + 63) / 64 <= 16) hipLaunchKernelGGL(lm1_gemv_kernel<4>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(lm1_gemv_kernel<8>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a);
+}
+
+// everything of a step after its first kernel
+void step_body(cv_lm1* m, float* logits, hipStream_t s) {
+    const int d = m->d;
+    float* x0 = m->x0.as<float>(); float* x1 = m->x1.as<float>(); float* h = m->h.as<float>(); float* ff = m->ff.as<float>(); float* part = m->part.as<float>();
+    hipLaunchKernelGGL(lm1_norm_kernel, dim3(1), dim3(64), 0, s, Lm1NormArgs{h, x0, m->embed_g, m->embed_beta, 1e-5f, m->xscale, d, m->act});
+    for (int i = 0; i < m->n_layers; ++i) {
+        const Lm1Layer& L = m->L[i];
+        gemv(m, LM1_PRO_LN, x0, L.ln1_g, L.ln1_b, 1e-12f, L.w_qkv, L.b_qkv, nullptr, nullptr, i, -1, 4 * d, d, ACT_NONE, s);
+        hipLaunchKernelGGL(lm1_attn_kernel, dim3(m->heads, LM1_SPLITS), dim3(256), 0, s, Lm1AttnArgs{m->dyn.as<Lm1Dyn>(), i, d, m->heads, 0.125f, part});
+        gemv(m, LM1_PRO_MERGE, part, nullptr, nullptr, 0.f, L.w_out, L.b_out, x0, x1, -1, -1, d, d, ACT_NONE, s);
+        gemv(m, LM1_PRO_LN, x1, L.ln2_g, L.ln2_b, 1e-12f, L.w1, L.b1, nullptr, ff, -1, -1, m->ffn, d, m->act, s);
+        gemv(m, LM1_PRO_NONE, ff, nullptr, nullptr, 0.f, L.w2, L.b2, x1, x0, -1, -1, d, m->ffn, ACT_NONE, s);
+    }
+    gemv(m, LM1_PRO_LN, x0, m->after_g, m->after_b, 1e-5f, m->dec_w, m->dec_b, nullptr, logits, -1, -1, m->n_out, d, ACT_NONE, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+cv_lm1* cv_lm1_create(const cv_lm1_config* c, const cv_lm1_layer_weights* layers) {
+    cv_lm1* m = nullptr;
+    int rc = guarded([&] {
+        CV_CHECK(c && layers, "cv_lm1_create: null argument");
+        CV_CHECK(c->n_layers >= 1 && c->n_layers <= LM1_MAX_LAYERS, "cv_lm1_create: 1..32 layers");
+        CV_CHECK(c->d == c->heads * 64 && c->d <= 1024 && c->d % 4 == 0, "cv_lm1_create: 64-wide heads, model width up to 1024");
+        CV_CHECK(c->ffn % 4 == 0 && c->ffn <= LM1_MAX_K && c->d_in % 4 == 0 && c->d_in <= LM1_MAX_K && c->n_out >= 1, "cv_lm1_create: widths");
+        CV_CHECK(c->act == CV_ACT_RELU || c->act == CV_ACT_SILU || c->act == CV_ACT_NONE, "cv_lm1_create: activation");
+        auto ok = [](const void* p) { return p && aligned16(p); };
+        m = new cv_lm1();
+        m->n_layers = c->n_layers; m->d = c->d; m->heads = c->heads; m->ffn = c->ffn; m->d_in = c->d_in; m->n_out = c->n_out; m->act = c->act; m->xscale = c->xscale;
+        for (int i = 0; i < c->n_layers; ++i) {
+            const cv_lm1_layer_weights& w = layers[i];
+            CV_CHECK(ok(w.ln1_g) && ok(w.ln1_b) && ok(w.w_qkv) && ok(w.b_qkv) && ok(w.w_out) && ok(w.b_out) && ok(w.ln2_g) && ok(w.ln2_b) && ok(w.w1) && ok(w.b1) && ok(w.w2) && ok(w.b2),
+                     "cv_lm1_create: every layer tensor present and 16B aligned");
+            m->L.push_back(Lm1Layer{w.ln1_g, w.ln1_b, w.w_qkv, w.b_qkv, w.w_out, w.b_out, w.ln2_g, w.ln2_b, w.w1, w.b1, w.w2, w.b2});
+        }
+        CV_CHECK(ok(c->embed_w) && ok(c->embed_b) && ok(c->embed_g) && ok(c->embed_beta) && ok(c->after_g) && ok(c->after_b) && ok(c->dec_w) && ok(c->dec_b),
+                 "cv_lm1_create: input layer / after_norm / decoder tensors present and 16B aligned");
+        m->embed_w = c->embed_w; m->embed_b = c->embed_b; m->embed_g = c->embed_g; m->embed_beta = c->embed_beta;
+        m->after_g = c->after_g; m->after_b = c->after_b; m->dec_w = c->dec_w; m->dec_b = c->dec_b;
+        m->dyn.ensure(sizeof(Lm1Dyn)); m->x0.ensure((size_t)c->d * 4); m->x1.ensure((size_t)c->d * 4); m->h.ensure((size_t)c->d * 4);
+        m->ff.ensure((size_t)c->ffn * 4); m->part.ensure((size_t)c->heads * LM1_SPLITS * 66 * 4);
+        CV_HIP(hipMemset(m->dyn.p, 0, sizeof(Lm1Dyn)));
+        if (const char* e = getenv("CV_LM1_GRAPH")) m->use_graph = atoi(e) != 0;
+    });
+    if (rc != 0) { delete m; return nullptr; }
+    return m;
+}
+
+void cv_lm1_destroy(cv_lm1* m) { delete m; }
+
+int cv_lm1_bind(cv_lm1* m, float* const* rows, const float* const* tabs, int32_t n_tab, int32_t cap, void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && rows && tabs, "cv_lm1_bind: null argument");
+        CV_CHECK(cap >= 1 && cap <= LM1_SPLITS * LM1_MAX_KEYS_PER_SPLIT, "cv_lm1_bind: a cache of up to 8192 positions");
+        CV_CHECK(n_tab >= cap, "cv_lm1_bind: the relative-position tables must cover the cache (n_tab >= cap)");
+        Lm1Dyn v{};
+        v.pos = 0; v.n_tab = n_tab;
+        for (int i = 0; i < m->n_layers; ++i) {
+            CV_CHECK(rows[i] && tabs[i] && aligned16(rows[i]) && aligned16(tabs[i]), "cv_lm1_bind: cache / table buffers present and 16B aligned");
+            v.rows[i] = rows[i]; v.tabs[i] = tabs[i];
+        }
+        hipLaunchKernelGGL(lm1_bind_kernel, dim3(1), dim3(64), 0, resolve(m, stream), m->dyn.as<Lm1Dyn>(), v);
+        m->cap = cap; m->bound = 1;
+    });
+}
+
+int cv_lm1_step(cv_lm1* m, const float* x_row, int32_t pos, float* logits, void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && x_row && logits && aligned16(x_row), "cv_lm1_step: null / unaligned argument");
+        CV_CHECK(m->bound, "cv_lm1_step: cv_lm1_bind first");
+        CV_CHECK(pos >= 0 && pos < m->cap, "cv_lm1_step: position beyond the bound cache");
+        hipStream_t s = resolve(m, stream);
+        // first kernel: the input layer's Linear on the caller's row; it publishes the position the rest of the step reads
+        gemv(m, LM1_PRO_NONE, x_row, nullptr, nullptr, 0.f, m->embed_w, m->embed_b, nullptr, m->h.as<float>(), -1, pos, m->d, m->d_in, ACT_NONE, s);
+        ++m->steps;
+        if (!m->use_graph) { step_body(m, logits, s); return; }
+        if (!m->graph || m->graph_logits != logits || m->graph_stream != s) {
+            std::lock_guard<std::recursive_mutex> lk(runtime_lock());
+            if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+            hipGraph_t g = capture_graph(s, [&] { step_body(m, logits, s); });
+            hipError_t e = hipGraphInstantiate(&m->graph, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) { m->graph = nullptr; CV_HIP(e); }
+            m->graph_logits = logits; m->graph_stream = s;
+        }
+        { std::lock_guard<std::recursive_mutex> lk(runtime_lock()); CV_HIP(hipGraphLaunch(m->graph, s)); }
+        ++m->graph_replays;
+    });
+}
+
+int64_t cv_lm1_stat(const cv_lm1* m, const char* name) {
+    if (!m || !name) return -1;
+    const std::string n(name);
+    if (n == "steps") return m->steps;
+    if (n == "graph_replays") return m->graph_replays;
+    if (n == "launches_per_step") return 3 + 5LL * m->n_layers;
+    return -1;
+}
+
+int cv_lm1_set_option(cv_lm1* m, const char* name, int32_t value) {
+    return guarded([&] {
+        CV_CHECK(m && name, "cv_lm1_set_option: null argument");
+        const std::string n(name);
+        if (n == "graph") m->use_graph = value != 0;
+        else CV_CHECK(false, "cv_lm1_set_option: unknown option");
+    });
+}
+
+}  // extern "C"

@@ -333,6 +333,38 @@ int cv_interp_rows(const float* x, float* y, int32_t C, int32_t T, int32_t Tn, i
 /* out [cols][rows] = in [rows][cols] transposed (channel-last <-> channel-first at the API boundary). */
 int cv_transpose(const float* in, float* out, int32_t rows, int32_t cols, void* stream);
 
+/* The decode step of CosyVoice-300M's TransformerLM as ONE call (round 4): replaces, per generated token, `self.llm.forward_chunk(lm_input, ..., att_cache, cnn_cache)`
+ * + `self.llm_decoder(y_pred[:, -1])` of TransformerLM.inference (cosyvoice/llm/llm.py:206-212; transformer/encoder.py:267-327 forward_chunk,
+ * encoder_layer.py:60-119, attention.py:200-330 RelPositionMultiHeadedAttention with its key / value cache).  Prefill (the first forward_chunk over the whole
+ * prompt) stays on cv_gemm_conv / cv_norm_rows / cv_attention and fills the same cache buffers; the sampler (ras_sampling, cosyvoice/utils/common.py:109-131)
+ * stays with the caller, as in the reference.  All weights: dev fp32, row pitch = K rounded up to 32 floats, zero padded (cv_gemm_conv's fp32 layout), owned by the caller
+ * and kept alive as long as the handle.
+ *   w_qkv / b_qkv : [4 d][d] rows (linear_q | linear_q | linear_k | linear_v), bias (b_q + pos_bias_u | b_q + pos_bias_v | b_k | b_v) - the layer's cache row is
+ *                   (q + u | q + v | k | v), what attention.py:300-318 forms from q;
+ *   cache rows    : per layer dev [cap][4 d] (cv_lm1_bind), rows 0 .. pos - 1 filled by the prefill and the earlier steps;
+ *   tabs          : per layer dev [2 n_tab - 1][d] = linear_pos(pos_emb), row m = relative position n_tab - 1 - m (embedding.py:143-160), n_tab >= cap.
+ * cv_lm1_step(x_row dev [d_in], pos) : input layer Linear -> LayerNorm(1e-5) -> act -> * xscale, n_layers pre-norm layers writing cache row `pos` and attending to
+ * rows 0 .. pos, after_norm, decoder -> logits dev [n_out].  73 launches for 14 layers, all but the first inside one hipGraph that is captured once per handle:
+ * position, cache and table addresses are read on the device from a block the first kernel / cv_lm1_bind update.  Results: every GEMV and LayerNorm has the bits of
+ * the cv_gemm_conv (M = 1) / cv_norm_rows launches it replaces; the one-query attention sums exact fp32 products in another order (fp32 rounding). */
+typedef struct cv_lm1 cv_lm1;
+typedef struct cv_lm1_layer_weights {
+    const float *ln1_g, *ln1_b, *w_qkv, *b_qkv, *w_out, *b_out, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2;
+} cv_lm1_layer_weights;
+typedef struct cv_lm1_config {
+    int32_t n_layers, d, heads, ffn, d_in, n_out;
+    int32_t act;                 /* CV_ACT_RELU (TransformerEncoder of CosyVoice-300M): the input layer's and the feed-forward activation */
+    float xscale;                /* sqrt(d): the positional encoding's input scale (embedding.py:74) */
+    const float *embed_w, *embed_b, *embed_g, *embed_beta, *after_g, *after_b, *dec_w, *dec_b;
+} cv_lm1_config;
+cv_lm1* cv_lm1_create(const cv_lm1_config* cfg, const cv_lm1_layer_weights* layers /* [n_layers] */);      /* NULL on error (cv_last_error) */
+void cv_lm1_destroy(cv_lm1* m);
+/* A request's buffers: rows / tabs are HOST arrays of n_layers device pointers.  Call again whenever a buffer is reallocated (a grown cache, grown tables). */
+int cv_lm1_bind(cv_lm1* m, float* const* rows, const float* const* tabs, int32_t n_tab, int32_t cap, void* stream);
+int cv_lm1_step(cv_lm1* m, const float* x_row, int32_t pos, float* logits, void* stream);
+int64_t cv_lm1_stat(const cv_lm1* m, const char* name);            /* "steps", "graph_replays", "launches_per_step"; -1 for an unknown name */
+int cv_lm1_set_option(cv_lm1* m, const char* name, int32_t value); /* "graph": 1 (default; env CV_LM1_GRAPH) replays the step as a hipGraph, 0 launches it kernel by kernel */
+
 #ifdef __cplusplus
 }
 #endif

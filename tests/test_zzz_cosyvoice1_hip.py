@@ -194,3 +194,61 @@ def test_concurrent_requests_on_one_stage_object_are_serialised(lib, monkeypatch
     for th in ths:
         th.join()
     assert set(both) == set(reqs) and all(torch.equal(alone[n], both[n]) for n in reqs)
+
+
+def test_fused_decode_step_matches_the_launch_per_operator_step(lib):
+    """Round 4: cv_lm1_step (csrc/lm1.hip - the whole decode row as 3 + 5 launches per layer inside one hipGraph) against forward_chunk + decoder sequenced from the
+    host (3 + 8 launches per layer).  GEMVs and LayerNorms repeat the operators' arithmetic; the one-query attention sums in another order -> logits to fp32
+    rounding, the cache rows it leaves behind likewise; graph replay vs kernel-by-kernel launches of the same step: equal bit for bit.  A cache that grows (and is
+    rebound) mid-request, and two requests stepping alternately on one handle."""
+    import ctypes as C
+    sd = W.make_cv1_llm(CFG)
+    lm = CK.TransformerLM(sd, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling=greedy, lib=lib)
+    assert lm.step is not None and lm.fused_step
+    K, enc = lm.k, lm.llm
+    assert lm.step.stat("launches_per_step") == 3 + 5 * enc.n_layers
+    gen = torch.Generator().manual_seed(5)
+    xd = K.put(torch.randn(16, enc.embed.k, generator=gen))
+
+    def run(fused, graph=1, cap=None, n_prompt=5):
+        lm.step.lib.cv_lm1_set_option(lm.step.h, b"graph", C.c_int32(graph))
+        state = CK._KVState(K, enc.n_layers, enc.d, cap) if cap else None
+        y, state = enc.forward_chunk(xd[:n_prompt], state)
+        out = []
+        for i in range(n_prompt, 16):
+            if fused:
+                out.append(enc.fused_step(lm.step, xd[i:i + 1], state).cpu().clone())
+            else:
+                y, state = enc.forward_chunk(xd[i:i + 1], state)
+                out.append(K.linear(y[-1:], lm.decoder, 1).reshape(-1).cpu().clone())
+        return torch.stack(out), [r[:state.len].cpu().clone() for r in state.rows]
+
+    want, rows_w = run(False)
+    got, rows_g = run(True)
+    torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
+    for a, b in zip(rows_g, rows_w):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4)
+    assert lm.step.stat("graph_replays") == 11
+    eager, _ = run(True, graph=0)
+    assert torch.equal(eager, got)
+    small, _ = run(True, cap=6)                                     # the cache doubles twice on the way to 16 rows: rebound each time
+    assert torch.equal(small, got)
+    # two requests taking turns on the one handle (the stage lock is per step): each sees its own cache
+    sa, sb = None, None
+    _, sa = enc.forward_chunk(xd[:5], sa)
+    _, sb = enc.forward_chunk(xd[:3], sb)
+    la, lb = [], []
+    for i in range(5, 9):
+        la.append(enc.fused_step(lm.step, xd[i:i + 1], sa).cpu().clone())
+        lb.append(enc.fused_step(lm.step, xd[i - 2:i - 1], sb).cpu().clone())
+    assert torch.equal(torch.stack(la), got[:4])
+    alone_b, _ = run(True, n_prompt=3)
+    assert torch.equal(torch.stack(lb), alone_b[:4])
+    # the generator end to end: same tokens with and without the fused step
+    g = gold("cv1k_llm")
+    kw = dict(text=g["text"], text_len=t(7), prompt_text=g["prompt_text"], prompt_text_len=t(4), prompt_speech_token=g["prompt_speech_token"],
+              prompt_speech_token_len=t(9), embedding=g["embedding"])
+    lm.fused_step = False
+    slow = list(lm.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw))
+    lm.fused_step = True
+    assert list(lm.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw)) == slow == g["tokens_greedy"].tolist()

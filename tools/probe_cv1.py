@@ -1,11 +1,12 @@
 """CosyVoice-300M on the kernels at its real dimensions (cosyvoice_amd/cosyvoice1_hip.py): where the time goes, on the MI355X.
 
-    gpurun -- python tools/probe_cv1.py [split3] [graphs] [profile]
+    gpurun -- python tools/probe_cv1.py [split3] [graphs] [profile] [nofused] [nograph]
 
 Per stage, with one synchronisation per measurement: LM prefill (text encoder + 132-row forward_chunk) and decode step (ms per token over 200 steps), one flow
 pass (ms per Euler step at T = 861), one HiFT pass (861 frames), and the host's share: the same python sequencing with the launches replaced by no-ops
 (`CV1_PROBE_DRY`: ctypes + allocation cost alone - what a C entry point + hipGraph per stage would remove).  `split3`: the weight GEMMs on the two-sided bf16 split
 (Kernels(split3=True)) instead of the fp32 MFMA chain.  `profile`: one short pass of every stage only (for `rocprofv3 --kernel-trace --stats`).
+`nofused`: the LM decode step as the launch-per-operator tape instead of cv_lm1_step (round 4, csrc/lm1.hip); `nograph`: cv_lm1_step launching kernel by kernel.
 """
 import os
 import sys
@@ -25,6 +26,12 @@ greedy = lambda scores, decoded, sampling: int(scores.argmax().item())
 lm = CK.TransformerLM(sd_llm, text_heads=cfg.text_heads, llm_heads=cfg.llm_heads, sampling=greedy, split3=split3)
 flow = CK.MaskedDiffWithXvec(sd_flow, enc_heads=cfg.flow_heads, est_heads=cfg.est_heads, input_frame_rate=cfg.input_frame_rate, split3=split3)
 hift = CK.HiFTGenerator(sd_hift, hcfg)
+if lm.step is not None:
+    import ctypes
+    lm.fused_step = "nofused" not in sys.argv
+    lm.step.lib.cv_lm1_set_option(lm.step.h, b"graph", ctypes.c_int32(0 if "nograph" in sys.argv else 1))
+print("LM decode step: %s" % ("cv_lm1_step (%d launches, %s)" % (lm.step.stat("launches_per_step"), "kernel by kernel" if "nograph" in sys.argv else "one hipGraph") if lm.fused_step
+                              else "launch-per-operator tape (3 + 8 launches per layer)"), flush=True)
 flow.k.use_graphs = graphs                                   # `graphs`: the estimator tape of a solve as a hipGraph (LaunchTape.capture), opt-in until measured
 tl = lambda n: torch.tensor([n], dtype=torch.int32)
 g = torch.Generator().manual_seed(300)
@@ -45,7 +52,7 @@ def lm_run(n_gen):
     return 1e3 * (t1 - t0), 1e3 * (t2 - t1) / max(1, len(toks) - 1), toks
 
 
-n_gen = 8 if profile else 200
+n_gen = 60 if profile else 200
 lm_run(4)
 pre, step, toks = lm_run(n_gen)
 print("LM: prefill + first token %.2f ms (132 rows), decode %.3f ms per token over %d steps (context 132 -> %d)" % (pre, step, n_gen - 1, 131 + n_gen), flush=True)
@@ -87,6 +94,7 @@ if not profile:
                 return lambda *a: None
             return getattr(self._lib, name)
     real = lm.k.lib
+    lm.fused_step = False                                       # (the host share of the launch-per-operator sequencing: what cv_lm1_step removed)
     for obj in (lm.k, lm.text_encoder.k, lm.llm.k):
         obj.lib = _Dry(real)
     _, dry_step, _ = lm_run(60)
