@@ -465,9 +465,21 @@ class TransformerLM(C1.TransformerLM):
         self.spk_affine = K.mat(sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"])
         self.decoder = K.mat(sd["llm_decoder.weight"], sd["llm_decoder.bias"])
         # the decode step behind one C entry point (cv_lm1_step); fused_step = False keeps the launch-per-operator tape (A/B and test knob)
+        self._host_logits = None
         self.step = self.llm.make_step(self.decoder)
         self.fused_step = self.step is not None
         self.lock = threading.Lock()                             # one Kernels object (its recorder, its workspaces) per stage: requests on one stage object are serialised
+
+    def _to_host(self, logits):
+        """The step's logits on the host (called under the stage lock).  On the GPU: into one pinned buffer, asynchronously, then one stream synchronisation - a pageable
+        `.cpu()` stages through the runtime's own bounce buffer and costs ~3x as much per token."""
+        if logits.device.type != "cuda":
+            return logits.cpu()
+        if self._host_logits is None or self._host_logits.numel() != logits.numel():
+            self._host_logits = torch.empty(logits.numel(), dtype=F32, pin_memory=True)
+        self._host_logits.copy_(logits, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return self._host_logits
 
     def encode_text(self, ids):
         """text_encoder + text_encoder_affine_layer (llm.py:84-91) for one unpadded id sequence -> [n, D] on the device."""
@@ -505,7 +517,7 @@ class TransformerLM(C1.TransformerLM):
                 else:
                     y, state = self.llm.forward_chunk(x, state)
                     logits = K.linear(y[-1:], self.decoder, 1)
-                logp = logits.reshape(-1).cpu().log_softmax(dim=-1)    # the sampler draws from the host RNG, like the reference's python sampler
+                logp = self._to_host(logits.reshape(-1)).log_softmax(dim=-1)    # the sampler draws from the host RNG, like the reference's python sampler
             if i < min_len:
                 logp[self.speech_token_size] = -float("inf")
             top = self.sampling(logp, out_tokens, sampling)

@@ -4,8 +4,8 @@
 // The step is one output row through 14 pre-norm layers over fp32 weights: 734 MB of weights per token, nothing else of size.  Until round 4 the host side
 // (cosyvoice1_hip.py) replayed it as 115 launches of the general operators (LayerNorm, tiled GEMM -> GEMV, the [H][1][n] matrix_bd GEMM, the MFMA attention
 // with one useful query row); what bounded it was the NUMBER of dependent launches, not their bytes.  Here the step is 73 launches inside one hipGraph:
-//     per layer   [LayerNorm + (q+u | q+v | k | v) GEMV -> the layer's cache row]  [one-query relative-position attention, keys split over 4 workgroups per head]
-//                 [merge of the 4 partial softmaxes + output GEMV + residual]  [LayerNorm + w_1 GEMV + ReLU]  [w_2 GEMV + residual]
+//     per layer   [LayerNorm + (q+u | q+v | k | v) GEMV -> the layer's cache row]  [one-query relative-position attention, keys split over 8 workgroups per head]
+//                 [merge of the 8 partial softmaxes + output GEMV + residual]  [LayerNorm + w_1 GEMV + ReLU]  [w_2 GEMV + residual]
 //     around it   [embed GEMV] [LayerNorm + ReLU, * sqrt(d)] ... [after_norm + decoder GEMV -> logits]
 // The GEMV is gemm_conv.h's gemv_f32_kernel (same lane / wave / k order, same four-way combine) with its input vector staged in LDS by a prologue; the LayerNorm
 // prologue repeats norm_rows_kernel's register path arithmetic, so every product of the step has the bits of the launch-per-operator path.  The attention is a
@@ -20,8 +20,8 @@
 namespace cv {
 
 constexpr int LM1_MAX_LAYERS = 32;
-constexpr int LM1_SPLITS = 4;                 // key ranges per head in the decode attention
-constexpr int LM1_MAX_KEYS_PER_SPLIT = 2048;  // scores of one split live in LDS
+constexpr int LM1_SPLITS = 8;                 // key ranges per head in the decode attention
+constexpr int LM1_MAX_KEYS_PER_SPLIT = 4096;  // (a bound on the cache a handle binds: 32768 positions)
 #define LM1_NEG_INF (-__builtin_huge_valf())
 constexpr int LM1_MAX_K = 4096;               // longest GEMV input (the feed-forward width)
 
@@ -61,7 +61,7 @@ static __global__ __launch_bounds__(256) void lm1_gemv_kernel(Lm1GemvArgs p) {
         for (int u = 0; u < U; ++u)                             // unconditional loads (clamped step) keep the vmcnt bookkeeping exact
             dst[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(wr + min(min(sb + u, s1 - 1) * 64 + sub * 4, p.Kp - 4)));
     };
-    if (s0 < s1) load_w(w, s0);
+    if (p.pro != LM1_PRO_LN && s0 < s1) load_w(w, s0);          // (the LayerNorm prologue requests its row first: its statistics then run under the weight loads)
     // ---- prologue: the input vector into LDS, zero beyond K up to the last 64-float step
     if (p.pro == LM1_PRO_LN) {
         // norm_rows_kernel's register path (C <= 1024, C % 4 == 0), every wave on the whole row; wave w parks chunk w
@@ -75,6 +75,7 @@ static __global__ __launch_bounds__(256) void lm1_gemv_kernel(Lm1GemvArgs p) {
         }
         const int cw = lane * 4 + wave * 256;                   // gamma / beta of the wave's chunk travel with the row, not after the statistics
         const float4 gw = *reinterpret_cast<const float4*>(p.g + min(cw, p.K - 4)), bw = *reinterpret_cast<const float4*>(p.b + min(cw, p.K - 4));
+        if (s0 < s1) load_w(w, s0);
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -198,11 +199,14 @@ static __global__ __launch_bounds__(64) void lm1_norm_kernel(Lm1NormArgs p) {
 
 // One query (the row at `pos`), head h, key range s of LM1_SPLITS:  score_j = ((q + u) . k_j + (q + v) . p_(n - 1 - j)) * scale  (attention.py:300-326; for the last
 // query rel_shift leaves column j = relative position n - 1 - j), partial softmax (m, l, acc[64]) over the range -> part[h][s][66].
+// ONE pass: a 16-lane group owns a key (4 of the 64 dimensions per lane) and requests its k, p AND v rows together, LM1_AU keys per group in flight - up to
+// 16 * LM1_AU * LM1_SPLITS = 512 keys the whole context is requested before the first score exists (the kernel is a chain of latencies, not of bytes); every
+// group keeps a running (m, l, acc) over its keys, the 16 groups merge through LDS.
+constexpr int LM1_AU = 4;
 struct Lm1AttnArgs { const Lm1Dyn* dyn; int layer, d, heads; float scale; float* part; };
 static __global__ __launch_bounds__(256) void lm1_attn_kernel(Lm1AttnArgs p) {
-    __shared__ float sc[LM1_MAX_KEYS_PER_SPLIT];
-    __shared__ float red[16];
-    __shared__ float accs[4][64];
+    __shared__ float gm[16], gl[16];
+    __shared__ float gacc[16][64];
     const int h = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, sub = tid & 15, kg = tid >> 4;
     const int pos = p.dyn->pos, n = pos + 1, d = p.d;
     const int per = (n + LM1_SPLITS - 1) / LM1_SPLITS, j0 = min(n, s * per), j1 = min(n, j0 + per), cnt = j1 - j0;
@@ -210,40 +214,62 @@ static __global__ __launch_bounds__(256) void lm1_attn_kernel(Lm1AttnArgs p) {
     const float* qrow = rows + (long long)pos * 4 * d + h * 64;
     const float* tab = p.dyn->tabs[p.layer] + (long long)(p.dyn->n_tab - n) * d + h * 64;
     float* out = p.part + ((long long)h * LM1_SPLITS + s) * 66;
-    const float4 qu = *reinterpret_cast<const float4*>(qrow + sub * 4), qv = *reinterpret_cast<const float4*>(qrow + d + sub * 4);
-    // pass 1: scores of the range, 16 keys per sweep (a 16-lane group per key, 4 of the 64 dimensions per lane), 2 sweeps in flight
-    float mt = LM1_NEG_INF;
-    for (int i0 = 0; i0 < cnt; i0 += 32) {
-        float4 kx[2], px[2];
+    float4 kx[LM1_AU], px[LM1_AU], vx[LM1_AU];
+    auto issue = [&](int i0) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int j = j0 + min(i0 + u * 16 + kg, cnt - 1);
-            kx[u] = *reinterpret_cast<const float4*>(rows + (long long)j * 4 * d + 2 * d + h * 64 + sub * 4);
+        for (int u = 0; u < LM1_AU; ++u) {                      // unconditional (clamped) loads: all 3 * LM1_AU in flight together
+            const int j = min(j0 + min(i0 + u * 16 + kg, max(cnt - 1, 0)), pos);      // (an empty range still reads a valid row: no branch around the loads)
+            const float* r = rows + (long long)j * 4 * d + h * 64 + sub * 4;
+            kx[u] = *reinterpret_cast<const float4*>(r + 2 * d);
+            vx[u] = *reinterpret_cast<const float4*>(r + 3 * d);
             px[u] = *reinterpret_cast<const float4*>(tab + (long long)j * d + sub * 4);
         }
+    };
+    float m_run = LM1_NEG_INF, l_run = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i0 = 0;; i0 += 16 * LM1_AU) {
+        issue(i0);
+        // the query is requested WITH the sweep's rows (an offset the compiler cannot see through keeps these two loads inside the loop: hoisted, they are waited
+        // for before the rows are requested - two round trips instead of one)
+        const int zero = cv_opaque_zero();
+        const float4 qu = *reinterpret_cast<const float4*>(qrow + sub * 4 + zero), qv = *reinterpret_cast<const float4*>(qrow + d + sub * 4 + zero);
+        float sc[LM1_AU];
+        float mt = m_run;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < LM1_AU; ++u) {
             float a = qu.x * kx[u].x; a += qu.y * kx[u].y; a += qu.z * kx[u].z; a += qu.w * kx[u].w;
             float b = qv.x * px[u].x; b += qv.y * px[u].y; b += qv.z * px[u].z; b += qv.w * px[u].w;
-            const float sc_j = (group16_sum(a) + group16_sum(b)) * p.scale;
-            const int i = i0 + u * 16 + kg;
-            if (i < cnt) { if (sub == 0) sc[i] = sc_j; mt = fmaxf(mt, sc_j); }
+            const float sj = (group16_sum(a) + group16_sum(b)) * p.scale;         // (collectives outside the select)
+            sc[u] = (i0 + u * 16 + kg < cnt) ? sj : LM1_NEG_INF;
+            mt = fmaxf(mt, sc[u]);
         }
+        if (mt != LM1_NEG_INF) {                                // (a group with no key in this sweep and none before keeps its empty state)
+            const float alpha = (m_run == LM1_NEG_INF) ? 0.f : expf(m_run - mt);
+            l_run *= alpha; acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
+#pragma unroll
+            for (int u = 0; u < LM1_AU; ++u) {
+                const float e = (sc[u] == LM1_NEG_INF) ? 0.f : expf(sc[u] - mt);
+                l_run += e; acc.x += e * vx[u].x; acc.y += e * vx[u].y; acc.z += e * vx[u].z; acc.w += e * vx[u].w;
+            }
+            m_run = mt;
+        }
+        if (i0 + 16 * LM1_AU >= cnt) break;
     }
-    const float m = block_max(mt, red);
+    if (sub == 0) { gm[kg] = m_run; gl[kg] = l_run; }
+    *reinterpret_cast<float4*>(&gacc[kg][sub * 4]) = acc;
     __syncthreads();
-    float lt = 0.f;
-    for (int i = tid; i < cnt; i += 256) { const float e = expf(sc[i] - m); sc[i] = e; lt += e; }
-    const float l = block_sum(lt, red);
-    __syncthreads();
-    // pass 2: acc[dd] = sum_j e_j v_j[dd]: thread = (key residue of 4, dimension), rows of 256 B
-    const int dd = tid & 63, kr = tid >> 6;
-    float a = 0.f;
-    for (int i = kr; i < cnt; i += 4) a += sc[i] * rows[(long long)(j0 + i) * 4 * d + 3 * d + h * 64 + dd];
-    accs[kr][dd] = a;
-    __syncthreads();
-    if (tid < 64) out[2 + tid] = ((accs[0][tid] + accs[1][tid]) + accs[2][tid]) + accs[3][tid];
-    if (tid == 0) { out[0] = cnt > 0 ? m : LM1_NEG_INF; out[1] = cnt > 0 ? l : 0.f; }
+    if (tid >= 64) return;
+    float M = LM1_NEG_INF;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) M = fmaxf(M, gm[g]);
+    float L = 0.f, a = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {                              // fixed group order
+        const float w = (gm[g] == LM1_NEG_INF) ? 0.f : expf(gm[g] - M);
+        L += gl[g] * w; a += gacc[g][tid] * w;
+    }
+    out[2 + tid] = a;
+    if (tid == 0) { out[0] = M; out[1] = L; }
 }
 
 static __global__ void lm1_bind_kernel(Lm1Dyn* dyn, Lm1Dyn v) { if (threadIdx.x == 0 && blockIdx.x == 0) *dyn = v; }
@@ -342,7 +368,7 @@ void cv_lm1_destroy(cv_lm1* m) { delete m; }
 int cv_lm1_bind(cv_lm1* m, float* const* rows, const float* const* tabs, int32_t n_tab, int32_t cap, void* stream) {
     return guarded([&] {
         CV_CHECK(m && rows && tabs, "cv_lm1_bind: null argument");
-        CV_CHECK(cap >= 1 && cap <= LM1_SPLITS * LM1_MAX_KEYS_PER_SPLIT, "cv_lm1_bind: a cache of up to 8192 positions");
+        CV_CHECK(cap >= 1 && cap <= LM1_SPLITS * LM1_MAX_KEYS_PER_SPLIT, "cv_lm1_bind: a cache of up to 32768 positions");
         CV_CHECK(n_tab >= cap, "cv_lm1_bind: the relative-position tables must cover the cache (n_tab >= cap)");
         Lm1Dyn v{};
         v.pos = 0; v.n_tab = n_tab;

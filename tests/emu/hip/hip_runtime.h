@@ -215,6 +215,7 @@ static inline emu_u32x2 emu_buf_load_b64(emu_rsrc rs, int voff, int soff) {
 /* global_load_lds_dwordx4: LDS destination = wave-uniform base + lane * 16 */
 #define CV_GLDS16(gptr, lds_wave_base) memcpy((char*)(lds_wave_base) + 16 * emu::lane_id(), (const void*)(gptr), 16)
 #define CV_VMCNT0() ((void)0)
+#define CV_OPAQUE_ZERO 1
 #define __builtin_amdgcn_exp2f(x) exp2f(x)                              /* v_exp_f32: callers stay out of the range where it flushes (results below 2^-126) */
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_wave_barrier() ((void)__shfl(0, 0))            /* the emulator's lanes are fibers: a wave-wide rendezvous */
