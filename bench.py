@@ -324,7 +324,7 @@ def cv3_workload(args):
 def cv1_workload(args):
     """SURVEY.md section 8 row f4 on ONE GPU: CosyVoice-300M (first generation: TransformerLM 14 x 1024, conformer flow encoder + InterpolateRegulator + the
     non-causal U-Net estimator, 22.05 kHz HiFT) at its real dimensions on the hand-written kernels, sequenced by the host (cosyvoice_amd/cosyvoice1_hip.py: one
-    ctypes call per launch for prefill, flow and vocoder; the LM decode step - 500 of them per request - is one library call replaying one hipGraph, cv_lm1_step).  One inference_sft-shaped request (cli/frontend.py
+    ctypes call per launch for prefill, flow and vocoder; the LM decode step - 500 of them per request - is one library call, cv_lm1_step).  One inference_sft-shaped request (cli/frontend.py
     frontend_sft: text + speaker embedding, no prompts): 25 text ids, the length forced to 500 speech tokens = 10.0 s at 22.05 kHz, greedy on the host like the
     reference's python sampler, 10 CFM Euler steps, fp32 throughout (the reference's default for this model).  Token check: every id against the
     torch-eager plumbing of the same weights on the HOST cores (cosyvoice1.py, the configs[0] path that the reference goldens pin)."""
@@ -383,7 +383,7 @@ def cv1_workload(args):
     return {"model": "CosyVoice-300M dimensions (TransformerLM 14 x 1024 + conformer text encoder, MaskedDiffWithXvec with the U-Net ConditionalDecoder, HiFTGenerator 22.05 kHz), "
                      "seeded random weights, fp32", "request": "inference_sft shape: 25 text ids, 500 generated tokens = %.2f s of audio, greedy, 10 Euler steps" % audio_s,
             "host": "python sequencing over the operator-level C ABI (cosyvoice1_hip.py); the LM decode step is ONE call (cv_lm1_step, csrc/lm1.hip: %s)"
-                    % ("%d launches per token inside one hipGraph, %d replays" % (lm.step.stat("launches_per_step"), lm.step.stat("graph_replays")) if lm.step is not None and lm.fused_step
+                    % ("%d launches per token, %d of the %d steps replayed as a hipGraph" % (lm.step.stat("launches_per_step"), lm.step.stat("graph_replays"), lm.step.stat("steps")) if lm.step is not None and lm.fused_step
                        else "off: launch-per-operator tape"), "audio_s_per_s": round(audio_s / per, 3),
             "ms_per_utterance": round(1e3 * per, 2), "stages": stages,
             "token_check": {"checked": n_chk, "equal_torch_eager_cpu": div is None, "first_difference": div},

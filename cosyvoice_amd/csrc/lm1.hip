@@ -3,7 +3,7 @@
 //
 // The step is one output row through 14 pre-norm layers over fp32 weights: 734 MB of weights per token, nothing else of size.  Until round 4 the host side
 // (cosyvoice1_hip.py) replayed it as 115 launches of the general operators (LayerNorm, tiled GEMM -> GEMV, the [H][1][n] matrix_bd GEMM, the MFMA attention
-// with one useful query row); what bounded it was the NUMBER of dependent launches, not their bytes.  Here the step is 73 launches inside one hipGraph:
+// with one useful query row); what bounded it was the NUMBER of dependent launches, not their bytes.  Here the step is 73 launches (optionally one hipGraph):
 //     per layer   [LayerNorm + (q+u | q+v | k | v) GEMV -> the layer's cache row]  [one-query relative-position attention, keys split over 8 workgroups per head]
 //                 [merge of the 8 partial softmaxes + output GEMV + residual]  [LayerNorm + w_1 GEMV + ReLU]  [w_2 GEMV + residual]
 //     around it   [embed GEMV] [LayerNorm + ReLU, * sqrt(d)] ... [after_norm + decoder GEMV -> logits]
@@ -12,7 +12,8 @@
 // new summation order (exact fp32 dot products per key instead of the MFMA chain): results agree to fp32 rounding.
 // What changes from token to token - the position, i.e. the cache row written, the key count and the first row of the relative-position table - is read by
 // the kernels from a device block (Lm1Dyn) that the step's FIRST kernel (launched outside the graph, it also takes the input row's address) updates; what
-// changes from request to request - the cache and table buffers - is rebound there by cv_lm1_bind.  One captured graph therefore serves every step of every request.
+// changes from request to request - the cache and table buffers - is rebound there by cv_lm1_bind.  One captured graph therefore serves every step of every request
+// (option "graph", off by default: on the MI355X the replay costs 0.607 ms per token against 0.591 ms for the same launches issued one by one).
 #include "api_common.h"
 #include "common.h"
 #include <vector>
@@ -45,15 +46,18 @@ struct Lm1GemvArgs {
 // y[N] = act(pro(x)[K] . W[N][K]^T + bias) (+ res).  4 output rows per workgroup, a 16-lane group per row, the 4 waves split K (gemv_f32_kernel).
 // U: 64-float steps a lane group has in flight (a wave's share of K = 1024 is 4 steps).  The wave's FIRST group of weight loads is issued before the prologue:
 // the weights do not depend on the previous kernel's output, the input vector does, so the prologue's dependent loads (x, gamma, beta) wait under them.
-template <int U>
-static __global__ __launch_bounds__(256) void lm1_gemv_kernel(Lm1GemvArgs p) {
+// NW: waves per workgroup (they split K): 4, or 8 for the K = 4096 product whose 1024 rows are only 256 workgroups - 16 steps per wave were two dependent
+// round trips per wave, 8 steps are one.
+template <int U, int NW>
+static __global__ __launch_bounds__(64 * NW) void lm1_gemv_kernel(Lm1GemvArgs p) {
     __shared__ float xs[LM1_MAX_K + 64];
-    __shared__ float part[4][4];
+    __shared__ float part[NW][4];
+    __shared__ float mw[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
     const int steps = (p.Kp + 63) / 64;
     if (p.set_pos >= 0 && blockIdx.x == 0 && tid == 0) p.dyn->pos = p.set_pos;
     const int row = min((int)blockIdx.x * 4 + grp, p.N - 1);      // clamped: the reductions are wave collectives
-    const int s0 = wave * steps / 4, s1 = (wave + 1) * steps / 4;
+    const int s0 = wave * steps / NW, s1 = (wave + 1) * steps / NW;
     const float* wr = p.W + (long long)row * p.ldw;
     v4f w[U], wn[U];
     auto load_w = [&](v4f (&dst)[U], int sb) {
@@ -101,29 +105,36 @@ static __global__ __launch_bounds__(256) void lm1_gemv_kernel(Lm1GemvArgs p) {
             if (cw < steps * 64) *reinterpret_cast<float4*>(&xs[cw]) = make_float4(o[0], o[1], o[2], o[3]);
         }
     } else if (p.pro == LM1_PRO_MERGE) {
-        // x[h * 64 + d] = sum_s acc_s[d] e^(m_s - M) / sum_s l_s e^(m_s - M): the key splits of one head's softmax, in split order
-        for (int e = tid; e < steps * 64; e += 256) {
+        // x[h * 64 + d] = sum_s acc_s[d] * (e^(m_s - M) / sum_s l_s e^(m_s - M)): the key ranges of one head's softmax, in range order.  The LM1_SPLITS weights of a
+        // head are made ONCE per workgroup (one lane per (head, range), the head's lanes combine through shuffles) and read back from LDS - not once per element.
+        {
+            const int hs = min(tid, (p.K >> 6) * LM1_SPLITS - 1);
+            const float* ph = p.x + (long long)hs * 66;
+            const float ms = ph[0], ls = ph[1];
+            float M = ms;
+#pragma unroll
+            for (int o = 1; o < LM1_SPLITS; o <<= 1) M = fmaxf(M, __shfl_xor(M, o));
+            const float w = (ms == LM1_NEG_INF) ? 0.f : expf(ms - M);
+            float L = ls * w;
+#pragma unroll
+            for (int o = 1; o < LM1_SPLITS; o <<= 1) L += __shfl_xor(L, o);
+            if (tid < (p.K >> 6) * LM1_SPLITS) mw[tid] = w / L;
+        }
+        __syncthreads();
+        for (int e = tid; e < steps * 64; e += blockDim.x) {
             float o = 0.f;
             if (e < p.K) {
-                const float* ph = p.x + (long long)(e >> 6) * LM1_SPLITS * 66;
-                float ms[LM1_SPLITS], ls[LM1_SPLITS], as[LM1_SPLITS];
+                const float* pa = p.x + (long long)(e >> 6) * LM1_SPLITS * 66 + 2 + (e & 63);
+                float as[LM1_SPLITS];
 #pragma unroll
-                for (int s = 0; s < LM1_SPLITS; ++s) { ms[s] = ph[s * 66]; ls[s] = ph[s * 66 + 1]; as[s] = ph[s * 66 + 2 + (e & 63)]; }
-                float M = LM1_NEG_INF;
+                for (int s = 0; s < LM1_SPLITS; ++s) as[s] = pa[s * 66];
 #pragma unroll
-                for (int s = 0; s < LM1_SPLITS; ++s) M = fmaxf(M, ms[s]);
-                float L = 0.f, a = 0.f;
-#pragma unroll
-                for (int s = 0; s < LM1_SPLITS; ++s) {
-                    const float w = (ms[s] == LM1_NEG_INF) ? 0.f : expf(ms[s] - M);
-                    L += ls[s] * w; a += as[s] * w;
-                }
-                o = a / L;
+                for (int s = 0; s < LM1_SPLITS; ++s) o += as[s] * mw[(e >> 6) * LM1_SPLITS + s];
             }
             xs[e] = o;
         }
     } else {
-        for (int e = tid * 4; e < steps * 64; e += 1024) {
+        for (int e = tid * 4; e < steps * 64; e += 256 * NW) {
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < p.K) t = *reinterpret_cast<const float4*>(p.x + e);           // K % 4 == 0
             *reinterpret_cast<float4*>(&xs[e]) = t;
@@ -156,6 +167,7 @@ static __global__ __launch_bounds__(256) void lm1_gemv_kernel(Lm1GemvArgs p) {
     const int n = (int)blockIdx.x * 4 + grp;
     if (n >= p.N) return;
     float v = ((part[0][grp] + part[1][grp]) + part[2][grp]) + part[3][grp];
+    if (NW == 8) v = (((v + part[4 % NW][grp]) + part[5 % NW][grp]) + part[6 % NW][grp]) + part[7 % NW][grp];
     if (p.bias) v += p.bias[n];
     v = apply_act(p.act, v, 0.f);
     if (p.res) v += p.res[n];
@@ -290,7 +302,7 @@ struct cv_lm1 {
     DevBuf dyn, x0, x1, h, ff, part;
     hipGraphExec_t graph = nullptr; float* graph_logits = nullptr; hipStream_t graph_stream = nullptr;
     hipStream_t own_stream = nullptr;          // a NULL stream argument means this (blocking) stream: it orders itself against the legacy default stream, and it can be captured
-    int use_graph = 1, bound = 0;
+    int use_graph = 0, bound = 0;              // measured on the MI355X (profiles/r4_cv1_fused_step_timing.txt): the replayed graph is 3 % SLOWER per token than the same 72 launches issued eagerly
     long long steps = 0, graph_replays = 0;
     ~cv_lm1() { if (graph) (void)hipGraphExecDestroy(graph); if (own_stream) (void)hipStreamDestroy(own_stream); }
 };
@@ -309,8 +321,10 @@ void gemv(cv_lm1* m, int pro, const float* x, const float* g, const float* b, fl
           int set_pos, int N, int K, int act, hipStream_t s) {
     CV_CHECK(K % 4 == 0 && K <= LM1_MAX_K && (pro != LM1_PRO_LN || K <= 1024), "cv_lm1: a GEMV input of up to 4096 floats (1024 under the LayerNorm prologue), K % 4 == 0");
     Lm1GemvArgs a{x, g, b, eps, W, (long long)kp_of(K), bias, res, y, m->dyn.as<Lm1Dyn>(), layer, set_pos, N, K, kp_of(K), act, pro};
-    if ((kp_of(K) + 63) / 64 <= 16) hipLaunchKernelGGL(lm1_gemv_kernel<4>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(lm1_gemv_kernel<8>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a);
+    const int steps = (kp_of(K) + 63) / 64;
+    if (steps <= 16) hipLaunchKernelGGL((lm1_gemv_kernel<4, 4>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a);
+    else if (pro == LM1_PRO_NONE && N <= 2048) hipLaunchKernelGGL((lm1_gemv_kernel<8, 8>), dim3((unsigned)((N + 3) / 4)), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((lm1_gemv_kernel<8, 4>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a);
 }
 
 // everything of a step after its first kernel

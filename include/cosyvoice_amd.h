@@ -344,7 +344,7 @@ int cv_transpose(const float* in, float* out, int32_t rows, int32_t cols, void* 
  *   cache rows    : per layer dev [cap][4 d] (cv_lm1_bind), rows 0 .. pos - 1 filled by the prefill and the earlier steps;
  *   tabs          : per layer dev [2 n_tab - 1][d] = linear_pos(pos_emb), row m = relative position n_tab - 1 - m (embedding.py:143-160), n_tab >= cap.
  * cv_lm1_step(x_row dev [d_in], pos) : input layer Linear -> LayerNorm(1e-5) -> act -> * xscale, n_layers pre-norm layers writing cache row `pos` and attending to
- * rows 0 .. pos, after_norm, decoder -> logits dev [n_out].  73 launches for 14 layers, all but the first inside one hipGraph that is captured once per handle:
+ * rows 0 .. pos, after_norm, decoder -> logits dev [n_out].  73 launches for 14 layers; with option "graph" all but the first are one hipGraph captured once per handle:
  * position, cache and table addresses are read on the device from a block the first kernel / cv_lm1_bind update.  Results: every GEMV and LayerNorm has the bits of
  * the cv_gemm_conv (M = 1) / cv_norm_rows launches it replaces; the one-query attention sums exact fp32 products in another order (fp32 rounding). */
 typedef struct cv_lm1 cv_lm1;
@@ -363,7 +363,7 @@ void cv_lm1_destroy(cv_lm1* m);
 int cv_lm1_bind(cv_lm1* m, float* const* rows, const float* const* tabs, int32_t n_tab, int32_t cap, void* stream);
 int cv_lm1_step(cv_lm1* m, const float* x_row, int32_t pos, float* logits, void* stream);
 int64_t cv_lm1_stat(const cv_lm1* m, const char* name);            /* "steps", "graph_replays", "launches_per_step"; -1 for an unknown name */
-int cv_lm1_set_option(cv_lm1* m, const char* name, int32_t value); /* "graph": 1 (default; env CV_LM1_GRAPH) replays the step as a hipGraph, 0 launches it kernel by kernel */
+int cv_lm1_set_option(cv_lm1* m, const char* name, int32_t value); /* "graph" (env CV_LM1_GRAPH): 1 replays the step as a hipGraph, 0 (default: measured 3 % faster per token) launches it kernel by kernel */
 
 #ifdef __cplusplus
 }

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round 4, twelfth call: cv_lm1_step after the one-pass attention (8 key ranges per head, rows and query in one round trip), LayerNorm row requested before the weights,
+# Round 4, twelfth and thirteenth calls: cv_lm1_step after the one-pass attention (8 key ranges per head, rows and query in one round trip), LayerNorm row requested before the weights,
 # logits through a pinned buffer.
 set -u
-O=gpurun_out/r4l; mkdir -p $O
+O=gpurun_out/r4m; mkdir -p $O
 R=$GRAFT_REPO_ROOT
 run() { local name=$1; shift; local t0=$(date +%s); echo "== $name"; timeout -k 5 "$@" > $O/$name.log 2>&1; echo "   rc=$? $(( $(date +%s) - t0 ))s ($(tail -1 $O/$name.log | cut -c1-300))"; }
 run pytest_cv1 600 python -m pytest tests/test_zzz_cosyvoice1_hip.py -q -m gpu -p no:cacheprovider -x
