@@ -557,7 +557,7 @@ def roofline_llm(model, u, cfgs):
     # HBM traffic per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run, x1024 B, x2 for
     # the gfx950 wide-read under-count — MI355X_MICROARCH.md §HBM); PMC cannot be collected from inside this process, hence the file.
     traffic, traffic_src = None, None
-    pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r3_pmc_gemv_fetch.json", "r2_pmc_gemv_fetch.json")) if os.path.exists(f)), None)
+    pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r4_pmc_gemv_fetch.json", "r3_pmc_gemv_fetch.json", "r2_pmc_gemv_fetch.json")) if os.path.exists(f)), None)
     if pmc is not None:
         import hashlib
         raw = open(pmc, "rb").read()
@@ -566,7 +566,7 @@ def roofline_llm(model, u, cfgs):
         if sel:
             traffic = int(sum(v["n"] * v["hbm_read_bytes_corrected"] for v in sel) / sum(v["n"] for v in sel))
             traffic_src = ("REPLAYED PMC RECORD, not measured by this run (PMC counters cannot be collected from inside the benchmark process): %s, sha1 %s - "
-                           "rocprofv3 --pmc FETCH_SIZE in its own run (tools/gpu_r3_validate.sh), x1024 B, x2 for the gfx950 wide-read under-count; mean over the "
+                           "rocprofv3 --pmc FETCH_SIZE in its own run (tools/gpu_r4_final.sh), x1024 B, x2 for the gfx950 wide-read under-count; mean over the "
                            "gemv_norm_kernel<7,2,5> (gate/up) launches of tools/profile_small.py llm, summarised by tools/pmc_summary.py"
                            % (os.path.relpath(pmc, ROOT), hashlib.sha1(raw).hexdigest()[:16]))
     step_us = sum(chain[k] * lc.layers for k in (0, 1, 2, 3, 4)) + chain[5]

@@ -239,7 +239,8 @@ def test_scheduler_batches_ready_requests_into_one_flow_pass():
                 boom = RuntimeError("flow pass failed")
 
                 def failing(jobs, stream=False, finalize=False, on_ready=None):
-                    on_ready(0, _FakeModel.token2wav(fm, stream=stream, finalize=finalize, **jobs[0]))
+                    i = next(k for k, j in enumerate(jobs) if j["prompt_token"].shape[1] != 5)     # one healthy member gets its audio before the pass dies
+                    on_ready(i, _FakeModel.token2wav(fm, stream=stream, finalize=finalize, **jobs[i]))
                     raise boom
                 fm.token2wav_batch = failing
                 single = Fm.token2wav
