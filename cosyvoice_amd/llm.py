@@ -226,7 +226,10 @@ class Qwen2LM:
         """Generator of Python ints, one per speech token (llm/llm.py:458-502, 535-549).  `first_chunk` (not in the reference): how many
         tokens the caller needs before it can do anything (tts(stream=True): hop + prompt pad + look-ahead) - the device loop hands tokens
         back in chunks of `decode_chunk` steps, and the first hand-back is cut to exactly that count instead of making the first audio
-        chunk wait for a full decode chunk."""
+        chunk wait for a full decode chunk.
+        The handle lock is held for the whole generation, yields included: a handle owns ONE KV cache, so a second request on this object cannot start before this one
+        ends (the reference's model object has the same property through its single `cache`).  Abandon a request by closing the generator (`gen.close()` / leaving the
+        `for`), which releases the lock; concurrent requests go through `inference_queue` / `serve_stream` (one cache per slot) or through separate handles."""
         n_text = int(text.shape[1])
         min_len = int(n_text * min_token_text_ratio)
         max_len = int(n_text * max_token_text_ratio)
