@@ -67,7 +67,7 @@ struct cv_flow {
     // "big_tile0" / "big_tile1": tile of the bf16-out / fp32-residual GEMMs, 0 = by measurement (64 x 64), 1 = 128x128, 2 = 128x64, 3 = 64x64.
     // `attn2_rows`: attention with 32 queries per wave (attn_flow_kernel<.., QG = 2>) from that many rows on; 0 = never, the default: at M = 10 784 it measured
     // 54.1 us per launch against 43.0 for QG = 1 (164 registers: one 8-wave workgroup per CU instead of two).
-    int big_rows = 5000, attn2_rows = 0, big_tile0 = 0, big_tile1 = 0;
+    int big_rows = 4000, attn2_rows = 0, big_tile0 = 0, big_tile1 = 0;       // 4000: from 3 utterances of U10 per pass (profiles/r4_flow_big_ab.txt, fourth series: 61.6 -> 57.4 ms at 3, 48.4 vs 50.8 at 2)
     int big_lds_epi = 1;               // "big_lds_epi": the large-M GEMMs store their output tile row-wise through LDS (flow_big.h, epilogue_lds); 0 = per-lane stores from the accumulator layout
     int big_glds = 0;                  // "big_glds": the large-M GEMM stages go global -> LDS by DMA (1: global_load_lds_dwordx4, common.h CV_GLDS16) or through registers + ds_write (0).
                                        // Off: as hipcc compiles it the DMA does not overlap the MFMAs (a vmcnt(0) lands in front of the fragment reads, flow_big.h)
