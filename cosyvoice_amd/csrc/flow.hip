@@ -64,7 +64,7 @@ struct cv_flow {
     // a pure speed knob.  Measured on MI355X (profiles/r4_flow_big_ab.txt, ms per shared pass small -> big): 2 utterances (M = 2696) 49.8 -> 66.9 with 128-wide
     // tiles, 4 (M = 5392) 77.9 -> 74.4, 8 (M = 10 784) 135.0 -> 109.4 with 64 x 64 tiles - which beat 128 x 64 (116.8) and 128 x 128 (136.6): these launches
     // are bound by per-workgroup latency chains (load -> LDS -> MFMA -> epilogue stores), not by re-read traffic, and more, smaller workgroups overlap them better.
-    // "big_tile0" / "big_tile1": tile of the bf16-out / fp32-residual GEMMs, 0 = by measurement (64 x 64), 1 = 128x128, 2 = 128x64, 3 = 64x64.
+    // "big_tile0" / "big_tile1": tile of the bf16-out / fp32-residual GEMMs, 0 = by measurement (64 x 64), 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x64 (the N = 256 residual GEMMs and convolutions are only 676 workgroups at M = 10 784 as 64 x 64 tiles).
     // `attn2_rows`: attention with 32 queries per wave (attn_flow_kernel<.., QG = 2>) from that many rows on; 0 = never, the default: at M = 10 784 it measured
     // 54.1 us per launch against 43.0 for QG = 1 (164 registers: one 8-wave workgroup per CU instead of two).
     int big_rows = 4000, attn2_rows = 0, big_tile0 = 0, big_tile1 = 0;       // 4000: from 3 utterances of U10 per pass (profiles/r4_flow_big_ab.txt, fourth series: 61.6 -> 57.4 ms at 3, 48.4 vs 50.8 at 2)
@@ -469,6 +469,7 @@ template <int OMODE, bool GLDS>
 static void gemm_big_launch2(const FlowGemmArgs& a, int tile, hipStream_t s) {
     if (tile == 1) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 128, OMODE, false, GLDS>), dim3(big_grid(a.M, a.N, 128, 128)), dim3(256), 0, s, a);
     else if (tile == 2) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 64, OMODE, false, GLDS>), dim3(big_grid(a.M, a.N, 128, 64)), dim3(256), 0, s, a);
+    else if (tile == 4) hipLaunchKernelGGL((flow_gemm_big_kernel<32, 64, OMODE, false, GLDS>), dim3(big_grid(a.M, a.N, 32, 64)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((flow_gemm_big_kernel<64, 64, OMODE, false, GLDS>), dim3(big_grid(a.M, a.N, 64, 64)), dim3(256), 0, s, a);
 }
 template <int OMODE>
@@ -500,6 +501,7 @@ template <bool GLDS>
 static void conv_big_launch(const FlowGemmArgs& a, int tile, hipStream_t s) {
     if (tile == 1) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 128, 1, true, GLDS>), dim3(big_grid(a.M, a.N, 128, 128)), dim3(256), 0, s, a);
     else if (tile == 2) hipLaunchKernelGGL((flow_gemm_big_kernel<128, 64, 1, true, GLDS>), dim3(big_grid(a.M, a.N, 128, 64)), dim3(256), 0, s, a);
+    else if (tile == 4) hipLaunchKernelGGL((flow_gemm_big_kernel<32, 64, 1, true, GLDS>), dim3(big_grid(a.M, a.N, 32, 64)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((flow_gemm_big_kernel<64, 64, 1, true, GLDS>), dim3(big_grid(a.M, a.N, 64, 64)), dim3(256), 0, s, a);
 }
 static void conv_big(const Lin& l, const bf16_t* A, int T, int nz, int pad_left, float* C, const float* res, const void* zeros, hipStream_t s) {
@@ -892,7 +894,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "tail_ring") { m->tail_ring = value == 16 ? 16 : 8; drop_graphs(m); }      // bf16 mode: one row-band launch after each attention (flow_tail.h) on / off
         else if (std::string(name) == "big_rows") { CV_CHECK(value >= 0, "big_rows must be >= 0"); m->big_rows = value; drop_graphs(m); }
         else if (std::string(name) == "attn2_rows") { CV_CHECK(value >= 0, "attn2_rows must be >= 0"); m->attn2_rows = value; drop_graphs(m); }
-        else if (std::string(name) == "big_tile0") { CV_CHECK(value >= 0 && value <= 3, "big_tile0 must be 0..3"); m->big_tile0 = value; drop_graphs(m); }
+        else if (std::string(name) == "big_tile0") { CV_CHECK(value >= 0 && value <= 4, "big_tile0 must be 0..4"); m->big_tile0 = value; drop_graphs(m); }
         else if (std::string(name) == "big_persist") { CV_CHECK(value >= -1 && value <= 8, "big_persist must be -1..8"); m->big_persist = value; drop_graphs(m); }
         else if (std::string(name) == "gemm_dbg") { m->gemm_dbg_on = value; if (value) { m->gemm_dbg.ensure((size_t)65536 * 8 * 8); CV_HIP(hipMemset(m->gemm_dbg.p, 0, m->gemm_dbg.bytes)); } drop_graphs(m); }
         else if (std::string(name) == "attn_dbg") { m->attn_dbg_on = value != 0; if (value) { m->attn_dbg.ensure((size_t)65536 * 8 * 8); CV_HIP(hipMemset(m->attn_dbg.p, 0, m->attn_dbg.bytes)); } drop_graphs(m); }
@@ -900,7 +902,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "enc_batch") m->enc_batch = value != 0;
         else if (std::string(name) == "big_glds") { m->big_glds = value != 0; drop_graphs(m); }
         else if (std::string(name) == "big_grid_cap") { CV_CHECK(value >= 0, "big_grid_cap must be >= 0"); m->big_grid_cap = value; drop_graphs(m); }
-        else if (std::string(name) == "big_tile1") { CV_CHECK(value >= 0 && value <= 3, "big_tile1 must be 0..3"); m->big_tile1 = value; drop_graphs(m); }
+        else if (std::string(name) == "big_tile1") { CV_CHECK(value >= 0 && value <= 4, "big_tile1 must be 0..4"); m->big_tile1 = value; drop_graphs(m); }
         else if (std::string(name) == "fused") { m->fused = value != 0; drop_graphs(m); }              // bf16 mode: fused transformer blocks (flow_fused.h) on / off
         else throw Error(std::string("unknown option ") + name);
     });

@@ -392,7 +392,7 @@ def test_two_n_tiles_per_workgroup_is_bit_identical(lib):
     lib.cv_flow_set_option(flow._h, b"flow_ntile", C.c_int32(0))
 
 
-@pytest.mark.parametrize("tile0,tile1", [(1, 1), (2, 2), (3, 3), (0, 0)])
+@pytest.mark.parametrize("tile0,tile1", [(1, 1), (2, 2), (3, 3), (0, 0), (3, 4), (4, 4)])
 def test_big_m_kernels_are_bit_identical(lib, tile0, tile1):
     """bf16 mode, round 4: the large-M kernel set (flow_big.h: LayerNorm once per row -> bf16, 128 x 128 / 128 x 64 / 64 x 64 GEMM tiles over a swizzled LDS ring,
     attention with 32 queries per wave) is selected by the ROW COUNT of a pass, so it has to compute every element exactly as the small-tile path does - an
