@@ -256,9 +256,12 @@ def _p(t):
 class _KVState:
     """Per-layer rows [cap, 4 d] = (q + u | q + v | k | v) of everything forwarded so far (forward_chunk's att_cache, kept in place)."""
 
+    _serials = iter(range(1, 1 << 62))
+
     def __init__(self, kern, n_layers, d, cap):
         self.kern, self.d, self.len, self.cap = kern, d, 0, cap
         self.rows = [kern.zeros(cap, 4 * d) for _ in range(n_layers)]
+        self.ident = (next(_KVState._serials), 0)               # (which state, which allocation of its rows): what a bound decode step (cv_lm1_bind) is valid for
 
     def reserve(self, n):
         if n <= self.cap:
@@ -269,6 +272,7 @@ class _KVState:
             new[: self.len].copy_(old[: self.len])
             self.rows[i] = new
         self.cap = cap
+        self.ident = (self.ident[0], self.ident[1] + 1)
 
 
 class _FusedStep:
@@ -414,7 +418,7 @@ class EspnetEncoder(C1.EspnetEncoder):
         K, t0 = self.k, state.len
         state.reserve(t0 + 1)
         self._pos_tables(state.cap)                             # the tables cover every position the cache can hold: n_tab >= cap
-        key = (state.cap, self._pos_n) + tuple(r.data_ptr() for r in state.rows)
+        key = (state.ident, self._pos_n)
         if step.bound != key:
             n = self.n_layers
             rows = (C.c_void_p * n)(*[r.data_ptr() for r in state.rows])
