@@ -677,7 +677,7 @@ def run_mixed(model, reqs, mine, slots=8):
     """This rank's shard through the throughput pipeline (LM continuous batching overlapped with flow + HiFT); returns {index: sha1 of wav}."""
     import hashlib
     out = {}
-    for j, res in model.tts_queue([reqs[i] for i in mine], slots=slots):
+    for j, res in model.tts_queue([reqs[i] for i in mine], slots=slots, order=os.environ.get("CV_BENCH_MIXED_ORDER", "longest_first")):      # (A/B knob: "fifo")
         out[mine[j]] = hashlib.sha1(res["tts_speech"].numpy().tobytes()).hexdigest()
     return out
 
@@ -718,9 +718,11 @@ def mixed64_extra(model, cfgs, lanes):
     toks = {}
     inf_q = model.llm.inference_queue
 
+    which = {id(r["text"]): i for i, r in enumerate(reqs)}             # tts_queue admits the requests longest first: the LM sees them permuted
+
     def spy(r, slots=8, **kw):
         for j, t in inf_q(r, slots=slots, **kw):
-            toks[mine[j]] = list(t)
+            toks[which[id(r[j]["text"])]] = list(t)
             yield j, t
     model.llm.inference_queue = spy
     try:

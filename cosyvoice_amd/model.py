@@ -419,15 +419,21 @@ class CosyVoice2Model:
             outs[i] = o
         return outs
 
-    def tts_queue(self, requests, slots=8, speed=1.0):
+    def tts_queue(self, requests, slots=8, speed=1.0, order="longest_first"):
         """Throughput pipeline for many offline requests (BASELINE.json configs[2]/[3]): a producer thread runs the LM with continuous
         batching (Qwen2LM.inference_queue, <= `slots` sequences in flight, on the LLM stream) while the calling thread turns every finished
         token sequence into audio (flow + HiFT on the caller's stream) - LM decode of the next sequences overlaps the vocoding of the
-        finished ones.  Yields (request_index, {'tts_speech': [1, S]}) in completion order; each waveform equals tts(**request)."""
+        finished ones.  Yields (request_index, {'tts_speech': [1, S]}) in completion order; each waveform equals tts(**request).
+        order: "longest_first" (default, round 4) admits the requests by decreasing length bound (text ids x max_token_text_ratio - what the reference's own
+        stopping rule makes the expected length proportional to, llm.py:484-485): the slots do not idle behind one long request admitted last, and requests of
+        similar length finish - and share flow passes - together; "fifo" admits them as listed.  The audio of a request does not depend on the order."""
         import queue
         q = queue.Queue()
+        assert order in ("longest_first", "fifo"), order
+        bound = lambda r: int(r["text"].shape[1]) * float(r.get("max_token_text_ratio", 20))
+        perm = sorted(range(len(requests)), key=lambda i: -bound(requests[i])) if order == "longest_first" else list(range(len(requests)))       # (stable: ties keep their order)
         lm_reqs = [dict(text=r["text"], prompt_text=r["prompt_text"], prompt_speech_token=r["llm_prompt_speech_token"],
-                        **{k: r[k] for k in ("min_token_text_ratio", "max_token_text_ratio") if k in r}) for r in requests]
+                        **{k: r[k] for k in ("min_token_text_ratio", "max_token_text_ratio") if k in r}) for r in (requests[i] for i in perm)]
 
         def produce():
             try:
@@ -457,7 +463,7 @@ class CosyVoice2Model:
                     elif isinstance(item, BaseException):
                         raise item
                     else:
-                        jobs.append((item[0], requests[item[0]], SilentTokenFilter(self.silent_tokens)(item[1])))
+                        jobs.append((perm[item[0]], requests[perm[item[0]]], SilentTokenFilter(self.silent_tokens)(item[1])))
                 if jobs:
                     yield jobs
 
