@@ -726,7 +726,7 @@ def mixed64_extra(model, cfgs, lanes):
             yield j, t
     model.llm.inference_queue = spy
     try:
-        slots = int(os.environ.get("CV_BENCH_MIXED_SLOTS", 16))       # sequences in flight on the one GPU (A/B knob; up to 32 since round 4)
+        slots = int(os.environ.get("CV_BENCH_MIXED_SLOTS", 32))       # sequences in flight on the one GPU (A/B knob; 16 until round 4: 373 vs 419 audio-s/s, profiles/r4_batch_serving_ab.txt)
         run_mixed(model, reqs, mine, slots=slots)
         torch.cuda.synchronize()
         toks.clear()
@@ -737,7 +737,8 @@ def mixed64_extra(model, cfgs, lanes):
     finally:
         model.llm.inference_queue = inf_q
     assert sorted(hashes) == mine
-    return {"workload": "64 seeded utterances, 125/250/375/500 generated tokens in equal mix (800 s of audio), one GPU, 16 sequences in flight", "audio_s_per_s": round(sum(costs) / 25.0 / el, 3),
+    return {"workload": "64 seeded utterances, 125/250/375/500 generated tokens in equal mix (800 s of audio), one GPU, %d sequences in flight, admitted %s"
+                        % (slots, os.environ.get("CV_BENCH_MIXED_ORDER", "longest_first").replace("_", " ")), "audio_s_per_s": round(sum(costs) / 25.0 / el, 3),
             "wall_s": round(el, 2), "lanes": lanes, "utterance_hashes_sha1": hashlib.sha1("".join(hashes[i] for i in mine).encode()).hexdigest(),
             "token_check": check_mixed_tokens(toks)}
 
