@@ -891,7 +891,7 @@ def main():
         mixed = {"hashes": {}}
 
         def step():
-            mixed["hashes"] = run_mixed(model, reqs, mine, slots=max(1, min(16, len(mine))))      # 8 in flight per GPU at 8 GPUs, 16 when one GPU takes all 64
+            mixed["hashes"] = run_mixed(model, reqs, mine, slots=max(1, min(32, len(mine))))      # 8 in flight per GPU at 8 GPUs, 32 when one GPU takes all 64
     else:
         def step():
             one_utterance(model, u)

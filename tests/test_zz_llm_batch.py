@@ -143,15 +143,17 @@ def test_model_tts_batch(lib):
     for i, a in enumerate(alone + alone[:1]):
         assert torch.equal(seen[i]["tts_speech"], a)
     # admission order (round 4): "longest_first" hands the LM the requests by decreasing length bound (text ids x max ratio), "fifo" as listed; the indices that come
-    # back are the caller's and the audio of a request is the same either way
+    # back are the caller's, each job carries its own request.  (The LM and the vocoder are stubbed here: what is under test is the bookkeeping.)
     admitted = []
-    inner = m.llm.inference_queue
-    m.llm.inference_queue = lambda reqs_, slots=8: (admitted.append([(int(r["text"].shape[1]), r.get("max_token_text_ratio", 20)) for r in reqs_]), inner(reqs_, slots=slots))[1]
+
+    def fake_queue(reqs_, slots=8):
+        admitted.append([int(r["text"].shape[1]) * r.get("max_token_text_ratio", 20) for r in reqs_])
+        for j, r in enumerate(reqs_):
+            yield j, [int(r.get("max_token_text_ratio", 20))] * 3                      # "tokens" that name the request they belong to
+    m.llm.inference_queue = fake_queue
+    m._vocode_all = lambda groups, speed: ((i, {"req": r, "tokens": toks}) for jobs in groups for i, r, toks in jobs)
     mixed = [dict(reqs[1], max_token_text_ratio=6), dict(reqs[0]), dict(reqs[0], max_token_text_ratio=7)]       # bounds 6, 20 (the default ratio), 7 (one text id each)
-    outs = {}
     for order, want in (("fifo", [6, 20, 7]), ("longest_first", [20, 7, 6])):
-        outs[order] = dict(m.tts_queue(mixed, slots=2, order=order))
-        assert [n * r for n, r in admitted[-1]] == want and sorted(outs[order]) == [0, 1, 2]
-    assert torch.equal(outs["fifo"][1]["tts_speech"], alone[0])                                                # (the per-request ratios of 0 and 2 give them their own lengths)
-    assert outs["fifo"][1]["tts_speech"].shape != outs["fifo"][2]["tts_speech"].shape
-    assert all(torch.equal(outs["fifo"][i]["tts_speech"], outs["longest_first"][i]["tts_speech"]) for i in range(3))
+        out = dict(m.tts_queue(mixed, slots=2, order=order))
+        assert admitted[-1] == want and sorted(out) == [0, 1, 2]
+        assert all(out[i]["req"] is mixed[i] and out[i]["tokens"] == [int(mixed[i].get("max_token_text_ratio", 20))] * 3 for i in range(3))
