@@ -628,8 +628,9 @@ static int down_ksplit(int inter) {
 
 // 4 waves = 192 keys per pass.  8 waves (384 keys: the whole context of a 10 s utterance in one load round) measured SLOWER: LM step 1013 -> 1111 us at 8
 // sequences (profiles/r2_batch_decode_ab.txt) - twice the waves per (head, sequence) cost more in the merge and in CU occupancy than the second round does.
-static void launch_attn_batch(const AttnDecodeBatchArgs& ad, int heads, int nb, hipStream_t s) {
-    hipLaunchKernelGGL(attn_decode_batch_kernel<4>, dim3(heads, nb), dim3(256), 0, s, ad);
+static void launch_attn_batch(AttnDecodeBatchArgs ad, int heads, int nb, hipStream_t s) {
+    ad.nb = nb;
+    hipLaunchKernelGGL(attn_decode_batch_kernel<4>, dim3((unsigned)(heads * nb)), dim3(256), 0, s, ad);
 }
 
 // one token for every slot: the launch sequence of llm_enqueue_step on the multi-sequence kernels

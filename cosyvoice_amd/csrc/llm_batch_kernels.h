@@ -862,15 +862,28 @@ struct AttnDecodeBatchArgs {
     const float* qkv; long long ldqkv; float* kcache; float* vcache; long long cache_stride;      // per-sequence strides
     const float* rope_cos; const float* rope_sin; int heads, kv_heads, max_len;
     const DecodeState* st; float* out; long long ldo;
+    int nb = 0;                                      // sequences of the launch (grid = heads * nb workgroups, 1-D)
 };
 
 template <int NW>
 static __global__ __launch_bounds__(NW * 64) void attn_decode_batch_kernel(AttnDecodeBatchArgs p) {
     constexpr int NS = 12, WPASS = 4 * NS, PASS = NW * WPASS;
     __shared__ __attribute__((aligned(16))) float pw[NW][ATTN_PART];
-    const int b = blockIdx.y, h = blockIdx.x;
+    // Workgroup -> (sequence b, head h).  The heads of one kv group read the SAME K / V rows; workgroup i runs on XCD i % 8 and the eight L2s are not coherent, so with
+    // heads as the fast index the 7 heads of a group sat on 7 XCDs and every one of them pulled the group's K / V from HBM (round 4, rocprof of the 32-slot mixed
+    // workload: 30 us per launch at contexts of ~600, the second largest kernel of the run).  Remapped: the heads of a (sequence, kv head) pair get ids that are equal
+    // mod 8 - one XCD, one HBM fetch, six L2 hits.  Same arithmetic per (b, h): same bits.
+    const int gsz = p.heads / p.kv_heads;
+    int b, h;
+    {
+        const int id = blockIdx.x, np = p.nb * p.kv_heads;
+        if ((np & 7) == 0) {
+            const int x = id & 7, q = id >> 3, pair = (q / gsz) * 8 + x;
+            b = pair / p.kv_heads; h = (pair % p.kv_heads) * gsz + q % gsz;
+        } else { b = id / p.heads; h = id % p.heads; }
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15, grp = lane >> 4;
-    const int gsz = p.heads / p.kv_heads, g = h / gsz;
+    const int g = h / gsz;
     const DecodeState* st = p.st + b;
     const float* qkv = p.qkv + (long long)b * p.ldqkv;
     float* kcache = p.kcache + (long long)b * p.cache_stride;
