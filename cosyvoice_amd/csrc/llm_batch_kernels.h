@@ -981,6 +981,127 @@ static __global__ __launch_bounds__(NW * 64) void attn_decode_batch_kernel(AttnD
     }
 }
 
+// The same attention with the heads of a kv group in ONE workgroup (round 4): workgroup = (sequence b, kv head g), 4 key waves x HS head subsets (wave = hs * 4 + kw);
+// a wave loads its key rows once and walks its subset's heads over them.  What it removes: in attn_decode_batch_kernel every one of the gsz query heads of a group
+// pulls the group's K / V rows through its own CU (gsz x the L2 -> CU traffic; at 32 slots and contexts of ~600 keys that kernel was 24 - 30 us per launch, the
+// second largest of the mixed workload).  Per head the arithmetic is that kernel's, slot for slot (same key -> (wave, slot, lane group) map, same online-softmax
+// updates, same merge order): same bits.  No register double buffer for the next pass: the two head subsets of a key wave share a SIMD and cover each other's loads.
+template <int HPW>                                   // heads per wave (subset size): gsz <= 2 * HPW
+static __global__ __launch_bounds__(512) void attn_decode_batch_gqa_kernel(AttnDecodeBatchArgs p) {
+    constexpr int NW = 4, NS = 12, WPASS = 4 * NS, PASS = NW * WPASS;
+    __shared__ __attribute__((aligned(16))) float pw[NW][2 * HPW][ATTN_PART];
+    const int gsz = p.heads / p.kv_heads;
+    const int g = blockIdx.x % p.kv_heads, b = blockIdx.x / p.kv_heads;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wave = wv & 3, hs = wv >> 2, sub = lane & 15, grp = lane >> 4;
+    const int h0 = hs * HPW, nh = min(HPW, gsz - h0);         // this wave's heads: g * gsz + h0 .. + nh - 1 (nh <= 0: a subset with nothing to do still joins the barrier)
+    const DecodeState* st = p.st + b;
+    const float* qkv = p.qkv + (long long)b * p.ldqkv;
+    float* kcache = p.kcache + (long long)b * p.cache_stride;
+    float* vcache = p.vcache + (long long)b * p.cache_stride;
+    const int pos = st->pos;
+    const int L = pos + 1;
+    const float* kc = kcache + (long long)g * p.max_len * 64;
+    const float* vc = vcache + (long long)g * p.max_len * 64;
+    float4 k4[NS], v4[NS];
+    auto load_pass = [&](int base) {
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            const int j = base + wave * WPASS + sl * 4 + grp;
+            const long long o = (long long)(j < pos ? j : 0) * 64 + sub * 4;      // unconditional, clamped
+            k4[sl] = *reinterpret_cast<const float4*>(kc + o);
+            v4[sl] = *reinterpret_cast<const float4*>(vc + o);
+        }
+    };
+    load_pass(0);
+    const float* kq = qkv + p.heads * 64 + g * 64;
+    const float* vq = qkv + (p.heads + p.kv_heads) * 64 + g * 64;
+    const int d0 = sub * 4, dp = (d0 + 32) & 63;
+    const float4 c4 = *reinterpret_cast<const float4*>(p.rope_cos + pos * 32 + (d0 & 31));
+    const float4 s4 = *reinterpret_cast<const float4*>(p.rope_sin + pos * 32 + (d0 & 31));
+    const float4 ka = *reinterpret_cast<const float4*>(kq + d0), kp = *reinterpret_cast<const float4*>(kq + dp);
+    const float4 vn4 = *reinterpret_cast<const float4*>(vq + d0);
+    const float sg = d0 < 32 ? -1.f : 1.f;
+    const float4 kn4 = make_float4(ka.x * c4.x + sg * kp.x * s4.x, ka.y * c4.y + sg * kp.y * s4.y, ka.z * c4.z + sg * kp.z * s4.z, ka.w * c4.w + sg * kp.w * s4.w);
+    float4 q4[HPW];
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) {
+        const float* qraw = qkv + (long long)(g * gsz + min(h0 + i, gsz - 1)) * 64;       // (clamped: unused entries of a short subset read a valid head)
+        const float4 qa = *reinterpret_cast<const float4*>(qraw + d0), qb = *reinterpret_cast<const float4*>(qraw + dp);
+        q4[i] = make_float4(qa.x * c4.x + sg * qb.x * s4.x, qa.y * c4.y + sg * qb.y * s4.y, qa.z * c4.z + sg * qb.z * s4.z, qa.w * c4.w + sg * qb.w * s4.w);
+    }
+    if (!st->done && wv == 0 && grp == 0) {                  // KV-cache append: one wave per workgroup
+        *reinterpret_cast<float4*>(kcache + ((long long)g * p.max_len + pos) * 64 + d0) = kn4;
+        *reinterpret_cast<float4*>(vcache + ((long long)g * p.max_len + pos) * 64 + d0) = vn4;
+    }
+    const float NEG = -__builtin_huge_valf();
+    float m_run[HPW], l_run[HPW];
+    float4 acc[HPW];
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) { m_run[i] = NEG; l_run[i] = 0.f; acc[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int base = 0; base < L; base += PASS) {     // workgroup-uniform
+        if (base > 0) load_pass(base);
+#pragma unroll
+        for (int i = 0; i < HPW; ++i) {
+            if (i >= nh) break;                      // wave-uniform
+            float sc[NS];
+            float mt = NEG;
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                const int j = base + wave * WPASS + sl * 4 + grp;
+                const float4 kk = (j == pos) ? kn4 : k4[sl];
+                float a = q4[i].x * kk.x + q4[i].y * kk.y + q4[i].z * kk.z + q4[i].w * kk.w;
+                a = group16_sum(a) * 0.125f;
+                sc[sl] = j < L ? a : NEG;
+                mt = fmaxf(mt, sc[sl]);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));
+            if (mt != NEG) {                         // wave-uniform: false when this wave holds no key of the pass
+                const float m_new = fmaxf(m_run[i], mt);
+                const float scale = (m_run[i] == NEG) ? 0.f : expf(m_run[i] - m_new);
+                acc[i].x *= scale; acc[i].y *= scale; acc[i].z *= scale; acc[i].w *= scale;
+                float lt = 0.f;
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {
+                    const int j = base + wave * WPASS + sl * 4 + grp;
+                    const float e = (sc[sl] == NEG) ? 0.f : expf(sc[sl] - m_new);
+                    const float4 vv = (j == pos) ? vn4 : v4[sl];
+                    acc[i].x += e * vv.x; acc[i].y += e * vv.y; acc[i].z += e * vv.z; acc[i].w += e * vv.w;
+                    lt += e;
+                }
+                l_run[i] = l_run[i] * scale + lt;
+                m_run[i] = m_new;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) {
+        if (i >= nh) break;
+        float4 a = acc[i]; float l = l_run[i];
+        a.x += __shfl_xor(a.x, 16); a.y += __shfl_xor(a.y, 16); a.z += __shfl_xor(a.z, 16); a.w += __shfl_xor(a.w, 16);
+        a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
+        l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+        if (grp == 0) *reinterpret_cast<float4*>(&pw[wave][h0 + i][sub * 4]) = a;
+        if (lane == 0) { pw[wave][h0 + i][64] = (l > 0.f) ? m_run[i] : 0.f; pw[wave][h0 + i][65] = l; }
+    }
+    __syncthreads();
+    if (tid < 16 * gsz) {                            // merge the key waves of every head (fixed order), normalise
+        const int hh = tid >> 4, t = tid & 15;
+        float M = NEG;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) if (pw[ww][hh][65] > 0.f) M = fmaxf(M, pw[ww][hh][64]);
+        float den = 0.f; float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) {
+            const float wgt = (pw[ww][hh][65] > 0.f) ? expf(pw[ww][hh][64] - M) : 0.f;
+            const float4 tq = *reinterpret_cast<const float4*>(&pw[ww][hh][t * 4]);
+            den += wgt * pw[ww][hh][65];
+            a.x += wgt * tq.x; a.y += wgt * tq.y; a.z += wgt * tq.z; a.w += wgt * tq.w;
+        }
+        const float inv = 1.f / den;
+        *reinterpret_cast<float4*>(p.out + (long long)b * p.ldo + (g * gsz + hh) * 64 + t * 4) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+    }
+}
+
 // advance the KV length of every slot after a backbone step
 static __global__ void advance_pos_batch_kernel(DecodeState* st, int nb) {
     const int b = threadIdx.x;

@@ -102,6 +102,24 @@ def test_more_than_sixteen_slots(lib, nb):
         assert [q[i] for i in range(nb)] == want
 
 
+@pytest.mark.parametrize("heads,kv_heads", [(14, 2), (6, 2)])
+def test_grouped_query_attention_in_one_workgroup(lib, heads, kv_heads, monkeypatch):
+    """Round 4: the batched decode attention with the heads of a kv group in ONE workgroup (attn_decode_batch_gqa_kernel: one load of the group's K / V rows for all of
+    its heads; 7 heads per group = CosyVoice2's shape, a short last subset; 3 per group = the two-heads-per-wave form) against one workgroup per head
+    (CV_ATTN_BATCH_GQA=0): the same tokens, equal to the oracle's, with contexts that cross the 192-key pass boundary."""
+    import dataclasses
+    cfg = dataclasses.replace(W.tiny()[0], heads=heads, kv_heads=kv_heads)                  # (hidden stays 128: the projections are 128 -> 64 * heads)
+    sd = W.make_llm(cfg)
+    reqs = [_req(cfg, 500 + i, 3, 2, (188, 7, 40, 195)[i]) for i in range(4)]          # prompt + text + generated tokens: ~200 / ~20 / ~50 / ~210 keys
+    want = [OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=4, min_token_text_ratio=2) for r in reqs]
+    got = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("CV_ATTN_BATCH_GQA", knob)                               # read when the step of a handle is captured
+        lm = Qwen2LM(sd, cfg, lib=lib, max_len=256, sampling="greedy", decode_chunk=5)
+        got[knob] = lm.inference_batch(reqs, max_token_text_ratio=4, min_token_text_ratio=2)
+    assert got["1"] == got["0"] == want
+
+
 def test_continuous_batching(lib):
     """inference_queue: 7 requests through 3 slots - finished slots are re-filled while the others keep decoding; every request gets
     exactly the tokens it gets alone."""

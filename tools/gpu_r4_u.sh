@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 4: the batched decode attention with the heads of a kv group on one XCD - LM step at 16 / 32 slots, mixed64, and its kernel stats.
+# Round 4: the batched decode attention with the heads of a kv group on one XCD (r4u), then in one workgroup (r4v) - LM step at 16 / 32 slots, mixed64, and its kernel stats.
 set -u
-O=gpurun_out/r4u; mkdir -p $O
+O=gpurun_out/r4v; mkdir -p $O
 R=$GRAFT_REPO_ROOT
 run() { local name=$1; shift; local t0=$(date +%s); echo "== $name"; timeout -k 5 "$@" > $O/$name.log 2>&1; echo "   rc=$? $(( $(date +%s) - t0 ))s"; }
 run pytest_batch 400 python -m pytest tests/test_zz_llm_batch.py tests/test_llm_fp8.py -q -m gpu -p no:cacheprovider -x
