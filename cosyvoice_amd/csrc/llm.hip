@@ -628,12 +628,14 @@ static int down_ksplit(int inter) {
 
 // 4 waves = 192 keys per pass.  8 waves (384 keys: the whole context of a 10 s utterance in one load round) measured SLOWER: LM step 1013 -> 1111 us at 8
 // sequences (profiles/r2_batch_decode_ab.txt) - twice the waves per (head, sequence) cost more in the merge and in CU occupancy than the second round does.
-// Round 4: one workgroup per (sequence, kv head) walks all heads of the group over one load of the K / V rows (attn_decode_batch_gqa_kernel) when a group has 2 .. 8
-// heads; CV_ATTN_BATCH_GQA=0 keeps one workgroup per head (A/B knob, read when a step is enqueued / captured).  Bit-identical either way.
+// Round 4: CV_ATTN_BATCH_GQA=1 (A/B knob, read when a step is enqueued / captured): one workgroup per (sequence, kv head) walks all heads of the group over one load of
+// the K / V rows (attn_decode_batch_gqa_kernel).  Bit-identical, measured SLOWER on the MI355X and therefore off (profiles/r4_batch_serving_ab.txt: LM step 896 -> 1133 us
+// at 16 slots, 1396 -> 1486 at 32; the kernel 24.1 -> 29.9 us per launch in the mixed workload): 7 x the arithmetic of a head on a seventh of the workgroups - the
+// softmax's exp / DPP work per loaded key, not the L2 traffic, is what the launch is made of once the heads of a group share an XCD (the remap in the kernel above).
 static void launch_attn_batch(AttnDecodeBatchArgs ad, int heads, int nb, hipStream_t s) {
     ad.nb = nb;
     const int gsz = heads / ad.kv_heads;
-    const bool gqa = [] { const char* e = getenv("CV_ATTN_BATCH_GQA"); return !(e && e[0] == '0'); }();
+    const bool gqa = [] { const char* e = getenv("CV_ATTN_BATCH_GQA"); return e && e[0] == '1'; }();
     if (gqa && gsz >= 2 && gsz <= 8 && heads % ad.kv_heads == 0) {
         const dim3 grid((unsigned)(ad.kv_heads * nb));
         if (gsz <= 2) hipLaunchKernelGGL(attn_decode_batch_gqa_kernel<1>, grid, dim3(512), 0, s, ad);

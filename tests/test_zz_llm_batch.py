@@ -105,8 +105,8 @@ def test_more_than_sixteen_slots(lib, nb):
 @pytest.mark.parametrize("heads,kv_heads", [(14, 2), (6, 2)])
 def test_grouped_query_attention_in_one_workgroup(lib, heads, kv_heads, monkeypatch):
     """Round 4: the batched decode attention with the heads of a kv group in ONE workgroup (attn_decode_batch_gqa_kernel: one load of the group's K / V rows for all of
-    its heads; 7 heads per group = CosyVoice2's shape, a short last subset; 3 per group = the two-heads-per-wave form) against one workgroup per head
-    (CV_ATTN_BATCH_GQA=0): the same tokens, equal to the oracle's, with contexts that cross the 192-key pass boundary."""
+    its heads; 7 heads per group = CosyVoice2's shape, a short last subset; 3 per group = the two-heads-per-wave form; opt-in with CV_ATTN_BATCH_GQA=1 - measured slower
+    on the MI355X) against one workgroup per head with the group's heads on one XCD (the default): the same tokens, equal to the oracle's, with contexts that cross the 192-key pass boundary."""
     import dataclasses
     cfg = dataclasses.replace(W.tiny()[0], heads=heads, kv_heads=kv_heads)                  # (hidden stays 128: the projections are 128 -> 64 * heads)
     sd = W.make_llm(cfg)
