@@ -7,11 +7,11 @@ set -u
 O=gpurun_out/checklist; mkdir -p $O
 R=$GRAFT_REPO_ROOT
 run() { local name=$1; shift; echo "== $name"; timeout -k 5 "$@" > $O/$name.log 2>&1; echo "   rc=$? ($(tail -1 $O/$name.log | cut -c1-150))"; }
-run pytest_gpu            800 python -X faulthandler -m pytest tests -q -m gpu -p no:cacheprovider         # [239 passed, 3 skipped, 4-10 min by the box]
+run pytest_gpu            800 python -X faulthandler -m pytest tests -q -m gpu -p no:cacheprovider         # [241 passed, 3 skipped, 4-10 min by the box]
 run smoke                  60 python -c "import __graft_entry__ as g; g.smoke()"
 # the driver's command; the line carries every other BASELINE.json configuration as an extra (each in a process of its own, 2 lanes):
-# [56.0 audio-s/s, first chunk 58.4 ms, gate/up 0.40; 8 streaming clients 161-172 audio-s/s at p50 119-121 ms; batch 8 / 16 / 32 222 / 354 / 392-406; mixed64 398-419 (32 in flight,
-#  longest first); cosyvoice3 61 / 353-362, fp8 321; cosyvoice300m 28.4-28.9]
+# [56.2 audio-s/s, first chunk 58.4 ms, gate/up 0.39-0.40; 8 streaming clients 173 audio-s/s at p50 117 ms; batch 8 / 16 / 32 226 / 367 / 416 (246 / 384 / 441 overlapped);
+#  mixed64 432 (32 in flight, longest first); cosyvoice3 60 / 368, fp8 330; cosyvoice300m 28.3-28.9]
 run bench_driver          600 python bench.py --gpus 1 --steps 20 --warmup 5
 python - "$O/bench_driver.log" <<'PY'
 import json, sys
