@@ -1,0 +1,71 @@
+"""The large-M kernel set of the flow estimator (round 4, csrc/flow_big.h): bit identity with the small-tile path, tile by tile and pass by pass.  In a file of its own:
+under the emulator every variant is a minute of work, and pytest-xdist hands out whole files."""
+import pytest
+import torch
+
+from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+from cosyvoice_amd import synthetic as W
+
+
+@pytest.mark.parametrize("tile0,tile1", [(1, 1), (2, 2), (3, 3), (0, 0), (3, 4), (4, 4)])
+def test_big_m_kernels_are_bit_identical(lib, tile0, tile1):
+    """bf16 mode, round 4: the large-M kernel set (flow_big.h: LayerNorm once per row -> bf16, 128 x 128 / 128 x 64 / 64 x 64 GEMM tiles over a swizzled LDS ring,
+    attention with 32 queries per wave) is selected by the ROW COUNT of a pass, so it has to compute every element exactly as the small-tile path does - an
+    utterance's mel must not depend on what it shared a pass with.  Forced on (big_rows = attn2_rows = 1) against forced off (0), bit for bit, on the emulator
+    AND on the hardware: two heads, T not a multiple of 4 / 16 / 64 / 128 (V^T pairs straddling requests, ragged row and query tiles), several key tiles,
+    both mask modes, CFG batch rows, K = 128 (two k stages) and K = 512 (FF2: eight)."""
+    import ctypes as C
+    import dataclasses
+    cfg = dataclasses.replace(W.tiny()[1], est_ch=128, est_heads=2, est_mid=1, chunk=13)
+    sd = W.make_flow(cfg)
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision="bf16")
+    g = torch.Generator().manual_seed(14)
+
+    def opt(big, attn2, cap=0, glds=0, epi=1):
+        for k, v in (("big_rows", big), ("attn2_rows", attn2), ("big_tile0", tile0), ("big_tile1", tile1), ("big_grid_cap", cap), ("big_glds", glds), ("big_lds_epi", epi)):
+            lib.cv_flow_set_option(flow._h, k.encode(), C.c_int32(v))
+    try:
+        for T in ((45, 150) if lib.emulated else (45, 150, 281)):       # (the third length only on the hardware: the emulator pays T^2 per attention)
+            x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g); cond = torch.randn(2, 80, T, generator=g)
+            spk = torch.randn(2, 80, generator=g); t = torch.tensor([0.3, 0.3]); mask = torch.ones(2, 1, T)
+            for streaming in (False, True):
+                outs = []
+                # cap = 3 / 1: the persistent form proper - three workgroups (one) walk all the tiles of a launch, the stage pipeline running across tile boundaries
+                # glds = 1: the stages by LDS-DMA (global_load_lds) instead of registers + ds_write
+                # epi = 0: per-lane stores from the accumulator layout instead of the row-wise stores through LDS (the default of the one-tile-per-workgroup form)
+                for big, attn2, cap, glds, epi in ((0, 0, 0, 0, 1), (1, 0, 0, 0, 1), (0, 1, 0, 0, 1), (1, 1, 0, 0, 1), (1, 0, 3, 0, 1), (1, 1, 1, 0, 1), (1, 0, 0, 1, 1), (1, 0, 2, 1, 1),
+                                                   (1, 0, 0, 0, 0), (1, 0, 0, 1, 0)):
+                    opt(big, attn2, cap, glds, epi)
+                    outs.append(flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu().clone())
+                assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
+                for k in range(1, len(outs)):
+                    assert torch.equal(outs[0], outs[k]), (T, streaming, k, (outs[0] - outs[k]).abs().max().item())
+    finally:
+        opt(5000, 0)
+        lib.cv_flow_set_option(flow._h, b"big_tile0", C.c_int32(0)); lib.cv_flow_set_option(flow._h, b"big_tile1", C.c_int32(0)); lib.cv_flow_set_option(flow._h, b"big_grid_cap", C.c_int32(0))
+
+
+def test_big_m_pass_equals_single_passes(lib):
+    """The contract the thresholds rely on, end to end: a padded pass over utterances of different lengths with the large-M kernels forced on gives every
+    utterance the mel of its own single pass with them off (cv_flow_inference_ragged, bf16 mode, streaming and not)."""
+    import ctypes as C
+    cfg = W.tiny()[1]
+    cfg = __import__("dataclasses").replace(cfg, n_timesteps=2)
+    sd = W.make_flow(cfg)
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision="bf16")
+    g = torch.Generator().manual_seed(15)
+    items = []
+    for n_t, n_p in ((40, 9), (33, 5), (37, 7)):
+        items.append(dict(token=torch.randint(0, cfg.vocab, (1, n_t), generator=g, dtype=torch.int32), prompt_token=torch.randint(0, cfg.vocab, (1, n_p), generator=g, dtype=torch.int32),
+                          prompt_feat=torch.randn(1, 2 * n_p, 80, generator=g) * 2 - 5, embedding=torch.randn(1, cfg.spk_dim, generator=g)))
+    try:
+        for k, v in (("big_rows", 0), ("attn2_rows", 0)):
+            lib.cv_flow_set_option(flow._h, k.encode(), C.c_int32(v))
+        single = [flow.inference_batch([it])[0].cpu().clone() for it in items]
+        for k, v in (("big_rows", 1), ("attn2_rows", 1)):
+            lib.cv_flow_set_option(flow._h, k.encode(), C.c_int32(v))
+        together = [m.cpu().clone() for m in flow.inference_batch(items)]
+        for a, b in zip(single, together):
+            assert a.shape == b.shape and torch.equal(a, b), (a.shape, (a - b).abs().max().item())
+    finally:
+        lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(5000)); lib.cv_flow_set_option(flow._h, b"attn2_rows", C.c_int32(0))
