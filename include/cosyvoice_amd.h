@@ -347,6 +347,7 @@ int cv_transpose(const float* in, float* out, int32_t rows, int32_t cols, void* 
  * rows 0 .. pos, after_norm, decoder -> logits dev [n_out].  73 launches for 14 layers; with option "graph" all but the first are one hipGraph captured once per handle:
  * position, cache and table addresses are read on the device from a block the first kernel / cv_lm1_bind update.  Results: every GEMV and LayerNorm has the bits of
  * the cv_gemm_conv (M = 1) / cv_norm_rows launches it replaces; the one-query attention sums exact fp32 products in another order (fp32 rounding). */
+/* A handle serves one step at a time (not thread-safe; the host side serialises requests per LM object); bind and step on the SAME stream. */
 typedef struct cv_lm1 cv_lm1;
 typedef struct cv_lm1_layer_weights {
     const float *ln1_g, *ln1_b, *w_qkv, *b_qkv, *w_out, *b_out, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2;
