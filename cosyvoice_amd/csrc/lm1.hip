@@ -16,6 +16,7 @@
 // (option "graph", off by default: on the MI355X the replay costs 0.607 ms per token against 0.591 ms for the same launches issued one by one).
 #include "api_common.h"
 #include "common.h"
+#include <cstdlib>
 #include <vector>
 
 namespace cv {
