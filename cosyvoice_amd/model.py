@@ -84,7 +84,7 @@ class CosyVoice2Model:
         # (cloned handles over the same weights, one HIP stream each) and concurrent token2wav calls then overlap on the GPU - the flow and
         # the vocoder are chains of small latency-bound kernels that leave most of the 256 CUs idle
         self.n_lanes, self._lane_q = 0, queue.Queue()
-        self.flow_batch = 4                    # offline batch paths (tts_batch / tts_queue): up to this many sequences share one flow pass ...
+        self.flow_batch = 8                    # offline batch paths (tts_batch / tts_queue): up to this many sequences share one flow pass (4 until round 4: from 3 per pass the large-M kernels serve it, 13 vs 17 ms per utterance at 8) ...
         self.flow_pad = 1.25                   # ... when the longest of them has at most this many times the frames of the shortest (padded pass)
         # ... and, opt-in until measured on the MI355X (bench.py --hift-batch / CV_HIFT_BATCH=1), the equal-length members of such a group share ONE HiFT launch
         # sequence as well (HiFTGenerator.inference_batch; bit-identical per utterance)
@@ -100,7 +100,7 @@ class CosyVoice2Model:
     def set_lanes(self, n):
         """n >= 1 token2wav lanes.  Call while no request is in flight.  Keep lanes + 2 (the LM stream, the default stream) within the runtime's hardware queues
         (ROCm: 4 per process): beyond that, which streams share a queue depends on the process's history and two busy lanes may serialise
-        (profiles/r3_stream_after_batch.txt).  With shared flow passes (flow_batch = 4) two lanes serve eight streaming clients.  (Lane streams restricted to a subset of the CUs with
+        (profiles/r3_stream_after_batch.txt).  With shared flow passes (flow_batch = 8) two lanes serve eight streaming clients.  (Lane streams restricted to a subset of the CUs with
         hipExtStreamCreateWithCUMask, to keep CUs free for the LM chain, were measured: every mask - even 224 of 256 CUs - more than doubled
         both the LM's and the vocoder's latency at 8 streaming clients, profiles/r2_lane_cu_mask_ab.txt.  Plain streams.)"""
         assert n >= 1
