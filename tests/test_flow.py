@@ -85,6 +85,17 @@ def test_estimator_padded_mask(lib, tiny, streaming, precision):
     bad = mask.clone(); bad[1, 0, 3] = 0
     with pytest.raises(NotImplementedError):
         flow.decoder.estimator(x, bad, mu, t, spk, cond, streaming=streaming)
+    # the entry point itself refuses key counts outside 1 .. T (an empty row, a row longer than the tensor) and key counts without a mask
+    import ctypes as C
+    from cosyvoice_amd._lib import CosyVoiceAmdError
+    dev = flow.device
+    ten = [lib.hook(a.to(dev).contiguous()) for a in (x, mask, mu, t, spk, cond)]
+    outb = lib.hook(torch.empty(2, 80, T, device=dev))
+    p = lambda a: C.c_void_p(a.data_ptr())
+    for kl, with_mask in (((T + 1, T), True), ((0, T), True), ((T, T), False)):
+        with pytest.raises(CosyVoiceAmdError, match="key_len"):
+            lib.cv_flow_estimator_masked(flow._h, p(ten[0]), p(ten[1]) if with_mask else None, (C.c_int32 * 2)(*kl), p(ten[2]), p(ten[3]), p(ten[4]), p(ten[5]),
+                                         C.c_int32(T), C.c_int32(int(streaming)), p(outb), None)
 
 
 def test_estimator_like_export_onnx_check(lib, tiny):
