@@ -60,7 +60,7 @@ struct cv_llm {
     // lock-step batched decode (llm_batch_kernels.h): nb slots, each with its own KV cache / state / token history
     struct Batch {
         int nb = 0;
-        DevBuf kcache, vcache, state, tokens, sparams, uniforms, h, qkv, act, logits, attn, dpart;   // attn: merged attention [nb][heads*64]; dpart: split-K partials of down
+        DevBuf kcache, vcache, state, tokens, sparams, uniforms, h, qkv, act, logits, attn, dpart, apart;   // attn: merged attention [nb][heads*64]; dpart: split-K partials of down
         std::vector<DecodeState> host_state; std::vector<int> host_tokens; std::vector<SampleParams> host_sp;
         hipGraphExec_t graph = nullptr; hipStream_t graph_stream = nullptr; int graph_nb = 0;
     } bt;
@@ -492,7 +492,7 @@ static void batch_begin(cv_llm* m, int nb, hipStream_t s) {
     b.state.ensure((size_t)nb * sizeof(DecodeState)); b.tokens.ensure((size_t)nb * c.max_len * sizeof(int));
     b.sparams.ensure((size_t)nb * sizeof(SampleParams)); b.uniforms.ensure((size_t)nb * 2 * c.max_len * 4);
     b.h.ensure((size_t)nb * c.hidden * 4); b.qkv.ensure((size_t)nb * m->qkv_dim * 4); b.act.ensure((size_t)nb * c.inter * 4);
-    b.logits.ensure((size_t)nb * m->V * 4); b.attn.ensure((size_t)nb * c.heads * 64 * 4); b.dpart.ensure((size_t)8 * nb * c.hidden * 4);
+    b.logits.ensure((size_t)nb * m->V * 4); b.attn.ensure((size_t)nb * c.heads * 64 * 4); b.dpart.ensure((size_t)8 * nb * c.hidden * 4); b.apart.ensure((size_t)nb * c.heads * 8 * ATTN_PART * 4);   // apart: key-slice partials of the batched attention (<= 8 slices)
     b.host_state.assign(nb, DecodeState{}); b.host_tokens.assign((size_t)nb * c.max_len, 0); b.host_sp.assign(nb, SampleParams{});
     for (auto& st : b.host_state) { st.done = 1; st.stop_token = -1; }           // empty slots are "finished"
     CV_HIP(hipMemcpyAsync(b.state.p, b.host_state.data(), (size_t)nb * sizeof(DecodeState), hipMemcpyHostToDevice, s));
@@ -632,9 +632,27 @@ static int down_ksplit(int inter) {
 // the K / V rows (attn_decode_batch_gqa_kernel).  Bit-identical, measured SLOWER on the MI355X and therefore off (profiles/r4_batch_serving_ab.txt: LM step 896 -> 1133 us
 // at 16 slots, 1396 -> 1486 at 32; the kernel 24.1 -> 29.9 us per launch in the mixed workload): 7 x the arithmetic of a head on a seventh of the workgroups - the
 // softmax's exp / DPP work per loaded key, not the L2 traffic, is what the launch is made of once the heads of a group share an XCD (the remap in the kernel above).
-static void launch_attn_batch(AttnDecodeBatchArgs ad, int heads, int nb, hipStream_t s) {
+// Round 5 (default): attn_decode_batch_mfma_kernel - workgroup = (sequence, kv head, key slice), the group's heads as the columns of the fp32 MFMA, K / V read once
+// per pair; nslice > 1 adds attn_merge_batch_kernel.  Slices: enough workgroups for one round over the 256 CUs (4-wave workgroups: 4 slices at 32 sequences x 2 kv
+// heads, 8 at 16).  A/B knobs, read when a step is enqueued / captured: CV_ATTN_BATCH=0 (the per-head VALU kernel of rounds 2-4), CV_ATTN_BATCH_SLICES=1..8,
+// CV_ATTN_BATCH_WAVES=4|8.
+static void launch_attn_batch(AttnDecodeBatchArgs ad, int heads, int nb, hipStream_t s, float* part) {
     ad.nb = nb;
     const int gsz = heads / ad.kv_heads;
+    const bool mfma = [] { const char* e = getenv("CV_ATTN_BATCH"); return !(e && e[0] == '0'); }();
+    if (mfma && part && gsz >= 1 && gsz <= 16 && heads % ad.kv_heads == 0) {
+        const int pairs = nb * ad.kv_heads;
+        const int nw = [] { const char* e = getenv("CV_ATTN_BATCH_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
+        int S = [] { const char* e = getenv("CV_ATTN_BATCH_SLICES"); return e ? atoi(e) : 0; }();
+        if (S <= 0) { S = 1; while (S < 8 && pairs * S * (nw / 4) < 256) S <<= 1; }
+        S = std::min(std::max(S, 1), 8);
+        ad.part = part; ad.nslice = S;
+        const dim3 grid((unsigned)(pairs * S));
+        if (nw == 8) hipLaunchKernelGGL(attn_decode_batch_mfma_kernel<8>, grid, dim3(512), 0, s, ad);
+        else hipLaunchKernelGGL(attn_decode_batch_mfma_kernel<4>, grid, dim3(256), 0, s, ad);
+        if (S > 1) hipLaunchKernelGGL(attn_merge_batch_kernel, dim3((unsigned)((nb * heads * 16 + 255) / 256)), dim3(256), 0, s, ad);
+        return;
+    }
     const bool gqa = [] { const char* e = getenv("CV_ATTN_BATCH_GQA"); return e && e[0] == '1'; }();
     if (gqa && gsz >= 2 && gsz <= 8 && heads % ad.kv_heads == 0) {
         const dim3 grid((unsigned)(ad.kv_heads * nb));
@@ -671,7 +689,7 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
             skinny_f8(SkinnyF8Args{F.qkv.w, F.qkv.s, L.bqkv, h, H, qkv, Q, (int)Q, c.hidden, L.ln1, c.rms_eps, nullptr, 0, 0, nb, 1}, 1, s);
             AttnDecodeBatchArgs ad{qkv, Q, b.kcache.as<float>() + m->layer_cache() * l, b.vcache.as<float>() + m->layer_cache() * l, (long long)m->slot_cache(),
                                    m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st, att, A};
-            launch_attn_batch(ad, c.heads, nb, s);
+            launch_attn_batch(ad, c.heads, nb, s, b.apart.as<float>());
             skinny_f8(SkinnyF8Args{F.o.w, F.o.s, nullptr, att, A, h, H, c.hidden, (int)A, nullptr, 0.f, h, H, 0, nb, 1}, 1, s);
             skinny_f8(SkinnyF8Args{F.gu.w, F.gu.s, nullptr, h, H, act, I, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 0, 1, nb, 1}, 2, s);
             if (k8 > 1) {
@@ -709,7 +727,7 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
         skinny(SkinnyArgs{L.wqkv, L.bqkv, h, H, qkv, Q, (int)Q, c.hidden, L.ln1, c.rms_eps, nullptr, 0, 0, nb, 1}, 1, s, m->pk(L.wqkv));
         AttnDecodeBatchArgs ad{qkv, Q, b.kcache.as<float>() + m->layer_cache() * l, b.vcache.as<float>() + m->layer_cache() * l, (long long)m->slot_cache(),
                                m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st, att, A};
-        launch_attn_batch(ad, c.heads, nb, s);
+        launch_attn_batch(ad, c.heads, nb, s, b.apart.as<float>());
         skinny(SkinnyArgs{L.wo, nullptr, att, A, h, H, c.hidden, (int)A, nullptr, 0.f, h, H, 0, nb, 1}, 1, s, m->pk(L.wo));
         // packed: four row tiles per workgroup (152 workgroups) measured 7.3 us against 8.0 for two and 8.7 for one (profiles/r3_skinny_probe.txt)
         skinny(SkinnyArgs{L.wgu, nullptr, h, H, act, I, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 0, 1, nb, 1}, m->pk(L.wgu) ? 4 : wide_rt, s, m->pk(L.wgu));

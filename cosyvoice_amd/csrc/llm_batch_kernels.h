@@ -843,12 +843,20 @@ static __global__ __launch_bounds__(256) void sum_partials_kernel(const float* p
     const int per = N >> 2;
     if (i >= nb * per) return;
     const int b = i / per, n = (i % per) * 4;
-    float4 v = *reinterpret_cast<const float4*>(part + (long long)b * N + n);
-    for (int s = 1; s < ksplit; ++s) {
-        const float4 o = *reinterpret_cast<const float4*>(part + ((long long)s * nb + b) * N + n);
-        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    // round 5: all the partials (and the residual) requested before the first add - with a run-time trip count every load of the loop was its own round trip
+    // to the memory side (the partials were written by other XCDs): 5.2 us per launch for 1 MB.  Same order of additions: same bits.
+    float4 o[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) o[s] = *reinterpret_cast<const float4*>(part + ((long long)min(s, ksplit - 1) * nb + b) * N + n);
+    const float4 r = *reinterpret_cast<const float4*>((res ? res + (long long)b * ldres : part) + n);
+    float4 v = o[0];
+#pragma unroll
+    for (int s = 1; s < 8; ++s) if (s < ksplit) { v.x += o[s].x; v.y += o[s].y; v.z += o[s].z; v.w += o[s].w; }
+    for (int s = 8; s < ksplit; ++s) {                                  // (never taken by the models here: down_ksplit() <= 8)
+        const float4 x = *reinterpret_cast<const float4*>(part + ((long long)s * nb + b) * N + n);
+        v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
     }
-    if (res) { const float4 r = *reinterpret_cast<const float4*>(res + (long long)b * ldres + n); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    if (res) { v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
     *reinterpret_cast<float4*>(y + (long long)b * ldy + n) = v;
 }
 
@@ -863,6 +871,7 @@ struct AttnDecodeBatchArgs {
     const float* rope_cos; const float* rope_sin; int heads, kv_heads, max_len;
     const DecodeState* st; float* out; long long ldo;
     int nb = 0;                                      // sequences of the launch (grid = heads * nb workgroups, 1-D)
+    float* part = nullptr; int nslice = 1;           // attn_decode_batch_mfma_kernel: key slices per (sequence, kv head); > 1: un-normalised partials [pair][slice][head][ATTN_PART]
 };
 
 template <int NW>
@@ -1100,6 +1109,211 @@ static __global__ __launch_bounds__(512) void attn_decode_batch_gqa_kernel(AttnD
         const float inv = 1.f / den;
         *reinterpret_cast<float4*>(p.out + (long long)b * p.ldo + (g * gsz + hh) * 64 + t * 4) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the same attention on the fp32 matrix pipe, K / V of a (sequence, kv head) pair read ONCE for all the heads of the group.
+// The per-head kernels above spend ~40 VALU instructions per (key slot of 4 keys, head) on 16-lane dot products, DPP reductions and softmax bookkeeping, once per
+// query head, and every head's workgroup pulls the group's rows through its own CU (rocprof, 32 slots, contexts of ~600 keys: 24 us per launch, 41 % of the
+// lock-step step, 0.8 TB/s).  Here the group's gsz <= 16 query heads are the 16 COLUMNS of v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation):
+//   S^T[key][head] = K[key][:] . Q^T[:][head]     16 MFMAs per tile of 16 keys (A = K rows as loaded, B = the RoPE'd, pre-scaled queries held in registers)
+//   O^T[d][head]  += V^T[d][key] . P[key][head]   16 MFMAs per tile (A = V rows as loaded, B = P straight from the S^T accumulators: S^T's C layout IS the B layout)
+// The reduction index of an MFMA may be permuted freely as long as A and B agree, and so may the output rows - so both operands are plain float4 loads of the
+// cache rows (lane (r = l % 16, q = l / 16): K[key0 + r][16 i + 4 q ..+3], V[key0 + 4 q + i][4 r ..+3], i = 0..3) and nothing goes through LDS before the merge.
+// Per lane the softmax is 4 scores per tile for ONE head (column r), with the running max made uniform over the 4 lane groups by two shuffles.
+// Workgroup = (sequence, kv head, key slice); its NW waves and the nslice slices deal the 16-key tiles round-robin (tile t -> wave t % (nslice * NW)), two tiles
+// per wave and round with the next round's rows in flight.  Waves merge through LDS in fixed order; nslice > 1 leaves un-normalised partials that
+// attn_merge_batch_kernel combines (a second launch is the cheap way to make partials visible across XCDs - see the header of this file).
+// Arithmetic differs from attn_decode_batch_kernel in summation order only (fp32 rounding): tokens are held to the oracle's by the same tests.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int NW>
+static __global__ __launch_bounds__(NW * 64) void attn_decode_batch_mfma_kernel(AttnDecodeBatchArgs p) {
+    constexpr int RT = 2;                            // key tiles per wave and round
+    __shared__ __attribute__((aligned(16))) float pw[NW][16][ATTN_PART];
+    const int S = p.nslice, W = S * NW;
+    const int slice = blockIdx.x % S, pair = blockIdx.x / S, g = pair % p.kv_heads, b = pair / p.kv_heads;
+    const int gsz = p.heads / p.kv_heads;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                          // scalar: the tile loop and its tests are wave-uniform branches, the loads stay counted
+    const DecodeState* st = p.st + b;
+    const float* qkv = p.qkv + (long long)b * p.ldqkv;
+    float* kcache = p.kcache + (long long)b * p.cache_stride;
+    float* vcache = p.vcache + (long long)b * p.cache_stride;
+    const int pos = __builtin_amdgcn_readfirstlane(st->pos);                            // the new token sits at index `pos`
+    const int L = pos + 1, nt = (L + 15) >> 4, tpos = pos >> 4;
+    const float* kc = kcache + (long long)g * p.max_len * 64;
+    const float* vc = vcache + (long long)g * p.max_len * 64;
+    const int wi = slice * NW + wave;                // this wave's place in the round-robin over the key tiles
+    auto load_round = [&](int t0, float4 (*kf)[4], float4 (*vf)[4]) {
+#pragma unroll
+        for (int u = 0; u < RT; ++u) {
+            const int key0 = (t0 + u * W) * 16;      // tiles >= nt re-read row 0 (clamped below; never used)
+            const int jk = key0 + r;
+            const float* kr = kc + (long long)(jk < pos ? jk : 0) * 64 + 4 * q;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kf[u][i] = *reinterpret_cast<const float4*>(kr + 16 * i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int jv = key0 + 4 * q + i;
+                vf[u][i] = *reinterpret_cast<const float4*>(vc + (long long)(jv < pos ? jv : 0) * 64 + 4 * r);
+            }
+        }
+    };
+    float4 kA[RT][4], vA[RT][4], kB[RT][4], vB[RT][4];
+    load_round(wi, kA, vA);                          // unconditional (tiles beyond the context re-read row 0): a load in a branch costs the compiler its vmcnt count
+    // rotate-half RoPE in registers, in the operand layouts: lane (r, q) holds dims 16 i + 4 q .. + 3 (i = 0..3) of query head r (B operand, pre-scaled by 1/8)
+    // and of the new key (substituted for the A operand of key row `pos`, which is not in the cache yet)
+    const float* kq = qkv + p.heads * 64 + g * 64;
+    const float* vq = qkv + (p.heads + p.kv_heads) * 64 + g * 64;
+    const float* qraw = qkv + (long long)(g * gsz + min(r, gsz - 1)) * 64;
+    float4 qf[4], kn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int d0 = 16 * i + 4 * q, dp = (d0 + 32) & 63;
+        const float4 c4 = *reinterpret_cast<const float4*>(p.rope_cos + pos * 32 + (d0 & 31));
+        const float4 s4 = *reinterpret_cast<const float4*>(p.rope_sin + pos * 32 + (d0 & 31));
+        const float4 qa = *reinterpret_cast<const float4*>(qraw + d0), qb = *reinterpret_cast<const float4*>(qraw + dp);
+        const float4 ka = *reinterpret_cast<const float4*>(kq + d0), kp = *reinterpret_cast<const float4*>(kq + dp);
+        const float sg = d0 < 32 ? -1.f : 1.f;
+        const float qs = r < gsz ? 0.125f : 0.f;     // columns beyond the group: zero queries (scores 0, never stored)
+        qf[i] = make_float4((qa.x * c4.x + sg * qb.x * s4.x) * qs, (qa.y * c4.y + sg * qb.y * s4.y) * qs, (qa.z * c4.z + sg * qb.z * s4.z) * qs, (qa.w * c4.w + sg * qb.w * s4.w) * qs);
+        kn[i] = make_float4(ka.x * c4.x + sg * kp.x * s4.x, ka.y * c4.y + sg * kp.y * s4.y, ka.z * c4.z + sg * kp.z * s4.z, ka.w * c4.w + sg * kp.w * s4.w);
+    }
+    const float4 vn4 = *reinterpret_cast<const float4*>(vq + 4 * r);
+    if (!st->done && slice == 0 && wave == 0) {      // KV-cache append: one wave per (sequence, kv head)
+        if (r == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(kcache + ((long long)g * p.max_len + pos) * 64 + 16 * i + 4 * q) = kn[i];
+        }
+        if (q == 0) *reinterpret_cast<float4*>(vcache + ((long long)g * p.max_len + pos) * 64 + 4 * r) = vn4;
+    }
+    const float NEG = -__builtin_huge_valf();
+    float m_run = NEG, l_run = 0.f;
+    v4f o[4];                                        // O^T tiles: o[c][ii] = numerator of dim 16 q + 4 ii + c, head r
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int t0 = wi; t0 < nt; t0 += RT * W) {       // wave-uniform
+        load_round(t0 + RT * W, kB, vB);             // the next round's rows are in flight under this round's arithmetic (unconditional, clamped)
+        v4f sc[RT];
+        float mt = NEG;
+#pragma unroll
+        for (int u = 0; u < RT; ++u) {
+            const int t = t0 + u * W;
+            if (t < nt) {                            // wave-uniform
+                if (t == tpos) {                     // the tile that holds the new key: its row comes from registers
+                    const bool mine = (t * 16 + r) == pos;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (mine) kA[u][i] = kn[i];
+                }
+                v4f c = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(kA[u][i].x, qf[i].x, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(kA[u][i].y, qf[i].y, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(kA[u][i].z, qf[i].z, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(kA[u][i].w, qf[i].w, c, 0, 0, 0);
+                }
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {     // C layout: row (key) 4 q + ii, column (head) r
+                    const float a = (t * 16 + 4 * q + ii) < L ? c[ii] : NEG;
+                    c[ii] = a; mt = fmaxf(mt, a);
+                }
+                sc[u] = c;
+            } else sc[u] = (v4f){NEG, NEG, NEG, NEG};
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));        // over the 4 lane groups: the running max of head r is the same in all of them
+        const float m_new = fmaxf(m_run, mt);        // finite: tile t0 holds at least one key
+        const float scale = (m_run == NEG) ? 0.f : expf(m_run - m_new);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { o[c][0] *= scale; o[c][1] *= scale; o[c][2] *= scale; o[c][3] *= scale; }
+        float lt = 0.f;
+#pragma unroll
+        for (int u = 0; u < RT; ++u) {
+            const int t = t0 + u * W;
+            if (t < nt) {                            // wave-uniform
+                v4f e;
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) { e[ii] = (sc[u][ii] == NEG) ? 0.f : expf(sc[u][ii] - m_new); lt += e[ii]; }
+                if (t == tpos) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if ((t * 16 + 4 * q + i) == pos) vA[u][i] = vn4;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {        // step i: reduction slot q <-> key 4 q + i (P of that key is accumulator register i of this lane)
+                    o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vA[u][i].x, e[i], o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vA[u][i].y, e[i], o[1], 0, 0, 0);
+                    o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vA[u][i].z, e[i], o[2], 0, 0, 0);
+                    o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vA[u][i].w, e[i], o[3], 0, 0, 0);
+                }
+            }
+        }
+        l_run = l_run * scale + lt;                  // per-lane partial (this lane's keys of head r)
+        m_run = m_new;
+#pragma unroll
+        for (int u = 0; u < RT; ++u) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { kA[u][i] = kB[u][i]; vA[u][i] = vB[u][i]; }
+        }
+    }
+    l_run += __shfl_xor(l_run, 16); l_run += __shfl_xor(l_run, 32);
+    if (r < gsz) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) *reinterpret_cast<float4*>(&pw[wave][r][16 * q + 4 * ii]) = make_float4(o[0][ii], o[1][ii], o[2][ii], o[3][ii]);
+        if (q == 0) { pw[wave][r][64] = (l_run > 0.f) ? m_run : 0.f; pw[wave][r][65] = l_run; }
+    }
+    __syncthreads();
+    for (int e = tid; e < 16 * gsz; e += NW * 64) {  // merge the waves of every head (fixed order)
+        const int hh = e >> 4, t = e & 15;
+        float M = NEG;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) if (pw[ww][hh][65] > 0.f) M = fmaxf(M, pw[ww][hh][64]);
+        float den = 0.f; float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) {
+            const float wgt = (pw[ww][hh][65] > 0.f) ? expf(pw[ww][hh][64] - M) : 0.f;
+            const float4 tq = *reinterpret_cast<const float4*>(&pw[ww][hh][t * 4]);
+            den += wgt * pw[ww][hh][65];
+            a.x += wgt * tq.x; a.y += wgt * tq.y; a.z += wgt * tq.z; a.w += wgt * tq.w;
+        }
+        if (S == 1) {
+            const float inv = 1.f / den;
+            *reinterpret_cast<float4*>(p.out + (long long)b * p.ldo + (g * gsz + hh) * 64 + t * 4) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+        } else {
+            float* pr = p.part + (((long long)pair * S + slice) * gsz + hh) * ATTN_PART;
+            *reinterpret_cast<float4*>(pr + t * 4) = a;
+            if (t == 0) { pr[64] = (den > 0.f) ? M : 0.f; pr[65] = den; }
+        }
+    }
+}
+
+// out[b][head][:] = softmax-merge of the nslice partials a (sequence, kv head) pair's workgroups left (fixed order; slices without a key carry denominator 0)
+static __global__ __launch_bounds__(256) void attn_merge_batch_kernel(AttnDecodeBatchArgs p) {
+    constexpr int MAXS = 8;
+    const int e = blockIdx.x * 256 + threadIdx.x;    // one thread per (sequence, head, 4 dims)
+    const int gsz = p.heads / p.kv_heads, S = p.nslice;
+    if (e >= p.nb * p.heads * 16) return;
+    const int t = e & 15, h = (e >> 4) % p.heads, b = (e >> 4) / p.heads, g = h / gsz, hh = h % gsz;
+    const float* pr = p.part + (((long long)(b * p.kv_heads + g) * S) * gsz + hh) * ATTN_PART;
+    float4 pa[MAXS]; float2 ml[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {                 // every partial requested before the first is used (unconditional, clamped)
+        const float* ps = pr + (long long)min(s, S - 1) * gsz * ATTN_PART;
+        pa[s] = *reinterpret_cast<const float4*>(ps + t * 4);
+        ml[s] = *reinterpret_cast<const float2*>(ps + 64);
+    }
+    const float NEG = -__builtin_huge_valf();
+    float M = NEG;
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) if (s < S && ml[s].y > 0.f) M = fmaxf(M, ml[s].x);
+    float den = 0.f; float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        const float wgt = (s < S && ml[s].y > 0.f) ? expf(ml[s].x - M) : 0.f;
+        den += wgt * ml[s].y;
+        a.x += wgt * pa[s].x; a.y += wgt * pa[s].y; a.z += wgt * pa[s].z; a.w += wgt * pa[s].w;
+    }
+    const float inv = 1.f / den;
+    *reinterpret_cast<float4*>(p.out + (long long)b * p.ldo + h * 64 + t * 4) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
 }
 
 // advance the KV length of every slot after a backbone step

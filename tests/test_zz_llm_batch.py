@@ -103,21 +103,29 @@ def test_more_than_sixteen_slots(lib, nb):
 
 
 @pytest.mark.parametrize("heads,kv_heads", [(14, 2), (6, 2)])
-def test_grouped_query_attention_in_one_workgroup(lib, heads, kv_heads, monkeypatch):
-    """Round 4: the batched decode attention with the heads of a kv group in ONE workgroup (attn_decode_batch_gqa_kernel: one load of the group's K / V rows for all of
-    its heads; 7 heads per group = CosyVoice2's shape, a short last subset; 3 per group = the two-heads-per-wave form; opt-in with CV_ATTN_BATCH_GQA=1 - measured slower
-    on the MI355X) against one workgroup per head with the group's heads on one XCD (the default): the same tokens, equal to the oracle's, with contexts that cross the 192-key pass boundary."""
+def test_grouped_query_attention_variants(lib, heads, kv_heads, monkeypatch):
+    """The batched decode attention in all its forms, at CosyVoice2's group shape (7 heads per kv head) and at 3 per group, with contexts that cross the 192-key pass
+    boundary of the per-head kernels and the 16-key tiles of the MFMA kernel:
+      * round 5 default: attn_decode_batch_mfma_kernel (workgroup = (sequence, kv head, key slice), the group's heads as MFMA columns) + attn_merge_batch_kernel,
+        with the slice count chosen by the launch rule, forced to 1 (no merge launch), 3 (slices that hold no key) and with 8-wave workgroups;
+      * CV_ATTN_BATCH=0: one workgroup per head (rounds 2-4), and its CV_ATTN_BATCH_GQA=1 form (one workgroup per (sequence, kv head), measured slower).
+    Every form yields the oracle's tokens in every slot."""
     import dataclasses
     cfg = dataclasses.replace(W.tiny()[0], heads=heads, kv_heads=kv_heads)                  # (hidden stays 128: the projections are 128 -> 64 * heads)
     sd = W.make_llm(cfg)
     reqs = [_req(cfg, 500 + i, 3, 2, (188, 7, 40, 195)[i]) for i in range(4)]          # prompt + text + generated tokens: ~200 / ~20 / ~50 / ~210 keys
     want = [OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=4, min_token_text_ratio=2) for r in reqs]
-    got = {}
-    for knob in ("1", "0"):
-        monkeypatch.setenv("CV_ATTN_BATCH_GQA", knob)                               # read when the step of a handle is captured
+    knobs = [{}, {"CV_ATTN_BATCH_SLICES": "1"}, {"CV_ATTN_BATCH_SLICES": "3", "CV_ATTN_BATCH_WAVES": "8"},
+             {"CV_ATTN_BATCH": "0"}, {"CV_ATTN_BATCH": "0", "CV_ATTN_BATCH_GQA": "1"}]
+    if heads == 6:
+        knobs = knobs[:2] + knobs[3:4]
+    for env in knobs:
+        for k in ("CV_ATTN_BATCH", "CV_ATTN_BATCH_SLICES", "CV_ATTN_BATCH_WAVES", "CV_ATTN_BATCH_GQA"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)                                                # read when the step of a handle is captured
         lm = Qwen2LM(sd, cfg, lib=lib, max_len=256, sampling="greedy", decode_chunk=5)
-        got[knob] = lm.inference_batch(reqs, max_token_text_ratio=4, min_token_text_ratio=2)
-    assert got["1"] == got["0"] == want
+        assert lm.inference_batch(reqs, max_token_text_ratio=4, min_token_text_ratio=2) == want, env
 
 
 def test_continuous_batching(lib):
