@@ -16,6 +16,7 @@
 #include "flow_fused.h"
 #include "flow_big.h"
 #include "flow_tail.h"
+#include "flow_band.h"
 
 using namespace cv;
 
@@ -26,7 +27,7 @@ struct LN { const float* g = nullptr; const float* b = nullptr; };
 
 struct ConformerW { LN norm_mha, norm_ff; Lin qkv, pos, out, ff1, ff2; const float* bias_u; const float* bias_v; };
 struct ResnetW { Lin mlp, conv1, conv2, res; LN ln1, ln2; };
-struct TBlockW { LN norm1, norm3; Lin qkv, out, ff1, ff2; const u32x4_t* tail = nullptr; const float* tail_prm = nullptr; bool tail_qkv = false; };   // tail: fragment-ordered stream of flow_tail_kernel (+ the next block's QKV)
+struct TBlockW { LN norm1, norm3; Lin qkv, out, ff1, ff2; const u32x4_t* tail = nullptr; const float* tail_prm = nullptr; bool tail_qkv = false; const u32x4_t* band = nullptr; };   // tail: fragment-ordered stream of flow_tail_kernel (+ the next block's QKV); band: the stream of flow_band_kernel (flow_band.h)
 struct StageW { ResnetW res; std::vector<TBlockW> tf; };
 struct DitBlockW { Lin mod, qkv, out, ff1, ff2; };       // DiTBlock (flow/DiT/modules.py:500-530)
 
@@ -82,6 +83,8 @@ struct cv_flow {
                                        // (profiles/r3_flow_tail_ab.txt): 46.3 vs 38.5 ms per flow.inference at batch 1 - a workgroup pulls its 2 MB of weights through one CU's
                                        // L1 at ~45 B/clk (~32 KB in flight, ~700 cycles), 33-40 us per launch whatever the band count, against 37 us for the four launches it
                                        // replaces.  Off by default; bit-identical to the five-launch form, tested both ways.
+    int fused_band = 1;                // bf16 mode, large passes (big_rows): everything between a block's attention and the next block's QKV GEMM in ONE launch per 64-row band
+                                       // (flow_band.h) instead of five (out-projection, LayerNorm, FF1, FF2, LayerNorm); bit-identical; option "fused_band", env CV_FLOW_BAND
     int fused = 1;                     // bf16 mode: LN-prologue GEMMs + bf16 activations + bf16 flash attention for the transformer blocks
     // tuning knobs of the fused pipeline.  "flow_tile": 0 = by size (one round of workgroups, see ln_gemm_bf16), 1 = 64x64, 2 = 64x128, 3 = 32x64,
     // 4 = 64x192; "attn_waves": 2 | 4 waves (32 | 64 queries) per workgroup; "attn_kt": 64-key tiles per iteration (1 | 2)
@@ -205,6 +208,10 @@ static void flow_finalize(cv_flow* m) {
                                         (t.tail_qkv ? 3LL * (inner / 64) * (C / 32) : 0);
                 t.tail = reinterpret_cast<const u32x4_t*>(m->tm.get(q + "tail", CV_BF16, 4 * frags * 64 * 8).p);
                 t.tail_prm = m->tm.f32(q + "tail_prm", 6LL * C + 4 * C);
+                if (m->tm.has(q + "band")) {                       // the 64-row band form of large passes (flow_band.h): out-projection + FF1 + FF2 fragments, 8 waves at C = 256, 4 at C = 64
+                    const long long bfr = (long long)(C / 16) * (inner / 32) + 2LL * (C / 16) * (4 * C / 32);
+                    t.band = reinterpret_cast<const u32x4_t*>(m->tm.get(q + "band", CV_BF16, bfr * 64 * 8).p);
+                }
             }
             st.tf.push_back(t);
         }
@@ -221,6 +228,7 @@ static void flow_finalize(cv_flow* m) {
     if (const char* e = getenv("CV_FLOW_BIG_LDS_EPI")) m->big_lds_epi = atoi(e) != 0;
     if (const char* e = getenv("CV_FLOW_ENC_BATCH")) m->enc_batch = atoi(e) != 0;
     if (const char* e = getenv("CV_FLOW_ATTN2_ROWS")) m->attn2_rows = atoi(e);
+    if (const char* e = getenv("CV_FLOW_BAND")) m->fused_band = e[0] != '0';        // dev knob for A/B runs (also: option "fused_band")
     if (const char* e = getenv("CV_FLOW_TAIL")) m->fused_tail = e[0] != '0';        // dev knob for A/B runs (also: option "fused_tail")
     if (const char* e = getenv("CV_FLOW_TAIL_RING")) m->tail_ring = atoi(e) == 16 ? 16 : 8;
     m->down_conv = get_lin(m, "est.down_conv", C, C, 3, true); m->up_conv = get_lin(m, "est.up_conv", C, C, 3, true);
@@ -512,6 +520,19 @@ static void conv_big(const Lin& l, const bf16_t* A, int T, int nz, int pad_left,
     const int tile = tl_big_tile1 ? tl_big_tile1 : 3;
     if (tl_big_glds) conv_big_launch<true>(a, tile, s); else conv_big_launch<false>(a, tile, s);
 }
+// everything between the attention of block `t` and the QKV GEMM of the next block in one launch, 64 rows per workgroup (flow_band.h)
+static void flow_band(const TBlockW& t, bool has_next, const bf16_t* att, int inner, float* x, int C, int M, bf16_t* xn, hipStream_t s) {
+    FlowBandArgs a{};
+    a.att = att; a.ld_att = inner; a.x = x; a.ldx = C; a.wstream = t.band; a.prm = t.tail_prm; a.eps = 1e-5f; a.M = M; a.xn = xn; a.ld_xn = C;
+    CV_CHECK(t.band && t.tail_prm && (!has_next || t.tail_qkv), "flow_band: block was not packed for this call");
+    const dim3 g((unsigned)((M + 63) / 64));
+    if (C == 256 && inner == 512) {
+        if (has_next) hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, true, 8>), g, dim3(512), 0, s, a); else hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, false, 8>), g, dim3(512), 0, s, a);
+    } else if (C == 64 && inner == 64) {
+        if (has_next) hipLaunchKernelGGL((flow_band_kernel<64, 64, 256, true, 4>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((flow_band_kernel<64, 64, 256, false, 4>), g, dim3(256), 0, s, a);
+    } else throw Error("flow_band: no instantiation for these dimensions");
+}
+
 // everything after the attention of block `t` (+ LayerNorm and QKV of `next`) in one launch, 16 rows per workgroup (flow_tail.h)
 static void flow_tail(const TBlockW& t, const TBlockW* next, const bf16_t* att, int inner, float* x, int C, int M, bf16_t* qk, bf16_t* vt, long long vt_batch, int ldt,
                       int rows_per_batch, int depth, hipStream_t s) {
@@ -606,6 +627,14 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
                 bf16_t* qk = m->h_qk.as<bf16_t>() + r0 * 2 * inner; bf16_t* vt = m->h_vt.as<bf16_t>() + b0 * vt_batch; bf16_t* ab = m->h_att.as<bf16_t>() + r0 * inner;
                 bf16_t* fb = m->h_ff.as<bf16_t>() + r0 * 4 * C;
                 const bool big = m->big_rows > 0 && R >= m->big_rows, big_attn = m->attn2_rows > 0 && R >= m->attn2_rows;
+                if (big && m->fused_band && t.band) {     // flow_band.h: QKV GEMM, attention, then ONE launch per 64-row band up to the next block's LayerNorm; bit-identical to the forms below
+                    bf16_t* xn = m->h_xn.as<bf16_t>() + r0 * C;
+                    if (ti == 0) ln_bf16(t.norm1, 1e-5f, x, (int)R, C, xn, s);         // later blocks: the previous block's band launch left LayerNorm(norm1) of its output in xn
+                    gemm_big_bf16(t.qkv, xn, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
+                    attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, klen, big_attn);
+                    flow_band(t, ti + 1 < st.tf.size(), ab, inner, x, C, (int)R, xn, s);
+                    continue;
+                }
                 if (big) {                    // flow_big.h: 7 launches of large tiles, bit-identical to the 5 below
                     bf16_t* xn = m->h_xn.as<bf16_t>() + r0 * C;
                     ln_bf16(t.norm1, 1e-5f, x, (int)R, C, xn, s);
@@ -890,6 +919,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "graph_max_rows") { CV_CHECK(value >= 0, "graph_max_rows must be >= 0"); m->graph_max_rows = value; drop_graphs(m); }
         else if (std::string(name) == "graph_cap") { CV_CHECK(value >= 1 && value <= 256, "graph_cap must be 1 .. 256"); drop_graphs(m); m->graph_cap = (size_t)value; }
         else if (std::string(name) == "fused_tail") { m->fused_tail = value != 0; drop_graphs(m); }
+        else if (std::string(name) == "fused_band") { m->fused_band = value != 0; drop_graphs(m); }      // bf16 mode, large passes: one 64-row band launch between attention and the next QKV GEMM (flow_band.h) on / off
         else if (std::string(name) == "flow_ntile") { CV_CHECK(value >= 0 && value <= 2, "flow_ntile must be 0, 1 or 2"); m->flow_ntile = value; drop_graphs(m); }
         else if (std::string(name) == "tail_ring") { m->tail_ring = value == 16 ? 16 : 8; drop_graphs(m); }      // bf16 mode: one row-band launch after each attention (flow_tail.h) on / off
         else if (std::string(name) == "big_rows") { CV_CHECK(value >= 0, "big_rows must be >= 0"); m->big_rows = value; drop_graphs(m); }

@@ -1,0 +1,250 @@
+// The row-local part of a flow-estimator transformer block for LARGE passes as ONE launch per 64-row band (round 5; matcha BasicTransformerBlock inside
+// CausalConditionalDecoder, cosyvoice/flow/decoder.py:405-494), bf16 mode:
+//
+//     attention output (bf16) -> out-projection + bias + residual -> LayerNorm(norm3) -> FF1 + bias + GELU(erf) -> FF2 + bias + residual
+//       [-> LayerNorm(norm1 of the NEXT block) -> bf16 rows: the operand of the next block's QKV GEMM]
+//
+// flow_big.h runs this as five launches (out-projection, LayerNorm, FF1, FF2, LayerNorm) of 64 x 64 tiles with K = 256 .. 1024: 70 of a block's 142 us at
+// M = 10 784 (8 utterances per pass), each launch a chain of first-load wait -> a few K stages -> stores, each writing and re-reading 11 - 22 MB of activations
+// (profiles/r4_flow_phase_stamps.txt: "nothing to pipeline inside one GEMM").  flow_tail.h (round 3) showed the other extreme: a 16-row band per workgroup pulls all
+// 2 MB of weights through one CU's load path for 16 rows of MFMA work - 48 us, bound by the L2 -> L1 path (674 bands x 2 MB).  Here a band is 64 rows (4 MFMA row
+// tiles): every weight fragment a wave loads (16 bytes per lane straight into the MFMA operand, fragment-ordered stream, weights.py::pack_flow_band) is multiplied
+// against FOUR activation fragments read from LDS - 4 x the rows per weight byte, ~170 workgroups = one round over the chip at M = 10 784, 1.3 MB of weights per band.
+//
+// LDS (147 KB, one workgroup of 8 waves per CU): X1 fp32 residual tile 64 x C (read once, written once), A1 / A2 bf16 operand tiles, the attention tile A0 overlaid
+// on A1 + A2 (dead after the out-projection).  FF1 -> FF2 run in FF / C chunks of C hidden columns: the chunk's GELU output (64 x C bf16) is the only part of
+// the 64 x FF intermediate that ever exists, FF2's accumulators stay in registers across the chunks - k ascending over the chunks, so every output element sums the
+// same products in the same order as the five-launch form (and the four small-tile launches): BIT-IDENTICAL to them, tests/test_flow_big.py.
+// Weight loads run one PASS (<= 16 fragments per wave) ahead of the MFMAs in a second register buffer, across phase boundaries and barriers (the stream does not
+// depend on activations); there is no global store before the last fragment has been consumed (a pending store costs the compiler its vmcnt bookkeeping).
+#pragma once
+#include "flow_fused.h"
+
+namespace cv {
+
+struct FlowBandArgs {
+    const bf16_t* att; int ld_att;            // attention output [M][INNER] bf16
+    float* x; int ldx;                        // residual stream [M][C] fp32, read once, written once
+    const u32x4_t* wstream;                   // packed fragments [NW waves][fragments per wave][64 lanes] (pack_flow_band)
+    const float* prm;                         // small operands of the block (the layout of flow_tail.h): [b_out C | norm3.g C | norm3.b C | b_ff1 FF | b_ff2 C | norm1.g of the NEXT block C | its norm1.b C]
+    float eps; int M;
+    bf16_t* xn; int ld_xn;                    // HAS_NEXT: LayerNorm(norm1 of the next block) of the new residual rows, bf16 [M][C]
+};
+
+// one pass: PT 16-column tiles x KS k-steps of 32 against the 4 row tiles of the band.  A: bf16 pairs in LDS, row pitch `pitch` dwords, first dword k0.
+template <int PT, int KS>
+__device__ __forceinline__ void band_mma(const u32x4_t (&w)[16], const unsigned* A, int pitch, int k0, int lq, int lg, v4f (&acc)[4][PT]) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        uint4 af[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) af[rt] = *reinterpret_cast<const uint4*>(&A[(16 * rt + lq) * pitch + k0 + ks * 16 + lg * 4]);
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+                acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, w[ks * PT + t]), __builtin_bit_cast(v8bf, af[rt]), acc[rt][t], 0, 0, 0);
+        }
+    }
+}
+template <int N>
+__device__ __forceinline__ void band_wload(u32x4_t (&dst)[16], const u32x4_t* ws, int frag0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) dst[i] = ws[(long long)(frag0 + i) * 64];
+    __builtin_amdgcn_sched_barrier(0);        // the requests stay HERE, a pass ahead of their use (left alone the scheduler sinks them down to the first MFMA that needs them)
+}
+
+// LayerNorm of the band's rows parked in X (fp32, pitch PX floats) -> bf16 operand tile (pitch `pa` dwords): the expressions of ln_bf16_kernel / tail_layernorm
+template <int C, int PX, int NT>
+__device__ __forceinline__ void band_layernorm(const float* X, unsigned* A, int pa, const float* gamma, const float* beta, float eps, int tid) {
+    constexpr int NJ = C / 64;
+    const int sub = tid & 15;
+#pragma unroll
+    for (int r0 = 0; r0 < 64; r0 += NT / 16) {
+        const int row = r0 + (tid >> 4);
+        float4 v[NJ];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { v[j] = *reinterpret_cast<const float4*>(&X[row * PX + 4 * sub + 64 * j]); s += v[j].x + v[j].y + v[j].z + v[j].w; }
+        const float mean = group16_sum(s) * (1.f / (float)C);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean; q += a * a + b * b + c * c + d * d; }
+        const float rstd = rsqrtf(group16_sum(q) * (1.f / (float)C) + eps);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int k = 4 * sub + 64 * j;
+            const float4 g = *reinterpret_cast<const float4*>(gamma + k), b = *reinterpret_cast<const float4*>(beta + k);      // gamma / beta: LDS copies
+            const float4 y = make_float4((v[j].x - mean) * rstd * g.x + b.x, (v[j].y - mean) * rstd * g.y + b.y, (v[j].z - mean) * rstd * g.z + b.z, (v[j].w - mean) * rstd * g.w + b.w);
+            *reinterpret_cast<uint2*>(&A[row * pa + k / 2]) = make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+        }
+    }
+}
+
+// fragments per wave of one block's stream (weights.py::pack_flow_band must agree)
+template <int C, int INNER, int FF, int NW>
+struct FlowBandShape {
+    static constexpr int TA = C / 16 / NW;                          // 16-column tiles per wave in every phase (all three GEMMs are cut to C output columns per pass)
+    static constexpr int KA = INNER / 32;                           // out-projection k-steps, in passes of <= 8
+    static constexpr int NPA = (KA + 7) / 8;
+    static constexpr int KC = C / 32;                               // FF1 chunk: K = C;  FF2 chunk: K = C hidden columns
+    static constexpr int NCH = FF / C;
+    static constexpr int TOTAL = TA * (KA + 2 * NCH * KC);
+    static_assert(C % (16 * NW) == 0 && TA >= 1 && TA <= 2 && KC <= 8 && INNER % 32 == 0 && FF % C == 0 && (KA <= 8 || KA % 8 == 0), "flow_band: unsupported dimensions");
+};
+
+template <int C, int INNER, int FF, bool HAS_NEXT, int NW>
+__global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
+    using S = FlowBandShape<C, INNER, FF, NW>;
+    constexpr int BM = 64, NT = NW * 64, TA = S::TA;
+    constexpr int PA0 = INNER / 2 + LDS_PAD, PX = C + LDS_PAD, PA1 = C / 2 + LDS_PAD;       // LDS row pitches (dwords / floats): 8 mod 16 (common.h, LDS_PAD)
+    constexpr int OPS = (BM * PA0 > 2 * BM * PA1) ? BM * PA0 : 2 * BM * PA1;                // the attention tile overlays A1 | A2
+    __shared__ __attribute__((aligned(16))) float X1[BM * PX];
+    __shared__ __attribute__((aligned(16))) unsigned OP[OPS];
+    unsigned* const A0 = OP; unsigned* const A1 = OP; unsigned* const A2 = OP + BM * PA1;
+    constexpr int O_BOUT = 0, O_G3 = C, O_BE3 = 2 * C, O_BFF1 = 3 * C, O_BFF2 = 3 * C + FF, O_G1N = 4 * C + FF, O_BE1N = 5 * C + FF, NPRM = 6 * C + FF;
+    __shared__ __attribute__((aligned(16))) float prm[NPRM];
+    const int tid = threadIdx.x, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * BM;
+
+    // ---- the band's small operands, its attention tile and its residual rows FIRST (unconditional, clamped), then the first pass of the weight stream
+    constexpr int NPV = NPRM / 4, PPT = (NPV + NT - 1) / NT;
+    float4 pv[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) pv[i] = *reinterpret_cast<const float4*>(p.prm + 4 * min(tid + NT * i, NPV - 1));
+    constexpr int APC = BM * INNER / 8, APT = (APC + NT - 1) / NT;          // 16-byte pieces of the attention tile per thread
+    u32x4_t av[APT];
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+        const int v = min(tid + NT * i, APC - 1), r = v / (INNER / 8), c = v % (INNER / 8);
+        av[i] = *reinterpret_cast<const u32x4_t*>(p.att + (long long)min(m0 + r, p.M - 1) * p.ld_att + c * 8);
+    }
+    constexpr int XPC = BM * C / 4, XPT = (XPC + NT - 1) / NT;              // float4 pieces of the residual tile per thread
+    float4 xv[XPT];
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        const int v = min(tid + NT * i, XPC - 1), r = v / (C / 4), c = v % (C / 4);
+        xv[i] = *reinterpret_cast<const float4*>(p.x + (long long)min(m0 + r, p.M - 1) * p.ldx + c * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const u32x4_t* ws = p.wstream + (long long)wave * S::TOTAL * 64 + lane;
+    u32x4_t wb0[16], wb1[16];
+    constexpr int FA0 = TA * (S::KA < 8 ? S::KA : 8);                       // fragments of the first out-projection pass
+    band_wload<FA0>(wb0, ws, 0);
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) { const int v = tid + NT * i; if (v < NPV) *reinterpret_cast<float4*>(&prm[4 * v]) = pv[i]; }
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+        const int v = tid + NT * i;
+        if (v < APC) *reinterpret_cast<u32x4_t*>(&A0[(v / (INNER / 8)) * PA0 + (v % (INNER / 8)) * 4]) = av[i];
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        const int v = tid + NT * i;
+        if (v < XPC) *reinterpret_cast<float4*>(&X1[(v / (C / 4)) * PX + (v % (C / 4)) * 4]) = xv[i];
+    }
+    __syncthreads();
+
+    // ---- A: out-projection + bias + residual -> X1 (fp32).  Wave w owns the 16-column tiles w + NW t.
+    constexpr int FCD = TA * S::KC;                                         // fragments of an FF1 / FF2 chunk pass
+    {
+        v4f acc[4][TA];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int t = 0; t < TA; ++t) acc[rt][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+        if constexpr (S::NPA == 1) {
+            band_wload<FCD>(wb1, ws, TA * S::KA);                           // FF1 chunk 0 in flight under the out-projection
+            band_mma<TA, S::KA>(wb0, A0, PA0, 0, lq, lg, acc);
+        } else {
+            static_assert(S::NPA <= 2, "flow_band: the out-projection runs in at most two passes (INNER <= 512)");
+            band_wload<TA * 8>(wb1, ws, TA * 8);
+            band_mma<TA, 8>(wb0, A0, PA0, 0, lq, lg, acc);
+            band_wload<FCD>(wb0, ws, TA * S::KA);                           // FF1 chunk 0
+            band_mma<TA, 8>(wb1, A0, PA0, 8 * 16, lq, lg, acc);
+        }
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+            const int n = 16 * (wave + NW * t) + 4 * lg;
+            const float4 b = *reinterpret_cast<const float4*>(&prm[O_BOUT + n]);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                float* xr = &X1[(16 * rt + lq) * PX + n];
+                const float4 r = *reinterpret_cast<const float4*>(xr);
+                *reinterpret_cast<float4*>(xr) = make_float4(acc[rt][t][0] + b.x + r.x, acc[rt][t][1] + b.y + r.y, acc[rt][t][2] + b.z + r.z, acc[rt][t][3] + b.w + r.w);   // the same lane read this element
+            }
+        }
+    }
+    __syncthreads();                                                        // X1 complete, A0 dead
+    // ---- B: LayerNorm(norm3) -> A1 (bf16)
+    band_layernorm<C, PX, NT>(X1, A1, PA1, &prm[O_G3], &prm[O_BE3], p.eps, tid);
+    __syncthreads();
+    // ---- C / D: FF1 chunk j (+ bias + GELU -> A2) and FF2 over that chunk's hidden columns, accumulators across the chunks.  Stream order: FF1_0 FF2_0 FF1_1 FF2_1 ..
+    // With NPA == 1 chunk 0's FF1 fragments sit in wb1, otherwise in wb0: the two buffers alternate from there.
+    v4f acc2[4][TA];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int t = 0; t < TA; ++t) acc2[rt][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    constexpr int F0 = TA * S::KA;                                          // first fragment of the FF stream
+    constexpr bool FF1_IN_WB1 = S::NPA == 1;
+#pragma unroll
+    for (int j = 0; j < S::NCH; ++j) {
+        v4f acc1[4][TA];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int t = 0; t < TA; ++t) acc1[rt][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+        // FF1 chunk j is in buffer X (loaded one pass ago); request FF2 chunk j into the other buffer, multiply
+        if constexpr (FF1_IN_WB1) { band_wload<FCD>(wb0, ws, F0 + (2 * j + 1) * FCD); band_mma<TA, S::KC>(wb1, A1, PA1, 0, lq, lg, acc1); }
+        else                      { band_wload<FCD>(wb1, ws, F0 + (2 * j + 1) * FCD); band_mma<TA, S::KC>(wb0, A1, PA1, 0, lq, lg, acc1); }
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+            const int n = 16 * (wave + NW * t) + 4 * lg;                    // column inside the chunk
+            const float4 b = *reinterpret_cast<const float4*>(&prm[O_BFF1 + j * C + n]);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const float4 y = apply_act4(ACT_GELU_ERF, make_float4(acc1[rt][t][0] + b.x, acc1[rt][t][1] + b.y, acc1[rt][t][2] + b.z, acc1[rt][t][3] + b.w), 0.f);
+                *reinterpret_cast<uint2*>(&A2[(16 * rt + lq) * PA1 + n / 2]) = make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+            }
+        }
+        __syncthreads();                                                    // the chunk's hidden tile is complete
+        // FF2 chunk j; request FF1 chunk j + 1 (the stream's last pass requests nothing)
+        if constexpr (FF1_IN_WB1) { if (j + 1 < S::NCH) band_wload<FCD>(wb1, ws, F0 + (2 * j + 2) * FCD); band_mma<TA, S::KC>(wb0, A2, PA1, 0, lq, lg, acc2); }
+        else                      { if (j + 1 < S::NCH) band_wload<FCD>(wb0, ws, F0 + (2 * j + 2) * FCD); band_mma<TA, S::KC>(wb1, A2, PA1, 0, lq, lg, acc2); }
+        if (j + 1 < S::NCH) __syncthreads();                                // before the next chunk overwrites A2
+    }
+    // ---- FF2 epilogue: + bias + residual -> X1 (the new residual stream)
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+        const int n = 16 * (wave + NW * t) + 4 * lg;
+        const float4 b = *reinterpret_cast<const float4*>(&prm[O_BFF2 + n]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            float* xr = &X1[(16 * rt + lq) * PX + n];
+            const float4 r = *reinterpret_cast<const float4*>(xr);
+            *reinterpret_cast<float4*>(xr) = make_float4(acc2[rt][t][0] + b.x + r.x, acc2[rt][t][1] + b.y + r.y, acc2[rt][t][2] + b.z + r.z, acc2[rt][t][3] + b.w + r.w);
+        }
+    }
+    __syncthreads();
+    if constexpr (HAS_NEXT) {
+        // ---- E: LayerNorm(norm1 of the next block) -> A1, written out as the bf16 operand rows of its QKV GEMM
+        band_layernorm<C, PX, NT>(X1, A1, PA1, &prm[O_G1N], &prm[O_BE1N], p.eps, tid);
+        __syncthreads();
+        constexpr int NP = BM * C / 8;
+#pragma unroll
+        for (int i = 0; i < (NP + NT - 1) / NT; ++i) {
+            const int v = tid + NT * i, r = v / (C / 8), c = v % (C / 8);
+            if (v < NP && m0 + r < p.M) *reinterpret_cast<u32x4_t*>(p.xn + (long long)(m0 + r) * p.ld_xn + c * 8) = *reinterpret_cast<const u32x4_t*>(&A1[r * PA1 + c * 4]);
+        }
+    }
+    // write-out of the residual stream: whole rows, 16 bytes per lane
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        const int v = tid + NT * i, r = v / (C / 4), c = v % (C / 4);
+        if (v < XPC && m0 + r < p.M) *reinterpret_cast<float4*>(p.x + (long long)(m0 + r) * p.ldx + c * 4) = *reinterpret_cast<const float4*>(&X1[r * PX + c * 4]);
+    }
+}
+
+}  // namespace cv

@@ -69,3 +69,56 @@ def test_big_m_pass_equals_single_passes(lib):
             assert a.shape == b.shape and torch.equal(a, b), (a.shape, (a - b).abs().max().item())
     finally:
         lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(5000)); lib.cv_flow_set_option(flow._h, b"attn2_rows", C.c_int32(0))
+
+
+@pytest.mark.parametrize("est_blocks", [1, 3])
+def test_band_kernel_is_bit_identical(lib, est_blocks):
+    """Round 5: in a large pass everything between a block's attention and the next block's QKV GEMM is ONE launch per 64-row band (flow_band.h: out-projection +
+    residual -> LayerNorm -> FF1 + GELU -> FF2 + residual -> the next block's LayerNorm as bf16 rows; FF1 -> FF2 in chunks with the accumulators kept across them).
+    Same rounding points, same k order into one accumulator chain per element, same LayerNorm expressions: bit-identical to the five launches it replaces
+    (fused_band = 0) and to the small-tile path (big_rows = 0) - on the emulator AND on the hardware.  est_blocks = 3: the chained form (the band's LayerNorm output
+    feeds the next QKV GEMM) and the closing one; T not a multiple of 64 (ragged last band), bands that straddle the CFG batch rows, both mask modes."""
+    import ctypes as C
+    import dataclasses
+    cfg = dataclasses.replace(W.tiny()[1], est_blocks=est_blocks, est_mid=1, chunk=13)
+    sd = W.make_flow(cfg)
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision="bf16")
+    assert any(k.endswith(".band") for k in flow._tensors), "weights.pack_flow did not produce the band streams"
+    g = torch.Generator().manual_seed(16)
+    try:
+        for T in (45, 150):
+            x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g); cond = torch.randn(2, 80, T, generator=g)
+            spk = torch.randn(2, 80, generator=g); t = torch.tensor([0.3, 0.3]); mask = torch.ones(2, 1, T)
+            for streaming in (False, True):
+                outs = []
+                for big, band in ((0, 0), (1, 0), (1, 1)):
+                    lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(big)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(band))
+                    outs.append(flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu().clone())
+                assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
+                assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (T, streaming, (outs[0] - outs[2]).abs().max().item())
+    finally:
+        lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(5000)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(1))
+
+
+def test_band_kernel_at_the_real_width(lib):
+    """The instantiation the MI355X runs (C = 256, 8 heads, FF = 1024: 8 waves, two column tiles per wave, the out-projection in two passes) against the five-launch
+    form and the small-tile path, bit for bit, on a short time axis (one full band and a ragged one)."""
+    import ctypes as C
+    import dataclasses
+    cfg = dataclasses.replace(W.tiny()[1], est_ch=256, est_heads=8, est_blocks=2, est_mid=1, chunk=13)
+    sd = W.make_flow(cfg)
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision="bf16")
+    assert any(k.endswith(".band") for k in flow._tensors)
+    g = torch.Generator().manual_seed(17)
+    T = 37
+    x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g); cond = torch.randn(2, 80, T, generator=g)
+    spk = torch.randn(2, 80, generator=g); t = torch.tensor([0.6, 0.6]); mask = torch.ones(2, 1, T)
+    try:
+        outs = []
+        for big, band in ((0, 0), (1, 0), (1, 1)):
+            lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(big)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(band))
+            outs.append(flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=False).cpu().clone())
+        assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (outs[0] - outs[2]).abs().max().item()
+    finally:
+        lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(5000)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(1))
