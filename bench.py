@@ -578,6 +578,50 @@ def roofline_llm(model, u, cfgs):
                 decode_step_us_from_chains=round(step_us, 1), per_kernel=per)
 
 
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak (the headline figures with 2:1 sparsity are not priced against)
+
+
+def roofline_mfma(model, cfgs, n_utt=8):
+    """The MFMA-bound side of the path (north_star: "rocprof HBM GB/s and MFMA-busy counters against chip peak"): one transformer block of the flow estimator in an
+    8-utterance shared pass (M = 2 x 8 x 674 = 10 784 rows - what tts_batch / tts_queue run) is three launches; each is timed live as 20 back-to-back launches between
+    one HIP-event pair on the current stream (cv_flow_profile_block) and priced at its ALGORITHMIC flops (2 x MACs of the dense contractions).
+    The record's headline is the launch with the largest share of the block; MFMA-busy comes from the PMC pass committed under profiles/ (separate rocprofv3 run)."""
+    import hashlib
+    from cosyvoice_amd._lib import stream_ptr
+    fc = cfgs[1]
+    flow = model.flow
+    T, nz = 2 * (N_PROMPT_TOK + N_GEN), 2 * n_utt
+    C_, H, FF = fc.est_ch, fc.est_heads, 4 * fc.est_ch
+    inner, M = 64 * H, nz * T
+    us = (C.c_float * 3)()
+    flow.lib.cv_flow_profile_block(flow._h, C.c_int32(nz), C.c_int32(T), C.c_int32(20), us, stream_ptr(flow.lib))
+    flops = {"flow_gemm_big_kernel<64,64,0> QKV (bf16 out, V^T transposed)": 2.0 * M * C_ * 3 * inner,
+             "attn_flow_kernel flash attention (QK^T + PV over all keys)": 4.0 * nz * H * T * T * 64,
+             "flow_band_kernel out-projection + LayerNorm + FF1 + GELU + FF2 (+ next LayerNorm), 64-row bands": 2.0 * M * (C_ * inner + 2 * C_ * FF)}
+    per = {}
+    for (name, fl), t in zip(flops.items(), us):
+        per[name] = {"flops_per_launch": int(fl), "avg_launch_us": round(float(t), 2), "TFLOPs": round(fl / (t * 1e-6) / 1e12, 1), "frac_of_peak": round(fl / (t * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+    dom = max(per, key=lambda k: per[k]["avg_launch_us"])
+    block_fl, block_us = sum(flops.values()), sum(float(t) for t in us)
+    busy, busy_src = None, None
+    pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r5_pmc_flow_batch8.json", "r4_pmc_flow_batch8_end.json")) if os.path.exists(f)), None)
+    if pmc is not None:
+        raw = open(pmc, "rb").read()
+        d = json.loads(raw)
+        key = "attn_flow" if "attn_flow" in dom else "flow_band" if "flow_band" in dom else "flow_gemm_big_kernel<64, 64, 0"
+        sel = [v for k, v in d.items() if key in k and isinstance(v, dict) and "mfma_busy_frac_of_chip" in v]
+        if sel:
+            busy = round(sum(v["n"] * v["mfma_busy_frac_of_chip"] for v in sel) / sum(v["n"] for v in sel), 4)
+            busy_src = ("REPLAYED PMC RECORD, not measured by this run: %s, sha1 %s - rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE in its own run over "
+                        "tools/profile_flow_batch.py 8, summarised by tools/pmc_summary.py" % (os.path.relpath(pmc, ROOT), hashlib.sha1(raw).hexdigest()[:16]))
+    return dict(bound="mfma", kernel=dom, achieved=per[dom]["TFLOPs"], peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=per[dom]["frac_of_peak"], flops_per_launch=per[dom]["flops_per_launch"],
+                avg_launch_us=per[dom]["avg_launch_us"], mfma_busy_frac=busy, mfma_busy_source=busy_src,
+                workload="one transformer block of the flow estimator in a shared pass over %d utterances of U10 (M = %d rows, C = %d, %d heads, T = %d)" % (n_utt, M, C_, H, T),
+                timing="20 back-to-back launches per kernel between one HIP-event pair on the launch stream (cv_flow_profile_block)",
+                block={"us": round(block_us, 1), "TFLOPs": round(block_fl / (block_us * 1e-6) / 1e12, 1), "frac_of_peak": round(block_fl / (block_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+                per_kernel=per)
+
+
 CPU_STAGES = ("llm", "flow", "hift")
 
 
@@ -997,6 +1041,12 @@ def main():
             log("first chunk p50 %.1f ms" % out["first_chunk_ms_p50"])
         out["roofline"] = roofline_llm(model, u, cfgs)          # rank 0's GPU (every replica runs the same kernels)
         log("roofline done")
+        if world == 1:
+            try:
+                out["roofline_mfma"] = roofline_mfma(model, cfgs)
+            except Exception as e:                                  # a measurement hook must not cost the line
+                out["roofline_mfma"] = {"error": repr(e)}
+            log("mfma roofline done")
         if world == 1 and not args.no_cpu_baseline:             # the CPU baseline is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfgs)
         print(json.dumps(out), flush=True)

@@ -55,6 +55,27 @@ __device__ __forceinline__ float fast_erf(float x) {
     const float y = 1.f - poly * fast_exp(-ax * ax);
     return x < 0.f ? -y : y;
 }
+// GELU(erf) of four values on the PACKED fp32 pipe (v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of arithmetic per issue slot, gfx90a+): the expressions of fast_erf
+// and of act4_call's GELU branch, operation for operation - every product and sum is rounded once in both forms, so the results are the same bits.  The exponential
+// is the bare v_exp_f32: exp2f() only adds the rescaling of results below 2^-126, and those vanish in `1 - poly * e` either way.  Round 5: the FF1 epilogue of the flow
+// estimator evaluates 64 x 1024 of these per 64-row band - at ~32 scalar instructions each it, not the matrix pipe, was what a band took (tools/ubench/band_probe).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f gelu_erf2(v2f t) {
+    const v2f x = t * 0.70710678118654752440f;
+    const v2f ax = __builtin_elementwise_abs(x);
+    const v2f den = 1.f + 0.3275911f * ax;
+    v2f r; r.x = fast_rcp(den.x); r.y = fast_rcp(den.y);
+    const v2f poly = ((((1.061405429f * r - 1.453152027f) * r + 1.421413741f) * r - 0.284496736f) * r + 0.254829592f) * r;
+    const v2f a = (-ax * ax) * 1.4426950408889634f;
+    v2f e; e.x = __builtin_amdgcn_exp2f(a.x); e.y = __builtin_amdgcn_exp2f(a.y);
+    const v2f y = 1.f - poly * e;
+    v2f er; er.x = x.x < 0.f ? -y.x : y.x; er.y = x.y < 0.f ? -y.y : y.y;
+    return 0.5f * t * (1.f + er);
+}
+__device__ __forceinline__ float4 gelu_erf4(float4 v) {
+    const v2f a = gelu_erf2((v2f){v.x, v.y}), b = gelu_erf2((v2f){v.z, v.w});
+    return make_float4(a.x, a.y, b.x, b.y);
+}
 // ONE out-of-line copy per kernel, four elements per call: inlined at every unrolled prologue / epilogue site the activation code
 // bloats the GEMM k-loop past the instruction cache again (measured: +8..15 us per launch on the 64x64 / 128x64 tiles).
 // The activation id is uniform over a launch but arrives in a VECTOR register (a function argument): compared there, every `if (act == ...)` becomes an
@@ -68,8 +89,8 @@ __device__ __noinline__ float4 act4_call(int act_v, float4 x) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float t = v[e]; v[e] = t * fast_rcp(1.f + fast_exp(-t)); }
     } else if (act == ACT_GELU_ERF) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float t = v[e]; v[e] = 0.5f * t * (1.f + fast_erf(t * 0.70710678118654752440f)); }
+        const float4 g = gelu_erf4(x);                       // the packed form of 0.5 t (1 + fast_erf(t / sqrt 2)): same bits
+        v[0] = g.x; v[1] = g.y; v[2] = g.z; v[3] = g.w;
     } else if (act == ACT_MISH) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float t = v[e]; const float n = fast_exp(fminf(t, 20.f)), w = n * (n + 2.f); v[e] = t > 20.f ? t : t * w * fast_rcp(w + 2.f); }

@@ -1004,6 +1004,38 @@ static void flow_estimator_call(cv_flow* m, const float* x, const float* mask, c
     // without key_len `mask` must be all ones for the in-kernel (index-computed) attention masks to be exact; either way it is applied to the output
     hipLaunchKernelGGL(to_channel_first_kernel, dim3(nblk(2LL * T * c.mel)), dim3(256), 0, s, m->s_out.as<float>(), out, 2, T, c.mel, 0, mask);
 }
+// Measurement hook of bench.py's MFMA roofline record: the three launches a transformer block of a LARGE pass is made of (QKV GEMM, flash attention, the 64-row band
+// launch of flow_band.h), each as `reps` back-to-back launches of stage 1 / block 0's weights between one HIP-event pair on `stream`, on the workspaces of a pass
+// over nz estimator batch rows of T frames (contents: whatever the last pass left - the timings do not depend on the values).  us3: microseconds per launch.
+static void flow_profile_block(cv_flow* m, int nz, int T, int reps, float* us3, hipStream_t s) {
+    const auto& c = m->cfg; const int C = c.est_ch, H = c.est_heads, inner = H * 64; const long long R = (long long)nz * T;
+    CV_CHECK(m->finalized && c.estimator == 0 && m->wbf16 && nz >= 2 && T > 0 && reps > 0 && us3, "cv_flow_profile_block: needs the bf16-mode U-Net estimator");
+    CV_CHECK(m->stages.size() >= 2 && m->stages[1].tf.size() >= 2 && m->stages[1].tf[0].band, "cv_flow_profile_block: no band stream for this configuration");
+    PrecisionScope prec(m);
+    est_reserve(m, T, nz);
+    const TBlockW& t = m->stages[1].tf[0];
+    const long long vt_batch = (long long)inner * m->vt_pitch;
+    bf16_t* qk = m->h_qk.as<bf16_t>(); bf16_t* vt = m->h_vt.as<bf16_t>(); bf16_t* ab = m->h_att.as<bf16_t>(); bf16_t* xn = m->h_xn.as<bf16_t>(); float* x = m->s_a.as<float>();
+    CV_HIP(hipMemsetAsync(x, 0, (size_t)R * C * 4, s)); CV_HIP(hipMemsetAsync(xn, 0, (size_t)R * C * 2, s));
+    hipEvent_t e0, e1; CV_HIP(hipEventCreate(&e0)); CV_HIP(hipEventCreate(&e1));
+    for (int which = 0; which < 3; ++which) {
+        for (int pass = 0; pass < 2; ++pass) {               // pass 0: warm-up
+            CV_HIP(hipEventRecord(e0, s));
+            for (int i = 0; i < reps; ++i) {
+                if (which == 0) gemm_big_bf16(t.qkv, xn, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
+                else if (which == 1) attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, 0, s, nullptr, m->attn2_rows > 0 && R >= m->attn2_rows);
+                else flow_band(t, true, ab, inner, x, C, (int)R, xn, s);
+            }
+            CV_HIP(hipEventRecord(e1, s)); CV_HIP(hipEventSynchronize(e1));
+            float ms = 0.f; CV_HIP(hipEventElapsedTime(&ms, e0, e1));
+            us3[which] = 1e3f * ms / reps;
+        }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+}
+int cv_flow_profile_block(cv_flow* m, int32_t nz, int32_t T, int32_t reps, float* us3, void* stream) {
+    return guarded([&] { CV_CHECK(m, "cv_flow_profile_block: null handle"); flow_profile_block(m, nz, T, reps, us3, as_stream(stream)); });
+}
 int cv_flow_estimator(cv_flow* m, const float* x, const float* mask, const float* mu, const float* t, const float* spks, const float* cond,
                       int32_t T, int32_t streaming, float* out, void* stream) {
     return guarded([&] { flow_estimator_call(m, x, mask, nullptr, mu, t, spks, cond, T, streaming, out, stream); });

@@ -29,16 +29,25 @@ struct FlowBandArgs {
     const float* prm;                         // small operands of the block (the layout of flow_tail.h): [b_out C | norm3.g C | norm3.b C | b_ff1 FF | b_ff2 C | norm1.g of the NEXT block C | its norm1.b C]
     float eps; int M;
     bf16_t* xn; int ld_xn;                    // HAS_NEXT: LayerNorm(norm1 of the next block) of the new residual rows, bf16 [M][C]
+    long long* dbg;                           // dev tool (tools/ubench/band_probe.hip): clock64() of thread 0 at the phase boundaries, 16 slots per workgroup; null in production
 };
 
 // one pass: PT 16-column tiles x KS k-steps of 32 against the 4 row tiles of the band.  A: bf16 pairs in LDS, row pitch `pitch` dwords, first dword k0.
-template <int PT, int KS>
+template <int PT, int KS, int MODE = 0>
 __device__ __forceinline__ void band_mma(const u32x4_t (&w)[16], const unsigned* A, int pitch, int k0, int lq, int lg, v4f (&acc)[4][PT]) {
+    if constexpr (MODE == 2) {                // probe: consume the fragments without the matrix pipe or LDS
+#pragma unroll
+        for (int i = 0; i < PT * KS; ++i) acc[0][0][0] += __uint_as_float(w[i][0] ^ w[i][1] ^ w[i][2] ^ w[i][3]);
+        return;
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         uint4 af[4];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) af[rt] = *reinterpret_cast<const uint4*>(&A[(16 * rt + lq) * pitch + k0 + ks * 16 + lg * 4]);
+        for (int rt = 0; rt < 4; ++rt) {
+            if constexpr (MODE == 3) af[rt] = make_uint4(0x3f803f80u + rt + ks, 0x3f003f00u + lq, 0x3e803e80u + lg, 0x3f803f80u);      // probe: no fragment reads
+            else af[rt] = *reinterpret_cast<const uint4*>(&A[(16 * rt + lq) * pitch + k0 + ks * 16 + lg * 4]);
+        }
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
 #pragma unroll
@@ -47,8 +56,9 @@ __device__ __forceinline__ void band_mma(const u32x4_t (&w)[16], const unsigned*
         }
     }
 }
-template <int N>
+template <int N, int MODE = 0>
 __device__ __forceinline__ void band_wload(u32x4_t (&dst)[16], const u32x4_t* ws, int frag0) {
+    if constexpr (MODE == 1) return;          // probe: the stream is not requested again
 #pragma unroll
     for (int i = 0; i < N; ++i) dst[i] = ws[(long long)(frag0 + i) * 64];
     __builtin_amdgcn_sched_barrier(0);        // the requests stay HERE, a pass ahead of their use (left alone the scheduler sinks them down to the first MFMA that needs them)
@@ -93,7 +103,9 @@ struct FlowBandShape {
     static_assert(C % (16 * NW) == 0 && TA >= 1 && TA <= 2 && KC <= 8 && INNER % 32 == 0 && FF % C == 0 && (KA <= 8 || KA % 8 == 0), "flow_band: unsupported dimensions");
 };
 
-template <int C, int INNER, int FF, bool HAS_NEXT, int NW>
+// MODE (dev tool only, tools/ubench/band_probe.hip): 0 = the kernel; 1 = the weight stream is requested once (prologue) and never again; 2 = no MFMA and no fragment
+// reads (the stream alone, consumed by a register checksum); 3 = MFMAs on register operands (no LDS fragment reads)
+template <int C, int INNER, int FF, bool HAS_NEXT, int NW, int MODE = 0>
 __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
     using S = FlowBandShape<C, INNER, FF, NW>;
     constexpr int BM = 64, NT = NW * 64, TA = S::TA;
@@ -132,6 +144,11 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
     u32x4_t wb0[16], wb1[16];
     constexpr int FA0 = TA * (S::KA < 8 ? S::KA : 8);                       // fragments of the first out-projection pass
     band_wload<FA0>(wb0, ws, 0);
+    if constexpr (MODE == 1) band_wload<16>(wb1, ws, 16);
+    long long* dbg = p.dbg ? p.dbg + (long long)blockIdx.x * 16 : nullptr;
+    int dn = 0;
+    auto stamp = [&]() { if (dbg && tid == 0) dbg[dn++] = clock64(); };
+    stamp();                                                                // 0: requests issued
 #pragma unroll
     for (int i = 0; i < PPT; ++i) { const int v = tid + NT * i; if (v < NPV) *reinterpret_cast<float4*>(&prm[4 * v]) = pv[i]; }
 #pragma unroll
@@ -145,6 +162,7 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
         if (v < XPC) *reinterpret_cast<float4*>(&X1[(v / (C / 4)) * PX + (v % (C / 4)) * 4]) = xv[i];
     }
     __syncthreads();
+    stamp();                                                                // 1: operands staged
 
     // ---- A: out-projection + bias + residual -> X1 (fp32).  Wave w owns the 16-column tiles w + NW t.
     constexpr int FCD = TA * S::KC;                                         // fragments of an FF1 / FF2 chunk pass
@@ -155,14 +173,14 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
 #pragma unroll
             for (int t = 0; t < TA; ++t) acc[rt][t] = (v4f){0.f, 0.f, 0.f, 0.f};
         if constexpr (S::NPA == 1) {
-            band_wload<FCD>(wb1, ws, TA * S::KA);                           // FF1 chunk 0 in flight under the out-projection
-            band_mma<TA, S::KA>(wb0, A0, PA0, 0, lq, lg, acc);
+            band_wload<FCD, MODE>(wb1, ws, TA * S::KA);                           // FF1 chunk 0 in flight under the out-projection
+            band_mma<TA, S::KA, MODE>(wb0, A0, PA0, 0, lq, lg, acc);
         } else {
             static_assert(S::NPA <= 2, "flow_band: the out-projection runs in at most two passes (INNER <= 512)");
-            band_wload<TA * 8>(wb1, ws, TA * 8);
-            band_mma<TA, 8>(wb0, A0, PA0, 0, lq, lg, acc);
-            band_wload<FCD>(wb0, ws, TA * S::KA);                           // FF1 chunk 0
-            band_mma<TA, 8>(wb1, A0, PA0, 8 * 16, lq, lg, acc);
+            band_wload<TA * 8, MODE>(wb1, ws, TA * 8);
+            band_mma<TA, 8, MODE>(wb0, A0, PA0, 0, lq, lg, acc);
+            band_wload<FCD, MODE>(wb0, ws, TA * S::KA);                           // FF1 chunk 0
+            band_mma<TA, 8, MODE>(wb1, A0, PA0, 8 * 16, lq, lg, acc);
         }
 #pragma unroll
         for (int t = 0; t < TA; ++t) {
@@ -177,9 +195,11 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
         }
     }
     __syncthreads();                                                        // X1 complete, A0 dead
+    stamp();                                                                // 2: out-projection done
     // ---- B: LayerNorm(norm3) -> A1 (bf16)
     band_layernorm<C, PX, NT>(X1, A1, PA1, &prm[O_G3], &prm[O_BE3], p.eps, tid);
     __syncthreads();
+    stamp();                                                                // 3: LayerNorm done
     // ---- C / D: FF1 chunk j (+ bias + GELU -> A2) and FF2 over that chunk's hidden columns, accumulators across the chunks.  Stream order: FF1_0 FF2_0 FF1_1 FF2_1 ..
     // With NPA == 1 chunk 0's FF1 fragments sit in wb1, otherwise in wb0: the two buffers alternate from there.
     v4f acc2[4][TA];
@@ -189,31 +209,33 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
         for (int t = 0; t < TA; ++t) acc2[rt][t] = (v4f){0.f, 0.f, 0.f, 0.f};
     constexpr int F0 = TA * S::KA;                                          // first fragment of the FF stream
     constexpr bool FF1_IN_WB1 = S::NPA == 1;
-#pragma unroll
-    for (int j = 0; j < S::NCH; ++j) {
+#pragma unroll 1
+    for (int j = 0; j < S::NCH; ++j) {                                      // a real loop: every chunk runs the same code on the same two buffers (and the epilogue's GELU stays one copy)
         v4f acc1[4][TA];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
             for (int t = 0; t < TA; ++t) acc1[rt][t] = (v4f){0.f, 0.f, 0.f, 0.f};
         // FF1 chunk j is in buffer X (loaded one pass ago); request FF2 chunk j into the other buffer, multiply
-        if constexpr (FF1_IN_WB1) { band_wload<FCD>(wb0, ws, F0 + (2 * j + 1) * FCD); band_mma<TA, S::KC>(wb1, A1, PA1, 0, lq, lg, acc1); }
-        else                      { band_wload<FCD>(wb1, ws, F0 + (2 * j + 1) * FCD); band_mma<TA, S::KC>(wb0, A1, PA1, 0, lq, lg, acc1); }
+        if constexpr (FF1_IN_WB1) { band_wload<FCD, MODE>(wb0, ws, F0 + (2 * j + 1) * FCD); band_mma<TA, S::KC, MODE>(wb1, A1, PA1, 0, lq, lg, acc1); }
+        else                      { band_wload<FCD, MODE>(wb1, ws, F0 + (2 * j + 1) * FCD); band_mma<TA, S::KC, MODE>(wb0, A1, PA1, 0, lq, lg, acc1); }
 #pragma unroll
         for (int t = 0; t < TA; ++t) {
             const int n = 16 * (wave + NW * t) + 4 * lg;                    // column inside the chunk
             const float4 b = *reinterpret_cast<const float4*>(&prm[O_BFF1 + j * C + n]);
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
-                const float4 y = apply_act4(ACT_GELU_ERF, make_float4(acc1[rt][t][0] + b.x, acc1[rt][t][1] + b.y, acc1[rt][t][2] + b.z, acc1[rt][t][3] + b.w), 0.f);
+                const float4 y = gelu_erf4(make_float4(acc1[rt][t][0] + b.x, acc1[rt][t][1] + b.y, acc1[rt][t][2] + b.z, acc1[rt][t][3] + b.w));      // = apply_act4(ACT_GELU_ERF, ..), inlined
                 *reinterpret_cast<uint2*>(&A2[(16 * rt + lq) * PA1 + n / 2]) = make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
             }
         }
         __syncthreads();                                                    // the chunk's hidden tile is complete
-        // FF2 chunk j; request FF1 chunk j + 1 (the stream's last pass requests nothing)
-        if constexpr (FF1_IN_WB1) { if (j + 1 < S::NCH) band_wload<FCD>(wb1, ws, F0 + (2 * j + 2) * FCD); band_mma<TA, S::KC>(wb0, A2, PA1, 0, lq, lg, acc2); }
-        else                      { if (j + 1 < S::NCH) band_wload<FCD>(wb0, ws, F0 + (2 * j + 2) * FCD); band_mma<TA, S::KC>(wb1, A2, PA1, 0, lq, lg, acc2); }
-        if (j + 1 < S::NCH) __syncthreads();                                // before the next chunk overwrites A2
+        // FF2 chunk j; request FF1 chunk j + 1 (unconditional: after the last chunk the request repeats that chunk's FF1 fragments and is never used)
+        const int nxt = F0 + 2 * min(j + 1, S::NCH - 1) * FCD;
+        if constexpr (FF1_IN_WB1) { band_wload<FCD, MODE>(wb1, ws, nxt); band_mma<TA, S::KC, MODE>(wb0, A2, PA1, 0, lq, lg, acc2); }
+        else                      { band_wload<FCD, MODE>(wb0, ws, nxt); band_mma<TA, S::KC, MODE>(wb1, A2, PA1, 0, lq, lg, acc2); }
+        __syncthreads();                                                    // before the next chunk overwrites A2 (and before the epilogue below touches X1's neighbours)
+        stamp();                                                            // 4 .. 3 + NCH: chunk j done
     }
     // ---- FF2 epilogue: + bias + residual -> X1 (the new residual stream)
 #pragma unroll
@@ -239,12 +261,14 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
             if (v < NP && m0 + r < p.M) *reinterpret_cast<u32x4_t*>(p.xn + (long long)(m0 + r) * p.ld_xn + c * 8) = *reinterpret_cast<const u32x4_t*>(&A1[r * PA1 + c * 4]);
         }
     }
+    stamp();                                                                // FF2 epilogue (+ next LayerNorm and its rows) done
     // write-out of the residual stream: whole rows, 16 bytes per lane
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
         const int v = tid + NT * i, r = v / (C / 4), c = v % (C / 4);
         if (v < XPC && m0 + r < p.M) *reinterpret_cast<float4*>(p.x + (long long)(m0 + r) * p.ldx + c * 4) = *reinterpret_cast<const float4*>(&X1[r * PX + c * 4]);
     }
+    stamp();
 }
 
 }  // namespace cv

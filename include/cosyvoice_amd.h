@@ -189,6 +189,10 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value);
 /* "graph_captures" (Euler-solve graphs captured so far), "graphs_cached" (held now; option "graph_cap", default 32) - test / monitoring hook, no reference counterpart */
 int cv_flow_get_stat(cv_flow* m, const char* name, int64_t* value);
 void cv_flow_destroy(cv_flow* m);
+/* measurement hook (bench.py `roofline_mfma`; no reference counterpart): the QKV GEMM, the flash attention and the 64-row band launch (csrc/flow_band.h) of one transformer
+ * block of a LARGE pass - nz estimator batch rows (2 per utterance) of T frames - each timed as `reps` back-to-back launches between one HIP-event pair on `stream`;
+ * us3[0..2] = microseconds per launch.  bf16 mode, U-Net estimator only. */
+int cv_flow_profile_block(cv_flow* m, int32_t nz, int32_t T, int32_t reps, float* us3, void* stream);
 /* B4: flow.encoder(token_emb[1,n,dim], token_len, context=[1,3,dim] or empty, streaming) -> h[1,2n,dim]
  * (cosyvoice/flow/flow.py:258-261, transformer/upsample_encoder.py:244-307).  tok_emb / context / h_out: dev fp32, row-major. */
 int cv_flow_encoder(cv_flow* m, const float* tok_emb, int32_t n_tok, const float* context, int32_t streaming, float* h_out, void* stream);

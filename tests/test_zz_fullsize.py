@@ -228,6 +228,37 @@ def test_flow_estimator_u10(lib, precision):
         assert err < (6e-6 if precision == "fp32" else 1.8e-2), (precision, streaming, err)
 
 
+@pytest.mark.parametrize("band", [1, 0])
+def test_flow_estimator_u10_large_m_kernels(lib, band):
+    """Round 5: the LARGE-M kernel set of a shared pass (flow_big.h; selected by the row count, big_rows = 1 forces it) held to the fp32 ORACLE at
+    full size - C = 256, 8 heads, K up to 1024, T = 674, CFG batch 2 - not only to the small-tile kernels at toy size.  band = 1: with the 64-row band launch of
+    flow_band.h between attention and the next QKV GEMM (the default of a large pass); band = 0: the seven-launch form.  Same bounds as the small-tile test above, and
+    bit-identical to it (the kernel choice may follow the row count of a pass)."""
+    import ctypes as C
+    fc = _cfgs(lib)[1]
+    sd = W.make_flow(fc)
+    flow = CausalMaskedDiffWithXvec(sd, fc, lib=lib, precision="bf16")
+    g = torch.Generator().manual_seed(13)
+    T = 57 if lib.emulated else 674
+    x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g); cond = torch.randn(2, 80, T, generator=g)
+    spk = torch.randn(2, 80, generator=g); t = torch.tensor([0.6, 0.6]); mask = torch.ones(2, 1, T)
+    mu[1] = 0; cond[1] = 0; spk[1] = 0
+    try:
+        for streaming in (False, True):
+            lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(0)); lib.cv_flow_set_option(flow._h, b"attn2_rows", C.c_int32(0))
+            small = flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu().clone()
+            lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(1)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(band))
+            out = flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu()
+            ref = OF.estimator(sd, fc, x, mask, mu, t, spk, cond, streaming)
+            err = _rel(out, ref)
+            _record(lib, "estimator_T674_bf16_large_m_band%d_streaming%d_rel_l2" % (band, int(streaming)), err)
+            _record(lib, "estimator_T674_bf16_large_m_band%d_streaming%d_max_abs" % (band, int(streaming)), (out - ref).abs().max().item())
+            assert err < 1.8e-2, (band, streaming, err)
+            assert torch.equal(out, small), (band, streaming, (out - small).abs().max().item())
+    finally:
+        lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(4000)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(1))
+
+
 def test_flow_inference_u10(lib):
     """flow.inference as token2wav calls it for U10 (87 prompt + 250 generated tokens, 174 prompt frames, 10 Euler steps, bf16 mode -
     the configuration bench.py times) against the fp32 oracle; SURVEY.md section 8c tolerance: mel max |diff| <= 5e-2."""
