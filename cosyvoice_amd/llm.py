@@ -210,12 +210,15 @@ class Qwen2LM:
             raise ValueError("%s: prompt (%d) + min_len (%d) exceeds the KV capacity %d" % (what, L0, min_len, self.max_len))
         return min(max_len, room)
 
-    def make_sampling(self, min_len, max_len):
+    def make_sampling(self, min_len, max_len, seed_key=None):
+        """Sampling parameters of one request.  The draw stream of the device sampler is keyed by `seed + k`: k = the handle's running request count, or - `seed_key`,
+        a request's `seed_key` entry in inference_batch / inference_queue - a number the CALLER ties to the request, so that under 'ras' sampling a request's tokens do
+        not depend on the order in which a queue admitted it (tts_queue passes the request's index in its list)."""
         self._request += 1
         # `eos` of the C sampler = first special id = the index sampling_ids masks while ignore_eos (llm/llm.py:150-160: literally
         # `speech_token_size`, which is eos for Qwen2LM and - a quirk kept as is - sos for CosyVoice3LM); n_stop ids from there stop decoding
         sp = SamplingC(1 if self.sampling == "ras" else 0, self.cfg.speech_token_size, self.cfg.n_special, min_len, max_len, self.top_p, self.top_k, self.win_size,
-                       self.tau_r, self.seed + self._request, 1 if self._uniforms is not None else 0)
+                       self.tau_r, self.seed + (self._request if seed_key is None else int(seed_key)), 1 if self._uniforms is not None else 0)
         if self._uniforms is not None:
             self.lib.cv_llm_set_uniforms(self._h, C.c_void_p(self._uniforms.data_ptr()), C.c_int32(min(self._uniforms.numel(), 2 * self.max_len)), stream_ptr(self.lib))
         return sp
@@ -271,7 +274,7 @@ class Qwen2LM:
                 max_len = int(n_text * r.get("max_token_text_ratio", max_token_text_ratio))
                 if max_len > 0:
                     max_len = self.clamp_max_len(lm_input.shape[0], min_len, max_len, "request %d" % i)
-                inputs.append(lm_input); sps.append(self.make_sampling(min_len, max(max_len, 1)))
+                inputs.append(lm_input); sps.append(self.make_sampling(min_len, max(max_len, 1), r.get("seed_key")))
                 max_lens.append(max_len)
             self._prefill_slots(list(range(nb)), inputs, sps, st)
             outs, fin = [[] for _ in range(nb)], [m == 0 for m in max_lens]
@@ -328,7 +331,7 @@ class Qwen2LM:
                         done.append((i, []))
                         continue
                     max_len = self.clamp_max_len(lm_input.shape[0], min_len, max_len, "request %d" % i)
-                    pending.append((slot, lm_input, self.make_sampling(min_len, max_len)))
+                    pending.append((slot, lm_input, self.make_sampling(min_len, max_len, r.get("seed_key"))))
                     owner[slot], outs[i], limit[i] = i, [], max_len
                     return
                 owner[slot] = None

@@ -426,14 +426,18 @@ class CosyVoice2Model:
         finished ones.  Yields (request_index, {'tts_speech': [1, S]}) in completion order; each waveform equals tts(**request).
         order: "longest_first" (default, round 4) admits the requests by decreasing length bound (text ids x max_token_text_ratio - what the reference's own
         stopping rule makes the expected length proportional to, llm.py:484-485): the slots do not idle behind one long request admitted last, and requests of
-        similar length finish - and share flow passes - together; "fifo" admits them as listed.  The audio of a request does not depend on the order."""
+        similar length finish - and share flow passes - together; "fifo" admits them as listed.  The audio of a request does not depend on the order: greedy decoding
+        has no random stream, and under 'ras' sampling the device sampler's stream of a request is keyed by the request's INDEX in `requests` (`seed_key`,
+        Qwen2LM.make_sampling), not by when the queue admitted it.  (tts(**request) alone draws from the handle's running request count instead: equal audio between
+        the two entry points is a property of greedy decoding only.)"""
         import queue
         q = queue.Queue()
         assert order in ("longest_first", "fifo"), order
         bound = lambda r: int(r["text"].shape[1]) * float(r.get("max_token_text_ratio", 20))
         perm = sorted(range(len(requests)), key=lambda i: -bound(requests[i])) if order == "longest_first" else list(range(len(requests)))       # (stable: ties keep their order)
-        lm_reqs = [dict(text=r["text"], prompt_text=r["prompt_text"], prompt_speech_token=r["llm_prompt_speech_token"],
-                        **{k: r[k] for k in ("min_token_text_ratio", "max_token_text_ratio") if k in r}) for r in (requests[i] for i in perm)]
+        base = getattr(self.llm, "_request", 0)
+        lm_reqs = [dict(text=requests[i]["text"], prompt_text=requests[i]["prompt_text"], prompt_speech_token=requests[i]["llm_prompt_speech_token"], seed_key=base + 1 + i,
+                        **{k: requests[i][k] for k in ("min_token_text_ratio", "max_token_text_ratio") if k in requests[i]}) for i in perm]
 
         def produce():
             try:

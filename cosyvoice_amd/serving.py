@@ -226,18 +226,24 @@ class StreamScheduler:
                 r.out.put(None)
             delivered.add(i)
         failed = {}
+        # A member's vocoder caches (mel / source / speech tail) advance inside token2wav_batch BEFORE its listener runs; if the pass - or deliver() itself - fails after
+        # that, a solo retry must start from the caches the chunk started from, or it would vocode the chunk a second time against already-advanced state.
+        with m.lock:
+            before = {i: m.hift_cache_dict.get(r.key) for i, (r, _, _) in enumerate(picks)}
         try:
             m.token2wav_batch(jobs, stream=(what == "chunk"), finalize=(what == "final"), on_ready=deliver)
-        except BaseException:
+        except Exception:
             # The shared pass (or one member's vocoder call) failed.  A request must not pay for a neighbour it happened to share a pass with:
-            # members that already got this chunk carry on untouched (their caches were updated by their own, finished HiFT call); the others are vocoded
-            # again ONE BY ONE - a request's caches only change at the end of its own successful call - and only those that fail alone end with their error.
+            # members that already got this chunk carry on untouched; the others are vocoded again ONE BY ONE from the cache state the chunk started from, and
+            # only those that fail alone end with their error.
             for i, (r, _, _) in enumerate(picks):
                 if i in delivered:
                     continue
                 try:
+                    with m.lock:
+                        m.hift_cache_dict[r.key] = before[i]
                     deliver(i, m.token2wav(stream=(what == "chunk"), finalize=(what == "final"), **jobs[i]))
-                except BaseException as e:                  # noqa: BLE001 - handed to the request's listener
+                except Exception as e:                      # handed to the request's listener
                     failed[i] = e
                     r.out.put(e)
         self.batched_passes += 1
