@@ -276,8 +276,16 @@ def cv3_workload(args):
             if len(toks) != len(gold["tokens"]) or (div is not None and gold["top2_margin"][div] > 1e-3):
                 raise RuntimeError("bench cosyvoice3: %s does not reproduce the oracle's tokens (first difference at step %s)" % (name, div))
         check = {"checked": True, "tokens_equal_oracle_single_and_16_slots": True, "oracle_min_top2_margin": gold["min_margin"]}
-    fp8 = None
-    if os.path.exists(gpath) and not args.llm_fp8:
+    # Round 5: the fp8 sub-line is RETIRED from the default line ("make it win or retire it, with numbers either way").  Measured on the MI355X under
+    # the driver's command (gpurun_out/r5g -> profiles/r5_fp8_retired.txt): 16 requests per GPU 318.5 audio-s/s on the fp8 path against 355.2 on W16A32, first divergence
+    # from the fp32 oracle's tokens at step 3, first-step max |d log p| 0.475 against the go bar of 0.1.  Every launch of the lock-step step is bound by its fixed
+    # cost (launch, first-byte latency, staging), not by its weight bytes (30 MB per layer = 3.7 us of HBM time inside ~40 us of launches), so halving the weight
+    # bytes cannot buy the 1.25 x the go bar asked for.  The kernels and their tests stay (an opt-in mode); CV_BENCH_CV3_FP8=1 measures the sub-line again.
+    fp8 = {"status": "retired from the default line in round 5: measured, not beneficial on W16A32-exact kernels (BASELINE.json configs[4]'s fp8 clause)",
+           "last_measured": {"round": 5, "batch16_audio_s_per_s_fp8": 318.458, "batch16_audio_s_per_s_w16a32": 355.249, "first_divergence_from_fp32_oracle_tokens": 3,
+                             "first_step_max_abs_dlogp_vs_w16a32": 0.47529, "go_bar": ">= 1.25 x the W16A32 step, >= 97 % teacher-forced agreement, first-step |d log p| <= 0.1"},
+           "rerun": "CV_BENCH_CV3_FP8=1 python bench.py --only-extra cosyvoice3"}
+    if os.path.exists(gpath) and not args.llm_fp8 and os.environ.get("CV_BENCH_CV3_FP8", "0") == "1":
         # BASELINE.json configs[4] AS QUOTED ("fp8 MFMA LLM path + 4-step CFM", 16 requests per GPU) under the same clock: the batched decode on e4m3 weight copies
         # (per-row scales) with per-sequence activation quantisation on v_mfma_f32_16x16x32_fp8_fp8.  THE REFERENCE HAS NO fp8 PATH: there is nothing to be equal to -
         # the line reports how far the quantised decode is from the fp32 oracle's tokens and, at the first step, from the W16A32 log-probabilities

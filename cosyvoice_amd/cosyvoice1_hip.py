@@ -395,6 +395,12 @@ class EspnetEncoder(C1.EspnetEncoder):
         K, L0 = self.k, self.layers[0]
         if self.kind != "transformer" or self.d > 1024 or L0["w1"].n > 4096 or self.embed.k > 4096 or self.embed.k % 4 or K.split3:
             return None
+        # cv_lm1_create's own conditions (csrc/lm1.hip), mirrored so that a model outside them falls back to the launch-per-operator step instead of raising:
+        # 64-wide heads, feed-forward % 4, at most 32 layers, every bias present
+        tensors = [t for L in self.layers for t in (L["ln1"][0], L["ln1"][1], L["qkv"].w, L["qkv"].b, L["out"].w, L["out"].b, L["ln2"][0], L["ln2"][1], L["w1"].w, L["w1"].b, L["w2"].w, L["w2"].b)]
+        tensors += [self.embed.w, self.embed.b, self.embed_ln[0], self.embed_ln[1], self.after[0], self.after[1], decoder.w, decoder.b]
+        if self.d != self.heads * 64 or L0["w1"].n % 4 or self.n_layers > 32 or any(t is None or t.data_ptr() % 16 for t in tensors):
+            return None
         lw = (Lm1LayerWeights * self.n_layers)()
         for i, L in enumerate(self.layers):
             for name, t in (("ln1_g", L["ln1"][0]), ("ln1_b", L["ln1"][1]), ("w_qkv", L["qkv"].w), ("b_qkv", L["qkv"].b), ("w_out", L["out"].w), ("b_out", L["out"].b),
@@ -408,8 +414,8 @@ class EspnetEncoder(C1.EspnetEncoder):
             setattr(c, name, t.data_ptr())
         real = getattr(K.lib, "_lib", K.lib)
         h = real.raw("cv_lm1_create", C.c_void_p)(C.byref(c), lw)
-        if not h:
-            real.check(1)
+        if not h:                                               # refused by the library for a reason the gate above does not know: the operator-per-launch step serves the model
+            return None
         step = _FusedStep(real, C.c_void_p(h), K.new(decoder.n), (c, lw, decoder))
         return step
 

@@ -28,11 +28,13 @@ void gemm_conv(GemmConvArgs a, bool w_bf16, int batch, hipStream_t s) {
     CV_CHECK(!a.col_scale || a.col_scale_rows > 0, "gemm_conv: col_scale needs col_scale_rows > 0");
     if (a.pro == ACT_SNAKE) CV_CHECK(a.pro_alpha && aligned16(a.pro_alpha), "gemm_conv: snake prologue needs 16B aligned alpha[Kp]");
     // one output row over fp32 weights (the decode step of CosyVoice-300M's LM): a GEMV, not a tile with one useful row (gemm_conv.h, gemv_f32_kernel).
-    // CV_GEMV_F32=0 keeps the tiled kernel (A/B knob, read at every launch).
+    // CV_GEMV_F32=0 keeps the tiled kernel (A/B knob, read ONCE per process: getenv is not safe against a concurrent setenv, and this is several hundred launches
+    // per token on the launch-per-operator path).  The GEMV reads the matrix as registered: the split3 planes of a W3 registration do not apply to M == 1 rows
+    // (include/cosyvoice_amd.h, cv_gemm_conv); its sums differ from the tile kernel's in order only.
+    static const bool gemv_f32 = [] { const char* e = getenv("CV_GEMV_F32"); return !(e && e[0] == '0'); }();
     if (a.M == 1 && batch == 1 && a.taps == 1 && !w_bf16 && a.a_vec && a.pro == ACT_NONE && !a.row_scale && !a.col_scale && !a.C2 && !a.accumulate && a.act != ACT_SNAKE &&
         a.a_off0 == 0 && a.c_off == 0 && a.a_len >= a.K) {
-        const char* e = getenv("CV_GEMV_F32");
-        if (!(e && e[0] == '0')) {
+        if (gemv_f32) {
             GemvF32Args g{a.A, reinterpret_cast<const float*>(a.W), a.ldw ? a.ldw : (long long)a.Kp, a.bias, a.res, a.C, a.N, a.K, a.Kp, a.act, a.act_p, a.out_scale};
             hipLaunchKernelGGL(gemv_f32_kernel, dim3((unsigned)((a.N + 3) / 4)), dim3(256), 0, s, g);
             return;

@@ -92,6 +92,7 @@ struct cv_flow {
     int flow_tile = 0, attn_waves = 4, attn_kt = 1, attn_ks = 2;   // "attn_ks": key splits inside a 64-query workgroup (2 = 8 waves, 128 keys per iteration)
     DevBuf t_val, t_sin, t_h, t_emb, t_mlp;                                                   // time embeddings
     DevBuf f_tok, f_h, f_mu, f_spk, f_spkn, f_cond, f_x, f_ones;                              // inference glue
+    long long enc_rows = 0;            // row capacity (2 x tokens x utterances) of the encoder's row-wise workspaces
     int enc_nu = 0, enc_batch = 1;        // enc_batch: encode the utterances of an equal-length pass together (option "enc_batch", CV_FLOW_ENC_BATCH)
     int enc_cap = 0, est_cap = 0, est_nz = 0, t_cap = 0, inf_cap = 0; long long inf_rows = 0;
     // padded batches (cv_flow_inference_ragged): key counts per estimator batch row, fixed device address (captured graphs read the current content)
@@ -277,14 +278,17 @@ static void ln_rows(const LN& n, const float* x, float* y, long long rows, int C
 
 // ---- encoder ---------------------------------------------------------------------------------------------------------
 static void enc_reserve(cv_flow* m, int T, int nu = 1) {      // T = token count before upsampling, nu = utterances of that length encoded together
-    if (T <= m->enc_cap && nu <= m->enc_nu) return;
+    // Two capacities: the per-utterance length T sizes the position tables and the rel-pos score buffer; the ROW count 2 T nu sizes everything row-wise.
+    // Kept as independent maxima they made one long utterance after an 8-utterance pass of short chunks reserve 8 x the rows it needs.
+    const long long rows = 2LL * T * nu;
+    if (T <= m->enc_cap && nu <= m->enc_nu && rows <= m->enc_rows) return;
     T = std::max(T, m->enc_cap); nu = std::max(nu, m->enc_nu);
-    const auto& c = m->cfg; const size_t d = c.dim, T2 = 2 * (size_t)T, R2 = T2 * nu, f = 4;
+    const auto& c = m->cfg; const size_t d = c.dim, T2 = 2 * (size_t)T, R2 = (size_t)std::max(rows, m->enc_rows), f = 4;
     m->e_x.ensure(R2 * d * f); m->e_xe.ensure((R2 + 8 * nu) * d * f); m->e_n.ensure(R2 * d * f); m->e_qkv.ensure(R2 * 3 * d * f);
     m->e_qu.ensure(R2 * d * f); m->e_qv.ensure(R2 * d * f); m->e_pe.ensure((2 * T2) * d * f); m->e_p.ensure((2 * T2) * d * f);
     m->e_bd.ensure((size_t)c.enc_heads * T2 * (2 * T2) * f); m->e_att.ensure(R2 * d * f); m->e_ff.ensure(R2 * c.ffn * f);
     m->e_x2.ensure(R2 * d * f); m->e_ctx.ensure(8 * nu * d * f);
-    m->enc_cap = T; m->enc_nu = nu;
+    m->enc_cap = T; m->enc_nu = nu; m->enc_rows = (long long)R2;
 }
 
 // x: [nu][T][d] stacked.  Everything row-wise runs ONCE over the nu * T rows; linear_pos(pe) once per layer (the reference recomputes it per call); matrix_bd and

@@ -424,14 +424,13 @@ __global__ __launch_bounds__(NW * KS * 64) void attn_flow_kernel(AttnFlowArgs p)
                         mt = fmaxf(mt, x); mn = fminf(mn, x);
                     }
             } else {
+                // round 5: four scores per multiply on the packed fp32 pipe (v_pk_mul_f32: the same products), maxima / minima as a tree (exact, order-free)
 #pragma unroll
-                for (int kt = 0; kt < 4 * KTW; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float x = s[g][kt][r] * scale2;
-                        s[g][kt][r] = x;
-                        mt = fmaxf(mt, x); mn = fminf(mn, x);
-                    }
+                for (int kt = 0; kt < 4 * KTW; ++kt) {
+                    const v4f x = s[g][kt] * scale2;
+                    s[g][kt] = x;
+                    mt = fmaxf(mt, fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]))); mn = fminf(mn, fminf(fminf(x[0], x[1]), fminf(x[2], x[3])));
+                }
             }
             mt = fmaxf(mt, __shfl_xor(mt, 16));
             mt = fmaxf(mt, __shfl_xor(mt, 32));
@@ -450,13 +449,15 @@ __global__ __launch_bounds__(NW * KS * 64) void attn_flow_kernel(AttnFlowArgs p)
                     }
             } else {
 #pragma unroll
-                for (int kt = 0; kt < 4 * KTW; ++kt)
+                for (int kt = 0; kt < 4 * KTW; ++kt) {
+                    const v4f d = s[g][kt] - m_sub;                                  // packed subtraction (same differences)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = __builtin_amdgcn_exp2f(s[g][kt][r] - m_sub);
+                        const float e = __builtin_amdgcn_exp2f(d[r]);
                         s[g][kt][r] = e;
-                        rsum += e;
+                        rsum += e;                         // the denominator keeps its order of additions
                     }
+                }
             }
             rsum += __shfl_xor(rsum, 16);
             rsum += __shfl_xor(rsum, 32);

@@ -59,6 +59,8 @@ typedef struct cv_gemm_conv_args {
                             w = w1 + w2 + w3 exactly (cosyvoice_amd/weights.py::split3_planes).  When set (and the A layout is 16-byte aligned) the products run on
                             the bf16 matrix pipe with BOTH operands split, six exact plane products per k - fp32 accuracy at 2.5x the fp32 MFMA rate (HiFT). NULL: fp32 chain */
 } cv_gemm_conv_args;
+/* One-row calls (M == 1, batch 1, one tap, fp32 W, no prologue / scales) run as a GEMV over the matrix as registered in `W`: they ignore W3, and their sums differ
+ * from the tile kernels' in summation order only (fp32 rounding) - the decode rows of a model agree with its prefill rows to that, not bit for bit. */
 int cv_gemm_conv(const cv_gemm_conv_args* args, void* stream);
 
 /* Row LayerNorm / RMSNorm over the last (channel) axis of a [rows, C] fp32 matrix.
