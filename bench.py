@@ -340,7 +340,10 @@ def cv1_workload(args):
     cfg, hcfg = W.cv1()
     sd_llm, sd_flow, sd_hift = W.make_cv1_llm(cfg), W.make_cv1_flow(cfg), W.make_hift(hcfg)
     greedy = lambda scores, decoded, sampling: int(scores.argmax().item())
-    lm = CK.TransformerLM(sd_llm, text_heads=cfg.text_heads, llm_heads=cfg.llm_heads, sampling=greedy)
+    # round 5: the decode loop on the device (sampling="greedy" -> cv_lm1_decode: sampler + embedding row next to the step, tokens back per chunk); CV_BENCH_CV1_HOST_LOOP=1
+    # keeps the reference-shaped loop (host sampler, one round trip per token) for A/B
+    host_loop = os.environ.get("CV_BENCH_CV1_HOST_LOOP", "0") == "1"
+    lm = CK.TransformerLM(sd_llm, text_heads=cfg.text_heads, llm_heads=cfg.llm_heads, sampling=greedy if host_loop else "greedy")
     m = CK.CosyVoiceModel(lm, CK.MaskedDiffWithXvec(sd_flow, enc_heads=cfg.flow_heads, est_heads=cfg.est_heads, input_frame_rate=cfg.input_frame_rate),
                           CK.HiFTGenerator(sd_hift, hcfg))
     g = torch.Generator().manual_seed(300)
@@ -390,6 +393,8 @@ def cv1_workload(args):
     div = next((k for k, (a, b) in enumerate(zip(tokens, want)) if a != b), None)
     return {"model": "CosyVoice-300M dimensions (TransformerLM 14 x 1024 + conformer text encoder, MaskedDiffWithXvec with the U-Net ConditionalDecoder, HiFTGenerator 22.05 kHz), "
                      "seeded random weights, fp32", "request": "inference_sft shape: 25 text ids, 500 generated tokens = %.2f s of audio, greedy, 10 Euler steps" % audio_s,
+            "lm_loop": "host sampler, one logits round trip per token (reference-shaped)" if host_loop else "on the device (cv_lm1_decode: sampler + embedding row in the launch sequence, tokens per 64-step chunk)",
+            "full_size_check_note": "the token check below is against the builder's torch-eager port (cosyvoice1.py), which the REAL reference classes pin at test dimensions only (tests/golden/cv1*_*.npz)",
             "host": "python sequencing over the operator-level C ABI (cosyvoice1_hip.py); the LM decode step is ONE call (cv_lm1_step, csrc/lm1.hip: %s)"
                     % ("%d launches per token, %d of the %d steps replayed as a hipGraph" % (lm.step.stat("launches_per_step"), lm.step.stat("graph_replays"), lm.step.stat("steps")) if lm.step is not None and lm.fused_step
                        else "off: launch-per-operator tape"), "audio_s_per_s": round(audio_s / per, 3),

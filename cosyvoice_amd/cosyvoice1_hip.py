@@ -436,6 +436,31 @@ class EspnetEncoder(C1.EspnetEncoder):
         state.plan = None
         return step.logits
 
+    def loop_begin(self, step, x_row, state, sp, emb_table, uniforms=None):
+        """Open the device-resident decode loop (cv_lm1_decode_begin): `x_row` [1, d_in] is the next input row, written at position state.len; `sp` a SamplingC with the
+        request's bounds; the cache is grown ONCE for every position the loop can write (no rebinding while it runs)."""
+        t0 = state.len
+        state.reserve(t0 + int(sp.max_len) + 1)
+        self._pos_tables(state.cap)
+        key = (state.ident, self._pos_n)
+        if step.bound != key:
+            n = self.n_layers
+            rows = (C.c_void_p * n)(*[r.data_ptr() for r in state.rows])
+            tabs = (C.c_void_p * n)(*[t.data_ptr() for t in self._pos_tab])
+            step.lib.cv_lm1_bind(step.h, rows, tabs, C.c_int32(self._pos_n), C.c_int32(state.cap), stream_ptr(step.lib))
+            step.bound = key
+        u = None if uniforms is None else uniforms.detach().to(torch.float32).cpu().contiguous()
+        step.lib.cv_lm1_decode_begin(step.h, C.c_void_p(x_row.data_ptr()), C.c_int32(t0), C.byref(sp), C.c_void_p(emb_table.data_ptr()), C.c_int32(int(sp.max_len)),
+                                     C.c_void_p(u.data_ptr()) if u is not None else None, C.c_int32(0 if u is None else u.numel()), stream_ptr(step.lib))
+        state.plan = None
+
+    def loop_steps(self, step, state, n):
+        """n steps of the open loop; returns (tokens emitted by these steps, finished)."""
+        buf, n_out, fin = (C.c_int32 * n)(), C.c_int32(0), C.c_int32(0)
+        step.lib.cv_lm1_decode(step.h, C.c_int32(n), buf, C.byref(n_out), C.byref(fin), stream_ptr(step.lib))
+        state.len += n_out.value                                 # (rows written past the last emitted token belong to nobody)
+        return [int(buf[k]) for k in range(n_out.value)], bool(fin.value)
+
     def _forward_rows(self, xs, t1, state, t0):
         x = self._embed(xs, t1)
         for i in range(self.n_layers):
@@ -461,8 +486,14 @@ class EspnetEncoder(C1.EspnetEncoder):
 class TransformerLM(C1.TransformerLM):
     """cosyvoice.llm.llm.TransformerLM.inference (llm/llm.py:162-223) on the kernels; sampling decisions on the host like the reference's python sampler."""
 
-    def __init__(self, sd, text_heads=16, llm_heads=16, sampling=C1.ras_sampling, lib=None, split3=False):
+    def __init__(self, sd, text_heads=16, llm_heads=16, sampling=C1.ras_sampling, lib=None, split3=False, seed=0, decode_chunk=64):
+        """sampling: a callable (scores, decoded, sampling) -> id - the reference's python sampler, run on the HOST once per token like the reference's loop (llm/llm.py:196-223:
+        the parity hook; its draws come from torch's global RNG) - or one of the strings "greedy" / "ras": the DEVICE sampler of csrc/llm_kernels.h (arg-max, or
+        repetition-aware sampling top_p 0.8 / top_k 25 / win 10 / tau_r 0.1 with the library's counter RNG keyed by `seed` + request count), which keeps the whole decode
+        loop on the device (cv_lm1_decode: tokens come back every `decode_chunk` steps).  Same decisions as the python sampler on the same probabilities; the draw stream
+        is the device's own (as for Qwen2LM)."""
         self.k = K = Kernels(lib, split3)
+        self.seed, self.decode_chunk, self._request, self._uniforms = int(seed), int(decode_chunk), 0, None
         self.sd = sd
         self.text_encoder = EspnetEncoder(sd, "text_encoder.", text_heads, "conformer", causal=True, kern=K)
         self.llm = EspnetEncoder(sd, "llm.", llm_heads, "transformer", kern=K)
@@ -519,6 +550,23 @@ class TransformerLM(C1.TransformerLM):
             if n_prompt:
                 lm_input[r:r + n_prompt].copy_(K.gather(self.speech_emb, prompt_speech_token))
         min_len, max_len = int(n_text * min_token_text_ratio), int(n_text * max_token_text_ratio)
+        if isinstance(self.sampling, str) and self.fused_step and max_len > 0 and L >= 2:
+            # the loop on the device: prefill all rows but the last through the chunk path, then the last row is the loop's first input
+            from .llm import SamplingC
+            with self.lock:
+                self._request += 1
+                _, state = self.llm.forward_chunk(lm_input[:L - 1], None)
+                sp = SamplingC(1 if self.sampling == "ras" else 0, self.eos_token, 1, min_len, max_len, 0.8, 25, 10, 0.1, self.seed + self._request,
+                               1 if self._uniforms is not None else 0)
+                self.llm.loop_begin(self.step, lm_input[L - 1:L].contiguous(), state, sp, self.speech_emb, self._uniforms)
+            done, n_yield = False, 0
+            while not done and n_yield < max_len:
+                with self.lock:
+                    toks, done = self.llm.loop_steps(self.step, state, min(self.decode_chunk, max_len - n_yield))
+                for t in toks:
+                    yield t
+                n_yield += len(toks)
+            return
         out_tokens, state, x = [], None, lm_input
         for i in range(max_len):
             with self.lock:

@@ -854,6 +854,7 @@ struct SampleArgs {
     const float* uniforms;                                    // explicit uniforms [2 per step] when sp->use_uniforms (parity tests)
     DecodeState* st; int* tokens; int max_tokens;
     const bf16_t* emb_table = nullptr; int emb_dim = 0; float* h_out = nullptr;   // when set: h_out = speech_embedding[token] for an emitted token (was embed_last_token_kernel)
+    const float* emb_table_f32 = nullptr;                     // the same with an fp32 table (CosyVoice-300M's speech_embedding, lm1.hip)
     // batched decode: workgroup b = blockIdx.x samples slot b; element strides between the slots (single sequence: one workgroup, strides unused)
     long long slot_logits = 0, slot_uniforms = 0, slot_tokens = 0, slot_h = 0;
 };
@@ -982,7 +983,8 @@ static __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs a) {
         }
     }
     if (a.h_out && !stop)                                     // input of the backbone step that follows in the same graph replay
-        for (int c = tid; c < a.emb_dim; c += 1024) a.h_out[c] = bf16_to_f32(a.emb_table[(long long)tok * a.emb_dim + c]);
+        for (int c = tid; c < a.emb_dim; c += 1024)
+            a.h_out[c] = a.emb_table_f32 ? a.emb_table_f32[(long long)tok * a.emb_dim + c] : bf16_to_f32(a.emb_table[(long long)tok * a.emb_dim + c]);
 }
 
 // advance the KV length after a backbone step

@@ -16,6 +16,7 @@
 // (option "graph", off by default: on the MI355X the replay costs 0.607 ms per token against 0.591 ms for the same launches issued one by one).
 #include "api_common.h"
 #include "common.h"
+#include "llm_kernels.h"
 #include <cstdlib>
 #include <vector>
 
@@ -40,7 +41,8 @@ struct Lm1GemvArgs {
     const float* g; const float* b; float eps; // LN prologue
     const float* W; long long ldw; const float* bias; const float* res; float* y;
     Lm1Dyn* dyn; int layer;                    // layer >= 0: y = dyn->rows[layer] + pos * N   (the cache row of this position)
-    int set_pos;                               // >= 0: block 0 publishes the step's position (first kernel of a step)
+    int set_pos;                               // >= 0: block 0 publishes the step's position (first kernel of a step); -2: the position of the device loop (st->pos)
+    const DecodeState* st;                     // set_pos == -2 (cv_lm1_decode): the loop state the sampler and advance_pos_kernel keep on the device
     int N, K, Kp, act, pro;
 };
 
@@ -57,6 +59,7 @@ static __global__ __launch_bounds__(64 * NW) void lm1_gemv_kernel(Lm1GemvArgs p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
     const int steps = (p.Kp + 63) / 64;
     if (p.set_pos >= 0 && blockIdx.x == 0 && tid == 0) p.dyn->pos = p.set_pos;
+    if (p.set_pos == -2 && blockIdx.x == 0 && tid == 0) p.dyn->pos = p.st->pos;
     const int row = min((int)blockIdx.x * 4 + grp, p.N - 1);      // clamped: the reductions are wave collectives
     const int s0 = wave * steps / NW, s1 = (wave + 1) * steps / NW;
     const float* wr = p.W + (long long)row * p.ldw;
@@ -301,6 +304,9 @@ struct cv_lm1 {
     std::vector<Lm1Layer> L;
     const float *embed_w = nullptr, *embed_b = nullptr, *embed_g = nullptr, *embed_beta = nullptr, *after_g = nullptr, *after_b = nullptr, *dec_w = nullptr, *dec_b = nullptr;
     DevBuf dyn, x0, x1, h, ff, part;
+    // the device-resident decode loop (cv_lm1_decode_begin / cv_lm1_decode): loop state, sampling parameters, emitted tokens, the next input row, logits, injected uniforms
+    DevBuf dstate, dsp, dtokens, xin, dlogits, duniforms;
+    int max_tokens = 0; const float* emb_table = nullptr; DecodeState host_state{}; std::vector<int> host_tokens; int loop_open = 0;
     hipGraphExec_t graph = nullptr; float* graph_logits = nullptr; hipStream_t graph_stream = nullptr;
     hipStream_t own_stream = nullptr;          // a NULL stream argument means this (blocking) stream: it orders itself against the legacy default stream, and it can be captured
     int use_graph = 0, bound = 0;              // measured on the MI355X (profiles/r4_cv1_fused_step_timing.txt): the replayed graph is 3 % SLOWER per token than the same 72 launches issued eagerly
@@ -321,7 +327,7 @@ hipStream_t resolve(cv_lm1* m, void* s) {
 void gemv(cv_lm1* m, int pro, const float* x, const float* g, const float* b, float eps, const float* W, const float* bias, const float* res, float* y, int layer,
           int set_pos, int N, int K, int act, hipStream_t s) {
     CV_CHECK(K % 4 == 0 && K <= LM1_MAX_K && (pro != LM1_PRO_LN || K <= 1024), "cv_lm1: a GEMV input of up to 4096 floats (1024 under the LayerNorm prologue), K % 4 == 0");
-    Lm1GemvArgs a{x, g, b, eps, W, (long long)kp_of(K), bias, res, y, m->dyn.as<Lm1Dyn>(), layer, set_pos, N, K, kp_of(K), act, pro};
+    Lm1GemvArgs a{x, g, b, eps, W, (long long)kp_of(K), bias, res, y, m->dyn.as<Lm1Dyn>(), layer, set_pos, m->dstate.as<DecodeState>(), N, K, kp_of(K), act, pro};
     const int steps = (kp_of(K) + 63) / 64;
     if (steps <= 16) hipLaunchKernelGGL((lm1_gemv_kernel<4, 4>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a);
     else if (pro == LM1_PRO_NONE && N <= 2048) hipLaunchKernelGGL((lm1_gemv_kernel<8, 8>), dim3((unsigned)((N + 3) / 4)), dim3(512), 0, s, a);
@@ -417,6 +423,70 @@ int cv_lm1_step(cv_lm1* m, const float* x_row, int32_t pos, float* logits, void*
         }
         { std::lock_guard<std::recursive_mutex> lk(runtime_lock()); CV_HIP(hipGraphLaunch(m->graph, s)); }
         ++m->graph_replays;
+    });
+}
+
+// ---- the decode loop on the device (round 5; reference: the python loop of TransformerLM.inference, llm/llm.py:196-223, one host round trip per token) ------------------
+// cv_lm1_decode_begin parks the first input row, the position of the row it will write and the request's sampling parameters on the device; every step of
+// cv_lm1_decode is then [input Linear on the parked row, publishing the position] [the 72 launches of cv_lm1_step] [sample_kernel: arg-max or repetition-aware
+// sampling on the logits, eos masked below min_len, the sampled token's speech_embedding row parked as the next input] [advance]: no logits, no token and no embedding
+// row cross the host boundary per step.  Tokens come back once per call (n_steps steps), like cv_llm_decode.
+int cv_lm1_decode_begin(cv_lm1* m, const float* x_row, int32_t pos, const cv_sampling* sp, const float* emb_table, int32_t max_tokens, const float* host_uniforms, int32_t n_uniforms,
+                        void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && x_row && sp && emb_table && aligned16(x_row) && aligned16(emb_table), "cv_lm1_decode_begin: null / unaligned argument");
+        CV_CHECK(m->bound, "cv_lm1_decode_begin: cv_lm1_bind first");
+        CV_CHECK(pos >= 0 && pos < m->cap && max_tokens >= 1, "cv_lm1_decode_begin: position beyond the bound cache");
+        CV_CHECK(m->n_out <= 8192, "cv_lm1_decode_begin: the device sampler holds at most 8192 logits");
+        CV_CHECK(sp->max_len > 0 && sp->eos >= 0 && sp->eos + sp->n_stop <= m->n_out, "cv_lm1_decode_begin: bad sampling parameters");
+        CV_CHECK(sp->mode == 0 || (sp->top_k > 0 && sp->top_k <= 64 && sp->win_size >= 0), "cv_lm1_decode_begin: bad RAS parameters");
+        CV_CHECK(!sp->use_uniforms || (host_uniforms && n_uniforms >= 2), "cv_lm1_decode_begin: use_uniforms needs the uniforms");
+        hipStream_t s = resolve(m, stream);
+        m->dstate.ensure(sizeof(DecodeState)); m->dsp.ensure(sizeof(SampleParams)); m->dtokens.ensure((size_t)max_tokens * 4); m->xin.ensure((size_t)m->d_in * 4);
+        m->dlogits.ensure((size_t)m->n_out * 4);
+        m->max_tokens = max_tokens; m->emb_table = emb_table; m->host_tokens.assign(max_tokens, 0);
+        DecodeState st{}; st.pos = pos; st.stop_token = -1;
+        m->host_state = st;
+        const SampleParams hp{sp->mode, sp->eos, sp->n_stop, sp->min_len, sp->max_len, sp->top_p, sp->top_k, sp->win_size, sp->tau_r, sp->use_uniforms, (unsigned long long)sp->seed};
+        CV_HIP(hipMemcpyAsync(m->dstate.p, &st, sizeof(st), hipMemcpyHostToDevice, s));
+        CV_HIP(hipMemcpyAsync(m->dsp.p, &hp, sizeof(hp), hipMemcpyHostToDevice, s));
+        CV_HIP(hipMemcpyAsync(m->xin.p, x_row, (size_t)m->d_in * 4, hipMemcpyDeviceToDevice, s));
+        if (sp->use_uniforms) {
+            m->duniforms.ensure((size_t)2 * sp->max_len * 4);
+            CV_HIP(hipMemcpyAsync(m->duniforms.p, host_uniforms, (size_t)std::min(n_uniforms, 2 * sp->max_len) * 4, hipMemcpyHostToDevice, s));
+        }
+        CV_HIP(hipStreamSynchronize(s));                        // the host copies above are stack / caller memory
+        m->loop_open = 1;
+    });
+}
+
+int cv_lm1_decode(cv_lm1* m, int32_t n_steps, int32_t* out_tokens, int32_t* n_out, int32_t* finished, void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && out_tokens && n_out && finished && n_steps > 0, "cv_lm1_decode: bad arguments");
+        CV_CHECK(m->loop_open, "cv_lm1_decode: cv_lm1_decode_begin first");
+        CV_CHECK(m->host_state.done || m->host_state.pos + n_steps <= m->cap, "cv_lm1_decode: the bound cache ends before these steps do");
+        hipStream_t s = resolve(m, stream);
+        DecodeState* st = m->dstate.as<DecodeState>();
+        const int before = m->host_state.n_tokens;
+        for (int i = 0; i < n_steps; ++i) {
+            gemv(m, LM1_PRO_NONE, m->xin.as<float>(), nullptr, nullptr, 0.f, m->embed_w, m->embed_b, nullptr, m->h.as<float>(), -1, -2, m->d, m->d_in, ACT_NONE, s);
+            step_body(m, m->dlogits.as<float>(), s);
+            SampleArgs sa{};
+            sa.logits = m->dlogits.as<float>(); sa.V = m->n_out; sa.sp = m->dsp.as<SampleParams>(); sa.uniforms = m->duniforms.as<float>();
+            sa.st = st; sa.tokens = m->dtokens.as<int>(); sa.max_tokens = m->max_tokens;
+            sa.emb_table_f32 = m->emb_table; sa.emb_dim = m->d_in; sa.h_out = m->xin.as<float>();
+            hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, s, sa);
+            hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, s, st);
+            ++m->steps;
+        }
+        CV_HIP(hipMemcpyAsync(&m->host_state, st, sizeof(DecodeState), hipMemcpyDeviceToHost, s));
+        CV_HIP(hipMemcpyAsync(m->host_tokens.data(), m->dtokens.p, (size_t)m->max_tokens * 4, hipMemcpyDeviceToHost, s));
+        CV_HIP(hipStreamSynchronize(s));
+        CV_HIP(hipGetLastError());
+        const int after = std::min(m->host_state.n_tokens, m->max_tokens);
+        *n_out = std::max(0, after - before);
+        for (int k = 0; k < *n_out; ++k) out_tokens[k] = m->host_tokens[before + k];
+        *finished = m->host_state.done ? 1 : 0;
     });
 }
 

@@ -369,6 +369,15 @@ void cv_lm1_destroy(cv_lm1* m);
 /* A request's buffers: rows / tabs are HOST arrays of n_layers device pointers.  Call again whenever a buffer is reallocated (a grown cache, grown tables). */
 int cv_lm1_bind(cv_lm1* m, float* const* rows, const float* const* tabs, int32_t n_tab, int32_t cap, void* stream);
 int cv_lm1_step(cv_lm1* m, const float* x_row, int32_t pos, float* logits, void* stream);
+/* The decode LOOP on the device (round 5; replaces the python loop of TransformerLM.inference, llm/llm.py:196-223, which takes the logits to the host, samples there and
+ * sends the embedding row of the sampled token back once per token).  cv_lm1_decode_begin: the first input row (dev [d_in]), the position it will be written at, the
+ * request's sampling parameters (cv_sampling: greedy or repetition-aware sampling with the device's counter RNG - or `host_uniforms`, two per step, when
+ * sp->use_uniforms: the parity hook), the fp32 speech_embedding table (dev [n_out][d_in]) and the token capacity.  cv_lm1_decode: n_steps steps of [input Linear]
+ * [72 launches of cv_lm1_step] [sampler + embedding row of the sampled token] [advance]; returns the tokens emitted by this call and whether the request ended (a stop
+ * id or max_len).  The logits of a step never leave the device.  cv_lm1_step stays: it is the launch sequence inside, and the host-sampler path (parity hook). */
+int cv_lm1_decode_begin(cv_lm1* m, const float* x_row, int32_t pos, const cv_sampling* sp, const float* emb_table, int32_t max_tokens, const float* host_uniforms,
+                        int32_t n_uniforms, void* stream);
+int cv_lm1_decode(cv_lm1* m, int32_t n_steps, int32_t* out_tokens, int32_t* n_out, int32_t* finished, void* stream);
 int64_t cv_lm1_stat(const cv_lm1* m, const char* name);            /* "steps", "graph_replays", "launches_per_step"; -1 for an unknown name */
 int cv_lm1_set_option(cv_lm1* m, const char* name, int32_t value); /* "graph" (env CV_LM1_GRAPH): 1 replays the step as a hipGraph, 0 (default: measured 3 % faster per token) launches it kernel by kernel */
 

@@ -252,3 +252,36 @@ def test_fused_decode_step_matches_the_launch_per_operator_step(lib):
     slow = list(lm.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw))
     lm.fused_step = True
     assert list(lm.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw)) == slow == g["tokens_greedy"].tolist()
+
+
+def test_device_resident_decode_loop(lib):
+    """Round 5: TransformerLM.inference with the loop on the device (cv_lm1_decode_begin / cv_lm1_decode: sampler + embedding row of the sampled token next to the step's 73
+    launches; tokens come back per chunk, no logits per token).  sampling="greedy": exactly the tokens of the REAL class's golden (and of the host-sampler loop), with a
+    prompt, without one (inference_sft shape), with chunks that do not divide the length and with eos arriving mid-chunk.  sampling="ras" with INJECTED uniform variates:
+    the decisions of the reference's rule (oracle.sampling: nucleus prefix, repetition window, full-distribution fallback) replayed on the host from the same variates."""
+    from oracle import sampling as OS
+    g = gold("cv1k_llm")
+    kw = dict(text=g["text"], text_len=t(7), prompt_text=g["prompt_text"], prompt_text_len=t(4), prompt_speech_token=g["prompt_speech_token"],
+              prompt_speech_token_len=t(9), embedding=g["embedding"])
+    sd = W.make_cv1_llm(CFG)
+    for chunk in (64, 5):
+        lm = CK.TransformerLM(sd, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling="greedy", lib=lib, decode_chunk=chunk)
+        assert lm.fused_step
+        assert list(lm.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw)) == g["tokens_greedy"].tolist()
+        e0 = torch.zeros(1, 0, dtype=torch.int32)
+        sft = dict(kw, prompt_text=e0, prompt_text_len=t(0), prompt_speech_token=e0, prompt_speech_token_len=t(0))
+        assert list(lm.inference(max_token_text_ratio=5, min_token_text_ratio=2, **sft)) == g["tokens_sft"].tolist()
+        assert lm.step.stat("steps") > 0
+    # repetition-aware sampling from fixed uniforms: device loop == host loop driven by the oracle's restatement of the rule with the same variates
+    u = torch.rand(2 * 64, generator=torch.Generator().manual_seed(21))
+    lm = CK.TransformerLM(sd, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling="ras", lib=lib, decode_chunk=7)
+    lm._uniforms = u
+    got = list(lm.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw))
+    step = [0]
+
+    def host_ras(scores, decoded, sampling):
+        i = step[0]; step[0] += 1
+        return OS.ras_sampling(scores.clone(), decoded, sampling, u=(float(u[2 * i]), float(u[2 * i + 1])))
+    ref = CK.TransformerLM(sd, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling=host_ras, lib=lib)
+    want = list(ref.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw))
+    assert got == want and 14 <= len(got) <= 42 and len(set(got)) > 3
