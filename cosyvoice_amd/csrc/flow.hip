@@ -83,6 +83,7 @@ struct cv_flow {
                                        // (profiles/r3_flow_tail_ab.txt): 46.3 vs 38.5 ms per flow.inference at batch 1 - a workgroup pulls its 2 MB of weights through one CU's
                                        // L1 at ~45 B/clk (~32 KB in flight, ~700 cycles), 33-40 us per launch whatever the band count, against 37 us for the four launches it
                                        // replaces.  Off by default; bit-identical to the five-launch form, tested both ways.
+    int band64_rows = 8000;            // "band64_rows": passes of at least this many estimator rows use 64-row bands, smaller large passes 32-row bands (env CV_FLOW_BAND64_ROWS)
     int fused_band = 1;                // bf16 mode, large passes (big_rows): everything between a block's attention and the next block's QKV GEMM in ONE launch per 64-row band
                                        // (flow_band.h) instead of five (out-projection, LayerNorm, FF1, FF2, LayerNorm); bit-identical; option "fused_band", env CV_FLOW_BAND
     int fused = 1;                     // bf16 mode: LN-prologue GEMMs + bf16 activations + bf16 flash attention for the transformer blocks
@@ -229,6 +230,7 @@ static void flow_finalize(cv_flow* m) {
     if (const char* e = getenv("CV_FLOW_BIG_LDS_EPI")) m->big_lds_epi = atoi(e) != 0;
     if (const char* e = getenv("CV_FLOW_ENC_BATCH")) m->enc_batch = atoi(e) != 0;
     if (const char* e = getenv("CV_FLOW_ATTN2_ROWS")) m->attn2_rows = atoi(e);
+    if (const char* e = getenv("CV_FLOW_BAND64_ROWS")) m->band64_rows = atoi(e);
     if (const char* e = getenv("CV_FLOW_BAND")) m->fused_band = e[0] != '0';        // dev knob for A/B runs (also: option "fused_band")
     if (const char* e = getenv("CV_FLOW_TAIL")) m->fused_tail = e[0] != '0';        // dev knob for A/B runs (also: option "fused_tail")
     if (const char* e = getenv("CV_FLOW_TAIL_RING")) m->tail_ring = atoi(e) == 16 ? 16 : 8;
@@ -524,16 +526,21 @@ static void conv_big(const Lin& l, const bf16_t* A, int T, int nz, int pad_left,
     const int tile = tl_big_tile1 ? tl_big_tile1 : 3;
     if (tl_big_glds) conv_big_launch<true>(a, tile, s); else conv_big_launch<false>(a, tile, s);
 }
-// everything between the attention of block `t` and the QKV GEMM of the next block in one launch, 64 rows per workgroup (flow_band.h)
-static void flow_band(const TBlockW& t, bool has_next, const bf16_t* att, int inner, float* x, int C, int M, bf16_t* xn, hipStream_t s) {
+// everything between the attention of block `t` and the QKV GEMM of the next block in one launch, 64 or 32 rows per workgroup (flow_band.h)
+static void flow_band(const TBlockW& t, bool has_next, const bf16_t* att, int inner, float* x, int C, int M, bf16_t* xn, int band64_rows, hipStream_t s) {
     FlowBandArgs a{};
     a.att = att; a.ld_att = inner; a.x = x; a.ldx = C; a.wstream = t.band; a.prm = t.tail_prm; a.eps = 1e-5f; a.M = M; a.xn = xn; a.ld_xn = C;
     CV_CHECK(t.band && t.tail_prm && (!has_next || t.tail_qkv), "flow_band: block was not packed for this call");
-    const dim3 g((unsigned)((M + 63) / 64));
+    // 64-row bands from `band64_rows` rows (one round of ~170 workgroups at 8 utterances of U10 per pass), 32-row bands below: twice the workgroups for the passes of
+    // 3 - 6 utterances and the shared chunk passes of the streaming scheduler, two per CU
+    const bool tall = M >= band64_rows;
+    const dim3 g((unsigned)(tall ? (M + 63) / 64 : (M + 31) / 32));
     if (C == 256 && inner == 512) {
-        if (has_next) hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, true, 8>), g, dim3(512), 0, s, a); else hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, false, 8>), g, dim3(512), 0, s, a);
+        if (tall) { if (has_next) hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, true, 8, 0, 64>), g, dim3(512), 0, s, a); else hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, false, 8, 0, 64>), g, dim3(512), 0, s, a); }
+        else      { if (has_next) hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, true, 8, 0, 32>), g, dim3(512), 0, s, a); else hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, false, 8, 0, 32>), g, dim3(512), 0, s, a); }
     } else if (C == 64 && inner == 64) {
-        if (has_next) hipLaunchKernelGGL((flow_band_kernel<64, 64, 256, true, 4>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((flow_band_kernel<64, 64, 256, false, 4>), g, dim3(256), 0, s, a);
+        if (tall) { if (has_next) hipLaunchKernelGGL((flow_band_kernel<64, 64, 256, true, 4, 0, 64>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((flow_band_kernel<64, 64, 256, false, 4, 0, 64>), g, dim3(256), 0, s, a); }
+        else      { if (has_next) hipLaunchKernelGGL((flow_band_kernel<64, 64, 256, true, 4, 0, 32>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((flow_band_kernel<64, 64, 256, false, 4, 0, 32>), g, dim3(256), 0, s, a); }
     } else throw Error("flow_band: no instantiation for these dimensions");
 }
 
@@ -636,7 +643,7 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
                     if (ti == 0) ln_bf16(t.norm1, 1e-5f, x, (int)R, C, xn, s);         // later blocks: the previous block's band launch left LayerNorm(norm1) of its output in xn
                     gemm_big_bf16(t.qkv, xn, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
                     attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, klen, big_attn);
-                    flow_band(t, ti + 1 < st.tf.size(), ab, inner, x, C, (int)R, xn, s);
+                    flow_band(t, ti + 1 < st.tf.size(), ab, inner, x, C, (int)R, xn, m->band64_rows, s);
                     continue;
                 }
                 if (big) {                    // flow_big.h: 7 launches of large tiles, bit-identical to the 5 below
@@ -923,6 +930,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "graph_max_rows") { CV_CHECK(value >= 0, "graph_max_rows must be >= 0"); m->graph_max_rows = value; drop_graphs(m); }
         else if (std::string(name) == "graph_cap") { CV_CHECK(value >= 1 && value <= 256, "graph_cap must be 1 .. 256"); drop_graphs(m); m->graph_cap = (size_t)value; }
         else if (std::string(name) == "fused_tail") { m->fused_tail = value != 0; drop_graphs(m); }
+        else if (std::string(name) == "band64_rows") { CV_CHECK(value >= 0, "band64_rows must be >= 0"); m->band64_rows = value; drop_graphs(m); }
         else if (std::string(name) == "fused_band") { m->fused_band = value != 0; drop_graphs(m); }      // bf16 mode, large passes: one 64-row band launch between attention and the next QKV GEMM (flow_band.h) on / off
         else if (std::string(name) == "flow_ntile") { CV_CHECK(value >= 0 && value <= 2, "flow_ntile must be 0, 1 or 2"); m->flow_ntile = value; drop_graphs(m); }
         else if (std::string(name) == "tail_ring") { m->tail_ring = value == 16 ? 16 : 8; drop_graphs(m); }      // bf16 mode: one row-band launch after each attention (flow_tail.h) on / off
@@ -1028,7 +1036,7 @@ static void flow_profile_block(cv_flow* m, int nz, int T, int reps, float* us3, 
             for (int i = 0; i < reps; ++i) {
                 if (which == 0) gemm_big_bf16(t.qkv, xn, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
                 else if (which == 1) attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, 0, s, nullptr, m->attn2_rows > 0 && R >= m->attn2_rows);
-                else flow_band(t, true, ab, inner, x, C, (int)R, xn, s);
+                else flow_band(t, true, ab, inner, x, C, (int)R, xn, m->band64_rows, s);
             }
             CV_HIP(hipEventRecord(e1, s)); CV_HIP(hipEventSynchronize(e1));
             float ms = 0.f; CV_HIP(hipEventElapsedTime(&ms, e0, e1));

@@ -33,8 +33,8 @@ struct FlowBandArgs {
 };
 
 // one pass: PT 16-column tiles x KS k-steps of 32 against the 4 row tiles of the band.  A: bf16 pairs in LDS, row pitch `pitch` dwords, first dword k0.
-template <int PT, int KS, int MODE = 0>
-__device__ __forceinline__ void band_mma(const u32x4_t (&w)[16], const unsigned* A, int pitch, int k0, int lq, int lg, v4f (&acc)[4][PT]) {
+template <int PT, int KS, int MODE = 0, int RT = 4>
+__device__ __forceinline__ void band_mma(const u32x4_t (&w)[16], const unsigned* A, int pitch, int k0, int lq, int lg, v4f (&acc)[RT][PT]) {
     if constexpr (MODE == 2) {                // probe: consume the fragments without the matrix pipe or LDS
 #pragma unroll
         for (int i = 0; i < PT * KS; ++i) acc[0][0][0] += __uint_as_float(w[i][0] ^ w[i][1] ^ w[i][2] ^ w[i][3]);
@@ -42,16 +42,16 @@ __device__ __forceinline__ void band_mma(const u32x4_t (&w)[16], const unsigned*
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        uint4 af[4];
+        uint4 af[RT];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
             if constexpr (MODE == 3) af[rt] = make_uint4(0x3f803f80u + rt + ks, 0x3f003f00u + lq, 0x3e803e80u + lg, 0x3f803f80u);      // probe: no fragment reads
             else af[rt] = *reinterpret_cast<const uint4*>(&A[(16 * rt + lq) * pitch + k0 + ks * 16 + lg * 4]);
         }
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
                 acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, w[ks * PT + t]), __builtin_bit_cast(v8bf, af[rt]), acc[rt][t], 0, 0, 0);
         }
     }
@@ -65,13 +65,14 @@ __device__ __forceinline__ void band_wload(u32x4_t (&dst)[16], const u32x4_t* ws
 }
 
 // LayerNorm of the band's rows parked in X (fp32, pitch PX floats) -> bf16 operand tile (pitch `pa` dwords): the expressions of ln_bf16_kernel / tail_layernorm
-template <int C, int PX, int NT>
+template <int C, int PX, int NT, int BM = 64>
 __device__ __forceinline__ void band_layernorm(const float* X, unsigned* A, int pa, const float* gamma, const float* beta, float eps, int tid) {
     constexpr int NJ = C / 64;
     const int sub = tid & 15;
 #pragma unroll
-    for (int r0 = 0; r0 < 64; r0 += NT / 16) {
+    for (int r0 = 0; r0 < BM; r0 += NT / 16) {
         const int row = r0 + (tid >> 4);
+        if (NT / 16 > BM && row >= BM) break;                 // (more 16-lane groups than rows: the 32-row band on 8 waves normalises its rows in one pass with half the groups)
         float4 v[NJ];
         float s = 0.f;
 #pragma unroll
@@ -105,10 +106,13 @@ struct FlowBandShape {
 
 // MODE (dev tool only, tools/ubench/band_probe.hip): 0 = the kernel; 1 = the weight stream is requested once (prologue) and never again; 2 = no MFMA and no fragment
 // reads (the stream alone, consumed by a register checksum); 3 = MFMAs on register operands (no LDS fragment reads)
-template <int C, int INNER, int FF, bool HAS_NEXT, int NW, int MODE = 0>
+// BM = rows per band: 64 (4 MFMA row tiles per weight fragment; large passes) or 32 (2 row tiles: twice the workgroups for passes whose 64-row bands would leave most of
+// the chip idle - 4 utterances per pass, the shared chunk passes of the streaming scheduler - at half the LDS, two workgroups per CU).  Same arithmetic per element.
+template <int C, int INNER, int FF, bool HAS_NEXT, int NW, int MODE = 0, int BM = 64>
 __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
     using S = FlowBandShape<C, INNER, FF, NW>;
-    constexpr int BM = 64, NT = NW * 64, TA = S::TA;
+    constexpr int NT = NW * 64, TA = S::TA, RT = BM / 16;
+    static_assert(BM == 64 || BM == 32, "flow_band: 64- or 32-row bands");
     constexpr int PA0 = INNER / 2 + LDS_PAD, PX = C + LDS_PAD, PA1 = C / 2 + LDS_PAD;       // LDS row pitches (dwords / floats): 8 mod 16 (common.h, LDS_PAD)
     constexpr int OPS = (BM * PA0 > 2 * BM * PA1) ? BM * PA0 : 2 * BM * PA1;                // the attention tile overlays A1 | A2
     __shared__ __attribute__((aligned(16))) float X1[BM * PX];
@@ -167,27 +171,27 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
     // ---- A: out-projection + bias + residual -> X1 (fp32).  Wave w owns the 16-column tiles w + NW t.
     constexpr int FCD = TA * S::KC;                                         // fragments of an FF1 / FF2 chunk pass
     {
-        v4f acc[4][TA];
+        v4f acc[RT][TA];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int t = 0; t < TA; ++t) acc[rt][t] = (v4f){0.f, 0.f, 0.f, 0.f};
         if constexpr (S::NPA == 1) {
             band_wload<FCD, MODE>(wb1, ws, TA * S::KA);                           // FF1 chunk 0 in flight under the out-projection
-            band_mma<TA, S::KA, MODE>(wb0, A0, PA0, 0, lq, lg, acc);
+            band_mma<TA, S::KA, MODE, RT>(wb0, A0, PA0, 0, lq, lg, acc);
         } else {
             static_assert(S::NPA <= 2, "flow_band: the out-projection runs in at most two passes (INNER <= 512)");
             band_wload<TA * 8, MODE>(wb1, ws, TA * 8);
-            band_mma<TA, 8, MODE>(wb0, A0, PA0, 0, lq, lg, acc);
+            band_mma<TA, 8, MODE, RT>(wb0, A0, PA0, 0, lq, lg, acc);
             band_wload<FCD, MODE>(wb0, ws, TA * S::KA);                           // FF1 chunk 0
-            band_mma<TA, 8, MODE>(wb1, A0, PA0, 8 * 16, lq, lg, acc);
+            band_mma<TA, 8, MODE, RT>(wb1, A0, PA0, 8 * 16, lq, lg, acc);
         }
 #pragma unroll
         for (int t = 0; t < TA; ++t) {
             const int n = 16 * (wave + NW * t) + 4 * lg;
             const float4 b = *reinterpret_cast<const float4*>(&prm[O_BOUT + n]);
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 float* xr = &X1[(16 * rt + lq) * PX + n];
                 const float4 r = *reinterpret_cast<const float4*>(xr);
                 *reinterpret_cast<float4*>(xr) = make_float4(acc[rt][t][0] + b.x + r.x, acc[rt][t][1] + b.y + r.y, acc[rt][t][2] + b.z + r.z, acc[rt][t][3] + b.w + r.w);   // the same lane read this element
@@ -197,34 +201,34 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
     __syncthreads();                                                        // X1 complete, A0 dead
     stamp();                                                                // 2: out-projection done
     // ---- B: LayerNorm(norm3) -> A1 (bf16)
-    band_layernorm<C, PX, NT>(X1, A1, PA1, &prm[O_G3], &prm[O_BE3], p.eps, tid);
+    band_layernorm<C, PX, NT, BM>(X1, A1, PA1, &prm[O_G3], &prm[O_BE3], p.eps, tid);
     __syncthreads();
     stamp();                                                                // 3: LayerNorm done
     // ---- C / D: FF1 chunk j (+ bias + GELU -> A2) and FF2 over that chunk's hidden columns, accumulators across the chunks.  Stream order: FF1_0 FF2_0 FF1_1 FF2_1 ..
     // With NPA == 1 chunk 0's FF1 fragments sit in wb1, otherwise in wb0: the two buffers alternate from there.
-    v4f acc2[4][TA];
+    v4f acc2[RT][TA];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int t = 0; t < TA; ++t) acc2[rt][t] = (v4f){0.f, 0.f, 0.f, 0.f};
     constexpr int F0 = TA * S::KA;                                          // first fragment of the FF stream
     constexpr bool FF1_IN_WB1 = S::NPA == 1;
 #pragma unroll 1
     for (int j = 0; j < S::NCH; ++j) {                                      // a real loop: every chunk runs the same code on the same two buffers (and the epilogue's GELU stays one copy)
-        v4f acc1[4][TA];
+        v4f acc1[RT][TA];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int t = 0; t < TA; ++t) acc1[rt][t] = (v4f){0.f, 0.f, 0.f, 0.f};
         // FF1 chunk j is in buffer X (loaded one pass ago); request FF2 chunk j into the other buffer, multiply
-        if constexpr (FF1_IN_WB1) { band_wload<FCD, MODE>(wb0, ws, F0 + (2 * j + 1) * FCD); band_mma<TA, S::KC, MODE>(wb1, A1, PA1, 0, lq, lg, acc1); }
-        else                      { band_wload<FCD, MODE>(wb1, ws, F0 + (2 * j + 1) * FCD); band_mma<TA, S::KC, MODE>(wb0, A1, PA1, 0, lq, lg, acc1); }
+        if constexpr (FF1_IN_WB1) { band_wload<FCD, MODE>(wb0, ws, F0 + (2 * j + 1) * FCD); band_mma<TA, S::KC, MODE, RT>(wb1, A1, PA1, 0, lq, lg, acc1); }
+        else                      { band_wload<FCD, MODE>(wb1, ws, F0 + (2 * j + 1) * FCD); band_mma<TA, S::KC, MODE, RT>(wb0, A1, PA1, 0, lq, lg, acc1); }
 #pragma unroll
         for (int t = 0; t < TA; ++t) {
             const int n = 16 * (wave + NW * t) + 4 * lg;                    // column inside the chunk
             const float4 b = *reinterpret_cast<const float4*>(&prm[O_BFF1 + j * C + n]);
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 const float4 y = gelu_erf4(make_float4(acc1[rt][t][0] + b.x, acc1[rt][t][1] + b.y, acc1[rt][t][2] + b.z, acc1[rt][t][3] + b.w));      // = apply_act4(ACT_GELU_ERF, ..), inlined
                 *reinterpret_cast<uint2*>(&A2[(16 * rt + lq) * PA1 + n / 2]) = make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
             }
@@ -232,8 +236,8 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
         __syncthreads();                                                    // the chunk's hidden tile is complete
         // FF2 chunk j; request FF1 chunk j + 1 (unconditional: after the last chunk the request repeats that chunk's FF1 fragments and is never used)
         const int nxt = F0 + 2 * min(j + 1, S::NCH - 1) * FCD;
-        if constexpr (FF1_IN_WB1) { band_wload<FCD, MODE>(wb1, ws, nxt); band_mma<TA, S::KC, MODE>(wb0, A2, PA1, 0, lq, lg, acc2); }
-        else                      { band_wload<FCD, MODE>(wb0, ws, nxt); band_mma<TA, S::KC, MODE>(wb1, A2, PA1, 0, lq, lg, acc2); }
+        if constexpr (FF1_IN_WB1) { band_wload<FCD, MODE>(wb1, ws, nxt); band_mma<TA, S::KC, MODE, RT>(wb0, A2, PA1, 0, lq, lg, acc2); }
+        else                      { band_wload<FCD, MODE>(wb0, ws, nxt); band_mma<TA, S::KC, MODE, RT>(wb1, A2, PA1, 0, lq, lg, acc2); }
         __syncthreads();                                                    // before the next chunk overwrites A2 (and before the epilogue below touches X1's neighbours)
         stamp();                                                            // 4 .. 3 + NCH: chunk j done
     }
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
         const int n = 16 * (wave + NW * t) + 4 * lg;
         const float4 b = *reinterpret_cast<const float4*>(&prm[O_BFF2 + n]);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
             float* xr = &X1[(16 * rt + lq) * PX + n];
             const float4 r = *reinterpret_cast<const float4*>(xr);
             *reinterpret_cast<float4*>(xr) = make_float4(acc2[rt][t][0] + b.x + r.x, acc2[rt][t][1] + b.y + r.y, acc2[rt][t][2] + b.z + r.z, acc2[rt][t][3] + b.w + r.w);
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
     __syncthreads();
     if constexpr (HAS_NEXT) {
         // ---- E: LayerNorm(norm1 of the next block) -> A1, written out as the bf16 operand rows of its QKV GEMM
-        band_layernorm<C, PX, NT>(X1, A1, PA1, &prm[O_G1N], &prm[O_BE1N], p.eps, tid);
+        band_layernorm<C, PX, NT, BM>(X1, A1, PA1, &prm[O_G1N], &prm[O_BE1N], p.eps, tid);
         __syncthreads();
         constexpr int NP = BM * C / 8;
 #pragma unroll

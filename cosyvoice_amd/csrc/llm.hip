@@ -62,7 +62,8 @@ struct cv_llm {
         int nb = 0;
         DevBuf kcache, vcache, state, tokens, sparams, uniforms, h, qkv, act, logits, attn, dpart, apart;   // attn: merged attention [nb][heads*64]; dpart: split-K partials of down
         std::vector<DecodeState> host_state; std::vector<int> host_tokens; std::vector<SampleParams> host_sp;
-        hipGraphExec_t graph = nullptr; hipStream_t graph_stream = nullptr; int graph_nb = 0;
+        hipGraphExec_t graph = nullptr; hipStream_t graph_stream = nullptr; int graph_nb = 0;      // graph: the step with the attention form of `attn_mode` ...
+        hipGraphExec_t graph_alt = nullptr; int attn_mode = 1;                                      // ... graph_alt: with the other form (both kept: a batch crosses the rule's threshold as its contexts grow)
     } bt;
     // Round 3: fragment-ordered copies of the matrices for the batched decode (skinny_pk_kernel, llm_batch_kernels.h), made on the device the first time
     // the batch path is used: [row tile][k tile][lane][8 bf16], so that one wave load is 1 KB contiguous.  Keyed by the row-major tensor's address.
@@ -77,6 +78,7 @@ struct cv_llm {
     ~cv_llm() {
         if (graph) (void)hipGraphExecDestroy(graph);
         if (bt.graph) (void)hipGraphExecDestroy(bt.graph);
+        if (bt.graph_alt) (void)hipGraphExecDestroy(bt.graph_alt);
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (host_tokens) (void)hipHostFree(host_tokens);
         if (host_state) (void)hipHostFree(host_state);
@@ -498,6 +500,7 @@ static void batch_begin(cv_llm* m, int nb, hipStream_t s) {
     CV_HIP(hipMemcpyAsync(b.state.p, b.host_state.data(), (size_t)nb * sizeof(DecodeState), hipMemcpyHostToDevice, s));
     CV_HIP(hipStreamSynchronize(s));
     if (b.graph && b.graph_nb != nb) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
+    if (b.graph_alt && b.graph_nb != nb) { (void)hipGraphExecDestroy(b.graph_alt); b.graph_alt = nullptr; }
     ensure_packed(m, s);
 }
 
@@ -634,13 +637,12 @@ static int down_ksplit(int inter) {
 // softmax's exp / DPP work per loaded key, not the L2 traffic, is what the launch is made of once the heads of a group share an XCD (the remap in the kernel above).
 // Round 5 (default): attn_decode_batch_mfma_kernel - workgroup = (sequence, kv head, key slice), the group's heads as the columns of the fp32 MFMA, K / V read once
 // per pair; nslice > 1 adds attn_merge_batch_kernel.  Slices: enough workgroups for one round over the 256 CUs (4-wave workgroups: 4 slices at 32 sequences x 2 kv
-// heads, 8 at 16).  A/B knobs, read when a step is enqueued / captured: CV_ATTN_BATCH=0 (the per-head VALU kernel of rounds 2-4), CV_ATTN_BATCH_SLICES=1..8,
-// CV_ATTN_BATCH_WAVES=4|8.
-static void launch_attn_batch(AttnDecodeBatchArgs ad, int heads, int nb, hipStream_t s, float* part) {
+// heads, 8 at 16).  Which form runs is decided per decode call (batch_decode: slot count and longest context); A/B knobs read when a step is captured:
+// CV_ATTN_BATCH_SLICES=1..8, CV_ATTN_BATCH_WAVES=4|8.
+static void launch_attn_batch(AttnDecodeBatchArgs ad, int heads, int nb, hipStream_t s, float* part, int mode) {
     ad.nb = nb;
     const int gsz = heads / ad.kv_heads;
-    const bool mfma = [] { const char* e = getenv("CV_ATTN_BATCH"); return !(e && e[0] == '0'); }();
-    if (mfma && part && gsz >= 1 && gsz <= 16 && heads % ad.kv_heads == 0) {
+    if (mode == 1 && part && gsz >= 1 && gsz <= 16 && heads % ad.kv_heads == 0) {
         const int pairs = nb * ad.kv_heads;
         const int nw = [] { const char* e = getenv("CV_ATTN_BATCH_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
         int S = [] { const char* e = getenv("CV_ATTN_BATCH_SLICES"); return e ? atoi(e) : 0; }();
@@ -689,7 +691,7 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
             skinny_f8(SkinnyF8Args{F.qkv.w, F.qkv.s, L.bqkv, h, H, qkv, Q, (int)Q, c.hidden, L.ln1, c.rms_eps, nullptr, 0, 0, nb, 1}, 1, s);
             AttnDecodeBatchArgs ad{qkv, Q, b.kcache.as<float>() + m->layer_cache() * l, b.vcache.as<float>() + m->layer_cache() * l, (long long)m->slot_cache(),
                                    m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st, att, A};
-            launch_attn_batch(ad, c.heads, nb, s, b.apart.as<float>());
+            launch_attn_batch(ad, c.heads, nb, s, b.apart.as<float>(), b.attn_mode);
             skinny_f8(SkinnyF8Args{F.o.w, F.o.s, nullptr, att, A, h, H, c.hidden, (int)A, nullptr, 0.f, h, H, 0, nb, 1}, 1, s);
             skinny_f8(SkinnyF8Args{F.gu.w, F.gu.s, nullptr, h, H, act, I, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 0, 1, nb, 1}, 2, s);
             if (k8 > 1) {
@@ -727,7 +729,7 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
         skinny(SkinnyArgs{L.wqkv, L.bqkv, h, H, qkv, Q, (int)Q, c.hidden, L.ln1, c.rms_eps, nullptr, 0, 0, nb, 1}, 1, s, m->pk(L.wqkv));
         AttnDecodeBatchArgs ad{qkv, Q, b.kcache.as<float>() + m->layer_cache() * l, b.vcache.as<float>() + m->layer_cache() * l, (long long)m->slot_cache(),
                                m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st, att, A};
-        launch_attn_batch(ad, c.heads, nb, s, b.apart.as<float>());
+        launch_attn_batch(ad, c.heads, nb, s, b.apart.as<float>(), b.attn_mode);
         skinny(SkinnyArgs{L.wo, nullptr, att, A, h, H, c.hidden, (int)A, nullptr, 0.f, h, H, 0, nb, 1}, 1, s, m->pk(L.wo));
         // packed: four row tiles per workgroup (152 workgroups) measured 7.3 us against 8.0 for two and 8.7 for one (profiles/r3_skinny_probe.txt)
         skinny(SkinnyArgs{L.wgu, nullptr, h, H, act, I, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 0, 1, nb, 1}, m->pk(L.wgu) ? 4 : wide_rt, s, m->pk(L.wgu));
@@ -755,18 +757,34 @@ static void batch_decode(cv_llm* m, int n_steps, int32_t* out_tokens, int32_t* n
         const int left = std::max(0, std::min(n_steps, b.host_sp[i].max_len - b.host_state[i].step));
         CV_CHECK(b.host_state[i].done || b.host_state[i].pos + left < c.max_len, "cv_llm_batch_decode: KV cache (max_len) exhausted in a slot");
     }
+    // Which decode attention (measured on the MI355X, profiles/r5_batch_decode_ab.txt section 5): the MFMA form (K / V once per (sequence, kv head), + a merge launch) wins
+    // with many slots or long contexts, the per-head VALU form (no second launch) with few slots at short contexts - 16 slots: 885 vs 928 us per step at contexts
+    // 130 - 380, 1089 vs 1061 at 443 - 693; 8 slots: 826 vs 871 and 963 vs 954; 32 slots: 1359 vs 1286 already at 130 - 380.  Decided per call from the slot count and
+    // the longest live context (known on the host from the last hand-back); both forms yield the oracle's tokens.  CV_ATTN_BATCH=0 / 1 pins one form (A/B knob).
+    int mode;
+    {
+        int longest = 0;
+        for (int i = 0; i < nb; ++i) if (!b.host_state[i].done) longest = std::max(longest, b.host_state[i].pos);
+        mode = (nb >= 24 || (nb >= 12 && longest >= 416) || longest >= 640) ? 1 : 0;
+        if (const char* e = getenv("CV_ATTN_BATCH")) mode = e[0] == '0' ? 0 : 1;      // (read per decode call - once per chunk of steps, not per step)
+    }
     {
         std::lock_guard<std::recursive_mutex> lk(runtime_lock());
         if (m->use_graph) {
-            if (!b.graph || b.graph_stream != s || b.graph_nb != nb) {
+            if (b.graph_stream != s || b.graph_nb != nb) {
                 if (b.graph) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
+                if (b.graph_alt) { (void)hipGraphExecDestroy(b.graph_alt); b.graph_alt = nullptr; }
+                b.graph_stream = s; b.graph_nb = nb;
+            }
+            if (mode != b.attn_mode) { std::swap(b.graph, b.graph_alt); b.attn_mode = mode; }      // the other form's graph, if it was captured before, is kept
+            if (!b.graph) {
                 hipGraph_t g = capture_graph(s, [&] { batch_enqueue_step(m, s); });
                 CV_HIP(hipGraphInstantiate(&b.graph, g, nullptr, nullptr, 0));
                 CV_HIP(hipGraphDestroy(g));
-                b.graph_stream = s; b.graph_nb = nb;
             }
             for (int i = 0; i < n_steps; ++i) CV_HIP(hipGraphLaunch(b.graph, s));
         } else {
+            b.attn_mode = mode;
             for (int i = 0; i < n_steps; ++i) batch_enqueue_step(m, s);
         }
     }
@@ -824,11 +842,11 @@ int cv_llm_set_option(cv_llm* m, const char* name, int32_t value) {
             m->attn_splits = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
         }
         else if (std::string(name) == "batch_packed") {      // batched decode on the fragment-ordered weight copies (skinny_pk_kernel) or on the row-major tensors (round 2)
-            m->batch_packed = value != 0; if (m->bt.graph) { (void)hipGraphExecDestroy(m->bt.graph); m->bt.graph = nullptr; }
+            m->batch_packed = value != 0; if (m->bt.graph) { (void)hipGraphExecDestroy(m->bt.graph); m->bt.graph = nullptr; } if (m->bt.graph_alt) { (void)hipGraphExecDestroy(m->bt.graph_alt); m->bt.graph_alt = nullptr; }
         }
         else if (std::string(name) == "batch_fp8") {         // batched decode on the fp8 copies of the weights (needs the .f8 / .f8s tensors)
             CV_CHECK(value == 0 || m->have_fp8, "batch_fp8: the fp8 tensors were not registered");
-            m->batch_fp8 = value != 0; if (m->bt.graph) { (void)hipGraphExecDestroy(m->bt.graph); m->bt.graph = nullptr; }
+            m->batch_fp8 = value != 0; if (m->bt.graph) { (void)hipGraphExecDestroy(m->bt.graph); m->bt.graph = nullptr; } if (m->bt.graph_alt) { (void)hipGraphExecDestroy(m->bt.graph_alt); m->bt.graph_alt = nullptr; }
         }
         else throw Error(std::string("unknown option ") + name);
     });

@@ -91,13 +91,15 @@ def test_band_kernel_is_bit_identical(lib, est_blocks):
             spk = torch.randn(2, 80, generator=g); t = torch.tensor([0.3, 0.3]); mask = torch.ones(2, 1, T)
             for streaming in (False, True):
                 outs = []
-                for big, band in ((0, 0), (1, 0), (1, 1)):
+                for big, band, b64 in ((0, 0, 1), (1, 0, 1), (1, 1, 1), (1, 1, 1 << 30)):        # band64_rows = 1: 64-row bands; 2^30: 32-row bands (two row tiles per weight fragment)
                     lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(big)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(band))
+                    lib.cv_flow_set_option(flow._h, b"band64_rows", C.c_int32(b64))
                     outs.append(flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu().clone())
                 assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
-                assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (T, streaming, (outs[0] - outs[2]).abs().max().item())
+                for k in range(1, len(outs)):
+                    assert torch.equal(outs[0], outs[k]), (T, streaming, k, (outs[0] - outs[k]).abs().max().item())
     finally:
-        lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(5000)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(1))
+        lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(5000)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(1)); lib.cv_flow_set_option(flow._h, b"band64_rows", C.c_int32(8000))
 
 
 def test_band_kernel_at_the_real_width(lib):
@@ -115,10 +117,11 @@ def test_band_kernel_at_the_real_width(lib):
     spk = torch.randn(2, 80, generator=g); t = torch.tensor([0.6, 0.6]); mask = torch.ones(2, 1, T)
     try:
         outs = []
-        for big, band in ((0, 0), (1, 0), (1, 1)):
-            lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(big)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(band))
+        for big, band, b64 in ((0, 0, 1), (1, 0, 1), (1, 1, 1), (1, 1, 1 << 30)):
+            lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(big)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(band)); lib.cv_flow_set_option(flow._h, b"band64_rows", C.c_int32(b64))
             outs.append(flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=False).cpu().clone())
         assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (outs[0] - outs[2]).abs().max().item()
+        for k in range(1, len(outs)):
+            assert torch.equal(outs[0], outs[k]), (k, (outs[0] - outs[k]).abs().max().item())
     finally:
-        lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(5000)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(1))
+        lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(5000)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(1)); lib.cv_flow_set_option(flow._h, b"band64_rows", C.c_int32(8000))

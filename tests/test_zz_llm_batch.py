@@ -115,8 +115,8 @@ def test_grouped_query_attention_variants(lib, heads, kv_heads, monkeypatch):
     sd = W.make_llm(cfg)
     reqs = [_req(cfg, 500 + i, 3, 2, (188, 7, 40, 195)[i]) for i in range(4)]          # prompt + text + generated tokens: ~200 / ~20 / ~50 / ~210 keys
     want = [OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=4, min_token_text_ratio=2) for r in reqs]
-    knobs = [{}, {"CV_ATTN_BATCH_SLICES": "1"}, {"CV_ATTN_BATCH_SLICES": "3", "CV_ATTN_BATCH_WAVES": "8"},
-             {"CV_ATTN_BATCH": "0"}, {"CV_ATTN_BATCH": "0", "CV_ATTN_BATCH_GQA": "1"}]
+    knobs = [{"CV_ATTN_BATCH": "1"}, {"CV_ATTN_BATCH": "1", "CV_ATTN_BATCH_SLICES": "1"}, {"CV_ATTN_BATCH": "1", "CV_ATTN_BATCH_SLICES": "3", "CV_ATTN_BATCH_WAVES": "8"},
+             {"CV_ATTN_BATCH": "0"}, {"CV_ATTN_BATCH": "0", "CV_ATTN_BATCH_GQA": "1"}, {}]      # {}: the launch rule (few slots, short contexts: the per-head form)
     if heads == 6:
         knobs = knobs[:2] + knobs[3:4]
     for env in knobs:
@@ -126,6 +126,20 @@ def test_grouped_query_attention_variants(lib, heads, kv_heads, monkeypatch):
             monkeypatch.setenv(k, v)                                                # read when the step of a handle is captured
         lm = Qwen2LM(sd, cfg, lib=lib, max_len=256, sampling="greedy", decode_chunk=5)
         assert lm.inference_batch(reqs, max_token_text_ratio=4, min_token_text_ratio=2) == want, env
+
+
+def test_attention_form_changes_with_the_context(lib):
+    """The decode attention of a lock-step batch is chosen per decode call from the slot count and the longest live context (llm.hip batch_decode: per-head VALU form for
+    few slots at short contexts, MFMA form + merge launch otherwise; one captured graph each, both kept).  12 slots whose contexts grow across the rule's threshold (416)
+    during the request: the step switches form between two decode chunks - tokens stay the oracle's, and a second batch on the handle re-uses both graphs."""
+    cfg = W.tiny()[0]
+    sd = W.make_llm(cfg)
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=512, sampling="greedy", decode_chunk=6)
+    reqs = [_req(cfg, 700 + i, 4, 2, 395 + (i % 3)) for i in range(12)]               # contexts ~404 .. ~420 and growing by up to 16 tokens
+    want = [OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=4, min_token_text_ratio=3) for r in reqs]
+    for _ in range(2):
+        assert lm.inference_batch(reqs, max_token_text_ratio=4, min_token_text_ratio=3) == want
+    assert max(len(w) for w in want) >= 12
 
 
 def test_continuous_batching(lib):

@@ -26,9 +26,9 @@ for plan in "$@"; do
     smoke)     run smoke 120 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench)     run bench_driver 1200 python bench.py --gpus 1 --steps 20 --warmup 5
                python tools/bench_summary.py $O/bench_driver.log $O/bench_driver.json ;;
-    extra:*)   IFS=: read -r _ name envs <<< "$plan"; tagname=$(echo "${name}_${envs:-default}" | tr -c 'A-Za-z0-9_\n' '_')
+    extra:*)   IFS=: read -r _ name envs <<< "$plan"; envs=${envs#:}; tagname=$(echo "${name}_${envs:-default}" | tr -c 'A-Za-z0-9_\n' '_')
                ( for kv in $(echo "${envs:-}" | tr ',' ' '); do export "$kv"; done; run extra_$tagname 900 python bench.py --only-extra $name --steps $STEPS ) ;;
-    prof:*)    IFS=: read -r _ name envs <<< "$plan"; ( for kv in $(echo "${envs:-}" | tr ',' ' '); do export "$kv"; done; prof $name python $R/bench.py --only-extra $name --steps 2 ) ;;
+    prof:*)    IFS=: read -r _ name envs <<< "$plan"; envs=${envs#:}; ( for kv in $(echo "${envs:-}" | tr ',' ' '); do export "$kv"; done; prof $name python $R/bench.py --only-extra $name --steps 2 ) ;;
     profbench) prof bench python $R/bench.py --gpus 1 --steps 5 --warmup 2 --no-extras --no-cpu-baseline ;;
     pmcgemv)   ( cd /tmp && export TMPDIR=/tmp && timeout -k 5 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_llm -- python $R/tools/profile_small.py llm > $R/$O/pmc_llm.log 2>&1; echo "== pmc llm rc=$?" )
                python tools/pmc_summary.py $O/pmc_gemv_fetch.json $O/pmc_llm -- gemv | head -12; rm -rf $O/pmc_llm ;;
@@ -36,8 +36,8 @@ for plan in "$@"; do
                ( cd /tmp && export TMPDIR=/tmp && timeout -k 5 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_fb8_fetch -- python $R/tools/profile_flow_batch.py 8 > $R/$O/pmc_fb8_fetch.log 2>&1; echo "== pmc flow batch 8 fetch rc=$?" )
                python tools/pmc_summary.py $O/pmc_flow_batch8.json $O/pmc_fb8_sq $O/pmc_fb8_fetch -- flow_gemm flow_band attn_flow ln_bf16 gemm_conv norm_rows | head -40; rm -rf $O/pmc_fb8_sq $O/pmc_fb8_fetch ;;
     bin:*)     IFS=: read -r _ exe <<< "$plan"; run bin_$(basename $exe) 600 $exe; cat $O/bin_$(basename $exe).log ;;
-    profpy:*)  IFS=: read -r _ script pargs envs <<< "$plan"; ( for kv in $(echo "${envs:-}" | tr ',' ' '); do export "$kv"; done; prof $(basename $script .py)_$(echo "${pargs:-}_${envs:-}" | tr -c 'A-Za-z0-9_\n' '_') python $R/tools/$script ${pargs:-} ) ;;
-    py:*)      IFS=: read -r _ script pargs envs <<< "$plan"; ( for kv in $(echo "${envs:-}" | tr ',' ' '); do export "$kv"; done; run py_$(basename $script .py)_$(echo "${pargs:-}_${envs:-}" | tr -c 'A-Za-z0-9_\n' '_') 900 python tools/$script ${pargs:-} ) ;;
+    profpy:*)  IFS=: read -r _ script pargs envs <<< "$plan"; envs=${envs#:}; ( for kv in $(echo "${envs:-}" | tr ',' ' '); do export "$kv"; done; prof $(basename $script .py)_$(echo "${pargs:-}_${envs:-}" | tr -c 'A-Za-z0-9_\n' '_') python $R/tools/$script ${pargs:-} ) ;;
+    py:*)      IFS=: read -r _ script pargs envs <<< "$plan"; envs=${envs#:}; ( for kv in $(echo "${envs:-}" | tr ',' ' '); do export "$kv"; done; run py_$(basename $script .py)_$(echo "${pargs:-}_${envs:-}" | tr -c 'A-Za-z0-9_\n' '_') 900 python tools/$script ${pargs:-} ) ;;
     *)         echo "unknown plan $plan" ;;
   esac
 done
