@@ -68,7 +68,7 @@ struct cv_flow {
     // "big_tile0" / "big_tile1": tile of the bf16-out / fp32-residual GEMMs, 0 = by measurement (64 x 64), 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x64 (the N = 256 residual GEMMs and convolutions are only 676 workgroups at M = 10 784 as 64 x 64 tiles).
     // `attn2_rows`: attention with 32 queries per wave (attn_flow_kernel<.., QG = 2>) from that many rows on; 0 = never, the default: at M = 10 784 it measured
     // 54.1 us per launch against 43.0 for QG = 1 (164 registers: one 8-wave workgroup per CU instead of two).
-    int big_rows = 4000, attn2_rows = 0, big_tile0 = 0, big_tile1 = 0;       // 4000: from 3 utterances of U10 per pass (profiles/r4_flow_big_ab.txt, fourth series: 61.6 -> 57.4 ms at 3, 48.4 vs 50.8 at 2)
+    int big_rows = 2000, attn2_rows = 0, big_tile0 = 0, big_tile1 = 0;       // 2000 (round 5, with the 32-row band launch): from 2 utterances of U10 per pass - 48.1 -> 43.8 ms at 2, 36.3 vs 36.9 at 1 (profiles/r5_flow_band.txt); round 4 without the band: 4000 (61.6 -> 57.4 ms at 3, 48.4 vs 50.8 at 2)
     int big_lds_epi = 1;               // "big_lds_epi": the large-M GEMMs store their output tile row-wise through LDS (flow_big.h, epilogue_lds); 0 = per-lane stores from the accumulator layout
     int big_glds = 0;                  // "big_glds": the large-M GEMM stages go global -> LDS by DMA (1: global_load_lds_dwordx4, common.h CV_GLDS16) or through registers + ds_write (0).
                                        // Off: as hipcc compiles it the DMA does not overlap the MFMAs (a vmcnt(0) lands in front of the fragment reads, flow_big.h)
@@ -83,7 +83,7 @@ struct cv_flow {
                                        // (profiles/r3_flow_tail_ab.txt): 46.3 vs 38.5 ms per flow.inference at batch 1 - a workgroup pulls its 2 MB of weights through one CU's
                                        // L1 at ~45 B/clk (~32 KB in flight, ~700 cycles), 33-40 us per launch whatever the band count, against 37 us for the four launches it
                                        // replaces.  Off by default; bit-identical to the five-launch form, tested both ways.
-    int band64_rows = 8000;            // "band64_rows": passes of at least this many estimator rows use 64-row bands, smaller large passes 32-row bands (env CV_FLOW_BAND64_ROWS)
+    int band64_rows = 10000;          // "band64_rows": passes of at least this many estimator rows use 64-row bands, smaller large passes 32-row bands (env CV_FLOW_BAND64_ROWS).  Measured (profiles/r5_flow_band.txt): 8 utterances of U10 (10 784 rows) 94.9 vs 96.7 ms, 6 (8088) 81.7 vs 72.1, 5 (6740) 74.5 vs 63.9, 4 (5392) 62.7 vs 55.6
     int fused_band = 1;                // bf16 mode, large passes (big_rows): everything between a block's attention and the next block's QKV GEMM in ONE launch per 64-row band
                                        // (flow_band.h) instead of five (out-projection, LayerNorm, FF1, FF2, LayerNorm); bit-identical; option "fused_band", env CV_FLOW_BAND
     int fused = 1;                     // bf16 mode: LN-prologue GEMMs + bf16 activations + bf16 flash attention for the transformer blocks

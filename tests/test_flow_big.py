@@ -99,7 +99,7 @@ def test_band_kernel_is_bit_identical(lib, est_blocks):
                 for k in range(1, len(outs)):
                     assert torch.equal(outs[0], outs[k]), (T, streaming, k, (outs[0] - outs[k]).abs().max().item())
     finally:
-        lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(5000)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(1)); lib.cv_flow_set_option(flow._h, b"band64_rows", C.c_int32(8000))
+        lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(5000)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(1)); lib.cv_flow_set_option(flow._h, b"band64_rows", C.c_int32(10000))
 
 
 def test_band_kernel_at_the_real_width(lib):
@@ -124,4 +124,4 @@ def test_band_kernel_at_the_real_width(lib):
         for k in range(1, len(outs)):
             assert torch.equal(outs[0], outs[k]), (k, (outs[0] - outs[k]).abs().max().item())
     finally:
-        lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(5000)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(1)); lib.cv_flow_set_option(flow._h, b"band64_rows", C.c_int32(8000))
+        lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(5000)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(1)); lib.cv_flow_set_option(flow._h, b"band64_rows", C.c_int32(10000))

@@ -256,7 +256,7 @@ def test_flow_estimator_u10_large_m_kernels(lib, band):
             assert err < 1.8e-2, (band, streaming, err)
             assert torch.equal(out, small), (band, streaming, (out - small).abs().max().item())
     finally:
-        lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(4000)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(1))
+        lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(2000)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(1))
 
 
 def test_flow_inference_u10(lib):
