@@ -186,7 +186,9 @@ int cv_flow_set_tensor(cv_flow* m, const char* name, const void* dev_ptr, int32_
 int cv_flow_finalize(cv_flow* m);
 /* Options: "use_graph" (Euler-solve hipGraph cache: up to 32 shapes per handle, least recently used evicted; default on), "bf16_mfma" (precision mode), "fused" (bf16
  * mode: fused transformer blocks, 1), "flow_tile" / "flow_ntile" / "attn_waves" / "attn_kt" / "attn_ks" (tile choices, 0 = by size).  Measured alternatives, default off:
- * "fused_tail" (+ "tail_ring" 8 | 16), "est_streams" (1 | 2); "graph_cap" (1 .. 256 cached shapes). */
+ * "fused_tail" (+ "tail_ring" 8 | 16), "est_streams" (1 | 2); "graph_cap" (1 .. 256 cached shapes).  Round 5: "big_rows" (2000: passes of at least this many estimator rows run
+ * on the large-M kernel set, csrc/flow_big.h), "fused_band" (1: in such passes everything between a block's attention and the next QKV GEMM is one launch per row band,
+ * csrc/flow_band.h), "band64_rows" (10000: 64-row bands from this many rows, 32-row bands below).  Every combination is bit-identical per utterance. */
 int cv_flow_set_option(cv_flow* m, const char* name, int32_t value);
 /* "graph_captures" (Euler-solve graphs captured so far), "graphs_cached" (held now; option "graph_cap", default 32) - test / monitoring hook, no reference counterpart */
 int cv_flow_get_stat(cv_flow* m, const char* name, int64_t* value);
