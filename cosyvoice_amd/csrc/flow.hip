@@ -27,7 +27,7 @@ struct LN { const float* g = nullptr; const float* b = nullptr; };
 
 struct ConformerW { LN norm_mha, norm_ff; Lin qkv, pos, out, ff1, ff2; const float* bias_u; const float* bias_v; };
 struct ResnetW { Lin mlp, conv1, conv2, res; LN ln1, ln2; };
-struct TBlockW { LN norm1, norm3; Lin qkv, out, ff1, ff2; const u32x4_t* tail = nullptr; const float* tail_prm = nullptr; bool tail_qkv = false; const u32x4_t* band = nullptr; };   // tail: fragment-ordered stream of flow_tail_kernel (+ the next block's QKV); band: the stream of flow_band_kernel (flow_band.h)
+struct TBlockW { LN norm1, norm3; Lin qkv, out, ff1, ff2; const u32x4_t* tail = nullptr; const float* tail_prm = nullptr; bool tail_qkv = false; const u32x4_t* band = nullptr; const u32x4_t* bandq = nullptr; };   // tail: fragment-ordered stream of flow_tail_kernel (+ the next block's QKV); band: the stream of flow_band_kernel (flow_band.h)
 struct StageW { ResnetW res; std::vector<TBlockW> tf; };
 struct DitBlockW { Lin mod, qkv, out, ff1, ff2; };       // DiTBlock (flow/DiT/modules.py:500-530)
 
@@ -84,6 +84,10 @@ struct cv_flow {
                                        // L1 at ~45 B/clk (~32 KB in flight, ~700 cycles), 33-40 us per launch whatever the band count, against 37 us for the four launches it
                                        // replaces.  Off by default; bit-identical to the five-launch form, tested both ways.
     int band64_rows = 10000;          // "band64_rows": passes of at least this many estimator rows use 64-row bands, smaller large passes 32-row bands (env CV_FLOW_BAND64_ROWS).  Measured (profiles/r5_flow_band.txt): 8 utterances of U10 (10 784 rows) 94.9 vs 96.7 ms, 6 (8088) 81.7 vs 72.1, 5 (6740) 74.5 vs 63.9, 4 (5392) 62.7 vs 55.6
+    int band_qkv = 1;                  // with fused_band: the band launch also runs the NEXT block's QKV GEMM (flow_band_kernel<.., HAS_QKV>): a block of a large pass is two launches
+                                       // (attention, band); bit-identical; option "band_qkv", env CV_FLOW_BAND_QKV
+    int band_bm = 0;                   // dev knob (option "band_bm", env CV_FLOW_BAND_BM): rows per band 32 / 48 / 64 whatever the row count; 0 = the rule (band64_rows / band48_rows)
+    int band48_rows = 0;               // passes of at least this many rows (and fewer than band64_rows) use 48-row bands; 0 = never
     int fused_band = 1;                // bf16 mode, large passes (big_rows): everything between a block's attention and the next block's QKV GEMM in ONE launch per 64-row band
                                        // (flow_band.h) instead of five (out-projection, LayerNorm, FF1, FF2, LayerNorm); bit-identical; option "fused_band", env CV_FLOW_BAND
     int fused = 1;                     // bf16 mode: LN-prologue GEMMs + bf16 activations + bf16 flash attention for the transformer blocks
@@ -213,6 +217,8 @@ static void flow_finalize(cv_flow* m) {
                 if (m->tm.has(q + "band")) {                       // the 64-row band form of large passes (flow_band.h): out-projection + FF1 + FF2 fragments, 8 waves at C = 256, 4 at C = 64
                     const long long bfr = (long long)(C / 16) * (inner / 32) + 2LL * (C / 16) * (4 * C / 32);
                     t.band = reinterpret_cast<const u32x4_t*>(m->tm.get(q + "band", CV_BF16, bfr * 64 * 8).p);
+                    if (t.tail_qkv && m->tm.has(q + "bandq"))      // the same stream + the NEXT block's QKV GEMM (flow_band_kernel<.., HAS_QKV>)
+                        t.bandq = reinterpret_cast<const u32x4_t*>(m->tm.get(q + "bandq", CV_BF16, (bfr + 3LL * (inner / 16) * (C / 32)) * 64 * 8).p);
                 }
             }
             st.tf.push_back(t);
@@ -231,6 +237,9 @@ static void flow_finalize(cv_flow* m) {
     if (const char* e = getenv("CV_FLOW_ENC_BATCH")) m->enc_batch = atoi(e) != 0;
     if (const char* e = getenv("CV_FLOW_ATTN2_ROWS")) m->attn2_rows = atoi(e);
     if (const char* e = getenv("CV_FLOW_BAND64_ROWS")) m->band64_rows = atoi(e);
+    if (const char* e = getenv("CV_FLOW_BAND_QKV")) m->band_qkv = e[0] != '0';
+    if (const char* e = getenv("CV_FLOW_BAND_BM")) m->band_bm = atoi(e);
+    if (const char* e = getenv("CV_FLOW_BAND48_ROWS")) m->band48_rows = atoi(e);
     if (const char* e = getenv("CV_FLOW_BAND")) m->fused_band = e[0] != '0';        // dev knob for A/B runs (also: option "fused_band")
     if (const char* e = getenv("CV_FLOW_TAIL")) m->fused_tail = e[0] != '0';        // dev knob for A/B runs (also: option "fused_tail")
     if (const char* e = getenv("CV_FLOW_TAIL_RING")) m->tail_ring = atoi(e) == 16 ? 16 : 8;
@@ -526,22 +535,30 @@ static void conv_big(const Lin& l, const bf16_t* A, int T, int nz, int pad_left,
     const int tile = tl_big_tile1 ? tl_big_tile1 : 3;
     if (tl_big_glds) conv_big_launch<true>(a, tile, s); else conv_big_launch<false>(a, tile, s);
 }
-// everything between the attention of block `t` and the QKV GEMM of the next block in one launch, 64 or 32 rows per workgroup (flow_band.h)
-static void flow_band(const TBlockW& t, bool has_next, const bf16_t* att, int inner, float* x, int C, int M, bf16_t* xn, int band64_rows, hipStream_t s) {
+// everything between the attention of block `t` and the QKV GEMM of the next block - or, with `q`, up to and including that GEMM - in one launch, 64 / 48 / 32 rows
+// per workgroup (flow_band.h)
+struct BandQkv { bf16_t* qk; int ld_qk; bf16_t* vt; long long vt_batch; int ldt; int rows_per_batch; };
+template <int C, int INNER, int FF, int NW>
+static void flow_band_launch(const FlowBandArgs& a, bool has_next, bool qkv, int bm, hipStream_t s) {
+    const dim3 g((unsigned)((a.M + bm - 1) / bm)), b(NW * 64);
+#define CV_BAND(BM_)                                                                                                                        \
+    if (qkv) hipLaunchKernelGGL((flow_band_kernel<C, INNER, FF, true, NW, 0, BM_, true>), g, b, 0, s, a);                                   \
+    else if (has_next) hipLaunchKernelGGL((flow_band_kernel<C, INNER, FF, true, NW, 0, BM_, false>), g, b, 0, s, a);                        \
+    else hipLaunchKernelGGL((flow_band_kernel<C, INNER, FF, false, NW, 0, BM_, false>), g, b, 0, s, a);
+    if (bm == 64) { CV_BAND(64) } else if (bm == 48) { CV_BAND(48) } else { CV_BAND(32) }
+#undef CV_BAND
+}
+static void flow_band(const cv_flow* m, const TBlockW& t, bool has_next, const BandQkv* q, const bf16_t* att, int inner, float* x, int C, int M, bf16_t* xn, hipStream_t s) {
     FlowBandArgs a{};
-    a.att = att; a.ld_att = inner; a.x = x; a.ldx = C; a.wstream = t.band; a.prm = t.tail_prm; a.eps = 1e-5f; a.M = M; a.xn = xn; a.ld_xn = C;
-    CV_CHECK(t.band && t.tail_prm && (!has_next || t.tail_qkv), "flow_band: block was not packed for this call");
+    a.att = att; a.ld_att = inner; a.x = x; a.ldx = C; a.wstream = q ? t.bandq : t.band; a.prm = t.tail_prm; a.eps = 1e-5f; a.M = M; a.xn = xn; a.ld_xn = C;
+    CV_CHECK(t.band && t.tail_prm && (!has_next || t.tail_qkv) && (!q || (has_next && t.bandq)), "flow_band: block was not packed for this call");
+    if (q) { a.qk = q->qk; a.ld_qk = q->ld_qk; a.vt = q->vt; a.vt_batch = q->vt_batch; a.ldt = q->ldt; a.rows_per_batch = q->rows_per_batch > 0 ? q->rows_per_batch : M; }
     // 64-row bands from `band64_rows` rows (one round of ~170 workgroups at 8 utterances of U10 per pass), 32-row bands below: twice the workgroups for the passes of
-    // 3 - 6 utterances and the shared chunk passes of the streaming scheduler, two per CU
-    const bool tall = M >= band64_rows;
-    const dim3 g((unsigned)(tall ? (M + 63) / 64 : (M + 31) / 32));
-    if (C == 256 && inner == 512) {
-        if (tall) { if (has_next) hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, true, 8, 0, 64>), g, dim3(512), 0, s, a); else hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, false, 8, 0, 64>), g, dim3(512), 0, s, a); }
-        else      { if (has_next) hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, true, 8, 0, 32>), g, dim3(512), 0, s, a); else hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, false, 8, 0, 32>), g, dim3(512), 0, s, a); }
-    } else if (C == 64 && inner == 64) {
-        if (tall) { if (has_next) hipLaunchKernelGGL((flow_band_kernel<64, 64, 256, true, 4, 0, 64>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((flow_band_kernel<64, 64, 256, false, 4, 0, 64>), g, dim3(256), 0, s, a); }
-        else      { if (has_next) hipLaunchKernelGGL((flow_band_kernel<64, 64, 256, true, 4, 0, 32>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((flow_band_kernel<64, 64, 256, false, 4, 0, 32>), g, dim3(256), 0, s, a); }
-    } else throw Error("flow_band: no instantiation for these dimensions");
+    // 3 - 6 utterances and the shared chunk passes of the streaming scheduler, two per CU; 48-row bands from `band48_rows` (225 workgroups at 8 utterances of U10)
+    const int bm = m->band_bm ? m->band_bm : M >= m->band64_rows ? 64 : (m->band48_rows > 0 && M >= m->band48_rows) ? 48 : 32;
+    if (C == 256 && inner == 512) flow_band_launch<256, 512, 1024, 8>(a, has_next, q != nullptr, bm, s);
+    else if (C == 64 && inner == 64) flow_band_launch<64, 64, 256, 4>(a, has_next, q != nullptr, bm, s);
+    else throw Error("flow_band: no instantiation for these dimensions");
 }
 
 // everything after the attention of block `t` (+ LayerNorm and QKV of `next`) in one launch, 16 rows per workgroup (flow_tail.h)
@@ -640,10 +657,13 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
                 const bool big = m->big_rows > 0 && R >= m->big_rows, big_attn = m->attn2_rows > 0 && R >= m->attn2_rows;
                 if (big && m->fused_band && t.band) {     // flow_band.h: QKV GEMM, attention, then ONE launch per 64-row band up to the next block's LayerNorm; bit-identical to the forms below
                     bf16_t* xn = m->h_xn.as<bf16_t>() + r0 * C;
-                    if (ti == 0) ln_bf16(t.norm1, 1e-5f, x, (int)R, C, xn, s);         // later blocks: the previous block's band launch left LayerNorm(norm1) of its output in xn
-                    gemm_big_bf16(t.qkv, xn, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
+                    if (ti == 0) ln_bf16(t.norm1, 1e-5f, x, (int)R, C, xn, s);         // later blocks: the previous block's band launch left LayerNorm(norm1) of its output in xn,
+                    const bool had_qkv = ti > 0 && m->band_qkv && st.tf[ti - 1].bandq;  // or (band_qkv) this block's Q | K and V^T themselves
+                    if (!had_qkv) gemm_big_bf16(t.qkv, xn, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
                     attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, klen, big_attn);
-                    flow_band(t, ti + 1 < st.tf.size(), ab, inner, x, C, (int)R, xn, m->band64_rows, s);
+                    const bool has_next = ti + 1 < st.tf.size();
+                    const BandQkv bq{qk, 2 * inner, vt, vt_batch, m->vt_pitch, T};
+                    flow_band(m, t, has_next, has_next && m->band_qkv && t.bandq ? &bq : nullptr, ab, inner, x, C, (int)R, xn, s);
                     continue;
                 }
                 if (big) {                    // flow_big.h: 7 launches of large tiles, bit-identical to the 5 below
@@ -931,6 +951,9 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "graph_cap") { CV_CHECK(value >= 1 && value <= 256, "graph_cap must be 1 .. 256"); drop_graphs(m); m->graph_cap = (size_t)value; }
         else if (std::string(name) == "fused_tail") { m->fused_tail = value != 0; drop_graphs(m); }
         else if (std::string(name) == "band64_rows") { CV_CHECK(value >= 0, "band64_rows must be >= 0"); m->band64_rows = value; drop_graphs(m); }
+        else if (std::string(name) == "band_qkv") { m->band_qkv = value != 0; drop_graphs(m); }
+        else if (std::string(name) == "band_bm") { CV_CHECK(value == 0 || value == 32 || value == 48 || value == 64, "band_bm must be 0, 32, 48 or 64"); m->band_bm = value; drop_graphs(m); }
+        else if (std::string(name) == "band48_rows") { CV_CHECK(value >= 0, "band48_rows must be >= 0"); m->band48_rows = value; drop_graphs(m); }
         else if (std::string(name) == "fused_band") { m->fused_band = value != 0; drop_graphs(m); }      // bf16 mode, large passes: one 64-row band launch between attention and the next QKV GEMM (flow_band.h) on / off
         else if (std::string(name) == "flow_ntile") { CV_CHECK(value >= 0 && value <= 2, "flow_ntile must be 0, 1 or 2"); m->flow_ntile = value; drop_graphs(m); }
         else if (std::string(name) == "tail_ring") { m->tail_ring = value == 16 ? 16 : 8; drop_graphs(m); }      // bf16 mode: one row-band launch after each attention (flow_tail.h) on / off
@@ -1036,7 +1059,7 @@ static void flow_profile_block(cv_flow* m, int nz, int T, int reps, float* us3, 
             for (int i = 0; i < reps; ++i) {
                 if (which == 0) gemm_big_bf16(t.qkv, xn, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
                 else if (which == 1) attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, 0, s, nullptr, m->attn2_rows > 0 && R >= m->attn2_rows);
-                else flow_band(t, true, ab, inner, x, C, (int)R, xn, m->band64_rows, s);
+                else { const BandQkv bq{qk, 2 * inner, vt, vt_batch, m->vt_pitch, T}; flow_band(m, t, true, m->band_qkv && t.bandq ? &bq : nullptr, ab, inner, x, C, (int)R, xn, s); }      // as a pass runs it: with the next block's QKV GEMM when band_qkv is on
             }
             CV_HIP(hipEventRecord(e1, s)); CV_HIP(hipEventSynchronize(e1));
             float ms = 0.f; CV_HIP(hipEventElapsedTime(&ms, e0, e1));

@@ -18,9 +18,15 @@
 // Weight loads run one PASS (<= 16 fragments per wave) ahead of the MFMAs in a second register buffer, across phase boundaries and barriers (the stream does not
 // depend on activations); there is no global store before the last fragment has been consumed (a pending store costs the compiler its vmcnt bookkeeping).
 #pragma once
+#include <type_traits>
 #include "flow_fused.h"
 
 namespace cv {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void band_static_for(F&& f) {          // f(integral_constant<int, I>) for I .. N - 1: the loop index as a compile-time constant (buffer choice per pass)
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); band_static_for<I + 1, N>(f); }
+}
 
 struct FlowBandArgs {
     const bf16_t* att; int ld_att;            // attention output [M][INNER] bf16
@@ -29,11 +35,14 @@ struct FlowBandArgs {
     const float* prm;                         // small operands of the block (the layout of flow_tail.h): [b_out C | norm3.g C | norm3.b C | b_ff1 FF | b_ff2 C | norm1.g of the NEXT block C | its norm1.b C]
     float eps; int M;
     bf16_t* xn; int ld_xn;                    // HAS_NEXT: LayerNorm(norm1 of the next block) of the new residual rows, bf16 [M][C]
+    bf16_t* qk; int ld_qk;                    // HAS_QKV: Q | K of the NEXT block [M][2 INNER] bf16 (what its flow_gemm_big_kernel<.., 0> launch would have written)
+    bf16_t* vt; long long vt_batch; int ldt; int rows_per_batch;      // HAS_QKV: its V^T [B][INNER][ldt] bf16, key-permuted (vt_col)
     long long* dbg;                           // dev tool (tools/ubench/band_probe.hip): clock64() of thread 0 at the phase boundaries, 16 slots per workgroup; null in production
 };
 
 // one pass: PT 16-column tiles x KS k-steps of 32 against the 4 row tiles of the band.  A: bf16 pairs in LDS, row pitch `pitch` dwords, first dword k0.
-template <int PT, int KS, int MODE = 0, int RT = 4>
+// SWAP: the activations as the MFMA "A" operand - a lane ends with 4 consecutive ROWS of one column (the V^T epilogue) instead of 4 consecutive columns of one row.
+template <int PT, int KS, int MODE = 0, int RT = 4, bool SWAP = false>
 __device__ __forceinline__ void band_mma(const u32x4_t (&w)[16], const unsigned* A, int pitch, int k0, int lq, int lg, v4f (&acc)[RT][PT]) {
     if constexpr (MODE == 2) {                // probe: consume the fragments without the matrix pipe or LDS
 #pragma unroll
@@ -51,8 +60,10 @@ __device__ __forceinline__ void band_mma(const u32x4_t (&w)[16], const unsigned*
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-                acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, w[ks * PT + t]), __builtin_bit_cast(v8bf, af[rt]), acc[rt][t], 0, 0, 0);
+            for (int rt = 0; rt < RT; ++rt) {
+                if constexpr (SWAP) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, af[rt]), __builtin_bit_cast(v8bf, w[ks * PT + t]), acc[rt][t], 0, 0, 0);
+                else                acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, w[ks * PT + t]), __builtin_bit_cast(v8bf, af[rt]), acc[rt][t], 0, 0, 0);
+            }
         }
     }
 }
@@ -72,7 +83,7 @@ __device__ __forceinline__ void band_layernorm(const float* X, unsigned* A, int 
 #pragma unroll
     for (int r0 = 0; r0 < BM; r0 += NT / 16) {
         const int row = r0 + (tid >> 4);
-        if (NT / 16 > BM && row >= BM) break;                 // (more 16-lane groups than rows: the 32-row band on 8 waves normalises its rows in one pass with half the groups)
+        if ((NT / 16 > BM || BM % (NT / 16) != 0) && row >= BM) break;      // (more 16-lane groups than rows: the 32-row band on 8 waves normalises its rows in one pass with half the groups; 48 rows: a pass and a half)
         float4 v[NJ];
         float s = 0.f;
 #pragma unroll
@@ -101,6 +112,9 @@ struct FlowBandShape {
     static constexpr int KC = C / 32;                               // FF1 chunk: K = C;  FF2 chunk: K = C hidden columns
     static constexpr int NCH = FF / C;
     static constexpr int TOTAL = TA * (KA + 2 * NCH * KC);
+    static constexpr int NQ = 3 * INNER / C;                        // HAS_QKV: Q | K | V of the next block in passes of C output columns (one pass = TA tiles x KC k-steps, like an FF1 chunk)
+    static constexpr int FQ0 = TOTAL, TOTALQ = TOTAL + NQ * TA * KC;
+    static_assert((2 * INNER) % C == 0 && NQ >= 2, "flow_band: a QKV pass may not straddle the K | V boundary");
     static_assert(C % (16 * NW) == 0 && TA >= 1 && TA <= 2 && KC <= 8 && INNER % 32 == 0 && FF % C == 0 && (KA <= 8 || KA % 8 == 0), "flow_band: unsupported dimensions");
 };
 
@@ -108,11 +122,15 @@ struct FlowBandShape {
 // reads (the stream alone, consumed by a register checksum); 3 = MFMAs on register operands (no LDS fragment reads)
 // BM = rows per band: 64 (4 MFMA row tiles per weight fragment; large passes) or 32 (2 row tiles: twice the workgroups for passes whose 64-row bands would leave most of
 // the chip idle - 4 utterances per pass, the shared chunk passes of the streaming scheduler - at half the LDS, two workgroups per CU).  Same arithmetic per element.
-template <int C, int INNER, int FF, bool HAS_NEXT, int NW, int MODE = 0, int BM = 64>
+// HAS_QKV (implies HAS_NEXT; the stream then carries the next block's QKV fragments behind the FF ones, weights.py::pack_flow_band(.., w_qkv_next)): the band also runs
+// the next block's QKV GEMM on its LayerNorm rows - Q | K rows and the V^T columns go straight from the accumulators to memory (the values and stores of
+// flow_gemm_big_kernel<.., OMODE 0>'s direct epilogue), so a block of a large pass is TWO launches (attention, band) and the bf16 LayerNorm rows never exist in memory.
+template <int C, int INNER, int FF, bool HAS_NEXT, int NW, int MODE = 0, int BM = 64, bool HAS_QKV = false>
 __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
     using S = FlowBandShape<C, INNER, FF, NW>;
     constexpr int NT = NW * 64, TA = S::TA, RT = BM / 16;
-    static_assert(BM == 64 || BM == 32, "flow_band: 64- or 32-row bands");
+    static_assert(BM == 64 || BM == 48 || BM == 32, "flow_band: 64-, 48- or 32-row bands");
+    static_assert(!HAS_QKV || HAS_NEXT, "flow_band: the QKV phase belongs to the next block");
     constexpr int PA0 = INNER / 2 + LDS_PAD, PX = C + LDS_PAD, PA1 = C / 2 + LDS_PAD;       // LDS row pitches (dwords / floats): 8 mod 16 (common.h, LDS_PAD)
     constexpr int OPS = (BM * PA0 > 2 * BM * PA1) ? BM * PA0 : 2 * BM * PA1;                // the attention tile overlays A1 | A2
     __shared__ __attribute__((aligned(16))) float X1[BM * PX];
@@ -144,7 +162,7 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
         xv[i] = *reinterpret_cast<const float4*>(p.x + (long long)min(m0 + r, p.M - 1) * p.ldx + c * 4);
     }
     __builtin_amdgcn_sched_barrier(0);
-    const u32x4_t* ws = p.wstream + (long long)wave * S::TOTAL * 64 + lane;
+    const u32x4_t* ws = p.wstream + (long long)wave * (HAS_QKV ? S::TOTALQ : S::TOTAL) * 64 + lane;
     u32x4_t wb0[16], wb1[16];
     constexpr int FA0 = TA * (S::KA < 8 ? S::KA : 8);                       // fragments of the first out-projection pass
     band_wload<FA0>(wb0, ws, 0);
@@ -235,11 +253,15 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
         }
         __syncthreads();                                                    // the chunk's hidden tile is complete
         // FF2 chunk j; request FF1 chunk j + 1 (unconditional: after the last chunk the request repeats that chunk's FF1 fragments and is never used)
-        const int nxt = F0 + 2 * min(j + 1, S::NCH - 1) * FCD;
+        // (HAS_QKV: after the last chunk the request is the first QKV pass of the next block instead)
+        const int nxt = (HAS_QKV && j == S::NCH - 1) ? S::FQ0 : F0 + 2 * min(j + 1, S::NCH - 1) * FCD;
         if constexpr (FF1_IN_WB1) { band_wload<FCD, MODE>(wb1, ws, nxt); band_mma<TA, S::KC, MODE, RT>(wb0, A2, PA1, 0, lq, lg, acc2); }
         else                      { band_wload<FCD, MODE>(wb0, ws, nxt); band_mma<TA, S::KC, MODE, RT>(wb1, A2, PA1, 0, lq, lg, acc2); }
         __syncthreads();                                                    // before the next chunk overwrites A2 (and before the epilogue below touches X1's neighbours)
         stamp();                                                            // 4 .. 3 + NCH: chunk j done
+    }
+    if constexpr (HAS_QKV) {                                                // QKV pass 1 into the buffer the last FF2 chunk has just left (pass 0 sits in the other one)
+        if constexpr (FF1_IN_WB1) band_wload<FCD, MODE>(wb0, ws, S::FQ0 + FCD); else band_wload<FCD, MODE>(wb1, ws, S::FQ0 + FCD);
     }
     // ---- FF2 epilogue: + bias + residual -> X1 (the new residual stream)
 #pragma unroll
@@ -258,11 +280,66 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
         // ---- E: LayerNorm(norm1 of the next block) -> A1, written out as the bf16 operand rows of its QKV GEMM
         band_layernorm<C, PX, NT, BM>(X1, A1, PA1, &prm[O_G1N], &prm[O_BE1N], p.eps, tid);
         __syncthreads();
-        constexpr int NP = BM * C / 8;
+        if constexpr (!HAS_QKV) {
+            constexpr int NP = BM * C / 8;
 #pragma unroll
-        for (int i = 0; i < (NP + NT - 1) / NT; ++i) {
-            const int v = tid + NT * i, r = v / (C / 8), c = v % (C / 8);
-            if (v < NP && m0 + r < p.M) *reinterpret_cast<u32x4_t*>(p.xn + (long long)(m0 + r) * p.ld_xn + c * 8) = *reinterpret_cast<const u32x4_t*>(&A1[r * PA1 + c * 4]);
+            for (int i = 0; i < (NP + NT - 1) / NT; ++i) {
+                const int v = tid + NT * i, r = v / (C / 8), c = v % (C / 8);
+                if (v < NP && m0 + r < p.M) *reinterpret_cast<u32x4_t*>(p.xn + (long long)(m0 + r) * p.ld_xn + c * 8) = *reinterpret_cast<const u32x4_t*>(&A1[r * PA1 + c * 4]);
+            }
+        } else {
+            // ---- F: Q | K | V of the next block, NQ passes of C output columns over K = C.  No barrier from here on (A1 is only read, nothing goes through LDS), so loads
+            // and stores stay counted: pass c multiplies, requests pass c + 2 into the buffer it has just emptied, THEN stores - the wait of pass c + 1 is for requests
+            // older than these stores.  Q | K: 4 columns of a row per lane (8 bytes); V: operands swapped, 4 consecutive rows (keys) of a column per lane - the V^T
+            // stores of flow_gemm_big_kernel (an aligned key group of one request = one 8-byte store at vt_col).
+            band_static_for<0, S::NQ>([&](auto ic) {
+                constexpr int c = decltype(ic)::value;
+                constexpr bool IS_V = c * C >= 2 * INNER;
+                constexpr bool IN_WB1 = (c % 2 == 0) == FF1_IN_WB1;
+                v4f acc[RT][TA];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < TA; ++t) acc[rt][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+                if constexpr (IN_WB1) band_mma<TA, S::KC, MODE, RT, IS_V>(wb1, A1, PA1, 0, lq, lg, acc); else band_mma<TA, S::KC, MODE, RT, IS_V>(wb0, A1, PA1, 0, lq, lg, acc);
+                if constexpr (c + 2 < S::NQ) { if constexpr (IN_WB1) band_wload<FCD, MODE>(wb1, ws, S::FQ0 + (c + 2) * FCD); else band_wload<FCD, MODE>(wb0, ws, S::FQ0 + (c + 2) * FCD); }
+                if constexpr (!IS_V) {
+#pragma unroll
+                    for (int t = 0; t < TA; ++t) {
+                        const int n = c * C + 16 * (wave + NW * t) + 4 * lg;
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            const int m = m0 + 16 * rt + lq;
+                            if (m < p.M) *reinterpret_cast<uint2*>(p.qk + (long long)m * p.ld_qk + n) = make_uint2(pack_bf16x2(acc[rt][t][0], acc[rt][t][1]), pack_bf16x2(acc[rt][t][2], acc[rt][t][3]));
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < TA; ++t) {
+                        const int n = c * C - 2 * INNER + 16 * (wave + NW * t) + lq;
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            const int m = m0 + 16 * rt + 4 * lg;
+                            const unsigned lo = pack_bf16x2(acc[rt][t][0] + 0.f, acc[rt][t][1] + 0.f), hi = pack_bf16x2(acc[rt][t][2] + 0.f, acc[rt][t][3] + 0.f);      // "+ 0": flow_gemm_big_kernel adds its (absent) bias here
+                            if (m >= p.M) continue;
+                            const int b = m / p.rows_per_batch, tt = m - b * p.rows_per_batch;
+                            bf16_t* row = p.vt + (long long)b * p.vt_batch + (long long)n * p.ldt;
+                            if (m + 3 < p.M && tt + 3 < p.rows_per_batch && (tt & 3) == 0) { *reinterpret_cast<uint2*>(row + vt_col(tt)) = make_uint2(lo, hi); continue; }
+                            if (m + 3 < p.M && tt + 3 < p.rows_per_batch && (tt & 1) == 0) {
+                                *reinterpret_cast<unsigned*>(row + vt_col(tt)) = lo; *reinterpret_cast<unsigned*>(row + vt_col(tt + 2)) = hi; continue;
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int mr = m + r;
+                                if (mr >= p.M) continue;
+                                const int br = mr / p.rows_per_batch, tr_ = mr - br * p.rows_per_batch;
+                                const unsigned u = r < 2 ? lo : hi;
+                                p.vt[(long long)br * p.vt_batch + (long long)n * p.ldt + vt_col(tr_)] = (bf16_t)((r & 1) ? (u >> 16) : (u & 0xffffu));
+                            }
+                        }
+                    }
+                }
+            });
         }
     }
     stamp();                                                                // FF2 epilogue (+ next LayerNorm and its rows) done

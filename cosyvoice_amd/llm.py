@@ -7,6 +7,7 @@ runs on the MI355X behind cv_llm_* (cosyvoice_amd/csrc/llm.hip); this class only
 and drains tokens in chunks.
 """
 import ctypes as C
+import os
 import threading
 
 import torch
@@ -30,6 +31,36 @@ def register_tensors(lib, set_fn, handle, tensors):
     for name, t in tensors.items():
         dt = {torch.float32: 0, torch.bfloat16: 1, torch.int32: 2, torch.uint8: 3}[t.dtype]
         getattr(lib, set_fn)(handle, name.encode(), C.c_void_p(t.data_ptr()), C.c_int32(dt), C.c_int64(t.numel()))
+
+
+class _Cursor:
+    """Admission cursor shared by the decode groups of one inference_queue call: hands out request indices in order, once."""
+
+    def __init__(self, n):
+        self.n, self.k, self.lock = n, 0, threading.Lock()
+
+    def take(self):
+        with self.lock:
+            if self.k >= self.n:
+                return None
+            self.k += 1
+            return self.k - 1
+
+
+class _no_groups:
+    """While the chains of a grouped call run, their handles decode their own share directly (no nested cut)."""
+
+    def __init__(self, handles):
+        self.handles = handles
+
+    def __enter__(self):
+        self.saved = [h.decode_groups for h in self.handles]
+        for h in self.handles:
+            h.decode_groups = 1
+
+    def __exit__(self, *a):
+        for h, v in zip(self.handles, self.saved):
+            h.decode_groups = v
 
 
 class Qwen2Encoder:
@@ -73,7 +104,7 @@ class Qwen2LM:
     'greedy' (the sampler north-star parity is defined on)."""
 
     def __init__(self, state_dict, cfg, lib=None, max_len=2048, sampling="ras", top_p=0.8, top_k=25, win_size=10, tau_r=0.1,
-                 seed=1986, decode_chunk=16, use_graph=True, attn_splits=8, batch_fp8=False):
+                 seed=1986, decode_chunk=16, use_graph=True, attn_splits=8, batch_fp8=False, decode_groups=None, group_min_slots=24):
         """batch_fp8 (opt-in, BASELINE.json configs[4] "fp8 MFMA LLM path"): the BATCHED decode (inference_batch / _queue / serve_stream) runs on OCP
         e4m3 copies of the weight matrices (one fp32 scale per row) with the activations quantised per sequence in the kernel and
         v_mfma_f32_16x16x32_fp8_fp8 products; prefill and the single-sequence path keep the bf16 weights.  Token ids are then no longer the fp32
@@ -106,6 +137,15 @@ class Qwen2LM:
         self.batch_fp8 = bool(batch_fp8)
         if batch_fp8:
             self.lib.cv_llm_set_option(self._h, b"batch_fp8", C.c_int32(1))
+        # Decode groups (round 5): a lock-step batch of >= `group_min_slots` sequences is cut into `decode_groups` independent chains of equal size, each on a handle
+        # of its own (a SIBLING: the same weight tensors, its own KV cache / workspaces / graphs), its own stream and host thread.  Every launch of the batched step is
+        # latency-bound and fills the chip only partly, so two chains side by side cost far less than their sum (profiles/r5_batch_decode_ab.txt section 4: 2 x 16 slots
+        # decode 1.17 x the tokens per second of 1 x 32).  Slots are independent, so a request's tokens do not depend on the cut.  env CV_LLM_GROUPS overrides.
+        self._opts = dict(use_graph=int(use_graph), attn_splits=int(attn_splits), batch_fp8=int(bool(batch_fp8)))
+        self._cfg_c = c
+        self.decode_groups = int(os.environ.get("CV_LLM_GROUPS", decode_groups if decode_groups is not None else 1))
+        self.group_min_slots = int(os.environ.get("CV_LLM_GROUP_MIN", group_min_slots))
+        self._siblings, self._group_streams = [], []
         self._uniforms = None
         self._request = 0
         self._kv_gen = 0                                     # bumped by everything that resets the handle's KV cache (a stale forward_one_step cache must be refused whoever replaced it)
@@ -117,6 +157,61 @@ class Qwen2LM:
                 self._h = None
         except Exception:
             pass
+
+    def sibling(self):
+        """A second handle over the SAME device weight tensors (nothing is copied): its own KV cache, workspaces, graphs, lock and request counter."""
+        import copy
+        sib = copy.copy(self)
+        sib.lock = threading.Lock()
+        sib._siblings, sib._group_streams, sib.decode_groups = [], [], 1
+        sib._h = C.c_void_p()
+        self.lib.cv_llm_create(C.byref(sib._h), C.byref(self._cfg_c))
+        register_tensors(self.lib, "cv_llm_set_tensor", sib._h, self._tensors)
+        self.lib.cv_llm_finalize(sib._h)
+        for k, v in self._opts.items():
+            if k != "batch_fp8" or v:
+                self.lib.cv_llm_set_option(sib._h, k.encode(), C.c_int32(v))
+        sib._uniforms, sib._kv_gen = None, 0
+        return sib
+
+    def _groups(self, n_slots):
+        """The handles a lock-step batch of `n_slots` sequences is cut over ([self] = no cut) and the stream each runs on (None: the caller's)."""
+        g = self.decode_groups if n_slots >= self.group_min_slots else 1
+        g = max(1, min(g, n_slots))
+        if g == 1:
+            return [self], [None]
+        while len(self._siblings) < g - 1:
+            self._siblings.append(self.sibling())
+        if self.device.type == "cuda":
+            while len(self._group_streams) < g:
+                self._group_streams.append(torch.cuda.Stream(self.device, priority=-1))
+            return [self] + self._siblings[: g - 1], self._group_streams[:g]
+        return [self] + self._siblings[: g - 1], [None] * g
+
+    def _run_groups(self, works):
+        """works: [(handle, stream, callable)] - each callable on a thread of its own under its stream; the first exception is re-raised."""
+        errs = []
+        ev = None
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event(); ev.record()                # what the caller's stream has queued (uploaded request tensors) precedes every chain
+
+        def run(stream, fn):
+            try:
+                if stream is not None:
+                    with torch.cuda.stream(stream):
+                        stream.wait_event(ev)
+                        fn()
+                        stream.synchronize()
+                else:
+                    fn()
+            except BaseException as e:                          # noqa: BLE001 - surfaces in the caller
+                errs.append(e)
+
+        ths = [threading.Thread(target=run, args=(st, fn), daemon=True) for _, st, fn in works]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        if errs:
+            raise errs[0]
 
     # ---- lm_input = [sos | embed_tokens(prompt_text ++ text) | task_id | speech_embedding(prompt)]  (llm.py:472-494)
     def build_lm_input(self, text, prompt_text, prompt_speech_token, stream=None):
@@ -261,6 +356,27 @@ class Qwen2LM:
         `max_token_text_ratio`.  Returns one token list per request - the
         same tokens `inference()` yields for that request alone (the per-sequence arithmetic is identical)."""
         nb = len(requests)
+        handles, streams = self._groups(nb)
+        if len(handles) > 1:
+            # decode groups: contiguous runs of the requests ordered by their length bound (a chain runs as long as its longest member: similar lengths together), every
+            # request with the sampler key it would have had on this handle alone
+            bound = lambda i: int(requests[i]["text"].shape[1]) * float(requests[i].get("max_token_text_ratio", max_token_text_ratio))
+            order = sorted(range(nb), key=lambda i: -bound(i))
+            base = self._request
+            reqs = [dict(requests[i], seed_key=requests[i].get("seed_key", base + 1 + i)) for i in range(nb)]
+            g = len(handles)
+            parts = [order[k * nb // g:(k + 1) * nb // g] for k in range(g)]
+            outs = [None] * nb
+
+            def work(h, part):
+                def fn():
+                    for i, toks in zip(part, h.inference_batch([reqs[i] for i in part], max_token_text_ratio, min_token_text_ratio)):
+                        outs[i] = toks
+                return fn
+            with _no_groups(handles):
+                self._run_groups([(h, st_, work(h, part)) for h, st_, part in zip(handles, streams, parts)])
+            self._request = base + nb                           # (this handle ran one of the chains: its counter advances as if it had run them all)
+            return outs
         assert 1 <= nb <= (16 if self.batch_fp8 else 32), "1..32 requests per batch (16 on the fp8 path)"
         with self.lock:
             st = stream_ptr(self.lib)
@@ -300,14 +416,55 @@ class Qwen2LM:
                                            (C.c_int32 * n)(*[int(x.shape[0]) for x in inputs]), (SamplingC * n)(*sps), st)
 
     @torch.inference_mode()
-    def inference_queue(self, requests, slots=8, max_token_text_ratio=20, min_token_text_ratio=2):
+    def inference_queue(self, requests, slots=8, max_token_text_ratio=20, min_token_text_ratio=2, _cursor=None):
         """Continuous batching over the lock-step decoder: any number of requests, at most `slots` (<= 8) in flight; when a
         sequence finishes its slot is re-filled from the queue (a normal prefill parked into the free slot) while the other sequences keep
         decoding.  Yields (request_index, token_list) in completion order; every token list equals `inference()` of that request alone."""
-        assert 1 <= slots <= (16 if self.batch_fp8 else 32)
         n = len(requests)
         if n == 0:
             return
+        handles, streams = self._groups(min(slots, n)) if _cursor is None else ([self], [None])
+        if len(handles) > 1:
+            # decode groups: every chain runs this generator over ONE shared admission cursor (the requests keep their order of admission) with slots / groups slots
+            import queue as _q
+            g = len(handles)
+            cur, res, END = _Cursor(n), _q.Queue(), object()
+            base = self._request
+            reqs = [dict(r, seed_key=r.get("seed_key", base + 1 + i)) for i, r in enumerate(requests)]
+
+            def work(h, k):
+                def fn():
+                    try:
+                        for item in h.inference_queue(reqs, slots=(slots + g - 1 - k) // g, max_token_text_ratio=max_token_text_ratio, min_token_text_ratio=min_token_text_ratio, _cursor=cur):
+                            res.put(item)
+                    finally:
+                        res.put(END)
+                return fn
+            errs = []
+
+            def runner():
+                try:
+                    with _no_groups(handles):
+                        self._run_groups([(h, st_, work(h, k)) for k, (h, st_) in enumerate(zip(handles, streams))])
+                except BaseException as e:                      # noqa: BLE001
+                    errs.append(e)
+                    for _ in range(g):
+                        res.put(END)
+            th = threading.Thread(target=runner, daemon=True)
+            th.start()
+            ended = 0
+            while ended < g:
+                item = res.get()
+                if item is END:
+                    ended += 1
+                else:
+                    yield item
+            th.join()
+            self._request = base + n
+            if errs:
+                raise errs[0]
+            return
+        assert 1 <= slots <= (16 if self.batch_fp8 else 32)
         with self.lock:
             st = stream_ptr(self.lib)
             nb = min(slots, n)
@@ -320,9 +477,17 @@ class Qwen2LM:
 
             def fill(slot):
                 nonlocal nxt
-                while nxt < n:
-                    i, r = nxt, requests[nxt]
-                    nxt += 1
+                while True:
+                    if _cursor is not None:
+                        i = _cursor.take()
+                        if i is None:
+                            break
+                    elif nxt < n:
+                        i = nxt
+                        nxt += 1
+                    else:
+                        break
+                    r = requests[i]
                     lm_input = self.build_lm_input(r["text"], r["prompt_text"], r["prompt_speech_token"])
                     n_text = int(r["text"].shape[1])
                     min_len = int(n_text * r.get("min_token_text_ratio", min_token_text_ratio))

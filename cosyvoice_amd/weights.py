@@ -117,13 +117,15 @@ def pack_flow_tail(w_out, w_ff1, w_ff2, w_qkv_next=None, waves=4):
     return torch.stack(out, 0).contiguous()
 
 
-def pack_flow_band(w_out, w_ff1, w_ff2, waves):
+def pack_flow_band(w_out, w_ff1, w_ff2, waves, w_qkv_next=None):
     """The weight stream of flow_band_kernel (csrc/flow_band.h) for one transformer block: out-projection [C][INNER], FF1 [FF][C] and FF2 [C][FF] cut into MFMA
     fragments in the order each wave consumes them.  Wave w owns the 16-column tiles w, w + waves, ... of every C-wide output; a PASS is (its tiles) x (<= 8
     k-steps), k-step major, tile minor: the out-projection in passes of 8 k-steps, then per chunk j of C hidden columns FF1 (rows j C .. j C + C of w_ff1, all of
-    K = C) followed by FF2 (all rows, k-steps of hidden columns j C .. j C + C).  Returns bf16 [waves][fragments per wave][64][8]."""
+    K = C) followed by FF2 (all rows, k-steps of hidden columns j C .. j C + C).  With `w_qkv_next` ([3 INNER][C], the NEXT block's fused q | k | v rows): behind them
+    its QKV GEMM in passes of C output rows, each laid out like an FF1 chunk (the HAS_QKV form of the kernel).  Returns bf16 [waves][fragments per wave][64][8]."""
     C = w_out.shape[0]
     fo, f1, f2 = _mfma_fragments(w_out), _mfma_fragments(w_ff1), _mfma_fragments(w_ff2)
+    fq = _mfma_fragments(w_qkv_next) if w_qkv_next is not None else None
     ka, kc, nch, tiles = fo.shape[1], C // 32, w_ff1.shape[0] // C, C // 16
     out = []
     for w in range(waves):
@@ -134,6 +136,10 @@ def pack_flow_band(w_out, w_ff1, w_ff2, waves):
         for j in range(nch):
             parts.append(f1[j * tiles:(j + 1) * tiles][w::waves].permute(1, 0, 2, 3).reshape(-1, 64, 8))
             parts.append(f2[w::waves][:, j * kc:(j + 1) * kc].permute(1, 0, 2, 3).reshape(-1, 64, 8))
+        if fq is not None:
+            assert w_qkv_next.shape[0] % C == 0 and w_qkv_next.shape[1] == C
+            for c in range(w_qkv_next.shape[0] // C):
+                parts.append(fq[c * tiles:(c + 1) * tiles][w::waves].permute(1, 0, 2, 3).reshape(-1, 64, 8))
         out.append(torch.cat(parts, 0))
     return torch.stack(out, 0).contiguous()
 
@@ -215,6 +221,9 @@ def pack_flow(sd, cfg, device, dtype=torch.bfloat16):
                 # the 64-row band form for large passes (csrc/flow_band.h): 8 waves at the real width, 4 at the test width
                 out[q + "band"] = pack_flow_band(out[q + "out.w"].reshape(cfg.est_ch, inner), out[q + "ff1.w"].reshape(4 * cfg.est_ch, cfg.est_ch),
                                                  out[q + "ff2.w"].reshape(cfg.est_ch, 4 * cfg.est_ch), 8 if cfg.est_ch == 256 else 4)
+                if nxt is not None:                                 # the same stream with the next block's QKV GEMM behind it (flow_band_kernel<.., HAS_QKV>)
+                    out[q + "bandq"] = pack_flow_band(out[q + "out.w"].reshape(cfg.est_ch, inner), out[q + "ff1.w"].reshape(4 * cfg.est_ch, cfg.est_ch),
+                                                      out[q + "ff2.w"].reshape(cfg.est_ch, 4 * cfg.est_ch), 8 if cfg.est_ch == 256 else 4, nxt)
     _conv(out, "est.down_conv", sd[s + "down_blocks.0.2.weight"], sd[s + "down_blocks.0.2.bias"], device, dtype)
     _conv(out, "est.up_conv", sd[s + "up_blocks.0.2.weight"], sd[s + "up_blocks.0.2.bias"], device, dtype)
     _conv(out, "est.final.conv", sd[s + "final_block.block.0.weight"], sd[s + "final_block.block.0.bias"], device, dtype)

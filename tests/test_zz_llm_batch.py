@@ -156,6 +156,30 @@ def test_continuous_batching(lib):
     assert list(lm.inference_queue([], slots=3)) == []
 
 
+@pytest.mark.parametrize("sampling", ["greedy", "ras"])
+def test_decode_groups(lib, sampling):
+    """Round 5: a lock-step batch of at least group_min_slots sequences is cut into `decode_groups` independent chains, each on a sibling handle (the same weight
+    tensors, its own KV cache), stream and host thread.  Slots are independent, so every request gets exactly the tokens of the uncut batch - also under 'ras'
+    sampling, where the chains key a request's sampler stream by the number it would have had on the one handle - through inference_batch and inference_queue."""
+    cfg = W.tiny()[0]
+    sd = W.make_llm(cfg)
+    reqs = [_req(cfg, 300 + i, 2 + (i % 4), 2 + (i % 2), 5 + 7 * (i % 3)) for i in range(7)]
+    one = Qwen2LM(sd, cfg, lib=lib, max_len=160, sampling=sampling, decode_chunk=4)
+    two = Qwen2LM(sd, cfg, lib=lib, max_len=160, sampling=sampling, decode_chunk=4, decode_groups=2, group_min_slots=4)
+    want_b = one.inference_batch(reqs[:5], max_token_text_ratio=4, min_token_text_ratio=1)
+    want_q = dict(one.inference_queue(reqs, slots=4, max_token_text_ratio=4, min_token_text_ratio=1))
+    got_b = two.inference_batch(reqs[:5], max_token_text_ratio=4, min_token_text_ratio=1)
+    assert len(two._siblings) == 1 and two._siblings[0]._h.value != two._h.value          # the cut really happened
+    got_q = dict(two.inference_queue(reqs, slots=4, max_token_text_ratio=4, min_token_text_ratio=1))
+    assert got_b == want_b
+    assert sorted(got_q) == list(range(7)) and got_q == want_q
+    if sampling == "greedy":
+        for r, g in zip(reqs[:5], got_b):
+            assert g == OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=4, min_token_text_ratio=1)
+    small = two.inference_batch(reqs[:3], max_token_text_ratio=4, min_token_text_ratio=1)   # below group_min_slots: the one handle
+    assert small == one.inference_batch(reqs[:3], max_token_text_ratio=4, min_token_text_ratio=1)
+
+
 def test_model_tts_batch(lib):
     """CosyVoice2Model.tts_batch == tts() per request (same tokens from the batched LM, same flow / HiFT)."""
     import dataclasses
