@@ -619,14 +619,22 @@ def roofline_mfma(model, cfgs, n_utt=8):
     inner, M = 64 * H, nz * T
     us = (C.c_float * 3)()
     flow.lib.cv_flow_profile_block(flow._h, C.c_int32(nz), C.c_int32(T), C.c_int32(20), us, stream_ptr(flow.lib))
-    flops = {"flow_gemm_big_kernel<64,64,0> QKV (bf16 out, V^T transposed)": 2.0 * M * C_ * 3 * inner,
+    # round 5: with band_qkv (the default) the band launch of a block also runs the NEXT block's QKV GEMM - a block of the pass is then two launches (attention, band)
+    # and the stand-alone QKV GEMM only opens a stage (1 block in 4); it stays in the record as a launch of its own
+    band_qkv = os.environ.get("CV_FLOW_BAND_QKV", "1") != "0"
+    flops = {"flow_gemm_big_kernel<64,64,0> QKV (bf16 out, V^T transposed)%s" % (" - first block of a stage only" if band_qkv else ""): 2.0 * M * C_ * 3 * inner,
              "attn_flow_kernel flash attention (QK^T + PV over all keys)": 4.0 * nz * H * T * T * 64,
-             "flow_band_kernel out-projection + LayerNorm + FF1 + GELU + FF2 (+ next LayerNorm), 64-row bands": 2.0 * M * (C_ * inner + 2 * C_ * FF)}
+             ("flow_band_kernel out-projection + LayerNorm + FF1 + GELU + FF2 + next LayerNorm + next QKV GEMM, 64-row bands" if band_qkv else
+              "flow_band_kernel out-projection + LayerNorm + FF1 + GELU + FF2 (+ next LayerNorm), 64-row bands"): 2.0 * M * (C_ * inner + 2 * C_ * FF + (C_ * 3 * inner if band_qkv else 0))}
     per = {}
     for (name, fl), t in zip(flops.items(), us):
         per[name] = {"flops_per_launch": int(fl), "avg_launch_us": round(float(t), 2), "TFLOPs": round(fl / (t * 1e-6) / 1e12, 1), "frac_of_peak": round(fl / (t * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
     dom = max(per, key=lambda k: per[k]["avg_launch_us"])
-    block_fl, block_us = sum(flops.values()), sum(float(t) for t in us)
+    names = list(flops)
+    if band_qkv:      # a block of the pass = attention + band (the band's flops include the QKV GEMM it replaces)
+        block_fl, block_us = flops[names[1]] + flops[names[2]], float(us[1]) + float(us[2])
+    else:
+        block_fl, block_us = sum(flops.values()), sum(float(t) for t in us)
     busy, busy_src = None, None
     pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r5_pmc_flow_batch8.json", "r4_pmc_flow_batch8_end.json")) if os.path.exists(f)), None)
     if pmc is not None:

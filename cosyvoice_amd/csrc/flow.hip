@@ -83,11 +83,9 @@ struct cv_flow {
                                        // (profiles/r3_flow_tail_ab.txt): 46.3 vs 38.5 ms per flow.inference at batch 1 - a workgroup pulls its 2 MB of weights through one CU's
                                        // L1 at ~45 B/clk (~32 KB in flight, ~700 cycles), 33-40 us per launch whatever the band count, against 37 us for the four launches it
                                        // replaces.  Off by default; bit-identical to the five-launch form, tested both ways.
-    int band64_rows = 10000;          // "band64_rows": passes of at least this many estimator rows use 64-row bands, smaller large passes 32-row bands (env CV_FLOW_BAND64_ROWS).  Measured (profiles/r5_flow_band.txt): 8 utterances of U10 (10 784 rows) 94.9 vs 96.7 ms, 6 (8088) 81.7 vs 72.1, 5 (6740) 74.5 vs 63.9, 4 (5392) 62.7 vs 55.6
     int band_qkv = 1;                  // with fused_band: the band launch also runs the NEXT block's QKV GEMM (flow_band_kernel<.., HAS_QKV>): a block of a large pass is two launches
                                        // (attention, band); bit-identical; option "band_qkv", env CV_FLOW_BAND_QKV
-    int band_bm = 0;                   // dev knob (option "band_bm", env CV_FLOW_BAND_BM): rows per band 32 / 48 / 64 whatever the row count; 0 = the rule (band64_rows / band48_rows)
-    int band48_rows = 0;               // passes of at least this many rows (and fewer than band64_rows) use 48-row bands; 0 = never
+    int band_bm = 0;                   // option "band_bm" (env CV_FLOW_BAND_BM): rows per band 32 / 48 / 64 whatever the row count; 0 = by the row count of the pass (band_rows_for)
     int fused_band = 1;                // bf16 mode, large passes (big_rows): everything between a block's attention and the next block's QKV GEMM in ONE launch per 64-row band
                                        // (flow_band.h) instead of five (out-projection, LayerNorm, FF1, FF2, LayerNorm); bit-identical; option "fused_band", env CV_FLOW_BAND
     int fused = 1;                     // bf16 mode: LN-prologue GEMMs + bf16 activations + bf16 flash attention for the transformer blocks
@@ -236,10 +234,8 @@ static void flow_finalize(cv_flow* m) {
     if (const char* e = getenv("CV_FLOW_BIG_LDS_EPI")) m->big_lds_epi = atoi(e) != 0;
     if (const char* e = getenv("CV_FLOW_ENC_BATCH")) m->enc_batch = atoi(e) != 0;
     if (const char* e = getenv("CV_FLOW_ATTN2_ROWS")) m->attn2_rows = atoi(e);
-    if (const char* e = getenv("CV_FLOW_BAND64_ROWS")) m->band64_rows = atoi(e);
     if (const char* e = getenv("CV_FLOW_BAND_QKV")) m->band_qkv = e[0] != '0';
     if (const char* e = getenv("CV_FLOW_BAND_BM")) m->band_bm = atoi(e);
-    if (const char* e = getenv("CV_FLOW_BAND48_ROWS")) m->band48_rows = atoi(e);
     if (const char* e = getenv("CV_FLOW_BAND")) m->fused_band = e[0] != '0';        // dev knob for A/B runs (also: option "fused_band")
     if (const char* e = getenv("CV_FLOW_TAIL")) m->fused_tail = e[0] != '0';        // dev knob for A/B runs (also: option "fused_tail")
     if (const char* e = getenv("CV_FLOW_TAIL_RING")) m->tail_ring = atoi(e) == 16 ? 16 : 8;
@@ -537,6 +533,20 @@ static void conv_big(const Lin& l, const bf16_t* A, int T, int nz, int pad_left,
 }
 // everything between the attention of block `t` and the QKV GEMM of the next block - or, with `q`, up to and including that GEMM - in one launch, 64 / 48 / 32 rows
 // per workgroup (flow_band.h)
+// Rows per band of a pass of M rows (every height computes the same bits): a band is one dependent chain of ~40 - 75 us, so what matters is how many ROUNDS of bands
+// the chip runs and how tall a band of the last round is.  Launch time of flow_band_kernel<.., HAS_QKV> by height and workgroup count k, from tools/ubench/bandq_probe
+// (profiles/r5_bandq_probe.txt; 64- and 48-row bands: one workgroup per CU, 32-row bands: two): t64 = 54 + 0.115 k, t48 = 45 + 0.10 k, t32 = 23 + 0.10 k up to one per
+// CU and ~70 - 80 us once CUs hold two.  8 utterances of U10 (10 784 rows) -> 48 rows (225 workgroups, one round), up to 8192 rows -> 32, 12 - 16 k rows -> 64.
+static int band_rows_for(int M) {
+    auto t = [](int bm, int k) { return bm == 64 ? 54.f + 0.115f * k : bm == 48 ? 45.f + 0.10f * k : k <= 256 ? 23.f + 0.10f * k : 1.05f * (70.f + 0.035f * (k - 256)); };
+    int best = 32; float best_t = 1e30f;
+    for (int bm : {32, 48, 64}) {
+        const int n = (M + bm - 1) / bm, cap = bm == 32 ? 512 : 256, full = n / cap, rem = n % cap;
+        const float est = full * t(bm, cap) + (rem ? t(bm, rem) : 0.f);
+        if (est < best_t) { best_t = est; best = bm; }
+    }
+    return best;
+}
 struct BandQkv { bf16_t* qk; int ld_qk; bf16_t* vt; long long vt_batch; int ldt; int rows_per_batch; };
 template <int C, int INNER, int FF, int NW>
 static void flow_band_launch(const FlowBandArgs& a, bool has_next, bool qkv, int bm, hipStream_t s) {
@@ -553,9 +563,7 @@ static void flow_band(const cv_flow* m, const TBlockW& t, bool has_next, const B
     a.att = att; a.ld_att = inner; a.x = x; a.ldx = C; a.wstream = q ? t.bandq : t.band; a.prm = t.tail_prm; a.eps = 1e-5f; a.M = M; a.xn = xn; a.ld_xn = C;
     CV_CHECK(t.band && t.tail_prm && (!has_next || t.tail_qkv) && (!q || (has_next && t.bandq)), "flow_band: block was not packed for this call");
     if (q) { a.qk = q->qk; a.ld_qk = q->ld_qk; a.vt = q->vt; a.vt_batch = q->vt_batch; a.ldt = q->ldt; a.rows_per_batch = q->rows_per_batch > 0 ? q->rows_per_batch : M; }
-    // 64-row bands from `band64_rows` rows (one round of ~170 workgroups at 8 utterances of U10 per pass), 32-row bands below: twice the workgroups for the passes of
-    // 3 - 6 utterances and the shared chunk passes of the streaming scheduler, two per CU; 48-row bands from `band48_rows` (225 workgroups at 8 utterances of U10)
-    const int bm = m->band_bm ? m->band_bm : M >= m->band64_rows ? 64 : (m->band48_rows > 0 && M >= m->band48_rows) ? 48 : 32;
+    const int bm = m->band_bm ? m->band_bm : band_rows_for(M);
     if (C == 256 && inner == 512) flow_band_launch<256, 512, 1024, 8>(a, has_next, q != nullptr, bm, s);
     else if (C == 64 && inner == 64) flow_band_launch<64, 64, 256, 4>(a, has_next, q != nullptr, bm, s);
     else throw Error("flow_band: no instantiation for these dimensions");
@@ -950,10 +958,8 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "graph_max_rows") { CV_CHECK(value >= 0, "graph_max_rows must be >= 0"); m->graph_max_rows = value; drop_graphs(m); }
         else if (std::string(name) == "graph_cap") { CV_CHECK(value >= 1 && value <= 256, "graph_cap must be 1 .. 256"); drop_graphs(m); m->graph_cap = (size_t)value; }
         else if (std::string(name) == "fused_tail") { m->fused_tail = value != 0; drop_graphs(m); }
-        else if (std::string(name) == "band64_rows") { CV_CHECK(value >= 0, "band64_rows must be >= 0"); m->band64_rows = value; drop_graphs(m); }
         else if (std::string(name) == "band_qkv") { m->band_qkv = value != 0; drop_graphs(m); }
         else if (std::string(name) == "band_bm") { CV_CHECK(value == 0 || value == 32 || value == 48 || value == 64, "band_bm must be 0, 32, 48 or 64"); m->band_bm = value; drop_graphs(m); }
-        else if (std::string(name) == "band48_rows") { CV_CHECK(value >= 0, "band48_rows must be >= 0"); m->band48_rows = value; drop_graphs(m); }
         else if (std::string(name) == "fused_band") { m->fused_band = value != 0; drop_graphs(m); }      // bf16 mode, large passes: one 64-row band launch between attention and the next QKV GEMM (flow_band.h) on / off
         else if (std::string(name) == "flow_ntile") { CV_CHECK(value >= 0 && value <= 2, "flow_ntile must be 0, 1 or 2"); m->flow_ntile = value; drop_graphs(m); }
         else if (std::string(name) == "tail_ring") { m->tail_ring = value == 16 ? 16 : 8; drop_graphs(m); }      // bf16 mode: one row-band launch after each attention (flow_tail.h) on / off

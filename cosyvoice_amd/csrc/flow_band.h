@@ -118,7 +118,7 @@ struct FlowBandShape {
     static_assert(C % (16 * NW) == 0 && TA >= 1 && TA <= 2 && KC <= 8 && INNER % 32 == 0 && FF % C == 0 && (KA <= 8 || KA % 8 == 0), "flow_band: unsupported dimensions");
 };
 
-// MODE (dev tool only, tools/ubench/band_probe.hip): 0 = the kernel; 1 = the weight stream is requested once (prologue) and never again; 2 = no MFMA and no fragment
+// MODE (dev tool only, tools/ubench/band_probe.hip; 4 = HAS_QKV without the Q | K | V^T stores, tools/ubench/bandq_probe.hip): 0 = the kernel; 1 = the weight stream is requested once (prologue) and never again; 2 = no MFMA and no fragment
 // reads (the stream alone, consumed by a register checksum); 3 = MFMAs on register operands (no LDS fragment reads)
 // BM = rows per band: 64 (4 MFMA row tiles per weight fragment; large passes) or 32 (2 row tiles: twice the workgroups for passes whose 64-row bands would leave most of
 // the chip idle - 4 utterances per pass, the shared chunk passes of the streaming scheduler - at half the LDS, two workgroups per CU).  Same arithmetic per element.
@@ -292,6 +292,8 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
             // and stores stay counted: pass c multiplies, requests pass c + 2 into the buffer it has just emptied, THEN stores - the wait of pass c + 1 is for requests
             // older than these stores.  Q | K: 4 columns of a row per lane (8 bytes); V: operands swapped, 4 consecutive rows (keys) of a column per lane - the V^T
             // stores of flow_gemm_big_kernel (an aligned key group of one request = one 8-byte store at vt_col).
+            stamp();                                                        // (HAS_QKV) FF2 epilogue + next LayerNorm done
+            float qsink = 0.f;
             band_static_for<0, S::NQ>([&](auto ic) {
                 constexpr int c = decltype(ic)::value;
                 constexpr bool IS_V = c * C >= 2 * INNER;
@@ -303,7 +305,23 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
                     for (int t = 0; t < TA; ++t) acc[rt][t] = (v4f){0.f, 0.f, 0.f, 0.f};
                 if constexpr (IN_WB1) band_mma<TA, S::KC, MODE, RT, IS_V>(wb1, A1, PA1, 0, lq, lg, acc); else band_mma<TA, S::KC, MODE, RT, IS_V>(wb0, A1, PA1, 0, lq, lg, acc);
                 if constexpr (c + 2 < S::NQ) { if constexpr (IN_WB1) band_wload<FCD, MODE>(wb1, ws, S::FQ0 + (c + 2) * FCD); else band_wload<FCD, MODE>(wb0, ws, S::FQ0 + (c + 2) * FCD); }
-                if constexpr (!IS_V) {
+                if constexpr (MODE == 4) {                   // probe: the QKV products without their stores (a register checksum keeps them)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int t = 0; t < TA; ++t) qsink += acc[rt][t][0] + acc[rt][t][1] + acc[rt][t][2] + acc[rt][t][3];
+                } else if constexpr (!IS_V && TA == 2) {
+                    // two tiles per wave: the stream pairs them so that a lane's 4 + 4 columns are ADJACENT (weights.py::pack_flow_band: MFMA row 4 g + r of tile t is output
+                    // column 32 wave + 8 g + 4 t + r of the pass) - one 16-byte store per row tile instead of two 8-byte ones, 64 contiguous bytes per row and instruction.
+                    // The epilogue is bound by the NUMBER of store instructions (cdna_hip_programming.md T21), not by their bytes.  Same dot products: same values.
+                    const int n = c * C + 32 * wave + 8 * lg;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const int m = m0 + 16 * rt + lq;
+                        if (m < p.M) *reinterpret_cast<uint4*>(p.qk + (long long)m * p.ld_qk + n) =
+                            make_uint4(pack_bf16x2(acc[rt][0][0], acc[rt][0][1]), pack_bf16x2(acc[rt][0][2], acc[rt][0][3]), pack_bf16x2(acc[rt][1][0], acc[rt][1][1]), pack_bf16x2(acc[rt][1][2], acc[rt][1][3]));
+                    }
+                } else if constexpr (!IS_V) {
 #pragma unroll
                     for (int t = 0; t < TA; ++t) {
                         const int n = c * C + 16 * (wave + NW * t) + 4 * lg;
@@ -340,6 +358,7 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
                     }
                 }
             });
+            if constexpr (MODE == 4) { if (qsink == 12345.678f) p.qk[0] = (bf16_t)0; }
         }
     }
     stamp();                                                                // FF2 epilogue (+ next LayerNorm and its rows) done

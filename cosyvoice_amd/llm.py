@@ -54,13 +54,13 @@ class _no_groups:
         self.handles = handles
 
     def __enter__(self):
-        self.saved = [h.decode_groups for h in self.handles]
+        self.saved = [(h.decode_groups, h.queue_groups) for h in self.handles]
         for h in self.handles:
-            h.decode_groups = 1
+            h.decode_groups = h.queue_groups = 1
 
     def __exit__(self, *a):
         for h, v in zip(self.handles, self.saved):
-            h.decode_groups = v
+            h.decode_groups, h.queue_groups = v
 
 
 class Qwen2Encoder:
@@ -104,7 +104,7 @@ class Qwen2LM:
     'greedy' (the sampler north-star parity is defined on)."""
 
     def __init__(self, state_dict, cfg, lib=None, max_len=2048, sampling="ras", top_p=0.8, top_k=25, win_size=10, tau_r=0.1,
-                 seed=1986, decode_chunk=16, use_graph=True, attn_splits=8, batch_fp8=False, decode_groups=None, group_min_slots=24):
+                 seed=1986, decode_chunk=16, use_graph=True, attn_splits=8, batch_fp8=False, decode_groups=2, queue_groups=1, group_min_slots=24):
         """batch_fp8 (opt-in, BASELINE.json configs[4] "fp8 MFMA LLM path"): the BATCHED decode (inference_batch / _queue / serve_stream) runs on OCP
         e4m3 copies of the weight matrices (one fp32 scale per row) with the activations quantised per sequence in the kernel and
         v_mfma_f32_16x16x32_fp8_fp8 products; prefill and the single-sequence path keep the bf16 weights.  Token ids are then no longer the fp32
@@ -140,10 +140,14 @@ class Qwen2LM:
         # Decode groups (round 5): a lock-step batch of >= `group_min_slots` sequences is cut into `decode_groups` independent chains of equal size, each on a handle
         # of its own (a SIBLING: the same weight tensors, its own KV cache / workspaces / graphs), its own stream and host thread.  Every launch of the batched step is
         # latency-bound and fills the chip only partly, so two chains side by side cost far less than their sum (profiles/r5_batch_decode_ab.txt section 4: 2 x 16 slots
-        # decode 1.17 x the tokens per second of 1 x 32).  Slots are independent, so a request's tokens do not depend on the cut.  env CV_LLM_GROUPS overrides.
+        # decode 1.17 x the tokens per second of 1 x 32, 2 x 12 1.25 x those of 1 x 24; 2 x 8 is SLOWER than 1 x 16: hence group_min_slots).  Slots are independent, so a
+        # request's tokens do not depend on the cut.  `decode_groups` (default 2, env CV_LLM_GROUPS) applies to inference_batch, where the LM has the chip to itself;
+        # `queue_groups` (default 1, env CV_LLM_QUEUE_GROUPS) to inference_queue: next to a running vocoder the idle CUs two chains would fill are already taken, and the
+        # chains' sequences finish apart, so fewer of them share a flow pass (measured: mixed64 509 -> 415 audio-s/s with 2, profiles/r5_decode_groups.txt).
         self._opts = dict(use_graph=int(use_graph), attn_splits=int(attn_splits), batch_fp8=int(bool(batch_fp8)))
         self._cfg_c = c
         self.decode_groups = int(os.environ.get("CV_LLM_GROUPS", decode_groups if decode_groups is not None else 1))
+        self.queue_groups = int(os.environ.get("CV_LLM_QUEUE_GROUPS", queue_groups if queue_groups is not None else 1))
         self.group_min_slots = int(os.environ.get("CV_LLM_GROUP_MIN", group_min_slots))
         self._siblings, self._group_streams = [], []
         self._uniforms = None
@@ -162,8 +166,10 @@ class Qwen2LM:
         """A second handle over the SAME device weight tensors (nothing is copied): its own KV cache, workspaces, graphs, lock and request counter."""
         import copy
         sib = copy.copy(self)
+        for k in [k for k in sib.__dict__ if callable(getattr(type(sib), k, None))]:
+            del sib.__dict__[k]                                 # an instance attribute that shadows a method (a caller's wrapper around THIS handle's method) stays with this handle
         sib.lock = threading.Lock()
-        sib._siblings, sib._group_streams, sib.decode_groups = [], [], 1
+        sib._siblings, sib._group_streams, sib.decode_groups, sib.queue_groups = [], [], 1, 1
         sib._h = C.c_void_p()
         self.lib.cv_llm_create(C.byref(sib._h), C.byref(self._cfg_c))
         register_tensors(self.lib, "cv_llm_set_tensor", sib._h, self._tensors)
@@ -174,9 +180,9 @@ class Qwen2LM:
         sib._uniforms, sib._kv_gen = None, 0
         return sib
 
-    def _groups(self, n_slots):
+    def _groups(self, n_slots, groups):
         """The handles a lock-step batch of `n_slots` sequences is cut over ([self] = no cut) and the stream each runs on (None: the caller's)."""
-        g = self.decode_groups if n_slots >= self.group_min_slots else 1
+        g = groups if n_slots >= self.group_min_slots and not self.batch_fp8 and self._uniforms is None else 1
         g = max(1, min(g, n_slots))
         if g == 1:
             return [self], [None]
@@ -356,7 +362,8 @@ class Qwen2LM:
         `max_token_text_ratio`.  Returns one token list per request - the
         same tokens `inference()` yields for that request alone (the per-sequence arithmetic is identical)."""
         nb = len(requests)
-        handles, streams = self._groups(nb)
+        assert 1 <= nb <= (16 if self.batch_fp8 else 32), "1..32 requests per batch (16 on the fp8 path)"
+        handles, streams = self._groups(nb, self.decode_groups)
         if len(handles) > 1:
             # decode groups: contiguous runs of the requests ordered by their length bound (a chain runs as long as its longest member: similar lengths together), every
             # request with the sampler key it would have had on this handle alone
@@ -370,7 +377,7 @@ class Qwen2LM:
 
             def work(h, part):
                 def fn():
-                    for i, toks in zip(part, h.inference_batch([reqs[i] for i in part], max_token_text_ratio, min_token_text_ratio)):
+                    for i, toks in zip(part, type(h).inference_batch(h, [reqs[i] for i in part], max_token_text_ratio, min_token_text_ratio)):
                         outs[i] = toks
                 return fn
             with _no_groups(handles):
@@ -423,7 +430,7 @@ class Qwen2LM:
         n = len(requests)
         if n == 0:
             return
-        handles, streams = self._groups(min(slots, n)) if _cursor is None else ([self], [None])
+        handles, streams = self._groups(min(slots, n), self.queue_groups) if _cursor is None else ([self], [None])
         if len(handles) > 1:
             # decode groups: every chain runs this generator over ONE shared admission cursor (the requests keep their order of admission) with slots / groups slots
             import queue as _q
@@ -435,7 +442,7 @@ class Qwen2LM:
             def work(h, k):
                 def fn():
                     try:
-                        for item in h.inference_queue(reqs, slots=(slots + g - 1 - k) // g, max_token_text_ratio=max_token_text_ratio, min_token_text_ratio=min_token_text_ratio, _cursor=cur):
+                        for item in type(h).inference_queue(h, reqs, slots=(slots + g - 1 - k) // g, max_token_text_ratio=max_token_text_ratio, min_token_text_ratio=min_token_text_ratio, _cursor=cur):
                             res.put(item)
                     finally:
                         res.put(END)

@@ -125,8 +125,23 @@ def pack_flow_band(w_out, w_ff1, w_ff2, waves, w_qkv_next=None):
     its QKV GEMM in passes of C output rows, each laid out like an FF1 chunk (the HAS_QKV form of the kernel).  Returns bf16 [waves][fragments per wave][64][8]."""
     C = w_out.shape[0]
     fo, f1, f2 = _mfma_fragments(w_out), _mfma_fragments(w_ff1), _mfma_fragments(w_ff2)
-    fq = _mfma_fragments(w_qkv_next) if w_qkv_next is not None else None
     ka, kc, nch, tiles = fo.shape[1], C // 32, w_ff1.shape[0] // C, C // 16
+    fq = None
+    if w_qkv_next is not None:
+        wq = w_qkv_next
+        if tiles == 2 * waves:
+            # Q | K passes with two tiles per wave: MFMA row 4 g + r of tile t (tile index wave + waves t of the pass) computes output column 32 wave + 8 g + 4 t + r, so
+            # that a lane's 4 + 4 accumulator columns are adjacent in memory (one 16-byte store per row tile, flow_band.h).  The V passes keep the plain order.
+            inner2 = 2 * (wq.shape[0] // 3)
+            idx = torch.arange(wq.shape[0])
+            i = torch.arange(16)
+            for c in range(inner2 // C):
+                for wv in range(waves):
+                    for t in range(2):
+                        j = wv + waves * t
+                        idx[c * C + 16 * j:c * C + 16 * j + 16] = c * C + 32 * wv + 8 * (i >> 2) + 4 * t + (i & 3)
+            wq = wq[idx.to(wq.device)]
+        fq = _mfma_fragments(wq)
     out = []
     for w in range(waves):
         parts = []

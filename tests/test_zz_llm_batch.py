@@ -164,8 +164,8 @@ def test_decode_groups(lib, sampling):
     cfg = W.tiny()[0]
     sd = W.make_llm(cfg)
     reqs = [_req(cfg, 300 + i, 2 + (i % 4), 2 + (i % 2), 5 + 7 * (i % 3)) for i in range(7)]
-    one = Qwen2LM(sd, cfg, lib=lib, max_len=160, sampling=sampling, decode_chunk=4)
-    two = Qwen2LM(sd, cfg, lib=lib, max_len=160, sampling=sampling, decode_chunk=4, decode_groups=2, group_min_slots=4)
+    one = Qwen2LM(sd, cfg, lib=lib, max_len=160, sampling=sampling, decode_chunk=4, decode_groups=1)
+    two = Qwen2LM(sd, cfg, lib=lib, max_len=160, sampling=sampling, decode_chunk=4, decode_groups=2, queue_groups=2, group_min_slots=4)
     want_b = one.inference_batch(reqs[:5], max_token_text_ratio=4, min_token_text_ratio=1)
     want_q = dict(one.inference_queue(reqs, slots=4, max_token_text_ratio=4, min_token_text_ratio=1))
     got_b = two.inference_batch(reqs[:5], max_token_text_ratio=4, min_token_text_ratio=1)
