@@ -117,6 +117,14 @@ struct cv_flow {
     // pass gains 1 % at batch 1 (38.8 -> 38.4 ms), 7 - 10 % for 2 - 8 utterances per pass, but a hipGraph with parallel branches leaves the runtime's
     // single-batch replay path: hipGraphLaunch then costs ~40 ms of HOST time per solve (bench step 178 -> 218 ms once nothing overlaps it).  Off by default.
     int est_streams = 1;
+    // Round 5: passes that run EAGER (graph_max_rows: every shared pass of 3000 estimator rows or more) can take the two-chain form without that cost - the host stays
+    // ~10 ms of enqueueing ahead of an 80 ms pass: option "eager_streams" = 2 (env CV_FLOW_EAGER_STREAMS).  An ISOLATED pass gains 4 - 8 % (8 utterances of U10 81.1 ->
+    // 74.5 ms, 6: 67.6 -> 62.4, 4: 54.2 -> 50.9, 2: 44.0 -> 42.3), but the token2wav LANES of the model already are two chains at a coarser grain, and four busy vocoder
+    // streams next to the LM lose: batch 16 393 -> 329, batch 32 494 -> 423, mixed64 478 -> 443 audio-s/s with two lanes; with one lane two chains beat one (340 -> 353,
+    // 408 -> 427, 413 -> 429) and still lose to two lanes of one chain (profiles/r5_band_qkv.txt section 3).  Default 1.
+    int eager_streams = 1;
+    bool two_chains_now = false;       // set by solve_euler around an eager body
+    long long rule_rows = 0;           // rows of the whole pass while its halves run as two chains (band_rows_for sees what the chip holds, not one chain's share)
     hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<float> host_t;
     ~cv_flow() {
@@ -234,6 +242,7 @@ static void flow_finalize(cv_flow* m) {
     if (const char* e = getenv("CV_FLOW_BIG_LDS_EPI")) m->big_lds_epi = atoi(e) != 0;
     if (const char* e = getenv("CV_FLOW_ENC_BATCH")) m->enc_batch = atoi(e) != 0;
     if (const char* e = getenv("CV_FLOW_ATTN2_ROWS")) m->attn2_rows = atoi(e);
+    if (const char* e = getenv("CV_FLOW_EAGER_STREAMS")) m->eager_streams = atoi(e) >= 2 ? 2 : 1;
     if (const char* e = getenv("CV_FLOW_BAND_QKV")) m->band_qkv = e[0] != '0';
     if (const char* e = getenv("CV_FLOW_BAND_BM")) m->band_bm = atoi(e);
     if (const char* e = getenv("CV_FLOW_BAND")) m->fused_band = e[0] != '0';        // dev knob for A/B runs (also: option "fused_band")
@@ -563,7 +572,7 @@ static void flow_band(const cv_flow* m, const TBlockW& t, bool has_next, const B
     a.att = att; a.ld_att = inner; a.x = x; a.ldx = C; a.wstream = q ? t.bandq : t.band; a.prm = t.tail_prm; a.eps = 1e-5f; a.M = M; a.xn = xn; a.ld_xn = C;
     CV_CHECK(t.band && t.tail_prm && (!has_next || t.tail_qkv) && (!q || (has_next && t.bandq)), "flow_band: block was not packed for this call");
     if (q) { a.qk = q->qk; a.ld_qk = q->ld_qk; a.vt = q->vt; a.vt_batch = q->vt_batch; a.ldt = q->ldt; a.rows_per_batch = q->rows_per_batch > 0 ? q->rows_per_batch : M; }
-    const int bm = m->band_bm ? m->band_bm : band_rows_for(M);
+    const int bm = m->band_bm ? m->band_bm : band_rows_for(m->rule_rows > M ? (int)m->rule_rows : M);
     if (C == 256 && inner == 512) flow_band_launch<256, 512, 1024, 8>(a, has_next, q != nullptr, bm, s);
     else if (C == 64 && inner == 64) flow_band_launch<64, 64, 256, 4>(a, has_next, q != nullptr, bm, s);
     else throw Error("flow_band: no instantiation for these dimensions");
@@ -634,7 +643,9 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
         if (fused && m->big_rows > 0 && R >= m->big_rows && din % 64 == 0 && C % 64 == 0) {
             // large pass (flow_big.h): the block's input and Mish(LN(block1)) are rounded to bf16 ONCE (the small bf16 tiles round them per tap and per N tile
             // when they stage them - same values), the convolutions run on 128-row tiles: bit-identical to the five launches below
-            bf16_t* cb = m->h_cur.as<bf16_t>() + r0 * din; bf16_t* hb = m->h_xn.as<bf16_t>() + r0 * C;
+            // (the chain's share of h_cur starts at the WIDEST stage input's pitch: with a per-stage pitch r0 * din the second chain of a two-chain evaluation, a stage
+            // behind or ahead of the first, would sit inside the first chain's rows of a wider stage - found in round 5 as a changed mixed64 hash under two lanes)
+            bf16_t* cb = m->h_cur.as<bf16_t>() + r0 * std::max(4 * c.mel, 2 * C); bf16_t* hb = m->h_xn.as<bf16_t>() + r0 * C;
             hipLaunchKernelGGL(cvt_bf16_kernel, dim3(nblk(R * din / 8)), dim3(256), 0, s, cur, cb, R * din / 8);
             conv_big(st.res.conv1, cb, T, nz, 2, x, nullptr, m->h_zero.p, s);
             { NormArgs na{x, nullptr, R, C, st.res.ln1.g, st.res.ln1.b, 1e-5f, 0, ACT_MISH, 1.f, nullptr, tm, rpb}; na.y16 = hb; norm_rows(na, s); }
@@ -733,14 +744,18 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
 // One estimator evaluation over nz batch rows: with est_streams = 2 (and an even nz) the two halves of the batch rows run as independent launch chains
 // on `s` and on the handle's side stream, forked and joined through events (graph edges when `s` is being captured).
 static void estimator_eval(cv_flow* m, int T, int t_row, int t_rows_total, bool t_shared, int streaming, hipStream_t s, int nz = 2) {
-    if (m->est_streams < 2 || nz < 2 || (nz & 1)) { estimator_forward(m, T, t_row, t_rows_total, t_shared, streaming, s, nz, 0); return; }
+    if ((m->est_streams < 2 && !m->two_chains_now) || nz < 2 || (nz & 1)) { estimator_forward(m, T, t_row, t_rows_total, t_shared, streaming, s, nz, 0); return; }
     if (!m->side_stream) {
         CV_HIP(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
         CV_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming)); CV_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     }
     CV_HIP(hipEventRecord(m->ev_fork, s)); CV_HIP(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
-    estimator_forward(m, T, t_row, t_rows_total, t_shared, streaming, s, nz / 2, 0);
-    estimator_forward(m, T, t_row, t_rows_total, t_shared, streaming, m->side_stream, nz / 2, nz / 2);
+    m->rule_rows = (long long)nz * T;
+    try {
+        estimator_forward(m, T, t_row, t_rows_total, t_shared, streaming, s, nz / 2, 0);
+        estimator_forward(m, T, t_row, t_rows_total, t_shared, streaming, m->side_stream, nz / 2, nz / 2);
+    } catch (...) { m->rule_rows = 0; throw; }
+    m->rule_rows = 0;
     CV_HIP(hipEventRecord(m->ev_join, m->side_stream)); CV_HIP(hipStreamWaitEvent(s, m->ev_join, 0));
 }
 
@@ -933,7 +948,10 @@ static void solve_euler(cv_flow* m, float* x /*[nu][T][mel] in/out*/, const floa
         CV_HIP(hipGraphLaunch(ge, s));
         return;
     }
-    body();
+    // an eager pass of a large shape: its batch rows as two launch chains (eager_streams); a first-sighting eager run of a graphable shape stays one chain
+    m->two_chains_now = !graphable && !dit && m->eager_streams >= 2;
+    try { body(); } catch (...) { m->two_chains_now = false; throw; }
+    m->two_chains_now = false;
 }
 
 extern "C" {
@@ -954,6 +972,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "attn_ks") { CV_CHECK(value >= 1 && value <= 4, "attn_ks must be 1 .. 4"); m->attn_ks = value; drop_graphs(m); }
         else if (std::string(name) == "attn_kt") { CV_CHECK(value == 1 || value == 2, "attn_kt must be 1 or 2"); m->attn_kt = value; drop_graphs(m); }
         else if (std::string(name) == "attn_waves") { CV_CHECK(value == 2 || value == 4, "attn_waves must be 2 or 4"); m->attn_waves = value; drop_graphs(m); }
+        else if (std::string(name) == "eager_streams") { CV_CHECK(value == 1 || value == 2, "eager_streams must be 1 or 2"); m->eager_streams = value; }
         else if (std::string(name) == "est_streams") { CV_CHECK(value == 1 || value == 2, "est_streams must be 1 or 2"); m->est_streams = value; drop_graphs(m); }
         else if (std::string(name) == "graph_max_rows") { CV_CHECK(value >= 0, "graph_max_rows must be >= 0"); m->graph_max_rows = value; drop_graphs(m); }
         else if (std::string(name) == "graph_cap") { CV_CHECK(value >= 1 && value <= 256, "graph_cap must be 1 .. 256"); drop_graphs(m); m->graph_cap = (size_t)value; }

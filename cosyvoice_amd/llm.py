@@ -150,6 +150,7 @@ class Qwen2LM:
         self.queue_groups = int(os.environ.get("CV_LLM_QUEUE_GROUPS", queue_groups if queue_groups is not None else 1))
         self.group_min_slots = int(os.environ.get("CV_LLM_GROUP_MIN", group_min_slots))
         self._siblings, self._group_streams = [], []
+        self.group_streams = None                            # streams for the second .. last chain (CosyVoice2Model.set_lanes hands over its lane streams)
         self._uniforms = None
         self._request = 0
         self._kv_gen = 0                                     # bumped by everything that resets the handle's KV cache (a stale forward_one_step cache must be refused whoever replaced it)
@@ -169,7 +170,7 @@ class Qwen2LM:
         for k in [k for k in sib.__dict__ if callable(getattr(type(sib), k, None))]:
             del sib.__dict__[k]                                 # an instance attribute that shadows a method (a caller's wrapper around THIS handle's method) stays with this handle
         sib.lock = threading.Lock()
-        sib._siblings, sib._group_streams, sib.decode_groups, sib.queue_groups = [], [], 1, 1
+        sib._siblings, sib._group_streams, sib.group_streams, sib.decode_groups, sib.queue_groups = [], [], None, 1, 1
         sib._h = C.c_void_p()
         self.lib.cv_llm_create(C.byref(sib._h), C.byref(self._cfg_c))
         register_tensors(self.lib, "cv_llm_set_tensor", sib._h, self._tensors)
@@ -189,9 +190,15 @@ class Qwen2LM:
         while len(self._siblings) < g - 1:
             self._siblings.append(self.sibling())
         if self.device.type == "cuda":
-            while len(self._group_streams) < g:
-                self._group_streams.append(torch.cuda.Stream(self.device, priority=-1))
-            return [self] + self._siblings[: g - 1], self._group_streams[:g]
+            # the first chain stays on the caller's stream; the others run on `group_streams` (set by the model: its token2wav lane streams, idle while tts_batch
+            # decodes) or on streams of their own.  A process has 4 hardware queues and a busy stream beyond them shares one with another (set_lanes): two extra
+            # streams for the chains slowed the pipelined runs that FOLLOWED a grouped batch in the same process (batch 32: 508 -> 441 audio-s/s, gpurun_out/r5w).
+            extra = list(self.group_streams or [])[: g - 1]
+            while len(extra) < g - 1:
+                if not self._group_streams:
+                    self._group_streams.append(torch.cuda.Stream(self.device, priority=-1))
+                extra.append(self._group_streams[0] if g == 2 else torch.cuda.Stream(self.device, priority=-1))
+            return [self] + self._siblings[: g - 1], [torch.cuda.current_stream(self.device)] + extra
         return [self] + self._siblings[: g - 1], [None] * g
 
     def _run_groups(self, works):

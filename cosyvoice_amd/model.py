@@ -115,6 +115,11 @@ class CosyVoice2Model:
             if self.flow is None:
                 break
         self.n_lanes = n
+        if getattr(self, "llm", None) is not None and hasattr(self.llm, "group_streams"):
+            # the LM's decode groups (Qwen2LM._groups) borrow the lane streams for their second chain: lanes are idle while tts_batch decodes, and the process stays
+            # within its four hardware queues (LM stream, default stream, two lanes)
+            lanes = list(self._lane_q.queue)
+            self.llm.group_streams = [ln.stream for ln in reversed(lanes) if ln.stream is not None] or None
 
     @contextmanager
     def _lane(self):

@@ -133,3 +133,28 @@ def test_band_kernel_at_the_real_width(lib):
     finally:
         lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(5000)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(1))
         lib.cv_flow_set_option(flow._h, b"band_bm", C.c_int32(0)); lib.cv_flow_set_option(flow._h, b"band_qkv", C.c_int32(1))
+
+
+def test_eager_large_pass_runs_two_chains(lib):
+    """Round 5: a pass that runs eager (graph_max_rows) takes the estimator's batch rows as TWO launch chains on two streams (option eager_streams = 2, the default) - the
+    same kernels on the same rows, the band height chosen from the rows of the WHOLE pass: every utterance's mel is the one chain's, bit for bit, in an equal-shape pass
+    and in a padded one, with the large-M kernel set and the band + QKV launch on."""
+    import ctypes as C
+    import dataclasses
+    cfg = dataclasses.replace(W.tiny()[1], n_timesteps=2, est_blocks=2, est_mid=1)
+    sd = W.make_flow(cfg)
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision="bf16")
+    g = torch.Generator().manual_seed(18)
+    items = []
+    for n_t, n_p in ((40, 9), (33, 5), (37, 7), (40, 9)):
+        items.append(dict(token=torch.randint(0, cfg.vocab, (1, n_t), generator=g, dtype=torch.int32), prompt_token=torch.randint(0, cfg.vocab, (1, n_p), generator=g, dtype=torch.int32),
+                          prompt_feat=torch.randn(1, 2 * n_p, 80, generator=g) * 2 - 5, embedding=torch.randn(1, cfg.spk_dim, generator=g)))
+    opt = lambda **kw: [lib.cv_flow_set_option(flow._h, k.encode(), C.c_int32(v)) for k, v in kw.items()]
+    opt(big_rows=1, graph_max_rows=1)                                # every pass is a large one and runs eager
+    outs = {}
+    for streams in (1, 2):
+        opt(eager_streams=streams)
+        outs[streams] = [m.cpu().clone() for m in flow.inference_batch(items)] + [m.cpu().clone() for m in flow.inference_batch([items[0], items[3]])]
+    assert all(torch.isfinite(m).all() and m.abs().max() > 0 for m in outs[1])
+    for a, b in zip(outs[1], outs[2]):
+        assert a.shape == b.shape and torch.equal(a, b), (a.shape, (a - b).abs().max().item())

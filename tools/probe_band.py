@@ -28,11 +28,15 @@ VARIANTS = [("small-tile path    ", dict(big_rows=1 << 30, fused_band=0, band_qk
             ("band + qkv, 64 rows", dict(fused_band=1, band_qkv=1, band_bm=64)),
             ("band + qkv, 48 rows", dict(fused_band=1, band_qkv=1, band_bm=48)),
             ("band + qkv, 32 rows", dict(fused_band=1, band_qkv=1, band_bm=32)),
-            ("band, 48 rows      ", dict(fused_band=1, band_qkv=0, band_bm=48))]
+            ("band, 48 rows      ", dict(fused_band=1, band_qkv=0, band_bm=48)),
+            ("2 chains, rule     ", dict(fused_band=1, band_qkv=1, band_bm=0, est_streams=2)),       # the batch rows as two launch chains on two streams (est_streams, round 3): eager passes only
+            ("2 chains, 64 rows  ", dict(fused_band=1, band_qkv=1, band_bm=64, est_streams=2)),
+            ("2 chains, 48 rows  ", dict(fused_band=1, band_qkv=1, band_bm=48, est_streams=2)),
+            ("2 chains, 32 rows  ", dict(fused_band=1, band_qkv=1, band_bm=32, est_streams=2))]
 for nu in nus:
     ref = None
     for name, kw in VARIANTS:
-        opt(**kw)
+        opt(**{"est_streams": 1, **kw})
         for _ in range(2):
             out = flow.inference_batch([item] * nu)
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -44,4 +48,4 @@ for nu in nus:
         if ref is None:
             ref = mel
         print("%d utterance(s), M = %5d  %s  %7.2f ms per pass = %6.2f ms per utterance   mel == first variant: %s" % (nu, 2 * nu * 674, name, ms, ms / nu, bool(torch.equal(mel, ref))), flush=True)
-opt(big_rows=2000, fused_band=1, band_qkv=1, band_bm=0)
+opt(big_rows=2000, fused_band=1, band_qkv=1, band_bm=0, est_streams=1)
