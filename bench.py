@@ -607,7 +607,7 @@ MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 
 
 def roofline_mfma(model, cfgs, n_utt=8):
     """The MFMA-bound side of the path (north_star: "rocprof HBM GB/s and MFMA-busy counters against chip peak"): one transformer block of the flow estimator in an
-    8-utterance shared pass (M = 2 x 8 x 674 = 10 784 rows - what tts_batch / tts_queue run) is three launches; each is timed live as 20 back-to-back launches between
+    8-utterance shared pass (M = 2 x 8 x 674 = 10 784 rows - what tts_batch / tts_queue run) is two launches (attention, band; a stage's first block adds the QKV GEMM); each is timed live as 20 back-to-back launches between
     one HIP-event pair on the current stream (cv_flow_profile_block) and priced at its ALGORITHMIC flops (2 x MACs of the dense contractions).
     The record's headline is the launch with the largest share of the block; MFMA-busy comes from the PMC pass committed under profiles/ (separate rocprofv3 run)."""
     import hashlib
@@ -624,8 +624,8 @@ def roofline_mfma(model, cfgs, n_utt=8):
     band_qkv = os.environ.get("CV_FLOW_BAND_QKV", "1") != "0"
     flops = {"flow_gemm_big_kernel<64,64,0> QKV (bf16 out, V^T transposed)%s" % (" - first block of a stage only" if band_qkv else ""): 2.0 * M * C_ * 3 * inner,
              "attn_flow_kernel flash attention (QK^T + PV over all keys)": 4.0 * nz * H * T * T * 64,
-             ("flow_band_kernel out-projection + LayerNorm + FF1 + GELU + FF2 + next LayerNorm + next QKV GEMM, 64-row bands" if band_qkv else
-              "flow_band_kernel out-projection + LayerNorm + FF1 + GELU + FF2 (+ next LayerNorm), 64-row bands"): 2.0 * M * (C_ * inner + 2 * C_ * FF + (C_ * 3 * inner if band_qkv else 0))}
+             ("flow_band_kernel out-projection + LayerNorm + FF1 + GELU + FF2 + next LayerNorm + next QKV GEMM, one launch per row band (48 rows at this size)" if band_qkv else
+              "flow_band_kernel out-projection + LayerNorm + FF1 + GELU + FF2 (+ next LayerNorm), one launch per row band (48 rows at this size)"): 2.0 * M * (C_ * inner + 2 * C_ * FF + (C_ * 3 * inner if band_qkv else 0))}
     per = {}
     for (name, fl), t in zip(flops.items(), us):
         per[name] = {"flops_per_launch": int(fl), "avg_launch_us": round(float(t), 2), "TFLOPs": round(fl / (t * 1e-6) / 1e12, 1), "frac_of_peak": round(fl / (t * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)}

@@ -188,7 +188,10 @@ int cv_flow_finalize(cv_flow* m);
  * mode: fused transformer blocks, 1), "flow_tile" / "flow_ntile" / "attn_waves" / "attn_kt" / "attn_ks" (tile choices, 0 = by size).  Measured alternatives, default off:
  * "fused_tail" (+ "tail_ring" 8 | 16), "est_streams" (1 | 2); "graph_cap" (1 .. 256 cached shapes).  Round 5: "big_rows" (2000: passes of at least this many estimator rows run
  * on the large-M kernel set, csrc/flow_big.h), "fused_band" (1: in such passes everything between a block's attention and the next QKV GEMM is one launch per row band,
- * csrc/flow_band.h), "band64_rows" (10000: 64-row bands from this many rows, 32-row bands below).  Every combination is bit-identical per utterance. */
+ * csrc/flow_band.h), "band_qkv" (1: that launch also runs the NEXT block's QKV GEMM - a block of a large pass is two launches, attention and band), "band_bm" (0: rows
+ * per band by the row count of the pass - 32 / 48 / 64, csrc/flow.hip::band_rows_for; 32 | 48 | 64 forces), "eager_streams" (1; 2: the batch rows of a pass that runs
+ * eager as two launch chains on two streams - faster in isolation, slower next to the model's token2wav lanes, profiles/r5_band_qkv.txt).  Every combination is
+ * bit-identical per utterance. */
 int cv_flow_set_option(cv_flow* m, const char* name, int32_t value);
 /* "graph_captures" (Euler-solve graphs captured so far), "graphs_cached" (held now; option "graph_cap", default 32) - test / monitoring hook, no reference counterpart */
 int cv_flow_get_stat(cv_flow* m, const char* name, int64_t* value);
