@@ -85,6 +85,9 @@ struct cv_flow {
                                        // replaces.  Off by default; bit-identical to the five-launch form, tested both ways.
     int band_qkv = 1;                  // with fused_band: the band launch also runs the NEXT block's QKV GEMM (flow_band_kernel<.., HAS_QKV>): a block of a large pass is two launches
                                        // (attention, band); bit-identical; option "band_qkv", env CV_FLOW_BAND_QKV
+    int band_pipe = 2;                 // option "band_pipe" (env CV_FLOW_BAND_PIPE): the FF1 -> GELU -> FF2 chunks of a band as a software pipeline (flow_band_kernel<.., PIPE>): 0 = never,
+                                       // 1 = 48-row bands, 2 = 48- and 32-row bands (default; a 32-row band then holds 96 KB of LDS - one workgroup per CU instead of two - and is
+                                       // still faster: 8 / 6 / 4 utterances of U10 per pass 79.1 -> 77.6 / 64.9 -> 63.4 / 52.1 -> 50.8 ms, profiles/r5_band_qkv.txt section 4)
     int band_bm = 0;                   // option "band_bm" (env CV_FLOW_BAND_BM): rows per band 32 / 48 / 64 whatever the row count; 0 = by the row count of the pass (band_rows_for)
     int fused_band = 1;                // bf16 mode, large passes (big_rows): everything between a block's attention and the next block's QKV GEMM in ONE launch per 64-row band
                                        // (flow_band.h) instead of five (out-projection, LayerNorm, FF1, FF2, LayerNorm); bit-identical; option "fused_band", env CV_FLOW_BAND
@@ -245,6 +248,7 @@ static void flow_finalize(cv_flow* m) {
     if (const char* e = getenv("CV_FLOW_EAGER_STREAMS")) m->eager_streams = atoi(e) >= 2 ? 2 : 1;
     if (const char* e = getenv("CV_FLOW_BAND_QKV")) m->band_qkv = e[0] != '0';
     if (const char* e = getenv("CV_FLOW_BAND_BM")) m->band_bm = atoi(e);
+    if (const char* e = getenv("CV_FLOW_BAND_PIPE")) m->band_pipe = atoi(e);
     if (const char* e = getenv("CV_FLOW_BAND")) m->fused_band = e[0] != '0';        // dev knob for A/B runs (also: option "fused_band")
     if (const char* e = getenv("CV_FLOW_TAIL")) m->fused_tail = e[0] != '0';        // dev knob for A/B runs (also: option "fused_tail")
     if (const char* e = getenv("CV_FLOW_TAIL_RING")) m->tail_ring = atoi(e) == 16 ? 16 : 8;
@@ -542,15 +546,16 @@ static void conv_big(const Lin& l, const bf16_t* A, int T, int nz, int pad_left,
 }
 // everything between the attention of block `t` and the QKV GEMM of the next block - or, with `q`, up to and including that GEMM - in one launch, 64 / 48 / 32 rows
 // per workgroup (flow_band.h)
-// Rows per band of a pass of M rows (every height computes the same bits): a band is one dependent chain of ~40 - 75 us, so what matters is how many ROUNDS of bands
-// the chip runs and how tall a band of the last round is.  Launch time of flow_band_kernel<.., HAS_QKV> by height and workgroup count k, from tools/ubench/bandq_probe
-// (profiles/r5_bandq_probe.txt; 64- and 48-row bands: one workgroup per CU, 32-row bands: two): t64 = 54 + 0.115 k, t48 = 45 + 0.10 k, t32 = 23 + 0.10 k up to one per
-// CU and ~70 - 80 us once CUs hold two.  8 utterances of U10 (10 784 rows) -> 48 rows (225 workgroups, one round), up to 8192 rows -> 32, 12 - 16 k rows -> 64.
+// Rows per band of a pass of M rows (every height computes the same bits): a band is one dependent chain of ~35 - 55 us, so what matters is how many ROUNDS of bands
+// the chip runs (one workgroup per CU at every height: the pipelined 32-row form holds 96 KB of LDS) and how tall a band of the last round is.  Launch time of
+// flow_band_kernel<.., HAS_QKV> by height and workgroup count k, from tools/ubench/bandq_probe (profiles/r5_band_qkv.txt section 4: after the staging arrays left
+// scratch memory): t64 = 50 + 0.026 k, t48 = 41.5 + 0.015 k (pipelined), t32 = 30 + 0.03 k (pipelined).  8 utterances of U10 (10 784 rows) -> 48 rows (225 workgroups,
+// one round), up to 8192 rows -> 32, 12 - 16 k rows -> 64.
 static int band_rows_for(int M) {
-    auto t = [](int bm, int k) { return bm == 64 ? 54.f + 0.115f * k : bm == 48 ? 45.f + 0.10f * k : k <= 256 ? 23.f + 0.10f * k : 1.05f * (70.f + 0.035f * (k - 256)); };
+    auto t = [](int bm, int k) { return bm == 64 ? 50.f + 0.026f * k : bm == 48 ? 41.5f + 0.015f * k : 30.f + 0.03f * k; };
     int best = 32; float best_t = 1e30f;
     for (int bm : {32, 48, 64}) {
-        const int n = (M + bm - 1) / bm, cap = bm == 32 ? 512 : 256, full = n / cap, rem = n % cap;
+        const int n = (M + bm - 1) / bm, cap = 256, full = n / cap, rem = n % cap;
         const float est = full * t(bm, cap) + (rem ? t(bm, rem) : 0.f);
         if (est < best_t) { best_t = est; best = bm; }
     }
@@ -558,13 +563,15 @@ static int band_rows_for(int M) {
 }
 struct BandQkv { bf16_t* qk; int ld_qk; bf16_t* vt; long long vt_batch; int ldt; int rows_per_batch; };
 template <int C, int INNER, int FF, int NW>
-static void flow_band_launch(const FlowBandArgs& a, bool has_next, bool qkv, int bm, hipStream_t s) {
+static void flow_band_launch(const FlowBandArgs& a, bool has_next, bool qkv, int bm, bool pipe, hipStream_t s) {
     const dim3 g((unsigned)((a.M + bm - 1) / bm)), b(NW * 64);
-#define CV_BAND(BM_)                                                                                                                        \
-    if (qkv) hipLaunchKernelGGL((flow_band_kernel<C, INNER, FF, true, NW, 0, BM_, true>), g, b, 0, s, a);                                   \
-    else if (has_next) hipLaunchKernelGGL((flow_band_kernel<C, INNER, FF, true, NW, 0, BM_, false>), g, b, 0, s, a);                        \
-    else hipLaunchKernelGGL((flow_band_kernel<C, INNER, FF, false, NW, 0, BM_, false>), g, b, 0, s, a);
-    if (bm == 64) { CV_BAND(64) } else if (bm == 48) { CV_BAND(48) } else { CV_BAND(32) }
+#define CV_BAND(BM_, PIPE_)                                                                                                                 \
+    if (qkv) hipLaunchKernelGGL((flow_band_kernel<C, INNER, FF, true, NW, 0, BM_, true, PIPE_>), g, b, 0, s, a);                            \
+    else if (has_next) hipLaunchKernelGGL((flow_band_kernel<C, INNER, FF, true, NW, 0, BM_, false, PIPE_>), g, b, 0, s, a);                 \
+    else hipLaunchKernelGGL((flow_band_kernel<C, INNER, FF, false, NW, 0, BM_, false, PIPE_>), g, b, 0, s, a);
+    if (bm == 64) { CV_BAND(64, false) }
+    else if (bm == 48) { if (pipe) { CV_BAND(48, true) } else { CV_BAND(48, false) } }
+    else { if (pipe) { CV_BAND(32, true) } else { CV_BAND(32, false) } }
 #undef CV_BAND
 }
 static void flow_band(const cv_flow* m, const TBlockW& t, bool has_next, const BandQkv* q, const bf16_t* att, int inner, float* x, int C, int M, bf16_t* xn, hipStream_t s) {
@@ -573,8 +580,9 @@ static void flow_band(const cv_flow* m, const TBlockW& t, bool has_next, const B
     CV_CHECK(t.band && t.tail_prm && (!has_next || t.tail_qkv) && (!q || (has_next && t.bandq)), "flow_band: block was not packed for this call");
     if (q) { a.qk = q->qk; a.ld_qk = q->ld_qk; a.vt = q->vt; a.vt_batch = q->vt_batch; a.ldt = q->ldt; a.rows_per_batch = q->rows_per_batch > 0 ? q->rows_per_batch : M; }
     const int bm = m->band_bm ? m->band_bm : band_rows_for(m->rule_rows > M ? (int)m->rule_rows : M);
-    if (C == 256 && inner == 512) flow_band_launch<256, 512, 1024, 8>(a, has_next, q != nullptr, bm, s);
-    else if (C == 64 && inner == 64) flow_band_launch<64, 64, 256, 4>(a, has_next, q != nullptr, bm, s);
+    const bool pipe = bm == 48 ? m->band_pipe >= 1 : bm == 32 ? m->band_pipe >= 2 : false;
+    if (C == 256 && inner == 512) flow_band_launch<256, 512, 1024, 8>(a, has_next, q != nullptr, bm, pipe, s);
+    else if (C == 64 && inner == 64) flow_band_launch<64, 64, 256, 4>(a, has_next, q != nullptr, bm, pipe, s);
     else throw Error("flow_band: no instantiation for these dimensions");
 }
 
@@ -978,6 +986,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "graph_cap") { CV_CHECK(value >= 1 && value <= 256, "graph_cap must be 1 .. 256"); drop_graphs(m); m->graph_cap = (size_t)value; }
         else if (std::string(name) == "fused_tail") { m->fused_tail = value != 0; drop_graphs(m); }
         else if (std::string(name) == "band_qkv") { m->band_qkv = value != 0; drop_graphs(m); }
+        else if (std::string(name) == "band_pipe") { CV_CHECK(value >= 0 && value <= 2, "band_pipe must be 0, 1 or 2"); m->band_pipe = value; drop_graphs(m); }
         else if (std::string(name) == "band_bm") { CV_CHECK(value == 0 || value == 32 || value == 48 || value == 64, "band_bm must be 0, 32, 48 or 64"); m->band_bm = value; drop_graphs(m); }
         else if (std::string(name) == "fused_band") { m->fused_band = value != 0; drop_graphs(m); }      // bf16 mode, large passes: one 64-row band launch between attention and the next QKV GEMM (flow_band.h) on / off
         else if (std::string(name) == "flow_ntile") { CV_CHECK(value >= 0 && value <= 2, "flow_ntile must be 0, 1 or 2"); m->flow_ntile = value; drop_graphs(m); }

@@ -42,15 +42,16 @@ struct FlowBandArgs {
 
 // one pass: PT 16-column tiles x KS k-steps of 32 against the 4 row tiles of the band.  A: bf16 pairs in LDS, row pitch `pitch` dwords, first dword k0.
 // SWAP: the activations as the MFMA "A" operand - a lane ends with 4 consecutive ROWS of one column (the V^T epilogue) instead of 4 consecutive columns of one row.
-template <int PT, int KS, int MODE = 0, int RT = 4, bool SWAP = false>
+// KS0: first k-step (the pipelined form multiplies a pass in slices of k-steps between the pieces of its GELU).
+template <int PT, int KS, int MODE = 0, int RT = 4, bool SWAP = false, int KS0 = 0>
 __device__ __forceinline__ void band_mma(const u32x4_t (&w)[16], const unsigned* A, int pitch, int k0, int lq, int lg, v4f (&acc)[RT][PT]) {
     if constexpr (MODE == 2) {                // probe: consume the fragments without the matrix pipe or LDS
 #pragma unroll
-        for (int i = 0; i < PT * KS; ++i) acc[0][0][0] += __uint_as_float(w[i][0] ^ w[i][1] ^ w[i][2] ^ w[i][3]);
+        for (int i = PT * KS0; i < PT * KS; ++i) acc[0][0][0] += __uint_as_float(w[i][0] ^ w[i][1] ^ w[i][2] ^ w[i][3]);
         return;
     }
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = KS0; ks < KS; ++ks) {
         uint4 af[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -125,7 +126,11 @@ struct FlowBandShape {
 // HAS_QKV (implies HAS_NEXT; the stream then carries the next block's QKV fragments behind the FF ones, weights.py::pack_flow_band(.., w_qkv_next)): the band also runs
 // the next block's QKV GEMM on its LayerNorm rows - Q | K rows and the V^T columns go straight from the accumulators to memory (the values and stores of
 // flow_gemm_big_kernel<.., OMODE 0>'s direct epilogue), so a block of a large pass is TWO launches (attention, band) and the bf16 LayerNorm rows never exist in memory.
-template <int C, int INNER, int FF, bool HAS_NEXT, int NW, int MODE = 0, int BM = 64, bool HAS_QKV = false>
+// PIPE (second session of round 5; bands of at most 48 rows - the second GELU tile does not fit next to a 64-row band): the FF1 -> GELU -> FF2 chunks as a software
+// pipeline.  Stage j multiplies FF2 of chunk j - 1 and FF1 of chunk j + 1 in slices of k-steps BETWEEN the pieces of chunk j's GELU, so the matrix pipe works under the
+// epilogue's VALU instructions (the rolled form runs them one after the other: 96 MFMAs = 1.5 k cycles per wave, then ~390 VALU instructions = 2.1 k), and a chunk costs
+// ONE barrier instead of two: the GELU tiles alternate between two LDS buffers.  Same products in the same order per output element: the same bits.
+template <int C, int INNER, int FF, bool HAS_NEXT, int NW, int MODE = 0, int BM = 64, bool HAS_QKV = false, bool PIPE = false>
 __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
     using S = FlowBandShape<C, INNER, FF, NW>;
     constexpr int NT = NW * 64, TA = S::TA, RT = BM / 16;
@@ -136,6 +141,8 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
     __shared__ __attribute__((aligned(16))) float X1[BM * PX];
     __shared__ __attribute__((aligned(16))) unsigned OP[OPS];
     unsigned* const A0 = OP; unsigned* const A1 = OP; unsigned* const A2 = OP + BM * PA1;
+    static_assert(!PIPE || (BM <= 48 && S::NCH >= 2), "flow_band: the pipelined chunks need a second GELU tile in LDS (bands of at most 48 rows)");
+    __shared__ __attribute__((aligned(16))) unsigned A2B[PIPE ? BM * PA1 : 4];      // PIPE: the GELU tile of the odd chunks
     constexpr int O_BOUT = 0, O_G3 = C, O_BE3 = 2 * C, O_BFF1 = 3 * C, O_BFF2 = 3 * C + FF, O_G1N = 4 * C + FF, O_BE1N = 5 * C + FF, NPRM = 6 * C + FF;
     __shared__ __attribute__((aligned(16))) float prm[NPRM];
     const int tid = threadIdx.x, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
@@ -144,9 +151,9 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
 
     // ---- the band's small operands, its attention tile and its residual rows FIRST (unconditional, clamped), then the first pass of the weight stream
     constexpr int NPV = NPRM / 4, PPT = (NPV + NT - 1) / NT;
-    float4 pv[PPT];
+    v4f pv[PPT];
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) pv[i] = *reinterpret_cast<const float4*>(p.prm + 4 * min(tid + NT * i, NPV - 1));
+    for (int i = 0; i < PPT; ++i) pv[i] = *reinterpret_cast<const v4f*>(p.prm + 4 * min(tid + NT * i, NPV - 1));
     constexpr int APC = BM * INNER / 8, APT = (APC + NT - 1) / NT;          // 16-byte pieces of the attention tile per thread
     u32x4_t av[APT];
 #pragma unroll
@@ -155,11 +162,14 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
         av[i] = *reinterpret_cast<const u32x4_t*>(p.att + (long long)min(m0 + r, p.M - 1) * p.ld_att + c * 8);
     }
     constexpr int XPC = BM * C / 4, XPT = (XPC + NT - 1) / NT;              // float4 pieces of the residual tile per thread
-    float4 xv[XPT];
+    // (native vectors, not the float4 struct: as float4 these staging arrays stayed allocas - parked in spare LDS where there was some, in SCRATCH otherwise: 6 - 8
+    // scratch stores and loads per lane in the staging phase of every band, found in the second session of round 5 through the pipelined form, which leaves no spare LDS)
+    using XV = v4f;
+    XV xv[XPT];
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
         const int v = min(tid + NT * i, XPC - 1), r = v / (C / 4), c = v % (C / 4);
-        xv[i] = *reinterpret_cast<const float4*>(p.x + (long long)min(m0 + r, p.M - 1) * p.ldx + c * 4);
+        xv[i] = *reinterpret_cast<const XV*>(p.x + (long long)min(m0 + r, p.M - 1) * p.ldx + c * 4);
     }
     __builtin_amdgcn_sched_barrier(0);
     const u32x4_t* ws = p.wstream + (long long)wave * (HAS_QKV ? S::TOTALQ : S::TOTAL) * 64 + lane;
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
     auto stamp = [&]() { if (dbg && tid == 0) dbg[dn++] = clock64(); };
     stamp();                                                                // 0: requests issued
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) { const int v = tid + NT * i; if (v < NPV) *reinterpret_cast<float4*>(&prm[4 * v]) = pv[i]; }
+    for (int i = 0; i < PPT; ++i) { const int v = tid + NT * i; if (v < NPV) *reinterpret_cast<v4f*>(&prm[4 * v]) = pv[i]; }
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
         const int v = tid + NT * i;
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
         const int v = tid + NT * i;
-        if (v < XPC) *reinterpret_cast<float4*>(&X1[(v / (C / 4)) * PX + (v % (C / 4)) * 4]) = xv[i];
+        if (v < XPC) *reinterpret_cast<XV*>(&X1[(v / (C / 4)) * PX + (v % (C / 4)) * 4]) = xv[i];
     }
     __syncthreads();
     stamp();                                                                // 1: operands staged
@@ -231,37 +241,99 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
         for (int t = 0; t < TA; ++t) acc2[rt][t] = (v4f){0.f, 0.f, 0.f, 0.f};
     constexpr int F0 = TA * S::KA;                                          // first fragment of the FF stream
     constexpr bool FF1_IN_WB1 = S::NPA == 1;
-#pragma unroll 1
-    for (int j = 0; j < S::NCH; ++j) {                                      // a real loop: every chunk runs the same code on the same two buffers (and the epilogue's GELU stays one copy)
-        v4f acc1[RT][TA];
+    if constexpr (PIPE) {
+        // wbF holds the FF1 passes (chunk 0 is in it: loaded under the out-projection), wbG the FF2 passes; a pass is requested as soon as its buffer has been multiplied
+        auto& wbF = FF1_IN_WB1 ? wb1 : wb0;
+        auto& wbG = FF1_IN_WB1 ? wb0 : wb1;
+        constexpr int NU = RT * TA;                                         // GELU pieces of a chunk per wave: one 16 x 16 accumulator tile each
+        constexpr int KC = S::KC;
+        v4f acc1[2][RT][TA];
+        auto zero1 = [&](int b) {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int t = 0; t < TA; ++t) acc1[rt][t] = (v4f){0.f, 0.f, 0.f, 0.f};
-        // FF1 chunk j is in buffer X (loaded one pass ago); request FF2 chunk j into the other buffer, multiply
-        if constexpr (FF1_IN_WB1) { band_wload<FCD, MODE>(wb0, ws, F0 + (2 * j + 1) * FCD); band_mma<TA, S::KC, MODE, RT>(wb1, A1, PA1, 0, lq, lg, acc1); }
-        else                      { band_wload<FCD, MODE>(wb1, ws, F0 + (2 * j + 1) * FCD); band_mma<TA, S::KC, MODE, RT>(wb0, A1, PA1, 0, lq, lg, acc1); }
-#pragma unroll
-        for (int t = 0; t < TA; ++t) {
-            const int n = 16 * (wave + NW * t) + 4 * lg;                    // column inside the chunk
-            const float4 b = *reinterpret_cast<const float4*>(&prm[O_BFF1 + j * C + n]);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const float4 y = gelu_erf4(make_float4(acc1[rt][t][0] + b.x, acc1[rt][t][1] + b.y, acc1[rt][t][2] + b.z, acc1[rt][t][3] + b.w));      // = apply_act4(ACT_GELU_ERF, ..), inlined
-                *reinterpret_cast<uint2*>(&A2[(16 * rt + lq) * PA1 + n / 2]) = make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+                for (int t = 0; t < TA; ++t) acc1[b][rt][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+        };
+        band_wload<FCD, MODE>(wbG, ws, F0 + FCD);                           // FF2 chunk 0
+        zero1(0);
+        band_mma<TA, KC, MODE, RT>(wbF, A1, PA1, 0, lq, lg, acc1[0]);      // FF1 chunk 0
+        band_wload<FCD, MODE>(wbF, ws, F0 + 2 * FCD);                       // FF1 chunk 1
+        band_static_for<0, S::NCH>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr bool HAS_F2 = j >= 1, HAS_F1 = j + 1 < S::NCH;        // FF2 of chunk j - 1 (its GELU tile was completed by the last barrier), FF1 of chunk j + 1
+            constexpr int NSTEP = (HAS_F2 ? KC : 0) + (HAS_F1 ? KC : 0);    // k-steps of this stage: FF2 first, then FF1
+            unsigned* const Gw = (j & 1) ? A2B : A2;                        // this chunk's GELU tile
+            const unsigned* const Gr = (j & 1) ? A2 : A2B;                  // the previous chunk's
+            if constexpr (HAS_F1) zero1((j + 1) & 1);
+            band_static_for<0, NU>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                constexpr int s0 = NSTEP * u / NU, s1 = NSTEP * (u + 1) / NU;       // this piece's slice of the stage's k-steps
+                band_static_for<s0, s1>([&](auto sc) {
+                    constexpr int st = decltype(sc)::value;
+                    if constexpr (HAS_F2 && st < KC) {
+                        band_mma<TA, st + 1, MODE, RT, false, st>(wbG, Gr, PA1, 0, lq, lg, acc2);
+                        if constexpr (st == KC - 1) {                       // wbG is free: FF2 of chunk j (or, after the last one, QKV pass 1)
+                            if constexpr (j < S::NCH) band_wload<FCD, MODE>(wbG, ws, F0 + (2 * j + 1) * FCD);
+                        }
+                    } else {
+                        constexpr int k = st - (HAS_F2 ? KC : 0);
+                        band_mma<TA, k + 1, MODE, RT, false, k>(wbF, A1, PA1, 0, lq, lg, acc1[(j + 1) & 1]);
+                        if constexpr (k == KC - 1) {                        // wbF is free: FF1 of chunk j + 2, or (HAS_QKV) the first QKV pass
+                            if constexpr (j + 2 < S::NCH) band_wload<FCD, MODE>(wbF, ws, F0 + 2 * (j + 2) * FCD);
+                            else if constexpr (HAS_QKV) band_wload<FCD, MODE>(wbF, ws, S::FQ0);
+                        }
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);                          // the slices stay between the pieces (left alone the scheduler gathers the MFMAs in front of the epilogue again)
+                {
+                    constexpr int t = u / RT, rt = u % RT;
+                    const int n = 16 * (wave + NW * t) + 4 * lg;            // column inside the chunk
+                    const float4 b = *reinterpret_cast<const float4*>(&prm[O_BFF1 + j * C + n]);
+                    const v4f a = acc1[j & 1][rt][t];
+                    const float4 y = gelu_erf4(make_float4(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w));
+                    *reinterpret_cast<uint2*>(&Gw[(16 * rt + lq) * PA1 + n / 2]) = make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            __syncthreads();                                                // chunk j's GELU tile is complete; the other tile may be overwritten by the next stage
+            stamp();
+        });
+        // FF2 of the last chunk; then (HAS_QKV) QKV pass 1 into wbG
+        band_mma<TA, KC, MODE, RT>(wbG, ((S::NCH - 1) & 1) ? A2B : A2, PA1, 0, lq, lg, acc2);
+        if constexpr (HAS_QKV) band_wload<FCD, MODE>(wbG, ws, S::FQ0 + FCD);
+    } else {
+    #pragma unroll 1
+        for (int j = 0; j < S::NCH; ++j) {                                      // a real loop: every chunk runs the same code on the same two buffers (and the epilogue's GELU stays one copy)
+            v4f acc1[RT][TA];
+    #pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+    #pragma unroll
+                for (int t = 0; t < TA; ++t) acc1[rt][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+            // FF1 chunk j is in buffer X (loaded one pass ago); request FF2 chunk j into the other buffer, multiply
+            if constexpr (FF1_IN_WB1) { band_wload<FCD, MODE>(wb0, ws, F0 + (2 * j + 1) * FCD); band_mma<TA, S::KC, MODE, RT>(wb1, A1, PA1, 0, lq, lg, acc1); }
+            else                      { band_wload<FCD, MODE>(wb1, ws, F0 + (2 * j + 1) * FCD); band_mma<TA, S::KC, MODE, RT>(wb0, A1, PA1, 0, lq, lg, acc1); }
+    #pragma unroll
+            for (int t = 0; t < TA; ++t) {
+                const int n = 16 * (wave + NW * t) + 4 * lg;                    // column inside the chunk
+                const float4 b = *reinterpret_cast<const float4*>(&prm[O_BFF1 + j * C + n]);
+    #pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const float4 y = gelu_erf4(make_float4(acc1[rt][t][0] + b.x, acc1[rt][t][1] + b.y, acc1[rt][t][2] + b.z, acc1[rt][t][3] + b.w));      // = apply_act4(ACT_GELU_ERF, ..), inlined
+                    *reinterpret_cast<uint2*>(&A2[(16 * rt + lq) * PA1 + n / 2]) = make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+                }
             }
+            __syncthreads();                                                    // the chunk's hidden tile is complete
+            // FF2 chunk j; request FF1 chunk j + 1 (unconditional: after the last chunk the request repeats that chunk's FF1 fragments and is never used)
+            // (HAS_QKV: after the last chunk the request is the first QKV pass of the next block instead)
+            const int nxt = (HAS_QKV && j == S::NCH - 1) ? S::FQ0 : F0 + 2 * min(j + 1, S::NCH - 1) * FCD;
+            if constexpr (FF1_IN_WB1) { band_wload<FCD, MODE>(wb1, ws, nxt); band_mma<TA, S::KC, MODE, RT>(wb0, A2, PA1, 0, lq, lg, acc2); }
+            else                      { band_wload<FCD, MODE>(wb0, ws, nxt); band_mma<TA, S::KC, MODE, RT>(wb1, A2, PA1, 0, lq, lg, acc2); }
+            __syncthreads();                                                    // before the next chunk overwrites A2 (and before the epilogue below touches X1's neighbours)
+            stamp();                                                            // 4 .. 3 + NCH: chunk j done
         }
-        __syncthreads();                                                    // the chunk's hidden tile is complete
-        // FF2 chunk j; request FF1 chunk j + 1 (unconditional: after the last chunk the request repeats that chunk's FF1 fragments and is never used)
-        // (HAS_QKV: after the last chunk the request is the first QKV pass of the next block instead)
-        const int nxt = (HAS_QKV && j == S::NCH - 1) ? S::FQ0 : F0 + 2 * min(j + 1, S::NCH - 1) * FCD;
-        if constexpr (FF1_IN_WB1) { band_wload<FCD, MODE>(wb1, ws, nxt); band_mma<TA, S::KC, MODE, RT>(wb0, A2, PA1, 0, lq, lg, acc2); }
-        else                      { band_wload<FCD, MODE>(wb0, ws, nxt); band_mma<TA, S::KC, MODE, RT>(wb1, A2, PA1, 0, lq, lg, acc2); }
-        __syncthreads();                                                    // before the next chunk overwrites A2 (and before the epilogue below touches X1's neighbours)
-        stamp();                                                            // 4 .. 3 + NCH: chunk j done
-    }
-    if constexpr (HAS_QKV) {                                                // QKV pass 1 into the buffer the last FF2 chunk has just left (pass 0 sits in the other one)
-        if constexpr (FF1_IN_WB1) band_wload<FCD, MODE>(wb0, ws, S::FQ0 + FCD); else band_wload<FCD, MODE>(wb1, ws, S::FQ0 + FCD);
+        if constexpr (HAS_QKV) {                                                // QKV pass 1 into the buffer the last FF2 chunk has just left (pass 0 sits in the other one)
+            if constexpr (FF1_IN_WB1) band_wload<FCD, MODE>(wb0, ws, S::FQ0 + FCD); else band_wload<FCD, MODE>(wb1, ws, S::FQ0 + FCD);
+        }
     }
     // ---- FF2 epilogue: + bias + residual -> X1 (the new residual stream)
 #pragma unroll

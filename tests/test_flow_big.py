@@ -93,19 +93,20 @@ def test_band_kernel_is_bit_identical(lib, est_blocks):
                 outs = []
                 # band_bm = 64 / 48 / 32 rows per band (four, three - a ragged LayerNorm pass - or two row tiles per weight fragment), 0 = by the row count of the pass;
                 # band_qkv = 1: the band launch also runs the NEXT block's QKV GEMM (Q | K rows and V^T columns straight from the accumulators) - only with a next block
-                variants = [(0, 0, 0, 0), (1, 0, 0, 0), (1, 1, 64, 0), (1, 1, 32, 0), (1, 1, 48, 0)]
+                # band_pipe = 1 / 2: the FF1 -> GELU -> FF2 chunks of a 48-row (and 32-row) band as a software pipeline (MFMA slices between the GELU pieces, two GELU tiles)
+                variants = [(0, 0, 0, 0, 0), (1, 0, 0, 0, 0), (1, 1, 64, 0, 0), (1, 1, 32, 0, 0), (1, 1, 48, 0, 0), (1, 1, 48, 0, 1), (1, 1, 32, 0, 2)]
                 if est_blocks > 1:
-                    variants += [(1, 1, 64, 1), (1, 1, 32, 1), (1, 1, 48, 1), (1, 1, 0, 1)]
-                for big, band, bm, qkv in variants:
+                    variants += [(1, 1, 64, 1, 0), (1, 1, 32, 1, 0), (1, 1, 48, 1, 0), (1, 1, 48, 1, 1), (1, 1, 32, 1, 2), (1, 1, 0, 1, 1)]
+                for big, band, bm, qkv, pipe in variants:
                     lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(big)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(band))
-                    lib.cv_flow_set_option(flow._h, b"band_bm", C.c_int32(bm)); lib.cv_flow_set_option(flow._h, b"band_qkv", C.c_int32(qkv))
+                    lib.cv_flow_set_option(flow._h, b"band_bm", C.c_int32(bm)); lib.cv_flow_set_option(flow._h, b"band_qkv", C.c_int32(qkv)); lib.cv_flow_set_option(flow._h, b"band_pipe", C.c_int32(pipe))
                     outs.append(flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu().clone())
                 assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
                 for k in range(1, len(outs)):
                     assert torch.equal(outs[0], outs[k]), (T, streaming, k, (outs[0] - outs[k]).abs().max().item())
     finally:
         lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(5000)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(1))
-        lib.cv_flow_set_option(flow._h, b"band_bm", C.c_int32(0)); lib.cv_flow_set_option(flow._h, b"band_qkv", C.c_int32(1))
+        lib.cv_flow_set_option(flow._h, b"band_bm", C.c_int32(0)); lib.cv_flow_set_option(flow._h, b"band_qkv", C.c_int32(1)); lib.cv_flow_set_option(flow._h, b"band_pipe", C.c_int32(2))
 
 
 def test_band_kernel_at_the_real_width(lib):
@@ -123,16 +124,16 @@ def test_band_kernel_at_the_real_width(lib):
     spk = torch.randn(2, 80, generator=g); t = torch.tensor([0.6, 0.6]); mask = torch.ones(2, 1, T)
     try:
         outs = []
-        for big, band, bm, qkv in ((0, 0, 0, 0), (1, 0, 0, 0), (1, 1, 64, 0), (1, 1, 32, 0), (1, 1, 64, 1), (1, 1, 32, 1), (1, 1, 48, 1)):
+        for big, band, bm, qkv, pipe in ((0, 0, 0, 0, 0), (1, 0, 0, 0, 0), (1, 1, 64, 0, 0), (1, 1, 32, 0, 0), (1, 1, 64, 1, 0), (1, 1, 32, 1, 0), (1, 1, 48, 1, 0), (1, 1, 48, 1, 1), (1, 1, 48, 0, 1), (1, 1, 32, 1, 2)):
             lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(big)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(band))
-            lib.cv_flow_set_option(flow._h, b"band_bm", C.c_int32(bm)); lib.cv_flow_set_option(flow._h, b"band_qkv", C.c_int32(qkv))
+            lib.cv_flow_set_option(flow._h, b"band_bm", C.c_int32(bm)); lib.cv_flow_set_option(flow._h, b"band_qkv", C.c_int32(qkv)); lib.cv_flow_set_option(flow._h, b"band_pipe", C.c_int32(pipe))
             outs.append(flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=False).cpu().clone())
         assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
         for k in range(1, len(outs)):
             assert torch.equal(outs[0], outs[k]), (k, (outs[0] - outs[k]).abs().max().item())
     finally:
         lib.cv_flow_set_option(flow._h, b"big_rows", C.c_int32(5000)); lib.cv_flow_set_option(flow._h, b"fused_band", C.c_int32(1))
-        lib.cv_flow_set_option(flow._h, b"band_bm", C.c_int32(0)); lib.cv_flow_set_option(flow._h, b"band_qkv", C.c_int32(1))
+        lib.cv_flow_set_option(flow._h, b"band_bm", C.c_int32(0)); lib.cv_flow_set_option(flow._h, b"band_qkv", C.c_int32(1)); lib.cv_flow_set_option(flow._h, b"band_pipe", C.c_int32(2))
 
 
 def test_eager_large_pass_runs_two_chains(lib):

@@ -29,6 +29,10 @@ VARIANTS = [("small-tile path    ", dict(big_rows=1 << 30, fused_band=0, band_qk
             ("band + qkv, 48 rows", dict(fused_band=1, band_qkv=1, band_bm=48)),
             ("band + qkv, 32 rows", dict(fused_band=1, band_qkv=1, band_bm=32)),
             ("band, 48 rows      ", dict(fused_band=1, band_qkv=0, band_bm=48)),
+            ("+ qkv, 48, no pipe ", dict(fused_band=1, band_qkv=1, band_bm=48, band_pipe=0)),       # band_pipe: the FF chunks of a 48-row (2: and 32-row) band as a software pipeline
+            ("+ qkv, 32, pipe    ", dict(fused_band=1, band_qkv=1, band_bm=32, band_pipe=2)),
+            ("+ qkv, rule, pipe 2", dict(fused_band=1, band_qkv=1, band_bm=0, band_pipe=2)),
+            ("+ qkv, rule, pipe 0", dict(fused_band=1, band_qkv=1, band_bm=0, band_pipe=0)),
             ("2 chains, rule     ", dict(fused_band=1, band_qkv=1, band_bm=0, est_streams=2)),       # the batch rows as two launch chains on two streams (est_streams, round 3): eager passes only
             ("2 chains, 64 rows  ", dict(fused_band=1, band_qkv=1, band_bm=64, est_streams=2)),
             ("2 chains, 48 rows  ", dict(fused_band=1, band_qkv=1, band_bm=48, est_streams=2)),
@@ -36,7 +40,7 @@ VARIANTS = [("small-tile path    ", dict(big_rows=1 << 30, fused_band=0, band_qk
 for nu in nus:
     ref = None
     for name, kw in VARIANTS:
-        opt(**{"est_streams": 1, **kw})
+        opt(**{"est_streams": 1, "band_pipe": 1, **kw})
         for _ in range(2):
             out = flow.inference_batch([item] * nu)
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -48,4 +52,4 @@ for nu in nus:
         if ref is None:
             ref = mel
         print("%d utterance(s), M = %5d  %s  %7.2f ms per pass = %6.2f ms per utterance   mel == first variant: %s" % (nu, 2 * nu * 674, name, ms, ms / nu, bool(torch.equal(mel, ref))), flush=True)
-opt(big_rows=2000, fused_band=1, band_qkv=1, band_bm=0, est_streams=1)
+opt(big_rows=2000, fused_band=1, band_qkv=1, band_bm=0, est_streams=1, band_pipe=1)

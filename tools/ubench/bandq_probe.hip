@@ -33,12 +33,14 @@ static float time_graph(int n_units, const std::function<void(hipStream_t)>& enq
     return best;
 }
 
-template <int BM, int FORM>      // FORM 0: band (next LayerNorm rows out); 1: band + QKV; 2: band + QKV without its stores
+template <int BM, int FORM>      // FORM 0: band (next LayerNorm rows out); 1: band + QKV; 2: band + QKV without its stores; 3: band + QKV, pipelined FF chunks (<= 48 rows)
 static void launch(const FlowBandArgs& a, hipStream_t s) {
     const dim3 g((a.M + BM - 1) / BM), b(512);
-    if (FORM == 0) hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, true, 8, 0, BM, false>), g, b, 0, s, a);
-    else if (FORM == 1) hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, true, 8, 0, BM, true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, true, 8, 4, BM, true>), g, b, 0, s, a);
+    if constexpr (FORM == 0) hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, true, 8, 0, BM, false>), g, b, 0, s, a);
+    else if constexpr (FORM == 1) hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, true, 8, 0, BM, true>), g, b, 0, s, a);
+    else if constexpr (FORM == 2) hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, true, 8, 4, BM, true>), g, b, 0, s, a);
+    else if constexpr (BM <= 48) hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, true, 8, 0, BM, true, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((flow_band_kernel<256, 512, 1024, true, 8, 0, BM, true>), g, b, 0, s, a);       // (64 rows: no pipelined form)
 }
 
 int main() {
@@ -66,15 +68,15 @@ int main() {
     };
     // NOTE: the FORM 0 kernel walks the same buffers with the stride of the shorter stream (S::TOTAL): synthetic values, only the time matters
     printf("flow_band_kernel<256,512,1024, 8 waves>: %d + %d fragments of 1 KB per wave\n", S::TOTAL, S::TOTALQ - S::TOTAL);
-    const char* form_names[3] = {"band (next LayerNorm rows out)", "band + next QKV GEMM", "band + next QKV GEMM, stores removed"};
+    const char* form_names[4] = {"band (next LayerNorm rows out)", "band + next QKV GEMM", "band + next QKV GEMM, stores removed", "band + next QKV GEMM, pipelined FF chunks"};
     for (int M : {10784, 5392}) {
-        for (int form = 0; form < 3; ++form) {
+        for (int form = 0; form < 4; ++form) {
             printf("M = %5d  %-40s", M, form_names[form]);
             for (int bm : {64, 48, 32}) {
                 const float us = time_graph(NB, [&](hipStream_t s) {
                     for (int b = 0; b < NB; ++b) {
                         const FlowBandArgs a = args(b, M, nullptr);
-#define L(BM_) { if (form == 0) launch<BM_, 0>(a, s); else if (form == 1) launch<BM_, 1>(a, s); else launch<BM_, 2>(a, s); }
+#define L(BM_) { if (form == 0) launch<BM_, 0>(a, s); else if (form == 1) launch<BM_, 1>(a, s); else if (form == 2) launch<BM_, 2>(a, s); else launch<BM_, 3>(a, s); }
                         if (bm == 64) L(64) else if (bm == 48) L(48) else L(32)
 #undef L
                     } });
@@ -83,15 +85,16 @@ int main() {
             printf("\n"); fflush(stdout);
         }
     }
-    for (int bm : {64, 48}) {
+    for (int bm : {64, 48, -48}) {                                            // -48: 48 rows, pipelined FF chunks
+        const bool pipe = bm < 0; if (pipe) bm = -bm;
         const int M = 10784, nwg = (M + bm - 1) / bm;
-        for (int rep = 0; rep < 3; ++rep) { const FlowBandArgs a = args(7 + rep, M, dbg); if (bm == 64) launch<64, 1>(a, nullptr); else launch<48, 1>(a, nullptr); }
+        for (int rep = 0; rep < 3; ++rep) { const FlowBandArgs a = args(7 + rep, M, dbg); if (bm == 64) launch<64, 1>(a, nullptr); else if (pipe) launch<48, 3>(a, nullptr); else launch<48, 1>(a, nullptr); }
         (void)hipDeviceSynchronize();
         std::vector<long long> h((size_t)nwg * 16);
         (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
         const char* names[10] = {"staging of the band's operands, barrier", "A out-projection", "B LayerNorm", "C/D chunk 0", "C/D chunk 1", "C/D chunk 2", "C/D chunk 3",
                                  "FF2 epilogue, next LayerNorm", "F next QKV GEMM (6 passes) + stores", "write-out of x"};
-        printf("phase durations of thread 0, %d-row bands, M = %d (%d workgroups), shader clocks (mean over workgroups; max of the total):\n", bm, M, nwg);
+        printf("phase durations of thread 0, %d-row bands%s, M = %d (%d workgroups), shader clocks (mean over workgroups; max of the total):\n", bm, pipe ? ", pipelined FF chunks (stages 0 - 3, then the last FF2 + epilogue)" : "", M, nwg);
         double tot_mean = 0; long long tot_max = 0;
         for (int k = 0; k < 10; ++k) {
             double m = 0; for (int w = 0; w < nwg; ++w) m += (double)(h[(size_t)w * 16 + k + 1] - h[(size_t)w * 16 + k]) / nwg;
