@@ -234,7 +234,9 @@ __global__ __launch_bounds__(NW * 64) CV_WAVES_PER_EU(1, 2) void attention_bf16_
 
     // thread t stages the key PAIRS (2j, 2j+1), j = (t >> 4) + (NT/16) i, columns c4 .. c4+3: adjacent keys land in one dword of V^T
     const int c4 = (tid & 15) * 4, j0 = tid >> 4;
-    float4 rkA[NI][2], rvA[NI][2], rkB[NW == 4 ? NI : 1][2], rvB[NW == 4 ? NI : 1][2];
+    // (native vectors, not the float4 struct: as float4 these staging arrays stayed ALLOCAS - 144 bytes per lane, which the backend parked in LDS (36 KB per workgroup next
+    // to the 18 KB declared) or, with three waves per SIMD, in scratch: the "spill" the register budget above was pinned against.  Round 5, found through flow_band.h.)
+    v4f rkA[NI][2], rvA[NI][2], rkB[NW == 4 ? NI : 1][2], rvB[NW == 4 ? NI : 1][2];
     auto load_kv = [&](int kt0, auto& rk, auto& rv) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
@@ -243,9 +245,9 @@ __global__ __launch_bounds__(NW * 64) CV_WAVES_PER_EU(1, 2) void attention_bf16_
                 const int key = kt0 + 2 * (j0 + (NT / 16) * i) + par;
                 const bool ok = key < p.Tk;                   // unconditional loads (clamped row) keep the vmcnt bookkeeping exact
                 const long long kr = ok ? key : 0;
-                float4 kx = *reinterpret_cast<const float4*>(kb + kr * p.k_row + c4);
-                float4 vx = *reinterpret_cast<const float4*>(vb + kr * p.v_row + c4);
-                if (!ok) { kx = make_float4(0.f, 0.f, 0.f, 0.f); vx = kx; }
+                v4f kx = *reinterpret_cast<const v4f*>(kb + kr * p.k_row + c4);
+                v4f vx = *reinterpret_cast<const v4f*>(vb + kr * p.v_row + c4);
+                if (!ok) { kx = (v4f){0.f, 0.f, 0.f, 0.f}; vx = kx; }
                 rk[i][par] = kx; rv[i][par] = vx;
             }
     };

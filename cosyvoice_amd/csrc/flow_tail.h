@@ -119,9 +119,9 @@ __global__ __launch_bounds__(256) void flow_tail_kernel(FlowTailArgs p) {
 
     // ---- every small operand FIRST (vmcnt retires in order: what is requested behind the ring can only be had by draining it)
     constexpr int NPV = NPRM / 4, PPT = (NPV + 255) / 256;                  // float4 pieces of the parameter block per thread
-    float4 pv[PPT];
+    v4f pv[PPT];                                                            // (a native vector: as a float4 struct array this stayed an alloca parked in LDS)
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) pv[i] = *reinterpret_cast<const float4*>(p.prm + 4 * min(tid + 256 * i, NPV - 1));
+    for (int i = 0; i < PPT; ++i) pv[i] = *reinterpret_cast<const v4f*>(p.prm + 4 * min(tid + 256 * i, NPV - 1));
     constexpr int PIECES = BM * INNER / 8, APT = (PIECES + 255) / 256;      // 16-byte pieces of the attention tile per thread
     u32x4_t av[APT];
 #pragma unroll
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void flow_tail_kernel(FlowTailArgs p) {
 #pragma unroll
     for (int i = 0; i < D; ++i) ring[i] = ws[(long long)(i < S::TOTAL ? i : 0) * 64];
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) { const int v = tid + 256 * i; if (v < NPV) *reinterpret_cast<float4*>(&prm[4 * v]) = pv[i]; }
+    for (int i = 0; i < PPT; ++i) { const int v = tid + 256 * i; if (v < NPV) *reinterpret_cast<v4f*>(&prm[4 * v]) = pv[i]; }
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
         const int v = tid + 256 * i;
