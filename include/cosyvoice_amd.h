@@ -189,7 +189,8 @@ int cv_flow_finalize(cv_flow* m);
  * "fused_tail" (+ "tail_ring" 8 | 16), "est_streams" (1 | 2); "graph_cap" (1 .. 256 cached shapes).  Round 5: "big_rows" (2000: passes of at least this many estimator rows run
  * on the large-M kernel set, csrc/flow_big.h), "fused_band" (1: in such passes everything between a block's attention and the next QKV GEMM is one launch per row band,
  * csrc/flow_band.h), "band_qkv" (1: that launch also runs the NEXT block's QKV GEMM - a block of a large pass is two launches, attention and band), "band_bm" (0: rows
- * per band by the row count of the pass - 32 / 48 / 64, csrc/flow.hip::band_rows_for; 32 | 48 | 64 forces), "eager_streams" (1; 2: the batch rows of a pass that runs
+ * per band by the row count of the pass - 32 / 48 / 64, csrc/flow.hip::band_rows_for; 32 | 48 | 64 forces), "band_pipe" (2: the feed-forward chunks of a 48- / 32-row band
+ * as a software pipeline - MFMA slices between the GELU pieces; 1: 48-row bands only, 0: never), "eager_streams" (1; 2: the batch rows of a pass that runs
  * eager as two launch chains on two streams - faster in isolation, slower next to the model's token2wav lanes, profiles/r5_band_qkv.txt).  Every combination is
  * bit-identical per utterance. */
 int cv_flow_set_option(cv_flow* m, const char* name, int32_t value);
