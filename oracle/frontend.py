@@ -3,7 +3,10 @@
 `librosa.filters.mel` (librosa, unpinned in requirements.txt) is not installed; both are restated from their published algorithms (SURVEY.md
 Appendix B): reflect pad (n_fft - hop) / 2, torch.stft(center=False, hann_window), sqrt(re^2 + im^2 + 1e-9), Slaney-scale area-normalised
 triangular filters, log(clamp(., 1e-5)).  The filterbank here is an independent float64 restatement (loops, not the product's vectorised code);
-its closed-form anchors are tested in tests/test_frontend.py."""
+its closed-form anchors are tested in tests/test_frontend.py.
+CROSS-CHECKED (round 5, tests/test_frontend_pinned.py): the Slaney mel basis, the prompt mel, the whisper log-mel and the Kaldi fbank of this file agree with the separate
+ports of the same published algorithms in Hugging Face `transformers` (audio_utils.mel_filter_bank / spectrogram, WhisperFeatureExtractor, SeamlessM4TFeatureExtractor -
+installed here) to 1e-12 / 2e-4 / 1e-4 / 5e-4.  That is not parity with the reference's own dependencies (still absent), but it is an independent implementation."""
 import math
 
 import numpy as np
