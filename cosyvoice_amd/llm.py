@@ -47,22 +47,6 @@ class _Cursor:
             return self.k - 1
 
 
-class _no_groups:
-    """While the chains of a grouped call run, their handles decode their own share directly (no nested cut)."""
-
-    def __init__(self, handles):
-        self.handles = handles
-
-    def __enter__(self):
-        self.saved = [(h.decode_groups, h.queue_groups) for h in self.handles]
-        for h in self.handles:
-            h.decode_groups = h.queue_groups = 1
-
-    def __exit__(self, *a):
-        for h, v in zip(self.handles, self.saved):
-            h.decode_groups, h.queue_groups = v
-
-
 class Qwen2Encoder:
     """Boundary B2, the finer hook: `Qwen2LM.llm.forward_one_step(xs, masks, cache)` of the reference (cosyvoice/llm/llm.py:242-254) over the handle's device KV
     cache, so that the reference's OWN decode loop (llm.py:535-549: forward_one_step -> llm_decoder -> sampling_ids -> speech_embedding) can run unchanged on top of
@@ -149,7 +133,7 @@ class Qwen2LM:
         self.decode_groups = int(os.environ.get("CV_LLM_GROUPS", decode_groups if decode_groups is not None else 1))
         self.queue_groups = int(os.environ.get("CV_LLM_QUEUE_GROUPS", queue_groups if queue_groups is not None else 1))
         self.group_min_slots = int(os.environ.get("CV_LLM_GROUP_MIN", group_min_slots))
-        self._siblings, self._group_streams = [], []
+        self._siblings, self._group_streams, self._sib_lock = [], [], threading.Lock()
         self.group_streams = None                            # streams for the second .. last chain (CosyVoice2Model.set_lanes hands over its lane streams)
         self._uniforms = None
         self._request = 0
@@ -187,17 +171,21 @@ class Qwen2LM:
         g = max(1, min(g, n_slots))
         if g == 1:
             return [self], [None]
-        while len(self._siblings) < g - 1:
-            self._siblings.append(self.sibling())
+        with self._sib_lock:                                    # (two server threads may ask for the first cut at the same time)
+            while len(self._siblings) < g - 1:
+                self._siblings.append(self.sibling())
         if self.device.type == "cuda":
             # the first chain stays on the caller's stream; the others run on `group_streams` (set by the model: its token2wav lane streams, idle while tts_batch
             # decodes) or on streams of their own.  A process has 4 hardware queues and a busy stream beyond them shares one with another (set_lanes): two extra
             # streams for the chains slowed the pipelined runs that FOLLOWED a grouped batch in the same process (batch 32: 508 -> 441 audio-s/s, gpurun_out/r5w).
             extra = list(self.group_streams or [])[: g - 1]
-            while len(extra) < g - 1:
-                if not self._group_streams:
-                    self._group_streams.append(torch.cuda.Stream(self.device, priority=-1))
-                extra.append(self._group_streams[0] if g == 2 else torch.cuda.Stream(self.device, priority=-1))
+            own = 0
+            while len(extra) < g - 1:                           # (streams of its own are made once and kept)
+                with self._sib_lock:
+                    if len(self._group_streams) <= own:
+                        self._group_streams.append(torch.cuda.Stream(self.device, priority=-1))
+                extra.append(self._group_streams[own])
+                own += 1
             return [self] + self._siblings[: g - 1], [torch.cuda.current_stream(self.device)] + extra
         return [self] + self._siblings[: g - 1], [None] * g
 
@@ -362,7 +350,7 @@ class Qwen2LM:
 
     # ------------------------------------------------------------------------------------------------ lock-step batched decode
     @torch.inference_mode()
-    def inference_batch(self, requests, max_token_text_ratio=20, min_token_text_ratio=2):
+    def inference_batch(self, requests, max_token_text_ratio=20, min_token_text_ratio=2, _cut=True):
         """Up to 8 requests decoded in lock step on this handle (BASELINE.json configs[2]/[3]; the reference batches through vLLM,
         cli/model.py:281-290): every weight matrix is streamed once per step for all sequences (llm_batch_kernels.h).  `requests` is a
         list of dicts with `text`, `prompt_text`, `prompt_speech_token` ([1, n] id tensors) and, optionally, per-request `min_token_text_ratio` /
@@ -370,7 +358,8 @@ class Qwen2LM:
         same tokens `inference()` yields for that request alone (the per-sequence arithmetic is identical)."""
         nb = len(requests)
         assert 1 <= nb <= (16 if self.batch_fp8 else 32), "1..32 requests per batch (16 on the fp8 path)"
-        handles, streams = self._groups(nb, self.decode_groups)
+        # (_cut=False: this call IS one chain of a cut batch.  An argument, not handle state: concurrent callers of one handle must not see each other's cut)
+        handles, streams = self._groups(nb, self.decode_groups) if _cut else ([self], [None])
         if len(handles) > 1:
             # decode groups: contiguous runs of the requests ordered by their length bound (a chain runs as long as its longest member: similar lengths together), every
             # request with the sampler key it would have had on this handle alone
@@ -384,11 +373,10 @@ class Qwen2LM:
 
             def work(h, part):
                 def fn():
-                    for i, toks in zip(part, type(h).inference_batch(h, [reqs[i] for i in part], max_token_text_ratio, min_token_text_ratio)):
+                    for i, toks in zip(part, type(h).inference_batch(h, [reqs[i] for i in part], max_token_text_ratio, min_token_text_ratio, _cut=False)):
                         outs[i] = toks
                 return fn
-            with _no_groups(handles):
-                self._run_groups([(h, st_, work(h, part)) for h, st_, part in zip(handles, streams, parts)])
+            self._run_groups([(h, st_, work(h, part)) for h, st_, part in zip(handles, streams, parts)])
             self._request = base + nb                           # (this handle ran one of the chains: its counter advances as if it had run them all)
             return outs
         assert 1 <= nb <= (16 if self.batch_fp8 else 32), "1..32 requests per batch (16 on the fp8 path)"
@@ -458,8 +446,7 @@ class Qwen2LM:
 
             def runner():
                 try:
-                    with _no_groups(handles):
-                        self._run_groups([(h, st_, work(h, k)) for k, (h, st_) in enumerate(zip(handles, streams))])
+                    self._run_groups([(h, st_, work(h, k)) for k, (h, st_) in enumerate(zip(handles, streams))])        # (_cursor marks each inner call as one chain)
                 except BaseException as e:                      # noqa: BLE001
                     errs.append(e)
                     for _ in range(g):

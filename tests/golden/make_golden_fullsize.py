@@ -1,0 +1,191 @@
+"""Golden vectors at the FULL model dimensions, made by the REAL reference classes (/root/reference) - build container only:
+
+    python tests/golden/make_golden_fullsize.py [llm] [llm_cv3] [cv1_llm] [flow] [hift]        (no argument: all five, ~6 min on 8 cores)
+
+The other generators (make_golden.py, make_golden_cv1.py) run the reference at test dimensions, which pins the oracle's ARITHMETIC; the full-size parity
+tests and every bench run then compare the kernels with the oracle's own full-size output (tests/golden/u10_oracle_tokens.json, cv3_u10_oracle_tokens.json,
+oracle.flow / oracle.hift computed on the spot).  This script closes that last link: the same real classes, loaded (strict=True) with the seeded full-size state
+dicts of cosyvoice_amd.synthetic, run the BENCHMARK requests themselves -
+
+  llm      cosyvoice.llm.llm.Qwen2LM.inference (llm/llm.py:458-549) at CosyVoice2-0.5B dimensions on U10: all 250 greedy ids + the first log-prob rows
+  llm_cv3  CosyVoice3LM.inference (llm/llm.py:664-706) at Fun-CosyVoice3-0.5B dimensions on bench.py's instruct request: all 250 ids
+  cv1_llm  TransformerLM.inference (llm/llm.py:162-223) at CosyVoice-300M dimensions on bench.py's inference_sft request: all 500 ids
+  flow     CausalMaskedDiffWithXvec.inference (flow/flow.py:235-281; estimator over the restated Matcha blocks of matcha_stub.py) on U10's 250 tokens: the
+           mel [80, 500]; the estimator boundary at T = 674 (offline and streaming masks); the encoder at 337 tokens
+  hift     HiFTGenerator.inference (hifigan/generator.py:557-569) at 24 kHz dimensions on 100 frames of that mel
+
+and tests/test_fullsize_pinned.py (CPU, `-m "not gpu"`) holds the oracle - and the committed oracle token files the GPU runs are checked against - to them.
+Weights are not stored (the factory regenerates them from the seed); the HiFT noise is the global torch RNG seeded right before the call, replayed by the test.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+_argv, sys.argv = sys.argv, sys.argv[:1]                # make_golden_cv1 reads its mode from argv at import
+import make_golden as MG  # noqa: E402  (installs the reference import stubs)
+import make_golden_cv1 as MG1  # noqa: E402
+sys.argv = _argv
+from cosyvoice_amd import configs as CF, synthetic as W  # noqa: E402
+
+N_GEN, N_TEXT, N_PROMPT_TEXT, N_PROMPT_TOK = 250, 30, 12, 87
+HIFT_FRAMES = 100
+
+
+def save(name, **arrs):
+    out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()}
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s: %s, %.0f KB" % (name, {k: v.shape for k, v in out.items()}, os.path.getsize(path) / 1024))
+
+
+def _qwen_lm(cfg, cls_name):
+    """The real Qwen2LM / CosyVoice3LM over a random-init Qwen2ForCausalLM of the configured size (the wrapper of make_golden.golden_llm: from_pretrained needs a
+    checkpoint directory; the decode mask follows the semantics the pinned transformers 4.51.3 gives the reference's all-ones mask)."""
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+    import cosyvoice.llm.llm as L
+
+    class Enc(L.Qwen2Encoder):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            hc = Qwen2Config(vocab_size=cfg.text_vocab, hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=cfg.layers,
+                             num_attention_heads=cfg.heads, num_key_value_heads=cfg.kv_heads, max_position_embeddings=4096, rms_norm_eps=cfg.rms_eps,
+                             rope_theta=cfg.rope_theta, tie_word_embeddings=True, attention_dropout=0.0)
+            self.model = Qwen2ForCausalLM(hc)
+
+        def forward_one_step(self, xs, masks, cache=None):
+            outs = self.model(inputs_embeds=xs, attention_mask=None if xs.shape[1] == 1 else masks[:, -1, :], output_hidden_states=True, return_dict=True,
+                              use_cache=True, past_key_values=cache)
+            return outs.hidden_states[-1], outs.past_key_values
+
+    logps = []
+
+    def greedy(scores, decoded, k):
+        logps.append(scores.clone())
+        return int(scores.argmax().item())
+
+    lm = getattr(L, cls_name)(cfg.hidden, cfg.hidden, cfg.speech_token_size, Enc(), greedy)
+    lm.load_state_dict(W.make_llm(cfg), strict=True)
+    return lm.eval(), logps
+
+
+def _margins(logps, mask_id):
+    out = []
+    for lp in logps:
+        lp = lp.clone()
+        lp[mask_id] = -float("inf")
+        top2 = torch.topk(lp, 2).values
+        out.append(float(top2[0] - top2[1]))
+    return np.array(out, dtype=np.float32)
+
+
+def _run_lm(lm, logps, u, cfg, n_prompt_tok):
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    ratio = N_GEN / N_TEXT
+    t0 = time.time()
+    toks = list(lm.inference(text=u["text"], text_len=t(u["text"].shape[1]), prompt_text=u["prompt_text"], prompt_text_len=t(u["prompt_text"].shape[1]),
+                             prompt_speech_token=u["llm_prompt_speech_token"], prompt_speech_token_len=t(n_prompt_tok), embedding=u["llm_embedding"],
+                             max_token_text_ratio=ratio, min_token_text_ratio=ratio))
+    print("  %d tokens from the real class in %.0f s" % (len(toks), time.time() - t0))
+    assert len(toks) == N_GEN
+    return toks
+
+
+def golden_llm():
+    lc, fc, _ = W.cv2()
+    lm, logps = _qwen_lm(lc, "Qwen2LM")
+    u = W.synthetic_utterance(lc, fc, n_prompt_tok=N_PROMPT_TOK, n_prompt_text=N_PROMPT_TEXT, n_text=N_TEXT)
+    toks = _run_lm(lm, logps, u, lc, N_PROMPT_TOK)
+    # (the reference logs a row AFTER sampling_ids masked index speech_token_size in place: that column is -inf in the stored rows)
+    save("fullsize_llm", tokens=np.array(toks, dtype=np.int32), logp=torch.stack([logps[i] for i in (0, 1, 2, 249)]), logp_steps=np.array([0, 1, 2, 249]),
+         top2_margin=_margins(logps, lc.speech_token_size))
+
+
+def golden_llm_cv3():
+    lc, fc = CF.cv3_llm(), CF.cv3_flow()
+    lm, logps = _qwen_lm(lc, "CosyVoice3LM")
+    u = W.synthetic_utterance(lc, fc, n_prompt_tok=N_PROMPT_TOK, n_prompt_text=24, n_text=N_TEXT, seed=2025)      # bench.py cv3_workload / make_cv3_u10.py
+    u["prompt_text"][0, 11] = lc.endofprompt_id
+    u["llm_prompt_speech_token"] = torch.zeros(1, 0, dtype=torch.int32)
+    toks = _run_lm(lm, logps, u, lc, 0)
+    save("fullsize_llm_cv3", tokens=np.array(toks, dtype=np.int32), logp=torch.stack([logps[i] for i in (0, 1, 249)]), logp_steps=np.array([0, 1, 249]),
+         top2_margin=_margins(logps, lc.speech_token_size))
+
+
+def golden_cv1_llm():
+    """bench.py cv1_workload's request (seed 300: 25 text ids, a speaker embedding, no prompts; the length forced to 500 tokens, greedy)."""
+    cfg, hcfg = W.cv1()
+    MG1.CFG, MG1.HCFG = cfg, hcfg
+    logps = []
+
+    def greedy(scores, decoded, sampling):
+        logps.append(scores.clone())
+        return int(scores.argmax().item())
+    m = MG1.build_llm(greedy)
+    g = torch.Generator().manual_seed(300)
+    n_text, n_gen = 25, 500
+    text = torch.randint(0, cfg.text_vocab, (1, n_text), generator=g, dtype=torch.int32)
+    emb = torch.randn(1, cfg.spk_dim, generator=g)
+    e0 = torch.zeros(1, 0, dtype=torch.int32)
+    tl = lambda n: torch.tensor([n], dtype=torch.int32)
+    t0 = time.time()
+    toks = list(m.inference(text=text, text_len=tl(n_text), prompt_text=e0, prompt_text_len=tl(0), prompt_speech_token=e0, prompt_speech_token_len=tl(0), embedding=emb,
+                            max_token_text_ratio=n_gen / n_text, min_token_text_ratio=n_gen / n_text))
+    print("  %d tokens from the real TransformerLM in %.0f s" % (len(toks), time.time() - t0))
+    assert len(toks) == n_gen
+    save("fullsize_cv1_llm", text=text, embedding=emb, tokens=np.array(toks, dtype=np.int32), logp=torch.stack([logps[i] for i in (0, 1, 499)]), logp_steps=np.array([0, 1, 499]),
+         top2_margin=_margins(logps, cfg.speech_token_size))
+
+
+def golden_flow():
+    lc, fc, _ = W.cv2()
+    flow = MG.build_ref_flow(fc)
+    u = W.synthetic_utterance(lc, fc, n_prompt_tok=N_PROMPT_TOK, n_prompt_text=N_PROMPT_TEXT, n_text=N_TEXT)
+    tokens = json.load(open(os.path.join(HERE, "u10_oracle_tokens.json")))["tokens"]        # (== the real class's: fullsize_llm.npz, checked by the test)
+    token = torch.tensor(tokens, dtype=torch.int32).unsqueeze(0)
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    common = dict(prompt_token=u["flow_prompt_speech_token"], prompt_token_len=t(N_PROMPT_TOK), prompt_feat=u["prompt_speech_feat"], prompt_feat_len=t(2 * N_PROMPT_TOK),
+                  embedding=u["flow_embedding"])
+    t0 = time.time()
+    mel_full, _ = flow.inference(token=token, token_len=t(N_GEN), streaming=False, finalize=True, **common)
+    # the first streamed chunk of the request (cli/model.py:345-351: hop 25 + prompt pad 13 + pre_lookahead 3 tokens)
+    n1 = 25 + 13 + 3
+    mel_chunk, _ = flow.inference(token=token[:, :n1], token_len=t(n1), streaming=True, finalize=False, **common)
+    print("  flow.inference x2 from the real class in %.0f s" % (time.time() - t0))
+    g = torch.Generator().manual_seed(12)
+    T = 2 * (N_PROMPT_TOK + N_GEN)
+    x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g); cond = torch.randn(2, 80, T, generator=g)
+    spk = torch.randn(2, 80, generator=g); tt = torch.tensor([0.25, 0.25]); mask = torch.ones(2, 1, T)
+    with torch.inference_mode():
+        e_full = flow.decoder.estimator(x, mask, mu, tt, spk, cond, streaming=False)
+        e_stream = flow.decoder.estimator(x, mask, mu, tt, spk, cond, streaming=True)
+        tok_emb = flow.input_embedding(torch.cat([u["flow_prompt_speech_token"], token], 1).long())
+        h_full, _ = flow.encoder(tok_emb, t(N_PROMPT_TOK + N_GEN), streaming=False)
+    # the estimator inputs are regenerated by the test from the seed; of the outputs, row 0 in full and a strided slice of row 1 keep the file small
+    save("fullsize_flow", mel_full=mel_full[0], mel_chunk=mel_chunk[0], est_full=e_full[0], est_full_row1=e_full[1, :, ::8], est_stream=e_stream[0],
+         est_stream_row1=e_stream[1, :, ::8], enc_full=h_full[0, ::4])
+
+
+def golden_hift():
+    _, _, hc = W.cv2()
+    hift = MG.build_ref_hift(hc)
+    mel = torch.from_numpy(np.load(os.path.join(HERE, "fullsize_flow.npz"))["mel_full"])[None, :, 200:200 + HIFT_FRAMES].contiguous()
+    with torch.inference_mode():
+        f0 = hift.f0_predictor(mel)
+        torch.manual_seed(99)
+        speech, source = hift.inference(speech_feat=mel)
+    # the test replays the draws (generator.py:245, :312): manual_seed(99); rand(1, 9) with column 0 zeroed; randn_like of the [1, 480 m, 9] transposed view
+    save("fullsize_hift", mel=mel[0], f0=f0, speech=speech, source=source)
+
+
+if __name__ == "__main__":
+    for w in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["llm", "llm_cv3", "cv1_llm", "flow", "hift"]):
+        print(w)
+        globals()["golden_" + w]()

@@ -178,6 +178,16 @@ def test_decode_groups(lib, sampling):
             assert g == OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=4, min_token_text_ratio=1)
     small = two.inference_batch(reqs[:3], max_token_text_ratio=4, min_token_text_ratio=1)   # below group_min_slots: the one handle
     assert small == one.inference_batch(reqs[:3], max_token_text_ratio=4, min_token_text_ratio=1)
+    if sampling == "greedy" and lib.emulated:                   # (host-side state only; added after the round's last GPU session, so it has run under the emulator only)
+        # two server threads batch on the SAME handle at once (gRPC workers share the model, runtime/python/grpc/server.py:69): each cut call gets its own tokens and the
+        # cut stays a property of the call - the handle's `decode_groups` is what it was (it used to be parked at 1 while a cut batch ran)
+        import threading
+        res = {}
+        ths = [threading.Thread(target=lambda k=k: res.__setitem__(k, two.inference_batch(reqs[k:k + 5], max_token_text_ratio=4, min_token_text_ratio=1))) for k in (0, 2)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        assert res[0] == want_b and res[2] == one.inference_batch(reqs[2:7], max_token_text_ratio=4, min_token_text_ratio=1)
+        assert two.decode_groups == 2 and two.queue_groups == 2 and len(two._siblings) == 1
 
 
 def test_model_tts_batch(lib):
