@@ -108,6 +108,17 @@ def stage_split(model, u, reps=3):
             "note": "one synchronisation per stage; flow_inference includes the encoder, hift_inference the f0 predictor and source"}
 
 
+def real_class_tokens(name):
+    """The ids the REAL reference class produced for a benchmark request at the full model dimensions (tests/golden/make_golden_fullsize.py ran cosyvoice.llm.llm.Qwen2LM /
+    CosyVoice3LM / TransformerLM in the build container; tests/test_fullsize_pinned.py holds the oracle to them on CPU).  None if the fixture is not there - reporting
+    only, never a reason to fail a run."""
+    try:
+        import numpy as np
+        return [int(t) for t in np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))["tokens"]]
+    except Exception:                                           # noqa: BLE001
+        return None
+
+
 def self_check(model, u):
     """Outside the timed region: the tokens the timed path produces for U10 must be the CPU oracle's greedy tokens, committed as
     tests/golden/u10_oracle_tokens.json (generated by tests/golden/make_u10.py; nothing from oracle/ is imported here), and the waveform must be
@@ -124,7 +135,8 @@ def self_check(model, u):
                               gold["top2_margin"][div] if div is not None else None))
     if not bool(torch.isfinite(wav).all()) or float(wav.abs().max()) > 0.99 + 1e-6 or float(wav.abs().max()) == 0.0:
         raise RuntimeError("bench self-check: waveform is not finite / not inside audio_limit")
-    return {"tokens_equal_oracle": True, "n_tokens": len(toks), "oracle_min_top2_margin": gold["min_margin"],
+    real = real_class_tokens("fullsize_llm")
+    return {"tokens_equal_oracle": True, "tokens_equal_real_reference_class": None if real is None else toks == real, "n_tokens": len(toks), "oracle_min_top2_margin": gold["min_margin"],
             "tokens_sha1": hashlib.sha1(",".join(map(str, toks)).encode()).hexdigest()[:16], "wav_abs_max": round(float(wav.abs().max()), 4),
             "wav_rms": round(float(wav.pow(2).mean().sqrt()), 5)}
 
@@ -275,7 +287,9 @@ def cv3_workload(args):
             div = next((k for k, (a, b) in enumerate(zip(toks, gold["tokens"])) if a != b), None)
             if len(toks) != len(gold["tokens"]) or (div is not None and gold["top2_margin"][div] > 1e-3):
                 raise RuntimeError("bench cosyvoice3: %s does not reproduce the oracle's tokens (first difference at step %s)" % (name, div))
-        check = {"checked": True, "tokens_equal_oracle_single_and_16_slots": True, "oracle_min_top2_margin": gold["min_margin"]}
+        real = real_class_tokens("fullsize_llm_cv3")
+        check = {"checked": True, "tokens_equal_oracle_single_and_16_slots": True, "tokens_equal_real_reference_class": None if real is None else list(seen["single"]) == real,
+                 "oracle_min_top2_margin": gold["min_margin"]}
     # Round 5: the fp8 sub-line is RETIRED from the default line ("make it win or retire it, with numbers either way").  Measured on the MI355X under
     # the driver's command (gpurun_out/r5g -> profiles/r5_fp8_retired.txt): 16 requests per GPU 318.5 audio-s/s on the fp8 path against 355.2 on W16A32, first divergence
     # from the fp32 oracle's tokens at step 3, first-step max |d log p| 0.475 against the go bar of 0.1.  Every launch of the lock-step step is bound by its fixed
@@ -394,12 +408,15 @@ def cv1_workload(args):
     return {"model": "CosyVoice-300M dimensions (TransformerLM 14 x 1024 + conformer text encoder, MaskedDiffWithXvec with the U-Net ConditionalDecoder, HiFTGenerator 22.05 kHz), "
                      "seeded random weights, fp32", "request": "inference_sft shape: 25 text ids, 500 generated tokens = %.2f s of audio, greedy, 10 Euler steps" % audio_s,
             "lm_loop": "host sampler, one logits round trip per token (reference-shaped)" if host_loop else "on the device (cv_lm1_decode: sampler + embedding row in the launch sequence, tokens per 64-step chunk)",
-            "full_size_check_note": "the token check below is against the builder's torch-eager port (cosyvoice1.py), which the REAL reference classes pin at test dimensions only (tests/golden/cv1*_*.npz)",
+            "full_size_check_note": "token check: against the builder's torch-eager port (cosyvoice1.py) run on this box, and - `equal_real_reference_class` - against the 500 ids the REAL TransformerLM "
+                                    "produced for this request at these dimensions (tests/golden/fullsize_cv1_llm.npz); flow / HiFT of this model: the real classes pin the port at test dimensions only",
             "host": "python sequencing over the operator-level C ABI (cosyvoice1_hip.py); the LM decode step is ONE call (cv_lm1_step, csrc/lm1.hip: %s)"
                     % ("%d launches per token, %d of the %d steps replayed as a hipGraph" % (lm.step.stat("launches_per_step"), lm.step.stat("graph_replays"), lm.step.stat("steps")) if lm.step is not None and lm.fused_step
                        else "off: launch-per-operator tape"), "audio_s_per_s": round(audio_s / per, 3),
             "ms_per_utterance": round(1e3 * per, 2), "stages": stages,
-            "token_check": {"checked": n_chk, "equal_torch_eager_cpu": div is None, "first_difference": div},
+            "token_check": {"checked": n_chk, "equal_torch_eager_cpu": div is None, "first_difference": div,
+                            # all ids against the REAL TransformerLM's (llm/llm.py:162-223 at these dimensions, tests/golden/fullsize_cv1_llm.npz); None: fixture absent or another length
+                            "equal_real_reference_class": (lambda real: None if real is None or len(real) != len(tokens) else tokens == real)(real_class_tokens("fullsize_cv1_llm"))},
             # the same LM on the host cores (cosyvoice1.py, torch fp32 eager = the configs[0] plumbing; text encoder + prompt pass + n_chk decode steps, sampled)
             "cpu_lm": {"kind": "port (torch eager), sampled", "tokens": n_chk, "ms_per_token_incl_prompt_pass": round(1e3 * cpu_lm_s / max(1, n_chk), 2), "threads": torch.get_num_threads()}}
 

@@ -88,7 +88,10 @@ def _margins(logps, mask_id):
 
 def _run_lm(lm, logps, u, cfg, n_prompt_tok):
     t = lambda n: torch.tensor([n], dtype=torch.int32)
-    ratio = N_GEN / N_TEXT
+    # The reference computes its length bounds as int(int32 TENSOR * python float) = float32 arithmetic (llm/llm.py:497-498): 30 * (250 / 30) is 249.99998 there and 249
+    # tokens come out, where python's double arithmetic (the oracle, the product: DESIGN.md section 4) gives 250.  (N + 0.5) / n_text yields N under both rules.
+    ratio = (N_GEN + 0.5) / N_TEXT
+    assert int(t(N_TEXT) * ratio) == N_GEN == int(N_TEXT * ratio)
     t0 = time.time()
     toks = list(lm.inference(text=u["text"], text_len=t(u["text"].shape[1]), prompt_text=u["prompt_text"], prompt_text_len=t(u["prompt_text"].shape[1]),
                              prompt_speech_token=u["llm_prompt_speech_token"], prompt_speech_token_len=t(n_prompt_tok), embedding=u["llm_embedding"],

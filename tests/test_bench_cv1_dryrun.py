@@ -21,5 +21,5 @@ def test_cosyvoice300m_extra_dry_run(emu_lib, monkeypatch):
     monkeypatch.setattr(H, "get_lib", lambda: emu_lib)
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     res = bench.cv1_workload(types.SimpleNamespace(steps=2))
-    assert res["token_check"] == {"checked": 25, "equal_torch_eager_cpu": True, "first_difference": None}
+    assert res["token_check"] == {"checked": 25, "equal_torch_eager_cpu": True, "first_difference": None, "equal_real_reference_class": None}   # (the real-class fixture holds the 500-id request)
     assert res["audio_s_per_s"] > 0 and set(res["stages"]) == {"llm_ms", "flow_ms", "hift_ms", "llm_us_per_token"}
