@@ -1,6 +1,6 @@
 """Golden vectors at the FULL model dimensions, made by the REAL reference classes (/root/reference) - build container only:
 
-    python tests/golden/make_golden_fullsize.py [llm] [llm_cv3] [cv1_llm] [flow] [hift]        (no argument: all five, ~6 min on 8 cores)
+    python tests/golden/make_golden_fullsize.py [llm] [llm_cv3] [cv1_llm] [flow] [hift] [dit] [causal_hift] [cv1_flow] [cv1_hift] [mixed64]   (no argument: all but mixed64, ~8 min on 8 cores)
 
 The other generators (make_golden.py, make_golden_cv1.py) run the reference at test dimensions, which pins the oracle's ARITHMETIC; the full-size parity
 tests and every bench run then compare the kernels with the oracle's own full-size output (tests/golden/u10_oracle_tokens.json, cv3_u10_oracle_tokens.json,
@@ -8,11 +8,14 @@ oracle.flow / oracle.hift computed on the spot).  This script closes that last l
 dicts of cosyvoice_amd.synthetic, run the BENCHMARK requests themselves -
 
   llm      cosyvoice.llm.llm.Qwen2LM.inference (llm/llm.py:458-549) at CosyVoice2-0.5B dimensions on U10: all 250 greedy ids + the first log-prob rows
+  mixed64  the same class on the 64 utterances of bench.py's mixed64 workload (configs[3]): every id (not in the default list: ~15 min)
   llm_cv3  CosyVoice3LM.inference (llm/llm.py:664-706) at Fun-CosyVoice3-0.5B dimensions on bench.py's instruct request: all 250 ids
   cv1_llm  TransformerLM.inference (llm/llm.py:162-223) at CosyVoice-300M dimensions on bench.py's inference_sft request: all 500 ids
   flow     CausalMaskedDiffWithXvec.inference (flow/flow.py:235-281; estimator over the restated Matcha blocks of matcha_stub.py) on U10's 250 tokens: the
            mel [80, 500]; the estimator boundary at T = 674 (offline and streaming masks); the encoder at 337 tokens
   hift     HiFTGenerator.inference (hifigan/generator.py:557-569) at 24 kHz dimensions on 100 frames of that mel
+  dit, causal_hift   CausalMaskedDiffWithDiT / DiT and CausalHiFTGenerator at Fun-CosyVoice3-0.5B dimensions (row a17)
+  cv1_flow, cv1_hift MaskedDiffWithXvec (U-Net ConditionalDecoder, flow cache) and the 22.05 kHz HiFTGenerator at CosyVoice-300M dimensions (rows a18 / f4)
 
 and tests/test_fullsize_pinned.py (CPU, `-m "not gpu"`) holds the oracle - and the committed oracle token files the GPU runs are checked against - to them.
 Weights are not stored (the factory regenerates them from the seed); the HiFT noise is the global torch RNG seeded right before the call, replayed by the test.
@@ -86,7 +89,7 @@ def _margins(logps, mask_id):
     return np.array(out, dtype=np.float32)
 
 
-def _run_lm(lm, logps, u, cfg, n_prompt_tok):
+def _run_lm(lm, logps, u, cfg, n_prompt_tok, N_GEN=N_GEN):
     t = lambda n: torch.tensor([n], dtype=torch.int32)
     # The reference computes its length bounds as int(int32 TENSOR * python float) = float32 arithmetic (llm/llm.py:497-498): 30 * (250 / 30) is 249.99998 there and 249
     # tokens come out, where python's double arithmetic (the oracle, the product: DESIGN.md section 4) gives 250.  (N + 0.5) / n_text yields N under both rules.
@@ -109,6 +112,21 @@ def golden_llm():
     # (the reference logs a row AFTER sampling_ids masked index speech_token_size in place: that column is -inf in the stored rows)
     save("fullsize_llm", tokens=np.array(toks, dtype=np.int32), logp=torch.stack([logps[i] for i in (0, 1, 2, 249)]), logp_steps=np.array([0, 1, 2, 249]),
          top2_margin=_margins(logps, lc.speech_token_size))
+
+
+def golden_mixed64():
+    """The 64 utterances of bench.py's mixed64 workload (BASELINE.json configs[3]: seeds 4000 + i, 125 / 250 / 375 / 500 tokens in equal mix; make_mixed64.py holds the
+    oracle's ids): every id from the real Qwen2LM (about a quarter of an hour of CPU)."""
+    lc, fc, _ = W.cv2()
+    lm, logps = _qwen_lm(lc, "Qwen2LM")
+    out = {}
+    for i in range(64):
+        n_gen = (125, 250, 375, 500)[i % 4]
+        u = W.synthetic_utterance(lc, fc, n_prompt_tok=N_PROMPT_TOK, n_prompt_text=N_PROMPT_TEXT, n_text=N_TEXT, seed=4000 + i)
+        del logps[:]
+        out["tokens_%02d" % i] = np.array(_run_lm(lm, logps, u, lc, N_PROMPT_TOK, n_gen), dtype=np.int16)
+        out["min_margin_%02d" % i] = _margins(logps, lc.speech_token_size).min()
+    save("fullsize_mixed64", **out)
 
 
 def golden_llm_cv3():
@@ -188,7 +206,89 @@ def golden_hift():
     save("fullsize_hift", mel=mel[0], f0=f0, speech=speech, source=source)
 
 
+def golden_dit():
+    """CausalMaskedDiffWithDiT.inference (flow/flow.py:369-414) + DiT (flow/DiT/dit.py:145-176; x_transformers' rotary restated in xtransformers_stub.py) at
+    Fun-CosyVoice3-0.5B dimensions on bench.py's cosyvoice3 request (250 tokens of cv3_u10_oracle_tokens.json, flow prompt 87 tokens): the estimator boundary at
+    T = 674 in both mask modes, and inference with 2 Euler steps (the reference hard-codes 10, flow/flow.py:409; the step count goes through the CFM's own
+    n_timesteps argument as in make_golden.golden_dit - two steps keep the CPU test that replays this short)."""
+    lc, fc = CF.cv3_llm(), CF.cv3_flow()
+    flow = MG.build_ref_dit_flow(fc)
+    u = W.synthetic_utterance(lc, fc, n_prompt_tok=N_PROMPT_TOK, n_prompt_text=24, n_text=N_TEXT, seed=2025)
+    token = torch.tensor(json.load(open(os.path.join(HERE, "cv3_u10_oracle_tokens.json")))["tokens"], dtype=torch.int32).unsqueeze(0)
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    orig_fwd = type(flow.decoder).forward
+
+    def fwd(self, mu, mask, spks, cond, n_timesteps=10, **kw):
+        return orig_fwd(self, mu=mu, mask=mask, spks=spks, cond=cond, n_timesteps=2, **kw)
+    type(flow.decoder).forward = fwd
+    t0 = time.time()
+    try:
+        mel, _ = flow.inference(token=token, token_len=t(N_GEN), prompt_token=u["flow_prompt_speech_token"], prompt_token_len=t(N_PROMPT_TOK),
+                                prompt_feat=u["prompt_speech_feat"], prompt_feat_len=t(2 * N_PROMPT_TOK), embedding=u["flow_embedding"], streaming=False, finalize=True)
+    finally:
+        type(flow.decoder).forward = orig_fwd
+    g = torch.Generator().manual_seed(14)
+    T = 2 * (N_PROMPT_TOK + N_GEN)
+    x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g); cond = torch.randn(2, 80, T, generator=g)
+    spk = torch.randn(2, 80, generator=g); tt = torch.tensor([0.25, 0.25]); mask = torch.ones(2, 1, T)
+    with torch.inference_mode():
+        e_full = flow.decoder.estimator(x, mask, mu, tt, spk, cond, streaming=False)
+        e_stream = flow.decoder.estimator(x, mask, mu, tt, spk, cond, streaming=True)
+    print("  DiT flow: inference (2 steps) + 2 estimator calls from the real class in %.0f s" % (time.time() - t0))
+    save("fullsize_dit", mel_2steps=mel[0], est_full=e_full[0, :, ::2], est_full_row1=e_full[1, :, ::8], est_stream=e_stream[0, :, ::2], est_stream_row1=e_stream[1, :, ::8])
+
+
+def golden_causal_hift():
+    """CausalHiFTGenerator.inference (hifigan/generator.py:572-726; float64 f0 predictor, :716-717) at Fun-CosyVoice3-0.5B dimensions on 100 mel frames, one-shot and
+    as a non-final chunk.  The generator's fixed noise buffers are construction-time draws (generator.py:223-226): they are set here from a seeded generator the test
+    replays."""
+    hc = CF.cv3_hift()
+    hift = MG.build_ref_causal_hift(hc)
+    g = torch.Generator().manual_seed(16)
+    sg = hift.m_source.l_sin_gen
+    sg.rand_ini = torch.rand(1, 9, generator=g); sg.rand_ini[:, 0] = 0
+    sg.sine_waves = torch.rand(1, 480 * HIFT_FRAMES, 9, generator=g)
+    mel = torch.from_numpy(np.load(os.path.join(HERE, "fullsize_dit.npz"))["mel_2steps"])[None, :, 150:150 + HIFT_FRAMES].contiguous()
+    with torch.inference_mode():
+        speech, source = hift.inference(speech_feat=mel, finalize=True)
+        speech_c, source_c = hift.inference(speech_feat=mel[:, :, :60], finalize=False)
+        f0 = hift.f0_predictor(mel.to(torch.float64), finalize=True).float()
+    save("fullsize_causal_hift", mel=mel[0], f0=f0, speech=speech, source=source, speech_c=speech_c, source_c=source_c)
+
+
+def golden_cv1_flow():
+    """MaskedDiffWithXvec.inference (flow/flow.py:102-146: InterpolateRegulator, ConditionalCFM with its flow cache, the U-Net ConditionalDecoder flow/decoder.py:88-291 over
+    the restated Matcha blocks) at CosyVoice-300M dimensions on bench.py's inference_sft request: the 500 ids of fullsize_cv1_llm.npz, no prompt.  The CFM noise is the
+    global torch RNG (flow_matching.py:50), seeded right before the call."""
+    cfg, hcfg = W.cv1()
+    MG1.CFG, MG1.HCFG = cfg, hcfg
+    flow = MG1.build_flow()
+    g = np.load(os.path.join(HERE, "fullsize_cv1_llm.npz"))
+    token, emb = torch.from_numpy(g["tokens"]).to(torch.int32).unsqueeze(0), torch.from_numpy(g["embedding"])
+    t = lambda n: torch.tensor([n], dtype=torch.int32)
+    e0 = torch.zeros(1, 0, dtype=torch.int32)
+    t0 = time.time()
+    torch.manual_seed(41)
+    feat, cache = flow.inference(token=token, token_len=t(token.shape[1]), prompt_token=e0, prompt_token_len=t(0), prompt_feat=torch.zeros(1, 0, 80), prompt_feat_len=t(0),
+                                 embedding=emb, flow_cache=torch.zeros(1, 80, 0, 2))
+    print("  MaskedDiffWithXvec.inference from the real class in %.0f s" % (time.time() - t0))
+    save("fullsize_cv1_flow", feat=feat[0], cache_tail=cache[0, :, -8:])
+
+
+def golden_cv1_hift():
+    """HiFTGenerator.inference at 22.05 kHz dimensions (upsample_rates [8, 8], SineGen type 1) on 100 frames of that mel; global RNG seeded before the call."""
+    cfg, hcfg = W.cv1()
+    MG1.CFG, MG1.HCFG = cfg, hcfg
+    h = MG1.build_hift()
+    feat = torch.from_numpy(np.load(os.path.join(HERE, "fullsize_cv1_flow.npz"))["feat"])[None, :, 300:300 + HIFT_FRAMES].contiguous()
+    torch.manual_seed(77)
+    speech, source = h.inference(speech_feat=feat)
+    with torch.inference_mode():
+        f0 = h.f0_predictor(feat)
+    save("fullsize_cv1_hift", feat=feat[0], f0=f0, speech=speech, source=source)
+
+
 if __name__ == "__main__":
-    for w in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["llm", "llm_cv3", "cv1_llm", "flow", "hift"]):
+    for w in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["llm", "llm_cv3", "cv1_llm", "flow", "hift", "dit", "causal_hift", "cv1_flow", "cv1_hift"]):
         print(w)
         globals()["golden_" + w]()

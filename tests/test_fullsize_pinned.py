@@ -154,3 +154,89 @@ def test_hift_fullsize():
         torch.testing.assert_close(source, g["source"], rtol=0, atol=2e-3)
         torch.testing.assert_close(OH.decode(sd, hc, mel, g["source"]), g["speech"], rtol=1e-4, atol=1e-4)
     assert (g["f0"] > hc.voiced_thr).any()
+
+
+def test_mixed64_oracle_tokens_are_the_real_qwen2lm_tokens():
+    """All 20 000 ids of the 64 utterances of the mixed64 workload (BASELINE.json configs[3]; bench.py checks every utterance of its batched / queued runs against
+    tests/golden/mixed64_oracle_tokens.json) are the real Qwen2LM's - including the steps whose top-2 margin is a few 1e-5."""
+    g, j = np.load(os.path.join(G, "fullsize_mixed64.npz")), _json("mixed64_oracle_tokens.json")
+    assert len(j["utterances"]) == 64
+    n = 0
+    for ut in j["utterances"]:
+        assert ut["tokens"] == g["tokens_%02d" % ut["index"]].tolist() and len(ut["tokens"]) == ut["n_gen"]
+        n += len(ut["tokens"])
+    assert n == 16 * (125 + 250 + 375 + 500)
+
+
+def test_dit_flow_fullsize():
+    """oracle.dit against the real CausalMaskedDiffWithDiT / DiT at Fun-CosyVoice3-0.5B dimensions (22 blocks x 1024) on bench.py's cosyvoice3 request: the estimator
+    boundary at T = 674 in both mask modes and inference with two Euler steps."""
+    from oracle import dit as OD
+    g = load("fullsize_dit")
+    lc, fc = CF.cv3_llm(), CF.cv3_flow()
+    sd = W.make_flow_dit(fc)
+    u = W.synthetic_utterance(lc, fc, n_prompt_tok=N_PROMPT_TOK, n_prompt_text=24, n_text=N_TEXT, seed=2025)
+    token = torch.tensor(_json("cv3_u10_oracle_tokens.json")["tokens"], dtype=torch.int32).unsqueeze(0)
+    gen = torch.Generator().manual_seed(14)
+    T = 2 * (N_PROMPT_TOK + N_GEN)
+    x = torch.randn(2, 80, T, generator=gen); mu = torch.randn(2, 80, T, generator=gen); cond = torch.randn(2, 80, T, generator=gen)
+    spk = torch.randn(2, 80, generator=gen); t = torch.tensor([0.25, 0.25]); mask = torch.ones(2, 1, T)
+    with torch.inference_mode():
+        for streaming, key in ((False, "est_full"), (True, "est_stream")):
+            out = OD.estimator(sd, fc, x, mask, mu, t, spk, cond, streaming)
+            for got, want in ((out[0, :, ::2], g[key]), (out[1, :, ::8], g[key + "_row1"])):
+                torch.testing.assert_close(got, want, rtol=1e-2, atol=1e-4)      # the reference's own export tolerance (bin/export_onnx.py:109)
+                torch.testing.assert_close(got, want, rtol=5e-4, atol=5e-4)
+        assert not torch.allclose(g["est_full"], g["est_stream"], atol=1e-3)
+        mel = OD.inference(sd, fc, token, u["flow_prompt_speech_token"], u["prompt_speech_feat"], u["flow_embedding"], streaming=False, finalize=True, n_timesteps=2)
+        assert mel.shape == (1, 80, 2 * N_GEN)
+        torch.testing.assert_close(mel[0], g["mel_2steps"], rtol=2e-3, atol=2e-3)
+
+
+def test_causal_hift_fullsize():
+    """oracle.hift causal_* against the real CausalHiFTGenerator (float64 f0 predictor) at Fun-CosyVoice3-0.5B dimensions, one-shot and as a non-final chunk."""
+    g = load("fullsize_causal_hift")
+    hc = CF.cv3_hift()
+    sd = W.make_hift(hc)
+    mel = g["mel"].unsqueeze(0)
+    m = mel.shape[2]
+    gen = torch.Generator().manual_seed(16)                             # the noise buffers make_golden_fullsize.golden_causal_hift gave the real generator
+    rand_ini = torch.rand(1, 9, generator=gen); rand_ini[:, 0] = 0
+    noise = torch.rand(1, 480 * m, 9, generator=gen)
+    with torch.inference_mode():
+        torch.testing.assert_close(OH.causal_f0_predictor(sd, mel, True), g["f0"], rtol=1e-5, atol=1e-4)
+        speech, source = OH.causal_inference(sd, hc, mel, True, rand_ini, noise)
+        torch.testing.assert_close(source, g["source"], rtol=0, atol=2e-3)
+        assert speech.shape == g["speech"].shape
+        torch.testing.assert_close(OH.causal_decode(sd, hc, mel, g["source"], True), g["speech"], rtol=1e-4, atol=1e-4)
+        speech_c, source_c = OH.causal_inference(sd, hc, mel[:, :, :60], False, rand_ini, noise)
+        torch.testing.assert_close(source_c, g["source_c"], rtol=0, atol=2e-3)
+        assert speech_c.shape == g["speech_c"].shape                   # a non-final chunk: the f0 predictor holds 3 frames back (generator.py:719-722), conv_pre 4 more
+        torch.testing.assert_close(OH.causal_decode(sd, hc, mel[:, :, :60 - 3], g["source_c"], False), g["speech_c"], rtol=1e-4, atol=1e-4)
+
+
+def test_cv1_port_flow_and_hift_fullsize():
+    """The torch-eager CosyVoice-300M port (cosyvoice_amd/cosyvoice1.py - what tests/test_zzzz_cosyvoice1_fullsize.py and bench.py hold the kernels to at full size)
+    against the real MaskedDiffWithXvec (InterpolateRegulator, flow cache, the U-Net ConditionalDecoder) and the real 22.05 kHz HiFTGenerator at CosyVoice-300M
+    dimensions on bench.py's inference_sft request (500 ids -> 861 mel frames); global-RNG draws seeded as the generator seeded them."""
+    from cosyvoice_amd import cosyvoice1 as C1
+    cfg, hcfg = W.cv1()
+    gl, gf, gh = load("fullsize_cv1_llm"), load("fullsize_cv1_flow"), load("fullsize_cv1_hift")
+    tl = lambda n: torch.tensor([n], dtype=torch.int32)
+    e0 = torch.zeros(1, 0, dtype=torch.int32)
+    flow = C1.MaskedDiffWithXvec(W.make_cv1_flow(cfg), enc_heads=cfg.flow_heads, est_heads=cfg.est_heads, input_frame_rate=cfg.input_frame_rate)
+    token = gl["tokens"].to(torch.int32).unsqueeze(0)
+    torch.manual_seed(41)
+    feat, cache = flow.inference(token=token, token_len=tl(500), prompt_token=e0, prompt_token_len=tl(0), prompt_feat=torch.zeros(1, 0, 80), prompt_feat_len=tl(0),
+                                 embedding=gl["embedding"], flow_cache=torch.zeros(1, 80, 0, 2))
+    assert feat.shape == (1, 80, int(500 / 50 * 22050 / 256))
+    torch.testing.assert_close(feat[0], gf["feat"], rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(cache[0, :, -8:], gf["cache_tail"], rtol=1e-4, atol=1e-4)
+    h = C1.HiFTGenerator(W.make_hift(hcfg), sampling_rate=hcfg.sr, upsample_rates=hcfg.ups, upsample_kernel_sizes=hcfg.up_k, source_resblock_kernel_sizes=hcfg.src_k)
+    mel = gh["feat"].unsqueeze(0)
+    torch.testing.assert_close(h.f0_predictor(mel), gh["f0"], rtol=1e-4, atol=1e-3)
+    torch.manual_seed(77)
+    speech, source = h.inference(speech_feat=mel)
+    assert speech.shape == gh["speech"].shape == (1, 100 * 256)
+    torch.testing.assert_close(source, gh["source"], rtol=0, atol=2e-3)      # (the harmonic phase is a cumulative sum: fp32 summation order shows at ~1e-4 in sin(phase))
+    torch.testing.assert_close(speech, gh["speech"], rtol=0, atol=5e-3)
