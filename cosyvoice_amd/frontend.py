@@ -319,3 +319,166 @@ def load_wav(wav, target_sr, min_sr=16000, lib=None):
         assert sample_rate >= min_sr, 'wav sample rate {} must be greater than {}'.format(sample_rate, target_sr)
         speech = Resample(sample_rate, target_sr, lib=lib)(speech)
     return speech
+
+
+# -----------------------------------------------------------------------------------------------------------------------------------
+# Request assembly: what `CosyVoiceFrontEnd.frontend_*` hand to `CosyVoice2Model.tts(**model_input)`
+# -----------------------------------------------------------------------------------------------------------------------------------
+_LLM_SPEECH_PROMPT = ("llm_prompt_speech_token", "llm_prompt_speech_token_len")
+_TEXT_PROMPT = ("prompt_text", "prompt_text_len")
+# what each prompt-driven mode REMOVES from the zero-shot request (cli/frontend.py:195-214): cross-lingual synthesis keeps no prompt inside the LLM at all, instruct2
+# keeps the instruction as prompt text but no speech prompt
+_MODE_DROPS = {"zero_shot": (), "cross_lingual": _TEXT_PROMPT + _LLM_SPEECH_PROMPT, "instruct2": _LLM_SPEECH_PROMPT}
+
+
+def _ort_session(model, providers):
+    """A path becomes an onnxruntime session configured as cli/frontend.py:42-48 does; a session-like object (`.get_inputs()`, `.run(None, feeds)`) is used as it is;
+    None stays None (speakers then come from spk2info only)."""
+    if model is None or not isinstance(model, (str, bytes)):
+        return model
+    try:
+        import onnxruntime
+    except ImportError as e:
+        raise RuntimeError("cosyvoice_amd.frontend: %r needs onnxruntime for the speech tokenizer / CAM++ networks (they stay ONNX sessions, as in the reference); "
+                           "pass a session object, or register speakers through spk2info" % model) from e
+    opt = onnxruntime.SessionOptions()
+    opt.graph_optimization_level = onnxruntime.GraphOptimizationLevel.ORT_ENABLE_ALL
+    opt.intra_op_num_threads = 1
+    return onnxruntime.InferenceSession(model, sess_options=opt, providers=providers)
+
+
+class CosyVoiceFrontEnd:
+    """Host mirror of `cosyvoice.cli.frontend.CosyVoiceFrontEnd` for everything between a tokenizer and `model.tts`: the three prompt extractors with their signal
+    processing on the device (PromptExtractors above; the two networks stay the ONNX sessions the reference uses), the speaker cache `spk2info` (cli/frontend.py:49-52 -
+    a cached speaker needs no network at all) and the request assembly of frontend_sft / _zero_shot / _cross_lingual / _instruct / _instruct2 / _vc
+    (cli/frontend.py:157-224).  Same method names, arguments and model_input keys as the reference; pinned by tests/golden/frontend_requests.npz, which the REAL class
+    produced (tests/golden/make_golden_frontend.py).
+
+    Not here (out of scope): text normalisation.  `text_normalize` passes text through exactly where the reference does without a normaliser
+    (generators, SSML-tagged text, text_frontend=False, '') and otherwise calls `text_normalizer(text, split)` if one was given.
+    A prompt is a path to a 16-bit PCM WAV (load_wav above) or a `(waveform[1, L], sample_rate)` pair already in memory."""
+
+    def __init__(self, get_tokenizer, feat_extractor=None, campplus_model=None, speech_tokenizer_model=None, spk2info="", allowed_special="all", lib=None,
+                 text_normalizer=None):
+        import os
+        self.lib = lib or get_lib()
+        self.device = torch.device(self.lib.device)
+        self.tokenizer = get_tokenizer()
+        self.feat_extractor = feat_extractor if feat_extractor is not None else MelSpectrogram(lib=self.lib)
+        self.campplus_session = _ort_session(campplus_model, ["CPUExecutionProvider"])
+        self.speech_tokenizer_session = _ort_session(speech_tokenizer_model, ["ROCMExecutionProvider", "CPUExecutionProvider"])
+        self._extractors = PromptExtractors(self.feat_extractor, self.campplus_session, self.speech_tokenizer_session, lib=self.lib)
+        if isinstance(spk2info, dict):
+            self.spk2info = spk2info
+        else:
+            self.spk2info = torch.load(spk2info, map_location=self.device, weights_only=True) if spk2info and os.path.exists(spk2info) else {}
+        self.allowed_special = allowed_special
+        self.text_normalizer = text_normalizer
+
+    # ---- extractors (cli/frontend.py:86-125)
+    def _extract_text_token(self, text):
+        from typing import Generator
+        if isinstance(text, Generator):                          # streamed text: ids one by one, and a dummy length (frontend.py:87-90)
+            return self._extract_text_token_generator(text), torch.tensor([0], dtype=torch.int32).to(self.device)
+        ids = torch.tensor([self.tokenizer.encode(text, allowed_special=self.allowed_special)], dtype=torch.int32).to(self.device)
+        return ids, torch.tensor([ids.shape[1]], dtype=torch.int32).to(self.device)
+
+    def _extract_text_token_generator(self, text_generator):
+        for piece in text_generator:
+            ids, _ = self._extract_text_token(piece)
+            for i in range(ids.shape[1]):
+                yield ids[:, i:i + 1]
+
+    def _speech(self, prompt_wav, rate):
+        if isinstance(prompt_wav, (tuple, list)):
+            wave_, sr = prompt_wav
+            return wave_ if int(sr) == rate else Resample(int(sr), rate, lib=self.lib)(wave_)
+        return load_wav(prompt_wav, rate, lib=self.lib)
+
+    def _need(self, session, what):
+        if session is None:
+            raise RuntimeError("cosyvoice_amd.frontend: no %s session - give the constructor the .onnx path or a session object, or use a speaker cached in spk2info" % what)
+
+    def _extract_speech_token(self, prompt_wav):
+        self._need(self.speech_tokenizer_session, "speech tokenizer")
+        return self._extractors._extract_speech_token(self._speech(prompt_wav, 16000))
+
+    def _extract_spk_embedding(self, prompt_wav):
+        self._need(self.campplus_session, "CAM++")
+        return self._extractors._extract_spk_embedding(self._speech(prompt_wav, 16000))
+
+    def _extract_speech_feat(self, prompt_wav):
+        return self._extractors._extract_speech_feat(self._speech(prompt_wav, 24000))       # (24 kHz whatever the model: frontend.py:121)
+
+    def text_normalize(self, text, split=True, text_frontend=True):
+        from typing import Generator
+        if isinstance(text, Generator):
+            return [text]
+        if ("<|" in text and "|>" in text) or text_frontend is False or text == "" or self.text_normalizer is None:
+            return [text] if split is True else text
+        return self.text_normalizer(text.strip(), split)
+
+    # ---- requests (cli/frontend.py:157-224)
+    def _prompt_fields(self, prompt_text, prompt_wav, resample_rate):
+        """Everything a request takes from a prompt recording: text ids, mel, speech tokens (the same ids prompt the LLM and the flow), x-vector."""
+        text, text_len = self._extract_text_token(prompt_text)
+        feat, feat_len = self._extract_speech_feat(prompt_wav)
+        tok, tok_len = self._extract_speech_token(prompt_wav)
+        if resample_rate == 24000:                              # 25 Hz tokens, 50 Hz mel: exactly two frames per token (frontend.py:169-173)
+            n = min(int(feat.shape[1] / 2), tok.shape[1])
+            feat, tok = feat[:, :2 * n], tok[:, :n]
+            feat_len[:], tok_len[:] = 2 * n, n
+        emb = self._extract_spk_embedding(prompt_wav)
+        return {"prompt_text": text, "prompt_text_len": text_len, "llm_prompt_speech_token": tok, "llm_prompt_speech_token_len": tok_len,
+                "flow_prompt_speech_token": tok, "flow_prompt_speech_token_len": tok_len, "prompt_speech_feat": feat, "prompt_speech_feat_len": feat_len,
+                "llm_embedding": emb, "flow_embedding": emb}
+
+    def _prompted(self, mode, tts_text, prompt_text, prompt_wav, resample_rate, zero_shot_spk_id):
+        # the text is tokenised first, as in the reference: with streamed text the generator is created before the prompt is read
+        text, text_len = self._extract_text_token(tts_text)
+        req = self._prompt_fields(prompt_text, prompt_wav, resample_rate) if zero_shot_spk_id == "" else dict(self.spk2info[zero_shot_spk_id])
+        req["text"], req["text_len"] = text, text_len
+        for k in _MODE_DROPS[mode]:
+            del req[k]
+        return req
+
+    def frontend_sft(self, tts_text, spk_id):
+        text, text_len = self._extract_text_token(tts_text)
+        emb = self.spk2info[spk_id]["embedding"]
+        return {"text": text, "text_len": text_len, "llm_embedding": emb, "flow_embedding": emb}
+
+    def frontend_zero_shot(self, tts_text, prompt_text, prompt_wav, resample_rate, zero_shot_spk_id):
+        return self._prompted("zero_shot", tts_text, prompt_text, prompt_wav, resample_rate, zero_shot_spk_id)
+
+    def frontend_cross_lingual(self, tts_text, prompt_wav, resample_rate, zero_shot_spk_id):
+        return self._prompted("cross_lingual", tts_text, "", prompt_wav, resample_rate, zero_shot_spk_id)
+
+    def frontend_instruct(self, tts_text, spk_id, instruct_text):
+        req = self.frontend_sft(tts_text, spk_id)
+        del req["llm_embedding"]                                # the speaker vector would leak into an instructed LLM (frontend.py:203-204)
+        req["prompt_text"], req["prompt_text_len"] = self._extract_text_token(instruct_text)
+        return req
+
+    def frontend_instruct2(self, tts_text, instruct_text, prompt_wav, resample_rate, zero_shot_spk_id):
+        return self._prompted("instruct2", tts_text, instruct_text, prompt_wav, resample_rate, zero_shot_spk_id)
+
+    def frontend_vc(self, source_speech_16k, prompt_wav, resample_rate):
+        tok, tok_len = self._extract_speech_token(prompt_wav)
+        feat, feat_len = self._extract_speech_feat(prompt_wav)
+        emb = self._extract_spk_embedding(prompt_wav)
+        src, src_len = self._extract_speech_token(source_speech_16k)
+        return {"source_speech_token": src, "source_speech_token_len": src_len, "flow_prompt_speech_token": tok, "flow_prompt_speech_token_len": tok_len,
+                "prompt_speech_feat": feat, "prompt_speech_feat_len": feat_len, "flow_embedding": emb}
+
+    # ---- the speaker cache (cli/cosyvoice.py:65-78 keeps these three on the model class; they only touch the front end's spk2info)
+    def list_available_spks(self):
+        return list(self.spk2info.keys())
+
+    def add_zero_shot_spk(self, prompt_text, prompt_wav, zero_shot_spk_id, resample_rate=24000):
+        assert zero_shot_spk_id != "", "do not use empty zero_shot_spk_id"
+        entry = self._prompt_fields(prompt_text, prompt_wav, resample_rate)
+        self.spk2info[zero_shot_spk_id] = entry
+        return True
+
+    def save_spkinfo(self, path):
+        torch.save(self.spk2info, path)

@@ -200,3 +200,48 @@ def test_load_wav_reads_pcm16_and_resamples(lib, tmp_path):
         with wave.open(p8, "wb") as w:
             w.setnchannels(1); w.setsampwidth(2); w.setframerate(8000); w.writeframes(x.numpy().tobytes())
         load_wav(p8, 16000, lib=lib)
+
+
+def test_front_end_from_a_wav_file_to_a_request(lib, tmp_path):
+    """cosyvoice_amd.frontend.CosyVoiceFrontEnd end to end (cli/frontend.py:157-184): a 16-bit WAV prompt at 22.05 kHz -> load_wav's resampler to 16 / 24 kHz on the
+    device -> whisper log-mel / Kaldi fbank / 24 kHz prompt mel on the device -> the two (stand-in) ONNX sessions -> a zero-shot request with the forced 2:1 mel / token
+    ratio; the same prompt registered in spk2info then serves a request without touching a network."""
+    import wave
+    from cosyvoice_amd.frontend import CosyVoiceFrontEnd
+
+    class Tok:
+        def encode(self, text, allowed_special="all"):
+            return [ord(c) for c in text]
+    sr = 22050
+    x = (_speechlike(sr // 2, sr, 11)[0] * 32767).round().to(torch.int16)
+    p = str(tmp_path / "prompt.wav")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr); w.writeframes(x.numpy().tobytes())
+    mono = (x.float() / 32768.0).unsqueeze(0)
+    n_tok = 9                                                          # the tokenizer network "returns" 9 tokens; the 24 kHz mel has 0.5 s * 50 = 25 frames
+    tok = _FakeSession(["feats", "feats_length"], np.arange(100, 100 + n_tok, dtype=np.int64)[None])
+    spk = _FakeSession(["input"], np.linspace(-1, 1, 192, dtype=np.float32)[None])
+    fe = CosyVoiceFrontEnd(Tok, campplus_model=spk, speech_tokenizer_model=tok, lib=lib)
+    req = fe.frontend_zero_shot("hi there", "prompt", p, 24000, "")
+    # (the oracle front ends take the waveform the DEVICE resampler produced - that one is held to oracle.sinc_resample by test_load_wav_reads_pcm16_and_resamples -
+    # so that the tolerances below are the ones the extractors' own tests state)
+    y16, y24 = load_wav(p, 16000, lib=lib).cpu(), load_wav(p, 24000, lib=lib).cpu()
+    torch.testing.assert_close(y24, OFE.sinc_resample(mono, sr, 24000), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(tok.feeds["feats"], OFE.whisper_log_mel(y16, 128).numpy(), atol=2e-3)
+    assert req["text"].tolist() == [[ord(c) for c in "hi there"]] and req["text_len"].tolist() == [8] and req["prompt_text_len"].tolist() == [6]
+    assert req["llm_prompt_speech_token"].tolist() == [list(range(100, 100 + n_tok))] and req["flow_prompt_speech_token_len"].tolist() == [n_tok]
+    want_mel = OFE.mel_spectrogram(y24)[0].transpose(0, 1)[: 2 * n_tok]
+    assert req["prompt_speech_feat"].shape == (1, 2 * n_tok, 80) and req["prompt_speech_feat_len"].tolist() == [2 * n_tok]
+    diff = (req["prompt_speech_feat"][0].cpu() - want_mel).abs()
+    loud = want_mel > np.log(1e-3)                                     # the tolerance rule of test_prompt_mel_matches_oracle
+    assert diff[loud].max().item() < 2e-3 and diff.max().item() < 5e-2
+    assert req["llm_embedding"].shape == (1, 192) and torch.equal(req["llm_embedding"], req["flow_embedding"])
+    # a (waveform, rate) pair instead of a path: the same request
+    req2 = fe.frontend_zero_shot("hi there", "prompt", (mono, sr), 24000, "")
+    assert all(torch.equal(req[k], req2[k]) for k in req)
+    # cached speaker: no session is touched again
+    fe.add_zero_shot_spk("prompt", p, "me")
+    tok.feeds = spk.feeds = None
+    req3 = fe.frontend_cross_lingual("hola", "unused.wav", 24000, "me")
+    assert tok.feeds is None and spk.feeds is None and "prompt_text" not in req3 and "llm_prompt_speech_token" not in req3
+    assert torch.equal(req3["prompt_speech_feat"], req["prompt_speech_feat"]) and req3["text"].tolist() == [[ord(c) for c in "hola"]]
