@@ -169,7 +169,8 @@ def ras_check(model, u):
     if div is not None:
         raise RuntimeError("bench RAS check: the device's sampled tokens leave the oracle's at step %s (device %s, oracle %s) where the decision margin is %s"
                            % (div, toks[div] if div < len(toks) else None, want[div] if div < len(want) else None, gold["margin"][div] if div < len(gold["margin"]) else None))
-    return {"ras_tokens_equal_oracle": div is None, "first_divergence": div, "margin_there": None if div is None else gold["margin"][div], "n_tokens": len(toks),
+    real = real_class_tokens("fullsize_llm_ras")                # the real Qwen2LM + the real ras_sampling on the same variates (make_golden_fullsize.py llm_ras)
+    return {"ras_tokens_equal_oracle": div is None, "ras_tokens_equal_real_reference_class": None if real is None else [int(t) for t in toks] == real, "first_divergence": div, "margin_there": None if div is None else gold["margin"][div], "n_tokens": len(toks),
             "distinct_ids": len(set(want)), "fallback_draws": gold["fallback_draws"], "oracle_min_margin": gold["min_margin"]}
 
 

@@ -1,6 +1,6 @@
 """Golden vectors at the FULL model dimensions, made by the REAL reference classes (/root/reference) - build container only:
 
-    python tests/golden/make_golden_fullsize.py [llm] [llm_cv3] [cv1_llm] [flow] [hift] [dit] [causal_hift] [cv1_flow] [cv1_hift] [mixed64]   (no argument: all but mixed64, ~8 min on 8 cores)
+    python tests/golden/make_golden_fullsize.py [llm] [llm_ras] [llm_cv3] [cv1_llm] [flow] [hift] [dit] [causal_hift] [cv1_flow] [cv1_hift] [mixed64]   (no argument: all but mixed64, ~8 min on 8 cores)
 
 The other generators (make_golden.py, make_golden_cv1.py) run the reference at test dimensions, which pins the oracle's ARITHMETIC; the full-size parity
 tests and every bench run then compare the kernels with the oracle's own full-size output (tests/golden/u10_oracle_tokens.json, cv3_u10_oracle_tokens.json,
@@ -8,6 +8,7 @@ oracle.flow / oracle.hift computed on the spot).  This script closes that last l
 dicts of cosyvoice_amd.synthetic, run the BENCHMARK requests themselves -
 
   llm      cosyvoice.llm.llm.Qwen2LM.inference (llm/llm.py:458-549) at CosyVoice2-0.5B dimensions on U10: all 250 greedy ids + the first log-prob rows
+  llm_ras  the same class with the REAL ras_sampling on U10, its multinomial draws replaced by the stored variates of u10_ras_oracle_tokens.json: all 250 ids
   mixed64  the same class on the 64 utterances of bench.py's mixed64 workload (configs[3]): every id (not in the default list: ~15 min)
   llm_cv3  CosyVoice3LM.inference (llm/llm.py:664-706) at Fun-CosyVoice3-0.5B dimensions on bench.py's instruct request: all 250 ids
   cv1_llm  TransformerLM.inference (llm/llm.py:162-223) at CosyVoice-300M dimensions on bench.py's inference_sft request: all 500 ids
@@ -127,6 +128,39 @@ def golden_mixed64():
         out["tokens_%02d" % i] = np.array(_run_lm(lm, logps, u, lc, N_PROMPT_TOK, n_gen), dtype=np.int16)
         out["min_margin_%02d" % i] = _margins(logps, lc.speech_token_size).min()
     save("fullsize_mixed64", **out)
+
+
+def golden_llm_ras():
+    """U10 decoded by the real Qwen2LM with the REAL repetition-aware sampler (cosyvoice/utils/common.py:138-167: ras_sampling -> nucleus_sampling / random_sampling)
+    at full size.  Its draws (`Tensor.multinomial` on the global RNG, which nothing else can reproduce) are replaced by an inverse CDF on the variates stored in
+    u10_ras_oracle_tokens.json - two per step, nucleus draw then fallback draw - i.e. the decision logic runs from the reference on the reference's own probabilities;
+    bench.py replays the same variates on the device (`self_check.ras`)."""
+    from cosyvoice.utils.common import ras_sampling
+    lc, fc, _ = W.cv2()
+    lm, _ = _qwen_lm(lc, "Qwen2LM")
+    gold = json.load(open(os.path.join(HERE, "u10_ras_oracle_tokens.json")))
+    us, cur, step, n_fallback = gold["variates"], [], [0], [0]
+
+    def fake_multinomial(self, n, replacement=False):
+        u = cur.pop(0)
+        cdf = torch.cumsum(self.double() / self.double().sum(), 0)
+        return torch.searchsorted(cdf, torch.tensor([u], dtype=torch.float64), right=True).clamp(max=self.numel() - 1)
+
+    def sampler(scores, decoded, sampling):
+        cur[:] = [us[2 * step[0]], us[2 * step[0] + 1]]
+        step[0] += 1
+        t = ras_sampling(scores, decoded, sampling)
+        n_fallback[0] += int(len(cur) == 0)                    # both variates used: the repetition fallback drew
+        return t
+    lm.sampling = sampler
+    orig = torch.Tensor.multinomial
+    torch.Tensor.multinomial = fake_multinomial
+    try:
+        u = W.synthetic_utterance(lc, fc, n_prompt_tok=N_PROMPT_TOK, n_prompt_text=N_PROMPT_TEXT, n_text=N_TEXT)
+        toks = _run_lm(lm, [], u, lc, N_PROMPT_TOK)
+    finally:
+        torch.Tensor.multinomial = orig
+    save("fullsize_llm_ras", tokens=np.array(toks, dtype=np.int32), fallback_draws=np.array(n_fallback[0]), distinct=np.array(len(set(toks))))
 
 
 def golden_llm_cv3():
@@ -289,6 +323,6 @@ def golden_cv1_hift():
 
 
 if __name__ == "__main__":
-    for w in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["llm", "llm_cv3", "cv1_llm", "flow", "hift", "dit", "causal_hift", "cv1_flow", "cv1_hift"]):
+    for w in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["llm", "llm_ras", "llm_cv3", "cv1_llm", "flow", "hift", "dit", "causal_hift", "cv1_flow", "cv1_hift"]):
         print(w)
         globals()["golden_" + w]()

@@ -41,6 +41,15 @@ def test_u10_oracle_tokens_are_the_real_qwen2lm_tokens():
     assert np.abs(np.array(j["top2_margin"]) - g["top2_margin"].numpy()).max() < 2e-4
 
 
+def test_u10_ras_oracle_tokens_are_the_real_sampler_tokens():
+    """The 250 repetition-aware-sampled ids of tests/golden/u10_ras_oracle_tokens.json (149 distinct; bench.py replays them on the device with the stored variates) are what
+    the real Qwen2LM produces with the REAL ras_sampling / nucleus_sampling / random_sampling (utils/common.py:138-167) when its multinomial draws are inverse-CDF draws on
+    those variates - the same 14 steps take the repetition fallback."""
+    g, j = load("fullsize_llm_ras"), _json("u10_ras_oracle_tokens.json")
+    assert len(j["tokens"]) == N_GEN and j["tokens"] == g["tokens"].tolist()
+    assert int(g["fallback_draws"]) == j["fallback_draws"] == 14 and int(g["distinct"]) == j["distinct"] == len(set(j["tokens"]))
+
+
 def test_cv3_oracle_tokens_are_the_real_cosyvoice3lm_tokens():
     g, j = load("fullsize_llm_cv3"), _json("cv3_u10_oracle_tokens.json")
     assert len(j["tokens"]) == N_GEN and j["tokens"] == g["tokens"].tolist()
