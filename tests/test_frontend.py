@@ -1,6 +1,7 @@
 """on-device 24 kHz prompt log-mel (cosyvoice/cli/frontend.py:120-125) vs the oracle restatement of
 matcha.utils.audio.mel_spectrogram (parity unpinned: the Matcha submodule and librosa are absent, see oracle/frontend.py)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -208,6 +209,9 @@ def test_front_end_from_a_wav_file_to_a_request(lib, tmp_path):
     ratio; the same prompt registered in spk2info then serves a request without touching a network."""
     import wave
     from cosyvoice_amd.frontend import CosyVoiceFrontEnd
+    if not lib.emulated and not os.environ.get("CV_TEST_UNVALIDATED"):
+        pytest.skip("written after the round's GPU minutes were spent: composes load_wav / WhisperLogMel / KaldiFbank / MelSpectrogram, each held to its oracle on the "
+                    "MI355X by the tests above; the composition itself has run under the emulator only (CV_TEST_UNVALIDATED=1 runs it)")
 
     class Tok:
         def encode(self, text, allowed_special="all"):
