@@ -72,6 +72,73 @@ class EstimatorModule(torch.nn.Module):
         return out.to(device=x.device, dtype=x.dtype)
 
 
+class EstimatorEngine:
+    """Boundary B3, second form: the object the reference's `forward_estimator` takes when `flow.decoder.estimator` is NOT an nn.Module
+    (flow/flow_matching.py:129-153 - the shape of its TensorRT path: `TrtContextWrapper`, utils/common.py:199-214, around an engine and its execution contexts).
+    `forward_estimator` then does
+
+        [ctx, stream], engine = estimator.acquire_estimator()
+        with stream: ctx.set_input_shape(name, shape) x 6; ctx.set_tensor_address(engine.get_tensor_name(i), ptr) for x, mask, mu, t, spks, cond and the OUTPUT
+                     aliased on x; ctx.execute_async_v3(current stream handle)
+        estimator.release_estimator(ctx, stream)
+
+    i.e. raw device pointers and a stream handle - exactly the arguments of cv_flow_estimator, which this object calls (the output may alias x: x is read by the
+    first launch only, the result written by the last).  Swap (cli/model.py:load_trt does the same two statements around its engine):
+
+        del model.flow.decoder.estimator
+        model.flow.decoder.estimator = EstimatorEngine(cosyvoice_amd_flow)
+
+    Like a TensorRT engine - and unlike EstimatorModule - it sees no dtypes and no `streaming` flag: buffers must be fp32 (the reference's fp16=False), the mask all
+    ones (flow.inference is batch 1, flow/flow.py:270), and the attention mode is fixed at construction (`streaming=False`: full attention, what the reference's
+    exported engine computes, bin/export_onnx.py:71-87).  One context (trt_concurrent = 1): concurrent callers queue on acquire_estimator, as they do on the
+    reference's pool."""
+
+    TENSOR_NAMES = ("x", "mask", "mu", "t", "spks", "cond", "estimator_out")      # bin/export_onnx.py:71-87
+
+    class _Context:
+        def __init__(self, engine):
+            self.engine, self.shapes, self.addrs = engine, {}, {}
+
+        def set_input_shape(self, name, shape):
+            self.shapes[name] = tuple(int(d) for d in shape)
+            return True
+
+        def set_tensor_address(self, name, ptr):
+            self.addrs[name] = int(ptr)
+            return True
+
+        def execute_async_v3(self, stream_handle):
+            f = self.engine.flow
+            mel = f.cfg.mel
+            T = (self.shapes.get("x") or (0, 0, 0))[2]
+            want = {"x": (2, mel, T), "mask": (2, 1, T), "mu": (2, mel, T), "t": (2,), "spks": (2, mel), "cond": (2, mel, T)}
+            if any(self.shapes.get(k) != v for k, v in want.items()) or any(not self.addrs.get(k) for k in EstimatorEngine.TENSOR_NAMES):
+                raise ValueError("EstimatorEngine: expected the estimator's six inputs as %s and seven tensor addresses, got shapes %s, addresses for %s"
+                                 % (want, self.shapes, sorted(self.addrs)))
+            a = self.addrs
+            f.lib.cv_flow_estimator(f._h, *[C.c_void_p(a[k]) for k in ("x", "mask", "mu", "t", "spks", "cond")], C.c_int32(T), C.c_int32(int(self.engine.streaming)),
+                                    C.c_void_p(a["estimator_out"]), C.c_void_p(int(stream_handle)) if stream_handle else None)
+            return True
+
+    def __init__(self, flow, streaming=False):
+        import contextlib
+        import queue
+        self.flow, self.streaming = flow, bool(streaming)
+        dev = flow.device
+        stream = torch.cuda.stream(torch.cuda.Stream(dev)) if dev.type == "cuda" else contextlib.nullcontext()
+        self._pool = queue.Queue(maxsize=1)
+        self._pool.put([EstimatorEngine._Context(self), stream])
+
+    def acquire_estimator(self):
+        return self._pool.get(), self
+
+    def release_estimator(self, context, stream):
+        self._pool.put([context, stream])
+
+    def get_tensor_name(self, i):
+        return EstimatorEngine.TENSOR_NAMES[i]
+
+
 class _Encoder(torch.nn.Module):
     """flow.encoder: (token_emb[1,n,dim], token_len, context=[1,3,dim] | empty, streaming) -> (h[1,2n,dim], mask[1,1,2n]).
 

@@ -206,6 +206,8 @@ int cv_flow_profile_block(cv_flow* m, int32_t nz, int32_t T, int32_t reps, float
 int cv_flow_encoder(cv_flow* m, const float* tok_emb, int32_t n_tok, const float* context, int32_t streaming, float* h_out, void* stream);
 /* B3: flow.decoder.estimator(x[2,80,T], mask[2,1,T], mu[2,80,T], t[2], spks[2,80], cond[2,80,T], streaming) -> [2,80,T]
  * (flow/flow_matching.py:126-128 nn.Module branch, flow/decoder.py:405-494); all dev fp32 contiguous, reference layouts.
+ * `out` may alias `x` (x is read by the first launch only): that is what the reference's other branch hands over - raw addresses with the output on x
+ * (flow_matching.py:129-153, the TensorRT-shaped form; host side: cosyvoice_amd.flow.EstimatorEngine).
  * mask must be all ones (batch-1 inference, flow.py:270); it is applied to the output like the reference's `output * mask`. */
 int cv_flow_estimator(cv_flow* m, const float* x, const float* mask, const float* mu, const float* t, const float* spks, const float* cond,
                       int32_t T, int32_t streaming, float* out, void* stream);

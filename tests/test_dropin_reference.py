@@ -151,6 +151,50 @@ def test_b3_estimator_with_a_padded_mask_inside_the_real_cfm(emu_lib, ref):
     assert float(outs[0][:, :, :n].abs().max()) > 0.1
 
 
+def test_b3_engine_form_inside_the_real_cfm(emu_lib, ref, monkeypatch):
+    """B3, the NON-Module branch of forward_estimator (flow/flow_matching.py:129-153, the shape of the reference's TensorRT path): `del decoder.estimator;
+    decoder.estimator = EstimatorEngine(amd_flow)`.  The REAL CausalConditionalCFM.forward -> solve_euler -> forward_estimator then acquires the context, sets six
+    input shapes and seven raw tensor addresses (the output aliased on x), executes on the current stream and releases - and gets what the nn.Module form
+    (EstimatorModule) gives, bit for bit, and the real estimator's result within the fp32 bound.  (No GPU here: `torch.cuda.current_stream()` of that branch is
+    stood in for; the addresses are host addresses the emulator build reads.)"""
+    from cosyvoice_amd.flow import EstimatorEngine, EstimatorModule
+    fc = ref["cfgs"][1]
+    g = torch.Generator().manual_seed(78)
+    T = 48
+    mu, cond, spks = torch.randn(1, 80, T, generator=g), torch.randn(1, 80, T, generator=g), torch.randn(1, 80, generator=g)
+    mask = torch.ones(1, 1, T)
+
+    class _Stream:
+        cuda_stream = 0
+
+        def synchronize(self):
+            pass
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _Stream())
+    outs = {}
+    for form in ("real", "module", "engine"):
+        flow = ref["MG"].build_ref_flow(fc)
+        amd = _amd_flow(ref, emu_lib)
+        if form == "module":
+            flow.decoder.estimator = EstimatorModule(amd)
+        elif form == "engine":
+            del flow.decoder.estimator                          # (a registered submodule name: cli/model.py:load_trt deletes it first, too)
+            flow.decoder.estimator = EstimatorEngine(amd)
+            assert not isinstance(flow.decoder.estimator, torch.nn.Module)
+        with torch.inference_mode():
+            y, _ = flow.decoder(mu=mu, mask=mask, spks=spks, cond=cond, n_timesteps=N_STEPS)
+        outs[form] = y.cpu()
+        if form == "engine":
+            eng = flow.decoder.estimator
+            assert eng._pool.qsize() == 1                       # released after every call
+            ctx = eng._pool.queue[0][0]
+            assert ctx.shapes["x"] == (2, 80, T) and ctx.addrs["estimator_out"] == ctx.addrs["x"] and set(ctx.addrs) == set(EstimatorEngine.TENSOR_NAMES)
+            with pytest.raises(ValueError):                     # a context that was not given the estimator's tensors says so instead of reading address 0
+                EstimatorEngine._Context(eng).execute_async_v3(0)
+    assert torch.equal(outs["engine"], outs["module"])
+    torch.testing.assert_close(outs["engine"], outs["real"], rtol=2e-4, atol=2e-4)
+    assert float(outs["real"].abs().max()) > 0.1
+
+
 def test_b4_encoder_swap_inside_the_real_model(emu_lib, ref):
     """B4: `model.flow.encoder = amd_flow.encoder`, the contract of the reference's own TorchScript encoder swap (cli/model.py:277-279)."""
     for stream in (False, True):
