@@ -748,7 +748,8 @@ def cpu_baseline(cfgs):
             stage_s[key], threads[key] = d[best][key], int(best)
     total = stage_s["llm_prefill"] + N_GEN * stage_s["llm_per_token"] + stage_s["flow_encoder"] + fc.n_timesteps * stage_s["flow_estimator_step"] + stage_s["hift_500_frames"]
     return dict(value=round(AUDIO_S / total, 4), unit="audio_s/s", cores=max(threads.values()), kind="port (sampled: bounded sample of U10 per stage, extrapolated)", host_cores=os.cpu_count(),
-                sample="oracle/ (torch fp32 eager, the CPU restatement of the reference - not the reference modules), one fresh process per stage, best of a thread sweep per "
+                sample="oracle/ (torch fp32 eager, the CPU restatement of the reference - not the reference modules, which cannot travel to this box; on this workload, at these dimensions, "
+                       "it reproduces the real classes' token ids exactly and their mel / waveform to 4e-6 / 3e-7: tests/test_fullsize_pinned.py), one fresh process per stage, best of a thread sweep per "
                        "stage: LLM prefill(131) + 12 decode steps (4 each at context 131 / 256 / 381, averaged: the range U10's 250 steps cover), flow encoder(337 tok) + 1 of 10 "
                        "estimator steps at T=674, HiFT 100 of 500 frames; per-stage times extrapolated to the full U10 utterance",
                 threads_used=threads, stage_seconds={k: round(v, 4) for k, v in stage_s.items()})
