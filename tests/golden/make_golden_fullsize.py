@@ -1,6 +1,6 @@
 """Golden vectors at the FULL model dimensions, made by the REAL reference classes (/root/reference) - build container only:
 
-    python tests/golden/make_golden_fullsize.py [llm] [llm_ras] [llm_cv3] [cv1_llm] [flow] [hift] [dit] [causal_hift] [cv1_flow] [cv1_hift] [mixed64]   (no argument: all but mixed64, ~8 min on 8 cores)
+    python tests/golden/make_golden_fullsize.py [llm] [llm_ras] [llm_cv3] [cv1_llm] [flow] [hift] [dit] [causal_hift] [cv1_flow] [cv1_hift] [model] [mixed64]   (no argument: all but mixed64, ~8 min on 8 cores)
 
 The other generators (make_golden.py, make_golden_cv1.py) run the reference at test dimensions, which pins the oracle's ARITHMETIC; the full-size parity
 tests and every bench run then compare the kernels with the oracle's own full-size output (tests/golden/u10_oracle_tokens.json, cv3_u10_oracle_tokens.json,
@@ -16,6 +16,7 @@ dicts of cosyvoice_amd.synthetic, run the BENCHMARK requests themselves -
            mel [80, 500]; the estimator boundary at T = 674 (offline and streaming masks); the encoder at 337 tokens
   hift     HiFTGenerator.inference (hifigan/generator.py:557-569) at 24 kHz dimensions on 100 frames of that mel
   dit, causal_hift   CausalMaskedDiffWithDiT / DiT and CausalHiFTGenerator at Fun-CosyVoice3-0.5B dimensions (row a17)
+  model    cli.model.CosyVoice2Model.tts on U10 with its default streaming settings, offline and streamed (scripted LLM = the 250 ids above): chunk lengths + waveforms
   cv1_flow, cv1_hift MaskedDiffWithXvec (U-Net ConditionalDecoder, flow cache) and the 22.05 kHz HiFTGenerator at CosyVoice-300M dimensions (rows a18 / f4)
 
 and tests/test_fullsize_pinned.py (CPU, `-m "not gpu"`) holds the oracle - and the committed oracle token files the GPU runs are checked against - to them.
@@ -322,7 +323,42 @@ def golden_cv1_hift():
     save("fullsize_cv1_hift", feat=feat[0], f0=f0, speech=speech, source=source)
 
 
+def golden_model():
+    """The whole benchmark request through the REAL cosyvoice.cli.model.CosyVoice2Model.tts (cli/model.py:328-394: token2wav, the streaming loop with its default hops
+    25 -> 50 -> 100 and the 13-token prompt pad, mel / source / speech caches, fade_in_out) around the real full-size flow + HiFT, offline and streaming, with a scripted LLM
+    that yields U10's 250 ids (= the real Qwen2LM's, fullsize_llm.npz).  SineGen2's additive noise (generator.py:312) is zeros for the run, the convention of every
+    model-level comparison here (make_golden.golden_model).  Stored: the chunk lengths and every 8th sample of the two waveforms."""
+    import cosyvoice.cli.model as M
+    lc, fc, hc = W.cv2()
+    flow, hift = MG.build_ref_flow(fc), MG.build_ref_hift(hc)
+    u = W.synthetic_utterance(lc, fc, n_prompt_tok=N_PROMPT_TOK, n_prompt_text=N_PROMPT_TEXT, n_text=N_TEXT)
+    tokens = [int(t) for t in np.load(os.path.join(HERE, "fullsize_llm.npz"))["tokens"]]
+
+    class ScriptedLLM:
+        def inference(self, **kw):
+            yield from tokens
+    orig_randn_like = torch.randn_like
+    torch.randn_like = lambda t, **kw: torch.zeros_like(t)
+    M.time.sleep = lambda s: None
+    out = {}
+    try:
+        for stream in (False, True):
+            t0 = time.time()
+            m = M.CosyVoice2Model(ScriptedLLM(), flow, hift)
+            with torch.inference_mode():
+                chunks = [o["tts_speech"] for o in m.tts(text=u["text"], flow_embedding=u["flow_embedding"], llm_embedding=u["llm_embedding"], prompt_text=u["prompt_text"],
+                                                        llm_prompt_speech_token=u["llm_prompt_speech_token"], flow_prompt_speech_token=u["flow_prompt_speech_token"],
+                                                        prompt_speech_feat=u["prompt_speech_feat"], stream=stream)]
+            key = "stream" if stream else "offline"
+            out[key + "_n"] = np.array([c.shape[1] for c in chunks])
+            out[key] = torch.cat(chunks, 1)[:, ::8]
+            print("  tts(stream=%s) from the real class in %.0f s: chunks %s" % (stream, time.time() - t0, out[key + "_n"].tolist()))
+    finally:
+        torch.randn_like = orig_randn_like
+    save("fullsize_model", **out)
+
+
 if __name__ == "__main__":
-    for w in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["llm", "llm_ras", "llm_cv3", "cv1_llm", "flow", "hift", "dit", "causal_hift", "cv1_flow", "cv1_hift"]):
+    for w in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["llm", "llm_ras", "llm_cv3", "cv1_llm", "flow", "hift", "dit", "causal_hift", "cv1_flow", "cv1_hift", "model"]):
         print(w)
         globals()["golden_" + w]()

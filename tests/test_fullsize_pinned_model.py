@@ -1,0 +1,37 @@
+"""The whole benchmark request at the FULL model dimensions: the oracle pipeline against the REAL cosyvoice.cli.model.CosyVoice2Model.tts (a file of its own: pytest-xdist
+hands out whole files, and this one test is 2.5 minutes of single-threaded oracle arithmetic).  See tests/test_fullsize_pinned.py for the per-stage pins."""
+import os
+
+import numpy as np
+import torch
+
+from cosyvoice_amd import synthetic as W
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+N_GEN, N_TEXT, N_PROMPT_TEXT, N_PROMPT_TOK = 250, 30, 12, 87
+
+
+def load(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, name + ".npz")).items()}
+
+
+def test_whole_request_fullsize():
+    """U10 end to end: oracle.model.Pipeline (what tests/test_zz_fullsize.py holds `CosyVoice2Model.tts` on the MI355X to) against the REAL
+    cosyvoice.cli.model.CosyVoice2Model.tts around the real full-size flow + HiFT with its default streaming settings - offline (240 000 samples) and streamed (first
+    chunk 32 640 samples = 25 + 13 + 3 tokens, then hops of 50 and 100 tokens and the rest): the same chunk lengths, the same waveform (every 8th sample stored;
+    tolerance as at test dimensions: the harmonic phase integration amplifies fp32 round-off)."""
+    from oracle import model as OM
+    g = load("fullsize_model")
+    cfgs = W.cv2()
+    lc, fc, hc = cfgs
+    u = W.synthetic_utterance(lc, fc, n_prompt_tok=N_PROMPT_TOK, n_prompt_text=N_PROMPT_TEXT, n_text=N_TEXT)
+    tokens = load("fullsize_llm")["tokens"].tolist()
+    pipe = OM.Pipeline((None, W.make_flow(fc), W.make_hift(hc)), cfgs)
+    with torch.inference_mode():
+        for key, stream in (("offline", False), ("stream", True)):
+            outs = pipe.tts(tokens, u, stream=stream)
+            assert [o.shape[1] for o in outs] == g[key + "_n"].tolist()
+            wav = torch.cat(outs, 1)
+            assert wav.shape[1] == 2 * 480 * N_GEN
+            torch.testing.assert_close(wav[:, ::8], g[key], rtol=0, atol=5e-3)
+    assert g["stream_n"].tolist() == [32640, 48000, 96000, 63360] and float(g["offline"].abs().max()) > 0.05
