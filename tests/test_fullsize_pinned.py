@@ -13,7 +13,6 @@ import json
 import os
 
 import numpy as np
-import pytest
 import torch
 
 from cosyvoice_amd import configs as CF, synthetic as W
@@ -27,16 +26,6 @@ N_GEN, N_TEXT, N_PROMPT_TEXT, N_PROMPT_TOK = 250, 30, 12, 87
 
 def load(name):
     return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, name + ".npz")).items()}
-
-@pytest.fixture(autouse=True, scope="module")
-def _oracle_threads():
-    """These tests are full-size torch arithmetic (GEMM-bound), not emulator runs: under pytest-xdist the workers are held to one intra-op thread (tests/conftest.py),
-    which this module lifts to four for its own duration."""
-    n = torch.get_num_threads()
-    torch.set_num_threads(max(n, min(4, os.cpu_count() or 4)))
-    yield
-    torch.set_num_threads(n)
-
 
 
 def _json(name):
