@@ -249,3 +249,25 @@ def test_cv1_port_flow_and_hift_fullsize():
     assert speech.shape == gh["speech"].shape == (1, 100 * 256)
     torch.testing.assert_close(source, gh["source"], rtol=0, atol=2e-3)      # (the harmonic phase is a cumulative sum: fp32 summation order shows at ~1e-4 in sin(phase))
     torch.testing.assert_close(speech, gh["speech"], rtol=0, atol=5e-3)
+
+
+def test_cv1_whole_request_fullsize():
+    """bench.py's CosyVoice-300M request end to end: the torch-eager port's CosyVoiceModel.tts (cosyvoice1.py) against the REAL cli.model.CosyVoiceModel.tts around the real
+    full-size MaskedDiffWithXvec + 22.05 kHz HiFTGenerator, offline, scripted LLM = the real TransformerLM's 500 ids, global RNG seeded as the generator seeded it:
+    220 416 samples, every 8th stored."""
+    from cosyvoice_amd import cosyvoice1 as C1
+    cfg, hcfg = W.cv1()
+    gl, g = load("fullsize_cv1_llm"), load("fullsize_model_cv1")
+    tokens = gl["tokens"].tolist()
+
+    class ScriptedLLM:
+        def inference(self, **kw):
+            yield from tokens
+    flow = C1.MaskedDiffWithXvec(W.make_cv1_flow(cfg), enc_heads=cfg.flow_heads, est_heads=cfg.est_heads, input_frame_rate=cfg.input_frame_rate)
+    hift = C1.HiFTGenerator(W.make_hift(hcfg), sampling_rate=hcfg.sr, upsample_rates=hcfg.ups, upsample_kernel_sizes=hcfg.up_k, source_resblock_kernel_sizes=hcfg.src_k)
+    m = C1.CosyVoiceModel(ScriptedLLM(), flow, hift)
+    torch.manual_seed(55)
+    chunks = [o["tts_speech"] for o in m.tts(text=gl["text"], flow_embedding=gl["embedding"], llm_embedding=gl["embedding"], stream=False)]
+    assert [c.shape[1] for c in chunks] == g["offline_n"].tolist() == [220416]
+    torch.testing.assert_close(torch.cat(chunks, 1)[:, ::8], g["offline"], rtol=0, atol=5e-3)
+    assert float(g["offline"].abs().max()) > 0.05
