@@ -1,6 +1,6 @@
 """Golden vectors at the FULL model dimensions, made by the REAL reference classes (/root/reference) - build container only:
 
-    python tests/golden/make_golden_fullsize.py [llm] [llm_ras] [llm_cv3] [cv1_llm] [flow] [hift] [dit] [causal_hift] [cv1_flow] [cv1_hift] [model] [model_cv1] [mixed64]   (no argument: all but mixed64, ~8 min on 8 cores)
+    python tests/golden/make_golden_fullsize.py [llm] [llm_ras] [llm_cv3] [cv1_llm] [flow] [hift] [dit] [causal_hift] [cv1_flow] [cv1_hift] [model] [model_cv3] [model_cv1] [mixed64]   (no argument: all but mixed64, ~8 min on 8 cores)
 
 The other generators (make_golden.py, make_golden_cv1.py) run the reference at test dimensions, which pins the oracle's ARITHMETIC; the full-size parity
 tests and every bench run then compare the kernels with the oracle's own full-size output (tests/golden/u10_oracle_tokens.json, cv3_u10_oracle_tokens.json,
@@ -17,6 +17,7 @@ dicts of cosyvoice_amd.synthetic, run the BENCHMARK requests themselves -
   hift     HiFTGenerator.inference (hifigan/generator.py:557-569) at 24 kHz dimensions on 100 frames of that mel
   dit, causal_hift   CausalMaskedDiffWithDiT / DiT and CausalHiFTGenerator at Fun-CosyVoice3-0.5B dimensions (row a17)
   model    cli.model.CosyVoice2Model.tts on U10 with its default streaming settings, offline and streamed (scripted LLM = the 250 ids above): chunk lengths + waveforms
+  model_cv3  cli.model.CosyVoice3Model.tts on the cosyvoice3 bench request, offline (its replay is an opt-in test: CV_TEST_FULL=1)
   model_cv1  cli.model.CosyVoiceModel.tts on the CosyVoice-300M bench request, offline
   cv1_flow, cv1_hift MaskedDiffWithXvec (U-Net ConditionalDecoder, flow cache) and the 22.05 kHz HiFTGenerator at CosyVoice-300M dimensions (rows a18 / f4)
 
@@ -359,6 +360,32 @@ def golden_model():
     save("fullsize_model", **out)
 
 
+def golden_model_cv3():
+    """bench.py's cosyvoice3 request through the REAL cli.model.CosyVoice3Model.tts (cli/model.py:397-450: silent-token filter, accumulating mel cache, speech offsets)
+    around the real full-size DiT flow (its hard-coded 10 Euler steps, flow/flow.py:409) + CausalHiFTGenerator, offline; scripted LLM = the 250 ids of the real CosyVoice3LM
+    (fullsize_llm_cv3.npz).  The generator's fixed noise buffer is zeros (the convention of make_golden.golden_model_cv3).  The test that replays it costs minutes of
+    single-threaded DiT arithmetic and is opt-in (CV_TEST_FULL=1)."""
+    import cosyvoice.cli.model as M
+    lc, fc, hc = CF.cv3_llm(), CF.cv3_flow(), CF.cv3_hift()
+    flow, hift = MG.build_ref_dit_flow(fc), MG.build_ref_causal_hift(hc)
+    hift.m_source.l_sin_gen.sine_waves = torch.zeros(1, 480 * 2 * N_GEN, 9)    # (build_ref_causal_hift shrinks the 300 s buffers to 2 s for its fixtures)
+    u = W.synthetic_utterance(lc, fc, n_prompt_tok=N_PROMPT_TOK, n_prompt_text=24, n_text=N_TEXT, seed=2025)
+    tokens = [int(t) for t in np.load(os.path.join(HERE, "fullsize_llm_cv3.npz"))["tokens"]]
+
+    class ScriptedLLM:
+        def inference(self, **kw):
+            yield from tokens
+    M.time.sleep = lambda s: None
+    t0 = time.time()
+    m = M.CosyVoice3Model(ScriptedLLM(), flow, hift)
+    with torch.inference_mode():
+        chunks = [o["tts_speech"] for o in m.tts(text=u["text"], flow_embedding=u["flow_embedding"], llm_embedding=u["llm_embedding"], prompt_text=u["prompt_text"],
+                                                llm_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32), flow_prompt_speech_token=u["flow_prompt_speech_token"],
+                                                prompt_speech_feat=u["prompt_speech_feat"], stream=False)]
+    print("  CosyVoice3Model.tts offline from the real class in %.0f s: %s samples" % (time.time() - t0, [c.shape[1] for c in chunks]))
+    save("fullsize_model_cv3", offline_n=np.array([c.shape[1] for c in chunks]), offline=torch.cat(chunks, 1)[:, ::8])
+
+
 def golden_model_cv1():
     """bench.py's CosyVoice-300M request through the REAL cli.model.CosyVoiceModel.tts (cli/model.py:135-242) around the real full-size MaskedDiffWithXvec + 22.05 kHz
     HiFTGenerator, offline; scripted LLM = the 500 ids of the real TransformerLM (fullsize_cv1_llm.npz); the global RNG (CFM noise, HiFT noise) seeded before the call."""
@@ -383,6 +410,6 @@ def golden_model_cv1():
 
 
 if __name__ == "__main__":
-    for w in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["llm", "llm_ras", "llm_cv3", "cv1_llm", "flow", "hift", "dit", "causal_hift", "cv1_flow", "cv1_hift", "model", "model_cv1"]):
+    for w in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["llm", "llm_ras", "llm_cv3", "cv1_llm", "flow", "hift", "dit", "causal_hift", "cv1_flow", "cv1_hift", "model", "model_cv3", "model_cv1"]):
         print(w)
         globals()["golden_" + w]()

@@ -49,3 +49,24 @@ def test_whole_request_fullsize():
             assert wav.shape[1] == 2 * 480 * N_GEN
             torch.testing.assert_close(wav[:, ::8], g[key], rtol=0, atol=5e-3)
     assert g["stream_n"].tolist() == [32640, 48000, 96000, 63360] and float(g["offline"].abs().max()) > 0.05
+
+
+def test_cv3_whole_request_fullsize():
+    """bench.py's cosyvoice3 request end to end at Fun-CosyVoice3-0.5B dimensions: oracle.model.Pipeline3 against the REAL cli.model.CosyVoice3Model.tts (silent-token filter,
+    accumulating mel cache, speech offsets) around the real DiT flow with its 10 Euler steps + CausalHiFTGenerator, offline (240 000 samples, every 8th stored).  Ten
+    full-size DiT passes on one thread take minutes: opt-in (CV_TEST_FULL=1; run when the fixture was made - the per-stage pins of test_fullsize_pinned.py run always)."""
+    import pytest
+    if not os.environ.get("CV_TEST_FULL"):
+        pytest.skip("CV_TEST_FULL=1 runs the full-size CosyVoice3 request through the oracle (minutes of CPU)")
+    from cosyvoice_amd import configs as CF
+    from oracle import model as OM
+    g = load("fullsize_model_cv3")
+    lc, fc, hc = CF.cv3_llm(), CF.cv3_flow(), CF.cv3_hift()
+    u = W.synthetic_utterance(lc, fc, n_prompt_tok=N_PROMPT_TOK, n_prompt_text=24, n_text=N_TEXT, seed=2025)
+    tokens = load("fullsize_llm_cv3")["tokens"].tolist()
+    pipe = OM.Pipeline3((None, W.make_flow_dit(fc), W.make_hift(hc)), (lc, fc, hc))
+    with torch.inference_mode():
+        outs = pipe.tts(tokens, u, stream=False)
+    assert [o.shape[1] for o in outs] == g["offline_n"].tolist() == [2 * 480 * N_GEN]
+    torch.testing.assert_close(torch.cat(outs, 1)[:, ::8], g["offline"], rtol=0, atol=5e-3)
+    assert float(g["offline"].abs().max()) > 0.05
