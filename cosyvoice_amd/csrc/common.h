@@ -217,6 +217,7 @@ __device__ __forceinline__ void cv_glds16(const void* gsrc, const void* lds_wave
 }
 #define CV_GLDS16(gptr, lds_wave_base) cv_glds16((gptr), (lds_wave_base))
 #define CV_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define CV_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")      // counted: the newest n vector-memory operations (DMA pieces included) may still be in flight
 #endif
 
 // Scheduling fence: the machine scheduler moves no instruction across it (no instruction is emitted).  Used where the ORDER of independent global

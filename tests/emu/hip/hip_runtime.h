@@ -214,7 +214,16 @@ static inline emu_u32x2 emu_buf_load_b64(emu_rsrc rs, int voff, int soff) {
 #define __builtin_amdgcn_readfirstlane(x) (x)      /* callers pass wave-uniform values (also inside divergent regions, where a fibre rendezvous would not complete) */
 /* global_load_lds_dwordx4: LDS destination = wave-uniform base + lane * 16 */
 #define CV_GLDS16(gptr, lds_wave_base) memcpy((char*)(lds_wave_base) + 16 * emu::lane_id(), (const void*)(gptr), 16)
+#define CV_GLDS16S(sbase, voff, lds_wave_base) memcpy((char*)(lds_wave_base) + 16 * emu::lane_id(), (const char*)(sbase) + (voff), 16)
 #define CV_VMCNT0() ((void)0)
+#define CV_VMCNT(n) ((void)0)
+/* v_permlane32_swap: the upper half of the first operand and the lower half of the second trade places; returns {new first, new second} */
+static inline emu_u32x2 emu_permlane32_swap(unsigned a, unsigned b) {
+    const int l = emu::lane_id();
+    const unsigned a_other = __shfl(a, l ^ 32), b_other = __shfl(b, l ^ 32);
+    return l < 32 ? emu_u32x2{a, a_other} : emu_u32x2{b_other, b};
+}
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) emu_permlane32_swap((a), (b))
 #define CV_OPAQUE_ZERO 1
 #define __builtin_amdgcn_exp2f(x) exp2f(x)                              /* v_exp_f32: callers stay out of the range where it flushes (results below 2^-126) */
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

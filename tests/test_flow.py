@@ -344,6 +344,43 @@ def test_estimator_module_contract(lib):
     torch.testing.assert_close(x, g["out"], rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.gpu
+def test_estimator_engine_raw_addresses_on_a_real_stream(hip_lib):
+    """B3, the NON-Module branch of forward_estimator (flow/flow_matching.py:129-153) on the MI355X: the statements of that branch - acquire, `with stream`, six
+    input shapes, seven raw `data_ptr()`s with the output aliased on x, `execute_async_v3(torch.cuda.current_stream().cuda_stream)`, synchronize, release - restated
+    here because /root/reference does not travel to the GPU box (the REAL branch drives the same object under the emulator, tests/test_dropin_reference.py).  The raw
+    hipStream_t is the context's own side stream, the result must be the nn.Module form's (EstimatorModule), bit for bit, and x must hold it (the aliased output)."""
+    from cosyvoice_amd.flow import EstimatorEngine, EstimatorModule
+    cfg = W.ref_small_flow()
+    flow = CausalMaskedDiffWithXvec(W.make_flow(cfg), cfg, lib=hip_lib)
+    eng, mod = EstimatorEngine(flow), EstimatorModule(flow)
+    dev = flow.device
+    g = torch.Generator().manual_seed(31)
+    for T in (48, 131):
+        x, mu, cond = (torch.randn(2, 80, T, generator=g).to(dev) for _ in range(3))
+        spks, t, mask = torch.randn(2, 80, generator=g).to(dev), torch.tensor([0.25, 0.25]).to(dev), torch.ones(2, 1, T, device=dev)
+        want = mod(x.clone(), mask, mu, t, spks, cond, streaming=False)
+        x0 = x.clone()
+        [ctx, stream], engine = eng.acquire_estimator()
+        torch.cuda.current_stream().synchronize()
+        with stream:
+            side = torch.cuda.current_stream().cuda_stream
+            assert side != 0 and side != torch.cuda.default_stream().cuda_stream          # a real, non-default hipStream_t crosses the C ABI
+            for name, shape in (("x", (2, 80, T)), ("mask", (2, 1, T)), ("mu", (2, 80, T)), ("t", (2,)), ("spks", (2, 80)), ("cond", (2, 80, T))):
+                ctx.set_input_shape(name, shape)
+            ptrs = [x.contiguous().data_ptr(), mask.contiguous().data_ptr(), mu.contiguous().data_ptr(), t.contiguous().data_ptr(), spks.contiguous().data_ptr(),
+                    cond.contiguous().data_ptr(), x.data_ptr()]
+            for i, p in enumerate(ptrs):
+                ctx.set_tensor_address(engine.get_tensor_name(i), p)
+            assert ctx.execute_async_v3(side) is True
+            torch.cuda.current_stream().synchronize()
+        eng.release_estimator(ctx, stream)
+        assert eng._pool.qsize() == 1
+        assert torch.equal(x, want) and not torch.equal(x, x0)
+        ref = OF.estimator(W.make_flow(cfg), cfg, x0.cpu(), mask.cpu(), mu.cpu(), t.cpu(), spks.cpu(), cond.cpu(), False)
+        torch.testing.assert_close(x.cpu(), ref, rtol=2e-4, atol=2e-4)
+
+
 @pytest.mark.parametrize("tile,waves,kt,ks", [(0, 4, 2, 2), (1, 2, 1, 1), (2, 4, 1, 1), (3, 2, 2, 1), (4, 4, 2, 1), (0, 4, 1, 3), (0, 4, 1, 4)])
 def test_fused_transformer_blocks_match_unfused(lib, tile, waves, kt, ks):
     """bf16 mode: the fused pipeline of the estimator's transformer blocks (flow_fused.h: LayerNorm in the GEMM prologue, bf16 Q / K / V^T /
