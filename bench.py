@@ -5,8 +5,9 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One process per GPU.  Utterances are independent, so ranks are replicas of the whole pipeline (no data-path collective, xGMI
-idle — SURVEY.md §8e); RCCL is used only for the barrier + max-over-ranks of the timed region.  A "step" is one complete
+One process per GPU, each pinned to its GPU with HIP_VISIBLE_DEVICES before the first HIP call (inside a rank there is exactly one device, so
+no host thread of the pipeline can land on a neighbour's).  Utterances are independent, so ranks are replicas of the whole pipeline: no data-path collective,
+xGMI idle, no RCCL - the barrier, the max-over-ranks of the timed region and the gather of the waveform hashes are host-side control traffic over gloo.  A "step" is one complete
 utterance: lm_input build -> LLM prefill(131) -> 250 greedy decode steps -> flow (encoder + 10 CFG Euler steps, T=674) -> HiFT
 (500 frames) -> 240 000 samples copied to the host.  Inputs are resident on the GPU when the timed region starts.
 Weights are seeded random tensors of the real architecture (no checkpoints on the box): `data: synthetic`.
@@ -31,6 +32,14 @@ def log(msg):
 
 
 N_GEN, N_TEXT, N_PROMPT_TEXT, N_PROMPT_TOK = 250, 30, 12, 87
+MIXED_N, MIXED_GEN = 64, (125, 250, 375, 500)
+# CV_BENCH_DRYRUN=1 (tests/test_replica.py, this container has no GPU): the REAL rank body below - device pinning, model build, shard assignment, step loop, barrier,
+# max-over-ranks, hash gather, the JSON line - at emulator size on the CPU (tests/emu: the kernels compiled for the host).  Nothing measured; every check that needs the
+# full-size fixtures or the hardware (oracle token files, RAS replay, rooflines, extras, CPU baseline) is left out of such a line, which says "dry_run": true.
+DRY = os.environ.get("CV_BENCH_DRYRUN") == "1"
+if DRY:
+    N_GEN, N_TEXT, N_PROMPT_TEXT, N_PROMPT_TOK = 6, 2, 2, 5
+    MIXED_N, MIXED_GEN = 6, (3, 6, 4, 5)
 AUDIO_S = N_GEN / 25.0
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -39,9 +48,19 @@ def build_model(flow_precision="bf16", batch_fp8=False):
     from cosyvoice_amd.configs import cv2
     from cosyvoice_amd.model import CosyVoice2Model
     from cosyvoice_amd import synthetic as W
-    cfgs = cv2()
-    model = CosyVoice2Model.from_state_dicts(W.make_llm(cfgs[0]), W.make_flow(cfgs[1]), W.make_hift(cfgs[2]), cfgs,
-                                             max_len=1024, sampling="greedy", decode_chunk=64, fp16=(flow_precision == "bf16"), batch_fp8=batch_fp8)
+    if DRY:
+        import dataclasses
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from emu.build_emu import build_emu
+        from cosyvoice_amd._lib import Lib
+        lc, fc, hc = W.tiny()
+        cfgs = (lc, dataclasses.replace(fc, n_timesteps=1), hc)
+        model = CosyVoice2Model.from_state_dicts(W.make_llm(cfgs[0]), W.make_flow(cfgs[1]), W.make_hift(cfgs[2]), cfgs, lib=Lib(build_emu(), allow_emulated=True),
+                                                 max_len=160, sampling="greedy", fp16=(flow_precision == "bf16"))
+    else:
+        cfgs = cv2()
+        model = CosyVoice2Model.from_state_dicts(W.make_llm(cfgs[0]), W.make_flow(cfgs[1]), W.make_hift(cfgs[2]), cfgs,
+                                                 max_len=1024, sampling="greedy", decode_chunk=64, fp16=(flow_precision == "bf16"), batch_fp8=batch_fp8)
     u = W.synthetic_utterance(cfgs[0], cfgs[1], n_prompt_tok=N_PROMPT_TOK, n_prompt_text=N_PROMPT_TEXT, n_text=N_TEXT)
     dev = model.device
     u = {k: v.to(dev) for k, v in u.items()}
@@ -56,7 +75,7 @@ def one_utterance(model, u, keep=None):
         tokens = list(model.llm.inference(text=u["text"], text_len=t(N_TEXT), prompt_text=u["prompt_text"], prompt_text_len=t(N_PROMPT_TEXT),
                                           prompt_speech_token=u["llm_prompt_speech_token"], prompt_speech_token_len=t(N_PROMPT_TOK),
                                           embedding=u["llm_embedding"], max_token_text_ratio=ratio, min_token_text_ratio=ratio))
-    assert len(tokens) == N_GEN, len(tokens)
+    assert len(tokens) == N_GEN or (DRY and tokens), len(tokens)      # (a dry run's emulator-size random LM may stop at one of the other special ids first)
     if keep is not None:
         keep["tokens"] = tokens
     uid = "bench"
@@ -65,7 +84,7 @@ def one_utterance(model, u, keep=None):
                           embedding=u["flow_embedding"], token_offset=0, uuid=uid, finalize=True)
     out = wav.cpu()
     model.hift_cache_dict.pop(uid, None)
-    assert out.shape[1] == N_GEN * 2 * 480
+    assert out.shape[1] == len(tokens) * 2 * 480
     return out
 
 
@@ -124,10 +143,13 @@ def self_check(model, u):
     tests/golden/u10_oracle_tokens.json (generated by tests/golden/make_u10.py; nothing from oracle/ is imported here), and the waveform must be
     finite and inside the generator's audio_limit.  A fast pipeline that computes something else is not a result: mismatch raises."""
     import hashlib
-    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "u10_oracle_tokens.json")))
     keep = {}
     wav = one_utterance(model, u, keep)
     toks = [int(t) for t in keep["tokens"]]
+    if DRY:                                                     # emulator-size dry run: no token file for this request; the waveform checks below still run
+        assert bool(torch.isfinite(wav).all()) and 0.0 < float(wav.abs().max()) <= 0.99 + 1e-6
+        return {"dry_run": True, "n_tokens": len(toks), "tokens_sha1": hashlib.sha1(",".join(map(str, toks)).encode()).hexdigest()[:16]}
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "u10_oracle_tokens.json")))
     div = next((i for i, (a, b) in enumerate(zip(toks, gold["tokens"])) if a != b), None)
     if div is not None or len(toks) != len(gold["tokens"]):
         raise RuntimeError("bench self-check: speech tokens differ from the oracle's at step %s (device %s, oracle %s, oracle top-2 margin %s)"
@@ -755,13 +777,13 @@ def cpu_baseline(cfgs):
                 threads_used=threads, stage_seconds={k: round(v, 4) for k, v in stage_s.items()})
 
 
-def mixed_requests(cfgs, device, n=64):
+def mixed_requests(cfgs, device, n=None):
     """BASELINE.json configs[3]: 64 seeded U-variants, generated lengths N in {125, 250, 375, 500} in equal
     mix, each with its own text / prompt / speaker tensors; the length is forced through the per-request min = max token/text ratio."""
     from cosyvoice_amd import synthetic as W
     reqs, costs = [], []
-    for i in range(n):
-        n_gen = (125, 250, 375, 500)[i % 4]
+    for i in range(MIXED_N if n is None else n):
+        n_gen = MIXED_GEN[i % 4]
         u = W.synthetic_utterance(cfgs[0], cfgs[1], n_prompt_tok=N_PROMPT_TOK, n_prompt_text=N_PROMPT_TEXT, n_text=N_TEXT, seed=4000 + i)
         r = {k: v.to(device) for k, v in u.items()}
         r["min_token_text_ratio"] = r["max_token_text_ratio"] = n_gen / N_TEXT
@@ -854,7 +876,7 @@ def spawn_ranks(n):
     relay rank 0's JSON line.  Fails loudly when the node does not have N GPUs - a silent N=1 run under an N-GPU label is worse than no run."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()
+    have = n if DRY else torch.cuda.device_count()
     if have < n:
         raise SystemExit("bench.py: --gpus %d requested but only %d GPU(s) are visible on this node" % (n, have))
     with socket.socket() as sk:
@@ -865,6 +887,23 @@ def spawn_ranks(n):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     log("spawning %d ranks: %s" % (n, " ".join(cmd)))
     sys.exit(subprocess.call(cmd, env=env))
+
+
+def pin_rank_to_its_gpu(local_rank, world):
+    """one process per GPU with HIP_VISIBLE_DEVICES=<its GPU>, set before the first HIP call of the process.  Inside a rank the only device is
+    index 0: `torch.device("cuda")` without an index (model.py, llm.py) and every host thread the pipeline starts (token2wav lanes, the LM thread, decode groups, the
+    serving scheduler) are on this rank's GPU by construction - nothing depends on a per-thread `torch.cuda.set_device`.  A device list the launcher's environment
+    already restricts (HIP_ / CUDA_VISIBLE_DEVICES) is honoured: rank i takes its i-th entry.  Returns the entry (None at world size 1: nothing to pin)."""
+    if world <= 1:
+        return None
+    assert not torch.cuda.is_initialized(), "bench.py: the rank's GPU must be pinned before the first CUDA / HIP call"
+    listed = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    ids = [v.strip() for v in listed.split(",") if v.strip()] if listed else [str(i) for i in range(world)]
+    if local_rank >= len(ids):
+        raise SystemExit("bench.py: local rank %d has no GPU in the visible device list %r" % (local_rank, ids))
+    os.environ["HIP_VISIBLE_DEVICES"] = ids[local_rank]
+    os.environ.pop("CUDA_VISIBLE_DEVICES", None)
+    return ids[local_rank]
 
 
 DEFAULT_EXTRAS = ("streaming_clients", "batched_decode", "batched_decode_16", "batched_decode_32", "mixed64", "cosyvoice3", "cosyvoice300m")
@@ -970,21 +1009,31 @@ def main():
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)                     # never returns
+    # stdout carries ONE JSON line and nothing else: whatever a library prints on file descriptor 1 (gloo's "[Gloo] Rank 0 is connected to ..." notes at world size
+    # 2 and up, runtime warnings) is sent to stderr from here on, and the line is written to the descriptor stdout had when the process started
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (torch.distributed.run --nproc-per-node %d), or run "
                          "`python bench.py --gpus %d` without WORLD_SIZE and it spawns the ranks itself" % (args.gpus, world, args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    pinned = pin_rank_to_its_gpu(local_rank, world)            # before the first HIP call: from here on this process has ONE GPU, index 0
+    if not DRY:
+        if world > 1 and torch.cuda.device_count() != 1:
+            raise SystemExit("bench.py: rank %d pinned HIP_VISIBLE_DEVICES=%s but sees %d devices" % (rank, pinned, torch.cuda.device_count()))
+        torch.cuda.set_device(0)
     # the product path's host work is a few tiny CPU tensor ops per utterance: keep torch's intra-op pool small so that N ranks on
     # one node do not oversubscribe the host (cpu_baseline() sets its own thread count for the oracle run)
     torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // max(world, 1))))
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # control traffic only (a barrier, one float64 maximum, one gather of host objects): gloo over 127.0.0.1 - the replicas exchange no device data, so no RCCL
+        # communicator (and none of its device-IPC setup between pinned processes) is created at all
+        dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
 
     model, u, cfgs = build_model(args.flow_precision, batch_fp8=args.llm_fp8)
     model.flow_batch = args.flow_batch
@@ -997,7 +1046,7 @@ def main():
         mixed = {"hashes": {}}
 
         def step():
-            mixed["hashes"] = run_mixed(model, reqs, mine, slots=max(1, min(32, len(mine))))      # 8 in flight per GPU at 8 GPUs, 32 when one GPU takes all 64
+            mixed["hashes"] = run_mixed(model, reqs, mine, slots=max(1, min(2 if DRY else 32, len(mine))))      # 8 in flight per GPU at 8 GPUs, 32 when one GPU takes all 64
     else:
         def step():
             one_utterance(model, u)
@@ -1008,7 +1057,8 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not DRY:
+            torch.cuda.synchronize()
 
     barrier()
     t0 = time.perf_counter()
@@ -1017,9 +1067,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    me = {"rank": rank, "local_rank": local_rank, "hip_visible_devices": pinned, "device": None if DRY else torch.cuda.get_device_name(0)}
+    rank_devices = [me]
+    if dist is not None:
+        rank_devices = [None] * world if rank == 0 else None
+        dist.gather_object(me, rank_devices, dst=0)
 
     all_hashes = None
     if mixed is not None:                                      # host-side gather of the per-utterance hashes (no data-path collective)
@@ -1050,18 +1105,24 @@ def main():
             "config": {"workload": "CosyVoice2-0.5B zero-shot, batch=1, 10 CFM Euler steps, synthetic U10: prompt 87 speech tokens / 174 mel frames, "
                                    "12+30 text tokens, 250 generated tokens = 10.0 s @ 24 kHz (BASELINE.json configs[1])",
                        "utterances_per_gpu_per_step": 1, "sampler": "greedy, length forced to 250", "flow_precision": args.flow_precision, "parallelism": "replicas x%d, no collective" % world},
-            "per_gpu_audio_s_per_s": round(value / world, 3),
+            "per_gpu_audio_s_per_s": round(value / world, 3), "rank_devices": rank_devices,
         }
+        if DRY:
+            out["dry_run"] = True
         if mixed is not None:
             out["scaling"] = "strong"
             out["config"]["workload"] = ("CosyVoice2-0.5B batched zero-shot, 64 seeded utterances with 125/250/375/500 generated tokens (equal mix, 800 s of audio "
-                                         "per step) dealt over the ranks by longest-processing-time-first, <= min(16, shard size) sequences in flight per GPU (BASELINE.json configs[3])")
+                                         "per step) dealt over the ranks by longest-processing-time-first, <= min(32, shard size) sequences in flight per GPU (BASELINE.json configs[3])")
+            out["config"]["assignment"] = {str(r): sh for r, sh in enumerate(shard_requests(costs, world))}
             out["config"]["utterances_per_gpu_per_step"] = len(mine)
             out["config"]["sampler"] = "greedy, length forced per utterance"
             # identical at every rank count / batch slot when the determinism contract of SURVEY.md section 8e holds
             out["utterance_hashes_sha1"] = hashlib.sha1("".join(all_hashes[i] for i in range(len(costs))).encode()).hexdigest()
         out["self_check"] = self_check(model, u)                 # U10 through the same model object, whatever the workload
         log("self-check passed: %s" % out["self_check"])
+        if DRY:
+            print(json.dumps(out), file=line_out, flush=True)
+    if rank == 0 and not DRY:                                    # everything below needs the full-size fixtures or the hardware
         out["self_check"]["ras"] = ras_check(model, u)           # ... and a sampled, non-degenerate sequence of the same utterance
         log("RAS check passed: %s" % out["self_check"]["ras"])
         if world == 1 and args.workload == "u10":
@@ -1111,7 +1172,7 @@ def main():
             log("mfma roofline done")
         if world == 1 and not args.no_cpu_baseline:             # the CPU baseline is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfgs)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=line_out, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

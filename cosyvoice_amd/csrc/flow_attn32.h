@@ -72,6 +72,10 @@ __global__ __launch_bounds__(NW * 64) CV_WAVES_PER_EU(WPE, WPE) void attn_flow32
     const float NEG_INF = -__builtin_huge_valf();
     const float c2 = p.scale * 1.4426950408889634f;                   // scores in log2 units: softmax on the bare v_exp_f32
     const float thr_raw = THR / c2;
+    long long* dbg = p.dbg ? p.dbg + (long long)blockIdx.x * 8 : nullptr;       // dev tool: wall_clock64() (100 MHz) of thread 0 at the phase boundaries; null in production
+    int dn = 0;
+    auto stamp = [&]() { if (dbg && tid == 0) dbg[dn++] = wall_clock64(); };
+    stamp();                                                          // 0: start
 
     const bf16_t* kb = p.k + (long long)b * p.T * p.ld + h * 64;
     const bf16_t* vb = p.vt + (long long)b * p.vt_batch + (long long)h * 64 * p.ldt;
@@ -139,6 +143,7 @@ __global__ __launch_bounds__(NW * 64) CV_WAVES_PER_EU(WPE, WPE) void attn_flow32
 
     float m_run = NEG_INF, m_s = NEG_INF, l_run = 0.f;
     v16f o0 = (v16f)(0.f), o1 = (v16f)(0.f);                                                    // O^T: d rows 0-31 / 32-63 x this lane's query
+    stamp();                                                          // 1: set up, two tiles requested
 
     auto tile = [&](auto stc, int t) {
         constexpr int ST = decltype(stc)::value;
@@ -148,6 +153,7 @@ __global__ __launch_bounds__(NW * 64) CV_WAVES_PER_EU(WPE, WPE) void attn_flow32
             if (t + 1 < ntile) CV_VMCNT(2 * PW); else CV_VMCNT0();
             __syncthreads();
         }
+        if (t == 0) stamp();                                          // 2: the first tile has landed
         if constexpr (!(ABL & 2)) if (t + 2 < ntile) issue_tile(kt0 + 2 * BKV, (ST + 2) % NST);
         if (kt0 >= kend_w) return;                                                             // wave-uniform (chunk mask: a later wave of the workgroup needs this tile)
         const uint4* S = lds + ST * 1024;
@@ -229,6 +235,7 @@ __global__ __launch_bounds__(NW * 64) CV_WAVES_PER_EU(WPE, WPE) void attn_flow32
         if (t + 1 < ntile) tile(attn_ic<1>{}, t + 1);
         if (t + 2 < ntile) tile(attn_ic<2>{}, t + 2);
     }
+    stamp();                                                          // 3: key loop done
     // ---- O / l -> bf16.  Register r of d tile dt is d = 32 dt + (r & 3) + 8 (r >> 2) + 4 hi: four consecutive d per register quad.
     const float l = xhalf_sum(l_run);                                 // (lanes l and l + 32 hold the same query: both or neither are valid)
     if (qvalid) {
@@ -240,6 +247,8 @@ __global__ __launch_bounds__(NW * 64) CV_WAVES_PER_EU(WPE, WPE) void attn_flow32
             *reinterpret_cast<uint2*>(op + 32 + 8 * g) = make_uint2(pack_bf16x2(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack_bf16x2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
         }
     }
+    stamp();                                                          // 4: stored
 }
+
 
 }  // namespace cv

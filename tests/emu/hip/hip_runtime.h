@@ -181,7 +181,7 @@ int emu_cvt_pk_fp8_f32(float a, float b, int old, bool word_sel);
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_f32_16x16x4f32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_f32_32x32x2f32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_f32_16x16x32_bf16(__builtin_bit_cast(emu_v8s, (a)), __builtin_bit_cast(emu_v8s, (b)), (c))
-#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_f32_32x32x16_bf16((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_f32_32x32x16_bf16(__builtin_bit_cast(emu_v8s, (a)), __builtin_bit_cast(emu_v8s, (b)), (c))
 // DPP row controls used by the kernels (gfx9 encodings): quad_perm 0x00-0xFF, row_half_mirror 0x141, row_mirror 0x140
 static inline int emu_update_dpp(int src, int ctrl) {
     int lane = emu::lane_id(), from;
@@ -230,5 +230,6 @@ static inline emu_u32x2 emu_permlane32_swap(unsigned a, unsigned b) {
 #define __builtin_amdgcn_wave_barrier() ((void)__shfl(0, 0))            /* the emulator's lanes are fibers: a wave-wide rendezvous */
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))

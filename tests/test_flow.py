@@ -381,7 +381,7 @@ def test_estimator_engine_raw_addresses_on_a_real_stream(hip_lib):
         torch.testing.assert_close(x.cpu(), ref, rtol=2e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("tile,waves,kt,ks", [(0, 4, 2, 2), (1, 2, 1, 1), (2, 4, 1, 1), (3, 2, 2, 1), (4, 4, 2, 1), (0, 4, 1, 3), (0, 4, 1, 4)])
+@pytest.mark.parametrize("tile,waves,kt,ks", [(0, 0, 0, 0), (0, 4, 2, 2), (1, 2, 1, 1), (2, 4, 1, 1), (3, 2, 2, 1), (4, 4, 2, 1), (0, 4, 1, 3), (0, 4, 1, 4)])
 def test_fused_transformer_blocks_match_unfused(lib, tile, waves, kt, ks):
     """bf16 mode: the fused pipeline of the estimator's transformer blocks (flow_fused.h: LayerNorm in the GEMM prologue, bf16 Q / K / V^T /
     attention output / FF hidden between kernels, bf16-in flash attention) rounds the same operands at the same points as the unfused
@@ -401,9 +401,11 @@ def test_fused_transformer_blocks_match_unfused(lib, tile, waves, kt, ks):
             for fused in (0, 1):
                 lib.cv_flow_set_option(flow._h, b"fused", C.c_int32(fused))
                 lib.cv_flow_set_option(flow._h, b"flow_tile", C.c_int32(tile))
-                lib.cv_flow_set_option(flow._h, b"attn_waves", C.c_int32(waves))
-                lib.cv_flow_set_option(flow._h, b"attn_kt", C.c_int32(kt))
-                lib.cv_flow_set_option(flow._h, b"attn_ks", C.c_int32(ks))
+                lib.cv_flow_set_option(flow._h, b"attn32", C.c_int32(int(waves == 0)))      # waves == 0: the round-6 attention (attn_flow32_kernel, the default); else attn_flow_kernel<waves, kt, ks>
+                if waves > 0:
+                    lib.cv_flow_set_option(flow._h, b"attn_waves", C.c_int32(waves))
+                    lib.cv_flow_set_option(flow._h, b"attn_kt", C.c_int32(kt))
+                    lib.cv_flow_set_option(flow._h, b"attn_ks", C.c_int32(ks))
                 outs.append(flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu())
             ref = OF.estimator(sd, cfg, x, mask, mu, t, spk, cond, streaming)
             # A bf16 computation is not a smooth function of its inputs (DESIGN.md section 5 "bf16 mode" iii): where the LayerNorm statistics of the

@@ -124,3 +124,39 @@ def test_flow_groups_bucket_by_length():
     assert groups([job(0, 100), job(1, 100, 80), job(2, 93), job(3, 100)]) == [[0, 3], [1, 2]]     # equal token totals only (prompt included)
     me.flow_batch = 1
     assert groups([job(0, 10), job(1, 10)]) == [[0], [1]]
+
+
+def _bench_line(gpus, workload, extra_env=None):
+    """`python bench.py --gpus N` with CV_BENCH_DRYRUN=1: bench.py itself spawns the N ranks through torch.distributed.run (rendezvous on 127.0.0.1) and every rank
+    runs the REAL rank body at emulator size - no copy of that code lives in the tests."""
+    import json, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")}
+    env.update(CV_BENCH_DRYRUN="1", OMP_NUM_THREADS="2", **(extra_env or {}))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "0", "--workload", workload],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                               # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(1800)
+def test_bench_rank_body_runs_at_world_size_2(emu_lib):
+    """bench.py's N > 1 branch had never executed anywhere.  Here the real rank body runs with world size 2 (gloo, CPU, the emulator build of the
+    kernels, emulator-size model) for BOTH workloads: one JSON line, n_gpus == 2, every rank pinned to its own device (HIP_VISIBLE_DEVICES = its local rank - or its
+    entry of a list the launcher already restricts), every mixed utterance assigned to exactly one rank, and the hash over the per-utterance waveform hashes equal
+    to the world-size-1 run's - the determinism contract of SURVEY.md section 8e.  (emu_lib: the emulator library is built before the ranks race for it.)"""
+    one = _bench_line(1, "mixed64")
+    two = _bench_line(2, "mixed64")
+    assert one["dry_run"] and two["dry_run"] and one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["scaling"] == "strong" and two["utterance_hashes_sha1"] == one["utterance_hashes_sha1"]
+    assign = two["config"]["assignment"]
+    n_utt = sum(len(v) for v in one["config"]["assignment"].values())
+    assert sorted(i for sh in assign.values() for i in sh) == list(range(n_utt)) and all(len(sh) > 0 for sh in assign.values())
+    assert [d["hip_visible_devices"] for d in two["rank_devices"]] == ["0", "1"] and [d["rank"] for d in two["rank_devices"]] == [0, 1]
+    assert one["rank_devices"][0]["hip_visible_devices"] is None        # world size 1: nothing is pinned, the process keeps the launcher's view
+    assert "min(32, shard size)" in two["config"]["workload"]
+    u10 = _bench_line(2, "u10", {"HIP_VISIBLE_DEVICES": "5,3"})           # a launcher that already restricts the node: rank i takes the i-th entry
+    assert u10["n_gpus"] == 2 and u10["scaling"] == "weak" and [d["hip_visible_devices"] for d in u10["rank_devices"]] == ["5", "3"]
+    assert u10["value"] > 0 and u10["self_check"]["n_tokens"] >= 1 and u10["config"]["parallelism"] == "replicas x2, no collective"

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <vector>
 #include <string>
+#include <algorithm>
 #include "flow_attn32.h"
 using namespace cv;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -123,6 +124,32 @@ int main(int argc, char** argv) {
             run("abl 15 MFMA only <4,3>", [&] { hipLaunchKernelGGL((attn_flow32_kernel<4, 3, 15>), dim3(g128), dim3(256), 0, 0, a); });
             run("abl 30 softmax only <4,3>", [&] { hipLaunchKernelGGL((attn_flow32_kernel<4, 3, 30>), dim3(g128), dim3(256), 0, 0, a); });
             run("abl 16 no MFMA <4,3>", [&] { hipLaunchKernelGGL((attn_flow32_kernel<4, 3, 16>), dim3(g128), dim3(256), 0, 0, a); });
+        }
+        if (only >= 0 || (c.B == 16 && c.T == 674 && c.chunk == 0) || (c.B == 2 && c.H == 8)) {
+            // phase stamps of attn_flow32<4,3> (wall_clock64, 10 ns ticks): one launch alone, then the second of two back-to-back launches
+            long long* ddbg; CK(hipMalloc(&ddbg, (size_t)g128 * 8 * 8));
+            for (int pass = 0; pass < 2; ++pass) {
+                CK(hipMemset(ddbg, 0, (size_t)g128 * 8 * 8)); CK(hipDeviceSynchronize());
+                AttnFlowArgs a2 = a; a2.dbg = ddbg;
+                if (pass) hipLaunchKernelGGL((attn_flow32_kernel<4, 3>), dim3(g128), dim3(256), 0, 0, a);
+                hipLaunchKernelGGL((attn_flow32_kernel<4, 3>), dim3(g128), dim3(256), 0, 0, a2);
+                CK(hipDeviceSynchronize());
+                std::vector<long long> hd((size_t)g128 * 8); CK(hipMemcpy(hd.data(), ddbg, hd.size() * 8, hipMemcpyDeviceToHost));
+                long long t0 = hd[0], tend = 0; double ph[4] = {0, 0, 0, 0}, startspread = 0; long long lateststart = 0;
+                for (unsigned w = 0; w < g128; ++w) { t0 = std::min(t0, hd[w * 8]); tend = std::max(tend, hd[w * 8 + 4]); lateststart = std::max(lateststart, hd[w * 8]); }
+                for (unsigned w = 0; w < g128; ++w) for (int k = 0; k < 4; ++k) ph[k] += (double)(hd[w * 8 + k + 1] - hd[w * 8 + k]) / g128;
+                {
+                    std::vector<double> ends, durs, loops;
+                    for (unsigned w = 0; w < g128; ++w) { ends.push_back((hd[w * 8 + 4] - t0) * 0.01); durs.push_back((hd[w * 8 + 4] - hd[w * 8]) * 0.01); loops.push_back((hd[w * 8 + 3] - hd[w * 8 + 2]) * 0.01); }
+                    std::sort(ends.begin(), ends.end()); std::sort(durs.begin(), durs.end()); std::sort(loops.begin(), loops.end());
+                    auto q = [&](std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+                    printf("    end time since first start, us: min %.2f  10%% %.2f  50%% %.2f  90%% %.2f  99%% %.2f  max %.2f;  lifetime: min %.2f 50%% %.2f 90%% %.2f max %.2f;  key loop: min %.2f 10%% %.2f 50%% %.2f 90%% %.2f max %.2f\n",
+                           q(ends, 0), q(ends, .1), q(ends, .5), q(ends, .9), q(ends, .99), q(ends, 1), q(durs, 0), q(durs, .5), q(durs, .9), q(durs, 1), q(loops, 0), q(loops, .1), q(loops, .5), q(loops, .9), q(loops, 1));
+                }
+                printf("  stamps attn_flow32<4,3> %s: first start -> last end %.2f us; starts spread over %.2f us; mean per workgroup: setup %.2f, first tile lands %.2f, key loop %.2f, store %.2f us\n",
+                       pass ? "behind another launch" : "alone", (tend - t0) * 0.01, (lateststart - t0) * 0.01, ph[0] * 0.01, ph[1] * 0.01, ph[2] * 0.01, ph[3] * 0.01);
+            }
+            CK(hipFree(ddbg));
         }
         CK(hipFree(dqk)); CK(hipFree(dvt)); CK(hipFree(dout)); CK(hipFree(dref)); CK(hipFree(dklen));
     }
