@@ -434,7 +434,7 @@ def cv1_workload(args):
             "full_size_check_note": "token check: against the builder's torch-eager port (cosyvoice1.py) run on this box, and - `equal_real_reference_class` - against the 500 ids the REAL TransformerLM "
                                     "produced for this request at these dimensions (tests/golden/fullsize_cv1_llm.npz); flow / HiFT of this model: the real classes pin the port at test dimensions only",
             "host": "python sequencing over the operator-level C ABI (cosyvoice1_hip.py); the LM decode step is ONE call (cv_lm1_step, csrc/lm1.hip: %s)"
-                    % ("%d launches per token, %d of the %d steps replayed as a hipGraph" % (lm.step.stat("launches_per_step"), lm.step.stat("graph_replays"), lm.step.stat("steps")) if lm.step is not None and lm.fused_step
+                    % ("%d launches per token, %d of the %d steps replayed as a hipGraph" % (lm.step.stat("launches_per_step"), lm.step_stat("graph_replays"), lm.step_stat("steps")) if lm.step is not None and lm.fused_step
                        else "off: launch-per-operator tape"), "audio_s_per_s": round(audio_s / per, 3),
             "ms_per_utterance": round(1e3 * per, 2), "stages": stages,
             "token_check": {"checked": n_chk, "equal_torch_eager_cpu": div is None, "first_difference": div,

@@ -77,6 +77,7 @@ class Lib:
         self.dll.cv_last_error.restype = C.c_char_p
         self.dll.cv_version.restype = C.c_char_p
         self.emulated = bool(self.dll.cv_is_emulated())
+        self.experiments = bool(self.dll.cv_has_experiments())     # built with CV_BUILD_EXPERIMENTS: the measured no-go variants exist and their options are accepted
         self.tensor_hook = None      # tests install a guard-page allocator here (tests/guard.py); identity in production
         if self.emulated and not allow_emulated:
             raise CosyVoiceAmdError("%s is the CPU-emulator test build; refusing to use it as the product path" % path)

@@ -22,7 +22,7 @@ def hip_sources():
 
 def _deps_mtime():
     m = 0.0
-    for d in (CSRC, os.path.join(ROOT, "..", "include")):
+    for d in (CSRC, os.path.join(CSRC, "experiments"), os.path.join(ROOT, "..", "include")):
         for f in os.listdir(d):
             m = max(m, os.path.getmtime(os.path.join(d, f)))
     return m
@@ -38,11 +38,16 @@ def _run(cmd):
 def build_hip(force=False, verbose=False):
     srcs = hip_sources()
     newest = _deps_mtime()
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
-        return LIB
     os.makedirs(OBJ_DIR, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
              "-I", CSRC, "-I", os.path.join(ROOT, "..", "include"), "-Wno-unused-result"]
+    if os.environ.get("CV_BUILD_EXPERIMENTS") == "1":       # the measured no-go variants (csrc/experiments/, attn_flow_kernel, qkv_attn_kernel ...): A/B builds only
+        flags.append("-DCV_BUILD_EXPERIMENTS")
+    stamp = os.path.join(OBJ_DIR, ".flags")                 # a changed flag set rebuilds everything (the objects are otherwise judged by their age alone)
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
+        return LIB
 
     def compile_one(src):
         obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
@@ -56,6 +61,7 @@ def build_hip(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))
     _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    open(stamp, "w").write(" ".join(flags))
     return LIB
 
 

@@ -510,6 +510,25 @@ class TransformerLM(C1.TransformerLM):
         self.step = self.llm.make_step(self.decoder)
         self.fused_step = self.step is not None
         self.lock = threading.Lock()                             # one Kernels object (its recorder, its workspaces) per stage: requests on one stage object are serialised
+        # The device-resident loop keeps its state (sampler state, sampled tokens, next input row, the bound KV rows) INSIDE a cv_lm1 handle, and the stage lock is
+        # released between two chunks of a request: a request therefore takes a handle of its own for as long as its loop is open (with one shared handle a
+        # second request's loop_begin - or a host-sampler step's rebind - in that gap made the first request decode on the other's sampler state and cache).  Handles
+        # are cheap (they point at the encoder's weight tensors and own a few rows of workspace) and go back to this pool when the generator ends or is closed;
+        # `self.step` stays the handle of the host-sampler path, which rebinds on every call.
+        self._loop_steps, self._pool_lock, self._step_options = [], threading.Lock(), {}
+
+    def set_step_option(self, name, value):
+        """cv_lm1_set_option on every decode-step handle of this stage: the host-sampler handle, the pooled loop handles, and the ones made later."""
+        self._step_options[name] = int(value)
+        with self._pool_lock:
+            for st in [self.step] + self._loop_steps:
+                if st is not None:
+                    st.lib.cv_lm1_set_option(st.h, name.encode(), C.c_int32(int(value)))
+
+    def step_stat(self, name):
+        """A counter (cv_lm1_stat) summed over the stage's handles that are at rest (the host-sampler handle + the pooled loop handles)."""
+        with self._pool_lock:
+            return sum(st.stat(name) for st in [self.step] + self._loop_steps if st is not None)
 
     def _to_host(self, logits):
         """The step's logits on the host (called under the stage lock).  On the GPU: into one pinned buffer, asynchronously, then one stream synchronisation - a pageable
@@ -530,8 +549,9 @@ class TransformerLM(C1.TransformerLM):
     @torch.inference_mode()
     def inference(self, text, text_len, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len, embedding,
                   sampling=25, max_token_text_ratio=20, min_token_text_ratio=2, uuid=""):
-        # The stage lock is taken PER STEP, never across a yield: a request's state is its own (_KVState, the recorded step with its buffers), so
-        # another request may prefill or step between two of this one's tokens, and a consumer that stops reading blocks nobody.
+        # The stage lock is taken PER STEP / PER CHUNK, never across a yield: a request's state is its own (_KVState, the recorded step with its buffers,
+        # and - device loop - a cv_lm1 handle of its own from the pool), so another request may prefill or step between two of this one's tokens, and a consumer that
+        # stops reading blocks nobody.
         K, D = self.k, self.llm_input_size
         with self.lock:
             ids = torch.cat([prompt_text, text], dim=1).reshape(-1).to(torch.int32)
@@ -553,19 +573,31 @@ class TransformerLM(C1.TransformerLM):
         if isinstance(self.sampling, str) and self.fused_step and max_len > 0 and L >= 2:
             # the loop on the device: prefill all rows but the last through the chunk path, then the last row is the loop's first input
             from .llm import SamplingC
-            with self.lock:
-                self._request += 1
-                _, state = self.llm.forward_chunk(lm_input[:L - 1], None)
-                sp = SamplingC(1 if self.sampling == "ras" else 0, self.eos_token, 1, min_len, max_len, 0.8, 25, 10, 0.1, self.seed + self._request,
-                               1 if self._uniforms is not None else 0)
-                self.llm.loop_begin(self.step, lm_input[L - 1:L].contiguous(), state, sp, self.speech_emb, self._uniforms)
-            done, n_yield = False, 0
-            while not done and n_yield < max_len:
+            with self._pool_lock:
+                step = self._loop_steps.pop() if self._loop_steps else None
+            try:
                 with self.lock:
-                    toks, done = self.llm.loop_steps(self.step, state, min(self.decode_chunk, max_len - n_yield))
-                for t in toks:
-                    yield t
-                n_yield += len(toks)
+                    if step is None:
+                        step = self.llm.make_step(self.decoder)      # (make_step succeeded for self.step: same arguments)
+                        for name, value in self._step_options.items():
+                            step.lib.cv_lm1_set_option(step.h, name.encode(), C.c_int32(value))
+                    self._request += 1
+                    _, state = self.llm.forward_chunk(lm_input[:L - 1], None)
+                    sp = SamplingC(1 if self.sampling == "ras" else 0, self.eos_token, 1, min_len, max_len, 0.8, 25, 10, 0.1, self.seed + self._request,
+                                   1 if self._uniforms is not None else 0)
+                    self.llm.loop_begin(step, lm_input[L - 1:L].contiguous(), state, sp, self.speech_emb, self._uniforms)
+                done, n_yield = False, 0
+                while not done and n_yield < max_len:
+                    with self.lock:
+                        toks, done = self.llm.loop_steps(step, state, min(self.decode_chunk, max_len - n_yield))
+                    for t in toks:
+                        yield t
+                    n_yield += len(toks)
+            finally:                                                 # also on GeneratorExit: an abandoned request gives its handle back
+                if step is not None:
+                    step.bound = None                                # the next request binds its own cache rows
+                    with self._pool_lock:
+                        self._loop_steps.append(step)
             return
         out_tokens, state, x = [], None, lm_input
         for i in range(max_len):

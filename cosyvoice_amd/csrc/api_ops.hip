@@ -1,8 +1,12 @@
 // Operator-level C ABI + shared launchers.
+#include <atomic>
 #include <cstdlib>
 #include "ops.h"
 
 namespace cv {
+
+// one output row over fp32 weights: gemv_f32_kernel (1) or the GEMM tile with one useful row (0).  Process-wide, set through cv_ops_set_option("gemv_f32").
+static std::atomic<int> g_gemv_f32{[] { const char* e = getenv("CV_GEMV_F32"); return (e && e[0] == '0') ? 0 : 1; }()};
 
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& s) { g_last_error = s; }
@@ -28,10 +32,10 @@ void gemm_conv(GemmConvArgs a, bool w_bf16, int batch, hipStream_t s) {
     CV_CHECK(!a.col_scale || a.col_scale_rows > 0, "gemm_conv: col_scale needs col_scale_rows > 0");
     if (a.pro == ACT_SNAKE) CV_CHECK(a.pro_alpha && aligned16(a.pro_alpha), "gemm_conv: snake prologue needs 16B aligned alpha[Kp]");
     // one output row over fp32 weights (the decode step of CosyVoice-300M's LM): a GEMV, not a tile with one useful row (gemm_conv.h, gemv_f32_kernel).
-    // CV_GEMV_F32=0 keeps the tiled kernel (A/B knob, read ONCE per process: getenv is not safe against a concurrent setenv, and this is several hundred launches
-    // per token on the launch-per-operator path).  The GEMV reads the matrix as registered: the split3 planes of a W3 registration do not apply to M == 1 rows
+    // cv_ops_set_option("gemv_f32", 0) keeps the tiled kernel (A/B and test knob; initialised ONCE per process from CV_GEMV_F32: getenv is not safe against a
+    // concurrent setenv, and this is several hundred launches per token on the launch-per-operator path).  The GEMV reads the matrix as registered: the split3 planes of a W3 registration do not apply to M == 1 rows
     // (include/cosyvoice_amd.h, cv_gemm_conv); its sums differ from the tile kernel's in order only.
-    static const bool gemv_f32 = [] { const char* e = getenv("CV_GEMV_F32"); return !(e && e[0] == '0'); }();
+    const bool gemv_f32 = g_gemv_f32.load(std::memory_order_relaxed) != 0;
     if (a.M == 1 && batch == 1 && a.taps == 1 && !w_bf16 && a.a_vec && a.pro == ACT_NONE && !a.row_scale && !a.col_scale && !a.C2 && !a.accumulate && a.act != ACT_SNAKE &&
         a.a_off0 == 0 && a.c_off == 0 && a.a_len >= a.K) {
         if (gemv_f32) {
@@ -98,6 +102,22 @@ int cv_is_emulated(void) {
 #else
     return 0;
 #endif
+}
+
+int cv_has_experiments(void) {
+#ifdef CV_BUILD_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+int cv_ops_set_option(const char* name, int32_t value) {
+    return cv::guarded([&] {
+        CV_CHECK(name, "cv_ops_set_option: null name");
+        if (std::string(name) == "gemv_f32") cv::g_gemv_f32.store(value != 0, std::memory_order_relaxed);
+        else throw cv::Error(std::string("cv_ops_set_option: unknown option ") + name);
+    });
 }
 
 int cv_gemm_conv(const cv_gemm_conv_args* g, void* stream) {

@@ -16,7 +16,9 @@
 #include "flow_fused.h"
 #include "flow_attn32.h"
 #include "flow_big.h"
-#include "flow_tail.h"
+#ifdef CV_BUILD_EXPERIMENTS
+#include "experiments/flow_tail.h"      // measured no-go (profiles/r3_flow_tail_ab.txt): built, and its option accepted, only with -DCV_BUILD_EXPERIMENTS
+#endif
 #include "flow_band.h"
 
 using namespace cv;
@@ -35,6 +37,16 @@ struct DitBlockW { Lin mod, qkv, out, ff1, ff2; };       // DiTBlock (flow/DiT/m
 inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
+
+// Options that select a measured no-go (kept as evidence, built only with -DCV_BUILD_EXPERIMENTS: VERDICT r5 item 9)
+#ifdef CV_BUILD_EXPERIMENTS
+static constexpr bool kExperiments = true;
+#else
+static constexpr bool kExperiments = false;
+#endif
+static void need_experiments(bool wanted, const char* what) {
+    if (wanted && !kExperiments) throw Error(std::string(what) + " selects an experiment this library was built without (rebuild with CV_BUILD_EXPERIMENTS=1)");
+}
 
 struct cv_flow {
     cv_flow_config cfg{};
@@ -219,11 +231,12 @@ static void flow_finalize(cv_flow* m) {
             t.norm1 = get_ln(m, q + "norm1", C); t.norm3 = get_ln(m, q + "norm3", C);
             t.qkv = get_lin(m, q + "qkv", 3 * inner, C, 1, false); t.out = get_lin(m, q + "out", C, inner, 1, true);
             t.ff1 = get_lin(m, q + "ff1", 4 * C, C, 1, true); t.ff2 = get_lin(m, q + "ff2", C, 4 * C, 1, true);
-            if (m->wbf16 && m->tm.has(q + "tail") && ((C == 256 && inner == 512) || (C == 64 && inner == 64))) {
+            if (m->wbf16 && m->tm.has(q + "tail_prm") && ((C == 256 && inner == 512) || (C == 64 && inner == 64))) {
                 t.tail_qkv = j + 1 < c.est_blocks;
                 const long long frags = (long long)(C / 64) * (inner / 32) + (long long)(4 * C / 64) * (C / 32) + (long long)(C / 64) * (4 * C / 32) +
                                         (t.tail_qkv ? 3LL * (inner / 64) * (C / 32) : 0);
-                t.tail = reinterpret_cast<const u32x4_t*>(m->tm.get(q + "tail", CV_BF16, 4 * frags * 64 * 8).p);
+                if (m->tm.has(q + "tail"))                         // (the 16-row tail stream: packed by weights.py for CV_BUILD_EXPERIMENTS libraries only)
+                    t.tail = reinterpret_cast<const u32x4_t*>(m->tm.get(q + "tail", CV_BF16, 4 * frags * 64 * 8).p);
                 t.tail_prm = m->tm.f32(q + "tail_prm", 6LL * C + 4 * C);
                 if (m->tm.has(q + "band")) {                       // the 64-row band form of large passes (flow_band.h): out-projection + FF1 + FF2 fragments, 8 waves at C = 256, 4 at C = 64
                     const long long bfr = (long long)(C / 16) * (inner / 32) + 2LL * (C / 16) * (4 * C / 32);
@@ -247,13 +260,15 @@ static void flow_finalize(cv_flow* m) {
     if (const char* e = getenv("CV_FLOW_BIG_LDS_EPI")) m->big_lds_epi = atoi(e) != 0;
     if (const char* e = getenv("CV_FLOW_ENC_BATCH")) m->enc_batch = atoi(e) != 0;
     if (const char* e = getenv("CV_FLOW_ATTN2_ROWS")) m->attn2_rows = atoi(e);
-    if (const char* e = getenv("CV_FLOW_ATTN32")) m->attn32 = e[0] != '0';
-    if (const char* e = getenv("CV_FLOW_EAGER_STREAMS")) m->eager_streams = atoi(e) >= 2 ? 2 : 1;
+    if (kExperiments) {                                                              // A/B knobs of experiment builds
+        if (const char* e = getenv("CV_FLOW_ATTN32")) m->attn32 = e[0] != '0';
+        if (const char* e = getenv("CV_FLOW_EAGER_STREAMS")) m->eager_streams = atoi(e) >= 2 ? 2 : 1;
+        if (const char* e = getenv("CV_FLOW_TAIL")) m->fused_tail = e[0] != '0';
+    }
     if (const char* e = getenv("CV_FLOW_BAND_QKV")) m->band_qkv = e[0] != '0';
     if (const char* e = getenv("CV_FLOW_BAND_BM")) m->band_bm = atoi(e);
     if (const char* e = getenv("CV_FLOW_BAND_PIPE")) m->band_pipe = atoi(e);
     if (const char* e = getenv("CV_FLOW_BAND")) m->fused_band = e[0] != '0';        // dev knob for A/B runs (also: option "fused_band")
-    if (const char* e = getenv("CV_FLOW_TAIL")) m->fused_tail = e[0] != '0';        // dev knob for A/B runs (also: option "fused_tail")
     if (const char* e = getenv("CV_FLOW_TAIL_RING")) m->tail_ring = atoi(e) == 16 ? 16 : 8;
     m->down_conv = get_lin(m, "est.down_conv", C, C, 3, true); m->up_conv = get_lin(m, "est.up_conv", C, C, 3, true);
     m->final_conv = get_lin(m, "est.final.conv", C, C, 3, true); m->final_ln = get_ln(m, "est.final.ln", C);
@@ -589,6 +604,7 @@ static void flow_band(const cv_flow* m, const TBlockW& t, bool has_next, const B
     else throw Error("flow_band: no instantiation for these dimensions");
 }
 
+#ifdef CV_BUILD_EXPERIMENTS
 // everything after the attention of block `t` (+ LayerNorm and QKV of `next`) in one launch, 16 rows per workgroup (flow_tail.h)
 static void flow_tail(const TBlockW& t, const TBlockW* next, const bf16_t* att, int inner, float* x, int C, int M, bf16_t* qk, bf16_t* vt, long long vt_batch, int ldt,
                       int rows_per_batch, int depth, hipStream_t s) {
@@ -605,6 +621,7 @@ static void flow_tail(const TBlockW& t, const TBlockW* next, const bf16_t* att, 
         if (next) hipLaunchKernelGGL((flow_tail_kernel<64, 64, 256, true, 8>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((flow_tail_kernel<64, 64, 256, false, 8>), g, dim3(256), 0, s, a);
     } else throw Error("flow_tail: no instantiation for these dimensions");
 }
+#endif
 static void attn_flow(const bf16_t* qk, int ld, int inner, const bf16_t* vt, long long vt_batch, int ldt, bf16_t* o, int B, int H, int T, int chunk, hipStream_t s, const int* klen = nullptr,
                       bool big = false) {
     AttnFlowArgs a{};
@@ -613,6 +630,7 @@ static void attn_flow(const bf16_t* qk, int ld, int inner, const bf16_t* vt, lon
     a.B = B; a.H = H; a.T = T; a.scale = 0.125f; a.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; a.chunk = chunk;
     const dim3 g2((unsigned)(((T + 31) / 32) * H * B)), g4((unsigned)(((T + 63) / 64) * H * B));
     if (tl_attn32) { hipLaunchKernelGGL((attn_flow32_kernel<4, 3>), dim3((unsigned)(((T + 127) / 128) * H * B)), dim3(256), 0, s, a); return; }
+#ifdef CV_BUILD_EXPERIMENTS      // attn_flow_kernel (flow_fused.h), the attention of rounds 2-5 in its workgroup shapes: superseded by attn_flow32_kernel, kept for A/B builds (option attn32 = 0)
     // 128-query workgroups (QG = 2): the same arithmetic per query as attn_flow_kernel<4, 2, 2>, so only that default may be replaced
     if (big && tl_attn_ks == 2) { hipLaunchKernelGGL((attn_flow_kernel<4, 2, 2, 2>), dim3((unsigned)(((T + 127) / 128) * H * B)), dim3(512), 0, s, a); return; }
     if (tl_attn_ks == 2) { hipLaunchKernelGGL((attn_flow_kernel<4, 2, 2>), g4, dim3(512), 0, s, a); return; }
@@ -626,6 +644,10 @@ static void attn_flow(const bf16_t* qk, int ld, int inner, const bf16_t* vt, lon
         if (tl_attn_kt == 2) hipLaunchKernelGGL((attn_flow_kernel<4, 2>), g4, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attn_flow_kernel<4, 1>), g4, dim3(256), 0, s, a);
     }
+#else
+    (void)big;
+    throw Error("flow: attn32 = 0 (attn_flow_kernel) needs a library built with CV_BUILD_EXPERIMENTS");
+#endif
 }
 
 // s_in: packed [2][T][4*mel]; t_row: which row of the time tables; t_shared: both CFG rows use the same row;
@@ -673,6 +695,7 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
         }
         for (size_t ti = 0; ti < st.tf.size(); ++ti) {      // matcha BasicTransformerBlock (self-attention + exact-erf GELU feed-forward)
             const TBlockW& t = st.tf[ti];
+#ifdef CV_BUILD_EXPERIMENTS
             if (fused && m->fused_tail && t.tail) {   // flow_tail.h: LN + QKV once per stage, then attention + ONE row-band launch per block
                 const long long vt_batch = (long long)inner * m->vt_pitch;
                 bf16_t* qk = m->h_qk.as<bf16_t>() + r0 * 2 * inner; bf16_t* vt = m->h_vt.as<bf16_t>() + b0 * vt_batch; bf16_t* ab = m->h_att.as<bf16_t>() + r0 * inner;
@@ -681,6 +704,7 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
                 flow_tail(t, ti + 1 < st.tf.size() ? &st.tf[ti + 1] : nullptr, ab, inner, x, C, (int)R, qk, vt, vt_batch, m->vt_pitch, T, m->tail_ring, s);
                 continue;
             }
+#endif
             if (fused) {                      // flow_fused.h: 5 launches, bf16 activations, same rounding points as the path below
                 const long long vt_batch = (long long)inner * m->vt_pitch;
                 bf16_t* qk = m->h_qk.as<bf16_t>() + r0 * 2 * inner; bf16_t* vt = m->h_vt.as<bf16_t>() + b0 * vt_batch; bf16_t* ab = m->h_att.as<bf16_t>() + r0 * inner;
@@ -981,15 +1005,15 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         if (std::string(name) == "use_graph") { m->use_graph = value != 0; drop_graphs(m); }
         else if (std::string(name) == "bf16_mfma") { m->bf16_mfma = value != 0; drop_graphs(m); }      // captured graphs bake the kernel choice
         else if (std::string(name) == "flow_tile") { CV_CHECK(value >= 0 && value <= 4, "flow_tile must be 0..4"); m->flow_tile = value; drop_graphs(m); }
-        else if (std::string(name) == "attn32") { m->attn32 = value != 0; drop_graphs(m); }
+        else if (std::string(name) == "attn32") { need_experiments(value == 0, "flow option attn32 = 0"); m->attn32 = value != 0; drop_graphs(m); }
         else if (std::string(name) == "attn_ks") { CV_CHECK(value >= 1 && value <= 4, "attn_ks must be 1 .. 4"); m->attn_ks = value; drop_graphs(m); }
         else if (std::string(name) == "attn_kt") { CV_CHECK(value == 1 || value == 2, "attn_kt must be 1 or 2"); m->attn_kt = value; drop_graphs(m); }
         else if (std::string(name) == "attn_waves") { CV_CHECK(value == 2 || value == 4, "attn_waves must be 2 or 4"); m->attn_waves = value; drop_graphs(m); }
-        else if (std::string(name) == "eager_streams") { CV_CHECK(value == 1 || value == 2, "eager_streams must be 1 or 2"); m->eager_streams = value; }
+        else if (std::string(name) == "eager_streams") { CV_CHECK(value == 1 || value == 2, "eager_streams must be 1 or 2"); need_experiments(value == 2, "flow option eager_streams = 2"); m->eager_streams = value; }
         else if (std::string(name) == "est_streams") { CV_CHECK(value == 1 || value == 2, "est_streams must be 1 or 2"); m->est_streams = value; drop_graphs(m); }
         else if (std::string(name) == "graph_max_rows") { CV_CHECK(value >= 0, "graph_max_rows must be >= 0"); m->graph_max_rows = value; drop_graphs(m); }
         else if (std::string(name) == "graph_cap") { CV_CHECK(value >= 1 && value <= 256, "graph_cap must be 1 .. 256"); drop_graphs(m); m->graph_cap = (size_t)value; }
-        else if (std::string(name) == "fused_tail") { m->fused_tail = value != 0; drop_graphs(m); }
+        else if (std::string(name) == "fused_tail") { need_experiments(value != 0, "flow option fused_tail"); m->fused_tail = value != 0; drop_graphs(m); }
         else if (std::string(name) == "band_qkv") { m->band_qkv = value != 0; drop_graphs(m); }
         else if (std::string(name) == "band_pipe") { CV_CHECK(value >= 0 && value <= 2, "band_pipe must be 0, 1 or 2"); m->band_pipe = value; drop_graphs(m); }
         else if (std::string(name) == "band_bm") { CV_CHECK(value == 0 || value == 32 || value == 48 || value == 64, "band_bm must be 0, 32, 48 or 64"); m->band_bm = value; drop_graphs(m); }

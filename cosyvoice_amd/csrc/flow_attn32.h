@@ -248,6 +248,7 @@ __global__ __launch_bounds__(NW * 64) CV_WAVES_PER_EU(WPE, WPE) void attn_flow32
         }
     }
     stamp();                                                          // 4: stored
+    if (dbg && tid == 0) { dbg[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); dbg[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)); dbg[7] = qb; }       // HW_ID, XCC_ID (where the workgroup ran), its query block
 }
 
 

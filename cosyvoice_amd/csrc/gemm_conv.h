@@ -46,6 +46,8 @@ struct GemmConvArgs {
     float* C2; const float* c2_alpha;   // optional second output, indexed like C: C2 = Snake(final value, c2_alpha[n]) - the next convolution's operand
     const void* W3;                 // optional: the SAME fp32 weights pre-split into three bf16 planes, rows [3 N][taps * Kp] with row 3 n + p = plane p of row n
                                     // (w = w1 + w2 + w3 exactly, weights.py::split3_planes).  With fp32 weights and a_vec the products then run on the bf16 pipe (WX3 below).
+    int w3_terms;                   // WX3 only: 0 / 6 = the six plane products of relative weight >= 2^-16 (fp32-exact class, the default); 3 = x1 w1 + x1 w2 + x2 w1 only
+                                    // (relative weight >= 2^-8; the dropped terms are <= 2^-16 of a product: 16 mantissa bits per factor - HiFT option "terms", round 6)
     long long* dbg;                 // dev tool (tools/ubench/gemm_probe.hip): per-phase clock64() stamps of wave 0, 64 slots per workgroup; null in production
 };
 
@@ -222,6 +224,34 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
     };
     auto compute_tile = [&]() {
         if constexpr (WX3) {
+            if (p.w3_terms == 3) {                              // launch-uniform: two planes of each operand, three products per k
+#pragma unroll
+                for (int kg = 0; kg < BK / 32; ++kg) {
+                    uint4 af[2][TM], wf[2][TN];
+                    const int kd = kg * 16 + (lane >> 4) * 4;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl)
+                            af[pl][i] = *reinterpret_cast<const uint4*>(&As[pl * APL + (wm * (BM / WM) + i * 16 + (lane & 15)) * LD + kd]);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl)
+                            wf[pl][j] = *reinterpret_cast<const uint4*>(&Ws[((wn * (BN / WN) + j * 16 + (lane & 15)) * 3 + pl) * LD + kd]);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {          // smallest terms first
+                            v4f a = acc[i][j];
+                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, wf[0][j]), __builtin_bit_cast(v8bf, af[1][i]), a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, wf[1][j]), __builtin_bit_cast(v8bf, af[0][i]), a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, wf[0][j]), __builtin_bit_cast(v8bf, af[0][i]), a, 0, 0, 0);
+                            acc[i][j] = a;
+                        }
+                }
+                return;
+            }
 #pragma unroll
             for (int kg = 0; kg < BK / 32; ++kg) {
                 uint4 af[3][TM], wf[3][TN];

@@ -19,6 +19,7 @@ inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 // every convolution runs with batch = nb (zero padding per block: the range check of gemm_conv is per batch base).  1 everywhere else - the single-utterance
 // launches are exactly what they were.
 thread_local int tl_nb = 1;
+thread_local int tl_terms = 0;      // GemmConvArgs::w3_terms of the handle being run (option "terms")
 }  // namespace
 
 struct cv_hift {
@@ -30,6 +31,8 @@ struct cv_hift {
     ResBlockW src_rb[4]; std::vector<ResBlockW> rb;
     int scale = 480, sd_rate[4] = {1, 1, 1, 1};
     DevBuf mel_cl, fa, fb, f0, P, s, sst, x, xs, t1, r0, r1, si, y_spec, xu, sn;
+    int terms = 6;                // option "terms": plane products per k of the two-sided split in the DECODER's convolutions (6 = fp32-exact class; 3: gemm_conv.h w3_terms).
+                                  // The f0 predictor always runs exact: its output is integrated into a phase over the whole utterance.
     bool f0_f64 = false;          // option "f0_float64": the f0 predictor in double (the reference's mode for the causal generator, generator.py:716-717)
     DevBuf fa64, fb64;
     int cap_m = 0;
@@ -109,7 +112,7 @@ static void conv(const Conv& w, const float* A, long long a_rows, long long M, i
     GemmConvArgs a{};
     a.A = A; a.a_batch = 0; a.a_len = a_rows * w.K; a.lda = w.K; a.a_off0 = -pad * w.K; a.tap_step = dil * w.K; a.taps = w.taps; a.K = w.K;
     a.pro = pro; a.pro_p = pro_p; a.pro_alpha = alpha;
-    a.W = w.w; a.W3 = w.w3; a.Kp = w.Kp; a.ldw = 0; a.w_batch = 0; a.bias = w.b;
+    a.W = w.w; a.W3 = w.w3; a.w3_terms = tl_terms; a.Kp = w.Kp; a.ldw = 0; a.w_batch = 0; a.bias = w.b;
     a.C = C; a.c_batch = 0; a.c_len = M * w.N; a.ldc = w.N; a.c_off = 0; a.M = (int)M; a.N = w.N;
     a.act = act; a.act_p = 0.f; a.res = res; a.res_batch = 0; a.out_scale = out_scale; a.row_scale = nullptr; a.accumulate = accumulate ? 1 : 0;
     a.act_alpha = act_alpha; a.C2 = C2; a.c2_alpha = c2_alpha;
@@ -208,6 +211,7 @@ static void hift_source(cv_hift* m, int frames, const float* noise, unsigned lon
 
 // decode(x = mel, s = source) -> waveform   (generator.py:507-539)
 static void hift_decode(cv_hift* m, const float* mel_cl, int frames, const float* src, float* speech, hipStream_t s) {
+    struct TermScope { TermScope(int t) { tl_terms = t; } ~TermScope() { tl_terms = 0; } } term_scope(m->terms == 3 ? 3 : 0);
     const auto& c = m->cfg;
     const long long L = (long long)frames * m->scale, F = L / 4 + 1;
     float* sst = m->sst.as<float>();
@@ -330,6 +334,7 @@ int cv_hift_set_option(cv_hift* m, const char* name, int32_t value) {
     return guarded([&] {
         CV_CHECK(m && name, "cv_hift_set_option: null argument");
         if (std::string(name) == "f0_float64") m->f0_f64 = value != 0;
+        else if (std::string(name) == "terms") { CV_CHECK(value == 3 || value == 6, "terms must be 6 (fp32-exact class) or 3"); m->terms = value; }
         else throw Error(std::string("cv_hift_set_option: unknown option ") + name);
     });
 }

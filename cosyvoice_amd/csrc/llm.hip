@@ -18,6 +18,18 @@
 
 using namespace cv;
 
+// Options / environment knobs that select a measured no-go (kept as evidence; their kernels are instantiated and their switches accepted only in a library built with
+// -DCV_BUILD_EXPERIMENTS): fused_qkv_attn (qkv_attn_kernel), fused_attn_oproj (attn_oproj_kernel), prefetch (weight-prefetch roles),
+// CV_ATTN_BATCH_GQA (attn_decode_batch_gqa_kernel), CV_DOWN_DEEP (skinny_deep_kernel).
+#ifdef CV_BUILD_EXPERIMENTS
+static constexpr bool kExperiments = true;
+#else
+static constexpr bool kExperiments = false;
+#endif
+static void need_experiments(bool wanted, const char* what) {
+    if (wanted && !kExperiments) throw cv::Error(std::string(what) + " selects an experiment this library was built without (rebuild with CV_BUILD_EXPERIMENTS=1)");
+}
+
 struct cv_llm {
     cv_llm_config cfg{};
     TensorMap tm;
@@ -68,8 +80,15 @@ struct cv_llm {
     // Round 3: fragment-ordered copies of the matrices for the batched decode (skinny_pk_kernel, llm_batch_kernels.h), made on the device the first time
     // the batch path is used: [row tile][k tile][lane][8 bf16], so that one wave load is 1 KB contiguous.  Keyed by the row-major tensor's address.
     // +0.73 GB of HBM for Qwen2-0.5B (the 288 GB of an MI355X are what the batched path is sized for).  Option "batch_packed" (default 1).
-    std::map<const void*, std::unique_ptr<DevBuf>> packed;
+    // Shared between the handles that register the SAME weight tensors (a decode group's sibling handles, llm.py Qwen2LM.sibling): one copy per tensor address in a
+    // process-wide table of weak references - the last handle that lets go frees it (every sibling used to pack its own 0.73 GB).
+    std::map<const void*, std::shared_ptr<DevBuf>> packed;
     int batch_packed = [] { const char* e = getenv("CV_BATCH_PACKED"); return (e && e[0] == '0') ? 0 : 1; }();        // env: A/B knob for bench runs
+    // Batched decode attention form: -1 = chosen per decode call from the slot count and the longest context (the default, the measured rule in batch_decode), 0 = the
+    // per-head VALU kernel, 1 = the fp32-MFMA kernel + merge.  The two forms sum the same products in a different order: with the automatic rule a request's logits
+    // depend - in the last fp32 bits - on how many slots shared its decode call and on its neighbours' context lengths.  A caller that needs a request's tokens to be
+    // independent of the batch composition down to near-tie argmax decisions pins one form (option "batch_attn", read once here from CV_ATTN_BATCH).
+    int batch_attn = [] { const char* e = getenv("CV_ATTN_BATCH"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
     const bf16_t* pk(const bf16_t* w) const { if (!batch_packed) return nullptr; auto it = packed.find(w); return it == packed.end() ? nullptr : it->second->as<bf16_t>(); }
     size_t slot_cache() const { return layer_cache() * cfg.layers; }
     // optional per-kernel HIP-event timing of one eager decode step (bench.py roofline)
@@ -144,12 +163,12 @@ static void llm_finalize(cv_llm* m) {
     m->h.ensure(H * 4); m->qkv.ensure((size_t)m->qkv_dim * 4);
     m->attn_part.ensure((size_t)c.heads * 16 * ATTN_PART * 4);
     m->newtok.ensure((size_t)(c.heads + 2 * c.kv_heads) * 64 * 4);
-    if (const char* e = getenv("CV_DECODE_FUSED_QKV")) m->fused_qkv_attn = e[0] != '0';     // dev knob for A/B runs (also: option "fused_qkv_attn")
+    if (kExperiments) if (const char* e = getenv("CV_DECODE_FUSED_QKV")) m->fused_qkv_attn = e[0] != '0';     // dev knob for A/B runs (also: option "fused_qkv_attn")
     if (const char* e = getenv("CV_HEAD_WAVES")) m->head_waves = atoi(e) == 7 ? 7 : 4;
-    if (const char* e = getenv("CV_DECODE_PREFETCH")) m->prefetch = atoi(e);                 // dev knobs for A/B runs (also: options "prefetch", "prefetch_shift")
+    if (kExperiments) if (const char* e = getenv("CV_DECODE_PREFETCH")) m->prefetch = atoi(e);                 // dev knobs for A/B runs (also: options "prefetch", "prefetch_shift")
     if (const char* e = getenv("CV_DECODE_PREFETCH_SHIFT")) m->prefetch_shift = atoi(e);
     m->pf_sink.ensure(64);
-    if (const char* e = getenv("CV_DECODE_FUSED_O")) m->fused_attn_oproj = e[0] != '0';      // dev knobs for A/B runs (also: options "fused_attn_oproj", "oproj_rblocks")
+    if (kExperiments) if (const char* e = getenv("CV_DECODE_FUSED_O")) m->fused_attn_oproj = e[0] != '0';      // dev knobs for A/B runs (also: options "fused_attn_oproj", "oproj_rblocks")
     if (const char* e = getenv("CV_OPROJ_RBLOCKS")) m->oproj_rblocks = atoi(e) == 8 ? 8 : 4;
     if (const char* e = getenv("CV_OPROJ_WAVES")) m->oproj_waves = atoi(e) == 16 ? 16 : 8;
     m->opart.ensure((size_t)16 * H * 4); m->h2.ensure(H * 4);
@@ -177,12 +196,18 @@ static LinearW lw(const bf16_t* w, const float* b, int N, int K) { LinearW l; l.
 static void ensure_packed(cv_llm* m, hipStream_t s) {
     if (!m->batch_packed || !m->packed.empty()) return;
     const auto& c = m->cfg;
+    static std::map<std::pair<const void*, long long>, std::weak_ptr<DevBuf>> shared;       // (tensor address, element count) -> the live copy, under runtime_lock()
+    std::lock_guard<std::recursive_mutex> lk(runtime_lock());
     auto pack = [&](const bf16_t* w, long long N, long long K) {
         if (!w || K % 32 != 0 || m->packed.count(w)) return;
-        const long long pieces = ((N + 15) / 16) * (K / 32) * 64;
-        auto buf = std::make_unique<DevBuf>(); buf->ensure((size_t)pieces * 16);
-        bf16_t* dst = buf->as<bf16_t>();
-        hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, w, dst, (int)N, (int)K);
+        auto& slot = shared[{w, N * K}];
+        std::shared_ptr<DevBuf> buf = slot.lock();
+        if (!buf) {
+            const long long pieces = ((N + 15) / 16) * (K / 32) * 64;
+            buf = std::make_shared<DevBuf>(); buf->ensure((size_t)pieces * 16);
+            hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, w, buf->as<bf16_t>(), (int)N, (int)K);
+            slot = buf;
+        }
         m->packed[w] = std::move(buf);
     };
     const long long H = c.hidden, A = c.heads * 64;
@@ -385,6 +410,7 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
             pdn.p = reinterpret_cast<const char*>(L.wdown); pdn.bytes = 2LL * c.hidden * c.inter; pdn.cons_bytes = 4 * c.inter * 2;
             pdn.n_cons = (c.hidden + 3) / 4; pdn.stride = round8(pdn.n_cons); pdn.shift = m->prefetch_shift; pdn.sink = pgu.sink;
         }
+#ifdef CV_BUILD_EXPERIMENTS
         if (m->fused_attn_oproj && !m->fused_qkv_attn) {
             // qkv -> attention + per-head o_proj contributions -> gate / up (residual + contributions in its prologue, h2 = the new residual) -> down (+ h2)
             if (want(0)) { ProfScope ps(m, s, 0); gemv(GemvArgs{L.wqkv, L.bqkv, h, qkv, m->qkv_dim, c.hidden, L.ln1, c.rms_eps, nullptr, 0, st}, 1, s); }
@@ -405,13 +431,16 @@ static void llm_enqueue_step(cv_llm* m, hipStream_t s) {
             if (want(4)) { ProfScope ps(m, s, 4); gemv(gd2, 1, s); }
             continue;
         }
+#endif
         if (m->fused_qkv_attn) {
+#ifdef CV_BUILD_EXPERIMENTS
             float* qn = m->newtok.as<float>(); float* kn = qn + c.heads * 64; float* vn = kn + c.kv_heads * 64;
             QkvAttnArgs qa{L.wqkv, L.bqkv, h, L.ln1, c.rms_eps, c.hidden, m->kcache.as<float>() + m->layer_cache() * i, m->vcache.as<float>() + m->layer_cache() * i,
                            m->rope_cos.as<float>(), m->rope_sin.as<float>(), c.heads, c.kv_heads, c.max_len, st, m->attn_part.as<float>(), nsp, qn, kn, vn};
             // profiling category 0 (qkv) carries the fused launch; category 1 (attention) stays empty in this mode
             if (want(0)) { ProfScope ps(m, s, 0); hipLaunchKernelGGL((qkv_attn_kernel<7>), dim3(c.heads * nsp + 2 * c.kv_heads), dim3(256), 0, s, qa); }
             go.qnew = qn; go.knew = kn; go.vnew = vn; go.kv_group = c.heads / c.kv_heads;
+#endif
         } else {
             GemvArgs gq{L.wqkv, L.bqkv, h, qkv, m->qkv_dim, c.hidden, L.ln1, c.rms_eps, nullptr, 0, st};
             if (m->prefetch == 2 && pgu.p) { gq.pf = pgu; gq.pf.first = round8((m->qkv_dim + 15) / 16); }
@@ -655,6 +684,7 @@ static void launch_attn_batch(AttnDecodeBatchArgs ad, int heads, int nb, hipStre
         if (S > 1) hipLaunchKernelGGL(attn_merge_batch_kernel, dim3((unsigned)((nb * heads * 16 + 255) / 256)), dim3(256), 0, s, ad);
         return;
     }
+#ifdef CV_BUILD_EXPERIMENTS
     const bool gqa = [] { const char* e = getenv("CV_ATTN_BATCH_GQA"); return e && e[0] == '1'; }();
     if (gqa && gsz >= 2 && gsz <= 8 && heads % ad.kv_heads == 0) {
         const dim3 grid((unsigned)(ad.kv_heads * nb));
@@ -663,6 +693,7 @@ static void launch_attn_batch(AttnDecodeBatchArgs ad, int heads, int nb, hipStre
         else hipLaunchKernelGGL(attn_decode_batch_gqa_kernel<4>, grid, dim3(512), 0, s, ad);
         return;
     }
+#endif
     hipLaunchKernelGGL(attn_decode_batch_kernel<4>, dim3((unsigned)(heads * nb)), dim3(256), 0, s, ad);
 }
 
@@ -710,7 +741,7 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
     // 448 workgroups + sum_partials_kernel.  Measured on MI355X (profiles/r3_batch_decode_ab.txt): 1086 vs 975 us per 8-sequence step - the weight
     // stream comes from HBM at ~25 GB/s per CU, so 56 CUs cannot pull 8.7 MB in the time 448 workgroups on 256 CUs do; the removed launch (4.8 us) does
     // not pay for that.  Kept, tested, off.
-    const bool deep_knob = [] { const char* e = getenv("CV_DOWN_DEEP"); return e && e[0] == '1'; }();       // read when a step is enqueued / captured
+    const bool deep_knob = kExperiments && [] { const char* e = getenv("CV_DOWN_DEEP"); return e && e[0] == '1'; }();       // read when a step is enqueued / captured
     const bool deep_down = deep_knob && nb <= 16 && (c.inter / 32 + 15) / 16 <= 10 && c.hidden % 4 == 0;
     // 2 row tiles per workgroup for the two wide GEMMs (gate/up: 304 workgroups, head: 206); 3 (203 / 137 workgroups, at most 3 tiles per CU instead
     // of 4 on 48 CUs) measured the same step time (profiles/r2_batch_decode_ab.txt): the launch is not bound by the busiest CU's MFMA share
@@ -733,10 +764,13 @@ static void batch_enqueue_step(cv_llm* m, hipStream_t s) {
         skinny(SkinnyArgs{L.wo, nullptr, att, A, h, H, c.hidden, (int)A, nullptr, 0.f, h, H, 0, nb, 1}, 1, s, m->pk(L.wo));
         // packed: four row tiles per workgroup (152 workgroups) measured 7.3 us against 8.0 for two and 8.7 for one (profiles/r3_skinny_probe.txt)
         skinny(SkinnyArgs{L.wgu, nullptr, h, H, act, I, 2 * c.inter, c.hidden, L.ln2, c.rms_eps, nullptr, 0, 1, nb, 1}, m->pk(L.wgu) ? 4 : wide_rt, s, m->pk(L.wgu));
+#ifdef CV_BUILD_EXPERIMENTS
         if (deep_down) {                                          // one launch: 16-wave workgroups over the whole K (skinny_deep_kernel)
             hipLaunchKernelGGL((skinny_deep_kernel<16, 5>), dim3((unsigned)((H + 15) / 16)), dim3(1024), 0, s,
                                SkinnyArgs{L.wdown, nullptr, act, I, h, H, c.hidden, c.inter, nullptr, 0.f, h, H, 0, nb, 1});
-        } else if (ks > 1) {
+        } else
+#endif
+        if (ks > 1) {
             skinny(SkinnyArgs{L.wdown, nullptr, act, I, dpart, H, c.hidden, c.inter, nullptr, 0.f, nullptr, 0, 2, nb, ks}, 2, s, m->pk(L.wdown));
             hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((nb * H / 4 + 255) / 256)), dim3(256), 0, s, dpart, ks, nb, c.hidden, h, H, h, H);
         } else {
@@ -760,13 +794,13 @@ static void batch_decode(cv_llm* m, int n_steps, int32_t* out_tokens, int32_t* n
     // Which decode attention (measured on the MI355X, profiles/r5_batch_decode_ab.txt section 5): the MFMA form (K / V once per (sequence, kv head), + a merge launch) wins
     // with many slots or long contexts, the per-head VALU form (no second launch) with few slots at short contexts - 16 slots: 885 vs 928 us per step at contexts
     // 130 - 380, 1089 vs 1061 at 443 - 693; 8 slots: 826 vs 871 and 963 vs 954; 32 slots: 1359 vs 1286 already at 130 - 380.  Decided per call from the slot count and
-    // the longest live context (known on the host from the last hand-back); both forms yield the oracle's tokens.  CV_ATTN_BATCH=0 / 1 pins one form (A/B knob).
+    // the longest live context (known on the host from the last hand-back); both forms yield the oracle's tokens.  Option "batch_attn" = 0 / 1 pins one form.
     int mode;
     {
         int longest = 0;
         for (int i = 0; i < nb; ++i) if (!b.host_state[i].done) longest = std::max(longest, b.host_state[i].pos);
         mode = (nb >= 24 || (nb >= 12 && longest >= 416) || longest >= 640) ? 1 : 0;
-        if (const char* e = getenv("CV_ATTN_BATCH")) mode = e[0] == '0' ? 0 : 1;      // (read per decode call - once per chunk of steps, not per step)
+        if (m->batch_attn >= 0) mode = m->batch_attn;                                 // pinned (option "batch_attn" / CV_ATTN_BATCH at handle creation)
     }
     {
         std::lock_guard<std::recursive_mutex> lk(runtime_lock());
@@ -827,20 +861,23 @@ int cv_llm_set_option(cv_llm* m, const char* name, int32_t value) {
         else if (std::string(name) == "fused_attn_oproj" || std::string(name) == "oproj_rblocks" || std::string(name) == "oproj_waves") {
             CV_CHECK(std::string(name) != "oproj_rblocks" || value == 4 || value == 8, "oproj_rblocks must be 4 or 8");
             CV_CHECK(std::string(name) != "oproj_waves" || value == 8 || value == 16, "oproj_waves must be 8 or 16");
+            need_experiments(std::string(name) == "fused_attn_oproj" && value != 0, "llm option fused_attn_oproj");
             (std::string(name) == "fused_attn_oproj" ? m->fused_attn_oproj : std::string(name) == "oproj_rblocks" ? m->oproj_rblocks : m->oproj_waves) = value;
             if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
         }
         else if (std::string(name) == "prefill_rows") m->prefill_rows = value != 0;
         else if (std::string(name) == "head_waves") { CV_CHECK(value == 4 || value == 7, "head_waves must be 4 or 7"); m->head_waves = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; } }
-        else if (std::string(name) == "fused_qkv_attn") { m->fused_qkv_attn = value != 0; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; } }
+        else if (std::string(name) == "fused_qkv_attn") { need_experiments(value != 0, "llm option fused_qkv_attn"); m->fused_qkv_attn = value != 0; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; } }
         else if (std::string(name) == "prefetch" || std::string(name) == "prefetch_shift") {
             CV_CHECK(std::string(name) != "prefetch" || (value >= 0 && value <= 2), "prefetch must be 0, 1 or 2");
+            need_experiments(std::string(name) == "prefetch" && value != 0, "llm option prefetch");
             (std::string(name) == "prefetch" ? m->prefetch : m->prefetch_shift) = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
         }
         else if (std::string(name) == "attn_splits") {       // key-range slices per head in the decode attention (4, 8 or 16)
             CV_CHECK(value == 4 || value == 8 || value == 16, "attn_splits must be 4, 8 or 16");
             m->attn_splits = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
         }
+        else if (std::string(name) == "batch_attn") { CV_CHECK(value >= -1 && value <= 1, "batch_attn must be -1 (by slot count and context), 0 (VALU form) or 1 (MFMA form)"); m->batch_attn = value; }
         else if (std::string(name) == "batch_packed") {      // batched decode on the fragment-ordered weight copies (skinny_pk_kernel) or on the row-major tensors (round 2)
             m->batch_packed = value != 0; if (m->bt.graph) { (void)hipGraphExecDestroy(m->bt.graph); m->bt.graph = nullptr; } if (m->bt.graph_alt) { (void)hipGraphExecDestroy(m->bt.graph_alt); m->bt.graph_alt = nullptr; }
         }

@@ -197,7 +197,7 @@ class CausalMaskedDiffWithXvec:
         self.output_size = cfg.mel
         self.vocab_size = cfg.vocab
         self.n_timesteps = n_timesteps or cfg.n_timesteps
-        pack = Wt.pack_flow_dit if cfg.estimator == "dit" else Wt.pack_flow
+        pack = Wt.pack_flow_dit if cfg.estimator == "dit" else (lambda *a: Wt.pack_flow(*a, experiments=getattr(self.lib, "experiments", False)))
         # `_tensors`: the packed device weights of another instance (clone()): a new library handle = own workspaces / graphs, same weights
         self._tensors = _tensors if _tensors is not None else {k: self.lib.hook(v) for k, v in pack(state_dict, cfg, self.device, weight_dtype).items()}
         c = FlowConfigC(cfg.vocab, cfg.dim, cfg.enc_heads, cfg.ffn, cfg.enc_blocks, cfg.up_blocks, cfg.spk_dim, cfg.mel, cfg.est_ch,

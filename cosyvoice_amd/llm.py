@@ -34,17 +34,22 @@ def register_tensors(lib, set_fn, handle, tensors):
 
 
 class _Cursor:
-    """Admission cursor shared by the decode groups of one inference_queue call: hands out request indices in order, once."""
+    """Admission cursor shared by the decode groups of one inference_queue call: hands out request indices in order, once.  `cancel()` (the consumer abandoned the
+    generator, or one chain failed) stops further admissions: the chains finish what they have in flight and end."""
 
     def __init__(self, n):
-        self.n, self.k, self.lock = n, 0, threading.Lock()
+        self.n, self.k, self.lock, self.cancelled = n, 0, threading.Lock(), False
 
     def take(self):
         with self.lock:
-            if self.k >= self.n:
+            if self.cancelled or self.k >= self.n:
                 return None
             self.k += 1
             return self.k - 1
+
+    def cancel(self):
+        with self.lock:
+            self.cancelled = True
 
 
 class Qwen2Encoder:
@@ -125,7 +130,8 @@ class Qwen2LM:
         # of its own (a SIBLING: the same weight tensors, its own KV cache / workspaces / graphs), its own stream and host thread.  Every launch of the batched step is
         # latency-bound and fills the chip only partly, so two chains side by side cost far less than their sum (profiles/r5_batch_decode_ab.txt section 4: 2 x 16 slots
         # decode 1.17 x the tokens per second of 1 x 32, 2 x 12 1.25 x those of 1 x 24; 2 x 8 is SLOWER than 1 x 16: hence group_min_slots).  Slots are independent, so a
-        # request's tokens do not depend on the cut.  `decode_groups` (default 2, env CV_LLM_GROUPS) applies to inference_batch, where the LM has the chip to itself;
+        # request's tokens do not depend on the cut - up to the fp32 summation order of the decode attention, whose kernel form follows the slot count (inference_batch's
+        # docstring; option "batch_attn" pins it).  `decode_groups` (default 2, env CV_LLM_GROUPS) applies to inference_batch, where the LM has the chip to itself;
         # `queue_groups` (default 1, env CV_LLM_QUEUE_GROUPS) to inference_queue: next to a running vocoder the idle CUs two chains would fill are already taken, and the
         # chains' sequences finish apart, so fewer of them share a flow pass (measured: mixed64 509 -> 415 audio-s/s with 2, profiles/r5_decode_groups.txt).
         self._opts = dict(use_graph=int(use_graph), attn_splits=int(attn_splits), batch_fp8=int(bool(batch_fp8)))
@@ -306,11 +312,21 @@ class Qwen2LM:
             raise ValueError("%s: prompt (%d) + min_len (%d) exceeds the KV capacity %d" % (what, L0, min_len, self.max_len))
         return min(max_len, room)
 
+    def reserve_keys(self, n):
+        """n consecutive draw-stream keys of this handle (base + 1 .. base + n) for the requests of one batch / queue; returns base.  Under a lock: overlapping callers
+        (two server threads, two queues) never see the same keys."""
+        with self._sib_lock:
+            base = self._request
+            self._request = base + int(n)
+        return base
+
     def make_sampling(self, min_len, max_len, seed_key=None):
         """Sampling parameters of one request.  The draw stream of the device sampler is keyed by `seed + k`: k = the handle's running request count, or - `seed_key`,
         a request's `seed_key` entry in inference_batch / inference_queue - a number the CALLER ties to the request, so that under 'ras' sampling a request's tokens do
         not depend on the order in which a queue admitted it (tts_queue passes the request's index in its list)."""
-        self._request += 1
+        if seed_key is None:
+            with self._sib_lock:
+                self._request += 1
         # `eos` of the C sampler = first special id = the index sampling_ids masks while ignore_eos (llm/llm.py:150-160: literally
         # `speech_token_size`, which is eos for Qwen2LM and - a quirk kept as is - sos for CosyVoice3LM); n_stop ids from there stop decoding
         sp = SamplingC(1 if self.sampling == "ras" else 0, self.cfg.speech_token_size, self.cfg.n_special, min_len, max_len, self.top_p, self.top_k, self.win_size,
@@ -354,8 +370,11 @@ class Qwen2LM:
         """Up to 8 requests decoded in lock step on this handle (BASELINE.json configs[2]/[3]; the reference batches through vLLM,
         cli/model.py:281-290): every weight matrix is streamed once per step for all sequences (llm_batch_kernels.h).  `requests` is a
         list of dicts with `text`, `prompt_text`, `prompt_speech_token` ([1, n] id tensors) and, optionally, per-request `min_token_text_ratio` /
-        `max_token_text_ratio`.  Returns one token list per request - the
-        same tokens `inference()` yields for that request alone (the per-sequence arithmetic is identical)."""
+        `max_token_text_ratio`.  Returns one token list per request - the tokens `inference()` yields for that request alone: per sequence the same products are summed,
+        and every GEMM sums them in the same order whatever the batch; the decode ATTENTION has two kernel forms with different fp32 summation orders, chosen per decode
+        call from the slot count and the longest context (csrc/llm.hip batch_decode), so a request's logits can differ in their last bits with the batch composition
+        and with the cut into decode groups.  Every test and bench workload (all 64 mixed64 requests, 32 slots, the groups) yields the oracle's ids either way; a caller
+        that needs independence down to near-tie decisions on real weights pins one form: `lib.cv_llm_set_option(h, b"batch_attn", 0 | 1)`."""
         nb = len(requests)
         assert 1 <= nb <= (16 if self.batch_fp8 else 32), "1..32 requests per batch (16 on the fp8 path)"
         # (_cut=False: this call IS one chain of a cut batch.  An argument, not handle state: concurrent callers of one handle must not see each other's cut)
@@ -365,7 +384,7 @@ class Qwen2LM:
             # request with the sampler key it would have had on this handle alone
             bound = lambda i: int(requests[i]["text"].shape[1]) * float(requests[i].get("max_token_text_ratio", max_token_text_ratio))
             order = sorted(range(nb), key=lambda i: -bound(i))
-            base = self._request
+            base = self.reserve_keys(nb)
             reqs = [dict(requests[i], seed_key=requests[i].get("seed_key", base + 1 + i)) for i in range(nb)]
             g = len(handles)
             parts = [order[k * nb // g:(k + 1) * nb // g] for k in range(g)]
@@ -377,7 +396,6 @@ class Qwen2LM:
                         outs[i] = toks
                 return fn
             self._run_groups([(h, st_, work(h, part)) for h, st_, part in zip(handles, streams, parts)])
-            self._request = base + nb                           # (this handle ran one of the chains: its counter advances as if it had run them all)
             return outs
         assert 1 <= nb <= (16 if self.batch_fp8 else 32), "1..32 requests per batch (16 on the fp8 path)"
         with self.lock:
@@ -431,7 +449,7 @@ class Qwen2LM:
             import queue as _q
             g = len(handles)
             cur, res, END = _Cursor(n), _q.Queue(), object()
-            base = self._request
+            base = self.reserve_keys(n)                         # overlapping queues on one handle must not be handed the same draw-stream keys
             reqs = [dict(r, seed_key=r.get("seed_key", base + 1 + i)) for i, r in enumerate(requests)]
 
             def work(h, k):
@@ -439,6 +457,9 @@ class Qwen2LM:
                     try:
                         for item in type(h).inference_queue(h, reqs, slots=(slots + g - 1 - k) // g, max_token_text_ratio=max_token_text_ratio, min_token_text_ratio=min_token_text_ratio, _cursor=cur):
                             res.put(item)
+                    except BaseException:                       # noqa: BLE001 - a failed chain stops the admissions of the others: the error surfaces as soon as they drain
+                        cur.cancel()
+                        raise
                     finally:
                         res.put(END)
                 return fn
@@ -454,14 +475,16 @@ class Qwen2LM:
             th = threading.Thread(target=runner, daemon=True)
             th.start()
             ended = 0
-            while ended < g:
-                item = res.get()
-                if item is END:
-                    ended += 1
-                else:
-                    yield item
+            try:
+                while ended < g:
+                    item = res.get()
+                    if item is END:
+                        ended += 1
+                    else:
+                        yield item
+            finally:                                            # GeneratorExit included: an abandoned queue admits nothing more, its chains end after their chunk in flight
+                cur.cancel()
             th.join()
-            self._request = base + n
             if errs:
                 raise errs[0]
             return

@@ -440,7 +440,7 @@ class CosyVoice2Model:
         assert order in ("longest_first", "fifo"), order
         bound = lambda r: int(r["text"].shape[1]) * float(r.get("max_token_text_ratio", 20))
         perm = sorted(range(len(requests)), key=lambda i: -bound(requests[i])) if order == "longest_first" else list(range(len(requests)))       # (stable: ties keep their order)
-        base = getattr(self.llm, "_request", 0)
+        base = self.llm.reserve_keys(len(requests)) if hasattr(self.llm, "reserve_keys") else getattr(self.llm, "_request", 0)
         lm_reqs = [dict(text=requests[i]["text"], prompt_text=requests[i]["prompt_text"], prompt_speech_token=requests[i]["llm_prompt_speech_token"], seed_key=base + 1 + i,
                         **{k: requests[i][k] for k in ("min_token_text_ratio", "max_token_text_ratio") if k in requests[i]}) for i in perm]
 

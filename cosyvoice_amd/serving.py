@@ -228,8 +228,11 @@ class StreamScheduler:
         failed = {}
         # A member's vocoder caches (mel / source / speech tail) advance inside token2wav_batch BEFORE its listener runs; if the pass - or deliver() itself - fails after
         # that, a solo retry must start from the caches the chunk started from, or it would vocode the chunk a second time against already-advanced state.
+        # SHALLOW COPIES, not references: CosyVoice3Model._t2w_tail updates its cache dict in place (cache['mel'] = concat(...), cache['speech_offset'] += ...), so a kept
+        # reference would show the advanced state and the restore below would be a no-op; the tensors themselves are never written in place.
+        snap = lambda c: dict(c) if isinstance(c, dict) else c
         with m.lock:
-            before = {i: m.hift_cache_dict.get(r.key) for i, (r, _, _) in enumerate(picks)}
+            before = {i: (r.key in m.hift_cache_dict, snap(m.hift_cache_dict.get(r.key))) for i, (r, _, _) in enumerate(picks)}
         try:
             m.token2wav_batch(jobs, stream=(what == "chunk"), finalize=(what == "final"), on_ready=deliver)
         except Exception:
@@ -241,7 +244,8 @@ class StreamScheduler:
                     continue
                 try:
                     with m.lock:
-                        m.hift_cache_dict[r.key] = before[i]
+                        if before[i][0] and r.key in m.hift_cache_dict:     # (a request popped in the meantime - ended, cancelled - is not given its key back)
+                            m.hift_cache_dict[r.key] = snap(before[i][1])
                     deliver(i, m.token2wav(stream=(what == "chunk"), finalize=(what == "final"), **jobs[i]))
                 except Exception as e:                      # handed to the request's listener
                     failed[i] = e

@@ -159,7 +159,7 @@ def pack_flow_band(w_out, w_ff1, w_ff2, waves, w_qkv_next=None):
     return torch.stack(out, 0).contiguous()
 
 
-def pack_flow(sd, cfg, device, dtype=torch.bfloat16):
+def pack_flow(sd, cfg, device, dtype=torch.bfloat16, experiments=False):
     """sd: CausalMaskedDiffWithXvec state dict (cosyvoice/flow/flow.py:150-186)."""
     out = {}
     out["input_embedding"] = _bf16(sd["input_embedding.weight"], device) if dtype == torch.bfloat16 else _f32(sd["input_embedding.weight"], device)
@@ -231,8 +231,9 @@ def pack_flow(sd, cfg, device, dtype=torch.bfloat16):
                 z = torch.zeros(cfg.est_ch, device=device)
                 out[q + "tail_prm"] = torch.cat([out[q + "out.b"], out[q + "norm3.g"], out[q + "norm3.b"], out[q + "ff1.b"], out[q + "ff2.b"],
                                                  out[dst + "tf.%d.norm1.g" % (j + 1)] if nxt is not None else z, out[dst + "tf.%d.norm1.b" % (j + 1)] if nxt is not None else z]).contiguous()
-                out[q + "tail"] = pack_flow_tail(out[q + "out.w"].reshape(cfg.est_ch, inner), out[q + "ff1.w"].reshape(4 * cfg.est_ch, cfg.est_ch),
-                                                 out[q + "ff2.w"].reshape(cfg.est_ch, 4 * cfg.est_ch), nxt)
+                if experiments:                                     # the 16-row tail of round 3 (csrc/experiments/flow_tail.h): only a CV_BUILD_EXPERIMENTS library can run it
+                    out[q + "tail"] = pack_flow_tail(out[q + "out.w"].reshape(cfg.est_ch, inner), out[q + "ff1.w"].reshape(4 * cfg.est_ch, cfg.est_ch),
+                                                     out[q + "ff2.w"].reshape(cfg.est_ch, 4 * cfg.est_ch), nxt)
                 # the 64-row band form for large passes (csrc/flow_band.h): 8 waves at the real width, 4 at the test width
                 out[q + "band"] = pack_flow_band(out[q + "out.w"].reshape(cfg.est_ch, inner), out[q + "ff1.w"].reshape(4 * cfg.est_ch, cfg.est_ch),
                                                  out[q + "ff2.w"].reshape(cfg.est_ch, 4 * cfg.est_ch), 8 if cfg.est_ch == 256 else 4)

@@ -31,6 +31,10 @@ const char* cv_last_error(void);
 const char* cv_version(void);
 /* 1 when the library was built by the CPU emulator used in tests (never shipped), 0 for the gfx950 build. */
 int cv_is_emulated(void);
+/* 1 when the library was built with -DCV_BUILD_EXPERIMENTS (cosyvoice_amd/build.py with CV_BUILD_EXPERIMENTS=1; always in the test-suite's emulator build): the measured
+ * no-go variants (csrc/experiments/, the attention kernels of rounds 2-5, the decode-step fusions of round 3 ...) are then instantiated and their option switches
+ * accepted; the default build leaves them out and a switch that selects one fails with an error. */
+int cv_has_experiments(void);
 
 /* ------------------------------------------------------------------------------------------------------
  * Operator level (used by the stage entry points below; exported so each kernel can be parity-tested
@@ -62,6 +66,9 @@ typedef struct cv_gemm_conv_args {
 /* One-row calls (M == 1, batch 1, one tap, fp32 W, no prologue / scales) run as a GEMV over the matrix as registered in `W`: they ignore W3, and their sums differ
  * from the tile kernels' in summation order only (fp32 rounding) - the decode rows of a model agree with its prefill rows to that, not bit for bit. */
 int cv_gemm_conv(const cv_gemm_conv_args* args, void* stream);
+/* Process-wide switches of the operator layer (no reference counterpart: A/B and test knobs).  "gemv_f32" (default 1, initialised once from CV_GEMV_F32): a
+ * cv_gemm_conv with ONE output row over fp32 weights runs on the GEMV kernel (1) or on the GEMM tile with one useful row (0); the two differ in summation order only. */
+int cv_ops_set_option(const char* name, int32_t value);
 
 /* Row LayerNorm / RMSNorm over the last (channel) axis of a [rows, C] fp32 matrix.
  * y = act( (x-mean)*rstd*gamma + beta ) * scale * row_scale[row] + col_add[batch_of_row][c]

@@ -31,12 +31,20 @@ def pytest_cmdline_main(config):
 
 # CPU suite under pytest-xdist (--dist loadfile hands whole files to idle workers in COLLECTION order): heaviest files first, so that the long ones do not
 # start last and leave five workers idle behind them (measured file totals under the emulator, seconds: round-4 `--durations=30` run).
-_HEAVY_FIRST = ["test_flow_big.py", "test_fullsize_pinned.py", "test_flow.py", "test_fullsize_pinned_model.py", "test_dropin_reference.py", "test_model_cv3.py", "test_llm_ras.py", "test_model_batch_padded.py", "test_model_cv3_filter.py", "test_causal_hift.py",
+_HEAVY_FIRST = ["test_fullsize_pinned_model.py", "test_flow_big.py", "test_fullsize_pinned.py", "test_flow.py", "test_dropin_reference.py", "test_model_cv3.py", "test_llm_ras.py", "test_model_batch_padded.py", "test_model_cv3_filter.py", "test_causal_hift.py",
                 "test_zz_llm_batch.py", "test_dropin_reference_cv1.py", "test_bench_cv1_dryrun.py", "test_zzz_cosyvoice1_hip_model.py", "test_model_load.py", "test_model.py", "test_model_batch.py",
                 "test_model_cv3_batch.py", "test_dit.py", "test_zzz_cosyvoice1_hip.py", "test_zzz_cosyvoice1_hip_hift.py", "test_zz_fullsize.py", "test_hift.py", "test_llm.py"]
 
 
 def pytest_collection_modifyitems(config, items):
+    # `experiments`: a test (or one of its parameter sets) of a measured no-go variant that only exists in a library built with CV_BUILD_EXPERIMENTS.
+    # The emulator build always has them (the CPU suite keeps every variant under test); the product build does not: on the hardware these items are deselected
+    # unless the run says the library under test was built with them (CV_BUILD_EXPERIMENTS=1 in the environment of both the build and the test run).
+    if os.environ.get("CV_BUILD_EXPERIMENTS") != "1":
+        drop = [it for it in items if it.get_closest_marker("experiments") and getattr(getattr(it, "callspec", None), "params", {}).get("lib") == "hip"]
+        if drop:
+            config.hook.pytest_deselected(items=drop)
+            items[:] = [it for it in items if it not in drop]
     if (config.getoption("markexpr", "") or "").strip() != "not gpu":
         return                                                   # GPU runs keep the alphabetical order (one process; the full-size tests last)
     rank = {name: i for i, name in enumerate(_HEAVY_FIRST)}
@@ -45,6 +53,7 @@ def pytest_collection_modifyitems(config, items):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "experiments: exercises a measured no-go variant that exists only in a CV_BUILD_EXPERIMENTS build (always under the emulator)")
     if os.environ.get("PYTEST_XDIST_WORKER"):
         # CPU suite under pytest-xdist (6 workers): the emulator is single-threaded and the oracle's torch ops are small, so one or two intra-op
         # threads per worker are enough - 6 workers x all cores each only fight over the machine

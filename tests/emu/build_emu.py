@@ -35,14 +35,14 @@ def _build_emu(force=False):
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
     srcs.append(os.path.join(HERE, "emu_runtime.cpp"))
     newest = 0.0
-    for d in (CSRC, os.path.join(REPO, "include"), HERE, os.path.join(HERE, "hip")):
+    for d in (CSRC, os.path.join(CSRC, "experiments"), os.path.join(REPO, "include"), HERE, os.path.join(HERE, "hip")):
         for f in os.listdir(d):
             if f.endswith((".h", ".hip", ".cpp")):
                 newest = max(newest, os.path.getmtime(os.path.join(d, f)))
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
         return LIB
     os.makedirs(OBJ_DIR, exist_ok=True)
-    flags = ["-O2", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-stack-protector",
+    flags = ["-O2", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-stack-protector", "-DCV_BUILD_EXPERIMENTS",      # the CPU suite keeps every variant under test
              "-I", HERE, "-I", CSRC, "-I", os.path.join(REPO, "include"),
              "-Wno-unused-value", "-Wno-unknown-attributes"]
 

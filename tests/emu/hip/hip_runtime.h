@@ -231,5 +231,6 @@ static inline emu_u32x2 emu_permlane32_swap(unsigned a, unsigned b) {
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
+#define __builtin_amdgcn_s_getreg(x) 0      /* hardware id registers (dev-tool stamps only) */
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))

@@ -381,7 +381,9 @@ def test_estimator_engine_raw_addresses_on_a_real_stream(hip_lib):
         torch.testing.assert_close(x.cpu(), ref, rtol=2e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("tile,waves,kt,ks", [(0, 0, 0, 0), (0, 4, 2, 2), (1, 2, 1, 1), (2, 4, 1, 1), (3, 2, 2, 1), (4, 4, 2, 1), (0, 4, 1, 3), (0, 4, 1, 4)])
+_X = pytest.mark.experiments          # attn_flow_kernel (rounds 2-5) in its workgroup shapes: CV_BUILD_EXPERIMENTS builds only; the LN-GEMM tile shapes ride on the default attention
+@pytest.mark.parametrize("tile,waves,kt,ks", [(0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0), (3, 0, 0, 0), (4, 0, 0, 0)] + [pytest.param(*v, marks=_X) for v in
+                                              ((0, 4, 2, 2), (1, 2, 1, 1), (2, 4, 1, 1), (3, 2, 2, 1), (4, 4, 2, 1), (0, 4, 1, 3), (0, 4, 1, 4))])
 def test_fused_transformer_blocks_match_unfused(lib, tile, waves, kt, ks):
     """bf16 mode: the fused pipeline of the estimator's transformer blocks (flow_fused.h: LayerNorm in the GEMM prologue, bf16 Q / K / V^T /
     attention output / FF hidden between kernels, bf16-in flash attention) rounds the same operands at the same points as the unfused
@@ -443,6 +445,7 @@ def test_two_n_tiles_per_workgroup_is_bit_identical(lib):
 
 
 @pytest.mark.parametrize("est_blocks", [1, 3])
+@pytest.mark.experiments
 def test_fused_tail_matches_five_launch_blocks(lib, est_blocks):
     """bf16 mode, round 3: everything after a block's attention as ONE launch per 16-row band (flow_tail.h: out-projection + residual -> LayerNorm ->
     FF1 + GELU -> FF2 + residual -> the next block's LayerNorm -> Q | K | V^T) against the five-launch form of round 2 (option fused_tail = 0) and

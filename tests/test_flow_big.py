@@ -136,6 +136,7 @@ def test_band_kernel_at_the_real_width(lib):
         lib.cv_flow_set_option(flow._h, b"band_bm", C.c_int32(0)); lib.cv_flow_set_option(flow._h, b"band_qkv", C.c_int32(1)); lib.cv_flow_set_option(flow._h, b"band_pipe", C.c_int32(2))
 
 
+@pytest.mark.experiments
 def test_eager_large_pass_runs_two_chains(lib):
     """Round 5: a pass that runs eager (graph_max_rows) takes the estimator's batch rows as TWO launch chains on two streams (option eager_streams = 2, the default) - the
     same kernels on the same rows, the band height chosen from the rows of the WHOLE pass: every utterance's mel is the one chain's, bit for bit, in an equal-shape pass

@@ -28,8 +28,8 @@ def test_whole_request_fullsize():
     tokens = load("fullsize_llm")["tokens"].tolist()
     pipe = OM.Pipeline((None, W.make_flow(fc), W.make_hift(hc)), cfgs)
     with torch.inference_mode():
-        # the streamed half is five flow passes + five vocoder calls at full size (2 minutes on one thread): the default suite checks its chunk SCHEDULE against the real
-        # class's and the offline waveform; CV_TEST_FULL=1 also computes the streamed waveform (done when the fixture was made: equal within the tolerance below)
+        # the streamed half is five flow passes + five vocoder calls at full size (2 minutes on one thread): every run checks its chunk SCHEDULE against the real
+        # class's, the offline waveform AND (round 6: no longer opt-in; CV_TEST_SKIP_FULL=1 leaves it out) the streamed waveform
         n_p = u["flow_prompt_speech_token"].shape[1]
         sched, off, hop, la = [], 0, pipe.token_hop_len, fc.pre_lookahead
         pad = int(np.ceil(n_p / hop) * hop - n_p)
@@ -41,7 +41,7 @@ def test_whole_request_fullsize():
         sched.append(480 * 2 * len(tokens) - sum(sched))
         assert sched == g["stream_n"].tolist()
         for key, stream in (("offline", False), ("stream", True)):
-            if stream and not os.environ.get("CV_TEST_FULL"):
+            if stream and os.environ.get("CV_TEST_SKIP_FULL"):
                 continue
             outs = pipe.tts(tokens, u, stream=stream)
             assert [o.shape[1] for o in outs] == g[key + "_n"].tolist()
@@ -54,10 +54,10 @@ def test_whole_request_fullsize():
 def test_cv3_whole_request_fullsize():
     """bench.py's cosyvoice3 request end to end at Fun-CosyVoice3-0.5B dimensions: oracle.model.Pipeline3 against the REAL cli.model.CosyVoice3Model.tts (silent-token filter,
     accumulating mel cache, speech offsets) around the real DiT flow with its 10 Euler steps + CausalHiFTGenerator, offline (240 000 samples, every 8th stored).  Ten
-    full-size DiT passes on one thread take minutes: opt-in (CV_TEST_FULL=1; run when the fixture was made - the per-stage pins of test_fullsize_pinned.py run always)."""
+    full-size DiT passes take a few minutes of CPU: part of the default suite since round 6 (profiles/r6_cv_test_full.log; CV_TEST_SKIP_FULL=1 leaves it out)."""
     import pytest
-    if not os.environ.get("CV_TEST_FULL"):
-        pytest.skip("CV_TEST_FULL=1 runs the full-size CosyVoice3 request through the oracle (minutes of CPU)")
+    if os.environ.get("CV_TEST_SKIP_FULL"):
+        pytest.skip("CV_TEST_SKIP_FULL=1: the full-size CosyVoice3 request through the oracle is left out")
     from cosyvoice_amd import configs as CF
     from oracle import model as OM
     g = load("fullsize_model_cv3")

@@ -206,6 +206,7 @@ def test_inference_bistream(lib, tiny_sd):
         OL.inference(sd, cfg, u["text"], u["prompt_text"], u["llm_prompt_speech_token"], max_token_text_ratio=3, min_token_text_ratio=1)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("splits,n_prompt", [(8, 11), (4, 300)])
 def test_fused_qkv_attention_variant(lib, tiny_sd, splits, n_prompt):
     """Option fused_qkv_attn = 1 (qkv_attn_kernel: RMSNorm + q / k / v rows + RoPE + split attention over the cached keys in one launch, the new
@@ -254,6 +255,7 @@ def test_prefill_weight_stationary_rows_path(lib, tiny_sd, n_prompt):
     assert not torch.equal(logits[0], logits[1])                  # (two different summation orders really ran)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("rblocks,waves,n_prompt", [(4, 8, 11), (8, 8, 430), (4, 16, 430)])
 def test_fused_attention_oproj_variant(lib, tiny_sd, rblocks, waves, n_prompt):
     """Option fused_attn_oproj = 1 (round 3, attn_oproj_kernel): attention and the o_proj GEMV in one launch, o_proj split by head, the per-head
@@ -280,6 +282,7 @@ def test_fused_attention_oproj_variant(lib, tiny_sd, rblocks, waves, n_prompt):
         torch.testing.assert_close(lm.last_logits().log_softmax(-1), trace["logp"][i], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("mode,shift", [(1, 0), (2, 0), (1, 3)])
 def test_decode_weight_prefetch_is_only_a_hint(lib, tiny_sd, mode, shift):
     """Option prefetch = 1 / 2 (round 3): extra workgroups of the short decode kernels (qkv / attention / o_proj) read the weights the gate / up and

@@ -45,7 +45,9 @@ def test_linear(lib, M, N, K, wdt):
 def test_single_row_gemv_fp32_weights(lib, N, K, act, monkeypatch):
     """Round 4: one output row over fp32 weights goes to gemv_f32_kernel (the decode step of CosyVoice-300M's LM) instead of a GEMM tile with one useful row -
     same epilogue contract as the tiled kernel ((act(x W^T + b) + res) * out_scale), K not a multiple of the 64-float step, N not a multiple of a workgroup's
-    4 rows, a row-pitched weight view; and the tiled kernel (CV_GEMV_F32=0) agrees to fp32 rounding."""
+    4 rows, a row-pitched weight view; and the tiled kernel (cv_ops_set_option "gemv_f32" = 0; the environment variable CV_GEMV_F32 is only read once per process,
+    so toggling IT here compared the GEMV with itself - ADVICE r5) agrees to fp32 rounding."""
+    import ctypes as C
     dev = _dev(lib)
     A = _rand((1, K), dev, 11)
     W = _rand((N, K), dev, 12, 0.2)
@@ -54,13 +56,18 @@ def test_single_row_gemv_fp32_weights(lib, N, K, act, monkeypatch):
     ref = {"none": lambda v: v, "relu": F.relu, "silu": F.silu}[act](A @ W.t() + b)
     ref = (ref + res) * 0.5
     outs = []
-    for knob in ("1", "0"):
-        monkeypatch.setenv("CV_GEMV_F32", knob)
-        out = ops.gemm_conv(lib, A, Wp, Kp, M=1, N=N, K=K, bias=b, act=act, res=res.reshape(1, 1, N), out_scale=0.5)
-        _sync(lib)
-        outs.append(out[0].cpu())
-        torch.testing.assert_close(outs[-1], ref.cpu(), rtol=3e-5, atol=3e-5)
+    try:
+        for knob in (1, 0):
+            lib.cv_ops_set_option(b"gemv_f32", C.c_int32(knob))
+            out = ops.gemm_conv(lib, A, Wp, Kp, M=1, N=N, K=K, bias=b, act=act, res=res.reshape(1, 1, N), out_scale=0.5)
+            _sync(lib)
+            outs.append(out[0].cpu())
+            torch.testing.assert_close(outs[-1], ref.cpu(), rtol=3e-5, atol=3e-5)
+    finally:
+        lib.cv_ops_set_option(b"gemv_f32", C.c_int32(1))
     torch.testing.assert_close(outs[0], outs[1], rtol=2e-5, atol=2e-5)
+    if K >= 1024:
+        assert not torch.equal(outs[0], outs[1])                    # two kernels, two summation orders: the knob really switched
 
 
 @pytest.mark.parametrize("M,N,K,taps", [(37, 48, 64, 1), (130, 200, 96, 1), (300, 256, 1024, 1), (70, 96, 320, 3), (33, 40, 36, 1)])

@@ -467,3 +467,49 @@ def test_grpc_adapter_with_stub_engine():
             assert e.value.code() == grpc.StatusCode.UNIMPLEMENTED
     finally:
         server.stop(0)
+
+
+@pytest.mark.timeout(120)
+def test_solo_retry_starts_from_the_cache_the_chunk_started_from_even_when_the_model_updates_it_in_place():
+    """CosyVoice3Model._t2w_tail updates a request's vocoder cache IN PLACE (cache['mel'] = concat(...), cache['speech_offset'] += ...).  The scheduler's
+    snapshot for the solo retry after a failed shared pass must therefore be a copy: here the model keeps a per-request dict {'speech_offset': samples vocoded so far}
+    that token2wav advances in place and checks against the chunk it is given; the shared pass advances EVERY member's cache and then dies before any member got
+    its audio.  With a reference snapshot the retry would see the advanced offset (the model raises); with the copy every stream gets each chunk exactly once."""
+    scripts = {1: list(range(47))}
+
+    class Cv3Like(_FakeModel):
+        flow_batch, flow_pad = 4, 1.25
+
+        def token2wav(self, token, prompt_token, prompt_feat, embedding, token_offset, uuid, stream=False, finalize=False, speed=1.0):
+            with self.lock:
+                cache = self.hift_cache_dict.get(uuid)
+                if cache is None:
+                    cache = self.hift_cache_dict[uuid] = {"speech_offset": 0}
+            if cache["speech_offset"] != token_offset * 960:
+                raise AssertionError("chunk at token %d vocoded against a cache at sample %d" % (token_offset, cache["speech_offset"]))
+            out = _FakeModel.token2wav(self, token, prompt_token, prompt_feat, embedding, token_offset, uuid, stream, finalize, speed)
+            cache["speech_offset"] += out.shape[1]                  # in place, like CosyVoice3Model._t2w_tail
+            return out
+
+        def token2wav_batch(self, jobs, stream=False, finalize=False, on_ready=None):
+            self.n_batches = getattr(self, "n_batches", 0) + 1
+            outs = [self.token2wav(stream=stream, finalize=finalize, **j) for j in jobs]       # every member's cache advances ...
+            if self.n_batches % 2 == 1:
+                del self.calls[-len(jobs):]
+                raise RuntimeError("the shared pass died before anyone was served")           # ... then every other pass dies
+            for i, o in enumerate(outs):
+                on_ready(i, o)
+
+    fm = Cv3Like(scripts)
+    sch = StreamScheduler(fm, slots=8, step_chunk=4)
+    try:
+        got = [None] * 3
+        th = [threading.Thread(target=lambda i=i: got.__setitem__(i, [o["tts_speech"].shape[1] // 960 for o in sch.submit(stream=True, **_fake_req(1))])) for i in range(3)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert got == [[7, 10, 20, 10]] * 3, got
+        assert fm.n_batches >= 1 and not sch._reqs and not fm.hift_cache_dict
+    finally:
+        sch.shutdown()

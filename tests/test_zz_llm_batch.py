@@ -40,6 +40,7 @@ def test_batch_matches_single_and_oracle(lib, use_graph):
         assert g == OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=3, min_token_text_ratio=1)
 
 
+@pytest.mark.experiments
 def test_deep_down_projection_variant(lib, monkeypatch):
     """CV_DOWN_DEEP=1: the down projection of the batched step as ONE launch (skinny_deep_kernel: 16-wave workgroups over the whole K, a ring of
     k-tiles per wave) instead of split-K partials + sum_partials_kernel.  Measured slower on the MI355X and off by default (llm.hip), but a kept
@@ -117,6 +118,8 @@ def test_grouped_query_attention_variants(lib, heads, kv_heads, monkeypatch):
     want = [OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=4, min_token_text_ratio=2) for r in reqs]
     knobs = [{"CV_ATTN_BATCH": "1"}, {"CV_ATTN_BATCH": "1", "CV_ATTN_BATCH_SLICES": "1"}, {"CV_ATTN_BATCH": "1", "CV_ATTN_BATCH_SLICES": "3", "CV_ATTN_BATCH_WAVES": "8"},
              {"CV_ATTN_BATCH": "0"}, {"CV_ATTN_BATCH": "0", "CV_ATTN_BATCH_GQA": "1"}, {}]      # {}: the launch rule (few slots, short contexts: the per-head form)
+    if not lib.experiments:
+        knobs = [k for k in knobs if "CV_ATTN_BATCH_GQA" not in k]                  # (the grouped form is a CV_BUILD_EXPERIMENTS kernel)
     if heads == 6:
         knobs = knobs[:2] + knobs[3:4]
     for env in knobs:

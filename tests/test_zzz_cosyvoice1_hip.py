@@ -271,7 +271,7 @@ def test_device_resident_decode_loop(lib):
         e0 = torch.zeros(1, 0, dtype=torch.int32)
         sft = dict(kw, prompt_text=e0, prompt_text_len=t(0), prompt_speech_token=e0, prompt_speech_token_len=t(0))
         assert list(lm.inference(max_token_text_ratio=5, min_token_text_ratio=2, **sft)) == g["tokens_sft"].tolist()
-        assert lm.step.stat("steps") > 0
+        assert lm.step_stat("steps") > 0 and len(lm._loop_steps) == 1      # (a loop handle of the request's own, returned to the pool)
     # repetition-aware sampling from fixed uniforms: device loop == host loop driven by the oracle's restatement of the rule with the same variates
     u = torch.rand(2 * 64, generator=torch.Generator().manual_seed(21))
     lm = CK.TransformerLM(sd, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling="ras", lib=lib, decode_chunk=7)
@@ -285,3 +285,41 @@ def test_device_resident_decode_loop(lib):
     ref = CK.TransformerLM(sd, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling=host_ras, lib=lib)
     want = list(ref.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw))
     assert got == want and 14 <= len(got) <= 42 and len(set(got)) > 3
+
+
+def test_interleaved_device_loops_do_not_share_loop_state(lib):
+    """the device-resident loop's state lives in a cv_lm1 handle and the stage lock is released between chunks - two requests whose generators are advanced
+    alternately (chunks of 3 tokens) must each get exactly the tokens they get alone, with a host-sampler request stepping in between as well; the handles go back
+    to the pool when a generator ends or is closed early."""
+    g = gold("cv1k_llm")
+    kw = dict(text=g["text"], text_len=t(7), prompt_text=g["prompt_text"], prompt_text_len=t(4), prompt_speech_token=g["prompt_speech_token"],
+              prompt_speech_token_len=t(9), embedding=g["embedding"])
+    e0 = torch.zeros(1, 0, dtype=torch.int32)
+    sft = dict(kw, prompt_text=e0, prompt_text_len=t(0), prompt_speech_token=e0, prompt_speech_token_len=t(0))
+    sd = W.make_cv1_llm(CFG)
+    lm = CK.TransformerLM(sd, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling="greedy", lib=lib, decode_chunk=3)
+    a = lm.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw)
+    b = lm.inference(max_token_text_ratio=5, min_token_text_ratio=2, **sft)
+    got_a, got_b, live = [], [], [a, b]
+    while live:
+        for gen, out in ((a, got_a), (b, got_b)):
+            if gen in live:
+                try:
+                    for _ in range(2):                              # two tokens at a time: the hand-over falls inside and between the 3-token chunks
+                        out.append(next(gen))
+                except StopIteration:
+                    live.remove(gen)
+    assert got_a == g["tokens_greedy"].tolist() and got_b == g["tokens_sft"].tolist()
+    assert len(lm._loop_steps) == 2 and all(s.bound is None for s in lm._loop_steps)
+    # an abandoned request returns its handle; a host-sampler model stepping between the chunks of a device loop does not disturb it (its own handle, rebound per call)
+    c = lm.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw)
+    first = [next(c), next(c)]
+    c.close()
+    assert first == g["tokens_greedy"].tolist()[:2] and len(lm._loop_steps) == 2
+    d = lm.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw)
+    got_d = [next(d)]
+    lm.sampling, keep = greedy, lm.sampling                          # a python sampler: the operator-per-token path on lm.step, in the gap of d's open loop
+    assert list(lm.inference(max_token_text_ratio=5, min_token_text_ratio=2, **sft)) == g["tokens_sft"].tolist()
+    lm.sampling = keep
+    got_d += list(d)
+    assert got_d == g["tokens_greedy"].tolist()

@@ -29,7 +29,7 @@ hift = CK.HiFTGenerator(sd_hift, hcfg)
 if lm.step is not None:
     import ctypes
     lm.fused_step = "nofused" not in sys.argv
-    lm.step.lib.cv_lm1_set_option(lm.step.h, b"graph", ctypes.c_int32(0 if "nograph" in sys.argv else 1))      # (the probe's default is the graph; the library's is eager)
+    lm.set_step_option("graph", 0 if "nograph" in sys.argv else 1)      # (the probe's default is the graph; the library's is eager)
 print("LM decode step: %s" % ("cv_lm1_step (%d launches, %s)" % (lm.step.stat("launches_per_step"), "kernel by kernel" if "nograph" in sys.argv else "one hipGraph") if lm.fused_step
                               else "launch-per-operator tape (3 + 8 launches per layer)"), flush=True)
 flow.k.use_graphs = graphs                                   # `graphs`: the estimator tape of a solve as a hipGraph (LaunchTape.capture), opt-in until measured

@@ -11,6 +11,7 @@
 #include <vector>
 #include <string>
 #include <algorithm>
+#include <map>
 #include "flow_attn32.h"
 using namespace cv;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -145,6 +146,21 @@ int main(int argc, char** argv) {
                     auto q = [&](std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
                     printf("    end time since first start, us: min %.2f  10%% %.2f  50%% %.2f  90%% %.2f  99%% %.2f  max %.2f;  lifetime: min %.2f 50%% %.2f 90%% %.2f max %.2f;  key loop: min %.2f 10%% %.2f 50%% %.2f 90%% %.2f max %.2f\n",
                            q(ends, 0), q(ends, .1), q(ends, .5), q(ends, .9), q(ends, .99), q(ends, 1), q(durs, 0), q(durs, .5), q(durs, .9), q(durs, 1), q(loops, 0), q(loops, .1), q(loops, .5), q(loops, .9), q(loops, 1));
+                }
+                if (pass) {
+                    // where the time goes by placement: key loop by query block, by XCC, and by how many workgroups shared the CU
+                    std::vector<double> byq(16, 0), nq(16, 0), byx(8, 0), nx(8, 0);
+                    std::map<long long, std::vector<double>> bycu;
+                    for (unsigned w = 0; w < g128; ++w) {
+                        const double lp = (hd[w * 8 + 3] - hd[w * 8 + 2]) * 0.01; const int qbi = (int)hd[w * 8 + 7], xcc = (int)(hd[w * 8 + 6] & 7); const long long hw = hd[w * 8 + 5];
+                        const int cu = (int)((hw >> 8) & 15), sh = (int)((hw >> 12) & 1), se = (int)((hw >> 13) & 7);
+                        if (qbi < 16) { byq[qbi] += lp; nq[qbi] += 1; } byx[xcc] += lp; nx[xcc] += 1;
+                        bycu[((long long)xcc << 16) | (se << 8) | (sh << 4) | cu].push_back(lp);
+                    }
+                    printf("    key loop by query block:"); for (int i = 0; i < 16; ++i) if (nq[i] > 0) printf(" %d: %.2f", i, byq[i] / nq[i]); printf("\n    key loop by XCC:");
+                    for (int i = 0; i < 8; ++i) if (nx[i] > 0) printf(" %d: %.2f (%d)", i, byx[i] / nx[i], (int)nx[i]); printf("\n    CUs by resident workgroups:");
+                    std::map<size_t, std::pair<int, double>> bycount; for (auto& kv : bycu) { double mx = 0; for (double v : kv.second) mx = std::max(mx, v); auto& e = bycount[kv.second.size()]; e.first++; e.second += mx; }
+                    for (auto& kv : bycount) printf(" %zu wg: %d CUs, mean of the CU's slowest key loop %.2f us;", kv.first, kv.second.first, kv.second.second / kv.second.first); printf("  (%zu CUs used)\n", bycu.size());
                 }
                 printf("  stamps attn_flow32<4,3> %s: first start -> last end %.2f us; starts spread over %.2f us; mean per workgroup: setup %.2f, first tile lands %.2f, key loop %.2f, store %.2f us\n",
                        pass ? "behind another launch" : "alone", (tend - t0) * 0.01, (lateststart - t0) * 0.01, ph[0] * 0.01, ph[1] * 0.01, ph[2] * 0.01, ph[3] * 0.01);

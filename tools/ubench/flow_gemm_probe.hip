@@ -2,7 +2,7 @@
 // round-2 kernels (flow_fused.h) against the round-3 forms (flow_gemm2.h), as dependent chains of 56 launches with 56 different weight sets inside a
 // hipGraph (the estimator's 56 blocks), plus clock64() phase stamps of thread 0 of every workgroup and the distribution of workgroup start times.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I cosyvoice_amd/csrc -I include tools/ubench/flow_gemm_probe.hip -o tools/ubench/flow_gemm_probe
-#include "../../cosyvoice_amd/csrc/flow_gemm2.h"
+#include "../../cosyvoice_amd/csrc/experiments/flow_gemm2.h"
 #include <vector>
 #include <cstdio>
 #include <cstring>

@@ -4,7 +4,7 @@
 // between one event pair.  Checks the one-launch result against the chain's and against a double-precision host reference, prints the
 // per-workgroup phase stamps (entry -> act published -> gather done -> exit) and the give-up flag.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I cosyvoice_amd/csrc -I include tools/ubench/persist_probe.hip -o tools/ubench/persist_probe
-#include "../../cosyvoice_amd/csrc/llm_persist.h"
+#include "../../cosyvoice_amd/csrc/experiments/llm_persist.h"
 #include <vector>
 #include <cstdio>
 #include <cstring>

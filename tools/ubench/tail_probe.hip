@@ -4,7 +4,7 @@
 //     launch as in the real Euler step) and with ONE stream re-used (L2-warm);
 //   * clock64() stamps of thread 0 at the phase boundaries (FlowTailArgs::dbg), averaged over the workgroups.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I cosyvoice_amd/csrc -I include tools/ubench/tail_probe.hip -o tools/ubench/tail_probe
-#include "../../cosyvoice_amd/csrc/flow_tail.h"
+#include "../../cosyvoice_amd/csrc/experiments/flow_tail.h"
 #include <vector>
 #include <cstdio>
 #include <cstring>
