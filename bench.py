@@ -774,6 +774,8 @@ def cpu_baseline(cfgs):
                        "it reproduces the real classes' token ids exactly and their mel / waveform to 4e-6 / 3e-7: tests/test_fullsize_pinned.py), one fresh process per stage, best of a thread sweep per "
                        "stage: LLM prefill(131) + 12 decode steps (4 each at context 131 / 256 / 381, averaged: the range U10's 250 steps cover), flow encoder(337 tok) + 1 of 10 "
                        "estimator steps at T=674, HiFT 100 of 500 frames; per-stage times extrapolated to the full U10 utterance",
+                port_vs_reference="RECORD of the build container, not measured by this run (profiles/r6_cpu_port_vs_reference.txt, tools/cpu_port_vs_reference.py): the port's time on "
+                                  "these stage samples over the REAL reference modules' (8 threads): LLM decode step 0.85, flow encoder 1.07, flow estimator 1.04, HiFT 0.76",
                 threads_used=threads, stage_seconds={k: round(v, 4) for k, v in stage_s.items()})
 
 
