@@ -856,7 +856,7 @@ def mixed64_extra(model, cfgs, lanes):
             yield j, t
     model.llm.inference_queue = spy
     try:
-        slots = int(os.environ.get("CV_BENCH_MIXED_SLOTS", 32))       # sequences in flight on the one GPU (A/B knob; 16 until round 4: 373 vs 419 audio-s/s, profiles/r4_batch_serving_ab.txt)
+        slots = int(os.environ.get("CV_BENCH_MIXED_SLOTS", 48))       # sequences in flight on the one GPU (A/B knob; 16 until round 4, 32 in rounds 4-5; round 6: 48 = three decode chains of 16, profiles/r6_queue_groups.txt)
         run_mixed(model, reqs, mine, slots=slots)
         torch.cuda.synchronize()
         toks.clear()
@@ -1048,7 +1048,7 @@ def main():
         mixed = {"hashes": {}}
 
         def step():
-            mixed["hashes"] = run_mixed(model, reqs, mine, slots=max(1, min(2 if DRY else 32, len(mine))))      # 8 in flight per GPU at 8 GPUs, 32 when one GPU takes all 64
+            mixed["hashes"] = run_mixed(model, reqs, mine, slots=max(1, min(2 if DRY else 48, len(mine))))      # 8 in flight per GPU at 8 GPUs, 48 (three chains of 16) when one GPU takes all 64
     else:
         def step():
             one_utterance(model, u)
@@ -1114,7 +1114,7 @@ def main():
         if mixed is not None:
             out["scaling"] = "strong"
             out["config"]["workload"] = ("CosyVoice2-0.5B batched zero-shot, 64 seeded utterances with 125/250/375/500 generated tokens (equal mix, 800 s of audio "
-                                         "per step) dealt over the ranks by longest-processing-time-first, <= min(32, shard size) sequences in flight per GPU (BASELINE.json configs[3])")
+                                         "per step) dealt over the ranks by longest-processing-time-first, <= min(48, shard size) sequences in flight per GPU (BASELINE.json configs[3])")
             out["config"]["assignment"] = {str(r): sh for r, sh in enumerate(shard_requests(costs, world))}
             out["config"]["utterances_per_gpu_per_step"] = len(mine)
             out["config"]["sampler"] = "greedy, length forced per utterance"

@@ -85,19 +85,10 @@ __global__ __launch_bounds__(NW * 64) CV_WAVES_PER_EU(WPE, WPE) void attn_flow32
         return p.mask_mode == MASK_CHUNK ? min(Tkb, (min(p.T - 1, q0 + nq - 1) / p.chunk + 1) * p.chunk) : Tkb;
     };
     const int kend = kend_of(qb * BQ, BQ);                            // workgroup (DMA, barriers)
-    const int kend_w = kend_of(qb * BQ + wave * 32, 32);              // this wave (its MFMAs): wave-uniform
-    const int qi = qb * BQ + wave * 32 + lq;
-    const bool qvalid = qi < p.T;
-    int klim = kend_w;                                                // rows past T compute finite garbage on zero queries, never stored
-    if (qvalid && p.mask_mode == MASK_CHUNK) klim = min(Tkb, (qi / p.chunk + 1) * p.chunk);
-    int klim_min_w = klim;                                            // tiles that end at or below it need no per-element mask
-    klim_min_w = min(klim_min_w, __shfl_xor(klim_min_w, 32));
-#pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) klim_min_w = min(klim_min_w, __shfl_xor(klim_min_w, o));
-    klim_min_w = __builtin_amdgcn_readfirstlane(klim_min_w);
 
     // ---- DMA: piece i of an operand tile = rows 8 i .. 8 i + 7; lane l lands at LDS chunk l % 8 of row 8 i + l / 8 and FETCHES global chunk (l % 8) ^ swz(row).
-    // Source = scalar tile base + the lane's byte offset inside a tile (the same for every tile; K rows >= T - only in the last tile - are clamped to row T - 1 and masked)
+    // Source = scalar tile base + the lane's byte offset inside a tile (the same for every tile; K rows >= T - only in the last tile - are clamped to row T - 1 and masked).
+    // The first two tiles are requested before anything else is worked out: their flight (the prologue's longest wait) covers the rest of the set-up.
     const int prow = lane >> 3, pch = lane & 7;
     unsigned koff[PW], voff[PW];
 #pragma unroll
@@ -120,6 +111,16 @@ __global__ __launch_bounds__(NW * 64) CV_WAVES_PER_EU(WPE, WPE) void attn_flow32
     const int ntile = (kend + BKV - 1) / BKV;
     if (ntile > 0) issue_tile(0, 0);
     if (ntile > 1) issue_tile(BKV, 1);
+
+    const int qw0 = qb * BQ + wave * 32;
+    const int kend_w = kend_of(qw0, 32);                              // this wave (its MFMAs): wave-uniform
+    const int qi = qw0 + lq;
+    const bool qvalid = qi < p.T;
+    int klim = kend_w;                                                // rows past T compute finite garbage on zero queries, never stored
+    if (qvalid && p.mask_mode == MASK_CHUNK) klim = min(Tkb, (qi / p.chunk + 1) * p.chunk);
+    // smallest key limit of the wave = its first query's (limits grow with the query index; rows past T carry kend_w, the largest): tiles that end at or below it need
+    // no per-element mask.  Wave-uniform by construction - no cross-lane reduction.
+    const int klim_min_w = p.mask_mode == MASK_CHUNK ? min(Tkb, (qw0 / p.chunk + 1) * p.chunk) : kend_w;
 
     // Q^T as the B operand of S^T = K.Q^T: lane (q = lq, hi) supplies d = 16 dk + 8 hi .. + 7
     uint4 qf[4];

@@ -74,8 +74,9 @@ struct cv_llm {
         int nb = 0;
         DevBuf kcache, vcache, state, tokens, sparams, uniforms, h, qkv, act, logits, attn, dpart, apart;   // attn: merged attention [nb][heads*64]; dpart: split-K partials of down
         std::vector<DecodeState> host_state; std::vector<int> host_tokens; std::vector<SampleParams> host_sp;
-        hipGraphExec_t graph = nullptr; hipStream_t graph_stream = nullptr; int graph_nb = 0;      // graph: the step with the attention form of `attn_mode` ...
-        hipGraphExec_t graph_alt = nullptr; int attn_mode = 1;                                      // ... graph_alt: with the other form (both kept: a batch crosses the rule's threshold as its contexts grow)
+        hipGraphExec_t graphs[3] = {nullptr, nullptr, nullptr}; hipStream_t graph_stream = nullptr; int graph_nb = 0;      // one captured step per attention form (0 VALU, 1 MFMA, 2 MFMA
+        int attn_mode = 1;                                       // with the fixed key partition): all kept - a batch crosses the rule's threshold as its contexts grow, a handle serves pinned and unpinned paths
+        void drop_graphs() { for (auto& g : graphs) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; } }
     } bt;
     // Round 3: fragment-ordered copies of the matrices for the batched decode (skinny_pk_kernel, llm_batch_kernels.h), made on the device the first time
     // the batch path is used: [row tile][k tile][lane][8 bf16], so that one wave load is 1 KB contiguous.  Keyed by the row-major tensor's address.
@@ -85,10 +86,10 @@ struct cv_llm {
     std::map<const void*, std::shared_ptr<DevBuf>> packed;
     int batch_packed = [] { const char* e = getenv("CV_BATCH_PACKED"); return (e && e[0] == '0') ? 0 : 1; }();        // env: A/B knob for bench runs
     // Batched decode attention form: -1 = chosen per decode call from the slot count and the longest context (the default, the measured rule in batch_decode), 0 = the
-    // per-head VALU kernel, 1 = the fp32-MFMA kernel + merge.  The two forms sum the same products in a different order: with the automatic rule a request's logits
+    // per-head VALU kernel, 1 = the fp32-MFMA kernel + merge (slice count by the slot count), 2 = the fp32-MFMA kernel with ONE key partition for every slot count.  The two forms sum the same products in a different order: with the automatic rule a request's logits
     // depend - in the last fp32 bits - on how many slots shared its decode call and on its neighbours' context lengths.  A caller that needs a request's tokens to be
     // independent of the batch composition down to near-tie argmax decisions pins one form (option "batch_attn", read once here from CV_ATTN_BATCH).
-    int batch_attn = [] { const char* e = getenv("CV_ATTN_BATCH"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+    int batch_attn = [] { const char* e = getenv("CV_ATTN_BATCH"); return !e ? -1 : (e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1); }();
     const bf16_t* pk(const bf16_t* w) const { if (!batch_packed) return nullptr; auto it = packed.find(w); return it == packed.end() ? nullptr : it->second->as<bf16_t>(); }
     size_t slot_cache() const { return layer_cache() * cfg.layers; }
     // optional per-kernel HIP-event timing of one eager decode step (bench.py roofline)
@@ -96,8 +97,7 @@ struct cv_llm {
     size_t layer_cache() const { return (size_t)cfg.kv_heads * cfg.max_len * 64; }
     ~cv_llm() {
         if (graph) (void)hipGraphExecDestroy(graph);
-        if (bt.graph) (void)hipGraphExecDestroy(bt.graph);
-        if (bt.graph_alt) (void)hipGraphExecDestroy(bt.graph_alt);
+        bt.drop_graphs();
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (host_tokens) (void)hipHostFree(host_tokens);
         if (host_state) (void)hipHostFree(host_state);
@@ -528,8 +528,7 @@ static void batch_begin(cv_llm* m, int nb, hipStream_t s) {
     for (auto& st : b.host_state) { st.done = 1; st.stop_token = -1; }           // empty slots are "finished"
     CV_HIP(hipMemcpyAsync(b.state.p, b.host_state.data(), (size_t)nb * sizeof(DecodeState), hipMemcpyHostToDevice, s));
     CV_HIP(hipStreamSynchronize(s));
-    if (b.graph && b.graph_nb != nb) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
-    if (b.graph_alt && b.graph_nb != nb) { (void)hipGraphExecDestroy(b.graph_alt); b.graph_alt = nullptr; }
+    if (b.graph_nb != nb) b.drop_graphs();
     ensure_packed(m, s);
 }
 
@@ -671,12 +670,15 @@ static int down_ksplit(int inter) {
 static void launch_attn_batch(AttnDecodeBatchArgs ad, int heads, int nb, hipStream_t s, float* part, int mode) {
     ad.nb = nb;
     const int gsz = heads / ad.kv_heads;
-    if (mode == 1 && part && gsz >= 1 && gsz <= 16 && heads % ad.kv_heads == 0) {
+    if (mode >= 1 && part && gsz >= 1 && gsz <= 16 && heads % ad.kv_heads == 0) {
         const int pairs = nb * ad.kv_heads;
-        const int nw = [] { const char* e = getenv("CV_ATTN_BATCH_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
+        int nw = [] { const char* e = getenv("CV_ATTN_BATCH_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
         int S = [] { const char* e = getenv("CV_ATTN_BATCH_SLICES"); return e ? atoi(e) : 0; }();
         if (S <= 0) { S = 1; while (S < 8 && pairs * S * (nw / 4) < 256) S <<= 1; }
         S = std::min(std::max(S, 1), 8);
+        // mode 2 (option batch_attn = 2, "invariant"): ONE partition of a sequence's keys whatever the slot count - 8 slices of 4-wave workgroups - so that a sequence's
+        // logits are the same bits in a batch of 1 and of 32, in one chain and in a cut batch (the slice count otherwise follows the slot count: 8 up to 16 slots, 4 at 32)
+        if (mode == 2) { S = 8; nw = 4; }
         ad.part = part; ad.nslice = S;
         const dim3 grid((unsigned)(pairs * S));
         if (nw == 8) hipLaunchKernelGGL(attn_decode_batch_mfma_kernel<8>, grid, dim3(512), 0, s, ad);
@@ -800,23 +802,23 @@ static void batch_decode(cv_llm* m, int n_steps, int32_t* out_tokens, int32_t* n
         int longest = 0;
         for (int i = 0; i < nb; ++i) if (!b.host_state[i].done) longest = std::max(longest, b.host_state[i].pos);
         mode = (nb >= 24 || (nb >= 12 && longest >= 416) || longest >= 640) ? 1 : 0;
-        if (m->batch_attn >= 0) mode = m->batch_attn;                                 // pinned (option "batch_attn" / CV_ATTN_BATCH at handle creation)
+        if (m->batch_attn >= 0) mode = m->batch_attn;                                 // pinned (option "batch_attn" / CV_ATTN_BATCH at handle creation): 0, 1 or 2 (MFMA form, fixed slicing)
     }
     {
         std::lock_guard<std::recursive_mutex> lk(runtime_lock());
         if (m->use_graph) {
             if (b.graph_stream != s || b.graph_nb != nb) {
-                if (b.graph) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
-                if (b.graph_alt) { (void)hipGraphExecDestroy(b.graph_alt); b.graph_alt = nullptr; }
+                b.drop_graphs();
                 b.graph_stream = s; b.graph_nb = nb;
             }
-            if (mode != b.attn_mode) { std::swap(b.graph, b.graph_alt); b.attn_mode = mode; }      // the other form's graph, if it was captured before, is kept
-            if (!b.graph) {
+            b.attn_mode = mode;                                  // (read by batch_enqueue_step during the capture)
+            hipGraphExec_t& bgraph = b.graphs[mode];             // the other forms' graphs, if they were captured before, are kept
+            if (!bgraph) {
                 hipGraph_t g = capture_graph(s, [&] { batch_enqueue_step(m, s); });
-                CV_HIP(hipGraphInstantiate(&b.graph, g, nullptr, nullptr, 0));
+                CV_HIP(hipGraphInstantiate(&bgraph, g, nullptr, nullptr, 0));
                 CV_HIP(hipGraphDestroy(g));
             }
-            for (int i = 0; i < n_steps; ++i) CV_HIP(hipGraphLaunch(b.graph, s));
+            for (int i = 0; i < n_steps; ++i) CV_HIP(hipGraphLaunch(bgraph, s));
         } else {
             b.attn_mode = mode;
             for (int i = 0; i < n_steps; ++i) batch_enqueue_step(m, s);
@@ -877,13 +879,16 @@ int cv_llm_set_option(cv_llm* m, const char* name, int32_t value) {
             CV_CHECK(value == 4 || value == 8 || value == 16, "attn_splits must be 4, 8 or 16");
             m->attn_splits = value; if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
         }
-        else if (std::string(name) == "batch_attn") { CV_CHECK(value >= -1 && value <= 1, "batch_attn must be -1 (by slot count and context), 0 (VALU form) or 1 (MFMA form)"); m->batch_attn = value; }
+        else if (std::string(name) == "batch_attn") {
+            CV_CHECK(value >= -1 && value <= 2, "batch_attn must be -1 (by slot count and context), 0 (VALU form), 1 (MFMA form) or 2 (MFMA form, one key partition for every slot count)");
+            m->batch_attn = value;                               // (every form keeps its own captured step: no graph is dropped)
+        }
         else if (std::string(name) == "batch_packed") {      // batched decode on the fragment-ordered weight copies (skinny_pk_kernel) or on the row-major tensors (round 2)
-            m->batch_packed = value != 0; if (m->bt.graph) { (void)hipGraphExecDestroy(m->bt.graph); m->bt.graph = nullptr; } if (m->bt.graph_alt) { (void)hipGraphExecDestroy(m->bt.graph_alt); m->bt.graph_alt = nullptr; }
+            m->batch_packed = value != 0; m->bt.drop_graphs();
         }
         else if (std::string(name) == "batch_fp8") {         // batched decode on the fp8 copies of the weights (needs the .f8 / .f8s tensors)
             CV_CHECK(value == 0 || m->have_fp8, "batch_fp8: the fp8 tensors were not registered");
-            m->batch_fp8 = value != 0; if (m->bt.graph) { (void)hipGraphExecDestroy(m->bt.graph); m->bt.graph = nullptr; } if (m->bt.graph_alt) { (void)hipGraphExecDestroy(m->bt.graph_alt); m->bt.graph_alt = nullptr; }
+            m->batch_fp8 = value != 0; m->bt.drop_graphs();
         }
         else throw Error(std::string("unknown option ") + name);
     });

@@ -35,17 +35,43 @@ def register_tensors(lib, set_fn, handle, tensors):
 
 class _Cursor:
     """Admission cursor shared by the decode groups of one inference_queue call: hands out request indices in order, once.  `cancel()` (the consumer abandoned the
-    generator, or one chain failed) stops further admissions: the chains finish what they have in flight and end."""
+    generator, or one chain failed) stops further admissions: the chains finish what they have in flight and end.
+    `first` (round 6): chain k's FIRST first[k] admissions come from a block of its own - [0, first[0]) for chain 0, the next first[1] indices for chain 1, ... - and
+    only then from the shared remainder.  With the requests sorted by length bound (tts_queue's default order) every chain starts on one length bucket: its
+    sequences finish in the same decode chunks and share flow passes, instead of each chain holding a mix of all lengths."""
 
-    def __init__(self, n):
-        self.n, self.k, self.lock, self.cancelled = n, 0, threading.Lock(), False
+    def __init__(self, n, first=None):
+        self.n, self.lock, self.cancelled = n, threading.Lock(), False
+        self.blocks = []
+        at = 0
+        for f in (first or []):
+            self.blocks.append([at, min(n, at + f)])
+            at = min(n, at + f)
+        self.k = at                                             # the shared remainder starts behind the blocks
 
-    def take(self):
+    def take(self, chain=None):
         with self.lock:
-            if self.cancelled or self.k >= self.n:
+            if self.cancelled:
                 return None
-            self.k += 1
-            return self.k - 1
+            if chain is not None and chain < len(self.blocks) and self.blocks[chain][0] < self.blocks[chain][1]:
+                self.blocks[chain][0] += 1
+                return self.blocks[chain][0] - 1
+            if self.k < self.n:
+                self.k += 1
+                return self.k - 1
+            for b in self.blocks:                               # the remainder is empty: help out with what another chain has not started yet
+                if b[0] < b[1]:
+                    b[1] -= 1
+                    return b[1]
+            return None
+
+    def view(self, chain):
+        cur = self
+
+        class _View:
+            def take(self):
+                return cur.take(chain)
+        return _View()
 
     def cancel(self):
         with self.lock:
@@ -93,7 +119,7 @@ class Qwen2LM:
     'greedy' (the sampler north-star parity is defined on)."""
 
     def __init__(self, state_dict, cfg, lib=None, max_len=2048, sampling="ras", top_p=0.8, top_k=25, win_size=10, tau_r=0.1,
-                 seed=1986, decode_chunk=16, use_graph=True, attn_splits=8, batch_fp8=False, decode_groups=2, queue_groups=1, group_min_slots=24):
+                 seed=1986, decode_chunk=16, use_graph=True, attn_splits=8, batch_fp8=False, decode_groups=2, queue_groups=0, group_min_slots=24):
         """batch_fp8 (opt-in, BASELINE.json configs[4] "fp8 MFMA LLM path"): the BATCHED decode (inference_batch / _queue / serve_stream) runs on OCP
         e4m3 copies of the weight matrices (one fp32 scale per row) with the activations quantised per sequence in the kernel and
         v_mfma_f32_16x16x32_fp8_fp8 products; prefill and the single-sequence path keep the bf16 weights.  Token ids are then no longer the fp32
@@ -137,7 +163,18 @@ class Qwen2LM:
         self._opts = dict(use_graph=int(use_graph), attn_splits=int(attn_splits), batch_fp8=int(bool(batch_fp8)))
         self._cfg_c = c
         self.decode_groups = int(os.environ.get("CV_LLM_GROUPS", decode_groups if decode_groups is not None else 1))
-        self.queue_groups = int(os.environ.get("CV_LLM_QUEUE_GROUPS", queue_groups if queue_groups is not None else 1))
+        # Round 6: `queue_groups` = 0 (the default) lets the queue choose - chains of SIXTEEN slots (one MFMA column tile of the batched GEMMs: 17 .. 32 slots run the
+        # two-tile kernels at a higher cost per token), up to three of them: 32 slots -> 2 x 16, 48 and more -> 3 x 16 (mixed64 on the MI355X with the round-6 attention:
+        # 1 x 32 534, 2 x 16 539, 2 x 24 558, 2 x 32 572, 3 x 16 586, 3 x 20 540, 4 x 16 489 audio-s/s - profiles/r6_queue_groups.txt), each chain starting on one
+        # length bucket of the sorted request list (_Cursor).  A number pins the chain count (1 = one chain, the round-5 behaviour).
+        self.queue_groups = int(os.environ.get("CV_LLM_QUEUE_GROUPS", queue_groups if queue_groups is not None else 0))
+        # The queue path is the one whose results are compared ACROSS slot counts and rank counts (bench.py mixed64: one hash over the utterance hashes, "the same at any
+        # rank count"): it pins the decode attention to the form with ONE key partition per sequence (option batch_attn = 2), so that a request's logits are the same
+        # bits in a chain of 8 and of 16 slots, cut or uncut - 1 - 4 % of the step (batch 8 / 16 / 32: 254 -> 244, 424 -> 415, 537 -> 527 audio-s/s) for a determinism
+        # contract that holds by construction rather than by the margins of the day.  inference_batch / serve_stream keep the per-call rule.
+        self.queue_invariant = os.environ.get("CV_LLM_QUEUE_INVARIANT", "1") != "0"
+        self.batch_attn = {"0": 0, "1": 1, "2": 2}.get(os.environ.get("CV_ATTN_BATCH", ""), -1)       # what the handle's option "batch_attn" is outside a queue (-1: the per-call rule)
+        self.queue_buckets = os.environ.get("CV_LLM_QUEUE_BUCKETS", "1") != "0"       # decode groups of a queue start on one length bucket each (_Cursor `first`; A/B knob)
         self.group_min_slots = int(os.environ.get("CV_LLM_GROUP_MIN", group_min_slots))
         self._siblings, self._group_streams, self._sib_lock = [], [], threading.Lock()
         self.group_streams = None                            # streams for the second .. last chain (CosyVoice2Model.set_lanes hands over its lane streams)
@@ -443,19 +480,40 @@ class Qwen2LM:
         n = len(requests)
         if n == 0:
             return
-        handles, streams = self._groups(min(slots, n), self.queue_groups) if _cursor is None else ([self], [None])
+        if _cursor is None:
+            want = min(slots, n)
+            g = self.queue_groups if self.queue_groups > 0 else max(1, min(3, want // 16))
+            if self.queue_groups <= 0 and g > 1:
+                slots = 16 * g                                  # chains of exactly sixteen (see __init__)
+            handles, streams = self._groups(min(slots, n), g)
+            if self.queue_invariant and not self.batch_fp8:    # one key partition per sequence whatever the slot count (see __init__); every form keeps its own captured step
+                for h in handles:
+                    self.lib.cv_llm_set_option(h._h, b"batch_attn", C.c_int32(2))
+                try:
+                    yield from self._inference_queue(requests, slots, max_token_text_ratio, min_token_text_ratio, None, handles, streams)
+                finally:
+                    for h in handles:
+                        self.lib.cv_llm_set_option(h._h, b"batch_attn", C.c_int32(self.batch_attn))
+                return
+        else:
+            handles, streams = [self], [None]
+        yield from self._inference_queue(requests, slots, max_token_text_ratio, min_token_text_ratio, _cursor, handles, streams)
+
+    @torch.inference_mode()
+    def _inference_queue(self, requests, slots, max_token_text_ratio, min_token_text_ratio, _cursor, handles, streams):
+        n = len(requests)
         if len(handles) > 1:
             # decode groups: every chain runs this generator over ONE shared admission cursor (the requests keep their order of admission) with slots / groups slots
             import queue as _q
             g = len(handles)
-            cur, res, END = _Cursor(n), _q.Queue(), object()
+            cur, res, END = _Cursor(n, first=[(slots + g - 1 - k) // g for k in range(g)] if self.queue_buckets else None), _q.Queue(), object()
             base = self.reserve_keys(n)                         # overlapping queues on one handle must not be handed the same draw-stream keys
             reqs = [dict(r, seed_key=r.get("seed_key", base + 1 + i)) for i, r in enumerate(requests)]
 
             def work(h, k):
                 def fn():
                     try:
-                        for item in type(h).inference_queue(h, reqs, slots=(slots + g - 1 - k) // g, max_token_text_ratio=max_token_text_ratio, min_token_text_ratio=min_token_text_ratio, _cursor=cur):
+                        for item in type(h).inference_queue(h, reqs, slots=(slots + g - 1 - k) // g, max_token_text_ratio=max_token_text_ratio, min_token_text_ratio=min_token_text_ratio, _cursor=cur.view(k)):
                             res.put(item)
                     except BaseException:                       # noqa: BLE001 - a failed chain stops the admissions of the others: the error surfaces as soon as they drain
                         cur.cancel()

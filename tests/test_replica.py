@@ -156,7 +156,7 @@ def test_bench_rank_body_runs_at_world_size_2(emu_lib):
     assert sorted(i for sh in assign.values() for i in sh) == list(range(n_utt)) and all(len(sh) > 0 for sh in assign.values())
     assert [d["hip_visible_devices"] for d in two["rank_devices"]] == ["0", "1"] and [d["rank"] for d in two["rank_devices"]] == [0, 1]
     assert one["rank_devices"][0]["hip_visible_devices"] is None        # world size 1: nothing is pinned, the process keeps the launcher's view
-    assert "min(32, shard size)" in two["config"]["workload"]
+    assert "min(48, shard size)" in two["config"]["workload"]
     u10 = _bench_line(2, "u10", {"HIP_VISIBLE_DEVICES": "5,3"})           # a launcher that already restricts the node: rank i takes the i-th entry
     assert u10["n_gpus"] == 2 and u10["scaling"] == "weak" and [d["hip_visible_devices"] for d in u10["rank_devices"]] == ["5", "3"]
     assert u10["value"] > 0 and u10["self_check"]["n_tokens"] >= 1 and u10["config"]["parallelism"] == "replicas x2, no collective"

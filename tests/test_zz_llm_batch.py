@@ -234,3 +234,47 @@ def test_model_tts_batch(lib):
         out = dict(m.tts_queue(mixed, slots=2, order=order))
         assert admitted[-1] == want and sorted(out) == [0, 1, 2]
         assert all(out[i]["req"] is mixed[i] and out[i]["tokens"] == [int(mixed[i].get("max_token_text_ratio", 20))] * 3 for i in range(3))
+
+
+def test_queue_cursor_hands_every_chain_a_length_bucket_first():
+    """_Cursor(n, first=[...]) (round 6): chain k's first admissions come from a block of its own in the (length-sorted) request list, then from the shared remainder,
+    then from what another chain has not started - every index exactly once whatever the interleaving; cancel() stops admissions."""
+    from cosyvoice_amd.llm import _Cursor
+    cur = _Cursor(10, first=[3, 3])
+    a, b = cur.view(0), cur.view(1)
+    assert [a.take(), b.take(), a.take(), a.take(), b.take()] == [0, 3, 1, 2, 4]     # own blocks first: [0, 3) and [3, 6)
+    assert a.take() == 6 and b.take() == 5 and b.take() == 7                          # chain 0's block is spent: the remainder; chain 1 finishes its block, then the remainder
+    assert [a.take(), b.take(), a.take()] == [8, 9, None]
+    cur = _Cursor(5, first=[4, 4])                                                    # fewer requests than slots: the blocks are cut to what exists, an idle chain helps itself
+    a, b = cur.view(0), cur.view(1)
+    got = [b.take(), b.take(), a.take(), b.take(), a.take(), a.take(), b.take()]
+    assert sorted(x for x in got if x is not None) == [0, 1, 2, 3, 4] and got[0] == 4 and got.count(None) == 2
+    cur = _Cursor(6, first=[2, 2])
+    assert cur.view(1).take() == 2
+    cur.cancel()
+    assert cur.view(0).take() is None and cur.take() is None
+    plain = _Cursor(3)
+    assert [plain.take(), plain.take(), plain.take(), plain.take()] == [0, 1, 2, None]
+
+
+def test_queue_cuts_itself_into_chains_of_sixteen(lib):
+    """Round 6: inference_queue with queue_groups = 0 (the default) cuts `slots` >= 32 into chains of sixteen slots on sibling handles (2 at 32 .. 47, 3 from 48) with a
+    length bucket of the sorted request list per chain, and pins the decode attention to the form with one key partition per sequence (batch_attn = 2) for the
+    duration of the call; every request gets the tokens of the plain one-chain queue and of the oracle, the handle's own attention rule is back afterwards."""
+    cfg = W.tiny()[0]
+    sd = W.make_llm(cfg)
+    reqs = [_req(cfg, 900 + i, 2 + (i % 3), 2, 4 + 5 * (i % 4)) for i in range(35)]
+    reqs.sort(key=lambda r: -int(r["text"].shape[1]))                                # tts_queue's order: longest bound first
+    lm = Qwen2LM(sd, cfg, lib=lib, max_len=96, sampling="greedy", decode_chunk=4)
+    assert lm.queue_groups == 0 and lm.queue_invariant and lm.batch_attn == -1
+    got = dict(lm.inference_queue(reqs, slots=34, max_token_text_ratio=3, min_token_text_ratio=1))
+    assert len(lm._siblings) == 1                                                    # 34 slots asked for -> two chains of sixteen
+    one = Qwen2LM(sd, cfg, lib=lib, max_len=96, sampling="greedy", decode_chunk=4, queue_groups=1)
+    one.queue_invariant = False
+    want = dict(one.inference_queue(reqs, slots=8, max_token_text_ratio=3, min_token_text_ratio=1))
+    assert sorted(got) == list(range(35)) and got == want and not one._siblings
+    for i in (0, 17, 34):
+        r = reqs[i]
+        assert got[i] == OL.inference(sd, cfg, r["text"], r["prompt_text"], r["prompt_speech_token"], max_token_text_ratio=3, min_token_text_ratio=1)
+    small = dict(lm.inference_queue(reqs[:5], slots=4, max_token_text_ratio=3, min_token_text_ratio=1))       # below 32 slots: one chain (still the pinned attention form)
+    assert small == {i: want[i] for i in range(5)}
