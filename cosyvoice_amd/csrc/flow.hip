@@ -30,7 +30,7 @@ struct LN { const float* g = nullptr; const float* b = nullptr; };
 
 struct ConformerW { LN norm_mha, norm_ff; Lin qkv, pos, out, ff1, ff2; const float* bias_u; const float* bias_v; };
 struct ResnetW { Lin mlp, conv1, conv2, res; LN ln1, ln2; };
-struct TBlockW { LN norm1, norm3; Lin qkv, out, ff1, ff2; const u32x4_t* tail = nullptr; const float* tail_prm = nullptr; bool tail_qkv = false; const u32x4_t* band = nullptr; const u32x4_t* bandq = nullptr; };   // tail: fragment-ordered stream of flow_tail_kernel (+ the next block's QKV); band: the stream of flow_band_kernel (flow_band.h)
+struct TBlockW { LN norm1, norm3; Lin qkv, out, ff1, ff2; const u32x4_t* tail = nullptr; const float* tail_prm = nullptr; bool tail_qkv = false; const u32x4_t* band = nullptr; const u32x4_t* bandq = nullptr; const u32x4_t* lnqkv = nullptr; };   // lnqkv: the stream of flow_lnqkv_kernel (first block of a stage); tail: fragment-ordered stream of flow_tail_kernel (+ the next block's QKV); band: the stream of flow_band_kernel (flow_band.h)
 struct StageW { ResnetW res; std::vector<TBlockW> tf; };
 struct DitBlockW { Lin mod, qkv, out, ff1, ff2; };       // DiTBlock (flow/DiT/modules.py:500-530)
 
@@ -96,6 +96,7 @@ struct cv_flow {
                                        // (profiles/r3_flow_tail_ab.txt): 46.3 vs 38.5 ms per flow.inference at batch 1 - a workgroup pulls its 2 MB of weights through one CU's
                                        // L1 at ~45 B/clk (~32 KB in flight, ~700 cycles), 33-40 us per launch whatever the band count, against 37 us for the four launches it
                                        // replaces.  Off by default; bit-identical to the five-launch form, tested both ways.
+    int ln_qkv = 1;                    // with band_qkv: the FIRST block of a stage gets its LayerNorm + QKV GEMM from one band launch too (flow_lnqkv_kernel, round 6; option "ln_qkv", env CV_FLOW_LN_QKV)
     int band_qkv = 1;                  // with fused_band: the band launch also runs the NEXT block's QKV GEMM (flow_band_kernel<.., HAS_QKV>): a block of a large pass is two launches
                                        // (attention, band); bit-identical; option "band_qkv", env CV_FLOW_BAND_QKV
     int band_pipe = 2;                 // option "band_pipe" (env CV_FLOW_BAND_PIPE): the FF1 -> GELU -> FF2 chunks of a band as a software pipeline (flow_band_kernel<.., PIPE>): 0 = never,
@@ -241,6 +242,8 @@ static void flow_finalize(cv_flow* m) {
                 if (m->tm.has(q + "band")) {                       // the 64-row band form of large passes (flow_band.h): out-projection + FF1 + FF2 fragments, 8 waves at C = 256, 4 at C = 64
                     const long long bfr = (long long)(C / 16) * (inner / 32) + 2LL * (C / 16) * (4 * C / 32);
                     t.band = reinterpret_cast<const u32x4_t*>(m->tm.get(q + "band", CV_BF16, bfr * 64 * 8).p);
+                    if (m->tm.has(q + "lnqkv"))                    // LayerNorm + QKV of THIS block as one band launch (flow_lnqkv_kernel: the first block of a stage)
+                        t.lnqkv = reinterpret_cast<const u32x4_t*>(m->tm.get(q + "lnqkv", CV_BF16, 3LL * (inner / 16) * (C / 32) * 64 * 8).p);
                     if (t.tail_qkv && m->tm.has(q + "bandq"))      // the same stream + the NEXT block's QKV GEMM (flow_band_kernel<.., HAS_QKV>)
                         t.bandq = reinterpret_cast<const u32x4_t*>(m->tm.get(q + "bandq", CV_BF16, (bfr + 3LL * (inner / 16) * (C / 32)) * 64 * 8).p);
                 }
@@ -266,6 +269,7 @@ static void flow_finalize(cv_flow* m) {
         if (const char* e = getenv("CV_FLOW_TAIL")) m->fused_tail = e[0] != '0';
     }
     if (const char* e = getenv("CV_FLOW_BAND_QKV")) m->band_qkv = e[0] != '0';
+    if (const char* e = getenv("CV_FLOW_LN_QKV")) m->ln_qkv = e[0] != '0';
     if (const char* e = getenv("CV_FLOW_BAND_BM")) m->band_bm = atoi(e);
     if (const char* e = getenv("CV_FLOW_BAND_PIPE")) m->band_pipe = atoi(e);
     if (const char* e = getenv("CV_FLOW_BAND")) m->fused_band = e[0] != '0';        // dev knob for A/B runs (also: option "fused_band")
@@ -604,6 +608,25 @@ static void flow_band(const cv_flow* m, const TBlockW& t, bool has_next, const B
     else throw Error("flow_band: no instantiation for these dimensions");
 }
 
+// LayerNorm(norm1) + QKV GEMM of a stage's first block in one launch per row band (flow_lnqkv_kernel; the band height of the pass, like flow_band)
+static void flow_lnqkv(const cv_flow* m, const TBlockW& t, const BandQkv& q, const float* x, int C, int inner, int M, hipStream_t s) {
+    FlowLnQkvArgs a{};
+    a.x = x; a.ldx = C; a.wstream = t.lnqkv; a.gamma = t.norm1.g; a.beta = t.norm1.b; a.eps = 1e-5f; a.M = M;
+    a.qk = q.qk; a.ld_qk = q.ld_qk; a.vt = q.vt; a.vt_batch = q.vt_batch; a.ldt = q.ldt; a.rows_per_batch = q.rows_per_batch > 0 ? q.rows_per_batch : M;
+    CV_CHECK(t.lnqkv && t.norm1.g && t.norm1.b, "flow_lnqkv: block was not packed for this call");
+    const int bm = m->band_bm ? m->band_bm : band_rows_for(m->rule_rows > M ? (int)m->rule_rows : M);
+    const dim3 g((unsigned)((M + bm - 1) / bm));
+    if (C == 256 && inner == 512) {
+        if (bm == 64) hipLaunchKernelGGL((flow_lnqkv_kernel<256, 512, 8, 64>), g, dim3(512), 0, s, a);
+        else if (bm == 48) hipLaunchKernelGGL((flow_lnqkv_kernel<256, 512, 8, 48>), g, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((flow_lnqkv_kernel<256, 512, 8, 32>), g, dim3(512), 0, s, a);
+    } else if (C == 64 && inner == 64) {
+        if (bm == 64) hipLaunchKernelGGL((flow_lnqkv_kernel<64, 64, 4, 64>), g, dim3(256), 0, s, a);
+        else if (bm == 48) hipLaunchKernelGGL((flow_lnqkv_kernel<64, 64, 4, 48>), g, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((flow_lnqkv_kernel<64, 64, 4, 32>), g, dim3(256), 0, s, a);
+    } else throw Error("flow_lnqkv: no instantiation for these dimensions");
+}
+
 #ifdef CV_BUILD_EXPERIMENTS
 // everything after the attention of block `t` (+ LayerNorm and QKV of `next`) in one launch, 16 rows per workgroup (flow_tail.h)
 static void flow_tail(const TBlockW& t, const TBlockW* next, const bf16_t* att, int inner, float* x, int C, int M, bf16_t* qk, bf16_t* vt, long long vt_batch, int ldt,
@@ -712,9 +735,14 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
                 const bool big = m->big_rows > 0 && R >= m->big_rows, big_attn = m->attn2_rows > 0 && R >= m->attn2_rows;
                 if (big && m->fused_band && t.band) {     // flow_band.h: QKV GEMM, attention, then ONE launch per 64-row band up to the next block's LayerNorm; bit-identical to the forms below
                     bf16_t* xn = m->h_xn.as<bf16_t>() + r0 * C;
-                    if (ti == 0) ln_bf16(t.norm1, 1e-5f, x, (int)R, C, xn, s);         // later blocks: the previous block's band launch left LayerNorm(norm1) of its output in xn,
-                    const bool had_qkv = ti > 0 && m->band_qkv && st.tf[ti - 1].bandq;  // or (band_qkv) this block's Q | K and V^T themselves
-                    if (!had_qkv) gemm_big_bf16(t.qkv, xn, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
+                    const bool had_qkv = ti > 0 && m->band_qkv && st.tf[ti - 1].bandq;  // later blocks: the previous block's band launch left this block's Q | K and V^T (band_qkv), or LayerNorm(norm1) of its output in xn
+                    if (ti == 0 && m->band_qkv && m->ln_qkv && t.lnqkv) {                // first block of a stage: LayerNorm + QKV GEMM in ONE launch per row band (round 6; the bits of the two launches below)
+                        const BandQkv bq0{qk, 2 * inner, vt, vt_batch, m->vt_pitch, T};
+                        flow_lnqkv(m, t, bq0, x, C, inner, (int)R, s);
+                    } else {
+                        if (ti == 0) ln_bf16(t.norm1, 1e-5f, x, (int)R, C, xn, s);
+                        if (!had_qkv) gemm_big_bf16(t.qkv, xn, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
+                    }
                     attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, klen, big_attn);
                     const bool has_next = ti + 1 < st.tf.size();
                     const BandQkv bq{qk, 2 * inner, vt, vt_batch, m->vt_pitch, T};
@@ -1015,6 +1043,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "graph_cap") { CV_CHECK(value >= 1 && value <= 256, "graph_cap must be 1 .. 256"); drop_graphs(m); m->graph_cap = (size_t)value; }
         else if (std::string(name) == "fused_tail") { need_experiments(value != 0, "flow option fused_tail"); m->fused_tail = value != 0; drop_graphs(m); }
         else if (std::string(name) == "band_qkv") { m->band_qkv = value != 0; drop_graphs(m); }
+        else if (std::string(name) == "ln_qkv") { m->ln_qkv = value != 0; drop_graphs(m); }
         else if (std::string(name) == "band_pipe") { CV_CHECK(value >= 0 && value <= 2, "band_pipe must be 0, 1 or 2"); m->band_pipe = value; drop_graphs(m); }
         else if (std::string(name) == "band_bm") { CV_CHECK(value == 0 || value == 32 || value == 48 || value == 64, "band_bm must be 0, 32, 48 or 64"); m->band_bm = value; drop_graphs(m); }
         else if (std::string(name) == "fused_band") { m->fused_band = value != 0; drop_graphs(m); }      // bf16 mode, large passes: one 64-row band launch between attention and the next QKV GEMM (flow_band.h) on / off

@@ -443,4 +443,125 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
     stamp();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// flow_lnqkv_kernel (round 6): LayerNorm(norm1) + the QKV GEMM of a stage's FIRST transformer block as one launch per row band.  Inside a stage the band launch of
+// block j runs block j + 1's QKV (HAS_QKV above); the first block of a stage follows the stage's resnet and had ln_bf16_kernel + flow_gemm_big_kernel<.., 0> to itself
+// (5.3 + 31.7 us at 8 utterances of U10 against 16 - 18 us for the same GEMM as a band phase: the LayerNorm rows stay in LDS, the weights arrive fragment-ordered).
+// The arithmetic is the band's phase F - the same LayerNorm expressions on the same rows, the same MFMA operands in the same k order, the same stores - so the bits are
+// those of the two launches it replaces.  Stream: weights.py::pack_flow_band_qkv (the QKV part of a `bandq` stream on its own).
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct FlowLnQkvArgs {
+    const float* x; int ldx;                  // residual stream [M][C] fp32 (read only)
+    const u32x4_t* wstream;                   // [NW waves][NQ passes x TA tiles x KC k-steps][64 lanes]
+    const float* gamma; const float* beta; float eps; int M;
+    bf16_t* qk; int ld_qk;                    // Q | K [M][2 INNER] bf16
+    bf16_t* vt; long long vt_batch; int ldt; int rows_per_batch;      // V^T [B][INNER][ldt] bf16, key-permuted (vt_col)
+};
+
+template <int C, int INNER, int NW, int BM>
+__global__ __launch_bounds__(NW * 64) void flow_lnqkv_kernel(FlowLnQkvArgs p) {
+    using S = FlowBandShape<C, INNER, 4 * C, NW>;
+    constexpr int NT = NW * 64, TA = S::TA, RT = BM / 16, PA1 = C / 2 + LDS_PAD, NJ = C / 64, FCD = TA * S::KC;
+    static_assert(BM == 64 || BM == 48 || BM == 32, "flow_lnqkv: 64-, 48- or 32-row bands");
+    __shared__ __attribute__((aligned(16))) unsigned A1[BM * PA1];
+    const int tid = threadIdx.x, lane = tid & 63, lq = lane & 15, lg = lane >> 4, sub = tid & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * BM;
+    // the band's rows first (a 16-lane group owns a row: the register layout of band_layernorm / ln_bf16_kernel), then the first two passes of the weight stream
+    constexpr int RP = (BM + NT / 16 - 1) / (NT / 16);              // rows per 16-lane group
+    v4f xr[RP][NJ];
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+        const int row = i * (NT / 16) + (tid >> 4);
+        const float* src = p.x + (long long)min(m0 + min(row, BM - 1), p.M - 1) * p.ldx;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) xr[i][j] = *reinterpret_cast<const v4f*>(src + 4 * sub + 64 * j);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const u32x4_t* ws = p.wstream + (long long)wave * (S::NQ * FCD) * 64 + lane;
+    u32x4_t wb0[16], wb1[16];
+    band_wload<FCD>(wb0, ws, 0);
+    band_wload<FCD>(wb1, ws, FCD);
+    // ---- LayerNorm -> A1 (bf16): the expressions of band_layernorm, operation for operation
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+        const int row = i * (NT / 16) + (tid >> 4);
+        if (row >= BM) break;
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) sm += xr[i][j][0] + xr[i][j][1] + xr[i][j][2] + xr[i][j][3];
+        const float mean = group16_sum(sm) * (1.f / (float)C);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { const float a = xr[i][j][0] - mean, b = xr[i][j][1] - mean, c = xr[i][j][2] - mean, d = xr[i][j][3] - mean; q += a * a + b * b + c * c + d * d; }
+        const float rstd = rsqrtf(group16_sum(q) * (1.f / (float)C) + p.eps);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int k = 4 * sub + 64 * j;
+            const float4 g = *reinterpret_cast<const float4*>(p.gamma + k), b = *reinterpret_cast<const float4*>(p.beta + k);
+            const float4 y = make_float4((xr[i][j][0] - mean) * rstd * g.x + b.x, (xr[i][j][1] - mean) * rstd * g.y + b.y, (xr[i][j][2] - mean) * rstd * g.z + b.z, (xr[i][j][3] - mean) * rstd * g.w + b.w);
+            *reinterpret_cast<uint2*>(&A1[row * PA1 + k / 2]) = make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+        }
+    }
+    __syncthreads();
+    // ---- Q | K | V: NQ passes of C output columns over K = C (phase F of flow_band_kernel with the stream starting at the QKV fragments: pass c sits in wb[c % 2])
+    band_static_for<0, S::NQ>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        constexpr bool IS_V = c * C >= 2 * INNER;
+        constexpr bool IN_WB1 = c % 2 == 1;
+        v4f acc[RT][TA];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < TA; ++t) acc[rt][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+        if constexpr (IN_WB1) band_mma<TA, S::KC, 0, RT, IS_V>(wb1, A1, PA1, 0, lq, lg, acc); else band_mma<TA, S::KC, 0, RT, IS_V>(wb0, A1, PA1, 0, lq, lg, acc);
+        if constexpr (c + 2 < S::NQ) { if constexpr (IN_WB1) band_wload<FCD>(wb1, ws, (c + 2) * FCD); else band_wload<FCD>(wb0, ws, (c + 2) * FCD); }
+        if constexpr (!IS_V && TA == 2) {
+            const int n = c * C + 32 * wave + 8 * lg;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int m = m0 + 16 * rt + lq;
+                if (m < p.M) *reinterpret_cast<uint4*>(p.qk + (long long)m * p.ld_qk + n) =
+                    make_uint4(pack_bf16x2(acc[rt][0][0], acc[rt][0][1]), pack_bf16x2(acc[rt][0][2], acc[rt][0][3]), pack_bf16x2(acc[rt][1][0], acc[rt][1][1]), pack_bf16x2(acc[rt][1][2], acc[rt][1][3]));
+            }
+        } else if constexpr (!IS_V) {
+#pragma unroll
+            for (int t = 0; t < TA; ++t) {
+                const int n = c * C + 16 * (wave + NW * t) + 4 * lg;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int m = m0 + 16 * rt + lq;
+                    if (m < p.M) *reinterpret_cast<uint2*>(p.qk + (long long)m * p.ld_qk + n) = make_uint2(pack_bf16x2(acc[rt][t][0], acc[rt][t][1]), pack_bf16x2(acc[rt][t][2], acc[rt][t][3]));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < TA; ++t) {
+                const int n = c * C - 2 * INNER + 16 * (wave + NW * t) + lq;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int m = m0 + 16 * rt + 4 * lg;
+                    const unsigned lo = pack_bf16x2(acc[rt][t][0] + 0.f, acc[rt][t][1] + 0.f), hi = pack_bf16x2(acc[rt][t][2] + 0.f, acc[rt][t][3] + 0.f);      // "+ 0": flow_gemm_big_kernel adds its (absent) bias here
+                    if (m >= p.M) continue;
+                    const int b = m / p.rows_per_batch, tt = m - b * p.rows_per_batch;
+                    bf16_t* row = p.vt + (long long)b * p.vt_batch + (long long)n * p.ldt;
+                    if (m + 3 < p.M && tt + 3 < p.rows_per_batch && (tt & 3) == 0) { *reinterpret_cast<uint2*>(row + vt_col(tt)) = make_uint2(lo, hi); continue; }
+                    if (m + 3 < p.M && tt + 3 < p.rows_per_batch && (tt & 1) == 0) {
+                        *reinterpret_cast<unsigned*>(row + vt_col(tt)) = lo; *reinterpret_cast<unsigned*>(row + vt_col(tt + 2)) = hi; continue;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int mr = m + r;
+                        if (mr >= p.M) continue;
+                        const int br = mr / p.rows_per_batch, tr_ = mr - br * p.rows_per_batch;
+                        const unsigned u = r < 2 ? lo : hi;
+                        p.vt[(long long)br * p.vt_batch + (long long)n * p.ldt + vt_col(tr_)] = (bf16_t)((r & 1) ? (u >> 16) : (u & 0xffffu));
+                    }
+                }
+            }
+        }
+    });
+}
+
 }  // namespace cv

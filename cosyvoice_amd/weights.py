@@ -117,6 +117,32 @@ def pack_flow_tail(w_out, w_ff1, w_ff2, w_qkv_next=None, waves=4):
     return torch.stack(out, 0).contiguous()
 
 
+def _band_qkv_parts(w_qkv, C, waves):
+    """The QKV GEMM of a block as band passes (flow_band.h phase F / flow_lnqkv_kernel): per wave, the fragments of its tiles for every pass of C output rows, k-step
+    major.  With two tiles per wave the Q | K rows are paired so that a lane's 4 + 4 accumulator columns are adjacent in memory (see pack_flow_band)."""
+    tiles = C // 16
+    wq = w_qkv
+    if tiles == 2 * waves:
+        inner2 = 2 * (wq.shape[0] // 3)
+        idx = torch.arange(wq.shape[0])
+        i = torch.arange(16)
+        for c in range(inner2 // C):
+            for wv in range(waves):
+                for t in range(2):
+                    j = wv + waves * t
+                    idx[c * C + 16 * j:c * C + 16 * j + 16] = c * C + 32 * wv + 8 * (i >> 2) + 4 * t + (i & 3)
+        wq = wq[idx.to(wq.device)]
+    fq = _mfma_fragments(wq)
+    assert w_qkv.shape[0] % C == 0 and w_qkv.shape[1] == C
+    return [[fq[c * tiles:(c + 1) * tiles][w::waves].permute(1, 0, 2, 3).reshape(-1, 64, 8) for c in range(w_qkv.shape[0] // C)] for w in range(waves)]
+
+
+def pack_flow_band_qkv(w_qkv, waves):
+    """The weight stream of flow_lnqkv_kernel (csrc/flow_band.h, round 6): LayerNorm + QKV of a stage's FIRST transformer block as one launch per row band - the
+    QKV part of a `bandq` stream on its own.  w_qkv: [3 INNER][C] fused q | k | v rows.  Returns bf16 [waves][fragments per wave][64][8]."""
+    return torch.stack([torch.cat(parts, 0) for parts in _band_qkv_parts(w_qkv, w_qkv.shape[1], waves)], 0).contiguous()
+
+
 def pack_flow_band(w_out, w_ff1, w_ff2, waves, w_qkv_next=None):
     """The weight stream of flow_band_kernel (csrc/flow_band.h) for one transformer block: out-projection [C][INNER], FF1 [FF][C] and FF2 [C][FF] cut into MFMA
     fragments in the order each wave consumes them.  Wave w owns the 16-column tiles w, w + waves, ... of every C-wide output; a PASS is (its tiles) x (<= 8
@@ -126,22 +152,7 @@ def pack_flow_band(w_out, w_ff1, w_ff2, waves, w_qkv_next=None):
     C = w_out.shape[0]
     fo, f1, f2 = _mfma_fragments(w_out), _mfma_fragments(w_ff1), _mfma_fragments(w_ff2)
     ka, kc, nch, tiles = fo.shape[1], C // 32, w_ff1.shape[0] // C, C // 16
-    fq = None
-    if w_qkv_next is not None:
-        wq = w_qkv_next
-        if tiles == 2 * waves:
-            # Q | K passes with two tiles per wave: MFMA row 4 g + r of tile t (tile index wave + waves t of the pass) computes output column 32 wave + 8 g + 4 t + r, so
-            # that a lane's 4 + 4 accumulator columns are adjacent in memory (one 16-byte store per row tile, flow_band.h).  The V passes keep the plain order.
-            inner2 = 2 * (wq.shape[0] // 3)
-            idx = torch.arange(wq.shape[0])
-            i = torch.arange(16)
-            for c in range(inner2 // C):
-                for wv in range(waves):
-                    for t in range(2):
-                        j = wv + waves * t
-                        idx[c * C + 16 * j:c * C + 16 * j + 16] = c * C + 32 * wv + 8 * (i >> 2) + 4 * t + (i & 3)
-            wq = wq[idx.to(wq.device)]
-        fq = _mfma_fragments(wq)
+    qparts = _band_qkv_parts(w_qkv_next, C, waves) if w_qkv_next is not None else None
     out = []
     for w in range(waves):
         parts = []
@@ -151,10 +162,8 @@ def pack_flow_band(w_out, w_ff1, w_ff2, waves, w_qkv_next=None):
         for j in range(nch):
             parts.append(f1[j * tiles:(j + 1) * tiles][w::waves].permute(1, 0, 2, 3).reshape(-1, 64, 8))
             parts.append(f2[w::waves][:, j * kc:(j + 1) * kc].permute(1, 0, 2, 3).reshape(-1, 64, 8))
-        if fq is not None:
-            assert w_qkv_next.shape[0] % C == 0 and w_qkv_next.shape[1] == C
-            for c in range(w_qkv_next.shape[0] // C):
-                parts.append(fq[c * tiles:(c + 1) * tiles][w::waves].permute(1, 0, 2, 3).reshape(-1, 64, 8))
+        if qparts is not None:
+            parts.extend(qparts[w])
         out.append(torch.cat(parts, 0))
     return torch.stack(out, 0).contiguous()
 
@@ -237,6 +246,8 @@ def pack_flow(sd, cfg, device, dtype=torch.bfloat16, experiments=False):
                 # the 64-row band form for large passes (csrc/flow_band.h): 8 waves at the real width, 4 at the test width
                 out[q + "band"] = pack_flow_band(out[q + "out.w"].reshape(cfg.est_ch, inner), out[q + "ff1.w"].reshape(4 * cfg.est_ch, cfg.est_ch),
                                                  out[q + "ff2.w"].reshape(cfg.est_ch, 4 * cfg.est_ch), 8 if cfg.est_ch == 256 else 4)
+                if j == 0:                                          # LayerNorm + QKV of the stage's first block as one band launch (flow_lnqkv_kernel, round 6)
+                    out[q + "lnqkv"] = pack_flow_band_qkv(out[q + "qkv.w"].reshape(3 * inner, cfg.est_ch), 8 if cfg.est_ch == 256 else 4)
                 if nxt is not None:                                 # the same stream with the next block's QKV GEMM behind it (flow_band_kernel<.., HAS_QKV>)
                     out[q + "bandq"] = pack_flow_band(out[q + "out.w"].reshape(cfg.est_ch, inner), out[q + "ff1.w"].reshape(4 * cfg.est_ch, cfg.est_ch),
                                                       out[q + "ff2.w"].reshape(cfg.est_ch, 4 * cfg.est_ch), 8 if cfg.est_ch == 256 else 4, nxt)
