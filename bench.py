@@ -610,7 +610,7 @@ def roofline_llm(model, u, cfgs):
     # HBM traffic per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own run, x1024 B, x2 for
     # the gfx950 wide-read under-count — MI355X_MICROARCH.md §HBM); PMC cannot be collected from inside this process, hence the file.
     traffic, traffic_src = None, None
-    pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r5_pmc_gemv_fetch.json", "r4_pmc_gemv_fetch.json", "r3_pmc_gemv_fetch.json", "r2_pmc_gemv_fetch.json")) if os.path.exists(f)), None)
+    pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r6_pmc_gemv_fetch.json", "r5_pmc_gemv_fetch.json", "r4_pmc_gemv_fetch.json", "r3_pmc_gemv_fetch.json", "r2_pmc_gemv_fetch.json")) if os.path.exists(f)), None)
     if pmc is not None:
         import hashlib
         raw = open(pmc, "rb").read()
@@ -624,7 +624,7 @@ def roofline_llm(model, u, cfgs):
                            % (os.path.relpath(pmc, ROOT), hashlib.sha1(raw).hexdigest()[:16]))
     # the same bytes over the rocprofv3 kernel-trace average of the committed summary (includes ~0.4 us of dispatch per graph-replayed kernel): the pessimistic clock
     frac_kt, kt_src = None, None
-    kt = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r5_rocprof_bench_kernel_stats.csv", "r4_rocprof_bench_kernel_stats.csv")) if os.path.exists(f)), None)
+    kt = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r6_rocprof_bench_kernel_stats.csv", "r5_rocprof_bench_kernel_stats.csv", "r4_rocprof_bench_kernel_stats.csv")) if os.path.exists(f)), None)
     if kt is not None:
         import csv
         for row in csv.DictReader(open(kt)):
@@ -663,7 +663,7 @@ def roofline_mfma(model, cfgs, n_utt=8):
     # and the stand-alone QKV GEMM only opens a stage (1 block in 4); it stays in the record as a launch of its own
     band_qkv = os.environ.get("CV_FLOW_BAND_QKV", "1") != "0"
     flops = {"flow_gemm_big_kernel<64,64,0> QKV (bf16 out, V^T transposed)%s" % (" - first block of a stage only" if band_qkv else ""): 2.0 * M * C_ * 3 * inner,
-             "attn_flow_kernel flash attention (QK^T + PV over all keys)": 4.0 * nz * H * T * T * 64,
+             "attn_flow32_kernel flash attention (QK^T + PV over all keys; round 6: 32 queries per wave on 32x32x16 tiles, LDS-DMA ring)": 4.0 * nz * H * T * T * 64,
              ("flow_band_kernel out-projection + LayerNorm + FF1 + GELU + FF2 + next LayerNorm + next QKV GEMM, one launch per row band (48 rows at this size)" if band_qkv else
               "flow_band_kernel out-projection + LayerNorm + FF1 + GELU + FF2 (+ next LayerNorm), one launch per row band (48 rows at this size)"): 2.0 * M * (C_ * inner + 2 * C_ * FF + (C_ * 3 * inner if band_qkv else 0))}
     per = {}
@@ -677,7 +677,7 @@ def roofline_mfma(model, cfgs, n_utt=8):
     else:
         block_fl, block_us = sum(flops.values()), sum(float(t) for t in us)
     busy, busy_src = None, None
-    pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r5_pmc_flow_batch8.json", "r4_pmc_flow_batch8_end.json")) if os.path.exists(f)), None)
+    pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r6_pmc_flow_batch8.json", "r5_pmc_flow_batch8.json", "r4_pmc_flow_batch8_end.json")) if os.path.exists(f)), None)
     if pmc is not None:
         raw = open(pmc, "rb").read()
         d = json.loads(raw)
@@ -899,7 +899,9 @@ def pin_rank_to_its_gpu(local_rank, world):
     if world <= 1:
         return None
     assert not torch.cuda.is_initialized(), "bench.py: the rank's GPU must be pinned before the first CUDA / HIP call"
-    listed = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    # (CV_BENCH_RANK_DEVICES: an explicit list for this purpose - tools/gpu_two_ranks.sh runs two ranks on the one GPU of a test box with "0,0", which the launcher's own
+    # parsing of HIP_VISIBLE_DEVICES would refuse)
+    listed = os.environ.get("CV_BENCH_RANK_DEVICES") or os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
     ids = [v.strip() for v in listed.split(",") if v.strip()] if listed else [str(i) for i in range(world)]
     if local_rank >= len(ids):
         raise SystemExit("bench.py: local rank %d has no GPU in the visible device list %r" % (local_rank, ids))
@@ -1046,6 +1048,8 @@ def main():
         reqs, costs = mixed_requests(cfgs, model.device)
         mine = shard_requests(costs, world)[rank]
         mixed = {"hashes": {}}
+        if not DRY:
+            model.set_lanes(args.lanes)                          # the throughput pipeline's token2wav lanes (what the mixed64 extra of the default line runs with: --lanes, default 2)
 
         def step():
             mixed["hashes"] = run_mixed(model, reqs, mine, slots=max(1, min(2 if DRY else 48, len(mine))))      # 8 in flight per GPU at 8 GPUs, 48 (three chains of 16) when one GPU takes all 64
@@ -1118,6 +1122,7 @@ def main():
             out["config"]["assignment"] = {str(r): sh for r, sh in enumerate(shard_requests(costs, world))}
             out["config"]["utterances_per_gpu_per_step"] = len(mine)
             out["config"]["sampler"] = "greedy, length forced per utterance"
+            out["config"]["lanes"] = None if DRY else args.lanes
             # identical at every rank count / batch slot when the determinism contract of SURVEY.md section 8e holds
             out["utterance_hashes_sha1"] = hashlib.sha1("".join(all_hashes[i] for i in range(len(costs))).encode()).hexdigest()
         out["self_check"] = self_check(model, u)                 # U10 through the same model object, whatever the workload

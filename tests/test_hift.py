@@ -95,3 +95,28 @@ def test_snake_once_and_two_sided_split_variants(lib, tiny, monkeypatch):
     assert not torch.equal(base, chain)                                # the split path really ran
     e_split, e_chain = (base - ref).abs().max().item(), (chain - ref).abs().max().item()
     assert e_split < 2e-4 and e_chain < 2e-4 and (base - chain).abs().max().item() < 2e-5, (e_split, e_chain)
+
+
+def test_three_plane_products_option(lib, tiny):
+    """cv_hift_set_option "terms" = 3 (round 6, off by default): the decoder's convolutions keep three of the six plane products of the two-sided bf16 split
+    (x1 w1 + x1 w2 + x2 w1: 16 mantissa bits per factor, gemm_conv.h w3_terms).  Stated tolerance: the waveform stays within 1e-4 rel-L2 / 70 dB of the six-term
+    (fp32-exact class) one on the same source (measured at full size on the MI355X: 1.5e-5 / 96 dB, profiles/r6_hift.txt); the f0 predictor - whose output is
+    integrated into a phase over the whole utterance - is NOT affected: bit-identical f0 and source; 6 restores the default bits."""
+    import ctypes as C
+    cfg, sd = tiny
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, "hift_tiny.npz")).items()}
+    hift = HiFTGenerator(sd, cfg, lib=lib)
+    six, src6 = hift.inference(g["mel"], noise=g["noise"])
+    six, src6 = six.cpu().clone(), src6.cpu().clone()
+    lib.cv_hift_set_option(hift._h, b"terms", C.c_int32(3))
+    three, src3 = hift.inference(g["mel"], noise=g["noise"])
+    three, src3 = three.cpu().clone(), src3.cpu().clone()
+    assert torch.equal(src3, src6)                                   # f0 predictor and source: exact either way
+    err = (three.double() - six.double())
+    rel = float(err.norm() / six.double().norm())
+    assert 0.0 < rel < 1e-4 and 20 * np.log10(1.0 / rel) > 70.0, rel # really another arithmetic, and inside the stated tolerance
+    lib.cv_hift_set_option(hift._h, b"terms", C.c_int32(6))
+    again, _ = hift.inference(g["mel"], noise=g["noise"])
+    assert torch.equal(again.cpu(), six)
+    with pytest.raises(Exception):
+        lib.cv_hift_set_option(hift._h, b"terms", C.c_int32(4))

@@ -34,7 +34,7 @@ for plan in "$@"; do
                python tools/pmc_summary.py $O/pmc_gemv_fetch.json $O/pmc_llm -- gemv | head -12; rm -rf $O/pmc_llm ;;
     pmcflow)   ( cd /tmp && export TMPDIR=/tmp && timeout -k 5 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$O/pmc_fb8_sq -- python $R/tools/profile_flow_batch.py 8 > $R/$O/pmc_fb8_sq.log 2>&1; echo "== pmc flow batch 8 sq rc=$?" )
                ( cd /tmp && export TMPDIR=/tmp && timeout -k 5 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_fb8_fetch -- python $R/tools/profile_flow_batch.py 8 > $R/$O/pmc_fb8_fetch.log 2>&1; echo "== pmc flow batch 8 fetch rc=$?" )
-               python tools/pmc_summary.py $O/pmc_flow_batch8.json $O/pmc_fb8_sq $O/pmc_fb8_fetch -- flow_gemm flow_band attn_flow ln_bf16 gemm_conv norm_rows | head -40; rm -rf $O/pmc_fb8_sq $O/pmc_fb8_fetch ;;
+               python tools/pmc_summary.py $O/pmc_flow_batch8.json $O/pmc_fb8_sq $O/pmc_fb8_fetch -- flow_gemm flow_band flow_lnqkv attn_flow ln_bf16 gemm_conv norm_rows | head -40; rm -rf $O/pmc_fb8_sq $O/pmc_fb8_fetch ;;
     bin:*)     IFS=: read -r _ exe <<< "$plan"; run bin_$(basename $exe) 600 $exe; cat $O/bin_$(basename $exe).log ;;
     profpy:*)  IFS=: read -r _ script pargs envs <<< "$plan"; envs=${envs#:}; ( for kv in $(echo "${envs:-}" | tr ',' ' '); do export "$kv"; done; prof $(basename $script .py)_$(echo "${pargs:-}_${envs:-}" | tr -c 'A-Za-z0-9_\n' '_') python $R/tools/$script ${pargs:-} ) ;;
     py:*)      IFS=: read -r _ script pargs envs <<< "$plan"; envs=${envs#:}; ( for kv in $(echo "${envs:-}" | tr ',' ' '); do export "$kv"; done; run py_$(basename $script .py)_$(echo "${pargs:-}_${envs:-}" | tr -c 'A-Za-z0-9_\n' '_') 900 python tools/$script ${pargs:-} ) ;;
