@@ -381,8 +381,8 @@ def cv1_workload(args):
     # keeps the reference-shaped loop (host sampler, one round trip per token) for A/B
     host_loop = os.environ.get("CV_BENCH_CV1_HOST_LOOP", "0") == "1"
     lm = CK.TransformerLM(sd_llm, text_heads=cfg.text_heads, llm_heads=cfg.llm_heads, sampling=greedy if host_loop else "greedy")
-    m = CK.CosyVoiceModel(lm, CK.MaskedDiffWithXvec(sd_flow, enc_heads=cfg.flow_heads, est_heads=cfg.est_heads, input_frame_rate=cfg.input_frame_rate),
-                          CK.HiFTGenerator(sd_hift, hcfg))
+    hift = CK.HiFTGenerator(sd_hift, hcfg)
+    m = CK.CosyVoiceModel(lm, CK.MaskedDiffWithXvec(sd_flow, enc_heads=cfg.flow_heads, est_heads=cfg.est_heads, input_frame_rate=cfg.input_frame_rate), hift)
     g = torch.Generator().manual_seed(300)
     n_text, n_gen = 25, int(os.environ.get("CV_BENCH_CV1_TOKENS", 500))       # (the variable: dry runs of this function under the emulator, tests/test_bench_host.py)
     text = torch.randint(0, cfg.text_vocab, (1, n_text), generator=g, dtype=torch.int32)
@@ -421,6 +421,48 @@ def cv1_workload(args):
     torch.cuda.synchronize(); stages["flow_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
     t0 = time.perf_counter(); m.hift.inference(speech_feat=mel); torch.cuda.synchronize(); stages["hift_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
     stages["llm_us_per_token"] = round(1e3 * stages["llm_ms"] / n_gen, 1)
+    # the model's fp16 mode (the reference: CosyVoice(model_dir, fp16=True) - LM and flow halved, cli/model.py:60-63): LM matrices as bf16 (W16A32, cv_lm1_use_bf16), the
+    # U-Net estimator in bf16 mode (csrc/flow.hip cfg.estimator == 2 on the fused transformer-block kernels); vocoder fp32.  Token check: the torch-eager port over the
+    # bf16-ROUNDED state dict; mel against the fp32 mode's on the same tokens and noise.
+    fp16 = None
+    if os.environ.get("CV_BENCH_CV1_FP16", "1") == "1":
+        lm16 = CK.TransformerLM(sd_llm, text_heads=cfg.text_heads, llm_heads=cfg.llm_heads, sampling=greedy if host_loop else "greedy", weight_dtype=torch.bfloat16)
+        flow16 = CK.MaskedDiffWithXvec(sd_flow, enc_heads=cfg.flow_heads, est_heads=cfg.est_heads, input_frame_rate=cfg.input_frame_rate, precision="bf16")
+        m16 = CK.CosyVoiceModel(lm16, flow16, hift)
+        inf16, seen16 = lm16.inference, {}
+
+        def spy16(**kw):
+            seen16["tokens"] = []
+            for tok in inf16(**dict(kw, max_token_text_ratio=n_gen / n_text, min_token_text_ratio=n_gen / n_text)):
+                seen16["tokens"].append(int(tok))
+                yield tok
+        lm16.inference = spy16
+        one16 = lambda: next(iter(m16.tts(text=text, flow_embedding=emb, llm_embedding=emb, stream=False)))["tts_speech"]
+        w16 = one16()
+        assert w16.shape == wav.shape and bool(torch.isfinite(w16).all()) and len(seen16["tokens"]) == n_gen
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            one16()
+        torch.cuda.synchronize()
+        per16 = (time.perf_counter() - t0) / reps
+        st16 = {}
+        t0 = time.perf_counter(); list(spy16(**lm_kw)); torch.cuda.synchronize(); st16["llm_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
+        fkw = dict(token=tok, token_len=tl(n_gen), prompt_token=e0, prompt_token_len=tl(0), prompt_feat=torch.zeros(1, 0, 80), prompt_feat_len=tl(0), embedding=emb,
+                   flow_cache=torch.zeros(1, 80, 0, 2))
+        torch.manual_seed(11); mel32, _ = m.flow.inference(**fkw)
+        torch.manual_seed(11); t0 = time.perf_counter(); mel16, _ = flow16.inference(**fkw); torch.cuda.synchronize(); st16["flow_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
+        st16["llm_us_per_token"] = round(1e3 * st16["llm_ms"] / n_gen, 1)
+        n16 = min(int(os.environ.get("CV_BENCH_CV1_CHECK16", 250)), n_gen)
+        ref16 = C1.TransformerLM(lm16.sd, text_heads=cfg.text_heads, llm_heads=cfg.llm_heads, sampling=greedy)
+        want16 = list(ref16.inference(max_token_text_ratio=n16 / n_text, min_token_text_ratio=n16 / n_text, **lm_kw))
+        d16 = next((k for k, (a, b) in enumerate(zip(seen16["tokens"], want16)) if a != b), None)
+        fp16 = {"mode": "the reference's fp16=True for this model (cli/cosyvoice.py:27-56, cli/model.py:60-63): LM W16A32 (bf16 matrices, fp32 activations / cache / logits), "
+                        "flow estimator in bf16 mode on the fused transformer-block kernels, HiFT fp32",
+                "audio_s_per_s": round(audio_s / per16, 3), "ms_per_utterance": round(1e3 * per16, 2), "stages": st16,
+                "token_check": {"against": "torch-eager port over the bf16-rounded state dict, host cores", "checked": n16, "equal": d16 is None, "first_difference": d16,
+                                "tokens_equal_fp32_mode": seen16["tokens"] == tokens},
+                "flow_mel_vs_fp32_mode": {"rel_l2": float((mel16 - mel32).norm() / mel32.norm()), "max_abs": float((mel16 - mel32).abs().max())}}
     # token check against the torch-eager plumbing on the host cores (every id of the forced-length run: eos is masked in both)
     n_chk = min(int(os.environ.get("CV_BENCH_CV1_CHECK", n_gen)), n_gen)          # all 500 since round 4 (~30 s of host time outside the timed region)
     ref = C1.TransformerLM(sd_llm, text_heads=cfg.text_heads, llm_heads=cfg.llm_heads, sampling=greedy)
@@ -436,7 +478,8 @@ def cv1_workload(args):
             "host": "python sequencing over the operator-level C ABI (cosyvoice1_hip.py); the LM decode step is ONE call (cv_lm1_step, csrc/lm1.hip: %s)"
                     % ("%d launches per token, %d of the %d steps replayed as a hipGraph" % (lm.step.stat("launches_per_step"), lm.step_stat("graph_replays"), lm.step_stat("steps")) if lm.step is not None and lm.fused_step
                        else "off: launch-per-operator tape"), "audio_s_per_s": round(audio_s / per, 3),
-            "ms_per_utterance": round(1e3 * per, 2), "stages": stages,
+            "ms_per_utterance": round(1e3 * per, 2), "stages": stages, "fp16_mode": fp16,
+            "flow_estimator": "the U-Net inside one library handle (csrc/flow.hip cfg.estimator == 2, round 6); fp32 mode = the same products as the launch-per-operator form",
             "token_check": {"checked": n_chk, "equal_torch_eager_cpu": div is None, "first_difference": div,
                             # all ids against the REAL TransformerLM's (llm/llm.py:162-223 at these dimensions, tests/golden/fullsize_cv1_llm.npz); None: fixture absent or another length
                             "equal_real_reference_class": (lambda real: None if real is None or len(real) != len(tokens) else tokens == real)(real_class_tokens("fullsize_cv1_llm"))},

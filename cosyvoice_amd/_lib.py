@@ -49,6 +49,11 @@ class Lm1LayerWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_out", "b_out", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2")]
 
 
+class Lm1LayerBf16(C.Structure):
+    """cv_lm1_layer_bf16 (include/cosyvoice_amd.h)"""
+    _fields_ = [(n, C.c_void_p) for n in ("w_qkv", "w_out", "w1", "w2")]
+
+
 class Lm1Config(C.Structure):
     """cv_lm1_config (include/cosyvoice_amd.h)"""
     _fields_ = [("n_layers", C.c_int32), ("d", C.c_int32), ("heads", C.c_int32), ("ffn", C.c_int32), ("d_in", C.c_int32), ("n_out", C.c_int32),

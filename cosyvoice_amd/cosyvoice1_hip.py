@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from . import cosyvoice1 as C1
-from ._lib import ACT, CV_F32, MASK, AttnArgs, Lm1Config, Lm1LayerWeights, get_lib, stream_ptr
+from ._lib import ACT, CV_F32, MASK, AttnArgs, Lm1Config, Lm1LayerBf16, Lm1LayerWeights, get_lib, stream_ptr
 from .hift import HiFTGenerator as _KernelHiFT
 from .ops import gemm_conv, norm_rows, pack_weight
 from .weights import split3_planes
@@ -389,9 +389,10 @@ class EspnetEncoder(C1.EspnetEncoder):
         return y, state
 
     # ---- the decode step as ONE library call (csrc/lm1.hip: 3 + 5 launches per layer inside a hipGraph instead of 3 + 8 per layer replayed from here) -----------
-    def make_step(self, decoder):
+    def make_step(self, decoder, bf16=False):
         """cv_lm1 handle over this encoder's weights + the LM's decoder matrix (`decoder`: _Mat [n_out, d]).  None when the shapes are outside what the fused
-        step serves (it is an acceleration of forward_chunk + decoder, not another model): d > 1024, feed-forward > 4096."""
+        step serves (it is an acceleration of forward_chunk + decoder, not another model): d > 1024, feed-forward > 4096.  bf16: the step reads bf16 copies of its
+        matrices (cv_lm1_use_bf16: the model's fp16 mode; the copies are made once per encoder and shared by every handle)."""
         K, L0 = self.k, self.layers[0]
         if self.kind != "transformer" or self.d > 1024 or L0["w1"].n > 4096 or self.embed.k > 4096 or self.embed.k % 4 or K.split3:
             return None
@@ -417,6 +418,15 @@ class EspnetEncoder(C1.EspnetEncoder):
         if not h:                                               # refused by the library for a reason the gate above does not know: the operator-per-launch step serves the model
             return None
         step = _FusedStep(real, C.c_void_p(h), K.new(decoder.n), (c, lw, decoder))
+        if bf16:
+            if getattr(self, "_w16", None) is None:
+                half = lambda m: K.put(m.w, torch.bfloat16)
+                self._w16 = ([tuple(half(L[n]) for n in ("qkv", "out", "w1", "w2")) for L in self.layers], half(self.embed), half(decoder))
+            l16 = (Lm1LayerBf16 * self.n_layers)()
+            for i, ws in enumerate(self._w16[0]):
+                l16[i].w_qkv, l16[i].w_out, l16[i].w1, l16[i].w2 = (t.data_ptr() for t in ws)
+            real.cv_lm1_use_bf16(step.h, l16, C.c_void_p(self._w16[1].data_ptr()), C.c_void_p(self._w16[2].data_ptr()))
+            step.keep = step.keep + (l16, self._w16)
         return step
 
     def fused_step(self, step, xs, state):
@@ -486,12 +496,20 @@ class EspnetEncoder(C1.EspnetEncoder):
 class TransformerLM(C1.TransformerLM):
     """cosyvoice.llm.llm.TransformerLM.inference (llm/llm.py:162-223) on the kernels; sampling decisions on the host like the reference's python sampler."""
 
-    def __init__(self, sd, text_heads=16, llm_heads=16, sampling=C1.ras_sampling, lib=None, split3=False, seed=0, decode_chunk=64):
+    def __init__(self, sd, text_heads=16, llm_heads=16, sampling=C1.ras_sampling, lib=None, split3=False, seed=0, decode_chunk=64, weight_dtype=None):
         """sampling: a callable (scores, decoded, sampling) -> id - the reference's python sampler, run on the HOST once per token like the reference's loop (llm/llm.py:196-223:
         the parity hook; its draws come from torch's global RNG) - or one of the strings "greedy" / "ras": the DEVICE sampler of csrc/llm_kernels.h (arg-max, or
         repetition-aware sampling top_p 0.8 / top_k 25 / win 10 / tau_r 0.1 with the library's counter RNG keyed by `seed` + request count), which keeps the whole decode
         loop on the device (cv_lm1_decode: tokens come back every `decode_chunk` steps).  Same decisions as the python sampler on the same probabilities; the draw stream
-        is the device's own (as for Qwen2LM)."""
+        is the device's own (as for Qwen2LM).
+        weight_dtype = torch.bfloat16: the model's fp16 mode (the reference: `CosyVoice(model_dir, fp16=True)` -> cli/model.py:60-63 `self.llm.half()`), here W16A32 -
+        every matrix and embedding table (tensors of two or more dimensions) is ROUNDED to bf16; prefill multiplies the rounded values as fp32, the decode step streams
+        them as bf16 (cv_lm1_use_bf16: half the bytes per token).  Activations, biases, norms, cache, logits stay fp32: the tokens are those of the torch-eager port
+        (cosyvoice1.py) over `self.sd`, the rounded state dict."""
+        assert weight_dtype in (None, torch.float32, torch.bfloat16)
+        self.w16 = weight_dtype == torch.bfloat16
+        if self.w16:
+            sd = {k: (v.to(torch.bfloat16).float() if torch.is_floating_point(v) and v.dim() >= 2 else v) for k, v in sd.items()}
         self.k = K = Kernels(lib, split3)
         self.seed, self.decode_chunk, self._request, self._uniforms = int(seed), int(decode_chunk), 0, None
         self.sd = sd
@@ -507,7 +525,7 @@ class TransformerLM(C1.TransformerLM):
         self.decoder = K.mat(sd["llm_decoder.weight"], sd["llm_decoder.bias"])
         # the decode step behind one C entry point (cv_lm1_step); fused_step = False keeps the launch-per-operator tape (A/B and test knob)
         self._host_logits = None
-        self.step = self.llm.make_step(self.decoder)
+        self.step = self.llm.make_step(self.decoder, bf16=self.w16)
         self.fused_step = self.step is not None
         self.lock = threading.Lock()                             # one Kernels object (its recorder, its workspaces) per stage: requests on one stage object are serialised
         # The device-resident loop keeps its state (sampler state, sampled tokens, next input row, the bound KV rows) INSIDE a cv_lm1 handle, and the stage lock is
@@ -578,7 +596,7 @@ class TransformerLM(C1.TransformerLM):
             try:
                 with self.lock:
                     if step is None:
-                        step = self.llm.make_step(self.decoder)      # (make_step succeeded for self.step: same arguments)
+                        step = self.llm.make_step(self.decoder, bf16=self.w16)      # (make_step succeeded for self.step: same arguments)
                         for name, value in self._step_options.items():
                             step.lib.cv_lm1_set_option(step.h, name.encode(), C.c_int32(value))
                     self._request += 1
@@ -669,7 +687,8 @@ class ConditionalDecoder:
         """time_mlp(SinusoidalPosEmb(t)) for every Euler step at once, then every ResnetBlock1D's Linear(Mish(t_emb)): [n_steps, C] per block."""
         K, n = self.k, len(t_host)
         emb = K.new(n, self.in_channels)
-        K.lib.cv_time_sinusoid(_p(K.put(torch.tensor(t_host, dtype=F32))), _p(emb), C.c_int32(n), C.c_int32(self.in_channels), stream_ptr(K.lib))
+        tv = K.put(torch.tensor(t_host, dtype=F32))             # a NAMED tensor: `_p(K.put(..))` hands the launch the address of a temporary that is freed before the call (found in round 6)
+        K.lib.cv_time_sinusoid(_p(tv), _p(emb), C.c_int32(n), C.c_int32(self.in_channels), stream_ptr(K.lib))
         temb = K.linear(K.linear(emb, self.t1, n, act="silu"), self.t2, n, act="mish")       # t_emb only ever enters through Mish (matcha ResnetBlock1D.mlp)
         # one row per Euler step, the blocks' projections side by side: the estimator reads its step's row from a FIXED buffer (`tcur`, see __call__), so that the
         # launches of one step can be recorded and replayed for the others
@@ -730,12 +749,79 @@ class ConditionalDecoder:
         return K.linear(x, self.proj, 2 * T), T
 
 
+class EstimatorHandle:
+    """The same U-Net inside ONE library handle (csrc/flow.hip, cfg.estimator == 2: `unet1_forward`), round 6: the launches of an estimator evaluation are sequenced in C++
+    and the ten evaluations of a solve replay as one hipGraph, the transformer blocks run on the kernels of the CosyVoice2 estimator.  precision "fp32": fp32 weights,
+    every product at fp32 accuracy - the launch-per-operator class above, sequenced natively; "bf16": Linear / Conv1d operands rounded to bf16 where they are staged, the
+    fused transformer-block kernels of flow_fused.h / flow_big.h / flow_band.h and the bf16 flash attention (the analogue of the reference's `fp16=True` for this model:
+    cli/cosyvoice.py:27-56 loads the flow encoder as fp16 TorchScript and the estimator as an fp16 TensorRT engine)."""
+
+    def __init__(self, sd, prefix, heads, lib, precision="fp32", cfg_rate=0.7, _tensors=None):
+        from .flow import FlowConfigC
+        from .llm import register_tensors
+        from . import weights as Wt
+        assert precision in ("fp32", "bf16")
+        self.lib, self.precision, self.dev = lib, precision, torch.device(lib.device)
+        dtype = torch.bfloat16 if precision == "bf16" else F32
+        if _tensors is None:
+            packed, dims = Wt.pack_unet1(sd, prefix, heads, self.dev, dtype)
+            _tensors = ({k: lib.hook(v) for k, v in packed.items()}, dims)
+        self._packed = _tensors                                   # (device tensors, dims): what a second handle over the same weights takes
+        tensors, dims = _tensors
+        self.mel = 80
+        c = FlowConfigC(0, 0, 1, 0, 0, 0, 0, self.mel, dims["C"], heads, dims["n_blocks"], dims["n_mid"], 0, 0, cfg_rate, 2)
+        self._h = C.c_void_p()
+        lib.cv_flow_create(C.byref(self._h), C.byref(c))
+        register_tensors(lib, "cv_flow_set_tensor", self._h, tensors)
+        lib.cv_flow_finalize(self._h)
+        lib.cv_flow_set_option(self._h, b"bf16_mfma", C.c_int32(int(precision == "bf16")))
+        # one request at a time and launches of 5 us and more: the host stays ahead of the GPU, and replaying the ~6000-node graph of a solve costs more than issuing it
+        # (MI355X, T = 1011: 40.5 ms eager / 43.0 as a graph in bf16 mode, 80 / 85 in fp32 - profiles/r6_cv1_flow_handle.txt); option "use_graph" = 1 turns it on
+        lib.cv_flow_set_option(self._h, b"use_graph", C.c_int32(0))
+
+    def set_option(self, name, value):
+        self.lib.cv_flow_set_option(self._h, name.encode(), C.c_int32(int(value)))
+
+    def stat(self, name):
+        v = C.c_int64(0)
+        self.lib.cv_flow_get_stat(self._h, name.encode(), C.byref(v))
+        return v.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.raw("cv_flow_destroy", None)(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def forward(self, x, mask, mu, t, spks, cond):
+        """ConditionalDecoder.forward (flow/decoder.py:204-291) in the reference's layouts: x, mu, cond [2, 80, T], mask [2, 1, T] (all ones), t [2], spks [2, 80] -> [2, 80, T]."""
+        T = x.shape[2]
+        assert bool((mask == 1).all()), "batch-1 requests: the mask is all ones"
+        args = [self.lib.hook(a.to(self.dev, F32).contiguous()) for a in (x, mask, mu, t, spks, cond)]
+        out = self.lib.hook(torch.empty(2, self.mel, T, dtype=F32, device=self.dev))
+        self.lib.cv_flow_estimator(self._h, *[_p(a) for a in args], C.c_int32(T), C.c_int32(0), _p(out), stream_ptr(self.lib))
+        return out
+
+    def solve(self, x, mu, spk, cond, T, n_steps):
+        """x [T, 80] channel-last (in: z, out: the mel after n_steps Euler steps), mu / cond [T, 80], spk [1, 80]: ConditionalCFM.solve_euler (flow_matching.py:71-124)."""
+        self.lib.cv_flow_solve(self._h, _p(x), _p(mu), _p(spk), _p(cond), C.c_int32(T), C.c_int32(n_steps), stream_ptr(self.lib))
+        return x
+
+
 class MaskedDiffWithXvec(C1.MaskedDiffWithXvec):
-    def __init__(self, sd, enc_heads=8, est_heads=8, input_frame_rate=50, n_timesteps=10, inference_cfg_rate=0.7, lib=None, split3=False):
+    def __init__(self, sd, enc_heads=8, est_heads=8, input_frame_rate=50, n_timesteps=10, inference_cfg_rate=0.7, lib=None, split3=False, estimator="handle",
+                 precision="fp32"):
+        """estimator: "handle" = the U-Net inside one library handle, the Euler solve as one hipGraph (EstimatorHandle, round 6); "operators" = one launch per operator
+        from this file (ConditionalDecoder: the first form, kept as the A/B reference of the handle).  precision ("handle" only): "fp32" | "bf16", see EstimatorHandle."""
+        assert estimator in ("handle", "operators")
         self.k = K = Kernels(lib, split3)
         self.sd, self.input_frame_rate, self.n_timesteps, self.cfg_rate = sd, input_frame_rate, n_timesteps, inference_cfg_rate
         self.encoder = EspnetEncoder(sd, "encoder.", enc_heads, "conformer", kern=K)
-        self.estimator = ConditionalDecoder(sd, "decoder.estimator.", est_heads, K)
+        self.estimator = ConditionalDecoder(sd, "decoder.estimator.", est_heads, K) if estimator == "operators" else \
+            EstimatorHandle(sd, "decoder.estimator.", est_heads, K.lib, precision, inference_cfg_rate)
+        self.precision = precision if estimator == "handle" else "fp32"
         self.output_size = sd["encoder_proj.weight"].shape[0]
         self.input_emb = K.put(sd["input_embedding.weight"])
         self.spk_affine = K.mat(sd["spk_embed_affine_layer.weight"], sd["spk_embed_affine_layer.bias"])
@@ -813,6 +899,8 @@ class MaskedDiffWithXvec(C1.MaskedDiffWithXvec):
             t = t + dt
             if step < len(t_span) - 1:
                 dt = t_span[step + 1] - t
+        if isinstance(self.estimator, EstimatorHandle):          # the same schedule, recurrences and update on the device (csrc/flow.hip::solve_euler)
+            return self.estimator.solve(K.put(z[0].t()), mu, spk, cond, T, self.n_timesteps), new_cache
         tall, offs = self.estimator.prepare(ts)
         tcur = K.new(tall.shape[1])
         x = K.put(z[0].t())                                                                    # [T, 80]
@@ -883,9 +971,13 @@ class HiFTGenerator(_KernelHiFT):
 class CosyVoiceModel(C1.CosyVoiceModel):
     """cli.model.CosyVoiceModel (cli/model.py:27-242) over the kernel-backed stages: same `load`, `tts`, `token2wav`, per-uuid state."""
 
-    def load(self, llm_model, flow_model, hift_model, hift_cfg=None, lib=None, **kw):
+    def load(self, llm_model, flow_model, hift_model, hift_cfg=None, lib=None, fp16=False, **kw):
+        """fp16: the reference's switch for this model (cli/cosyvoice.py:27-56 `CosyVoice(model_dir, fp16=True)`: cli/model.py:60-63 halves the LM and the flow, the
+        estimator runs as an fp16 TensorRT engine).  Here: the LM's matrices as bf16 with fp32 activations (TransformerLM weight_dtype), the flow estimator in bf16 mode
+        (EstimatorHandle precision "bf16"); the vocoder stays fp32 like the reference's."""
         from .configs import cv1
         ld = lambda f: {k: v.float() for k, v in torch.load(f, map_location="cpu", weights_only=True).items()}
-        self.llm = TransformerLM(ld(llm_model), lib=lib, **{k: kw[k] for k in ("text_heads", "llm_heads") if k in kw})
-        self.flow = MaskedDiffWithXvec(ld(flow_model), lib=lib, **{k: kw[k] for k in ("enc_heads", "est_heads", "input_frame_rate") if k in kw})
+        self.fp16 = bool(fp16)
+        self.llm = TransformerLM(ld(llm_model), lib=lib, weight_dtype=torch.bfloat16 if fp16 else None, **{k: kw[k] for k in ("text_heads", "llm_heads") if k in kw})
+        self.flow = MaskedDiffWithXvec(ld(flow_model), lib=lib, precision="bf16" if fp16 else "fp32", **{k: kw[k] for k in ("enc_heads", "est_heads", "input_frame_rate") if k in kw})
         self.hift = HiFTGenerator({k.replace("generator.", ""): v for k, v in ld(hift_model).items()}, hift_cfg or cv1()[1], lib=lib, **kw.get("hift", {}))

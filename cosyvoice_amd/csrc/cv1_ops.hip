@@ -7,59 +7,9 @@
 #include "common.h"
 #include "flow_kernels.h"
 #include "hift_kernels.h"
+#include "group_norm.h"
 
 namespace cv {
-
-// ---- GroupNorm (torch.nn.GroupNorm(G, C) on [B, C, T]; here channel-last x [B][T][C]) ----------------------------------------------------
-// Pass 1: partial sums per (batch, group, time slice) in double (a group of the regulator is the whole [80 x T] utterance: fp32 running sums would
-// lose the digits torch's two-level Welford keeps).  part[((b * G + g) * S + s) * 2 + {0, 1}] = {sum, sum of squares}.
-static __global__ __launch_bounds__(256) void group_stats_kernel(const float* x, double* part, int T, int C, int G, int S) {
-    __shared__ double red[2][4];
-    const int s = blockIdx.x, g = blockIdx.y, b = blockIdx.z, cg = C / G;
-    const int t0 = (int)((long long)T * s / S), t1 = (int)((long long)T * (s + 1) / S);
-    const float* xb = x + ((long long)b * T) * C + (long long)g * cg;
-    const long long n = (long long)(t1 - t0) * cg;
-    double a = 0.0, q = 0.0;
-    for (long long i = threadIdx.x; i < n; i += 256) {
-        const int t = t0 + (int)(i / cg), c = (int)(i % cg);
-        const double v = (double)xb[(long long)t * C + c];
-        a += v; q += v * v;
-    }
-    // fixed-order reduction: lanes of a wave through shuffles, then the four waves through LDS
-    for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); q += __shfl_xor(q, off); }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) { red[0][w] = a; red[1][w] = q; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double* o = part + (((long long)b * G + g) * S + s) * 2;
-        o[0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-        o[1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
-    }
-}
-
-// Pass 2: y = act((x - mean_g) * rstd_g * gamma[c] + beta[c]) + col_add[b][c]
-//   (Block1D: Conv1d -> GroupNorm -> Mish, matcha decoder.py; the ResnetBlock1D's time projection `h += mlp(t_emb)[:, :, None]` rides along as col_add)
-static __global__ __launch_bounds__(256) void group_apply_kernel(const float* x, float* y, const double* part, int T, int C, int G, int S,
-                                                                  const float* gamma, const float* beta, float eps, int act,
-                                                                  const float* col_add, long long col_add_batch, long long total) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int c = (int)(i % C), cg = C / G, g = c / cg;
-    const int b = (int)(i / ((long long)T * C));
-    const double* p = part + ((long long)b * G + g) * S * 2;
-    double a = 0.0, q = 0.0;
-    for (int s = 0; s < S; ++s) { a += p[2 * s]; q += p[2 * s + 1]; }
-    const double n = (double)T * cg, mean = a / n;
-    double var = q / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    float v = (x[i] - (float)mean) * rstd;
-    if (gamma) v *= gamma[c];
-    if (beta) v += beta[c];
-    v = apply_act(act, v, 0.f);
-    if (col_add) v += col_add[(long long)b * col_add_batch + c];
-    y[i] = v;
-}
 
 // ---- SineGen (type 1) + SourceModuleHnNSF of the 22.05 kHz HiFTGenerator (hifigan/generator.py:125-186, 318-375) ------------------------
 // The reference integrates f0 * (h + 1) / sr over the SAMPLES (torch.cumsum, fp32) and takes the result mod 1.  f0 is constant over a frame
@@ -102,17 +52,6 @@ static __global__ __launch_bounds__(256) void sinegen1_source_kernel(const float
     s[t] = tanhf(acc + lb[0]);
 }
 
-// out[b][t][0:ca] = a[b][t], out[b][t][ca:ca+cb] = bb[b][t] for t < T; a / bb have their own per-batch pitches (rows per batch may exceed T:
-// the up-sampled stream of the U-Net is cut to the skip connection's length, flow/decoder.py:275)
-static __global__ __launch_bounds__(256) void concat_cols_batched_kernel(const float* a, int ca, long long a_batch, const float* bb, int cb, long long b_batch,
-                                                                          float* out, int T, int B) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int w = ca + cb;
-    if (i >= (long long)B * T * w) return;
-    const int c = (int)(i % w), t = (int)((i / w) % T), b = (int)(i / ((long long)w * T));
-    out[i] = c < ca ? a[(long long)b * a_batch + (long long)t * ca + c] : bb[(long long)b * b_batch + (long long)t * cb + (c - ca)];
-}
-
 // F.interpolate(x, size=Tn, mode='linear') over TIME for channel-last rows: y[t][c] (row pitch ldy), x [T][C]   (length_regulator.py:52-70)
 static __global__ __launch_bounds__(256) void interp_rows_kernel(const float* x, float* y, int C, int T, int Tn, int ldy) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -137,12 +76,7 @@ int cv_group_norm(const float* x, float* y, int32_t B, int32_t T, int32_t C, int
     return cv::guarded([&] {
         CV_CHECK(B > 0 && T > 0 && C > 0 && G > 0 && C % G == 0, "cv_group_norm: bad shape");
         CV_CHECK(workspace != nullptr, "cv_group_norm: workspace of B * G * 64 doubles");
-        hipStream_t s = cv::as_stream(stream);
-        int S = (int)(((long long)T * (C / G) + 8191) / 8192);            // ~8 K elements per workgroup of pass 1
-        S = S < 1 ? 1 : (S > 32 ? 32 : S);
-        hipLaunchKernelGGL(cv::group_stats_kernel, dim3(S, G, B), dim3(256), 0, s, x, workspace, T, C, G, S);
-        const long long total = (long long)B * T * C;
-        hipLaunchKernelGGL(cv::group_apply_kernel, dim3(cv::nblk256(total)), dim3(256), 0, s, x, y, workspace, T, C, G, S, gamma, beta, eps, act, col_add, (long long)col_add_batch, total);
+        cv::group_norm(x, y, B, T, C, G, gamma, beta, eps, act, col_add, (long long)col_add_batch, workspace, cv::as_stream(stream));
     });
 }
 

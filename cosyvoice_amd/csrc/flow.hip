@@ -20,6 +20,7 @@
 #include "experiments/flow_tail.h"      // measured no-go (profiles/r3_flow_tail_ab.txt): built, and its option accepted, only with -DCV_BUILD_EXPERIMENTS
 #endif
 #include "flow_band.h"
+#include "group_norm.h"
 
 using namespace cv;
 
@@ -33,6 +34,10 @@ struct ResnetW { Lin mlp, conv1, conv2, res; LN ln1, ln2; };
 struct TBlockW { LN norm1, norm3; Lin qkv, out, ff1, ff2; const u32x4_t* tail = nullptr; const float* tail_prm = nullptr; bool tail_qkv = false; const u32x4_t* band = nullptr; const u32x4_t* bandq = nullptr; const u32x4_t* lnqkv = nullptr; };   // lnqkv: the stream of flow_lnqkv_kernel (first block of a stage); tail: fragment-ordered stream of flow_tail_kernel (+ the next block's QKV); band: the stream of flow_band_kernel (flow_band.h)
 struct StageW { ResnetW res; std::vector<TBlockW> tf; };
 struct DitBlockW { Lin mod, qkv, out, ff1, ff2; };       // DiTBlock (flow/DiT/modules.py:500-530)
+// cfg.estimator == 2, the U-Net of CosyVoice-300M (flow/decoder.py:88-291): what a stage is and what follows its transformer blocks.  kind 0 = down (its output is kept as a
+// skip connection), 1 = mid, 2 = up (its input is the stream cut to the skip's length ++ the skip); post 0 = nothing, 1 = Conv1d(k 3, pad 1), 2 = Downsample1D
+// (Conv1d k 3, stride 2, pad 1 as a Linear over rows of pitch 2 C: post_lin.K = 3 C), 3 = Upsample1D (ConvTranspose1d k 4, stride 2, pad 1 in polyphase form: N = 2 C, 2 taps)
+struct UStageW { int kind = 1, post = 0; Lin post_lin; };
 
 inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
@@ -65,6 +70,9 @@ struct cv_flow {
     Lin time1, time2, down_conv, up_conv, final_conv, final_proj;
     LN final_ln;
     std::vector<StageW> stages;
+    std::vector<UStageW> ust;                                                                 // cfg.estimator == 2: one per stage
+    DevBuf u_skip[4]; DevBuf u_gn;                                                       // ... its skip connections (one per down stage) and the GroupNorm partial sums
+    int solve_cap = 0;                                                                        // cv_flow_solve: frames the f_* staging buffers hold
     // workspaces
     DevBuf e_x, e_xe, e_n, e_qkv, e_qu, e_qv, e_pe, e_p, e_bd, e_att, e_ff, e_x2, e_ctx;    // encoder
     DevBuf s_in, s_a, s_b, s_c, s_n, s_qkv, s_att, s_ff, s_skip, s_cat, s_out;                    // estimator
@@ -173,12 +181,17 @@ static LN get_ln(const cv_flow* m, const std::string& name, int C) { LN n; n.g =
 static void flow_finalize(cv_flow* m) {
     const auto& c = m->cfg;
     CV_CHECK(c.mel == 80, "flow: mel must be 80 (solve_euler hard-codes it, flow_matching.py:95)");
-    CV_CHECK(c.estimator == 1 || (c.dim % 64 == 0 && c.dim / c.enc_heads == 64 && c.est_ch % 32 == 0), "flow: head_dim is fixed at 64");
-    CV_CHECK(m->tm.has("spk_affine.w"), "flow: missing tensor 'spk_affine.w'");
-    m->wbf16 = m->tm.t.at("spk_affine.w").dtype == CV_BF16;
+    CV_CHECK(c.estimator >= 0 && c.estimator <= 2, "flow: estimator must be 0 (causal U-Net), 1 (DiT) or 2 (the U-Net of CosyVoice-300M)");
+    const bool unet1 = c.estimator == 2;      // ConditionalDecoder alone: the rest of MaskedDiffWithXvec (another encoder family, length regulator, flow cache) stays with the caller
+    CV_CHECK(c.estimator == 1 || (unet1 ? c.est_ch % 32 == 0 : (c.dim % 64 == 0 && c.dim / c.enc_heads == 64 && c.est_ch % 32 == 0)), "flow: head_dim is fixed at 64");
+    const char* probe = unet1 ? "est.time1.w" : "spk_affine.w";
+    CV_CHECK(m->tm.has(probe), std::string("flow: missing tensor '") + probe + "'");
+    m->wbf16 = m->tm.t.at(probe).dtype == CV_BF16;
     const int d = c.dim, C = c.est_ch, inner = c.est_heads * 64, tdim = 4 * C, cin = 4 * c.mel;
-    m->input_embedding = m->tm.get("input_embedding", m->wbf16 ? CV_BF16 : CV_F32, (long long)c.vocab * d).p;
-    m->spk_affine = get_lin(m, "spk_affine", c.mel, c.spk_dim, 1, true);
+    if (!unet1) {
+        m->input_embedding = m->tm.get("input_embedding", m->wbf16 ? CV_BF16 : CV_F32, (long long)c.vocab * d).p;
+        m->spk_affine = get_lin(m, "spk_affine", c.mel, c.spk_dim, 1, true);
+    }
     if (c.estimator == 1) {            // CausalMaskedDiffWithDiT: no conformer encoder, DiT estimator
         const int D = c.est_ch, Cp = c.ffn, ffi = c.est_mid * D;
         CV_CHECK(d == c.mel && D % 64 == 0 && D / c.est_heads == 64 && D % 16 == 0 && (D / 16) % 4 == 0 && c.enc_blocks == 0 && c.up_blocks == 0,
@@ -198,6 +211,7 @@ static void flow_finalize(cv_flow* m) {
         m->finalized = true;
         return;
     }
+    if (!unet1) {
     m->embed_lin = get_lin(m, "enc.embed.lin", d, d, 1, true); m->embed_ln = get_ln(m, "enc.embed.ln", d);
     m->up_embed_lin = get_lin(m, "enc.up_embed.lin", d, d, 1, true); m->up_embed_ln = get_ln(m, "enc.up_embed.ln", d);
     m->after_norm = get_ln(m, "enc.after_norm", d);
@@ -216,11 +230,18 @@ static void flow_finalize(cv_flow* m) {
     };
     for (int i = 0; i < c.enc_blocks; ++i) m->enc.push_back(conformer("enc.layers." + std::to_string(i) + "."));
     for (int i = 0; i < c.up_blocks; ++i) m->enc_up.push_back(conformer("enc.up_layers." + std::to_string(i) + "."));
+    }
     m->time1 = get_lin(m, "est.time1", tdim, cin, 1, true); m->time2 = get_lin(m, "est.time2", tdim, tdim, 1, true);
-    const int nst = c.est_mid + 2;
+    int nst = c.est_mid + 2, n_down = 1;
+    if (unet1) {                       // len(channels) down stages, est_mid mid stages, len(channels) up stages - counted from the tensors that were set
+        nst = 0;
+        while (m->tm.has("est.stage." + std::to_string(nst) + ".res.mlp.w")) ++nst;
+        n_down = (nst - c.est_mid) / 2;
+        CV_CHECK(n_down >= 1 && n_down <= 4 && nst == 2 * n_down + c.est_mid, "flow(unet1): stages must be n down + est_mid mid + n up, n <= 4");
+    }
     for (int s = 0; s < nst; ++s) {
         const std::string p = "est.stage." + std::to_string(s) + ".";
-        const int din = s == 0 ? cin : (s == nst - 1 ? 2 * C : C);
+        const int din = s == 0 ? cin : (s >= nst - n_down ? 2 * C : C);
         StageW st;
         st.res.mlp = get_lin(m, p + "res.mlp", C, tdim, 1, true);
         st.res.conv1 = get_lin(m, p + "res.block1.conv", C, din, 3, true); st.res.ln1 = get_ln(m, p + "res.block1.ln", C);
@@ -251,6 +272,13 @@ static void flow_finalize(cv_flow* m) {
             st.tf.push_back(t);
         }
         m->stages.push_back(st);
+        if (unet1) {
+            UStageW u;
+            u.kind = s < n_down ? 0 : (s < n_down + c.est_mid ? 1 : 2);
+            if (u.kind == 0) { u.post = s == n_down - 1 ? 1 : 2; u.post_lin = u.post == 1 ? get_lin(m, p + "post", C, C, 3, true) : get_lin(m, p + "post", C, 3 * C, 1, true); }
+            if (u.kind == 2) { u.post = s == nst - 1 ? 1 : 3; u.post_lin = u.post == 1 ? get_lin(m, p + "post", C, C, 3, true) : get_lin(m, p + "post", 2 * C, C, 2, true); }
+            m->ust.push_back(u);
+        }
     }
     if (const char* e = getenv("CV_FLOW_NTILE")) m->flow_ntile = atoi(e);
     // dev knobs of the large-M kernel set for A/B runs through bench.py (options of the same names without the prefix)
@@ -274,7 +302,7 @@ static void flow_finalize(cv_flow* m) {
     if (const char* e = getenv("CV_FLOW_BAND_PIPE")) m->band_pipe = atoi(e);
     if (const char* e = getenv("CV_FLOW_BAND")) m->fused_band = e[0] != '0';        // dev knob for A/B runs (also: option "fused_band")
     if (const char* e = getenv("CV_FLOW_TAIL_RING")) m->tail_ring = atoi(e) == 16 ? 16 : 8;
-    m->down_conv = get_lin(m, "est.down_conv", C, C, 3, true); m->up_conv = get_lin(m, "est.up_conv", C, C, 3, true);
+    if (!unet1) { m->down_conv = get_lin(m, "est.down_conv", C, C, 3, true); m->up_conv = get_lin(m, "est.up_conv", C, C, 3, true); }
     m->final_conv = get_lin(m, "est.final.conv", C, C, 3, true); m->final_ln = get_ln(m, "est.final.ln", C);
     m->final_proj = get_lin(m, "est.final_proj", c.mel, C, 1, true);
     m->finalized = true;
@@ -429,6 +457,7 @@ static void drop_graphs(cv_flow* m) { std::lock_guard<std::recursive_mutex> lk(r
 
 // nz = batch rows of the estimator: 2 (the CFG pair of one utterance) or 2 x the utterances of a batched solve
 static void est_reserve(cv_flow* m, int T, int nz = 2) {
+    if (m->cfg.estimator == 2) T += 2;    // the up-sampled stream is 2 ceil(T / 2) rows before it is cut to the skip's length (flow/decoder.py:275)
     if (T <= m->est_cap && nz <= m->est_nz) return;
     drop_graphs(m);                       // captured kernels hold the old workspace addresses
     T = std::max(T, m->est_cap); nz = std::max(nz, m->est_nz);
@@ -436,6 +465,11 @@ static void est_reserve(cv_flow* m, int T, int nz = 2) {
     m->s_in.ensure(R * 4 * c.mel * f); m->s_a.ensure(R * C * f); m->s_b.ensure(R * C * f); m->s_c.ensure(R * C * f); m->s_n.ensure(R * C * f);
     m->s_qkv.ensure(R * 3 * c.est_heads * 64 * f); m->s_att.ensure(R * c.est_heads * 64 * f); m->s_ff.ensure(R * 4 * C * f);
     m->s_skip.ensure(R * C * f); m->s_cat.ensure(R * 2 * C * f); m->s_out.ensure(R * c.mel * f);
+    if (c.estimator == 2) {
+        size_t nd = 0; for (const auto& u : m->ust) nd += u.kind == 0;
+        for (size_t i = 0; i < nd; ++i) m->u_skip[i].ensure(R * C * f);
+        m->u_gn.ensure((size_t)nz * 8 * 64 * sizeof(double));
+    }
     {   // bf16 activations of the fused pipeline; V^T is [nz][heads * 64][pitch] and its never-written pad columns must stay finite (0 x P)
         const size_t inner = (size_t)c.est_heads * 64, pitch = (size_t)(T + T / 2 + 63) / 64 * 64;
         m->h_qk.ensure(R * 2 * inner * 2); m->h_att.ensure(R * inner * 2); m->h_ff.ensure(R * 4 * C * 2); if (!m->h_zero.p) { m->h_zero.ensure(64); CV_HIP(hipMemset(m->h_zero.p, 0, 64)); }
@@ -451,7 +485,7 @@ static void time_reserve(cv_flow* m, int n) {
     drop_graphs(m);
     const auto& c = m->cfg; const size_t tdim = 4 * c.est_ch;
     m->t_val.ensure((size_t)n * 4); m->t_sin.ensure((size_t)n * 4 * c.mel * 4); m->t_h.ensure((size_t)n * tdim * 4); m->t_emb.ensure((size_t)n * tdim * 4);
-    m->t_mlp.ensure((size_t)(c.est_mid + 2) * n * c.est_ch * 4);
+    m->t_mlp.ensure(m->stages.size() * n * c.est_ch * 4);
     m->t_cap = n;
 }
 // t_val[n] (device) -> per-resnet time projections t_mlp[stage][n][C]  (SinusoidalPosEmb -> TimestepEmbedding -> Mish -> Linear)
@@ -677,12 +711,86 @@ static void attn_flow(const bf16_t* qk, int ld, int inner, const bf16_t* vt, lon
 // result in s_out [2][T][mel] (not masked).  Buffer discipline: a stage never writes the buffer it reads its input from
 // (res_conv re-reads the stage input after block1/block2), outputs ping-pong between s_a and s_c, s_b is scratch.
 // nz batch rows starting at batch row b0 of the packed workspaces (b0 > 0: the second half of a two-stream evaluation, estimator_eval)
-static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bool t_shared, int streaming, hipStream_t s, int nz = 2, int b0 = 0) {
+// The transformer blocks of one U-Net stage on the residual stream x [nz][T][C] (matcha BasicTransformerBlock x n_blocks; flow/decoder.py:455-466 causal, 232-243 CosyVoice-300M):
+// rows r0 .. of every workspace (r0 = b0 * T: the second launch chain of a two-chain evaluation works behind the first one's rows).
+static void stage_blocks(cv_flow* m, const StageW& st, float* x, int T, int nz, int b0, long long r0, int chunk, const int* klen, bool fused, hipStream_t s) {
     const auto& c = m->cfg; const int C = c.est_ch, H = c.est_heads, inner = H * 64; const long long R = (long long)nz * T;
+    float* n = m->s_n.as<float>() + r0 * C; float* qkv = m->s_qkv.as<float>() + r0 * 3 * inner;
+    float* att = m->s_att.as<float>() + r0 * inner; float* ff = m->s_ff.as<float>() + r0 * 4 * C;
+    for (size_t ti = 0; ti < st.tf.size(); ++ti) {      // matcha BasicTransformerBlock (self-attention + exact-erf GELU feed-forward)
+        const TBlockW& t = st.tf[ti];
+#ifdef CV_BUILD_EXPERIMENTS
+        if (fused && m->fused_tail && t.tail) {   // flow_tail.h: LN + QKV once per stage, then attention + ONE row-band launch per block
+            const long long vt_batch = (long long)inner * m->vt_pitch;
+            bf16_t* qk = m->h_qk.as<bf16_t>() + r0 * 2 * inner; bf16_t* vt = m->h_vt.as<bf16_t>() + b0 * vt_batch; bf16_t* ab = m->h_att.as<bf16_t>() + r0 * inner;
+            if (ti == 0) ln_gemm_bf16(t.qkv, &t.norm1, 1e-5f, x, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
+            attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, klen);
+            flow_tail(t, ti + 1 < st.tf.size() ? &st.tf[ti + 1] : nullptr, ab, inner, x, C, (int)R, qk, vt, vt_batch, m->vt_pitch, T, m->tail_ring, s);
+            continue;
+        }
+#endif
+        if (fused) {                      // flow_fused.h: 5 launches, bf16 activations, same rounding points as the path below
+            const long long vt_batch = (long long)inner * m->vt_pitch;
+            bf16_t* qk = m->h_qk.as<bf16_t>() + r0 * 2 * inner; bf16_t* vt = m->h_vt.as<bf16_t>() + b0 * vt_batch; bf16_t* ab = m->h_att.as<bf16_t>() + r0 * inner;
+            bf16_t* fb = m->h_ff.as<bf16_t>() + r0 * 4 * C;
+            const bool big = m->big_rows > 0 && R >= m->big_rows, big_attn = m->attn2_rows > 0 && R >= m->attn2_rows;
+            if (big && m->fused_band && t.band) {     // flow_band.h: QKV GEMM, attention, then ONE launch per 64-row band up to the next block's LayerNorm; bit-identical to the forms below
+                bf16_t* xn = m->h_xn.as<bf16_t>() + r0 * C;
+                const bool had_qkv = ti > 0 && m->band_qkv && st.tf[ti - 1].bandq;  // later blocks: the previous block's band launch left this block's Q | K and V^T (band_qkv), or LayerNorm(norm1) of its output in xn
+                if (ti == 0 && m->band_qkv && m->ln_qkv && t.lnqkv) {                // first block of a stage: LayerNorm + QKV GEMM in ONE launch per row band (round 6; the bits of the two launches below)
+                    const BandQkv bq0{qk, 2 * inner, vt, vt_batch, m->vt_pitch, T};
+                    flow_lnqkv(m, t, bq0, x, C, inner, (int)R, s);
+                } else {
+                    if (ti == 0) ln_bf16(t.norm1, 1e-5f, x, (int)R, C, xn, s);
+                    if (!had_qkv) gemm_big_bf16(t.qkv, xn, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
+                }
+                attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, klen, big_attn);
+                const bool has_next = ti + 1 < st.tf.size();
+                const BandQkv bq{qk, 2 * inner, vt, vt_batch, m->vt_pitch, T};
+                flow_band(m, t, has_next, has_next && m->band_qkv && t.bandq ? &bq : nullptr, ab, inner, x, C, (int)R, xn, s);
+                continue;
+            }
+            if (big) {                    // flow_big.h: 7 launches of large tiles, bit-identical to the 5 below
+                bf16_t* xn = m->h_xn.as<bf16_t>() + r0 * C;
+                ln_bf16(t.norm1, 1e-5f, x, (int)R, C, xn, s);
+                gemm_big_bf16(t.qkv, xn, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
+                attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, klen, big_attn);
+                gemm_big_res(t.out, ab, inner, (int)R, x, x, s);
+                ln_bf16(t.norm3, 1e-5f, x, (int)R, C, xn, s);
+                gemm_big_bf16(t.ff1, xn, (int)R, ACT_GELU_ERF, fb, 4 * C, 4 * C, nullptr, 0, 0, 0, s);
+                gemm_big_res(t.ff2, fb, 4 * C, (int)R, x, x, s);
+                continue;
+            }
+            ln_gemm_bf16(t.qkv, &t.norm1, 1e-5f, x, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
+            attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, klen, big_attn);
+            gemm_bf16_res(t.out, ab, inner, (int)R, x, x, s);
+            ln_gemm_bf16(t.ff1, &t.norm3, 1e-5f, x, (int)R, ACT_GELU_ERF, fb, 4 * C, 4 * C, nullptr, 0, 0, 0, s);
+            gemm_bf16_res(t.ff2, fb, 4 * C, (int)R, x, x, s);
+            continue;
+        }
+        ln_rows(t.norm1, x, n, R, C, 1e-5f, s);
+        lin_cl(t.qkv, n, R, qkv, ACT_NONE, nullptr, s);
+        AttnArgs at{};
+        at.q = qkv; at.q_batch = (long long)T * 3 * inner; at.q_row = 3 * inner; at.q_head = 64;
+        at.k = qkv + inner; at.k_batch = at.q_batch; at.k_row = 3 * inner; at.k_head = 64;
+        at.v = qkv + 2 * inner; at.v_batch = at.q_batch; at.v_row = 3 * inner; at.v_head = 64;
+        at.o = att; at.o_batch = (long long)T * inner; at.o_row = inner; at.o_head = 64;
+        at.B = nz; at.H = H; at.kv_group = 1; at.Tq = T; at.Tk = T; at.scale = 0.125f;
+        at.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; at.chunk = chunk; at.rel_bd = nullptr;
+        at.bf16 = tl_bf16_mfma; at.klen = klen;
+        attention(at, s);
+        lin_cl(t.out, att, R, x, ACT_NONE, x, s);
+        ln_rows(t.norm3, x, n, R, C, 1e-5f, s);
+        lin_cl(t.ff1, n, R, ff, ACT_GELU_ERF, nullptr, s);
+        lin_cl(t.ff2, ff, R, x, ACT_NONE, x, s);
+    }
+}
+
+static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bool t_shared, int streaming, hipStream_t s, int nz = 2, int b0 = 0) {
+    const auto& c = m->cfg; const int C = c.est_ch; const long long R = (long long)nz * T;
     const long long r0 = (long long)b0 * T;              // first row of this call in every [batch rows x T][...] workspace
     float* pp[2] = {m->s_a.as<float>() + r0 * C, m->s_c.as<float>() + r0 * C};
-    float* xb = m->s_b.as<float>() + r0 * C; float* n = m->s_n.as<float>() + r0 * C; float* qkv = m->s_qkv.as<float>() + r0 * 3 * inner;
-    float* att = m->s_att.as<float>() + r0 * inner; float* ff = m->s_ff.as<float>() + r0 * 4 * C; float* skip = m->s_skip.as<float>() + r0 * C;
+    float* xb = m->s_b.as<float>() + r0 * C; float* skip = m->s_skip.as<float>() + r0 * C;
     float* cat = m->s_cat.as<float>() + r0 * 2 * C;
     const int* klen = m->cur_klen ? m->cur_klen + b0 : nullptr;
     const int chunk = streaming ? 2 * c.chunk : 0;
@@ -716,73 +824,7 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
         ln_rows(st.res.ln2, x, xb, R, C, 1e-5f, s, ACT_MISH);
         conv_cl(st.res.res, cur, T, T, nz, 0, 1, x, ACT_NONE, 0.f, xb, s);           // x = res_conv(input) + h
         }
-        for (size_t ti = 0; ti < st.tf.size(); ++ti) {      // matcha BasicTransformerBlock (self-attention + exact-erf GELU feed-forward)
-            const TBlockW& t = st.tf[ti];
-#ifdef CV_BUILD_EXPERIMENTS
-            if (fused && m->fused_tail && t.tail) {   // flow_tail.h: LN + QKV once per stage, then attention + ONE row-band launch per block
-                const long long vt_batch = (long long)inner * m->vt_pitch;
-                bf16_t* qk = m->h_qk.as<bf16_t>() + r0 * 2 * inner; bf16_t* vt = m->h_vt.as<bf16_t>() + b0 * vt_batch; bf16_t* ab = m->h_att.as<bf16_t>() + r0 * inner;
-                if (ti == 0) ln_gemm_bf16(t.qkv, &t.norm1, 1e-5f, x, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
-                attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, klen);
-                flow_tail(t, ti + 1 < st.tf.size() ? &st.tf[ti + 1] : nullptr, ab, inner, x, C, (int)R, qk, vt, vt_batch, m->vt_pitch, T, m->tail_ring, s);
-                continue;
-            }
-#endif
-            if (fused) {                      // flow_fused.h: 5 launches, bf16 activations, same rounding points as the path below
-                const long long vt_batch = (long long)inner * m->vt_pitch;
-                bf16_t* qk = m->h_qk.as<bf16_t>() + r0 * 2 * inner; bf16_t* vt = m->h_vt.as<bf16_t>() + b0 * vt_batch; bf16_t* ab = m->h_att.as<bf16_t>() + r0 * inner;
-                bf16_t* fb = m->h_ff.as<bf16_t>() + r0 * 4 * C;
-                const bool big = m->big_rows > 0 && R >= m->big_rows, big_attn = m->attn2_rows > 0 && R >= m->attn2_rows;
-                if (big && m->fused_band && t.band) {     // flow_band.h: QKV GEMM, attention, then ONE launch per 64-row band up to the next block's LayerNorm; bit-identical to the forms below
-                    bf16_t* xn = m->h_xn.as<bf16_t>() + r0 * C;
-                    const bool had_qkv = ti > 0 && m->band_qkv && st.tf[ti - 1].bandq;  // later blocks: the previous block's band launch left this block's Q | K and V^T (band_qkv), or LayerNorm(norm1) of its output in xn
-                    if (ti == 0 && m->band_qkv && m->ln_qkv && t.lnqkv) {                // first block of a stage: LayerNorm + QKV GEMM in ONE launch per row band (round 6; the bits of the two launches below)
-                        const BandQkv bq0{qk, 2 * inner, vt, vt_batch, m->vt_pitch, T};
-                        flow_lnqkv(m, t, bq0, x, C, inner, (int)R, s);
-                    } else {
-                        if (ti == 0) ln_bf16(t.norm1, 1e-5f, x, (int)R, C, xn, s);
-                        if (!had_qkv) gemm_big_bf16(t.qkv, xn, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
-                    }
-                    attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, klen, big_attn);
-                    const bool has_next = ti + 1 < st.tf.size();
-                    const BandQkv bq{qk, 2 * inner, vt, vt_batch, m->vt_pitch, T};
-                    flow_band(m, t, has_next, has_next && m->band_qkv && t.bandq ? &bq : nullptr, ab, inner, x, C, (int)R, xn, s);
-                    continue;
-                }
-                if (big) {                    // flow_big.h: 7 launches of large tiles, bit-identical to the 5 below
-                    bf16_t* xn = m->h_xn.as<bf16_t>() + r0 * C;
-                    ln_bf16(t.norm1, 1e-5f, x, (int)R, C, xn, s);
-                    gemm_big_bf16(t.qkv, xn, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
-                    attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, klen, big_attn);
-                    gemm_big_res(t.out, ab, inner, (int)R, x, x, s);
-                    ln_bf16(t.norm3, 1e-5f, x, (int)R, C, xn, s);
-                    gemm_big_bf16(t.ff1, xn, (int)R, ACT_GELU_ERF, fb, 4 * C, 4 * C, nullptr, 0, 0, 0, s);
-                    gemm_big_res(t.ff2, fb, 4 * C, (int)R, x, x, s);
-                    continue;
-                }
-                ln_gemm_bf16(t.qkv, &t.norm1, 1e-5f, x, (int)R, ACT_NONE, qk, 2 * inner, 2 * inner, vt, vt_batch, m->vt_pitch, T, s);
-                attn_flow(qk, 2 * inner, inner, vt, vt_batch, m->vt_pitch, ab, nz, H, T, chunk, s, klen, big_attn);
-                gemm_bf16_res(t.out, ab, inner, (int)R, x, x, s);
-                ln_gemm_bf16(t.ff1, &t.norm3, 1e-5f, x, (int)R, ACT_GELU_ERF, fb, 4 * C, 4 * C, nullptr, 0, 0, 0, s);
-                gemm_bf16_res(t.ff2, fb, 4 * C, (int)R, x, x, s);
-                continue;
-            }
-            ln_rows(t.norm1, x, n, R, C, 1e-5f, s);
-            lin_cl(t.qkv, n, R, qkv, ACT_NONE, nullptr, s);
-            AttnArgs at{};
-            at.q = qkv; at.q_batch = (long long)T * 3 * inner; at.q_row = 3 * inner; at.q_head = 64;
-            at.k = qkv + inner; at.k_batch = at.q_batch; at.k_row = 3 * inner; at.k_head = 64;
-            at.v = qkv + 2 * inner; at.v_batch = at.q_batch; at.v_row = 3 * inner; at.v_head = 64;
-            at.o = att; at.o_batch = (long long)T * inner; at.o_row = inner; at.o_head = 64;
-            at.B = nz; at.H = H; at.kv_group = 1; at.Tq = T; at.Tk = T; at.scale = 0.125f;
-            at.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; at.chunk = chunk; at.rel_bd = nullptr;
-            at.bf16 = tl_bf16_mfma; at.klen = klen;
-            attention(at, s);
-            lin_cl(t.out, att, R, x, ACT_NONE, x, s);
-            ln_rows(t.norm3, x, n, R, C, 1e-5f, s);
-            lin_cl(t.ff1, n, R, ff, ACT_GELU_ERF, nullptr, s);
-            lin_cl(t.ff2, ff, R, x, ACT_NONE, x, s);
-        }
+        stage_blocks(m, st, x, T, nz, b0, r0, chunk, klen, fused, s);
         flip ^= 1;
         if (si == 0) {                         // keep the skip, then the stride-1 "downsample" CausalConv1d (decoder.py:452-453)
             CV_HIP(hipMemcpyAsync(skip, x, (size_t)R * C * 4, hipMemcpyDeviceToDevice, s));
@@ -805,9 +847,73 @@ static void estimator_forward(cv_flow* m, int T, int t_row, int t_rows_total, bo
     conv_cl(m->final_proj, xb, T, T, nz, 0, 1, m->s_out.as<float>() + r0 * c.mel, ACT_NONE, 0.f, nullptr, s);
 }
 
+// ---- ConditionalDecoder of CosyVoice-300M (cfg.estimator == 2; flow/decoder.py:88-291 over matcha's Block1D / ResnetBlock1D / Downsample1D / Upsample1D) ------------
+// The same stage as above with three differences: the convolutions are centred (pad 1 on both sides), a Block1D normalises with GroupNorm(8) over (channels of the
+// group x TIME) instead of a LayerNorm per frame, and the stream changes resolution (stride-2 convolution down, transposed convolution up, cut to the skip's length).
+// The transformer blocks are the ones of the causal U-Net: stage_blocks() with full attention - in bf16 mode the fused kernels of flow_fused.h / flow_big.h / flow_band.h.
+// Batch-1 requests: the mask is all ones.
+static void unet1_forward(cv_flow* m, int T, int t_row, int t_rows_total, bool t_shared, hipStream_t s, int nz = 2) {
+    const auto& c = m->cfg; const int C = c.est_ch, G = 8;
+    float* pp[2] = {m->s_a.as<float>(), m->s_c.as<float>()};
+    float* xb = m->s_b.as<float>(); float* cat = m->s_cat.as<float>(); double* gn = m->u_gn.as<double>();
+    const bool fused = tl_bf16_mfma && m->fused && C <= 256 && m->wbf16;
+    auto conv = [&](const Lin& l, const float* in, int Tn, float* out, const float* res) { conv_cl(l, in, Tn, Tn, nz, l.taps / 2, 1, out, ACT_NONE, 0.f, res, s); };
+    const float* cur = m->s_in.as<float>();
+    int Tc = T, flip = 0, level = 0;
+    std::vector<int> skip_t;
+    for (size_t si = 0; si < m->stages.size(); ++si) {
+        const StageW& st = m->stages[si]; const UStageW& u = m->ust[si];
+        if (u.kind == 2) {                   // x[:, :, :skip length] ++ skip along the channels (decoder.py:275-276)
+            const int Ts = skip_t.back(); skip_t.pop_back(); --level;
+            hipLaunchKernelGGL(concat_cols_batched_kernel, dim3(nblk((long long)nz * Ts * 2 * C)), dim3(256), 0, s, cur, C, (long long)Tc * C, m->u_skip[level].as<float>(), C,
+                               (long long)Ts * C, cat, Ts, nz);
+            cur = cat; Tc = Ts;
+        }
+        const long long R = (long long)nz * Tc;
+        const float* tm = m->t_mlp.as<float>() + ((size_t)si * t_rows_total + t_row) * C;
+        float* x = pp[flip];                 // stage output (cur never aliases it)
+        // ResnetBlock1D (matcha decoder.py): block1 -> + mlp(t) -> block2 -> + res_conv(x)
+        conv(st.res.conv1, cur, Tc, x, nullptr);
+        group_norm(x, xb, nz, Tc, C, G, st.res.ln1.g, st.res.ln1.b, 1e-5f, ACT_MISH, tm, t_shared ? 0 : C, gn, s);
+        conv(st.res.conv2, xb, Tc, x, nullptr);
+        group_norm(x, xb, nz, Tc, C, G, st.res.ln2.g, st.res.ln2.b, 1e-5f, ACT_MISH, nullptr, 0, gn, s);
+        conv(st.res.res, cur, Tc, x, xb);
+        stage_blocks(m, st, x, Tc, nz, 0, 0, 0, nullptr, fused, s);
+        flip ^= 1;
+        if (u.kind == 0) { CV_HIP(hipMemcpyAsync(m->u_skip[level].p, x, (size_t)R * C * 4, hipMemcpyDeviceToDevice, s)); skip_t.push_back(Tc); ++level; }
+        if (u.post == 0) { cur = x; continue; }
+        float* y = pp[flip];
+        const Lin& l = u.post_lin;
+        if (u.post == 1) conv(l, x, Tc, y, nullptr);
+        else {
+            GemmConvArgs a{};
+            a.A = x; a.a_batch = (long long)Tc * C; a.a_len = (long long)Tc * C; a.K = l.K; a.taps = l.taps; a.pro = ACT_NONE; a.W = l.w; a.Kp = l.Kp; a.bias = l.b;
+            a.C = y; a.N = l.N; a.act = ACT_NONE; a.out_scale = 1.f; a.a_bf16 = tl_bf16_mfma && l.bf16;
+            int Tn;
+            if (u.post == 2) {               // Downsample1D: output row j = rows 2 j - 1 .. 2 j + 1, contiguous in a channel-last sequence
+                Tn = (Tc - 1) / 2 + 1;
+                a.lda = 2 * C; a.a_off0 = -C; a.tap_step = 0; a.M = Tn; a.ldc = l.N; a.c_batch = (long long)Tn * l.N; a.c_len = a.c_batch;
+            } else {                         // Upsample1D: GEMM row j = output rows 2 j - 1, 2 j (phase r of the kernel in columns r C .. r C + C), tap q reads row j - q
+                Tn = 2 * Tc;
+                a.lda = C; a.a_off0 = 0; a.tap_step = -C; a.M = Tc + 1; a.ldc = l.N; a.c_off = -C; a.c_batch = (long long)Tn * C; a.c_len = a.c_batch;
+            }
+            a.res_batch = a.c_batch; a.row_scale_batch = a.M;
+            gemm_conv(a, l.bf16, nz, s);
+            Tc = Tn;
+        }
+        cur = y; flip ^= 1;
+    }
+    CV_CHECK(Tc == T && skip_t.empty(), "flow(unet1): the up path must come back to the input length");
+    float* y = pp[flip];
+    conv(m->final_conv, cur, T, y, nullptr);
+    group_norm(y, xb, nz, T, C, G, m->final_ln.g, m->final_ln.b, 1e-5f, ACT_MISH, nullptr, 0, gn, s);
+    conv(m->final_proj, xb, T, m->s_out.as<float>(), nullptr);
+}
+
 // One estimator evaluation over nz batch rows: with est_streams = 2 (and an even nz) the two halves of the batch rows run as independent launch chains
 // on `s` and on the handle's side stream, forked and joined through events (graph edges when `s` is being captured).
 static void estimator_eval(cv_flow* m, int T, int t_row, int t_rows_total, bool t_shared, int streaming, hipStream_t s, int nz = 2) {
+    if (m->cfg.estimator == 2) { unet1_forward(m, T, t_row, t_rows_total, t_shared, s, nz); return; }
     if ((m->est_streams < 2 && !m->two_chains_now) || nz < 2 || (nz & 1)) { estimator_forward(m, T, t_row, t_rows_total, t_shared, streaming, s, nz, 0); return; }
     if (!m->side_stream) {
         CV_HIP(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
@@ -1296,6 +1402,24 @@ static void flow_inference_ragged(cv_flow* m, int nu, const int32_t* token_ids, 
     }
 }
 
+int cv_flow_solve(cv_flow* m, float* x, const float* mu, const float* spks, const float* cond, int32_t T, int32_t n_timesteps, void* stream) {
+    return guarded([&] {
+        CV_CHECK(m && m->finalized && x && mu && spks && cond && T > 0 && n_timesteps > 0, "cv_flow_solve: bad arguments");
+        PrecisionScope prec(m);
+        hipStream_t s = resolve(m, stream);
+        const auto& c = m->cfg; const size_t per = (size_t)T * c.mel * 4;
+        if (T > m->solve_cap || m->f_x.bytes < per || m->f_mu.bytes < per || m->f_cond.bytes < per || m->f_spk.bytes < (size_t)c.mel * 4) {
+            drop_graphs(m);               // captured solves hold the staging addresses
+            m->f_x.ensure(per); m->f_mu.ensure(per); m->f_cond.ensure(per); m->f_spk.ensure((size_t)8 * c.mel * 4);
+            m->solve_cap = T;
+        }
+        // the solve runs on the handle's own staging buffers: a captured graph bakes its addresses in, the caller's tensors come and go
+        CV_HIP(hipMemcpyAsync(m->f_x.p, x, per, hipMemcpyDeviceToDevice, s)); CV_HIP(hipMemcpyAsync(m->f_mu.p, mu, per, hipMemcpyDeviceToDevice, s));
+        CV_HIP(hipMemcpyAsync(m->f_cond.p, cond, per, hipMemcpyDeviceToDevice, s)); CV_HIP(hipMemcpyAsync(m->f_spk.p, spks, (size_t)c.mel * 4, hipMemcpyDeviceToDevice, s));
+        solve_euler(m, m->f_x.as<float>(), m->f_mu.as<float>(), m->f_spk.as<float>(), m->f_cond.as<float>(), T, n_timesteps, 0, s, 1);
+        CV_HIP(hipMemcpyAsync(x, m->f_x.p, per, hipMemcpyDeviceToDevice, s));
+    });
+}
 int cv_flow_inference_ragged(cv_flow* m, int32_t n_utt, const int32_t* token_ids, const int32_t* n_tok, const float* prompt_feat, const int32_t* mel_len1,
                              const float* embedding, const float* noise_cl, int32_t streaming, int32_t finalize, int32_t n_timesteps, float* mel_out,
                              int32_t* mel_len2_out, void* stream) {

@@ -18,6 +18,7 @@
 #include "common.h"
 #include "llm_kernels.h"
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace cv {
@@ -51,7 +52,10 @@ struct Lm1GemvArgs {
 // the weights do not depend on the previous kernel's output, the input vector does, so the prologue's dependent loads (x, gamma, beta) wait under them.
 // NW: waves per workgroup (they split K): 4, or 8 for the K = 4096 product whose 1024 rows are only 256 workgroups - 16 steps per wave were two dependent
 // round trips per wave, 8 steps are one.
-template <int U, int NW>
+// W16 (round 6, the model's fp16 mode: cv_lm1_use_bf16): the matrix is stored as bf16 [N][Kp]; a lane takes the SAME four k-values of a step as 8 bytes and widens them when
+// the step is consumed - the products and their order are those of the fp32 kernel on the bf16-rounded weights, half the bytes per token.
+typedef unsigned lm1_u32x2 __attribute__((ext_vector_type(2)));
+template <int U, int NW, bool W16 = false>
 static __global__ __launch_bounds__(64 * NW) void lm1_gemv_kernel(Lm1GemvArgs p) {
     __shared__ float xs[LM1_MAX_K + 64];
     __shared__ float part[NW][4];
@@ -62,12 +66,21 @@ static __global__ __launch_bounds__(64 * NW) void lm1_gemv_kernel(Lm1GemvArgs p)
     if (p.set_pos == -2 && blockIdx.x == 0 && tid == 0) p.dyn->pos = p.st->pos;
     const int row = min((int)blockIdx.x * 4 + grp, p.N - 1);      // clamped: the reductions are wave collectives
     const int s0 = wave * steps / NW, s1 = (wave + 1) * steps / NW;
-    const float* wr = p.W + (long long)row * p.ldw;
-    v4f w[U], wn[U];
-    auto load_w = [&](v4f (&dst)[U], int sb) {
+    using raw_t = typename std::conditional<W16, lm1_u32x2, v4f>::type;
+    const float* wr = p.W + (W16 ? 0 : (long long)row * p.ldw);
+    const unsigned short* wr16 = reinterpret_cast<const unsigned short*>(p.W) + (W16 ? (long long)row * p.ldw : 0);
+    raw_t w[U], wn[U];
+    auto load_w = [&](raw_t (&dst)[U], int sb) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)                             // unconditional loads (clamped step) keep the vmcnt bookkeeping exact
-            dst[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(wr + min(min(sb + u, s1 - 1) * 64 + sub * 4, p.Kp - 4)));
+        for (int u = 0; u < U; ++u) {                           // unconditional loads (clamped step) keep the vmcnt bookkeeping exact
+            const int k = min(min(sb + u, s1 - 1) * 64 + sub * 4, p.Kp - 4);
+            if constexpr (W16) dst[u] = __builtin_nontemporal_load(reinterpret_cast<const lm1_u32x2*>(wr16 + k));
+            else dst[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(wr + k));
+        }
+    };
+    auto wide = [](const raw_t& r) -> v4f {
+        if constexpr (W16) return (v4f){__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+        else return r;
     };
     if (p.pro != LM1_PRO_LN && s0 < s1) load_w(w, s0);          // (the LayerNorm prologue requests its row first: its statistics then run under the weight loads)
     // ---- prologue: the input vector into LDS, zero beyond K up to the last 64-float step
@@ -158,7 +171,7 @@ static __global__ __launch_bounds__(64 * NW) void lm1_gemv_kernel(Lm1GemvArgs p)
             if (sb + u >= s1) x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) { acc += w[u][0] * x[u].x; acc += w[u][1] * x[u].y; acc += w[u][2] * x[u].z; acc += w[u][3] * x[u].w; }
+        for (int u = 0; u < U; ++u) { const v4f wf = wide(w[u]); acc += wf[0] * x[u].x; acc += wf[1] * x[u].y; acc += wf[2] * x[u].z; acc += wf[3] * x[u].w; }
         if (more) {
 #pragma unroll
             for (int u = 0; u < U; ++u) w[u] = wn[u];
@@ -303,6 +316,9 @@ struct cv_lm1 {
     float xscale = 1.f;
     std::vector<Lm1Layer> L;
     const float *embed_w = nullptr, *embed_b = nullptr, *embed_g = nullptr, *embed_beta = nullptr, *after_g = nullptr, *after_b = nullptr, *dec_w = nullptr, *dec_b = nullptr;
+    // fp16 mode of this model (cv_lm1_use_bf16): the same matrices as bf16 [N][Kp]; null = fp32
+    struct L16 { const void *w_qkv = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr; };
+    std::vector<L16> L16s; const void* embed_w16 = nullptr; const void* dec_w16 = nullptr; bool w16 = false;
     DevBuf dyn, x0, x1, h, ff, part;
     // the device-resident decode loop (cv_lm1_decode_begin / cv_lm1_decode): loop state, sampling parameters, emitted tokens, the next input row, logits, injected uniforms
     DevBuf dstate, dsp, dtokens, xin, dlogits, duniforms;
@@ -324,14 +340,23 @@ hipStream_t resolve(cv_lm1* m, void* s) {
     return m->own_stream;
 }
 
-void gemv(cv_lm1* m, int pro, const float* x, const float* g, const float* b, float eps, const float* W, const float* bias, const float* res, float* y, int layer,
+// W16: the bf16 copy of W (cv_lm1_use_bf16) or null
+void gemv(cv_lm1* m, int pro, const float* x, const float* g, const float* b, float eps, const float* W, const void* W16, const float* bias, const float* res, float* y, int layer,
           int set_pos, int N, int K, int act, hipStream_t s) {
     CV_CHECK(K % 4 == 0 && K <= LM1_MAX_K && (pro != LM1_PRO_LN || K <= 1024), "cv_lm1: a GEMV input of up to 4096 floats (1024 under the LayerNorm prologue), K % 4 == 0");
-    Lm1GemvArgs a{x, g, b, eps, W, (long long)kp_of(K), bias, res, y, m->dyn.as<Lm1Dyn>(), layer, set_pos, m->dstate.as<DecodeState>(), N, K, kp_of(K), act, pro};
+    const bool h16 = m->w16 && W16 != nullptr;
+    Lm1GemvArgs a{x, g, b, eps, h16 ? reinterpret_cast<const float*>(W16) : W, (long long)kp_of(K), bias, res, y, m->dyn.as<Lm1Dyn>(), layer, set_pos, m->dstate.as<DecodeState>(), N, K, kp_of(K), act, pro};
     const int steps = (kp_of(K) + 63) / 64;
-    if (steps <= 16) hipLaunchKernelGGL((lm1_gemv_kernel<4, 4>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a);
-    else if (pro == LM1_PRO_NONE && N <= 2048) hipLaunchKernelGGL((lm1_gemv_kernel<8, 8>), dim3((unsigned)((N + 3) / 4)), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((lm1_gemv_kernel<8, 4>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)((N + 3) / 4));
+    if (h16) {
+        if (steps <= 16) hipLaunchKernelGGL((lm1_gemv_kernel<4, 4, true>), grid, dim3(256), 0, s, a);
+        else if (pro == LM1_PRO_NONE && N <= 2048) hipLaunchKernelGGL((lm1_gemv_kernel<8, 8, true>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((lm1_gemv_kernel<8, 4, true>), grid, dim3(256), 0, s, a);
+        return;
+    }
+    if (steps <= 16) hipLaunchKernelGGL((lm1_gemv_kernel<4, 4>), grid, dim3(256), 0, s, a);
+    else if (pro == LM1_PRO_NONE && N <= 2048) hipLaunchKernelGGL((lm1_gemv_kernel<8, 8>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((lm1_gemv_kernel<8, 4>), grid, dim3(256), 0, s, a);
 }
 
 // everything of a step after its first kernel
@@ -341,13 +366,14 @@ void step_body(cv_lm1* m, float* logits, hipStream_t s) {
     hipLaunchKernelGGL(lm1_norm_kernel, dim3(1), dim3(64), 0, s, Lm1NormArgs{h, x0, m->embed_g, m->embed_beta, 1e-5f, m->xscale, d, m->act});
     for (int i = 0; i < m->n_layers; ++i) {
         const Lm1Layer& L = m->L[i];
-        gemv(m, LM1_PRO_LN, x0, L.ln1_g, L.ln1_b, 1e-12f, L.w_qkv, L.b_qkv, nullptr, nullptr, i, -1, 4 * d, d, ACT_NONE, s);
+        const cv_lm1::L16 H = m->w16 ? m->L16s[i] : cv_lm1::L16{};
+        gemv(m, LM1_PRO_LN, x0, L.ln1_g, L.ln1_b, 1e-12f, L.w_qkv, H.w_qkv, L.b_qkv, nullptr, nullptr, i, -1, 4 * d, d, ACT_NONE, s);
         hipLaunchKernelGGL(lm1_attn_kernel, dim3(m->heads, LM1_SPLITS), dim3(256), 0, s, Lm1AttnArgs{m->dyn.as<Lm1Dyn>(), i, d, m->heads, 0.125f, part});
-        gemv(m, LM1_PRO_MERGE, part, nullptr, nullptr, 0.f, L.w_out, L.b_out, x0, x1, -1, -1, d, d, ACT_NONE, s);
-        gemv(m, LM1_PRO_LN, x1, L.ln2_g, L.ln2_b, 1e-12f, L.w1, L.b1, nullptr, ff, -1, -1, m->ffn, d, m->act, s);
-        gemv(m, LM1_PRO_NONE, ff, nullptr, nullptr, 0.f, L.w2, L.b2, x1, x0, -1, -1, d, m->ffn, ACT_NONE, s);
+        gemv(m, LM1_PRO_MERGE, part, nullptr, nullptr, 0.f, L.w_out, H.w_out, L.b_out, x0, x1, -1, -1, d, d, ACT_NONE, s);
+        gemv(m, LM1_PRO_LN, x1, L.ln2_g, L.ln2_b, 1e-12f, L.w1, H.w1, L.b1, nullptr, ff, -1, -1, m->ffn, d, m->act, s);
+        gemv(m, LM1_PRO_NONE, ff, nullptr, nullptr, 0.f, L.w2, H.w2, L.b2, x1, x0, -1, -1, d, m->ffn, ACT_NONE, s);
     }
-    gemv(m, LM1_PRO_LN, x0, m->after_g, m->after_b, 1e-5f, m->dec_w, m->dec_b, nullptr, logits, -1, -1, m->n_out, d, ACT_NONE, s);
+    gemv(m, LM1_PRO_LN, x0, m->after_g, m->after_b, 1e-5f, m->dec_w, m->dec_w16, m->dec_b, nullptr, logits, -1, -1, m->n_out, d, ACT_NONE, s);
 }
 
 }  // namespace
@@ -386,6 +412,24 @@ cv_lm1* cv_lm1_create(const cv_lm1_config* c, const cv_lm1_layer_weights* layers
 
 void cv_lm1_destroy(cv_lm1* m) { delete m; }
 
+int cv_lm1_use_bf16(cv_lm1* m, const cv_lm1_layer_bf16* layers, const void* embed_w, const void* dec_w) {
+    return guarded([&] {
+        CV_CHECK(m, "cv_lm1_use_bf16: null handle");
+        std::lock_guard<std::recursive_mutex> lk(runtime_lock());
+        if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }       // a captured step holds the kernel choice and the matrix addresses
+        if (!layers) { m->w16 = false; m->L16s.clear(); m->embed_w16 = m->dec_w16 = nullptr; return; }
+        m->L16s.clear();
+        for (int i = 0; i < m->n_layers; ++i) {
+            const cv_lm1_layer_bf16& w = layers[i];
+            CV_CHECK(w.w_qkv && w.w_out && w.w1 && w.w2 && aligned16(w.w_qkv) && aligned16(w.w_out) && aligned16(w.w1) && aligned16(w.w2), "cv_lm1_use_bf16: four 16B-aligned matrices per layer");
+            cv_lm1::L16 h; h.w_qkv = w.w_qkv; h.w_out = w.w_out; h.w1 = w.w1; h.w2 = w.w2;
+            m->L16s.push_back(h);
+        }
+        CV_CHECK((!embed_w || aligned16(embed_w)) && (!dec_w || aligned16(dec_w)), "cv_lm1_use_bf16: 16B-aligned matrices");
+        m->embed_w16 = embed_w; m->dec_w16 = dec_w; m->w16 = true;
+    });
+}
+
 int cv_lm1_bind(cv_lm1* m, float* const* rows, const float* const* tabs, int32_t n_tab, int32_t cap, void* stream) {
     return guarded([&] {
         CV_CHECK(m && rows && tabs, "cv_lm1_bind: null argument");
@@ -409,7 +453,7 @@ int cv_lm1_step(cv_lm1* m, const float* x_row, int32_t pos, float* logits, void*
         CV_CHECK(pos >= 0 && pos < m->cap, "cv_lm1_step: position beyond the bound cache");
         hipStream_t s = resolve(m, stream);
         // first kernel: the input layer's Linear on the caller's row; it publishes the position the rest of the step reads
-        gemv(m, LM1_PRO_NONE, x_row, nullptr, nullptr, 0.f, m->embed_w, m->embed_b, nullptr, m->h.as<float>(), -1, pos, m->d, m->d_in, ACT_NONE, s);
+        gemv(m, LM1_PRO_NONE, x_row, nullptr, nullptr, 0.f, m->embed_w, m->embed_w16, m->embed_b, nullptr, m->h.as<float>(), -1, pos, m->d, m->d_in, ACT_NONE, s);
         ++m->steps;
         if (!m->use_graph) { step_body(m, logits, s); return; }
         if (!m->graph || m->graph_logits != logits || m->graph_stream != s) {
@@ -469,7 +513,7 @@ int cv_lm1_decode(cv_lm1* m, int32_t n_steps, int32_t* out_tokens, int32_t* n_ou
         DecodeState* st = m->dstate.as<DecodeState>();
         const int before = m->host_state.n_tokens;
         for (int i = 0; i < n_steps; ++i) {
-            gemv(m, LM1_PRO_NONE, m->xin.as<float>(), nullptr, nullptr, 0.f, m->embed_w, m->embed_b, nullptr, m->h.as<float>(), -1, -2, m->d, m->d_in, ACT_NONE, s);
+            gemv(m, LM1_PRO_NONE, m->xin.as<float>(), nullptr, nullptr, 0.f, m->embed_w, m->embed_w16, m->embed_b, nullptr, m->h.as<float>(), -1, -2, m->d, m->d_in, ACT_NONE, s);
             step_body(m, m->dlogits.as<float>(), s);
             SampleArgs sa{};
             sa.logits = m->dlogits.as<float>(); sa.V = m->n_out; sa.sp = m->dsp.as<SampleParams>(); sa.uniforms = m->duniforms.as<float>();

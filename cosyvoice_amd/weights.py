@@ -260,6 +260,80 @@ def pack_flow(sd, cfg, device, dtype=torch.bfloat16, experiments=False):
     return out
 
 
+def pack_unet1(sd, prefix, est_heads, device, dtype=torch.float32):
+    """The ConditionalDecoder of CosyVoice-300M (flow/decoder.py:88-291; state-dict keys under `prefix`, e.g. "decoder.estimator.") for a flow handle with
+    cfg.estimator == 2 (csrc/flow.hip::unet1_forward): stages in execution order (down..., mid..., up...), each with its ResnetBlock1D (GroupNorm scale / shift under the
+    names the causal U-Net uses for its LayerNorms), its transformer blocks, and `post` = what follows them (Conv1d k 3 | Downsample1D as a Linear over 3 C-wide windows |
+    Upsample1D in polyphase form).  dtype bf16 adds the band / QKV streams of the large-M kernels (C = 256 with 8 heads, or the 64-wide test shape)."""
+    out, s = {}, prefix
+    count = lambda stem: len({k[len(s + stem):].split(".")[0] for k in sd if k.startswith(s + stem)})
+    n_down, n_mid, n_up = count("down_blocks."), count("mid_blocks."), count("up_blocks.")
+    assert n_down == n_up and n_down >= 1
+    _lin(out, "est.time1", sd[s + "time_mlp.linear_1.weight"], sd[s + "time_mlp.linear_1.bias"], device, dtype)
+    _lin(out, "est.time2", sd[s + "time_mlp.linear_2.weight"], sd[s + "time_mlp.linear_2.bias"], device, dtype)
+    stages = [(s + "down_blocks.%d." % i, "down") for i in range(n_down)] + [(s + "mid_blocks.%d." % i, "mid") for i in range(n_mid)] + \
+             [(s + "up_blocks.%d." % i, "up") for i in range(n_up)]
+    C = sd[s + "final_proj.weight"].shape[1]
+    inner = est_heads * 64
+    band_ok = dtype == torch.bfloat16 and (C, inner) in ((256, 512), (64, 64))
+    for si, (src, kind) in enumerate(stages):
+        dst = "est.stage.%d." % si
+        r = src + "0."
+        _lin(out, dst + "res.mlp", sd[r + "mlp.1.weight"], sd[r + "mlp.1.bias"], device, dtype)
+        for b in ("block1", "block2"):                              # Block1D: Conv1d, GroupNorm(8), Mish
+            _conv(out, dst + "res." + b + ".conv", sd[r + b + ".block.0.weight"], sd[r + b + ".block.0.bias"], device, dtype)
+            out[dst + "res." + b + ".ln.g"] = _f32(sd[r + b + ".block.1.weight"], device)
+            out[dst + "res." + b + ".ln.b"] = _f32(sd[r + b + ".block.1.bias"], device)
+        _conv(out, dst + "res.res", sd[r + "res_conv.weight"], sd[r + "res_conv.bias"], device, dtype)
+        n_blocks = len({k[len(src + "1."):].split(".")[0] for k in sd if k.startswith(src + "1.")})
+        for j in range(n_blocks):
+            t, q = src + "1.%d." % j, dst + "tf.%d." % j
+            assert sd[t + "attn1.to_q.weight"].shape == (inner, C), "the estimator's attention heads are 64 wide"
+            out[q + "norm1.g"] = _f32(sd[t + "norm1.weight"], device); out[q + "norm1.b"] = _f32(sd[t + "norm1.bias"], device)
+            _lin(out, q + "qkv", torch.cat([sd[t + "attn1.to_q.weight"], sd[t + "attn1.to_k.weight"], sd[t + "attn1.to_v.weight"]], 0), None, device, dtype)
+            _lin(out, q + "out", sd[t + "attn1.to_out.0.weight"], sd[t + "attn1.to_out.0.bias"], device, dtype)
+            out[q + "norm3.g"] = _f32(sd[t + "norm3.weight"], device); out[q + "norm3.b"] = _f32(sd[t + "norm3.bias"], device)
+            _lin(out, q + "ff1", sd[t + "ff.net.0.proj.weight"], sd[t + "ff.net.0.proj.bias"], device, dtype)
+            _lin(out, q + "ff2", sd[t + "ff.net.2.weight"], sd[t + "ff.net.2.bias"], device, dtype)
+        if band_ok:                                                 # the streams of flow_band_kernel / flow_lnqkv_kernel, as pack_flow() makes them for the causal U-Net
+            waves = 8 if C == 256 else 4
+            for j in range(n_blocks):
+                q = dst + "tf.%d." % j
+                nxt = out[dst + "tf.%d.qkv.w" % (j + 1)].reshape(3 * inner, C) if j + 1 < n_blocks else None
+                z = torch.zeros(C, device=device)
+                out[q + "tail_prm"] = torch.cat([out[q + "out.b"], out[q + "norm3.g"], out[q + "norm3.b"], out[q + "ff1.b"], out[q + "ff2.b"],
+                                                 out[dst + "tf.%d.norm1.g" % (j + 1)] if nxt is not None else z, out[dst + "tf.%d.norm1.b" % (j + 1)] if nxt is not None else z]).contiguous()
+                mats = (out[q + "out.w"].reshape(C, inner), out[q + "ff1.w"].reshape(4 * C, C), out[q + "ff2.w"].reshape(C, 4 * C))
+                out[q + "band"] = pack_flow_band(*mats, waves)
+                if j == 0:
+                    out[q + "lnqkv"] = pack_flow_band_qkv(out[q + "qkv.w"].reshape(3 * inner, C), waves)
+                if nxt is not None:
+                    out[q + "bandq"] = pack_flow_band(*mats, waves, nxt)
+        if kind == "mid":
+            continue
+        if (src + "2.conv.weight") in sd:                           # Downsample1D: Conv1d(k 3, stride 2, pad 1) / Upsample1D: ConvTranspose1d(k 4, stride 2, pad 1)
+            w, b = sd[src + "2.conv.weight"].float(), sd[src + "2.conv.bias"].float()
+            if kind == "down":
+                _lin(out, dst + "post", w.permute(0, 2, 1).reshape(w.shape[0], -1), b, device, dtype)
+            else:                                                   # [C_in, C_out, 4] -> [2 C_out][2 taps][C_in]: phase r, tap j holds kernel element r + 2 j
+                cin, cout, k = w.shape
+                assert k == 4
+                wp = torch.zeros(2, cout, 2, cin)
+                for ph in range(2):
+                    for j in range(2):
+                        wp[ph, :, j, :] = w[:, :, ph + 2 * j].t()
+                wpk, _ = pack_weight(wp.reshape(2 * cout, 2, cin).to(device), dtype)
+                out[dst + "post.w"] = wpk
+                out[dst + "post.b"] = _f32(b.repeat(2), device)
+        else:
+            _conv(out, dst + "post", sd[src + "2.weight"], sd[src + "2.bias"], device, dtype)
+    _conv(out, "est.final.conv", sd[s + "final_block.block.0.weight"], sd[s + "final_block.block.0.bias"], device, dtype)
+    out["est.final.ln.g"] = _f32(sd[s + "final_block.block.1.weight"], device)
+    out["est.final.ln.b"] = _f32(sd[s + "final_block.block.1.bias"], device)
+    _conv(out, "est.final_proj", sd[s + "final_proj.weight"], sd[s + "final_proj.bias"], device, dtype)
+    return out, dict(C=C, n_blocks=n_blocks, n_mid=n_mid, n_down=n_down)
+
+
 def pack_flow_dit(sd, cfg, device, dtype=torch.bfloat16):
     """sd: CausalMaskedDiffWithDiT state dict (cosyvoice/flow/flow.py:284-318 + flow/DiT/dit.py:104-144).  Device layout: q / k / v fused; the
     in_proj columns permuted from the reference's cat order [x | cond | mu | spks] (dit.py:90-96) to the packed estimator input [x | mu | spks |

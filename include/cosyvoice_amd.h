@@ -186,7 +186,10 @@ typedef struct cv_flow_config {
     float cfg_rate;
     int32_t estimator;   /* 0: CausalConditionalDecoder U-Net (CosyVoice2, flow/decoder.py:294-494); 1: DiT (Fun-CosyVoice3: CausalMaskedDiffWithDiT.inference
                           * flow/flow.py:369-414, DiT.forward flow/DiT/dit.py:145-176).  For 1: dim = input_size = 80, ffn = PreLookaheadLayer channels,
-                          * est_ch = DiT width, est_blocks = depth, est_mid = ff_mult, enc_blocks = up_blocks = 0. */
+                          * est_ch = DiT width, est_blocks = depth, est_mid = ff_mult, enc_blocks = up_blocks = 0.
+                          * 2: ConditionalDecoder, the U-Net of CosyVoice-300M (flow/decoder.py:88-291) ALONE - the handle then serves cv_flow_estimator and
+                          * cv_flow_solve only (that model's encoder / length regulator / flow cache are the caller's, cosyvoice_amd/cosyvoice1_hip.py); mel, est_ch
+                          * (one width for every level), est_heads, est_blocks, est_mid and cfg_rate are read, the number of down / up stages is taken from the tensors. */
 } cv_flow_config;
 int cv_flow_create(cv_flow** out, const cv_flow_config* cfg);
 int cv_flow_set_tensor(cv_flow* m, const char* name, const void* dev_ptr, int32_t dtype, int64_t numel);
@@ -224,6 +227,10 @@ int cv_flow_estimator(cv_flow* m, const float* x, const float* mask, const float
  * padded positions are zero (`output * mask`).  key_len == NULL: cv_flow_estimator. */
 int cv_flow_estimator_masked(cv_flow* m, const float* x, const float* mask, const int32_t* key_len, const float* mu, const float* t, const float* spks,
                              const float* cond, int32_t T, int32_t streaming, float* out, void* stream);
+/* ConditionalCFM.solve_euler for ONE utterance (flow/flow_matching.py:71-124; cosine t schedule, classifier-free guidance at cfg.cfg_rate, the estimator the handle
+ * was built with): x [T][mel] dev fp32 CHANNEL-LAST - in: the initial noise z (with whatever the caller's flow cache wrote over its head), out: the mel; mu, cond
+ * [T][mel] channel-last, spks [mel].  The n_timesteps estimator evaluations are one hipGraph from the second call of a shape on (option "use_graph"). */
+int cv_flow_solve(cv_flow* m, float* x, const float* mu, const float* spks, const float* cond, int32_t T, int32_t n_timesteps, void* stream);
 /* B5: flow.inference(token ++ prompt_token, prompt_feat, embedding, streaming, finalize) -> mel[1,80,mel_len2]
  * (flow/flow.py:235-281 + flow_matching.py:71-124,203-227).  token_ids: dev int32 [n_tok] = prompt tokens then new tokens;
  * prompt_feat: dev [mel_len1,80]; embedding: dev [spk_dim]; noise_cl: dev [>=T,80] = CausalConditionalCFM.rand_noise
@@ -381,6 +388,12 @@ typedef struct cv_lm1_config {
 } cv_lm1_config;
 cv_lm1* cv_lm1_create(const cv_lm1_config* cfg, const cv_lm1_layer_weights* layers /* [n_layers] */);      /* NULL on error (cv_last_error) */
 void cv_lm1_destroy(cv_lm1* m);
+/* The model's fp16 mode (the reference: cli/cosyvoice.py:27-56 `fp16=True` -> cli/model.py:60-63 `self.llm.half()`), here W16A32: the decode step reads the SAME matrices
+ * as bf16 [N][Kp] (row pitch Kp = round_up(K, 32) elements, like the fp32 form) - half the bytes per token; activations, biases, norms, cache and logits stay fp32 and
+ * every product is the fp32 product of the bf16 weight, in the fp32 kernels' order (bit-identical to the fp32 step over bf16-ROUNDED fp32 matrices).  embed_w / dec_w may
+ * be NULL (that product then stays on the fp32 matrix).  layers == NULL switches back to fp32.  The pointers must outlive the handle. */
+typedef struct cv_lm1_layer_bf16 { const void *w_qkv, *w_out, *w1, *w2; } cv_lm1_layer_bf16;
+int cv_lm1_use_bf16(cv_lm1* m, const cv_lm1_layer_bf16* layers /* [n_layers] */, const void* embed_w, const void* dec_w);
 /* A request's buffers: rows / tabs are HOST arrays of n_layers device pointers.  Call again whenever a buffer is reallocated (a grown cache, grown tables). */
 int cv_lm1_bind(cv_lm1* m, float* const* rows, const float* const* tabs, int32_t n_tab, int32_t cap, void* stream);
 int cv_lm1_step(cv_lm1* m, const float* x_row, int32_t pos, float* logits, void* stream);

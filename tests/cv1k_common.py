@@ -20,8 +20,10 @@ t = lambda n: torch.tensor([n], dtype=torch.int32)
 greedy = lambda scores, decoded, sampling: int(scores.argmax().item())
 
 
-def build_flow(lib):
-    return CK.MaskedDiffWithXvec(W.make_cv1_flow(CFG), enc_heads=CFG.flow_heads, est_heads=CFG.est_heads, input_frame_rate=CFG.input_frame_rate, lib=lib)
+def build_flow(lib, estimator="handle", precision="fp32"):
+    """estimator: "handle" (the product default: the U-Net inside one library handle) | "operators" (one launch per operator, sequenced in python)."""
+    return CK.MaskedDiffWithXvec(W.make_cv1_flow(CFG), enc_heads=CFG.flow_heads, est_heads=CFG.est_heads, input_frame_rate=CFG.input_frame_rate, lib=lib,
+                                 estimator=estimator, precision=precision)
 
 
 def build_hift(lib, rng="host"):

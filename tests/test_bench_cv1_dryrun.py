@@ -23,3 +23,6 @@ def test_cosyvoice300m_extra_dry_run(emu_lib, monkeypatch):
     res = bench.cv1_workload(types.SimpleNamespace(steps=2))
     assert res["token_check"] == {"checked": 25, "equal_torch_eager_cpu": True, "first_difference": None, "equal_real_reference_class": None}   # (the real-class fixture holds the 500-id request)
     assert res["audio_s_per_s"] > 0 and set(res["stages"]) == {"llm_ms", "flow_ms", "hift_ms", "llm_us_per_token"}
+    f16 = res["fp16_mode"]                                          # round 6: the model's fp16 mode next to it (W16A32 LM + bf16-mode estimator)
+    assert f16["token_check"]["equal"] and f16["token_check"]["checked"] == 25 and f16["audio_s_per_s"] > 0
+    assert 0 < f16["flow_mel_vs_fp32_mode"]["rel_l2"] < 5e-2

@@ -98,6 +98,51 @@ def test_flow_inference_with_flow_cache_matches_reference(lib):
         torch.testing.assert_close(cache.cpu(), g["cache_" + name], rtol=1e-4, atol=1e-4)
 
 
+def test_estimator_handle_matches_the_operator_sequence_and_the_reference(lib):
+    """The U-Net of CosyVoice-300M inside one library handle (csrc/flow.hip cfg.estimator == 2, round 6) against (1) the launch-per-operator class on the same
+    ConditionalDecoder.forward call (flow/decoder.py:204-291; an odd frame count: the up-sampled stream is one row longer than the skip it is cut to) and (2) the real
+    MaskedDiffWithXvec's golden through both requests of the flow-cache test; the default of MaskedDiffWithXvec IS the handle (build_flow above)."""
+    K = CK.Kernels(lib)
+    sd = W.make_cv1_flow(CFG)
+    ops = CK.ConditionalDecoder(sd, "decoder.estimator.", CFG.est_heads, K)
+    hd = CK.EstimatorHandle(sd, "decoder.estimator.", CFG.est_heads, lib, "fp32")
+    gen = torch.Generator().manual_seed(1)
+    for T in (67, 40):
+        x, mu, cond = (torch.randn(2, 80, T, generator=gen) for _ in range(3))
+        spks, tt = torch.randn(2, 80, generator=gen), torch.tensor([0.3, 0.3])
+        got = hd.forward(x, torch.ones(2, 1, T), mu, tt, spks, cond).cpu()
+        tall, offs = ops.prepare([0.3])
+        h = K.put(torch.cat([x, mu, spks.unsqueeze(2).expand(-1, -1, T), cond], 1).transpose(1, 2))
+        want = ops(h, T, tall[0], offs)[0].view(2, T, 80).transpose(1, 2).cpu()
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    assert isinstance(build_flow(lib).estimator, CK.EstimatorHandle)
+    g = gold("cv1k_flow")
+    flow = build_flow(lib, "operators")
+    torch.manual_seed(90)
+    feat, _ = flow.inference(token=g["token_a"], token_len=t(50), prompt_token=g["prompt_token"], prompt_token_len=t(12), prompt_feat=g["prompt_feat"],
+                             prompt_feat_len=t(25), embedding=g["embedding"], flow_cache=torch.zeros(1, 80, 0, 2))
+    torch.testing.assert_close(feat.cpu(), g["feat_a"], rtol=1e-3, atol=1e-3)
+
+
+def test_estimator_handle_bf16_mode_and_solve_graph(lib):
+    """precision "bf16" (the analogue of the reference's fp16=True for this model): the fused transformer-block kernels of the CosyVoice2 estimator under the U-Net of
+    CosyVoice-300M - within the bf16 tolerance of the real class's mel; the solve is captured at the second sighting of a shape and the replay returns the eager bits."""
+    g = gold("cv1k_flow")
+    flow = build_flow(lib, "handle", "bf16")
+    flow.estimator.set_option("use_graph", 1)                    # (off by default for this model: measured slower than issuing the launches)
+    kw = dict(token=g["token_a"], token_len=t(50), prompt_token=g["prompt_token"], prompt_token_len=t(12), prompt_feat=g["prompt_feat"], prompt_feat_len=t(25),
+              embedding=g["embedding"], flow_cache=torch.zeros(1, 80, 0, 2))
+    feats = []
+    for _ in range(3):
+        torch.manual_seed(90)
+        feats.append(flow.inference(**kw)[0].cpu())
+    want = g["feat_a"]
+    rel = float((feats[0] - want).norm() / want.norm())
+    assert rel < 2e-2, rel                                       # measured 4.2e-3 at this size (fp32 mode: 4e-7)
+    assert torch.equal(feats[0], feats[1]) and torch.equal(feats[1], feats[2])
+    assert flow.estimator.stat("graph_captures") == 1
+
+
 def test_load_takes_reference_state_dict_files(lib, tmp_path):
     """CosyVoiceModel.load(llm.pt, flow.pt, hift.pt) (cli/model.py:65-73) into the kernel-backed stages; an inference_sft-shaped request end to end."""
     torch.save(W.make_cv1_llm(CFG), tmp_path / "llm.pt")
@@ -125,7 +170,7 @@ def test_split3_weights_option(lib):
     assert lm.affine.w3 is not None and lm.affine.w3.dtype == torch.bfloat16
     assert list(lm.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw)) == g["tokens_greedy"].tolist()
     g = gold("cv1k_flow")
-    flow = CK.MaskedDiffWithXvec(W.make_cv1_flow(CFG), enc_heads=CFG.flow_heads, est_heads=CFG.est_heads, input_frame_rate=CFG.input_frame_rate, lib=lib, split3=True)
+    flow = CK.MaskedDiffWithXvec(W.make_cv1_flow(CFG), enc_heads=CFG.flow_heads, est_heads=CFG.est_heads, input_frame_rate=CFG.input_frame_rate, lib=lib, split3=True, estimator="operators")
     torch.manual_seed(90)
     feat, _ = flow.inference(token=g["token_a"], token_len=t(50), prompt_token=g["prompt_token"], prompt_token_len=t(12), prompt_feat=g["prompt_feat"],
                              prompt_feat_len=t(25), embedding=g["embedding"], flow_cache=torch.zeros(1, 80, 0, 2))
@@ -136,7 +181,7 @@ def test_launch_tapes_are_bit_identical_to_eager_sequencing(lib):
     """LaunchTape replays (the estimator of Euler steps 2..n, the LM decode step) against the same launches sequenced from scratch (Kernels.use_tapes = False):
     the same kernels on the same operands, so the mel and the decode rows are equal bit for bit."""
     g = gold("cv1k_flow")
-    flow = build_flow(lib)
+    flow = build_flow(lib, "operators")                         # (the handle sequences its launches in C++: no tape)
     out = {}
     for tapes in (True, False):
         flow.k.use_tapes = tapes
@@ -166,7 +211,7 @@ def test_concurrent_requests_on_one_stage_object_are_serialised(lib, monkeypatch
     interleaving: for this test it is a fixed tensor per request length.)"""
     import threading
     g = gold("cv1k_flow")
-    flow = build_flow(lib)
+    flow = build_flow(lib, "operators")
     gen = torch.Generator().manual_seed(17)
     reqs = {n: torch.randint(0, 40, (1, n), generator=gen, dtype=torch.int32) for n in (24, 30)}
     noise = {25 + int(n / 50 * 22050 / 256): torch.randn(1, 80, 25 + int(n / 50 * 22050 / 256), generator=gen) for n in reqs}
@@ -285,6 +330,32 @@ def test_device_resident_decode_loop(lib):
     ref = CK.TransformerLM(sd, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling=host_ras, lib=lib)
     want = list(ref.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw))
     assert got == want and 14 <= len(got) <= 42 and len(set(got)) > 3
+
+
+def test_bf16_weight_mode_streams_the_rounded_matrices(lib):
+    """weight_dtype=torch.bfloat16 (the model's fp16 mode, W16A32): the decode step reads bf16 copies of its matrices (cv_lm1_use_bf16) and must give, bit for bit, the
+    logits of the fp32 step over the bf16-ROUNDED matrices (same lanes, same k order, the bf16 widened exactly); the tokens - host sampler and device loop - are those
+    of the torch-eager port over the rounded state dict."""
+    g = gold("cv1k_llm")
+    kw = dict(text=g["text"], text_len=t(7), prompt_text=g["prompt_text"], prompt_text_len=t(4), prompt_speech_token=g["prompt_speech_token"],
+              prompt_speech_token_len=t(9), embedding=g["embedding"])
+    sd = W.make_cv1_llm(CFG)
+    lm16 = CK.TransformerLM(sd, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling=greedy, lib=lib, weight_dtype=torch.bfloat16)
+    assert lm16.w16 and lm16.fused_step and lm16.llm._w16[0][0][0].dtype == torch.bfloat16
+    rounded = lm16.sd
+    assert not torch.equal(rounded["llm_decoder.weight"], sd["llm_decoder.weight"]) and torch.equal(rounded["llm_decoder.bias"], sd["llm_decoder.bias"])
+    lm32 = CK.TransformerLM(rounded, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling=greedy, lib=lib)          # fp32 storage of the same values
+    seen = {}
+    for name, lm in (("w16", lm16), ("w32", lm32)):
+        rows = []
+        lm.sampling = lambda scores, decoded, sampling, _r=rows: (_r.append(scores.clone()), int(scores.argmax().item()))[1]
+        seen[name] = (list(lm.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw)), torch.stack(rows))
+    assert seen["w16"][0] == seen["w32"][0] and torch.equal(seen["w16"][1], seen["w32"][1])
+    ref = C1.TransformerLM(rounded, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling=greedy)
+    want = list(ref.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw))
+    assert seen["w16"][0] == want and len(want) >= 14
+    loop = CK.TransformerLM(sd, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling="greedy", lib=lib, weight_dtype=torch.bfloat16, decode_chunk=5)
+    assert list(loop.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw)) == want
 
 
 def test_interleaved_device_loops_do_not_share_loop_state(lib):
