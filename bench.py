@@ -451,7 +451,7 @@ def cv1_workload(args):
         fkw = dict(token=tok, token_len=tl(n_gen), prompt_token=e0, prompt_token_len=tl(0), prompt_feat=torch.zeros(1, 0, 80), prompt_feat_len=tl(0), embedding=emb,
                    flow_cache=torch.zeros(1, 80, 0, 2))
         torch.manual_seed(11); mel32, _ = m.flow.inference(**fkw)
-        torch.manual_seed(11); t0 = time.perf_counter(); mel16, _ = flow16.inference(**fkw); torch.cuda.synchronize(); st16["flow_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
+        torch.cuda.synchronize(); torch.manual_seed(11); t0 = time.perf_counter(); mel16, _ = flow16.inference(**fkw); torch.cuda.synchronize(); st16["flow_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
         st16["llm_us_per_token"] = round(1e3 * st16["llm_ms"] / n_gen, 1)
         n16 = min(int(os.environ.get("CV_BENCH_CV1_CHECK16", 250)), n_gen)
         ref16 = C1.TransformerLM(lm16.sd, text_heads=cfg.text_heads, llm_heads=cfg.llm_heads, sampling=greedy)

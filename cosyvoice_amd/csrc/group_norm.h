@@ -90,11 +90,23 @@ static __global__ __launch_bounds__(256) void group_stats_rows_kernel(const floa
 static __global__ __launch_bounds__(256) void group_apply_rows_kernel(const float* x, float* y, const double* part, int T, int C, int G, int S, int rows_per_wg,
                                                                        const float* gamma, const float* beta, float eps, int act,
                                                                        const float* col_add, long long col_add_batch) {
+    __shared__ double ps[2 * 8 * 32];                        // the batch row's partial sums [G][S][2] (G <= 8, S <= 32: see group_norm()), then the totals behind them
+    __shared__ double tot[2 * 8];
     const int b = blockIdx.y, q = C >> 2, R = 256 / q, cg = C / G;
     const int j = threadIdx.x % q, r = threadIdx.x / q, c = 4 * j, g = c / cg;
-    const double* p = part + ((long long)b * G + g) * S * 2;
-    double a = 0.0, sq = 0.0;
-    for (int s = 0; s < S; ++s) { a += p[2 * s]; sq += p[2 * s + 1]; }
+    // every lane needs ITS group's totals: S dependent loads per lane were what this launch took (11.5 us at S = 32).  The workgroup fetches the G * S pairs once, 2 G lanes
+    // add them in slice order (the order of group_apply_kernel: the same bits), everybody reads the result.
+    const double* p = part + (long long)b * G * S * 2;
+    for (int i = threadIdx.x; i < G * S * 2; i += 256) ps[i] = p[i];
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * G) {
+        const int gg = threadIdx.x >> 1, which = threadIdx.x & 1;
+        double acc = 0.0;
+        for (int s = 0; s < S; ++s) acc += ps[(gg * S + s) * 2 + which];
+        tot[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    const double a = tot[2 * g], sq = tot[2 * g + 1];
     const double n = (double)T * cg, mean = a / n;
     double var = sq / n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -123,7 +135,7 @@ static inline void group_norm(const float* x, float* y, int B, int T, int C, int
     const int q = C / 4;
     int S;
     const bool al16 = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)col_add) & 15) == 0 && col_add_batch % 4 == 0;
-    if (C % 4 == 0 && q <= 256 && 256 % q == 0 && (C / G) % 4 == 0 && G <= 256 && al16) {
+    if (C % 4 == 0 && q <= 256 && 256 % q == 0 && (C / G) % 4 == 0 && G <= 8 && al16) {
         const int R = 256 / q;
         S = (T + 8 * R - 1) / (8 * R);                                    // ~8 rows per lane
         S = S < 1 ? 1 : (S > 32 ? 32 : S);

@@ -47,42 +47,12 @@ struct Lm1GemvArgs {
     int N, K, Kp, act, pro;
 };
 
-// y[N] = act(pro(x)[K] . W[N][K]^T + bias) (+ res).  4 output rows per workgroup, a 16-lane group per row, the 4 waves split K (gemv_f32_kernel).
-// U: 64-float steps a lane group has in flight (a wave's share of K = 1024 is 4 steps).  The wave's FIRST group of weight loads is issued before the prologue:
-// the weights do not depend on the previous kernel's output, the input vector does, so the prologue's dependent loads (x, gamma, beta) wait under them.
-// NW: waves per workgroup (they split K): 4, or 8 for the K = 4096 product whose 1024 rows are only 256 workgroups - 16 steps per wave were two dependent
-// round trips per wave, 8 steps are one.
-// W16 (round 6, the model's fp16 mode: cv_lm1_use_bf16): the matrix is stored as bf16 [N][Kp]; a lane takes the SAME four k-values of a step as 8 bytes and widens them when
-// the step is consumed - the products and their order are those of the fp32 kernel on the bf16-rounded weights, half the bytes per token.
-typedef unsigned lm1_u32x2 __attribute__((ext_vector_type(2)));
-template <int U, int NW, bool W16 = false>
-static __global__ __launch_bounds__(64 * NW) void lm1_gemv_kernel(Lm1GemvArgs p) {
-    __shared__ float xs[LM1_MAX_K + 64];
-    __shared__ float part[NW][4];
-    __shared__ float mw[256];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
-    const int steps = (p.Kp + 63) / 64;
-    if (p.set_pos >= 0 && blockIdx.x == 0 && tid == 0) p.dyn->pos = p.set_pos;
-    if (p.set_pos == -2 && blockIdx.x == 0 && tid == 0) p.dyn->pos = p.st->pos;
-    const int row = min((int)blockIdx.x * 4 + grp, p.N - 1);      // clamped: the reductions are wave collectives
-    const int s0 = wave * steps / NW, s1 = (wave + 1) * steps / NW;
-    using raw_t = typename std::conditional<W16, lm1_u32x2, v4f>::type;
-    const float* wr = p.W + (W16 ? 0 : (long long)row * p.ldw);
-    const unsigned short* wr16 = reinterpret_cast<const unsigned short*>(p.W) + (W16 ? (long long)row * p.ldw : 0);
-    raw_t w[U], wn[U];
-    auto load_w = [&](raw_t (&dst)[U], int sb) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {                           // unconditional loads (clamped step) keep the vmcnt bookkeeping exact
-            const int k = min(min(sb + u, s1 - 1) * 64 + sub * 4, p.Kp - 4);
-            if constexpr (W16) dst[u] = __builtin_nontemporal_load(reinterpret_cast<const lm1_u32x2*>(wr16 + k));
-            else dst[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(wr + k));
-        }
-    };
-    auto wide = [](const raw_t& r) -> v4f {
-        if constexpr (W16) return (v4f){__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
-        else return r;
-    };
-    if (p.pro != LM1_PRO_LN && s0 < s1) load_w(w, s0);          // (the LayerNorm prologue requests its row first: its statistics then run under the weight loads)
+// The prologue of the decode GEMVs: the input vector into LDS (xs, zero beyond K up to steps * 64 floats), by one of three rules; `issue_weights()` requests the caller's
+// first weight loads at the point where they hide the most (before everything - or, under the LayerNorm, right behind the row's own loads).
+template <int NW, typename F>
+static __device__ __forceinline__ void lm1_gemv_prologue(const Lm1GemvArgs& p, float* xs, float* mw, int steps, F&& issue_weights) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (p.pro != LM1_PRO_LN) issue_weights();                   // (the LayerNorm prologue requests its row first: its statistics then run under the weight loads)
     // ---- prologue: the input vector into LDS, zero beyond K up to the last 64-float step
     if (p.pro == LM1_PRO_LN) {
         // norm_rows_kernel's register path (C <= 1024, C % 4 == 0), every wave on the whole row; wave w parks chunk w
@@ -96,7 +66,7 @@ static __global__ __launch_bounds__(64 * NW) void lm1_gemv_kernel(Lm1GemvArgs p)
         }
         const int cw = lane * 4 + wave * 256;                   // gamma / beta of the wave's chunk travel with the row, not after the statistics
         const float4 gw = *reinterpret_cast<const float4*>(p.g + min(cw, p.K - 4)), bw = *reinterpret_cast<const float4*>(p.b + min(cw, p.K - 4));
-        if (s0 < s1) load_w(w, s0);
+        issue_weights();
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -157,9 +127,53 @@ static __global__ __launch_bounds__(64 * NW) void lm1_gemv_kernel(Lm1GemvArgs p)
             *reinterpret_cast<float4*>(&xs[e]) = t;
         }
     }
+}
+
+// y[N] = act(pro(x)[K] . W[N][K]^T + bias) (+ res).  4 output rows per workgroup, a 16-lane group per row, the 4 waves split K (gemv_f32_kernel).
+// U: 64-float steps a lane group has in flight (a wave's share of K = 1024 is 4 steps).  The wave's FIRST group of weight loads is issued before the prologue:
+// the weights do not depend on the previous kernel's output, the input vector does, so the prologue's dependent loads (x, gamma, beta) wait under them.
+// NW: waves per workgroup (they split K): 4, or 8 for the K = 4096 product whose 1024 rows are only 256 workgroups - 16 steps per wave were two dependent
+// round trips per wave, 8 steps are one.
+// W16 (round 6, the model's fp16 mode: cv_lm1_use_bf16): the matrix is stored as bf16 [N][Kp]; a lane takes the SAME four k-values of a step as 8 bytes and widens them when
+// the step is consumed - the products and their order are those of the fp32 kernel on the bf16-rounded weights, half the bytes per token.
+typedef unsigned lm1_u32x2 __attribute__((ext_vector_type(2)));
+// RPG: output rows per 16-lane group (4 RPG rows per workgroup).  A row's products and their order do not depend on it; what does is how much of the prologue (the input
+// vector, its LayerNorm, the barrier) a workgroup pays per byte of weights and how many weight bytes a CU has in flight (option "gemv_rows").
+template <int U, int NW, bool W16 = false, int RPG = 1>
+static __global__ __launch_bounds__(64 * NW) void lm1_gemv_kernel(Lm1GemvArgs p) {
+    __shared__ float xs[LM1_MAX_K + 64];
+    __shared__ float part[NW][4 * RPG];
+    __shared__ float mw[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
+    const int steps = (p.Kp + 63) / 64;
+    if (p.set_pos >= 0 && blockIdx.x == 0 && tid == 0) p.dyn->pos = p.set_pos;
+    if (p.set_pos == -2 && blockIdx.x == 0 && tid == 0) p.dyn->pos = p.st->pos;
+    const int row0 = ((int)blockIdx.x * 4 + grp) * RPG;           // this group's rows row0 .. row0 + RPG - 1 (clamped below: the reductions are wave collectives)
+    const int s0 = wave * steps / NW, s1 = (wave + 1) * steps / NW;
+    using raw_t = typename std::conditional<W16, lm1_u32x2, v4f>::type;
+    raw_t w[RPG][U], wn[RPG][U];
+    auto load_w = [&](raw_t (&dst)[RPG][U], int sb) {
+#pragma unroll
+        for (int i = 0; i < RPG; ++i) {
+            const long long ro = (long long)min(row0 + i, p.N - 1) * p.ldw;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                       // unconditional loads (clamped step) keep the vmcnt bookkeeping exact
+                const int k = min(min(sb + u, s1 - 1) * 64 + sub * 4, p.Kp - 4);
+                if constexpr (W16) dst[i][u] = __builtin_nontemporal_load(reinterpret_cast<const lm1_u32x2*>(reinterpret_cast<const unsigned short*>(p.W) + ro + k));
+                else dst[i][u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p.W + ro + k));
+            }
+        }
+    };
+    auto wide = [](const raw_t& r) -> v4f {
+        if constexpr (W16) return (v4f){__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+        else return r;
+    };
+    lm1_gemv_prologue<NW>(p, xs, mw, steps, [&] { if (s0 < s1) load_w(w, s0); });
     __syncthreads();
     // ---- the rows' dot products (gemv_f32_kernel: same loads, same order)
-    float acc = 0.f;
+    float acc[RPG];
+#pragma unroll
+    for (int i = 0; i < RPG; ++i) acc[i] = 0.f;
     for (int sb = s0; sb < s1; sb += U) {
         const bool more = sb + U < s1;
         if (more) load_w(wn, sb + U);                           // the next group is requested before this one is consumed
@@ -171,25 +185,118 @@ static __global__ __launch_bounds__(64 * NW) void lm1_gemv_kernel(Lm1GemvArgs p)
             if (sb + u >= s1) x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const v4f wf = wide(w[u]); acc += wf[0] * x[u].x; acc += wf[1] * x[u].y; acc += wf[2] * x[u].z; acc += wf[3] * x[u].w; }
+        for (int i = 0; i < RPG; ++i)
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const v4f wf = wide(w[i][u]); acc[i] += wf[0] * x[u].x; acc[i] += wf[1] * x[u].y; acc[i] += wf[2] * x[u].z; acc[i] += wf[3] * x[u].w; }
         if (more) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) w[u] = wn[u];
+            for (int i = 0; i < RPG; ++i)
+#pragma unroll
+                for (int u = 0; u < U; ++u) w[i][u] = wn[i][u];
         }
     }
-    acc = group16_sum(acc);
-    if (sub == 0) part[wave][grp] = acc;
+#pragma unroll
+    for (int i = 0; i < RPG; ++i) {
+        const float a = group16_sum(acc[i]);
+        if (sub == 0) part[wave][grp * RPG + i] = a;
+    }
     __syncthreads();
-    if (wave != 0 || sub != 0) return;
-    const int n = (int)blockIdx.x * 4 + grp;
+    if (wave != 0 || sub >= RPG) return;
+    const int gi = grp * RPG + sub, n = row0 + sub;              // lane `sub` of the group finishes its row `sub`
     if (n >= p.N) return;
-    float v = ((part[0][grp] + part[1][grp]) + part[2][grp]) + part[3][grp];
-    if (NW == 8) v = (((v + part[4 % NW][grp]) + part[5 % NW][grp]) + part[6 % NW][grp]) + part[7 % NW][grp];
+    float v = ((part[0][gi] + part[1][gi]) + part[2][gi]) + part[3][gi];
+    if (NW == 8) v = (((v + part[4 % NW][gi]) + part[5 % NW][gi]) + part[6 % NW][gi]) + part[7 % NW][gi];
     if (p.bias) v += p.bias[n];
     v = apply_act(p.act, v, 0.f);
     if (p.res) v += p.res[n];
     float* y = p.layer >= 0 ? p.dyn->rows[p.layer] + (long long)p.dyn->pos * p.N : p.y;
     y[n] = v;
+}
+
+// The bf16 matrices again, laid out over the lanes the way the CosyVoice2 decode GEMVs are (llm_kernels.h gemv_norm_kernel), round 6: a 16-lane group owns ROWS whole rows
+// and a lane 8 consecutive k-values per 128-float step as ONE 16-byte load, every load of the workgroup's share requested before the prologue's barrier.
+//   KSPLIT = false: a wave's four groups keep their rows to themselves over the whole K (K <= 128 STEPS) - 4 NW ROWS rows per workgroup, e.g. 256 workgroups for the
+//                   [4096][1024] products: the input row and its LayerNorm are made once per 16 rows instead of once per 4 (lm1_gemv_kernel: 1024 workgroups, each
+//                   re-reading 16 KB of x / gamma / beta against 8 KB of weights);
+//   KSPLIT = true:  the NW waves share 4 ROWS rows and split K (the [1024][4096] product and the products with few rows), partial sums combined in wave order.
+// The k order of a row's sum differs from lm1_gemv_kernel's: results agree to fp32 rounding, the bf16 weights are the same values (option "gemv16_wide", default 1).
+typedef unsigned lm1_u32x4 __attribute__((ext_vector_type(4)));
+// W16 = false: the same layout over fp32 matrices (a step = 16 lanes x 4 floats = 64 k-values; KSPLIT = false only: the split forms ARE lm1_gemv_kernel's) - option "gemv_wide".
+template <bool W16, int STEPS, int ROWS, int NW, bool KSPLIT>
+static __global__ __launch_bounds__(64 * NW) void lm1_gemv16_kernel(Lm1GemvArgs p) {
+    constexpr int SK = W16 ? 128 : 64, LK = W16 ? 8 : 4;        // k-values per step / per lane and step
+    __shared__ __attribute__((aligned(16))) float xs[LM1_MAX_K + 64];
+    __shared__ float part[NW][4 * ROWS];
+    __shared__ float mw[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, sub = lane & 15;
+    const int steps = p.Kp / SK;                                 // steps of a row (the launcher checks Kp % SK == 0)
+    if (p.set_pos >= 0 && blockIdx.x == 0 && tid == 0) p.dyn->pos = p.set_pos;
+    if (p.set_pos == -2 && blockIdx.x == 0 && tid == 0) p.dyn->pos = p.st->pos;
+    const int unit = KSPLIT ? (int)blockIdx.x * 4 + grp : ((int)blockIdx.x * NW + wave) * 4 + grp;
+    const int row0 = unit * ROWS;
+    const int s0 = KSPLIT ? wave * steps / NW : 0, s1 = KSPLIT ? (wave + 1) * steps / NW : steps;
+    lm1_u32x4 w[ROWS][STEPS];
+    lm1_gemv_prologue<NW>(p, xs, mw, steps * SK / 64, [&] {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const long long ro = (long long)min(row0 + r, p.N - 1) * p.ldw + sub * LK;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {                     // unconditional loads (clamped step): the vmcnt bookkeeping stays exact
+                const long long k = ro + (long long)min(s0 + s, max(s1 - 1, 0)) * SK;
+                if constexpr (W16) w[r][s] = __builtin_nontemporal_load(reinterpret_cast<const lm1_u32x4*>(reinterpret_cast<const unsigned short*>(p.W) + k));
+                else w[r][s] = __builtin_nontemporal_load(reinterpret_cast<const lm1_u32x4*>(p.W + k));
+            }
+        }
+    });
+    __syncthreads();
+    float acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        if (s0 + s < s1) {
+            const float4 xa = *reinterpret_cast<const float4*>(&xs[(s0 + s) * SK + sub * LK]);
+            float4 xb = xa;
+            if constexpr (W16) xb = *reinterpret_cast<const float4*>(&xs[(s0 + s) * SK + sub * LK + 4]);
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const lm1_u32x4 u = w[r][s];
+                float a = acc[r];
+                if constexpr (W16) {
+                    a += __uint_as_float(u[0] << 16) * xa.x;          a += __uint_as_float(u[0] & 0xffff0000u) * xa.y;
+                    a += __uint_as_float(u[1] << 16) * xa.z;          a += __uint_as_float(u[1] & 0xffff0000u) * xa.w;
+                    a += __uint_as_float(u[2] << 16) * xb.x;          a += __uint_as_float(u[2] & 0xffff0000u) * xb.y;
+                    a += __uint_as_float(u[3] << 16) * xb.z;          a += __uint_as_float(u[3] & 0xffff0000u) * xb.w;
+                } else {
+                    a += __uint_as_float(u[0]) * xa.x; a += __uint_as_float(u[1]) * xa.y; a += __uint_as_float(u[2]) * xa.z; a += __uint_as_float(u[3]) * xa.w;
+                }
+                acc[r] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = group16_sum(acc[r]);
+    if constexpr (KSPLIT) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) if (sub == 0) part[wave][grp * ROWS + r] = acc[r];
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { float t = 0.f; for (int ww = 0; ww < NW; ++ww) t += part[ww][grp * ROWS + r]; acc[r] = t; }
+    }
+    if (sub != 0) return;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int n = row0 + r;
+        if (n < p.N) {
+            float v = acc[r];
+            if (p.bias) v += p.bias[n];
+            v = apply_act(p.act, v, 0.f);
+            if (p.res) v += p.res[n];
+            float* y = p.layer >= 0 ? p.dyn->rows[p.layer] + (long long)p.dyn->pos * p.N : p.y;
+            y[n] = v;
+        }
+    }
 }
 
 // LayerNorm -> activation -> * scale of one row (the input layer's norm; its output is the residual stream, so it is materialised)
@@ -319,6 +426,9 @@ struct cv_lm1 {
     // fp16 mode of this model (cv_lm1_use_bf16): the same matrices as bf16 [N][Kp]; null = fp32
     struct L16 { const void *w_qkv = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr; };
     std::vector<L16> L16s; const void* embed_w16 = nullptr; const void* dec_w16 = nullptr; bool w16 = false;
+    int wide16 = 1;                    // bf16 matrices on lm1_gemv16_kernel (16-byte loads, whole rows per lane group; option "gemv16_wide", env CV_LM1_WIDE16); 0: lm1_gemv_kernel<.., true>
+    int wide32 = 1;                    // the same for the fp32 matrices of the [N >= 2048][K <= 1024] products (option "gemv_wide", env CV_LM1_WIDE)
+    int rows32 = 1, rows16 = 1;        // output rows per 16-lane group of the decode GEMVs over fp32 / bf16 matrices (option "gemv_rows" / "gemv_rows16": 1 | 2 | 4; the same bits)
     DevBuf dyn, x0, x1, h, ff, part;
     // the device-resident decode loop (cv_lm1_decode_begin / cv_lm1_decode): loop state, sampling parameters, emitted tokens, the next input row, logits, injected uniforms
     DevBuf dstate, dsp, dtokens, xin, dlogits, duniforms;
@@ -347,16 +457,30 @@ void gemv(cv_lm1* m, int pro, const float* x, const float* g, const float* b, fl
     const bool h16 = m->w16 && W16 != nullptr;
     Lm1GemvArgs a{x, g, b, eps, h16 ? reinterpret_cast<const float*>(W16) : W, (long long)kp_of(K), bias, res, y, m->dyn.as<Lm1Dyn>(), layer, set_pos, m->dstate.as<DecodeState>(), N, K, kp_of(K), act, pro};
     const int steps = (kp_of(K) + 63) / 64;
-    const dim3 grid((unsigned)((N + 3) / 4));
+    const int rpg = h16 ? m->rows16 : m->rows32;
+    const dim3 grid((unsigned)((N + 4 * rpg - 1) / (4 * rpg)));
+#define LM1_GEMV(U_, NW_, W16_, RPG_) hipLaunchKernelGGL((lm1_gemv_kernel<U_, NW_, W16_, RPG_>), grid, dim3(64 * NW_), 0, s, a)
+#define LM1_GEMV_R(U_, NW_, W16_) do { if (rpg == 4) LM1_GEMV(U_, NW_, W16_, 4); else if (rpg == 2) LM1_GEMV(U_, NW_, W16_, 2); else LM1_GEMV(U_, NW_, W16_, 1); } while (0)
+    if (h16 && m->wide16 && kp_of(K) % 128 == 0) {             // 16-byte loads, whole rows per lane group (lm1_gemv16_kernel)
+        const int st = kp_of(K) / 128;
+        if (st <= 8 && N >= 2048) { hipLaunchKernelGGL((lm1_gemv16_kernel<true, 8, 1, 4, false>), dim3((unsigned)((N + 15) / 16)), dim3(256), 0, s, a); return; }
+        if (st <= 8) { hipLaunchKernelGGL((lm1_gemv16_kernel<true, 2, 1, 4, true>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a); return; }
+        if (st <= 32 && pro == LM1_PRO_NONE) { hipLaunchKernelGGL((lm1_gemv16_kernel<true, 4, 1, 8, true>), dim3((unsigned)((N + 3) / 4)), dim3(512), 0, s, a); return; }
+    }
+    if (!h16 && m->wide32 && kp_of(K) % 64 == 0 && kp_of(K) <= 1024 && N >= 2048) {      // fp32 matrices, whole rows per lane group, 16 rows per workgroup
+        hipLaunchKernelGGL((lm1_gemv16_kernel<false, 16, 1, 4, false>), dim3((unsigned)((N + 15) / 16)), dim3(256), 0, s, a); return;
+    }
     if (h16) {
-        if (steps <= 16) hipLaunchKernelGGL((lm1_gemv_kernel<4, 4, true>), grid, dim3(256), 0, s, a);
-        else if (pro == LM1_PRO_NONE && N <= 2048) hipLaunchKernelGGL((lm1_gemv_kernel<8, 8, true>), grid, dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((lm1_gemv_kernel<8, 4, true>), grid, dim3(256), 0, s, a);
+        if (steps <= 16) LM1_GEMV_R(4, 4, true);
+        else if (pro == LM1_PRO_NONE && N <= 2048) LM1_GEMV_R(8, 8, true);
+        else LM1_GEMV_R(8, 4, true);
         return;
     }
-    if (steps <= 16) hipLaunchKernelGGL((lm1_gemv_kernel<4, 4>), grid, dim3(256), 0, s, a);
-    else if (pro == LM1_PRO_NONE && N <= 2048) hipLaunchKernelGGL((lm1_gemv_kernel<8, 8>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((lm1_gemv_kernel<8, 4>), grid, dim3(256), 0, s, a);
+    if (steps <= 16) LM1_GEMV_R(4, 4, false);
+    else if (pro == LM1_PRO_NONE && N <= 2048) LM1_GEMV_R(8, 8, false);
+    else LM1_GEMV_R(8, 4, false);
+#undef LM1_GEMV_R
+#undef LM1_GEMV
 }
 
 // everything of a step after its first kernel
@@ -405,6 +529,10 @@ cv_lm1* cv_lm1_create(const cv_lm1_config* c, const cv_lm1_layer_weights* layers
         m->ff.ensure((size_t)c->ffn * 4); m->part.ensure((size_t)c->heads * LM1_SPLITS * 66 * 4);
         CV_HIP(hipMemset(m->dyn.p, 0, sizeof(Lm1Dyn)));
         if (const char* e = getenv("CV_LM1_GRAPH")) m->use_graph = atoi(e) != 0;
+        if (const char* e = getenv("CV_LM1_WIDE16")) m->wide16 = atoi(e) != 0;
+        if (const char* e = getenv("CV_LM1_WIDE")) m->wide32 = atoi(e) != 0;
+        if (const char* e = getenv("CV_LM1_ROWS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) m->rows32 = v; }         // A/B knobs (options "gemv_rows" / "gemv_rows16")
+        if (const char* e = getenv("CV_LM1_ROWS16")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) m->rows16 = v; }
     });
     if (rc != 0) { delete m; return nullptr; }
     return m;
@@ -548,6 +676,17 @@ int cv_lm1_set_option(cv_lm1* m, const char* name, int32_t value) {
         CV_CHECK(m && name, "cv_lm1_set_option: null argument");
         const std::string n(name);
         if (n == "graph") m->use_graph = value != 0;
+        else if (n == "gemv16_wide" || n == "gemv_wide") {
+            std::lock_guard<std::recursive_mutex> lk(runtime_lock());
+            if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+            (n == "gemv_wide" ? m->wide32 : m->wide16) = value != 0;
+        }
+        else if (n == "gemv_rows" || n == "gemv_rows16") {
+            CV_CHECK(value == 1 || value == 2 || value == 4, "cv_lm1_set_option: gemv_rows must be 1, 2 or 4");
+            std::lock_guard<std::recursive_mutex> lk(runtime_lock());
+            if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+            (n == "gemv_rows" ? m->rows32 : m->rows16) = value;
+        }
         else CV_CHECK(false, "cv_lm1_set_option: unknown option");
     });
 }

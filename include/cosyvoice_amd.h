@@ -407,7 +407,9 @@ int cv_lm1_decode_begin(cv_lm1* m, const float* x_row, int32_t pos, const cv_sam
                         int32_t n_uniforms, void* stream);
 int cv_lm1_decode(cv_lm1* m, int32_t n_steps, int32_t* out_tokens, int32_t* n_out, int32_t* finished, void* stream);
 int64_t cv_lm1_stat(const cv_lm1* m, const char* name);            /* "steps", "graph_replays", "launches_per_step"; -1 for an unknown name */
-int cv_lm1_set_option(cv_lm1* m, const char* name, int32_t value); /* "graph" (env CV_LM1_GRAPH): 1 replays the step as a hipGraph, 0 (default: measured 3 % faster per token) launches it kernel by kernel */
+int cv_lm1_set_option(cv_lm1* m, const char* name, int32_t value); /* "graph" (env CV_LM1_GRAPH): 1 replays the step as a hipGraph, 0 (default: measured 3 % faster per token) launches it kernel by kernel;
+                                                                     * "gemv_rows" / "gemv_rows16" (1 | 2 | 4; env CV_LM1_ROWS / CV_LM1_ROWS16): output rows per 16-lane group of the decode GEMVs over
+                                                                     * fp32 / bf16 matrices - the same bits, a different split of the rows over workgroups */
 
 #ifdef __cplusplus
 }

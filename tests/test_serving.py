@@ -3,6 +3,7 @@
 import dataclasses
 import io
 import threading
+import time
 import wave
 
 import numpy as np
@@ -500,16 +501,25 @@ def test_solo_retry_starts_from_the_cache_the_chunk_started_from_even_when_the_m
             for i, o in enumerate(outs):
                 on_ready(i, o)
 
-    fm = Cv3Like(scripts)
-    sch = StreamScheduler(fm, slots=8, step_chunk=4)
-    try:
-        got = [None] * 3
-        th = [threading.Thread(target=lambda i=i: got.__setitem__(i, [o["tts_speech"].shape[1] // 960 for o in sch.submit(stream=True, **_fake_req(1))])) for i in range(3)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        assert got == [[7, 10, 20, 10]] * 3, got
-        assert fm.n_batches >= 1 and not sch._reqs and not fm.hift_cache_dict
-    finally:
-        sch.shutdown()
+    shared = 0
+    for attempt in range(8):                                        # whether three streams' chunks meet in ONE pass is a matter of thread timing (a loaded machine can serve them
+        fm = Cv3Like(scripts)                                       # one by one): every attempt must be served correctly, and one of them must have gone through a shared pass
+        sch = StreamScheduler(fm, slots=8, step_chunk=4)
+        try:
+            got = [None] * 3
+            th = [threading.Thread(target=lambda i=i: got.__setitem__(i, [o["tts_speech"].shape[1] // 960 for o in sch.submit(stream=True, **_fake_req(1))])) for i in range(3)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            assert got == [[7, 10, 20, 10]] * 3, got
+            deadline = time.time() + 5.0                            # (a worker hands the last chunk over BEFORE it drops the request's state: the client can be back first)
+            while (sch._reqs or fm.hift_cache_dict) and time.time() < deadline:
+                time.sleep(0.01)
+            assert not sch._reqs and not fm.hift_cache_dict
+            shared += getattr(fm, "n_batches", 0)
+        finally:
+            sch.shutdown()
+        if shared:
+            break
+    assert shared >= 1

@@ -158,6 +158,18 @@ def test_load_takes_reference_state_dict_files(lib, tmp_path):
     torch.manual_seed(1)
     out = next(iter(m.tts(text=g["text"], flow_embedding=g["embedding"], llm_embedding=g["embedding"], stream=False)))["tts_speech"]
     assert out.shape == (1, int(21 / 50 * 22050 / 256) * 256) and torch.isfinite(out).all() and float(out.abs().max()) > 0
+    assert not m.fp16 and not m.llm.w16 and m.flow.precision == "fp32"
+    # fp16=True, the reference's switch for this model (cli/cosyvoice.py:27-56): the LM's matrices as bf16, the estimator in bf16 mode
+    h = CK.CosyVoiceModel()
+    h.load(str(tmp_path / "llm.pt"), str(tmp_path / "flow.pt"), str(tmp_path / "hift.pt"), hift_cfg=HCFG, lib=lib, fp16=True, text_heads=CFG.text_heads,
+           llm_heads=CFG.llm_heads, enc_heads=CFG.flow_heads, est_heads=CFG.est_heads)
+    assert h.fp16 and h.llm.w16 and h.flow.precision == "bf16" and h.flow.estimator.precision == "bf16"
+    h.llm.sampling = greedy
+    inf16 = h.llm.inference
+    h.llm.inference = lambda **kw: inf16(**dict(kw, max_token_text_ratio=3, min_token_text_ratio=3))
+    torch.manual_seed(1)
+    out16 = next(iter(h.tts(text=g["text"], flow_embedding=g["embedding"], llm_embedding=g["embedding"], stream=False)))["tts_speech"]
+    assert out16.shape == out.shape and torch.isfinite(out16).all() and float(out16.abs().max()) > 0
 
 
 def test_split3_weights_option(lib):
@@ -333,9 +345,9 @@ def test_device_resident_decode_loop(lib):
 
 
 def test_bf16_weight_mode_streams_the_rounded_matrices(lib):
-    """weight_dtype=torch.bfloat16 (the model's fp16 mode, W16A32): the decode step reads bf16 copies of its matrices (cv_lm1_use_bf16) and must give, bit for bit, the
-    logits of the fp32 step over the bf16-ROUNDED matrices (same lanes, same k order, the bf16 widened exactly); the tokens - host sampler and device loop - are those
-    of the torch-eager port over the rounded state dict."""
+    """weight_dtype=torch.bfloat16 (the model's fp16 mode, W16A32): the decode step reads bf16 copies of its matrices (cv_lm1_use_bf16).  With the fp32 kernels' lane
+    layout (option gemv16_wide = 0) it must give, bit for bit, the logits of the fp32 step over the bf16-ROUNDED matrices (same lanes, same k order, the bf16 widened
+    exactly); the default layout agrees to fp32 rounding; the tokens - host sampler and device loop - are those of the torch-eager port over the rounded state dict."""
     g = gold("cv1k_llm")
     kw = dict(text=g["text"], text_len=t(7), prompt_text=g["prompt_text"], prompt_text_len=t(4), prompt_speech_token=g["prompt_speech_token"],
               prompt_speech_token_len=t(9), embedding=g["embedding"])
@@ -345,12 +357,17 @@ def test_bf16_weight_mode_streams_the_rounded_matrices(lib):
     rounded = lm16.sd
     assert not torch.equal(rounded["llm_decoder.weight"], sd["llm_decoder.weight"]) and torch.equal(rounded["llm_decoder.bias"], sd["llm_decoder.bias"])
     lm32 = CK.TransformerLM(rounded, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling=greedy, lib=lib)          # fp32 storage of the same values
+    lm16n = CK.TransformerLM(sd, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling=greedy, lib=lib, weight_dtype=torch.bfloat16)
+    lm16n.set_step_option("gemv16_wide", 0)                       # the fp32 kernels' lane layout over the bf16 matrices: their bits
     seen = {}
-    for name, lm in (("w16", lm16), ("w32", lm32)):
+    for name, lm in (("w16", lm16), ("w16n", lm16n), ("w32", lm32)):
         rows = []
         lm.sampling = lambda scores, decoded, sampling, _r=rows: (_r.append(scores.clone()), int(scores.argmax().item()))[1]
         seen[name] = (list(lm.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw)), torch.stack(rows))
-    assert seen["w16"][0] == seen["w32"][0] and torch.equal(seen["w16"][1], seen["w32"][1])
+    assert seen["w16n"][0] == seen["w32"][0] and torch.equal(seen["w16n"][1], seen["w32"][1])
+    # the default layout (lm1_gemv16_kernel: 16-byte loads, whole rows per lane group) sums a row in another k order: the same tokens, logits to fp32 rounding
+    assert seen["w16"][0] == seen["w32"][0] and not torch.equal(seen["w16"][1], seen["w32"][1])
+    torch.testing.assert_close(seen["w16"][1], seen["w32"][1], rtol=1e-4, atol=1e-4)
     ref = C1.TransformerLM(rounded, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling=greedy)
     want = list(ref.inference(max_token_text_ratio=6, min_token_text_ratio=2, **kw))
     assert seen["w16"][0] == want and len(want) >= 14
@@ -394,3 +411,50 @@ def test_interleaved_device_loops_do_not_share_loop_state(lib):
     lm.sampling = keep
     got_d += list(d)
     assert got_d == g["tokens_greedy"].tolist()
+
+
+def test_gemv_rows_option_keeps_the_bits(lib):
+    """cv_lm1 options "gemv_rows" / "gemv_rows16": 1, 2 or 4 output rows per 16-lane group of the decode GEMVs - a row's products and their order do not depend on it."""
+    g = gold("cv1k_llm")
+    kw = dict(text=g["text"], text_len=t(7), prompt_text=g["prompt_text"], prompt_text_len=t(4), prompt_speech_token=g["prompt_speech_token"],
+              prompt_speech_token_len=t(9), embedding=g["embedding"])
+    sd = W.make_cv1_llm(CFG)
+    for dtype, opt in ((None, "gemv_rows"), (torch.bfloat16, "gemv_rows16")):
+        seen = {}
+        for rows in (1, 2, 4):
+            lm = CK.TransformerLM(sd, text_heads=CFG.text_heads, llm_heads=CFG.llm_heads, sampling=greedy, lib=lib, weight_dtype=dtype)
+            if dtype is not None:
+                lm.set_step_option("gemv16_wide", 0)              # (the rows option belongs to lm1_gemv_kernel)
+            lm.set_step_option(opt, rows)
+            logits = []
+            lm.sampling = lambda scores, decoded, sampling, _r=logits: (_r.append(scores.clone()), int(scores.argmax().item()))[1]
+            seen[rows] = (list(lm.inference(max_token_text_ratio=3, min_token_text_ratio=2, **kw)), torch.stack(logits))
+        assert seen[1][0] == seen[2][0] == seen[4][0] and torch.equal(seen[1][1], seen[2][1]) and torch.equal(seen[1][1], seen[4][1])
+
+
+def test_wide_bf16_gemv_kernels_at_a_middle_size(lib):
+    """lm1_gemv16_kernel's other two forms, which the 128-wide test model does not reach: whole rows per lane group over 16 rows per workgroup (N >= 2048: the
+    [4 d][d] and [ffn][d] products) and K split over 8 waves (the [d][ffn] product, ffn > 1024) - a 2-layer model with d = 512, ffn = 1280: tokens of the torch-eager
+    port over the rounded state dict, logits of the narrow layout to fp32 rounding."""
+    import dataclasses
+    cfg = dataclasses.replace(CFG, llm_dim=512, text_heads=8, text_ffn=128, text_blocks=1, llm_heads=8, llm_ffn=1280, llm_blocks=2)
+    sd = W.make_cv1_llm(cfg)
+    gen = torch.Generator().manual_seed(5)
+    text = torch.randint(0, cfg.text_vocab, (1, 6), generator=gen, dtype=torch.int32)
+    e0 = torch.zeros(1, 0, dtype=torch.int32)
+    kw = dict(text=text, text_len=t(6), prompt_text=e0, prompt_text_len=t(0), prompt_speech_token=e0, prompt_speech_token_len=t(0), embedding=torch.randn(1, cfg.spk_dim, generator=gen),
+              max_token_text_ratio=2, min_token_text_ratio=2)
+    seen = {}
+    for wide in (1, 0, 32):                                        # 32: fp32 storage of the rounded values on the fp32 form of the wide kernel (option gemv_wide)
+        lm = CK.TransformerLM(sd if wide != 32 else seen[1][2], text_heads=cfg.text_heads, llm_heads=cfg.llm_heads, sampling=greedy, lib=lib,
+                              weight_dtype=torch.bfloat16 if wide != 32 else None)
+        assert lm.fused_step
+        lm.set_step_option("gemv16_wide" if wide != 32 else "gemv_wide", 1 if wide else 0)
+        rows = []
+        lm.sampling = lambda scores, decoded, sampling, _r=rows: (_r.append(scores.clone()), int(scores.argmax().item()))[1]
+        seen[wide] = (list(lm.inference(**kw)), torch.stack(rows), lm.sd)
+    ref = C1.TransformerLM(seen[1][2], text_heads=cfg.text_heads, llm_heads=cfg.llm_heads, sampling=greedy)
+    assert seen[1][0] == seen[0][0] == seen[32][0] == list(ref.inference(**kw)) and len(seen[1][0]) == 12
+    torch.testing.assert_close(seen[1][1], seen[0][1], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(seen[32][1], seen[0][1], rtol=1e-4, atol=1e-4)
+    assert not torch.equal(seen[1][1], seen[0][1]) and not torch.equal(seen[32][1], seen[0][1])
