@@ -33,7 +33,7 @@ def pytest_cmdline_main(config):
 # start last and leave five workers idle behind them (measured file totals under the emulator, seconds: round-4 `--durations=30` run).
 _HEAVY_FIRST = ["test_fullsize_pinned_model.py", "test_flow_big.py", "test_fullsize_pinned.py", "test_flow.py", "test_dropin_reference.py", "test_model_cv3.py", "test_llm_ras.py", "test_model_batch_padded.py", "test_model_cv3_filter.py", "test_causal_hift.py",
                 "test_zz_llm_batch.py", "test_dropin_reference_cv1.py", "test_bench_cv1_dryrun.py", "test_zzz_cosyvoice1_hip_model.py", "test_model_load.py", "test_model.py", "test_model_batch.py",
-                "test_model_cv3_batch.py", "test_dit.py", "test_zzz_cosyvoice1_hip.py", "test_zzz_cosyvoice1_hip_hift.py", "test_zz_fullsize.py", "test_hift.py", "test_llm.py"]
+                "test_model_cv3_batch.py", "test_dit.py", "test_zzz_cosyvoice1_hip.py", "test_zzz_cosyvoice1_hip_r6.py", "test_zzz_cosyvoice1_hip_hift.py", "test_zz_fullsize.py", "test_hift.py", "test_llm.py"]
 
 
 def pytest_collection_modifyitems(config, items):
