@@ -52,7 +52,7 @@ struct Lm1GemvArgs {
 template <int NW, typename F>
 static __device__ __forceinline__ void lm1_gemv_prologue(const Lm1GemvArgs& p, float* xs, float* mw, int steps, F&& issue_weights) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (p.pro != LM1_PRO_LN) issue_weights();                   // (the LayerNorm prologue requests its row first: its statistics then run under the weight loads)
+    // (every prologue requests its own small operands BEFORE the caller's weight rows: vmcnt retires in issue order, what the prologue waits for must not queue behind the weight stream)
     // ---- prologue: the input vector into LDS, zero beyond K up to the last 64-float step
     if (p.pro == LM1_PRO_LN) {
         // norm_rows_kernel's register path (C <= 1024, C % 4 == 0), every wave on the whole row; wave w parks chunk w
@@ -94,10 +94,22 @@ static __device__ __forceinline__ void lm1_gemv_prologue(const Lm1GemvArgs& p, f
     } else if (p.pro == LM1_PRO_MERGE) {
         // x[h * 64 + d] = sum_s acc_s[d] * (e^(m_s - M) / sum_s l_s e^(m_s - M)): the key ranges of one head's softmax, in range order.  The LM1_SPLITS weights of a
         // head are made ONCE per workgroup (one lane per (head, range), the head's lanes combine through shuffles) and read back from LDS - not once per element.
+        // Round 6: a lane's partial accumulators (up to 4 elements x LM1_SPLITS ranges) are REQUESTED before the weights are made - they do not depend on them, and
+        // behind the barrier they were a second global round trip on the critical path of the launch (5.5 us for a 2 - 4 MB matrix).  Same sums, same order.
+        constexpr int EPT = 4;
+        const int hs = min(tid, (p.K >> 6) * LM1_SPLITS - 1);
+        const float* ph = p.x + (long long)hs * 66;
+        const float ms = ph[0], ls = ph[1];                      // first in the queue: the weights' shuffles start when these two land
+        float as[EPT][LM1_SPLITS];
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = min(tid + i * (int)blockDim.x, p.K - 1);
+            const float* pa = p.x + (long long)(e >> 6) * LM1_SPLITS * 66 + 2 + (e & 63);
+#pragma unroll
+            for (int s = 0; s < LM1_SPLITS; ++s) as[i][s] = pa[s * 66];
+        }
+        issue_weights();
         {
-            const int hs = min(tid, (p.K >> 6) * LM1_SPLITS - 1);
-            const float* ph = p.x + (long long)hs * 66;
-            const float ms = ph[0], ls = ph[1];
             float M = ms;
 #pragma unroll
             for (int o = 1; o < LM1_SPLITS; o <<= 1) M = fmaxf(M, __shfl_xor(M, o));
@@ -108,19 +120,33 @@ static __device__ __forceinline__ void lm1_gemv_prologue(const Lm1GemvArgs& p, f
             if (tid < (p.K >> 6) * LM1_SPLITS) mw[tid] = w / L;
         }
         __syncthreads();
-        for (int e = tid; e < steps * 64; e += blockDim.x) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = tid + i * (int)blockDim.x;
+            if (e < steps * 64) {
+                float o = 0.f;
+                if (e < p.K) {
+#pragma unroll
+                    for (int s = 0; s < LM1_SPLITS; ++s) o += as[i][s] * mw[(e >> 6) * LM1_SPLITS + s];
+                }
+                xs[e] = o;
+            }
+        }
+        for (int e = tid + EPT * (int)blockDim.x; e < steps * 64; e += blockDim.x) {      // (beyond 4 elements per lane: not reached at the supported widths, d <= 1024)
             float o = 0.f;
             if (e < p.K) {
                 const float* pa = p.x + (long long)(e >> 6) * LM1_SPLITS * 66 + 2 + (e & 63);
-                float as[LM1_SPLITS];
+                float a2[LM1_SPLITS];
 #pragma unroll
-                for (int s = 0; s < LM1_SPLITS; ++s) as[s] = pa[s * 66];
+                for (int s = 0; s < LM1_SPLITS; ++s) a2[s] = pa[s * 66];
 #pragma unroll
-                for (int s = 0; s < LM1_SPLITS; ++s) o += as[s] * mw[(e >> 6) * LM1_SPLITS + s];
+                for (int s = 0; s < LM1_SPLITS; ++s) o += a2[s] * mw[(e >> 6) * LM1_SPLITS + s];
             }
             xs[e] = o;
         }
     } else {
+        // (requesting the vector BEFORE the weight rows - llm_kernels.h XFIRST - measured the same on this model: 327 vs 321 us per token, round 6; the weights go first)
+        issue_weights();
         for (int e = tid * 4; e < steps * 64; e += 256 * NW) {
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < p.K) t = *reinterpret_cast<const float4*>(p.x + e);           // K % 4 == 0
