@@ -118,6 +118,8 @@ struct cv_flow {
     // 4 = 64x192; "attn_waves": 2 | 4 waves (32 | 64 queries) per workgroup; "attn_kt": 64-key tiles per iteration (1 | 2)
     int flow_ntile = 0;                // "flow_ntile": N tiles per workgroup of the LayerNorm-prologue GEMMs: 0 = by grid size (two when that makes one round), 1, 2 (env CV_FLOW_NTILE)
     int flow_tile = 0, attn_waves = 4, attn_kt = 1, attn_ks = 2;   // "attn_ks": key splits inside a 64-query workgroup (2 = 8 waves, 128 keys per iteration)
+    int res_tile = 1;      // tile of the small-pass residual GEMMs (out-projection, FF2): 1 = 32 x 32 (344 workgroups at M = 1348: 37.5 -> 36.1 ms per flow.inference, round 6), 0 = 32 x 64 (option "res_tile", env CV_FLOW_RES_TILE)
+    int attn32_waves = 0;  // waves (x 32 queries) per workgroup of attn_flow32_kernel: 0 = 4 (the measured choice at every size), 2 | 4 (option "attn32_waves", env CV_FLOW_ATTN32_WAVES)
     int attn32 = 1;        // round 6: every bf16 attention of the estimator on attn_flow32_kernel (flow_attn32.h: 32 queries per wave on 32x32x16 tiles); 0 = attn_flow_kernel as configured above
     DevBuf t_val, t_sin, t_h, t_emb, t_mlp;                                                   // time embeddings
     DevBuf f_tok, f_h, f_mu, f_spk, f_spkn, f_cond, f_x, f_ones;                              // inference glue
@@ -296,6 +298,8 @@ static void flow_finalize(cv_flow* m) {
         if (const char* e = getenv("CV_FLOW_EAGER_STREAMS")) m->eager_streams = atoi(e) >= 2 ? 2 : 1;
         if (const char* e = getenv("CV_FLOW_TAIL")) m->fused_tail = e[0] != '0';
     }
+    if (const char* e = getenv("CV_FLOW_RES_TILE")) m->res_tile = atoi(e) == 1;
+    if (const char* e = getenv("CV_FLOW_ATTN32_WAVES")) { const int v = atoi(e); if (v == 0 || v == 2 || v == 4) m->attn32_waves = v; }
     if (const char* e = getenv("CV_FLOW_BAND_QKV")) m->band_qkv = e[0] != '0';
     if (const char* e = getenv("CV_FLOW_LN_QKV")) m->ln_qkv = e[0] != '0';
     if (const char* e = getenv("CV_FLOW_BAND_BM")) m->band_bm = atoi(e);
@@ -310,17 +314,17 @@ static void flow_finalize(cv_flow* m) {
 
 // precision of the Linear / Conv1d products issued by the current entry point (set from the handle's option for the duration of a call)
 static thread_local int tl_bf16_mfma = 0;
-static thread_local int tl_flow_tile = 0, tl_attn_waves = 4, tl_attn_kt = 2, tl_attn_ks = 1, tl_flow_ntile = 0, tl_attn32 = 1;     // tuning knobs of the fused pipeline, per call like the precision
+static thread_local int tl_flow_tile = 0, tl_attn_waves = 4, tl_attn_kt = 2, tl_attn_ks = 1, tl_flow_ntile = 0, tl_attn32 = 1, tl_attn32_waves = 0, tl_res_tile = 1;     // tuning knobs of the fused pipeline, per call like the precision
 static thread_local long long* tl_attn_dbg = nullptr; static thread_local long long* tl_gemm_dbg = nullptr; static thread_local int tl_gemm_dbg_which = 0;
 static thread_local int tl_big_tile0 = 0, tl_big_tile1 = 0, tl_big_persist = -1, tl_big_grid_cap = 0, tl_big_glds = 0, tl_big_lds_epi = 1;
 struct PrecisionScope {
-    int prev, pt, pw, pk, ps, pn, p32, pb0, pb1, pbp, pbc, pbg, pbe;
-    explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves), pk(tl_attn_kt), ps(tl_attn_ks), pn(tl_flow_ntile), p32(tl_attn32), pb0(tl_big_tile0), pb1(tl_big_tile1), pbp(tl_big_persist), pbc(tl_big_grid_cap), pbg(tl_big_glds), pbe(tl_big_lds_epi) {
-        tl_bf16_mfma = m->bf16_mfma; tl_flow_tile = m->flow_tile; tl_attn_waves = m->attn_waves; tl_attn_kt = m->attn_kt; tl_attn_ks = m->attn_ks; tl_flow_ntile = m->flow_ntile; tl_attn32 = m->attn32;
+    int prev, pt, pw, pk, ps, pn, p32, p32w, prt, pb0, pb1, pbp, pbc, pbg, pbe;
+    explicit PrecisionScope(const cv_flow* m) : prev(tl_bf16_mfma), pt(tl_flow_tile), pw(tl_attn_waves), pk(tl_attn_kt), ps(tl_attn_ks), pn(tl_flow_ntile), p32(tl_attn32), p32w(tl_attn32_waves), prt(tl_res_tile), pb0(tl_big_tile0), pb1(tl_big_tile1), pbp(tl_big_persist), pbc(tl_big_grid_cap), pbg(tl_big_glds), pbe(tl_big_lds_epi) {
+        tl_bf16_mfma = m->bf16_mfma; tl_flow_tile = m->flow_tile; tl_attn_waves = m->attn_waves; tl_attn_kt = m->attn_kt; tl_attn_ks = m->attn_ks; tl_flow_ntile = m->flow_ntile; tl_attn32 = m->attn32; tl_attn32_waves = m->attn32_waves; tl_res_tile = m->res_tile;
         tl_big_tile0 = m->big_tile0; tl_big_tile1 = m->big_tile1; tl_big_persist = m->big_persist; tl_big_grid_cap = m->big_grid_cap; tl_big_glds = m->big_glds; tl_big_lds_epi = m->big_lds_epi; tl_attn_dbg = m->attn_dbg_on ? const_cast<cv_flow*>(m)->attn_dbg.as<long long>() : nullptr;
         tl_gemm_dbg = m->gemm_dbg_on ? const_cast<cv_flow*>(m)->gemm_dbg.as<long long>() : nullptr; tl_gemm_dbg_which = m->gemm_dbg_on;
     }
-    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; tl_attn_ks = ps; tl_flow_ntile = pn; tl_attn32 = p32; tl_big_tile0 = pb0; tl_big_tile1 = pb1; tl_big_persist = pbp; tl_big_grid_cap = pbc; tl_big_glds = pbg; tl_big_lds_epi = pbe; tl_attn_dbg = nullptr; tl_gemm_dbg = nullptr; tl_gemm_dbg_which = 0; }
+    ~PrecisionScope() { tl_bf16_mfma = prev; tl_flow_tile = pt; tl_attn_waves = pw; tl_attn_kt = pk; tl_attn_ks = ps; tl_flow_ntile = pn; tl_attn32 = p32; tl_attn32_waves = p32w; tl_res_tile = prt; tl_big_tile0 = pb0; tl_big_tile1 = pb1; tl_big_persist = pbp; tl_big_grid_cap = pbc; tl_big_glds = pbg; tl_big_lds_epi = pbe; tl_attn_dbg = nullptr; tl_gemm_dbg = nullptr; tl_gemm_dbg_which = 0; }
 };
 
 // ---- generic conv/linear on channel-last activations -----------------------------------------------------------------
@@ -535,6 +539,8 @@ static void gemm_bf16_res(const Lin& l, const bf16_t* A, int lda, int M, float* 
     FlowGemmArgs a{};
     a.A = A; a.lda = lda; a.W = reinterpret_cast<const bf16_t*>(l.w); a.Kp = l.Kp; a.bias = l.b; a.M = M; a.N = l.N; a.K = l.K;
     a.C = C; a.ldc = l.N; a.res = res; a.n_row = l.N;
+    // 32 x 64 tiles; 32 x 32 (option "res_tile" = 1; the same k order per element: the same bits) doubles the workgroups of these N = 256 GEMMs (172 at M = 1348)
+    if (tl_res_tile == 1 && l.N % 32 == 0) { hipLaunchKernelGGL((flow_gemm_kernel<32, 32, 0, 1>), dim3(((M + 31) / 32) * ((l.N + 31) / 32)), dim3(256), 0, s, a); return; }
     const unsigned g = ((M + 31) / 32) * ((l.N + 63) / 64);
     hipLaunchKernelGGL((flow_gemm_kernel<32, 64, 0, 1>), dim3(g), dim3(256), 0, s, a);
 }
@@ -686,7 +692,15 @@ static void attn_flow(const bf16_t* qk, int ld, int inner, const bf16_t* vt, lon
     a.q = qk; a.k = qk + inner; a.ld = ld; a.vt = vt; a.vt_batch = vt_batch; a.ldt = ldt; a.o = o; a.ldo = inner;
     a.B = B; a.H = H; a.T = T; a.scale = 0.125f; a.mask_mode = chunk > 0 ? MASK_CHUNK : MASK_NONE; a.chunk = chunk;
     const dim3 g2((unsigned)(((T + 31) / 32) * H * B)), g4((unsigned)(((T + 63) / 64) * H * B));
-    if (tl_attn32) { hipLaunchKernelGGL((attn_flow32_kernel<4, 3>), dim3((unsigned)(((T + 127) / 128) * H * B)), dim3(256), 0, s, a); return; }
+    if (tl_attn32) {
+        // 128 queries per workgroup (4 waves).  64 (2 waves; option "attn32_waves" = 2) fill more CUs for a single utterance (176 instead of 96 workgroups at T = 674) and
+        // measured SLOWER: 39.2 vs 37.5 ms per flow.inference (tools/probe_flow_r6b.py) - each K / V tile then serves half the queries.  Same bits either way.
+        const unsigned g128 = (unsigned)(((T + 127) / 128) * H * B);
+        const int nw = tl_attn32_waves == 2 ? 2 : 4;
+        if (nw == 2) hipLaunchKernelGGL((attn_flow32_kernel<2, 3>), dim3((unsigned)(((T + 63) / 64) * H * B)), dim3(128), 0, s, a);
+        else hipLaunchKernelGGL((attn_flow32_kernel<4, 3>), dim3(g128), dim3(256), 0, s, a);
+        return;
+    }
 #ifdef CV_BUILD_EXPERIMENTS      // attn_flow_kernel (flow_fused.h), the attention of rounds 2-5 in its workgroup shapes: superseded by attn_flow32_kernel, kept for A/B builds (option attn32 = 0)
     // 128-query workgroups (QG = 2): the same arithmetic per query as attn_flow_kernel<4, 2, 2>, so only that default may be replaced
     if (big && tl_attn_ks == 2) { hipLaunchKernelGGL((attn_flow_kernel<4, 2, 2, 2>), dim3((unsigned)(((T + 127) / 128) * H * B)), dim3(512), 0, s, a); return; }
@@ -1140,6 +1154,8 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "bf16_mfma") { m->bf16_mfma = value != 0; drop_graphs(m); }      // captured graphs bake the kernel choice
         else if (std::string(name) == "flow_tile") { CV_CHECK(value >= 0 && value <= 4, "flow_tile must be 0..4"); m->flow_tile = value; drop_graphs(m); }
         else if (std::string(name) == "attn32") { need_experiments(value == 0, "flow option attn32 = 0"); m->attn32 = value != 0; drop_graphs(m); }
+        else if (std::string(name) == "res_tile") { CV_CHECK(value == 0 || value == 1, "res_tile must be 0 or 1"); m->res_tile = value; drop_graphs(m); }
+        else if (std::string(name) == "attn32_waves") { CV_CHECK(value == 0 || value == 2 || value == 4, "attn32_waves must be 0, 2 or 4"); m->attn32_waves = value; drop_graphs(m); }
         else if (std::string(name) == "attn_ks") { CV_CHECK(value >= 1 && value <= 4, "attn_ks must be 1 .. 4"); m->attn_ks = value; drop_graphs(m); }
         else if (std::string(name) == "attn_kt") { CV_CHECK(value == 1 || value == 2, "attn_kt must be 1 or 2"); m->attn_kt = value; drop_graphs(m); }
         else if (std::string(name) == "attn_waves") { CV_CHECK(value == 2 || value == 4, "attn_waves must be 2 or 4"); m->attn_waves = value; drop_graphs(m); }

@@ -202,7 +202,8 @@ int cv_flow_finalize(cv_flow* m);
  * per band by the row count of the pass - 32 / 48 / 64, csrc/flow.hip::band_rows_for; 32 | 48 | 64 forces), "band_pipe" (2: the feed-forward chunks of a 48- / 32-row band
  * as a software pipeline - MFMA slices between the GELU pieces; 1: 48-row bands only, 0: never), "eager_streams" (1; 2: the batch rows of a pass that runs
  * eager as two launch chains on two streams - faster in isolation, slower next to the model's token2wav lanes, profiles/r5_band_qkv.txt).  Every combination is
- * bit-identical per utterance. */
+ * bit-identical per utterance.  Round 6: "ln_qkv" (1), "attn32_waves" (0 = 4 | 2 | 4: 128- or 64-query workgroups of the flash attention), "res_tile" (1: the
+ * small-pass residual GEMMs on 32 x 32 tiles, 0: 32 x 64). */
 int cv_flow_set_option(cv_flow* m, const char* name, int32_t value);
 /* "graph_captures" (Euler-solve graphs captured so far), "graphs_cached" (held now; option "graph_cap", default 32) - test / monitoring hook, no reference counterpart */
 int cv_flow_get_stat(cv_flow* m, const char* name, int64_t* value);

@@ -20,7 +20,7 @@ def pytest_cmdline_main(config):
         return None
     if (config.getoption("markexpr", "") or "").strip() == "not gpu" and getattr(config.option, "numprocesses", None) is None \
             and not os.environ.get("CV_TEST_SERIAL") and not os.environ.get("PYTEST_XDIST_WORKER"):
-        config.option.numprocesses = 6
+        config.option.numprocesses = max(2, min(8, os.cpu_count() or 6))      # round 6: one worker per core (the suite is ~6500 core-seconds of single-threaded emulator work)
         config.option.dist = "loadfile"
         # xdist would re-sort the files by their NUMBER of tests (--loadscope-reorder, on by default), which puts the heavy single-test files (a whole model under the
         # emulator each) last; pytest_collection_modifyitems below orders the files by measured weight instead
@@ -58,7 +58,7 @@ def pytest_configure(config):
         # CPU suite under pytest-xdist (6 workers): the emulator is single-threaded and the oracle's torch ops are small, so one or two intra-op
         # threads per worker are enough - 6 workers x all cores each only fight over the machine
         import torch
-        torch.set_num_threads(max(1, min(2, (os.cpu_count() or 6) // 6)))
+        torch.set_num_threads(1)
 
 
 @pytest.fixture(scope="session")

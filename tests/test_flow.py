@@ -621,3 +621,27 @@ def test_two_stream_estimator_is_bit_identical(lib, precision):
     ea, eb = (f.inference_batch([items[0], items[3]]) for f in flows)
     for p, q in zip(ea, eb):
         assert torch.equal(p.cpu(), q.cpu())
+
+
+def test_attention_workgroup_size_keeps_the_bits(lib):
+    """bf16 mode: attn_flow32_kernel with 2 or 4 waves (64 / 128 queries) per workgroup (option attn32_waves; 0 = 4, the measured choice) computes every query with
+    the same operations in the same order, and the residual GEMMs on 32 x 32 or 32 x 64 tiles (option res_tile) every element in the same k order: bit-identical
+    estimator outputs, both mask modes, a time axis that ends inside a 32-query group."""
+    import ctypes as C
+    import dataclasses
+    cfg = dataclasses.replace(W.tiny()[1], est_ch=128, est_heads=2, est_mid=1, chunk=13)
+    sd = W.make_flow(cfg)
+    flow = CausalMaskedDiffWithXvec(sd, cfg, lib=lib, precision="bf16")
+    g = torch.Generator().manual_seed(5)
+    for T in (70, 150):
+        x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g); cond = torch.randn(2, 80, T, generator=g)
+        spk = torch.randn(2, 80, generator=g); t = torch.tensor([0.3, 0.3]); mask = torch.ones(2, 1, T)
+        for streaming in (False, True):
+            outs = {}
+            for waves in (0, 2, 4):
+                lib.cv_flow_set_option(flow._h, b"attn32_waves", C.c_int32(waves))
+                outs[waves] = flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu()
+            assert torch.isfinite(outs[2]).all() and torch.equal(outs[2], outs[4]) and torch.equal(outs[0], outs[2])
+            lib.cv_flow_set_option(flow._h, b"res_tile", C.c_int32(0))      # the residual GEMMs on 32 x 64 tiles (the default is 32 x 32): the same k order per element
+            assert torch.equal(flow.decoder.estimator(x, mask, mu, t, spk, cond, streaming=streaming).cpu(), outs[0])
+            lib.cv_flow_set_option(flow._h, b"res_tile", C.c_int32(1))
