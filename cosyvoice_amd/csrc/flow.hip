@@ -131,7 +131,11 @@ struct cv_flow {
     // hipGraph cache of the whole Euler solve, keyed by (T, n_steps, streaming): ~5000 launches per utterance become one replay.
     // A key is captured the second time it is seen (streaming requests change T every chunk and would only pay the instantiation).
     bool use_graph = true;
-    int graph_max_rows = 3000;         // "graph_max_rows": passes of at least this many estimator rows (2 x utterances x T) are not captured (0 = capture everything); CV_FLOW_GRAPH_MAX_ROWS
+    int graph_max_rows = 1000;         // "graph_max_rows": passes of at least this many estimator rows (2 x utterances x T) are not captured (0 = capture everything); CV_FLOW_GRAPH_MAX_ROWS.
+                                       // 3000 until round 6; 1000 since: at 1348 rows (one utterance of U10) the launches average 9 us against the host's ~4 us per launch, the host stays
+                                       // ahead and replaying the 3640-node graph costs more than issuing it - flow.inference 36.3 -> 34.9 ms, the bench 177.3 -> 176.0 ms per U10; the
+                                       // chunks of a streaming request (460 rows and up: 5 - 7 us launches) keep their graphs (8 clients: 217.7 vs 217.7 audio-s/s, p50 102.7 vs 103.1 ms);
+                                       // no graphs at all costs the 8-client run 3 ms of p50 (profiles/r6_flow_graph_threshold.txt)
     int bf16_mfma = 0;                 // 1: Linear / Conv1d products on the bf16 MFMA (activations rounded to bf16 in LDS), 0: fp32-accurate (three-term split for bf16 weights, fp32 MFMA chain otherwise)
     std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
     std::map<std::tuple<int, int, int>, unsigned long long> graph_used; unsigned long long graph_clock = 0;   // last use per key (least-recently-used eviction)
