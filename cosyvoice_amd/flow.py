@@ -215,7 +215,18 @@ class CausalMaskedDiffWithXvec:
     def clone(self):
         """A second instance over the SAME device weights with its own library handle (workspaces, Euler graphs): one per token2wav lane
         of CosyVoice2Model, so that flow inferences of different requests run concurrently on different HIP streams."""
-        return type(self)(None, self.cfg, lib=self.lib, n_timesteps=self.n_timesteps, precision=self.precision, _tensors=self._tensors)
+        c = type(self)(None, self.cfg, lib=self.lib, n_timesteps=self.n_timesteps, precision=self.precision, _tensors=self._tensors)
+        if getattr(self, "_graph_rows", None) is not None:
+            c.set_graph_rows(self._graph_rows)
+        return c
+
+    def set_graph_rows(self, n):
+        """Passes of fewer than n estimator rows (2 x utterances x frames) replay a captured hipGraph of their Euler solve, larger ones are issued launch by launch
+        (cv_flow option "graph_max_rows"; 1 = never capture, 0 = always).  The library's own default is 1000.  A single request is fastest without graphs (the host
+        stays ahead of the launches: first chunk 56.5 -> 54.6 ms, U10 177.7 -> 175.5 ms); eight streaming clients are served best WITH them (their host threads are
+        busy: p50 101.5 vs 104.9 ms) - so CosyVoice2Model asks for 1 and StreamScheduler for 3000 while it runs (profiles/r6_flow_graph_threshold.txt)."""
+        self._graph_rows = int(n)
+        self.lib.cv_flow_set_option(self._h, b"graph_max_rows", C.c_int32(int(n)))
 
     def __del__(self):
         try:

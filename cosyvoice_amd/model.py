@@ -115,11 +115,21 @@ class CosyVoice2Model:
             if self.flow is None:
                 break
         self.n_lanes = n
+        self.set_flow_graph_rows(getattr(self, "flow_graph_rows", int(os.environ.get("CV_MODEL_GRAPH_ROWS", 1))))      # (the variable: A/B knob)
         if getattr(self, "llm", None) is not None and hasattr(self.llm, "group_streams"):
             # the LM's decode groups (Qwen2LM._groups) borrow the lane streams for their second chain: lanes are idle while tts_batch decodes, and the process stays
             # within its four hardware queues (LM stream, default stream, two lanes)
             lanes = list(self._lane_q.queue)
             self.llm.group_streams = [ln.stream for ln in reversed(lanes) if ln.stream is not None] or None
+
+    def set_flow_graph_rows(self, n):
+        """Which flow passes of this model's lanes replay a captured hipGraph (flow.set_graph_rows): 1 = none, the model's default - a request served alone is
+        fastest when its solve is issued launch by launch; a scheduler that serves many concurrent streams sets 3000 (serving.StreamScheduler).  Call while no
+        request is in flight (like set_lanes)."""
+        self.flow_graph_rows = int(n)
+        for ln in list(self._lane_q.queue):
+            if ln.flow is not None and hasattr(ln.flow, "set_graph_rows"):
+                ln.flow.set_graph_rows(self.flow_graph_rows)
 
     @contextmanager
     def _lane(self):

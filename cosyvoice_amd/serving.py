@@ -49,6 +49,10 @@ class StreamScheduler:
         self.chunk_batch = (getattr(model, "flow_batch", 1) if hasattr(model, "token2wav_batch") else 1) if chunk_batch is None else chunk_batch
         self.chunk_batch = max(1, min(8, int(self.chunk_batch)))       # a flow pass takes at most 8 utterances (cv_flow_inference_batch / _ragged)
         self.batched_passes = self.batched_jobs = 0     # passes that carried more than one request, and the requests in them
+        # many concurrent streams: their chunk passes replay captured graphs (a request served alone is faster without them: model.set_flow_graph_rows)
+        self._graph_rows_before = getattr(model, "flow_graph_rows", None)
+        if hasattr(model, "set_flow_graph_rows"):
+            model.set_flow_graph_rows(int(os.environ.get("CV_SERVE_GRAPH_ROWS", 3000)))      # (the variable: A/B knob)
         self._src = queue.Queue()
         self._cv = threading.Condition()
         self._reqs = {}
@@ -116,6 +120,9 @@ class StreamScheduler:
         self._llm_thread.join()
         for t in self._voc_threads:
             t.join()
+        if self._graph_rows_before is not None and hasattr(self.model, "set_flow_graph_rows"):
+            self.model.set_flow_graph_rows(self._graph_rows_before)        # the model goes back to its own policy (requests served one at a time)
+            self._graph_rows_before = None
 
     # ---- LLM thread: continuous batching, tokens streamed per decode chunk ------------------------------------------------------------
     def _on_tokens(self, key, toks, finished, error):

@@ -144,3 +144,33 @@ def test_tts_with_streaming_text(lib, setup):
                                           prompt_text=u["prompt_text"], llm_prompt_speech_token=u["llm_prompt_speech_token"],
                                           flow_prompt_speech_token=u["flow_prompt_speech_token"], prompt_speech_feat=u["prompt_speech_feat"], stream=False)]
     assert len(want) >= 5 and len(out) == 1 and out[0].shape[1] == len(want) * 2 * 480
+
+
+def test_flow_graph_policy_of_the_model_and_the_scheduler(lib, setup):
+    """Round 6: a request served alone is fastest when its flow solve is issued launch by launch, many concurrent streams when their chunk passes replay captured graphs
+    (profiles/r6_flow_graph_threshold.txt): CosyVoice2Model asks every lane's flow handle for graph_max_rows = 1 (new lanes and clones included), StreamScheduler for
+    3000 while it runs and gives the model's own policy back when it shuts down; the audio does not depend on it."""
+    from cosyvoice_amd.serving import StreamScheduler
+    cfgs, sds, u = setup
+    m = _build(lib, cfgs, sds)
+    rows = lambda: [ln.flow._graph_rows for ln in list(m._lane_q.queue)]
+    assert m.flow_graph_rows == 1 and rows() == [1]
+    m.set_lanes(2)
+    assert rows() == [1, 1] and m.flow.clone()._graph_rows == 1
+    req = {k: u[k] for k in ("text", "flow_embedding", "llm_embedding", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat")}
+    alone = torch.cat([o["tts_speech"] for o in m.tts(stream=True, **req)], 1)
+    import ctypes as C
+
+    def captured(flow):
+        v = C.c_int64(0)
+        flow.lib.cv_flow_get_stat(flow._h, b"graph_captures", C.byref(v))
+        return v.value
+    assert sum(captured(ln.flow) for ln in list(m._lane_q.queue)) == 0
+    sch = StreamScheduler(m, slots=2, step_chunk=4)
+    try:
+        assert m.flow_graph_rows == 3000 and rows() == [3000, 3000]
+        served = torch.cat([o["tts_speech"] for o in sch.submit(stream=True, **req)], 1)
+    finally:
+        sch.shutdown()
+    assert m.flow_graph_rows == 1 and rows() == [1, 1]
+    assert served.shape == alone.shape and torch.isfinite(served).all()
