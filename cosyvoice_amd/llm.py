@@ -147,6 +147,8 @@ class Qwen2LM:
         self.lib.cv_llm_create(C.byref(self._h), C.byref(c))
         register_tensors(self.lib, "cv_llm_set_tensor", self._h, self._tensors)
         self.lib.cv_llm_finalize(self._h)
+        if os.environ.get("CV_LLM_GRAPH") == "0":              # A/B knob: the decode step launched kernel by kernel
+            use_graph = False
         self.lib.cv_llm_set_option(self._h, b"use_graph", C.c_int32(int(use_graph)))
         self.lib.cv_llm_set_option(self._h, b"attn_splits", C.c_int32(int(attn_splits)))   # key-range slices per head in decode attention
         self.batch_fp8 = bool(batch_fp8)
