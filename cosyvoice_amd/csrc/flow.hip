@@ -110,6 +110,7 @@ struct cv_flow {
     int band_pipe = 2;                 // option "band_pipe" (env CV_FLOW_BAND_PIPE): the FF1 -> GELU -> FF2 chunks of a band as a software pipeline (flow_band_kernel<.., PIPE>): 0 = never,
                                        // 1 = 48-row bands, 2 = 48- and 32-row bands (default; a 32-row band then holds 96 KB of LDS - one workgroup per CU instead of two - and is
                                        // still faster: 8 / 6 / 4 utterances of U10 per pass 79.1 -> 77.6 / 64.9 -> 63.4 / 52.1 -> 50.8 ms, profiles/r5_band_qkv.txt section 4)
+    int band_stagger = 0;              // experiments builds only, option "band_stagger" (env CV_FLOW_BAND_STAGGER): FlowBandArgs::stagger; 0 = all bands of a launch start together
     int band_bm = 0;                   // option "band_bm" (env CV_FLOW_BAND_BM): rows per band 32 / 48 / 64 whatever the row count; 0 = by the row count of the pass (band_rows_for)
     int fused_band = 1;                // bf16 mode, large passes (big_rows): everything between a block's attention and the next block's QKV GEMM in ONE launch per 64-row band
                                        // (flow_band.h) instead of five (out-projection, LayerNorm, FF1, FF2, LayerNorm); bit-identical; option "fused_band", env CV_FLOW_BAND
@@ -301,6 +302,7 @@ static void flow_finalize(cv_flow* m) {
         if (const char* e = getenv("CV_FLOW_ATTN32")) m->attn32 = e[0] != '0';
         if (const char* e = getenv("CV_FLOW_EAGER_STREAMS")) m->eager_streams = atoi(e) >= 2 ? 2 : 1;
         if (const char* e = getenv("CV_FLOW_TAIL")) m->fused_tail = e[0] != '0';
+        if (const char* e = getenv("CV_FLOW_BAND_STAGGER")) m->band_stagger = atoi(e) > 0 ? atoi(e) : 0;
     }
     if (const char* e = getenv("CV_FLOW_RES_TILE")) m->res_tile = atoi(e) == 1;
     if (const char* e = getenv("CV_FLOW_ATTN32_WAVES")) { const int v = atoi(e); if (v == 0 || v == 2 || v == 4) m->attn32_waves = v; }
@@ -642,7 +644,7 @@ static void flow_band_launch(const FlowBandArgs& a, bool has_next, bool qkv, int
 }
 static void flow_band(const cv_flow* m, const TBlockW& t, bool has_next, const BandQkv* q, const bf16_t* att, int inner, float* x, int C, int M, bf16_t* xn, hipStream_t s) {
     FlowBandArgs a{};
-    a.att = att; a.ld_att = inner; a.x = x; a.ldx = C; a.wstream = q ? t.bandq : t.band; a.prm = t.tail_prm; a.eps = 1e-5f; a.M = M; a.xn = xn; a.ld_xn = C;
+    a.att = att; a.ld_att = inner; a.x = x; a.ldx = C; a.wstream = q ? t.bandq : t.band; a.prm = t.tail_prm; a.eps = 1e-5f; a.M = M; a.xn = xn; a.ld_xn = C; a.stagger = m->band_stagger;
     CV_CHECK(t.band && t.tail_prm && (!has_next || t.tail_qkv) && (!q || (has_next && t.bandq)), "flow_band: block was not packed for this call");
     if (q) { a.qk = q->qk; a.ld_qk = q->ld_qk; a.vt = q->vt; a.vt_batch = q->vt_batch; a.ldt = q->ldt; a.rows_per_batch = q->rows_per_batch > 0 ? q->rows_per_batch : M; }
     const int bm = m->band_bm ? m->band_bm : band_rows_for(m->rule_rows > M ? (int)m->rule_rows : M);
@@ -1170,6 +1172,7 @@ int cv_flow_set_option(cv_flow* m, const char* name, int32_t value) {
         else if (std::string(name) == "fused_tail") { need_experiments(value != 0, "flow option fused_tail"); m->fused_tail = value != 0; drop_graphs(m); }
         else if (std::string(name) == "band_qkv") { m->band_qkv = value != 0; drop_graphs(m); }
         else if (std::string(name) == "ln_qkv") { m->ln_qkv = value != 0; drop_graphs(m); }
+        else if (std::string(name) == "band_stagger") { CV_CHECK(value >= 0 && value <= 64, "band_stagger must be 0 .. 64"); need_experiments(value != 0, "flow option band_stagger"); m->band_stagger = value; drop_graphs(m); }
         else if (std::string(name) == "band_pipe") { CV_CHECK(value >= 0 && value <= 2, "band_pipe must be 0, 1 or 2"); m->band_pipe = value; drop_graphs(m); }
         else if (std::string(name) == "band_bm") { CV_CHECK(value == 0 || value == 32 || value == 48 || value == 64, "band_bm must be 0, 32, 48 or 64"); m->band_bm = value; drop_graphs(m); }
         else if (std::string(name) == "fused_band") { m->fused_band = value != 0; drop_graphs(m); }      // bf16 mode, large passes: one 64-row band launch between attention and the next QKV GEMM (flow_band.h) on / off

@@ -38,6 +38,8 @@ struct FlowBandArgs {
     bf16_t* qk; int ld_qk;                    // HAS_QKV: Q | K of the NEXT block [M][2 INNER] bf16 (what its flow_gemm_big_kernel<.., 0> launch would have written)
     bf16_t* vt; long long vt_batch; int ldt; int rows_per_batch;      // HAS_QKV: its V^T [B][INNER][ldt] bf16, key-permuted (vt_col)
     long long* dbg;                           // dev tool (tools/ubench/band_probe.hip): clock64() of thread 0 at the phase boundaries, 16 slots per workgroup; null in production
+    int stagger;                              // dev probe (option "band_stagger", round 6): band b starts (b mod 4) * stagger * ~0.9 us late (s_sleep), so that the phases of the
+                                              // bands of one round - the staging loads, the Q | K | V^T store burst - do not coincide; experiments builds only (measured, a loss: profiles/r6_band_stagger.txt)
 };
 
 // one pass: PT 16-column tiles x KS k-steps of 32 against the 4 row tiles of the band.  A: bf16 pairs in LDS, row pitch `pitch` dwords, first dword k0.
@@ -148,6 +150,9 @@ __global__ __launch_bounds__(NW * 64) void flow_band_kernel(FlowBandArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * BM;
+#ifdef CV_BUILD_EXPERIMENTS
+    if (p.stagger) for (int i = (blockIdx.x & 3) * p.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(32);       // dev probe: 32 x 64 clocks per unit
+#endif
 
     // ---- the band's small operands, its attention tile and its residual rows FIRST (unconditional, clamped), then the first pass of the weight stream
     constexpr int NPV = NPRM / 4, PPT = (NPV + NT - 1) / NT;

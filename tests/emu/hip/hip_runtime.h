@@ -230,6 +230,7 @@ static inline emu_u32x2 emu_permlane32_swap(unsigned a, unsigned b) {
 #define __builtin_amdgcn_wave_barrier() ((void)__shfl(0, 0))            /* the emulator's lanes are fibers: a wave-wide rendezvous */
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 #define __builtin_amdgcn_s_getreg(x) 0      /* hardware id registers (dev-tool stamps only) */
 #define __builtin_nontemporal_load(p) (*(p))
