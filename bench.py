@@ -361,7 +361,10 @@ def cv3_workload(args):
                "first_step_max_abs_dlogp_vs_w16a32": round(float((lp8 - lp16).abs().max()), 5), "first_step_token_equal": t8 == t16,
                "oracle_top2_margin_at_divergence": None if min(divs) >= len(gold["top2_margin"]) else gold["top2_margin"][min(divs)]}
     return {"fp8": fp8, "model": "Fun-CosyVoice3-0.5B dimensions (CosyVoice3LM, DiT 22 x 1024, CausalHiFTGenerator), seeded random weights", "cfm_steps": args.cv3_steps,
-            "flow_precision": args.flow_precision, "llm": ("batch of 16: fp8 e4m3 weights + activations on the fp8 MFMA; single request: W16A32" if args.llm_fp8 else "W16A32"),
+            "flow_precision": args.flow_precision,
+            "hift": ("decoder convolutions with 16 significand bits per factor, fp32 accumulation (option terms = 3): the model's fp16 mode - the reference runs this model's "
+                     "vocoder under autocast, cli/model.py:426-447" if m.hift.terms == 3 else "fp32-exact class (terms = 6)"),
+            "llm": ("batch of 16: fp8 e4m3 weights + activations on the fp8 MFMA; single request: W16A32" if args.llm_fp8 else "W16A32"),
             "batch1_audio_s_per_s": round(AUDIO_S / single, 3), "batch1_ms_per_utterance": round(1e3 * single, 2),
             "batch16_audio_s_per_s": round(nb * AUDIO_S / batch_s, 3), "batch16_ms_per_batch": round(1e3 * batch_s, 2), "lanes": args.lanes, "flow_batch": args.flow_batch, "token_check": check}
 

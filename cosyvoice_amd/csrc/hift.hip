@@ -267,6 +267,7 @@ static void hift_decode(cv_hift* m, const float* mel_cl, int frames, const float
 // `look_right` frames are only the right context of conv_pre, the source STFT loses its last prod(ups) * look_right frames and the last
 // prod(ups) * hop samples of the iSTFT are withheld.  Returns the number of samples written to `speech`.
 static long long hift_decode_causal(cv_hift* m, const float* mel_cl, int mx, const float* src, bool finalize, float* speech, hipStream_t s) {
+    struct TermScope { TermScope(int t) { tl_terms = t; } ~TermScope() { tl_terms = 0; } } term_scope(m->terms == 3 ? 3 : 0);       // option "terms" (CosyVoice3Model fp16 mode), as in hift_decode
     const auto& c = m->cfg;
     int up = 1; for (int i = 0; i < c.n_ups; ++i) up *= c.ups[i];
     const long long Ls = (long long)mx * m->scale, Fall = Ls / 4 + 1, F = finalize ? Fall : Fall - (long long)up * c.look_right;

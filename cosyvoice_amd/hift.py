@@ -40,9 +40,12 @@ class _F0Predictor:
 
 
 class HiFTGenerator:
-    def __init__(self, state_dict, cfg, lib=None, seed=1986, _tensors=None, f0_float64=False):
+    def __init__(self, state_dict, cfg, lib=None, seed=1986, _tensors=None, f0_float64=False, terms=6):
         """f0_float64: the f0 predictor with every sum in double (cv_hift_set_option "f0_float64") - the mode the reference runs the causal generator's
-        predictor in (generator.py:716-717); default off: fp32 on the exact-fp32 matrix pipe (bounds against float64: tests/test_zz_fullsize.py)."""
+        predictor in (generator.py:716-717); default off: fp32 on the exact-fp32 matrix pipe (bounds against float64: tests/test_zz_fullsize.py).
+        terms: plane products per k of the decoder's convolutions (cv_hift_set_option "terms"): 6 = the fp32-exact class (default), 3 = 16 significand bits per
+        factor with fp32 accumulation - the reduced-precision mode CosyVoice3Model(fp16=True) selects where the reference runs its vocoder under
+        autocast (cli/model.py:426-447); the f0 predictor and the source are not affected."""
         self.lib = lib or get_lib()
         self.cfg = cfg
         self.device = torch.device(self.lib.device)
@@ -64,11 +67,14 @@ class HiFTGenerator:
         self.f0_float64 = bool(f0_float64)
         if self.f0_float64:
             self.lib.cv_hift_set_option(self._h, b"f0_float64", C.c_int32(1))
+        self.terms = int(terms)
+        if self.terms != 6:
+            self.lib.cv_hift_set_option(self._h, b"terms", C.c_int32(self.terms))
         self.f0_predictor = _F0Predictor(self)
 
     def clone(self):
         """Same device weights, own library handle (workspaces): one per token2wav lane of CosyVoice2Model."""
-        return type(self)(None, self.cfg, lib=self.lib, seed=self.seed, _tensors=self._tensors, f0_float64=self.f0_float64)
+        return type(self)(None, self.cfg, lib=self.lib, seed=self.seed, _tensors=self._tensors, f0_float64=self.f0_float64, terms=self.terms)
 
     def __del__(self):
         try:

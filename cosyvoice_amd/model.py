@@ -575,7 +575,12 @@ class CosyVoice3Model(CosyVoice2Model):
     llm_job / streaming loop of CosyVoice2Model over CosyVoice3LM + CausalMaskedDiffWithDiT + CausalHiFTGenerator, with the silent / breath
     token filter switched on (:423) and its own token2wav: the mel of a request accumulates in `hift_cache_dict[uuid]['mel']`, every call
     vocodes the whole mel so far with the causal generator (finalize flag = look-ahead handling) and returns the samples beyond
-    `speech_offset` - no overlap cross-fade, no source cache."""
+    `speech_offset` - no overlap cross-fade, no source cache.
+
+    fp16=True: the reference runs flow AND vocoder of this model under `torch.cuda.amp.autocast(self.fp16)` (cli/model.py:426-447).  Here the flow's products go to
+    the bf16 MFMA with fp32 accumulation (precision="bf16", as for CosyVoice2) and the vocoder's decoder convolutions keep 16 significand bits per factor with fp32
+    accumulation (HiFT option "terms" = 3: more bits than autocast's fp16 operands, measured 96 dB against the fp32-exact class at full size, profiles/r6_hift.txt);
+    the f0 predictor stays in double as in the reference (autocast leaves float64 operands alone, generator.py:716-717)."""
 
     def __init__(self, llm, flow, hift, fp16=False, lib=None):
         super().__init__(llm, flow, hift, fp16=fp16, lib=lib)
@@ -587,7 +592,7 @@ class CosyVoice3Model(CosyVoice2Model):
         lc, fc, hc = cfgs
         lib = lib or get_lib()
         flow = CausalMaskedDiffWithDiT(flow_sd, fc, lib=lib, precision="bf16" if fp16 else "fp32")
-        return cls(CosyVoice3LM(llm_sd, lc, lib=lib, **llm_kw), flow, CausalHiFTGenerator(hift_sd, hc, lib=lib, f0_float64=f0_float64), fp16=fp16)
+        return cls(CosyVoice3LM(llm_sd, lc, lib=lib, **llm_kw), flow, CausalHiFTGenerator(hift_sd, hc, lib=lib, f0_float64=f0_float64, terms=3 if fp16 else 6), fp16=fp16)
 
     def load(self, llm_model, flow_model, hift_model, cfgs=None, f0_float64=True, **llm_kw):
         from .configs import cv3_flow, cv3_hift, cv3_llm
@@ -597,7 +602,7 @@ class CosyVoice3Model(CosyVoice2Model):
         hift_sd = {k.replace("generator.", ""): v for k, v in torch.load(hift_model, map_location="cpu", weights_only=True).items()}
         self.llm = CosyVoice3LM(llm_sd, lc, lib=self.lib, **llm_kw)
         self.flow = CausalMaskedDiffWithDiT(flow_sd, fc, lib=self.lib, precision="bf16" if self.fp16 else "fp32")
-        self.hift = CausalHiFTGenerator(hift_sd, hc, lib=self.lib, f0_float64=f0_float64)
+        self.hift = CausalHiFTGenerator(hift_sd, hc, lib=self.lib, f0_float64=f0_float64, terms=3 if self.fp16 else 6)
         self.set_lanes(max(1, self.n_lanes))
         self._warmup()
 

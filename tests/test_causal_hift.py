@@ -67,3 +67,24 @@ def test_causal_hift_streaming_equals_one_shot(lib, tiny):
     _, src_o = OH.causal_inference(sd, cfg, mel, True, None, noise, f0_dtype=torch.float32)
     torch.testing.assert_close(src.cpu(), src_o, rtol=0, atol=5e-3)
     torch.testing.assert_close(h.decode(mel, src_o, True).cpu(), OH.causal_decode(sd, cfg, mel, src_o, True), rtol=2e-4, atol=2e-4)
+
+
+def test_reduced_products_mode_of_the_causal_decoder(lib, tiny):
+    """CosyVoice3Model(fp16=True) (the reference runs flow AND vocoder of that model under autocast, cli/model.py:426-447) builds its CausalHiFTGenerator with
+    terms=3: the causal decoder's convolutions keep 16 significand bits per factor (fp32 accumulation; more than autocast's fp16 operands).  Against the golden of the
+    REAL class the decoder stays inside the default mode's tolerance, against the default mode it is within 1e-4 rel-L2 (> 80 dB), f0 (double) is untouched, clones
+    keep the mode, and a chunk still equals the one-shot prefix."""
+    cfg, sd = tiny
+    g = _gold()
+    h6 = CausalHiFTGenerator(sd, cfg, lib=lib)
+    h3 = CausalHiFTGenerator(sd, cfg, lib=lib, terms=3)
+    assert h3.terms == 3 and h3.clone().terms == 3 and h6.terms == 6
+    six = h6.decode(g["mel"], g["source"], True).cpu().clone()
+    three = h3.decode(g["mel"], g["source"], True).cpu().clone()
+    torch.testing.assert_close(three, g["speech"], rtol=2e-4, atol=2e-4)                     # the real class's waveform, the default mode's bound
+    rel = float((three.double() - six.double()).norm() / six.double().norm())
+    assert 0.0 < rel < 1e-4, rel                                                             # really another arithmetic, > 80 dB
+    assert torch.equal(h3.f0(g["mel"], True).cpu(), h6.f0(g["mel"], True).cpu())            # the predictor is not part of the mode
+    assert torch.equal(h3.clone().decode(g["mel"], g["source"], True).cpu(), three)
+    part = h3.decode(g["mel"][:, :, :10], g["source_c"], False).cpu()
+    torch.testing.assert_close(part, g["speech_c"], rtol=2e-4, atol=2e-4)
