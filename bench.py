@@ -645,9 +645,13 @@ def roofline_llm(model, u, cfgs):
             llm.lib.cv_llm_profile_chain(llm._h, k, 20, C.byref(ms1), C.byref(n1), stream_ptr(llm.lib))
             chain[k] = 1e3 * ms1.value / max(n1.value, 1)
             per[names[k]]["chain_avg_us"] = round(chain[k], 2)
+            if k == 5:                                         # one head launch per token: the replayed graph has ONE node, so this is the replay period of a one-node graph
+                per[names[k]]["chain_note"] = ("one-node graph: chain_avg_us is the graph replay period, not the kernel's duration (its instantiation is the qkv GEMV's, "
+                                               "4.7 us by the kernel trace); used as head + sampler in decode_step_us_from_chains")
             if k in wbytes:
                 per[names[k]]["weight_bytes"] = wbytes[k]
-                per[names[k]]["GBps"] = round(wbytes[k] / (chain[k] * 1e-6) / 1e9, 1)
+                if k != 5:
+                    per[names[k]]["GBps"] = round(wbytes[k] / (chain[k] * 1e-6) / 1e9, 1)
     # dominant kernel of the whole path: the gate/up GEMV (gemv_norm_kernel<7,2,5>): 24 launches per token, ~26 % of the decode step, the largest
     # single share of an utterance
     bytes_per_launch = wbytes[3]
