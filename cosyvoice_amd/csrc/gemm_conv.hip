@@ -21,6 +21,13 @@ static void launch_cfg(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_
         const char* e = getenv("CV_GEMM_WX3");
         if (!(e && e[0] == '0')) {
             constexpr int BK3 = BK > 64 ? 64 : BK;
+#ifdef CV_BUILD_EXPERIMENTS
+            // dev knob (experiments builds): a deeper register ring for the two-sided split (3 or 4 tiles in flight per wave)
+            if (const char* st = getenv("CV_GEMM_WX3_STAGES"); st && BM <= 64) {
+                if (st[0] == '3') { hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK3, true, true, 3, false, 2, 2, true, true>), grid, block, 0, stream, a); return; }
+                if (st[0] == '4') { hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK3, true, true, 4, false, 2, 2, true, true>), grid, block, 0, stream, a); return; }
+            }
+#endif
             hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK3, true, true, ST, false, 2, 2, true, true>), grid, block, 0, stream, a);
             return;
         }
@@ -66,6 +73,10 @@ void launch_gemm_conv(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_t
     // A tile taller than 32 rows may not pad M by more than 25 %: the LLM prefill of U10 has M = 131 = 128 + 3, and the 128-row tile ran half of its
     // workgroups on 3 useful rows (prefill 5.14 -> 4.38 ms with this rule; asking for more workgroups on top gave 4.2: profiles/r2_batch_decode_ab.txt).
     // CV_GEMM_MAX_WASTE / CV_GEMM_MIN_BLOCKS_F32: dev knobs for such sweeps, read at every launch.
+    // The two-sided split (WX3: HiFT's fp32 weights) stages 3 BN weight rows per k-step and splits its activations on the VALU: its launches are bound by that staging, not by the
+    // matrix pipe, and want ~3 workgroups per CU like the bf16 tiles (round 6, HiFT at 500 frames: 4.47 ms at 480, 4.14 at 720 - 1000, 4.23 - 4.28 from 1260, 4.95 - 6.6 below 480:
+    // profiles/r6_hift.txt section 3; the tile shape does not change a result bit - every output element sums the same products in the same order).
+    if (!bf16_path && a.a_vec && !w_bf16 && a.W3) min_blocks = 720;
     double max_waste = 1.25;
     if (const char* e = getenv("CV_GEMM_MIN_BLOCKS_F32"); e && !bf16_path) min_blocks = atoll(e);
     if (const char* e = getenv("CV_GEMM_MAX_WASTE")) max_waste = atof(e);
