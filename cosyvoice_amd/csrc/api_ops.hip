@@ -30,17 +30,6 @@ void gemm_conv(GemmConvArgs a, bool w_bf16, int batch, hipStream_t s) {
               (!a.bias || (aligned16(a.bias) && a.bias_batch % 4 == 0)) && (!a.res || (aligned16(a.res) && a.res_batch % 4 == 0)) &&
               (!a.col_scale || (aligned16(a.col_scale) && a.col_scale_stride % 4 == 0));
     CV_CHECK(!a.col_scale || a.col_scale_rows > 0, "gemm_conv: col_scale needs col_scale_rows > 0");
-    if (a.A3 || a.C3 || a.C23) {                     // pre-split bf16 planes (gemm_conv.h; HiFT ResBlocks): vector paths only, every output group whole
-        CV_CHECK(a.W3 && !w_bf16 && a.a_vec && a.c_vec, "gemm_conv: pre-split planes need the two-sided split path (W3) and 16-byte aligned operands");
-        CV_CHECK(!a.A3 || (a.pro == ACT_NONE && aligned16(a.A3) && a.a3_plane % 8 == 0 && a.a3_plane >= (long long)batch * (a.a_batch ? a.a_batch : a.a_len)),
-                 "gemm_conv: A3 planes take no prologue activation; plane stride = a multiple of 8 elements covering the operand");
-        CV_CHECK(!(a.C3 || a.C23) || (a.N % 4 == 0 && a.c_off == 0 && a.ldc == a.N && a.c_len == (long long)a.M * a.N && a.c3_plane % 8 == 0 &&
-                                      a.c3_plane >= (long long)batch * (a.c_batch ? a.c_batch : a.c_len) && aligned16(a.C3) && aligned16(a.C23)),
-                 "gemm_conv: plane outputs need a dense [M][N] output, N % 4 == 0, plane stride covering it");
-        CV_CHECK(!a.C23 || a.c2_alpha, "gemm_conv: the Snake-activated plane output needs c2_alpha[N]");
-        CV_CHECK(!a.c3_only || (a.C3 && !a.C2 && !a.C23 && !a.accumulate), "gemm_conv: c3_only replaces the fp32 store of a plain output");
-        CV_CHECK(!(a.M == 1 && batch == 1), "gemm_conv: pre-split planes are for tiled launches");
-    }
     if (a.pro == ACT_SNAKE) CV_CHECK(a.pro_alpha && aligned16(a.pro_alpha), "gemm_conv: snake prologue needs 16B aligned alpha[Kp]");
     // one output row over fp32 weights (the decode step of CosyVoice-300M's LM): a GEMV, not a tile with one useful row (gemm_conv.h, gemv_f32_kernel).
     // cv_ops_set_option("gemv_f32", 0) keeps the tiled kernel (A/B and test knob; initialised ONCE per process from CV_GEMV_F32: getenv is not safe against a

@@ -164,15 +164,6 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
-// x = x1 + x2 + x3 exactly, each a bf16 (x1 = bf16(x), x2 = bf16(x - x1), x3 = x - x1 - x2: every residual is exact in fp32) - four values at a time, packed pairs
-__device__ __forceinline__ void split3_bf16(float4 x, uint2& p1, uint2& p2, uint2& p3) {
-    const unsigned a0 = pack_bf16x2(x.x, x.y), a1 = pack_bf16x2(x.z, x.w);
-    x.x -= __uint_as_float(a0 << 16); x.y -= __uint_as_float(a0 & 0xffff0000u); x.z -= __uint_as_float(a1 << 16); x.w -= __uint_as_float(a1 & 0xffff0000u);
-    const unsigned b0 = pack_bf16x2(x.x, x.y), b1 = pack_bf16x2(x.z, x.w);
-    x.x -= __uint_as_float(b0 << 16); x.y -= __uint_as_float(b0 & 0xffff0000u); x.z -= __uint_as_float(b1 << 16); x.w -= __uint_as_float(b1 & 0xffff0000u);
-    p1 = make_uint2(a0, a1); p2 = make_uint2(b0, b1); p3 = make_uint2(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w));
-}
-
 // Buffer addressing: a 128-bit resource (base, byte size) + a 32-bit byte offset per lane.  The hardware range-checks every dword
 // against the size and returns 0 outside, so zero padding, ragged tiles and masked rows cost no compare / select / 64-bit add in the
 // inner loops (a negative offset is a huge unsigned one).  BUF_OOB is the offset used to force a zero: operands must be < 1.75 GiB.

@@ -49,11 +49,6 @@ struct GemmConvArgs {
     int w3_terms;                   // WX3 only: 0 / 6 = the six plane products of relative weight >= 2^-16 (fp32-exact class, the default); 3 = x1 w1 + x1 w2 + x2 w1 only
                                     // (relative weight >= 2^-8; the dropped terms are <= 2^-16 of a product: 16 mantissa bits per factor - HiFT option "terms", round 6)
     long long* dbg;                 // dev tool (tools/ubench/gemm_probe.hip): per-phase clock64() stamps of wave 0, 64 slots per workgroup; null in production
-    // Pre-split activations (round 6, WX3 kernels only - HiFT's ResBlocks).  The two-sided split spends more VALU instructions on splitting its activations (once per tap
-    // and per N tile: a k = 7 convolution over two N tiles splits every value 14 times) than the matrix pipe spends on the products (profiles/r6_pmc_hift.json).  A value is
-    // split ONCE, by its producer: three bf16 planes x = x1 + x2 + x3 (split3_bf16 - the very operations the staging code performs), plane p at element offset p * plane.
-    const void* A3; long long a3_plane;     // A as three bf16 planes, indexed like A (same flat index, same zero padding); needs pro == ACT_NONE.  The consumer stages them as they are.
-    void* C3; void* C23; long long c3_plane; int c3_only;   // the final values (C3) / their Snake (C23, alpha = c2_alpha) as three bf16 planes indexed like C; c3_only: no fp32 store to C
 };
 
 // Pipeline: most GEMMs on this path are small (M ~ 10^3, K = 256..1024) and run ~1 workgroup per CU, so nothing hides global
@@ -72,10 +67,8 @@ struct GemmConvArgs {
 // x1 w3, x3 w1), every one exact, accumulated in fp32 smallest first; the dropped x2 w3 + x3 w2 + x3 w3 are <= 2^-23 of a product - the size of ONE fp32
 // rounding of it, so the result is as accurate as the fp32 MFMA chain (whose own accumulation error is ~ sqrt(K) roundings) for 6 x 16 instead of
 // 8 x 32 matrix-pipe cycles per 32 k.  A WX3 kernel is an AX3 kernel whose weight tile has 3 BN rows.
-// APRE (WX3 only): the A operand arrives pre-split (GemmConvArgs::A3) and is staged without any arithmetic.
-template <int BM, int BN, int BK, bool WBF16, bool AVEC, int STAGES = 2, bool ABF16 = false, int WM = 2, int WN = 2, bool AX3 = false, bool WX3 = false, bool APRE = false>
+template <int BM, int BN, int BK, bool WBF16, bool AVEC, int STAGES = 2, bool ABF16 = false, int WM = 2, int WN = 2, bool AX3 = false, bool WX3 = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p) {
-    static_assert(!APRE || WX3, "pre-split activations feed the two-sided split kernels");
     static_assert(!ABF16 || WBF16, "the bf16 MFMA path takes bf16 weights");
     static_assert(!AX3 || (WBF16 && !ABF16), "the three-term split is the exact path for bf16 weights");
     static_assert(!WX3 || (AX3 && AVEC), "the two-sided split is an AX3 kernel over pre-split weight planes");
@@ -111,7 +104,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
     // STAGES register sets form the prefetch ring (2..4): every tile pays a full L2-miss round trip (its slowest line), measured at
     // several microseconds on these shapes, so the small tiles — which have the registers — keep 4 tiles in flight per wave.
     float4 ra0[AV], rw0[WV], ra1[AV], rw1[WV], ra2[STAGES > 2 ? AV : 1], rw2[STAGES > 2 ? WV : 1], ra3[STAGES > 3 ? AV : 1], rw3[STAGES > 3 ? WV : 1];
-    uint2 rc0[APRE ? AV : 1], rc1[APRE ? AV : 1], rc2[APRE && STAGES > 2 ? AV : 1], rc3[APRE && STAGES > 3 ? AV : 1];      // APRE: ra = planes 1 | 2 of a group, rc = plane 3
 
     // Loads are UNCONDITIONAL (clamped address + select): a load inside a divergent branch makes the compiler lose count of the
     // outstanding vector-memory operations and fall back to s_waitcnt vmcnt(0), which drains the prefetch ring every iteration.
@@ -123,10 +115,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
     // vectorised operands go through buffer resources: 32-bit byte offsets, hardware range check (see common.h)
     constexpr int WE = WBF16 ? 2 : 4;                 // bytes per weight element
     int a_boff[AV], w_boff[WV];
-    const bf16_t* A3b = APRE ? reinterpret_cast<const bf16_t*>(p.A3) + (long long)b * p.a_batch : nullptr;
-    const __amdgpu_buffer_rsrc_t rsA = APRE ? make_rsrc(A3b, (unsigned)(p.a_len * 2)) : make_rsrc(Ab, (unsigned)(p.a_len * 4));
-    const __amdgpu_buffer_rsrc_t rsA2 = APRE ? make_rsrc(A3b + p.a3_plane, (unsigned)(p.a_len * 2)) : rsA;
-    const __amdgpu_buffer_rsrc_t rsA3 = APRE ? make_rsrc(A3b + 2 * p.a3_plane, (unsigned)(p.a_len * 2)) : rsA;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(Ab, (unsigned)(p.a_len * 4));
     const void* Wp = WX3 ? p.W3 : p.W;
     const __amdgpu_buffer_rsrc_t rsW = make_rsrc(reinterpret_cast<const char*>(Wp) + wb * WE, (unsigned)(((long long)(WR * p.N - 1) * ldw + (long long)p.taps * p.Kp) * WE));
 #pragma unroll
@@ -135,7 +124,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
         a_c4[i] = (v % KV) * 4;
         a_row_ok[i] = m < p.M;
         a_base[i] = (long long)m * p.lda + p.a_off0 + a_c4[i];
-        a_boff[i] = a_row_ok[i] ? (int)(a_base[i] * (APRE ? 2 : 4)) : BUF_OOB;
+        a_boff[i] = a_row_ok[i] ? (int)(a_base[i] * 4) : BUF_OOB;
     }
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
@@ -145,19 +134,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
         w_base[i] = wb + (long long)n * ldw + w_c4[i];
         w_boff[i] = (int)(((long long)n * ldw + w_c4[i]) * WE);
     }
-    auto load_tile = [&](int tap, int k0, auto& ra, auto& rc, auto& rw) {
+    auto load_tile = [&](int tap, int k0, auto& ra, auto& rw) {
         const long long a_off = (long long)tap * p.tap_step + k0;       // uniform
         const long long w_off = (long long)tap * p.Kp + k0;             // uniform
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const int kk = k0 + a_c4[i];
             const long long idx = a_base[i] + a_off;
-            if constexpr (APRE) {   // three 8-byte loads per group: the planes as they were written by the producer (zero outside [0, a_len) like the fp32 operand)
-                const int off = kk < p.K ? a_boff[i] + (int)a_off * 2 : BUF_OOB;
-                const uint2 u1 = buf_load_u2(rsA, off), u2 = buf_load_u2(rsA2, off);
-                rc[i] = buf_load_u2(rsA3, off);
-                ra[i] = make_float4(__uint_as_float(u1.x), __uint_as_float(u1.y), __uint_as_float(u2.x), __uint_as_float(u2.y));
-            } else if (AVEC) {       // K % 4 == 0 and every float4 group is 16B aligned and entirely in or out of [0, a_len)
+            if (AVEC) {       // K % 4 == 0 and every float4 group is 16B aligned and entirely in or out of [0, a_len)
                 ra[i] = buf_load_f4(rsA, kk < p.K ? a_boff[i] + (int)a_off * 4 : BUF_OOB);      // rows >= M, idx outside [0, a_len): hardware zero
             } else {
                 float t[4];
@@ -201,18 +185,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
             rw[i] = wv;
         }
     };
-    auto store_tile = [&](int k0, const auto& ra, const auto& rc, const auto& rw) {
+    auto store_tile = [&](int k0, const auto& ra, const auto& rw) {
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const int v = tid + i * NT, kk = k0 + a_c4[i];
             float4 x = ra[i];
-            if constexpr (APRE) {
-                const int o = (v / KV) * LD + a_c4[i] / 2;
-                *reinterpret_cast<uint2*>(&As[o]) = make_uint2(__float_as_uint(x.x), __float_as_uint(x.y));
-                *reinterpret_cast<uint2*>(&As[APL + o]) = make_uint2(__float_as_uint(x.z), __float_as_uint(x.w));
-                *reinterpret_cast<uint2*>(&As[2 * APL + o]) = rc[i];
-                continue;
-            }
             if (p.pro != ACT_NONE) {
                 if (p.pro == ACT_LEAKY) {
                     x.x = x.x > 0.f ? x.x : x.x * p.pro_p; x.y = x.y > 0.f ? x.y : x.y * p.pro_p;
@@ -227,12 +204,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
                 }
             }
             if constexpr (AX3) {
-                uint2 q1, q2, q3;
-                split3_bf16(x, q1, q2, q3);
+                const unsigned a0 = pack_bf16x2(x.x, x.y), a1 = pack_bf16x2(x.z, x.w);
+                x.x -= __uint_as_float(a0 << 16); x.y -= __uint_as_float(a0 & 0xffff0000u); x.z -= __uint_as_float(a1 << 16); x.w -= __uint_as_float(a1 & 0xffff0000u);
+                const unsigned b0 = pack_bf16x2(x.x, x.y), b1 = pack_bf16x2(x.z, x.w);
+                x.x -= __uint_as_float(b0 << 16); x.y -= __uint_as_float(b0 & 0xffff0000u); x.z -= __uint_as_float(b1 << 16); x.w -= __uint_as_float(b1 & 0xffff0000u);
                 const int o = (v / KV) * LD + a_c4[i] / 2;
-                *reinterpret_cast<uint2*>(&As[o]) = q1;
-                *reinterpret_cast<uint2*>(&As[APL + o]) = q2;
-                *reinterpret_cast<uint2*>(&As[2 * APL + o]) = q3;
+                *reinterpret_cast<uint2*>(&As[o]) = make_uint2(a0, a1);
+                *reinterpret_cast<uint2*>(&As[APL + o]) = make_uint2(b0, b1);
+                *reinterpret_cast<uint2*>(&As[2 * APL + o]) = make_uint2(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w));
             } else if (ABF16) *reinterpret_cast<uint2*>(&As[(v / KV) * LD + a_c4[i] / 2]) = make_uint2(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w));
             else *reinterpret_cast<float4*>(&As[(v / KV) * LD + a_c4[i]]) = x;
         }
@@ -379,41 +358,41 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
     auto advance = [&]() { l_k0 += BK; if (l_k0 >= p.Kp) { l_k0 = 0; ++l_tap; } };
     int ks0 = 0, ks1 = 0, ks2 = 0, ks3 = 0;
     stamp();
-    load_tile(l_tap, l_k0, ra0, rc0, rw0); ks0 = l_k0; advance();
-    if (nit > 1) { load_tile(l_tap, l_k0, ra1, rc1, rw1); ks1 = l_k0; advance(); }
-    if constexpr (STAGES > 2) { if (nit > 2) { load_tile(l_tap, l_k0, ra2, rc2, rw2); ks2 = l_k0; advance(); } }
-    if constexpr (STAGES > 3) { if (nit > 3) { load_tile(l_tap, l_k0, ra3, rc3, rw3); ks3 = l_k0; advance(); } }
+    load_tile(l_tap, l_k0, ra0, rw0); ks0 = l_k0; advance();
+    if (nit > 1) { load_tile(l_tap, l_k0, ra1, rw1); ks1 = l_k0; advance(); }
+    if constexpr (STAGES > 2) { if (nit > 2) { load_tile(l_tap, l_k0, ra2, rw2); ks2 = l_k0; advance(); } }
+    if constexpr (STAGES > 3) { if (nit > 3) { load_tile(l_tap, l_k0, ra3, rw3); ks3 = l_k0; advance(); } }
     stamp();
     for (int it = 0; it < nit; it += STAGES) {
-        store_tile(ks0, ra0, rc0, rw0);
+        store_tile(ks0, ra0, rw0);
         stamp();
         __syncthreads();
-        if (it + STAGES < nit) { load_tile(l_tap, l_k0, ra0, rc0, rw0); ks0 = l_k0; advance(); }     // in flight for the next STAGES-1 tiles
+        if (it + STAGES < nit) { load_tile(l_tap, l_k0, ra0, rw0); ks0 = l_k0; advance(); }     // in flight for the next STAGES-1 tiles
         stamp();
         compute_tile();
         stamp();
         __syncthreads();
         if (it + 1 < nit) {
-            store_tile(ks1, ra1, rc1, rw1);
+            store_tile(ks1, ra1, rw1);
             __syncthreads();
-            if (it + 1 + STAGES < nit) { load_tile(l_tap, l_k0, ra1, rc1, rw1); ks1 = l_k0; advance(); }
+            if (it + 1 + STAGES < nit) { load_tile(l_tap, l_k0, ra1, rw1); ks1 = l_k0; advance(); }
             compute_tile();
             __syncthreads();
         }
         if constexpr (STAGES > 2) {
             if (it + 2 < nit) {
-                store_tile(ks2, ra2, rc2, rw2);
+                store_tile(ks2, ra2, rw2);
                 __syncthreads();
-                if (it + 2 + STAGES < nit) { load_tile(l_tap, l_k0, ra2, rc2, rw2); ks2 = l_k0; advance(); }
+                if (it + 2 + STAGES < nit) { load_tile(l_tap, l_k0, ra2, rw2); ks2 = l_k0; advance(); }
                 compute_tile();
                 __syncthreads();
             }
         }
         if constexpr (STAGES > 3) {
             if (it + 3 < nit) {
-                store_tile(ks3, ra3, rc3, rw3);
+                store_tile(ks3, ra3, rw3);
                 __syncthreads();
-                if (it + 3 + STAGES < nit) { load_tile(l_tap, l_k0, ra3, rc3, rw3); ks3 = l_k0; advance(); }
+                if (it + 3 + STAGES < nit) { load_tile(l_tap, l_k0, ra3, rw3); ks3 = l_k0; advance(); }
                 compute_tile();
                 __syncthreads();
             }
@@ -471,21 +450,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (v[e] * cs[e] + rr[e]) * p.out_scale * rs + oo[e];
-            if constexpr (WX3) {                             // plane outputs for a pre-split consumer (the host only asks for them where every group is `full`)
-                if (p.C3 && full) {
-                    uint2 q1, q2, q3;
-                    split3_bf16(make_float4(v[0], v[1], v[2], v[3]), q1, q2, q3);
-                    bf16_t* c3 = reinterpret_cast<bf16_t*>(p.C3) + (long long)b * p.c_batch + idx;
-                    *reinterpret_cast<uint2*>(c3) = q1; *reinterpret_cast<uint2*>(c3 + p.c3_plane) = q2; *reinterpret_cast<uint2*>(c3 + 2 * p.c3_plane) = q3;
-                }
-                if (p.C23 && full) {
-                    uint2 q1, q2, q3;
-                    split3_bf16(make_float4(snake_f(v[0], p.c2_alpha[n]), snake_f(v[1], p.c2_alpha[n + 1]), snake_f(v[2], p.c2_alpha[n + 2]), snake_f(v[3], p.c2_alpha[n + 3])), q1, q2, q3);
-                    bf16_t* c3 = reinterpret_cast<bf16_t*>(p.C23) + (long long)b * p.c_batch + idx;
-                    *reinterpret_cast<uint2*>(c3) = q1; *reinterpret_cast<uint2*>(c3 + p.c3_plane) = q2; *reinterpret_cast<uint2*>(c3 + 2 * p.c3_plane) = q3;
-                }
-                if (p.c3_only) continue;
-            }
             if (full) {
                 *reinterpret_cast<float4*>(Cb + idx) = make_float4(v[0], v[1], v[2], v[3]);
             } else {

@@ -28,12 +28,10 @@ static void launch_cfg(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_
                 if (st[0] == '4') { hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK3, true, true, 4, false, 2, 2, true, true>), grid, block, 0, stream, a); return; }
             }
 #endif
-            if (a.A3) hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK3, true, true, ST, false, 2, 2, true, true, true>), grid, block, 0, stream, a);      // pre-split activations
-            else hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK3, true, true, ST, false, 2, 2, true, true>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK3, true, true, ST, false, 2, 2, true, true>), grid, block, 0, stream, a);
             return;
         }
     }
-    if (a.A3 || a.C3 || a.C23) throw Error("gemm_conv: pre-split planes (A3 / C3 / C23) exist on the two-sided split path only (fp32 weights registered with their W3 planes)");
     // fp32 activations x bf16 weights: the exact three-term split on the bf16 matrix pipe (gemm_conv.h, AX3).  CV_GEMM_X3=0 pins the fp32 MFMA chain
     // (A/B knob, read at every launch); results agree to fp32 rounding either way.
     if (a.a_vec && w_bf16) {

@@ -33,8 +33,6 @@ struct cv_hift {
     DevBuf mel_cl, fa, fb, f0, P, s, sst, x, xs, t1, r0, r1, si, y_spec, xu, sn;
     int terms = 6;                // option "terms": plane products per k of the two-sided split in the DECODER's convolutions (6 = fp32-exact class; 3: gemm_conv.h w3_terms).
                                   // The f0 predictor always runs exact: its output is integrated into a phase over the whole utterance.
-    int presplit = 1;             // option "presplit" (round 6, default on): the operands of the ResBlock convolutions travel as three bf16 planes written ONCE by their producer
-                                  // (gemm_conv.h A3 / C3 / C23) instead of fp32 values every tap and N tile of the consumer splits again; bit-identical (same split values)
     bool f0_f64 = false;          // option "f0_float64": the f0 predictor in double (the reference's mode for the causal generator, generator.py:716-717)
     DevBuf fa64, fb64;
     int cap_m = 0;
@@ -102,8 +100,7 @@ static void reserve(cv_hift* m, int frames) {
     big = std::max(big, mm * (size_t)std::max(c.base, c.f0_ch));
     m->mel_cl.ensure(mm * c.mel * 4); m->fa.ensure(mm * c.f0_ch * 4); m->fb.ensure(mm * c.f0_ch * 4); m->f0.ensure((mm + 4) * 4);
     m->P.ensure(mm * (c.harmonics + 1) * 4); m->s.ensure(L * 4); m->sst.ensure(F * 18 * 4); m->y_spec.ensure(F * 18 * 4);
-    for (DevBuf* b : {&m->x, &m->xs, &m->r0, &m->r1, &m->si}) b->ensure(big * 4);
-    for (DevBuf* b : {&m->t1, &m->sn}) b->ensure((big + 8) * 6);          // fp32 values, or three bf16 planes of them (option "presplit")
+    for (DevBuf* b : {&m->x, &m->xs, &m->t1, &m->r0, &m->r1, &m->si, &m->sn}) b->ensure(big * 4);
     if (c.causal) m->xu.ensure(2 * big * 4);               // nearest-upsampled input of a CausalConv1dUpsample (twice the channels of its output)
     m->cap_m = frames;
 }
@@ -147,36 +144,6 @@ static void resblock(cv_hift* m, const ResBlockW& w, const float* in, long long 
     }
     const int C = w.c1[0].K;
     CV_CHECK(C % 4 == 0, "hift: ResBlock channels must be a multiple of 4");
-    bool planes = m->presplit && C % 8 == 0;
-    for (int j = 0; j < c.n_dil; ++j) planes = planes && w.c1[j].w3 && w.c2[j].w3 && w.c1[j].N == C && w.c2[j].N == C && w.c2[j].K == C;
-    if (planes) {
-        // the same launches with the two inner operands (sn = Snake(x), t1 = Snake(conv1)) as bf16 planes: split once where they are produced
-        bf16_t* sn3 = m->sn.as<bf16_t>(); bf16_t* t13 = m->t1.as<bf16_t>();
-        const long long plane = ((long long)tl_nb * T * C + 7) / 8 * 8;
-        hipLaunchKernelGGL(snake_rows_planes_kernel, dim3(nblk(tl_nb * T * C / 4)), dim3(256), 0, s, in, sn3, plane, w.a1[0], tl_nb * T * C / 4, C);
-        auto conv3 = [&](const Conv& cw, const bf16_t* a3, int pad, int dil, float* Cout, bf16_t* c3, bool c3_only, int act, const float* act_alpha, const float* res,
-                         float scale, bool acc, bf16_t* c23, const float* c2_alpha) {
-            GemmConvArgs a{};
-            a.A = nullptr; a.A3 = a3; a.a3_plane = plane; a.a_batch = 0; a.a_len = T * cw.K; a.lda = cw.K; a.a_off0 = -pad * cw.K; a.tap_step = dil * cw.K; a.taps = cw.taps; a.K = cw.K;
-            a.pro = ACT_NONE; a.W = cw.w; a.W3 = cw.w3; a.w3_terms = tl_terms; a.Kp = cw.Kp; a.ldw = 0; a.w_batch = 0; a.bias = cw.b;
-            a.C = Cout; a.C3 = c3; a.C23 = c23; a.c3_plane = plane; a.c3_only = c3_only ? 1 : 0; a.c2_alpha = c2_alpha;
-            a.c_batch = 0; a.c_len = T * cw.N; a.ldc = cw.N; a.c_off = 0; a.M = (int)T; a.N = cw.N;
-            a.act = act; a.act_alpha = act_alpha; a.res = res; a.out_scale = scale; a.accumulate = acc ? 1 : 0;
-            if (tl_nb > 1) { a.a_batch = T * cw.K; a.c_batch = T * cw.N; a.res_batch = res ? T * cw.N : 0; }
-            gemm_conv(a, false, tl_nb, s);
-        };
-        for (int j = 0; j < c.n_dil; ++j) {
-            const int d = c.dil[j], k = w.k;
-            const bool last = j == c.n_dil - 1;
-            float* out = last ? dest : r[j & 1];
-            // t1 = Snake(conv1(sn)) exists as planes only (c3_only: no fp32 store)
-            conv3(w.c1[j], sn3, c.causal ? (k - 1) * d : (k * d - d) / 2, d, nullptr, t13, true, ACT_SNAKE, w.a2[j], nullptr, 1.f, false, nullptr, nullptr);
-            conv3(w.c2[j], t13, c.causal ? k - 1 : (k - 1) / 2, 1, out, nullptr, false, ACT_NONE, nullptr, cur, last ? out_scale : 1.f, last && accumulate,
-                  last ? nullptr : sn3, last ? nullptr : w.a1[j + 1]);
-            cur = out;
-        }
-        return;
-    }
     float* sn = m->sn.as<float>();
     hipLaunchKernelGGL(snake_rows_kernel, dim3(nblk(tl_nb * T * C / 4)), dim3(256), 0, s, in, sn, w.a1[0], tl_nb * T * C / 4, C);
     for (int j = 0; j < c.n_dil; ++j) {
@@ -368,7 +335,6 @@ int cv_hift_set_option(cv_hift* m, const char* name, int32_t value) {
     return guarded([&] {
         CV_CHECK(m && name, "cv_hift_set_option: null argument");
         if (std::string(name) == "f0_float64") m->f0_f64 = value != 0;
-        else if (std::string(name) == "presplit") m->presplit = value != 0;
         else if (std::string(name) == "terms") { CV_CHECK(value == 3 || value == 6, "terms must be 6 (fp32-exact class) or 3"); m->terms = value; }
         else throw Error(std::string("cv_hift_set_option: unknown option ") + name);
     });

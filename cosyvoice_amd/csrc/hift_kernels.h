@@ -178,18 +178,6 @@ static __global__ __launch_bounds__(256) void snake_rows_kernel(const float* x, 
 }
 
 
-// The same values as three bf16 planes (gemm_conv.h split3_bf16, A3): the pre-split operand of a ResBlock's first convolution (round 6)
-static __global__ __launch_bounds__(256) void snake_rows_planes_kernel(const float* x, bf16_t* y3, long long plane, const float* alpha, long long n4, int C) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // float4 index over [rows][C / 4]
-    if (i >= n4) return;
-    const int c = (int)((i * 4) % C);
-    const float4 v = *reinterpret_cast<const float4*>(x + i * 4), a = *reinterpret_cast<const float4*>(alpha + c);
-    uint2 q1, q2, q3;
-    split3_bf16(make_float4(snake_f(v.x, a.x), snake_f(v.y, a.y), snake_f(v.z, a.z), snake_f(v.w, a.w)), q1, q2, q3);
-    *reinterpret_cast<uint2*>(y3 + i * 4) = q1; *reinterpret_cast<uint2*>(y3 + plane + i * 4) = q2; *reinterpret_cast<uint2*>(y3 + 2 * plane + i * 4) = q3;
-}
-
-
 // Conv1d in DOUBLE over channel-last rows - the float64 mode of the f0 predictor (the reference runs CausalConvRNNF0Predictor in float64, generator.py:716-717:
 // its module is converted with .to(torch.float64), i.e. fp32 weights widened exactly, and so are they here).  out[t][n] = act(b[n] + sum_{j, c} in[t + j - pad][c] *
 // W[n][j * Kp + c]), rows outside [0, in_rows) read as zero.  One workgroup = 16 rows x 64 columns, k in steps of 32 through LDS; a thread owns 4 rows of one

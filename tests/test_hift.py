@@ -120,34 +120,3 @@ def test_three_plane_products_option(lib, tiny):
     assert torch.equal(again.cpu(), six)
     with pytest.raises(Exception):
         lib.cv_hift_set_option(hift._h, b"terms", C.c_int32(4))
-
-
-def test_presplit_planes_are_bit_identical(lib, tiny):
-    """cv_hift_set_option "presplit" (round 6, default on): the operands of the ResBlock convolutions travel as three bf16 planes written once by their producer
-    (snake_rows_planes_kernel, the C3 / C23 epilogue outputs of gemm_conv.h) and are staged by the consumer as they are (A3), instead of fp32 values that every tap and
-    N tile of the consumer splits again.  The planes are the very values the staging code computes: waveform and source are bit-identical with the option off, in the
-    six- and in the three-product mode, for the non-causal and the causal generator (chunked too)."""
-    import ctypes as C
-    import dataclasses
-    from cosyvoice_amd.hift import CausalHiFTGenerator
-    cfg, sd = tiny
-    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, "hift_tiny.npz")).items()}
-    hift = HiFTGenerator(sd, cfg, lib=lib)
-    outs = {}
-    for pre in (1, 0):
-        lib.cv_hift_set_option(hift._h, b"presplit", C.c_int32(pre))
-        for terms in (6, 3):
-            lib.cv_hift_set_option(hift._h, b"terms", C.c_int32(terms))
-            w, s = hift.inference(g["mel"], noise=g["noise"])
-            outs[pre, terms] = (w.cpu().clone(), s.cpu().clone())
-    for terms in (6, 3):
-        assert torch.equal(outs[1, terms][0], outs[0, terms][0]) and torch.equal(outs[1, terms][1], outs[0, terms][1])
-    assert not torch.equal(outs[1, 6][0], outs[1, 3][0])
-    ccfg = dataclasses.replace(cfg, causal=True)
-    ch = CausalHiFTGenerator(W.make_hift(ccfg), ccfg, lib=lib)
-    gc = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, "causal_hift_tiny.npz")).items()}
-    got = {}
-    for pre in (1, 0):
-        lib.cv_hift_set_option(ch._h, b"presplit", C.c_int32(pre))
-        got[pre] = (ch.decode(gc["mel"], gc["source"], True).cpu().clone(), ch.decode(gc["mel"][:, :, :10], gc["source_c"], False).cpu().clone())
-    assert torch.equal(got[1][0], got[0][0]) and torch.equal(got[1][1], got[0][1])
