@@ -499,7 +499,7 @@ def streaming_clients(model, u, clients, n_requests):
     keys = ("text", "flow_embedding", "llm_embedding", "prompt_text", "llm_prompt_speech_token", "flow_prompt_speech_token", "prompt_speech_feat")
     req = {k: u[k] for k in keys}
     req["min_token_text_ratio"] = req["max_token_text_ratio"] = N_GEN / N_TEXT
-    sch = StreamScheduler(model, slots=min(8, clients), step_chunk=8)
+    sch = StreamScheduler(model, slots=min(8, clients), step_chunk=int(os.environ.get("CV_BENCH_STEP_CHUNK", 8)))      # (the variable: A/B knob, profiles/r6_stream_step_chunk.txt)
     if os.environ.get("CV_SWITCH_INTERVAL"):                      # dev knob: the interpreter's thread switch interval in seconds (default 0.005)
         sys.setswitchinterval(float(os.environ["CV_SWITCH_INTERVAL"]))
     lat, samples, errs, lock, todo = [], [0], [], threading.Lock(), [n_requests]
