@@ -67,11 +67,8 @@ struct GemmConvArgs {
 // x1 w3, x3 w1), every one exact, accumulated in fp32 smallest first; the dropped x2 w3 + x3 w2 + x3 w3 are <= 2^-23 of a product - the size of ONE fp32
 // rounding of it, so the result is as accurate as the fp32 MFMA chain (whose own accumulation error is ~ sqrt(K) roundings) for 6 x 16 instead of
 // 8 x 32 matrix-pipe cycles per 32 k.  A WX3 kernel is an AX3 kernel whose weight tile has 3 BN rows.
-// DB (experiments, round 6): two LDS buffers - the staging of tile t + 1 (activation split, LDS writes) is issued before the products of tile t and ONE barrier separates
-// the steps instead of two.  Same products in the same order: bit-identical.
-template <int BM, int BN, int BK, bool WBF16, bool AVEC, int STAGES = 2, bool ABF16 = false, int WM = 2, int WN = 2, bool AX3 = false, bool WX3 = false, bool DB = false>
+template <int BM, int BN, int BK, bool WBF16, bool AVEC, int STAGES = 2, bool ABF16 = false, int WM = 2, int WN = 2, bool AX3 = false, bool WX3 = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p) {
-    static_assert(!DB || STAGES == 2, "the double-buffered loop is written for the two-stage register ring");
     static_assert(!ABF16 || WBF16, "the bf16 MFMA path takes bf16 weights");
     static_assert(!AX3 || (WBF16 && !ABF16), "the three-term split is the exact path for bf16 weights");
     static_assert(!WX3 || (AX3 && AVEC), "the two-sided split is an AX3 kernel over pre-split weight planes");
@@ -84,11 +81,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
     constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN);   // 16x16 tiles per wave (wave tile = BM/WM x BN/WN)
     constexpr int AV = BM * KV / NT, WV = WR * BN * KV / NT;  // float4 groups per thread per k-step
     static_assert(TM >= 1 && TN >= 1 && AV >= 1 && WV >= 1 && BM * KV % NT == 0 && WR * BN * KV % NT == 0, "tile does not divide over the workgroup");
-    constexpr int ASZ = (AX3 ? 3 : 1) * APL, WSZ = WR * BN * LD;
-    __shared__ __attribute__((aligned(16))) float As_all[(DB ? 2 : 1) * ASZ];
-    __shared__ __attribute__((aligned(16))) float Ws_all[(DB ? 2 : 1) * WSZ];
-    float* As = As_all; float* Ws = Ws_all;                               // DB: switched between the two buffers by use_buf
-    auto use_buf = [&](int bsel) { As = As_all + bsel * ASZ; Ws = Ws_all + bsel * WSZ; };
+    __shared__ __attribute__((aligned(16))) float As[(AX3 ? 3 : 1) * APL];
+    __shared__ __attribute__((aligned(16))) float Ws[WR * BN * LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
@@ -369,27 +363,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_conv_kernel(GemmConvArgs p)
     if constexpr (STAGES > 2) { if (nit > 2) { load_tile(l_tap, l_k0, ra2, rw2); ks2 = l_k0; advance(); } }
     if constexpr (STAGES > 3) { if (nit > 3) { load_tile(l_tap, l_k0, ra3, rw3); ks3 = l_k0; advance(); } }
     stamp();
-    if constexpr (DB) {
-        use_buf(0); store_tile(ks0, ra0, rw0);
-        if (2 < nit) { load_tile(l_tap, l_k0, ra0, rw0); ks0 = l_k0; advance(); }
-        __syncthreads();
-        for (int it = 0; it < nit; it += 2) {
-            if (it + 1 < nit) {
-                use_buf(1); store_tile(ks1, ra1, rw1);
-                if (it + 3 < nit) { load_tile(l_tap, l_k0, ra1, rw1); ks1 = l_k0; advance(); }
-            }
-            use_buf(0); compute_tile();
-            __syncthreads();
-            if (it + 1 < nit) {
-                if (it + 2 < nit) {
-                    use_buf(0); store_tile(ks0, ra0, rw0);
-                    if (it + 4 < nit) { load_tile(l_tap, l_k0, ra0, rw0); ks0 = l_k0; advance(); }
-                }
-                use_buf(1); compute_tile();
-                __syncthreads();
-            }
-        }
-    } else
     for (int it = 0; it < nit; it += STAGES) {
         store_tile(ks0, ra0, rw0);
         stamp();

@@ -26,13 +26,6 @@ static void launch_cfg(const GemmConvArgs& a, bool w_bf16, int batch, hipStream_
             if constexpr (BM <= 64 && BK3 == 64) if (const char* bk = getenv("CV_GEMM_WX3_BK"); bk && bk[0] == '3') {
                 hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, 32, true, true, ST, false, 2, 2, true, true>), grid, block, 0, stream, a); return;
             }
-            // dev knob (experiments builds): two LDS buffers, one barrier per k-step (gemm_conv.h DB), on half-depth k tiles
-            if constexpr (BM <= 64 && BK3 == 64) if (const char* db = getenv("CV_GEMM_WX3_DB"); db && db[0] == '1') {
-                hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, 32, true, true, 2, false, 2, 2, true, true, true>), grid, block, 0, stream, a); return;
-            }
-            if constexpr (BM <= 32 && BK3 == 64) if (const char* db = getenv("CV_GEMM_WX3_DB"); db && db[0] == '2') {
-                hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, 64, true, true, 2, false, 2, 2, true, true, true>), grid, block, 0, stream, a); return;
-            }
             // dev knob (experiments builds): a deeper register ring for the two-sided split (3 or 4 tiles in flight per wave)
             if constexpr (BM <= 64) if (const char* st = getenv("CV_GEMM_WX3_STAGES")) {
                 if (st[0] == '3') { hipLaunchKernelGGL((gemm_conv_kernel<BM, BN, BK3, true, true, 3, false, 2, 2, true, true>), grid, block, 0, stream, a); return; }
