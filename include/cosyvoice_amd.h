@@ -269,7 +269,10 @@ int cv_hift_create(cv_hift** out, const cv_hift_config* cfg);
 int cv_hift_set_tensor(cv_hift* m, const char* name, const void* dev_ptr, int32_t dtype, int64_t numel);
 int cv_hift_finalize(cv_hift* m);
 /* Options: "f0_float64" (0 | 1, default 0): the f0 predictor - five convolutions + classifier - with every sum in double and f0 rounded to fp32 at the end, the mode
- * the reference runs CausalConvRNNF0Predictor in (hifigan/generator.py:716-717: module and input converted to float64 on every call).  Works for both generators. */
+ * the reference runs CausalConvRNNF0Predictor in (hifigan/generator.py:716-717: module and input converted to float64 on every call).  Works for both generators.
+ * "terms" (6 | 3, default 6): plane products per k of the decoder's convolutions (both generators) - 6 = the fp32-exact class, 3 = 16 significand bits per factor with
+ * fp32 accumulation: the reduced-precision mode CosyVoice3Model(fp16=True) selects where the reference runs its vocoder under autocast (cli/model.py:426-447); the f0
+ * predictor and the source are not affected. */
 int cv_hift_set_option(cv_hift* m, const char* name, int32_t value);
 void cv_hift_destroy(cv_hift* m);
 /* ConvRNNF0Predictor.forward (hifigan/f0_predictor.py:56-59): speech_feat dev [80, frames] -> f0 dev [frames] */
