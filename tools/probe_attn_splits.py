@@ -6,7 +6,8 @@ import bench
 model, u, cfgs = bench.build_model("bf16")
 llm = model.llm
 t = lambda n: torch.tensor([n], dtype=torch.int32)
-ratio = bench.N_GEN / bench.N_TEXT
+N = int(sys.argv[1]) if len(sys.argv) > 1 else bench.N_GEN
+ratio = N / bench.N_TEXT
 def run():
     with model.llm_context:
         return list(llm.inference(text=u["text"], text_len=t(bench.N_TEXT), prompt_text=u["prompt_text"], prompt_text_len=t(bench.N_PROMPT_TEXT), prompt_speech_token=u["llm_prompt_speech_token"],
@@ -21,4 +22,4 @@ for nsp in (8, 4, 16, 8, 4, 16):
         toks = run()
     torch.cuda.synchronize()
     base = base or toks
-    print("attn_splits %2d: %.2f ms per LM stage (250 tokens)  tokens equal to the first run: %s" % (nsp, (time.perf_counter() - t0) / 10 * 1e3, toks == base), flush=True)
+    print("attn_splits %2d: %.2f ms per LM stage (%d tokens)  tokens equal to the first run: %s" % (nsp, (time.perf_counter() - t0) / 10 * 1e3, len(toks), toks == base), flush=True)
