@@ -13,7 +13,7 @@ def run():
         return list(llm.inference(text=u["text"], text_len=t(bench.N_TEXT), prompt_text=u["prompt_text"], prompt_text_len=t(bench.N_PROMPT_TEXT), prompt_speech_token=u["llm_prompt_speech_token"],
                                   prompt_speech_token_len=t(bench.N_PROMPT_TOK), embedding=u["llm_embedding"], max_token_text_ratio=ratio, min_token_text_ratio=ratio))
 base = None
-for nsp in (8, 4, 16, 8, 4, 16):
+for nsp in [int(a) for a in sys.argv[2:]] or (8, 4, 16, 8, 4, 16):
     llm.lib.cv_llm_set_option(llm._h, b"attn_splits", C.c_int32(nsp))
     for _ in range(3):
         toks = run()
